@@ -1,0 +1,118 @@
+"""Independent numpy/scipy restatement of the hot path (cross-check for the C oracle).
+
+TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (see oracle/o3d_oracle.h).
+Written separately from o3d_oracle.c, against SURVEY.md Appendix A, using
+scipy.spatial.cKDTree(leafsize=15) for the exact NN search and numpy.linalg
+for the 6x6 solve and the 3x3 eigen-decomposition, so that agreement between
+the two is evidence that each restates Open3D v0.15.1's algorithm rather than
+sharing one bug.
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy.spatial import cKDTree
+
+
+def rot_zyx(a, b, g):
+    ca, sa, cb, sb, cg, sg = np.cos(a), np.sin(a), np.cos(b), np.sin(b), np.cos(g), np.sin(g)
+    Rx = np.array([[1, 0, 0], [0, ca, -sa], [0, sa, ca]])
+    Ry = np.array([[cb, 0, sb], [0, 1, 0], [-sb, 0, cb]])
+    Rz = np.array([[cg, -sg, 0], [sg, cg, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def vector6_to_matrix4(x):
+    T = np.eye(4)
+    T[:3, :3] = rot_zyx(x[0], x[1], x[2])
+    T[:3, 3] = x[3:6]
+    return T
+
+
+def evaluate(tree: cKDTree, P, r):
+    d, j = tree.query(P, k=1, distance_upper_bound=r)  # inf / n when none
+    ok = np.isfinite(d) & (d * d < r * r)
+    nc = int(ok.sum())
+    if nc == 0:
+        return np.where(ok, j, -1), 0.0, 0.0, 0
+    return np.where(ok, j, -1), nc / len(P), float(np.sqrt(np.sum(d[ok] ** 2) / nc)), nc
+
+
+def jtj_jtr(P, Q, Nq, corr):
+    m = corr >= 0
+    p, q, n = P[m], Q[corr[m]], Nq[corr[m]]
+    r = np.einsum("ij,ij->i", p - q, n)
+    J = np.concatenate([np.cross(p, n), n], axis=1)
+    return J.T @ J, J.T @ r, float(r @ r)
+
+
+def icp_point_to_plane(src, tgt, nrm, max_corr, init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6):
+    tree = cKDTree(tgt, leafsize=15)
+    T = np.eye(4) if init is None else np.array(init, dtype=np.float64)
+    P = src @ T[:3, :3].T + T[:3, 3]
+    corr, fit, rmse, nc = evaluate(tree, P, max_corr)
+    it = 0
+    for _ in range(max_iter):
+        if nc == 0:
+            U = np.eye(4)
+        else:
+            A, b, _ = jtj_jtr(P, tgt, nrm, corr)
+            U = vector6_to_matrix4(np.linalg.solve(A, -b))
+        T = U @ T
+        P = P @ U[:3, :3].T + U[:3, 3]
+        pf, pr = fit, rmse
+        corr, fit, rmse, nc = evaluate(tree, P, max_corr)
+        it += 1
+        if abs(pf - fit) < rel_fitness and abs(pr - rmse) < rel_rmse:
+            break
+    return dict(transformation=T, fitness=fit, inlier_rmse=rmse, iterations=it, n_corr=nc)
+
+
+def estimate_normals(pts, radius, max_nn):
+    tree = cKDTree(pts, leafsize=15)
+    d, j = tree.query(pts, k=max_nn, distance_upper_bound=radius)
+    if max_nn == 1:
+        d, j = d[:, None], j[:, None]
+    out = np.empty_like(pts)
+    for i in range(len(pts)):
+        ok = np.isfinite(d[i]) & (d[i] ** 2 < radius * radius)
+        nb = pts[j[i][ok]]
+        if len(nb) >= 3:
+            mu = nb.mean(0)
+            cov = (nb.T @ nb) / len(nb) - np.outer(mu, mu)
+        else:
+            cov = np.eye(3)
+        w, v = np.linalg.eigh(cov)
+        n = v[:, 0]
+        if len(nb) < 3:
+            n = np.array([0.0, 0.0, 1.0])  # identity covariance -> diagonal branch -> (0,0,1)
+        n = n / np.linalg.norm(n)
+        if n @ (-pts[i]) < 0:
+            n = -n
+        out[i] = n
+    return out
+
+
+def voxel_down_sample(pts, voxel):
+    o = pts.min(0) - voxel / 2
+    keys = np.floor((pts - o) / voxel).astype(np.int64)
+    uk, inv = np.unique(keys, axis=0, return_inverse=True)
+    inv = inv.ravel()
+    out = np.zeros((len(uk), 3))
+    np.add.at(out, inv, pts)
+    cnt = np.bincount(inv, minlength=len(uk))
+    return out / cnt[:, None], uk
+
+
+def voxelize_world(pts, nrm, voxel):
+    keys = np.floor(pts * (1.0 / voxel)).astype(np.int64)
+    uk, inv = np.unique(keys, axis=0, return_inverse=True)
+    inv = inv.ravel()
+    out = np.zeros((len(uk), 3))
+    on = np.zeros((len(uk), 3))
+    np.add.at(out, inv, pts)
+    np.add.at(on, inv, nrm)
+    cnt = np.bincount(inv, minlength=len(uk))
+    on = on / cnt[:, None]
+    nn = np.linalg.norm(on, axis=1, keepdims=True)
+    on = np.where(nn > 0, on / np.where(nn > 0, nn, 1), on)
+    return out / cnt[:, None], on, uk

@@ -1,0 +1,919 @@
+/*
+ * o3d_oracle.c -- CPU ORACLE (test infrastructure only; PARITY UNPINNED, see o3d_oracle.h).
+ *
+ * Restates, in plain C + OpenMP, the algorithm of the reference's scan-to-map
+ * point-to-plane ICP / map-fusion hot path.  In-tree citations are relative to
+ * /root/reference/open3d_slam/open3d_slam/; "[O3D]" marks behaviour of Open3D
+ * v0.15.1 (third-party, absent from the tree) restated from its published
+ * algorithm as summarised in SURVEY.md Appendix A.
+ */
+#include "o3d_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ threads */
+int orc_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
+/* ------------------------------------------------------------------ KD-tree
+ * [O3D] KDTreeFlann wraps nanoflann: L2, leaf_max_size 15, exact search.
+ * The split rule only affects speed, never results; we use widest-dimension
+ * median splits and store the points in tree order for locality. */
+#define ORC_LEAF 15
+
+typedef struct {
+  int32_t left, right; /* -1 => leaf */
+  int32_t begin, end;
+  int32_t dim;
+  double split;
+} orc_node;
+
+struct orc_kdtree {
+  size_t n;
+  double* pts;  /* 3n, tree order */
+  int32_t* idx; /* tree position -> original index */
+  orc_node* nodes;
+  int32_t n_nodes, cap_nodes;
+};
+
+typedef struct {
+  double p[3];
+  int32_t id;
+  int32_t pad;
+} kd_item; /* 32 B: build works on a physically permuted copy so every pass is sequential */
+
+static inline void swap_item(kd_item* a, kd_item* b) {
+  kd_item t = *a;
+  *a = *b;
+  *b = t;
+}
+
+/* quickselect (Hoare partition, robust to duplicate keys): on return it[k] is the k-th smallest along dim in [lo,hi) */
+static void select_kth(kd_item* it, int32_t lo, int32_t hi, int32_t k, int dim) {
+  int32_t l = lo, r = hi - 1;
+  while (l < r) {
+    double a = it[l].p[dim], b = it[l + (r - l) / 2].p[dim], c = it[r].p[dim];
+    double pivot = (a < b) ? ((b < c) ? b : ((a < c) ? c : a)) : ((a < c) ? a : ((b < c) ? c : b));
+    int32_t i = l, j = r;
+    while (i <= j) {
+      while (it[i].p[dim] < pivot) ++i;
+      while (it[j].p[dim] > pivot) --j;
+      if (i <= j) {
+        swap_item(&it[i], &it[j]);
+        ++i;
+        --j;
+      }
+    }
+    if (k <= j)
+      r = j;
+    else if (k >= i)
+      l = i;
+    else
+      return;
+  }
+}
+
+static int32_t new_node(orc_kdtree* t) {
+  if (t->n_nodes == t->cap_nodes) {
+    t->cap_nodes = t->cap_nodes ? t->cap_nodes * 2 : 1024;
+    t->nodes = (orc_node*)realloc(t->nodes, sizeof(orc_node) * (size_t)t->cap_nodes);
+  }
+  return t->n_nodes++;
+}
+
+static int32_t build_rec(orc_kdtree* t, kd_item* it, int32_t lo, int32_t hi) {
+  int32_t id = new_node(t);
+  orc_node nd;
+  nd.begin = lo;
+  nd.end = hi;
+  nd.left = nd.right = -1;
+  nd.dim = 0;
+  nd.split = 0.0;
+  if (hi - lo > ORC_LEAF) {
+    double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+    for (int32_t i = lo; i < hi; ++i) {
+      const double* p = it[i].p;
+      for (int d = 0; d < 3; ++d) {
+        if (p[d] < mn[d]) mn[d] = p[d];
+        if (p[d] > mx[d]) mx[d] = p[d];
+      }
+    }
+    int dim = 0;
+    double span = mx[0] - mn[0];
+    for (int d = 1; d < 3; ++d)
+      if (mx[d] - mn[d] > span) {
+        span = mx[d] - mn[d];
+        dim = d;
+      }
+    if (span > 0.0) {
+      int32_t mid = lo + (hi - lo) / 2;
+      select_kth(it, lo, hi, mid, dim);
+      nd.dim = dim;
+      nd.split = it[mid].p[dim];
+      t->nodes[id] = nd;
+      int32_t l = build_rec(t, it, lo, mid);
+      int32_t r = build_rec(t, it, mid, hi);
+      nd.left = l;
+      nd.right = r;
+    } /* else: all points identical -> oversized leaf */
+  }
+  t->nodes[id] = nd;
+  return id;
+}
+
+orc_kdtree* orc_kdtree_build(const double* pts, size_t n) {
+  orc_kdtree* t = (orc_kdtree*)calloc(1, sizeof(orc_kdtree));
+  t->n = n;
+  t->idx = (int32_t*)malloc(sizeof(int32_t) * (n ? n : 1));
+  t->pts = (double*)malloc(sizeof(double) * 3 * (n ? n : 1));
+  kd_item* it = (kd_item*)malloc(sizeof(kd_item) * (n ? n : 1));
+  for (size_t i = 0; i < n; ++i) {
+    memcpy(it[i].p, pts + 3 * i, 3 * sizeof(double));
+    it[i].id = (int32_t)i;
+  }
+  if (n > 0) build_rec(t, it, 0, (int32_t)n);
+  for (size_t i = 0; i < n; ++i) {
+    memcpy(t->pts + 3 * i, it[i].p, 3 * sizeof(double));
+    t->idx[i] = it[i].id;
+  }
+  free(it);
+  return t;
+}
+
+void orc_kdtree_free(orc_kdtree* t) {
+  if (!t) return;
+  free(t->pts);
+  free(t->idx);
+  free(t->nodes);
+  free(t);
+}
+
+typedef struct {
+  int k, count;
+  double worst; /* candidates must satisfy d2 < worst (strict) */
+  int32_t* idx;
+  double* d2;
+} knn_state;
+
+static inline void knn_push(knn_state* s, double d2, int32_t id) {
+  /* insertion into ascending list of at most k entries */
+  int pos = s->count < s->k ? s->count : s->k - 1;
+  while (pos > 0 && s->d2[pos - 1] > d2) {
+    s->d2[pos] = s->d2[pos - 1];
+    s->idx[pos] = s->idx[pos - 1];
+    --pos;
+  }
+  s->d2[pos] = d2;
+  s->idx[pos] = id;
+  if (s->count < s->k) ++s->count;
+  if (s->count == s->k) s->worst = s->d2[s->k - 1];
+}
+
+static void search_rec(const orc_kdtree* t, int32_t node, const double q[3], knn_state* s) {
+  const orc_node* nd = &t->nodes[node];
+  if (nd->left < 0) {
+    for (int32_t i = nd->begin; i < nd->end; ++i) {
+      const double* p = t->pts + 3 * (size_t)i;
+      double dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
+      double d2 = dx * dx + dy * dy + dz * dz;
+      if (d2 < s->worst) knn_push(s, d2, t->idx[i]);
+    }
+    return;
+  }
+  double diff = q[nd->dim] - nd->split;
+  int32_t near = diff < 0 ? nd->left : nd->right;
+  int32_t far = diff < 0 ? nd->right : nd->left;
+  search_rec(t, near, q, s);
+  if (diff * diff < s->worst) search_rec(t, far, q, s);
+}
+
+int orc_kdtree_search_hybrid(const orc_kdtree* t, const double q[3], double radius, int max_nn, int32_t* idx, double* d2) {
+  if (!t || t->n == 0 || max_nn <= 0) return 0;
+  knn_state s;
+  s.k = max_nn;
+  s.count = 0;
+  s.worst = radius * radius; /* [O3D] kNN then keep entries with d2 < r^2 (lower_bound) */
+  s.idx = idx;
+  s.d2 = d2;
+  search_rec(t, 0, q, &s);
+  return s.count;
+}
+
+int orc_kdtree_search_knn(const orc_kdtree* t, const double q[3], int k, int32_t* idx, double* d2) {
+  if (!t || t->n == 0 || k <= 0) return 0;
+  knn_state s;
+  s.k = k;
+  s.count = 0;
+  s.worst = DBL_MAX;
+  s.idx = idx;
+  s.d2 = d2;
+  search_rec(t, 0, q, &s);
+  return s.count;
+}
+
+/* ------------------------------------------------------------------ A.2
+ * [O3D] GetRegistrationResultAndCorrespondences: 1-NN, accept iff d2 < r^2. */
+void orc_evaluate(const orc_kdtree* t, const double* src, size_t n, double max_corr, int32_t* corr, double* d2_out, double* fitness,
+                  double* inlier_rmse, uint64_t* n_corr) {
+  double err2 = 0.0;
+  uint64_t cnt = 0;
+  if (max_corr > 0.0) {
+#pragma omp parallel for schedule(static) reduction(+ : err2, cnt)
+    for (long i = 0; i < (long)n; ++i) {
+      int32_t id;
+      double d2;
+      int k = orc_kdtree_search_hybrid(t, src + 3 * (size_t)i, max_corr, 1, &id, &d2);
+      if (k > 0) {
+        corr[i] = id;
+        if (d2_out) d2_out[i] = d2;
+        err2 += d2;
+        cnt += 1;
+      } else {
+        corr[i] = -1;
+        if (d2_out) d2_out[i] = -1.0;
+      }
+    }
+  } else {
+    for (size_t i = 0; i < n; ++i) corr[i] = -1;
+  }
+  if (cnt == 0) {
+    *fitness = 0.0;
+    *inlier_rmse = 0.0;
+  } else {
+    *fitness = (double)cnt / (double)n;
+    *inlier_rmse = sqrt(err2 / (double)cnt);
+  }
+  *n_corr = cnt;
+}
+
+/* ------------------------------------------------------------------ A.3
+ * [O3D] TransformationEstimationPointToPlane::ComputeTransformation +
+ * utility::ComputeJTJandJTr: r = (p - q).n ; J = [p x n ; n] ; w = 1 (L2 loss). */
+void orc_compute_jtj_jtr(const double* src, size_t n, const double* tgt, const double* tgt_nrm, const int32_t* corr, double JTJ[36],
+                         double JTr[6], double* r2_sum) {
+  int nt = orc_num_threads();
+  double* part = (double*)calloc((size_t)nt * 44, sizeof(double));
+#pragma omp parallel
+  {
+#ifdef _OPENMP
+    int tid = omp_get_thread_num();
+#else
+    int tid = 0;
+#endif
+    double A[36] = {0}, b[6] = {0}, r2 = 0.0;
+#pragma omp for schedule(static)
+    for (long i = 0; i < (long)n; ++i) {
+      int32_t j = corr[i];
+      if (j < 0) continue;
+      const double* p = src + 3 * (size_t)i;
+      const double* q = tgt + 3 * (size_t)j;
+      const double* nn = tgt_nrm + 3 * (size_t)j;
+      double r = (p[0] - q[0]) * nn[0] + (p[1] - q[1]) * nn[1] + (p[2] - q[2]) * nn[2];
+      double J[6] = {p[1] * nn[2] - p[2] * nn[1], p[2] * nn[0] - p[0] * nn[2], p[0] * nn[1] - p[1] * nn[0], nn[0], nn[1], nn[2]};
+      for (int a = 0; a < 6; ++a) {
+        for (int c = 0; c < 6; ++c) A[a * 6 + c] += J[a] * J[c];
+        b[a] += J[a] * r;
+      }
+      r2 += r * r;
+    }
+    memcpy(part + (size_t)tid * 44, A, sizeof(A));
+    memcpy(part + (size_t)tid * 44 + 36, b, sizeof(b));
+    part[(size_t)tid * 44 + 42] = r2;
+  }
+  memset(JTJ, 0, 36 * sizeof(double));
+  memset(JTr, 0, 6 * sizeof(double));
+  double r2 = 0.0;
+  for (int t = 0; t < nt; ++t) { /* fixed thread order: deterministic for a fixed thread count */
+    for (int a = 0; a < 36; ++a) JTJ[a] += part[(size_t)t * 44 + a];
+    for (int a = 0; a < 6; ++a) JTr[a] += part[(size_t)t * 44 + 36 + a];
+    r2 += part[(size_t)t * 44 + 42];
+  }
+  if (r2_sum) *r2_sum = r2;
+  free(part);
+}
+
+/* [O3D] TransformVector6dToMatrix4d: R = Rz(x[2]) * Ry(x[1]) * Rx(x[0]); t = x[3:6]. Column-major out. */
+void orc_vector6_to_matrix4(const double x[6], double U[16]) {
+  double ca = cos(x[0]), sa = sin(x[0]);
+  double cb = cos(x[1]), sb = sin(x[1]);
+  double cg = cos(x[2]), sg = sin(x[2]);
+  double R[3][3];
+  R[0][0] = cg * cb;
+  R[0][1] = cg * sb * sa - sg * ca;
+  R[0][2] = cg * sb * ca + sg * sa;
+  R[1][0] = sg * cb;
+  R[1][1] = sg * sb * sa + cg * ca;
+  R[1][2] = sg * sb * ca - cg * sa;
+  R[2][0] = -sb;
+  R[2][1] = cb * sa;
+  R[2][2] = cb * ca;
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) U[c * 4 + r] = R[r][c];
+  U[3] = U[7] = U[11] = 0.0;
+  U[12] = x[3];
+  U[13] = x[4];
+  U[14] = x[5];
+  U[15] = 1.0;
+}
+
+/* [O3D] SolveLinearSystemPSD(A,-b) = A.ldlt().solve(-b): LDL^T with symmetric
+ * (largest-|diagonal|) pivoting as Eigen's LDLT does; no PSD/determinant check. */
+int orc_solve_update(const double JTJ[36], const double JTr[6], double U[16], double x_out[6]) {
+  double A[6][6], b[6], x[6];
+  int perm[6];
+  for (int i = 0; i < 6; ++i) {
+    perm[i] = i;
+    b[i] = -JTr[i];
+    for (int j = 0; j < 6; ++j) A[i][j] = JTJ[i * 6 + j];
+  }
+  for (int k = 0; k < 6; ++k) {
+    int piv = k;
+    double best = fabs(A[k][k]);
+    for (int i = k + 1; i < 6; ++i)
+      if (fabs(A[i][i]) > best) {
+        best = fabs(A[i][i]);
+        piv = i;
+      }
+    if (piv != k) {
+      for (int j = 0; j < 6; ++j) {
+        double t = A[k][j];
+        A[k][j] = A[piv][j];
+        A[piv][j] = t;
+      }
+      for (int i = 0; i < 6; ++i) {
+        double t = A[i][k];
+        A[i][k] = A[i][piv];
+        A[i][piv] = t;
+      }
+      double tb = b[k];
+      b[k] = b[piv];
+      b[piv] = tb;
+      int tp = perm[k];
+      perm[k] = perm[piv];
+      perm[piv] = tp;
+    }
+    double d = A[k][k];
+    for (int i = k + 1; i < 6; ++i) {
+      double l = A[i][k] / d;
+      for (int j = k + 1; j < 6; ++j) A[i][j] -= l * A[k][j];
+      A[i][k] = l; /* store L */
+    }
+  }
+  /* forward: L y = b */
+  double y[6];
+  for (int i = 0; i < 6; ++i) {
+    double s = b[i];
+    for (int j = 0; j < i; ++j) s -= A[i][j] * y[j];
+    y[i] = s;
+  }
+  /* D z = y ; L^T w = z */
+  double w[6];
+  for (int i = 5; i >= 0; --i) {
+    double s = y[i] / A[i][i];
+    for (int j = i + 1; j < 6; ++j) s -= A[j][i] * w[j];
+    w[i] = s;
+  }
+  for (int i = 0; i < 6; ++i) x[perm[i]] = w[i];
+  if (x_out) memcpy(x_out, x, sizeof(x));
+  orc_vector6_to_matrix4(x, U);
+  return 0;
+}
+
+/* ------------------------------------------------------------------ A.4 */
+void orc_transform_points(double* pts, size_t n, const double T[16]) {
+  for (size_t i = 0; i < n; ++i) {
+    double x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+    double nx = T[0] * x + T[4] * y + T[8] * z + T[12];
+    double ny = T[1] * x + T[5] * y + T[9] * z + T[13];
+    double nz = T[2] * x + T[6] * y + T[10] * z + T[14];
+    double w = T[3] * x + T[7] * y + T[11] * z + T[15];
+    pts[3 * i] = nx / w;
+    pts[3 * i + 1] = ny / w;
+    pts[3 * i + 2] = nz / w;
+  }
+}
+void orc_transform_normals(double* nrm, size_t n, const double T[16]) {
+  for (size_t i = 0; i < n; ++i) {
+    double x = nrm[3 * i], y = nrm[3 * i + 1], z = nrm[3 * i + 2];
+    nrm[3 * i] = T[0] * x + T[4] * y + T[8] * z;
+    nrm[3 * i + 1] = T[1] * x + T[5] * y + T[9] * z;
+    nrm[3 * i + 2] = T[2] * x + T[6] * y + T[10] * z;
+  }
+}
+
+static void mat4_mul(const double A[16], const double B[16], double C[16]) { /* column-major C = A*B */
+  double R[16];
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) {
+      double s = 0.0;
+      for (int k = 0; k < 4; ++k) s += A[k * 4 + r] * B[c * 4 + k];
+      R[c * 4 + r] = s;
+    }
+  memcpy(C, R, sizeof(R));
+}
+
+static int is_identity16(const double T[16]) {
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r)
+      if (fabs(T[c * 4 + r] - (r == c ? 1.0 : 0.0)) > 1e-12) return 0; /* Eigen isIdentity default precision */
+  return 1;
+}
+
+/* ------------------------------------------------------------------ A.1
+ * [O3D] RegistrationICP as called from src/CloudRegistration.cpp:44-48. */
+int orc_icp_point_to_plane(const double* src, size_t n, const double* tgt, const double* tgt_nrm, size_t N, const orc_kdtree* tree,
+                           double max_corr, const double init[16], int max_iter, double rel_fitness, double rel_rmse,
+                           orc_icp_result* out) {
+  if (max_corr <= 0.0) return -1; /* [O3D] LogError("Invalid max_correspondence_distance.") */
+  if (!tgt_nrm) return -2;        /* [O3D] point-to-plane requires target normals */
+  orc_kdtree* own = NULL;
+  if (!tree) { /* the reference rebuilds the KD-tree on every registerClouds call */
+    own = orc_kdtree_build(tgt, N);
+    tree = own;
+  }
+  double* P = (double*)malloc(sizeof(double) * 3 * (n ? n : 1));
+  int32_t* corr = (int32_t*)malloc(sizeof(int32_t) * (n ? n : 1));
+  memcpy(P, src, sizeof(double) * 3 * n);
+  double T[16];
+  memcpy(T, init, sizeof(T));
+  if (!is_identity16(init)) orc_transform_points(P, n, init);
+  double fit, rmse;
+  uint64_t nc;
+  orc_evaluate(tree, P, n, max_corr, corr, NULL, &fit, &rmse, &nc);
+  int it = 0, converged = 0;
+  for (int i = 0; i < max_iter; ++i) {
+    double U[16], JTJ[36], JTr[6], r2;
+    if (nc == 0) {
+      double I6[6] = {0, 0, 0, 0, 0, 0};
+      orc_vector6_to_matrix4(I6, U); /* empty correspondence set => identity update */
+    } else {
+      orc_compute_jtj_jtr(P, n, tgt, tgt_nrm, corr, JTJ, JTr, &r2);
+      orc_solve_update(JTJ, JTr, U, NULL);
+    }
+    mat4_mul(U, T, T);
+    orc_transform_points(P, n, U);
+    double pf = fit, pr = rmse;
+    orc_evaluate(tree, P, n, max_corr, corr, NULL, &fit, &rmse, &nc);
+    ++it;
+    if (fabs(pf - fit) < rel_fitness && fabs(pr - rmse) < rel_rmse) {
+      converged = 1;
+      break;
+    }
+  }
+  memcpy(out->transformation, T, sizeof(T));
+  out->fitness = fit;
+  out->inlier_rmse = rmse;
+  out->iterations = it;
+  out->converged = converged;
+  out->n_corr = nc;
+  free(P);
+  free(corr);
+  if (own) orc_kdtree_free(own);
+  return 0;
+}
+
+/* ------------------------------------------------------------------ A.5
+ * [O3D] FastEigen3x3 (Geometric Tools "robust eigensolver for 3x3 symmetric
+ * matrices"): returns the eigenvector of the smallest eigenvalue. */
+static void cross3(const double a[3], const double b[3], double c[3]) {
+  c[0] = a[1] * b[2] - a[2] * b[1];
+  c[1] = a[2] * b[0] - a[0] * b[2];
+  c[2] = a[0] * b[1] - a[1] * b[0];
+}
+static double dot3(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+static void eigvec0(const double A[9], double ev, double out[3]) {
+  double r0[3] = {A[0] - ev, A[1], A[2]}, r1[3] = {A[1], A[4] - ev, A[5]}, r2[3] = {A[2], A[5], A[8] - ev};
+  double c01[3], c02[3], c12[3];
+  cross3(r0, r1, c01);
+  cross3(r0, r2, c02);
+  cross3(r1, r2, c12);
+  double d0 = dot3(c01, c01), d1 = dot3(c02, c02), d2 = dot3(c12, c12);
+  const double* best = c01;
+  double dm = d0;
+  if (d1 > dm) {
+    dm = d1;
+    best = c02;
+  }
+  if (d2 > dm) {
+    dm = d2;
+    best = c12;
+  }
+  double s = sqrt(dm);
+  out[0] = best[0] / s;
+  out[1] = best[1] / s;
+  out[2] = best[2] / s;
+}
+
+static void eigvec1(const double A[9], const double e0[3], double ev, double out[3]) {
+  double U[3], V[3];
+  if (fabs(e0[0]) > fabs(e0[1])) {
+    double inv = 1.0 / sqrt(e0[0] * e0[0] + e0[2] * e0[2]);
+    U[0] = -e0[2] * inv;
+    U[1] = 0.0;
+    U[2] = e0[0] * inv;
+  } else {
+    double inv = 1.0 / sqrt(e0[1] * e0[1] + e0[2] * e0[2]);
+    U[0] = 0.0;
+    U[1] = e0[2] * inv;
+    U[2] = -e0[1] * inv;
+  }
+  cross3(e0, U, V);
+  double AU[3] = {A[0] * U[0] + A[1] * U[1] + A[2] * U[2], A[1] * U[0] + A[4] * U[1] + A[5] * U[2], A[2] * U[0] + A[5] * U[1] + A[8] * U[2]};
+  double AV[3] = {A[0] * V[0] + A[1] * V[1] + A[2] * V[2], A[1] * V[0] + A[4] * V[1] + A[5] * V[2], A[2] * V[0] + A[5] * V[1] + A[8] * V[2]};
+  double m00 = dot3(U, AU) - ev, m01 = dot3(U, AV), m11 = dot3(V, AV) - ev;
+  double a00 = fabs(m00), a01 = fabs(m01), a11 = fabs(m11);
+  if (a00 >= a11) {
+    double mx = a00 > a01 ? a00 : a01;
+    if (mx > 0) {
+      if (a00 >= a01) {
+        m01 /= m00;
+        m00 = 1.0 / sqrt(1 + m01 * m01);
+        m01 *= m00;
+      } else {
+        m00 /= m01;
+        m01 = 1.0 / sqrt(1 + m00 * m00);
+        m00 *= m01;
+      }
+      for (int i = 0; i < 3; ++i) out[i] = m01 * U[i] - m00 * V[i];
+    } else {
+      for (int i = 0; i < 3; ++i) out[i] = U[i];
+    }
+  } else {
+    double mx = a11 > a01 ? a11 : a01;
+    if (mx > 0) {
+      if (a11 >= a01) {
+        m01 /= m11;
+        m11 = 1.0 / sqrt(1 + m01 * m01);
+        m01 *= m11;
+      } else {
+        m11 /= m01;
+        m01 = 1.0 / sqrt(1 + m11 * m11);
+        m11 *= m01;
+      }
+      for (int i = 0; i < 3; ++i) out[i] = m11 * U[i] - m01 * V[i];
+    } else {
+      for (int i = 0; i < 3; ++i) out[i] = U[i];
+    }
+  }
+}
+
+void orc_fast_eigen3x3_min_evec(const double cov[9], double out[3]) {
+  double A[9];
+  double mc = cov[0];
+  for (int i = 1; i < 9; ++i)
+    if (cov[i] > mc) mc = cov[i];
+  if (mc == 0.0) {
+    out[0] = out[1] = out[2] = 0.0;
+    return;
+  }
+  for (int i = 0; i < 9; ++i) A[i] = cov[i] / mc;
+  double norm = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+  if (norm > 0.0) {
+    double q = (A[0] + A[4] + A[8]) / 3.0;
+    double b00 = A[0] - q, b11 = A[4] - q, b22 = A[8] - q;
+    double p = sqrt((b00 * b00 + b11 * b11 + b22 * b22 + norm * 2.0) / 6.0);
+    double c00 = b11 * b22 - A[5] * A[5];
+    double c01 = A[1] * b22 - A[5] * A[2];
+    double c02 = A[1] * A[5] - b11 * A[2];
+    double det = (b00 * c00 - A[1] * c01 + A[2] * c02) / (p * p * p);
+    double half_det = det * 0.5;
+    if (half_det < -1.0) half_det = -1.0;
+    if (half_det > 1.0) half_det = 1.0;
+    double angle = acos(half_det) / 3.0;
+    const double two_thirds_pi = 2.09439510239319549;
+    double beta2 = cos(angle) * 2.0;
+    double beta0 = cos(angle + two_thirds_pi) * 2.0;
+    double beta1 = -(beta0 + beta2);
+    double e0 = q + p * beta0, e1 = q + p * beta1, e2 = q + p * beta2;
+    double v0[3], v1[3], v2[3];
+    if (half_det >= 0.0) {
+      eigvec0(A, e2, v2);
+      if (e2 < e0 && e2 < e1) {
+        memcpy(out, v2, sizeof(v2));
+        return;
+      }
+      eigvec1(A, v2, e1, v1);
+      if (e1 < e0 && e1 < e2) {
+        memcpy(out, v1, sizeof(v1));
+        return;
+      }
+      cross3(v1, v2, v0);
+      memcpy(out, v0, sizeof(v0));
+    } else {
+      eigvec0(A, e0, v0);
+      if (e0 < e1 && e0 < e2) {
+        memcpy(out, v0, sizeof(v0));
+        return;
+      }
+      eigvec1(A, v0, e1, v1);
+      if (e1 < e0 && e1 < e2) {
+        memcpy(out, v1, sizeof(v1));
+        return;
+      }
+      cross3(v0, v1, v2);
+      memcpy(out, v2, sizeof(v2));
+    }
+  } else { /* diagonal */
+    if (cov[0] < cov[4] && cov[0] < cov[8]) {
+      out[0] = 1;
+      out[1] = 0;
+      out[2] = 0;
+    } else if (cov[4] < cov[0] && cov[4] < cov[8]) {
+      out[0] = 0;
+      out[1] = 1;
+      out[2] = 0;
+    } else {
+      out[0] = 0;
+      out[1] = 0;
+      out[2] = 1;
+    }
+  }
+}
+
+/* [O3D] EstimatePerPointCovariances + ComputeNormal + NormalizeNormals +
+ * OrientNormalsTowardsCameraLocation(0,0,0); call site src/CloudRegistration.cpp:49-56 */
+void orc_estimate_normals(const double* pts, size_t n, double radius, int max_nn, double* normals) {
+  orc_kdtree* t = orc_kdtree_build(pts, n);
+#pragma omp parallel
+  {
+    int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * (size_t)(max_nn > 0 ? max_nn : 1));
+    double* d2 = (double*)malloc(sizeof(double) * (size_t)(max_nn > 0 ? max_nn : 1));
+#pragma omp for schedule(static)
+    for (long i = 0; i < (long)n; ++i) {
+      const double* p = pts + 3 * (size_t)i;
+      int k = orc_kdtree_search_hybrid(t, p, radius, max_nn, idx, d2);
+      double cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      if (k >= 3) {
+        double c[9] = {0};
+        for (int j = 0; j < k; ++j) {
+          const double* v = pts + 3 * (size_t)idx[j];
+          c[0] += v[0];
+          c[1] += v[1];
+          c[2] += v[2];
+          c[3] += v[0] * v[0];
+          c[4] += v[0] * v[1];
+          c[5] += v[0] * v[2];
+          c[6] += v[1] * v[1];
+          c[7] += v[1] * v[2];
+          c[8] += v[2] * v[2];
+        }
+        for (int j = 0; j < 9; ++j) c[j] /= (double)k;
+        cov[0] = c[3] - c[0] * c[0];
+        cov[4] = c[6] - c[1] * c[1];
+        cov[8] = c[8] - c[2] * c[2];
+        cov[1] = cov[3] = c[4] - c[0] * c[1];
+        cov[2] = cov[6] = c[5] - c[0] * c[2];
+        cov[5] = cov[7] = c[7] - c[1] * c[2];
+      }
+      double nv[3];
+      orc_fast_eigen3x3_min_evec(cov, nv);
+      double nn = sqrt(dot3(nv, nv));
+      if (nn == 0.0) {
+        nv[0] = 0;
+        nv[1] = 0;
+        nv[2] = 1;
+        nn = 1.0;
+      }
+      /* NormalizeNormals */
+      nv[0] /= nn;
+      nv[1] /= nn;
+      nv[2] /= nn;
+      if (isnan(nv[0])) {
+        nv[0] = 0;
+        nv[1] = 0;
+        nv[2] = 1;
+      }
+      /* OrientNormalsTowardsCameraLocation(camera = 0): reference = -p */
+      double ref[3] = {-p[0], -p[1], -p[2]};
+      if (dot3(nv, nv) == 0.0) {
+        double rn = sqrt(dot3(ref, ref));
+        if (rn == 0.0) {
+          nv[0] = 0;
+          nv[1] = 0;
+          nv[2] = 1;
+        } else {
+          nv[0] = ref[0] / rn;
+          nv[1] = ref[1] / rn;
+          nv[2] = ref[2] / rn;
+        }
+      } else if (dot3(nv, ref) < 0.0) {
+        nv[0] = -nv[0];
+        nv[1] = -nv[1];
+        nv[2] = -nv[2];
+      }
+      normals[3 * (size_t)i] = nv[0];
+      normals[3 * (size_t)i + 1] = nv[1];
+      normals[3 * (size_t)i + 2] = nv[2];
+    }
+    free(idx);
+    free(d2);
+  }
+  orc_kdtree_free(t);
+}
+
+/* ------------------------------------------------------------------ voxel hash (oracle-private) */
+typedef struct {
+  size_t cap; /* power of two */
+  int32_t* keys; /* 3*cap */
+  int64_t* slot; /* cap, -1 empty */
+} vhash;
+
+static void vhash_init(vhash* h, size_t n) {
+  size_t cap = 16;
+  while (cap < 2 * n + 1) cap <<= 1;
+  h->cap = cap;
+  h->keys = (int32_t*)malloc(sizeof(int32_t) * 3 * cap);
+  h->slot = (int64_t*)malloc(sizeof(int64_t) * cap);
+  for (size_t i = 0; i < cap; ++i) h->slot[i] = -1;
+}
+static void vhash_free(vhash* h) {
+  free(h->keys);
+  free(h->slot);
+}
+/* returns slot id; *is_new set when inserted with next_id */
+static int64_t vhash_get(vhash* h, int32_t x, int32_t y, int32_t z, int64_t next_id, int* is_new) {
+  /* probe start: the reference's own hash, include/open3d_slam/VoxelHashMap.hpp:25-35 */
+  uint32_t hv = (uint32_t)((int64_t)x + (int64_t)y * 17191LL + (int64_t)z * 17191LL * 17191LL);
+  size_t pos = (size_t)(hv * 2654435761u) & (h->cap - 1);
+  for (;;) {
+    if (h->slot[pos] < 0) {
+      h->slot[pos] = next_id;
+      h->keys[3 * pos] = x;
+      h->keys[3 * pos + 1] = y;
+      h->keys[3 * pos + 2] = z;
+      *is_new = 1;
+      return next_id;
+    }
+    if (h->keys[3 * pos] == x && h->keys[3 * pos + 1] == y && h->keys[3 * pos + 2] == z) {
+      *is_new = 0;
+      return h->slot[pos];
+    }
+    pos = (pos + 1) & (h->cap - 1);
+  }
+}
+
+/* [O3D] PointCloud::VoxelDownSample via src/helpers.cpp:107-113 */
+size_t orc_voxel_down_sample(const double* pts, const double* nrm, size_t n, double voxel, double* out_pts, double* out_nrm) {
+  if (n == 0) return 0;
+  if (voxel <= 0.0) { /* wrapper returns the cloud unchanged, helpers.cpp:108-110 */
+    memcpy(out_pts, pts, sizeof(double) * 3 * n);
+    if (nrm && out_nrm) memcpy(out_nrm, nrm, sizeof(double) * 3 * n);
+    return n;
+  }
+  double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX};
+  for (size_t i = 0; i < n; ++i)
+    for (int d = 0; d < 3; ++d)
+      if (pts[3 * i + d] < mn[d]) mn[d] = pts[3 * i + d];
+  for (int d = 0; d < 3; ++d) mn[d] -= voxel * 0.5; /* voxel_min_bound = min_bound - voxel/2 */
+  vhash h;
+  vhash_init(&h, n);
+  int64_t* cnt = (int64_t*)calloc(n, sizeof(int64_t));
+  size_t m = 0;
+  for (size_t i = 0; i < n; ++i) {
+    int32_t k[3];
+    for (int d = 0; d < 3; ++d) k[d] = (int32_t)floor((pts[3 * i + d] - mn[d]) / voxel);
+    int is_new;
+    int64_t s = vhash_get(&h, k[0], k[1], k[2], (int64_t)m, &is_new);
+    if (is_new) {
+      for (int d = 0; d < 3; ++d) {
+        out_pts[3 * m + d] = 0.0;
+        if (nrm && out_nrm) out_nrm[3 * m + d] = 0.0;
+      }
+      ++m;
+    }
+    for (int d = 0; d < 3; ++d) {
+      out_pts[3 * (size_t)s + d] += pts[3 * i + d];
+      if (nrm && out_nrm) out_nrm[3 * (size_t)s + d] += nrm[3 * i + d];
+    }
+    cnt[s] += 1;
+  }
+  for (size_t s = 0; s < m; ++s)
+    for (int d = 0; d < 3; ++d) {
+      out_pts[3 * s + d] /= (double)cnt[s];
+      if (nrm && out_nrm) out_nrm[3 * s + d] /= (double)cnt[s]; /* [O3D] normals averaged, not re-normalised */
+    }
+  free(cnt);
+  vhash_free(&h);
+  return m;
+}
+
+/* ------------------------------------------------------------------ croppers: src/croppers.cpp:121-165 */
+static int within_volume(const double* p, const orc_crop* c) {
+  int in = 1;
+  double dx = p[0] - c->center[0], dy = p[1] - c->center[1], dz = p[2] - c->center[2];
+  switch (c->kind) {
+    case ORC_CROP_MAX_RADIUS:
+      in = sqrt(dx * dx + dy * dy + dz * dz) <= c->rmax; /* croppers.cpp:136-138 */
+      break;
+    case ORC_CROP_MIN_RADIUS:
+      in = sqrt(dx * dx + dy * dy + dz * dz) >= c->rmin; /* croppers.cpp:149-151 */
+      break;
+    case ORC_CROP_MIN_MAX_RADIUS: {
+      double d = sqrt(dx * dx + dy * dy + dz * dz); /* croppers.cpp:121-124 */
+      in = d <= c->rmax && d >= c->rmin;
+      break;
+    }
+    case ORC_CROP_CYLINDER:
+      in = p[2] >= c->zmin && p[2] <= c->zmax && sqrt(dx * dx + dy * dy) <= c->rmax; /* croppers.cpp:163-165 */
+      break;
+    default:
+      in = 1; /* CroppingVolume::isWithinVolumeImpl base, croppers.cpp:49-51 */
+  }
+  return c->invert ? !in : in;
+}
+
+size_t orc_crop_indices(const double* pts, size_t n, const orc_crop* c, int64_t* out_idx) {
+  size_t k = 0;
+  for (size_t i = 0; i < n; ++i)
+    if (within_volume(pts + 3 * i, c)) {
+      if (out_idx) out_idx[k] = (int64_t)i;
+      ++k;
+    }
+  return k;
+}
+
+/* ------------------------------------------------------------------ map merge: src/helpers.cpp:115-183 */
+size_t orc_voxelize_within_volume(const double* pts, const double* nrm, size_t n, double voxel, const orc_crop* c, double* out_pts,
+                                  double* out_nrm, size_t* n_pass) {
+  if (voxel <= 0.0) { /* helpers.cpp:119-123 */
+    memcpy(out_pts, pts, sizeof(double) * 3 * n);
+    if (nrm && out_nrm) memcpy(out_nrm, nrm, sizeof(double) * 3 * n);
+    if (n_pass) *n_pass = n;
+    return n;
+  }
+  const double inv = 1.0 / voxel; /* fromVoxelSize, VoxelHashMap.hpp:43-45 */
+  vhash h;
+  vhash_init(&h, n);
+  double* sp = (double*)malloc(sizeof(double) * 3 * (n ? n : 1));
+  double* sn = (double*)malloc(sizeof(double) * 3 * (n ? n : 1));
+  int64_t* cnt = (int64_t*)calloc(n ? n : 1, sizeof(int64_t));
+  size_t m = 0, np = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const double* p = pts + 3 * i;
+    if (within_volume(p, c)) {
+      int32_t k[3];
+      for (int d = 0; d < 3; ++d) k[d] = (int32_t)floor(p[d] * inv); /* getVoxelIdx, VoxelHashMap.hpp:47-50 */
+      int is_new;
+      int64_t s = vhash_get(&h, k[0], k[1], k[2], (int64_t)m, &is_new);
+      if (is_new) {
+        for (int d = 0; d < 3; ++d) sp[3 * m + d] = sn[3 * m + d] = 0.0;
+        ++m;
+      }
+      for (int d = 0; d < 3; ++d) sp[3 * (size_t)s + d] += p[d];
+      if (nrm) { /* AccumulatedPoint::AddPoint skips NaN normals, helpers.cpp:34-38 */
+        const double* q = nrm + 3 * i;
+        if (!isnan(q[0]) && !isnan(q[1]) && !isnan(q[2]))
+          for (int d = 0; d < 3; ++d) sn[3 * (size_t)s + d] += q[d];
+      }
+      cnt[s] += 1;
+    } else { /* pass-through, helpers.cpp:155-166 */
+      for (int d = 0; d < 3; ++d) {
+        out_pts[3 * np + d] = p[d];
+        if (nrm && out_nrm) out_nrm[3 * np + d] = nrm[3 * i + d];
+      }
+      ++np;
+    }
+  }
+  for (size_t s = 0; s < m; ++s) {
+    double a[3];
+    for (int d = 0; d < 3; ++d) {
+      out_pts[3 * (np + s) + d] = sp[3 * s + d] / (double)cnt[s];
+      a[d] = sn[3 * s + d] / (double)cnt[s];
+    }
+    if (nrm && out_nrm) { /* GetAverageNormal().normalized(), helpers.cpp:172 (Eigen: unchanged if norm==0) */
+      double z = dot3(a, a);
+      if (z > 0.0) {
+        double s2 = sqrt(z);
+        a[0] /= s2;
+        a[1] /= s2;
+        a[2] /= s2;
+      }
+      for (int d = 0; d < 3; ++d) out_nrm[3 * (np + s) + d] = a[d];
+    }
+  }
+  free(sp);
+  free(sn);
+  free(cnt);
+  vhash_free(&h);
+  if (n_pass) *n_pass = np;
+  return np + m;
+}

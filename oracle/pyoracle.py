@@ -1,0 +1,242 @@
+"""ctypes loader for the CPU oracle (oracle/libo3d_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never from the product package.
+PARITY UNPINNED (see oracle/o3d_oracle.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libo3d_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "o3d_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return _LIB_PATH
+
+
+class IcpResult(C.Structure):
+    _fields_ = [("transformation", C.c_double * 16), ("fitness", C.c_double), ("inlier_rmse", C.c_double),
+                ("iterations", C.c_int32), ("converged", C.c_int32), ("n_corr", C.c_uint64)]
+
+
+class Crop(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("invert", C.c_int32), ("center", C.c_double * 3), ("rmin", C.c_double),
+                ("rmax", C.c_double), ("zmin", C.c_double), ("zmax", C.c_double)]
+
+
+CROP_NONE, CROP_MAX_RADIUS, CROP_MIN_RADIUS, CROP_MIN_MAX_RADIUS, CROP_CYLINDER = range(5)
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_kdtree_build.restype = C.c_void_p
+        L.orc_kdtree_build.argtypes = [_dp, C.c_size_t]
+        L.orc_kdtree_free.argtypes = [C.c_void_p]
+        L.orc_kdtree_search_hybrid.restype = C.c_int
+        L.orc_kdtree_search_hybrid.argtypes = [C.c_void_p, _dp, C.c_double, C.c_int, _ip, _dp]
+        L.orc_kdtree_search_knn.restype = C.c_int
+        L.orc_kdtree_search_knn.argtypes = [C.c_void_p, _dp, C.c_int, _ip, _dp]
+        L.orc_evaluate.argtypes = [C.c_void_p, _dp, C.c_size_t, C.c_double, _ip, _dp, _dp, _dp, C.POINTER(C.c_uint64)]
+        L.orc_compute_jtj_jtr.argtypes = [_dp, C.c_size_t, _dp, _dp, _ip, _dp, _dp, _dp]
+        L.orc_solve_update.restype = C.c_int
+        L.orc_solve_update.argtypes = [_dp, _dp, _dp, _dp]
+        L.orc_vector6_to_matrix4.argtypes = [_dp, _dp]
+        L.orc_transform_points.argtypes = [_dp, C.c_size_t, _dp]
+        L.orc_transform_normals.argtypes = [_dp, C.c_size_t, _dp]
+        L.orc_icp_point_to_plane.restype = C.c_int
+        L.orc_icp_point_to_plane.argtypes = [_dp, C.c_size_t, _dp, _dp, C.c_size_t, C.c_void_p, C.c_double, _dp, C.c_int,
+                                             C.c_double, C.c_double, C.POINTER(IcpResult)]
+        L.orc_estimate_normals.argtypes = [_dp, C.c_size_t, C.c_double, C.c_int, _dp]
+        L.orc_fast_eigen3x3_min_evec.argtypes = [_dp, _dp]
+        L.orc_voxel_down_sample.restype = C.c_size_t
+        L.orc_voxel_down_sample.argtypes = [_dp, _dp, C.c_size_t, C.c_double, _dp, _dp]
+        L.orc_crop_indices.restype = C.c_size_t
+        L.orc_crop_indices.argtypes = [_dp, C.c_size_t, C.POINTER(Crop), C.POINTER(C.c_int64)]
+        L.orc_voxelize_within_volume.restype = C.c_size_t
+        L.orc_voxelize_within_volume.argtypes = [_dp, _dp, C.c_size_t, C.c_double, C.POINTER(Crop), _dp, _dp,
+                                                 C.POINTER(C.c_size_t)]
+        L.orc_num_threads.restype = C.c_int
+        L.orc_set_num_threads.argtypes = [C.c_int]
+        _lib = L
+    return _lib
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+def colmajor(T) -> np.ndarray:
+    """numpy 4x4 (row-major view) -> 16 doubles column-major."""
+    return np.ascontiguousarray(np.asarray(T, dtype=np.float64).T).ravel()
+
+
+def from_colmajor(v) -> np.ndarray:
+    return np.array(v, dtype=np.float64).reshape(4, 4).T.copy()
+
+
+def make_crop(kind=CROP_NONE, center=(0, 0, 0), rmin=0.0, rmax=0.0, zmin=0.0, zmax=0.0, invert=False) -> Crop:
+    c = Crop()
+    c.kind, c.invert = int(kind), int(bool(invert))
+    c.center[:] = [float(x) for x in center]
+    c.rmin, c.rmax, c.zmin, c.zmax = float(rmin), float(rmax), float(zmin), float(zmax)
+    return c
+
+
+class KDTree:
+    def __init__(self, pts):
+        self.pts, p = _d(pts)
+        self.h = lib().orc_kdtree_build(p, len(self.pts))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_kdtree_free(self.h)
+            self.h = None
+
+    def search_hybrid(self, q, radius, max_nn):
+        q, qp = _d(q)
+        idx = np.empty(max_nn, np.int32)
+        d2 = np.empty(max_nn, np.float64)
+        k = lib().orc_kdtree_search_hybrid(self.h, qp, radius, max_nn, idx.ctypes.data_as(_ip), d2.ctypes.data_as(_dp))
+        return idx[:k], d2[:k]
+
+    def search_knn(self, q, k):
+        q, qp = _d(q)
+        idx = np.empty(k, np.int32)
+        d2 = np.empty(k, np.float64)
+        kk = lib().orc_kdtree_search_knn(self.h, qp, k, idx.ctypes.data_as(_ip), d2.ctypes.data_as(_dp))
+        return idx[:kk], d2[:kk]
+
+
+def evaluate(tree: KDTree, src, max_corr):
+    src, sp = _d(src)
+    n = len(src)
+    corr = np.empty(n, np.int32)
+    d2 = np.empty(n, np.float64)
+    fit, rmse, nc = C.c_double(), C.c_double(), C.c_uint64()
+    lib().orc_evaluate(tree.h, sp, n, max_corr, corr.ctypes.data_as(_ip), d2.ctypes.data_as(_dp), C.byref(fit), C.byref(rmse),
+                       C.byref(nc))
+    return corr, d2, fit.value, rmse.value, nc.value
+
+
+def compute_jtj_jtr(src, tgt, nrm, corr):
+    src, sp = _d(src)
+    tgt, tp = _d(tgt)
+    nrm, npp = _d(nrm)
+    corr = np.ascontiguousarray(corr, np.int32)
+    JTJ = np.zeros(36)
+    JTr = np.zeros(6)
+    r2 = C.c_double()
+    lib().orc_compute_jtj_jtr(sp, len(src), tp, npp, corr.ctypes.data_as(_ip), JTJ.ctypes.data_as(_dp), JTr.ctypes.data_as(_dp),
+                              C.byref(r2))
+    return JTJ.reshape(6, 6), JTr, r2.value
+
+
+def solve_update(JTJ, JTr):
+    JTJ, jp = _d(np.asarray(JTJ).reshape(36))
+    JTr, rp = _d(JTr)
+    U = np.zeros(16)
+    x = np.zeros(6)
+    lib().orc_solve_update(jp, rp, U.ctypes.data_as(_dp), x.ctypes.data_as(_dp))
+    return from_colmajor(U), x
+
+
+def vector6_to_matrix4(x):
+    x, xp = _d(x)
+    U = np.zeros(16)
+    lib().orc_vector6_to_matrix4(xp, U.ctypes.data_as(_dp))
+    return from_colmajor(U)
+
+
+def transform_points(pts, T):
+    out = np.array(pts, dtype=np.float64, order="C", copy=True)
+    Tc, tp = _d(colmajor(T))
+    lib().orc_transform_points(out.ctypes.data_as(_dp), len(out), tp)
+    return out
+
+
+def transform_normals(nrm, T):
+    out = np.array(nrm, dtype=np.float64, order="C", copy=True)
+    Tc, tp = _d(colmajor(T))
+    lib().orc_transform_normals(out.ctypes.data_as(_dp), len(out), tp)
+    return out
+
+
+def icp_point_to_plane(src, tgt, nrm, max_corr, init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6, tree: KDTree | None = None):
+    src, sp = _d(src)
+    tgt, tp = _d(tgt)
+    nrm, npp = _d(nrm)
+    init = np.eye(4) if init is None else init
+    Tc, ip = _d(colmajor(init))
+    out = IcpResult()
+    rc = lib().orc_icp_point_to_plane(sp, len(src), tp, npp, len(tgt), tree.h if tree is not None else None, max_corr, ip,
+                                      max_iter, rel_fitness, rel_rmse, C.byref(out))
+    if rc != 0:
+        raise RuntimeError(f"orc_icp_point_to_plane rc={rc}")
+    return dict(transformation=from_colmajor(out.transformation), fitness=out.fitness, inlier_rmse=out.inlier_rmse,
+                iterations=out.iterations, converged=bool(out.converged), n_corr=int(out.n_corr))
+
+
+def estimate_normals(pts, radius, max_nn):
+    pts, pp = _d(pts)
+    out = np.empty_like(pts)
+    lib().orc_estimate_normals(pp, len(pts), radius, max_nn, out.ctypes.data_as(_dp))
+    return out
+
+
+def fast_eigen3x3_min_evec(cov):
+    cov, cp = _d(np.asarray(cov).reshape(9))
+    out = np.zeros(3)
+    lib().orc_fast_eigen3x3_min_evec(cp, out.ctypes.data_as(_dp))
+    return out
+
+
+def voxel_down_sample(pts, voxel, nrm=None):
+    pts, pp = _d(pts)
+    n = len(pts)
+    out = np.empty((max(n, 1), 3))
+    if nrm is not None:
+        nrm, npp = _d(nrm)
+        on = np.empty((max(n, 1), 3))
+        m = lib().orc_voxel_down_sample(pp, npp, n, voxel, out.ctypes.data_as(_dp), on.ctypes.data_as(_dp))
+        return out[:m].copy(), on[:m].copy()
+    m = lib().orc_voxel_down_sample(pp, None, n, voxel, out.ctypes.data_as(_dp), None)
+    return out[:m].copy()
+
+
+def crop_indices(pts, crop: Crop):
+    pts, pp = _d(pts)
+    idx = np.empty(max(len(pts), 1), np.int64)
+    k = lib().orc_crop_indices(pp, len(pts), C.byref(crop), idx.ctypes.data_as(C.POINTER(C.c_int64)))
+    return idx[:k].copy()
+
+
+def voxelize_within_volume(pts, nrm, voxel, crop: Crop):
+    pts, pp = _d(pts)
+    n = len(pts)
+    out = np.empty((max(n, 1), 3))
+    npass = C.c_size_t()
+    if nrm is not None:
+        nrm, npp = _d(nrm)
+        on = np.empty((max(n, 1), 3))
+        m = lib().orc_voxelize_within_volume(pp, npp, n, voxel, C.byref(crop), out.ctypes.data_as(_dp), on.ctypes.data_as(_dp),
+                                             C.byref(npass))
+        return out[:m].copy(), on[:m].copy(), int(npass.value)
+    m = lib().orc_voxelize_within_volume(pp, None, n, voxel, C.byref(crop), out.ctypes.data_as(_dp), None, C.byref(npass))
+    return out[:m].copy(), None, int(npass.value)
