@@ -1,0 +1,187 @@
+#!/usr/bin/env python
+"""bench.py -- ICP iterations/s of the scan-to-map hot path on MI355X (BASELINE.json metric).
+
+One STEP = one registerClouds-equivalent (CloudRegistration.cpp:44-48): point-to-plane ICP of a 65 536-pt
+VLP-16-like scan against a 1 000 000-pt submap with normals (BASELINE.json configs[1]), FIXED 10 iterations
+(relative_fitness = relative_rmse = 0 so the convergence test never fires), initial guess =
+identity, truth = (0.30,-0.20,0.05) m / rpy (0.5,-0.5,2.0) deg.  Clouds and the target index are resident in HBM
+before the timed region (index build reported separately as index_build_ms).
+
+N GPUs (one process per GPU, launched by torch.distributed.run): rank r holds ITS OWN 1M-pt submap (seed 1235+r)
+and the whole scan; every ICP iteration all-reduces the 32-double normal-equation record over RCCL ("submap"
+partitioning, open3d_slam_amd/sharded.py).  Weak scaling: per-GPU work is fixed; value counts the
+scan-vs-submap iterations all ranks processed per second.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ICP_ITERS = 10
+N_SRC, N_MAP = 65536, 1_000_000
+MAX_CORR = 1.0
+ALGO_BYTES_PER_POINT = 228  # 12 src + 16*12 NN candidates + 12 matched point + 12 matched normal
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(src, tgt, nrm, budget_s=20.0):
+    """CPU restatement of Open3D v0.15.1 (the oracle, 'port'), timed on this box's host cores."""
+    from oracle import pyoracle as po
+
+    threads = po.lib().orc_num_threads()
+    t0 = time.perf_counter()
+    tree = po.KDTree(tgt)
+    build_s = time.perf_counter() - t0
+    reps, spent, res = 0, 0.0, None
+    while reps < 2 or (spent < budget_s and reps < 50):
+        t0 = time.perf_counter()
+        res = po.icp_point_to_plane(src, tgt, nrm, MAX_CORR, max_iter=ICP_ITERS, rel_fitness=0.0, rel_rmse=0.0, tree=tree)
+        spent += time.perf_counter() - t0
+        reps += 1
+        if spent > budget_s:
+            break
+    per_reg = spent / reps
+    return dict(value=ICP_ITERS / per_reg, unit="icp_iterations/s", cores=threads, kind="port",
+                sample=f"{reps} x (64k scan vs 1M map, {ICP_ITERS} iters, KD-tree prebuilt) = {spent:.1f}s; "
+                       f"KD-tree build {build_s*1e3:.0f} ms -> {ICP_ITERS/(per_reg+build_s):.2f} it/s when rebuilt per call as the reference does; "
+                       f"CPU restatement of Open3D v0.15.1, {threads} OpenMP threads"), res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--precision", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--cell", type=float, default=0.0, help="NN grid cell size (0 = max_corr/4)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from open3d_slam_amd import backend, sharded, synthetic as syn
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+
+    # ---- synthetic workload (seeded)
+    scene = syn.make_scene()
+    T_gt = syn.ground_truth_pose()
+    src = syn.vlp16_scan(scene, T_gt)
+    tgt, nrm = syn.sample_map(scene, N_MAP, seed=syn.SEED_MAP + rank)
+    assert len(src) == N_SRC
+
+    prec = backend.PRECISION_F64 if args.precision == "f64" else backend.PRECISION_F32
+    be = backend.Backend(local_rank, prec)
+    s_id = be.upload(src)
+    t_id = be.upload(tgt, nrm)
+    t0 = time.perf_counter()
+    be.build_index(t_id, MAX_CORR, args.cell)
+    be.synchronize()
+    index_build_ms = (time.perf_counter() - t0) * 1e3
+
+    if world > 1:
+        drv = sharded.ShardedIcp(be, mode="submap")
+
+        def step():
+            return drv.register(s_id, t_id, N_SRC, MAX_CORR, max_iter=ICP_ITERS, rel_fitness=0.0, rel_rmse=0.0,
+                                check_every=ICP_ITERS + 2)
+    else:
+        def step():
+            return be.icp_point_to_plane_dev(s_id, t_id, MAX_CORR, max_iter=ICP_ITERS, rel_fitness=0.0, rel_rmse=0.0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    res = None
+    for _ in range(args.warmup):
+        res = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert res["iterations"] == ICP_ITERS
+
+    # ---- roofline of the dominant kernel (icp_accumulate_kernel): same K steps re-run with hipEvent brackets around
+    # every launch on the launch stream (kept out of the timed region above so the brackets do not perturb `value`)
+    be.profile_enable(True)
+    for _ in range(args.steps):
+        step()
+    n_launch, kern_ms = be.profile_read()
+    be.profile_enable(False)
+    avg_kernel_s = kern_ms * 1e-3 / max(n_launch, 1)
+    algo_bytes = N_SRC * ALGO_BYTES_PER_POINT
+    achieved_gbs = algo_bytes / avg_kernel_s / 1e9
+
+    if rank == 0:
+        dt_gt, dr_gt = syn.se3_error(res["transformation"], T_gt)
+        out = {
+            "metric": "icp_iterations_per_sec",
+            "value": world * ICP_ITERS * args.steps / elapsed,
+            "unit": "icp_iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32 points, f64 accumulate" if prec == backend.PRECISION_F32 else "f64",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: point-to-plane ICP, 65536-pt VLP-16 scan vs 1,000,000-pt submap, "
+                                   f"max_corr {MAX_CORR} m, {ICP_ITERS} fixed iterations/step (+1 evaluation pass), index prebuilt",
+                       "n_src": N_SRC, "n_map_per_gpu": N_MAP, "icp_iterations_per_step": ICP_ITERS,
+                       "parallelism": "1 GPU" if world == 1 else f"{world} submaps x 1 GPU, 256-B RCCL all-reduce / iteration",
+                       "nn_cell_m": args.cell if args.cell > 0 else MAX_CORR / 4},
+            "index_build_ms": index_build_ms,
+            "scans_per_sec_icp_only": world * args.steps / elapsed,
+            "pose_error_vs_truth": {"dt_m": dt_gt, "dr_rad": dr_gt, "fitness": res["fitness"], "inlier_rmse": res["inlier_rmse"]},
+            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "icp_accumulate_kernel", "launches": n_launch, "avg_launch_us": avg_kernel_s * 1e6,
+                         "algorithmic_bytes_per_launch": algo_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, cres = cpu_baseline(src, tgt, nrm, args.cpu_budget)
+            out["cpu_baseline"] = cb
+            dt, dr = syn.se3_error(res["transformation"], cres["transformation"])
+            out["parity_vs_cpu"] = {"dt_m": dt, "dr_rad": dr, "fitness_gpu": res["fitness"], "fitness_cpu": cres["fitness"]}
+            out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
+        print(json.dumps(out), flush=True)
+    be.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

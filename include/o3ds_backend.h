@@ -1,0 +1,182 @@
+/*
+ * o3ds_backend.h -- C-ABI of the MI355X (gfx950) scan-matching / map-fusion backend
+ * for open3d_slam.  Plain pointers and sizes only; no C++/torch/Eigen types.
+ *
+ * Every entry point names the reference interface it replaces; paths are relative to
+ * /root/reference/open3d_slam/open3d_slam/.  "[O3D]" = Open3D v0.15.1 routine the
+ * reference calls at that line (third-party, pinned by open3d_catkin/CMakeLists.txt:116-118).
+ *
+ * Conventions
+ *   clouds : const double* xyz, 3*n contiguous == std::vector<Eigen::Vector3d>::data()->data()
+ *            (open3d::geometry::PointCloud::points_ / normals_, typedefs.hpp:24)
+ *   poses  : const double[16] COLUMN-MAJOR == Eigen::Matrix4d::data() / Transform::matrix().data()
+ *            (Transform = Eigen::Isometry3d, Transform.hpp:15)
+ *   errors : every call returns O3DS_OK (0) or a negative o3ds_status; text via o3ds_last_error().
+ *            Nothing throws across the ABI; the C++ adapter (open3d_slam_amd/host/) re-throws
+ *            std::runtime_error to keep the reference's behaviour (assert.hpp:13-64).
+ *   threads: a handle owns one HIP stream and its scratch; it is NOT re-entrant -- create one
+ *            handle per calling thread (odometryWorker / mappingWorker / loopClosureWorker,
+ *            SlamWrapper.cpp:258-347,406-448).  Device clouds/maps belong to the handle that made them.
+ *   device : all work is enqueued on the handle's stream; calls that return host data synchronise it.
+ */
+#ifndef O3DS_BACKEND_H
+#define O3DS_BACKEND_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct o3ds_context* o3ds_handle;
+typedef uint64_t o3ds_cloud;  /* device-resident cloud (+ optional normals, + optional NN index) */
+
+typedef enum {
+  O3DS_OK = 0,
+  O3DS_ERR_INVALID_ARG = -1,   /* e.g. max_correspondence_distance <= 0  ([O3D] RegistrationICP LogError) */
+  O3DS_ERR_NO_NORMALS = -2,    /* point-to-plane needs target normals    ([O3D] RegistrationICP LogError) */
+  O3DS_ERR_OOM = -3,
+  O3DS_ERR_HIP = -4,
+  O3DS_ERR_BAD_HANDLE = -5,
+  O3DS_ERR_EMPTY = -6,         /* assert_gt(size,0): ScanToMapRegistration.cpp:51-52,60 */
+  O3DS_ERR_CAPACITY = -7       /* caller-provided output buffer too small */
+} o3ds_status;
+
+/* numeric storage of device clouds: f32 xyz (default; accumulation is always f64) or f64 xyz */
+typedef enum { O3DS_PRECISION_F32 = 0, O3DS_PRECISION_F64 = 1 } o3ds_precision;
+
+/* croppers.hpp:26-47, croppers.cpp:121-165 (+ setIsInvertVolume croppers.cpp:57-59) */
+typedef enum {
+  O3DS_CROP_NONE = 0,
+  O3DS_CROP_MAX_RADIUS = 1,
+  O3DS_CROP_MIN_RADIUS = 2,
+  O3DS_CROP_MIN_MAX_RADIUS = 3,
+  O3DS_CROP_CYLINDER = 4
+} o3ds_crop_kind;
+
+typedef struct {
+  int32_t kind;      /* o3ds_crop_kind */
+  int32_t invert;    /* isInvertVolume_ */
+  double center[3];  /* pose_.translation() -- only the translation is used (croppers.cpp:121-165) */
+  double rmin, rmax; /* ScanCroppingParameters::croppingMinRadius_/MaxRadius_ (Parameters.hpp:52-58) */
+  double zmin, zmax; /* croppingMinZ_/MaxZ_ (cylinder) */
+} o3ds_crop;
+
+/* open3d::pipelines::registration::RegistrationResult as consumed by open3d_slam
+ * (Odometry.cpp:51-72, Mapper.cpp:151-159): transformation_, fitness_, inlier_rmse_.
+ * correspondence_set_ is never read for ICP results and is not materialised. */
+typedef struct {
+  double transformation[16]; /* column-major */
+  double fitness;
+  double inlier_rmse;
+  int32_t iterations; /* Gauss-Newton updates applied */
+  int32_t converged;  /* ICPConvergenceCriteria test fired */
+  uint64_t n_corr;
+} o3ds_icp_result;
+
+/* IcpParameters (Parameters.hpp:66-71) + [O3D] ICPConvergenceCriteria */
+typedef struct {
+  double max_correspondence_distance; /* IcpParameters::maxCorrespondenceDistance_ */
+  int32_t max_iteration;              /* IcpParameters::maxNumIter_ -> criteria.max_iteration_ (CloudRegistration.cpp:63) */
+  int32_t reserved;
+  double relative_fitness;            /* [O3D] default 1e-6, never overridden by the reference */
+  double relative_rmse;               /* [O3D] default 1e-6 */
+} o3ds_icp_params;
+
+/* ---- lifecycle --------------------------------------------------------------------------- */
+int o3ds_create(int device_id, o3ds_handle* out);
+int o3ds_destroy(o3ds_handle h);
+const char* o3ds_last_error(o3ds_handle h); /* h may be NULL: last error of the calling thread */
+int o3ds_set_precision(o3ds_handle h, int precision /* o3ds_precision */);
+int o3ds_synchronize(o3ds_handle h);
+/* the hipStream_t all work of this handle is enqueued on (for event timing / interop) */
+void* o3ds_stream(o3ds_handle h);
+/* Enqueue this handle's work on the caller's hipStream_t instead (e.g. torch's current stream, so that a
+ * torch.distributed all-reduce of the step-wise record is stream-ordered with the kernels); NULL restores the
+ * handle's own stream.  The caller keeps the stream alive. */
+int o3ds_set_stream(o3ds_handle h, void* hip_stream);
+/* Kernel timing for bench.py's roofline line: when enabled, every ICP correspondence/reduction pass
+ * (icp_accumulate_kernel launch) is bracketed by hipEvents on the launch stream.  profile_read synchronises,
+ * returns the number of bracketed launches and their summed duration (ms), and resets the counters. */
+int o3ds_profile_enable(o3ds_handle h, int on);
+int o3ds_profile_read(o3ds_handle h, uint64_t* n_launches, double* total_ms);
+/* library / kernel identification string (arch, build flags) */
+const char* o3ds_version(void);
+
+/* ---- device clouds ----------------------------------------------------------------------- */
+/* Upload a host cloud (PointCloud::points_, normals_ may be NULL). */
+int o3ds_cloud_upload(o3ds_handle h, const double* xyz, const double* normals, size_t n, o3ds_cloud* out);
+int o3ds_cloud_free(o3ds_handle h, o3ds_cloud c);
+int o3ds_cloud_size(o3ds_handle h, o3ds_cloud c, size_t* n, int* has_normals);
+/* Download into caller buffers of capacity >= n points (normals may be NULL). */
+int o3ds_cloud_download(o3ds_handle h, o3ds_cloud c, double* xyz, double* normals, size_t capacity);
+/* Build the nearest-neighbour index of a cloud (replaces [O3D] KDTreeFlann::SetGeometry(target), which
+ * RegistrationICP does on every call).  cell_size <= 0 selects max_corr_hint/4.  Idempotent per cell size. */
+int o3ds_cloud_build_index(o3ds_handle h, o3ds_cloud c, double max_corr_hint, double cell_size);
+
+/* ---- Seam 1: CloudRegistration::registerClouds (CloudRegistration.hpp:25) ----------------- */
+/* RegistrationIcpPointToPlane::registerClouds (CloudRegistration.cpp:44-48) = [O3D] RegistrationICP with
+ * TransformationEstimationPointToPlane.  Host-buffer form: uploads both clouds, builds the target index
+ * (as the reference rebuilds its KD-tree per call), runs ICP, frees the device copies. */
+int o3ds_icp_point_to_plane(o3ds_handle h, const double* src_xyz, size_t n_src, const double* tgt_xyz, const double* tgt_normals,
+                            size_t n_tgt, const double init[16], const o3ds_icp_params* params, o3ds_icp_result* out);
+/* Device-resident form.  target must have normals and an index.  target_crop (may be NULL) restricts the
+ * target to the points inside the volume -- ScanToMapIcp::scanToMapRegistration's
+ * scanMatcherCropper_->crop(activeSubmapPointCloud) (ScanToMapRegistration.cpp:58-59) fused into the search. */
+int o3ds_icp_point_to_plane_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3ds_crop* target_crop,
+                                const double init[16], const o3ds_icp_params* params, o3ds_icp_result* out);
+
+/* Step-wise form of the same loop, for sharded (multi-GPU) registration: the caller all-reduces the 32-double
+ * normal-equation record between accumulate and update.  Record layout (doubles):
+ *   [0..20] upper triangle of JtJ row-major, [21..26] Jtr, [27] sum r^2, [28] #corr, [29] sum d^2, [30..31] 0.
+ * begin      : T <- init, resets iteration state.
+ * accumulate : one correspondence + reduction pass ([O3D] GetRegistrationResultAndCorrespondences +
+ *              ComputeJTJandJTr) of source points [first, first+count) under the current T; writes the record to
+ *              d_record (DEVICE pointer to 32 doubles, e.g. a torch tensor's data_ptr).
+ * update     : consumes a (possibly all-reduced) record on the device: convergence test against the previous pass,
+ *              6x6 LDLT, T <- U*T ([O3D] SolveJacobianSystemAndObtainExtrinsicMatrix).  n_src_total = |source| over
+ *              all shards (fitness denominator).
+ * finish     : synchronises and returns the result (state after the last evaluated pass). */
+int o3ds_icp_begin(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3ds_crop* target_crop, const double init[16],
+                   const o3ds_icp_params* params);
+int o3ds_icp_accumulate(o3ds_handle h, size_t first, size_t count, double* d_record);
+int o3ds_icp_update(o3ds_handle h, const double* d_record, uint64_t n_src_total);
+int o3ds_icp_finish(o3ds_handle h, o3ds_icp_result* out);
+/* 1 when the device-side loop has terminated (converged or max_iteration reached); synchronises. */
+int o3ds_icp_done(o3ds_handle h, int* done);
+
+/* ---- scan pre-processing: ScanToMapIcp::preprocess (ScanToMapRegistration.cpp:35-40),
+ *      LidarOdometry::preprocess (Odometry.cpp:25-30) ------------------------------------------ */
+/* CroppingVolume::crop (croppers.cpp:76-106): stable compaction of points (+normals) inside the volume. */
+int o3ds_crop_cloud(o3ds_handle h, o3ds_cloud in, const o3ds_crop* crop, o3ds_cloud* out);
+/* o3d_slam::voxelize (helpers.cpp:107-113) -> [O3D] PointCloud::VoxelDownSample: data-anchored grid,
+ * per-voxel mean of points (and normals).  Output order: ascending voxel key (the reference's order is
+ * unordered_map iteration order, i.e. unspecified).  voxel <= 0 returns a copy. */
+int o3ds_voxel_down_sample(o3ds_handle h, o3ds_cloud in, double voxel_size, o3ds_cloud* out);
+/* RegistrationIcpPointToPlane::estimateNormalsOrCovariancesIfNeeded (CloudRegistration.cpp:49-56):
+ * [O3D] EstimateNormals(KDTreeSearchParamHybrid(radius,max_nn)) + NormalizeNormals +
+ * OrientNormalsTowardsCameraLocation(0,0,0).  In place (adds/overwrites the cloud's normals). */
+int o3ds_estimate_normals(o3ds_handle h, o3ds_cloud c, double radius, int max_nn);
+/* [O3D] RandomDownSample is seeded from std::random_device (non-reproducible); the ABI takes the
+ * kept indices explicitly: SelectByIndex(keep_idx[0..m)). */
+int o3ds_select_by_index(o3ds_handle h, o3ds_cloud in, const uint32_t* keep_idx, size_t m, o3ds_cloud* out);
+
+/* ---- map fusion: Submap::insertScan (Submap.cpp:39-75) ------------------------------------- */
+/* o3d_slam::transform (helpers.cpp:273-305): p' = (T p).xyz/w, n' = R n.  Returns a new cloud.
+ * (The reference's duplicate-on-identity quirk, SURVEY B4, is intentionally not reproduced.) */
+int o3ds_transform_cloud(o3ds_handle h, o3ds_cloud in, const double T[16], o3ds_cloud* out);
+/* mapCloud_ += cloud (Submap.cpp:70; [O3D] PointCloud::operator+=). Appends `add` to `map` in place. */
+int o3ds_cloud_append(o3ds_handle h, o3ds_cloud map, o3ds_cloud add);
+/* voxelizeWithinCroppingVolume (helpers.cpp:115-183) via Submap::voxelizeInsideCroppingVolume (Submap.cpp:138-144):
+ * points outside the volume pass through (original order, first); points inside are replaced by per-voxel means on
+ * the WORLD-anchored grid key = floor(p * (1/voxel)) (VoxelHashMap.hpp:47-50), normals averaged (NaN skipped) and
+ * re-normalised (helpers.cpp:172).  Voxel means are emitted in ascending key order.  In place. */
+int o3ds_voxelize_within_volume(o3ds_handle h, o3ds_cloud map, double voxel_size, const o3ds_crop* crop);
+/* Submap::insertScan core (Submap.cpp:54,70-72) in one call: map += T*scan; re-voxelize inside crop; rebuild the
+ * NN index (max_corr_hint as in o3ds_cloud_build_index; <= 0 skips the rebuild). */
+int o3ds_map_insert_scan(o3ds_handle h, o3ds_cloud map, o3ds_cloud scan, const double T[16], double map_voxel_size,
+                         const o3ds_crop* map_builder_crop, double max_corr_hint);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* O3DS_BACKEND_H */

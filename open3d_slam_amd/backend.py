@@ -1,0 +1,291 @@
+"""ctypes binding of the C-ABI in include/o3ds_backend.h (libo3ds_backend.so, HIP/gfx950).
+
+This is plumbing only: every function forwards to the shared library.  There is NO CPU
+fallback -- if the library is missing or no GPU is present the calls raise (the product
+path must fail loudly rather than silently run something else).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libo3ds_backend.so")
+
+OK = 0
+ERR_INVALID_ARG, ERR_NO_NORMALS, ERR_OOM, ERR_HIP, ERR_BAD_HANDLE, ERR_EMPTY, ERR_CAPACITY = -1, -2, -3, -4, -5, -6, -7
+PRECISION_F32, PRECISION_F64 = 0, 1
+CROP_NONE, CROP_MAX_RADIUS, CROP_MIN_RADIUS, CROP_MIN_MAX_RADIUS, CROP_CYLINDER = range(5)
+
+
+class Crop(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("invert", C.c_int32), ("center", C.c_double * 3), ("rmin", C.c_double),
+                ("rmax", C.c_double), ("zmin", C.c_double), ("zmax", C.c_double)]
+
+
+class IcpResult(C.Structure):
+    _fields_ = [("transformation", C.c_double * 16), ("fitness", C.c_double), ("inlier_rmse", C.c_double),
+                ("iterations", C.c_int32), ("converged", C.c_int32), ("n_corr", C.c_uint64)]
+
+
+class IcpParams(C.Structure):
+    _fields_ = [("max_correspondence_distance", C.c_double), ("max_iteration", C.c_int32), ("reserved", C.c_int32),
+                ("relative_fitness", C.c_double), ("relative_rmse", C.c_double)]
+
+
+_dp = C.POINTER(C.c_double)
+_H = C.c_void_p
+_CL = C.c_uint64
+
+# name -> (restype, argtypes); must list every symbol include/o3ds_backend.h declares
+SIGNATURES = {
+    "o3ds_create": (C.c_int, [C.c_int, C.POINTER(_H)]),
+    "o3ds_destroy": (C.c_int, [_H]),
+    "o3ds_last_error": (C.c_char_p, [_H]),
+    "o3ds_set_precision": (C.c_int, [_H, C.c_int]),
+    "o3ds_synchronize": (C.c_int, [_H]),
+    "o3ds_stream": (C.c_void_p, [_H]),
+    "o3ds_version": (C.c_char_p, []),
+    "o3ds_set_stream": (C.c_int, [_H, C.c_void_p]),
+    "o3ds_profile_enable": (C.c_int, [_H, C.c_int]),
+    "o3ds_profile_read": (C.c_int, [_H, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
+    "o3ds_cloud_upload": (C.c_int, [_H, _dp, _dp, C.c_size_t, C.POINTER(_CL)]),
+    "o3ds_cloud_free": (C.c_int, [_H, _CL]),
+    "o3ds_cloud_size": (C.c_int, [_H, _CL, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
+    "o3ds_cloud_download": (C.c_int, [_H, _CL, _dp, _dp, C.c_size_t]),
+    "o3ds_cloud_build_index": (C.c_int, [_H, _CL, C.c_double, C.c_double]),
+    "o3ds_icp_point_to_plane": (C.c_int, [_H, _dp, C.c_size_t, _dp, _dp, C.c_size_t, _dp, C.POINTER(IcpParams),
+                                          C.POINTER(IcpResult)]),
+    "o3ds_icp_point_to_plane_dev": (C.c_int, [_H, _CL, _CL, C.POINTER(Crop), _dp, C.POINTER(IcpParams), C.POINTER(IcpResult)]),
+    "o3ds_icp_begin": (C.c_int, [_H, _CL, _CL, C.POINTER(Crop), _dp, C.POINTER(IcpParams)]),
+    "o3ds_icp_accumulate": (C.c_int, [_H, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "o3ds_icp_update": (C.c_int, [_H, C.c_void_p, C.c_uint64]),
+    "o3ds_icp_finish": (C.c_int, [_H, C.POINTER(IcpResult)]),
+    "o3ds_icp_done": (C.c_int, [_H, C.POINTER(C.c_int)]),
+    "o3ds_crop_cloud": (C.c_int, [_H, _CL, C.POINTER(Crop), C.POINTER(_CL)]),
+    "o3ds_voxel_down_sample": (C.c_int, [_H, _CL, C.c_double, C.POINTER(_CL)]),
+    "o3ds_estimate_normals": (C.c_int, [_H, _CL, C.c_double, C.c_int]),
+    "o3ds_select_by_index": (C.c_int, [_H, _CL, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(_CL)]),
+    "o3ds_transform_cloud": (C.c_int, [_H, _CL, _dp, C.POINTER(_CL)]),
+    "o3ds_cloud_append": (C.c_int, [_H, _CL, _CL]),
+    "o3ds_voxelize_within_volume": (C.c_int, [_H, _CL, C.c_double, C.POINTER(Crop)]),
+    "o3ds_map_insert_scan": (C.c_int, [_H, _CL, _CL, _dp, C.c_double, C.POINTER(Crop), C.c_double]),
+}
+
+_lib = None
+
+
+class BackendError(RuntimeError):
+    """Mirrors the std::runtime_error the reference throws (assert.hpp:13-64 / Open3D LogError)."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"o3ds error {code}: {msg}")
+        self.code = code
+
+
+def load():
+    """dlopen the HIP backend; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} not built -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def make_crop(kind=CROP_NONE, center=(0.0, 0.0, 0.0), rmin=0.0, rmax=0.0, zmin=0.0, zmax=0.0, invert=False) -> Crop:
+    c = Crop()
+    c.kind, c.invert = int(kind), int(bool(invert))
+    c.center[:] = [float(x) for x in center]
+    c.rmin, c.rmax, c.zmin, c.zmax = float(rmin), float(rmax), float(zmin), float(zmax)
+    return c
+
+
+def colmajor(T) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(T, dtype=np.float64).T).ravel()
+
+
+def from_colmajor(v) -> np.ndarray:
+    return np.array(v, dtype=np.float64).reshape(4, 4).T.copy()
+
+
+def _d(a):
+    if a is None:
+        return None, None
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+class Backend:
+    """One handle = one HIP stream + scratch (not re-entrant; one per thread)."""
+
+    def __init__(self, device_id: int = 0, precision: int = PRECISION_F32):
+        self.lib = load()
+        self.h = _H()
+        rc = self.lib.o3ds_create(device_id, C.byref(self.h))
+        if rc != OK:
+            raise BackendError(rc, (self.lib.o3ds_last_error(None) or b"").decode())
+        if precision != PRECISION_F32:
+            self._ck(self.lib.o3ds_set_precision(self.h, precision))
+        self.device_id = device_id
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.o3ds_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc: int):
+        if rc != OK:
+            raise BackendError(rc, (self.lib.o3ds_last_error(self.h) or b"").decode())
+
+    # -- clouds
+    def upload(self, xyz, normals=None) -> int:
+        xyz, xp = _d(np.asarray(xyz).reshape(-1, 3))
+        nrm, npp = _d(None if normals is None else np.asarray(normals).reshape(-1, 3))
+        cid = _CL()
+        self._ck(self.lib.o3ds_cloud_upload(self.h, xp, npp, len(xyz), C.byref(cid)))
+        return cid.value
+
+    def free(self, cid: int):
+        self._ck(self.lib.o3ds_cloud_free(self.h, cid))
+
+    def size(self, cid: int):
+        n, hn = C.c_size_t(), C.c_int()
+        self._ck(self.lib.o3ds_cloud_size(self.h, cid, C.byref(n), C.byref(hn)))
+        return n.value, bool(hn.value)
+
+    def download(self, cid: int):
+        n, hn = self.size(cid)
+        xyz = np.empty((n, 3))
+        nrm = np.empty((n, 3)) if hn else None
+        self._ck(self.lib.o3ds_cloud_download(self.h, cid, xyz.ctypes.data_as(_dp),
+                                              nrm.ctypes.data_as(_dp) if hn else None, n))
+        return xyz, nrm
+
+    def build_index(self, cid: int, max_corr_hint: float, cell_size: float = 0.0):
+        self._ck(self.lib.o3ds_cloud_build_index(self.h, cid, max_corr_hint, cell_size))
+
+    # -- ICP
+    @staticmethod
+    def _params(max_corr, max_iter, rel_fitness, rel_rmse) -> IcpParams:
+        p = IcpParams()
+        p.max_correspondence_distance = float(max_corr)
+        p.max_iteration = int(max_iter)
+        p.relative_fitness = float(rel_fitness)
+        p.relative_rmse = float(rel_rmse)
+        return p
+
+    @staticmethod
+    def _result(r: IcpResult) -> dict:
+        return dict(transformation=from_colmajor(r.transformation), fitness=r.fitness, inlier_rmse=r.inlier_rmse,
+                    iterations=r.iterations, converged=bool(r.converged), n_corr=int(r.n_corr))
+
+    def icp_point_to_plane(self, src, tgt, tgt_normals, max_corr, init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6):
+        src, sp = _d(np.asarray(src).reshape(-1, 3))
+        tgt, tp = _d(np.asarray(tgt).reshape(-1, 3))
+        nrm, npp = _d(None if tgt_normals is None else np.asarray(tgt_normals).reshape(-1, 3))
+        T0, ip = _d(colmajor(np.eye(4) if init is None else init))
+        p = self._params(max_corr, max_iter, rel_fitness, rel_rmse)
+        out = IcpResult()
+        self._ck(self.lib.o3ds_icp_point_to_plane(self.h, sp, len(src), tp, npp, len(tgt), ip, C.byref(p), C.byref(out)))
+        return self._result(out)
+
+    def icp_point_to_plane_dev(self, source: int, target: int, max_corr, init=None, max_iter=30, rel_fitness=1e-6,
+                               rel_rmse=1e-6, target_crop: Crop | None = None):
+        T0, ip = _d(colmajor(np.eye(4) if init is None else init))
+        p = self._params(max_corr, max_iter, rel_fitness, rel_rmse)
+        out = IcpResult()
+        self._ck(self.lib.o3ds_icp_point_to_plane_dev(self.h, source, target, C.byref(target_crop) if target_crop else None, ip,
+                                                      C.byref(p), C.byref(out)))
+        return self._result(out)
+
+    def icp_begin(self, source: int, target: int, max_corr, init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6,
+                  target_crop: Crop | None = None):
+        T0, ip = _d(colmajor(np.eye(4) if init is None else init))
+        p = self._params(max_corr, max_iter, rel_fitness, rel_rmse)
+        self._ck(self.lib.o3ds_icp_begin(self.h, source, target, C.byref(target_crop) if target_crop else None, ip, C.byref(p)))
+
+    def icp_accumulate(self, first: int, count: int, d_record_ptr: int):
+        self._ck(self.lib.o3ds_icp_accumulate(self.h, first, count, C.c_void_p(d_record_ptr)))
+
+    def icp_update(self, d_record_ptr: int, n_src_total: int):
+        self._ck(self.lib.o3ds_icp_update(self.h, C.c_void_p(d_record_ptr), n_src_total))
+
+    def icp_done(self) -> bool:
+        d = C.c_int()
+        self._ck(self.lib.o3ds_icp_done(self.h, C.byref(d)))
+        return bool(d.value)
+
+    def icp_finish(self) -> dict:
+        out = IcpResult()
+        self._ck(self.lib.o3ds_icp_finish(self.h, C.byref(out)))
+        return self._result(out)
+
+    def synchronize(self):
+        self._ck(self.lib.o3ds_synchronize(self.h))
+
+    def set_stream(self, hip_stream: int | None):
+        self._ck(self.lib.o3ds_set_stream(self.h, C.c_void_p(hip_stream or 0)))
+
+    def profile_enable(self, on: bool):
+        self._ck(self.lib.o3ds_profile_enable(self.h, int(on)))
+
+    def profile_read(self):
+        n, ms = C.c_uint64(), C.c_double()
+        self._ck(self.lib.o3ds_profile_read(self.h, C.byref(n), C.byref(ms)))
+        return int(n.value), float(ms.value)
+
+    @property
+    def stream(self) -> int:
+        return int(self.lib.o3ds_stream(self.h) or 0)
+
+    # -- pre-processing
+    def crop_cloud(self, cid: int, crop: Crop) -> int:
+        out = _CL()
+        self._ck(self.lib.o3ds_crop_cloud(self.h, cid, C.byref(crop), C.byref(out)))
+        return out.value
+
+    def voxel_down_sample(self, cid: int, voxel: float) -> int:
+        out = _CL()
+        self._ck(self.lib.o3ds_voxel_down_sample(self.h, cid, voxel, C.byref(out)))
+        return out.value
+
+    def estimate_normals(self, cid: int, radius: float, max_nn: int):
+        self._ck(self.lib.o3ds_estimate_normals(self.h, cid, radius, max_nn))
+
+    def select_by_index(self, cid: int, idx) -> int:
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        out = _CL()
+        self._ck(self.lib.o3ds_select_by_index(self.h, cid, idx.ctypes.data_as(C.POINTER(C.c_uint32)), len(idx), C.byref(out)))
+        return out.value
+
+    # -- map fusion
+    def transform_cloud(self, cid: int, T) -> int:
+        Tc, tp = _d(colmajor(T))
+        out = _CL()
+        self._ck(self.lib.o3ds_transform_cloud(self.h, cid, tp, C.byref(out)))
+        return out.value
+
+    def cloud_append(self, map_id: int, add_id: int):
+        self._ck(self.lib.o3ds_cloud_append(self.h, map_id, add_id))
+
+    def voxelize_within_volume(self, map_id: int, voxel: float, crop: Crop):
+        self._ck(self.lib.o3ds_voxelize_within_volume(self.h, map_id, voxel, C.byref(crop)))
+
+    def map_insert_scan(self, map_id: int, scan_id: int, T, map_voxel: float, crop: Crop, max_corr_hint: float = 0.0):
+        Tc, tp = _d(colmajor(T))
+        self._ck(self.lib.o3ds_map_insert_scan(self.h, map_id, scan_id, tp, map_voxel, C.byref(crop), max_corr_hint))

@@ -1,0 +1,959 @@
+// backend.hip -- C-ABI (include/o3ds_backend.h) of the gfx950 scan-matching / map-fusion backend.
+// Host-side orchestration only; all arithmetic is in icp_kernels.hpp / cloud_kernels.hpp.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "cloud_kernels.hpp"
+#include "common.hpp"
+#include "icp_kernels.hpp"
+
+using namespace o3ds;
+
+namespace {
+
+thread_local std::string g_thread_error;
+
+struct CloudRec {
+  size_t n = 0;
+  int precision = 0;
+  void* pts = nullptr;  // P4[n]
+  void* nrm = nullptr;  // P4[n] or null
+  // nearest-neighbour index
+  bool has_index = false;
+  GridDev grid{};
+  int* cell_start = nullptr;
+  void* spts = nullptr;
+  void* snrm = nullptr;
+};
+
+constexpr int kMaxPassBlocks = 2048;
+constexpr size_t kMaxCells = (size_t)1 << 27;  // 512 MiB of cell_start at most
+
+}  // namespace
+
+struct o3ds_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int precision = O3DS_PRECISION_F32;
+  std::string err;
+  std::unordered_map<uint64_t, CloudRec> clouds;
+  uint64_t next_id = 1;
+  // ICP scratch
+  double* d_partials = nullptr;     // [kMaxPassBlocks][kRec]
+  IcpStateDev* d_state = nullptr;
+  IcpStateDev* h_state = nullptr;   // pinned
+  // step-wise ICP session
+  bool session = false;
+  IcpPassArgs pass{};
+  o3ds_icp_params params{};
+  size_t session_n_src = 0;
+  int session_precision = 0;
+  bool session_crop = false;
+  hipStream_t own_stream = nullptr;
+  // profiling (bench.py roofline): event pairs around every accumulate launch
+  bool profiling = false;
+  std::vector<hipEvent_t> ev;
+  size_t ev_used = 0;
+};
+
+namespace {
+
+int fail(o3ds_handle h, int code, const std::string& msg) {
+  g_thread_error = msg;
+  if (h) h->err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                       \
+  do {                                                                                                      \
+    hipError_t _e = (expr);                                                                                 \
+    if (_e != hipSuccess)                                                                                   \
+      return fail(h, _e == hipErrorOutOfMemory ? O3DS_ERR_OOM : O3DS_ERR_HIP,                               \
+                  std::string(#expr) + ": " + hipGetErrorString(_e) + " @" + __FILE__ + ":" + std::to_string(__LINE__)); \
+  } while (0)
+
+#define CHECK_HANDLE(h) \
+  if (!(h)) return fail(nullptr, O3DS_ERR_BAD_HANDLE, "null handle")
+
+inline int grid_for(size_t n, int cap = 4096) {
+  size_t g = (n + kBlock - 1) / kBlock;
+  if (g < 1) g = 1;
+  if (g > (size_t)cap) g = cap;
+  return (int)g;
+}
+
+size_t p4_size(int precision) { return precision == O3DS_PRECISION_F64 ? sizeof(P4d) : sizeof(P4f); }
+
+CloudRec* find_cloud(o3ds_handle h, o3ds_cloud id) {
+  auto it = h->clouds.find(id);
+  return it == h->clouds.end() ? nullptr : &it->second;
+}
+
+void free_index(CloudRec& c) {
+  if (c.cell_start) (void)hipFree(c.cell_start);
+  if (c.spts) (void)hipFree(c.spts);
+  if (c.snrm) (void)hipFree(c.snrm);
+  c.cell_start = nullptr;
+  c.spts = c.snrm = nullptr;
+  c.has_index = false;
+}
+void free_cloud(CloudRec& c) {
+  free_index(c);
+  if (c.pts) (void)hipFree(c.pts);
+  if (c.nrm) (void)hipFree(c.nrm);
+  c.pts = c.nrm = nullptr;
+  c.n = 0;
+}
+
+// exclusive scan of m ints (in -> out) with the hand-written 3-phase scan; in may alias out
+int exclusive_scan_int(o3ds_handle h, const int* in, int* out, size_t m) {
+  if (m == 0) return O3DS_OK;
+  const int nb = (int)((m + kScanPerBlock - 1) / kScanPerBlock);
+  int* sums = nullptr;
+  HIP_TRY(hipMalloc(&sums, sizeof(int) * (size_t)nb));
+  scan_local_kernel<<<nb, kBlock, 0, h->stream>>>(in, out, sums, m);
+  if (nb > 1) {
+    scan_sums_kernel<<<1, kBlock, 0, h->stream>>>(sums, nb);
+    scan_add_kernel<<<nb, kBlock, 0, h->stream>>>(out, sums, m);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipFree(sums));
+  return O3DS_OK;
+}
+
+template <typename P4>
+int bbox_of(o3ds_handle h, const P4* pts, size_t n, double mn[3], double mx[3]) {
+  const int g = grid_for(n, 1024);
+  double* d = nullptr;
+  HIP_TRY(hipMalloc(&d, sizeof(double) * 6 * (size_t)g));
+  bbox_kernel<P4><<<g, kBlock, 0, h->stream>>>(pts, n, d);
+  std::vector<double> hb(6 * (size_t)g);
+  HIP_TRY(hipMemcpyAsync(hb.data(), d, sizeof(double) * hb.size(), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipFree(d));
+  for (int a = 0; a < 3; ++a) {
+    mn[a] = 1e300;
+    mx[a] = -1e300;
+  }
+  for (int b = 0; b < g; ++b)
+    for (int a = 0; a < 3; ++a) {
+      mn[a] = std::min(mn[a], hb[(size_t)b * 6 + a]);
+      mx[a] = std::max(mx[a], hb[(size_t)b * 6 + 3 + a]);
+    }
+  return O3DS_OK;
+}
+
+template <typename P4>
+int build_index_t(o3ds_handle h, CloudRec& c, double cell) {
+  free_index(c);
+  if (c.n == 0) return fail(h, O3DS_ERR_EMPTY, "build_index: empty cloud");
+  double mn[3], mx[3];
+  int rc = bbox_of<P4>(h, (const P4*)c.pts, c.n, mn, mx);
+  if (rc) return rc;
+  for (int a = 0; a < 3; ++a)
+    if (!std::isfinite(mn[a]) || !std::isfinite(mx[a])) return fail(h, O3DS_ERR_INVALID_ARG, "build_index: non-finite coordinates");
+  size_t nx, ny, nz;
+  for (;;) {
+    nx = (size_t)std::floor((mx[0] - mn[0]) / cell) + 1;
+    ny = (size_t)std::floor((mx[1] - mn[1]) / cell) + 1;
+    nz = (size_t)std::floor((mx[2] - mn[2]) / cell) + 1;
+    if (nx * ny * nz <= kMaxCells) break;
+    cell *= 1.26;  // ~ x2 fewer cells per step
+  }
+  const size_t ncell = nx * ny * nz;
+  GridDev g{};
+  g.ox = mn[0];
+  g.oy = mn[1];
+  g.oz = mn[2];
+  g.cell = cell;
+  g.inv_cell = 1.0 / cell;
+  g.nx = (int)nx;
+  g.ny = (int)ny;
+  g.nz = (int)nz;
+  int *counts = nullptr, *cursor = nullptr, *cell_id = nullptr;
+  HIP_TRY(hipMalloc(&counts, sizeof(int) * (ncell + 1)));
+  HIP_TRY(hipMalloc(&cursor, sizeof(int) * ncell));
+  HIP_TRY(hipMalloc(&cell_id, sizeof(int) * c.n));
+  HIP_TRY(hipMalloc(&c.cell_start, sizeof(int) * (ncell + 1)));
+  HIP_TRY(hipMalloc(&c.spts, sizeof(P4) * c.n));
+  if (c.nrm) HIP_TRY(hipMalloc(&c.snrm, sizeof(P4) * c.n));
+  HIP_TRY(hipMemsetAsync(counts, 0, sizeof(int) * (ncell + 1), h->stream));
+  HIP_TRY(hipMemsetAsync(cursor, 0, sizeof(int) * ncell, h->stream));
+  cell_count_kernel<P4><<<grid_for(c.n), kBlock, 0, h->stream>>>((const P4*)c.pts, c.n, g, counts, cell_id);
+  rc = exclusive_scan_int(h, counts, c.cell_start, ncell + 1);
+  if (rc) return rc;
+  scatter_kernel<P4><<<grid_for(c.n), kBlock, 0, h->stream>>>((const P4*)c.pts, (const P4*)c.nrm, c.n, cell_id, c.cell_start, cursor,
+                                                              (P4*)c.spts, (P4*)c.snrm);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipFree(counts));
+  HIP_TRY(hipFree(cursor));
+  HIP_TRY(hipFree(cell_id));
+  g.cell_start = c.cell_start;
+  c.grid = g;
+  c.has_index = true;
+  return O3DS_OK;
+}
+
+int build_index(o3ds_handle h, CloudRec& c, double cell) {
+  return c.precision == O3DS_PRECISION_F64 ? build_index_t<P4d>(h, c, cell) : build_index_t<P4f>(h, c, cell);
+}
+
+template <typename P4>
+int upload_t(o3ds_handle h, const double* xyz, const double* normals, size_t n, CloudRec& c) {
+  c.n = n;
+  c.precision = h->precision;
+  if (n == 0) return O3DS_OK;
+  double* stage = nullptr;
+  HIP_TRY(hipMalloc(&stage, sizeof(double) * 3 * n));
+  HIP_TRY(hipMalloc(&c.pts, sizeof(P4) * n));
+  HIP_TRY(hipMemcpyAsync(stage, xyz, sizeof(double) * 3 * n, hipMemcpyHostToDevice, h->stream));
+  pack_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(stage, n, (P4*)c.pts);
+  if (normals) {
+    HIP_TRY(hipMalloc(&c.nrm, sizeof(P4) * n));
+    HIP_TRY(hipStreamSynchronize(h->stream));  // stage is reused
+    HIP_TRY(hipMemcpyAsync(stage, normals, sizeof(double) * 3 * n, hipMemcpyHostToDevice, h->stream));
+    pack_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(stage, n, (P4*)c.nrm);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipFree(stage));
+  return O3DS_OK;
+}
+
+template <typename P4>
+int download_t(o3ds_handle h, const CloudRec& c, double* xyz, double* normals) {
+  if (c.n == 0) return O3DS_OK;
+  double* stage = nullptr;
+  HIP_TRY(hipMalloc(&stage, sizeof(double) * 3 * c.n));
+  if (xyz) {
+    unpack_kernel<P4><<<grid_for(c.n), kBlock, 0, h->stream>>>((const P4*)c.pts, c.n, stage);
+    HIP_TRY(hipMemcpyAsync(xyz, stage, sizeof(double) * 3 * c.n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  if (normals && c.nrm) {
+    unpack_kernel<P4><<<grid_for(c.n), kBlock, 0, h->stream>>>((const P4*)c.nrm, c.n, stage);
+    HIP_TRY(hipMemcpyAsync(normals, stage, sizeof(double) * 3 * c.n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipFree(stage));
+  return O3DS_OK;
+}
+
+o3ds_cloud add_cloud(o3ds_handle h, CloudRec&& c) {
+  const uint64_t id = h->next_id++;
+  h->clouds.emplace(id, std::move(c));
+  return id;
+}
+
+// ---- ICP launch helpers -------------------------------------------------------------------------
+template <typename P4>
+void launch_accumulate(o3ds_handle h, const IcpPassArgs& a, bool crop, int nblocks) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (h->profiling) {
+    if (h->ev_used + 2 > h->ev.size()) {
+      hipEvent_t a0, a1;
+      if (hipEventCreate(&a0) == hipSuccess && hipEventCreate(&a1) == hipSuccess) {
+        h->ev.push_back(a0);
+        h->ev.push_back(a1);
+      }
+    }
+    if (h->ev_used + 2 <= h->ev.size()) {
+      e0 = h->ev[h->ev_used];
+      e1 = h->ev[h->ev_used + 1];
+      h->ev_used += 2;
+      (void)hipEventRecord(e0, h->stream);
+    }
+  }
+  if (crop)
+    icp_accumulate_kernel<P4, true><<<nblocks, kBlock, 0, h->stream>>>(a);
+  else
+    icp_accumulate_kernel<P4, false><<<nblocks, kBlock, 0, h->stream>>>(a);
+  if (e1) (void)hipEventRecord(e1, h->stream);
+}
+
+int pass_blocks(size_t count) {
+  size_t g = (count + kBlock - 1) / kBlock;
+  if (g < 1) g = 1;
+  if (g > (size_t)kMaxPassBlocks) g = kMaxPassBlocks;
+  return (int)g;
+}
+
+int validate_icp(o3ds_handle h, const CloudRec* src, const CloudRec* tgt, const o3ds_icp_params* p) {
+  if (!src || !tgt) return fail(h, O3DS_ERR_INVALID_ARG, "icp: unknown cloud id");
+  if (!p) return fail(h, O3DS_ERR_INVALID_ARG, "icp: null params");
+  if (!(p->max_correspondence_distance > 0.0))
+    return fail(h, O3DS_ERR_INVALID_ARG, "Invalid max_correspondence_distance.");  // [O3D] RegistrationICP
+  if (!tgt->nrm) return fail(h, O3DS_ERR_NO_NORMALS, "TransformationEstimationPointToPlane requires target normals");
+  if (src->precision != tgt->precision) return fail(h, O3DS_ERR_INVALID_ARG, "icp: source/target precision mismatch");
+  if (p->max_iteration < 0) return fail(h, O3DS_ERR_INVALID_ARG, "icp: negative max_iteration");
+  return O3DS_OK;
+}
+
+int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3ds_crop* crop, const double init[16],
+                  const o3ds_icp_params* params) {
+  CloudRec* src = find_cloud(h, source);
+  CloudRec* tgt = find_cloud(h, target);
+  int rc = validate_icp(h, src, tgt, params);
+  if (rc) return rc;
+  if (tgt->n == 0) return fail(h, O3DS_ERR_EMPTY, "icp: empty target");
+  if (!tgt->has_index || (tgt->nrm && !tgt->snrm)) {
+    rc = build_index(h, *tgt, params->max_correspondence_distance / 4.0);
+    if (rc) return rc;
+  }
+  IcpStateDev st{};
+  memcpy(st.T, init, sizeof(double) * 16);
+  *h->h_state = st;
+  HIP_TRY(hipMemcpyAsync(h->d_state, h->h_state, sizeof(IcpStateDev), hipMemcpyHostToDevice, h->stream));
+  IcpPassArgs a{};
+  a.src = src->pts;
+  a.first = 0;
+  a.count = src->n;
+  a.tpts = tgt->spts;
+  a.tnrm = tgt->snrm;
+  a.grid = tgt->grid;
+  a.crop = to_dev(crop);
+  const double r = params->max_correspondence_distance;
+  a.r2max = r * r;
+  a.rmax_cells = (int)std::ceil(r / tgt->grid.cell);
+  if (a.rmax_cells < 1) a.rmax_cells = 1;
+  a.state = h->d_state;
+  a.partials = h->d_partials;
+  h->pass = a;
+  h->params = *params;
+  h->session = true;
+  h->session_n_src = src->n;
+  h->session_precision = src->precision;
+  h->session_crop = crop && crop->kind != O3DS_CROP_NONE;
+  return O3DS_OK;
+}
+
+int read_state(o3ds_handle h, o3ds_icp_result* out) {
+  HIP_TRY(hipMemcpyAsync(h->h_state, h->d_state, sizeof(IcpStateDev), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (out) {
+    memcpy(out->transformation, h->h_state->T, sizeof(double) * 16);
+    out->fitness = h->h_state->fitness;
+    out->inlier_rmse = h->h_state->rmse;
+    out->iterations = h->h_state->iterations;
+    out->converged = h->h_state->converged;
+    out->n_corr = h->h_state->n_corr;
+  }
+  return O3DS_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char* o3ds_version(void) { return "o3ds_backend 0.1 (gfx950, hip, f32/f64 storage, f64 accumulate)"; }
+
+const char* o3ds_last_error(o3ds_handle h) { return h ? h->err.c_str() : g_thread_error.c_str(); }
+
+int o3ds_create(int device_id, o3ds_handle* out) {
+  if (!out) return fail(nullptr, O3DS_ERR_INVALID_ARG, "o3ds_create: null out");
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(nullptr, O3DS_ERR_HIP, std::string("o3ds_create: no HIP device (") + hipGetErrorString(e) + ")");
+  if (device_id < 0 || device_id >= count) return fail(nullptr, O3DS_ERR_INVALID_ARG, "o3ds_create: bad device id");
+  o3ds_handle h = new o3ds_context();
+  h->device = device_id;
+  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+      (h->own_stream = h->stream, false) || hipMalloc(&h->d_partials, sizeof(double) * kRec * kMaxPassBlocks) != hipSuccess ||
+      hipMalloc(&h->d_state, sizeof(IcpStateDev)) != hipSuccess ||
+      hipHostMalloc((void**)&h->h_state, sizeof(IcpStateDev), hipHostMallocDefault) != hipSuccess) {
+    delete h;
+    return fail(nullptr, O3DS_ERR_HIP, "o3ds_create: device initialisation failed");
+  }
+  *out = h;
+  return O3DS_OK;
+}
+
+int o3ds_destroy(o3ds_handle h) {
+  CHECK_HANDLE(h);
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  (void)hipStreamSynchronize(h->own_stream);
+  for (auto& kv : h->clouds) free_cloud(kv.second);
+  if (h->d_partials) (void)hipFree(h->d_partials);
+  if (h->d_state) (void)hipFree(h->d_state);
+  if (h->h_state) (void)hipHostFree(h->h_state);
+  for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+  return O3DS_OK;
+}
+
+int o3ds_set_precision(o3ds_handle h, int precision) {
+  CHECK_HANDLE(h);
+  if (precision != O3DS_PRECISION_F32 && precision != O3DS_PRECISION_F64) return fail(h, O3DS_ERR_INVALID_ARG, "bad precision");
+  h->precision = precision;
+  return O3DS_OK;
+}
+
+int o3ds_synchronize(o3ds_handle h) {
+  CHECK_HANDLE(h);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return O3DS_OK;
+}
+
+void* o3ds_stream(o3ds_handle h) { return h ? (void*)h->stream : nullptr; }
+
+int o3ds_set_stream(o3ds_handle h, void* hip_stream) {
+  CHECK_HANDLE(h);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  return O3DS_OK;
+}
+
+int o3ds_profile_enable(o3ds_handle h, int on) {
+  CHECK_HANDLE(h);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->profiling = on != 0;
+  h->ev_used = 0;
+  return O3DS_OK;
+}
+
+int o3ds_profile_read(o3ds_handle h, uint64_t* n_launches, double* total_ms) {
+  CHECK_HANDLE(h);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  double tot = 0.0;
+  for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+    tot += (double)ms;
+  }
+  if (n_launches) *n_launches = h->ev_used / 2;
+  if (total_ms) *total_ms = tot;
+  h->ev_used = 0;
+  return O3DS_OK;
+}
+
+// ---- clouds ------------------------------------------------------------------------------------
+int o3ds_cloud_upload(o3ds_handle h, const double* xyz, const double* normals, size_t n, o3ds_cloud* out) {
+  CHECK_HANDLE(h);
+  if (!out || (n > 0 && !xyz)) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_upload: null argument");
+  if (n > 0x7fffffffull) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_upload: more than 2^31-1 points");
+  HIP_TRY(hipSetDevice(h->device));
+  CloudRec c;
+  int rc = h->precision == O3DS_PRECISION_F64 ? upload_t<P4d>(h, xyz, normals, n, c) : upload_t<P4f>(h, xyz, normals, n, c);
+  if (rc) {
+    free_cloud(c);
+    return rc;
+  }
+  *out = add_cloud(h, std::move(c));
+  return O3DS_OK;
+}
+
+int o3ds_cloud_free(o3ds_handle h, o3ds_cloud id) {
+  CHECK_HANDLE(h);
+  auto it = h->clouds.find(id);
+  if (it == h->clouds.end()) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_free: unknown cloud id");
+  (void)hipStreamSynchronize(h->stream);
+  free_cloud(it->second);
+  h->clouds.erase(it);
+  return O3DS_OK;
+}
+
+int o3ds_cloud_size(o3ds_handle h, o3ds_cloud id, size_t* n, int* has_normals) {
+  CHECK_HANDLE(h);
+  CloudRec* c = find_cloud(h, id);
+  if (!c) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_size: unknown cloud id");
+  if (n) *n = c->n;
+  if (has_normals) *has_normals = c->nrm != nullptr;
+  return O3DS_OK;
+}
+
+int o3ds_cloud_download(o3ds_handle h, o3ds_cloud id, double* xyz, double* normals, size_t capacity) {
+  CHECK_HANDLE(h);
+  CloudRec* c = find_cloud(h, id);
+  if (!c) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_download: unknown cloud id");
+  if (capacity < c->n) return fail(h, O3DS_ERR_CAPACITY, "cloud_download: capacity < cloud size");
+  return c->precision == O3DS_PRECISION_F64 ? download_t<P4d>(h, *c, xyz, normals) : download_t<P4f>(h, *c, xyz, normals);
+}
+
+int o3ds_cloud_build_index(o3ds_handle h, o3ds_cloud id, double max_corr_hint, double cell_size) {
+  CHECK_HANDLE(h);
+  CloudRec* c = find_cloud(h, id);
+  if (!c) return fail(h, O3DS_ERR_INVALID_ARG, "build_index: unknown cloud id");
+  double cell = cell_size > 0.0 ? cell_size : max_corr_hint / 4.0;
+  if (!(cell > 0.0)) return fail(h, O3DS_ERR_INVALID_ARG, "build_index: need cell_size > 0 or max_corr_hint > 0");
+  return build_index(h, *c, cell);
+}
+
+// ---- ICP ---------------------------------------------------------------------------------------
+int o3ds_icp_begin(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3ds_crop* target_crop, const double init[16],
+                   const o3ds_icp_params* params) {
+  CHECK_HANDLE(h);
+  if (!init) return fail(h, O3DS_ERR_INVALID_ARG, "icp_begin: null init");
+  return begin_session(h, source, target, target_crop, init, params);
+}
+
+int o3ds_icp_accumulate(o3ds_handle h, size_t first, size_t count, double* d_record) {
+  CHECK_HANDLE(h);
+  if (!h->session) return fail(h, O3DS_ERR_INVALID_ARG, "icp_accumulate: no session (call o3ds_icp_begin)");
+  if (!d_record) return fail(h, O3DS_ERR_INVALID_ARG, "icp_accumulate: null record");
+  if (first + count > h->session_n_src) return fail(h, O3DS_ERR_INVALID_ARG, "icp_accumulate: range outside source");
+  IcpPassArgs a = h->pass;
+  a.first = first;
+  a.count = count;
+  const int nb = pass_blocks(count);
+  if (h->session_precision == O3DS_PRECISION_F64)
+    launch_accumulate<P4d>(h, a, h->session_crop, nb);
+  else
+    launch_accumulate<P4f>(h, a, h->session_crop, nb);
+  icp_reduce_kernel<<<1, kBlock, 0, h->stream>>>(h->d_partials, nb, h->d_state, d_record);
+  HIP_TRY(hipGetLastError());
+  return O3DS_OK;
+}
+
+int o3ds_icp_update(o3ds_handle h, const double* d_record, uint64_t n_src_total) {
+  CHECK_HANDLE(h);
+  if (!h->session) return fail(h, O3DS_ERR_INVALID_ARG, "icp_update: no session");
+  if (!d_record) return fail(h, O3DS_ERR_INVALID_ARG, "icp_update: null record");
+  icp_update_kernel<<<1, 64, 0, h->stream>>>(d_record, h->d_state, (unsigned long long)n_src_total, h->params.max_iteration,
+                                             h->params.relative_fitness, h->params.relative_rmse);
+  HIP_TRY(hipGetLastError());
+  return O3DS_OK;
+}
+
+int o3ds_icp_done(o3ds_handle h, int* done) {
+  CHECK_HANDLE(h);
+  if (!h->session) return fail(h, O3DS_ERR_INVALID_ARG, "icp_done: no session");
+  int rc = read_state(h, nullptr);
+  if (rc) return rc;
+  if (done) *done = h->h_state->done;
+  return O3DS_OK;
+}
+
+int o3ds_icp_finish(o3ds_handle h, o3ds_icp_result* out) {
+  CHECK_HANDLE(h);
+  if (!h->session) return fail(h, O3DS_ERR_INVALID_ARG, "icp_finish: no session");
+  if (!out) return fail(h, O3DS_ERR_INVALID_ARG, "icp_finish: null out");
+  h->session = false;
+  return read_state(h, out);
+}
+
+int o3ds_icp_point_to_plane_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3ds_crop* target_crop,
+                                const double init[16], const o3ds_icp_params* params, o3ds_icp_result* out) {
+  CHECK_HANDLE(h);
+  if (!init || !out) return fail(h, O3DS_ERR_INVALID_ARG, "icp: null init/out");
+  int rc = begin_session(h, source, target, target_crop, init, params);
+  if (rc) return rc;
+  h->session = false;  // the loop below owns the state
+  const IcpPassArgs a = h->pass;
+  const int nb = pass_blocks(a.count);
+  const int total_passes = params->max_iteration + 1;  // max_iter updates need max_iter+1 correspondence passes
+  int launched = 0;
+  while (launched < total_passes) {
+    // the device loop terminates itself (done flag); the host only checks between chunks of queued passes
+    const int chunk = std::min(total_passes - launched, launched == 0 ? 12 : 8);
+    for (int k = 0; k < chunk; ++k) {
+      if (h->session_precision == O3DS_PRECISION_F64)
+        launch_accumulate<P4d>(h, a, h->session_crop, nb);
+      else
+        launch_accumulate<P4f>(h, a, h->session_crop, nb);
+      icp_reduce_update_kernel<<<1, kBlock, 0, h->stream>>>(h->d_partials, nb, h->d_state, (unsigned long long)a.count,
+                                                            params->max_iteration, params->relative_fitness, params->relative_rmse);
+    }
+    launched += chunk;
+    HIP_TRY(hipGetLastError());
+    rc = read_state(h, out);
+    if (rc) return rc;
+    if (h->h_state->done) break;
+  }
+  return O3DS_OK;
+}
+
+int o3ds_icp_point_to_plane(o3ds_handle h, const double* src_xyz, size_t n_src, const double* tgt_xyz, const double* tgt_normals,
+                            size_t n_tgt, const double init[16], const o3ds_icp_params* params, o3ds_icp_result* out) {
+  CHECK_HANDLE(h);
+  if (!params || !out || !init) return fail(h, O3DS_ERR_INVALID_ARG, "icp: null argument");
+  if (!(params->max_correspondence_distance > 0.0)) return fail(h, O3DS_ERR_INVALID_ARG, "Invalid max_correspondence_distance.");
+  if (!tgt_normals) return fail(h, O3DS_ERR_NO_NORMALS, "TransformationEstimationPointToPlane requires target normals");
+  o3ds_cloud s = 0, t = 0;
+  int rc = o3ds_cloud_upload(h, src_xyz, nullptr, n_src, &s);
+  if (rc) return rc;
+  rc = o3ds_cloud_upload(h, tgt_xyz, tgt_normals, n_tgt, &t);
+  if (!rc) rc = o3ds_icp_point_to_plane_dev(h, s, t, nullptr, init, params, out);
+  const std::string keep = h->err;
+  (void)o3ds_cloud_free(h, s);
+  if (t) (void)o3ds_cloud_free(h, t);
+  if (rc) h->err = keep;
+  return rc;
+}
+
+
+// ---- pre-processing -----------------------------------------------------------------------------
+}  // extern "C" (helpers below are C++)
+
+namespace {
+
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void reindex_copy_kernel(const P4* __restrict__ in, size_t n, P4* __restrict__ out, size_t off, int set_index) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    P4 p = in[i];
+    if (set_index) p.i = (typename Scalar<P4>::index)(off + i);
+    out[off + i] = p;
+  }
+}
+
+// occupied cells of a grid index = cells whose start differs from the next start
+__global__ __launch_bounds__(kBlock) void count_occupied_kernel(const int* __restrict__ cs, size_t m, unsigned long long* __restrict__ out) {
+  unsigned long long c = 0;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (size_t)gridDim.x * kBlock) c += cs[i + 1] != cs[i];
+  for (int k = 32; k >= 1; k >>= 1) c += __shfl_xor(c, k, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+// first position whose key has the pass-through bit (keys sorted ascending) -> number of in-volume points
+__global__ void first_pass_kernel(const unsigned long long* __restrict__ keys, size_t n, unsigned long long* __restrict__ out) {
+  if (threadIdx.x || blockIdx.x) return;
+  size_t lo = 0, hi = n;
+  while (lo < hi) {
+    const size_t mid = (lo + hi) / 2;
+    if (keys[mid] & kPassBit)
+      hi = mid;
+    else
+      lo = mid + 1;
+  }
+  *out = lo;
+}
+
+template <typename P4>
+int crop_t(o3ds_handle h, const CloudRec& in, const CropDev& crop, CloudRec& out) {
+  out.precision = in.precision;
+  out.n = 0;
+  if (in.n == 0) return O3DS_OK;
+  int *flags = nullptr, *pos = nullptr;
+  HIP_TRY(hipMalloc(&flags, sizeof(int) * (in.n + 1)));
+  HIP_TRY(hipMalloc(&pos, sizeof(int) * (in.n + 1)));
+  HIP_TRY(hipMemsetAsync(flags + in.n, 0, sizeof(int), h->stream));
+  crop_flag_kernel<P4><<<grid_for(in.n), kBlock, 0, h->stream>>>((const P4*)in.pts, in.n, crop, flags);
+  int rc = exclusive_scan_int(h, flags, pos, in.n + 1);
+  if (rc) return rc;
+  int total = 0;
+  HIP_TRY(hipMemcpy(&total, pos + in.n, sizeof(int), hipMemcpyDeviceToHost));
+  out.n = (size_t)total;
+  if (total > 0) {
+    HIP_TRY(hipMalloc(&out.pts, sizeof(P4) * out.n));
+    if (in.nrm) HIP_TRY(hipMalloc(&out.nrm, sizeof(P4) * out.n));
+    compact_kernel<P4><<<grid_for(in.n), kBlock, 0, h->stream>>>((const P4*)in.pts, (const P4*)in.nrm, in.n, flags, pos, 1, (P4*)out.pts,
+                                                               (P4*)out.nrm);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  HIP_TRY(hipFree(flags));
+  HIP_TRY(hipFree(pos));
+  return O3DS_OK;
+}
+
+// shared by VoxelDownSample (mode 0) and voxelizeWithinCroppingVolume (mode 1)
+template <typename P4>
+int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, const CropDev& crop, CloudRec& out) {
+  out.precision = in.precision;
+  out.n = 0;
+  const size_t n = in.n;
+  if (n == 0) return O3DS_OK;
+  double ox = 0, oy = 0, oz = 0;
+  if (mode == 0) {  // [O3D] voxel_min_bound = GetMinBound() - voxel_size * 0.5
+    double mn[3], mx[3];
+    int rc = bbox_of<P4>(h, (const P4*)in.pts, n, mn, mx);
+    if (rc) return rc;
+    if (voxel * 2147483647.0 < std::max({mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]}) + voxel)
+      return fail(h, O3DS_ERR_INVALID_ARG, "[VoxelDownSample] voxel_size is too small.");
+    ox = mn[0] - voxel * 0.5;
+    oy = mn[1] - voxel * 0.5;
+    oz = mn[2] - voxel * 0.5;
+  }
+  unsigned long long *k0 = nullptr, *k1 = nullptr, *d_scalar = nullptr;
+  uint32_t *v0 = nullptr, *v1 = nullptr;
+  int *head = nullptr, *seg_id = nullptr, *seg_start = nullptr;
+  HIP_TRY(hipMalloc(&k0, sizeof(unsigned long long) * n));
+  HIP_TRY(hipMalloc(&k1, sizeof(unsigned long long) * n));
+  HIP_TRY(hipMalloc(&v0, sizeof(uint32_t) * n));
+  HIP_TRY(hipMalloc(&v1, sizeof(uint32_t) * n));
+  HIP_TRY(hipMalloc(&head, sizeof(int) * (n + 1)));
+  HIP_TRY(hipMalloc(&seg_id, sizeof(int) * (n + 1)));
+  HIP_TRY(hipMalloc(&d_scalar, sizeof(unsigned long long)));
+  voxel_key_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>((const P4*)in.pts, n, mode, ox, oy, oz, voxel, crop, k0, v0);
+  size_t temp_bytes = 0;
+  HIP_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, k0, k1, v0, v1, n, 0, 64, h->stream));
+  void* temp = nullptr;
+  HIP_TRY(hipMalloc(&temp, temp_bytes ? temp_bytes : 16));
+  HIP_TRY(rocprim::radix_sort_pairs(temp, temp_bytes, k0, k1, v0, v1, n, 0, 64, h->stream));
+  HIP_TRY(hipMemsetAsync(head + n, 0, sizeof(int), h->stream));
+  segment_head_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(k1, n, head);
+  first_pass_kernel<<<1, 64, 0, h->stream>>>(k1, n, d_scalar);
+  int rc = exclusive_scan_int(h, head, seg_id, n + 1);
+  if (rc) return rc;
+  int n_seg = 0;
+  unsigned long long n_inside = 0;
+  HIP_TRY(hipMemcpy(&n_seg, seg_id + n, sizeof(int), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&n_inside, d_scalar, sizeof(n_inside), hipMemcpyDeviceToHost));
+  const size_t n_pass = n - (size_t)n_inside;
+  HIP_TRY(hipMalloc(&seg_start, sizeof(int) * ((size_t)n_seg + 1)));
+  segment_start_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(head, seg_id, n, seg_start);
+  out.n = (size_t)n_seg;
+  HIP_TRY(hipMalloc(&out.pts, sizeof(P4) * out.n));
+  if (in.nrm) HIP_TRY(hipMalloc(&out.nrm, sizeof(P4) * out.n));
+  segment_mean_kernel<P4><<<grid_for(out.n), kBlock, 0, h->stream>>>((const P4*)in.pts, (const P4*)in.nrm, k1, v1, seg_start, out.n, n,
+                                                                    mode == 1 ? 1 : 0, n_pass, (P4*)out.pts, (P4*)out.nrm);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (void* p : {(void*)k0, (void*)k1, (void*)v0, (void*)v1, (void*)head, (void*)seg_id, (void*)seg_start, (void*)d_scalar, temp})
+    HIP_TRY(hipFree(p));
+  return O3DS_OK;
+}
+
+template <typename P4>
+int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn) {
+  if (c.n == 0) return O3DS_OK;
+  // pilot grid at radius/8 to measure the surface density, then pick the cell so that the max_nn-th neighbour
+  // typically lies inside the first 3x3x3 ring: avg points per occupied cell ~ max_nn / pi
+  CloudRec tmp;
+  tmp.n = c.n;
+  tmp.precision = c.precision;
+  tmp.pts = c.pts;  // borrowed
+  int rc = build_index_t<P4>(h, tmp, radius / 8.0);
+  if (rc) {
+    tmp.pts = nullptr;
+    free_index(tmp);
+    return rc;
+  }
+  const size_t ncell = (size_t)tmp.grid.nx * tmp.grid.ny * tmp.grid.nz;
+  unsigned long long* d_cnt = nullptr;
+  HIP_TRY(hipMalloc(&d_cnt, sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), h->stream));
+  count_occupied_kernel<<<grid_for(ncell), kBlock, 0, h->stream>>>(tmp.cell_start, ncell, d_cnt);
+  unsigned long long occ = 0;
+  HIP_TRY(hipMemcpy(&occ, d_cnt, sizeof(occ), hipMemcpyDeviceToHost));
+  HIP_TRY(hipFree(d_cnt));
+  const double avg = occ ? (double)c.n / (double)occ : 1.0;
+  double cell = tmp.grid.cell * std::sqrt(std::max(1.0, (double)max_nn) / (3.14159265358979 * avg));
+  cell = std::min(std::max(cell, radius / 64.0), radius);
+  if (std::fabs(cell - tmp.grid.cell) > 0.05 * tmp.grid.cell) {
+    rc = build_index_t<P4>(h, tmp, cell);
+    if (rc) {
+      tmp.pts = nullptr;
+      free_index(tmp);
+      return rc;
+    }
+  }
+  if (!c.nrm) HIP_TRY(hipMalloc(&c.nrm, sizeof(P4) * c.n));
+  const int rmax = std::max(1, (int)std::ceil(radius / tmp.grid.cell));
+  if (max_nn <= 32)
+    normals_kernel<P4, 32><<<grid_for(c.n), kBlock, 0, h->stream>>>((const P4*)c.pts, c.n, tmp.grid, (const P4*)tmp.spts, radius, max_nn, rmax,
+                                                                  (P4*)c.nrm);
+  else
+    normals_kernel<P4, 128><<<grid_for(c.n), kBlock, 0, h->stream>>>((const P4*)c.pts, c.n, tmp.grid, (const P4*)tmp.spts, radius, max_nn, rmax,
+                                                                   (P4*)c.nrm);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  tmp.pts = nullptr;
+  free_index(tmp);
+  free_index(c);  // the cloud's own index (if any) no longer matches its normals
+  return O3DS_OK;
+}
+
+template <typename P4>
+int transform_t(o3ds_handle h, const CloudRec& in, const double T[16], CloudRec& out) {
+  out.precision = in.precision;
+  out.n = in.n;
+  if (in.n == 0) return O3DS_OK;
+  Mat34 M;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) M.m[r * 4 + c] = T[c * 4 + r];
+  HIP_TRY(hipMalloc(&out.pts, sizeof(P4) * in.n));
+  if (in.nrm) HIP_TRY(hipMalloc(&out.nrm, sizeof(P4) * in.n));
+  transform_kernel<P4><<<grid_for(in.n), kBlock, 0, h->stream>>>((const P4*)in.pts, (const P4*)in.nrm, in.n, M, T[3], T[7], T[11], T[15],
+                                                               (P4*)out.pts, (P4*)out.nrm, 0);
+  HIP_TRY(hipGetLastError());
+  return O3DS_OK;
+}
+
+template <typename P4>
+int append_t(o3ds_handle h, CloudRec& map, const CloudRec& add) {
+  // [O3D] PointCloud::operator+= : normals survive only if (map empty or map has normals) and add has normals
+  const bool keep_nrm = (map.n == 0 || map.nrm) && add.nrm;
+  const size_t n = map.n + add.n;
+  void *np = nullptr, *nn = nullptr;
+  if (n > 0) HIP_TRY(hipMalloc(&np, sizeof(P4) * n));
+  if (keep_nrm && n > 0) HIP_TRY(hipMalloc(&nn, sizeof(P4) * n));
+  if (map.n) {
+    HIP_TRY(hipMemcpyAsync(np, map.pts, sizeof(P4) * map.n, hipMemcpyDeviceToDevice, h->stream));
+    if (keep_nrm) HIP_TRY(hipMemcpyAsync(nn, map.nrm, sizeof(P4) * map.n, hipMemcpyDeviceToDevice, h->stream));
+  }
+  if (add.n) {
+    reindex_copy_kernel<P4><<<grid_for(add.n), kBlock, 0, h->stream>>>((const P4*)add.pts, add.n, (P4*)np, map.n, 1);
+    if (keep_nrm) reindex_copy_kernel<P4><<<grid_for(add.n), kBlock, 0, h->stream>>>((const P4*)add.nrm, add.n, (P4*)nn, map.n, 0);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  free_index(map);
+  if (map.pts) HIP_TRY(hipFree(map.pts));
+  if (map.nrm) HIP_TRY(hipFree(map.nrm));
+  map.pts = np;
+  map.nrm = nn;
+  map.n = n;
+  return O3DS_OK;
+}
+
+#define DISPATCH(prec, fn, ...) ((prec) == O3DS_PRECISION_F64 ? fn<P4d>(__VA_ARGS__) : fn<P4f>(__VA_ARGS__))
+
+}  // namespace
+
+extern "C" {
+
+int o3ds_crop_cloud(o3ds_handle h, o3ds_cloud in, const o3ds_crop* crop, o3ds_cloud* out) {
+  CHECK_HANDLE(h);
+  CloudRec* c = find_cloud(h, in);
+  if (!c || !out) return fail(h, O3DS_ERR_INVALID_ARG, "crop_cloud: bad argument");
+  CloudRec o;
+  const CropDev cd = to_dev(crop);
+  int rc = DISPATCH(c->precision, crop_t, h, *c, cd, o);
+  if (rc) {
+    free_cloud(o);
+    return rc;
+  }
+  *out = add_cloud(h, std::move(o));
+  return O3DS_OK;
+}
+
+int o3ds_voxel_down_sample(o3ds_handle h, o3ds_cloud in, double voxel_size, o3ds_cloud* out) {
+  CHECK_HANDLE(h);
+  CloudRec* c = find_cloud(h, in);
+  if (!c || !out) return fail(h, O3DS_ERR_INVALID_ARG, "voxel_down_sample: bad argument");
+  CloudRec o;
+  int rc;
+  if (voxel_size <= 0.0) {  // o3d_slam::voxelize returns the cloud unchanged (helpers.cpp:108-110)
+    o.precision = c->precision;
+    rc = DISPATCH(c->precision, append_t, h, o, *c);
+  } else {
+    CropDev none{};
+    rc = DISPATCH(c->precision, voxel_reduce_t, h, *c, 0, voxel_size, none, o);
+  }
+  if (rc) {
+    free_cloud(o);
+    return rc;
+  }
+  *out = add_cloud(h, std::move(o));
+  return O3DS_OK;
+}
+
+int o3ds_estimate_normals(o3ds_handle h, o3ds_cloud id, double radius, int max_nn) {
+  CHECK_HANDLE(h);
+  CloudRec* c = find_cloud(h, id);
+  if (!c) return fail(h, O3DS_ERR_INVALID_ARG, "estimate_normals: unknown cloud id");
+  if (!(radius > 0.0)) return fail(h, O3DS_ERR_INVALID_ARG, "maxRadiusNormalEstimation_ must be > 0");  // CloudRegistration.cpp:50
+  if (max_nn <= 0) return fail(h, O3DS_ERR_INVALID_ARG, "knnNormalEstimation_ must be > 0");              // CloudRegistration.cpp:51
+  if (max_nn > 128) return fail(h, O3DS_ERR_INVALID_ARG, "estimate_normals: max_nn > 128 unsupported");
+  return DISPATCH(c->precision, normals_t, h, *c, radius, max_nn);
+}
+
+int o3ds_select_by_index(o3ds_handle h, o3ds_cloud in, const uint32_t* keep_idx, size_t m, o3ds_cloud* out) {
+  CHECK_HANDLE(h);
+  CloudRec* c = find_cloud(h, in);
+  if (!c || !out || (m && !keep_idx)) return fail(h, O3DS_ERR_INVALID_ARG, "select_by_index: bad argument");
+  for (size_t i = 0; i < m; ++i)
+    if (keep_idx[i] >= c->n) return fail(h, O3DS_ERR_INVALID_ARG, "select_by_index: index out of range");
+  CloudRec o;
+  o.precision = c->precision;
+  o.n = m;
+  if (m) {
+    uint32_t* d_idx = nullptr;
+    const size_t psz = p4_size(c->precision);
+    HIP_TRY(hipMalloc(&d_idx, sizeof(uint32_t) * m));
+    HIP_TRY(hipMemcpyAsync(d_idx, keep_idx, sizeof(uint32_t) * m, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMalloc(&o.pts, psz * m));
+    if (c->nrm) HIP_TRY(hipMalloc(&o.nrm, psz * m));
+    if (c->precision == O3DS_PRECISION_F64)
+      gather_kernel<P4d><<<grid_for(m), kBlock, 0, h->stream>>>((const P4d*)c->pts, (const P4d*)c->nrm, d_idx, m, (P4d*)o.pts, (P4d*)o.nrm);
+    else
+      gather_kernel<P4f><<<grid_for(m), kBlock, 0, h->stream>>>((const P4f*)c->pts, (const P4f*)c->nrm, d_idx, m, (P4f*)o.pts, (P4f*)o.nrm);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipFree(d_idx));
+  }
+  *out = add_cloud(h, std::move(o));
+  return O3DS_OK;
+}
+
+int o3ds_transform_cloud(o3ds_handle h, o3ds_cloud in, const double T[16], o3ds_cloud* out) {
+  CHECK_HANDLE(h);
+  CloudRec* c = find_cloud(h, in);
+  if (!c || !out || !T) return fail(h, O3DS_ERR_INVALID_ARG, "transform_cloud: bad argument");
+  CloudRec o;
+  int rc = DISPATCH(c->precision, transform_t, h, *c, T, o);
+  if (rc) {
+    free_cloud(o);
+    return rc;
+  }
+  *out = add_cloud(h, std::move(o));
+  return O3DS_OK;
+}
+
+int o3ds_cloud_append(o3ds_handle h, o3ds_cloud map, o3ds_cloud add) {
+  CHECK_HANDLE(h);
+  CloudRec* m = find_cloud(h, map);
+  CloudRec* a = find_cloud(h, add);
+  if (!m || !a || m == a) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_append: bad cloud id");
+  if (m->n && a->n && m->precision != a->precision) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_append: precision mismatch");
+  if (m->n == 0) m->precision = a->precision;
+  return DISPATCH(m->precision, append_t, h, *m, *a);
+}
+
+int o3ds_voxelize_within_volume(o3ds_handle h, o3ds_cloud map, double voxel_size, const o3ds_crop* crop) {
+  CHECK_HANDLE(h);
+  CloudRec* m = find_cloud(h, map);
+  if (!m) return fail(h, O3DS_ERR_INVALID_ARG, "voxelize_within_volume: unknown cloud id");
+  if (voxel_size <= 0.0 || m->n == 0) return O3DS_OK;  // helpers.cpp:119-123 / Submap.cpp:139: unchanged
+  CloudRec o;
+  const CropDev cd = to_dev(crop);
+  int rc = DISPATCH(m->precision, voxel_reduce_t, h, *m, 1, voxel_size, cd, o);
+  if (rc) {
+    free_cloud(o);
+    return rc;
+  }
+  free_cloud(*m);
+  *m = o;
+  return O3DS_OK;
+}
+
+int o3ds_map_insert_scan(o3ds_handle h, o3ds_cloud map, o3ds_cloud scan, const double T[16], double map_voxel_size,
+                         const o3ds_crop* map_builder_crop, double max_corr_hint) {
+  CHECK_HANDLE(h);
+  CloudRec* m = find_cloud(h, map);
+  CloudRec* s = find_cloud(h, scan);
+  if (!m || !s || !T || m == s) return fail(h, O3DS_ERR_INVALID_ARG, "map_insert_scan: bad argument");
+  if (s->n == 0) return O3DS_OK;  // Submap.cpp:41-43: empty pre-processed scan is a no-op
+  if (m->n == 0) m->precision = s->precision;
+  if (m->precision != s->precision) return fail(h, O3DS_ERR_INVALID_ARG, "map_insert_scan: precision mismatch");
+  CloudRec t;
+  int rc = DISPATCH(s->precision, transform_t, h, *s, T, t);  // Submap.cpp:54
+  if (!rc) rc = DISPATCH(m->precision, append_t, h, *m, t);   // Submap.cpp:70
+  free_cloud(t);
+  if (rc) return rc;
+  rc = o3ds_voxelize_within_volume(h, map, map_voxel_size, map_builder_crop);  // Submap.cpp:71-72
+  if (rc) return rc;
+  m = find_cloud(h, map);
+  if (max_corr_hint > 0.0) rc = build_index(h, *m, max_corr_hint / 4.0);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,485 @@
+// cloud_kernels.hpp -- device-cloud plumbing and the pre-processing / map-fusion kernels for gfx950.
+//
+//   pack/unpack          host fp64 AoS (std::vector<Eigen::Vector3d>) <-> device P4 records
+//   crop                 CroppingVolume::crop                 croppers.cpp:76-106
+//   transform            o3d_slam::transform                  helpers.cpp:273-305   ([O3D] PointCloud::Transform)
+//   voxel keys / reduce  [O3D] VoxelDownSample (helpers.cpp:107-113) and voxelizeWithinCroppingVolume (helpers.cpp:115-183)
+//   normals              [O3D] EstimateNormals(Hybrid) + NormalizeNormals + OrientNormalsTowardsCameraLocation
+//                        (CloudRegistration.cpp:49-56)
+#pragma once
+#include "common.hpp"
+#include "icp_kernels.hpp"
+
+namespace o3ds {
+
+// ---------------------------------------------------------------------------------------------- pack / unpack
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void pack_kernel(const double* __restrict__ xyz, size_t n, P4* __restrict__ out) {
+  using R = typename Scalar<P4>::type;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    P4 p;
+    p.x = (R)xyz[3 * i];
+    p.y = (R)xyz[3 * i + 1];
+    p.z = (R)xyz[3 * i + 2];
+    p.i = (typename Scalar<P4>::index)i;
+    out[i] = p;
+  }
+}
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void unpack_kernel(const P4* __restrict__ in, size_t n, double* __restrict__ xyz) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const P4 p = in[i];
+    xyz[3 * i] = (double)p.x;
+    xyz[3 * i + 1] = (double)p.y;
+    xyz[3 * i + 2] = (double)p.z;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- stream compaction
+// flags -> exclusive positions: reuse the 3-phase int scan of icp_kernels.hpp.
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void crop_flag_kernel(const P4* __restrict__ pts, size_t n, CropDev crop, int* __restrict__ flags) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const P4 p = pts[i];
+    flags[i] = crop_contains(crop, (double)p.x, (double)p.y, (double)p.z) ? 1 : 0;
+  }
+}
+// stable compaction: out[pos[i]] = in[i] where flags[i]; `want` selects flag value 1 (inside) or 0 (outside, pos = i - pos[i])
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void compact_kernel(const P4* __restrict__ pts, const P4* __restrict__ nrm, size_t n,
+                                                         const int* __restrict__ flags, const int* __restrict__ pos, int want,
+                                                         P4* __restrict__ out_pts, P4* __restrict__ out_nrm) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    if (flags[i] != want) continue;
+    const size_t o = want ? (size_t)pos[i] : i - (size_t)pos[i];
+    P4 p = pts[i];
+    p.i = (typename Scalar<P4>::index)o;
+    out_pts[o] = p;
+    if (nrm) out_nrm[o] = nrm[i];
+  }
+}
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void gather_kernel(const P4* __restrict__ pts, const P4* __restrict__ nrm, const uint32_t* __restrict__ idx,
+                                                        size_t m, P4* __restrict__ out_pts, P4* __restrict__ out_nrm) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (size_t)gridDim.x * kBlock) {
+    P4 p = pts[idx[i]];
+    p.i = (typename Scalar<P4>::index)i;
+    out_pts[i] = p;
+    if (nrm) out_nrm[i] = nrm[idx[i]];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- rigid transform
+struct Mat34 {
+  double m[12];  // row-major 3x4
+};
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void transform_kernel(const P4* __restrict__ pts, const P4* __restrict__ nrm, size_t n, Mat34 M,
+                                                            double w0, double w1, double w2, double w3, P4* __restrict__ out_pts,
+                                                            P4* __restrict__ out_nrm, size_t out_off) {
+  using R = typename Scalar<P4>::type;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const P4 p = pts[i];
+    const double x = (double)p.x, y = (double)p.y, z = (double)p.z;
+    const double w = w0 * x + w1 * y + w2 * z + w3;  // helpers.cpp:289-290: xyz / new_point(3)
+    P4 o;
+    o.x = (R)((M.m[0] * x + M.m[1] * y + M.m[2] * z + M.m[3]) / w);
+    o.y = (R)((M.m[4] * x + M.m[5] * y + M.m[6] * z + M.m[7]) / w);
+    o.z = (R)((M.m[8] * x + M.m[9] * y + M.m[10] * z + M.m[11]) / w);
+    o.i = (typename Scalar<P4>::index)(out_off + i);
+    out_pts[out_off + i] = o;
+    if (nrm) {
+      const P4 q = nrm[i];
+      const double a = (double)q.x, b = (double)q.y, c = (double)q.z;
+      P4 on;
+      on.x = (R)(M.m[0] * a + M.m[1] * b + M.m[2] * c);  // helpers.cpp:294-296: T * (n, 0)
+      on.y = (R)(M.m[4] * a + M.m[5] * b + M.m[6] * c);
+      on.z = (R)(M.m[8] * a + M.m[9] * b + M.m[10] * c);
+      on.i = 0;
+      out_nrm[out_off + i] = on;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- voxel reduction
+// Voxel keys are packed into one sortable u64: 21 bits per axis, biased by 2^20 (|k| < 2^20 voxels per axis;
+// at the 0.02 m dense-map voxel that is +-20 km).  Points outside the crop volume get a pass-through key
+// (top bit set | original index) so that one sort yields [voxelised inside points by key][pass-through in order]...
+// the reference emits pass-through first; the host-visible order is fixed up at emit time.
+constexpr unsigned long long kPassBit = 1ull << 63;
+
+__host__ __device__ __forceinline__ unsigned long long pack_key(long long kx, long long ky, long long kz) {
+  const unsigned long long bx = (unsigned long long)(kx + (1ll << 20)) & 0x1FFFFFull;
+  const unsigned long long by = (unsigned long long)(ky + (1ll << 20)) & 0x1FFFFFull;
+  const unsigned long long bz = (unsigned long long)(kz + (1ll << 20)) & 0x1FFFFFull;
+  return (bz << 42) | (by << 21) | bx;
+}
+
+// mode 0: data-anchored ([O3D] VoxelDownSample: floor((p - origin)/v));  mode 1: world-anchored (floor(p * (1/v)))
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void voxel_key_kernel(const P4* __restrict__ pts, size_t n, int mode, double ox, double oy, double oz, double v,
+                                                           CropDev crop, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const double inv = 1.0 / v;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const P4 p = pts[i];
+    const double x = (double)p.x, y = (double)p.y, z = (double)p.z;
+    unsigned long long k;
+    if (mode == 1 && !crop_contains(crop, x, y, z)) {
+      k = kPassBit | (unsigned long long)i;
+    } else if (mode == 0) {
+      k = pack_key((long long)floor((x - ox) / v), (long long)floor((y - oy) / v), (long long)floor((z - oz) / v));
+    } else {
+      k = pack_key((long long)floor(x * inv), (long long)floor(y * inv), (long long)floor(z * inv));
+    }
+    keys[i] = k;
+    vals[i] = (uint32_t)i;
+  }
+}
+
+// after sorting (key, val): head[i] = 1 where a new segment starts
+__global__ __launch_bounds__(kBlock) void segment_head_kernel(const unsigned long long* __restrict__ keys, size_t n, int* __restrict__ head) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
+    head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+}
+// seg_start[seg_id] = i for every head (seg ids from the exclusive scan of head)
+__global__ __launch_bounds__(kBlock) void segment_start_kernel(const int* __restrict__ head, const int* __restrict__ seg_id, size_t n,
+                                                               int* __restrict__ seg_start) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
+    if (head[i]) seg_start[seg_id[i]] = (int)i;
+}
+
+// one thread per output segment: mean of points / normals in ascending original-index order (vals are sorted
+// within a segment because the radix sort is stable and vals were emitted ascending) => deterministic sums.
+// renorm: re-normalise the mean normal (helpers.cpp:172); skip_nan: ignore NaN normals (helpers.cpp:35-38)
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void segment_mean_kernel(const P4* __restrict__ pts, const P4* __restrict__ nrm,
+                                                              const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                              const int* __restrict__ seg_start, size_t n_seg, size_t n, int renorm,
+                                                              size_t n_pass, P4* __restrict__ out_pts, P4* __restrict__ out_nrm) {
+  using R = typename Scalar<P4>::type;
+  for (size_t s = (size_t)blockIdx.x * kBlock + threadIdx.x; s < n_seg; s += (size_t)gridDim.x * kBlock) {
+    const size_t b = (size_t)seg_start[s], e = (s + 1 < n_seg) ? (size_t)seg_start[s + 1] : n;
+    const bool pass = (keys[b] & kPassBit) != 0;
+    // reference order: pass-through points first, voxel means after (helpers.cpp:151-181).  Sorted order has the
+    // voxel segments first (n_seg - n_pass of them), pass-through segments (one point each, by original index) last.
+    const size_t n_vox = n_seg - n_pass;
+    const size_t o = pass ? (s - n_vox) : (n_pass + s);
+    double sx = 0, sy = 0, sz = 0, nx = 0, ny = 0, nz = 0;
+    for (size_t j = b; j < e; ++j) {
+      const uint32_t id = vals[j];
+      const P4 p = pts[id];
+      sx += (double)p.x;
+      sy += (double)p.y;
+      sz += (double)p.z;
+      if (nrm) {
+        const P4 q = nrm[id];
+        const double a = (double)q.x, bb = (double)q.y, c = (double)q.z;
+        if (!renorm || !(isnan(a) || isnan(bb) || isnan(c))) {
+          nx += a;
+          ny += bb;
+          nz += c;
+        }
+      }
+    }
+    const double cnt = (double)(e - b);
+    P4 op;
+    if (pass) {
+      op = pts[vals[b]];
+    } else {
+      op.x = (R)(sx / cnt);
+      op.y = (R)(sy / cnt);
+      op.z = (R)(sz / cnt);
+    }
+    op.i = (typename Scalar<P4>::index)o;
+    out_pts[o] = op;
+    if (nrm) {
+      P4 on;
+      if (pass) {
+        on = nrm[vals[b]];
+      } else {
+        nx /= cnt;
+        ny /= cnt;
+        nz /= cnt;
+        if (renorm) {  // Eigen normalized(): unchanged when the squared norm is 0
+          const double z2 = nx * nx + ny * ny + nz * nz;
+          if (z2 > 0.0) {
+            const double inv = 1.0 / sqrt(z2);
+            nx *= inv;
+            ny *= inv;
+            nz *= inv;
+          }
+        }
+        on.x = (R)nx;
+        on.y = (R)ny;
+        on.z = (R)nz;
+      }
+      on.i = 0;
+      out_nrm[o] = on;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- normal estimation
+// k nearest within radius on the same grid index (self included), population covariance from 9 cumulants,
+// eigenvector of the smallest eigenvalue by the Geometric-Tools closed form ([O3D] FastEigen3x3).
+__host__ __device__ inline void cross3(const double a[3], const double b[3], double c[3]) {
+  c[0] = a[1] * b[2] - a[2] * b[1];
+  c[1] = a[2] * b[0] - a[0] * b[2];
+  c[2] = a[0] * b[1] - a[1] * b[0];
+}
+__host__ __device__ inline double dot3(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+__host__ __device__ inline void eigvec0(const double A[6] /* a00 a01 a02 a11 a12 a22 */, double ev, double out[3]) {
+  const double r0[3] = {A[0] - ev, A[1], A[2]}, r1[3] = {A[1], A[3] - ev, A[4]}, r2[3] = {A[2], A[4], A[5] - ev};
+  double c01[3], c02[3], c12[3];
+  cross3(r0, r1, c01);
+  cross3(r0, r2, c02);
+  cross3(r1, r2, c12);
+  const double d0 = dot3(c01, c01), d1 = dot3(c02, c02), d2 = dot3(c12, c12);
+  double dm = d0;
+  int im = 0;
+  if (d1 > dm) {
+    dm = d1;
+    im = 1;
+  }
+  if (d2 > dm) {
+    dm = d2;
+    im = 2;
+  }
+  const double s = 1.0 / sqrt(dm);
+  const double* b = im == 0 ? c01 : (im == 1 ? c02 : c12);
+  out[0] = b[0] * s;
+  out[1] = b[1] * s;
+  out[2] = b[2] * s;
+}
+
+__host__ __device__ inline void eigvec1(const double A[6], const double e0[3], double ev, double out[3]) {
+  double U[3], V[3];
+  if (fabs(e0[0]) > fabs(e0[1])) {
+    const double inv = 1.0 / sqrt(e0[0] * e0[0] + e0[2] * e0[2]);
+    U[0] = -e0[2] * inv;
+    U[1] = 0.0;
+    U[2] = e0[0] * inv;
+  } else {
+    const double inv = 1.0 / sqrt(e0[1] * e0[1] + e0[2] * e0[2]);
+    U[0] = 0.0;
+    U[1] = e0[2] * inv;
+    U[2] = -e0[1] * inv;
+  }
+  cross3(e0, U, V);
+  const double AU[3] = {A[0] * U[0] + A[1] * U[1] + A[2] * U[2], A[1] * U[0] + A[3] * U[1] + A[4] * U[2],
+                        A[2] * U[0] + A[4] * U[1] + A[5] * U[2]};
+  const double AV[3] = {A[0] * V[0] + A[1] * V[1] + A[2] * V[2], A[1] * V[0] + A[3] * V[1] + A[4] * V[2],
+                        A[2] * V[0] + A[4] * V[1] + A[5] * V[2]};
+  double m00 = dot3(U, AU) - ev, m01 = dot3(U, AV), m11 = dot3(V, AV) - ev;
+  const double a00 = fabs(m00), a01 = fabs(m01), a11 = fabs(m11);
+  if (a00 >= a11) {
+    if (fmax(a00, a01) > 0.0) {
+      if (a00 >= a01) {
+        m01 /= m00;
+        m00 = 1.0 / sqrt(1.0 + m01 * m01);
+        m01 *= m00;
+      } else {
+        m00 /= m01;
+        m01 = 1.0 / sqrt(1.0 + m00 * m00);
+        m00 *= m01;
+      }
+      for (int i = 0; i < 3; ++i) out[i] = m01 * U[i] - m00 * V[i];
+    } else {
+      for (int i = 0; i < 3; ++i) out[i] = U[i];
+    }
+  } else {
+    if (fmax(a11, a01) > 0.0) {
+      if (a11 >= a01) {
+        m01 /= m11;
+        m11 = 1.0 / sqrt(1.0 + m01 * m01);
+        m01 *= m11;
+      } else {
+        m11 /= m01;
+        m01 = 1.0 / sqrt(1.0 + m11 * m11);
+        m11 *= m01;
+      }
+      for (int i = 0; i < 3; ++i) out[i] = m11 * U[i] - m01 * V[i];
+    } else {
+      for (int i = 0; i < 3; ++i) out[i] = U[i];
+    }
+  }
+}
+
+// cov = {c00 c01 c02 c11 c12 c22}; returns the (unnormalised-sign) eigenvector of the smallest eigenvalue
+__host__ __device__ inline void fast_eigen3x3_min(const double cov[6], double out[3]) {
+  double mc = cov[0];
+  for (int i = 1; i < 6; ++i) mc = cov[i] > mc ? cov[i] : mc;
+  if (mc == 0.0) {
+    out[0] = out[1] = out[2] = 0.0;
+    return;
+  }
+  double A[6];
+  for (int i = 0; i < 6; ++i) A[i] = cov[i] / mc;
+  const double norm = A[1] * A[1] + A[2] * A[2] + A[4] * A[4];
+  if (norm > 0.0) {
+    const double q = (A[0] + A[3] + A[5]) / 3.0;
+    const double b00 = A[0] - q, b11 = A[3] - q, b22 = A[5] - q;
+    const double p = sqrt((b00 * b00 + b11 * b11 + b22 * b22 + norm * 2.0) / 6.0);
+    const double c00 = b11 * b22 - A[4] * A[4];
+    const double c01 = A[1] * b22 - A[4] * A[2];
+    const double c02 = A[1] * A[4] - b11 * A[2];
+    const double det = (b00 * c00 - A[1] * c01 + A[2] * c02) / (p * p * p);
+    double half_det = det * 0.5;
+    half_det = fmin(fmax(half_det, -1.0), 1.0);
+    const double angle = acos(half_det) / 3.0;
+    const double two_thirds_pi = 2.09439510239319549;
+    const double beta2 = cos(angle) * 2.0;
+    const double beta0 = cos(angle + two_thirds_pi) * 2.0;
+    const double beta1 = -(beta0 + beta2);
+    const double e0 = q + p * beta0, e1 = q + p * beta1, e2 = q + p * beta2;
+    double v0[3], v1[3], v2[3];
+    if (half_det >= 0.0) {
+      eigvec0(A, e2, v2);
+      if (e2 < e0 && e2 < e1) {
+        out[0] = v2[0], out[1] = v2[1], out[2] = v2[2];
+        return;
+      }
+      eigvec1(A, v2, e1, v1);
+      if (e1 < e0 && e1 < e2) {
+        out[0] = v1[0], out[1] = v1[1], out[2] = v1[2];
+        return;
+      }
+      cross3(v1, v2, out);
+    } else {
+      eigvec0(A, e0, v0);
+      if (e0 < e1 && e0 < e2) {
+        out[0] = v0[0], out[1] = v0[1], out[2] = v0[2];
+        return;
+      }
+      eigvec1(A, v0, e1, v1);
+      if (e1 < e0 && e1 < e2) {
+        out[0] = v1[0], out[1] = v1[1], out[2] = v1[2];
+        return;
+      }
+      cross3(v0, v1, out);
+    }
+  } else {
+    if (cov[0] < cov[3] && cov[0] < cov[5]) {
+      out[0] = 1, out[1] = 0, out[2] = 0;
+    } else if (cov[3] < cov[0] && cov[3] < cov[5]) {
+      out[0] = 0, out[1] = 1, out[2] = 0;
+    } else {
+      out[0] = 0, out[1] = 0, out[2] = 1;
+    }
+  }
+}
+
+constexpr int kMaxKnn = 32;  // per-lane k-best list kept in registers/scratch; larger max_nn handled by the slow path
+
+// One thread per point.  The grid index is over the cloud itself (cell = radius / rings).
+template <typename P4, int KMAX>
+__global__ __launch_bounds__(kBlock) void normals_kernel(const P4* __restrict__ pts /* original order */, size_t n, GridDev g,
+                                                         const P4* __restrict__ sp /* sorted */, double radius, int max_nn, int rmax_cells,
+                                                         P4* __restrict__ out_nrm) {
+  using R = typename Scalar<P4>::type;
+  const int* __restrict__ cs = g.cell_start;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const P4 q = pts[i];
+    const R qx = q.x, qy = q.y, qz = q.z;
+    R bd[KMAX];
+    int bp[KMAX];
+    int cnt = 0;
+    R worst = (R)(radius * radius);  // candidates need d2 < worst
+    const double fx = ((double)qx - g.ox) * g.inv_cell, fy = ((double)qy - g.oy) * g.inv_cell, fz = ((double)qz - g.oz) * g.inv_cell;
+    const int ix = (int)floor(fx), iy = (int)floor(fy), iz = (int)floor(fz);
+    double mf = fmin(fx - floor(fx), 1.0 - (fx - floor(fx)));
+    mf = fmin(mf, fmin(fy - floor(fy), 1.0 - (fy - floor(fy))));
+    mf = fmin(mf, fmin(fz - floor(fz), 1.0 - (fz - floor(fz))));
+    for (int ring = 0; ring <= rmax_cells; ++ring) {
+      if (ring >= 1) {
+        const double lb = g.cell * ((double)(ring - 1) + mf) * (1.0 - 1e-6);
+        if ((double)worst <= lb * lb) break;  // k-th best (or r^2) already inside the searched block
+      }
+      for (int dz = -ring; dz <= ring; ++dz) {
+        const int z = iz + dz;
+        if ((unsigned)z >= (unsigned)g.nz) continue;
+        for (int dy = -ring; dy <= ring; ++dy) {
+          const int y = iy + dy;
+          if ((unsigned)y >= (unsigned)g.ny) continue;
+          const int row = (z * g.ny + y) * g.nx;
+          const bool shell = (dz == -ring || dz == ring || dy == -ring || dy == ring);
+          int segs = shell ? 1 : (ring == 0 ? 1 : 2);
+          for (int sgi = 0; sgi < segs; ++sgi) {
+            int x0, x1;
+            if (shell || ring == 0) {
+              x0 = max(ix - ring, 0);
+              x1 = min(ix + ring, g.nx - 1);
+            } else {
+              x0 = x1 = (sgi == 0) ? ix - ring : ix + ring;
+              if ((unsigned)x0 >= (unsigned)g.nx) continue;
+            }
+            if (x0 > x1) continue;
+            const int s = cs[row + x0], e = cs[row + x1 + 1];
+            for (int p = s; p < e; ++p) {
+              const P4 t = sp[p];
+              const R dx = t.x - qx, dy2 = t.y - qy, dz2 = t.z - qz;
+              const R d2 = dx * dx + dy2 * dy2 + dz2 * dz2;
+              if (d2 < worst) {
+                int pos = cnt < max_nn ? cnt : max_nn - 1;
+                while (pos > 0 && bd[pos - 1] > d2) {
+                  bd[pos] = bd[pos - 1];
+                  bp[pos] = bp[pos - 1];
+                  --pos;
+                }
+                bd[pos] = d2;
+                bp[pos] = p;
+                if (cnt < max_nn) ++cnt;
+                if (cnt == max_nn) worst = bd[max_nn - 1];
+              }
+            }
+          }
+        }
+      }
+    }
+    double cov[6] = {1, 0, 0, 1, 0, 1};
+    if (cnt >= 3) {
+      double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (int j = 0; j < cnt; ++j) {
+        const P4 t = sp[bp[j]];
+        const double x = (double)t.x, y = (double)t.y, z = (double)t.z;
+        c[0] += x;
+        c[1] += y;
+        c[2] += z;
+        c[3] += x * x;
+        c[4] += x * y;
+        c[5] += x * z;
+        c[6] += y * y;
+        c[7] += y * z;
+        c[8] += z * z;
+      }
+      const double inv = 1.0 / (double)cnt;
+      for (int j = 0; j < 9; ++j) c[j] *= inv;
+      cov[0] = c[3] - c[0] * c[0];
+      cov[1] = c[4] - c[0] * c[1];
+      cov[2] = c[5] - c[0] * c[2];
+      cov[3] = c[6] - c[1] * c[1];
+      cov[4] = c[7] - c[1] * c[2];
+      cov[5] = c[8] - c[2] * c[2];
+    }
+    double nv[3];
+    fast_eigen3x3_min(cov, nv);
+    double nn = sqrt(dot3(nv, nv));
+    if (nn == 0.0) {
+      nv[0] = 0, nv[1] = 0, nv[2] = 1;
+      nn = 1.0;
+    }
+    nv[0] /= nn, nv[1] /= nn, nv[2] /= nn;
+    if (isnan(nv[0])) nv[0] = 0, nv[1] = 0, nv[2] = 1;
+    // OrientNormalsTowardsCameraLocation(0,0,0): flip when n . (0 - p) < 0
+    if (nv[0] * -(double)qx + nv[1] * -(double)qy + nv[2] * -(double)qz < 0.0) nv[0] = -nv[0], nv[1] = -nv[1], nv[2] = -nv[2];
+    P4 o;
+    o.x = (R)nv[0];
+    o.y = (R)nv[1];
+    o.z = (R)nv[2];
+    o.i = 0;
+    out_nrm[i] = o;
+  }
+}
+
+}  // namespace o3ds

@@ -1,0 +1,112 @@
+// common.hpp -- shared device/host types of the gfx950 backend (no torch, no Eigen).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/o3ds_backend.h"
+
+namespace o3ds {
+
+// Device point records.  xyz + the point's index in its source cloud, one aligned vector load each
+// (16 B for f32 storage, 32 B for f64 storage).
+struct alignas(16) P4f {
+  float x, y, z;
+  int32_t i;
+};
+struct alignas(32) P4d {
+  double x, y, z;
+  int64_t i;
+};
+
+template <typename P4>
+struct Scalar;
+template <>
+struct Scalar<P4f> {
+  using type = float;
+  using index = int32_t;
+};
+template <>
+struct Scalar<P4d> {
+  using type = double;
+  using index = int64_t;
+};
+
+// Cropping volume in device form (croppers.cpp:121-165).  Radii are compared squared.
+struct CropDev {
+  int kind;    // o3ds_crop_kind
+  int invert;
+  double cx, cy, cz;
+  double rmin, rmax;  // NOT squared (predicate uses sqrt like the reference for boundary fidelity)
+  double zmin, zmax;
+};
+
+__host__ __device__ inline bool crop_contains(const CropDev& c, double x, double y, double z) {
+  bool in = true;
+  const double dx = x - c.cx, dy = y - c.cy, dz = z - c.cz;
+  switch (c.kind) {
+    case O3DS_CROP_MAX_RADIUS:
+      in = sqrt(dx * dx + dy * dy + dz * dz) <= c.rmax;
+      break;
+    case O3DS_CROP_MIN_RADIUS:
+      in = sqrt(dx * dx + dy * dy + dz * dz) >= c.rmin;
+      break;
+    case O3DS_CROP_MIN_MAX_RADIUS: {
+      const double d = sqrt(dx * dx + dy * dy + dz * dz);
+      in = d <= c.rmax && d >= c.rmin;
+      break;
+    }
+    case O3DS_CROP_CYLINDER:
+      in = z >= c.zmin && z <= c.zmax && sqrt(dx * dx + dy * dy) <= c.rmax;
+      break;
+    default:
+      return true;  // O3DS_CROP_NONE: no volume, invert ignored
+  }
+  return c.invert ? !in : in;
+}
+
+inline CropDev to_dev(const o3ds_crop* c) {
+  CropDev d{};
+  if (!c) {
+    d.kind = O3DS_CROP_NONE;
+    return d;
+  }
+  d.kind = c->kind;
+  d.invert = c->invert;
+  d.cx = c->center[0];
+  d.cy = c->center[1];
+  d.cz = c->center[2];
+  d.rmin = c->rmin;
+  d.rmax = c->rmax;
+  d.zmin = c->zmin;
+  d.zmax = c->zmax;
+  return d;
+}
+
+// Uniform grid over the target's bounding box; points are stored sorted by linear cell id
+// (x fastest), so the cells x0..x1 of one (y,z) row are ONE contiguous range of the sorted array:
+// [cell_start[row+x0], cell_start[row+x1+1]).
+struct GridDev {
+  double ox, oy, oz;  // min corner
+  double cell;        // edge length
+  double inv_cell;
+  int nx, ny, nz;
+  const int* cell_start;  // nx*ny*nz + 1 entries (exclusive scan of per-cell counts)
+};
+
+// The 32-double normal-equation record (see include/o3ds_backend.h, o3ds_icp_accumulate).
+constexpr int kRec = 32;
+constexpr int kRecR2 = 27, kRecCount = 28, kRecD2 = 29;
+
+// Device-side ICP loop state ([O3D] RegistrationICP locals).
+struct IcpStateDev {
+  double T[16];  // column-major current transformation
+  double fitness, rmse;
+  unsigned long long n_corr;
+  int pass;        // correspondence passes evaluated
+  int iterations;  // updates applied
+  int done;
+  int converged;
+};
+
+}  // namespace o3ds

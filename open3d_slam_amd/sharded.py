@@ -1,0 +1,93 @@
+"""Multi-GPU scan-to-map registration: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI)
+carrying ONE 32-double all-reduce per ICP iteration -- the only exchange step the path has.
+
+Two partitionings, both expressed through the step-wise C-ABI (o3ds_icp_begin/accumulate/update/finish):
+
+* "source"  : every rank holds the same target (+index); rank r accumulates source points
+              [r*n/W, (r+1)*n/W).  Sum of the records == the single-GPU record, so the result is the
+              single-GPU registration (up to fp64 reassociation of the W-way sum).
+* "submap"  : every rank holds ITS OWN target submap and the whole source; the summed record is the joint
+              point-to-plane problem over all submaps (north_star: "RCCL all-reduce of the per-submap 6x6
+              normal equations").  Fitness is the mean per-submap fitness (n_src_total = W * n).
+
+All ranks apply the identical update to identical state, so no broadcast is needed.
+The reference has no multi-device code at all; this is a new design, not a translation.
+"""
+from __future__ import annotations
+
+from typing import Callable
+
+
+def shard_range(n: int, rank: int, world: int):
+    """Contiguous, balanced split of n source points: returns (first, count)."""
+    base, rem = divmod(n, world)
+    first = rank * base + min(rank, rem)
+    return first, base + (1 if rank < rem else 0)
+
+
+def run_sharded_loop(accumulate: Callable[[], object], all_reduce: Callable[[object], None], update: Callable[[object], None],
+                     is_done: Callable[[], bool], max_iteration: int, check_every: int = 4) -> int:
+    """[O3D] RegistrationICP loop with the reduction distributed: max_iteration updates need max_iteration+1
+    correspondence passes; the device decides termination (convergence test inside update), the host only polls
+    `is_done` every `check_every` passes so that no per-iteration host sync is needed.  Returns passes issued."""
+    passes = 0
+    total = max_iteration + 1
+    while passes < total:
+        rec = accumulate()
+        all_reduce(rec)
+        update(rec)
+        passes += 1
+        if passes < total and passes % check_every == 0 and is_done():
+            break
+    return passes
+
+
+class ShardedIcp:
+    """GPU driver of run_sharded_loop over a Backend handle and a torch.distributed process group."""
+
+    def __init__(self, be, mode: str = "source", group=None):
+        import torch
+        import torch.distributed as dist
+
+        assert mode in ("source", "submap")
+        self.be, self.mode, self.group = be, mode, group
+        self.dist, self.torch = dist, torch
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        dev = torch.device(f"cuda:{be.device_id}")
+        # a dedicated torch stream shared by the backend's kernels and the collective: accumulate -> all_reduce ->
+        # update are stream-ordered, no host sync per iteration (torch's default stream has handle 0 == "NULL = own
+        # stream" in o3ds_set_stream, hence an explicit side stream)
+        self.tstream = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(self.tstream):
+            self.rec = torch.zeros(32, dtype=torch.float64, device=dev)
+        self.tstream.synchronize()
+        be.set_stream(self.tstream.cuda_stream)
+
+    def register(self, source: int, target: int, n_src: int, max_corr: float, init=None, max_iter: int = 30,
+                 rel_fitness: float = 1e-6, rel_rmse: float = 1e-6, target_crop=None, check_every: int = 4) -> dict:
+        be, dist = self.be, self.dist
+        if self.mode == "source":
+            first, count = shard_range(n_src, self.rank, self.world)
+            n_total = n_src
+        else:
+            first, count = 0, n_src
+            n_total = n_src * self.world
+        be.icp_begin(source, target, max_corr, init=init, max_iter=max_iter, rel_fitness=rel_fitness, rel_rmse=rel_rmse,
+                     target_crop=target_crop)
+        ptr = self.rec.data_ptr()
+
+        def accumulate():
+            be.icp_accumulate(first, count, ptr)
+            return self.rec
+
+        def all_reduce(rec):
+            if self.world > 1:
+                dist.all_reduce(rec, op=dist.ReduceOp.SUM, group=self.group)
+
+        def update(rec):
+            be.icp_update(ptr, n_total)
+
+        with self.torch.cuda.stream(self.tstream):
+            run_sharded_loop(accumulate, all_reduce, update, be.icp_done, max_iter, check_every)
+            return be.icp_finish()

@@ -1,0 +1,74 @@
+"""C-ABI checks that need no GPU: the library loads, exports every symbol include/o3ds_backend.h
+declares, and reports errors through status codes (no compute calls)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from open3d_slam_amd import backend
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "o3ds_backend.h")
+
+
+def _declared():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(o3ds_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_all_exported_and_bound():
+    names = _declared()
+    assert len(names) >= 25
+    lib = backend.load()
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in o3ds_backend.h but not exported"
+    assert sorted(backend.SIGNATURES) == names, set(names) ^ set(backend.SIGNATURES)
+
+
+def test_header_is_plain_c():
+    import subprocess
+    import tempfile
+
+    with tempfile.NamedTemporaryFile("w", suffix=".c", delete=False) as f:
+        f.write(f'#include "{HEADER}"\nint main(void){{ o3ds_icp_params p; p.max_iteration = 1; return sizeof(o3ds_icp_result) == 160 ? p.max_iteration - 1 : 1; }}\n')
+    exe = f.name + ".out"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-o", exe, f.name])
+    assert subprocess.call([exe]) == 0
+    os.unlink(f.name)
+    os.unlink(exe)
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(backend.IcpResult) == 16 * 8 + 8 + 8 + 4 + 4 + 8
+    assert C.sizeof(backend.IcpParams) == 8 + 4 + 4 + 8 + 8
+    assert C.sizeof(backend.Crop) == 4 + 4 + 24 + 16 + 16
+
+
+def test_null_handle_is_rejected_without_gpu():
+    lib = backend.load()
+    assert lib.o3ds_synchronize(None) == backend.ERR_BAD_HANDLE
+    assert lib.o3ds_cloud_free(None, 1) == backend.ERR_BAD_HANDLE
+    assert b"null handle" in lib.o3ds_last_error(None)
+    assert b"gfx950" in lib.o3ds_version()
+
+
+def test_create_fails_loudly_without_device():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(backend.BackendError) as e:
+        backend.Backend(0)
+    assert e.value.code == backend.ERR_HIP
+
+
+def test_no_product_import_of_oracle():
+    """The product package must never import/call the oracle (tier rule 3)."""
+    pkg = os.path.join(ROOT, "open3d_slam_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "pyoracle" not in txt and "np_oracle" not in txt and "o3d_oracle" not in txt, os.path.join(dp, f)

@@ -1,0 +1,239 @@
+"""HIP point-to-plane ICP vs the CPU oracle, through the C-ABI (needs an MI355X)."""
+import os
+
+import numpy as np
+import pytest
+
+from open3d_slam_amd import backend, synthetic as syn
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+# SURVEY 8c stated tolerances (same fixed number of iterations, same init, same clouds)
+TOL_T, TOL_R = 1e-3, 1e-3          # f32 point storage, f64 accumulation
+TOL_T64, TOL_R64 = 1e-6, 1e-6      # f64 point storage
+
+
+def _check(got, ref, n_src, tol_t, tol_r):
+    dt, dr = syn.se3_error(got["transformation"], ref["transformation"])
+    assert dt <= tol_t and dr <= tol_r, (dt, dr)
+    assert abs(got["fitness"] - ref["fitness"]) <= 4.0 / n_src
+    assert abs(got["inlier_rmse"] - ref["inlier_rmse"]) <= 1e-3 * max(ref["inlier_rmse"], 1e-9)
+    return dt, dr
+
+
+def test_small_fixed_iterations_f32(backend_f32, oracle, small_c2):
+    src, tgt, nrm, _ = small_c2
+    got = backend_f32.icp_point_to_plane(src, tgt, nrm, 1.0, max_iter=10, rel_fitness=0.0, rel_rmse=0.0)
+    ref = oracle.icp_point_to_plane(src, tgt, nrm, 1.0, max_iter=10, rel_fitness=0.0, rel_rmse=0.0)
+    assert got["iterations"] == 10 and not got["converged"]
+    dt, dr = _check(got, ref, len(src), TOL_T, TOL_R)
+    print("f32 small:", dt, dr)
+
+
+def test_small_fixed_iterations_f64(backend_f64, oracle, small_c2):
+    src, tgt, nrm, _ = small_c2
+    got = backend_f64.icp_point_to_plane(src, tgt, nrm, 1.0, max_iter=10, rel_fitness=0.0, rel_rmse=0.0)
+    ref = oracle.icp_point_to_plane(src, tgt, nrm, 1.0, max_iter=10, rel_fitness=0.0, rel_rmse=0.0)
+    dt, dr = _check(got, ref, len(src), TOL_T64, TOL_R64)
+    assert got["n_corr"] == ref["n_corr"]
+    assert abs(got["fitness"] - ref["fitness"]) < 1e-12
+    print("f64 small:", dt, dr)
+
+
+def test_every_iteration_count_matches(backend_f64, oracle, small_c2):
+    """k = 0..6 fixed iterations: the whole trajectory of poses matches, not only the end point."""
+    src, tgt, nrm, _ = small_c2
+    tree = oracle.KDTree(tgt)
+    s = backend_f64.upload(src)
+    t = backend_f64.upload(tgt, nrm)
+    backend_f64.build_index(t, 1.0)
+    for k in range(0, 7):
+        got = backend_f64.icp_point_to_plane_dev(s, t, 1.0, max_iter=k, rel_fitness=0.0, rel_rmse=0.0)
+        ref = oracle.icp_point_to_plane(src, tgt, nrm, 1.0, max_iter=k, rel_fitness=0.0, rel_rmse=0.0, tree=tree)
+        assert got["iterations"] == k
+        _check(got, ref, len(src), TOL_T64, TOL_R64)
+    backend_f64.free(s)
+    backend_f64.free(t)
+
+
+def test_convergence_criteria_default(backend_f64, backend_f32, oracle, small_c2):
+    src, tgt, nrm, _ = small_c2
+    ref = oracle.icp_point_to_plane(src, tgt, nrm, 1.0, max_iter=30)
+    got = backend_f64.icp_point_to_plane(src, tgt, nrm, 1.0, max_iter=30)
+    assert ref["converged"] and got["converged"]
+    assert got["iterations"] == ref["iterations"]
+    _check(got, ref, len(src), TOL_T64, TOL_R64)
+    got32 = backend_f32.icp_point_to_plane(src, tgt, nrm, 1.0, max_iter=30)
+    assert got32["converged"] and abs(got32["iterations"] - ref["iterations"]) <= 1  # 1e-6 thresholds vs f32 quantisation
+    _check(got32, ref, len(src), TOL_T, TOL_R)
+
+
+def test_non_identity_init_and_cell_sizes(backend_f32, oracle, small_c2):
+    src, tgt, nrm, _ = small_c2
+    T0 = syn.make_pose([0.2, -0.1, 0.02], [0.2, 0.1, 1.0])
+    ref = oracle.icp_point_to_plane(src, tgt, nrm, 0.7, init=T0, max_iter=6, rel_fitness=0.0, rel_rmse=0.0)
+    s = backend_f32.upload(src)
+    t = backend_f32.upload(tgt, nrm)
+    res = []
+    for cell in (0.05, 0.175, 0.4, 1.3):  # the NN search is exact for any cell size
+        backend_f32.build_index(t, 0.7, cell)
+        got = backend_f32.icp_point_to_plane_dev(s, t, 0.7, init=T0, max_iter=6, rel_fitness=0.0, rel_rmse=0.0)
+        _check(got, ref, len(src), TOL_T, TOL_R)
+        res.append(got)
+    for r in res[1:]:  # identical correspondences => identical sums up to nothing: bitwise equal results
+        np.testing.assert_array_equal(r["transformation"], res[0]["transformation"])
+        assert r["n_corr"] == res[0]["n_corr"]
+    backend_f32.free(s)
+    backend_f32.free(t)
+
+
+def test_deterministic_bitwise(backend_f32, small_c2):
+    src, tgt, nrm, _ = small_c2
+    a = backend_f32.icp_point_to_plane(src, tgt, nrm, 1.0, max_iter=8, rel_fitness=0.0, rel_rmse=0.0)
+    b = backend_f32.icp_point_to_plane(src, tgt, nrm, 1.0, max_iter=8, rel_fitness=0.0, rel_rmse=0.0)
+    np.testing.assert_array_equal(a["transformation"], b["transformation"])
+    assert a["inlier_rmse"] == b["inlier_rmse"] and a["fitness"] == b["fitness"]
+
+
+def test_fused_map_crop_equals_cropped_target(backend_f64, oracle, small_c2):
+    """scanMatcherCropper_->crop(map) (ScanToMapRegistration.cpp:58-59) fused into the search == ICP on the cropped copy."""
+    src, tgt, nrm, _ = small_c2
+    crop_o = oracle.make_crop(oracle.CROP_MAX_RADIUS, center=(1.0, -2.0, 0.0), rmax=20.0)
+    keep = oracle.crop_indices(tgt, crop_o)
+    assert 0 < len(keep) < len(tgt)
+    ref = oracle.icp_point_to_plane(src, tgt[keep], nrm[keep], 1.0, max_iter=5, rel_fitness=0.0, rel_rmse=0.0)
+    s = backend_f64.upload(src)
+    t = backend_f64.upload(tgt, nrm)
+    crop = backend.make_crop(backend.CROP_MAX_RADIUS, center=(1.0, -2.0, 0.0), rmax=20.0)
+    got = backend_f64.icp_point_to_plane_dev(s, t, 1.0, max_iter=5, rel_fitness=0.0, rel_rmse=0.0, target_crop=crop)
+    _check(got, ref, len(src), TOL_T64, TOL_R64)
+    assert got["n_corr"] == ref["n_corr"]
+    backend_f64.free(s)
+    backend_f64.free(t)
+
+
+def test_stepwise_equals_oneshot(backend_f32, small_c2):
+    import torch
+
+    src, tgt, nrm, _ = small_c2
+    s = backend_f32.upload(src)
+    t = backend_f32.upload(tgt, nrm)
+    backend_f32.build_index(t, 1.0)
+    one = backend_f32.icp_point_to_plane_dev(s, t, 1.0, max_iter=6, rel_fitness=0.0, rel_rmse=0.0)
+    rec = torch.zeros(32, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    backend_f32.icp_begin(s, t, 1.0, max_iter=6, rel_fitness=0.0, rel_rmse=0.0)
+    for _ in range(7):
+        backend_f32.icp_accumulate(0, len(src), rec.data_ptr())
+        backend_f32.icp_update(rec.data_ptr(), len(src))
+    assert backend_f32.icp_done()
+    step = backend_f32.icp_finish()
+    np.testing.assert_array_equal(step["transformation"], one["transformation"])
+    assert step["iterations"] == 6 and step["fitness"] == one["fitness"]
+    # two shards summed by the caller == one shard (up to fp reassociation of the 2-way split)
+    rec2 = torch.zeros(32, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    backend_f32.icp_begin(s, t, 1.0, max_iter=6, rel_fitness=0.0, rel_rmse=0.0)
+    h = len(src) // 2
+    for _ in range(7):
+        backend_f32.icp_accumulate(0, h, rec.data_ptr())
+        backend_f32.icp_accumulate(h, len(src) - h, rec2.data_ptr())
+        backend_f32.synchronize()
+        tot = rec + rec2
+        torch.cuda.synchronize()
+        backend_f32.icp_update(tot.data_ptr(), len(src))
+        backend_f32.synchronize()
+    two = backend_f32.icp_finish()
+    np.testing.assert_allclose(two["transformation"], one["transformation"], atol=1e-10)
+    assert two["n_corr"] == one["n_corr"]
+    backend_f32.free(s)
+    backend_f32.free(t)
+
+
+def test_error_conventions(backend_f32, small_c2):
+    src, tgt, nrm, _ = small_c2
+    with pytest.raises(backend.BackendError) as e:
+        backend_f32.icp_point_to_plane(src, tgt, nrm, 0.0)
+    assert e.value.code == backend.ERR_INVALID_ARG and "max_correspondence_distance" in str(e.value)
+    with pytest.raises(backend.BackendError) as e:
+        backend_f32.icp_point_to_plane(src, tgt, None, 1.0)
+    assert e.value.code == backend.ERR_NO_NORMALS
+    with pytest.raises(backend.BackendError) as e:
+        backend_f32.icp_point_to_plane(src, np.zeros((0, 3)), np.zeros((0, 3)), 1.0)
+    assert e.value.code == backend.ERR_EMPTY
+    with pytest.raises(backend.BackendError):
+        backend_f32.free(123456)
+
+
+def test_no_correspondences_and_empty_source(backend_f32, oracle, small_c2):
+    src, tgt, nrm, _ = small_c2
+    far = src + 1000.0
+    T0 = syn.make_pose([0.1, 0, 0], [0, 0, 0.3])
+    got = backend_f32.icp_point_to_plane(far, tgt, nrm, 1.0, init=T0, max_iter=5)
+    ref = oracle.icp_point_to_plane(far, tgt, nrm, 1.0, init=T0, max_iter=5)
+    assert got["fitness"] == 0.0 and got["inlier_rmse"] == 0.0 and got["n_corr"] == 0
+    np.testing.assert_allclose(got["transformation"], T0, atol=1e-15)  # identity updates only
+    assert got["iterations"] == ref["iterations"] == 1 and got["converged"] and ref["converged"]
+    got = backend_f32.icp_point_to_plane(np.zeros((0, 3)), tgt, nrm, 1.0, max_iter=3)
+    assert got["fitness"] == 0.0 and got["n_corr"] == 0
+
+
+def test_ragged_sizes(backend_f64, oracle):
+    """Sizes that are not multiples of the wavefront/workgroup; targets smaller than one cell row."""
+    scene = syn.make_scene()
+    tgt, nrm = syn.sample_map(scene, 30_011)
+    for n_az in (1, 3, 37):
+        src = syn.vlp16_scan(scene, syn.ground_truth_pose(), n_az=n_az)
+        got = backend_f64.icp_point_to_plane(src, tgt, nrm, 1.5, max_iter=4, rel_fitness=0.0, rel_rmse=0.0)
+        ref = oracle.icp_point_to_plane(src, tgt, nrm, 1.5, max_iter=4, rel_fitness=0.0, rel_rmse=0.0)
+        assert got["n_corr"] == ref["n_corr"]
+        _check(got, ref, len(src), 1e-5, 1e-5)  # few points => ill-conditioned, still tight in f64
+    tiny_t, tiny_n = tgt[:7], nrm[:7]
+    got = backend_f64.icp_point_to_plane(tgt[:50], tiny_t, tiny_n, 5.0, max_iter=1, rel_fitness=0.0, rel_rmse=0.0)
+    ref = oracle.icp_point_to_plane(tgt[:50], tiny_t, tiny_n, 5.0, max_iter=1, rel_fitness=0.0, rel_rmse=0.0)
+    assert got["n_corr"] == ref["n_corr"] and abs(got["inlier_rmse"] - ref["inlier_rmse"]) < 1e-9
+
+
+def test_golden_fixture(backend_f64, backend_f32):
+    g = np.load(os.path.join(GOLD, "icp_scan_to_map.npz"))
+    src, tgt, nrm, _ = syn.config2_inputs(n_map=int(g["n_map"]), n_az=int(g["n_az"]))
+    got = backend_f64.icp_point_to_plane(src, tgt, nrm, float(g["max_corr"]), max_iter=10, rel_fitness=0.0, rel_rmse=0.0)
+    dt, dr = syn.se3_error(got["transformation"], g["T10"])
+    assert dt < TOL_T64 and dr < TOL_R64
+    assert abs(got["fitness"] - float(g["fitness10"])) < 1e-12
+    got = backend_f64.icp_point_to_plane(src, tgt, nrm, float(g["max_corr"]), max_iter=30)
+    assert got["iterations"] == int(g["iters_conv"])
+    got = backend_f32.icp_point_to_plane(src, tgt, nrm, float(g["max_corr"]), max_iter=10, rel_fitness=0.0, rel_rmse=0.0)
+    dt, dr = syn.se3_error(got["transformation"], g["T10"])
+    assert dt < TOL_T and dr < TOL_R
+
+
+def test_full_size_config2(backend_f32, oracle):
+    """BASELINE.json configs[1]: 65 536-pt scan vs 1 000 000-pt map, 10 iterations, vs the oracle + ground truth."""
+    src, tgt, nrm, T_gt = syn.config2_inputs()
+    assert len(src) == 65536 and len(tgt) == 1_000_000
+    got = backend_f32.icp_point_to_plane(src, tgt, nrm, 1.0, max_iter=10, rel_fitness=0.0, rel_rmse=0.0)
+    ref = oracle.icp_point_to_plane(src, tgt, nrm, 1.0, max_iter=10, rel_fitness=0.0, rel_rmse=0.0)
+    dt, dr = _check(got, ref, len(src), TOL_T, TOL_R)
+    gt_t, gt_r = syn.se3_error(got["transformation"], T_gt)
+    print(f"C2 full: vs oracle dt={dt:.3e} dr={dr:.3e}; vs truth dt={gt_t:.3e} dr={gt_r:.3e}; fitness={got['fitness']}")
+    assert gt_t < 5e-3 and gt_r < 5e-4
+
+
+def test_full_size_properties(backend_f32):
+    """Size-independent properties at full size: registering a map subset against the map is a fixed point
+    (fitness 1, rmse 0, T = I), and a pure translation along a wall normal is recovered."""
+    _, tgt, nrm, _ = syn.config2_inputs()
+    sub = tgt[::16][:65536]
+    s = backend_f32.upload(sub)
+    t = backend_f32.upload(tgt, nrm)
+    backend_f32.build_index(t, 1.0)
+    got = backend_f32.icp_point_to_plane_dev(s, t, 1.0, max_iter=3, rel_fitness=0.0, rel_rmse=0.0)
+    assert got["fitness"] == 1.0 and got["inlier_rmse"] == 0.0
+    np.testing.assert_allclose(got["transformation"], np.eye(4), atol=1e-12)
+    shifted = backend_f32.upload(sub + np.array([0.05, -0.04, 0.03]))
+    got = backend_f32.icp_point_to_plane_dev(shifted, t, 1.0, max_iter=15, rel_fitness=0.0, rel_rmse=0.0)
+    np.testing.assert_allclose(got["transformation"][:3, 3], [-0.05, 0.04, -0.03], atol=2e-3)
+    for c in (s, t, shifted):
+        backend_f32.free(c)

@@ -1,0 +1,287 @@
+"""Oracle self-tests (CPU).  The reference has no tests/golden vectors for this path,
+so the oracle is pinned by (i) analytic known-answer cases, (ii) an independent numpy/scipy
+restatement, (iii) golden fixtures generated from that restatement (tests/golden/make_golden.py)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from open3d_slam_amd import synthetic as syn
+from oracle import np_oracle as no
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _three_planes(n=4000, seed=0):
+    """Points on 3 orthogonal planes (x=0,y=0,z=0 patches) with analytic normals."""
+    rng = np.random.default_rng(seed)
+    u, v = rng.uniform(0.5, 5.0, (2, n))
+    k = rng.integers(0, 3, n)
+    pts = np.zeros((n, 3))
+    nrm = np.zeros((n, 3))
+    for a in range(3):
+        m = k == a
+        b, c = (a + 1) % 3, (a + 2) % 3
+        pts[m, b], pts[m, c] = u[m], v[m]
+        nrm[m, a] = 1.0
+    return pts, nrm
+
+
+def test_vector6_to_matrix4_is_rz_ry_rx(oracle):
+    x = np.array([0.11, -0.23, 0.37, 1.0, -2.0, 3.0])
+    T = oracle.vector6_to_matrix4(x)
+    ca, sa, cb, sb, cg, sg = math.cos(x[0]), math.sin(x[0]), math.cos(x[1]), math.sin(x[1]), math.cos(x[2]), math.sin(x[2])
+    Rx = np.array([[1, 0, 0], [0, ca, -sa], [0, sa, ca]])
+    Ry = np.array([[cb, 0, sb], [0, 1, 0], [-sb, 0, cb]])
+    Rz = np.array([[cg, -sg, 0], [sg, cg, 0], [0, 0, 1]])
+    np.testing.assert_allclose(T[:3, :3], Rz @ Ry @ Rx, atol=1e-15)
+    np.testing.assert_allclose(T[:3, 3], x[3:], atol=0)
+    np.testing.assert_allclose(T[3], [0, 0, 0, 1], atol=0)
+    np.testing.assert_allclose(T, no.vector6_to_matrix4(x), atol=1e-15)
+
+
+def test_single_gauss_newton_step_hand_derived(oracle):
+    """3 orthogonal planes, source = target shifted by t: JtJ/Jtr from the explicit formula, and the
+    translation-only solution recovers -t exactly (planes pin all 3 translations)."""
+    tgt, nrm = _three_planes()
+    t = np.array([0.01, -0.02, 0.015])
+    src = tgt + t
+    corr = np.arange(len(tgt), dtype=np.int32)
+    JTJ, JTr, r2 = oracle.compute_jtj_jtr(src, tgt, nrm, corr)
+    r = np.einsum("ij,ij->i", src - tgt, nrm)
+    J = np.concatenate([np.cross(src, nrm), nrm], 1)
+    np.testing.assert_allclose(JTJ, J.T @ J, rtol=1e-12)
+    np.testing.assert_allclose(JTr, J.T @ r, rtol=1e-12, atol=1e-12)
+    assert abs(r2 - r @ r) < 1e-12
+    U, x = oracle.solve_update(JTJ, JTr)
+    np.testing.assert_allclose(x, np.linalg.solve(J.T @ J, -(J.T @ r)), rtol=1e-9, atol=1e-12)
+    # exact linear model => one step lands on the solution
+    moved = src @ U[:3, :3].T + U[:3, 3]
+    assert np.abs(np.einsum("ij,ij->i", moved - tgt, nrm)).max() < 1e-6
+
+
+def test_ldlt_pivoting_handles_bad_ordering(oracle):
+    rng = np.random.default_rng(3)
+    M = rng.normal(size=(40, 6)) * np.array([1e-3, 1.0, 1e3, 1e-2, 10.0, 1e2])
+    A = M.T @ M
+    b = rng.normal(size=6)
+    _, x = oracle.solve_update(A, b)
+    np.testing.assert_allclose(A @ x, -b, rtol=1e-7, atol=1e-9)
+
+
+def test_icp_recovers_known_pose_noise_free(oracle):
+    scene = syn.make_scene()
+    tgt, nrm = syn.sample_map(scene, 200_000)
+    T_gt = syn.make_pose([0.10, -0.05, 0.02], [0.2, -0.1, 0.5])
+    src = syn.vlp16_scan(scene, T_gt, noise_sigma=0.0, n_az=256)
+    r = oracle.icp_point_to_plane(src, tgt, nrm, 1.0, max_iter=50, rel_fitness=1e-12, rel_rmse=1e-12)
+    dt, dr = syn.se3_error(r["transformation"], T_gt)
+    # point-to-plane on exact planes/cylinders: the minimum is the true pose up to sampling of the curved cylinders
+    assert dt < 2e-3 and dr < 2e-4, (dt, dr)
+    assert r["fitness"] > 0.999
+
+
+def test_icp_planes_only_exact(oracle):
+    """Pure planar target: the point-to-plane optimum is the true pose to round-off."""
+    tgt, nrm = _three_planes(20000, seed=1)
+    T = syn.make_pose([0.02, -0.03, 0.01], [0.3, -0.2, 0.4])
+    src_in_map, _ = _three_planes(3000, seed=2)
+    Ti = np.linalg.inv(T)
+    src = src_in_map @ Ti[:3, :3].T + Ti[:3, 3]
+    r = oracle.icp_point_to_plane(src, tgt, nrm, 0.5, max_iter=60, rel_fitness=0.0, rel_rmse=0.0)
+    moved = src @ r["transformation"][:3, :3].T + r["transformation"][:3, 3]
+    # every source point ends on its plane (distance along the plane normal it belongs to)
+    k = np.argmin(np.abs(src_in_map), axis=1)
+    assert np.abs(moved[np.arange(len(k)), k]).max() < 1e-6
+
+
+def test_hybrid_search_self_and_strict_radius(oracle):
+    pts = np.array([[0.0, 0, 0], [1.0, 0, 0], [2.0, 0, 0], [0.5, 0, 0]])
+    t = oracle.KDTree(pts)
+    idx, d2 = t.search_hybrid([0, 0, 0], 1.0, 10)  # d2 < 1 strictly: point at distance exactly 1 excluded
+    assert list(idx) == [0, 3] and np.allclose(d2, [0, 0.25])
+    idx, d2 = t.search_hybrid([0, 0, 0], 1.0 + 1e-12, 10)
+    assert list(idx) == [0, 3, 1]
+    idx, d2 = t.search_hybrid([0, 0, 0], 10.0, 2)  # k caps
+    assert list(idx) == [0, 3]
+    idx, _ = t.search_knn([2.1, 0, 0], 1)
+    assert list(idx) == [2]
+
+
+def test_kdtree_matches_scipy_exact(oracle, small_c2):
+    from scipy.spatial import cKDTree
+
+    src, tgt, nrm, _ = small_c2
+    tree = oracle.KDTree(tgt)
+    corr, d2, fit, rmse, nc = oracle.evaluate(tree, src, 1.0)
+    d, j = cKDTree(tgt, leafsize=15).query(src, k=1, distance_upper_bound=1.0)
+    ok = np.isfinite(d)
+    assert (np.where(ok, j, -1) == corr).all()
+    np.testing.assert_allclose(d2[ok], d[ok] ** 2, rtol=1e-12)
+    assert nc == ok.sum() and abs(fit - ok.mean()) < 1e-15
+
+
+def test_voxel_keys_floor_and_anchors(oracle):
+    # negative coordinates use floor (not trunc): -0.05 and +0.05 are different voxels on the world grid
+    pts = np.array([[-0.05, 0.0, 0.0], [0.05, 0.0, 0.0], [-0.06, 0.0, 0.0]])
+    crop = oracle.make_crop(oracle.CROP_MAX_RADIUS, rmax=100.0)
+    out, _, npass = oracle.voxelize_within_volume(pts, None, 0.1, crop)
+    assert npass == 0 and len(out) == 2
+    got = np.sort(out[:, 0])
+    np.testing.assert_allclose(got, [-0.055, 0.05], atol=1e-15)
+    # data-anchored grid (VoxelDownSample): origin = min - v/2 => first voxel spans [-0.11,-0.01): -0.06,-0.05 merge
+    out2 = oracle.voxel_down_sample(pts, 0.1)
+    np.testing.assert_allclose(np.sort(out2[:, 0]), [-0.055, 0.05], atol=1e-15)
+    pts3 = np.array([[0.0, 0, 0], [0.049, 0, 0], [0.051, 0, 0]])
+    # world grid: all in voxel 0; data grid: origin -0.05 -> [ -0.05,0.05 ) holds the first two only
+    o_w, _, _ = oracle.voxelize_within_volume(pts3, None, 0.1, crop)
+    assert len(o_w) == 1
+    assert len(oracle.voxel_down_sample(pts3, 0.1)) == 2
+
+
+def test_croppers_inclusive_boundaries(oracle):
+    pts = np.array([[2.0, 0, 0], [1.9999999, 0, 0], [30.0, 0, 0], [30.0000001, 0, 0], [0, 0, 5.0]])
+    c = oracle.make_crop(oracle.CROP_MIN_MAX_RADIUS, rmin=2.0, rmax=30.0)
+    assert list(oracle.crop_indices(pts, c)) == [0, 2, 4]
+    c = oracle.make_crop(oracle.CROP_MAX_RADIUS, rmax=2.0)
+    assert list(oracle.crop_indices(pts, c)) == [0, 1]
+    c = oracle.make_crop(oracle.CROP_MIN_RADIUS, rmin=30.0)
+    assert list(oracle.crop_indices(pts, c)) == [2, 3]
+    c = oracle.make_crop(oracle.CROP_CYLINDER, rmax=2.0, zmin=-1.0, zmax=5.0)
+    assert list(oracle.crop_indices(pts, c)) == [0, 1, 4]
+    c = oracle.make_crop(oracle.CROP_CYLINDER, rmax=2.0, zmin=-1.0, zmax=5.0, invert=True)
+    assert list(oracle.crop_indices(pts, c)) == [2, 3]
+    # only the pose translation matters
+    c = oracle.make_crop(oracle.CROP_MAX_RADIUS, center=(28.0, 0, 0), rmax=2.0)
+    assert list(oracle.crop_indices(pts, c)) == [2]
+
+
+def test_normals_orientation_and_plane(oracle):
+    rng = np.random.default_rng(5)
+    xy = rng.uniform(-5, 5, (3000, 2))
+    pts = np.column_stack([xy, np.full(len(xy), -1.5)])  # floor below the sensor
+    n = oracle.estimate_normals(pts, 1.0, 20)
+    np.testing.assert_allclose(n, np.tile([0, 0, 1.0], (len(pts), 1)), atol=1e-9)  # towards origin => +z
+    pts2 = pts * [1, 1, -1]  # ceiling above
+    n2 = oracle.estimate_normals(pts2, 1.0, 20)
+    np.testing.assert_allclose(n2, np.tile([0, 0, -1.0], (len(pts), 1)), atol=1e-9)
+    # fewer than 3 neighbours within radius => identity covariance => (0,0,1) then oriented
+    lone = np.array([[0.0, 0, 10.0], [100.0, 0, 0]])
+    nl = oracle.estimate_normals(lone, 0.5, 20)
+    np.testing.assert_allclose(nl, [[0, 0, -1], [0, 0, 1]], atol=0)
+
+
+def test_fast_eigen_matches_eigh(oracle):
+    rng = np.random.default_rng(7)
+    for _ in range(200):
+        M = rng.normal(size=(3, 3)) * rng.uniform(0.01, 10, 3)
+        A = M @ M.T
+        v = oracle.fast_eigen3x3_min_evec(A)
+        w, V = np.linalg.eigh(A)
+        assert abs(abs(v @ V[:, 0]) - 1.0) < 1e-7, (w, v, V[:, 0])
+    assert list(oracle.fast_eigen3x3_min_evec(np.diag([3.0, 1.0, 2.0]))) == [0, 1, 0]
+    assert list(oracle.fast_eigen3x3_min_evec(np.zeros((3, 3)))) == [0, 0, 0]
+    assert list(oracle.fast_eigen3x3_min_evec(np.eye(3))) == [0, 0, 1]
+
+
+def test_c_oracle_equals_numpy_restatement(oracle, small_c2):
+    src, tgt, nrm, _ = small_c2
+    a = oracle.icp_point_to_plane(src, tgt, nrm, 1.0, max_iter=10, rel_fitness=0.0, rel_rmse=0.0)
+    b = no.icp_point_to_plane(src, tgt, nrm, 1.0, max_iter=10, rel_fitness=0.0, rel_rmse=0.0)
+    np.testing.assert_allclose(a["transformation"], b["transformation"], atol=1e-9)
+    assert abs(a["fitness"] - b["fitness"]) < 1e-15 and abs(a["inlier_rmse"] - b["inlier_rmse"]) < 1e-12
+    # default convergence criteria: same number of iterations
+    a = oracle.icp_point_to_plane(src, tgt, nrm, 1.0, max_iter=30)
+    b = no.icp_point_to_plane(src, tgt, nrm, 1.0, max_iter=30)
+    assert a["iterations"] == b["iterations"] and a["converged"]
+    np.testing.assert_allclose(a["transformation"], b["transformation"], atol=1e-9)
+    # non-identity init
+    T0 = syn.make_pose([0.2, -0.1, 0.0], [0, 0, 1.0])
+    a = oracle.icp_point_to_plane(src, tgt, nrm, 1.0, init=T0, max_iter=5, rel_fitness=0.0, rel_rmse=0.0)
+    b = no.icp_point_to_plane(src, tgt, nrm, 1.0, init=T0, max_iter=5, rel_fitness=0.0, rel_rmse=0.0)
+    np.testing.assert_allclose(a["transformation"], b["transformation"], atol=1e-9)
+
+
+def test_c_normals_and_voxel_equal_numpy(oracle):
+    a, _ = syn.config1_inputs(n_az=128)
+    av = oracle.voxel_down_sample(a, 0.1)
+    bv, _ = no.voxel_down_sample(a, 0.1)
+    assert len(av) == len(bv)
+    sa = av[np.lexsort((av[:, 2], av[:, 1], av[:, 0]))]
+    sb = bv[np.lexsort((bv[:, 2], bv[:, 1], bv[:, 0]))]
+    np.testing.assert_allclose(sa, sb, atol=1e-12)
+    n1 = oracle.estimate_normals(av, 3.0, 20)
+    n2 = no.estimate_normals(av, 3.0, 20)
+    dots = np.einsum("ij,ij->i", n1, n2)
+    # the orientation sign is ill-defined when the fitted plane passes through the sensor origin (n.p ~ 0: e.g. the
+    # neighbours are one azimuth column of a sparse scan); everywhere else the two restatements must agree
+    view = np.abs(np.einsum("ij,ij->i", n1, av / np.linalg.norm(av, axis=1, keepdims=True)))
+    assert (np.abs(dots) > 1 - 1e-6).mean() > 0.999
+    assert (dots[view > 1e-6] > 1 - 1e-6).mean() > 0.999
+
+
+def test_map_merge_matches_numpy(oracle):
+    rng = np.random.default_rng(11)
+    pts = rng.uniform(-3, 3, (5000, 3))
+    nrm = rng.normal(size=(5000, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    crop = oracle.make_crop(oracle.CROP_MAX_RADIUS, center=(0.5, 0, 0), rmax=2.0)
+    out, on, npass = oracle.voxelize_within_volume(pts, nrm, 0.25, crop)
+    inside = np.linalg.norm(pts - [0.5, 0, 0], axis=1) <= 2.0
+    assert npass == (~inside).sum()
+    np.testing.assert_array_equal(out[:npass], pts[~inside])  # pass-through first, original order
+    np.testing.assert_array_equal(on[:npass], nrm[~inside])
+    vp, vn, _ = no.voxelize_world(pts[inside], nrm[inside], 0.25)
+    got = out[npass:]
+    o1 = np.lexsort((got[:, 2], got[:, 1], got[:, 0]))
+    o2 = np.lexsort((vp[:, 2], vp[:, 1], vp[:, 0]))
+    np.testing.assert_allclose(got[o1], vp[o2], atol=1e-12)
+    np.testing.assert_allclose(on[npass:][o1], vn[o2], atol=1e-12)
+    # idempotent: voxel means stay in their voxel
+    out2, on2, np2 = oracle.voxelize_within_volume(out, on, 0.25, crop)
+    assert len(out2) == len(out)
+
+
+def test_transform_matches_matrix_form(oracle):
+    rng = np.random.default_rng(2)
+    p = rng.normal(size=(100, 3))
+    T = syn.make_pose([1, 2, 3], [10, 20, 30])
+    np.testing.assert_allclose(oracle.transform_points(p, T), p @ T[:3, :3].T + T[:3, 3], atol=1e-14)
+    np.testing.assert_allclose(oracle.transform_normals(p, T), p @ T[:3, :3].T, atol=1e-14)
+
+
+def test_error_conventions(oracle):
+    src = np.zeros((4, 3))
+    with pytest.raises(RuntimeError):
+        oracle.icp_point_to_plane(src, src, src, 0.0)  # Invalid max_correspondence_distance
+
+
+def test_golden_scan_to_map(oracle):
+    g = np.load(os.path.join(GOLD, "icp_scan_to_map.npz"))
+    src, tgt, nrm, _ = syn.config2_inputs(n_map=int(g["n_map"]), n_az=int(g["n_az"]))
+    r = oracle.icp_point_to_plane(src, tgt, nrm, float(g["max_corr"]), max_iter=10, rel_fitness=0.0, rel_rmse=0.0)
+    np.testing.assert_allclose(r["transformation"], g["T10"], atol=1e-9)
+    assert abs(r["fitness"] - float(g["fitness10"])) < 1e-15
+    assert abs(r["inlier_rmse"] - float(g["rmse10"])) < 1e-12
+    rc = oracle.icp_point_to_plane(src, tgt, nrm, float(g["max_corr"]), max_iter=30)
+    assert rc["iterations"] == int(g["iters_conv"])
+    np.testing.assert_allclose(rc["transformation"], g["Tconv"], atol=1e-9)
+
+
+def test_golden_scan_pair(oracle):
+    g = np.load(os.path.join(GOLD, "scan_pair.npz"))
+    a, b = syn.config1_inputs(n_az=int(g["n_az"]))
+    av = oracle.voxel_down_sample(a, float(g["voxel"]))
+    bv = oracle.voxel_down_sample(b, float(g["voxel"]))
+    assert len(av) == int(g["n_a"]) and len(bv) == int(g["n_b"])
+    bn = oracle.estimate_normals(bv, float(g["radius"]), int(g["knn"]))
+    order = np.lexsort((bv[:, 2], bv[:, 1], bv[:, 0]))
+    np.testing.assert_allclose(bv[order][:64], g["b_sorted_head"], atol=1e-12)
+    dots = np.einsum("ij,ij->i", bn[order][:64], g["bn_sorted_head"])
+    assert (dots > 1 - 1e-6).all()
+    r = oracle.icp_point_to_plane(av, bv, bn, 1.0, max_iter=10, rel_fitness=0.0, rel_rmse=0.0)
+    # same voxel SET but different point ORDER (first-occurrence vs sorted) => fp reassociation only
+    dt, dr = syn.se3_error(r["transformation"], g["T10"])
+    assert dt < 1e-7 and dr < 1e-7
+    assert abs(r["fitness"] - float(g["fitness10"])) < 1e-12
