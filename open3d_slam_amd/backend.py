@@ -75,6 +75,7 @@ SIGNATURES = {
 }
 
 _lib = None
+_EMPTY = (C.c_double * 3)()  # non-NULL placeholder for zero-length clouds
 
 
 class BackendError(RuntimeError):
@@ -121,6 +122,9 @@ def _d(a):
     if a is None:
         return None, None
     a = np.ascontiguousarray(a, dtype=np.float64)
+    if a.size == 0:  # numpy may hand out a NULL data pointer for empty arrays; the ABI reads NULL as "absent"
+        a = np.zeros((0, 3), dtype=np.float64)
+        return a, C.cast(_EMPTY, _dp)
     return a, a.ctypes.data_as(_dp)
 
 

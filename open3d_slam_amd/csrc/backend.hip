@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -34,9 +35,14 @@ struct CloudRec {
   int* cell_start = nullptr;
   void* spts = nullptr;
   void* snrm = nullptr;
+  // coarse grid for far queries (cell >= max correspondence distance); built on demand
+  bool has_coarse = false;
+  GridDev coarse{};
+  int* ccell_start = nullptr;
+  void* cpts = nullptr;
 };
 
-constexpr int kMaxPassBlocks = 2048;
+constexpr int kMaxPassBlocks = 4096;  // capacity of the partial-record buffer (rows per pass <= pass_rows <= this)
 constexpr size_t kMaxCells = (size_t)1 << 27;  // 512 MiB of cell_start at most
 
 }  // namespace
@@ -60,6 +66,11 @@ struct o3ds_context {
   int session_precision = 0;
   bool session_crop = false;
   hipStream_t own_stream = nullptr;
+  // launch geometry of the ICP pass kernel (tunable through O3DS_PASS_BLOCK / O3DS_PASS_ROWS for experiments)
+  int debug_update = 0;  // O3DS_DEBUG_UPDATE: timing experiments only
+  int pass_block = 256;
+  int pass_group = 4;
+  int pass_rows = 1024;
   // profiling (bench.py roofline): event pairs around every accumulate launch
   bool profiling = false;
   std::vector<hipEvent_t> ev;
@@ -99,6 +110,13 @@ CloudRec* find_cloud(o3ds_handle h, o3ds_cloud id) {
   return it == h->clouds.end() ? nullptr : &it->second;
 }
 
+void free_coarse(CloudRec& c) {
+  if (c.ccell_start) (void)hipFree(c.ccell_start);
+  if (c.cpts) (void)hipFree(c.cpts);
+  c.ccell_start = nullptr;
+  c.cpts = nullptr;
+  c.has_coarse = false;
+}
 void free_index(CloudRec& c) {
   if (c.cell_start) (void)hipFree(c.cell_start);
   if (c.spts) (void)hipFree(c.spts);
@@ -106,6 +124,7 @@ void free_index(CloudRec& c) {
   c.cell_start = nullptr;
   c.spts = c.snrm = nullptr;
   c.has_index = false;
+  free_coarse(c);
 }
 void free_cloud(CloudRec& c) {
   free_index(c);
@@ -154,12 +173,14 @@ int bbox_of(o3ds_handle h, const P4* pts, size_t n, double mn[3], double mx[3]) 
   return O3DS_OK;
 }
 
+// Build one uniform grid over `pts`: cell_start (exclusive scan of the per-cell counts) and the points (+ normals when
+// given) re-stored in cell order.  Output buffers are allocated here; the caller owns them.
 template <typename P4>
-int build_index_t(o3ds_handle h, CloudRec& c, double cell) {
-  free_index(c);
-  if (c.n == 0) return fail(h, O3DS_ERR_EMPTY, "build_index: empty cloud");
+int build_grid_t(o3ds_handle h, const P4* pts, const P4* nrm, size_t n, double cell, GridDev* out_grid, int** out_cell_start, void** out_spts,
+                 void** out_snrm) {
+  if (n == 0) return fail(h, O3DS_ERR_EMPTY, "build_index: empty cloud");
   double mn[3], mx[3];
-  int rc = bbox_of<P4>(h, (const P4*)c.pts, c.n, mn, mx);
+  int rc = bbox_of<P4>(h, pts, n, mn, mx);
   if (rc) return rc;
   for (int a = 0; a < 3; ++a)
     if (!std::isfinite(mn[a]) || !std::isfinite(mx[a])) return fail(h, O3DS_ERR_INVALID_ARG, "build_index: non-finite coordinates");
@@ -181,29 +202,53 @@ int build_index_t(o3ds_handle h, CloudRec& c, double cell) {
   g.nx = (int)nx;
   g.ny = (int)ny;
   g.nz = (int)nz;
-  int *counts = nullptr, *cursor = nullptr, *cell_id = nullptr;
+  int *counts = nullptr, *cursor = nullptr, *cell_id = nullptr, *cell_start = nullptr;
+  void *spts = nullptr, *snrm = nullptr;
   HIP_TRY(hipMalloc(&counts, sizeof(int) * (ncell + 1)));
   HIP_TRY(hipMalloc(&cursor, sizeof(int) * ncell));
-  HIP_TRY(hipMalloc(&cell_id, sizeof(int) * c.n));
-  HIP_TRY(hipMalloc(&c.cell_start, sizeof(int) * (ncell + 1)));
-  HIP_TRY(hipMalloc(&c.spts, sizeof(P4) * c.n));
-  if (c.nrm) HIP_TRY(hipMalloc(&c.snrm, sizeof(P4) * c.n));
+  HIP_TRY(hipMalloc(&cell_id, sizeof(int) * n));
+  HIP_TRY(hipMalloc(&cell_start, sizeof(int) * (ncell + 1)));
+  HIP_TRY(hipMalloc(&spts, sizeof(P4) * n));
+  if (nrm) HIP_TRY(hipMalloc(&snrm, sizeof(P4) * n));
   HIP_TRY(hipMemsetAsync(counts, 0, sizeof(int) * (ncell + 1), h->stream));
   HIP_TRY(hipMemsetAsync(cursor, 0, sizeof(int) * ncell, h->stream));
-  cell_count_kernel<P4><<<grid_for(c.n), kBlock, 0, h->stream>>>((const P4*)c.pts, c.n, g, counts, cell_id);
-  rc = exclusive_scan_int(h, counts, c.cell_start, ncell + 1);
+  cell_count_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(pts, n, g, counts, cell_id);
+  rc = exclusive_scan_int(h, counts, cell_start, ncell + 1);
   if (rc) return rc;
-  scatter_kernel<P4><<<grid_for(c.n), kBlock, 0, h->stream>>>((const P4*)c.pts, (const P4*)c.nrm, c.n, cell_id, c.cell_start, cursor,
-                                                              (P4*)c.spts, (P4*)c.snrm);
+  scatter_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(pts, nrm, n, cell_id, cell_start, cursor, (P4*)spts, (P4*)snrm);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipFree(counts));
   HIP_TRY(hipFree(cursor));
   HIP_TRY(hipFree(cell_id));
-  g.cell_start = c.cell_start;
-  c.grid = g;
+  g.cell_start = cell_start;
+  *out_grid = g;
+  *out_cell_start = cell_start;
+  *out_spts = spts;
+  if (out_snrm) *out_snrm = snrm;
+  return O3DS_OK;
+}
+
+template <typename P4>
+int build_index_t(o3ds_handle h, CloudRec& c, double cell) {
+  free_index(c);
+  int rc = build_grid_t<P4>(h, (const P4*)c.pts, (const P4*)c.nrm, c.n, cell, &c.grid, &c.cell_start, &c.spts, &c.snrm);
+  if (rc) return rc;
   c.has_index = true;
   return O3DS_OK;
+}
+
+template <typename P4>
+int build_coarse_t(o3ds_handle h, CloudRec& c, double cell) {
+  free_coarse(c);
+  int rc = build_grid_t<P4>(h, (const P4*)c.pts, (const P4*)nullptr, c.n, cell, &c.coarse, &c.ccell_start, &c.cpts, nullptr);
+  if (rc) return rc;
+  c.has_coarse = true;
+  return O3DS_OK;
+}
+
+int build_coarse(o3ds_handle h, CloudRec& c, double cell) {
+  return c.precision == O3DS_PRECISION_F64 ? build_coarse_t<P4d>(h, c, cell) : build_coarse_t<P4f>(h, c, cell);
 }
 
 int build_index(o3ds_handle h, CloudRec& c, double cell) {
@@ -277,23 +322,38 @@ void launch_accumulate(o3ds_handle h, const IcpPassArgs& a, bool crop, int nbloc
       (void)hipEventRecord(e0, h->stream);
     }
   }
-  if (crop)
-    icp_accumulate_kernel<P4, true><<<nblocks, kBlock, 0, h->stream>>>(a);
-  else
-    icp_accumulate_kernel<P4, false><<<nblocks, kBlock, 0, h->stream>>>(a);
+#define O3DS_LAUNCH_PASS(BLK, GRP)                                                              \
+  do {                                                                                          \
+    if (crop)                                                                                   \
+      icp_accumulate_kernel<P4, true, BLK, GRP><<<nblocks, BLK, 0, h->stream>>>(a);            \
+    else                                                                                        \
+      icp_accumulate_kernel<P4, false, BLK, GRP><<<nblocks, BLK, 0, h->stream>>>(a);           \
+  } while (0)
+  const int key = h->pass_block * 100 + h->pass_group;
+  switch (key) {
+    case 25602: O3DS_LAUNCH_PASS(256, 2); break;
+    case 25604: O3DS_LAUNCH_PASS(256, 4); break;
+    case 25608: O3DS_LAUNCH_PASS(256, 8); break;
+    case 51202: O3DS_LAUNCH_PASS(512, 2); break;
+    case 51204: O3DS_LAUNCH_PASS(512, 4); break;
+    default: O3DS_LAUNCH_PASS(512, 8); break;
+  }
+#undef O3DS_LAUNCH_PASS
   if (e1) (void)hipEventRecord(e1, h->stream);
 }
 
-int pass_blocks(size_t count) {
-  size_t g = (count + kBlock - 1) / kBlock;
+int pass_blocks(o3ds_handle h, size_t count) {
+  const size_t qpb = (size_t)h->pass_block / h->pass_group;  // one batch of BLOCK/G queries per workgroup iteration
+  size_t g = (count + qpb - 1) / qpb;
   if (g < 1) g = 1;
-  if (g > (size_t)kMaxPassBlocks) g = kMaxPassBlocks;
+  if (g > (size_t)h->pass_rows) g = h->pass_rows;
   return (int)g;
 }
 
 int validate_icp(o3ds_handle h, const CloudRec* src, const CloudRec* tgt, const o3ds_icp_params* p) {
   if (!src || !tgt) return fail(h, O3DS_ERR_INVALID_ARG, "icp: unknown cloud id");
   if (!p) return fail(h, O3DS_ERR_INVALID_ARG, "icp: null params");
+  if (tgt->n == 0) return fail(h, O3DS_ERR_EMPTY, "icp: empty target (map patch size is zero)");  // ScanToMapRegistration.cpp:60
   if (!(p->max_correspondence_distance > 0.0))
     return fail(h, O3DS_ERR_INVALID_ARG, "Invalid max_correspondence_distance.");  // [O3D] RegistrationICP
   if (!tgt->nrm) return fail(h, O3DS_ERR_NO_NORMALS, "TransformationEstimationPointToPlane requires target normals");
@@ -308,10 +368,16 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
   CloudRec* tgt = find_cloud(h, target);
   int rc = validate_icp(h, src, tgt, params);
   if (rc) return rc;
-  if (tgt->n == 0) return fail(h, O3DS_ERR_EMPTY, "icp: empty target");
   if (!tgt->has_index || (tgt->nrm && !tgt->snrm)) {
     rc = build_index(h, *tgt, params->max_correspondence_distance / 4.0);
     if (rc) return rc;
+  }
+  const double r_corr = params->max_correspondence_distance;
+  if (tgt->grid.cell < r_corr) {  // far queries need the coarse grid: cell >= r (3x3x3 block covers the ball), not wastefully larger
+    if (!tgt->has_coarse || tgt->coarse.cell < r_corr || tgt->coarse.cell > 2.0 * r_corr) {
+      rc = build_coarse(h, *tgt, r_corr);
+      if (rc) return rc;
+    }
   }
   IcpStateDev st{};
   memcpy(st.T, init, sizeof(double) * 16);
@@ -324,13 +390,17 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
   a.tpts = tgt->spts;
   a.tnrm = tgt->snrm;
   a.grid = tgt->grid;
+  a.cpts = tgt->has_coarse ? tgt->cpts : nullptr;
+  a.coarse = tgt->coarse;
+  a.opts = tgt->pts;
+  a.onrm = tgt->nrm;
   a.crop = to_dev(crop);
   const double r = params->max_correspondence_distance;
   a.r2max = r * r;
-  a.rmax_cells = (int)std::ceil(r / tgt->grid.cell);
-  if (a.rmax_cells < 1) a.rmax_cells = 1;
+  a.rmax_cells = tgt->grid.cell >= r ? 1 : 2;  // 1: the fine 3x3x3 block already covers the ball of radius r
   a.state = h->d_state;
   a.partials = h->d_partials;
+  a.debug = getenv("O3DS_DEBUG_ACC") ? atoi(getenv("O3DS_DEBUG_ACC")) : 0;
   h->pass = a;
   h->params = *params;
   h->session = true;
@@ -380,6 +450,13 @@ int o3ds_create(int device_id, o3ds_handle* out) {
     delete h;
     return fail(nullptr, O3DS_ERR_HIP, "o3ds_create: device initialisation failed");
   }
+  if (const char* e = getenv("O3DS_DEBUG_UPDATE")) h->debug_update = atoi(e);
+  if (const char* e = getenv("O3DS_PASS_BLOCK")) h->pass_block = atoi(e) == 512 ? 512 : 256;
+  if (const char* e = getenv("O3DS_PASS_GROUP")) {
+    const int g = atoi(e);
+    h->pass_group = (g == 2 || g == 4 || g == 8) ? g : 4;
+  }
+  if (const char* e = getenv("O3DS_PASS_ROWS")) h->pass_rows = std::min(std::max(atoi(e), 1), kMaxPassBlocks);
   *out = h;
   return O3DS_OK;
 }
@@ -493,7 +570,9 @@ int o3ds_cloud_build_index(o3ds_handle h, o3ds_cloud id, double max_corr_hint, d
   if (!c) return fail(h, O3DS_ERR_INVALID_ARG, "build_index: unknown cloud id");
   double cell = cell_size > 0.0 ? cell_size : max_corr_hint / 4.0;
   if (!(cell > 0.0)) return fail(h, O3DS_ERR_INVALID_ARG, "build_index: need cell_size > 0 or max_corr_hint > 0");
-  return build_index(h, *c, cell);
+  int rc = build_index(h, *c, cell);
+  if (rc == O3DS_OK && max_corr_hint > 0.0 && c->grid.cell < max_corr_hint) rc = build_coarse(h, *c, max_corr_hint);
+  return rc;
 }
 
 // ---- ICP ---------------------------------------------------------------------------------------
@@ -512,12 +591,12 @@ int o3ds_icp_accumulate(o3ds_handle h, size_t first, size_t count, double* d_rec
   IcpPassArgs a = h->pass;
   a.first = first;
   a.count = count;
-  const int nb = pass_blocks(count);
+  const int nb = pass_blocks(h, count);
   if (h->session_precision == O3DS_PRECISION_F64)
     launch_accumulate<P4d>(h, a, h->session_crop, nb);
   else
     launch_accumulate<P4f>(h, a, h->session_crop, nb);
-  icp_reduce_kernel<<<1, kBlock, 0, h->stream>>>(h->d_partials, nb, h->d_state, d_record);
+  icp_reduce_kernel<<<1, kUpdBlock, 0, h->stream>>>(h->d_partials, nb, h->d_state, d_record);
   HIP_TRY(hipGetLastError());
   return O3DS_OK;
 }
@@ -557,7 +636,7 @@ int o3ds_icp_point_to_plane_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud tar
   if (rc) return rc;
   h->session = false;  // the loop below owns the state
   const IcpPassArgs a = h->pass;
-  const int nb = pass_blocks(a.count);
+  const int nb = pass_blocks(h, a.count);
   const int total_passes = params->max_iteration + 1;  // max_iter updates need max_iter+1 correspondence passes
   int launched = 0;
   while (launched < total_passes) {
@@ -568,8 +647,9 @@ int o3ds_icp_point_to_plane_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud tar
         launch_accumulate<P4d>(h, a, h->session_crop, nb);
       else
         launch_accumulate<P4f>(h, a, h->session_crop, nb);
-      icp_reduce_update_kernel<<<1, kBlock, 0, h->stream>>>(h->d_partials, nb, h->d_state, (unsigned long long)a.count,
-                                                            params->max_iteration, params->relative_fitness, params->relative_rmse);
+      icp_reduce_update_kernel<<<1, kUpdBlock, 0, h->stream>>>(h->d_partials, nb, h->d_state, (unsigned long long)a.count,
+                                                            params->max_iteration, params->relative_fitness, params->relative_rmse,
+                                                            h->debug_update);
     }
     launched += chunk;
     HIP_TRY(hipGetLastError());
@@ -585,6 +665,7 @@ int o3ds_icp_point_to_plane(o3ds_handle h, const double* src_xyz, size_t n_src, 
   CHECK_HANDLE(h);
   if (!params || !out || !init) return fail(h, O3DS_ERR_INVALID_ARG, "icp: null argument");
   if (!(params->max_correspondence_distance > 0.0)) return fail(h, O3DS_ERR_INVALID_ARG, "Invalid max_correspondence_distance.");
+  if (n_tgt == 0) return fail(h, O3DS_ERR_EMPTY, "icp: empty target (map patch size is zero)");
   if (!tgt_normals) return fail(h, O3DS_ERR_NO_NORMALS, "TransformationEstimationPointToPlane requires target normals");
   o3ds_cloud s = 0, t = 0;
   int rc = o3ds_cloud_upload(h, src_xyz, nullptr, n_src, &s);
@@ -952,7 +1033,10 @@ int o3ds_map_insert_scan(o3ds_handle h, o3ds_cloud map, o3ds_cloud scan, const d
   rc = o3ds_voxelize_within_volume(h, map, map_voxel_size, map_builder_crop);  // Submap.cpp:71-72
   if (rc) return rc;
   m = find_cloud(h, map);
-  if (max_corr_hint > 0.0) rc = build_index(h, *m, max_corr_hint / 4.0);
+  if (max_corr_hint > 0.0) {
+    rc = build_index(h, *m, max_corr_hint / 4.0);
+    if (rc == O3DS_OK && m->grid.cell < max_corr_hint) rc = build_coarse(h, *m, max_corr_hint);
+  }
   return rc;
 }
 

@@ -166,41 +166,82 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(const P4* __restrict__ 
 }
 
 // ----------------------------------------------------------------------------------------------
-// exact 1-NN within radius on the grid ([O3D] KDTreeFlann::SearchHybrid(q, r, 1))
+// exact 1-NN within radius on the grid ([O3D] KDTreeFlann::SearchHybrid(q, r, 1)), G lanes per query
 // ----------------------------------------------------------------------------------------------
+// Two costs trade against each other (measured with PMC counters on MI355X): with many lanes per query the per-query
+// set-up and the per-candidate bookkeeping are replicated per wavefront and the kernel becomes VALU-issue bound; with one
+// lane per query the candidate loads of a lane form one long dependent chain and the kernel is latency bound.  So a
+// query is served by a small group of G lanes (template parameter, 2/4/8), each lane keeps FOUR independent 16-B loads
+// in flight, and the candidate test is branch-free.  Ties go to the smaller original index, so the result does not
+// depend on row order, sort order, cell size or G.
+
 template <typename P4>
-struct NNResult {
+struct NNBest {
   typename Scalar<P4>::type d2;
-  int pos;  // position in the sorted target arrays, -1 = none
+  int pos;  // position in the fine-sorted target arrays; -1 = none; -2 = found through the coarse grid (use idx)
   typename Scalar<P4>::index idx;
 };
 
+// branch-free candidate test (the crop predicate, when compiled in, is only evaluated for would-be winners)
 template <typename P4, bool kCrop>
-__device__ __forceinline__ void scan_range(const P4* __restrict__ tp, int s, int e, typename Scalar<P4>::type qx,
-                                           typename Scalar<P4>::type qy, typename Scalar<P4>::type qz, const CropDev& crop,
-                                           NNResult<P4>& best) {
+__device__ __forceinline__ void consider(const P4& t, int p, bool valid, typename Scalar<P4>::type qx, typename Scalar<P4>::type qy,
+                                         typename Scalar<P4>::type qz, const CropDev& crop, NNBest<P4>& best) {
   using R = typename Scalar<P4>::type;
-  for (int p = s; p < e; ++p) {
-    const P4 t = tp[p];
-    const R dx = t.x - qx, dy = t.y - qy, dz = t.z - qz;
-    const R d2 = dx * dx + dy * dy + dz * dz;
-    // strict d2 < best (initially r^2) ; ties broken towards the smaller original index => order-independent result
-    if (d2 < best.d2 || (d2 == best.d2 && t.i < best.idx)) {
-      if (!kCrop || crop_contains(crop, (double)t.x, (double)t.y, (double)t.z)) {
-        best.d2 = d2;
-        best.pos = p;
-        best.idx = t.i;
-      }
-    }
+  const R dx = t.x - qx, dy = t.y - qy, dz = t.z - qz;
+  const R d2 = dx * dx + dy * dy + dz * dz;
+  // strict d2 < best (initially r^2); ties broken towards the smaller original index
+  bool better = valid & ((d2 < best.d2) | ((d2 == best.d2) & (t.i < best.idx)));
+  if (kCrop) {
+    if (better) better = crop_contains(crop, (double)t.x, (double)t.y, (double)t.z);
+  }
+  best.d2 = better ? d2 : best.d2;
+  best.pos = better ? p : best.pos;
+  best.idx = better ? t.i : best.idx;
+}
+
+// candidates s+lane, s+lane+stride, ... of [s,e): four loads issued before the first is consumed
+template <typename P4, bool kCrop, bool kCoarse>
+__device__ __forceinline__ void scan_strided(const P4* __restrict__ tp, int s, int e, int lane, int stride, typename Scalar<P4>::type qx,
+                                             typename Scalar<P4>::type qy, typename Scalar<P4>::type qz, const CropDev& crop,
+                                             NNBest<P4>& best) {
+  for (int p = s + lane; p < e; p += 4 * stride) {
+    const int p1 = p + stride, p2 = p + 2 * stride, p3 = p + 3 * stride;
+    const bool v1 = p1 < e, v2 = p2 < e, v3 = p3 < e;
+    const P4 t0 = tp[p];
+    const P4 t1 = tp[v1 ? p1 : p];
+    const P4 t2 = tp[v2 ? p2 : p];
+    const P4 t3 = tp[v3 ? p3 : p];
+    consider<P4, kCrop>(t0, kCoarse ? -2 : p, true, qx, qy, qz, crop, best);
+    consider<P4, kCrop>(t1, kCoarse ? -2 : p1, v1, qx, qy, qz, crop, best);
+    consider<P4, kCrop>(t2, kCoarse ? -2 : p2, v2, qx, qy, qz, crop, best);
+    consider<P4, kCrop>(t3, kCoarse ? -2 : p3, v3, qx, qy, qz, crop, best);
   }
 }
 
-template <typename P4, bool kCrop>
-__device__ __forceinline__ NNResult<P4> nn_search(const GridDev& g, const P4* __restrict__ tp, typename Scalar<P4>::type qx,
-                                                  typename Scalar<P4>::type qy, typename Scalar<P4>::type qz,
-                                                  typename Scalar<P4>::type r2max, int rmax_cells, const CropDev& crop) {
-  using R = typename Scalar<P4>::type;
-  NNResult<P4> best;
+template <typename P4, int W>
+__device__ __forceinline__ void lanes_min(NNBest<P4>& b) {
+#pragma unroll
+  for (int m = 1; m < W; m <<= 1) {
+    const auto od2 = __shfl_xor(b.d2, m, W);
+    const int opos = __shfl_xor(b.pos, m, W);
+    const auto oidx = __shfl_xor(b.idx, m, W);
+    const bool take = (opos != -1) & ((od2 < b.d2) | ((od2 == b.d2) & (oidx < b.idx)));
+    b.d2 = take ? od2 : b.d2;
+    b.pos = take ? opos : b.pos;
+    b.idx = take ? oidx : b.idx;
+  }
+}
+
+// All G lanes of a group call this with the same query; every lane returns the same winner.
+// The 3x3x3 cell block = 9 rows of <= 3 contiguous cells = 9 contiguous ranges of the cell-sorted target.  Lane l
+// fetches the bounds of rows l, l+G, ..; they are broadcast, and each row's candidates are dealt to the lanes with
+// stride G.  *resolved tells whether the block provably contains the nearest neighbour.
+template <typename P4, bool kCrop, int G>
+__device__ __forceinline__ NNBest<P4> nn_search_group(const GridDev& g, const P4* __restrict__ tp, typename Scalar<P4>::type qx,
+                                                      typename Scalar<P4>::type qy, typename Scalar<P4>::type qz,
+                                                      typename Scalar<P4>::type r2max, int rmax_cells, const CropDev& crop, int gl,
+                                                      bool* resolved) {
+  NNBest<P4> best;
   best.d2 = r2max;
   best.pos = -1;
   best.idx = -1;
@@ -213,46 +254,81 @@ __device__ __forceinline__ NNResult<P4> nn_search(const GridDev& g, const P4* __
   mf = fmin(mf, fmin(fy - fly, 1.0 - (fy - fly)));
   mf = fmin(mf, fmin(fz - flz, 1.0 - (fz - flz)));
   const int* __restrict__ cs = g.cell_start;
-
-  // ---- ring 1: the 3x3x3 block = 9 rows of up to 3 contiguous cells; row bounds are loaded up front
-  {
-    const int x0 = max(ix - 1, 0), x1 = min(ix + 1, g.nx - 1);
-    int rs[9], re[9];
+  const int x0 = max(ix - 1, 0), x1 = min(ix + 1, g.nx - 1);
+  constexpr int kOwn = (9 + G - 1) / G;  // rows whose bounds this lane fetches
+  int s_own[kOwn], e_own[kOwn];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const int y = iy + (k % 3) - 1, z = iz + (k / 3) - 1;
-      const bool ok = x0 <= x1 && (unsigned)y < (unsigned)g.ny && (unsigned)z < (unsigned)g.nz;
-      const int row = ok ? (z * g.ny + y) * g.nx : 0;
-      rs[k] = ok ? cs[row + x0] : 0;
-      re[k] = ok ? cs[row + x1 + 1] : 0;
+  for (int k = 0; k < kOwn; ++k) {
+    const int r = gl + k * G;
+    const int y = iy + (r % 3) - 1, z = iz + (r / 3) - 1;
+    s_own[k] = 0;
+    e_own[k] = 0;
+    if (r < 9 && x0 <= x1 && (unsigned)y < (unsigned)g.ny && (unsigned)z < (unsigned)g.nz) {
+      const int row = (z * g.ny + y) * g.nx;
+      s_own[k] = cs[row + x0];
+      e_own[k] = cs[row + x1 + 1];
     }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) scan_range<P4, kCrop>(tp, rs[k], re[k], qx, qy, qz, crop, best);
   }
-  // ---- rings 2..rmax: only while a closer point could still hide outside the searched block
-  for (int ring = 2; ring <= rmax_cells; ++ring) {
-    const double lb = g.cell * ((double)(ring - 1) + mf) * (1.0 - 1e-6);
-    if ((double)best.d2 <= lb * lb) break;
-    for (int dz = -ring; dz <= ring; ++dz) {
-      const int z = iz + dz;
-      if ((unsigned)z >= (unsigned)g.nz) continue;
-      for (int dy = -ring; dy <= ring; ++dy) {
-        const int y = iy + dy;
-        if ((unsigned)y >= (unsigned)g.ny) continue;
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const int sr = __shfl(s_own[r / G], r % G, G), er = __shfl(e_own[r / G], r % G, G);
+    scan_strided<P4, kCrop, false>(tp, sr, er, gl, G, qx, qy, qz, crop, best);
+  }
+  lanes_min<P4, G>(best);
+  // exactness bound: everything outside the 3x3x3 block is farther than cell*(1 + distance-to-nearest-face)
+  const double lb = g.cell * (1.0 + mf) * (1.0 - 1e-6);
+  *resolved = rmax_cells <= 1 || (double)best.d2 <= lb * lb;
+  return best;
+}
+
+// Far queries (the fine 3x3x3 block could not prove exactness): all 64 lanes of the wavefront search the 3x3x3 block
+// of the COARSE grid (cell >= r, so the block contains every point within r) for ONE query.  Rows and cells that
+// cannot beat the current bound are culled.  Winners found here carry pos = -2 (their point/normal are gathered
+// through the original index).
+template <typename P4, bool kCrop>
+__device__ __forceinline__ void nn_search_wave_coarse(const GridDev& g, const P4* __restrict__ cp, typename Scalar<P4>::type qx,
+                                                      typename Scalar<P4>::type qy, typename Scalar<P4>::type qz, const CropDev& crop,
+                                                      NNBest<P4>& best, int lane) {
+  const double dqx = (double)qx, dqy = (double)qy, dqz = (double)qz;
+  const double lim = 1.0e9;
+  const int ix = (int)fmin(fmax(floor((dqx - g.ox) * g.inv_cell), -lim), lim);
+  const int iy = (int)fmin(fmax(floor((dqy - g.oy) * g.inv_cell), -lim), lim);
+  const int iz = (int)fmin(fmax(floor((dqz - g.oz) * g.inv_cell), -lim), lim);
+  const double bound2 = (double)best.d2 * (1.0 + 1e-5);
+  const int* __restrict__ cs = g.cell_start;
+  int s_own = 0, e_own = 0;
+  if (lane < 9) {
+    const int y = iy + (lane % 3) - 1, z = iz + (lane / 3) - 1;
+    if ((unsigned)y < (unsigned)g.ny && (unsigned)z < (unsigned)g.nz) {
+      const double ylo = g.oy + (double)y * g.cell, zlo = g.oz + (double)z * g.cell;
+      const double ddy = fmax(0.0, fmax(ylo - dqy, dqy - (ylo + g.cell))), ddz = fmax(0.0, fmax(zlo - dqz, dqz - (zlo + g.cell)));
+      const double rowd2 = ddy * ddy + ddz * ddz;
+      int x0 = 1 << 30, x1 = -(1 << 30);
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int x = ix + dx;
+        if ((unsigned)x >= (unsigned)g.nx) continue;
+        const double xlo = g.ox + (double)x * g.cell;
+        const double ddx = fmax(0.0, fmax(xlo - dqx, dqx - (xlo + g.cell)));
+        if (rowd2 + ddx * ddx > bound2) continue;  // no point of this cell can beat the current best
+        x0 = min(x0, x);
+        x1 = max(x1, x);
+      }
+      if (x0 <= x1) {  // kept cells are contiguous: the cell distance grows monotonically away from the query
         const int row = (z * g.ny + y) * g.nx;
-        const bool shell = (dz == -ring || dz == ring || dy == -ring || dy == ring);
-        if (shell) {
-          const int x0 = max(ix - ring, 0), x1 = min(ix + ring, g.nx - 1);
-          if (x0 <= x1) scan_range<P4, kCrop>(tp, cs[row + x0], cs[row + x1 + 1], qx, qy, qz, crop, best);
-        } else {
-          const int xl = ix - ring, xr = ix + ring;
-          if ((unsigned)xl < (unsigned)g.nx) scan_range<P4, kCrop>(tp, cs[row + xl], cs[row + xl + 1], qx, qy, qz, crop, best);
-          if ((unsigned)xr < (unsigned)g.nx) scan_range<P4, kCrop>(tp, cs[row + xr], cs[row + xr + 1], qx, qy, qz, crop, best);
-        }
+        s_own = cs[row + x0];
+        e_own = cs[row + x1 + 1];
       }
     }
   }
-  return best;
+  NNBest<P4> mine = best;
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const int sr = __shfl(s_own, r, 64), er = __shfl(e_own, r, 64);
+    scan_strided<P4, kCrop, true>(cp, sr, er, lane, 64, qx, qy, qz, crop, mine);
+  }
+  lanes_min<P4, 64>(mine);
+  best = mine;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -261,102 +337,172 @@ __device__ __forceinline__ NNResult<P4> nn_search(const GridDev& g, const P4* __
 struct IcpPassArgs {
   const void* src;   // P4[n_src]
   size_t first, count;
-  const void* tpts;  // sorted target points
-  const void* tnrm;  // sorted target normals
-  GridDev grid;
+  const void* tpts;  // target points sorted by fine cell
+  const void* tnrm;  // target normals, same order
+  GridDev grid;      // fine grid (cell = r/4 by default): ring-1 search, 8 lanes per query
+  const void* cpts;  // target points sorted by coarse cell (null when the fine cell already covers r)
+  GridDev coarse;    // coarse grid (cell >= r): far queries, 64 lanes per query
+  const void* opts;  // target points / normals in original order (winners of the coarse search)
+  const void* onrm;
   CropDev crop;
   double r2max;
   int rmax_cells;
   const IcpStateDev* state;
   double* partials;  // [gridDim.x][kRec]
+  int debug;         // timing experiments only (O3DS_DEBUG_ACC): 1 = exit after prologue, 2 = no search, 3 = no winner gather
 };
 
-template <typename P4, bool kCrop>
-__global__ __launch_bounds__(kBlock) void icp_accumulate_kernel(IcpPassArgs a) {
+// Per-query record staged in LDS: {J0..J5, r, one, d2, 0}.  Every entry of the 32-double normal-equation record is a
+// product of two slots: JtJ[a][b] = J[a]*J[b], Jtr[a] = J[a]*r, sum r^2 = r*r, count = one*one, sum d^2 = d2*one.
+constexpr int kRecSlots = 10;
+__device__ const unsigned char kTermA[kRec] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9};
+__device__ const unsigned char kTermB[kRec] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5, 6, 6, 6, 6, 6, 6, 6, 7, 7, 9, 9};
+
+// Workgroup = BLOCK threads = BLOCK/G queries x G lanes for the search, then (32 record terms) x (BLOCK/32 query slices) for the
+// accumulation: one f64 accumulator per thread instead of 30, so the kernel stays small in registers and the chip can
+// keep enough wavefronts in flight to hide the dependent-load latency of the search.
+template <typename P4, bool kCrop, int kPassBlock, int kGroup>
+__global__ __launch_bounds__(kPassBlock) void icp_accumulate_kernel(IcpPassArgs a) {
+  constexpr int kQPB = kPassBlock / kGroup;
   using R = typename Scalar<P4>::type;
   if (a.state->done) return;  // device-side loop already terminated: keep the previous partials
+  __shared__ double s_rec[kQPB][kRecSlots];
+  __shared__ double s_red[kPassBlock / 32][kRec];
   const P4* __restrict__ src = (const P4*)a.src;
   const P4* __restrict__ tp = (const P4*)a.tpts;
   const P4* __restrict__ tn = (const P4*)a.tnrm;
   const double* T = a.state->T;  // column-major
   const double t00 = T[0], t10 = T[1], t20 = T[2], t01 = T[4], t11 = T[5], t21 = T[6], t02 = T[8], t12 = T[9], t22 = T[10],
                t03 = T[12], t13 = T[13], t23 = T[14];
-  double acc[30];
-#pragma unroll
-  for (int k = 0; k < 30; ++k) acc[k] = 0.0;
-
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < a.count; i += (size_t)gridDim.x * kBlock) {
-    const P4 s = src[a.first + i];
-    // [O3D] PointCloud::Transform: rigid 4x4 (bottom row 0 0 0 1 for every pose the reference passes)
-    const double px = t00 * (double)s.x + t01 * (double)s.y + t02 * (double)s.z + t03;
-    const double py = t10 * (double)s.x + t11 * (double)s.y + t12 * (double)s.z + t13;
-    const double pz = t20 * (double)s.x + t21 * (double)s.y + t22 * (double)s.z + t23;
-    const NNResult<P4> nn = nn_search<P4, kCrop>(a.grid, tp, (R)px, (R)py, (R)pz, (R)a.r2max, a.rmax_cells, a.crop);
-    if (nn.pos >= 0) {
-      const P4 q = tp[nn.pos];
-      const P4 nq = tn[nn.pos];
-      const double dx = px - (double)q.x, dy = py - (double)q.y, dz = pz - (double)q.z;
-      const double nx = (double)nq.x, ny = (double)nq.y, nz = (double)nq.z;
-      const double r = dx * nx + dy * ny + dz * nz;  // (p - q) . n
-      double J[6];
-      J[0] = py * nz - pz * ny;  // p x n
-      J[1] = pz * nx - px * nz;
-      J[2] = px * ny - py * nx;
-      J[3] = nx;
-      J[4] = ny;
-      J[5] = nz;
-      int k = 0;
-#pragma unroll
-      for (int r0 = 0; r0 < 6; ++r0)
-#pragma unroll
-        for (int c0 = r0; c0 < 6; ++c0) acc[k++] += J[r0] * J[c0];
-#pragma unroll
-      for (int r0 = 0; r0 < 6; ++r0) acc[21 + r0] += J[r0] * r;
-      acc[kRecR2] += r * r;
-      acc[kRecCount] += 1.0;
-      acc[kRecD2] += dx * dx + dy * dy + dz * dz;
+  const int gl = threadIdx.x & (kGroup - 1), ql = threadIdx.x / kGroup;
+  const int term = threadIdx.x & 31, qs = threadIdx.x >> 5;
+  const int ta = kTermA[term], tb = kTermB[term];
+  double acc = 0.0;
+  if (a.debug == 1) {
+    if (threadIdx.x < kRec) a.partials[(size_t)blockIdx.x * kRec + threadIdx.x] = t00 * 1e-300;
+    return;
+  }
+  const size_t n_batches = (a.count + kQPB - 1) / kQPB;
+  for (size_t b = blockIdx.x; b < n_batches; b += gridDim.x) {
+    const size_t i = b * kQPB + ql;
+    double px = 0, py = 0, pz = 0;
+    NNBest<P4> nn;
+    nn.pos = -1;
+    nn.idx = -1;
+    nn.d2 = (R)0;
+    bool unresolved = false;
+    if (i < a.count) {  // uniform across the 8 lanes of a group
+      const P4 s = src[a.first + i];
+      // [O3D] PointCloud::Transform: rigid 4x4 (bottom row 0 0 0 1 for every pose the reference passes)
+      px = t00 * (double)s.x + t01 * (double)s.y + t02 * (double)s.z + t03;
+      py = t10 * (double)s.x + t11 * (double)s.y + t12 * (double)s.z + t13;
+      pz = t20 * (double)s.x + t21 * (double)s.y + t22 * (double)s.z + t23;
+      bool resolved = true;
+      if (a.debug == 2) {
+        nn.pos = (int)(i % 1000);
+        nn.idx = nn.pos;
+      } else
+      nn = nn_search_group<P4, kCrop, kGroup>(a.grid, tp, (R)px, (R)py, (R)pz, (R)a.r2max, a.rmax_cells, a.crop, gl, &resolved);
+      unresolved = !resolved;
     }
-  }
-  // wavefront reduction, then 4 waves -> 1 through LDS; fixed order => bitwise reproducible per launch geometry
-  __shared__ double s_part[kBlock / 64][kRec];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // far queries of this wavefront, one after the other, 64 lanes each (wave-uniform loop)
+    {
+      const int lane = threadIdx.x & 63;
+      unsigned long long m = __ballot(unresolved && gl == 0);
+      while (m) {
+        const int sl = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        NNBest<P4> b;
+        b.d2 = __shfl(nn.d2, sl, 64);
+        b.pos = __shfl(nn.pos, sl, 64);
+        b.idx = __shfl(nn.idx, sl, 64);
+        const R bx = __shfl((R)px, sl, 64), by = __shfl((R)py, sl, 64), bz = __shfl((R)pz, sl, 64);
+        nn_search_wave_coarse<P4, kCrop>(a.coarse, (const P4*)a.cpts, bx, by, bz, a.crop, b, lane);
+        if ((lane & ~(kGroup - 1)) == sl) nn = b;
+      }
+    }
+    if (gl == 0) {
+      double* rec = s_rec[ql];
+      if (nn.pos != -1) {
+        if (a.debug == 3) nn.pos = (int)(i % 1000);
+        const P4 q = nn.pos >= 0 ? tp[nn.pos] : ((const P4*)a.opts)[nn.idx];
+        const P4 nq = nn.pos >= 0 ? tn[nn.pos] : ((const P4*)a.onrm)[nn.idx];
+        const double dx = px - (double)q.x, dy = py - (double)q.y, dz = pz - (double)q.z;
+        const double nx = (double)nq.x, ny = (double)nq.y, nz = (double)nq.z;
+        rec[0] = py * nz - pz * ny;  // J = [p x n ; n]
+        rec[1] = pz * nx - px * nz;
+        rec[2] = px * ny - py * nx;
+        rec[3] = nx;
+        rec[4] = ny;
+        rec[5] = nz;
+        rec[6] = dx * nx + dy * ny + dz * nz;  // r = (p - q) . n
+        rec[7] = 1.0;
+        rec[8] = dx * dx + dy * dy + dz * dz;
+        rec[9] = 0.0;
+      } else {
 #pragma unroll
-  for (int k = 0; k < 30; ++k) {
-    const double v = wave_sum(acc[k]);
-    if (lane == 0) s_part[w][k] = v;
+        for (int k = 0; k < kRecSlots; ++k) rec[k] = 0.0;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int qq = 0; qq < kQPB / (kPassBlock / 32); ++qq) {
+      const double* rec = s_rec[qs * (kQPB / (kPassBlock / 32)) + qq];
+      acc += rec[ta] * rec[tb];
+    }
+    __syncthreads();  // s_rec is rewritten by the next batch
   }
+  // 16 query slices -> 1, fixed order => bitwise reproducible for a given launch geometry
+  s_red[qs][term] = acc;
   __syncthreads();
   if (threadIdx.x < kRec) {
     double v = 0.0;
-    if (threadIdx.x < 30) {
-      for (int k = 0; k < kBlock / 64; ++k) v += s_part[k][threadIdx.x];
-    }
-    a.partials[(size_t)blockIdx.x * kRec + threadIdx.x] = v;
+#pragma unroll
+    for (int k = 0; k < kPassBlock / 32; ++k) v += s_red[k][threadIdx.x];
+    a.partials[(size_t)blockIdx.x * kRec + threadIdx.x] = threadIdx.x < 30 ? v : 0.0;
   }
 }
 
-// sum the per-block partial records into one 32-double record (fixed order)
-__device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int nblocks, double* s_rec /* LDS [8][32] */,
-                                                double* rec_out /* LDS [32] */) {
-  const int col = threadIdx.x & 31, part = threadIdx.x >> 5;  // 8 parts x 32 columns
+// ----------------------------------------------------------------------------------------------
+// per-pass serial tail: sum the partial records, convergence test, 6x6 solve, T <- U*T   (one workgroup)
+// ----------------------------------------------------------------------------------------------
+constexpr int kUpdBlock = 1024;
+
+// sum the per-block partial records into one 32-double record (fixed order); result in s_out[0..31].
+// The rows were written by other CUs/XCDs and come from memory, so each dependent load round costs ~1 us: all (<= 32) loads
+// of a thread are issued before the first add (measured: an add-per-load loop took 10 us, 8-deep batches 8 us).
+__device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int nrows, double* s_part /* [32][32] */,
+                                                double* s_out /* [32] */) {
+  constexpr int kParts = kUpdBlock / 32;
+  const int col = threadIdx.x & 31, part = threadIdx.x >> 5;  // 32 parts x 32 columns
   double v = 0.0;
-  for (int b = part; b < nblocks; b += kBlock / 32) v += partials[(size_t)b * kRec + col];
-  s_rec[part * kRec + col] = v;
+  for (int b0 = part; b0 < nrows; b0 += 32 * kParts) {
+    double x[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      const int b = b0 + k * kParts;
+      x[k] = b < nrows ? partials[(size_t)b * kRec + col] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 32; ++k) v += x[k];
+  }
+  s_part[part * kRec + col] = v;
   __syncthreads();
   if (threadIdx.x < kRec) {
     double t = 0.0;
-    for (int k = 0; k < kBlock / 32; ++k) t += s_rec[k * kRec + threadIdx.x];
-    rec_out[threadIdx.x] = t;
+#pragma unroll
+    for (int k = 0; k < kParts; ++k) t += s_part[k * kRec + threadIdx.x];
+    s_out[threadIdx.x] = t;
   }
   __syncthreads();
 }
 
-__global__ __launch_bounds__(kBlock) void icp_reduce_kernel(const double* __restrict__ partials, int nblocks, const IcpStateDev* state,
-                                                            double* __restrict__ record) {
+__global__ __launch_bounds__(kUpdBlock) void icp_reduce_kernel(const double* __restrict__ partials, int nrows, const IcpStateDev* state,
+                                                               double* __restrict__ record) {
   if (state->done) return;
-  __shared__ double s_rec[(kBlock / 32) * kRec];
+  __shared__ double s_part[(kUpdBlock / 32) * kRec];
   __shared__ double s_out[kRec];
-  reduce_partials(partials, nblocks, s_rec, s_out);
+  reduce_partials(partials, nrows, s_part, s_out);
   if (threadIdx.x < kRec) record[threadIdx.x] = s_out[threadIdx.x];
 }
 
@@ -472,65 +618,110 @@ __host__ __device__ inline void solve6_ldlt(const double* rec, double x[6]) {
 }
 
 // [O3D] RegistrationICP loop body after the correspondence pass: convergence test, solve, T <- U*T.
-__device__ inline void icp_step_from_record(const double* rec, IcpStateDev* st, unsigned long long n_src_total, int max_iter,
-                                            double rel_fitness, double rel_rmse) {
-  const double count = rec[kRecCount];
-  const double fitness = count > 0.0 ? count / (double)n_src_total : 0.0;
-  const double rmse = count > 0.0 ? sqrt(rec[kRecD2] / count) : 0.0;
-  bool conv = false;
-  if (st->pass > 0) conv = fabs(st->fitness - fitness) < rel_fitness && fabs(st->rmse - rmse) < rel_rmse;
-  st->fitness = fitness;
-  st->rmse = rmse;
-  st->n_corr = (unsigned long long)(count + 0.5);
-  st->pass += 1;
-  if (conv) {
-    st->converged = 1;
-    st->done = 1;
-    return;
-  }
-  if (st->iterations >= max_iter) {
-    st->done = 1;
-    return;
-  }
-  double U[16];
-  if (count > 0.0) {
-    double x[6];
-    solve6_ldlt(rec, x);
-    vector6_to_matrix4(x, U);
-  } else {  // empty correspondence set => identity update
-    for (int i = 0; i < 16; ++i) U[i] = (i % 5 == 0) ? 1.0 : 0.0;
-  }
-  double Tn[16];
-  for (int c = 0; c < 4; ++c)
-    for (int r = 0; r < 4; ++r) {
-      double s = 0.0;
-      for (int k = 0; k < 4; ++k) s += U[k * 4 + r] * st->T[c * 4 + k];
-      Tn[c * 4 + r] = s;
+// Called by every thread of one workgroup (>= 64 threads) with the record in LDS.  Thread 0 runs the scalar part
+// (statistics, convergence, LDL^T); the trigonometry and the 4x4 products are spread over lanes because f64
+// sin/cos and divides are long dependent chains and this tail is on the critical path of every iteration.
+__device__ __forceinline__ void icp_step_block(const double* s_rec, IcpStateDev* st, unsigned long long n_src_total, int max_iter,
+                                               double rel_fitness, double rel_rmse, double* s_x /* [8] */, double* s_sc /* [8] */,
+                                               double* s_U /* [16] */, double* s_T /* [16] */, int* s_go) {
+  if (threadIdx.x == 0) {
+    const double count = s_rec[kRecCount];
+    const double fitness = count > 0.0 ? count / (double)n_src_total : 0.0;
+    const double rmse = count > 0.0 ? sqrt(s_rec[kRecD2] / count) : 0.0;
+    bool conv = false;
+    if (st->pass > 0) conv = fabs(st->fitness - fitness) < rel_fitness && fabs(st->rmse - rmse) < rel_rmse;
+    st->fitness = fitness;
+    st->rmse = rmse;
+    st->n_corr = (unsigned long long)(count + 0.5);
+    st->pass += 1;
+    int go = 0;
+    if (conv) {
+      st->converged = 1;
+      st->done = 1;
+    } else if (st->iterations >= max_iter) {
+      st->done = 1;
+    } else {
+      go = 1;
+      double x[6] = {0, 0, 0, 0, 0, 0};  // empty correspondence set => identity update
+      if (count > 0.0) solve6_ldlt(s_rec, x);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) s_x[k] = x[k];
     }
-  for (int i = 0; i < 16; ++i) st->T[i] = Tn[i];
-  st->iterations += 1;
+    *s_go = go;
+  }
+  if (threadIdx.x < 16) s_T[threadIdx.x] = st->T[threadIdx.x];
+  __syncthreads();
+  if (!*s_go) return;
+  if (threadIdx.x < 3) {
+    double sn, cs;
+    sincos(s_x[threadIdx.x], &sn, &cs);
+    s_sc[threadIdx.x] = sn;
+    s_sc[4 + threadIdx.x] = cs;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {  // [O3D] TransformVector6dToMatrix4d: R = Rz(x2) Ry(x1) Rx(x0), t = x[3:6]; column-major
+    const double sa = s_sc[0], sb = s_sc[1], sg = s_sc[2], ca = s_sc[4], cb = s_sc[5], cg = s_sc[6];
+    double v;
+    switch (threadIdx.x) {
+      case 0: v = cg * cb; break;
+      case 1: v = sg * cb; break;
+      case 2: v = -sb; break;
+      case 4: v = cg * sb * sa - sg * ca; break;
+      case 5: v = sg * sb * sa + cg * ca; break;
+      case 6: v = cb * sa; break;
+      case 8: v = cg * sb * ca + sg * sa; break;
+      case 9: v = sg * sb * ca - cg * sa; break;
+      case 10: v = cb * ca; break;
+      case 12: v = s_x[3]; break;
+      case 13: v = s_x[4]; break;
+      case 14: v = s_x[5]; break;
+      case 15: v = 1.0; break;
+      default: v = 0.0; break;
+    }
+    s_U[threadIdx.x] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {  // T <- U * T
+    const int c = threadIdx.x >> 2, r = threadIdx.x & 3;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s += s_U[k * 4 + r] * s_T[c * 4 + k];
+    st->T[threadIdx.x] = s;
+  }
+  if (threadIdx.x == 0) st->iterations += 1;
 }
 
 // single-GPU path: reduce the partials and step, one workgroup
-__global__ __launch_bounds__(kBlock) void icp_reduce_update_kernel(const double* __restrict__ partials, int nblocks, IcpStateDev* state,
-                                                                   unsigned long long n_src_total, int max_iter, double rel_fitness,
-                                                                   double rel_rmse) {
+__global__ __launch_bounds__(kUpdBlock) void icp_reduce_update_kernel(const double* __restrict__ partials, int nrows, IcpStateDev* state,
+                                                                      unsigned long long n_src_total, int max_iter, double rel_fitness,
+                                                                      double rel_rmse, int debug_mode) {
   if (state->done) return;
-  __shared__ double s_rec[(kBlock / 32) * kRec];
+  if (debug_mode == 1) {  // timing experiment: launch + done check only
+    if (threadIdx.x == 0) { state->pass += 1; state->iterations += 1; if (state->iterations > max_iter) state->done = 1; }
+    return;
+  }
+  __shared__ double s_part[(kUpdBlock / 32) * kRec];
   __shared__ double s_out[kRec];
-  reduce_partials(partials, nblocks, s_rec, s_out);
-  if (threadIdx.x == 0) icp_step_from_record(s_out, state, n_src_total, max_iter, rel_fitness, rel_rmse);
+  __shared__ double s_x[8], s_sc[8], s_U[16], s_T[16];
+  __shared__ int s_go;
+  reduce_partials(partials, nrows, s_part, s_out);
+  if (debug_mode == 2) {  // timing experiment: reduction only
+    if (threadIdx.x == 0) { state->pass += 1; state->iterations += 1; state->fitness = s_out[28]; if (state->iterations > max_iter) state->done = 1; }
+    return;
+  }
+  icp_step_block(s_out, state, n_src_total, max_iter, rel_fitness, rel_rmse, s_x, s_sc, s_U, s_T, &s_go);
 }
 
 // sharded path: the record was all-reduced by the caller
-__global__ void icp_update_kernel(const double* __restrict__ record, IcpStateDev* state, unsigned long long n_src_total, int max_iter,
-                                  double rel_fitness, double rel_rmse) {
+__global__ __launch_bounds__(64) void icp_update_kernel(const double* __restrict__ record, IcpStateDev* state, unsigned long long n_src_total,
+                                                        int max_iter, double rel_fitness, double rel_rmse) {
   if (state->done) return;
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double rec[kRec];
-    for (int i = 0; i < kRec; ++i) rec[i] = record[i];
-    icp_step_from_record(rec, state, n_src_total, max_iter, rel_fitness, rel_rmse);
-  }
+  __shared__ double s_out[kRec];
+  __shared__ double s_x[8], s_sc[8], s_U[16], s_T[16];
+  __shared__ int s_go;
+  if (threadIdx.x < kRec) s_out[threadIdx.x] = record[threadIdx.x];
+  __syncthreads();
+  icp_step_block(s_out, state, n_src_total, max_iter, rel_fitness, rel_rmse, s_x, s_sc, s_U, s_T, &s_go);
 }
 
 }  // namespace o3ds

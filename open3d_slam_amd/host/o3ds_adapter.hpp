@@ -1,0 +1,410 @@
+// o3ds_adapter.hpp -- C++ host side of the drop-in: the reference's own hot-path classes, re-implemented over the
+// C-ABI of include/o3ds_backend.h.  Same names, members, argument meaning and error behaviour
+// (std::runtime_error where the reference's assert_* / Open3D LogError throw) as:
+//   CloudRegistration / RegistrationIcpPointToPlane / cloudRegistrationFactory
+//        include/open3d_slam/CloudRegistration.hpp:19-42, src/CloudRegistration.cpp:44-65,85-100
+//   CroppingVolume family / croppingVolumeFactory      include/open3d_slam/croppers.hpp:26-47, src/croppers.cpp
+//   voxelize / voxelizeWithinCroppingVolume / transform include/open3d_slam/helpers.hpp:20-25, src/helpers.cpp:107-183,273-305
+//   ScanToMapIcp (device-resident map variant)          src/ScanToMapRegistration.cpp:35-62, src/Submap.cpp:39-75
+// Header-only; link with -lo3ds_backend.  One backend handle per calling thread (thread_local), because the reference
+// calls registerClouds concurrently from odometry / mapping / loop-closure threads (SlamWrapper.cpp:258-347,406-448).
+#pragma once
+#include <cmath>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/o3ds_backend.h"
+#ifdef O3DS_USE_OPEN3D
+#include <open3d/geometry/PointCloud.h>
+#include <open3d/pipelines/registration/Registration.h>
+#include "open3d_slam/Transform.hpp"
+#else
+#include "o3ds_standalone_types.hpp"
+#endif
+
+namespace o3d_slam {
+
+using PointCloud = open3d::geometry::PointCloud;
+using PointCloudPtr = std::shared_ptr<PointCloud>;
+using RegistrationResult = open3d::pipelines::registration::RegistrationResult;
+
+// ---- Parameters (include/open3d_slam/Parameters.hpp:37-76,94-98; same names and defaults) -------------------------
+enum class CloudRegistrationType : int { PointToPlaneIcp, PointToPointIcp, GeneralizedIcp };
+struct ScanCroppingParameters {
+  double croppingMinZ_ = -10.0, croppingMaxZ_ = 10.0, croppingMinRadius_ = 0.0, croppingMaxRadius_ = 20.0;
+  std::string cropperName_ = "MaxRadius";
+};
+struct IcpParameters {
+  int maxNumIter_ = 50;
+  double maxCorrespondenceDistance_ = 0.2;
+  int knn_ = 5;
+  double maxDistanceKnn_ = 10.0;
+};
+struct CloudRegistrationParameters {
+  CloudRegistrationType regType_ = CloudRegistrationType::PointToPlaneIcp;
+  IcpParameters icp_;
+};
+
+namespace o3ds_detail {
+
+inline const double* xyz(const std::vector<decltype(PointCloud::points_)::value_type>& v) {
+  return v.empty() ? nullptr : reinterpret_cast<const double*>(v.data());
+}
+inline const double* pose_data(const Transform& T) {
+#ifdef O3DS_USE_OPEN3D
+  return T.matrix().data();
+#else
+  return T.data();
+#endif
+}
+
+// RAII handle, one per thread.  Errors become std::runtime_error like the reference's assert_* (assert.hpp:13-64).
+class Handle {
+ public:
+  static o3ds_handle get() {
+    thread_local Handle h;
+    return h.h_;
+  }
+  static void check(int rc) {
+    if (rc != O3DS_OK) throw std::runtime_error(std::string("o3ds: ") + o3ds_last_error(rc == O3DS_ERR_BAD_HANDLE ? nullptr : get_nothrow()));
+  }
+
+ private:
+  static o3ds_handle get_nothrow() {
+    try {
+      return get();
+    } catch (...) {
+      return nullptr;
+    }
+  }
+  Handle() {
+    const int rc = o3ds_create(0, &h_);
+    if (rc != O3DS_OK) throw std::runtime_error(std::string("o3ds_create: ") + o3ds_last_error(nullptr));
+  }
+  ~Handle() {
+    if (h_) o3ds_destroy(h_);
+  }
+  o3ds_handle h_ = nullptr;
+};
+
+// scoped device cloud
+class DevCloud {
+ public:
+  DevCloud() = default;
+  explicit DevCloud(const PointCloud& c) {
+    Handle::check(o3ds_cloud_upload(Handle::get(), xyz(c.points_), c.HasNormals() ? xyz(c.normals_) : nullptr, c.points_.size(), &id_));
+  }
+  explicit DevCloud(o3ds_cloud id) : id_(id) {}
+  DevCloud(const DevCloud&) = delete;
+  DevCloud& operator=(const DevCloud&) = delete;
+  DevCloud(DevCloud&& o) noexcept : id_(o.id_) { o.id_ = 0; }
+  DevCloud& operator=(DevCloud&& o) noexcept {
+    reset();
+    id_ = o.id_;
+    o.id_ = 0;
+    return *this;
+  }
+  ~DevCloud() { reset(); }
+  void reset() {
+    if (id_) o3ds_cloud_free(Handle::get(), id_);
+    id_ = 0;
+  }
+  o3ds_cloud id() const { return id_; }
+  o3ds_cloud release() {  // forget the id without freeing it (borrowed clouds)
+    const o3ds_cloud i = id_;
+    id_ = 0;
+    return i;
+  }
+  size_t size() const {
+    size_t n = 0;
+    Handle::check(o3ds_cloud_size(Handle::get(), id_, &n, nullptr));
+    return n;
+  }
+  void download(PointCloud* out) const {
+    size_t n = 0;
+    int hn = 0;
+    Handle::check(o3ds_cloud_size(Handle::get(), id_, &n, &hn));
+    out->points_.resize(n);
+    out->normals_.resize(hn ? n : 0);
+    if (n)
+      Handle::check(o3ds_cloud_download(Handle::get(), id_, reinterpret_cast<double*>(out->points_.data()),
+                                        hn ? reinterpret_cast<double*>(out->normals_.data()) : nullptr, n));
+  }
+
+ private:
+  o3ds_cloud id_ = 0;
+};
+
+}  // namespace o3ds_detail
+
+// ---- croppers (croppers.hpp:26-47) ---------------------------------------------------------------------------------
+enum class CroppingVolumeEnum : int { MaxRadius, MinRadius, Cylinder, MinMaxRadius };
+static const std::map<std::string, CroppingVolumeEnum> cropperNames{{"MaxRadius", CroppingVolumeEnum::MaxRadius},
+                                                                    {"MinRadius", CroppingVolumeEnum::MinRadius},
+                                                                    {"Cylinder", CroppingVolumeEnum::Cylinder},
+                                                                    {"MinMaxRadius", CroppingVolumeEnum::MinMaxRadius}};
+
+class CroppingVolume {
+ public:
+  virtual ~CroppingVolume() = default;
+  virtual void setScaling(double) {}
+  void setIsInvertVolume(bool v) { isInvertVolume_ = v; }
+  void setPose(const Transform& pose) { pose_ = pose; }
+  // o3ds_crop of this volume: only pose_.translation() enters the predicate (croppers.cpp:121-165)
+  o3ds_crop toAbi() const {
+    o3ds_crop c{};
+    fill(&c);
+    c.invert = isInvertVolume_ ? 1 : 0;
+    const double* m = o3ds_detail::pose_data(pose_);
+    c.center[0] = m[12];
+    c.center[1] = m[13];
+    c.center[2] = m[14];
+    return c;
+  }
+  // CroppingVolume::crop (croppers.cpp:76-106)
+  std::shared_ptr<PointCloud> crop(const PointCloud& cloud) const {
+    auto out = std::make_shared<PointCloud>();
+    if (cloud.points_.empty()) return out;
+    o3ds_detail::DevCloud in(cloud);
+    const o3ds_crop c = toAbi();
+    o3ds_cloud o = 0;
+    o3ds_detail::Handle::check(o3ds_crop_cloud(o3ds_detail::Handle::get(), in.id(), &c, &o));
+    o3ds_detail::DevCloud(o).download(out.get());
+    return out;
+  }
+  void crop(PointCloud* cloud) const { *cloud = std::move(*crop(*cloud)); }
+
+ protected:
+  virtual void fill(o3ds_crop* c) const { c->kind = O3DS_CROP_NONE; }
+  Transform pose_ = Transform::Identity();
+  bool isInvertVolume_ = false;
+};
+class MinMaxRadiusCroppingVolume : public CroppingVolume {
+ public:
+  MinMaxRadiusCroppingVolume() = default;
+  MinMaxRadiusCroppingVolume(double radiusMin, double radiusMax) : radiusMin_(radiusMin), radiusMax_(radiusMax) {}
+  void setParameters(double radiusMin, double radiusMax) { radiusMin_ = radiusMin, radiusMax_ = radiusMax; }
+
+ private:
+  void fill(o3ds_crop* c) const final { c->kind = O3DS_CROP_MIN_MAX_RADIUS, c->rmin = radiusMin_, c->rmax = radiusMax_; }
+  double radiusMin_ = 0.0, radiusMax_ = 1e4;
+};
+class MaxRadiusCroppingVolume : public CroppingVolume {
+ public:
+  MaxRadiusCroppingVolume() = default;
+  explicit MaxRadiusCroppingVolume(double radius) : radius_(radius) {}
+  void setParameters(double radius) { radius_ = radius; }
+
+ private:
+  void fill(o3ds_crop* c) const final { c->kind = O3DS_CROP_MAX_RADIUS, c->rmax = radius_; }
+  double radius_ = 1e4;
+};
+class MinRadiusCroppingVolume : public CroppingVolume {
+ public:
+  MinRadiusCroppingVolume() = default;
+  explicit MinRadiusCroppingVolume(double radius) : radius_(radius) {}
+  void setParameters(double radius) { radius_ = radius; }
+
+ private:
+  void fill(o3ds_crop* c) const final { c->kind = O3DS_CROP_MIN_RADIUS, c->rmin = radius_; }
+  double radius_ = 0.0;
+};
+class CylinderCroppingVolume : public CroppingVolume {
+ public:
+  CylinderCroppingVolume() = default;
+  CylinderCroppingVolume(double radius, double minZ, double maxZ) : radius_(radius), minZ_(minZ), maxZ_(maxZ) {}
+  void setParameters(double radius, double minZ, double maxZ) { radius_ = radius, minZ_ = minZ, maxZ_ = maxZ; }
+
+ private:
+  void fill(o3ds_crop* c) const final { c->kind = O3DS_CROP_CYLINDER, c->rmax = radius_, c->zmin = minZ_, c->zmax = maxZ_; }
+  double radius_ = 1e4, minZ_ = -1e4, maxZ_ = 1e4;
+};
+
+inline std::unique_ptr<CroppingVolume> croppingVolumeFactory(CroppingVolumeEnum type, const ScanCroppingParameters& p) {  // croppers.cpp:23-47
+  switch (type) {
+    case CroppingVolumeEnum::Cylinder:
+      return std::make_unique<CylinderCroppingVolume>(p.croppingMaxRadius_, p.croppingMinZ_, p.croppingMaxZ_);
+    case CroppingVolumeEnum::MinRadius:
+      return std::make_unique<MinRadiusCroppingVolume>(p.croppingMinRadius_);
+    case CroppingVolumeEnum::MaxRadius:
+      return std::make_unique<MaxRadiusCroppingVolume>(p.croppingMaxRadius_);
+    case CroppingVolumeEnum::MinMaxRadius:
+      return std::make_unique<MinMaxRadiusCroppingVolume>(p.croppingMinRadius_, p.croppingMaxRadius_);
+    default:
+      throw std::runtime_error("Unknown cropper type");
+  }
+}
+inline std::unique_ptr<CroppingVolume> croppingVolumeFactory(const ScanCroppingParameters& p) {  // croppers.cpp:20-22
+  return croppingVolumeFactory(cropperNames.at(p.cropperName_), p);
+}
+
+// ---- CloudRegistration seam (CloudRegistration.hpp:19-42) ----------------------------------------------------------
+class CloudRegistration {
+ public:
+  using RegistrationResult = open3d::pipelines::registration::RegistrationResult;
+  CloudRegistration() = default;
+  virtual ~CloudRegistration() = default;
+  virtual RegistrationResult registerClouds(const PointCloud& source, const PointCloud& target, const Transform& init) const = 0;
+  virtual void estimateNormalsOrCovariancesIfNeeded(PointCloud* cloud) const {}
+};
+
+class RegistrationIcpPointToPlane : public CloudRegistration {
+ public:
+  // CloudRegistration.cpp:44-48: RegistrationICP(source, target, maxCorrespondenceDistance_, init, pointToPlane_, criteria)
+  RegistrationResult registerClouds(const PointCloud& source, const PointCloud& target, const Transform& init) const final {
+    o3ds_icp_params p{};
+    p.max_correspondence_distance = maxCorrespondenceDistance_;
+    p.max_iteration = icpConvergenceCriteria_.max_iteration_;
+    p.relative_fitness = icpConvergenceCriteria_.relative_fitness_;
+    p.relative_rmse = icpConvergenceCriteria_.relative_rmse_;
+    o3ds_icp_result r{};
+    o3ds_detail::Handle::check(o3ds_icp_point_to_plane(o3ds_detail::Handle::get(), o3ds_detail::xyz(source.points_), source.points_.size(),
+                                                       o3ds_detail::xyz(target.points_),
+                                                       target.HasNormals() ? o3ds_detail::xyz(target.normals_) : nullptr,
+                                                       target.points_.size(), o3ds_detail::pose_data(init), &p, &r));
+    return toResult(r);
+  }
+  // CloudRegistration.cpp:49-56
+  void estimateNormalsOrCovariancesIfNeeded(PointCloud* cloud) const final {
+    if (!(maxRadiusNormalEstimation_ > 0.0)) throw std::runtime_error("maxRadiusNormalEstimation_");  // assert_gt
+    if (!(knnNormalEstimation_ > 0)) throw std::runtime_error("knnNormalEstimation_");
+    if (cloud->points_.empty()) return;
+    PointCloud bare;
+    bare.points_ = cloud->points_;
+    o3ds_detail::DevCloud d(bare);
+    o3ds_detail::Handle::check(o3ds_estimate_normals(o3ds_detail::Handle::get(), d.id(), maxRadiusNormalEstimation_, knnNormalEstimation_));
+    d.download(cloud);
+  }
+  static RegistrationResult toResult(const o3ds_icp_result& r) {
+    RegistrationResult out;
+#ifdef O3DS_USE_OPEN3D
+    out.transformation_ = Eigen::Map<const Eigen::Matrix4d>(r.transformation);
+#else
+    for (int i = 0; i < 16; ++i) out.transformation_[i] = r.transformation[i];
+#endif
+    out.fitness_ = r.fitness;
+    out.inlier_rmse_ = r.inlier_rmse;
+    return out;
+  }
+
+  double maxCorrespondenceDistance_ = 1.0;
+  int knnNormalEstimation_ = 10;
+  double maxRadiusNormalEstimation_ = 2.0;
+  open3d::pipelines::registration::ICPConvergenceCriteria icpConvergenceCriteria_;
+};
+
+inline std::unique_ptr<RegistrationIcpPointToPlane> createPointToPlaneIcp(const CloudRegistrationParameters& p) {  // CloudRegistration.cpp:58-65
+  auto ret = std::make_unique<RegistrationIcpPointToPlane>();
+  ret->maxCorrespondenceDistance_ = p.icp_.maxCorrespondenceDistance_;
+  ret->knnNormalEstimation_ = p.icp_.knn_;
+  ret->maxRadiusNormalEstimation_ = p.icp_.maxDistanceKnn_;
+  ret->icpConvergenceCriteria_.max_iteration_ = p.icp_.maxNumIter_;
+  return ret;
+}
+
+inline std::unique_ptr<CloudRegistration> cloudRegistrationFactory(const CloudRegistrationParameters& p) {  // CloudRegistration.cpp:85-100
+  switch (p.regType_) {
+    case CloudRegistrationType::PointToPlaneIcp:
+      return createPointToPlaneIcp(p);
+    case CloudRegistrationType::PointToPointIcp:
+    case CloudRegistrationType::GeneralizedIcp:
+      // next rows: in the reference tree these two keep their Open3D CPU implementations
+      throw std::runtime_error("cloud: registration type not available on the HIP backend yet");
+    default:
+      throw std::runtime_error("cloud: unknown type of cloud registration");
+  }
+}
+
+// ---- helpers (helpers.hpp:20-25) -----------------------------------------------------------------------------------
+inline void voxelize(double voxelSize, PointCloud* pcl) {  // helpers.cpp:107-113
+  if (voxelSize <= 0 || pcl->points_.empty()) return;
+  o3ds_detail::DevCloud in(*pcl);
+  o3ds_cloud o = 0;
+  o3ds_detail::Handle::check(o3ds_voxel_down_sample(o3ds_detail::Handle::get(), in.id(), voxelSize, &o));
+  o3ds_detail::DevCloud(o).download(pcl);
+}
+inline std::shared_ptr<PointCloud> voxelizeWithinCroppingVolume(double voxel_size, const CroppingVolume& croppingVolume,
+                                                                const PointCloud& cloud) {  // helpers.cpp:115-183
+  auto out = std::make_shared<PointCloud>();
+  *out = cloud;
+  if (voxel_size <= 0.0 || cloud.points_.empty()) return out;
+  o3ds_detail::DevCloud m(cloud);
+  const o3ds_crop c = croppingVolume.toAbi();
+  o3ds_detail::Handle::check(o3ds_voxelize_within_volume(o3ds_detail::Handle::get(), m.id(), voxel_size, &c));
+  m.download(out.get());
+  return out;
+}
+inline std::shared_ptr<PointCloud> transform(const Transform& T, const PointCloud& cloud) {  // helpers.cpp:273-305 (Matrix4d in the reference)
+  auto out = std::make_shared<PointCloud>();
+  if (cloud.points_.empty()) return out;
+  o3ds_detail::DevCloud in(cloud);
+  o3ds_cloud o = 0;
+  o3ds_detail::Handle::check(o3ds_transform_cloud(o3ds_detail::Handle::get(), in.id(), o3ds_detail::pose_data(T), &o));
+  o3ds_detail::DevCloud(o).download(out.get());
+  return out;
+}
+
+// ---- device-resident scan-to-map (ScanToMapRegistration.cpp:55-62 + Submap.cpp:39-75) ------------------------------
+// The reference keeps mapCloud_ on the host, re-crops it and rebuilds a KD-tree for every scan; this keeps the submap and
+// its index in HBM across scans, so scanToMapRegistration moves only the scan (<= 1.5 MB) over PCIe.
+class DeviceSubmap {
+ public:
+  DeviceSubmap() { o3ds_detail::Handle::check(o3ds_cloud_upload(o3ds_detail::Handle::get(), nullptr, nullptr, 0, &map_)); }
+  ~DeviceSubmap() {
+    if (map_) o3ds_cloud_free(o3ds_detail::Handle::get(), map_);
+  }
+  DeviceSubmap(const DeviceSubmap&) = delete;
+  DeviceSubmap& operator=(const DeviceSubmap&) = delete;
+  // Submap::insertScan core (Submap.cpp:54,70-72); carving is a next row
+  bool insertScan(const PointCloud& preProcessedScan, const Transform& mapToRangeSensor, double mapVoxelSize,
+                  CroppingVolume* mapBuilderCropper, double maxCorrespondenceDistance) {
+    if (preProcessedScan.IsEmpty()) return true;
+    o3ds_detail::DevCloud s(preProcessedScan);
+    mapBuilderCropper->setPose(mapToRangeSensor);
+    const o3ds_crop c = mapBuilderCropper->toAbi();
+    o3ds_detail::Handle::check(o3ds_map_insert_scan(o3ds_detail::Handle::get(), map_, s.id(), o3ds_detail::pose_data(mapToRangeSensor),
+                                                    mapVoxelSize, &c, maxCorrespondenceDistance));
+    return true;
+  }
+  // ScanToMapIcp::scanToMapRegistration (ScanToMapRegistration.cpp:55-62): crop volume fused into the search
+  RegistrationResult scanToMapRegistration(const PointCloud& scan, CroppingVolume* scanMatcherCropper, const Transform& mapToRangeSensor,
+                                           const Transform& initialGuess, const RegistrationIcpPointToPlane& reg) const {
+    size_t n = 0;
+    o3ds_detail::Handle::check(o3ds_cloud_size(o3ds_detail::Handle::get(), map_, &n, nullptr));
+    if (n == 0) throw std::runtime_error("map patch size is zero");  // assert_gt, ScanToMapRegistration.cpp:60
+    scanMatcherCropper->setPose(mapToRangeSensor);
+    const o3ds_crop c = scanMatcherCropper->toAbi();
+    o3ds_detail::DevCloud s(scan);
+    o3ds_icp_params p{};
+    p.max_correspondence_distance = reg.maxCorrespondenceDistance_;
+    p.max_iteration = reg.icpConvergenceCriteria_.max_iteration_;
+    p.relative_fitness = reg.icpConvergenceCriteria_.relative_fitness_;
+    p.relative_rmse = reg.icpConvergenceCriteria_.relative_rmse_;
+    o3ds_icp_result r{};
+    o3ds_detail::Handle::check(o3ds_icp_point_to_plane_dev(o3ds_detail::Handle::get(), s.id(), map_, &c, o3ds_detail::pose_data(initialGuess), &p, &r));
+    return RegistrationIcpPointToPlane::toResult(r);
+  }
+  void getMapPointCloud(PointCloud* out) const {
+    o3ds_detail::DevCloud borrowed(map_);
+    try {
+      borrowed.download(out);
+    } catch (...) {
+      borrowed.release();
+      throw;
+    }
+    borrowed.release();
+  }
+  size_t size() const {
+    size_t n = 0;
+    o3ds_detail::Handle::check(o3ds_cloud_size(o3ds_detail::Handle::get(), map_, &n, nullptr));
+    return n;
+  }
+
+ private:
+  o3ds_cloud map_ = 0;
+};
+
+}  // namespace o3d_slam

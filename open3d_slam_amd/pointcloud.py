@@ -1,0 +1,48 @@
+"""Device-resident stand-in for open3d::geometry::PointCloud at the hot-path seams (typedefs.hpp:24).
+Holds an o3ds_cloud id; points_/normals_ download lazily.  Method names follow the Open3D members the
+reference touches on this path (HasNormals, IsEmpty, points_, normals_)."""
+from __future__ import annotations
+
+import numpy as np
+
+
+class PointCloud:
+    def __init__(self, be, cid: int, owns: bool = True):
+        self.be, self.id, self._owns = be, cid, owns
+
+    @classmethod
+    def from_numpy(cls, be, points, normals=None) -> "PointCloud":
+        return cls(be, be.upload(np.asarray(points, dtype=np.float64).reshape(-1, 3), normals))
+
+    def __len__(self) -> int:
+        return self.be.size(self.id)[0]
+
+    def IsEmpty(self) -> bool:
+        return len(self) == 0
+
+    def HasNormals(self) -> bool:
+        n, hn = self.be.size(self.id)
+        return n > 0 and hn
+
+    @property
+    def points_(self) -> np.ndarray:
+        return self.be.download(self.id)[0]
+
+    @property
+    def normals_(self):
+        return self.be.download(self.id)[1]
+
+    def release(self):
+        if self._owns and self.id:
+            try:
+                self.be.free(self.id)
+            except Exception:
+                pass
+            self.id = 0
+
+    def __del__(self):
+        try:
+            if getattr(self.be, "h", None):
+                self.release()
+        except Exception:
+            pass

@@ -1,0 +1,130 @@
+"""ScanToMapRegistration seam (include/open3d_slam/ScanToMapRegistration.hpp:24-59, src/ScanToMapRegistration.cpp)."""
+from __future__ import annotations
+
+import dataclasses
+
+import numpy as np
+
+from .cloud_registration import RegistrationResult, cloudRegistrationFactory
+from .croppers import croppingVolumeFactory
+from .parameters import (CloudRegistrationParameters, CloudRegistrationType, MapperParameters, ScanToMapRegistrationParameters,
+                         ScanToMapRegistrationType)
+from .pointcloud import PointCloud
+
+
+@dataclasses.dataclass
+class ProcessedScans:  # ScanToMapRegistration.hpp:24-27
+    merge_: PointCloud
+    match_: PointCloud
+
+
+def toCloudRegistrationType(p: ScanToMapRegistrationParameters) -> CloudRegistrationParameters:  # ScanToMapRegistration.cpp:104-129
+    ret = CloudRegistrationParameters()
+    ret.icp_ = p.icp_
+    m = {ScanToMapRegistrationType.PointToPlaneIcp: CloudRegistrationType.PointToPlaneIcp,
+         ScanToMapRegistrationType.PointToPointIcp: CloudRegistrationType.PointToPointIcp,
+         ScanToMapRegistrationType.GeneralizedIcp: CloudRegistrationType.GeneralizedIcp}
+    if p.scanToMapRegType_ not in m:
+        raise RuntimeError("Conversion not possible from ScanToMapRegistrationParameters to CloudRegistrationParameters, "
+                           "for this particular scan to map reg type")
+    ret.regType_ = m[p.scanToMapRegType_]
+    return ret
+
+
+class ScanToMapRegistration:  # ScanToMapRegistration.hpp:29-38
+    def processForScanMatchingAndMerging(self, cloud: PointCloud, mapToRangeSensor) -> ProcessedScans:
+        raise NotImplementedError
+
+    def scanToMapRegistration(self, scan: PointCloud, activeSubmap, mapToRangeSensor, initialGuess) -> RegistrationResult:
+        raise NotImplementedError
+
+    def isMergeScanValid(self, cloud: PointCloud) -> bool:
+        raise NotImplementedError
+
+    def prepareInitialMap(self, map_: PointCloud) -> None:
+        raise NotImplementedError
+
+
+class ScanToMapIcp(ScanToMapRegistration):  # ScanToMapRegistration.hpp:40-59
+    def __init__(self):
+        self.params_ = MapperParameters()
+        self._downsample_rng = None  # [O3D] RandomDownSample seeds from random_device; see setDownSampleSeed
+        self.update(self.params_)
+
+    def setParameters(self, p: MapperParameters):  # ScanToMapRegistration.cpp:24-27
+        self.params_ = p
+        self.update(p)
+
+    def update(self, p: MapperParameters):  # ScanToMapRegistration.cpp:28-32
+        self.mapBuilderCropper_ = croppingVolumeFactory(self.params_.mapBuilder_.cropper_)
+        self.scanMatcherCropper_ = croppingVolumeFactory(self.params_.scanProcessing_.cropper_)
+        self.cloudRegistration = cloudRegistrationFactory(toCloudRegistrationType(p.scanMatcher_))
+
+    def setDownSampleSeed(self, seed: int | None):
+        """The reference's RandomDownSample is seeded from std::random_device (non-reproducible); a seed makes
+        the kept-index list reproducible.  ratio >= 1 never subsamples."""
+        self._downsample_rng = None if seed is None else np.random.default_rng(seed)
+
+    def _random_down_sample(self, cloud: PointCloud, ratio: float) -> PointCloud:
+        n = len(cloud)
+        if ratio >= 1.0 or n == 0:
+            return cloud
+        rng = self._downsample_rng or np.random.default_rng()
+        keep = rng.permutation(n)[: int(ratio * n)]  # [O3D] shuffle, keep the first int(ratio*size), SelectByIndex
+        out = PointCloud(cloud.be, cloud.be.select_by_index(cloud.id, keep))
+        cloud.release()
+        return out
+
+    def preprocess(self, cloud: PointCloud) -> PointCloud:  # ScanToMapRegistration.cpp:35-40
+        cropped = self.mapBuilderCropper_.crop(cloud)
+        be = cloud.be
+        voxelized = PointCloud(be, be.voxel_down_sample(cropped.id, self.params_.scanProcessing_.voxelSize_))
+        cropped.release()
+        self.cloudRegistration.estimateNormalsOrCovariancesIfNeeded(voxelized)
+        return self._random_down_sample(voxelized, self.params_.scanProcessing_.downSamplingRatio_)
+
+    def processForScanMatchingAndMerging(self, cloud: PointCloud, mapToRangeSensor) -> ProcessedScans:  # .cpp:42-54
+        wide = self.preprocess(cloud)
+        self.scanMatcherCropper_.setPose(np.eye(4))
+        narrow = self.scanMatcherCropper_.crop(wide)
+        if not len(narrow) > 0:
+            raise RuntimeError("ScanToMapIcp::narrow cropped size is zero")  # assert_gt
+        if not len(wide) > 0:
+            raise RuntimeError("ScanToMapIcp::wideCropped cropped size is zero")
+        return ProcessedScans(merge_=wide, match_=narrow)
+
+    def scanToMapRegistration(self, scan: PointCloud, activeSubmap, mapToRangeSensor, initialGuess) -> RegistrationResult:
+        """ScanToMapRegistration.cpp:55-62.  The reference copies the map patch inside the scan-matcher volume around
+        the PREVIOUS pose (B1) and rebuilds a KD-tree on it; here the volume is a predicate fused into the search over
+        the submap's resident index -- same correspondences, no O(N) copy or rebuild per scan."""
+        mapCloud = activeSubmap.getMapPointCloud()
+        self.scanMatcherCropper_.setPose(mapToRangeSensor)
+        if len(mapCloud) == 0:
+            raise RuntimeError("map patch size is zero")
+        r = self.cloudRegistration.registerClouds(scan, mapCloud, initialGuess, target_crop=self.scanMatcherCropper_.to_abi())
+        return r
+
+    def isMergeScanValid(self, cloud: PointCloud) -> bool:  # ScanToMapRegistration.cpp:64-80
+        t = self.params_.scanMatcher_.scanToMapRegType_
+        if t == ScanToMapRegistrationType.PointToPlaneIcp:
+            return cloud.HasNormals()
+        if t == ScanToMapRegistrationType.PointToPointIcp:
+            return True
+        if t == ScanToMapRegistrationType.GeneralizedIcp:
+            return cloud.HasNormals()
+        raise RuntimeError("cannot check whether merge scan is valid for this registration type")
+
+    def prepareInitialMap(self, map_: PointCloud) -> None:  # ScanToMapRegistration.cpp:81-84
+        self.cloudRegistration.estimateNormalsOrCovariancesIfNeeded(map_)
+
+
+def createScanToMapIcp(p: MapperParameters) -> ScanToMapIcp:
+    ret = ScanToMapIcp()
+    ret.setParameters(p)
+    return ret
+
+
+def scanToMapRegistrationFactory(p: MapperParameters) -> ScanToMapRegistration:  # ScanToMapRegistration.cpp:91-102
+    if p.scanMatcher_.scanToMapRegType_ in tuple(ScanToMapRegistrationType):
+        return createScanToMapIcp(p)
+    raise RuntimeError("scanToMapRegistrationFactory: unknown type of registration scan to map")

@@ -1,0 +1,28 @@
+#!/bin/bash
+# quick A/B of launch geometry / cell size on the GPU box; prints one compact line per variant
+R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
+run() { # label, env..., -- bench args
+  label=$1; shift
+  envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
+  env "${envs[@]}" timeout 300 python bench.py --steps 30 --warmup 3 --no-cpu-baseline "$@" 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); r=d['roofline']
+print('%-28s %8.0f it/s  %7.3f ms/step  kernel %6.1f us  frac %.4f' % ('$label', d['value'], d['ms_per_step'], r['avg_launch_us'], r['frac']))"
+}
+{
+for g in 2 4 8; do for b in 256 512; do
+run "G$g b$b r1024" O3DS_PASS_GROUP=$g O3DS_PASS_BLOCK=$b O3DS_PASS_ROWS=1024 --
+done; done
+run "G2 b256 r512" O3DS_PASS_GROUP=2 O3DS_PASS_BLOCK=256 O3DS_PASS_ROWS=512 --
+run "G4 b256 r512" O3DS_PASS_GROUP=4 O3DS_PASS_BLOCK=256 O3DS_PASS_ROWS=512 --
+run "G4 b256 r768" O3DS_PASS_GROUP=4 O3DS_PASS_BLOCK=256 O3DS_PASS_ROWS=768 --
+run "G4 b256 r1024 cell.175" O3DS_PASS_GROUP=4 O3DS_PASS_BLOCK=256 O3DS_PASS_ROWS=1024 -- --cell 0.175
+run "G4 b256 r1024 cell.125" O3DS_PASS_GROUP=4 O3DS_PASS_BLOCK=256 O3DS_PASS_ROWS=1024 -- --cell 0.125
+run "G2 b256 r1024 cell.175" O3DS_PASS_GROUP=2 O3DS_PASS_BLOCK=256 O3DS_PASS_ROWS=1024 -- --cell 0.175
+run "G2 b256 r1024 cell.125" O3DS_PASS_GROUP=2 O3DS_PASS_BLOCK=256 O3DS_PASS_ROWS=1024 -- --cell 0.125
+run "G4 b256 r1024 f64" O3DS_PASS_GROUP=4 O3DS_PASS_BLOCK=256 O3DS_PASS_ROWS=1024 -- --precision f64
+} | tee $OUT/sweep.txt
+timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 2>&1 | tail -15 | tee $OUT/pytest_gpu.log
+cd /tmp && export TMPDIR=/tmp; rm -rf $OUT/prof
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline > $OUT/rocprof_bench.json 2> $OUT/rocprof.err
+python $R/scripts/prof_summary.py $OUT/prof/bench_results.db $OUT/rocprof_stats.txt | head -30

@@ -1,0 +1,33 @@
+"""C++ host adapter (open3d_slam_amd/host/o3ds_adapter.hpp): the reference-named classes over the C-ABI.
+CPU: it compiles with plain g++ and its device-free checks pass.  GPU: the full self-checking program runs."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBDIR = os.path.join(ROOT, "open3d_slam_amd", "lib")
+
+
+@pytest.fixture(scope="module")
+def adapter_exe(tmp_path_factory):
+    from open3d_slam_amd import build
+
+    build.build_backend()
+    exe = str(tmp_path_factory.mktemp("adapter") / "test_adapter")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_adapter.cpp"),
+                           "-L" + LIBDIR, "-lo3ds_backend", "-Wl,-rpath," + LIBDIR])
+    return exe
+
+
+def test_adapter_compiles_and_device_free_checks(adapter_exe):
+    out = subprocess.run([adapter_exe, "--no-gpu"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "no-gpu checks ok" in out.stdout
+
+
+@pytest.mark.gpu
+def test_adapter_on_gpu(adapter_exe):
+    out = subprocess.run([adapter_exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "gpu checks ok" in out.stdout

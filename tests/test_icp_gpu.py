@@ -188,6 +188,11 @@ def test_ragged_sizes(backend_f64, oracle):
         got = backend_f64.icp_point_to_plane(src, tgt, nrm, 1.5, max_iter=4, rel_fitness=0.0, rel_rmse=0.0)
         ref = oracle.icp_point_to_plane(src, tgt, nrm, 1.5, max_iter=4, rel_fitness=0.0, rel_rmse=0.0)
         assert got["n_corr"] == ref["n_corr"]
+        if not np.isfinite(ref["transformation"]).all():
+            # one azimuth column = points in one plane through the sensor: JtJ is singular and, as in Open3D (no PSD /
+            # determinant check on this code path), NaNs propagate -- on both sides
+            assert n_az == 1 and not np.isfinite(got["transformation"]).all()
+            continue
         _check(got, ref, len(src), 1e-5, 1e-5)  # few points => ill-conditioned, still tight in f64
     tiny_t, tiny_n = tgt[:7], nrm[:7]
     got = backend_f64.icp_point_to_plane(tgt[:50], tiny_t, tiny_n, 5.0, max_iter=1, rel_fitness=0.0, rel_rmse=0.0)
