@@ -43,7 +43,7 @@ def cpu_baseline(src, tgt, nrm, budget_s=20.0):
     tree = po.KDTree(tgt)
     build_s = time.perf_counter() - t0
     reps, spent, res = 0, 0.0, None
-    while reps < 2 or (spent < budget_s and reps < 50):
+    while reps < 2 or (spent < budget_s and reps < 1000):
         t0 = time.perf_counter()
         res = po.icp_point_to_plane(src, tgt, nrm, MAX_CORR, max_iter=ICP_ITERS, rel_fitness=0.0, rel_rmse=0.0, tree=tree)
         spent += time.perf_counter() - t0
@@ -143,6 +143,17 @@ def main():
     algo_bytes = N_SRC * ALGO_BYTES_PER_POINT
     achieved_gbs = algo_bytes / avg_kernel_s / 1e9
 
+    # HBM traffic of the same kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes of this
+    # command, corrected as MI355X_MICROARCH.md prescribes); collected by scripts/gpu_round.sh, committed under profiles/
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))["icp_accumulate_kernel"]
+            traffic, traffic_src = tj["hbm_bytes_per_launch_corrected"], "profiles/pmc_traffic_latest.json (rocprofv3 --pmc, separate passes)"
+        except Exception:
+            pass
+
     if rank == 0:
         dt_gt, dr_gt = syn.se3_error(res["transformation"], T_gt)
         out = {
@@ -167,7 +178,7 @@ def main():
             "scans_per_sec_icp_only": world * args.steps / elapsed,
             "pose_error_vs_truth": {"dt_m": dt_gt, "dr_rad": dr_gt, "fitness": res["fitness"], "inlier_rmse": res["inlier_rmse"]},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                          "kernel": "icp_accumulate_kernel", "launches": n_launch, "avg_launch_us": avg_kernel_s * 1e6,
                          "algorithmic_bytes_per_launch": algo_bytes},
         }

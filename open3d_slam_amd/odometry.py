@@ -1,0 +1,77 @@
+"""LidarOdometry (include/open3d_slam/Odometry.hpp:27, src/Odometry.cpp:25-79): a CALLER of the hot path, kept as a thin
+host harness with the reference's method names so that config 3 (full odometry + mapper loop) can be driven end to end.
+All arithmetic goes through the CloudRegistration seam on the device."""
+from __future__ import annotations
+
+import numpy as np
+
+from .cloud_registration import cloudRegistrationFactory
+from .croppers import CroppingVolume, croppingVolumeFactory
+from .parameters import OdometryParameters
+from .pointcloud import PointCloud
+
+
+class LidarOdometry:
+    def __init__(self, be):
+        self.be = be
+        self.params_ = OdometryParameters()
+        self.cropper_ = CroppingVolume()  # Odometry.cpp:20-23: base volume = everything, until setParameters
+        self.cloudRegistration_ = cloudRegistrationFactory(self.params_.scanMatcher_)
+        self.cloudPrev_: PointCloud | None = None
+        self.odomToRangeSensorCumulative_ = np.eye(4)
+        self.odomToRangeSensorBuffer_: list[tuple[float, np.ndarray]] = []
+        self.lastMeasurementTimestamp_ = None
+
+    def setParameters(self, p: OdometryParameters):  # Odometry.cpp:96-100
+        self.params_ = p
+        self.cropper_ = croppingVolumeFactory(p.scanProcessing_.cropper_)
+        self.cloudRegistration_ = cloudRegistrationFactory(p.scanMatcher_)
+
+    def preprocess(self, cloud: PointCloud) -> PointCloud:  # Odometry.cpp:25-30
+        cropped = self.cropper_.crop(cloud)
+        vox = PointCloud(self.be, self.be.voxel_down_sample(cropped.id, self.params_.scanProcessing_.voxelSize_))
+        cropped.release()
+        self.cloudRegistration_.estimateNormalsOrCovariancesIfNeeded(vox)
+        # RandomDownSample(ratio): ratio = 1 in every benchmark config (non-reproducible otherwise)
+        if self.params_.scanProcessing_.downSamplingRatio_ < 1.0:
+            n = len(vox)
+            keep = np.random.default_rng().permutation(n)[: int(self.params_.scanProcessing_.downSamplingRatio_ * n)]
+            sub = PointCloud(self.be, self.be.select_by_index(vox.id, keep))
+            vox.release()
+            vox = sub
+        return vox
+
+    def addRangeScan(self, cloud: PointCloud, timestamp: float) -> bool:  # Odometry.cpp:32-79
+        if self.cloudPrev_ is None or self.cloudPrev_.IsEmpty():
+            self.cloudPrev_ = self.preprocess(cloud)
+            self.odomToRangeSensorBuffer_.append((timestamp, self.odomToRangeSensorCumulative_.copy()))
+            self.lastMeasurementTimestamp_ = timestamp
+            return True
+        if timestamp < self.lastMeasurementTimestamp_:
+            return False  # measurements came out of order
+        pre = self.preprocess(cloud)
+        # B3: registers PREVIOUS -> CURRENT and integrates the inverse; the target normals are the current scan's
+        self.be.build_index(pre.id, self.cloudRegistration_.maxCorrespondenceDistance_)
+        result = self.cloudRegistration_.registerClouds(self.cloudPrev_, pre, np.eye(4))
+        ok = result.fitness_ > 0.1  # Odometry.cpp:51 ("todo magic")
+        if not ok:
+            if not pre.IsEmpty():
+                self.cloudPrev_.release()
+                self.cloudPrev_ = pre
+            return False
+        self.odomToRangeSensorCumulative_ = self.odomToRangeSensorCumulative_ @ np.linalg.inv(result.transformation_)
+        self.cloudPrev_.release()
+        self.cloudPrev_ = pre
+        self.odomToRangeSensorBuffer_.append((timestamp, self.odomToRangeSensorCumulative_.copy()))
+        self.lastMeasurementTimestamp_ = timestamp
+        return True
+
+    def getOdomToRangeSensor(self, t: float) -> np.ndarray:
+        """exact-stamp lookup (the reference interpolates in TransformInterpolationBuffer; the harness feeds exact stamps)"""
+        for ts, T in reversed(self.odomToRangeSensorBuffer_):
+            if ts == t:
+                return T
+        raise RuntimeError("odomToRangeSensorBuffer_ does not have the desired transform")
+
+    def hasTransform(self, t: float) -> bool:
+        return any(ts == t for ts, _ in self.odomToRangeSensorBuffer_)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# One GPU-box visit: parity tests, bench line, rocprofv3 kernel stats.  Outputs under gpurun_out/.
+# One GPU-box visit: parity tests, bench line, rocprofv3 kernel stats, PMC traffic.  Outputs under gpurun_out/.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
@@ -7,15 +7,15 @@ cd $R
 { echo "nproc=$(nproc)"; lscpu | grep -E "Model name|Socket|Core|Thread|MHz" ; } > $OUT/host.txt 2>&1
 timeout 1500 python -m pytest tests -m gpu -q -rA --timeout 900 2>&1 | tail -150 > $OUT/pytest_gpu.log
 echo "pytest rc=${PIPESTATUS[0]}" >> $OUT/pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/smoke.log
 timeout 600 python bench.py --steps 50 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 echo "bench rc=$?" >> $OUT/bench.err
-for c in 0.125 0.175 0.35 0.5; do
-  timeout 300 python bench.py --steps 30 --warmup 3 --no-cpu-baseline --cell $c > $OUT/bench_cell_$c.json 2>> $OUT/bench.err
-done
-timeout 300 python bench.py --steps 30 --warmup 3 --no-cpu-baseline --precision f64 > $OUT/bench_f64.json 2>> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
-rm -rf $OUT/prof
+rm -rf $OUT/prof $OUT/pmc_fetch $OUT/pmc_write
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline > $OUT/rocprof_bench.json 2> $OUT/rocprof.err
 echo "rocprof rc=$?" >> $OUT/rocprof.err
 python $R/scripts/prof_summary.py $OUT/prof/bench_results.db $OUT/rocprof_stats.txt > /dev/null
-tail -5 $OUT/pytest_gpu.log; cat $OUT/bench.json; tail -3 $OUT/bench.err; head -8 $OUT/rocprof_stats.txt
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- python $R/bench.py --steps 10 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- python $R/bench.py --steps 10 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+python $R/scripts/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic.json > /dev/null
+grep -E "passed|failed" $OUT/pytest_gpu.log | tail -3; tail -2 $OUT/smoke.log; cat $OUT/bench.json; tail -2 $OUT/bench.err; head -5 $OUT/rocprof_stats.txt; cat $OUT/pmc_traffic.json

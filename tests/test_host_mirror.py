@@ -1,0 +1,87 @@
+"""Host mirror of the reference seams (no GPU needed): factories, parameter copy, predicates, error behaviour."""
+import numpy as np
+import pytest
+
+from open3d_slam_amd import backend, croppers, parameters as P
+from open3d_slam_amd.cloud_registration import (RegistrationIcpPointToPlane, cloudRegistrationFactory, createPointToPlaneIcp)
+from open3d_slam_amd.scan_to_map_registration import ScanToMapIcp, scanToMapRegistrationFactory, toCloudRegistrationType
+
+
+def test_parameter_defaults_match_reference_structs():
+    icp = P.IcpParameters()  # Parameters.hpp:66-71
+    assert (icp.maxNumIter_, icp.maxCorrespondenceDistance_, icp.knn_, icp.maxDistanceKnn_) == (50, 0.2, 5, 10.0)
+    c = P.ScanCroppingParameters()  # Parameters.hpp:51-57
+    assert (c.croppingMinZ_, c.croppingMaxZ_, c.croppingMinRadius_, c.croppingMaxRadius_, c.cropperName_) == (-10.0, 10.0, 0.0, 20.0, "MaxRadius")
+    assert P.ScanProcessingParameters().voxelSize_ == 0.03 and P.MapBuilderParameters().mapVoxelSize_ == 0.03
+    assert P.ScanToMapRegistrationParameters().minRefinementFitness_ == 0.7
+    assert P.CloudRegistrationParameters().regType_ == P.CloudRegistrationType.PointToPlaneIcp
+    lua = P.lua_default_mapper_parameters()
+    assert lua.scanMatcher_.icp_.knn_ == 20 and lua.scanMatcher_.icp_.maxDistanceKnn_ == 3.0
+    assert lua.scanProcessing_.cropper_.cropperName_ == "MinMaxRadius"
+
+
+def test_cloud_registration_factory_copies_parameters():
+    p = P.CloudRegistrationParameters()
+    p.icp_ = P.IcpParameters(maxNumIter_=17, maxCorrespondenceDistance_=0.7, knn_=9, maxDistanceKnn_=1.5)
+    reg = cloudRegistrationFactory(p)
+    assert isinstance(reg, RegistrationIcpPointToPlane)
+    assert (reg.maxCorrespondenceDistance_, reg.knnNormalEstimation_, reg.maxRadiusNormalEstimation_) == (0.7, 9, 1.5)
+    c = reg.icpConvergenceCriteria_
+    assert (c.max_iteration_, c.relative_fitness_, c.relative_rmse_) == (17, 1e-6, 1e-6)  # only max_iteration_ is overridden
+    assert createPointToPlaneIcp(p).maxCorrespondenceDistance_ == 0.7
+    for t in (P.CloudRegistrationType.PointToPointIcp, P.CloudRegistrationType.GeneralizedIcp):
+        p.regType_ = t
+        with pytest.raises(NotImplementedError):  # next rows: fail loudly, never fall back to something else
+            cloudRegistrationFactory(p)
+    p.regType_ = 42
+    with pytest.raises(RuntimeError, match="unknown type"):
+        cloudRegistrationFactory(p)
+
+
+def test_normal_estimation_parameter_asserts():
+    reg = RegistrationIcpPointToPlane()
+    reg.maxRadiusNormalEstimation_ = 0.0
+    with pytest.raises(RuntimeError, match="maxRadiusNormalEstimation_"):
+        reg.estimateNormalsOrCovariancesIfNeeded(None)
+    reg.maxRadiusNormalEstimation_ = 1.0
+    reg.knnNormalEstimation_ = 0
+    with pytest.raises(RuntimeError, match="knnNormalEstimation_"):
+        reg.estimateNormalsOrCovariancesIfNeeded(None)
+
+
+def test_cropper_factory_and_predicates(oracle):
+    sp = P.ScanCroppingParameters(croppingMinZ_=-1.0, croppingMaxZ_=5.0, croppingMinRadius_=2.0, croppingMaxRadius_=30.0)
+    pts = np.array([[2.0, 0, 0], [1.9999999, 0, 0], [30.0, 0, 0], [30.0000001, 0, 0], [0, 0, 5.0], [1.0, 1.0, 6.0]])
+    kinds = {"MaxRadius": oracle.CROP_MAX_RADIUS, "MinRadius": oracle.CROP_MIN_RADIUS, "MinMaxRadius": oracle.CROP_MIN_MAX_RADIUS,
+             "Cylinder": oracle.CROP_CYLINDER}
+    pose = np.eye(4)
+    pose[:3, 3] = [0.5, -0.25, 0.1]
+    for name, ok in kinds.items():
+        sp.cropperName_ = name
+        cr = croppers.croppingVolumeFactory(sp)
+        cr.setPose(pose)
+        for inv in (False, True):
+            cr.setIsInvertVolume(inv)
+            abi = cr.to_abi()
+            assert abi.kind == ok and bool(abi.invert) == inv and list(abi.center) == [0.5, -0.25, 0.1]
+            oc = oracle.make_crop(ok, center=pose[:3, 3], rmin=abi.rmin, rmax=abi.rmax, zmin=abi.zmin, zmax=abi.zmax, invert=inv)
+            keep = set(oracle.crop_indices(pts, oc).tolist())
+            assert {i for i, p in enumerate(pts) if cr.isWithinVolume(p)} == keep, (name, inv)
+    sp.cropperName_ = "NoSuchCropper"
+    with pytest.raises(RuntimeError):
+        croppers.croppingVolumeFactory(sp)
+    base = croppers.CroppingVolume()
+    assert base.isWithinVolume([1e9, 0, 0]) and base.to_abi().kind == backend.CROP_NONE
+
+
+def test_scan_to_map_factory_and_type_mapping():
+    p = P.lua_default_mapper_parameters()
+    s2m = scanToMapRegistrationFactory(p)
+    assert isinstance(s2m, ScanToMapIcp)
+    assert s2m.cloudRegistration.maxCorrespondenceDistance_ == 1.0 and s2m.cloudRegistration.knnNormalEstimation_ == 20
+    assert s2m.mapBuilderCropper_.radiusMin_ == 2.0 and s2m.scanMatcherCropper_.radiusMax_ == 30.0
+    cr = toCloudRegistrationType(p.scanMatcher_)
+    assert cr.regType_ == P.CloudRegistrationType.PointToPlaneIcp and cr.icp_ is p.scanMatcher_.icp_
+    p.scanMatcher_.scanToMapRegType_ = 42
+    with pytest.raises(RuntimeError):
+        scanToMapRegistrationFactory(p)

@@ -242,3 +242,28 @@ def test_full_size_properties(backend_f32):
     np.testing.assert_allclose(got["transformation"][:3, 3], [-0.05, 0.04, -0.03], atol=2e-3)
     for c in (s, t, shifted):
         backend_f32.free(c)
+
+
+def test_sharded_driver_single_rank_on_gpu(backend_f32, small_c2):
+    """open3d_slam_amd.sharded.ShardedIcp with world_size 1 (no process group): the step-wise ABI driven on a torch side
+    stream (o3ds_set_stream) reproduces the one-shot registration bit for bit, in both partitionings."""
+    from open3d_slam_amd import sharded
+
+    src, tgt, nrm, _ = small_c2
+    s = backend_f32.upload(src)
+    t = backend_f32.upload(tgt, nrm)
+    backend_f32.build_index(t, 1.0)
+    one = backend_f32.icp_point_to_plane_dev(s, t, 1.0, max_iter=30)
+    try:
+        for mode in ("source", "submap"):
+            drv = sharded.ShardedIcp(backend_f32, mode=mode)
+            got = drv.register(s, t, len(src), 1.0, max_iter=30, check_every=3)
+            np.testing.assert_array_equal(got["transformation"], one["transformation"])
+            assert got["iterations"] == one["iterations"] and got["converged"] == one["converged"]
+            assert got["fitness"] == one["fitness"] and got["inlier_rmse"] == one["inlier_rmse"]
+    finally:
+        backend_f32.set_stream(None)
+    again = backend_f32.icp_point_to_plane_dev(s, t, 1.0, max_iter=30)
+    np.testing.assert_array_equal(again["transformation"], one["transformation"])
+    backend_f32.free(s)
+    backend_f32.free(t)

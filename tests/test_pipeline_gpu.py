@@ -1,0 +1,118 @@
+"""BASELINE.json configs[2] (reduced): full odometry + mapper loop with voxel-hash submap merge on an OS-128-like synthetic
+stream, driven through the reference-named host classes on the device, against the same loop played by the CPU oracle."""
+import numpy as np
+import pytest
+
+from open3d_slam_amd import backend, parameters as P, synthetic as syn
+from open3d_slam_amd.mapper import Mapper
+from open3d_slam_amd.odometry import LidarOdometry
+from open3d_slam_amd.pointcloud import PointCloud
+
+pytestmark = pytest.mark.gpu
+
+N_FRAMES, N_AZ = 6, 256  # 32 768 raw points per frame
+
+
+def _params():
+    mp = P.lua_default_mapper_parameters()
+    mp.scanMatcher_.icp_.maxNumIter_ = 10
+    op = P.OdometryParameters()
+    op.scanMatcher_.icp_ = P.IcpParameters(maxNumIter_=10, maxCorrespondenceDistance_=1.0, knn_=20, maxDistanceKnn_=3.0)
+    op.scanProcessing_.voxelSize_ = 0.1
+    op.scanProcessing_.cropper_ = P.ScanCroppingParameters(croppingMinRadius_=2.0, croppingMaxRadius_=30.0, cropperName_="MinMaxRadius")
+    return mp, op
+
+
+class _OracleLoop:
+    """The same orchestration (Odometry.cpp:25-79, Mapper.cpp:101-181, ScanToMapRegistration.cpp:35-62, Submap.cpp:39-75) on
+    the CPU oracle."""
+
+    def __init__(self, oracle, mp, op):
+        self.o, self.mp, self.op = oracle, mp, op
+        self.map_p = np.zeros((0, 3))
+        self.map_n = np.zeros((0, 3))
+        self.T = np.eye(4)
+        self.Tprev = np.eye(4)
+        self.odom = np.eye(4)
+        self.odom_at = {}
+        self.prev = None
+        self.last_t = None
+
+    def _pre(self, raw, crop_p, voxel, icp):
+        o = self.o
+        keep = o.crop_indices(raw, o.make_crop(o.CROP_MIN_MAX_RADIUS, rmin=crop_p.croppingMinRadius_, rmax=crop_p.croppingMaxRadius_))
+        v = o.voxel_down_sample(raw[keep], voxel)
+        return v, o.estimate_normals(v, icp.maxDistanceKnn_, icp.knn_)
+
+    def odometry(self, raw, t):
+        icp = self.op.scanMatcher_.icp_
+        v, n = self._pre(raw, self.op.scanProcessing_.cropper_, self.op.scanProcessing_.voxelSize_, icp)
+        if self.prev is not None:
+            r = self.o.icp_point_to_plane(self.prev, v, n, icp.maxCorrespondenceDistance_, max_iter=icp.maxNumIter_)
+            assert r["fitness"] > 0.1
+            self.odom = self.odom @ np.linalg.inv(r["transformation"])
+        self.prev = v
+        self.odom_at[t] = self.odom.copy()
+
+    def mapping(self, raw, t):
+        o, mp = self.o, self.mp
+        icp = mp.scanMatcher_.icp_
+        v, n = self._pre(raw, mp.mapBuilder_.cropper_, mp.scanProcessing_.voxelSize_, icp)
+        sc = mp.scanProcessing_.cropper_
+        keep = o.crop_indices(v, o.make_crop(o.CROP_MIN_MAX_RADIUS, rmin=sc.croppingMinRadius_, rmax=sc.croppingMaxRadius_))
+        match = v[keep]
+        if len(self.map_p) == 0:
+            T_ins = np.eye(4)
+        else:
+            est = self.Tprev @ (np.linalg.inv(self.odom_at[self.last_t]) @ self.odom_at[t])
+            patch = o.crop_indices(self.map_p, o.make_crop(o.CROP_MIN_MAX_RADIUS, center=self.T[:3, 3], rmin=sc.croppingMinRadius_,
+                                                            rmax=sc.croppingMaxRadius_))
+            r = o.icp_point_to_plane(match, self.map_p[patch], self.map_n[patch], icp.maxCorrespondenceDistance_, init=est,
+                                     max_iter=icp.maxNumIter_)
+            assert r["fitness"] >= mp.scanMatcher_.minRefinementFitness_
+            self.T = r["transformation"]
+            T_ins = self.T
+        tp, tn = o.transform_points(v, T_ins), o.transform_normals(n, T_ins)
+        mc = mp.mapBuilder_.cropper_
+        crop = o.make_crop(o.CROP_MIN_MAX_RADIUS, center=T_ins[:3, 3], rmin=mc.croppingMinRadius_, rmax=mc.croppingMaxRadius_)
+        self.map_p, self.map_n, _ = o.voxelize_within_volume(np.vstack([self.map_p, tp]), np.vstack([self.map_n, tn]),
+                                                             mp.mapBuilder_.mapVoxelSize_, crop)
+        self.last_t = t
+        self.Tprev = self.T.copy()
+
+
+def test_odometry_mapper_loop_matches_oracle(backend_f64, oracle):
+    be = backend_f64
+    mp, op = _params()
+    scene = syn.make_scene()
+    poses = syn.figure_eight_poses(200, 0.1)[:N_FRAMES]
+    odo = LidarOdometry(be)
+    odo.setParameters(op)
+    mapper = Mapper(be, odo)
+    mapper.setParameters(mp)
+    ref = _OracleLoop(oracle, mp, op)
+    for k in range(N_FRAMES):
+        raw = syn.os128_scan(scene, poses[k], frame=k, n_az=N_AZ)
+        t = 0.1 * k
+        cloud = PointCloud.from_numpy(be, raw)
+        assert odo.addRangeScan(cloud, t)
+        assert mapper.addRangeMeasurement(cloud, t)
+        cloud.release()
+        ref.odometry(raw, t)
+        ref.mapping(raw, t)
+        dt, dr = syn.se3_error(mapper.getMapToRangeSensor(), ref.T)
+        do_t, do_r = syn.se3_error(odo.odomToRangeSensorCumulative_, ref.odom)
+        print(f"frame {k}: map pose vs oracle {dt:.2e} m {dr:.2e} rad; odom {do_t:.2e} {do_r:.2e}; map size {len(mapper.getActiveSubmap().getMapPointCloud())}/{len(ref.map_p)}")
+        # Scan-to-scan odometry agrees to round-off.  The mapping poses agree to the stated SE(3) tolerance only: ~0.6 % of the
+        # scan normals are not defined by the data (collinear neighbourhoods, planes through the sensor whose orientation sign
+        # is decided by rounding -- measured 115 of 18 702 at frame 0), they enter the map by voxel averaging, and from
+        # then on the two maps -- and hence the poses -- differ slightly (7e-8 m at frame 1, <1e-3 m afterwards); the same
+        # happens between two runs of the reference itself (OpenMP summation order).
+        assert do_t < 1e-6 and do_r < 1e-6
+        assert dt < 5e-3 and dr < 1e-3, (k, dt, dr)
+        n_dev, n_ref = len(mapper.getActiveSubmap().getMapPointCloud()), len(ref.map_p)
+        assert abs(n_dev - n_ref) <= 0.005 * n_ref
+    # and against ground truth: the loop tracks the trajectory (relative to the first pose)
+    T_gt = np.linalg.inv(poses[0]) @ poses[N_FRAMES - 1]
+    gt_t, gt_r = syn.se3_error(mapper.getMapToRangeSensor(), T_gt)
+    assert gt_t < 0.05 and gt_r < 0.01, (gt_t, gt_r)
