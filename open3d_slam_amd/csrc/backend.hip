@@ -374,8 +374,10 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
   }
   const double r_corr = params->max_correspondence_distance;
   if (tgt->grid.cell < r_corr) {  // far queries need the coarse grid: cell >= r (3x3x3 block covers the ball), not wastefully larger
-    if (!tgt->has_coarse || tgt->coarse.cell < r_corr || tgt->coarse.cell > 2.0 * r_corr) {
-      rc = build_coarse(h, *tgt, r_corr);
+    // coarse cell = r / kCoarseH: the (2H+1)^3 block covers the ball of radius r; rebuilt when r grows past it or shrinks a lot
+    const double want = r_corr / (double)kCoarseH;
+    if (!tgt->has_coarse || tgt->coarse.cell < want || tgt->coarse.cell > 2.0 * want) {
+      rc = build_coarse(h, *tgt, want);
       if (rc) return rc;
     }
   }
@@ -571,7 +573,7 @@ int o3ds_cloud_build_index(o3ds_handle h, o3ds_cloud id, double max_corr_hint, d
   double cell = cell_size > 0.0 ? cell_size : max_corr_hint / 4.0;
   if (!(cell > 0.0)) return fail(h, O3DS_ERR_INVALID_ARG, "build_index: need cell_size > 0 or max_corr_hint > 0");
   int rc = build_index(h, *c, cell);
-  if (rc == O3DS_OK && max_corr_hint > 0.0 && c->grid.cell < max_corr_hint) rc = build_coarse(h, *c, max_corr_hint);
+  if (rc == O3DS_OK && max_corr_hint > 0.0 && c->grid.cell < max_corr_hint) rc = build_coarse(h, *c, max_corr_hint / (double)kCoarseH);
   return rc;
 }
 
@@ -1035,7 +1037,7 @@ int o3ds_map_insert_scan(o3ds_handle h, o3ds_cloud map, o3ds_cloud scan, const d
   m = find_cloud(h, map);
   if (max_corr_hint > 0.0) {
     rc = build_index(h, *m, max_corr_hint / 4.0);
-    if (rc == O3DS_OK && m->grid.cell < max_corr_hint) rc = build_coarse(h, *m, max_corr_hint);
+    if (rc == O3DS_OK && m->grid.cell < max_corr_hint) rc = build_coarse(h, *m, max_corr_hint / (double)kCoarseH);
   }
   return rc;
 }

@@ -281,14 +281,20 @@ __device__ __forceinline__ NNBest<P4> nn_search_group(const GridDev& g, const P4
   return best;
 }
 
-// Far queries (the fine 3x3x3 block could not prove exactness): all 64 lanes of the wavefront search the 3x3x3 block
-// of the COARSE grid (cell >= r, so the block contains every point within r) for ONE query.  Rows and cells that
-// cannot beat the current bound are culled.  Winners found here carry pos = -2 (their point/normal are gathered
-// through the original index).
+// Far queries (the fine 3x3x3 block could not prove exactness): all 64 lanes of the wavefront search the COARSE grid
+// for ONE query.  The coarse cell is r/kCoarseH, so the (2H+1)^3 block around the query's coarse cell contains every
+// point within r; its (2H+1)^2 rows are one contiguous range each.  Lane j fetches the bounds of row j, trimmed to the
+// cells that can still beat the current bound; the centre row is scanned first and its result tightens the bound that
+// culls the remaining rows (at the misaligned first pass most far queries start with bound = r).
+// Winners found here carry pos = -2 (their point/normal are gathered through the original index).
+constexpr int kCoarseH = 1;
+
 template <typename P4, bool kCrop>
 __device__ __forceinline__ void nn_search_wave_coarse(const GridDev& g, const P4* __restrict__ cp, typename Scalar<P4>::type qx,
                                                       typename Scalar<P4>::type qy, typename Scalar<P4>::type qz, const CropDev& crop,
                                                       NNBest<P4>& best, int lane) {
+  constexpr int kSide = 2 * kCoarseH + 1, kRows = kSide * kSide, kCentre = kRows / 2;
+  static_assert(kRows <= 64, "one lane per coarse row");
   const double dqx = (double)qx, dqy = (double)qy, dqz = (double)qz;
   const double lim = 1.0e9;
   const int ix = (int)fmin(fmax(floor((dqx - g.ox) * g.inv_cell), -lim), lim);
@@ -297,15 +303,16 @@ __device__ __forceinline__ void nn_search_wave_coarse(const GridDev& g, const P4
   const double bound2 = (double)best.d2 * (1.0 + 1e-5);
   const int* __restrict__ cs = g.cell_start;
   int s_own = 0, e_own = 0;
-  if (lane < 9) {
-    const int y = iy + (lane % 3) - 1, z = iz + (lane / 3) - 1;
+  float rowd2_own = 3.0e38f;
+  if (lane < kRows) {
+    const int y = iy + (lane % kSide) - kCoarseH, z = iz + (lane / kSide) - kCoarseH;
     if ((unsigned)y < (unsigned)g.ny && (unsigned)z < (unsigned)g.nz) {
       const double ylo = g.oy + (double)y * g.cell, zlo = g.oz + (double)z * g.cell;
       const double ddy = fmax(0.0, fmax(ylo - dqy, dqy - (ylo + g.cell))), ddz = fmax(0.0, fmax(zlo - dqz, dqz - (zlo + g.cell)));
       const double rowd2 = ddy * ddy + ddz * ddz;
       int x0 = 1 << 30, x1 = -(1 << 30);
 #pragma unroll
-      for (int dx = -1; dx <= 1; ++dx) {
+      for (int dx = -kCoarseH; dx <= kCoarseH; ++dx) {
         const int x = ix + dx;
         if ((unsigned)x >= (unsigned)g.nx) continue;
         const double xlo = g.ox + (double)x * g.cell;
@@ -318,14 +325,21 @@ __device__ __forceinline__ void nn_search_wave_coarse(const GridDev& g, const P4
         const int row = (z * g.ny + y) * g.nx;
         s_own = cs[row + x0];
         e_own = cs[row + x1 + 1];
+        rowd2_own = (float)(rowd2 * (1.0 - 1e-5));  // conservative (smaller) so that rounding never culls a needed row
       }
     }
   }
   NNBest<P4> mine = best;
-#pragma unroll
-  for (int r = 0; r < 9; ++r) {
-    const int sr = __shfl(s_own, r, 64), er = __shfl(e_own, r, 64);
-    scan_strided<P4, kCrop, true>(cp, sr, er, lane, 64, qx, qy, qz, crop, mine);
+  // centre row first: its winner bounds everything else
+  scan_strided<P4, kCrop, true>(cp, __shfl(s_own, kCentre, 64), __shfl(e_own, kCentre, 64), lane, 64, qx, qy, qz, crop, mine);
+  lanes_min<P4, 64>(mine);
+  const float cur = (float)mine.d2 * (1.0f + 1e-5f);
+  // rows that can still hold a closer point (wave-uniform decisions)
+  unsigned long long need = __ballot(lane < kRows && lane != kCentre && e_own > s_own && rowd2_own <= cur);
+  while (need) {
+    const int r = __ffsll((long long)need) - 1;
+    need &= need - 1;
+    scan_strided<P4, kCrop, true>(cp, __shfl(s_own, r, 64), __shfl(e_own, r, 64), lane, 64, qx, qy, qz, crop, mine);
   }
   lanes_min<P4, 64>(mine);
   best = mine;

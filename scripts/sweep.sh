@@ -10,17 +10,10 @@ d=json.loads(sys.stdin.readline()); r=d['roofline']
 print('%-28s %8.0f it/s  %7.3f ms/step  kernel %6.1f us  frac %.4f' % ('$label', d['value'], d['ms_per_step'], r['avg_launch_us'], r['frac']))"
 }
 {
-for g in 2 4 8; do for b in 256 512; do
-run "G$g b$b r1024" O3DS_PASS_GROUP=$g O3DS_PASS_BLOCK=$b O3DS_PASS_ROWS=1024 --
-done; done
-run "G2 b256 r512" O3DS_PASS_GROUP=2 O3DS_PASS_BLOCK=256 O3DS_PASS_ROWS=512 --
-run "G4 b256 r512" O3DS_PASS_GROUP=4 O3DS_PASS_BLOCK=256 O3DS_PASS_ROWS=512 --
-run "G4 b256 r768" O3DS_PASS_GROUP=4 O3DS_PASS_BLOCK=256 O3DS_PASS_ROWS=768 --
+run "G4 b256 r1024" O3DS_PASS_GROUP=4 O3DS_PASS_BLOCK=256 O3DS_PASS_ROWS=1024 --
+run "G4 b512 r1024" O3DS_PASS_GROUP=4 O3DS_PASS_BLOCK=512 O3DS_PASS_ROWS=1024 --
 run "G4 b256 r1024 cell.175" O3DS_PASS_GROUP=4 O3DS_PASS_BLOCK=256 O3DS_PASS_ROWS=1024 -- --cell 0.175
-run "G4 b256 r1024 cell.125" O3DS_PASS_GROUP=4 O3DS_PASS_BLOCK=256 O3DS_PASS_ROWS=1024 -- --cell 0.125
-run "G2 b256 r1024 cell.175" O3DS_PASS_GROUP=2 O3DS_PASS_BLOCK=256 O3DS_PASS_ROWS=1024 -- --cell 0.175
-run "G2 b256 r1024 cell.125" O3DS_PASS_GROUP=2 O3DS_PASS_BLOCK=256 O3DS_PASS_ROWS=1024 -- --cell 0.125
-run "G4 b256 r1024 f64" O3DS_PASS_GROUP=4 O3DS_PASS_BLOCK=256 O3DS_PASS_ROWS=1024 -- --precision f64
+run "G4 b256 r1024 cell.35" O3DS_PASS_GROUP=4 O3DS_PASS_BLOCK=256 O3DS_PASS_ROWS=1024 -- --cell 0.35
 } | tee $OUT/sweep.txt
 timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 2>&1 | tail -15 | tee $OUT/pytest_gpu.log
 cd /tmp && export TMPDIR=/tmp; rm -rf $OUT/prof
