@@ -110,26 +110,26 @@ CloudRec* find_cloud(o3ds_handle h, o3ds_cloud id) {
   return it == h->clouds.end() ? nullptr : &it->second;
 }
 
-void free_coarse(CloudRec& c) {
-  if (c.ccell_start) (void)hipFree(c.ccell_start);
-  if (c.cpts) (void)hipFree(c.cpts);
+void free_coarse(o3ds_handle h, CloudRec& c) {
+  if (c.ccell_start) (void)hipFreeAsync(c.ccell_start, h->stream);
+  if (c.cpts) (void)hipFreeAsync(c.cpts, h->stream);
   c.ccell_start = nullptr;
   c.cpts = nullptr;
   c.has_coarse = false;
 }
-void free_index(CloudRec& c) {
-  if (c.cell_start) (void)hipFree(c.cell_start);
-  if (c.spts) (void)hipFree(c.spts);
-  if (c.snrm) (void)hipFree(c.snrm);
+void free_index(o3ds_handle h, CloudRec& c) {
+  if (c.cell_start) (void)hipFreeAsync(c.cell_start, h->stream);
+  if (c.spts) (void)hipFreeAsync(c.spts, h->stream);
+  if (c.snrm) (void)hipFreeAsync(c.snrm, h->stream);
   c.cell_start = nullptr;
   c.spts = c.snrm = nullptr;
   c.has_index = false;
-  free_coarse(c);
+  free_coarse(h, c);
 }
-void free_cloud(CloudRec& c) {
-  free_index(c);
-  if (c.pts) (void)hipFree(c.pts);
-  if (c.nrm) (void)hipFree(c.nrm);
+void free_cloud(o3ds_handle h, CloudRec& c) {
+  free_index(h, c);
+  if (c.pts) (void)hipFreeAsync(c.pts, h->stream);
+  if (c.nrm) (void)hipFreeAsync(c.nrm, h->stream);
   c.pts = c.nrm = nullptr;
   c.n = 0;
 }
@@ -139,7 +139,7 @@ int exclusive_scan_int(o3ds_handle h, const int* in, int* out, size_t m) {
   if (m == 0) return O3DS_OK;
   const int nb = (int)((m + kScanPerBlock - 1) / kScanPerBlock);
   int* sums = nullptr;
-  HIP_TRY(hipMalloc(&sums, sizeof(int) * (size_t)nb));
+  HIP_TRY(hipMallocAsync((void**)&sums, sizeof(int) * (size_t)nb, h->stream));
   scan_local_kernel<<<nb, kBlock, 0, h->stream>>>(in, out, sums, m);
   if (nb > 1) {
     scan_sums_kernel<<<1, kBlock, 0, h->stream>>>(sums, nb);
@@ -147,7 +147,7 @@ int exclusive_scan_int(o3ds_handle h, const int* in, int* out, size_t m) {
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
-  HIP_TRY(hipFree(sums));
+  HIP_TRY(hipFreeAsync(sums, h->stream));
   return O3DS_OK;
 }
 
@@ -155,12 +155,12 @@ template <typename P4>
 int bbox_of(o3ds_handle h, const P4* pts, size_t n, double mn[3], double mx[3]) {
   const int g = grid_for(n, 1024);
   double* d = nullptr;
-  HIP_TRY(hipMalloc(&d, sizeof(double) * 6 * (size_t)g));
+  HIP_TRY(hipMallocAsync((void**)&d, sizeof(double) * 6 * (size_t)g, h->stream));
   bbox_kernel<P4><<<g, kBlock, 0, h->stream>>>(pts, n, d);
   std::vector<double> hb(6 * (size_t)g);
   HIP_TRY(hipMemcpyAsync(hb.data(), d, sizeof(double) * hb.size(), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  HIP_TRY(hipFree(d));
+  HIP_TRY(hipFreeAsync(d, h->stream));
   for (int a = 0; a < 3; ++a) {
     mn[a] = 1e300;
     mx[a] = -1e300;
@@ -204,12 +204,12 @@ int build_grid_t(o3ds_handle h, const P4* pts, const P4* nrm, size_t n, double c
   g.nz = (int)nz;
   int *counts = nullptr, *cursor = nullptr, *cell_id = nullptr, *cell_start = nullptr;
   void *spts = nullptr, *snrm = nullptr;
-  HIP_TRY(hipMalloc(&counts, sizeof(int) * (ncell + 1)));
-  HIP_TRY(hipMalloc(&cursor, sizeof(int) * ncell));
-  HIP_TRY(hipMalloc(&cell_id, sizeof(int) * n));
-  HIP_TRY(hipMalloc(&cell_start, sizeof(int) * (ncell + 1)));
-  HIP_TRY(hipMalloc(&spts, sizeof(P4) * n));
-  if (nrm) HIP_TRY(hipMalloc(&snrm, sizeof(P4) * n));
+  HIP_TRY(hipMallocAsync((void**)&counts, sizeof(int) * (ncell + 1), h->stream));
+  HIP_TRY(hipMallocAsync((void**)&cursor, sizeof(int) * ncell, h->stream));
+  HIP_TRY(hipMallocAsync((void**)&cell_id, sizeof(int) * n, h->stream));
+  HIP_TRY(hipMallocAsync((void**)&cell_start, sizeof(int) * (ncell + 1), h->stream));
+  HIP_TRY(hipMallocAsync((void**)&spts, sizeof(P4) * n, h->stream));
+  if (nrm) HIP_TRY(hipMallocAsync((void**)&snrm, sizeof(P4) * n, h->stream));
   HIP_TRY(hipMemsetAsync(counts, 0, sizeof(int) * (ncell + 1), h->stream));
   HIP_TRY(hipMemsetAsync(cursor, 0, sizeof(int) * ncell, h->stream));
   cell_count_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(pts, n, g, counts, cell_id);
@@ -218,9 +218,9 @@ int build_grid_t(o3ds_handle h, const P4* pts, const P4* nrm, size_t n, double c
   scatter_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(pts, nrm, n, cell_id, cell_start, cursor, (P4*)spts, (P4*)snrm);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
-  HIP_TRY(hipFree(counts));
-  HIP_TRY(hipFree(cursor));
-  HIP_TRY(hipFree(cell_id));
+  HIP_TRY(hipFreeAsync(counts, h->stream));
+  HIP_TRY(hipFreeAsync(cursor, h->stream));
+  HIP_TRY(hipFreeAsync(cell_id, h->stream));
   g.cell_start = cell_start;
   *out_grid = g;
   *out_cell_start = cell_start;
@@ -231,7 +231,7 @@ int build_grid_t(o3ds_handle h, const P4* pts, const P4* nrm, size_t n, double c
 
 template <typename P4>
 int build_index_t(o3ds_handle h, CloudRec& c, double cell) {
-  free_index(c);
+  free_index(h, c);
   int rc = build_grid_t<P4>(h, (const P4*)c.pts, (const P4*)c.nrm, c.n, cell, &c.grid, &c.cell_start, &c.spts, &c.snrm);
   if (rc) return rc;
   c.has_index = true;
@@ -240,7 +240,7 @@ int build_index_t(o3ds_handle h, CloudRec& c, double cell) {
 
 template <typename P4>
 int build_coarse_t(o3ds_handle h, CloudRec& c, double cell) {
-  free_coarse(c);
+  free_coarse(h, c);
   int rc = build_grid_t<P4>(h, (const P4*)c.pts, (const P4*)nullptr, c.n, cell, &c.coarse, &c.ccell_start, &c.cpts, nullptr);
   if (rc) return rc;
   c.has_coarse = true;
@@ -261,19 +261,19 @@ int upload_t(o3ds_handle h, const double* xyz, const double* normals, size_t n, 
   c.precision = h->precision;
   if (n == 0) return O3DS_OK;
   double* stage = nullptr;
-  HIP_TRY(hipMalloc(&stage, sizeof(double) * 3 * n));
-  HIP_TRY(hipMalloc(&c.pts, sizeof(P4) * n));
+  HIP_TRY(hipMallocAsync((void**)&stage, sizeof(double) * 3 * n, h->stream));
+  HIP_TRY(hipMallocAsync((void**)&c.pts, sizeof(P4) * n, h->stream));
   HIP_TRY(hipMemcpyAsync(stage, xyz, sizeof(double) * 3 * n, hipMemcpyHostToDevice, h->stream));
   pack_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(stage, n, (P4*)c.pts);
   if (normals) {
-    HIP_TRY(hipMalloc(&c.nrm, sizeof(P4) * n));
+    HIP_TRY(hipMallocAsync((void**)&c.nrm, sizeof(P4) * n, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));  // stage is reused
     HIP_TRY(hipMemcpyAsync(stage, normals, sizeof(double) * 3 * n, hipMemcpyHostToDevice, h->stream));
     pack_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(stage, n, (P4*)c.nrm);
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
-  HIP_TRY(hipFree(stage));
+  HIP_TRY(hipFreeAsync(stage, h->stream));
   return O3DS_OK;
 }
 
@@ -281,7 +281,7 @@ template <typename P4>
 int download_t(o3ds_handle h, const CloudRec& c, double* xyz, double* normals) {
   if (c.n == 0) return O3DS_OK;
   double* stage = nullptr;
-  HIP_TRY(hipMalloc(&stage, sizeof(double) * 3 * c.n));
+  HIP_TRY(hipMallocAsync((void**)&stage, sizeof(double) * 3 * c.n, h->stream));
   if (xyz) {
     unpack_kernel<P4><<<grid_for(c.n), kBlock, 0, h->stream>>>((const P4*)c.pts, c.n, stage);
     HIP_TRY(hipMemcpyAsync(xyz, stage, sizeof(double) * 3 * c.n, hipMemcpyDeviceToHost, h->stream));
@@ -293,7 +293,7 @@ int download_t(o3ds_handle h, const CloudRec& c, double* xyz, double* normals) {
     HIP_TRY(hipStreamSynchronize(h->stream));
   }
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipFree(stage));
+  HIP_TRY(hipFreeAsync(stage, h->stream));
   return O3DS_OK;
 }
 
@@ -452,6 +452,13 @@ int o3ds_create(int device_id, o3ds_handle* out) {
     delete h;
     return fail(nullptr, O3DS_ERR_HIP, "o3ds_create: device initialisation failed");
   }
+  {  // stream-ordered allocations come from the device pool; keep freed blocks cached instead of returning them to the driver
+    hipMemPool_t pool = nullptr;
+    if (hipDeviceGetDefaultMemPool(&pool, device_id) == hipSuccess && pool) {
+      uint64_t keep = UINT64_MAX;
+      (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
+  }
   if (const char* e = getenv("O3DS_DEBUG_UPDATE")) h->debug_update = atoi(e);
   if (const char* e = getenv("O3DS_PASS_BLOCK")) h->pass_block = atoi(e) == 512 ? 512 : 256;
   if (const char* e = getenv("O3DS_PASS_GROUP")) {
@@ -468,7 +475,7 @@ int o3ds_destroy(o3ds_handle h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   (void)hipStreamSynchronize(h->own_stream);
-  for (auto& kv : h->clouds) free_cloud(kv.second);
+  for (auto& kv : h->clouds) free_cloud(h, kv.second);
   if (h->d_partials) (void)hipFree(h->d_partials);
   if (h->d_state) (void)hipFree(h->d_state);
   if (h->h_state) (void)hipHostFree(h->h_state);
@@ -532,7 +539,7 @@ int o3ds_cloud_upload(o3ds_handle h, const double* xyz, const double* normals, s
   CloudRec c;
   int rc = h->precision == O3DS_PRECISION_F64 ? upload_t<P4d>(h, xyz, normals, n, c) : upload_t<P4f>(h, xyz, normals, n, c);
   if (rc) {
-    free_cloud(c);
+    free_cloud(h, c);
     return rc;
   }
   *out = add_cloud(h, std::move(c));
@@ -544,7 +551,7 @@ int o3ds_cloud_free(o3ds_handle h, o3ds_cloud id) {
   auto it = h->clouds.find(id);
   if (it == h->clouds.end()) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_free: unknown cloud id");
   (void)hipStreamSynchronize(h->stream);
-  free_cloud(it->second);
+  free_cloud(h, it->second);
   h->clouds.erase(it);
   return O3DS_OK;
 }
@@ -724,8 +731,8 @@ int crop_t(o3ds_handle h, const CloudRec& in, const CropDev& crop, CloudRec& out
   out.n = 0;
   if (in.n == 0) return O3DS_OK;
   int *flags = nullptr, *pos = nullptr;
-  HIP_TRY(hipMalloc(&flags, sizeof(int) * (in.n + 1)));
-  HIP_TRY(hipMalloc(&pos, sizeof(int) * (in.n + 1)));
+  HIP_TRY(hipMallocAsync((void**)&flags, sizeof(int) * (in.n + 1), h->stream));
+  HIP_TRY(hipMallocAsync((void**)&pos, sizeof(int) * (in.n + 1), h->stream));
   HIP_TRY(hipMemsetAsync(flags + in.n, 0, sizeof(int), h->stream));
   crop_flag_kernel<P4><<<grid_for(in.n), kBlock, 0, h->stream>>>((const P4*)in.pts, in.n, crop, flags);
   int rc = exclusive_scan_int(h, flags, pos, in.n + 1);
@@ -734,15 +741,15 @@ int crop_t(o3ds_handle h, const CloudRec& in, const CropDev& crop, CloudRec& out
   HIP_TRY(hipMemcpy(&total, pos + in.n, sizeof(int), hipMemcpyDeviceToHost));
   out.n = (size_t)total;
   if (total > 0) {
-    HIP_TRY(hipMalloc(&out.pts, sizeof(P4) * out.n));
-    if (in.nrm) HIP_TRY(hipMalloc(&out.nrm, sizeof(P4) * out.n));
+    HIP_TRY(hipMallocAsync((void**)&out.pts, sizeof(P4) * out.n, h->stream));
+    if (in.nrm) HIP_TRY(hipMallocAsync((void**)&out.nrm, sizeof(P4) * out.n, h->stream));
     compact_kernel<P4><<<grid_for(in.n), kBlock, 0, h->stream>>>((const P4*)in.pts, (const P4*)in.nrm, in.n, flags, pos, 1, (P4*)out.pts,
                                                                (P4*)out.nrm);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
   }
-  HIP_TRY(hipFree(flags));
-  HIP_TRY(hipFree(pos));
+  HIP_TRY(hipFreeAsync(flags, h->stream));
+  HIP_TRY(hipFreeAsync(pos, h->stream));
   return O3DS_OK;
 }
 
@@ -767,18 +774,18 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
   unsigned long long *k0 = nullptr, *k1 = nullptr, *d_scalar = nullptr;
   uint32_t *v0 = nullptr, *v1 = nullptr;
   int *head = nullptr, *seg_id = nullptr, *seg_start = nullptr;
-  HIP_TRY(hipMalloc(&k0, sizeof(unsigned long long) * n));
-  HIP_TRY(hipMalloc(&k1, sizeof(unsigned long long) * n));
-  HIP_TRY(hipMalloc(&v0, sizeof(uint32_t) * n));
-  HIP_TRY(hipMalloc(&v1, sizeof(uint32_t) * n));
-  HIP_TRY(hipMalloc(&head, sizeof(int) * (n + 1)));
-  HIP_TRY(hipMalloc(&seg_id, sizeof(int) * (n + 1)));
-  HIP_TRY(hipMalloc(&d_scalar, sizeof(unsigned long long)));
+  HIP_TRY(hipMallocAsync((void**)&k0, sizeof(unsigned long long) * n, h->stream));
+  HIP_TRY(hipMallocAsync((void**)&k1, sizeof(unsigned long long) * n, h->stream));
+  HIP_TRY(hipMallocAsync((void**)&v0, sizeof(uint32_t) * n, h->stream));
+  HIP_TRY(hipMallocAsync((void**)&v1, sizeof(uint32_t) * n, h->stream));
+  HIP_TRY(hipMallocAsync((void**)&head, sizeof(int) * (n + 1), h->stream));
+  HIP_TRY(hipMallocAsync((void**)&seg_id, sizeof(int) * (n + 1), h->stream));
+  HIP_TRY(hipMallocAsync((void**)&d_scalar, sizeof(unsigned long long), h->stream));
   voxel_key_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>((const P4*)in.pts, n, mode, ox, oy, oz, voxel, crop, k0, v0);
   size_t temp_bytes = 0;
   HIP_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, k0, k1, v0, v1, n, 0, 64, h->stream));
   void* temp = nullptr;
-  HIP_TRY(hipMalloc(&temp, temp_bytes ? temp_bytes : 16));
+  HIP_TRY(hipMallocAsync((void**)&temp, temp_bytes ? temp_bytes : 16, h->stream));
   HIP_TRY(rocprim::radix_sort_pairs(temp, temp_bytes, k0, k1, v0, v1, n, 0, 64, h->stream));
   HIP_TRY(hipMemsetAsync(head + n, 0, sizeof(int), h->stream));
   segment_head_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(k1, n, head);
@@ -790,17 +797,17 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
   HIP_TRY(hipMemcpy(&n_seg, seg_id + n, sizeof(int), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(&n_inside, d_scalar, sizeof(n_inside), hipMemcpyDeviceToHost));
   const size_t n_pass = n - (size_t)n_inside;
-  HIP_TRY(hipMalloc(&seg_start, sizeof(int) * ((size_t)n_seg + 1)));
+  HIP_TRY(hipMallocAsync((void**)&seg_start, sizeof(int) * ((size_t)n_seg + 1), h->stream));
   segment_start_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(head, seg_id, n, seg_start);
   out.n = (size_t)n_seg;
-  HIP_TRY(hipMalloc(&out.pts, sizeof(P4) * out.n));
-  if (in.nrm) HIP_TRY(hipMalloc(&out.nrm, sizeof(P4) * out.n));
+  HIP_TRY(hipMallocAsync((void**)&out.pts, sizeof(P4) * out.n, h->stream));
+  if (in.nrm) HIP_TRY(hipMallocAsync((void**)&out.nrm, sizeof(P4) * out.n, h->stream));
   segment_mean_kernel<P4><<<grid_for(out.n), kBlock, 0, h->stream>>>((const P4*)in.pts, (const P4*)in.nrm, k1, v1, seg_start, out.n, n,
                                                                     mode == 1 ? 1 : 0, n_pass, (P4*)out.pts, (P4*)out.nrm);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   for (void* p : {(void*)k0, (void*)k1, (void*)v0, (void*)v1, (void*)head, (void*)seg_id, (void*)seg_start, (void*)d_scalar, temp})
-    HIP_TRY(hipFree(p));
+    HIP_TRY(hipFreeAsync(p, h->stream));
   return O3DS_OK;
 }
 
@@ -816,17 +823,17 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn) {
   int rc = build_index_t<P4>(h, tmp, radius / 8.0);
   if (rc) {
     tmp.pts = nullptr;
-    free_index(tmp);
+    free_index(h, tmp);
     return rc;
   }
   const size_t ncell = (size_t)tmp.grid.nx * tmp.grid.ny * tmp.grid.nz;
   unsigned long long* d_cnt = nullptr;
-  HIP_TRY(hipMalloc(&d_cnt, sizeof(unsigned long long)));
+  HIP_TRY(hipMallocAsync((void**)&d_cnt, sizeof(unsigned long long), h->stream));
   HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), h->stream));
   count_occupied_kernel<<<grid_for(ncell), kBlock, 0, h->stream>>>(tmp.cell_start, ncell, d_cnt);
   unsigned long long occ = 0;
   HIP_TRY(hipMemcpy(&occ, d_cnt, sizeof(occ), hipMemcpyDeviceToHost));
-  HIP_TRY(hipFree(d_cnt));
+  HIP_TRY(hipFreeAsync(d_cnt, h->stream));
   const double avg = occ ? (double)c.n / (double)occ : 1.0;
   double cell = tmp.grid.cell * std::sqrt(std::max(1.0, (double)max_nn) / (3.14159265358979 * avg));
   cell = std::min(std::max(cell, radius / 64.0), radius);
@@ -834,23 +841,31 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn) {
     rc = build_index_t<P4>(h, tmp, cell);
     if (rc) {
       tmp.pts = nullptr;
-      free_index(tmp);
+      free_index(h, tmp);
       return rc;
     }
   }
-  if (!c.nrm) HIP_TRY(hipMalloc(&c.nrm, sizeof(P4) * c.n));
+  if (!c.nrm) HIP_TRY(hipMallocAsync((void**)&c.nrm, sizeof(P4) * c.n, h->stream));
   const int rmax = std::max(1, (int)std::ceil(radius / tmp.grid.cell));
-  if (max_nn <= 32)
-    normals_kernel<P4, 32><<<grid_for(c.n), kBlock, 0, h->stream>>>((const P4*)c.pts, c.n, tmp.grid, (const P4*)tmp.spts, radius, max_nn, rmax,
-                                                                  (P4*)c.nrm);
-  else
-    normals_kernel<P4, 128><<<grid_for(c.n), kBlock, 0, h->stream>>>((const P4*)c.pts, c.n, tmp.grid, (const P4*)tmp.spts, radius, max_nn, rmax,
-                                                                   (P4*)c.nrm);
+  // the k-best lists live in LDS ([slot][thread]); pick the instantiation by max_nn so that ~64 KB serve one workgroup
+  {
+    const P4* p_pts = (const P4*)c.pts;
+    const P4* p_sp = (const P4*)tmp.spts;
+    P4* p_out = (P4*)c.nrm;
+    constexpr bool kWide = sizeof(P4) > 16;  // f64 storage: half the threads per workgroup for the same LDS footprint
+    if (max_nn <= 32) {
+      constexpr int B = kWide ? 128 : 256;
+      normals_kernel<P4, 32, B><<<(int)std::min<size_t>((c.n + B - 1) / B, 8192), B, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, p_out);
+    } else {
+      constexpr int B = kWide ? 64 : 64;
+      normals_kernel<P4, 128, B><<<(int)std::min<size_t>((c.n + B - 1) / B, 16384), B, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, p_out);
+    }
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   tmp.pts = nullptr;
-  free_index(tmp);
-  free_index(c);  // the cloud's own index (if any) no longer matches its normals
+  free_index(h, tmp);
+  free_index(h, c);  // the cloud's own index (if any) no longer matches its normals
   return O3DS_OK;
 }
 
@@ -862,8 +877,8 @@ int transform_t(o3ds_handle h, const CloudRec& in, const double T[16], CloudRec&
   Mat34 M;
   for (int r = 0; r < 3; ++r)
     for (int c = 0; c < 4; ++c) M.m[r * 4 + c] = T[c * 4 + r];
-  HIP_TRY(hipMalloc(&out.pts, sizeof(P4) * in.n));
-  if (in.nrm) HIP_TRY(hipMalloc(&out.nrm, sizeof(P4) * in.n));
+  HIP_TRY(hipMallocAsync((void**)&out.pts, sizeof(P4) * in.n, h->stream));
+  if (in.nrm) HIP_TRY(hipMallocAsync((void**)&out.nrm, sizeof(P4) * in.n, h->stream));
   transform_kernel<P4><<<grid_for(in.n), kBlock, 0, h->stream>>>((const P4*)in.pts, (const P4*)in.nrm, in.n, M, T[3], T[7], T[11], T[15],
                                                                (P4*)out.pts, (P4*)out.nrm, 0);
   HIP_TRY(hipGetLastError());
@@ -876,8 +891,8 @@ int append_t(o3ds_handle h, CloudRec& map, const CloudRec& add) {
   const bool keep_nrm = (map.n == 0 || map.nrm) && add.nrm;
   const size_t n = map.n + add.n;
   void *np = nullptr, *nn = nullptr;
-  if (n > 0) HIP_TRY(hipMalloc(&np, sizeof(P4) * n));
-  if (keep_nrm && n > 0) HIP_TRY(hipMalloc(&nn, sizeof(P4) * n));
+  if (n > 0) HIP_TRY(hipMallocAsync((void**)&np, sizeof(P4) * n, h->stream));
+  if (keep_nrm && n > 0) HIP_TRY(hipMallocAsync((void**)&nn, sizeof(P4) * n, h->stream));
   if (map.n) {
     HIP_TRY(hipMemcpyAsync(np, map.pts, sizeof(P4) * map.n, hipMemcpyDeviceToDevice, h->stream));
     if (keep_nrm) HIP_TRY(hipMemcpyAsync(nn, map.nrm, sizeof(P4) * map.n, hipMemcpyDeviceToDevice, h->stream));
@@ -888,9 +903,9 @@ int append_t(o3ds_handle h, CloudRec& map, const CloudRec& add) {
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
-  free_index(map);
-  if (map.pts) HIP_TRY(hipFree(map.pts));
-  if (map.nrm) HIP_TRY(hipFree(map.nrm));
+  free_index(h, map);
+  if (map.pts) HIP_TRY(hipFreeAsync(map.pts, h->stream));
+  if (map.nrm) HIP_TRY(hipFreeAsync(map.nrm, h->stream));
   map.pts = np;
   map.nrm = nn;
   map.n = n;
@@ -911,7 +926,7 @@ int o3ds_crop_cloud(o3ds_handle h, o3ds_cloud in, const o3ds_crop* crop, o3ds_cl
   const CropDev cd = to_dev(crop);
   int rc = DISPATCH(c->precision, crop_t, h, *c, cd, o);
   if (rc) {
-    free_cloud(o);
+    free_cloud(h, o);
     return rc;
   }
   *out = add_cloud(h, std::move(o));
@@ -932,7 +947,7 @@ int o3ds_voxel_down_sample(o3ds_handle h, o3ds_cloud in, double voxel_size, o3ds
     rc = DISPATCH(c->precision, voxel_reduce_t, h, *c, 0, voxel_size, none, o);
   }
   if (rc) {
-    free_cloud(o);
+    free_cloud(h, o);
     return rc;
   }
   *out = add_cloud(h, std::move(o));
@@ -961,17 +976,17 @@ int o3ds_select_by_index(o3ds_handle h, o3ds_cloud in, const uint32_t* keep_idx,
   if (m) {
     uint32_t* d_idx = nullptr;
     const size_t psz = p4_size(c->precision);
-    HIP_TRY(hipMalloc(&d_idx, sizeof(uint32_t) * m));
+    HIP_TRY(hipMallocAsync((void**)&d_idx, sizeof(uint32_t) * m, h->stream));
     HIP_TRY(hipMemcpyAsync(d_idx, keep_idx, sizeof(uint32_t) * m, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMalloc(&o.pts, psz * m));
-    if (c->nrm) HIP_TRY(hipMalloc(&o.nrm, psz * m));
+    HIP_TRY(hipMallocAsync((void**)&o.pts, psz * m, h->stream));
+    if (c->nrm) HIP_TRY(hipMallocAsync((void**)&o.nrm, psz * m, h->stream));
     if (c->precision == O3DS_PRECISION_F64)
       gather_kernel<P4d><<<grid_for(m), kBlock, 0, h->stream>>>((const P4d*)c->pts, (const P4d*)c->nrm, d_idx, m, (P4d*)o.pts, (P4d*)o.nrm);
     else
       gather_kernel<P4f><<<grid_for(m), kBlock, 0, h->stream>>>((const P4f*)c->pts, (const P4f*)c->nrm, d_idx, m, (P4f*)o.pts, (P4f*)o.nrm);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipFree(d_idx));
+    HIP_TRY(hipFreeAsync(d_idx, h->stream));
   }
   *out = add_cloud(h, std::move(o));
   return O3DS_OK;
@@ -984,7 +999,7 @@ int o3ds_transform_cloud(o3ds_handle h, o3ds_cloud in, const double T[16], o3ds_
   CloudRec o;
   int rc = DISPATCH(c->precision, transform_t, h, *c, T, o);
   if (rc) {
-    free_cloud(o);
+    free_cloud(h, o);
     return rc;
   }
   *out = add_cloud(h, std::move(o));
@@ -1010,10 +1025,10 @@ int o3ds_voxelize_within_volume(o3ds_handle h, o3ds_cloud map, double voxel_size
   const CropDev cd = to_dev(crop);
   int rc = DISPATCH(m->precision, voxel_reduce_t, h, *m, 1, voxel_size, cd, o);
   if (rc) {
-    free_cloud(o);
+    free_cloud(h, o);
     return rc;
   }
-  free_cloud(*m);
+  free_cloud(h, *m);
   *m = o;
   return O3DS_OK;
 }
@@ -1030,7 +1045,7 @@ int o3ds_map_insert_scan(o3ds_handle h, o3ds_cloud map, o3ds_cloud scan, const d
   CloudRec t;
   int rc = DISPATCH(s->precision, transform_t, h, *s, T, t);  // Submap.cpp:54
   if (!rc) rc = DISPATCH(m->precision, append_t, h, *m, t);   // Submap.cpp:70
-  free_cloud(t);
+  free_cloud(h, t);
   if (rc) return rc;
   rc = o3ds_voxelize_within_volume(h, map, map_voxel_size, map_builder_crop);  // Submap.cpp:71-72
   if (rc) return rc;
