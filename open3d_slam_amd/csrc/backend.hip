@@ -42,6 +42,7 @@ struct CloudRec {
   void* cpts = nullptr;
 };
 
+constexpr int kMaxLoopWgs = 1024;     // >= CUs of any device this runs on
 constexpr int kMaxPassBlocks = 4096;  // capacity of the partial-record buffer (rows per pass <= pass_rows <= this)
 constexpr size_t kMaxCells = (size_t)1 << 27;  // 512 MiB of cell_start at most
 
@@ -67,6 +68,13 @@ struct o3ds_context {
   bool session_crop = false;
   hipStream_t own_stream = nullptr;
   // launch geometry of the ICP pass kernel (tunable through O3DS_PASS_BLOCK / O3DS_PASS_ROWS for experiments)
+  // two launches per pass (default) vs ONE persistent loop kernel per registration (O3DS_ICP_MODE=persistent);
+  // measured on MI355X the grid rendezvous of the persistent form costs what the launches cost (profiles/r01_*), so the
+  // simpler form is the default
+  bool persistent = false;
+  int cu_count = 256;
+  double* d_rows = nullptr;        // [2][kMaxLoopWgs][kRec]
+  unsigned int* d_counter = nullptr;
   int debug_update = 0;  // O3DS_DEBUG_UPDATE: timing experiments only
   int pass_block = 256;
   int pass_group = 4;
@@ -342,6 +350,40 @@ void launch_accumulate(o3ds_handle h, const IcpPassArgs& a, bool crop, int nbloc
   if (e1) (void)hipEventRecord(e1, h->stream);
 }
 
+// persistent loop kernel: one workgroup per CU (fewer when the source has fewer batches), 1024 threads each
+int loop_wgs(o3ds_handle h, size_t count) {
+  const size_t qpb = (size_t)kLoopBlock / 4;
+  size_t g = (count + qpb - 1) / qpb;
+  if (g < 1) g = 1;
+  if (g > (size_t)h->cu_count) g = h->cu_count;
+  return (int)g;
+}
+
+template <typename P4>
+void launch_loop(o3ds_handle h, const IcpLoopArgs& la, bool crop, int nwg) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (h->profiling && !la.single_pass) {
+    if (h->ev_used + 2 > h->ev.size()) {
+      hipEvent_t a0, a1;
+      if (hipEventCreate(&a0) == hipSuccess && hipEventCreate(&a1) == hipSuccess) {
+        h->ev.push_back(a0);
+        h->ev.push_back(a1);
+      }
+    }
+    if (h->ev_used + 2 <= h->ev.size()) {
+      e0 = h->ev[h->ev_used];
+      e1 = h->ev[h->ev_used + 1];
+      h->ev_used += 2;
+      (void)hipEventRecord(e0, h->stream);
+    }
+  }
+  if (crop)
+    icp_loop_kernel<P4, true, 4><<<nwg, kLoopBlock, 0, h->stream>>>(la);
+  else
+    icp_loop_kernel<P4, false, 4><<<nwg, kLoopBlock, 0, h->stream>>>(la);
+  if (e1) (void)hipEventRecord(e1, h->stream);
+}
+
 int pass_blocks(o3ds_handle h, size_t count) {
   const size_t qpb = (size_t)h->pass_block / h->pass_group;  // one batch of BLOCK/G queries per workgroup iteration
   size_t g = (count + qpb - 1) / qpb;
@@ -459,6 +501,16 @@ int o3ds_create(int device_id, o3ds_handle* out) {
       (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
     }
   }
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
+      h->cu_count = std::min(prop.multiProcessorCount, kMaxLoopWgs);
+    if (hipMalloc(&h->d_rows, sizeof(double) * 2 * kMaxLoopWgs * kRec) != hipSuccess || hipMalloc(&h->d_counter, sizeof(unsigned int)) != hipSuccess) {
+      o3ds_destroy(h);
+      return fail(nullptr, O3DS_ERR_OOM, "o3ds_create: scratch allocation failed");
+    }
+    if (const char* e = getenv("O3DS_ICP_MODE")) h->persistent = std::string(e) == "persistent";
+  }
   if (const char* e = getenv("O3DS_DEBUG_UPDATE")) h->debug_update = atoi(e);
   if (const char* e = getenv("O3DS_PASS_BLOCK")) h->pass_block = atoi(e) == 512 ? 512 : 256;
   if (const char* e = getenv("O3DS_PASS_GROUP")) {
@@ -476,6 +528,8 @@ int o3ds_destroy(o3ds_handle h) {
   (void)hipStreamSynchronize(h->stream);
   (void)hipStreamSynchronize(h->own_stream);
   for (auto& kv : h->clouds) free_cloud(h, kv.second);
+  if (h->d_rows) (void)hipFree(h->d_rows);
+  if (h->d_counter) (void)hipFree(h->d_counter);
   if (h->d_partials) (void)hipFree(h->d_partials);
   if (h->d_state) (void)hipFree(h->d_state);
   if (h->h_state) (void)hipHostFree(h->h_state);
@@ -600,12 +654,27 @@ int o3ds_icp_accumulate(o3ds_handle h, size_t first, size_t count, double* d_rec
   IcpPassArgs a = h->pass;
   a.first = first;
   a.count = count;
-  const int nb = pass_blocks(h, count);
-  if (h->session_precision == O3DS_PRECISION_F64)
-    launch_accumulate<P4d>(h, a, h->session_crop, nb);
-  else
-    launch_accumulate<P4f>(h, a, h->session_crop, nb);
-  icp_reduce_kernel<<<1, kUpdBlock, 0, h->stream>>>(h->d_partials, nb, h->d_state, d_record);
+  if (h->persistent) {  // same workgroup geometry and summation order as the one-shot persistent loop => identical records
+    IcpLoopArgs la{};
+    la.pass = a;
+    la.state = h->d_state;
+    la.rows = h->d_rows;
+    la.counter = h->d_counter;
+    la.single_pass = 1;
+    const int nwg = loop_wgs(h, count);
+    if (h->session_precision == O3DS_PRECISION_F64)
+      launch_loop<P4d>(h, la, h->session_crop, nwg);
+    else
+      launch_loop<P4f>(h, la, h->session_crop, nwg);
+    icp_reduce_kernel<<<1, kUpdBlock, 0, h->stream>>>(h->d_rows, nwg, h->d_state, d_record);
+  } else {
+    const int nb = pass_blocks(h, count);
+    if (h->session_precision == O3DS_PRECISION_F64)
+      launch_accumulate<P4d>(h, a, h->session_crop, nb);
+    else
+      launch_accumulate<P4f>(h, a, h->session_crop, nb);
+    icp_reduce_kernel<<<1, kUpdBlock, 0, h->stream>>>(h->d_partials, nb, h->d_state, d_record);
+  }
   HIP_TRY(hipGetLastError());
   return O3DS_OK;
 }
@@ -645,6 +714,29 @@ int o3ds_icp_point_to_plane_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud tar
   if (rc) return rc;
   h->session = false;  // the loop below owns the state
   const IcpPassArgs a = h->pass;
+  if (h->persistent) {  // all passes in one launch; the device decides termination
+    IcpLoopArgs la{};
+    la.pass = a;
+    la.state = h->d_state;
+    la.rows = h->d_rows;
+    la.counter = h->d_counter;
+    la.n_src_total = (unsigned long long)a.count;
+    la.max_iter = params->max_iteration;
+    la.rel_fitness = params->relative_fitness;
+    la.rel_rmse = params->relative_rmse;
+    la.single_pass = 0;
+    const int nwg = loop_wgs(h, a.count);
+    HIP_TRY(hipMemsetAsync(h->d_counter, 0, sizeof(unsigned int), h->stream));
+    if (h->session_precision == O3DS_PRECISION_F64)
+      launch_loop<P4d>(h, la, h->session_crop, nwg);
+    else
+      launch_loop<P4f>(h, la, h->session_crop, nwg);
+    HIP_TRY(hipGetLastError());
+    rc = read_state(h, out);
+    if (rc) return rc;
+    if (h->h_state->error) return fail(h, O3DS_ERR_HIP, "icp: persistent loop kernel timed out at the grid rendezvous");
+    return O3DS_OK;
+  }
   const int nb = pass_blocks(h, a.count);
   const int total_passes = params->max_iteration + 1;  // max_iter updates need max_iter+1 correspondence passes
   int launched = 0;

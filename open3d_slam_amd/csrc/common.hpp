@@ -107,6 +107,8 @@ struct IcpStateDev {
   int iterations;  // updates applied
   int done;
   int converged;
+  int error;  // 1: a workgroup of the persistent loop kernel timed out at the grid rendezvous (never expected)
+  int pad;
 };
 
 }  // namespace o3ds

@@ -375,29 +375,32 @@ __device__ const unsigned char kTermB[kRec] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 
 // Workgroup = BLOCK threads = BLOCK/G queries x G lanes for the search, then (32 record terms) x (BLOCK/32 query slices) for the
 // accumulation: one f64 accumulator per thread instead of 30, so the kernel stays small in registers and the chip can
 // keep enough wavefronts in flight to hide the dependent-load latency of the search.
+__device__ __forceinline__ double to_sgpr(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+// One correspondence + reduction pass of the workgroup's share of the source (batches wg, wg+nwg, ..) under the
+// transformation Tm (column-major, 16 doubles, any address space).  Leaves the workgroup's 32-double partial record
+// in s_red[0][0..31]... more precisely returns it in `row_val` of threads 0..31.
 template <typename P4, bool kCrop, int kPassBlock, int kGroup>
-__global__ __launch_bounds__(kPassBlock) void icp_accumulate_kernel(IcpPassArgs a) {
+__device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const double* Tm, int wg, int nwg, double (*s_rec)[kRecSlots],
+                                                double (*s_red)[kRec]) {
   constexpr int kQPB = kPassBlock / kGroup;
   using R = typename Scalar<P4>::type;
-  if (a.state->done) return;  // device-side loop already terminated: keep the previous partials
-  __shared__ double s_rec[kQPB][kRecSlots];
-  __shared__ double s_red[kPassBlock / 32][kRec];
   const P4* __restrict__ src = (const P4*)a.src;
   const P4* __restrict__ tp = (const P4*)a.tpts;
   const P4* __restrict__ tn = (const P4*)a.tnrm;
-  const double* T = a.state->T;  // column-major
-  const double t00 = T[0], t10 = T[1], t20 = T[2], t01 = T[4], t11 = T[5], t21 = T[6], t02 = T[8], t12 = T[9], t22 = T[10],
-               t03 = T[12], t13 = T[13], t23 = T[14];
+  // the pose is wave-uniform: keep it in scalar registers (it arrives through LDS in the persistent kernel)
+  const double t00 = to_sgpr(Tm[0]), t10 = to_sgpr(Tm[1]), t20 = to_sgpr(Tm[2]), t01 = to_sgpr(Tm[4]), t11 = to_sgpr(Tm[5]),
+               t21 = to_sgpr(Tm[6]), t02 = to_sgpr(Tm[8]), t12 = to_sgpr(Tm[9]), t22 = to_sgpr(Tm[10]), t03 = to_sgpr(Tm[12]),
+               t13 = to_sgpr(Tm[13]), t23 = to_sgpr(Tm[14]);
   const int gl = threadIdx.x & (kGroup - 1), ql = threadIdx.x / kGroup;
   const int term = threadIdx.x & 31, qs = threadIdx.x >> 5;
   const int ta = kTermA[term], tb = kTermB[term];
   double acc = 0.0;
-  if (a.debug == 1) {
-    if (threadIdx.x < kRec) a.partials[(size_t)blockIdx.x * kRec + threadIdx.x] = t00 * 1e-300;
-    return;
-  }
   const size_t n_batches = (a.count + kQPB - 1) / kQPB;
-  for (size_t b = blockIdx.x; b < n_batches; b += gridDim.x) {
+  for (size_t b = (size_t)wg; b < n_batches; b += (size_t)nwg) {
     const size_t i = b * kQPB + ql;
     double px = 0, py = 0, pz = 0;
     NNBest<P4> nn;
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(kPassBlock) void icp_accumulate_kernel(IcpPassArgs 
     nn.idx = -1;
     nn.d2 = (R)0;
     bool unresolved = false;
-    if (i < a.count) {  // uniform across the 8 lanes of a group
+    if (i < a.count) {  // uniform across the lanes of a group
       const P4 s = src[a.first + i];
       // [O3D] PointCloud::Transform: rigid 4x4 (bottom row 0 0 0 1 for every pose the reference passes)
       px = t00 * (double)s.x + t01 * (double)s.y + t02 * (double)s.z + t03;
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(kPassBlock) void icp_accumulate_kernel(IcpPassArgs 
         nn.pos = (int)(i % 1000);
         nn.idx = nn.pos;
       } else
-      nn = nn_search_group<P4, kCrop, kGroup>(a.grid, tp, (R)px, (R)py, (R)pz, (R)a.r2max, a.rmax_cells, a.crop, gl, &resolved);
+        nn = nn_search_group<P4, kCrop, kGroup>(a.grid, tp, (R)px, (R)py, (R)pz, (R)a.r2max, a.rmax_cells, a.crop, gl, &resolved);
       unresolved = !resolved;
     }
     // far queries of this wavefront, one after the other, 64 lanes each (wave-uniform loop)
@@ -426,13 +429,13 @@ __global__ __launch_bounds__(kPassBlock) void icp_accumulate_kernel(IcpPassArgs 
       while (m) {
         const int sl = __ffsll((long long)m) - 1;
         m &= m - 1;
-        NNBest<P4> b;
-        b.d2 = __shfl(nn.d2, sl, 64);
-        b.pos = __shfl(nn.pos, sl, 64);
-        b.idx = __shfl(nn.idx, sl, 64);
+        NNBest<P4> bq;
+        bq.d2 = __shfl(nn.d2, sl, 64);
+        bq.pos = __shfl(nn.pos, sl, 64);
+        bq.idx = __shfl(nn.idx, sl, 64);
         const R bx = __shfl((R)px, sl, 64), by = __shfl((R)py, sl, 64), bz = __shfl((R)pz, sl, 64);
-        nn_search_wave_coarse<P4, kCrop>(a.coarse, (const P4*)a.cpts, bx, by, bz, a.crop, b, lane);
-        if ((lane & ~(kGroup - 1)) == sl) nn = b;
+        nn_search_wave_coarse<P4, kCrop>(a.coarse, (const P4*)a.cpts, bx, by, bz, a.crop, bq, lane);
+        if ((lane & ~(kGroup - 1)) == sl) nn = bq;
       }
     }
     if (gl == 0) {
@@ -466,15 +469,34 @@ __global__ __launch_bounds__(kPassBlock) void icp_accumulate_kernel(IcpPassArgs 
     }
     __syncthreads();  // s_rec is rewritten by the next batch
   }
-  // 16 query slices -> 1, fixed order => bitwise reproducible for a given launch geometry
+  // query slices -> 1, fixed order => bitwise reproducible for a given launch geometry
   s_red[qs][term] = acc;
   __syncthreads();
+  double v = 0.0;
   if (threadIdx.x < kRec) {
-    double v = 0.0;
 #pragma unroll
     for (int k = 0; k < kPassBlock / 32; ++k) v += s_red[k][threadIdx.x];
-    a.partials[(size_t)blockIdx.x * kRec + threadIdx.x] = threadIdx.x < 30 ? v : 0.0;
+    if (threadIdx.x >= 30) v = 0.0;
   }
+  __syncthreads();  // s_red may be reused by the caller
+  return v;         // valid in threads 0..31
+}
+
+// Workgroup = BLOCK threads = BLOCK/G queries x G lanes for the search, then (32 record terms) x (BLOCK/32 query slices) for the
+// accumulation: one f64 accumulator per thread instead of 30, so the kernel stays small in registers and the chip can
+// keep enough wavefronts in flight to hide the dependent-load latency of the search.
+template <typename P4, bool kCrop, int kPassBlock, int kGroup>
+__global__ __launch_bounds__(kPassBlock) void icp_accumulate_kernel(IcpPassArgs a) {
+  constexpr int kQPB = kPassBlock / kGroup;
+  if (a.state->done) return;  // device-side loop already terminated: keep the previous partials
+  __shared__ double s_rec[kQPB][kRecSlots];
+  __shared__ double s_red[kPassBlock / 32][kRec];
+  if (a.debug == 1) {
+    if (threadIdx.x < kRec) a.partials[(size_t)blockIdx.x * kRec + threadIdx.x] = a.state->T[0] * 1e-300;
+    return;
+  }
+  const double v = icp_pass_body<P4, kCrop, kPassBlock, kGroup>(a, a.state->T, blockIdx.x, gridDim.x, s_rec, s_red);
+  if (threadIdx.x < kRec) a.partials[(size_t)blockIdx.x * kRec + threadIdx.x] = v;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -631,9 +653,80 @@ __host__ __device__ inline void solve6_ldlt(const double* rec, double x[6]) {
       if (perm[i] == k) x[k] = w[i];
 }
 
+// The same solve spread over the first six lanes of a wavefront: lane i owns row i of the augmented system [JtJ | -Jtr].
+// Symmetric pivoting on the largest |diagonal| (first occurrence, as Eigen's LDLT), elimination with the multipliers of
+// all remaining rows computed in parallel, back substitution.  Arithmetically this is the L D L^T solve (elimination of the
+// right-hand side is L y = b; back substitution on D L^T is D z = y, L^T w = z fused), so it agrees with solve6_ldlt to
+// rounding; it keeps ~30 VGPRs instead of ~90 and has 6 dependent divisions instead of 21, which matters because this
+// tail is on the critical path of every ICP iteration (measured: 3-4 us serial, vs 1 us here).
+__device__ __forceinline__ void solve6_wave(const double* rec, double* x_out, int lane) {
+  double a[6], b = 0.0;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int r = min(lane, j), c = max(lane, j);
+    a[j] = lane < 6 ? rec[r * 6 - (r * (r - 1)) / 2 + (c - r)] : (j == 0 ? 1.0 : 0.0);
+  }
+  if (lane < 6) b = -rec[21 + lane];
+  int perm = lane;
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
+    double diag = a[0];
+#pragma unroll
+    for (int k = 1; k < 6; ++k) diag = lane == k ? a[k] : diag;
+    const double ad = fabs(diag);
+    int piv = s;
+    double best = __shfl(ad, s, 64);
+#pragma unroll
+    for (int j = s + 1; j < 6; ++j) {
+      const double v = __shfl(ad, j, 64);
+      if (v > best) {
+        best = v;
+        piv = j;
+      }
+    }
+    if (piv != s) {  // wave-uniform
+      const int srcl = lane == s ? piv : (lane == piv ? s : lane);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) a[k] = __shfl(a[k], srcl, 64);
+      b = __shfl(b, srcl, 64);
+      perm = __shfl(perm, srcl, 64);
+#pragma unroll
+      for (int k = s + 1; k < 6; ++k) {
+        if (piv == k) {
+          const double t = a[s];
+          a[s] = a[k];
+          a[k] = t;
+        }
+      }
+    }
+    const double d = __shfl(a[s], s, 64);
+    const double bs = __shfl(b, s, 64);
+    const double l = a[s] / d;
+    const bool below = lane > s && lane < 6;
+#pragma unroll
+    for (int j = s + 1; j < 6; ++j) {
+      const double rs = __shfl(a[j], s, 64);
+      if (below) a[j] -= l * rs;
+    }
+    if (below) b -= l * bs;
+  }
+  double xs[6];
+  double mine = 0.0;
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    double num = b;
+#pragma unroll
+    for (int j = i + 1; j < 6; ++j) num -= a[j] * xs[j];
+    const double xi = num / a[i];
+    xs[i] = __shfl(xi, i, 64);
+    if (lane == i) mine = xi;
+  }
+  if (lane < 6) x_out[perm] = mine;
+}
+
 // [O3D] RegistrationICP loop body after the correspondence pass: convergence test, solve, T <- U*T.
 // Called by every thread of one workgroup (>= 64 threads) with the record in LDS.  Thread 0 runs the scalar part
-// (statistics, convergence, LDL^T); the trigonometry and the 4x4 products are spread over lanes because f64
+// (statistics, convergence); the solve, the trigonometry and the 4x4 products are spread over lanes because f64
 // sin/cos and divides are long dependent chains and this tail is on the critical path of every iteration.
 __device__ __forceinline__ void icp_step_block(const double* s_rec, IcpStateDev* st, unsigned long long n_src_total, int max_iter,
                                                double rel_fitness, double rel_rmse, double* s_x /* [8] */, double* s_sc /* [8] */,
@@ -655,17 +748,16 @@ __device__ __forceinline__ void icp_step_block(const double* s_rec, IcpStateDev*
     } else if (st->iterations >= max_iter) {
       st->done = 1;
     } else {
-      go = 1;
-      double x[6] = {0, 0, 0, 0, 0, 0};  // empty correspondence set => identity update
-      if (count > 0.0) solve6_ldlt(s_rec, x);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) s_x[k] = x[k];
+      go = count > 0.0 ? 2 : 1;  // 1: empty correspondence set => identity update (x = 0)
     }
     *s_go = go;
   }
   if (threadIdx.x < 16) s_T[threadIdx.x] = st->T[threadIdx.x];
+  if (threadIdx.x < 8) s_x[threadIdx.x] = 0.0;
   __syncthreads();
   if (!*s_go) return;
+  if (*s_go == 2 && threadIdx.x < 64) solve6_wave(s_rec, s_x, threadIdx.x);
+  __syncthreads();
   if (threadIdx.x < 3) {
     double sn, cs;
     sincos(s_x[threadIdx.x], &sn, &cs);
@@ -736,6 +828,111 @@ __global__ __launch_bounds__(64) void icp_update_kernel(const double* __restrict
   if (threadIdx.x < kRec) s_out[threadIdx.x] = record[threadIdx.x];
   __syncthreads();
   icp_step_block(s_out, state, n_src_total, max_iter, rel_fitness, rel_rmse, s_x, s_sc, s_U, s_T, &s_go);
+}
+
+// ----------------------------------------------------------------------------------------------
+// persistent ICP loop: ALL passes of one registration in ONE launch
+// ----------------------------------------------------------------------------------------------
+// Measured on MI355X: every kernel launch on the dependent chain costs ~4.6-5 us of floor plus ~3.3 us of boundary, so
+// the two-launch-per-pass scheme spends 16 of its 30 us per iteration outside the arithmetic.  Here one workgroup per
+// CU stays resident for the whole registration.  Per pass every workgroup accumulates its share of the source,
+// publishes its 32-double record with write-through (sc1) stores, arrives on a monotonic device-scope counter, waits
+// for all arrivals, and then EVERY workgroup redundantly sums the records in the same fixed order and runs the same
+// convergence test / 6x6 solve / pose update -- identical inputs, identical instruction stream, identical T in every
+// workgroup, so no second rendezvous and no broadcast are needed.  Record rows are double-buffered by pass parity: a
+// workgroup can run at most one pass ahead of the slowest one.
+// Publication follows the release/acquire-free form of the CDNA guide (G16 R1): sc1 payload stores, s_waitcnt vmcnt(0)
+// in the storing wave, one relaxed agent-scope atomic on the counter; consumers poll the counter relaxed and read the
+// payload with sc1 (agent-scope relaxed atomic) loads.  Every spin is bounded.
+struct IcpLoopArgs {
+  IcpPassArgs pass;
+  IcpStateDev* state;
+  double* rows;          // [2][gridDim.x][kRec]
+  unsigned int* counter; // zeroed by the host before every launch
+  unsigned long long n_src_total;
+  int max_iter;
+  double rel_fitness, rel_rmse;
+  int single_pass;       // 1: publish the rows of ONE pass to rows[0] and exit (step-wise / sharded path)
+};
+
+constexpr int kLoopBlock = 1024;
+
+template <typename P4, bool kCrop, int kGroup>
+__global__ __launch_bounds__(kLoopBlock) void icp_loop_kernel(IcpLoopArgs la) {
+  constexpr int kQPB = kLoopBlock / kGroup;
+  __shared__ double s_rec[kQPB][kRecSlots];
+  __shared__ double s_red[kLoopBlock / 32][kRec];
+  __shared__ double s_out[kRec];
+  __shared__ double s_x[8], s_sc[8], s_U[16], s_T[16];
+  __shared__ IcpStateDev s_st;
+  __shared__ int s_go, s_timeout;
+  const int nwg = gridDim.x, wg = blockIdx.x;
+  if (threadIdx.x == 0) {
+    s_st = *la.state;
+    s_timeout = 0;
+  }
+  __syncthreads();
+  if (s_st.done) return;
+  for (int pass = 0;; ++pass) {
+    const double v = icp_pass_body<P4, kCrop, kLoopBlock, kGroup>(la.pass, s_st.T, wg, nwg, s_rec, s_red);
+    double* rows = la.rows + (size_t)(la.single_pass ? 0 : (pass & 1)) * nwg * kRec;
+    if (threadIdx.x < kRec) {
+      __hip_atomic_store(rows + (size_t)wg * kRec + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the storing wave drains its write-through stores
+    }
+    if (la.single_pass) return;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(la.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned int target = (unsigned int)(pass + 1) * (unsigned int)nwg;
+      unsigned int spins = 0;
+      while (__hip_atomic_load(la.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 22)) {  // ~seconds: another workgroup never arrived
+          s_timeout = 1;
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    if (s_timeout) {
+      if (wg == 0 && threadIdx.x == 0) {
+        s_st.error = 1;
+        s_st.done = 1;
+        *la.state = s_st;
+      }
+      return;
+    }
+    // every workgroup sums all records in the same fixed order (32 parts x 32 columns; rows part, part+32, ..)
+    {
+      constexpr int kParts = kLoopBlock / 32;
+      const int col = threadIdx.x & 31, part = threadIdx.x >> 5;
+      double acc = 0.0;
+      for (int b0 = part; b0 < nwg; b0 += 16 * kParts) {
+        double x[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const int b = b0 + k * kParts;
+          x[k] = b < nwg ? __hip_atomic_load(rows + (size_t)b * kRec + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += x[k];
+      }
+      s_red[part][col] = acc;
+      __syncthreads();
+      if (threadIdx.x < kRec) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < kParts; ++k) t += s_red[k][threadIdx.x];
+        s_out[threadIdx.x] = t;
+      }
+      __syncthreads();
+    }
+    icp_step_block(s_out, &s_st, la.n_src_total, la.max_iter, la.rel_fitness, la.rel_rmse, s_x, s_sc, s_U, s_T, &s_go);
+    __syncthreads();
+    if (s_st.done) break;
+  }
+  if (wg == 0 && threadIdx.x == 0) *la.state = s_st;
 }
 
 }  // namespace o3ds

@@ -10,10 +10,9 @@ d=json.loads(sys.stdin.readline()); r=d['roofline']
 print('%-28s %8.0f it/s  %7.3f ms/step  kernel %6.1f us  frac %.4f' % ('$label', d['value'], d['ms_per_step'], r['avg_launch_us'], r['frac']))"
 }
 {
-run "G4 b256 r1024" O3DS_PASS_GROUP=4 O3DS_PASS_BLOCK=256 O3DS_PASS_ROWS=1024 --
-run "G4 b512 r1024" O3DS_PASS_GROUP=4 O3DS_PASS_BLOCK=512 O3DS_PASS_ROWS=1024 --
-run "G4 b256 r1024 cell.175" O3DS_PASS_GROUP=4 O3DS_PASS_BLOCK=256 O3DS_PASS_ROWS=1024 -- --cell 0.175
-run "G4 b256 r1024 cell.35" O3DS_PASS_GROUP=4 O3DS_PASS_BLOCK=256 O3DS_PASS_ROWS=1024 -- --cell 0.35
+run "persistent" O3DS_ICP_MODE=persistent --
+run "launch G4 b256 r1024" O3DS_ICP_MODE=launch O3DS_PASS_GROUP=4 O3DS_PASS_BLOCK=256 O3DS_PASS_ROWS=1024 --
+run "persistent f64" O3DS_ICP_MODE=persistent -- --precision f64
 } | tee $OUT/sweep.txt
 timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 2>&1 | tail -15 | tee $OUT/pytest_gpu.log
 cd /tmp && export TMPDIR=/tmp; rm -rf $OUT/prof

@@ -267,3 +267,34 @@ def test_sharded_driver_single_rank_on_gpu(backend_f32, small_c2):
     np.testing.assert_array_equal(again["transformation"], one["transformation"])
     backend_f32.free(s)
     backend_f32.free(t)
+
+
+def test_persistent_loop_kernel_mode(oracle, small_c2, monkeypatch):
+    """O3DS_ICP_MODE=persistent: all passes of a registration in ONE launch (grid rendezvous on a device-scope counter, every
+    workgroup solving redundantly).  Same results as the oracle, and step-wise == one-shot bit for bit in this mode too."""
+    import torch
+
+    monkeypatch.setenv("O3DS_ICP_MODE", "persistent")
+    be = backend.Backend(0, backend.PRECISION_F64)
+    try:
+        src, tgt, nrm, _ = small_c2
+        for kw in (dict(max_iter=10, rel_fitness=0.0, rel_rmse=0.0), dict(max_iter=30)):
+            got = be.icp_point_to_plane(src, tgt, nrm, 1.0, **kw)
+            ref = oracle.icp_point_to_plane(src, tgt, nrm, 1.0, **kw)
+            assert got["iterations"] == ref["iterations"] and got["converged"] == ref["converged"]
+            _check(got, ref, len(src), TOL_T64, TOL_R64)
+        s, t = be.upload(src), be.upload(tgt, nrm)
+        be.build_index(t, 1.0)
+        one = be.icp_point_to_plane_dev(s, t, 1.0, max_iter=6, rel_fitness=0.0, rel_rmse=0.0)
+        rec = torch.zeros(32, dtype=torch.float64, device="cuda:0")
+        torch.cuda.synchronize()
+        be.icp_begin(s, t, 1.0, max_iter=6, rel_fitness=0.0, rel_rmse=0.0)
+        for _ in range(7):
+            be.icp_accumulate(0, len(src), rec.data_ptr())
+            be.icp_update(rec.data_ptr(), len(src))
+        step = be.icp_finish()
+        np.testing.assert_array_equal(step["transformation"], one["transformation"])
+        far = be.icp_point_to_plane(src + 1000.0, tgt, nrm, 1.0, max_iter=5)
+        assert far["fitness"] == 0.0 and far["iterations"] == 1 and far["converged"]
+    finally:
+        be.close()
