@@ -73,11 +73,14 @@ typedef struct {
   uint64_t n_corr;
 } o3ds_icp_result;
 
+/* CloudRegistrationType (Parameters.hpp:37-42) as far as the HIP backend implements it */
+typedef enum { O3DS_ICP_POINT_TO_PLANE = 0, O3DS_ICP_GENERALIZED = 1 } o3ds_icp_method;
+
 /* IcpParameters (Parameters.hpp:66-71) + [O3D] ICPConvergenceCriteria */
 typedef struct {
   double max_correspondence_distance; /* IcpParameters::maxCorrespondenceDistance_ */
   int32_t max_iteration;              /* IcpParameters::maxNumIter_ -> criteria.max_iteration_ (CloudRegistration.cpp:63) */
-  int32_t reserved;
+  int32_t method;                     /* o3ds_icp_method; read by o3ds_icp_register_dev / o3ds_icp_begin only */
   double relative_fitness;            /* [O3D] default 1e-6, never overridden by the reference */
   double relative_rmse;               /* [O3D] default 1e-6 */
 } o3ds_icp_params;
@@ -124,6 +127,21 @@ int o3ds_icp_point_to_plane(o3ds_handle h, const double* src_xyz, size_t n_src, 
  * scanMatcherCropper_->crop(activeSubmapPointCloud) (ScanToMapRegistration.cpp:58-59) fused into the search. */
 int o3ds_icp_point_to_plane_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3ds_crop* target_crop,
                                 const double init[16], const o3ds_icp_params* params, o3ds_icp_result* out);
+
+/* Same loop with params->method selecting the estimator (point-to-plane or generalized). */
+int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3ds_crop* target_crop, const double init[16],
+                          const o3ds_icp_params* params, o3ds_icp_result* out);
+/* RegistrationIcpGeneralized::registerClouds (CloudRegistration.cpp:16-21) = [O3D] RegistrationGeneralizedICP with a
+ * default TransformationEstimationForGeneralizedICP (epsilon 1e-3): per-point covariances C = Rx diag(eps,1,1) Rx^T built from
+ * the clouds' (unit) normals, residual (Ct + R Cs R^T)^-1/2 (p - q), same loop / solve / convergence test as point-to-plane.
+ * BOTH clouds must carry normals -- open3d_slam always calls estimateNormalsOrCovariancesIfNeeded first
+ * (CloudRegistration.cpp:22-30; Open3D itself would estimate them with KNN(20) when absent, which this backend does not). */
+int o3ds_icp_generalized(o3ds_handle h, const double* src_xyz, const double* src_normals, size_t n_src, const double* tgt_xyz,
+                         const double* tgt_normals, size_t n_tgt, const double init[16], const o3ds_icp_params* params, o3ds_icp_result* out);
+int o3ds_icp_generalized_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3ds_crop* target_crop, const double init[16],
+                             const o3ds_icp_params* params, o3ds_icp_result* out);
+/* epsilon of the plane-to-plane covariance model (default 1e-3, Open3D's default) */
+int o3ds_set_gicp_epsilon(o3ds_handle h, double epsilon);
 
 /* Step-wise form of the same loop, for sharded (multi-GPU) registration: the caller all-reduces the 32-double
  * normal-equation record between accumulate and update.  Record layout (doubles):

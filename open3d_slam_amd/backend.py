@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libo3ds_backend.so")
 OK = 0
 ERR_INVALID_ARG, ERR_NO_NORMALS, ERR_OOM, ERR_HIP, ERR_BAD_HANDLE, ERR_EMPTY, ERR_CAPACITY = -1, -2, -3, -4, -5, -6, -7
 PRECISION_F32, PRECISION_F64 = 0, 1
+ICP_POINT_TO_PLANE, ICP_GENERALIZED = 0, 1
 CROP_NONE, CROP_MAX_RADIUS, CROP_MIN_RADIUS, CROP_MIN_MAX_RADIUS, CROP_CYLINDER = range(5)
 
 
@@ -31,7 +32,7 @@ class IcpResult(C.Structure):
 
 
 class IcpParams(C.Structure):
-    _fields_ = [("max_correspondence_distance", C.c_double), ("max_iteration", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("max_correspondence_distance", C.c_double), ("max_iteration", C.c_int32), ("method", C.c_int32),
                 ("relative_fitness", C.c_double), ("relative_rmse", C.c_double)]
 
 
@@ -59,6 +60,10 @@ SIGNATURES = {
     "o3ds_icp_point_to_plane": (C.c_int, [_H, _dp, C.c_size_t, _dp, _dp, C.c_size_t, _dp, C.POINTER(IcpParams),
                                           C.POINTER(IcpResult)]),
     "o3ds_icp_point_to_plane_dev": (C.c_int, [_H, _CL, _CL, C.POINTER(Crop), _dp, C.POINTER(IcpParams), C.POINTER(IcpResult)]),
+    "o3ds_icp_register_dev": (C.c_int, [_H, _CL, _CL, C.POINTER(Crop), _dp, C.POINTER(IcpParams), C.POINTER(IcpResult)]),
+    "o3ds_icp_generalized": (C.c_int, [_H, _dp, _dp, C.c_size_t, _dp, _dp, C.c_size_t, _dp, C.POINTER(IcpParams), C.POINTER(IcpResult)]),
+    "o3ds_icp_generalized_dev": (C.c_int, [_H, _CL, _CL, C.POINTER(Crop), _dp, C.POINTER(IcpParams), C.POINTER(IcpResult)]),
+    "o3ds_set_gicp_epsilon": (C.c_int, [_H, C.c_double]),
     "o3ds_icp_begin": (C.c_int, [_H, _CL, _CL, C.POINTER(Crop), _dp, C.POINTER(IcpParams)]),
     "o3ds_icp_accumulate": (C.c_int, [_H, C.c_size_t, C.c_size_t, C.c_void_p]),
     "o3ds_icp_update": (C.c_int, [_H, C.c_void_p, C.c_uint64]),
@@ -185,8 +190,9 @@ class Backend:
 
     # -- ICP
     @staticmethod
-    def _params(max_corr, max_iter, rel_fitness, rel_rmse) -> IcpParams:
+    def _params(max_corr, max_iter, rel_fitness, rel_rmse, method=ICP_POINT_TO_PLANE) -> IcpParams:
         p = IcpParams()
+        p.method = int(method)
         p.max_correspondence_distance = float(max_corr)
         p.max_iteration = int(max_iter)
         p.relative_fitness = float(rel_fitness)
@@ -217,10 +223,33 @@ class Backend:
                                                       C.byref(p), C.byref(out)))
         return self._result(out)
 
-    def icp_begin(self, source: int, target: int, max_corr, init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6,
-                  target_crop: Crop | None = None):
+    def icp_generalized(self, src, src_normals, tgt, tgt_normals, max_corr, init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6):
+        src, sp = _d(np.asarray(src).reshape(-1, 3))
+        sn, snp = _d(None if src_normals is None else np.asarray(src_normals).reshape(-1, 3))
+        tgt, tp = _d(np.asarray(tgt).reshape(-1, 3))
+        tn, tnp = _d(None if tgt_normals is None else np.asarray(tgt_normals).reshape(-1, 3))
         T0, ip = _d(colmajor(np.eye(4) if init is None else init))
-        p = self._params(max_corr, max_iter, rel_fitness, rel_rmse)
+        p = self._params(max_corr, max_iter, rel_fitness, rel_rmse, ICP_GENERALIZED)
+        out = IcpResult()
+        self._ck(self.lib.o3ds_icp_generalized(self.h, sp, snp, len(src), tp, tnp, len(tgt), ip, C.byref(p), C.byref(out)))
+        return self._result(out)
+
+    def icp_generalized_dev(self, source: int, target: int, max_corr, init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6,
+                            target_crop: Crop | None = None):
+        T0, ip = _d(colmajor(np.eye(4) if init is None else init))
+        p = self._params(max_corr, max_iter, rel_fitness, rel_rmse, ICP_GENERALIZED)
+        out = IcpResult()
+        self._ck(self.lib.o3ds_icp_generalized_dev(self.h, source, target, C.byref(target_crop) if target_crop else None, ip,
+                                                   C.byref(p), C.byref(out)))
+        return self._result(out)
+
+    def set_gicp_epsilon(self, eps: float):
+        self._ck(self.lib.o3ds_set_gicp_epsilon(self.h, float(eps)))
+
+    def icp_begin(self, source: int, target: int, max_corr, init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6,
+                  target_crop: Crop | None = None, method=ICP_POINT_TO_PLANE):
+        T0, ip = _d(colmajor(np.eye(4) if init is None else init))
+        p = self._params(max_corr, max_iter, rel_fitness, rel_rmse, method)
         self._ck(self.lib.o3ds_icp_begin(self.h, source, target, C.byref(target_crop) if target_crop else None, ip, C.byref(p)))
 
     def icp_accumulate(self, first: int, count: int, d_record_ptr: int):

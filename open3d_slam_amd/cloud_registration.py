@@ -68,6 +68,41 @@ class RegistrationIcpPointToPlane(CloudRegistration):  # CloudRegistration.hpp:2
         cloud.be.estimate_normals(cloud.id, self.maxRadiusNormalEstimation_, self.knnNormalEstimation_)
 
 
+class RegistrationIcpGeneralized(CloudRegistration):  # CloudRegistration.hpp:56-69
+    def __init__(self):
+        self.maxCorrespondenceDistance_ = 1.0
+        self.knnNormalEstimation_ = 10
+        self.maxRadiusNormalEstimation_ = 2.0
+        self.icpConvergenceCriteria_ = ICPConvergenceCriteria()
+
+    def registerClouds(self, source: PointCloud, target: PointCloud, init, target_crop=None) -> RegistrationResult:
+        """CloudRegistration.cpp:16-21 -> [O3D] RegistrationGeneralizedICP(source, target, maxCorrespondenceDistance_, init,
+        TransformationEstimationForGeneralizedICP(), icpConvergenceCriteria_); covariances are built from the clouds' normals."""
+        c = self.icpConvergenceCriteria_
+        try:
+            r = source.be.icp_generalized_dev(source.id, target.id, self.maxCorrespondenceDistance_, init=init, max_iter=c.max_iteration_,
+                                              rel_fitness=c.relative_fitness_, rel_rmse=c.relative_rmse_, target_crop=target_crop)
+        except _b.BackendError as e:
+            raise RuntimeError(str(e)) from e
+        return RegistrationResult(r["transformation"], r["fitness"], r["inlier_rmse"], r["iterations"], r["converged"])
+
+    def estimateNormalsOrCovariancesIfNeeded(self, cloud: PointCloud) -> None:  # CloudRegistration.cpp:22-30
+        if not self.maxRadiusNormalEstimation_ > 0.0:
+            raise RuntimeError("maxRadiusNormalEstimation_")
+        if not self.knnNormalEstimation_ > 0:
+            raise RuntimeError("knnNormalEstimation_")
+        cloud.be.estimate_normals(cloud.id, self.maxRadiusNormalEstimation_, self.knnNormalEstimation_)
+
+
+def createGeneralizedIcp(p: CloudRegistrationParameters) -> RegistrationIcpGeneralized:  # CloudRegistration.cpp:32-39
+    ret = RegistrationIcpGeneralized()
+    ret.maxCorrespondenceDistance_ = p.icp_.maxCorrespondenceDistance_
+    ret.knnNormalEstimation_ = p.icp_.knn_
+    ret.maxRadiusNormalEstimation_ = p.icp_.maxDistanceKnn_
+    ret.icpConvergenceCriteria_.max_iteration_ = p.icp_.maxNumIter_
+    return ret
+
+
 def createPointToPlaneIcp(p: CloudRegistrationParameters) -> RegistrationIcpPointToPlane:  # CloudRegistration.cpp:58-65
     ret = RegistrationIcpPointToPlane()
     ret.maxCorrespondenceDistance_ = p.icp_.maxCorrespondenceDistance_
@@ -80,7 +115,9 @@ def createPointToPlaneIcp(p: CloudRegistrationParameters) -> RegistrationIcpPoin
 def cloudRegistrationFactory(p: CloudRegistrationParameters) -> CloudRegistration:  # CloudRegistration.cpp:85-100
     if p.regType_ == CloudRegistrationType.PointToPlaneIcp:
         return createPointToPlaneIcp(p)
-    if p.regType_ in (CloudRegistrationType.PointToPointIcp, CloudRegistrationType.GeneralizedIcp):
-        # next rows; not on the north-star path.  Fail loudly, never fall back.
-        raise NotImplementedError(f"{CloudRegistrationType(p.regType_).name}: not built yet on the HIP backend (SURVEY.md 8f)")
+    if p.regType_ == CloudRegistrationType.GeneralizedIcp:
+        return createGeneralizedIcp(p)
+    if p.regType_ == CloudRegistrationType.PointToPointIcp:
+        # SURVEY.md 8f rank 1 (closed-form Umeyama step): not built yet.  Fail loudly, never fall back.
+        raise NotImplementedError("PointToPointIcp: not built yet on the HIP backend (SURVEY.md 8f)")
     raise RuntimeError("cloud: unknown type of cloud registration")

@@ -66,6 +66,8 @@ struct o3ds_context {
   size_t session_n_src = 0;
   int session_precision = 0;
   bool session_crop = false;
+  int session_method = O3DS_ICP_POINT_TO_PLANE;
+  double gicp_epsilon = 1e-3;  // [O3D] TransformationEstimationForGeneralizedICP default
   hipStream_t own_stream = nullptr;
   // launch geometry of the ICP pass kernel (tunable through O3DS_PASS_BLOCK / O3DS_PASS_ROWS for experiments)
   // two launches per pass (default) vs ONE persistent loop kernel per registration (O3DS_ICP_MODE=persistent);
@@ -330,21 +332,23 @@ void launch_accumulate(o3ds_handle h, const IcpPassArgs& a, bool crop, int nbloc
       (void)hipEventRecord(e0, h->stream);
     }
   }
-#define O3DS_LAUNCH_PASS(BLK, GRP)                                                              \
-  do {                                                                                          \
-    if (crop)                                                                                   \
-      icp_accumulate_kernel<P4, true, BLK, GRP><<<nblocks, BLK, 0, h->stream>>>(a);            \
-    else                                                                                        \
-      icp_accumulate_kernel<P4, false, BLK, GRP><<<nblocks, BLK, 0, h->stream>>>(a);           \
+#define O3DS_LAUNCH_PASS(BLK, GRP, GICP)                                                              \
+  do {                                                                                                \
+    if (crop)                                                                                         \
+      icp_accumulate_kernel<P4, true, BLK, GRP, GICP><<<nblocks, BLK, 0, h->stream>>>(a);            \
+    else                                                                                              \
+      icp_accumulate_kernel<P4, false, BLK, GRP, GICP><<<nblocks, BLK, 0, h->stream>>>(a);           \
   } while (0)
-  const int key = h->pass_block * 100 + h->pass_group;
-  switch (key) {
-    case 25602: O3DS_LAUNCH_PASS(256, 2); break;
-    case 25604: O3DS_LAUNCH_PASS(256, 4); break;
-    case 25608: O3DS_LAUNCH_PASS(256, 8); break;
-    case 51202: O3DS_LAUNCH_PASS(512, 2); break;
-    case 51204: O3DS_LAUNCH_PASS(512, 4); break;
-    default: O3DS_LAUNCH_PASS(512, 8); break;
+  if (h->session_method == O3DS_ICP_GENERALIZED) {
+    O3DS_LAUNCH_PASS(256, 4, true);
+  } else {
+    const int key = h->pass_block * 100 + h->pass_group;
+    switch (key) {
+      case 25602: O3DS_LAUNCH_PASS(256, 2, false); break;
+      case 25608: O3DS_LAUNCH_PASS(256, 8, false); break;
+      case 51204: O3DS_LAUNCH_PASS(512, 4, false); break;
+      default: O3DS_LAUNCH_PASS(256, 4, false); break;
+    }
   }
 #undef O3DS_LAUNCH_PASS
   if (e1) (void)hipEventRecord(e1, h->stream);
@@ -377,15 +381,25 @@ void launch_loop(o3ds_handle h, const IcpLoopArgs& la, bool crop, int nwg) {
       (void)hipEventRecord(e0, h->stream);
     }
   }
-  if (crop)
-    icp_loop_kernel<P4, true, 4><<<nwg, kLoopBlock, 0, h->stream>>>(la);
-  else
-    icp_loop_kernel<P4, false, 4><<<nwg, kLoopBlock, 0, h->stream>>>(la);
+  if (h->session_method == O3DS_ICP_GENERALIZED) {
+    if (crop)
+      icp_loop_kernel<P4, true, 4, true><<<nwg, kLoopBlock, 0, h->stream>>>(la);
+    else
+      icp_loop_kernel<P4, false, 4, true><<<nwg, kLoopBlock, 0, h->stream>>>(la);
+  } else {
+    if (crop)
+      icp_loop_kernel<P4, true, 4, false><<<nwg, kLoopBlock, 0, h->stream>>>(la);
+    else
+      icp_loop_kernel<P4, false, 4, false><<<nwg, kLoopBlock, 0, h->stream>>>(la);
+  }
   if (e1) (void)hipEventRecord(e1, h->stream);
 }
 
 int pass_blocks(o3ds_handle h, size_t count) {
-  const size_t qpb = (size_t)h->pass_block / h->pass_group;  // one batch of BLOCK/G queries per workgroup iteration
+  const bool gicp = h->session_method == O3DS_ICP_GENERALIZED;
+  const int blk = gicp ? 256 : (h->pass_block == 512 && h->pass_group == 4 ? 512 : 256);
+  const int grp = gicp ? 4 : ((h->pass_block == 256 && (h->pass_group == 2 || h->pass_group == 8)) ? h->pass_group : 4);
+  const size_t qpb = (size_t)blk / grp;  // one batch of BLOCK/G queries per workgroup iteration
   size_t g = (count + qpb - 1) / qpb;
   if (g < 1) g = 1;
   if (g > (size_t)h->pass_rows) g = h->pass_rows;
@@ -398,7 +412,12 @@ int validate_icp(o3ds_handle h, const CloudRec* src, const CloudRec* tgt, const 
   if (tgt->n == 0) return fail(h, O3DS_ERR_EMPTY, "icp: empty target (map patch size is zero)");  // ScanToMapRegistration.cpp:60
   if (!(p->max_correspondence_distance > 0.0))
     return fail(h, O3DS_ERR_INVALID_ARG, "Invalid max_correspondence_distance.");  // [O3D] RegistrationICP
-  if (!tgt->nrm) return fail(h, O3DS_ERR_NO_NORMALS, "TransformationEstimationPointToPlane requires target normals");
+  if (p->method != O3DS_ICP_POINT_TO_PLANE && p->method != O3DS_ICP_GENERALIZED) return fail(h, O3DS_ERR_INVALID_ARG, "icp: unknown method");
+  if (!tgt->nrm)
+    return fail(h, O3DS_ERR_NO_NORMALS, p->method == O3DS_ICP_GENERALIZED ? "generalized ICP: target has no normals (covariances are built from normals)"
+                                                                           : "TransformationEstimationPointToPlane requires target normals");
+  if (p->method == O3DS_ICP_GENERALIZED && src->n > 0 && !src->nrm)
+    return fail(h, O3DS_ERR_NO_NORMALS, "generalized ICP: source has no normals (covariances are built from normals)");
   if (src->precision != tgt->precision) return fail(h, O3DS_ERR_INVALID_ARG, "icp: source/target precision mismatch");
   if (p->max_iteration < 0) return fail(h, O3DS_ERR_INVALID_ARG, "icp: negative max_iteration");
   return O3DS_OK;
@@ -442,6 +461,8 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
   const double r = params->max_correspondence_distance;
   a.r2max = r * r;
   a.rmax_cells = tgt->grid.cell >= r ? 1 : 2;  // 1: the fine 3x3x3 block already covers the ball of radius r
+  a.snrm = src->nrm;
+  a.gicp_k = 1.0 - h->gicp_epsilon;
   a.state = h->d_state;
   a.partials = h->d_partials;
   a.debug = getenv("O3DS_DEBUG_ACC") ? atoi(getenv("O3DS_DEBUG_ACC")) : 0;
@@ -451,6 +472,7 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
   h->session_n_src = src->n;
   h->session_precision = src->precision;
   h->session_crop = crop && crop->kind != O3DS_CROP_NONE;
+  h->session_method = params->method;
   return O3DS_OK;
 }
 
@@ -706,8 +728,52 @@ int o3ds_icp_finish(o3ds_handle h, o3ds_icp_result* out) {
   return read_state(h, out);
 }
 
+int o3ds_set_gicp_epsilon(o3ds_handle h, double epsilon) {
+  CHECK_HANDLE(h);
+  if (!(epsilon > 0.0 && epsilon <= 1.0)) return fail(h, O3DS_ERR_INVALID_ARG, "gicp epsilon must be in (0, 1]");
+  h->gicp_epsilon = epsilon;
+  return O3DS_OK;
+}
+
 int o3ds_icp_point_to_plane_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3ds_crop* target_crop,
                                 const double init[16], const o3ds_icp_params* params, o3ds_icp_result* out) {
+  CHECK_HANDLE(h);
+  if (!params) return fail(h, O3DS_ERR_INVALID_ARG, "icp: null params");
+  o3ds_icp_params p = *params;
+  p.method = O3DS_ICP_POINT_TO_PLANE;
+  return o3ds_icp_register_dev(h, source, target, target_crop, init, &p, out);
+}
+
+int o3ds_icp_generalized_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3ds_crop* target_crop, const double init[16],
+                             const o3ds_icp_params* params, o3ds_icp_result* out) {
+  CHECK_HANDLE(h);
+  if (!params) return fail(h, O3DS_ERR_INVALID_ARG, "icp: null params");
+  o3ds_icp_params p = *params;
+  p.method = O3DS_ICP_GENERALIZED;
+  return o3ds_icp_register_dev(h, source, target, target_crop, init, &p, out);
+}
+
+int o3ds_icp_generalized(o3ds_handle h, const double* src_xyz, const double* src_normals, size_t n_src, const double* tgt_xyz,
+                         const double* tgt_normals, size_t n_tgt, const double init[16], const o3ds_icp_params* params, o3ds_icp_result* out) {
+  CHECK_HANDLE(h);
+  if (!params || !out || !init) return fail(h, O3DS_ERR_INVALID_ARG, "icp: null argument");
+  if (!(params->max_correspondence_distance > 0.0)) return fail(h, O3DS_ERR_INVALID_ARG, "Invalid max_correspondence_distance.");
+  if (n_tgt == 0) return fail(h, O3DS_ERR_EMPTY, "icp: empty target (map patch size is zero)");
+  if (!tgt_normals || (n_src > 0 && !src_normals)) return fail(h, O3DS_ERR_NO_NORMALS, "generalized ICP: both clouds need normals");
+  o3ds_cloud s = 0, t = 0;
+  int rc = o3ds_cloud_upload(h, src_xyz, src_normals, n_src, &s);
+  if (rc) return rc;
+  rc = o3ds_cloud_upload(h, tgt_xyz, tgt_normals, n_tgt, &t);
+  if (!rc) rc = o3ds_icp_generalized_dev(h, s, t, nullptr, init, params, out);
+  const std::string keep = h->err;
+  (void)o3ds_cloud_free(h, s);
+  if (t) (void)o3ds_cloud_free(h, t);
+  if (rc) h->err = keep;
+  return rc;
+}
+
+int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3ds_crop* target_crop, const double init[16],
+                          const o3ds_icp_params* params, o3ds_icp_result* out) {
   CHECK_HANDLE(h);
   if (!init || !out) return fail(h, O3DS_ERR_INVALID_ARG, "icp: null init/out");
   int rc = begin_session(h, source, target, target_crop, init, params);

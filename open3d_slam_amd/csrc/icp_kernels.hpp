@@ -361,6 +361,8 @@ struct IcpPassArgs {
   CropDev crop;
   double r2max;
   int rmax_cells;
+  const void* snrm;  // source normals (generalized ICP only), same order as src
+  double gicp_k;     // 1 - epsilon of [O3D] TransformationEstimationForGeneralizedICP (covariance = I - k n n^T)
   const IcpStateDev* state;
   double* partials;  // [gridDim.x][kRec]
   int debug;         // timing experiments only (O3DS_DEBUG_ACC): 1 = exit after prologue, 2 = no search, 3 = no winner gather
@@ -383,10 +385,55 @@ __device__ __forceinline__ double to_sgpr(double v) {
 // One correspondence + reduction pass of the workgroup's share of the source (batches wg, wg+nwg, ..) under the
 // transformation Tm (column-major, 16 doubles, any address space).  Leaves the workgroup's 32-double partial record
 // in s_red[0][0..31]... more precisely returns it in `row_val` of threads 0..31.
-template <typename P4, bool kCrop, int kPassBlock, int kGroup>
-__device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const double* Tm, int wg, int nwg, double (*s_rec)[kRecSlots],
+// [O3D] GeneralizedICP (reference call site CloudRegistration.cpp:16-21), closed form for covariances built
+// from unit normals: C = Rx diag(eps,1,1) Rx^T = I - k n n^T (k = 1 - eps; n := e1 when n.x < -0.99, GetRotationFromE1ToX's
+// special case), so M = Ct + R Cs R^T = 2I - k (a a^T + b b^T).  With A = [-[p]x | I] and W = M^-1/2 the three residual rows
+// W d and Jacobian rows W A contribute  J^T J = A^T M^-1 A  and  J^T r = A^T M^-1 d : only M^-1 is needed (3x3 cofactors).
+// Writes the 21 + 6 + 3 record values of ONE correspondence.
+__device__ __forceinline__ void gicp_record(double px, double py, double pz, double dx, double dy, double dz, const double a[3],
+                                            const double b[3], double k, double* rec) {
+  const double m00 = 2.0 - k * (a[0] * a[0] + b[0] * b[0]), m01 = -k * (a[0] * a[1] + b[0] * b[1]), m02 = -k * (a[0] * a[2] + b[0] * b[2]);
+  const double m11 = 2.0 - k * (a[1] * a[1] + b[1] * b[1]), m12 = -k * (a[1] * a[2] + b[1] * b[2]), m22 = 2.0 - k * (a[2] * a[2] + b[2] * b[2]);
+  const double c00 = m11 * m22 - m12 * m12, c01 = m02 * m12 - m01 * m22, c02 = m01 * m12 - m02 * m11;
+  const double c11 = m00 * m22 - m02 * m02, c12 = m01 * m02 - m00 * m12, c22 = m00 * m11 - m01 * m01;
+  const double idet = 1.0 / (m00 * c00 + m01 * c01 + m02 * c02);
+  const double B[3][3] = {{c00 * idet, c01 * idet, c02 * idet}, {c01 * idet, c11 * idet, c12 * idet}, {c02 * idet, c12 * idet, c22 * idet}};
+  const double S[3][3] = {{0.0, -pz, py}, {pz, 0.0, -px}, {-py, px, 0.0}};  // S[c] = column c of -[p]x
+  double BS[3][3];  // BS[c] = B * S[c]
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) BS[c][r] = B[r][0] * S[c][0] + B[r][1] * S[c][1] + B[r][2] * S[c][2];
+  const double Bd[3] = {B[0][0] * dx + B[0][1] * dy + B[0][2] * dz, B[1][0] * dx + B[1][1] * dy + B[1][2] * dz,
+                        B[2][0] * dx + B[2][1] * dy + B[2][2] * dz};
+  int t = 0;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int c = r; c < 3; ++c) rec[t++] = S[r][0] * BS[c][0] + S[r][1] * BS[c][1] + S[r][2] * BS[c][2];  // S^T B S
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rec[t++] = BS[r][c];  // S^T B  (row r, col 3+c) = (B S[r])[c]
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = r; c < 3; ++c) rec[t++] = B[r][c];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) rec[21 + r] = S[r][0] * Bd[0] + S[r][1] * Bd[1] + S[r][2] * Bd[2];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) rec[24 + r] = Bd[r];
+  rec[kRecR2] = dx * Bd[0] + dy * Bd[1] + dz * Bd[2];
+  rec[kRecCount] = 1.0;
+  rec[kRecD2] = dx * dx + dy * dy + dz * dz;
+  rec[30] = 0.0;
+  rec[31] = 0.0;
+}
+
+template <typename P4, bool kCrop, int kPassBlock, int kGroup, bool kGicp>
+__device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const double* Tm, int wg, int nwg, double* s_rec_flat,
                                                 double (*s_red)[kRec]) {
   constexpr int kQPB = kPassBlock / kGroup;
+  constexpr int kStride = kGicp ? kRec : kRecSlots;  // doubles per query record
   using R = typename Scalar<P4>::type;
   const P4* __restrict__ src = (const P4*)a.src;
   const P4* __restrict__ tp = (const P4*)a.tpts;
@@ -439,13 +486,23 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
       }
     }
     if (gl == 0) {
-      double* rec = s_rec[ql];
+      double* rec = s_rec_flat + ql * kStride;
       if (nn.pos != -1) {
         if (a.debug == 3) nn.pos = (int)(i % 1000);
         const P4 q = nn.pos >= 0 ? tp[nn.pos] : ((const P4*)a.opts)[nn.idx];
         const P4 nq = nn.pos >= 0 ? tn[nn.pos] : ((const P4*)a.onrm)[nn.idx];
         const double dx = px - (double)q.x, dy = py - (double)q.y, dz = pz - (double)q.z;
         const double nx = (double)nq.x, ny = (double)nq.y, nz = (double)nq.z;
+        if (kGicp) {
+          const P4 ns = ((const P4*)a.snrm)[a.first + i];
+          double sa[3] = {(double)ns.x, (double)ns.y, (double)ns.z};
+          if (sa[0] < -0.99) sa[0] = 1.0, sa[1] = 0.0, sa[2] = 0.0;  // GetRotationFromE1ToX special case (decided on the stored normal)
+          const double av[3] = {t00 * sa[0] + t01 * sa[1] + t02 * sa[2], t10 * sa[0] + t11 * sa[1] + t12 * sa[2],
+                                t20 * sa[0] + t21 * sa[1] + t22 * sa[2]};  // covariance rotates with the cloud
+          double bv[3] = {nx, ny, nz};
+          if (bv[0] < -0.99) bv[0] = 1.0, bv[1] = 0.0, bv[2] = 0.0;
+          gicp_record(px, py, pz, dx, dy, dz, av, bv, a.gicp_k, rec);
+        } else {
         rec[0] = py * nz - pz * ny;  // J = [p x n ; n]
         rec[1] = pz * nx - px * nz;
         rec[2] = px * ny - py * nx;
@@ -456,16 +513,20 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
         rec[7] = 1.0;
         rec[8] = dx * dx + dy * dy + dz * dz;
         rec[9] = 0.0;
+        }
       } else {
 #pragma unroll
-        for (int k = 0; k < kRecSlots; ++k) rec[k] = 0.0;
+        for (int k = 0; k < kStride; ++k) rec[k] = 0.0;
       }
     }
     __syncthreads();
 #pragma unroll
     for (int qq = 0; qq < kQPB / (kPassBlock / 32); ++qq) {
-      const double* rec = s_rec[qs * (kQPB / (kPassBlock / 32)) + qq];
-      acc += rec[ta] * rec[tb];
+      const double* rec = s_rec_flat + (qs * (kQPB / (kPassBlock / 32)) + qq) * kStride;
+      if (kGicp)
+        acc += rec[term];  // the record already holds the 32 terms of this correspondence
+      else
+        acc += rec[ta] * rec[tb];
     }
     __syncthreads();  // s_rec is rewritten by the next batch
   }
@@ -485,17 +546,17 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
 // Workgroup = BLOCK threads = BLOCK/G queries x G lanes for the search, then (32 record terms) x (BLOCK/32 query slices) for the
 // accumulation: one f64 accumulator per thread instead of 30, so the kernel stays small in registers and the chip can
 // keep enough wavefronts in flight to hide the dependent-load latency of the search.
-template <typename P4, bool kCrop, int kPassBlock, int kGroup>
+template <typename P4, bool kCrop, int kPassBlock, int kGroup, bool kGicp>
 __global__ __launch_bounds__(kPassBlock) void icp_accumulate_kernel(IcpPassArgs a) {
   constexpr int kQPB = kPassBlock / kGroup;
   if (a.state->done) return;  // device-side loop already terminated: keep the previous partials
-  __shared__ double s_rec[kQPB][kRecSlots];
+  __shared__ double s_rec[kQPB * (kGicp ? kRec : kRecSlots)];
   __shared__ double s_red[kPassBlock / 32][kRec];
   if (a.debug == 1) {
     if (threadIdx.x < kRec) a.partials[(size_t)blockIdx.x * kRec + threadIdx.x] = a.state->T[0] * 1e-300;
     return;
   }
-  const double v = icp_pass_body<P4, kCrop, kPassBlock, kGroup>(a, a.state->T, blockIdx.x, gridDim.x, s_rec, s_red);
+  const double v = icp_pass_body<P4, kCrop, kPassBlock, kGroup, kGicp>(a, a.state->T, blockIdx.x, gridDim.x, s_rec, s_red);
   if (threadIdx.x < kRec) a.partials[(size_t)blockIdx.x * kRec + threadIdx.x] = v;
 }
 
@@ -857,10 +918,10 @@ struct IcpLoopArgs {
 
 constexpr int kLoopBlock = 1024;
 
-template <typename P4, bool kCrop, int kGroup>
+template <typename P4, bool kCrop, int kGroup, bool kGicp>
 __global__ __launch_bounds__(kLoopBlock) void icp_loop_kernel(IcpLoopArgs la) {
   constexpr int kQPB = kLoopBlock / kGroup;
-  __shared__ double s_rec[kQPB][kRecSlots];
+  __shared__ double s_rec[kQPB * (kGicp ? kRec : kRecSlots)];
   __shared__ double s_red[kLoopBlock / 32][kRec];
   __shared__ double s_out[kRec];
   __shared__ double s_x[8], s_sc[8], s_U[16], s_T[16];
@@ -874,7 +935,7 @@ __global__ __launch_bounds__(kLoopBlock) void icp_loop_kernel(IcpLoopArgs la) {
   __syncthreads();
   if (s_st.done) return;
   for (int pass = 0;; ++pass) {
-    const double v = icp_pass_body<P4, kCrop, kLoopBlock, kGroup>(la.pass, s_st.T, wg, nwg, s_rec, s_red);
+    const double v = icp_pass_body<P4, kCrop, kLoopBlock, kGroup, kGicp>(la.pass, s_st.T, wg, nwg, s_rec, s_red);
     double* rows = la.rows + (size_t)(la.single_pass ? 0 : (pass & 1)) * nwg * kRec;
     if (threadIdx.x < kRec) {
       __hip_atomic_store(rows + (size_t)wg * kRec + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -116,3 +116,67 @@ def voxelize_world(pts, nrm, voxel):
     nn = np.linalg.norm(on, axis=1, keepdims=True)
     on = np.where(nn > 0, on / np.where(nn > 0, nn, 1), on)
     return out / cnt[:, None], on, uk
+
+
+# ---- A.8 generalized ICP (independent restatement: numpy eigh for M^-1/2, explicit 3-row Jacobians) --------------------
+def rotation_e1_to_x(x):
+    e1 = np.array([1.0, 0.0, 0.0])
+    v = np.cross(e1, x)
+    c = float(e1 @ x)
+    if c < -0.99:
+        return np.eye(3)
+    sv = np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+    return np.eye(3) + sv + (sv @ sv) / (1.0 + c)
+
+
+def covariances_from_normals(nrm, eps=1e-3):
+    C = np.diag([eps, 1.0, 1.0])
+    out = np.empty((len(nrm), 3, 3))
+    for i, n in enumerate(nrm):
+        R = rotation_e1_to_x(n)
+        out[i] = R @ C @ R.T
+    return out
+
+
+def gicp_jtj_jtr(P, Cs, Q, Ct, corr):
+    A = np.zeros((6, 6))
+    b = np.zeros(6)
+    for i in np.nonzero(corr >= 0)[0]:
+        j = corr[i]
+        d = P[i] - Q[j]
+        w, V = np.linalg.eigh(Ct[j] + Cs[i])
+        W = (V / np.sqrt(w)) @ V.T
+        p = P[i]
+        S = -np.array([[0, -p[2], p[1]], [p[2], 0, -p[0]], [-p[1], p[0], 0]])
+        J = W @ np.hstack([S, np.eye(3)])
+        r = W @ d
+        A += J.T @ J
+        b += J.T @ r
+    return A, b
+
+
+def icp_generalized(src, src_nrm, tgt, tgt_nrm, max_corr, init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6, eps=1e-3):
+    tree = cKDTree(tgt, leafsize=15)
+    T = np.eye(4) if init is None else np.array(init, dtype=np.float64)
+    Cs0 = covariances_from_normals(src_nrm, eps)
+    Ct = covariances_from_normals(tgt_nrm, eps)
+    R0 = T[:3, :3]
+    P = src @ R0.T + T[:3, 3]
+    Cs = np.einsum("ab,nbc,dc->nad", R0, Cs0, R0)
+    corr, fit, rmse, nc = evaluate(tree, P, max_corr)
+    it = 0
+    for _ in range(max_iter):
+        if nc == 0:
+            U = np.eye(4)
+        else:
+            A, b = gicp_jtj_jtr(P, Cs, tgt, Ct, corr)
+            U = vector6_to_matrix4(np.linalg.solve(A, -b))
+        T = U @ T
+        P = P @ U[:3, :3].T + U[:3, 3]
+        Cs = np.einsum("ab,nbc,dc->nad", U[:3, :3], Cs, U[:3, :3])
+        pf, pr = fit, rmse
+        corr, fit, rmse, nc = evaluate(tree, P, max_corr)
+        it += 1
+        if abs(pf - fit) < rel_fitness and abs(pr - rmse) < rel_rmse:
+            break
+    return dict(transformation=T, fitness=fit, inlier_rmse=rmse, iterations=it, n_corr=nc)

@@ -490,6 +490,211 @@ int orc_icp_point_to_plane(const double* src, size_t n, const double* tgt, const
   return 0;
 }
 
+/* ------------------------------------------------------------------ A.8 Generalized ICP
+ * [O3D] GeneralizedICP.cpp: GetRotationFromE1ToX, InitializePointCloudForGeneralizedICP,
+ * TransformationEstimationForGeneralizedICP::ComputeTransformation; reference call site src/CloudRegistration.cpp:16-21. */
+static void mat3_mul(const double A[9], const double B[9], double C[9]) { /* row-major */
+  double R[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) R[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+  memcpy(C, R, sizeof(R));
+}
+static void mat3_t(const double A[9], double T[9]) {
+  double R[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) R[i * 3 + j] = A[j * 3 + i];
+  memcpy(T, R, sizeof(R));
+}
+
+void orc_covariance_from_normal(const double x[3], double epsilon, double cov[9]) {
+  /* Rx = GetRotationFromE1ToX(x): v = e1 x x, c = e1 . x; c < -0.99 -> Identity; else I + [v]x + [v]x^2 / (1 + c) */
+  double Rx[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  const double c = x[0];
+  if (!(c < -0.99)) {
+    const double v[3] = {0.0, -x[2], x[1]}; /* e1 x x */
+    const double sv[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0};
+    double sv2[9];
+    mat3_mul(sv, sv, sv2);
+    const double f = 1.0 / (1.0 + c);
+    for (int i = 0; i < 9; ++i) Rx[i] += sv[i] + sv2[i] * f;
+  }
+  const double C[9] = {epsilon, 0, 0, 0, 1, 0, 0, 0, 1};
+  double RxT[9], t[9];
+  mat3_t(Rx, RxT);
+  mat3_mul(Rx, C, t);
+  mat3_mul(t, RxT, cov);
+}
+
+/* symmetric 3x3: W = M^-1/2 via Jacobi eigen-decomposition (Eigen: M.inverse().sqrt()) */
+static void sym3_eig(const double Min[9], double w[3], double V[9]) {
+  double A[9];
+  memcpy(A, Min, sizeof(A));
+  double Q[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+    if (off < 1e-300) break;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        double apq = A[p * 3 + q];
+        if (fabs(apq) < 1e-300) continue;
+        double theta = (A[q * 3 + q] - A[p * 3 + p]) / (2.0 * apq);
+        double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 3; ++k) { /* A <- A * G */
+          double akp = A[k * 3 + p], akq = A[k * 3 + q];
+          A[k * 3 + p] = c * akp - s * akq;
+          A[k * 3 + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < 3; ++k) { /* A <- G^T * A */
+          double apk = A[p * 3 + k], aqk = A[q * 3 + k];
+          A[p * 3 + k] = c * apk - s * aqk;
+          A[q * 3 + k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < 3; ++k) {
+          double qkp = Q[k * 3 + p], qkq = Q[k * 3 + q];
+          Q[k * 3 + p] = c * qkp - s * qkq;
+          Q[k * 3 + q] = s * qkp + c * qkq;
+        }
+      }
+  }
+  w[0] = A[0];
+  w[1] = A[4];
+  w[2] = A[8];
+  memcpy(V, Q, sizeof(Q));
+}
+static void sym3_inv_sqrt(const double M[9], double W[9]) {
+  double w[3], V[9];
+  sym3_eig(M, w, V);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double s = 0.0;
+      for (int k = 0; k < 3; ++k) s += V[i * 3 + k] * (1.0 / sqrt(w[k])) * V[j * 3 + k];
+      W[i * 3 + j] = s;
+    }
+}
+
+void orc_gicp_jtj_jtr(const double* src, const double* src_cov, size_t n, const double* tgt, const double* tgt_cov, const int32_t* corr,
+                      double JTJ[36], double JTr[6]) {
+  int nt = orc_num_threads();
+  double* part = (double*)calloc((size_t)nt * 44, sizeof(double));
+#pragma omp parallel
+  {
+#ifdef _OPENMP
+    int tid = omp_get_thread_num();
+#else
+    int tid = 0;
+#endif
+    double A[36] = {0}, b[6] = {0};
+#pragma omp for schedule(static)
+    for (long i = 0; i < (long)n; ++i) {
+      int32_t j = corr[i];
+      if (j < 0) continue;
+      const double* vs = src + 3 * (size_t)i;
+      const double* vt = tgt + 3 * (size_t)j;
+      const double d[3] = {vs[0] - vt[0], vs[1] - vt[1], vs[2] - vt[2]};
+      double M[9], W[9];
+      for (int k = 0; k < 9; ++k) M[k] = tgt_cov[9 * (size_t)j + k] + src_cov[9 * (size_t)i + k];
+      sym3_inv_sqrt(M, W);
+      /* J = W * [ -[vs]x | I ] (3x6) */
+      const double S[9] = {0, vs[2], -vs[1], -vs[2], 0, vs[0], vs[1], -vs[0], 0}; /* -SkewMatrix(vs) */
+      double J[3][6];
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+          J[r][c] = W[r * 3] * S[c] + W[r * 3 + 1] * S[3 + c] + W[r * 3 + 2] * S[6 + c];
+          J[r][3 + c] = W[r * 3 + c];
+        }
+      for (int r = 0; r < 3; ++r) {
+        const double res = W[r * 3] * d[0] + W[r * 3 + 1] * d[1] + W[r * 3 + 2] * d[2];
+        for (int a = 0; a < 6; ++a) {
+          for (int c = 0; c < 6; ++c) A[a * 6 + c] += J[r][a] * J[r][c];
+          b[a] += J[r][a] * res;
+        }
+      }
+    }
+    memcpy(part + (size_t)tid * 44, A, sizeof(A));
+    memcpy(part + (size_t)tid * 44 + 36, b, sizeof(b));
+  }
+  memset(JTJ, 0, 36 * sizeof(double));
+  memset(JTr, 0, 6 * sizeof(double));
+  for (int t = 0; t < nt; ++t) {
+    for (int a = 0; a < 36; ++a) JTJ[a] += part[(size_t)t * 44 + a];
+    for (int a = 0; a < 6; ++a) JTr[a] += part[(size_t)t * 44 + 36 + a];
+  }
+  free(part);
+}
+
+static void transform_covs(double* cov, size_t n, const double T[16]) { /* [O3D] PointCloud::Transform: R C R^T */
+  const double R[9] = {T[0], T[4], T[8], T[1], T[5], T[9], T[2], T[6], T[10]};
+  double RT[9];
+  mat3_t(R, RT);
+  for (size_t i = 0; i < n; ++i) {
+    double t[9];
+    mat3_mul(R, cov + 9 * i, t);
+    mat3_mul(t, RT, cov + 9 * i);
+  }
+}
+
+int orc_icp_generalized(const double* src, const double* src_nrm, size_t n, const double* tgt, const double* tgt_nrm, size_t N,
+                        const orc_kdtree* tree, double max_corr, const double init[16], int max_iter, double rel_fitness, double rel_rmse,
+                        double epsilon, orc_icp_result* out) {
+  if (max_corr <= 0.0) return -1;
+  if (!src_nrm || !tgt_nrm) return -2; /* the reference always reaches this call with normals on both clouds */
+  orc_kdtree* own = NULL;
+  if (!tree) {
+    own = orc_kdtree_build(tgt, N);
+    tree = own;
+  }
+  double* P = (double*)malloc(sizeof(double) * 3 * (n ? n : 1));
+  double* Cs = (double*)malloc(sizeof(double) * 9 * (n ? n : 1));
+  double* Ct = (double*)malloc(sizeof(double) * 9 * (N ? N : 1));
+  int32_t* corr = (int32_t*)malloc(sizeof(int32_t) * (n ? n : 1));
+  memcpy(P, src, sizeof(double) * 3 * n);
+  for (size_t i = 0; i < n; ++i) orc_covariance_from_normal(src_nrm + 3 * i, epsilon, Cs + 9 * i);
+  for (size_t i = 0; i < N; ++i) orc_covariance_from_normal(tgt_nrm + 3 * i, epsilon, Ct + 9 * i);
+  double T[16];
+  memcpy(T, init, sizeof(T));
+  if (!is_identity16(init)) {
+    orc_transform_points(P, n, init);
+    transform_covs(Cs, n, init);
+  }
+  double fit, rmse;
+  uint64_t nc;
+  orc_evaluate(tree, P, n, max_corr, corr, NULL, &fit, &rmse, &nc);
+  int it = 0, converged = 0;
+  for (int i = 0; i < max_iter; ++i) {
+    double U[16], JTJ[36], JTr[6];
+    if (nc == 0) {
+      double z[6] = {0, 0, 0, 0, 0, 0};
+      orc_vector6_to_matrix4(z, U);
+    } else {
+      orc_gicp_jtj_jtr(P, Cs, n, tgt, Ct, corr, JTJ, JTr);
+      orc_solve_update(JTJ, JTr, U, NULL);
+    }
+    mat4_mul(U, T, T);
+    orc_transform_points(P, n, U);
+    transform_covs(Cs, n, U);
+    double pf = fit, pr = rmse;
+    orc_evaluate(tree, P, n, max_corr, corr, NULL, &fit, &rmse, &nc);
+    ++it;
+    if (fabs(pf - fit) < rel_fitness && fabs(pr - rmse) < rel_rmse) {
+      converged = 1;
+      break;
+    }
+  }
+  memcpy(out->transformation, T, sizeof(T));
+  out->fitness = fit;
+  out->inlier_rmse = rmse;
+  out->iterations = it;
+  out->converged = converged;
+  out->n_corr = nc;
+  free(P);
+  free(Cs);
+  free(Ct);
+  free(corr);
+  if (own) orc_kdtree_free(own);
+  return 0;
+}
+
 /* ------------------------------------------------------------------ A.5
  * [O3D] FastEigen3x3 (Geometric Tools "robust eigensolver for 3x3 symmetric
  * matrices"): returns the eigenvector of the smallest eigenvalue. */

@@ -75,6 +75,18 @@ int orc_icp_point_to_plane(const double* src, size_t n, const double* tgt, const
                            double max_corr, const double init[16], int max_iter, double rel_fitness, double rel_rmse,
                            orc_icp_result* out);
 
+/* A.8 RegistrationGeneralizedICP (call site src/CloudRegistration.cpp:16-21): covariances from normals
+ * (C = Rx diag(eps,1,1) Rx^T, Rx = GetRotationFromE1ToX(normal)), per pair M = Ct + R Cs R^T, W = M^-1/2, residual W d (3 rows),
+ * Jacobian rows W [-[p]x | I]; same loop / solve / convergence as A.1.  Both clouds must carry normals (as they always do
+ * when open3d_slam reaches this call); epsilon: Open3D default 1e-3. */
+int orc_icp_generalized(const double* src, const double* src_nrm, size_t n, const double* tgt, const double* tgt_nrm, size_t N,
+                        const orc_kdtree* tree, double max_corr, const double init[16], int max_iter, double rel_fitness, double rel_rmse,
+                        double epsilon, orc_icp_result* out);
+/* one accumulation of the GICP normal equations for given correspondences (for step tests): JTJ row-major 6x6 */
+void orc_gicp_jtj_jtr(const double* src, const double* src_cov /* 9n */, size_t n, const double* tgt, const double* tgt_cov /* 9N */,
+                      const int32_t* corr, double JTJ[36], double JTr[6]);
+void orc_covariance_from_normal(const double nrm[3], double epsilon, double cov[9]);
+
 /* A.5 EstimateNormals(Hybrid(radius,max_nn), fast) + NormalizeNormals + OrientNormalsTowardsCameraLocation(0)
  * (call site open3d_slam/src/CloudRegistration.cpp:49-56).  normals out: 3n */
 void orc_estimate_normals(const double* pts, size_t n, double radius, int max_nn, double* normals);

@@ -62,6 +62,11 @@ def lib():
         L.orc_icp_point_to_plane.restype = C.c_int
         L.orc_icp_point_to_plane.argtypes = [_dp, C.c_size_t, _dp, _dp, C.c_size_t, C.c_void_p, C.c_double, _dp, C.c_int,
                                              C.c_double, C.c_double, C.POINTER(IcpResult)]
+        L.orc_icp_generalized.restype = C.c_int
+        L.orc_icp_generalized.argtypes = [_dp, _dp, C.c_size_t, _dp, _dp, C.c_size_t, C.c_void_p, C.c_double, _dp, C.c_int, C.c_double,
+                                          C.c_double, C.c_double, C.POINTER(IcpResult)]
+        L.orc_gicp_jtj_jtr.argtypes = [_dp, _dp, C.c_size_t, _dp, _dp, _ip, _dp, _dp]
+        L.orc_covariance_from_normal.argtypes = [_dp, C.c_double, _dp]
         L.orc_estimate_normals.argtypes = [_dp, C.c_size_t, C.c_double, C.c_int, _dp]
         L.orc_fast_eigen3x3_min_evec.argtypes = [_dp, _dp]
         L.orc_voxel_down_sample.restype = C.c_size_t
@@ -191,6 +196,42 @@ def icp_point_to_plane(src, tgt, nrm, max_corr, init=None, max_iter=30, rel_fitn
         raise RuntimeError(f"orc_icp_point_to_plane rc={rc}")
     return dict(transformation=from_colmajor(out.transformation), fitness=out.fitness, inlier_rmse=out.inlier_rmse,
                 iterations=out.iterations, converged=bool(out.converged), n_corr=int(out.n_corr))
+
+
+def icp_generalized(src, src_nrm, tgt, tgt_nrm, max_corr, init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6, epsilon=1e-3,
+                    tree: KDTree | None = None):
+    src, sp = _d(src)
+    sn, snp = (None, None) if src_nrm is None else _d(src_nrm)
+    tgt, tp = _d(tgt)
+    tn, tnp = (None, None) if tgt_nrm is None else _d(tgt_nrm)
+    init = np.eye(4) if init is None else init
+    Tc, ip = _d(colmajor(init))
+    out = IcpResult()
+    rc = lib().orc_icp_generalized(sp, snp, len(src), tp, tnp, len(tgt), tree.h if tree is not None else None, max_corr, ip, max_iter,
+                                   rel_fitness, rel_rmse, epsilon, C.byref(out))
+    if rc != 0:
+        raise RuntimeError(f"orc_icp_generalized rc={rc}")
+    return dict(transformation=from_colmajor(out.transformation), fitness=out.fitness, inlier_rmse=out.inlier_rmse,
+                iterations=out.iterations, converged=bool(out.converged), n_corr=int(out.n_corr))
+
+
+def covariance_from_normal(nrm, epsilon=1e-3):
+    n, npp = _d(np.asarray(nrm, dtype=np.float64).reshape(3))
+    cov = np.zeros(9)
+    lib().orc_covariance_from_normal(npp, epsilon, cov.ctypes.data_as(_dp))
+    return cov.reshape(3, 3)
+
+
+def gicp_jtj_jtr(src, src_cov, tgt, tgt_cov, corr):
+    src, sp = _d(src)
+    sc, scp = _d(np.asarray(src_cov).reshape(-1, 9))
+    tgt, tp = _d(tgt)
+    tc, tcp = _d(np.asarray(tgt_cov).reshape(-1, 9))
+    corr = np.ascontiguousarray(corr, np.int32)
+    JTJ = np.zeros(36)
+    JTr = np.zeros(6)
+    lib().orc_gicp_jtj_jtr(sp, scp, len(src), tp, tcp, corr.ctypes.data_as(_ip), JTJ.ctypes.data_as(_dp), JTr.ctypes.data_as(_dp))
+    return JTJ.reshape(6, 6), JTr
 
 
 def estimate_normals(pts, radius, max_nn):

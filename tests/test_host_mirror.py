@@ -29,10 +29,12 @@ def test_cloud_registration_factory_copies_parameters():
     c = reg.icpConvergenceCriteria_
     assert (c.max_iteration_, c.relative_fitness_, c.relative_rmse_) == (17, 1e-6, 1e-6)  # only max_iteration_ is overridden
     assert createPointToPlaneIcp(p).maxCorrespondenceDistance_ == 0.7
-    for t in (P.CloudRegistrationType.PointToPointIcp, P.CloudRegistrationType.GeneralizedIcp):
-        p.regType_ = t
-        with pytest.raises(NotImplementedError):  # next rows: fail loudly, never fall back to something else
-            cloudRegistrationFactory(p)
+    p.regType_ = P.CloudRegistrationType.GeneralizedIcp
+    g = cloudRegistrationFactory(p)
+    assert type(g).__name__ == "RegistrationIcpGeneralized" and g.maxCorrespondenceDistance_ == 0.7 and g.icpConvergenceCriteria_.max_iteration_ == 17
+    p.regType_ = P.CloudRegistrationType.PointToPointIcp
+    with pytest.raises(NotImplementedError):  # next row: fail loudly, never fall back to something else
+        cloudRegistrationFactory(p)
     p.regType_ = 42
     with pytest.raises(RuntimeError, match="unknown type"):
         cloudRegistrationFactory(p)

@@ -298,3 +298,76 @@ def test_persistent_loop_kernel_mode(oracle, small_c2, monkeypatch):
         assert far["fitness"] == 0.0 and far["iterations"] == 1 and far["converged"]
     finally:
         be.close()
+
+
+# ---- generalized ICP (what the shipped Lua configs select) --------------------------------------------
+def test_gicp_matches_oracle(backend_f64, backend_f32, oracle, small_c2):
+    src, tgt, nrm, T_gt = small_c2
+    sn = oracle.estimate_normals(src, 3.0, 20)
+    for kw in (dict(max_iter=8, rel_fitness=0.0, rel_rmse=0.0), dict(max_iter=30)):
+        ref = oracle.icp_generalized(src, sn, tgt, nrm, 1.0, **kw)
+        got = backend_f64.icp_generalized(src, sn, tgt, nrm, 1.0, **kw)
+        assert got["iterations"] == ref["iterations"] and got["converged"] == ref["converged"]
+        dt, dr = _check(got, ref, len(src), TOL_T64, TOL_R64)
+        assert got["n_corr"] == ref["n_corr"]
+        got32 = backend_f32.icp_generalized(src, sn, tgt, nrm, 1.0, **kw)
+        _check(got32, ref, len(src), TOL_T, TOL_R)
+    # non-identity init: the source covariances rotate with the cloud
+    T0 = syn.make_pose([0.1, -0.1, 0.0], [1.0, -2.0, 3.0])
+    ref = oracle.icp_generalized(src, sn, tgt, nrm, 1.0, init=T0, max_iter=5, rel_fitness=0.0, rel_rmse=0.0)
+    got = backend_f64.icp_generalized(src, sn, tgt, nrm, 1.0, init=T0, max_iter=5, rel_fitness=0.0, rel_rmse=0.0)
+    _check(got, ref, len(src), TOL_T64, TOL_R64)
+    # normals close to -e1 take GetRotationFromE1ToX's special case on both sides
+    sn2, nrm2 = sn.copy(), nrm.copy()
+    sn2[::7] = [-1.0, 0.0, 0.0]
+    nrm2[::5] = [-0.999, 0.0447101778, 0.0]
+    nrm2[::5] /= np.linalg.norm(nrm2[::5], axis=1, keepdims=True)
+    ref = oracle.icp_generalized(src, sn2, tgt, nrm2, 1.0, max_iter=4, rel_fitness=0.0, rel_rmse=0.0)
+    got = backend_f64.icp_generalized(src, sn2, tgt, nrm2, 1.0, max_iter=4, rel_fitness=0.0, rel_rmse=0.0)
+    _check(got, ref, len(src), TOL_T64, TOL_R64)
+
+
+def test_gicp_device_forms_and_errors(backend_f32, oracle, small_c2):
+    import torch
+
+    src, tgt, nrm, _ = small_c2
+    sn = oracle.estimate_normals(src, 3.0, 20)
+    s, t = backend_f32.upload(src, sn), backend_f32.upload(tgt, nrm)
+    backend_f32.build_index(t, 1.0)
+    one = backend_f32.icp_generalized_dev(s, t, 1.0, max_iter=6, rel_fitness=0.0, rel_rmse=0.0)
+    p2p = backend_f32.icp_point_to_plane_dev(s, t, 1.0, max_iter=6, rel_fitness=0.0, rel_rmse=0.0)
+    assert not np.array_equal(one["transformation"], p2p["transformation"])  # different estimator, not a silent alias
+    rec = torch.zeros(32, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    backend_f32.icp_begin(s, t, 1.0, max_iter=6, rel_fitness=0.0, rel_rmse=0.0, method=backend.ICP_GENERALIZED)
+    for _ in range(7):
+        backend_f32.icp_accumulate(0, len(src), rec.data_ptr())
+        backend_f32.icp_update(rec.data_ptr(), len(src))
+    step = backend_f32.icp_finish()
+    np.testing.assert_array_equal(step["transformation"], one["transformation"])
+    # fused map crop
+    crop_o = oracle.make_crop(oracle.CROP_MAX_RADIUS, center=(1.0, -2.0, 0.0), rmax=20.0)
+    keep = oracle.crop_indices(tgt, crop_o)
+    ref = oracle.icp_generalized(src, sn, tgt[keep], nrm[keep], 1.0, max_iter=4, rel_fitness=0.0, rel_rmse=0.0)
+    got = backend_f32.icp_generalized_dev(s, t, 1.0, max_iter=4, rel_fitness=0.0, rel_rmse=0.0,
+                                          target_crop=backend.make_crop(backend.CROP_MAX_RADIUS, center=(1.0, -2.0, 0.0), rmax=20.0))
+    _check(got, ref, len(src), TOL_T, TOL_R)
+    bare = backend_f32.upload(src)
+    with pytest.raises(backend.BackendError) as e:
+        backend_f32.icp_generalized_dev(bare, t, 1.0)
+    assert e.value.code == backend.ERR_NO_NORMALS
+    with pytest.raises(backend.BackendError):
+        backend_f32.set_gicp_epsilon(0.0)
+    for c in (s, t, bare):
+        backend_f32.free(c)
+
+
+def test_gicp_full_size_config2(backend_f32, oracle):
+    src, tgt, nrm, T_gt = syn.config2_inputs()
+    sn = oracle.estimate_normals(src, 3.0, 20)
+    got = backend_f32.icp_generalized(src, sn, tgt, nrm, 1.0, max_iter=10, rel_fitness=0.0, rel_rmse=0.0)
+    ref = oracle.icp_generalized(src, sn, tgt, nrm, 1.0, max_iter=10, rel_fitness=0.0, rel_rmse=0.0)
+    dt, dr = _check(got, ref, len(src), TOL_T, TOL_R)
+    gt_t, gt_r = syn.se3_error(got["transformation"], T_gt)
+    print(f"GICP C2 full: vs oracle {dt:.2e} {dr:.2e}; vs truth {gt_t:.2e} {gt_r:.2e}")
+    assert gt_t < 5e-3 and gt_r < 5e-4

@@ -285,3 +285,43 @@ def test_golden_scan_pair(oracle):
     dt, dr = syn.se3_error(r["transformation"], g["T10"])
     assert dt < 1e-7 and dr < 1e-7
     assert abs(r["fitness"] - float(g["fitness10"])) < 1e-12
+
+
+def test_gicp_covariance_model_and_special_case(oracle):
+    """C = Rx diag(eps,1,1) Rx^T == I - (1-eps) n n^T for unit normals; n.x < -0.99 uses e1 (GetRotationFromE1ToX)."""
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        n = rng.normal(size=3)
+        n /= np.linalg.norm(n)
+        C = oracle.covariance_from_normal(n, 1e-3)
+        a = np.array([1.0, 0, 0]) if n[0] < -0.99 else n
+        np.testing.assert_allclose(C, np.eye(3) - (1 - 1e-3) * np.outer(a, a), atol=1e-12)
+        np.testing.assert_allclose(C, no.covariances_from_normals([n])[0], atol=1e-14)
+    np.testing.assert_allclose(oracle.covariance_from_normal([-1.0, 0, 0]), np.diag([1e-3, 1, 1]), atol=0)
+
+
+def test_gicp_c_oracle_equals_numpy_restatement(oracle):
+    src, tgt, nrm, T_gt = syn.config2_inputs(n_map=30_000, n_az=64)
+    sn = oracle.estimate_normals(src, 3.0, 20)
+    a = oracle.icp_generalized(src, sn, tgt, nrm, 1.0, max_iter=8, rel_fitness=0.0, rel_rmse=0.0)
+    b = no.icp_generalized(src, sn, tgt, nrm, 1.0, max_iter=8, rel_fitness=0.0, rel_rmse=0.0)
+    np.testing.assert_allclose(a["transformation"], b["transformation"], atol=1e-9)
+    assert abs(a["inlier_rmse"] - b["inlier_rmse"]) < 1e-12 and a["fitness"] == b["fitness"]
+    dt, dr = syn.se3_error(a["transformation"], T_gt)
+    assert dt < 0.02 and dr < 5e-3  # 1024-pt scan vs a sparse 30k map, 8 iterations
+    # one accumulation: A^T M^-1 A form == the three-row W form
+    tree = oracle.KDTree(tgt)
+    corr, *_ = oracle.evaluate(tree, src, 1.0)
+    Cs, Ct = no.covariances_from_normals(sn), no.covariances_from_normals(nrm)
+    A1, b1 = oracle.gicp_jtj_jtr(src, Cs, tgt, Ct, corr)
+    A2, b2 = np.zeros((6, 6)), np.zeros(6)
+    for i in np.nonzero(corr >= 0)[0]:
+        p, d = src[i], src[i] - tgt[corr[i]]
+        Am = np.hstack([-np.array([[0, -p[2], p[1]], [p[2], 0, -p[0]], [-p[1], p[0], 0]]), np.eye(3)])
+        Mi = np.linalg.inv(Ct[corr[i]] + Cs[i])
+        A2 += Am.T @ Mi @ Am
+        b2 += Am.T @ Mi @ d
+    np.testing.assert_allclose(A1, A2, rtol=1e-10)
+    np.testing.assert_allclose(b1, b2, rtol=1e-9, atol=1e-9)
+    with pytest.raises(RuntimeError):
+        oracle.icp_generalized(src, None, tgt, nrm, 1.0)
