@@ -104,10 +104,17 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                              "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         args.gpus = world
+    # one rank per GPU; O3DS_BENCH_BACKEND=gloo lets the N>1 path be smoke-tested on a box with fewer GPUs than ranks
+    dist_backend = os.environ.get("O3DS_BENCH_BACKEND", "nccl")
+    if dist_backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        if dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(dist_backend, rank=rank, world_size=world)
 
     # ---- synthetic workload (seeded)
     scene = syn.make_scene()

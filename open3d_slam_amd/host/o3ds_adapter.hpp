@@ -296,6 +296,44 @@ class RegistrationIcpPointToPlane : public CloudRegistration {
   open3d::pipelines::registration::ICPConvergenceCriteria icpConvergenceCriteria_;
 };
 
+// RegistrationIcpGeneralized (CloudRegistration.hpp:56-69, CloudRegistration.cpp:16-39): the estimator the shipped Lua configs select
+class RegistrationIcpGeneralized : public CloudRegistration {
+ public:
+  RegistrationResult registerClouds(const PointCloud& source, const PointCloud& target, const Transform& init) const final {
+    o3ds_icp_params p{};
+    p.max_correspondence_distance = maxCorrespondenceDistance_;
+    p.max_iteration = icpConvergenceCriteria_.max_iteration_;
+    p.relative_fitness = icpConvergenceCriteria_.relative_fitness_;
+    p.relative_rmse = icpConvergenceCriteria_.relative_rmse_;
+    o3ds_icp_result r{};
+    o3ds_detail::Handle::check(o3ds_icp_generalized(o3ds_detail::Handle::get(), o3ds_detail::xyz(source.points_),
+                                                    source.HasNormals() ? o3ds_detail::xyz(source.normals_) : nullptr, source.points_.size(),
+                                                    o3ds_detail::xyz(target.points_),
+                                                    target.HasNormals() ? o3ds_detail::xyz(target.normals_) : nullptr, target.points_.size(),
+                                                    o3ds_detail::pose_data(init), &p, &r));
+    return RegistrationIcpPointToPlane::toResult(r);
+  }
+  void estimateNormalsOrCovariancesIfNeeded(PointCloud* cloud) const final {  // CloudRegistration.cpp:22-30
+    RegistrationIcpPointToPlane tmp;
+    tmp.knnNormalEstimation_ = knnNormalEstimation_;
+    tmp.maxRadiusNormalEstimation_ = maxRadiusNormalEstimation_;
+    tmp.estimateNormalsOrCovariancesIfNeeded(cloud);
+  }
+  double maxCorrespondenceDistance_ = 1.0;
+  int knnNormalEstimation_ = 10;
+  double maxRadiusNormalEstimation_ = 2.0;
+  open3d::pipelines::registration::ICPConvergenceCriteria icpConvergenceCriteria_;
+};
+
+inline std::unique_ptr<RegistrationIcpGeneralized> createGeneralizedIcp(const CloudRegistrationParameters& p) {  // CloudRegistration.cpp:32-39
+  auto ret = std::make_unique<RegistrationIcpGeneralized>();
+  ret->maxCorrespondenceDistance_ = p.icp_.maxCorrespondenceDistance_;
+  ret->knnNormalEstimation_ = p.icp_.knn_;
+  ret->maxRadiusNormalEstimation_ = p.icp_.maxDistanceKnn_;
+  ret->icpConvergenceCriteria_.max_iteration_ = p.icp_.maxNumIter_;
+  return ret;
+}
+
 inline std::unique_ptr<RegistrationIcpPointToPlane> createPointToPlaneIcp(const CloudRegistrationParameters& p) {  // CloudRegistration.cpp:58-65
   auto ret = std::make_unique<RegistrationIcpPointToPlane>();
   ret->maxCorrespondenceDistance_ = p.icp_.maxCorrespondenceDistance_;
@@ -309,10 +347,11 @@ inline std::unique_ptr<CloudRegistration> cloudRegistrationFactory(const CloudRe
   switch (p.regType_) {
     case CloudRegistrationType::PointToPlaneIcp:
       return createPointToPlaneIcp(p);
-    case CloudRegistrationType::PointToPointIcp:
     case CloudRegistrationType::GeneralizedIcp:
-      // next rows: in the reference tree these two keep their Open3D CPU implementations
-      throw std::runtime_error("cloud: registration type not available on the HIP backend yet");
+      return createGeneralizedIcp(p);
+    case CloudRegistrationType::PointToPointIcp:
+      // next row: in the reference tree this one keeps its Open3D CPU implementation
+      throw std::runtime_error("cloud: PointToPointIcp not available on the HIP backend yet");
     default:
       throw std::runtime_error("cloud: unknown type of cloud registration");
   }

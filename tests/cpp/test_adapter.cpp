@@ -66,6 +66,12 @@ static void noGpuChecks() {
   CHECK(p2p->maxCorrespondenceDistance_ == 0.7 && p2p->knnNormalEstimation_ == 9 && p2p->maxRadiusNormalEstimation_ == 1.5);
   CHECK(p2p->icpConvergenceCriteria_.max_iteration_ == 17);
   CHECK(p2p->icpConvergenceCriteria_.relative_fitness_ == 1e-6 && p2p->icpConvergenceCriteria_.relative_rmse_ == 1e-6);
+  p.regType_ = CloudRegistrationType::GeneralizedIcp;
+  auto g = cloudRegistrationFactory(p);
+  CHECK(dynamic_cast<RegistrationIcpGeneralized*>(g.get()) != nullptr);
+  CHECK(dynamic_cast<RegistrationIcpGeneralized*>(g.get())->icpConvergenceCriteria_.max_iteration_ == 17);
+  p.regType_ = CloudRegistrationType::PointToPointIcp;
+  CHECK(throws([&] { cloudRegistrationFactory(p); }));
   p.regType_ = static_cast<CloudRegistrationType>(42);
   CHECK(throws([&] { cloudRegistrationFactory(p); }));
   ScanCroppingParameters cp;
@@ -113,6 +119,22 @@ static void gpuChecks() {
   p2p->maxCorrespondenceDistance_ = 0.0;
   CHECK(throws([&] { reg->registerClouds(source, target, Transform::Identity()); }));
   p2p->maxCorrespondenceDistance_ = 0.5;
+  // generalized ICP through the same seam (needs normals on both clouds)
+  {
+    CloudRegistrationParameters gp = prm;
+    gp.regType_ = CloudRegistrationType::GeneralizedIcp;
+    auto greg = cloudRegistrationFactory(gp);
+    PointCloud srcN = source;
+    CHECK(throws([&] { greg->registerClouds(srcN, target, Transform::Identity()); }));  // source without normals
+    srcN.normals_.clear();
+    for (size_t i = 0; i < srcN.points_.size(); ++i) {  // normals of the plane each source point came from, rotated into the scan frame
+      std::array<double, 3> nn{{0, 0, 0}};
+      nn[i % 3] = 1.0;
+      srcN.normals_.push_back({{c * nn[0] + s * nn[1], -s * nn[0] + c * nn[1], nn[2]}});
+    }
+    const RegistrationResult rg = greg->registerClouds(srcN, target, Transform::Identity());
+    CHECK(rg.fitness_ > 0.99 && std::fabs(rg.transformation_[12] - 0.03) < 1e-3 && std::fabs(rg.transformation_[13] + 0.02) < 1e-3);
+  }
   // normals: plane z=0 seen from above -> +z
   PointCloud flat;
   std::mt19937 rng(5);
