@@ -69,6 +69,10 @@ struct o3ds_context {
   int session_method = O3DS_ICP_POINT_TO_PLANE;
   double gicp_epsilon = 1e-3;  // [O3D] TransformationEstimationForGeneralizedICP default
   hipStream_t own_stream = nullptr;
+  // bump arena for the temporaries of one top-level ABI call (stream-ordered reuse: everything runs on one stream)
+  std::vector<std::pair<char*, size_t>> arena_blocks;
+  size_t arena_cur = 0, arena_off = 0;
+  int arena_depth = 0;
   // launch geometry of the ICP pass kernel (tunable through O3DS_PASS_BLOCK / O3DS_PASS_ROWS for experiments)
   // two launches per pass (default) vs ONE persistent loop kernel per registration (O3DS_ICP_MODE=persistent);
   // measured on MI355X the grid rendezvous of the persistent form costs what the launches cost (profiles/r01_*), so the
@@ -105,6 +109,76 @@ int fail(o3ds_handle h, int code, const std::string& msg) {
 
 #define CHECK_HANDLE(h) \
   if (!(h)) return fail(nullptr, O3DS_ERR_BAD_HANDLE, "null handle")
+
+// ---- scratch arena ------------------------------------------------------------------------------------------------
+// Temporaries (scan block sums, flags, sort buffers, staging copies ...) are bump-allocated from blocks that persist
+// for the life of the handle: a per-scan pipeline makes ~120 allocations otherwise (4.6 us each + free).  The bump
+// pointer is reset at the start of every outermost ABI call; safe without synchronisation because all work of a handle
+// is ordered on one stream.
+int arena_alloc(o3ds_handle h, void** out, size_t bytes) {
+  bytes = (bytes + 255) & ~(size_t)255;
+  if (bytes == 0) bytes = 256;
+  static const bool no_reuse = getenv("O3DS_NO_ARENA") != nullptr;  // debugging aid: every temporary is its own pool allocation
+  if (no_reuse) {
+    char* p = nullptr;
+    if (hipMallocAsync((void**)&p, bytes, h->stream) != hipSuccess) return fail(h, O3DS_ERR_OOM, "arena: out of memory");
+    h->arena_blocks.emplace_back(p, 0);
+    *out = p;
+    return O3DS_OK;
+  }
+  for (;;) {
+    if (h->arena_cur < h->arena_blocks.size()) {
+      auto& b = h->arena_blocks[h->arena_cur];
+      if (h->arena_off + bytes <= b.second) {
+        *out = b.first + h->arena_off;
+        h->arena_off += bytes;
+        return O3DS_OK;
+      }
+      ++h->arena_cur;
+      h->arena_off = 0;
+      continue;
+    }
+    static const size_t first_mb = getenv("O3DS_ARENA_MB") ? (size_t)atoi(getenv("O3DS_ARENA_MB")) : 32;
+    size_t want = std::max<size_t>(bytes, first_mb << 20);
+    if (!h->arena_blocks.empty()) want = std::max(want, 2 * h->arena_blocks.back().second);
+    char* p = nullptr;
+    hipError_t e = hipMallocAsync((void**)&p, want, h->stream);
+    if (e != hipSuccess) return fail(h, O3DS_ERR_OOM, std::string("arena: ") + hipGetErrorString(e));
+    h->arena_blocks.emplace_back(p, want);
+    if (getenv("O3DS_ARENA_LOG"))
+      fprintf(stderr, "[arena] new block %zu MB (request %zu B, blocks now %zu, prev off %zu)\n", want >> 20, bytes, h->arena_blocks.size(), h->arena_off);
+  }
+}
+struct ArenaScope {
+  o3ds_handle h;
+  explicit ArenaScope(o3ds_handle hh) : h(hh) {
+    if (h && h->arena_depth++ == 0) {
+      if (getenv("O3DS_NO_ARENA")) {
+        for (auto& b : h->arena_blocks) (void)hipFreeAsync(b.first, h->stream);
+        h->arena_blocks.clear();
+      }
+      // Blocks are never returned or merged while the handle lives: they grow geometrically, so there are at most a
+      // handful, and a call simply walks through them.  (Freeing a 32 MB and a 64 MB block and immediately requesting
+      // one 96 MB block from the stream-ordered pool corrupted live data on ROCm 7.2 -- timing dependent, reproduced
+      // with scripts/debug_stream.py -- so the arena avoids free/alloc churn altogether.)
+      h->arena_cur = 0;
+      h->arena_off = 0;
+    }
+  }
+  ~ArenaScope() {
+    if (h) --h->arena_depth;
+  }
+};
+// debugging aid: O3DS_SYNC_MASK re-inserts a stream synchronisation at the end of selected internal steps
+inline void dbg_sync(o3ds_handle h, int bit) {
+  static const int mask = getenv("O3DS_SYNC_MASK") ? atoi(getenv("O3DS_SYNC_MASK")) : 0;
+  if (mask & bit) (void)hipStreamSynchronize(h->stream);
+}
+#define TMP_ALLOC(ptr, bytes)                                   \
+  do {                                                          \
+    int _rc = arena_alloc(h, (void**)&(ptr), (size_t)(bytes));  \
+    if (_rc) return _rc;                                        \
+  } while (0)
 
 inline int grid_for(size_t n, int cap = 4096) {
   size_t g = (n + kBlock - 1) / kBlock;
@@ -149,28 +223,26 @@ int exclusive_scan_int(o3ds_handle h, const int* in, int* out, size_t m) {
   if (m == 0) return O3DS_OK;
   const int nb = (int)((m + kScanPerBlock - 1) / kScanPerBlock);
   int* sums = nullptr;
-  HIP_TRY(hipMallocAsync((void**)&sums, sizeof(int) * (size_t)nb, h->stream));
+  TMP_ALLOC(sums, sizeof(int) * (size_t)nb);
   scan_local_kernel<<<nb, kBlock, 0, h->stream>>>(in, out, sums, m);
   if (nb > 1) {
     scan_sums_kernel<<<1, kBlock, 0, h->stream>>>(sums, nb);
     scan_add_kernel<<<nb, kBlock, 0, h->stream>>>(out, sums, m);
   }
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  HIP_TRY(hipFreeAsync(sums, h->stream));
-  return O3DS_OK;
+  dbg_sync(h, 1);
+  return O3DS_OK;  // results are stream-ordered; callers that need a value on the host copy it back and synchronise
 }
 
 template <typename P4>
 int bbox_of(o3ds_handle h, const P4* pts, size_t n, double mn[3], double mx[3]) {
   const int g = grid_for(n, 1024);
   double* d = nullptr;
-  HIP_TRY(hipMallocAsync((void**)&d, sizeof(double) * 6 * (size_t)g, h->stream));
+  TMP_ALLOC(d, sizeof(double) * 6 * (size_t)g);
   bbox_kernel<P4><<<g, kBlock, 0, h->stream>>>(pts, n, d);
   std::vector<double> hb(6 * (size_t)g);
   HIP_TRY(hipMemcpyAsync(hb.data(), d, sizeof(double) * hb.size(), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  HIP_TRY(hipFreeAsync(d, h->stream));
   for (int a = 0; a < 3; ++a) {
     mn[a] = 1e300;
     mx[a] = -1e300;
@@ -214,9 +286,9 @@ int build_grid_t(o3ds_handle h, const P4* pts, const P4* nrm, size_t n, double c
   g.nz = (int)nz;
   int *counts = nullptr, *cursor = nullptr, *cell_id = nullptr, *cell_start = nullptr;
   void *spts = nullptr, *snrm = nullptr;
-  HIP_TRY(hipMallocAsync((void**)&counts, sizeof(int) * (ncell + 1), h->stream));
-  HIP_TRY(hipMallocAsync((void**)&cursor, sizeof(int) * ncell, h->stream));
-  HIP_TRY(hipMallocAsync((void**)&cell_id, sizeof(int) * n, h->stream));
+  TMP_ALLOC(counts, sizeof(int) * (ncell + 1));
+  TMP_ALLOC(cursor, sizeof(int) * ncell);
+  TMP_ALLOC(cell_id, sizeof(int) * n);
   HIP_TRY(hipMallocAsync((void**)&cell_start, sizeof(int) * (ncell + 1), h->stream));
   HIP_TRY(hipMallocAsync((void**)&spts, sizeof(P4) * n, h->stream));
   if (nrm) HIP_TRY(hipMallocAsync((void**)&snrm, sizeof(P4) * n, h->stream));
@@ -227,10 +299,7 @@ int build_grid_t(o3ds_handle h, const P4* pts, const P4* nrm, size_t n, double c
   if (rc) return rc;
   scatter_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(pts, nrm, n, cell_id, cell_start, cursor, (P4*)spts, (P4*)snrm);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  HIP_TRY(hipFreeAsync(counts, h->stream));
-  HIP_TRY(hipFreeAsync(cursor, h->stream));
-  HIP_TRY(hipFreeAsync(cell_id, h->stream));
+  dbg_sync(h, 2);
   g.cell_start = cell_start;
   *out_grid = g;
   *out_cell_start = cell_start;
@@ -270,20 +339,19 @@ int upload_t(o3ds_handle h, const double* xyz, const double* normals, size_t n, 
   c.n = n;
   c.precision = h->precision;
   if (n == 0) return O3DS_OK;
-  double* stage = nullptr;
-  HIP_TRY(hipMallocAsync((void**)&stage, sizeof(double) * 3 * n, h->stream));
+  double *stage = nullptr, *stage_n = nullptr;
+  TMP_ALLOC(stage, sizeof(double) * 3 * n);
   HIP_TRY(hipMallocAsync((void**)&c.pts, sizeof(P4) * n, h->stream));
   HIP_TRY(hipMemcpyAsync(stage, xyz, sizeof(double) * 3 * n, hipMemcpyHostToDevice, h->stream));
   pack_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(stage, n, (P4*)c.pts);
   if (normals) {
+    TMP_ALLOC(stage_n, sizeof(double) * 3 * n);
     HIP_TRY(hipMallocAsync((void**)&c.nrm, sizeof(P4) * n, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));  // stage is reused
-    HIP_TRY(hipMemcpyAsync(stage, normals, sizeof(double) * 3 * n, hipMemcpyHostToDevice, h->stream));
-    pack_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(stage, n, (P4*)c.nrm);
+    HIP_TRY(hipMemcpyAsync(stage_n, normals, sizeof(double) * 3 * n, hipMemcpyHostToDevice, h->stream));
+    pack_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(stage_n, n, (P4*)c.nrm);
   }
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  HIP_TRY(hipFreeAsync(stage, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));  // the caller may release its host buffers as soon as this returns
   return O3DS_OK;
 }
 
@@ -291,7 +359,7 @@ template <typename P4>
 int download_t(o3ds_handle h, const CloudRec& c, double* xyz, double* normals) {
   if (c.n == 0) return O3DS_OK;
   double* stage = nullptr;
-  HIP_TRY(hipMallocAsync((void**)&stage, sizeof(double) * 3 * c.n, h->stream));
+  TMP_ALLOC(stage, sizeof(double) * 3 * c.n);
   if (xyz) {
     unpack_kernel<P4><<<grid_for(c.n), kBlock, 0, h->stream>>>((const P4*)c.pts, c.n, stage);
     HIP_TRY(hipMemcpyAsync(xyz, stage, sizeof(double) * 3 * c.n, hipMemcpyDeviceToHost, h->stream));
@@ -303,7 +371,6 @@ int download_t(o3ds_handle h, const CloudRec& c, double* xyz, double* normals) {
     HIP_TRY(hipStreamSynchronize(h->stream));
   }
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipFreeAsync(stage, h->stream));
   return O3DS_OK;
 }
 
@@ -550,6 +617,8 @@ int o3ds_destroy(o3ds_handle h) {
   (void)hipStreamSynchronize(h->stream);
   (void)hipStreamSynchronize(h->own_stream);
   for (auto& kv : h->clouds) free_cloud(h, kv.second);
+  for (auto& b : h->arena_blocks) (void)hipFreeAsync(b.first, h->stream);
+  (void)hipStreamSynchronize(h->stream);
   if (h->d_rows) (void)hipFree(h->d_rows);
   if (h->d_counter) (void)hipFree(h->d_counter);
   if (h->d_partials) (void)hipFree(h->d_partials);
@@ -609,6 +678,7 @@ int o3ds_profile_read(o3ds_handle h, uint64_t* n_launches, double* total_ms) {
 // ---- clouds ------------------------------------------------------------------------------------
 int o3ds_cloud_upload(o3ds_handle h, const double* xyz, const double* normals, size_t n, o3ds_cloud* out) {
   CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
   if (!out || (n > 0 && !xyz)) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_upload: null argument");
   if (n > 0x7fffffffull) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_upload: more than 2^31-1 points");
   HIP_TRY(hipSetDevice(h->device));
@@ -643,6 +713,7 @@ int o3ds_cloud_size(o3ds_handle h, o3ds_cloud id, size_t* n, int* has_normals) {
 
 int o3ds_cloud_download(o3ds_handle h, o3ds_cloud id, double* xyz, double* normals, size_t capacity) {
   CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
   CloudRec* c = find_cloud(h, id);
   if (!c) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_download: unknown cloud id");
   if (capacity < c->n) return fail(h, O3DS_ERR_CAPACITY, "cloud_download: capacity < cloud size");
@@ -651,6 +722,7 @@ int o3ds_cloud_download(o3ds_handle h, o3ds_cloud id, double* xyz, double* norma
 
 int o3ds_cloud_build_index(o3ds_handle h, o3ds_cloud id, double max_corr_hint, double cell_size) {
   CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
   CloudRec* c = find_cloud(h, id);
   if (!c) return fail(h, O3DS_ERR_INVALID_ARG, "build_index: unknown cloud id");
   double cell = cell_size > 0.0 ? cell_size : max_corr_hint / 4.0;
@@ -664,12 +736,14 @@ int o3ds_cloud_build_index(o3ds_handle h, o3ds_cloud id, double max_corr_hint, d
 int o3ds_icp_begin(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3ds_crop* target_crop, const double init[16],
                    const o3ds_icp_params* params) {
   CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
   if (!init) return fail(h, O3DS_ERR_INVALID_ARG, "icp_begin: null init");
   return begin_session(h, source, target, target_crop, init, params);
 }
 
 int o3ds_icp_accumulate(o3ds_handle h, size_t first, size_t count, double* d_record) {
   CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
   if (!h->session) return fail(h, O3DS_ERR_INVALID_ARG, "icp_accumulate: no session (call o3ds_icp_begin)");
   if (!d_record) return fail(h, O3DS_ERR_INVALID_ARG, "icp_accumulate: null record");
   if (first + count > h->session_n_src) return fail(h, O3DS_ERR_INVALID_ARG, "icp_accumulate: range outside source");
@@ -756,6 +830,7 @@ int o3ds_icp_generalized_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target
 int o3ds_icp_generalized(o3ds_handle h, const double* src_xyz, const double* src_normals, size_t n_src, const double* tgt_xyz,
                          const double* tgt_normals, size_t n_tgt, const double init[16], const o3ds_icp_params* params, o3ds_icp_result* out) {
   CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
   if (!params || !out || !init) return fail(h, O3DS_ERR_INVALID_ARG, "icp: null argument");
   if (!(params->max_correspondence_distance > 0.0)) return fail(h, O3DS_ERR_INVALID_ARG, "Invalid max_correspondence_distance.");
   if (n_tgt == 0) return fail(h, O3DS_ERR_EMPTY, "icp: empty target (map patch size is zero)");
@@ -775,6 +850,7 @@ int o3ds_icp_generalized(o3ds_handle h, const double* src_xyz, const double* src
 int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3ds_crop* target_crop, const double init[16],
                           const o3ds_icp_params* params, o3ds_icp_result* out) {
   CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
   if (!init || !out) return fail(h, O3DS_ERR_INVALID_ARG, "icp: null init/out");
   int rc = begin_session(h, source, target, target_crop, init, params);
   if (rc) return rc;
@@ -830,6 +906,7 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
 int o3ds_icp_point_to_plane(o3ds_handle h, const double* src_xyz, size_t n_src, const double* tgt_xyz, const double* tgt_normals,
                             size_t n_tgt, const double init[16], const o3ds_icp_params* params, o3ds_icp_result* out) {
   CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
   if (!params || !out || !init) return fail(h, O3DS_ERR_INVALID_ARG, "icp: null argument");
   if (!(params->max_correspondence_distance > 0.0)) return fail(h, O3DS_ERR_INVALID_ARG, "Invalid max_correspondence_distance.");
   if (n_tgt == 0) return fail(h, O3DS_ERR_EMPTY, "icp: empty target (map patch size is zero)");
@@ -889,14 +966,15 @@ int crop_t(o3ds_handle h, const CloudRec& in, const CropDev& crop, CloudRec& out
   out.n = 0;
   if (in.n == 0) return O3DS_OK;
   int *flags = nullptr, *pos = nullptr;
-  HIP_TRY(hipMallocAsync((void**)&flags, sizeof(int) * (in.n + 1), h->stream));
-  HIP_TRY(hipMallocAsync((void**)&pos, sizeof(int) * (in.n + 1), h->stream));
+  TMP_ALLOC(flags, sizeof(int) * (in.n + 1));
+  TMP_ALLOC(pos, sizeof(int) * (in.n + 1));
   HIP_TRY(hipMemsetAsync(flags + in.n, 0, sizeof(int), h->stream));
   crop_flag_kernel<P4><<<grid_for(in.n), kBlock, 0, h->stream>>>((const P4*)in.pts, in.n, crop, flags);
   int rc = exclusive_scan_int(h, flags, pos, in.n + 1);
   if (rc) return rc;
   int total = 0;
-  HIP_TRY(hipMemcpy(&total, pos + in.n, sizeof(int), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpyAsync(&total, pos + in.n, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   out.n = (size_t)total;
   if (total > 0) {
     HIP_TRY(hipMallocAsync((void**)&out.pts, sizeof(P4) * out.n, h->stream));
@@ -904,10 +982,8 @@ int crop_t(o3ds_handle h, const CloudRec& in, const CropDev& crop, CloudRec& out
     compact_kernel<P4><<<grid_for(in.n), kBlock, 0, h->stream>>>((const P4*)in.pts, (const P4*)in.nrm, in.n, flags, pos, 1, (P4*)out.pts,
                                                                (P4*)out.nrm);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(h->stream));
   }
-  HIP_TRY(hipFreeAsync(flags, h->stream));
-  HIP_TRY(hipFreeAsync(pos, h->stream));
+  dbg_sync(h, 4);
   return O3DS_OK;
 }
 
@@ -932,18 +1008,18 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
   unsigned long long *k0 = nullptr, *k1 = nullptr, *d_scalar = nullptr;
   uint32_t *v0 = nullptr, *v1 = nullptr;
   int *head = nullptr, *seg_id = nullptr, *seg_start = nullptr;
-  HIP_TRY(hipMallocAsync((void**)&k0, sizeof(unsigned long long) * n, h->stream));
-  HIP_TRY(hipMallocAsync((void**)&k1, sizeof(unsigned long long) * n, h->stream));
-  HIP_TRY(hipMallocAsync((void**)&v0, sizeof(uint32_t) * n, h->stream));
-  HIP_TRY(hipMallocAsync((void**)&v1, sizeof(uint32_t) * n, h->stream));
-  HIP_TRY(hipMallocAsync((void**)&head, sizeof(int) * (n + 1), h->stream));
-  HIP_TRY(hipMallocAsync((void**)&seg_id, sizeof(int) * (n + 1), h->stream));
-  HIP_TRY(hipMallocAsync((void**)&d_scalar, sizeof(unsigned long long), h->stream));
+  TMP_ALLOC(k0, sizeof(unsigned long long) * n);
+  TMP_ALLOC(k1, sizeof(unsigned long long) * n);
+  TMP_ALLOC(v0, sizeof(uint32_t) * n);
+  TMP_ALLOC(v1, sizeof(uint32_t) * n);
+  TMP_ALLOC(head, sizeof(int) * (n + 1));
+  TMP_ALLOC(seg_id, sizeof(int) * (n + 1));
+  TMP_ALLOC(d_scalar, sizeof(unsigned long long));
   voxel_key_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>((const P4*)in.pts, n, mode, ox, oy, oz, voxel, crop, k0, v0);
   size_t temp_bytes = 0;
   HIP_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, k0, k1, v0, v1, n, 0, 64, h->stream));
   void* temp = nullptr;
-  HIP_TRY(hipMallocAsync((void**)&temp, temp_bytes ? temp_bytes : 16, h->stream));
+  TMP_ALLOC(temp, temp_bytes ? temp_bytes : 16);
   HIP_TRY(rocprim::radix_sort_pairs(temp, temp_bytes, k0, k1, v0, v1, n, 0, 64, h->stream));
   HIP_TRY(hipMemsetAsync(head + n, 0, sizeof(int), h->stream));
   segment_head_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(k1, n, head);
@@ -952,10 +1028,11 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
   if (rc) return rc;
   int n_seg = 0;
   unsigned long long n_inside = 0;
-  HIP_TRY(hipMemcpy(&n_seg, seg_id + n, sizeof(int), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(&n_inside, d_scalar, sizeof(n_inside), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpyAsync(&n_seg, seg_id + n, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(&n_inside, d_scalar, sizeof(n_inside), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   const size_t n_pass = n - (size_t)n_inside;
-  HIP_TRY(hipMallocAsync((void**)&seg_start, sizeof(int) * ((size_t)n_seg + 1), h->stream));
+  TMP_ALLOC(seg_start, sizeof(int) * ((size_t)n_seg + 1));
   segment_start_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(head, seg_id, n, seg_start);
   out.n = (size_t)n_seg;
   HIP_TRY(hipMallocAsync((void**)&out.pts, sizeof(P4) * out.n, h->stream));
@@ -963,9 +1040,7 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
   segment_mean_kernel<P4><<<grid_for(out.n), kBlock, 0, h->stream>>>((const P4*)in.pts, (const P4*)in.nrm, k1, v1, seg_start, out.n, n,
                                                                     mode == 1 ? 1 : 0, n_pass, (P4*)out.pts, (P4*)out.nrm);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  for (void* p : {(void*)k0, (void*)k1, (void*)v0, (void*)v1, (void*)head, (void*)seg_id, (void*)seg_start, (void*)d_scalar, temp})
-    HIP_TRY(hipFreeAsync(p, h->stream));
+  dbg_sync(h, 8);
   return O3DS_OK;
 }
 
@@ -986,12 +1061,12 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn) {
   }
   const size_t ncell = (size_t)tmp.grid.nx * tmp.grid.ny * tmp.grid.nz;
   unsigned long long* d_cnt = nullptr;
-  HIP_TRY(hipMallocAsync((void**)&d_cnt, sizeof(unsigned long long), h->stream));
+  TMP_ALLOC(d_cnt, sizeof(unsigned long long));
   HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), h->stream));
   count_occupied_kernel<<<grid_for(ncell), kBlock, 0, h->stream>>>(tmp.cell_start, ncell, d_cnt);
   unsigned long long occ = 0;
-  HIP_TRY(hipMemcpy(&occ, d_cnt, sizeof(occ), hipMemcpyDeviceToHost));
-  HIP_TRY(hipFreeAsync(d_cnt, h->stream));
+  HIP_TRY(hipMemcpyAsync(&occ, d_cnt, sizeof(occ), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   const double avg = occ ? (double)c.n / (double)occ : 1.0;
   double cell = tmp.grid.cell * std::sqrt(std::max(1.0, (double)max_nn) / (3.14159265358979 * avg));
   cell = std::min(std::max(cell, radius / 64.0), radius);
@@ -1020,7 +1095,7 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn) {
     }
   }
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  dbg_sync(h, 16);
   tmp.pts = nullptr;
   free_index(h, tmp);
   free_index(h, c);  // the cloud's own index (if any) no longer matches its normals
@@ -1060,7 +1135,7 @@ int append_t(o3ds_handle h, CloudRec& map, const CloudRec& add) {
     if (keep_nrm) reindex_copy_kernel<P4><<<grid_for(add.n), kBlock, 0, h->stream>>>((const P4*)add.nrm, add.n, (P4*)nn, map.n, 0);
   }
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  dbg_sync(h, 32);
   free_index(h, map);
   if (map.pts) HIP_TRY(hipFreeAsync(map.pts, h->stream));
   if (map.nrm) HIP_TRY(hipFreeAsync(map.nrm, h->stream));
@@ -1078,6 +1153,7 @@ extern "C" {
 
 int o3ds_crop_cloud(o3ds_handle h, o3ds_cloud in, const o3ds_crop* crop, o3ds_cloud* out) {
   CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
   CloudRec* c = find_cloud(h, in);
   if (!c || !out) return fail(h, O3DS_ERR_INVALID_ARG, "crop_cloud: bad argument");
   CloudRec o;
@@ -1093,6 +1169,7 @@ int o3ds_crop_cloud(o3ds_handle h, o3ds_cloud in, const o3ds_crop* crop, o3ds_cl
 
 int o3ds_voxel_down_sample(o3ds_handle h, o3ds_cloud in, double voxel_size, o3ds_cloud* out) {
   CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
   CloudRec* c = find_cloud(h, in);
   if (!c || !out) return fail(h, O3DS_ERR_INVALID_ARG, "voxel_down_sample: bad argument");
   CloudRec o;
@@ -1114,6 +1191,7 @@ int o3ds_voxel_down_sample(o3ds_handle h, o3ds_cloud in, double voxel_size, o3ds
 
 int o3ds_estimate_normals(o3ds_handle h, o3ds_cloud id, double radius, int max_nn) {
   CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
   CloudRec* c = find_cloud(h, id);
   if (!c) return fail(h, O3DS_ERR_INVALID_ARG, "estimate_normals: unknown cloud id");
   if (!(radius > 0.0)) return fail(h, O3DS_ERR_INVALID_ARG, "maxRadiusNormalEstimation_ must be > 0");  // CloudRegistration.cpp:50
@@ -1124,6 +1202,7 @@ int o3ds_estimate_normals(o3ds_handle h, o3ds_cloud id, double radius, int max_n
 
 int o3ds_select_by_index(o3ds_handle h, o3ds_cloud in, const uint32_t* keep_idx, size_t m, o3ds_cloud* out) {
   CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
   CloudRec* c = find_cloud(h, in);
   if (!c || !out || (m && !keep_idx)) return fail(h, O3DS_ERR_INVALID_ARG, "select_by_index: bad argument");
   for (size_t i = 0; i < m; ++i)
@@ -1134,7 +1213,7 @@ int o3ds_select_by_index(o3ds_handle h, o3ds_cloud in, const uint32_t* keep_idx,
   if (m) {
     uint32_t* d_idx = nullptr;
     const size_t psz = p4_size(c->precision);
-    HIP_TRY(hipMallocAsync((void**)&d_idx, sizeof(uint32_t) * m, h->stream));
+    TMP_ALLOC(d_idx, sizeof(uint32_t) * m);
     HIP_TRY(hipMemcpyAsync(d_idx, keep_idx, sizeof(uint32_t) * m, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMallocAsync((void**)&o.pts, psz * m, h->stream));
     if (c->nrm) HIP_TRY(hipMallocAsync((void**)&o.nrm, psz * m, h->stream));
@@ -1143,8 +1222,7 @@ int o3ds_select_by_index(o3ds_handle h, o3ds_cloud in, const uint32_t* keep_idx,
     else
       gather_kernel<P4f><<<grid_for(m), kBlock, 0, h->stream>>>((const P4f*)c->pts, (const P4f*)c->nrm, d_idx, m, (P4f*)o.pts, (P4f*)o.nrm);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipFreeAsync(d_idx, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));  // keep_idx may be released by the caller
   }
   *out = add_cloud(h, std::move(o));
   return O3DS_OK;
@@ -1152,6 +1230,7 @@ int o3ds_select_by_index(o3ds_handle h, o3ds_cloud in, const uint32_t* keep_idx,
 
 int o3ds_transform_cloud(o3ds_handle h, o3ds_cloud in, const double T[16], o3ds_cloud* out) {
   CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
   CloudRec* c = find_cloud(h, in);
   if (!c || !out || !T) return fail(h, O3DS_ERR_INVALID_ARG, "transform_cloud: bad argument");
   CloudRec o;
@@ -1166,6 +1245,7 @@ int o3ds_transform_cloud(o3ds_handle h, o3ds_cloud in, const double T[16], o3ds_
 
 int o3ds_cloud_append(o3ds_handle h, o3ds_cloud map, o3ds_cloud add) {
   CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
   CloudRec* m = find_cloud(h, map);
   CloudRec* a = find_cloud(h, add);
   if (!m || !a || m == a) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_append: bad cloud id");
@@ -1176,6 +1256,7 @@ int o3ds_cloud_append(o3ds_handle h, o3ds_cloud map, o3ds_cloud add) {
 
 int o3ds_voxelize_within_volume(o3ds_handle h, o3ds_cloud map, double voxel_size, const o3ds_crop* crop) {
   CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
   CloudRec* m = find_cloud(h, map);
   if (!m) return fail(h, O3DS_ERR_INVALID_ARG, "voxelize_within_volume: unknown cloud id");
   if (voxel_size <= 0.0 || m->n == 0) return O3DS_OK;  // helpers.cpp:119-123 / Submap.cpp:139: unchanged
@@ -1194,6 +1275,7 @@ int o3ds_voxelize_within_volume(o3ds_handle h, o3ds_cloud map, double voxel_size
 int o3ds_map_insert_scan(o3ds_handle h, o3ds_cloud map, o3ds_cloud scan, const double T[16], double map_voxel_size,
                          const o3ds_crop* map_builder_crop, double max_corr_hint) {
   CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
   CloudRec* m = find_cloud(h, map);
   CloudRec* s = find_cloud(h, scan);
   if (!m || !s || !T || m == s) return fail(h, O3DS_ERR_INVALID_ARG, "map_insert_scan: bad argument");
