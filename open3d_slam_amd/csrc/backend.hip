@@ -78,6 +78,9 @@ struct o3ds_context {
   // measured on MI355X the grid rendezvous of the persistent form costs what the launches cost (profiles/r01_*), so the
   // simpler form is the default
   bool persistent = false;
+  // ONE launch per pass with the previous pass's tail in its prologue (O3DS_ICP_MODE=fused), see icp_fused_kernel
+  bool fused = false;
+  char* d_fused = nullptr;  // [2 states | 2x64 tickets | 2x64 slot records | 2 x kMaxPassBlocks rows]
   int cu_count = 256;
   double* d_rows = nullptr;        // [2][kMaxLoopWgs][kRec]
   unsigned int* d_counter = nullptr;
@@ -462,6 +465,46 @@ void launch_loop(o3ds_handle h, const IcpLoopArgs& la, bool crop, int nwg) {
   if (e1) (void)hipEventRecord(e1, h->stream);
 }
 
+// fused form: byte offsets inside d_fused
+constexpr size_t kFusedStateStride = 256;
+constexpr size_t kFusedTicketsOff = 2 * kFusedStateStride;
+constexpr size_t kFusedSlotsOff = kFusedTicketsOff + 2 * kFusedSlots * sizeof(unsigned int);
+constexpr size_t kFusedRowsOff = kFusedSlotsOff + 2 * (size_t)kFusedSlots * kRec * sizeof(double);
+constexpr size_t kFusedBytes = kFusedRowsOff + 2 * (size_t)kMaxPassBlocks * kRec * sizeof(double);
+static_assert(sizeof(IcpStateDev) <= kFusedStateStride, "state slot too small");
+
+template <typename P4>
+void launch_fused(o3ds_handle h, const IcpFusedArgs& fa, bool crop, int nblocks, bool bracket) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (h->profiling && bracket) {
+    if (h->ev_used + 2 > h->ev.size()) {
+      hipEvent_t a0, a1;
+      if (hipEventCreate(&a0) == hipSuccess && hipEventCreate(&a1) == hipSuccess) {
+        h->ev.push_back(a0);
+        h->ev.push_back(a1);
+      }
+    }
+    if (h->ev_used + 2 <= h->ev.size()) {
+      e0 = h->ev[h->ev_used];
+      e1 = h->ev[h->ev_used + 1];
+      h->ev_used += 2;
+      (void)hipEventRecord(e0, h->stream);
+    }
+  }
+  if (h->session_method == O3DS_ICP_GENERALIZED) {
+    if (crop)
+      icp_fused_kernel<P4, true, 256, 4, true><<<nblocks, 256, 0, h->stream>>>(fa);
+    else
+      icp_fused_kernel<P4, false, 256, 4, true><<<nblocks, 256, 0, h->stream>>>(fa);
+  } else {
+    if (crop)
+      icp_fused_kernel<P4, true, 256, 4, false><<<nblocks, 256, 0, h->stream>>>(fa);
+    else
+      icp_fused_kernel<P4, false, 256, 4, false><<<nblocks, 256, 0, h->stream>>>(fa);
+  }
+  if (e1) (void)hipEventRecord(e1, h->stream);
+}
+
 int pass_blocks(o3ds_handle h, size_t count) {
   const bool gicp = h->session_method == O3DS_ICP_GENERALIZED;
   const int blk = gicp ? 256 : (h->pass_block == 512 && h->pass_group == 4 ? 512 : 256);
@@ -543,8 +586,8 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
   return O3DS_OK;
 }
 
-int read_state(o3ds_handle h, o3ds_icp_result* out) {
-  HIP_TRY(hipMemcpyAsync(h->h_state, h->d_state, sizeof(IcpStateDev), hipMemcpyDeviceToHost, h->stream));
+int read_state(o3ds_handle h, o3ds_icp_result* out, const IcpStateDev* d_from = nullptr) {
+  HIP_TRY(hipMemcpyAsync(h->h_state, d_from ? d_from : h->d_state, sizeof(IcpStateDev), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (out) {
     memcpy(out->transformation, h->h_state->T, sizeof(double) * 16);
@@ -598,7 +641,14 @@ int o3ds_create(int device_id, o3ds_handle* out) {
       o3ds_destroy(h);
       return fail(nullptr, O3DS_ERR_OOM, "o3ds_create: scratch allocation failed");
     }
-    if (const char* e = getenv("O3DS_ICP_MODE")) h->persistent = std::string(e) == "persistent";
+    if (hipMalloc((void**)&h->d_fused, kFusedBytes) != hipSuccess || hipMemset(h->d_fused, 0, kFusedBytes) != hipSuccess) {
+      o3ds_destroy(h);
+      return fail(nullptr, O3DS_ERR_OOM, "o3ds_create: scratch allocation failed");
+    }
+    if (const char* e = getenv("O3DS_ICP_MODE")) {
+      h->persistent = std::string(e) == "persistent";
+      h->fused = std::string(e) == "fused";
+    }
   }
   if (const char* e = getenv("O3DS_DEBUG_UPDATE")) h->debug_update = atoi(e);
   if (const char* e = getenv("O3DS_PASS_BLOCK")) h->pass_block = atoi(e) == 512 ? 512 : 256;
@@ -621,6 +671,7 @@ int o3ds_destroy(o3ds_handle h) {
   (void)hipStreamSynchronize(h->stream);
   if (h->d_rows) (void)hipFree(h->d_rows);
   if (h->d_counter) (void)hipFree(h->d_counter);
+  if (h->d_fused) (void)hipFree(h->d_fused);
   if (h->d_partials) (void)hipFree(h->d_partials);
   if (h->d_state) (void)hipFree(h->d_state);
   if (h->h_state) (void)hipHostFree(h->h_state);
@@ -877,6 +928,44 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
     rc = read_state(h, out);
     if (rc) return rc;
     if (h->h_state->error) return fail(h, O3DS_ERR_HIP, "icp: persistent loop kernel timed out at the grid rendezvous");
+    return O3DS_OK;
+  }
+  if (h->fused) {
+    // launch j = [tail of pass j-1 in every workgroup's prologue] + pass j; launch max_iter+1 is prologue-only (one workgroup)
+    IcpFusedArgs fa{};
+    fa.pass = a;
+    fa.n_src_total = (unsigned long long)a.count;
+    fa.max_iter = params->max_iteration;
+    fa.rel_fitness = params->relative_fitness;
+    fa.rel_rmse = params->relative_rmse;
+    const int nb = std::min(pass_blocks(h, a.count), kMaxPassBlocks);
+    fa.nslots_in = std::min(nb, kFusedSlots);
+    const int total = params->max_iteration + 2;
+    int j = 0;
+    const IcpStateDev* last = h->d_state;
+    while (j < total) {
+      const int chunk = std::min(total - j, j == 0 ? 12 : 8);
+      for (int k = 0; k < chunk; ++k, ++j) {
+        const int par = j & 1;
+        fa.first = j == 0;
+        fa.state_in = last;
+        fa.state_out = (IcpStateDev*)(h->d_fused + par * kFusedStateStride);
+        fa.tickets = (unsigned int*)(h->d_fused + kFusedTicketsOff) + par * kFusedSlots;
+        fa.slots_in = (const double*)(h->d_fused + kFusedSlotsOff) + (size_t)(par ^ 1) * kFusedSlots * kRec;
+        fa.slots_out = (double*)(h->d_fused + kFusedSlotsOff) + (size_t)par * kFusedSlots * kRec;
+        fa.rows = (double*)(h->d_fused + kFusedRowsOff) + (size_t)par * kMaxPassBlocks * kRec;
+        const bool tail_only = j == total - 1;
+        if (h->session_precision == O3DS_PRECISION_F64)
+          launch_fused<P4d>(h, fa, h->session_crop, tail_only ? 1 : nb, !tail_only);
+        else
+          launch_fused<P4f>(h, fa, h->session_crop, tail_only ? 1 : nb, !tail_only);
+        last = fa.state_out;
+      }
+      HIP_TRY(hipGetLastError());
+      rc = read_state(h, out, last);
+      if (rc) return rc;
+      if (h->h_state->done) break;
+    }
     return O3DS_OK;
   }
   const int nb = pass_blocks(h, a.count);

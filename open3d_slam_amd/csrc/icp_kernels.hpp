@@ -892,6 +892,117 @@ __global__ __launch_bounds__(64) void icp_update_kernel(const double* __restrict
 }
 
 // ----------------------------------------------------------------------------------------------
+// fused form: ONE launch per pass, no separate update kernel, no grid rendezvous
+// ----------------------------------------------------------------------------------------------
+// The serial tail of pass j-1 (sum the records, convergence test, 6x6 solve, T <- U*T) is executed redundantly in the
+// PROLOGUE of every workgroup of pass j's launch -- identical inputs, identical instruction stream, identical result in
+// every workgroup -- so the dependent chain per iteration is one kernel instead of two (each launch on the chain costs
+// ~5 us of floor + ~3.3 us of boundary on MI355X).  To keep that prologue cheap the 1024 per-workgroup records of a pass
+// are first folded into kFusedSlots slot records: workgroups publish their record with write-through (sc1) stores and
+// take a ticket on their slot's counter; the last arriver of a slot sums the slot's records in ascending workgroup
+// order (sc1 loads) -- deterministic, and no workgroup ever waits for another one.  State, records, slots and tickets are
+// double-buffered by pass parity, so a launch only reads what the previous launch wrote.
+// Visibility follows the CDNA guide's G16/R1 form: sc1 payload stores -> s_waitcnt vmcnt(0) in the storing wave ->
+// relaxed agent-scope ticket; the consumer reads the payload with sc1 loads.
+constexpr int kFusedSlots = 64;
+
+struct IcpFusedArgs {
+  IcpPassArgs pass;               // pass.state / pass.partials are unused here
+  const IcpStateDev* state_in;    // written by the previous launch (or by the host for launch 0)
+  IcpStateDev* state_out;         // written by workgroup 0
+  const double* slots_in;         // [kFusedSlots][kRec] of the previous pass
+  double* slots_out;              // [kFusedSlots][kRec] of this pass
+  double* rows;                   // [gridDim.x][kRec] of this pass
+  unsigned int* tickets;          // [kFusedSlots] of this pass; zero on entry, zero again on exit
+  unsigned long long n_src_total;
+  int max_iter;
+  double rel_fitness, rel_rmse;
+  int first;                      // 1: launch 0 -- there is no previous pass to fold
+  int nslots_in;                  // min(kFusedSlots, workgroups of the previous pass's launch)
+};
+
+template <typename P4, bool kCrop, int kPassBlock, int kGroup, bool kGicp>
+__global__ __launch_bounds__(kPassBlock) void icp_fused_kernel(IcpFusedArgs fa) {
+  constexpr int kQPB = kPassBlock / kGroup;
+  constexpr int kParts = kPassBlock / 32;
+  constexpr int kPer = kFusedSlots / kParts;
+  static_assert(kFusedSlots % kParts == 0, "slot count must be a multiple of the column groups");
+  __shared__ double s_rec[kQPB * (kGicp ? kRec : kRecSlots)];
+  __shared__ double s_red[kParts][kRec];
+  __shared__ double s_out[kRec];
+  __shared__ double s_x[8], s_sc[8], s_U[16], s_T[16];
+  __shared__ IcpStateDev s_st;
+  __shared__ int s_go, s_last;
+  // ---------------- prologue: this pass's state from the previous state and the previous pass's slot records ----------------
+  const int col = threadIdx.x & 31, part = threadIdx.x >> 5;
+  double x[kPer];
+  if (!fa.first) {  // issue the slot loads before the state is looked at: one memory round trip instead of two
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int sidx = part + k * kParts;
+      x[k] = sidx < fa.nslots_in ? fa.slots_in[(size_t)sidx * kRec + col] : 0.0;
+    }
+  }
+  if (threadIdx.x == 0) s_st = *fa.state_in;
+  __syncthreads();
+  if (s_st.done) {  // loop already terminated: hand the final state on
+    if (blockIdx.x == 0 && threadIdx.x == 0) *fa.state_out = s_st;
+    return;
+  }
+  if (!fa.first) {
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) v += x[k];
+    s_red[part][col] = v;
+    __syncthreads();
+    if (threadIdx.x < kRec) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < kParts; ++k) t += s_red[k][threadIdx.x];
+      s_out[threadIdx.x] = t;
+    }
+    __syncthreads();
+    icp_step_block(s_out, &s_st, fa.n_src_total, fa.max_iter, fa.rel_fitness, fa.rel_rmse, s_x, s_sc, s_U, s_T, &s_go);
+    __syncthreads();
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *fa.state_out = s_st;
+  if (s_st.done) return;
+  // ---------------- body: correspondence + reduction pass under the new pose ----------------
+  const double v = icp_pass_body<P4, kCrop, kPassBlock, kGroup, kGicp>(fa.pass, s_st.T, blockIdx.x, gridDim.x, s_rec, s_red);
+  // ---------------- epilogue: publish the record; the last arriver of the slot folds the slot ----------------
+  if (threadIdx.x < kRec) {
+    __hip_atomic_store(fa.rows + (size_t)blockIdx.x * kRec + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  const int slot = blockIdx.x % kFusedSlots;
+  const int members = ((int)gridDim.x - slot + kFusedSlots - 1) / kFusedSlots;  // workgroups slot, slot+64, ...
+  if (threadIdx.x == 0) {
+    unsigned int* tk = fa.tickets + slot;
+    const unsigned int t = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == (unsigned int)(members - 1));
+    if (s_last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the pass after next
+  }
+  __syncthreads();
+  if (s_last && threadIdx.x < kRec) {
+    double acc = 0.0;
+    for (int m0 = 0; m0 < members; m0 += 16) {
+      double y[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int m = m0 + k;
+        y[k] = m < members ? __hip_atomic_load(fa.rows + (size_t)(slot + m * kFusedSlots) * kRec + threadIdx.x, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT)
+                           : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc += y[k];
+    }
+    fa.slots_out[(size_t)slot * kRec + threadIdx.x] = acc;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
 // persistent ICP loop: ALL passes of one registration in ONE launch
 // ----------------------------------------------------------------------------------------------
 // Measured on MI355X: every kernel launch on the dependent chain costs ~4.6-5 us of floor plus ~3.3 us of boundary, so

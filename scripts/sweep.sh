@@ -9,12 +9,14 @@ import json,sys
 d=json.loads(sys.stdin.readline()); r=d['roofline']
 print('%-28s %8.0f it/s  %7.3f ms/step  kernel %6.1f us  frac %.4f' % ('$label', d['value'], d['ms_per_step'], r['avg_launch_us'], r['frac']))"
 }
+timeout 600 python -m pytest tests/test_icp_gpu.py -m gpu -q -x --timeout 600 -k "fused or persistent" 2>&1 | tail -15 | tee $OUT/pytest_gpu.log
 {
-run "persistent" O3DS_ICP_MODE=persistent --
+run "fused" O3DS_ICP_MODE=fused --
 run "launch G4 b256 r1024" O3DS_ICP_MODE=launch O3DS_PASS_GROUP=4 O3DS_PASS_BLOCK=256 O3DS_PASS_ROWS=1024 --
-run "persistent f64" O3DS_ICP_MODE=persistent -- --precision f64
+run "fused r2048" O3DS_ICP_MODE=fused O3DS_PASS_ROWS=2048 --
+run "fused r512" O3DS_ICP_MODE=fused O3DS_PASS_ROWS=512 --
+run "fused f64" O3DS_ICP_MODE=fused -- --precision f64
 } | tee $OUT/sweep.txt
-timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 2>&1 | tail -15 | tee $OUT/pytest_gpu.log
 cd /tmp && export TMPDIR=/tmp; rm -rf $OUT/prof
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline > $OUT/rocprof_bench.json 2> $OUT/rocprof.err
+O3DS_ICP_MODE=fused timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline > $OUT/rocprof_bench.json 2> $OUT/rocprof.err
 python $R/scripts/prof_summary.py $OUT/prof/bench_results.db $OUT/rocprof_stats.txt | head -30

@@ -300,6 +300,41 @@ def test_persistent_loop_kernel_mode(oracle, small_c2, monkeypatch):
         be.close()
 
 
+def test_fused_prologue_kernel_mode(oracle, small_c2, monkeypatch):
+    """O3DS_ICP_MODE=fused: ONE launch per pass -- the previous pass's tail (record fold, convergence test, 6x6 solve, T <- U*T) runs
+    in every workgroup's prologue.  Same loop semantics (iterations / converged / early stop / empty set) as the oracle, both
+    precisions, point-to-plane and generalized, with and without a crop, and bitwise repeatable."""
+    monkeypatch.setenv("O3DS_ICP_MODE", "fused")
+    src, tgt, nrm, _ = small_c2
+    for prec, tt, tr in ((backend.PRECISION_F64, TOL_T64, TOL_R64), (backend.PRECISION_F32, TOL_T, TOL_R)):
+        be = backend.Backend(0, prec)
+        try:
+            for kw in (dict(max_iter=10, rel_fitness=0.0, rel_rmse=0.0), dict(max_iter=30), dict(max_iter=0), dict(max_iter=1)):
+                got = be.icp_point_to_plane(src, tgt, nrm, 1.0, **kw)
+                ref = oracle.icp_point_to_plane(src, tgt, nrm, 1.0, **kw)
+                assert got["iterations"] == ref["iterations"] and got["converged"] == ref["converged"], kw
+                _check(got, ref, len(src), tt, tr)
+            a = be.icp_point_to_plane(src, tgt, nrm, 1.0, max_iter=7, rel_fitness=0.0, rel_rmse=0.0)
+            b = be.icp_point_to_plane(src, tgt, nrm, 1.0, max_iter=7, rel_fitness=0.0, rel_rmse=0.0)
+            np.testing.assert_array_equal(a["transformation"], b["transformation"])
+            far = be.icp_point_to_plane(src + 1000.0, tgt, nrm, 1.0, max_iter=5)
+            assert far["fitness"] == 0.0 and far["iterations"] == 1 and far["converged"]
+            tiny = be.icp_point_to_plane(src[:37], tgt, nrm, 1.0, max_iter=5, rel_fitness=0.0, rel_rmse=0.0)  # < 64 workgroups: empty slots
+            ref = oracle.icp_point_to_plane(src[:37], tgt, nrm, 1.0, max_iter=5, rel_fitness=0.0, rel_rmse=0.0)
+            _check(tiny, ref, 37, tt, tr)
+        finally:
+            be.close()
+    be = backend.Backend(0, backend.PRECISION_F64)
+    try:
+        sn = oracle.estimate_normals(src, 3.0, 20)
+        ref = oracle.icp_generalized(src, sn, tgt, nrm, 1.0, max_iter=8, rel_fitness=0.0, rel_rmse=0.0)
+        got = be.icp_generalized(src, sn, tgt, nrm, 1.0, max_iter=8, rel_fitness=0.0, rel_rmse=0.0)
+        assert got["iterations"] == ref["iterations"]
+        _check(got, ref, len(src), TOL_T64, TOL_R64)
+    finally:
+        be.close()
+
+
 # ---- generalized ICP (SURVEY.md 8f rank 1: what the shipped Lua configs select) --------------------------------------------
 def test_gicp_matches_oracle(backend_f64, backend_f32, oracle, small_c2):
     src, tgt, nrm, T_gt = small_c2
