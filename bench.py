@@ -162,7 +162,8 @@ def main():
         elapsed = float(tmax.item())
     assert res["iterations"] == ICP_ITERS
 
-    # ---- roofline of the dominant kernel (icp_accumulate_kernel): same K steps re-run with hipEvent brackets around
+    # ---- roofline of the dominant kernel (icp_fused_kernel: one ICP pass + the previous pass's solve/update in its prologue;
+    # icp_accumulate_kernel when O3DS_ICP_MODE=launch or on the sharded step-wise path): same K steps re-run with hipEvent brackets around
     # every launch on the launch stream (kept out of the timed region above so the brackets do not perturb `value`)
     be.profile_enable(True)
     for _ in range(args.steps):
@@ -175,11 +176,12 @@ def main():
 
     # HBM traffic of the same kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes of this
     # command, corrected as MI355X_MICROARCH.md prescribes); collected by scripts/gpu_round.sh, committed under profiles/
+    pass_kernel = "icp_accumulate_kernel" if (world > 1 or os.environ.get("O3DS_ICP_MODE") == "launch") else "icp_fused_kernel"
     traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
     if os.path.exists(tpath):
         try:
-            tj = json.load(open(tpath))["icp_accumulate_kernel"]
+            tj = json.load(open(tpath))[pass_kernel]
             traffic, traffic_src = tj["hbm_bytes_per_launch_corrected"], "profiles/pmc_traffic_latest.json (rocprofv3 --pmc, separate passes)"
         except Exception:
             pass
@@ -209,7 +211,7 @@ def main():
             "pose_error_vs_truth": {"dt_m": dt_gt, "dr_rad": dr_gt, "fitness": res["fitness"], "inlier_rmse": res["inlier_rmse"]},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                         "kernel": "icp_accumulate_kernel", "launches": n_launch, "avg_launch_us": avg_kernel_s * 1e6,
+                         "kernel": pass_kernel, "launches": n_launch, "avg_launch_us": avg_kernel_s * 1e6,
                          "algorithmic_bytes_per_launch": algo_bytes},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -35,14 +35,8 @@ struct CloudRec {
   int* cell_start = nullptr;
   void* spts = nullptr;
   void* snrm = nullptr;
-  // coarse grid for far queries (cell >= max correspondence distance); built on demand
-  bool has_coarse = false;
-  GridDev coarse{};
-  int* ccell_start = nullptr;
-  void* cpts = nullptr;
 };
 
-constexpr int kMaxLoopWgs = 1024;     // >= CUs of any device this runs on
 constexpr int kMaxPassBlocks = 4096;  // capacity of the partial-record buffer (rows per pass <= pass_rows <= this)
 constexpr size_t kMaxCells = (size_t)1 << 27;  // 512 MiB of cell_start at most
 
@@ -74,16 +68,11 @@ struct o3ds_context {
   size_t arena_cur = 0, arena_off = 0;
   int arena_depth = 0;
   // launch geometry of the ICP pass kernel (tunable through O3DS_PASS_BLOCK / O3DS_PASS_ROWS for experiments)
-  // two launches per pass (default) vs ONE persistent loop kernel per registration (O3DS_ICP_MODE=persistent);
-  // measured on MI355X the grid rendezvous of the persistent form costs what the launches cost (profiles/r01_*), so the
-  // simpler form is the default
-  bool persistent = false;
   // ONE launch per pass with the previous pass's tail in its prologue (O3DS_ICP_MODE=fused), see icp_fused_kernel
-  bool fused = false;
+  bool fused = true;  // O3DS_ICP_MODE=launch selects the two-kernel form (same results bit for bit)
+  int* d_nn_cache = nullptr;  // per-query match of the previous pass (bound for the pruned search); grown on demand
+  size_t nn_cache_cap = 0;
   char* d_fused = nullptr;  // [2 states | 2x64 tickets | 2x64 slot records | 2 x kMaxPassBlocks rows]
-  int cu_count = 256;
-  double* d_rows = nullptr;        // [2][kMaxLoopWgs][kRec]
-  unsigned int* d_counter = nullptr;
   int debug_update = 0;  // O3DS_DEBUG_UPDATE: timing experiments only
   int pass_block = 256;
   int pass_group = 4;
@@ -197,13 +186,6 @@ CloudRec* find_cloud(o3ds_handle h, o3ds_cloud id) {
   return it == h->clouds.end() ? nullptr : &it->second;
 }
 
-void free_coarse(o3ds_handle h, CloudRec& c) {
-  if (c.ccell_start) (void)hipFreeAsync(c.ccell_start, h->stream);
-  if (c.cpts) (void)hipFreeAsync(c.cpts, h->stream);
-  c.ccell_start = nullptr;
-  c.cpts = nullptr;
-  c.has_coarse = false;
-}
 void free_index(o3ds_handle h, CloudRec& c) {
   if (c.cell_start) (void)hipFreeAsync(c.cell_start, h->stream);
   if (c.spts) (void)hipFreeAsync(c.spts, h->stream);
@@ -211,7 +193,6 @@ void free_index(o3ds_handle h, CloudRec& c) {
   c.cell_start = nullptr;
   c.spts = c.snrm = nullptr;
   c.has_index = false;
-  free_coarse(h, c);
 }
 void free_cloud(o3ds_handle h, CloudRec& c) {
   free_index(h, c);
@@ -320,19 +301,6 @@ int build_index_t(o3ds_handle h, CloudRec& c, double cell) {
   return O3DS_OK;
 }
 
-template <typename P4>
-int build_coarse_t(o3ds_handle h, CloudRec& c, double cell) {
-  free_coarse(h, c);
-  int rc = build_grid_t<P4>(h, (const P4*)c.pts, (const P4*)nullptr, c.n, cell, &c.coarse, &c.ccell_start, &c.cpts, nullptr);
-  if (rc) return rc;
-  c.has_coarse = true;
-  return O3DS_OK;
-}
-
-int build_coarse(o3ds_handle h, CloudRec& c, double cell) {
-  return c.precision == O3DS_PRECISION_F64 ? build_coarse_t<P4d>(h, c, cell) : build_coarse_t<P4f>(h, c, cell);
-}
-
 int build_index(o3ds_handle h, CloudRec& c, double cell) {
   return c.precision == O3DS_PRECISION_F64 ? build_index_t<P4d>(h, c, cell) : build_index_t<P4f>(h, c, cell);
 }
@@ -424,46 +392,6 @@ void launch_accumulate(o3ds_handle h, const IcpPassArgs& a, bool crop, int nbloc
   if (e1) (void)hipEventRecord(e1, h->stream);
 }
 
-// persistent loop kernel: one workgroup per CU (fewer when the source has fewer batches), 1024 threads each
-int loop_wgs(o3ds_handle h, size_t count) {
-  const size_t qpb = (size_t)kLoopBlock / 4;
-  size_t g = (count + qpb - 1) / qpb;
-  if (g < 1) g = 1;
-  if (g > (size_t)h->cu_count) g = h->cu_count;
-  return (int)g;
-}
-
-template <typename P4>
-void launch_loop(o3ds_handle h, const IcpLoopArgs& la, bool crop, int nwg) {
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (h->profiling && !la.single_pass) {
-    if (h->ev_used + 2 > h->ev.size()) {
-      hipEvent_t a0, a1;
-      if (hipEventCreate(&a0) == hipSuccess && hipEventCreate(&a1) == hipSuccess) {
-        h->ev.push_back(a0);
-        h->ev.push_back(a1);
-      }
-    }
-    if (h->ev_used + 2 <= h->ev.size()) {
-      e0 = h->ev[h->ev_used];
-      e1 = h->ev[h->ev_used + 1];
-      h->ev_used += 2;
-      (void)hipEventRecord(e0, h->stream);
-    }
-  }
-  if (h->session_method == O3DS_ICP_GENERALIZED) {
-    if (crop)
-      icp_loop_kernel<P4, true, 4, true><<<nwg, kLoopBlock, 0, h->stream>>>(la);
-    else
-      icp_loop_kernel<P4, false, 4, true><<<nwg, kLoopBlock, 0, h->stream>>>(la);
-  } else {
-    if (crop)
-      icp_loop_kernel<P4, true, 4, false><<<nwg, kLoopBlock, 0, h->stream>>>(la);
-    else
-      icp_loop_kernel<P4, false, 4, false><<<nwg, kLoopBlock, 0, h->stream>>>(la);
-  }
-  if (e1) (void)hipEventRecord(e1, h->stream);
-}
 
 // fused form: byte offsets inside d_fused
 constexpr size_t kFusedStateStride = 256;
@@ -544,13 +472,16 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
     if (rc) return rc;
   }
   const double r_corr = params->max_correspondence_distance;
-  if (tgt->grid.cell < r_corr) {  // far queries need the coarse grid: cell >= r (3x3x3 block covers the ball), not wastefully larger
-    // coarse cell = r / kCoarseH: the (2H+1)^3 block covers the ball of radius r; rebuilt when r grows past it or shrinks a lot
-    const double want = r_corr / (double)kCoarseH;
-    if (!tgt->has_coarse || tgt->coarse.cell < want || tgt->coarse.cell > 2.0 * want) {
-      rc = build_coarse(h, *tgt, want);
-      if (rc) return rc;
+  if (src->n > h->nn_cache_cap) {
+    if (h->d_nn_cache) {
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      (void)hipFree(h->d_nn_cache);
+      h->d_nn_cache = nullptr;
+      h->nn_cache_cap = 0;
     }
+    const size_t cap = std::max<size_t>(src->n + src->n / 4, 1 << 16);
+    if (hipMalloc((void**)&h->d_nn_cache, cap * sizeof(int)) != hipSuccess) return fail(h, O3DS_ERR_OOM, "icp: match cache allocation failed");
+    h->nn_cache_cap = cap;
   }
   IcpStateDev st{};
   memcpy(st.T, init, sizeof(double) * 16);
@@ -563,14 +494,12 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
   a.tpts = tgt->spts;
   a.tnrm = tgt->snrm;
   a.grid = tgt->grid;
-  a.cpts = tgt->has_coarse ? tgt->cpts : nullptr;
-  a.coarse = tgt->coarse;
-  a.opts = tgt->pts;
-  a.onrm = tgt->nrm;
   a.crop = to_dev(crop);
   const double r = params->max_correspondence_distance;
   a.r2max = r * r;
-  a.rmax_cells = tgt->grid.cell >= r ? 1 : 2;  // 1: the fine 3x3x3 block already covers the ball of radius r
+  a.kmax = std::max(1, (int)std::ceil(r / tgt->grid.cell));  // a neighbour within r is at most this many cells away
+  a.nn_cache = h->d_nn_cache;
+  a.n_tgt = (int)tgt->n;
   a.snrm = src->nrm;
   a.gicp_k = 1.0 - h->gicp_epsilon;
   a.state = h->d_state;
@@ -634,20 +563,12 @@ int o3ds_create(int device_id, o3ds_handle* out) {
     }
   }
   {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
-      h->cu_count = std::min(prop.multiProcessorCount, kMaxLoopWgs);
-    if (hipMalloc(&h->d_rows, sizeof(double) * 2 * kMaxLoopWgs * kRec) != hipSuccess || hipMalloc(&h->d_counter, sizeof(unsigned int)) != hipSuccess) {
-      o3ds_destroy(h);
-      return fail(nullptr, O3DS_ERR_OOM, "o3ds_create: scratch allocation failed");
-    }
     if (hipMalloc((void**)&h->d_fused, kFusedBytes) != hipSuccess || hipMemset(h->d_fused, 0, kFusedBytes) != hipSuccess) {
       o3ds_destroy(h);
       return fail(nullptr, O3DS_ERR_OOM, "o3ds_create: scratch allocation failed");
     }
     if (const char* e = getenv("O3DS_ICP_MODE")) {
-      h->persistent = std::string(e) == "persistent";
-      h->fused = std::string(e) == "fused";
+      h->fused = std::string(e) != "launch";
     }
   }
   if (const char* e = getenv("O3DS_DEBUG_UPDATE")) h->debug_update = atoi(e);
@@ -669,9 +590,8 @@ int o3ds_destroy(o3ds_handle h) {
   for (auto& kv : h->clouds) free_cloud(h, kv.second);
   for (auto& b : h->arena_blocks) (void)hipFreeAsync(b.first, h->stream);
   (void)hipStreamSynchronize(h->stream);
-  if (h->d_rows) (void)hipFree(h->d_rows);
-  if (h->d_counter) (void)hipFree(h->d_counter);
   if (h->d_fused) (void)hipFree(h->d_fused);
+  if (h->d_nn_cache) (void)hipFree(h->d_nn_cache);
   if (h->d_partials) (void)hipFree(h->d_partials);
   if (h->d_state) (void)hipFree(h->d_state);
   if (h->h_state) (void)hipHostFree(h->h_state);
@@ -779,7 +699,6 @@ int o3ds_cloud_build_index(o3ds_handle h, o3ds_cloud id, double max_corr_hint, d
   double cell = cell_size > 0.0 ? cell_size : max_corr_hint / 4.0;
   if (!(cell > 0.0)) return fail(h, O3DS_ERR_INVALID_ARG, "build_index: need cell_size > 0 or max_corr_hint > 0");
   int rc = build_index(h, *c, cell);
-  if (rc == O3DS_OK && max_corr_hint > 0.0 && c->grid.cell < max_corr_hint) rc = build_coarse(h, *c, max_corr_hint / (double)kCoarseH);
   return rc;
 }
 
@@ -801,20 +720,7 @@ int o3ds_icp_accumulate(o3ds_handle h, size_t first, size_t count, double* d_rec
   IcpPassArgs a = h->pass;
   a.first = first;
   a.count = count;
-  if (h->persistent) {  // same workgroup geometry and summation order as the one-shot persistent loop => identical records
-    IcpLoopArgs la{};
-    la.pass = a;
-    la.state = h->d_state;
-    la.rows = h->d_rows;
-    la.counter = h->d_counter;
-    la.single_pass = 1;
-    const int nwg = loop_wgs(h, count);
-    if (h->session_precision == O3DS_PRECISION_F64)
-      launch_loop<P4d>(h, la, h->session_crop, nwg);
-    else
-      launch_loop<P4f>(h, la, h->session_crop, nwg);
-    icp_reduce_kernel<<<1, kUpdBlock, 0, h->stream>>>(h->d_rows, nwg, h->d_state, d_record);
-  } else {
+  {
     const int nb = pass_blocks(h, count);
     if (h->session_precision == O3DS_PRECISION_F64)
       launch_accumulate<P4d>(h, a, h->session_crop, nb);
@@ -907,29 +813,6 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
   if (rc) return rc;
   h->session = false;  // the loop below owns the state
   const IcpPassArgs a = h->pass;
-  if (h->persistent) {  // all passes in one launch; the device decides termination
-    IcpLoopArgs la{};
-    la.pass = a;
-    la.state = h->d_state;
-    la.rows = h->d_rows;
-    la.counter = h->d_counter;
-    la.n_src_total = (unsigned long long)a.count;
-    la.max_iter = params->max_iteration;
-    la.rel_fitness = params->relative_fitness;
-    la.rel_rmse = params->relative_rmse;
-    la.single_pass = 0;
-    const int nwg = loop_wgs(h, a.count);
-    HIP_TRY(hipMemsetAsync(h->d_counter, 0, sizeof(unsigned int), h->stream));
-    if (h->session_precision == O3DS_PRECISION_F64)
-      launch_loop<P4d>(h, la, h->session_crop, nwg);
-    else
-      launch_loop<P4f>(h, la, h->session_crop, nwg);
-    HIP_TRY(hipGetLastError());
-    rc = read_state(h, out);
-    if (rc) return rc;
-    if (h->h_state->error) return fail(h, O3DS_ERR_HIP, "icp: persistent loop kernel timed out at the grid rendezvous");
-    return O3DS_OK;
-  }
   if (h->fused) {
     // launch j = [tail of pass j-1 in every workgroup's prologue] + pass j; launch max_iter+1 is prologue-only (one workgroup)
     IcpFusedArgs fa{};
@@ -941,6 +824,13 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
     const int nb = std::min(pass_blocks(h, a.count), kMaxPassBlocks);
     fa.nslots_in = std::min(nb, kFusedSlots);
     const int total = params->max_iteration + 2;
+    // O3DS_FUSED_TRACE=<file>: phase timestamps of every workgroup of launch 5 (development aid, see scripts/fused_trace.py)
+    const char* trace_path = getenv("O3DS_FUSED_TRACE");
+    unsigned long long* d_trace = nullptr;
+    if (trace_path && total > 6) {
+      HIP_TRY(hipMalloc((void**)&d_trace, sizeof(unsigned long long) * 16 * nb));
+      HIP_TRY(hipMemset(d_trace, 0, sizeof(unsigned long long) * 16 * nb));
+    }
     int j = 0;
     const IcpStateDev* last = h->d_state;
     while (j < total) {
@@ -955,6 +845,7 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
         fa.slots_out = (double*)(h->d_fused + kFusedSlotsOff) + (size_t)par * kFusedSlots * kRec;
         fa.rows = (double*)(h->d_fused + kFusedRowsOff) + (size_t)par * kMaxPassBlocks * kRec;
         const bool tail_only = j == total - 1;
+        fa.trace = j == 5 ? d_trace : nullptr;
         if (h->session_precision == O3DS_PRECISION_F64)
           launch_fused<P4d>(h, fa, h->session_crop, tail_only ? 1 : nb, !tail_only);
         else
@@ -965,6 +856,18 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
       rc = read_state(h, out, last);
       if (rc) return rc;
       if (h->h_state->done) break;
+    }
+    if (d_trace) {
+      std::vector<unsigned long long> t((size_t)16 * nb);
+      (void)hipMemcpy(t.data(), d_trace, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+      (void)hipFree(d_trace);
+      if (FILE* f = fopen(trace_path, "w")) {
+        for (int b = 0; b < nb; ++b) {
+          for (int k = 0; k < 16; ++k) fprintf(f, "%llu ", t[(size_t)b * 16 + k]);
+          fprintf(f, "\n");
+        }
+        fclose(f);
+      }
     }
     return O3DS_OK;
   }
@@ -1381,7 +1284,6 @@ int o3ds_map_insert_scan(o3ds_handle h, o3ds_cloud map, o3ds_cloud scan, const d
   m = find_cloud(h, map);
   if (max_corr_hint > 0.0) {
     rc = build_index(h, *m, max_corr_hint / 4.0);
-    if (rc == O3DS_OK && m->grid.cell < max_corr_hint) rc = build_coarse(h, *m, max_corr_hint / (double)kCoarseH);
   }
   return rc;
 }

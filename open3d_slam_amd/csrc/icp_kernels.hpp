@@ -178,7 +178,7 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(const P4* __restrict__ 
 template <typename P4>
 struct NNBest {
   typename Scalar<P4>::type d2;
-  int pos;  // position in the fine-sorted target arrays; -1 = none; -2 = found through the coarse grid (use idx)
+  int pos;  // position in the cell-sorted target arrays; -1 = none
   typename Scalar<P4>::index idx;
 };
 
@@ -200,7 +200,7 @@ __device__ __forceinline__ void consider(const P4& t, int p, bool valid, typenam
 }
 
 // candidates s+lane, s+lane+stride, ... of [s,e): four loads issued before the first is consumed
-template <typename P4, bool kCrop, bool kCoarse>
+template <typename P4, bool kCrop>
 __device__ __forceinline__ void scan_strided(const P4* __restrict__ tp, int s, int e, int lane, int stride, typename Scalar<P4>::type qx,
                                              typename Scalar<P4>::type qy, typename Scalar<P4>::type qz, const CropDev& crop,
                                              NNBest<P4>& best) {
@@ -211,10 +211,10 @@ __device__ __forceinline__ void scan_strided(const P4* __restrict__ tp, int s, i
     const P4 t1 = tp[v1 ? p1 : p];
     const P4 t2 = tp[v2 ? p2 : p];
     const P4 t3 = tp[v3 ? p3 : p];
-    consider<P4, kCrop>(t0, kCoarse ? -2 : p, true, qx, qy, qz, crop, best);
-    consider<P4, kCrop>(t1, kCoarse ? -2 : p1, v1, qx, qy, qz, crop, best);
-    consider<P4, kCrop>(t2, kCoarse ? -2 : p2, v2, qx, qy, qz, crop, best);
-    consider<P4, kCrop>(t3, kCoarse ? -2 : p3, v3, qx, qy, qz, crop, best);
+    consider<P4, kCrop>(t0, p, true, qx, qy, qz, crop, best);
+    consider<P4, kCrop>(t1, p1, v1, qx, qy, qz, crop, best);
+    consider<P4, kCrop>(t2, p2, v2, qx, qy, qz, crop, best);
+    consider<P4, kCrop>(t3, p3, v3, qx, qy, qz, crop, best);
   }
 }
 
@@ -232,114 +232,269 @@ __device__ __forceinline__ void lanes_min(NNBest<P4>& b) {
   }
 }
 
+// ---- bound-pruned search -------------------------------------------------------------------------
+// The cells of one (y,z) row are ONE contiguous range of the cell-sorted target, so a "segment" (row, xa..xb) costs two
+// cell_start values and is scanned with one strided loop.  What a pass costs is the number of dependent memory rounds, and
+// the rounds of a wavefront are those of its slowest query group; at the bench's map density (~100 pts/m^2, own cell
+// empty for 45 % of the queries) a full 3x3x3 scan is ~58 candidates in ~5 rows = 5-7 rounds, although the converged
+// nearest neighbour is 5 cm away.  So every search starts from an UPPER BOUND and only touches cells inside that ball:
+//   bound    the query's match of the previous pass (nn_cache, one gathered point): an ICP update moves a point by
+//            millimetres near convergence, so the ball usually covers one or two cells.  Any target point is a valid
+//            bound, so a stale entry can cost time but never correctness; pass 0 of a registration starts from r;
+//   stage 1  the 3x3x3 block, every row trimmed to the x-extent of the ball at that row (rows out of reach vanish).
+//            Proven exact if best <= cell * (1 + distance to the nearest face);
+//   stage 2  (only if not proven) the 5x5x5 shell, trimmed the same way.  Proven if best <= cell * (2 + face distance);
+//   stage 3  (nearest neighbour farther than two cells) the whole wavefront serves the query, nn_search_wave_far.
+// All cell_start values stage 1 can need (9 rows x 4) are fetched in ONE batch together with the cached match; stage 2
+// fetches its bounds in two batches.  Non-empty segments are compacted into a per-group LDS list, so a wavefront
+// iterates max-over-groups(#segments) times and not over the union of the groups' rows.  Pruned cells only hold points
+// strictly farther than the current best, so the result (nearest within r, ties to the smaller original index) is the
+// one the full scan gives.
+constexpr int kSegMax = 20;  // stage 1: <= 9 segments; stage 2: two batches of <= 13 rows, the inner ones split in two (<= 19)
+
+__device__ __forceinline__ void lds_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// exclusive prefix sum of c over the G lanes of a group; *total = group sum
+template <int G>
+__device__ __forceinline__ int group_exclusive_sum(int c, int gl, int* total) {
+  int incl = c;
+#pragma unroll
+  for (int d = 1; d < G; d <<= 1) {
+    const int o = __shfl_up(incl, d, G);
+    if (gl >= d) incl += o;
+  }
+  *total = __shfl(incl, G - 1, G);
+  return incl - c;
+}
+
+struct QueryCell {
+  float ux, uy, uz;  // position inside the own cell, [0,1]
+  float mf;          // distance to the nearest cell face, cell units
+  int ix, iy, iz;
+};
+
+// Cell coordinates come from the same f64 expression the index build uses; everything the pruning does afterwards is
+// relative to the own cell, in cell units, in f32 with margins (1e-4 cells) far above the rounding of either side.
+__device__ __forceinline__ QueryCell locate(const GridDev& g, double qx, double qy, double qz) {
+  QueryCell c;
+  const double fx = (qx - g.ox) * g.inv_cell, fy = (qy - g.oy) * g.inv_cell, fz = (qz - g.oz) * g.inv_cell;
+  const double flx = floor(fx), fly = floor(fy), flz = floor(fz);
+  const double lim = 1.0e9;  // queries far outside the grid cannot have a neighbour within r: clamp so the int conversion is safe
+  c.ix = (int)fmin(fmax(flx, -lim), lim);
+  c.iy = (int)fmin(fmax(fly, -lim), lim);
+  c.iz = (int)fmin(fmax(flz, -lim), lim);
+  c.ux = (float)(fx - flx);
+  c.uy = (float)(fy - fly);
+  c.uz = (float)(fz - flz);
+  c.mf = fminf(fminf(fminf(c.ux, 1.0f - c.ux), fminf(c.uy, 1.0f - c.uy)), fminf(c.uz, 1.0f - c.uz));
+  return c;
+}
+
+// distance (cell units) from the query to the slab of cells at offset d along one axis; u = position inside the own cell
+__device__ __forceinline__ float slab_dist(int d, float u) { return d == 0 ? 0.0f : (d < 0 ? u + (float)(-d - 1) : (1.0f - u) + (float)(d - 1)); }
+
+// x-extent [xa, xb] (cell offsets relative to the own cell) of the ball of squared radius b2 (cell units, already
+// inflated) at a row whose squared distance is rowd2; returns false if the row is out of reach
+__device__ __forceinline__ bool row_extent(float b2, float rowd2, float ux, int* xa, int* xb) {
+  const float w2 = b2 - rowd2;
+  if (!(w2 >= 0.0f)) return false;
+  const float w = sqrtf(w2) + 1e-4f;
+  *xa = (int)floorf(fmaxf(ux - w, -64.0f));
+  *xb = (int)floorf(fminf(ux + w, 64.0f));
+  return true;
+}
+
+// squared bound in cell units, inflated so that rounding never culls a needed cell
+template <typename R>
+__device__ __forceinline__ float bound_cells2(R d2, const GridDev& g) {
+  const float ic = (float)g.inv_cell;
+  return (float)d2 * ic * ic * (1.0f + 1e-4f) + 1e-6f;
+}
+
 // All G lanes of a group call this with the same query; every lane returns the same winner.
-// The 3x3x3 cell block = 9 rows of <= 3 contiguous cells = 9 contiguous ranges of the cell-sorted target.  Lane l
-// fetches the bounds of rows l, l+G, ..; they are broadcast, and each row's candidates are dealt to the lanes with
-// stride G.  *resolved tells whether the block provably contains the nearest neighbour.
 template <typename P4, bool kCrop, int G>
 __device__ __forceinline__ NNBest<P4> nn_search_group(const GridDev& g, const P4* __restrict__ tp, typename Scalar<P4>::type qx,
                                                       typename Scalar<P4>::type qy, typename Scalar<P4>::type qz,
-                                                      typename Scalar<P4>::type r2max, int rmax_cells, const CropDev& crop, int gl,
-                                                      bool* resolved) {
+                                                      typename Scalar<P4>::type r2max, int kmax, const CropDev& crop, int gl,
+                                                      int2* seg /* this group's kSegMax entries */, int prev, bool* resolved) {
   NNBest<P4> best;
   best.d2 = r2max;
   best.pos = -1;
   best.idx = -1;
-  const double fx = ((double)qx - g.ox) * g.inv_cell, fy = ((double)qy - g.oy) * g.inv_cell, fz = ((double)qz - g.oz) * g.inv_cell;
-  const double flx = floor(fx), fly = floor(fy), flz = floor(fz);
-  // queries far outside the grid cannot have a neighbour within r: clamp so the int conversion is safe
-  const double lim = 1.0e9;
-  const int ix = (int)fmin(fmax(flx, -lim), lim), iy = (int)fmin(fmax(fly, -lim), lim), iz = (int)fmin(fmax(flz, -lim), lim);
-  double mf = fmin(fx - flx, 1.0 - (fx - flx));
-  mf = fmin(mf, fmin(fy - fly, 1.0 - (fy - fly)));
-  mf = fmin(mf, fmin(fz - flz, 1.0 - (fz - flz)));
+  const QueryCell c = locate(g, (double)qx, (double)qy, (double)qz);
   const int* __restrict__ cs = g.cell_start;
-  const int x0 = max(ix - 1, 0), x1 = min(ix + 1, g.nx - 1);
-  constexpr int kOwn = (9 + G - 1) / G;  // rows whose bounds this lane fetches
-  int s_own[kOwn], e_own[kOwn];
+  // ---- one batch: the cached match and the 4 cell_start values of each of this lane's rows of the 3x3 cross-section
+  const int xlo = max(c.ix - 1, 0), xhi = min(c.ix + 1, g.nx - 1);
+  constexpr int kOwn = (9 + G - 1) / G;
+  int v[kOwn][4];
+  bool rv[kOwn];
+  const P4 tprev = tp[max(prev, 0)];
 #pragma unroll
   for (int k = 0; k < kOwn; ++k) {
     const int r = gl + k * G;
-    const int y = iy + (r % 3) - 1, z = iz + (r / 3) - 1;
-    s_own[k] = 0;
-    e_own[k] = 0;
-    if (r < 9 && x0 <= x1 && (unsigned)y < (unsigned)g.ny && (unsigned)z < (unsigned)g.nz) {
-      const int row = (z * g.ny + y) * g.nx;
-      s_own[k] = cs[row + x0];
-      e_own[k] = cs[row + x1 + 1];
-    }
-  }
+    const int y = c.iy + (r % 3) - 1, z = c.iz + (r / 3) - 1;
+    rv[k] = r < 9 && xlo <= xhi && (unsigned)y < (unsigned)g.ny && (unsigned)z < (unsigned)g.nz;
+    const int row = rv[k] ? (z * g.ny + y) * g.nx : 0;
 #pragma unroll
-  for (int r = 0; r < 9; ++r) {
-    const int sr = __shfl(s_own[r / G], r % G, G), er = __shfl(e_own[r / G], r % G, G);
-    scan_strided<P4, kCrop, false>(tp, sr, er, gl, G, qx, qy, qz, crop, best);
+    for (int j = 0; j < 4; ++j) v[k][j] = rv[k] ? cs[row + min(xlo + j, xhi + 1)] : 0;
   }
-  lanes_min<P4, G>(best);
-  // exactness bound: everything outside the 3x3x3 block is farther than cell*(1 + distance-to-nearest-face)
-  const double lb = g.cell * (1.0 + mf) * (1.0 - 1e-6);
-  *resolved = rmax_cells <= 1 || (double)best.d2 <= lb * lb;
+  consider<P4, kCrop>(tprev, prev, prev >= 0, qx, qy, qz, crop, best);
+  // ---- stage 1: the 3x3x3 block, trimmed by the bound
+  {
+    const float b2 = bound_cells2(best.d2, g);
+    int ss[kOwn], ee[kOwn];
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < kOwn; ++k) {
+      const int r = gl + k * G;
+      const float ddy = slab_dist((r % 3) - 1, c.uy), ddz = slab_dist((r / 3) - 1, c.uz);
+      int xa, xb;
+      ss[k] = ee[k] = 0;
+      if (rv[k] && row_extent(b2, ddy * ddy + ddz * ddz, c.ux, &xa, &xb)) {
+        xa = max(c.ix + xa, xlo);
+        xb = min(c.ix + xb, xhi);
+        if (xa <= xb) {
+          const int ja = xa - xlo, jb = xb - xlo + 1;
+          ss[k] = ja == 0 ? v[k][0] : (ja == 1 ? v[k][1] : v[k][2]);
+          ee[k] = jb == 1 ? v[k][1] : (jb == 2 ? v[k][2] : v[k][3]);
+        }
+      }
+      cnt += ee[k] > ss[k] ? 1 : 0;
+    }
+    int total;
+    int off = group_exclusive_sum<G>(cnt, gl, &total);
+#pragma unroll
+    for (int k = 0; k < kOwn; ++k)
+      if (ee[k] > ss[k]) seg[off++] = make_int2(ss[k], ee[k]);
+    lds_wave_sync();
+    for (int t = 0; t < total; ++t) {
+      const int2 se = seg[t];
+      scan_strided<P4, kCrop>(tp, se.x, se.y, gl, G, qx, qy, qz, crop, best);
+    }
+    lds_wave_sync();  // the list is rewritten by stage 2
+    lanes_min<P4, G>(best);
+  }
+  // proven exact if nothing outside the scanned block can be nearer: best <= (cell * (k + face distance))^2, tested with margin
+  const float ic2 = (float)(g.inv_cell * g.inv_cell) * (1.0f + 1e-4f);
+  bool proven = kmax <= 1 || (float)best.d2 * ic2 <= (1.0f + c.mf) * (1.0f + c.mf);
+  // ---- stage 2: the 5x5x5 shell, trimmed by the bound (group-uniform branch), rows in two batches
+  if (!proven) {
+    constexpr int kHalf = 13, kOwn2 = (kHalf + G - 1) / G;
+#pragma unroll 1
+    for (int r0 = 0; r0 < 25; r0 += kHalf) {
+      const float b2 = bound_cells2(best.d2, g);
+      int s2[2 * kOwn2], e2[2 * kOwn2];
+#pragma unroll
+      for (int k = 0; k < kOwn2; ++k) {
+        const int rl = gl + k * G, r = r0 + rl;
+        const int dy = (r % 5) - 2, dz = (r / 5) - 2;
+        const int y = c.iy + dy, z = c.iz + dz;
+        s2[2 * k] = e2[2 * k] = s2[2 * k + 1] = e2[2 * k + 1] = 0;
+        if (rl < kHalf && r < 25 && (unsigned)y < (unsigned)g.ny && (unsigned)z < (unsigned)g.nz) {
+          const float ddy = slab_dist(dy, c.uy), ddz = slab_dist(dz, c.uz);
+          int xa, xb;
+          if (row_extent(b2, ddy * ddy + ddz * ddz, c.ux, &xa, &xb)) {
+            xa = max(max(c.ix + xa, c.ix - 2), 0);
+            xb = min(min(c.ix + xb, c.ix + 2), g.nx - 1);
+            const bool inner = abs(dy) <= 1 && abs(dz) <= 1;  // cells ix-1..ix+1 of these rows were stage 1
+            const int row = (z * g.ny + y) * g.nx;
+            const int xb1 = inner ? min(xb, c.ix - 2) : xb;
+            if (xa <= xb1) {
+              s2[2 * k] = cs[row + xa];
+              e2[2 * k] = cs[row + xb1 + 1];
+            }
+            const int xa2 = max(xa, c.ix + 2);
+            if (inner && xa2 <= xb) {
+              s2[2 * k + 1] = cs[row + xa2];
+              e2[2 * k + 1] = cs[row + xb + 1];
+            }
+          }
+        }
+      }
+      int cnt = 0;
+#pragma unroll
+      for (int k = 0; k < 2 * kOwn2; ++k) cnt += e2[k] > s2[k] ? 1 : 0;
+      int total;
+      int off = group_exclusive_sum<G>(cnt, gl, &total);
+#pragma unroll
+      for (int k = 0; k < 2 * kOwn2; ++k)
+        if (e2[k] > s2[k]) seg[off++] = make_int2(s2[k], e2[k]);
+      lds_wave_sync();
+      for (int t = 0; t < total; ++t) {
+        const int2 se = seg[t];
+        scan_strided<P4, kCrop>(tp, se.x, se.y, gl, G, qx, qy, qz, crop, best);
+      }
+      lds_wave_sync();
+      lanes_min<P4, G>(best);
+    }
+    proven = kmax <= 2 || (float)best.d2 * ic2 <= (2.0f + c.mf) * (2.0f + c.mf);
+  }
+  *resolved = proven;
   return best;
 }
 
-// Far queries (the fine 3x3x3 block could not prove exactness): all 64 lanes of the wavefront search the COARSE grid
-// for ONE query.  The coarse cell is r/kCoarseH, so the (2H+1)^3 block around the query's coarse cell contains every
-// point within r; its (2H+1)^2 rows are one contiguous range each.  Lane j fetches the bounds of row j, trimmed to the
-// cells that can still beat the current bound; the centre row is scanned first and its result tightens the bound that
-// culls the remaining rows (at the misaligned first pass most far queries start with bound = r).
-// Winners found here carry pos = -2 (their point/normal are gathered through the original index).
-constexpr int kCoarseH = 1;
-
+// Stage 3 -- queries whose nearest neighbour (if any) is farther than two cells: all 64 lanes of the wavefront serve ONE
+// query, still on the fine grid.  The half-rows of the (2K+1)^2 cross-section (K = ceil(r / cell)) that intersect the ball
+// of the current bound and were not scanned by stages 0-2 are dealt to the lanes (one cell_start pair each), compacted
+// through the wavefront's LDS list (mbcnt rank), and the lanes regroup so that every listed half-row gets
+// 64 / pow2(#rows) (>= 4) lanes striding over it.
 template <typename P4, bool kCrop>
-__device__ __forceinline__ void nn_search_wave_coarse(const GridDev& g, const P4* __restrict__ cp, typename Scalar<P4>::type qx,
-                                                      typename Scalar<P4>::type qy, typename Scalar<P4>::type qz, const CropDev& crop,
-                                                      NNBest<P4>& best, int lane) {
-  constexpr int kSide = 2 * kCoarseH + 1, kRows = kSide * kSide, kCentre = kRows / 2;
-  static_assert(kRows <= 64, "one lane per coarse row");
-  const double dqx = (double)qx, dqy = (double)qy, dqz = (double)qz;
-  const double lim = 1.0e9;
-  const int ix = (int)fmin(fmax(floor((dqx - g.ox) * g.inv_cell), -lim), lim);
-  const int iy = (int)fmin(fmax(floor((dqy - g.oy) * g.inv_cell), -lim), lim);
-  const int iz = (int)fmin(fmax(floor((dqz - g.oz) * g.inv_cell), -lim), lim);
-  const double bound2 = (double)best.d2 * (1.0 + 1e-5);
+__device__ __forceinline__ void nn_search_wave_far(const GridDev& g, const P4* __restrict__ tp, typename Scalar<P4>::type qx,
+                                                   typename Scalar<P4>::type qy, typename Scalar<P4>::type qz, int K,
+                                                   const CropDev& crop, NNBest<P4>& best, int lane, int2* s_list /* 64 entries */) {
+  constexpr int kdone = 2;  // cells within offset 2 were scanned by the group stages
+  const QueryCell c = locate(g, (double)qx, (double)qy, (double)qz);
+  const float b2 = bound_cells2(best.d2, g);
   const int* __restrict__ cs = g.cell_start;
-  int s_own = 0, e_own = 0;
-  float rowd2_own = 3.0e38f;
-  if (lane < kRows) {
-    const int y = iy + (lane % kSide) - kCoarseH, z = iz + (lane / kSide) - kCoarseH;
-    if ((unsigned)y < (unsigned)g.ny && (unsigned)z < (unsigned)g.nz) {
-      const double ylo = g.oy + (double)y * g.cell, zlo = g.oz + (double)z * g.cell;
-      const double ddy = fmax(0.0, fmax(ylo - dqy, dqy - (ylo + g.cell))), ddz = fmax(0.0, fmax(zlo - dqz, dqz - (zlo + g.cell)));
-      const double rowd2 = ddy * ddy + ddz * ddz;
-      int x0 = 1 << 30, x1 = -(1 << 30);
-#pragma unroll
-      for (int dx = -kCoarseH; dx <= kCoarseH; ++dx) {
-        const int x = ix + dx;
-        if ((unsigned)x >= (unsigned)g.nx) continue;
-        const double xlo = g.ox + (double)x * g.cell;
-        const double ddx = fmax(0.0, fmax(xlo - dqx, dqx - (xlo + g.cell)));
-        if (rowd2 + ddx * ddx > bound2) continue;  // no point of this cell can beat the current best
-        x0 = min(x0, x);
-        x1 = max(x1, x);
-      }
-      if (x0 <= x1) {  // kept cells are contiguous: the cell distance grows monotonically away from the query
-        const int row = (z * g.ny + y) * g.nx;
-        s_own = cs[row + x0];
-        e_own = cs[row + x1 + 1];
-        rowd2_own = (float)(rowd2 * (1.0 - 1e-5));  // conservative (smaller) so that rounding never culls a needed row
+  const int side = 2 * K + 1, entries = 2 * side * side;
+  NNBest<P4> mine = best;
+  for (int base = 0; base < entries; base += 64) {  // wave-uniform
+    const int e = base + lane;
+    int s_own = 0, e_own = 0;
+    if (e < entries) {
+      const int half = e & 1, rr = e >> 1;
+      const int dy = rr % side - K, dz = rr / side - K;
+      const int y = c.iy + dy, z = c.iz + dz;
+      if ((unsigned)y < (unsigned)g.ny && (unsigned)z < (unsigned)g.nz) {
+        const float ddy = slab_dist(dy, c.uy), ddz = slab_dist(dz, c.uz);
+        int xa, xb;
+        if (row_extent(b2, ddy * ddy + ddz * ddz, c.ux, &xa, &xb)) {
+          xa = max(c.ix + xa, c.ix - K);
+          xb = min(c.ix + xb, c.ix + K);
+          const bool inner = abs(dy) <= kdone && abs(dz) <= kdone;
+          if (half == 0)
+            xb = min(xb, inner ? c.ix - kdone - 1 : c.ix);
+          else
+            xa = max(xa, inner ? c.ix + kdone + 1 : c.ix + 1);
+          xa = max(xa, 0);
+          xb = min(xb, g.nx - 1);
+          if (xa <= xb) {
+            const int row = (z * g.ny + y) * g.nx;
+            s_own = cs[row + xa];
+            e_own = cs[row + xb + 1];
+          }
+        }
       }
     }
-  }
-  NNBest<P4> mine = best;
-  // centre row first: its winner bounds everything else
-  scan_strided<P4, kCrop, true>(cp, __shfl(s_own, kCentre, 64), __shfl(e_own, kCentre, 64), lane, 64, qx, qy, qz, crop, mine);
-  lanes_min<P4, 64>(mine);
-  const float cur = (float)mine.d2 * (1.0f + 1e-5f);
-  // rows that can still hold a closer point (wave-uniform decisions)
-  unsigned long long need = __ballot(lane < kRows && lane != kCentre && e_own > s_own && rowd2_own <= cur);
-  while (need) {
-    const int r = __ffsll((long long)need) - 1;
-    need &= need - 1;
-    scan_strided<P4, kCrop, true>(cp, __shfl(s_own, r, 64), __shfl(e_own, r, 64), lane, 64, qx, qy, qz, crop, mine);
+    const unsigned long long have = __ballot(e_own > s_own);
+    if (!have) continue;
+    const int total = __popcll(have);
+    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(have >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)have, 0u));
+    if (e_own > s_own) s_list[rank] = make_int2(s_own, e_own);
+    lds_wave_sync();
+    int groups = 1;  // lanes per listed half-row: 64 / pow2ceil(min(total,16)), i.e. 64,32,16,8,4
+    while (groups < total && groups < 16) groups <<= 1;
+    const int W = 64 / groups;
+    const int grp = lane / W, gl = lane % W;
+    for (int t = grp; t < total; t += groups) {
+      const int2 se = s_list[t];
+      scan_strided<P4, kCrop>(tp, se.x, se.y, gl, W, qx, qy, qz, crop, mine);
+    }
+    lds_wave_sync();  // s_list is rewritten by the next chunk
   }
   lanes_min<P4, 64>(mine);
   best = mine;
@@ -353,14 +508,12 @@ struct IcpPassArgs {
   size_t first, count;
   const void* tpts;  // target points sorted by fine cell
   const void* tnrm;  // target normals, same order
-  GridDev grid;      // fine grid (cell = r/4 by default): ring-1 search, 8 lanes per query
-  const void* cpts;  // target points sorted by coarse cell (null when the fine cell already covers r)
-  GridDev coarse;    // coarse grid (cell >= r): far queries, 64 lanes per query
-  const void* opts;  // target points / normals in original order (winners of the coarse search)
-  const void* onrm;
+  GridDev grid;      // uniform grid, cell = r/4 by default
   CropDev crop;
   double r2max;
-  int rmax_cells;
+  int kmax;          // ceil(r / cell): how many cells away a neighbour within r can be
+  int* nn_cache;     // [n_src] position (in the sorted target) of each query's match in the previous pass of this registration
+  int n_tgt;
   const void* snrm;  // source normals (generalized ICP only), same order as src
   double gicp_k;     // 1 - epsilon of [O3D] TransformationEstimationForGeneralizedICP (covariance = I - k n n^T)
   const IcpStateDev* state;
@@ -431,7 +584,8 @@ __device__ __forceinline__ void gicp_record(double px, double py, double pz, dou
 
 template <typename P4, bool kCrop, int kPassBlock, int kGroup, bool kGicp>
 __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const double* Tm, int wg, int nwg, double* s_rec_flat,
-                                                double (*s_red)[kRec]) {
+                                                double (*s_red)[kRec], int2* s_seg /* [kPassBlock / kGroup][kSegMax] */,
+                                                bool use_cache) {
   constexpr int kQPB = kPassBlock / kGroup;
   constexpr int kStride = kGicp ? kRec : kRecSlots;  // doubles per query record
   using R = typename Scalar<P4>::type;
@@ -462,11 +616,13 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
       py = t10 * (double)s.x + t11 * (double)s.y + t12 * (double)s.z + t13;
       pz = t20 * (double)s.x + t21 * (double)s.y + t22 * (double)s.z + t23;
       bool resolved = true;
+      int prev = use_cache ? a.nn_cache[a.first + i] : -1;
+      if (prev >= a.n_tgt) prev = -1;  // never trust the cache with an address
       if (a.debug == 2) {
         nn.pos = (int)(i % 1000);
         nn.idx = nn.pos;
       } else
-        nn = nn_search_group<P4, kCrop, kGroup>(a.grid, tp, (R)px, (R)py, (R)pz, (R)a.r2max, a.rmax_cells, a.crop, gl, &resolved);
+        nn = nn_search_group<P4, kCrop, kGroup>(a.grid, tp, (R)px, (R)py, (R)pz, (R)a.r2max, a.kmax, a.crop, gl, s_seg + ql * kSegMax, prev, &resolved);
       unresolved = !resolved;
     }
     // far queries of this wavefront, one after the other, 64 lanes each (wave-uniform loop)
@@ -481,16 +637,17 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
         bq.pos = __shfl(nn.pos, sl, 64);
         bq.idx = __shfl(nn.idx, sl, 64);
         const R bx = __shfl((R)px, sl, 64), by = __shfl((R)py, sl, 64), bz = __shfl((R)pz, sl, 64);
-        nn_search_wave_coarse<P4, kCrop>(a.coarse, (const P4*)a.cpts, bx, by, bz, a.crop, bq, lane);
+        nn_search_wave_far<P4, kCrop>(a.grid, tp, bx, by, bz, a.kmax, a.crop, bq, lane, s_seg + (threadIdx.x >> 6) * (64 / kGroup) * kSegMax);
         if ((lane & ~(kGroup - 1)) == sl) nn = bq;
       }
     }
     if (gl == 0) {
+      if (i < a.count) a.nn_cache[a.first + i] = nn.pos;
       double* rec = s_rec_flat + ql * kStride;
       if (nn.pos != -1) {
         if (a.debug == 3) nn.pos = (int)(i % 1000);
-        const P4 q = nn.pos >= 0 ? tp[nn.pos] : ((const P4*)a.opts)[nn.idx];
-        const P4 nq = nn.pos >= 0 ? tn[nn.pos] : ((const P4*)a.onrm)[nn.idx];
+        const P4 q = tp[nn.pos];
+        const P4 nq = tn[nn.pos];
         const double dx = px - (double)q.x, dy = py - (double)q.y, dz = pz - (double)q.z;
         const double nx = (double)nq.x, ny = (double)nq.y, nz = (double)nq.z;
         if (kGicp) {
@@ -547,16 +704,17 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
 // accumulation: one f64 accumulator per thread instead of 30, so the kernel stays small in registers and the chip can
 // keep enough wavefronts in flight to hide the dependent-load latency of the search.
 template <typename P4, bool kCrop, int kPassBlock, int kGroup, bool kGicp>
-__global__ __launch_bounds__(kPassBlock) void icp_accumulate_kernel(IcpPassArgs a) {
+__global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4))) void icp_accumulate_kernel(IcpPassArgs a) {
   constexpr int kQPB = kPassBlock / kGroup;
   if (a.state->done) return;  // device-side loop already terminated: keep the previous partials
   __shared__ double s_rec[kQPB * (kGicp ? kRec : kRecSlots)];
   __shared__ double s_red[kPassBlock / 32][kRec];
+  __shared__ int2 s_seg[kQPB * kSegMax];
   if (a.debug == 1) {
     if (threadIdx.x < kRec) a.partials[(size_t)blockIdx.x * kRec + threadIdx.x] = a.state->T[0] * 1e-300;
     return;
   }
-  const double v = icp_pass_body<P4, kCrop, kPassBlock, kGroup, kGicp>(a, a.state->T, blockIdx.x, gridDim.x, s_rec, s_red);
+  const double v = icp_pass_body<P4, kCrop, kPassBlock, kGroup, kGicp>(a, a.state->T, blockIdx.x, gridDim.x, s_rec, s_red, s_seg, a.state->pass > 0);
   if (threadIdx.x < kRec) a.partials[(size_t)blockIdx.x * kRec + threadIdx.x] = v;
 }
 
@@ -720,6 +878,10 @@ __host__ __device__ inline void solve6_ldlt(const double* rec, double x[6]) {
 // right-hand side is L y = b; back substitution on D L^T is D z = y, L^T w = z fused), so it agrees with solve6_ldlt to
 // rounding; it keeps ~30 VGPRs instead of ~90 and has 6 dependent divisions instead of 21, which matters because this
 // tail is on the critical path of every ICP iteration (measured: 3-4 us serial, vs 1 us here).
+// broadcast of lane SRC (compile-time constant after unrolling) through v_readlane: a few cycles, where ds_bpermute (__shfl)
+// costs an LDS round trip -- the solve has ~80 of them on the critical path of every ICP iteration
+#define O3DS_BCAST(v, SRC) __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), (SRC)), __builtin_amdgcn_readlane(__double2loint(v), (SRC)))
+
 __device__ __forceinline__ void solve6_wave(const double* rec, double* x_out, int lane) {
   double a[6], b = 0.0;
 #pragma unroll
@@ -736,10 +898,10 @@ __device__ __forceinline__ void solve6_wave(const double* rec, double* x_out, in
     for (int k = 1; k < 6; ++k) diag = lane == k ? a[k] : diag;
     const double ad = fabs(diag);
     int piv = s;
-    double best = __shfl(ad, s, 64);
+    double best = O3DS_BCAST(ad, s);
 #pragma unroll
     for (int j = s + 1; j < 6; ++j) {
-      const double v = __shfl(ad, j, 64);
+      const double v = O3DS_BCAST(ad, j);
       if (v > best) {
         best = v;
         piv = j;
@@ -760,13 +922,13 @@ __device__ __forceinline__ void solve6_wave(const double* rec, double* x_out, in
         }
       }
     }
-    const double d = __shfl(a[s], s, 64);
-    const double bs = __shfl(b, s, 64);
+    const double d = O3DS_BCAST(a[s], s);
+    const double bs = O3DS_BCAST(b, s);
     const double l = a[s] / d;
     const bool below = lane > s && lane < 6;
 #pragma unroll
     for (int j = s + 1; j < 6; ++j) {
-      const double rs = __shfl(a[j], s, 64);
+      const double rs = O3DS_BCAST(a[j], s);
       if (below) a[j] -= l * rs;
     }
     if (below) b -= l * bs;
@@ -779,57 +941,67 @@ __device__ __forceinline__ void solve6_wave(const double* rec, double* x_out, in
 #pragma unroll
     for (int j = i + 1; j < 6; ++j) num -= a[j] * xs[j];
     const double xi = num / a[i];
-    xs[i] = __shfl(xi, i, 64);
+    xs[i] = O3DS_BCAST(xi, i);
     if (lane == i) mine = xi;
   }
   if (lane < 6) x_out[perm] = mine;
 }
 
 // [O3D] RegistrationICP loop body after the correspondence pass: convergence test, solve, T <- U*T.
-// Called by every thread of one workgroup (>= 64 threads) with the record in LDS.  Thread 0 runs the scalar part
-// (statistics, convergence); the solve, the trigonometry and the 4x4 products are spread over lanes because f64
-// sin/cos and divides are long dependent chains and this tail is on the critical path of every iteration.
+// Called by every thread of one workgroup (>= 64 threads) with the record in LDS; the work is done by the FIRST WAVEFRONT
+// alone, so there is no workgroup barrier inside (the caller synchronises afterwards): the scalar statistics are computed
+// redundantly by all lanes, the solve is lane-parallel, the three sincos run in three lanes and are broadcast with
+// v_readlane, the 4x4 product goes through LDS with wavefront-level ordering.  This tail is on the critical path of every
+// ICP iteration (measured inside icp_fused_kernel: 4.7 us in the barrier-and-shuffle form it replaces).
 __device__ __forceinline__ void icp_step_block(const double* s_rec, IcpStateDev* st, unsigned long long n_src_total, int max_iter,
                                                double rel_fitness, double rel_rmse, double* s_x /* [8] */, double* s_sc /* [8] */,
-                                               double* s_U /* [16] */, double* s_T /* [16] */, int* s_go) {
-  if (threadIdx.x == 0) {
-    const double count = s_rec[kRecCount];
-    const double fitness = count > 0.0 ? count / (double)n_src_total : 0.0;
-    const double rmse = count > 0.0 ? sqrt(s_rec[kRecD2] / count) : 0.0;
-    bool conv = false;
-    if (st->pass > 0) conv = fabs(st->fitness - fitness) < rel_fitness && fabs(st->rmse - rmse) < rel_rmse;
+                                               double* s_U /* [16] */, double* s_T /* [16] */, int* s_go,
+                                               unsigned long long* tr = nullptr /* 8 timestamps, development aid */) {
+  if (threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
+#define O3DS_TSTAMP(k)                                  \
+  do {                                                  \
+    if (tr && lane == 0) tr[k] = wall_clock64();        \
+  } while (0)
+  O3DS_TSTAMP(0);
+  const double count = s_rec[kRecCount];
+  const double fitness = count > 0.0 ? count / (double)n_src_total : 0.0;
+  const double rmse = count > 0.0 ? sqrt(s_rec[kRecD2] / count) : 0.0;
+  const int pass = st->pass, iterations = st->iterations;
+  const bool conv = pass > 0 && fabs(st->fitness - fitness) < rel_fitness && fabs(st->rmse - rmse) < rel_rmse;
+  const double told = lane < 16 ? st->T[lane] : 0.0;
+  lds_wave_sync();  // every lane has read the old state before lane 0 overwrites it
+  int go = 0;  // wave-uniform
+  if (!conv && iterations < max_iter) go = count > 0.0 ? 2 : 1;  // 1: empty correspondence set => identity update (x = 0)
+  if (lane == 0) {
     st->fitness = fitness;
     st->rmse = rmse;
     st->n_corr = (unsigned long long)(count + 0.5);
-    st->pass += 1;
-    int go = 0;
-    if (conv) {
-      st->converged = 1;
-      st->done = 1;
-    } else if (st->iterations >= max_iter) {
-      st->done = 1;
-    } else {
-      go = count > 0.0 ? 2 : 1;  // 1: empty correspondence set => identity update (x = 0)
-    }
+    st->pass = pass + 1;
+    if (conv) st->converged = 1;
+    if (!go) st->done = 1;
     *s_go = go;
   }
-  if (threadIdx.x < 16) s_T[threadIdx.x] = st->T[threadIdx.x];
-  if (threadIdx.x < 8) s_x[threadIdx.x] = 0.0;
-  __syncthreads();
-  if (!*s_go) return;
-  if (*s_go == 2 && threadIdx.x < 64) solve6_wave(s_rec, s_x, threadIdx.x);
-  __syncthreads();
-  if (threadIdx.x < 3) {
-    double sn, cs;
-    sincos(s_x[threadIdx.x], &sn, &cs);
-    s_sc[threadIdx.x] = sn;
-    s_sc[4 + threadIdx.x] = cs;
+  if (!go) return;
+  O3DS_TSTAMP(1);
+  if (lane < 16) s_T[lane] = told;
+  if (lane < 8) s_x[lane] = 0.0;
+  lds_wave_sync();
+  if (go == 2) {
+    solve6_wave(s_rec, s_x, lane);
+    lds_wave_sync();
   }
-  __syncthreads();
-  if (threadIdx.x < 16) {  // [O3D] TransformVector6dToMatrix4d: R = Rz(x2) Ry(x1) Rx(x0), t = x[3:6]; column-major
-    const double sa = s_sc[0], sb = s_sc[1], sg = s_sc[2], ca = s_sc[4], cb = s_sc[5], cg = s_sc[6];
+  O3DS_TSTAMP(2);
+  double sn = 0.0, cs = 1.0;
+  const double ang = s_x[lane < 6 ? lane : 0];
+  if (lane < 3) sincos(ang, &sn, &cs);
+  const double sa = O3DS_BCAST(sn, 0), sb = O3DS_BCAST(sn, 1), sg = O3DS_BCAST(sn, 2);
+  const double ca = O3DS_BCAST(cs, 0), cb = O3DS_BCAST(cs, 1), cg = O3DS_BCAST(cs, 2);
+  const double tx = O3DS_BCAST(ang, 3), ty = O3DS_BCAST(ang, 4), tz = O3DS_BCAST(ang, 5);
+  O3DS_TSTAMP(3);
+  if (lane < 16) {  // [O3D] TransformVector6dToMatrix4d: R = Rz(x2) Ry(x1) Rx(x0), t = x[3:6]; column-major
     double v;
-    switch (threadIdx.x) {
+    switch (lane) {
       case 0: v = cg * cb; break;
       case 1: v = sg * cb; break;
       case 2: v = -sb; break;
@@ -839,23 +1011,25 @@ __device__ __forceinline__ void icp_step_block(const double* s_rec, IcpStateDev*
       case 8: v = cg * sb * ca + sg * sa; break;
       case 9: v = sg * sb * ca - cg * sa; break;
       case 10: v = cb * ca; break;
-      case 12: v = s_x[3]; break;
-      case 13: v = s_x[4]; break;
-      case 14: v = s_x[5]; break;
+      case 12: v = tx; break;
+      case 13: v = ty; break;
+      case 14: v = tz; break;
       case 15: v = 1.0; break;
       default: v = 0.0; break;
     }
-    s_U[threadIdx.x] = v;
+    s_U[lane] = v;
   }
-  __syncthreads();
-  if (threadIdx.x < 16) {  // T <- U * T
-    const int c = threadIdx.x >> 2, r = threadIdx.x & 3;
-    double s = 0.0;
+  lds_wave_sync();
+  if (lane < 16) {  // T <- U * T
+    const int c = lane >> 2, r = lane & 3;
+    double acc = 0.0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) s += s_U[k * 4 + r] * s_T[c * 4 + k];
-    st->T[threadIdx.x] = s;
+    for (int k = 0; k < 4; ++k) acc += s_U[k * 4 + r] * s_T[c * 4 + k];
+    st->T[lane] = acc;
   }
-  if (threadIdx.x == 0) st->iterations += 1;
+  if (lane == 0) st->iterations = iterations + 1;
+  O3DS_TSTAMP(4);
+#undef O3DS_TSTAMP
 }
 
 // single-GPU path: reduce the partials and step, one workgroup
@@ -898,13 +1072,13 @@ __global__ __launch_bounds__(64) void icp_update_kernel(const double* __restrict
 // PROLOGUE of every workgroup of pass j's launch -- identical inputs, identical instruction stream, identical result in
 // every workgroup -- so the dependent chain per iteration is one kernel instead of two (each launch on the chain costs
 // ~5 us of floor + ~3.3 us of boundary on MI355X).  To keep that prologue cheap the 1024 per-workgroup records of a pass
-// are first folded into kFusedSlots slot records: workgroups publish their record with write-through (sc1) stores and
+// are first folded into kFusedSlots (32) slot records: workgroups publish their record with write-through (sc1) stores and
 // take a ticket on their slot's counter; the last arriver of a slot sums the slot's records in ascending workgroup
 // order (sc1 loads) -- deterministic, and no workgroup ever waits for another one.  State, records, slots and tickets are
 // double-buffered by pass parity, so a launch only reads what the previous launch wrote.
 // Visibility follows the CDNA guide's G16/R1 form: sc1 payload stores -> s_waitcnt vmcnt(0) in the storing wave ->
 // relaxed agent-scope ticket; the consumer reads the payload with sc1 loads.
-constexpr int kFusedSlots = 64;
+constexpr int kFusedSlots = 32;  // = the column groups of reduce_partials: fused, two-launch and step-wise forms sum in the SAME order
 
 struct IcpFusedArgs {
   IcpPassArgs pass;               // pass.state / pass.partials are unused here
@@ -919,29 +1093,31 @@ struct IcpFusedArgs {
   double rel_fitness, rel_rmse;
   int first;                      // 1: launch 0 -- there is no previous pass to fold
   int nslots_in;                  // min(kFusedSlots, workgroups of the previous pass's launch)
+  unsigned long long* trace;      // null, or [gridDim.x][16] phase timestamps (100 MHz wall clock) of thread 0 (O3DS_FUSED_TRACE)
 };
 
 template <typename P4, bool kCrop, int kPassBlock, int kGroup, bool kGicp>
-__global__ __launch_bounds__(kPassBlock) void icp_fused_kernel(IcpFusedArgs fa) {
+__global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4))) void icp_fused_kernel(IcpFusedArgs fa) {
   constexpr int kQPB = kPassBlock / kGroup;
   constexpr int kParts = kPassBlock / 32;
-  constexpr int kPer = kFusedSlots / kParts;
-  static_assert(kFusedSlots % kParts == 0, "slot count must be a multiple of the column groups");
+  static_assert(kFusedSlots == kUpdBlock / 32, "slot = row % 32 is the summation order of reduce_partials");
   __shared__ double s_rec[kQPB * (kGicp ? kRec : kRecSlots)];
   __shared__ double s_red[kParts][kRec];
+  __shared__ int2 s_seg[kQPB * kSegMax];
   __shared__ double s_out[kRec];
   __shared__ double s_x[8], s_sc[8], s_U[16], s_T[16];
   __shared__ IcpStateDev s_st;
   __shared__ int s_go, s_last;
+#define O3DS_STAMP(k)                                                                                  \
+  do {                                                                                                 \
+    if (fa.trace && threadIdx.x == 0) fa.trace[(size_t)blockIdx.x * 16 + (k)] = wall_clock64();         \
+  } while (0)
+  O3DS_STAMP(0);
   // ---------------- prologue: this pass's state from the previous state and the previous pass's slot records ----------------
-  const int col = threadIdx.x & 31, part = threadIdx.x >> 5;
-  double x[kPer];
-  if (!fa.first) {  // issue the slot loads before the state is looked at: one memory round trip instead of two
+  double x[kFusedSlots];
+  if (!fa.first && threadIdx.x < kRec) {  // issue the slot loads before the state is looked at: one memory round trip instead of two
 #pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-      const int sidx = part + k * kParts;
-      x[k] = sidx < fa.nslots_in ? fa.slots_in[(size_t)sidx * kRec + col] : 0.0;
-    }
+    for (int k = 0; k < kFusedSlots; ++k) x[k] = k < fa.nslots_in ? fa.slots_in[(size_t)k * kRec + threadIdx.x] : 0.0;
   }
   if (threadIdx.x == 0) s_st = *fa.state_in;
   __syncthreads();
@@ -949,32 +1125,32 @@ __global__ __launch_bounds__(kPassBlock) void icp_fused_kernel(IcpFusedArgs fa) 
     if (blockIdx.x == 0 && threadIdx.x == 0) *fa.state_out = s_st;
     return;
   }
+  O3DS_STAMP(1);
   if (!fa.first) {
-    double v = 0.0;
-#pragma unroll
-    for (int k = 0; k < kPer; ++k) v += x[k];
-    s_red[part][col] = v;
-    __syncthreads();
-    if (threadIdx.x < kRec) {
+    if (threadIdx.x < kRec) {  // slots in ascending order, like the last stage of reduce_partials
       double t = 0.0;
 #pragma unroll
-      for (int k = 0; k < kParts; ++k) t += s_red[k][threadIdx.x];
+      for (int k = 0; k < kFusedSlots; ++k) t += x[k];
       s_out[threadIdx.x] = t;
     }
     __syncthreads();
-    icp_step_block(s_out, &s_st, fa.n_src_total, fa.max_iter, fa.rel_fitness, fa.rel_rmse, s_x, s_sc, s_U, s_T, &s_go);
+    icp_step_block(s_out, &s_st, fa.n_src_total, fa.max_iter, fa.rel_fitness, fa.rel_rmse, s_x, s_sc, s_U, s_T, &s_go,
+                   fa.trace ? fa.trace + (size_t)blockIdx.x * 16 + 8 : nullptr);
     __syncthreads();
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) *fa.state_out = s_st;
   if (s_st.done) return;
+  O3DS_STAMP(2);
   // ---------------- body: correspondence + reduction pass under the new pose ----------------
-  const double v = icp_pass_body<P4, kCrop, kPassBlock, kGroup, kGicp>(fa.pass, s_st.T, blockIdx.x, gridDim.x, s_rec, s_red);
+  const double v = icp_pass_body<P4, kCrop, kPassBlock, kGroup, kGicp>(fa.pass, s_st.T, blockIdx.x, gridDim.x, s_rec, s_red, s_seg, s_st.pass > 0);
+  O3DS_STAMP(3);
   // ---------------- epilogue: publish the record; the last arriver of the slot folds the slot ----------------
   if (threadIdx.x < kRec) {
     __hip_atomic_store(fa.rows + (size_t)blockIdx.x * kRec + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
+  O3DS_STAMP(4);
   const int slot = blockIdx.x % kFusedSlots;
   const int members = ((int)gridDim.x - slot + kFusedSlots - 1) / kFusedSlots;  // workgroups slot, slot+64, ...
   if (threadIdx.x == 0) {
@@ -984,127 +1160,26 @@ __global__ __launch_bounds__(kPassBlock) void icp_fused_kernel(IcpFusedArgs fa) 
     if (s_last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the pass after next
   }
   __syncthreads();
+  O3DS_STAMP(5);
   if (s_last && threadIdx.x < kRec) {
     double acc = 0.0;
-    for (int m0 = 0; m0 < members; m0 += 16) {
-      double y[16];
+    for (int m0 = 0; m0 < members; m0 += 32) {  // ascending rows of the slot, like the first stage of reduce_partials
+      double y[32];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
+      for (int k = 0; k < 32; ++k) {
         const int m = m0 + k;
         y[k] = m < members ? __hip_atomic_load(fa.rows + (size_t)(slot + m * kFusedSlots) * kRec + threadIdx.x, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT)
                            : 0.0;
       }
 #pragma unroll
-      for (int k = 0; k < 16; ++k) acc += y[k];
+      for (int k = 0; k < 32; ++k) acc += y[k];
     }
     fa.slots_out[(size_t)slot * kRec + threadIdx.x] = acc;
   }
-}
-
-// ----------------------------------------------------------------------------------------------
-// persistent ICP loop: ALL passes of one registration in ONE launch
-// ----------------------------------------------------------------------------------------------
-// Measured on MI355X: every kernel launch on the dependent chain costs ~4.6-5 us of floor plus ~3.3 us of boundary, so
-// the two-launch-per-pass scheme spends 16 of its 30 us per iteration outside the arithmetic.  Here one workgroup per
-// CU stays resident for the whole registration.  Per pass every workgroup accumulates its share of the source,
-// publishes its 32-double record with write-through (sc1) stores, arrives on a monotonic device-scope counter, waits
-// for all arrivals, and then EVERY workgroup redundantly sums the records in the same fixed order and runs the same
-// convergence test / 6x6 solve / pose update -- identical inputs, identical instruction stream, identical T in every
-// workgroup, so no second rendezvous and no broadcast are needed.  Record rows are double-buffered by pass parity: a
-// workgroup can run at most one pass ahead of the slowest one.
-// Publication follows the release/acquire-free form of the CDNA guide (G16 R1): sc1 payload stores, s_waitcnt vmcnt(0)
-// in the storing wave, one relaxed agent-scope atomic on the counter; consumers poll the counter relaxed and read the
-// payload with sc1 (agent-scope relaxed atomic) loads.  Every spin is bounded.
-struct IcpLoopArgs {
-  IcpPassArgs pass;
-  IcpStateDev* state;
-  double* rows;          // [2][gridDim.x][kRec]
-  unsigned int* counter; // zeroed by the host before every launch
-  unsigned long long n_src_total;
-  int max_iter;
-  double rel_fitness, rel_rmse;
-  int single_pass;       // 1: publish the rows of ONE pass to rows[0] and exit (step-wise / sharded path)
-};
-
-constexpr int kLoopBlock = 1024;
-
-template <typename P4, bool kCrop, int kGroup, bool kGicp>
-__global__ __launch_bounds__(kLoopBlock) void icp_loop_kernel(IcpLoopArgs la) {
-  constexpr int kQPB = kLoopBlock / kGroup;
-  __shared__ double s_rec[kQPB * (kGicp ? kRec : kRecSlots)];
-  __shared__ double s_red[kLoopBlock / 32][kRec];
-  __shared__ double s_out[kRec];
-  __shared__ double s_x[8], s_sc[8], s_U[16], s_T[16];
-  __shared__ IcpStateDev s_st;
-  __shared__ int s_go, s_timeout;
-  const int nwg = gridDim.x, wg = blockIdx.x;
-  if (threadIdx.x == 0) {
-    s_st = *la.state;
-    s_timeout = 0;
-  }
-  __syncthreads();
-  if (s_st.done) return;
-  for (int pass = 0;; ++pass) {
-    const double v = icp_pass_body<P4, kCrop, kLoopBlock, kGroup, kGicp>(la.pass, s_st.T, wg, nwg, s_rec, s_red);
-    double* rows = la.rows + (size_t)(la.single_pass ? 0 : (pass & 1)) * nwg * kRec;
-    if (threadIdx.x < kRec) {
-      __hip_atomic_store(rows + (size_t)wg * kRec + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the storing wave drains its write-through stores
-    }
-    if (la.single_pass) return;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __hip_atomic_fetch_add(la.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned int target = (unsigned int)(pass + 1) * (unsigned int)nwg;
-      unsigned int spins = 0;
-      while (__hip_atomic_load(la.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1u << 22)) {  // ~seconds: another workgroup never arrived
-          s_timeout = 1;
-          break;
-        }
-      }
-    }
-    __syncthreads();
-    if (s_timeout) {
-      if (wg == 0 && threadIdx.x == 0) {
-        s_st.error = 1;
-        s_st.done = 1;
-        *la.state = s_st;
-      }
-      return;
-    }
-    // every workgroup sums all records in the same fixed order (32 parts x 32 columns; rows part, part+32, ..)
-    {
-      constexpr int kParts = kLoopBlock / 32;
-      const int col = threadIdx.x & 31, part = threadIdx.x >> 5;
-      double acc = 0.0;
-      for (int b0 = part; b0 < nwg; b0 += 16 * kParts) {
-        double x[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          const int b = b0 + k * kParts;
-          x[k] = b < nwg ? __hip_atomic_load(rows + (size_t)b * kRec + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-        }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) acc += x[k];
-      }
-      s_red[part][col] = acc;
-      __syncthreads();
-      if (threadIdx.x < kRec) {
-        double t = 0.0;
-#pragma unroll
-        for (int k = 0; k < kParts; ++k) t += s_red[k][threadIdx.x];
-        s_out[threadIdx.x] = t;
-      }
-      __syncthreads();
-    }
-    icp_step_block(s_out, &s_st, la.n_src_total, la.max_iter, la.rel_fitness, la.rel_rmse, s_x, s_sc, s_U, s_T, &s_go);
-    __syncthreads();
-    if (s_st.done) break;
-  }
-  if (wg == 0 && threadIdx.x == 0) *la.state = s_st;
+  O3DS_STAMP(6);
+  if (fa.trace && threadIdx.x == 0) fa.trace[(size_t)blockIdx.x * 16 + 7] = (unsigned long long)s_last;
+#undef O3DS_STAMP
 }
 
 }  // namespace o3ds

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:  # load order: torch bundles its own HIP runtime; it must be in the process before libo3ds_backend.so pulls in /opt/rocm's,
+    import torch  # noqa: F401  # otherwise a later torch.cuda init reports "No HIP GPUs are available" (seen with pytest -k on one test)
+except Exception:  # torch is plumbing for the sharded path only; the backend itself does not need it
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
