@@ -273,7 +273,7 @@ int build_grid_t(o3ds_handle h, const P4* pts, const P4* nrm, size_t n, double c
   TMP_ALLOC(counts, sizeof(int) * (ncell + 1));
   TMP_ALLOC(cursor, sizeof(int) * ncell);
   TMP_ALLOC(cell_id, sizeof(int) * n);
-  HIP_TRY(hipMallocAsync((void**)&cell_start, sizeof(int) * (ncell + 1), h->stream));
+  HIP_TRY(hipMallocAsync((void**)&cell_start, sizeof(int) * (ncell + 1 + 4), h->stream));  // +4: the search reads rows as unaligned 16-B vectors
   HIP_TRY(hipMallocAsync((void**)&spts, sizeof(P4) * n, h->stream));
   if (nrm) HIP_TRY(hipMallocAsync((void**)&snrm, sizeof(P4) * n, h->stream));
   HIP_TRY(hipMemsetAsync(counts, 0, sizeof(int) * (ncell + 1), h->stream));
@@ -736,7 +736,7 @@ int o3ds_icp_update(o3ds_handle h, const double* d_record, uint64_t n_src_total)
   CHECK_HANDLE(h);
   if (!h->session) return fail(h, O3DS_ERR_INVALID_ARG, "icp_update: no session");
   if (!d_record) return fail(h, O3DS_ERR_INVALID_ARG, "icp_update: null record");
-  icp_update_kernel<<<1, 64, 0, h->stream>>>(d_record, h->d_state, (unsigned long long)n_src_total, h->params.max_iteration,
+  icp_update_kernel<<<1, 128, 0, h->stream>>>(d_record, h->d_state, (unsigned long long)n_src_total, h->params.max_iteration,
                                              h->params.relative_fitness, h->params.relative_rmse);
   HIP_TRY(hipGetLastError());
   return O3DS_OK;
@@ -827,7 +827,8 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
     // O3DS_FUSED_TRACE=<file>: phase timestamps of every workgroup of launch 5 (development aid, see scripts/fused_trace.py)
     const char* trace_path = getenv("O3DS_FUSED_TRACE");
     unsigned long long* d_trace = nullptr;
-    if (trace_path && total > 6) {
+    const int trace_launch = getenv("O3DS_FUSED_TRACE_LAUNCH") ? atoi(getenv("O3DS_FUSED_TRACE_LAUNCH")) : 5;
+    if (trace_path && total > trace_launch + 1) {
       HIP_TRY(hipMalloc((void**)&d_trace, sizeof(unsigned long long) * 16 * nb));
       HIP_TRY(hipMemset(d_trace, 0, sizeof(unsigned long long) * 16 * nb));
     }
@@ -845,7 +846,7 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
         fa.slots_out = (double*)(h->d_fused + kFusedSlotsOff) + (size_t)par * kFusedSlots * kRec;
         fa.rows = (double*)(h->d_fused + kFusedRowsOff) + (size_t)par * kMaxPassBlocks * kRec;
         const bool tail_only = j == total - 1;
-        fa.trace = j == 5 ? d_trace : nullptr;
+        fa.trace = j == trace_launch ? d_trace : nullptr;
         if (h->session_precision == O3DS_PRECISION_F64)
           launch_fused<P4d>(h, fa, h->session_crop, tail_only ? 1 : nb, !tail_only);
         else

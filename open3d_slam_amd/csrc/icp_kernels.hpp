@@ -208,7 +208,7 @@ __device__ __forceinline__ void scan_strided(const P4* __restrict__ tp, int s, i
     const int p1 = p + stride, p2 = p + 2 * stride, p3 = p + 3 * stride;
     const bool v1 = p1 < e, v2 = p2 < e, v3 = p3 < e;
     const P4 t0 = tp[p];
-    const P4 t1 = tp[v1 ? p1 : p];
+    const P4 t1 = tp[v1 ? p1 : p];  // clamped, not predicated: branches around the loads measured slower
     const P4 t2 = tp[v2 ? p2 : p];
     const P4 t3 = tp[v3 ? p3 : p];
     consider<P4, kCrop>(t0, p, true, qx, qy, qz, crop, best);
@@ -250,7 +250,8 @@ __device__ __forceinline__ void lanes_min(NNBest<P4>& b) {
 // iterates max-over-groups(#segments) times and not over the union of the groups' rows.  Pruned cells only hold points
 // strictly farther than the current best, so the result (nearest within r, ties to the smaller original index) is the
 // one the full scan gives.
-constexpr int kSegMax = 20;  // stage 1: <= 9 segments; stage 2: two batches of <= 13 rows, the inner ones split in two (<= 19)
+constexpr int kFarList = 256;  // stage 3 list, aliased onto the wavefront's groups' lists
+constexpr int kSegMax = 32;   // stage 1: <= 9 segments; stage 2: <= 19 per batch of 13 rows; 32 so that a wavefront (>= 8 groups) owns >= kFarList entries
 
 __device__ __forceinline__ void lds_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -320,19 +321,20 @@ template <typename P4, bool kCrop, int G>
 __device__ __forceinline__ NNBest<P4> nn_search_group(const GridDev& g, const P4* __restrict__ tp, typename Scalar<P4>::type qx,
                                                       typename Scalar<P4>::type qy, typename Scalar<P4>::type qz,
                                                       typename Scalar<P4>::type r2max, int kmax, const CropDev& crop, int gl,
-                                                      int2* seg /* this group's kSegMax entries */, int prev, bool* resolved) {
+                                                      int2* seg /* this group's kSegMax entries */, int prev, const P4& tprev,
+                                                      bool* resolved) {
   NNBest<P4> best;
   best.d2 = r2max;
   best.pos = -1;
   best.idx = -1;
   const QueryCell c = locate(g, (double)qx, (double)qy, (double)qz);
   const int* __restrict__ cs = g.cell_start;
-  // ---- one batch: the cached match and the 4 cell_start values of each of this lane's rows of the 3x3 cross-section
+  // ---- one batch, issued before the bound is even computed: the 4 cell_start values of each of this lane's rows of the 3x3
+  // cross-section (fetching only the rows in reach, after the bound, measured slower: the ALU chain delays the loads)
   const int xlo = max(c.ix - 1, 0), xhi = min(c.ix + 1, g.nx - 1);
   constexpr int kOwn = (9 + G - 1) / G;
   int v[kOwn][4];
   bool rv[kOwn];
-  const P4 tprev = tp[max(prev, 0)];
 #pragma unroll
   for (int k = 0; k < kOwn; ++k) {
     const int r = gl + k * G;
@@ -445,46 +447,56 @@ __device__ __forceinline__ NNBest<P4> nn_search_group(const GridDev& g, const P4
 template <typename P4, bool kCrop>
 __device__ __forceinline__ void nn_search_wave_far(const GridDev& g, const P4* __restrict__ tp, typename Scalar<P4>::type qx,
                                                    typename Scalar<P4>::type qy, typename Scalar<P4>::type qz, int K,
-                                                   const CropDev& crop, NNBest<P4>& best, int lane, int2* s_list /* 64 entries */) {
+                                                   const CropDev& crop, NNBest<P4>& best, int lane, int2* s_list /* kFarList entries */) {
   constexpr int kdone = 2;  // cells within offset 2 were scanned by the group stages
+  constexpr int kPer = 4;   // half-rows per lane and round: all their bounds are fetched in one batch
   const QueryCell c = locate(g, (double)qx, (double)qy, (double)qz);
   const float b2 = bound_cells2(best.d2, g);
   const int* __restrict__ cs = g.cell_start;
   const int side = 2 * K + 1, entries = 2 * side * side;
   NNBest<P4> mine = best;
-  for (int base = 0; base < entries; base += 64) {  // wave-uniform
-    const int e = base + lane;
-    int s_own = 0, e_own = 0;
-    if (e < entries) {
-      const int half = e & 1, rr = e >> 1;
-      const int dy = rr % side - K, dz = rr / side - K;
-      const int y = c.iy + dy, z = c.iz + dz;
-      if ((unsigned)y < (unsigned)g.ny && (unsigned)z < (unsigned)g.nz) {
-        const float ddy = slab_dist(dy, c.uy), ddz = slab_dist(dz, c.uz);
-        int xa, xb;
-        if (row_extent(b2, ddy * ddy + ddz * ddz, c.ux, &xa, &xb)) {
-          xa = max(c.ix + xa, c.ix - K);
-          xb = min(c.ix + xb, c.ix + K);
-          const bool inner = abs(dy) <= kdone && abs(dz) <= kdone;
-          if (half == 0)
-            xb = min(xb, inner ? c.ix - kdone - 1 : c.ix);
-          else
-            xa = max(xa, inner ? c.ix + kdone + 1 : c.ix + 1);
-          xa = max(xa, 0);
-          xb = min(xb, g.nx - 1);
-          if (xa <= xb) {
-            const int row = (z * g.ny + y) * g.nx;
-            s_own = cs[row + xa];
-            e_own = cs[row + xb + 1];
+  for (int base = 0; base < entries; base += 64 * kPer) {  // wave-uniform; one round for K <= 5
+    int s_own[kPer], e_own[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int e = base + u * 64 + lane;
+      s_own[u] = e_own[u] = 0;
+      if (e < entries) {
+        const int half = e & 1, rr = e >> 1;
+        const int dy = rr % side - K, dz = rr / side - K;
+        const int y = c.iy + dy, z = c.iz + dz;
+        if ((unsigned)y < (unsigned)g.ny && (unsigned)z < (unsigned)g.nz) {
+          const float ddy = slab_dist(dy, c.uy), ddz = slab_dist(dz, c.uz);
+          int xa, xb;
+          if (row_extent(b2, ddy * ddy + ddz * ddz, c.ux, &xa, &xb)) {
+            xa = max(c.ix + xa, c.ix - K);
+            xb = min(c.ix + xb, c.ix + K);
+            const bool inner = abs(dy) <= kdone && abs(dz) <= kdone;
+            if (half == 0)
+              xb = min(xb, inner ? c.ix - kdone - 1 : c.ix);
+            else
+              xa = max(xa, inner ? c.ix + kdone + 1 : c.ix + 1);
+            xa = max(xa, 0);
+            xb = min(xb, g.nx - 1);
+            if (xa <= xb) {
+              const int row = (z * g.ny + y) * g.nx;
+              s_own[u] = cs[row + xa];
+              e_own[u] = cs[row + xb + 1];
+            }
           }
         }
       }
     }
-    const unsigned long long have = __ballot(e_own > s_own);
-    if (!have) continue;
-    const int total = __popcll(have);
-    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(have >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)have, 0u));
-    if (e_own > s_own) s_list[rank] = make_int2(s_own, e_own);
+    // compact the non-empty half-rows of all kPer slices into the wavefront's list
+    int total = 0;
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const unsigned long long have = __ballot(e_own[u] > s_own[u]);
+      const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(have >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)have, 0u));
+      if (e_own[u] > s_own[u]) s_list[total + rank] = make_int2(s_own[u], e_own[u]);
+      total += __popcll(have);
+    }
+    if (!total) continue;
     lds_wave_sync();
     int groups = 1;  // lanes per listed half-row: 64 / pow2ceil(min(total,16)), i.e. 64,32,16,8,4
     while (groups < total && groups < 16) groups <<= 1;
@@ -494,7 +506,7 @@ __device__ __forceinline__ void nn_search_wave_far(const GridDev& g, const P4* _
       const int2 se = s_list[t];
       scan_strided<P4, kCrop>(tp, se.x, se.y, gl, W, qx, qy, qz, crop, mine);
     }
-    lds_wave_sync();  // s_list is rewritten by the next chunk
+    lds_wave_sync();  // s_list is rewritten by the next round
   }
   lanes_min<P4, 64>(mine);
   best = mine;
@@ -582,12 +594,54 @@ __device__ __forceinline__ void gicp_record(double px, double py, double pz, dou
   rec[31] = 0.0;
 }
 
+// Which query slot ql of batch b serves.  Passes that have a cached match per query take CONSECUTIVE queries (neighbours on a
+// scan ring share cells and cache lines).  Pass 0 of a registration has no bound, so queries whose neighbour is far are
+// expensive and they cluster (the misalignment grows with range: measured mean 21 us per workgroup, slowest 85 us); it
+// takes queries count/16 apart, which spreads every region of the scan over all wavefronts.
+template <int kQPB, int kQPW /* queries per wavefront */>
+__device__ __forceinline__ size_t query_index(size_t count, size_t b, int ql, bool spread) {
+  if (!spread) return b * kQPB + (size_t)ql;
+  // the kQPW queries of one wavefront are count/kQPW apart (a wavefront serves its far queries one after the other, so the
+  // mix has to hold per wavefront, not just per workgroup)
+  const size_t n_off = (count + kQPW - 1) / kQPW;
+  const size_t off = b * (kQPB / kQPW) + (size_t)(ql / kQPW);
+  return off < n_off ? (size_t)(ql % kQPW) * n_off + off : count;
+}
+
+// What a query's search needs that does NOT depend on the pose: its source point, the position of its match in the previous
+// pass and that matched target point.  The fused kernel issues these loads for the workgroup's first batch BEFORE it waits
+// for the previous pass's records and runs the solve, so two of the body's dependent memory rounds overlap the serial tail.
+template <typename P4>
+struct QueryPrefetch {
+  P4 s, tprev;
+  int prev;
+};
+
+template <typename P4, int kPassBlock, int kGroup>
+__device__ __forceinline__ QueryPrefetch<P4> prefetch_query(const IcpPassArgs& a, size_t batch, bool use_cache) {
+  constexpr int kQPB = kPassBlock / kGroup;
+  QueryPrefetch<P4> q;
+  q.prev = -1;
+  q.s = P4{};
+  const size_t i = query_index<kQPB, 64 / kGroup>(a.count, batch, threadIdx.x / kGroup, !use_cache);
+  if (i < a.count) {
+    q.s = ((const P4*)a.src)[a.first + i];
+    int prev = use_cache ? a.nn_cache[a.first + i] : -1;
+    if (prev >= a.n_tgt) prev = -1;  // never trust the cache with an address
+    q.prev = prev;
+  }
+  q.tprev = ((const P4*)a.tpts)[max(q.prev, 0)];
+  return q;
+}
+
 template <typename P4, bool kCrop, int kPassBlock, int kGroup, bool kGicp>
 __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const double* Tm, int wg, int nwg, double* s_rec_flat,
                                                 double (*s_red)[kRec], int2* s_seg /* [kPassBlock / kGroup][kSegMax] */,
-                                                bool use_cache) {
+                                                bool use_cache, const QueryPrefetch<P4>& first_batch,
+                                                unsigned long long* tr = nullptr /* 3 timestamps, development aid */) {
   constexpr int kQPB = kPassBlock / kGroup;
   constexpr int kStride = kGicp ? kRec : kRecSlots;  // doubles per query record
+  static_assert((64 / kGroup) * kSegMax >= kFarList, "a wavefront's share of s_seg holds the stage-3 list");
   using R = typename Scalar<P4>::type;
   const P4* __restrict__ src = (const P4*)a.src;
   const P4* __restrict__ tp = (const P4*)a.tpts;
@@ -602,29 +656,29 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
   double acc = 0.0;
   const size_t n_batches = (a.count + kQPB - 1) / kQPB;
   for (size_t b = (size_t)wg; b < n_batches; b += (size_t)nwg) {
-    const size_t i = b * kQPB + ql;
+    const size_t i = query_index<kQPB, 64 / kGroup>(a.count, b, ql, !use_cache);
     double px = 0, py = 0, pz = 0;
     NNBest<P4> nn;
     nn.pos = -1;
     nn.idx = -1;
     nn.d2 = (R)0;
     bool unresolved = false;
+    const QueryPrefetch<P4> qp = b == (size_t)wg ? first_batch : prefetch_query<P4, kPassBlock, kGroup>(a, b, use_cache);
     if (i < a.count) {  // uniform across the lanes of a group
-      const P4 s = src[a.first + i];
+      const P4 s = qp.s;
       // [O3D] PointCloud::Transform: rigid 4x4 (bottom row 0 0 0 1 for every pose the reference passes)
       px = t00 * (double)s.x + t01 * (double)s.y + t02 * (double)s.z + t03;
       py = t10 * (double)s.x + t11 * (double)s.y + t12 * (double)s.z + t13;
       pz = t20 * (double)s.x + t21 * (double)s.y + t22 * (double)s.z + t23;
       bool resolved = true;
-      int prev = use_cache ? a.nn_cache[a.first + i] : -1;
-      if (prev >= a.n_tgt) prev = -1;  // never trust the cache with an address
       if (a.debug == 2) {
         nn.pos = (int)(i % 1000);
         nn.idx = nn.pos;
       } else
-        nn = nn_search_group<P4, kCrop, kGroup>(a.grid, tp, (R)px, (R)py, (R)pz, (R)a.r2max, a.kmax, a.crop, gl, s_seg + ql * kSegMax, prev, &resolved);
+        nn = nn_search_group<P4, kCrop, kGroup>(a.grid, tp, (R)px, (R)py, (R)pz, (R)a.r2max, a.kmax, a.crop, gl, s_seg + ql * kSegMax, qp.prev, qp.tprev, &resolved);
       unresolved = !resolved;
     }
+    if (tr && threadIdx.x == 0) tr[0] = wall_clock64();
     // far queries of this wavefront, one after the other, 64 lanes each (wave-uniform loop)
     {
       const int lane = threadIdx.x & 63;
@@ -641,6 +695,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
         if ((lane & ~(kGroup - 1)) == sl) nn = bq;
       }
     }
+    if (tr && threadIdx.x == 0) tr[1] = wall_clock64();
     if (gl == 0) {
       if (i < a.count) a.nn_cache[a.first + i] = nn.pos;
       double* rec = s_rec_flat + ql * kStride;
@@ -677,6 +732,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
       }
     }
     __syncthreads();
+    if (tr && threadIdx.x == 0) tr[2] = wall_clock64();
 #pragma unroll
     for (int qq = 0; qq < kQPB / (kPassBlock / 32); ++qq) {
       const double* rec = s_rec_flat + (qs * (kQPB / (kPassBlock / 32)) + qq) * kStride;
@@ -714,7 +770,9 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
     if (threadIdx.x < kRec) a.partials[(size_t)blockIdx.x * kRec + threadIdx.x] = a.state->T[0] * 1e-300;
     return;
   }
-  const double v = icp_pass_body<P4, kCrop, kPassBlock, kGroup, kGicp>(a, a.state->T, blockIdx.x, gridDim.x, s_rec, s_red, s_seg, a.state->pass > 0);
+  const bool use_cache = a.state->pass > 0;
+  const QueryPrefetch<P4> qp = prefetch_query<P4, kPassBlock, kGroup>(a, blockIdx.x, use_cache);
+  const double v = icp_pass_body<P4, kCrop, kPassBlock, kGroup, kGicp>(a, a.state->T, blockIdx.x, gridDim.x, s_rec, s_red, s_seg, use_cache, qp);
   if (threadIdx.x < kRec) a.partials[(size_t)blockIdx.x * kRec + threadIdx.x] = v;
 }
 
@@ -875,8 +933,8 @@ __host__ __device__ inline void solve6_ldlt(const double* rec, double x[6]) {
 // The same solve spread over the first six lanes of a wavefront: lane i owns row i of the augmented system [JtJ | -Jtr].
 // Symmetric pivoting on the largest |diagonal| (first occurrence, as Eigen's LDLT), elimination with the multipliers of
 // all remaining rows computed in parallel, back substitution.  Arithmetically this is the L D L^T solve (elimination of the
-// right-hand side is L y = b; back substitution on D L^T is D z = y, L^T w = z fused), so it agrees with solve6_ldlt to
-// rounding; it keeps ~30 VGPRs instead of ~90 and has 6 dependent divisions instead of 21, which matters because this
+// right-hand side is L y = b; back substitution on D L^T is D z = y, L^T w = z fused) with multiplications by the pivots'
+// reciprocals in place of divisions, so it agrees with solve6_ldlt to rounding; it keeps ~30 VGPRs instead of ~90 and has 6 dependent divisions instead of 21, which matters because this
 // tail is on the critical path of every ICP iteration (measured: 3-4 us serial, vs 1 us here).
 // broadcast of lane SRC (compile-time constant after unrolling) through v_readlane: a few cycles, where ds_bpermute (__shfl)
 // costs an LDS round trip -- the solve has ~80 of them on the critical path of every ICP iteration
@@ -891,6 +949,7 @@ __device__ __forceinline__ void solve6_wave(const double* rec, double* x_out, in
   }
   if (lane < 6) b = -rec[21 + lane];
   int perm = lane;
+  double rd[6];  // reciprocals of the pivots (wave-uniform): ONE division per elimination step, none in the back substitution
 #pragma unroll
   for (int s = 0; s < 6; ++s) {
     double diag = a[0];
@@ -924,7 +983,8 @@ __device__ __forceinline__ void solve6_wave(const double* rec, double* x_out, in
     }
     const double d = O3DS_BCAST(a[s], s);
     const double bs = O3DS_BCAST(b, s);
-    const double l = a[s] / d;
+    rd[s] = 1.0 / d;
+    const double l = a[s] * rd[s];
     const bool below = lane > s && lane < 6;
 #pragma unroll
     for (int j = s + 1; j < 6; ++j) {
@@ -940,7 +1000,7 @@ __device__ __forceinline__ void solve6_wave(const double* rec, double* x_out, in
     double num = b;
 #pragma unroll
     for (int j = i + 1; j < 6; ++j) num -= a[j] * xs[j];
-    const double xi = num / a[i];
+    const double xi = num * rd[i];  // a[i] of lane i is pivot i
     xs[i] = O3DS_BCAST(xi, i);
     if (lane == i) mine = xi;
   }
@@ -948,86 +1008,87 @@ __device__ __forceinline__ void solve6_wave(const double* rec, double* x_out, in
 }
 
 // [O3D] RegistrationICP loop body after the correspondence pass: convergence test, solve, T <- U*T.
-// Called by every thread of one workgroup (>= 64 threads) with the record in LDS; the work is done by the FIRST WAVEFRONT
-// alone, so there is no workgroup barrier inside (the caller synchronises afterwards): the scalar statistics are computed
-// redundantly by all lanes, the solve is lane-parallel, the three sincos run in three lanes and are broadcast with
-// v_readlane, the 4x4 product goes through LDS with wavefront-level ordering.  This tail is on the critical path of every
-// ICP iteration (measured inside icp_fused_kernel: 4.7 us in the barrier-and-shuffle form it replaces).
+// Called by every thread of one workgroup (>= 128 threads) with the record in LDS.  This tail is on the critical path of
+// every ICP iteration, so its two dependent chains run on two wavefronts (= two SIMDs) at once and meet at ONE workgroup
+// barrier: wavefront 0 solves (lane-parallel), takes the three sincos in three lanes (broadcast with v_readlane) and forms
+// U*T speculatively; wavefront 1 computes fitness / rmse and the convergence test and decides whether the update is
+// applied.  (Measured inside icp_fused_kernel: 4.7 us for the one-thread-plus-barriers form this replaces.)
 __device__ __forceinline__ void icp_step_block(const double* s_rec, IcpStateDev* st, unsigned long long n_src_total, int max_iter,
-                                               double rel_fitness, double rel_rmse, double* s_x /* [8] */, double* s_sc /* [8] */,
+                                               double rel_fitness, double rel_rmse, double* s_x /* [8] */, double* s_sc /* unused */,
                                                double* s_U /* [16] */, double* s_T /* [16] */, int* s_go,
                                                unsigned long long* tr = nullptr /* 8 timestamps, development aid */) {
-  if (threadIdx.x >= 64) return;
-  const int lane = threadIdx.x;
-#define O3DS_TSTAMP(k)                                  \
-  do {                                                  \
-    if (tr && lane == 0) tr[k] = wall_clock64();        \
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#define O3DS_TSTAMP(k)                                       \
+  do {                                                       \
+    if (tr && threadIdx.x == 0) tr[k] = wall_clock64();      \
   } while (0)
   O3DS_TSTAMP(0);
   const double count = s_rec[kRecCount];
-  const double fitness = count > 0.0 ? count / (double)n_src_total : 0.0;
-  const double rmse = count > 0.0 ? sqrt(s_rec[kRecD2] / count) : 0.0;
-  const int pass = st->pass, iterations = st->iterations;
-  const bool conv = pass > 0 && fabs(st->fitness - fitness) < rel_fitness && fabs(st->rmse - rmse) < rel_rmse;
-  const double told = lane < 16 ? st->T[lane] : 0.0;
-  lds_wave_sync();  // every lane has read the old state before lane 0 overwrites it
-  int go = 0;  // wave-uniform
-  if (!conv && iterations < max_iter) go = count > 0.0 ? 2 : 1;  // 1: empty correspondence set => identity update (x = 0)
-  if (lane == 0) {
-    st->fitness = fitness;
-    st->rmse = rmse;
-    st->n_corr = (unsigned long long)(count + 0.5);
-    st->pass = pass + 1;
-    if (conv) st->converged = 1;
-    if (!go) st->done = 1;
-    *s_go = go;
-  }
-  if (!go) return;
-  O3DS_TSTAMP(1);
-  if (lane < 16) s_T[lane] = told;
-  if (lane < 8) s_x[lane] = 0.0;
-  lds_wave_sync();
-  if (go == 2) {
-    solve6_wave(s_rec, s_x, lane);
+  double tnew = 0.0;
+  if (wv == 0) {
+    if (lane < 16) s_T[lane] = st->T[lane];
+    if (lane < 8) s_x[lane] = 0.0;
     lds_wave_sync();
-  }
-  O3DS_TSTAMP(2);
-  double sn = 0.0, cs = 1.0;
-  const double ang = s_x[lane < 6 ? lane : 0];
-  if (lane < 3) sincos(ang, &sn, &cs);
-  const double sa = O3DS_BCAST(sn, 0), sb = O3DS_BCAST(sn, 1), sg = O3DS_BCAST(sn, 2);
-  const double ca = O3DS_BCAST(cs, 0), cb = O3DS_BCAST(cs, 1), cg = O3DS_BCAST(cs, 2);
-  const double tx = O3DS_BCAST(ang, 3), ty = O3DS_BCAST(ang, 4), tz = O3DS_BCAST(ang, 5);
-  O3DS_TSTAMP(3);
-  if (lane < 16) {  // [O3D] TransformVector6dToMatrix4d: R = Rz(x2) Ry(x1) Rx(x0), t = x[3:6]; column-major
-    double v;
-    switch (lane) {
-      case 0: v = cg * cb; break;
-      case 1: v = sg * cb; break;
-      case 2: v = -sb; break;
-      case 4: v = cg * sb * sa - sg * ca; break;
-      case 5: v = sg * sb * sa + cg * ca; break;
-      case 6: v = cb * sa; break;
-      case 8: v = cg * sb * ca + sg * sa; break;
-      case 9: v = sg * sb * ca - cg * sa; break;
-      case 10: v = cb * ca; break;
-      case 12: v = tx; break;
-      case 13: v = ty; break;
-      case 14: v = tz; break;
-      case 15: v = 1.0; break;
-      default: v = 0.0; break;
+    if (count > 0.0) {  // empty correspondence set => identity update (x = 0)
+      solve6_wave(s_rec, s_x, lane);
+      lds_wave_sync();
     }
-    s_U[lane] = v;
-  }
-  lds_wave_sync();
-  if (lane < 16) {  // T <- U * T
-    const int c = lane >> 2, r = lane & 3;
-    double acc = 0.0;
+    O3DS_TSTAMP(2);
+    double sn = 0.0, cs = 1.0;
+    const double ang = s_x[lane < 6 ? lane : 0];
+    if (lane < 3) sincos(ang, &sn, &cs);
+    const double sa = O3DS_BCAST(sn, 0), sb = O3DS_BCAST(sn, 1), sg = O3DS_BCAST(sn, 2);
+    const double ca = O3DS_BCAST(cs, 0), cb = O3DS_BCAST(cs, 1), cg = O3DS_BCAST(cs, 2);
+    const double tx = O3DS_BCAST(ang, 3), ty = O3DS_BCAST(ang, 4), tz = O3DS_BCAST(ang, 5);
+    O3DS_TSTAMP(3);
+    if (lane < 16) {  // [O3D] TransformVector6dToMatrix4d: R = Rz(x2) Ry(x1) Rx(x0), t = x[3:6]; column-major
+      double v;
+      switch (lane) {
+        case 0: v = cg * cb; break;
+        case 1: v = sg * cb; break;
+        case 2: v = -sb; break;
+        case 4: v = cg * sb * sa - sg * ca; break;
+        case 5: v = sg * sb * sa + cg * ca; break;
+        case 6: v = cb * sa; break;
+        case 8: v = cg * sb * ca + sg * sa; break;
+        case 9: v = sg * sb * ca - cg * sa; break;
+        case 10: v = cb * ca; break;
+        case 12: v = tx; break;
+        case 13: v = ty; break;
+        case 14: v = tz; break;
+        case 15: v = 1.0; break;
+        default: v = 0.0; break;
+      }
+      s_U[lane] = v;
+    }
+    lds_wave_sync();
+    if (lane < 16) {  // U * T
+      const int c = lane >> 2, r = lane & 3;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc += s_U[k * 4 + r] * s_T[c * 4 + k];
-    st->T[lane] = acc;
+      for (int k = 0; k < 4; ++k) tnew += s_U[k * 4 + r] * s_T[c * 4 + k];
+    }
+  } else if (wv == 1) {
+    const double fitness = count > 0.0 ? count / (double)n_src_total : 0.0;
+    const double rmse = count > 0.0 ? sqrt(s_rec[kRecD2] / count) : 0.0;
+    const int pass = st->pass;
+    const bool conv = pass > 0 && fabs(st->fitness - fitness) < rel_fitness && fabs(st->rmse - rmse) < rel_rmse;
+    const int go = (!conv && st->iterations < max_iter) ? 1 : 0;
+    lds_wave_sync();  // every lane has read the old state before lane 0 overwrites it
+    if (lane == 0) {
+      st->fitness = fitness;
+      st->rmse = rmse;
+      st->n_corr = (unsigned long long)(count + 0.5);
+      st->pass = pass + 1;
+      if (conv) st->converged = 1;
+      if (!go) st->done = 1;
+      *s_go = go;
+    }
   }
-  if (lane == 0) st->iterations = iterations + 1;
+  __syncthreads();
+  if (wv == 0 && *s_go) {  // T <- U * T
+    if (lane < 16) st->T[lane] = tnew;
+    if (lane == 0) st->iterations += 1;
+  }
   O3DS_TSTAMP(4);
 #undef O3DS_TSTAMP
 }
@@ -1054,7 +1115,7 @@ __global__ __launch_bounds__(kUpdBlock) void icp_reduce_update_kernel(const doub
 }
 
 // sharded path: the record was all-reduced by the caller
-__global__ __launch_bounds__(64) void icp_update_kernel(const double* __restrict__ record, IcpStateDev* state, unsigned long long n_src_total,
+__global__ __launch_bounds__(128) void icp_update_kernel(const double* __restrict__ record, IcpStateDev* state, unsigned long long n_src_total,
                                                         int max_iter, double rel_fitness, double rel_rmse) {
   if (state->done) return;
   __shared__ double s_out[kRec];
@@ -1113,6 +1174,9 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
     if (fa.trace && threadIdx.x == 0) fa.trace[(size_t)blockIdx.x * 16 + (k)] = wall_clock64();         \
   } while (0)
   O3DS_STAMP(0);
+  // pose-independent loads of this workgroup's queries go out first; they land while the tail of the previous pass is computed
+  const bool use_cache = !fa.first;  // launch j evaluates pass j of the registration
+  const QueryPrefetch<P4> qp = prefetch_query<P4, kPassBlock, kGroup>(fa.pass, blockIdx.x, use_cache);
   // ---------------- prologue: this pass's state from the previous state and the previous pass's slot records ----------------
   double x[kFusedSlots];
   if (!fa.first && threadIdx.x < kRec) {  // issue the slot loads before the state is looked at: one memory round trip instead of two
@@ -1142,7 +1206,8 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   if (s_st.done) return;
   O3DS_STAMP(2);
   // ---------------- body: correspondence + reduction pass under the new pose ----------------
-  const double v = icp_pass_body<P4, kCrop, kPassBlock, kGroup, kGicp>(fa.pass, s_st.T, blockIdx.x, gridDim.x, s_rec, s_red, s_seg, s_st.pass > 0);
+  const double v = icp_pass_body<P4, kCrop, kPassBlock, kGroup, kGicp>(fa.pass, s_st.T, blockIdx.x, gridDim.x, s_rec, s_red, s_seg, use_cache, qp,
+                                                                       fa.trace ? fa.trace + (size_t)blockIdx.x * 16 + 13 : nullptr);
   O3DS_STAMP(3);
   // ---------------- epilogue: publish the record; the last arriver of the slot folds the slot ----------------
   if (threadIdx.x < kRec) {

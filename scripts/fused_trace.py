@@ -17,5 +17,8 @@ for k in range(6):
     print("  %-22s %6.2f %6.2f %6.2f" % (names[k] + "->" + names[k + 1], d[:, k].mean(), np.percentile(d[:, k], 95), d[:, k].max()))
 la = t[:, 7] == 1
 print("last arrivers: ticket->end mean %.2f max %.2f ; others %.2f" % (d[la, 5].mean(), d[la, 5].max(), d[~la, 5].mean()))
-st = (t[:, 8:13] - t[:, 1:2]) / 100.0
-print("inside the step, us after 'loaded' (mean): enter %.2f | stats %.2f | solved %.2f | sincos %.2f | done %.2f" % tuple(st.mean(0)))
+st = (t[:, [8, 10, 11, 12]] - t[:, 1:2]) / 100.0
+print("inside the step, us after 'loaded' (mean): enter %.2f | solved %.2f | sincos %.2f | done %.2f" % tuple(st.mean(0)))
+bd = (t[:, 13:16] - t[:, 2:3]) / 100.0
+print("inside the body, us after 'stepped' (mean / max): group search %.2f / %.2f | far loop %.2f / %.2f | records+barrier %.2f / %.2f | body end %.2f / %.2f" % (
+    bd[:, 0].mean(), bd[:, 0].max(), bd[:, 1].mean(), bd[:, 1].max(), bd[:, 2].mean(), bd[:, 2].max(), d[:, 2].mean(), d[:, 2].max()))
