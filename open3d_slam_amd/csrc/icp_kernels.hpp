@@ -605,7 +605,11 @@ __device__ __forceinline__ size_t query_index(size_t count, size_t b, int ql, bo
   // mix has to hold per wavefront, not just per workgroup)
   const size_t n_off = (count + kQPW - 1) / kQPW;
   const size_t off = b * (kQPB / kQPW) + (size_t)(ql / kQPW);
-  return off < n_off ? (size_t)(ql % kQPW) * n_off + off : count;
+  // ... and the offsets are scattered by a multiplicative bijection (prime multiplier, n_off < 2^40), so that the wavefronts
+  // of one workgroup do not all sample the same azimuth sector of the scan
+  constexpr unsigned long long kMul = 1000003ull;
+  const size_t offs = n_off % kMul ? (size_t)(((unsigned long long)off * kMul) % n_off) : off;
+  return off < n_off ? (size_t)(ql % kQPW) * n_off + offs : count;
 }
 
 // What a query's search needs that does NOT depend on the pose: its source point, the position of its match in the previous
@@ -634,6 +638,21 @@ __device__ __forceinline__ QueryPrefetch<P4> prefetch_query(const IcpPassArgs& a
   return q;
 }
 
+// lane 0 takes the next ticket of an LDS counter; the result is a scalar (SGPR) value in every lane
+__device__ __forceinline__ int wave_pop(int* counter, int lane) {
+  int k = 0;
+  if (lane == 0) k = atomicAdd(counter, 1);
+  return __builtin_amdgcn_readfirstlane(k);
+}
+
+// an unresolved query parked for stage 3
+template <typename P4>
+struct FarItem {
+  typename Scalar<P4>::type x, y, z, d2;
+  typename Scalar<P4>::index idx;
+  int pos;
+};
+
 template <typename P4, bool kCrop, int kPassBlock, int kGroup, bool kGicp>
 __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const double* Tm, int wg, int nwg, double* s_rec_flat,
                                                 double (*s_red)[kRec], int2* s_seg /* [kPassBlock / kGroup][kSegMax] */,
@@ -655,6 +674,11 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
   const int ta = kTermA[term], tb = kTermB[term];
   double acc = 0.0;
   const size_t n_batches = (a.count + kQPB - 1) / kQPB;
+  static_assert(sizeof(FarItem<P4>) <= kStride * sizeof(double), "a parked far query fits its record slot");
+  static_assert((2 + kQPB) * sizeof(int) <= (kPassBlock / 32) * kRec * sizeof(double), "the far list fits s_red");
+  int* s_far = (int*)&s_red[0][0];  // [0] count, [1] next, [2..] query slots; s_red itself is only used after the loop
+  if (threadIdx.x == 0) s_far[0] = s_far[1] = 0;
+  __syncthreads();
   for (size_t b = (size_t)wg; b < n_batches; b += (size_t)nwg) {
     const size_t i = query_index<kQPB, 64 / kGroup>(a.count, b, ql, !use_cache);
     double px = 0, py = 0, pz = 0;
@@ -679,20 +703,47 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
       unresolved = !resolved;
     }
     if (tr && threadIdx.x == 0) tr[0] = wall_clock64();
-    // far queries of this wavefront, one after the other, 64 lanes each (wave-uniform loop)
+    // Stage 3.  A far query takes a whole wavefront for a few memory rounds, and far queries cluster, so they are pooled per
+    // WORKGROUP: every unresolved query parks its state in its (still unused) record slot and enters a list; the four
+    // wavefronts then pop queries from the list until it is empty and write the winner back for the owner.  The search
+    // result does not depend on who computes it, and the records stay in their slots, so the sums are unchanged.
     {
-      const int lane = threadIdx.x & 63;
-      unsigned long long m = __ballot(unresolved && gl == 0);
-      while (m) {
-        const int sl = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        NNBest<P4> bq;
-        bq.d2 = __shfl(nn.d2, sl, 64);
-        bq.pos = __shfl(nn.pos, sl, 64);
-        bq.idx = __shfl(nn.idx, sl, 64);
-        const R bx = __shfl((R)px, sl, 64), by = __shfl((R)py, sl, 64), bz = __shfl((R)pz, sl, 64);
-        nn_search_wave_far<P4, kCrop>(a.grid, tp, bx, by, bz, a.kmax, a.crop, bq, lane, s_seg + (threadIdx.x >> 6) * (64 / kGroup) * kSegMax);
-        if ((lane & ~(kGroup - 1)) == sl) nn = bq;
+      FarItem<P4>* mine_item = (FarItem<P4>*)(s_rec_flat + ql * kStride);
+      if (a.debug == 16) unresolved = false;
+      if (unresolved && gl == 0) {
+        const int k = atomicAdd(&s_far[0], 1);
+        s_far[2 + k] = ql;
+        mine_item->x = (R)px;
+        mine_item->y = (R)py;
+        mine_item->z = (R)pz;
+        mine_item->d2 = nn.d2;
+        mine_item->idx = nn.idx;
+        mine_item->pos = nn.pos;
+      }
+      __syncthreads();
+      const int n_far = __builtin_amdgcn_readfirstlane(s_far[0]);
+      if (n_far > 0) {  // workgroup-uniform
+        const int lane = threadIdx.x & 63;
+        int2* list = s_seg + (threadIdx.x >> 6) * (64 / kGroup) * kSegMax;
+        for (int k = wave_pop(&s_far[1], lane); k < n_far; k = wave_pop(&s_far[1], lane)) {  // k is scalar: a uniform loop
+          FarItem<P4>* it = (FarItem<P4>*)(s_rec_flat + s_far[2 + k] * kStride);
+          NNBest<P4> bq;
+          bq.d2 = it->d2;
+          bq.pos = it->pos;
+          bq.idx = it->idx;
+          if (a.debug != 32) nn_search_wave_far<P4, kCrop>(a.grid, tp, it->x, it->y, it->z, a.kmax, a.crop, bq, lane, list);
+          // every lane holds the same winner and stores it (same address, same value): no lane-0 branch inside this loop --
+          // with one, the structurised code re-ran the body for the other lanes forever (seen on ROCm 7.2)
+          it->d2 = bq.d2;
+          it->pos = bq.pos;
+          it->idx = bq.idx;
+        }
+        __syncthreads();
+        if (unresolved && gl == 0) {
+          nn.d2 = mine_item->d2;
+          nn.pos = mine_item->pos;
+          nn.idx = mine_item->idx;
+        }
       }
     }
     if (tr && threadIdx.x == 0) tr[1] = wall_clock64();
@@ -733,6 +784,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
     }
     __syncthreads();
     if (tr && threadIdx.x == 0) tr[2] = wall_clock64();
+    if (threadIdx.x == 0) s_far[0] = s_far[1] = 0;  // everyone is past the far list (ordered before its next use by the barrier below)
 #pragma unroll
     for (int qq = 0; qq < kQPB / (kPassBlock / 32); ++qq) {
       const double* rec = s_rec_flat + (qs * (kQPB / (kPassBlock / 32)) + qq) * kStride;
