@@ -375,6 +375,142 @@ __host__ __device__ inline void fast_eigen3x3_min(const double cov[6], double ou
 // the current worst and the maximum is recomputed by one sweep over the k slots.  Only the SET of the k nearest matters
 // (the covariance is a sum), so no ordering is maintained.  Candidate loads are issued four at a time: a load-per-
 // iteration loop with a scratch-resident sorted list measured 3.8 ms for 100 k points; this form is bound by LDS sweeps.
+// normalise, orient towards the sensor origin ([O3D] NormalizeNormals + OrientNormalsTowardsCameraLocation(0,0,0)), store
+template <typename P4>
+__device__ __forceinline__ void finish_normal(const P4& q, double nv[3], P4* out) {
+  using R = typename Scalar<P4>::type;
+  double nn = sqrt(dot3(nv, nv));
+  if (nn == 0.0) {
+    nv[0] = 0, nv[1] = 0, nv[2] = 1;
+    nn = 1.0;
+  }
+  nv[0] /= nn, nv[1] /= nn, nv[2] /= nn;
+  if (isnan(nv[0])) nv[0] = 0, nv[1] = 0, nv[2] = 1;
+  // flip when n . (0 - p) < 0
+  if (nv[0] * -(double)q.x + nv[1] * -(double)q.y + nv[2] * -(double)q.z < 0.0) nv[0] = -nv[0], nv[1] = -nv[1], nv[2] = -nv[2];
+  P4 o;
+  o.x = (R)nv[0];
+  o.y = (R)nv[1];
+  o.z = (R)nv[2];
+  o.i = 0;
+  *out = o;
+}
+
+// One lane walks the rings around its point and keeps the max_nn-best SET in LDS slots sd[j * stride], sp_[j * stride]
+// (only the set matters for a covariance); nv = eigenvector of the smallest eigenvalue, not normalised.
+template <typename P4>
+__device__ __forceinline__ void normal_one_lane(const P4& q, const GridDev& g, const P4* __restrict__ sp, double radius, int max_nn,
+                                                int rmax_cells, typename Scalar<P4>::type* sd, int* sp_, int stride, double nv[3]) {
+  using R = typename Scalar<P4>::type;
+  const int* __restrict__ cs = g.cell_start;
+  const R qx = q.x, qy = q.y, qz = q.z;
+  int cnt = 0, worst_slot = 0;
+  R worst = (R)(radius * radius);  // candidates need d2 < worst
+  const double fx = ((double)qx - g.ox) * g.inv_cell, fy = ((double)qy - g.oy) * g.inv_cell, fz = ((double)qz - g.oz) * g.inv_cell;
+  const int ix = (int)floor(fx), iy = (int)floor(fy), iz = (int)floor(fz);
+  double mf = fmin(fx - floor(fx), 1.0 - (fx - floor(fx)));
+  mf = fmin(mf, fmin(fy - floor(fy), 1.0 - (fy - floor(fy))));
+  mf = fmin(mf, fmin(fz - floor(fz), 1.0 - (fz - floor(fz))));
+
+  auto offer = [&](R d2, int p, bool ok) {
+    if (ok && d2 < worst) {
+      const int slot = cnt < max_nn ? cnt : worst_slot;
+      sd[slot * stride] = d2;
+      sp_[slot * stride] = p;
+      if (cnt < max_nn) ++cnt;
+      if (cnt == max_nn) {  // list full: the bound becomes the current maximum
+        R m = sd[0];
+        int ms = 0;
+        for (int j = 1; j < max_nn; ++j) {
+          const R v = sd[j * stride];
+          if (v > m) {
+            m = v;
+            ms = j;
+          }
+        }
+        worst = m;
+        worst_slot = ms;
+      }
+    }
+  };
+  auto scan = [&](int s, int e) {
+    for (int p = s; p < e; p += 4) {
+      const bool v1 = p + 1 < e, v2 = p + 2 < e, v3 = p + 3 < e;
+      const P4 t0 = sp[p], t1 = sp[v1 ? p + 1 : p], t2 = sp[v2 ? p + 2 : p], t3 = sp[v3 ? p + 3 : p];
+      const R a0 = t0.x - qx, b0 = t0.y - qy, c0 = t0.z - qz;
+      const R a1 = t1.x - qx, b1 = t1.y - qy, c1 = t1.z - qz;
+      const R a2 = t2.x - qx, b2 = t2.y - qy, c2 = t2.z - qz;
+      const R a3 = t3.x - qx, b3 = t3.y - qy, c3 = t3.z - qz;
+      offer(a0 * a0 + b0 * b0 + c0 * c0, p, true);
+      offer(a1 * a1 + b1 * b1 + c1 * c1, p + 1, v1);
+      offer(a2 * a2 + b2 * b2 + c2 * c2, p + 2, v2);
+      offer(a3 * a3 + b3 * b3 + c3 * c3, p + 3, v3);
+    }
+  };
+
+  for (int ring = 0; ring <= rmax_cells; ++ring) {
+    if (ring >= 1) {
+      const double lb = g.cell * ((double)(ring - 1) + mf) * (1.0 - 1e-6);
+      if ((double)worst <= lb * lb) break;  // the k-th best (or r^2) already lies inside the searched block
+    }
+    for (int dz = -ring; dz <= ring; ++dz) {
+      const int z = iz + dz;
+      if ((unsigned)z >= (unsigned)g.nz) continue;
+      for (int dy = -ring; dy <= ring; ++dy) {
+        const int y = iy + dy;
+        if ((unsigned)y >= (unsigned)g.ny) continue;
+        const int row = (z * g.ny + y) * g.nx;
+        const bool shell = (dz == -ring || dz == ring || dy == -ring || dy == ring);
+        if (shell || ring == 0) {
+          const int x0 = max(ix - ring, 0), x1 = min(ix + ring, g.nx - 1);
+          if (x0 <= x1) scan(cs[row + x0], cs[row + x1 + 1]);
+        } else {  // interior rows: only the two end cells are new
+          const int xl = ix - ring, xr = ix + ring;
+          if ((unsigned)xl < (unsigned)g.nx) scan(cs[row + xl], cs[row + xl + 1]);
+          if ((unsigned)xr < (unsigned)g.nx) scan(cs[row + xr], cs[row + xr + 1]);
+        }
+      }
+    }
+  }
+  double cov[6] = {1, 0, 0, 1, 0, 1};
+  if (cnt >= 3) {
+    double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < cnt; j += 4) {  // re-gather the neighbours, four loads in flight
+      const bool v1 = j + 1 < cnt, v2 = j + 2 < cnt, v3 = j + 3 < cnt;
+      const P4 t[4] = {sp[sp_[j * stride]], sp[sp_[(v1 ? j + 1 : j) * stride]], sp[sp_[(v2 ? j + 2 : j) * stride]],
+                       sp[sp_[(v3 ? j + 3 : j) * stride]]};
+      const bool ok[4] = {true, v1, v2, v3};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!ok[u]) continue;
+        const double x = (double)t[u].x, y = (double)t[u].y, z = (double)t[u].z;
+        c[0] += x;
+        c[1] += y;
+        c[2] += z;
+        c[3] += x * x;
+        c[4] += x * y;
+        c[5] += x * z;
+        c[6] += y * y;
+        c[7] += y * z;
+        c[8] += z * z;
+      }
+    }
+    const double inv = 1.0 / (double)cnt;
+    for (int j = 0; j < 9; ++j) c[j] *= inv;
+    cov[0] = c[3] - c[0] * c[0];
+    cov[1] = c[4] - c[0] * c[1];
+    cov[2] = c[5] - c[0] * c[2];
+    cov[3] = c[6] - c[1] * c[1];
+    cov[4] = c[7] - c[1] * c[2];
+    cov[5] = c[8] - c[2] * c[2];
+  }
+  fast_eigen3x3_min(cov, nv);
+}
+
+// One thread per point.  (A variant with 8 lanes per point -- candidates of the 3x3x3 block collected into LDS stacks, the
+// max_nn-th distance found by bisection on the float bit pattern, lane-parallel cumulants -- was exact but slower on the
+// ~100 k-point voxel-filtered scans of the config-2 stream: 0.73 ms vs 0.38 ms; at that size this kernel already fills the
+// chip and the selection overhead dominates.  Removed.)
 template <typename P4, int KMAX, int BLK>
 __global__ __launch_bounds__(BLK) void normals_kernel(const P4* __restrict__ pts /* original order */, size_t n, GridDev g,
                                                       const P4* __restrict__ sp /* sorted by cell */, double radius, int max_nn, int rmax_cells,
@@ -383,126 +519,11 @@ __global__ __launch_bounds__(BLK) void normals_kernel(const P4* __restrict__ pts
   __shared__ R s_d[KMAX][BLK];
   __shared__ int s_p[KMAX][BLK];
   const int tid = threadIdx.x;
-  const int* __restrict__ cs = g.cell_start;
   for (size_t i = (size_t)blockIdx.x * BLK + tid; i < n; i += (size_t)gridDim.x * BLK) {
     const P4 q = pts[i];
-    const R qx = q.x, qy = q.y, qz = q.z;
-    int cnt = 0, worst_slot = 0;
-    R worst = (R)(radius * radius);  // candidates need d2 < worst
-    const double fx = ((double)qx - g.ox) * g.inv_cell, fy = ((double)qy - g.oy) * g.inv_cell, fz = ((double)qz - g.oz) * g.inv_cell;
-    const int ix = (int)floor(fx), iy = (int)floor(fy), iz = (int)floor(fz);
-    double mf = fmin(fx - floor(fx), 1.0 - (fx - floor(fx)));
-    mf = fmin(mf, fmin(fy - floor(fy), 1.0 - (fy - floor(fy))));
-    mf = fmin(mf, fmin(fz - floor(fz), 1.0 - (fz - floor(fz))));
-
-    auto offer = [&](R d2, int p, bool ok) {
-      if (ok && d2 < worst) {
-        const int slot = cnt < max_nn ? cnt : worst_slot;
-        s_d[slot][tid] = d2;
-        s_p[slot][tid] = p;
-        if (cnt < max_nn) ++cnt;
-        if (cnt == max_nn) {  // list full: the bound becomes the current maximum
-          R m = s_d[0][tid];
-          int ms = 0;
-          for (int j = 1; j < max_nn; ++j) {
-            const R v = s_d[j][tid];
-            if (v > m) {
-              m = v;
-              ms = j;
-            }
-          }
-          worst = m;
-          worst_slot = ms;
-        }
-      }
-    };
-    auto scan = [&](int s, int e) {
-      for (int p = s; p < e; p += 4) {
-        const bool v1 = p + 1 < e, v2 = p + 2 < e, v3 = p + 3 < e;
-        const P4 t0 = sp[p], t1 = sp[v1 ? p + 1 : p], t2 = sp[v2 ? p + 2 : p], t3 = sp[v3 ? p + 3 : p];
-        const R a0 = t0.x - qx, b0 = t0.y - qy, c0 = t0.z - qz;
-        const R a1 = t1.x - qx, b1 = t1.y - qy, c1 = t1.z - qz;
-        const R a2 = t2.x - qx, b2 = t2.y - qy, c2 = t2.z - qz;
-        const R a3 = t3.x - qx, b3 = t3.y - qy, c3 = t3.z - qz;
-        offer(a0 * a0 + b0 * b0 + c0 * c0, p, true);
-        offer(a1 * a1 + b1 * b1 + c1 * c1, p + 1, v1);
-        offer(a2 * a2 + b2 * b2 + c2 * c2, p + 2, v2);
-        offer(a3 * a3 + b3 * b3 + c3 * c3, p + 3, v3);
-      }
-    };
-
-    for (int ring = 0; ring <= rmax_cells; ++ring) {
-      if (ring >= 1) {
-        const double lb = g.cell * ((double)(ring - 1) + mf) * (1.0 - 1e-6);
-        if ((double)worst <= lb * lb) break;  // the k-th best (or r^2) already lies inside the searched block
-      }
-      for (int dz = -ring; dz <= ring; ++dz) {
-        const int z = iz + dz;
-        if ((unsigned)z >= (unsigned)g.nz) continue;
-        for (int dy = -ring; dy <= ring; ++dy) {
-          const int y = iy + dy;
-          if ((unsigned)y >= (unsigned)g.ny) continue;
-          const int row = (z * g.ny + y) * g.nx;
-          const bool shell = (dz == -ring || dz == ring || dy == -ring || dy == ring);
-          if (shell || ring == 0) {
-            const int x0 = max(ix - ring, 0), x1 = min(ix + ring, g.nx - 1);
-            if (x0 <= x1) scan(cs[row + x0], cs[row + x1 + 1]);
-          } else {  // interior rows: only the two end cells are new
-            const int xl = ix - ring, xr = ix + ring;
-            if ((unsigned)xl < (unsigned)g.nx) scan(cs[row + xl], cs[row + xl + 1]);
-            if ((unsigned)xr < (unsigned)g.nx) scan(cs[row + xr], cs[row + xr + 1]);
-          }
-        }
-      }
-    }
-    double cov[6] = {1, 0, 0, 1, 0, 1};
-    if (cnt >= 3) {
-      double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-      for (int j = 0; j < cnt; j += 4) {  // re-gather the neighbours, four loads in flight
-        const bool v1 = j + 1 < cnt, v2 = j + 2 < cnt, v3 = j + 3 < cnt;
-        const P4 t[4] = {sp[s_p[j][tid]], sp[s_p[v1 ? j + 1 : j][tid]], sp[s_p[v2 ? j + 2 : j][tid]], sp[s_p[v3 ? j + 3 : j][tid]]};
-        const bool ok[4] = {true, v1, v2, v3};
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (!ok[u]) continue;
-          const double x = (double)t[u].x, y = (double)t[u].y, z = (double)t[u].z;
-          c[0] += x;
-          c[1] += y;
-          c[2] += z;
-          c[3] += x * x;
-          c[4] += x * y;
-          c[5] += x * z;
-          c[6] += y * y;
-          c[7] += y * z;
-          c[8] += z * z;
-        }
-      }
-      const double inv = 1.0 / (double)cnt;
-      for (int j = 0; j < 9; ++j) c[j] *= inv;
-      cov[0] = c[3] - c[0] * c[0];
-      cov[1] = c[4] - c[0] * c[1];
-      cov[2] = c[5] - c[0] * c[2];
-      cov[3] = c[6] - c[1] * c[1];
-      cov[4] = c[7] - c[1] * c[2];
-      cov[5] = c[8] - c[2] * c[2];
-    }
     double nv[3];
-    fast_eigen3x3_min(cov, nv);
-    double nn = sqrt(dot3(nv, nv));
-    if (nn == 0.0) {
-      nv[0] = 0, nv[1] = 0, nv[2] = 1;
-      nn = 1.0;
-    }
-    nv[0] /= nn, nv[1] /= nn, nv[2] /= nn;
-    if (isnan(nv[0])) nv[0] = 0, nv[1] = 0, nv[2] = 1;
-    // OrientNormalsTowardsCameraLocation(0,0,0): flip when n . (0 - p) < 0
-    if (nv[0] * -(double)qx + nv[1] * -(double)qy + nv[2] * -(double)qz < 0.0) nv[0] = -nv[0], nv[1] = -nv[1], nv[2] = -nv[2];
-    P4 o;
-    o.x = (R)nv[0];
-    o.y = (R)nv[1];
-    o.z = (R)nv[2];
-    o.i = 0;
-    out_nrm[i] = o;
+    normal_one_lane<P4>(q, g, sp, radius, max_nn, rmax_cells, &s_d[0][tid], &s_p[0][tid], BLK, nv);
+    finish_normal<P4>(q, nv, &out_nrm[i]);
   }
 }
 
