@@ -52,7 +52,8 @@ struct o3ds_context {
   // ICP scratch
   double* d_partials = nullptr;     // [kMaxPassBlocks][kRec]
   IcpStateDev* d_state = nullptr;
-  IcpStateDev* h_state = nullptr;   // pinned
+  IcpStateDev* h_state = nullptr;   // pinned, mapped
+  IcpStateDev* h_state_dev = nullptr;  // the device's view of h_state
   // step-wise ICP session
   bool session = false;
   IcpPassArgs pass{};
@@ -462,7 +463,7 @@ int validate_icp(o3ds_handle h, const CloudRec* src, const CloudRec* tgt, const 
 }
 
 int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3ds_crop* crop, const double init[16],
-                  const o3ds_icp_params* params) {
+                  const o3ds_icp_params* params, bool upload_state = true) {
   CloudRec* src = find_cloud(h, source);
   CloudRec* tgt = find_cloud(h, target);
   int rc = validate_icp(h, src, tgt, params);
@@ -486,7 +487,7 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
   IcpStateDev st{};
   memcpy(st.T, init, sizeof(double) * 16);
   *h->h_state = st;
-  HIP_TRY(hipMemcpyAsync(h->d_state, h->h_state, sizeof(IcpStateDev), hipMemcpyHostToDevice, h->stream));
+  if (upload_state) HIP_TRY(hipMemcpyAsync(h->d_state, h->h_state, sizeof(IcpStateDev), hipMemcpyHostToDevice, h->stream));
   IcpPassArgs a{};
   a.src = src->pts;
   a.first = 0;
@@ -513,6 +514,17 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
   h->session_crop = crop && crop->kind != O3DS_CROP_NONE;
   h->session_method = params->method;
   return O3DS_OK;
+}
+
+void copy_result(o3ds_handle h, o3ds_icp_result* out) {
+  if (out) {
+    memcpy(out->transformation, h->h_state->T, sizeof(double) * 16);
+    out->fitness = h->h_state->fitness;
+    out->inlier_rmse = h->h_state->rmse;
+    out->iterations = h->h_state->iterations;
+    out->converged = h->h_state->converged;
+    out->n_corr = h->h_state->n_corr;
+  }
 }
 
 int read_state(o3ds_handle h, o3ds_icp_result* out, const IcpStateDev* d_from = nullptr) {
@@ -551,7 +563,8 @@ int o3ds_create(int device_id, o3ds_handle* out) {
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
       (h->own_stream = h->stream, false) || hipMalloc(&h->d_partials, sizeof(double) * kRec * kMaxPassBlocks) != hipSuccess ||
       hipMalloc(&h->d_state, sizeof(IcpStateDev)) != hipSuccess ||
-      hipHostMalloc((void**)&h->h_state, sizeof(IcpStateDev), hipHostMallocDefault) != hipSuccess) {
+      hipHostMalloc((void**)&h->h_state, sizeof(IcpStateDev), hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&h->h_state_dev, h->h_state, 0) != hipSuccess) {
     delete h;
     return fail(nullptr, O3DS_ERR_HIP, "o3ds_create: device initialisation failed");
   }
@@ -809,7 +822,7 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
   CHECK_HANDLE(h);
   ArenaScope arena_scope(h);
   if (!init || !out) return fail(h, O3DS_ERR_INVALID_ARG, "icp: null init/out");
-  int rc = begin_session(h, source, target, target_crop, init, params);
+  int rc = begin_session(h, source, target, target_crop, init, params, !h->fused);
   if (rc) return rc;
   h->session = false;  // the loop below owns the state
   const IcpPassArgs a = h->pass;
@@ -823,6 +836,7 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
     fa.rel_rmse = params->relative_rmse;
     const int nb = std::min(pass_blocks(h, a.count), kMaxPassBlocks);
     fa.nslots_in = std::min(nb, kFusedSlots);
+    fa.init = *h->h_state;
     const int total = params->max_iteration + 2;
     // O3DS_FUSED_TRACE=<file>: phase timestamps of every workgroup of launch 5 (development aid, see scripts/fused_trace.py)
     const char* trace_path = getenv("O3DS_FUSED_TRACE");
@@ -847,6 +861,7 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
         fa.rows = (double*)(h->d_fused + kFusedRowsOff) + (size_t)par * kMaxPassBlocks * kRec;
         const bool tail_only = j == total - 1;
         fa.trace = j == trace_launch ? d_trace : nullptr;
+        fa.state_host = k == chunk - 1 ? h->h_state_dev : nullptr;  // the launch the host waits for also writes the pinned copy
         if (h->session_precision == O3DS_PRECISION_F64)
           launch_fused<P4d>(h, fa, h->session_crop, tail_only ? 1 : nb, !tail_only);
         else
@@ -854,8 +869,8 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
         last = fa.state_out;
       }
       HIP_TRY(hipGetLastError());
-      rc = read_state(h, out, last);
-      if (rc) return rc;
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      copy_result(h, out);
       if (h->h_state->done) break;
     }
     if (d_trace) {

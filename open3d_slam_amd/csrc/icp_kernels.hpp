@@ -601,15 +601,22 @@ __device__ __forceinline__ void gicp_record(double px, double py, double pz, dou
 template <int kQPB, int kQPW /* queries per wavefront */>
 __device__ __forceinline__ size_t query_index(size_t count, size_t b, int ql, bool spread) {
   if (!spread) return b * kQPB + (size_t)ql;
-  // the kQPW queries of one wavefront are count/kQPW apart (a wavefront serves its far queries one after the other, so the
-  // mix has to hold per wavefront, not just per workgroup)
-  const size_t n_off = (count + kQPW - 1) / kQPW;
+  // a wavefront takes kQPW / kRun runs of kRun consecutive queries, the runs count/(kQPW/kRun) apart (a wavefront serves its
+  // far queries one after the other, so the mix has to hold per wavefront, not just per workgroup; runs keep some of the
+  // cache-line sharing of neighbouring queries) ...
+  constexpr int kRun = 1, kRuns = kQPW / kRun;  // runs of 4 consecutive queries: body mean 37 -> 32 us but slowest workgroup 55 -> 58 us
+  static_assert(kQPW % kRun == 0, "runs tile a wavefront");
+  const size_t n_run = (count + kRun - 1) / kRun;         // runs in the scan
+  const size_t n_off = (n_run + kRuns - 1) / kRuns;       // offsets: one per wavefront slot
   const size_t off = b * (kQPB / kQPW) + (size_t)(ql / kQPW);
-  // ... and the offsets are scattered by a multiplicative bijection (prime multiplier, n_off < 2^40), so that the wavefronts
-  // of one workgroup do not all sample the same azimuth sector of the scan
+  // ... and the offsets are scattered by a multiplicative bijection (prime multiplier), so that the wavefronts of one
+  // workgroup do not all sample the same azimuth sector of the scan
   constexpr unsigned long long kMul = 1000003ull;
   const size_t offs = n_off % kMul ? (size_t)(((unsigned long long)off * kMul) % n_off) : off;
-  return off < n_off ? (size_t)(ql % kQPW) * n_off + offs : count;
+  const int qw = ql % kQPW;
+  const size_t run = (size_t)(qw / kRun) * n_off + offs;
+  const size_t i = run * kRun + (size_t)(qw % kRun);
+  return off < n_off && run < n_run && i < count ? i : count;
 }
 
 // What a query's search needs that does NOT depend on the pose: its source point, the position of its match in the previous
@@ -1195,8 +1202,11 @@ constexpr int kFusedSlots = 32;  // = the column groups of reduce_partials: fuse
 
 struct IcpFusedArgs {
   IcpPassArgs pass;               // pass.state / pass.partials are unused here
-  const IcpStateDev* state_in;    // written by the previous launch (or by the host for launch 0)
+  const IcpStateDev* state_in;    // written by the previous launch (unused by launch 0: its state is `init`)
   IcpStateDev* state_out;         // written by workgroup 0
+  IcpStateDev* state_host;        // null, or pinned host memory that also receives the state (last launch of a chunk): the host
+                                  // then only has to wait for the stream, there is no copy on the chain
+  IcpStateDev init;               // launch 0: the initial state travels in the kernel arguments (no host-to-device copy)
   const double* slots_in;         // [kFusedSlots][kRec] of the previous pass
   double* slots_out;              // [kFusedSlots][kRec] of this pass
   double* rows;                   // [gridDim.x][kRec] of this pass
@@ -1235,10 +1245,13 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
 #pragma unroll
     for (int k = 0; k < kFusedSlots; ++k) x[k] = k < fa.nslots_in ? fa.slots_in[(size_t)k * kRec + threadIdx.x] : 0.0;
   }
-  if (threadIdx.x == 0) s_st = *fa.state_in;
+  if (threadIdx.x == 0) s_st = fa.first ? fa.init : *fa.state_in;
   __syncthreads();
   if (s_st.done) {  // loop already terminated: hand the final state on
-    if (blockIdx.x == 0 && threadIdx.x == 0) *fa.state_out = s_st;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      *fa.state_out = s_st;
+      if (fa.state_host) *fa.state_host = s_st;
+    }
     return;
   }
   O3DS_STAMP(1);
@@ -1254,7 +1267,10 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
                    fa.trace ? fa.trace + (size_t)blockIdx.x * 16 + 8 : nullptr);
     __syncthreads();
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) *fa.state_out = s_st;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *fa.state_out = s_st;
+    if (fa.state_host) *fa.state_host = s_st;
+  }
   if (s_st.done) return;
   O3DS_STAMP(2);
   // ---------------- body: correspondence + reduction pass under the new pose ----------------
