@@ -70,6 +70,10 @@ struct o3ds_context {
   int arena_depth = 0;
   // launch geometry of the ICP pass kernel (tunable through O3DS_PASS_BLOCK / O3DS_PASS_ROWS for experiments)
   // ONE launch per pass with the previous pass's tail in its prologue (O3DS_ICP_MODE=fused), see icp_fused_kernel
+  // normal estimation: remembered cell size of the ring search (see normals_t)
+  double nrm_cell = 0.0, nrm_radius = 0.0;
+  int nrm_knn = 0, nrm_age = 0;
+  size_t nrm_n = 0;
   bool fused = true;  // O3DS_ICP_MODE=launch selects the two-kernel form (same results bit for bit)
   int* d_nn_cache = nullptr;  // per-query match of the previous pass (bound for the pruned search); grown on demand
   size_t nn_cache_cap = 0;
@@ -1055,36 +1059,56 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
 template <typename P4>
 int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn) {
   if (c.n == 0) return O3DS_OK;
-  // pilot grid at radius/8 to measure the surface density, then pick the cell so that the max_nn-th neighbour
-  // typically lies inside the first 3x3x3 ring: avg points per occupied cell ~ max_nn / pi
+  // The cell size only steers the cost of the (exact) ring search: aim at max_nn / pi points per occupied cell, so that the
+  // max_nn-th neighbour typically lies inside the first 3x3x3 ring.  The density comes from a pilot grid at radius/8 -- one
+  // extra index build, one counting kernel and a host round trip -- so it is remembered per (radius, max_nn) and reused
+  // while the cloud size stays within 25 % (a lidar stream: every scan), refreshed every 32 calls.
   CloudRec tmp;
   tmp.n = c.n;
   tmp.precision = c.precision;
   tmp.pts = c.pts;  // borrowed
-  int rc = build_index_t<P4>(h, tmp, radius / 8.0);
-  if (rc) {
-    tmp.pts = nullptr;
-    free_index(h, tmp);
-    return rc;
-  }
-  const size_t ncell = (size_t)tmp.grid.nx * tmp.grid.ny * tmp.grid.nz;
-  unsigned long long* d_cnt = nullptr;
-  TMP_ALLOC(d_cnt, sizeof(unsigned long long));
-  HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), h->stream));
-  count_occupied_kernel<<<grid_for(ncell), kBlock, 0, h->stream>>>(tmp.cell_start, ncell, d_cnt);
-  unsigned long long occ = 0;
-  HIP_TRY(hipMemcpyAsync(&occ, d_cnt, sizeof(occ), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  const double avg = occ ? (double)c.n / (double)occ : 1.0;
-  double cell = tmp.grid.cell * std::sqrt(std::max(1.0, (double)max_nn) / (3.14159265358979 * avg));
-  cell = std::min(std::max(cell, radius / 64.0), radius);
-  if (std::fabs(cell - tmp.grid.cell) > 0.05 * tmp.grid.cell) {
-    rc = build_index_t<P4>(h, tmp, cell);
+  int rc = O3DS_OK;
+  const bool reuse = h->nrm_cell > 0.0 && h->nrm_radius == radius && h->nrm_knn == max_nn && h->nrm_age < 32 &&
+                     (double)c.n <= 1.25 * (double)h->nrm_n && (double)c.n >= 0.75 * (double)h->nrm_n;
+  if (reuse) {
+    ++h->nrm_age;
+    rc = build_index_t<P4>(h, tmp, h->nrm_cell);
     if (rc) {
       tmp.pts = nullptr;
       free_index(h, tmp);
       return rc;
     }
+  } else {
+    rc = build_index_t<P4>(h, tmp, radius / 8.0);
+    if (rc) {
+      tmp.pts = nullptr;
+      free_index(h, tmp);
+      return rc;
+    }
+    const size_t ncell = (size_t)tmp.grid.nx * tmp.grid.ny * tmp.grid.nz;
+    unsigned long long* d_cnt = nullptr;
+    TMP_ALLOC(d_cnt, sizeof(unsigned long long));
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), h->stream));
+    count_occupied_kernel<<<grid_for(ncell), kBlock, 0, h->stream>>>(tmp.cell_start, ncell, d_cnt);
+    unsigned long long occ = 0;
+    HIP_TRY(hipMemcpyAsync(&occ, d_cnt, sizeof(occ), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const double avg = occ ? (double)c.n / (double)occ : 1.0;
+    double cell = tmp.grid.cell * std::sqrt(std::max(1.0, (double)max_nn) / (3.14159265358979 * avg));
+    cell = std::min(std::max(cell, radius / 64.0), radius);
+    if (std::fabs(cell - tmp.grid.cell) > 0.05 * tmp.grid.cell) {
+      rc = build_index_t<P4>(h, tmp, cell);
+      if (rc) {
+        tmp.pts = nullptr;
+        free_index(h, tmp);
+        return rc;
+      }
+    }
+    h->nrm_cell = tmp.grid.cell;
+    h->nrm_radius = radius;
+    h->nrm_knn = max_nn;
+    h->nrm_n = c.n;
+    h->nrm_age = 0;
   }
   if (!c.nrm) HIP_TRY(hipMallocAsync((void**)&c.nrm, sizeof(P4) * c.n, h->stream));
   const int rmax = std::max(1, (int)std::ceil(radius / tmp.grid.cell));
@@ -1094,7 +1118,10 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn) {
     const P4* p_sp = (const P4*)tmp.spts;
     P4* p_out = (P4*)c.nrm;
     constexpr bool kWide = sizeof(P4) > 16;  // f64 storage: half the threads per workgroup for the same LDS footprint
-    if (max_nn <= 32) {
+    if (max_nn <= 20) {  // the shipped configs' knn: 40 KB of LDS per workgroup instead of 64 KB, twice the wavefronts per SIMD
+      constexpr int B = kWide ? 128 : 256;
+      normals_kernel<P4, 20, B><<<(int)std::min<size_t>((c.n + B - 1) / B, 8192), B, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, p_out);
+    } else if (max_nn <= 32) {
       constexpr int B = kWide ? 128 : 256;
       normals_kernel<P4, 32, B><<<(int)std::min<size_t>((c.n + B - 1) / B, 8192), B, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, p_out);
     } else {
