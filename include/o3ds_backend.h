@@ -74,7 +74,7 @@ typedef struct {
 } o3ds_icp_result;
 
 /* CloudRegistrationType (Parameters.hpp:37-42) as far as the HIP backend implements it */
-typedef enum { O3DS_ICP_POINT_TO_PLANE = 0, O3DS_ICP_GENERALIZED = 1 } o3ds_icp_method;
+typedef enum { O3DS_ICP_POINT_TO_PLANE = 0, O3DS_ICP_GENERALIZED = 1, O3DS_ICP_POINT_TO_POINT = 2 } o3ds_icp_method;
 
 /* IcpParameters (Parameters.hpp:66-71) + [O3D] ICPConvergenceCriteria */
 typedef struct {
@@ -128,7 +128,7 @@ int o3ds_icp_point_to_plane(o3ds_handle h, const double* src_xyz, size_t n_src, 
 int o3ds_icp_point_to_plane_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3ds_crop* target_crop,
                                 const double init[16], const o3ds_icp_params* params, o3ds_icp_result* out);
 
-/* Same loop with params->method selecting the estimator (point-to-plane or generalized). */
+/* Same loop with params->method selecting the estimator (point-to-plane, generalized or point-to-point). */
 int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3ds_crop* target_crop, const double init[16],
                           const o3ds_icp_params* params, o3ds_icp_result* out);
 /* RegistrationIcpGeneralized::registerClouds (CloudRegistration.cpp:16-21) = [O3D] RegistrationGeneralizedICP with a
@@ -140,6 +140,15 @@ int o3ds_icp_generalized(o3ds_handle h, const double* src_xyz, const double* src
                          const double* tgt_normals, size_t n_tgt, const double init[16], const o3ds_icp_params* params, o3ds_icp_result* out);
 int o3ds_icp_generalized_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3ds_crop* target_crop, const double init[16],
                              const o3ds_icp_params* params, o3ds_icp_result* out);
+/* RegistrationIcpPointToPoint::registerClouds (CloudRegistration.cpp:69-74) = [O3D] RegistrationICP with
+ * TransformationEstimationPointToPoint: the update of every iteration is the closed-form Eigen::umeyama (no scaling) of the
+ * matched pairs; same loop and convergence test.  No normals are needed on either cloud.
+ * Step-wise record in this method: [0..8] sum q_a p_b (row-major, q = matched target point, p = transformed source point),
+ * [9..11] sum p, [12..14] sum q, [28] #corr, [29] sum d^2, the rest 0. */
+int o3ds_icp_point_to_point(o3ds_handle h, const double* src_xyz, size_t n_src, const double* tgt_xyz, size_t n_tgt,
+                            const double init[16], const o3ds_icp_params* params, o3ds_icp_result* out);
+int o3ds_icp_point_to_point_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3ds_crop* target_crop, const double init[16],
+                                const o3ds_icp_params* params, o3ds_icp_result* out);
 /* epsilon of the plane-to-plane covariance model (default 1e-3, Open3D's default) */
 int o3ds_set_gicp_epsilon(o3ds_handle h, double epsilon);
 

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libo3ds_backend.so")
 OK = 0
 ERR_INVALID_ARG, ERR_NO_NORMALS, ERR_OOM, ERR_HIP, ERR_BAD_HANDLE, ERR_EMPTY, ERR_CAPACITY = -1, -2, -3, -4, -5, -6, -7
 PRECISION_F32, PRECISION_F64 = 0, 1
-ICP_POINT_TO_PLANE, ICP_GENERALIZED = 0, 1
+ICP_POINT_TO_PLANE, ICP_GENERALIZED, ICP_POINT_TO_POINT = 0, 1, 2
 CROP_NONE, CROP_MAX_RADIUS, CROP_MIN_RADIUS, CROP_MIN_MAX_RADIUS, CROP_CYLINDER = range(5)
 
 
@@ -61,6 +61,8 @@ SIGNATURES = {
                                           C.POINTER(IcpResult)]),
     "o3ds_icp_point_to_plane_dev": (C.c_int, [_H, _CL, _CL, C.POINTER(Crop), _dp, C.POINTER(IcpParams), C.POINTER(IcpResult)]),
     "o3ds_icp_register_dev": (C.c_int, [_H, _CL, _CL, C.POINTER(Crop), _dp, C.POINTER(IcpParams), C.POINTER(IcpResult)]),
+    "o3ds_icp_point_to_point": (C.c_int, [_H, _dp, C.c_size_t, _dp, C.c_size_t, _dp, C.POINTER(IcpParams), C.POINTER(IcpResult)]),
+    "o3ds_icp_point_to_point_dev": (C.c_int, [_H, _CL, _CL, C.POINTER(Crop), _dp, C.POINTER(IcpParams), C.POINTER(IcpResult)]),
     "o3ds_icp_generalized": (C.c_int, [_H, _dp, _dp, C.c_size_t, _dp, _dp, C.c_size_t, _dp, C.POINTER(IcpParams), C.POINTER(IcpResult)]),
     "o3ds_icp_generalized_dev": (C.c_int, [_H, _CL, _CL, C.POINTER(Crop), _dp, C.POINTER(IcpParams), C.POINTER(IcpResult)]),
     "o3ds_set_gicp_epsilon": (C.c_int, [_H, C.c_double]),
@@ -220,6 +222,24 @@ class Backend:
         p = self._params(max_corr, max_iter, rel_fitness, rel_rmse)
         out = IcpResult()
         self._ck(self.lib.o3ds_icp_point_to_plane_dev(self.h, source, target, C.byref(target_crop) if target_crop else None, ip,
+                                                      C.byref(p), C.byref(out)))
+        return self._result(out)
+
+    def icp_point_to_point(self, src, tgt, max_corr, init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6):
+        src, sp = _d(np.asarray(src).reshape(-1, 3))
+        tgt, tp = _d(np.asarray(tgt).reshape(-1, 3))
+        T0, ip = _d(colmajor(np.eye(4) if init is None else init))
+        p = self._params(max_corr, max_iter, rel_fitness, rel_rmse, ICP_POINT_TO_POINT)
+        out = IcpResult()
+        self._ck(self.lib.o3ds_icp_point_to_point(self.h, sp, len(src), tp, len(tgt), ip, C.byref(p), C.byref(out)))
+        return self._result(out)
+
+    def icp_point_to_point_dev(self, source: int, target: int, max_corr, init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6,
+                               target_crop: Crop | None = None):
+        T0, ip = _d(colmajor(np.eye(4) if init is None else init))
+        p = self._params(max_corr, max_iter, rel_fitness, rel_rmse, ICP_POINT_TO_POINT)
+        out = IcpResult()
+        self._ck(self.lib.o3ds_icp_point_to_point_dev(self.h, source, target, C.byref(target_crop) if target_crop else None, ip,
                                                       C.byref(p), C.byref(out)))
         return self._result(out)
 

@@ -94,6 +94,33 @@ class RegistrationIcpGeneralized(CloudRegistration):  # CloudRegistration.hpp:56
         cloud.be.estimate_normals(cloud.id, self.maxRadiusNormalEstimation_, self.knnNormalEstimation_)
 
 
+class RegistrationIcpPointToPoint(CloudRegistration):  # CloudRegistration.hpp:30-41
+    def __init__(self):
+        self.maxCorrespondenceDistance_ = 1.0
+        self.icpConvergenceCriteria_ = ICPConvergenceCriteria()
+
+    def registerClouds(self, source: PointCloud, target: PointCloud, init, target_crop=None) -> RegistrationResult:
+        """CloudRegistration.cpp:69-74 -> [O3D] RegistrationICP(source, target, maxCorrespondenceDistance_, init,
+        TransformationEstimationPointToPoint(), icpConvergenceCriteria_): closed-form Umeyama update per iteration."""
+        c = self.icpConvergenceCriteria_
+        try:
+            r = source.be.icp_point_to_point_dev(source.id, target.id, self.maxCorrespondenceDistance_, init=init, max_iter=c.max_iteration_,
+                                                 rel_fitness=c.relative_fitness_, rel_rmse=c.relative_rmse_, target_crop=target_crop)
+        except _b.BackendError as e:
+            raise RuntimeError(str(e)) from e
+        return RegistrationResult(r["transformation"], r["fitness"], r["inlier_rmse"], r["iterations"], r["converged"])
+
+    def estimateNormalsOrCovariancesIfNeeded(self, cloud: PointCloud) -> None:  # base-class no-op (CloudRegistration.hpp:26)
+        return None
+
+
+def createPointToPointIcp(p: CloudRegistrationParameters) -> RegistrationIcpPointToPoint:  # CloudRegistration.cpp:76-81
+    ret = RegistrationIcpPointToPoint()
+    ret.maxCorrespondenceDistance_ = p.icp_.maxCorrespondenceDistance_
+    ret.icpConvergenceCriteria_.max_iteration_ = p.icp_.maxNumIter_
+    return ret
+
+
 def createGeneralizedIcp(p: CloudRegistrationParameters) -> RegistrationIcpGeneralized:  # CloudRegistration.cpp:32-39
     ret = RegistrationIcpGeneralized()
     ret.maxCorrespondenceDistance_ = p.icp_.maxCorrespondenceDistance_
@@ -118,6 +145,5 @@ def cloudRegistrationFactory(p: CloudRegistrationParameters) -> CloudRegistratio
     if p.regType_ == CloudRegistrationType.GeneralizedIcp:
         return createGeneralizedIcp(p)
     if p.regType_ == CloudRegistrationType.PointToPointIcp:
-        # SURVEY.md 8f rank 1 (closed-form Umeyama step): not built yet.  Fail loudly, never fall back.
-        raise NotImplementedError("PointToPointIcp: not built yet on the HIP backend (SURVEY.md 8f)")
+        return createPointToPointIcp(p)
     raise RuntimeError("cloud: unknown type of cloud registration")

@@ -455,8 +455,9 @@ int validate_icp(o3ds_handle h, const CloudRec* src, const CloudRec* tgt, const 
   if (tgt->n == 0) return fail(h, O3DS_ERR_EMPTY, "icp: empty target (map patch size is zero)");  // ScanToMapRegistration.cpp:60
   if (!(p->max_correspondence_distance > 0.0))
     return fail(h, O3DS_ERR_INVALID_ARG, "Invalid max_correspondence_distance.");  // [O3D] RegistrationICP
-  if (p->method != O3DS_ICP_POINT_TO_PLANE && p->method != O3DS_ICP_GENERALIZED) return fail(h, O3DS_ERR_INVALID_ARG, "icp: unknown method");
-  if (!tgt->nrm)
+  if (p->method != O3DS_ICP_POINT_TO_PLANE && p->method != O3DS_ICP_GENERALIZED && p->method != O3DS_ICP_POINT_TO_POINT)
+    return fail(h, O3DS_ERR_INVALID_ARG, "icp: unknown method");
+  if (!tgt->nrm && p->method != O3DS_ICP_POINT_TO_POINT)
     return fail(h, O3DS_ERR_NO_NORMALS, p->method == O3DS_ICP_GENERALIZED ? "generalized ICP: target has no normals (covariances are built from normals)"
                                                                            : "TransformationEstimationPointToPlane requires target normals");
   if (p->method == O3DS_ICP_GENERALIZED && src->n > 0 && !src->nrm)
@@ -502,6 +503,7 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
   a.crop = to_dev(crop);
   const double r = params->max_correspondence_distance;
   a.r2max = r * r;
+  a.method = params->method;
   a.kmax = std::max(1, (int)std::ceil(r / tgt->grid.cell));  // a neighbour within r is at most this many cells away
   a.nn_cache = h->d_nn_cache;
   a.n_tgt = (int)tgt->n;
@@ -754,7 +756,7 @@ int o3ds_icp_update(o3ds_handle h, const double* d_record, uint64_t n_src_total)
   if (!h->session) return fail(h, O3DS_ERR_INVALID_ARG, "icp_update: no session");
   if (!d_record) return fail(h, O3DS_ERR_INVALID_ARG, "icp_update: null record");
   icp_update_kernel<<<1, 128, 0, h->stream>>>(d_record, h->d_state, (unsigned long long)n_src_total, h->params.max_iteration,
-                                             h->params.relative_fitness, h->params.relative_rmse);
+                                             h->params.relative_fitness, h->params.relative_rmse, h->session_method);
   HIP_TRY(hipGetLastError());
   return O3DS_OK;
 }
@@ -790,6 +792,34 @@ int o3ds_icp_point_to_plane_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud tar
   o3ds_icp_params p = *params;
   p.method = O3DS_ICP_POINT_TO_PLANE;
   return o3ds_icp_register_dev(h, source, target, target_crop, init, &p, out);
+}
+
+int o3ds_icp_point_to_point_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3ds_crop* target_crop, const double init[16],
+                                const o3ds_icp_params* params, o3ds_icp_result* out) {
+  CHECK_HANDLE(h);
+  if (!params) return fail(h, O3DS_ERR_INVALID_ARG, "icp: null params");
+  o3ds_icp_params p = *params;
+  p.method = O3DS_ICP_POINT_TO_POINT;
+  return o3ds_icp_register_dev(h, source, target, target_crop, init, &p, out);
+}
+
+int o3ds_icp_point_to_point(o3ds_handle h, const double* src_xyz, size_t n_src, const double* tgt_xyz, size_t n_tgt, const double init[16],
+                            const o3ds_icp_params* params, o3ds_icp_result* out) {
+  CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
+  if (!params || !out || !init) return fail(h, O3DS_ERR_INVALID_ARG, "icp: null argument");
+  if (!(params->max_correspondence_distance > 0.0)) return fail(h, O3DS_ERR_INVALID_ARG, "Invalid max_correspondence_distance.");
+  if (n_tgt == 0) return fail(h, O3DS_ERR_EMPTY, "icp: empty target (map patch size is zero)");
+  o3ds_cloud s = 0, t = 0;
+  int rc = o3ds_cloud_upload(h, src_xyz, nullptr, n_src, &s);
+  if (rc) return rc;
+  rc = o3ds_cloud_upload(h, tgt_xyz, nullptr, n_tgt, &t);
+  if (!rc) rc = o3ds_icp_point_to_point_dev(h, s, t, nullptr, init, params, out);
+  const std::string keep = h->err;
+  (void)o3ds_cloud_free(h, s);
+  if (t) (void)o3ds_cloud_free(h, t);
+  if (rc) h->err = keep;
+  return rc;
 }
 
 int o3ds_icp_generalized_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3ds_crop* target_crop, const double init[16],
@@ -904,7 +934,7 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
         launch_accumulate<P4f>(h, a, h->session_crop, nb);
       icp_reduce_update_kernel<<<1, kUpdBlock, 0, h->stream>>>(h->d_partials, nb, h->d_state, (unsigned long long)a.count,
                                                             params->max_iteration, params->relative_fitness, params->relative_rmse,
-                                                            h->debug_update);
+                                                            h->debug_update, h->session_method);
     }
     launched += chunk;
     HIP_TRY(hipGetLastError());

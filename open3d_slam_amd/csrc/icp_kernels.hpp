@@ -524,6 +524,7 @@ struct IcpPassArgs {
   CropDev crop;
   double r2max;
   int kmax;          // ceil(r / cell): how many cells away a neighbour within r can be
+  int method;        // o3ds_icp_method: which record a correspondence contributes (the GICP record is a separate instantiation)
   int* nn_cache;     // [n_src] position (in the sorted target) of each query's match in the previous pass of this registration
   int n_tgt;
   const void* snrm;  // source normals (generalized ICP only), same order as src
@@ -538,6 +539,10 @@ struct IcpPassArgs {
 constexpr int kRecSlots = 10;
 __device__ const unsigned char kTermA[kRec] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9};
 __device__ const unsigned char kTermB[kRec] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5, 6, 6, 6, 6, 6, 6, 6, 7, 7, 9, 9};
+// Point-to-point ([O3D] TransformationEstimationPointToPoint = Eigen::umeyama without scaling): per-query slots {p[3], q[3], 0, one,
+// d2, 0}; record [0..8] = sum q_a p_b (row a, column b), [9..11] = sum p, [12..14] = sum q, [28] = count, [29] = sum d2.
+__device__ const unsigned char kTermA_p2p[kRec] = {3, 3, 3, 4, 4, 4, 5, 5, 5, 0, 1, 2, 3, 4, 5, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 7, 8, 9, 9};
+__device__ const unsigned char kTermB_p2p[kRec] = {0, 1, 2, 0, 1, 2, 0, 1, 2, 7, 7, 7, 7, 7, 7, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 7, 7, 9, 9};
 
 // Workgroup = BLOCK threads = BLOCK/G queries x G lanes for the search, then (32 record terms) x (BLOCK/32 query slices) for the
 // accumulation: one f64 accumulator per thread instead of 30, so the kernel stays small in registers and the chip can
@@ -678,7 +683,8 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
                t13 = to_sgpr(Tm[13]), t23 = to_sgpr(Tm[14]);
   const int gl = threadIdx.x & (kGroup - 1), ql = threadIdx.x / kGroup;
   const int term = threadIdx.x & 31, qs = threadIdx.x >> 5;
-  const int ta = kTermA[term], tb = kTermB[term];
+  const bool p2p = a.method == O3DS_ICP_POINT_TO_POINT;  // uniform
+  const int ta = p2p ? kTermA_p2p[term] : kTermA[term], tb = p2p ? kTermB_p2p[term] : kTermB[term];
   double acc = 0.0;
   const size_t n_batches = (a.count + kQPB - 1) / kQPB;
   static_assert(sizeof(FarItem<P4>) <= kStride * sizeof(double), "a parked far query fits its record slot");
@@ -760,8 +766,20 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
       if (nn.pos != -1) {
         if (a.debug == 3) nn.pos = (int)(i % 1000);
         const P4 q = tp[nn.pos];
-        const P4 nq = tn[nn.pos];
         const double dx = px - (double)q.x, dy = py - (double)q.y, dz = pz - (double)q.z;
+        if (!kGicp && p2p) {
+          rec[0] = px;
+          rec[1] = py;
+          rec[2] = pz;
+          rec[3] = (double)q.x;
+          rec[4] = (double)q.y;
+          rec[5] = (double)q.z;
+          rec[6] = 0.0;
+          rec[7] = 1.0;
+          rec[8] = dx * dx + dy * dy + dz * dz;
+          rec[9] = 0.0;
+        } else {
+        const P4 nq = tn[nn.pos];
         const double nx = (double)nq.x, ny = (double)nq.y, nz = (double)nq.z;
         if (kGicp) {
           const P4 ns = ((const P4*)a.snrm)[a.first + i];
@@ -783,6 +801,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
         rec[7] = 1.0;
         rec[8] = dx * dx + dy * dy + dz * dz;
         rec[9] = 0.0;
+        }
         }
       } else {
 #pragma unroll
@@ -1066,6 +1085,116 @@ __device__ __forceinline__ void solve6_wave(const double* rec, double* x_out, in
   if (lane < 6) x_out[perm] = mine;
 }
 
+// One-sided Jacobi SVD of a 3x3 (row-major): A = U diag(d) V^T, d descending; columns of U for vanishing singular values are
+// completed by cross products.  One lane, f64: the point-to-point step is closed form and this is all it costs.
+__device__ inline void svd3_jacobi(const double Ain[9], double U[9], double d[3], double V[9]) {
+  double a0[3] = {Ain[0], Ain[3], Ain[6]}, a1[3] = {Ain[1], Ain[4], Ain[7]}, a2[3] = {Ain[2], Ain[5], Ain[8]};  // columns
+  double v0[3] = {1, 0, 0}, v1[3] = {0, 1, 0}, v2[3] = {0, 0, 1};
+  auto rot = [](double* ap, double* aq, double* vp, double* vq) -> double {
+    const double alpha = ap[0] * ap[0] + ap[1] * ap[1] + ap[2] * ap[2], beta = aq[0] * aq[0] + aq[1] * aq[1] + aq[2] * aq[2];
+    const double gamma = ap[0] * aq[0] + ap[1] * aq[1] + ap[2] * aq[2];
+    if (fabs(gamma) <= 1e-300 || fabs(gamma) <= 1e-17 * sqrt(alpha * beta)) return 0.0;
+    const double zeta = (beta - alpha) / (2.0 * gamma);
+    const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+    const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const double x = ap[r], y = aq[r];
+      ap[r] = c * x - sn * y;
+      aq[r] = sn * x + c * y;
+      const double vx = vp[r], vy = vq[r];
+      vp[r] = c * vx - sn * vy;
+      vq[r] = sn * vx + c * vy;
+    }
+    return fabs(gamma);
+  };
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    const double off = rot(a0, a1, v0, v1) + rot(a0, a2, v0, v2) + rot(a1, a2, v1, v2);
+    if (off == 0.0) break;
+  }
+  double n0 = sqrt(a0[0] * a0[0] + a0[1] * a0[1] + a0[2] * a0[2]), n1 = sqrt(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]),
+         n2 = sqrt(a2[0] * a2[0] + a2[1] * a2[1] + a2[2] * a2[2]);
+  auto swp = [](double* x, double* y, double* vx, double* vy, double& nx, double& ny) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      double t = x[r];
+      x[r] = y[r];
+      y[r] = t;
+      t = vx[r];
+      vx[r] = vy[r];
+      vy[r] = t;
+    }
+    const double t = nx;
+    nx = ny;
+    ny = t;
+  };
+  if (n1 > n0) swp(a0, a1, v0, v1, n0, n1);  // descending
+  if (n2 > n0) swp(a0, a2, v0, v2, n0, n2);
+  if (n2 > n1) swp(a1, a2, v1, v2, n1, n2);
+  const double tiny = 1e-14 * (n0 > 0 ? n0 : 1.0);
+  double u0[3], u1[3], u2[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    u0[r] = n0 > tiny ? a0[r] / n0 : 0.0;
+    u1[r] = n1 > tiny ? a1[r] / n1 : 0.0;
+    u2[r] = n2 > tiny ? a2[r] / n2 : 0.0;
+  }
+  if (!(n0 > tiny)) {
+    u0[0] = 1, u0[1] = 0, u0[2] = 0, u1[0] = 0, u1[1] = 1, u1[2] = 0, u2[0] = 0, u2[1] = 0, u2[2] = 1;
+  } else {
+    if (!(n1 > tiny)) {  // any unit vector orthogonal to u0
+      const int k = fabs(u0[0]) <= fabs(u0[1]) ? (fabs(u0[0]) <= fabs(u0[2]) ? 0 : 2) : (fabs(u0[1]) <= fabs(u0[2]) ? 1 : 2);
+      const double dp = k == 0 ? u0[0] : (k == 1 ? u0[1] : u0[2]);
+      double w[3] = {(k == 0 ? 1.0 : 0.0) - dp * u0[0], (k == 1 ? 1.0 : 0.0) - dp * u0[1], (k == 2 ? 1.0 : 0.0) - dp * u0[2]};
+      const double wn = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+      u1[0] = w[0] / wn, u1[1] = w[1] / wn, u1[2] = w[2] / wn;
+    }
+    if (!(n2 > tiny)) {  // u2 = u0 x u1
+      u2[0] = u0[1] * u1[2] - u0[2] * u1[1];
+      u2[1] = u0[2] * u1[0] - u0[0] * u1[2];
+      u2[2] = u0[0] * u1[1] - u0[1] * u1[0];
+    }
+  }
+  d[0] = n0, d[1] = n1, d[2] = n2;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    U[r * 3] = u0[r], U[r * 3 + 1] = u1[r], U[r * 3 + 2] = u2[r];
+    V[r * 3] = v0[r], V[r * 3 + 1] = v1[r], V[r * 3 + 2] = v2[r];
+  }
+}
+
+__device__ inline double det3_rm(const double A[9]) {
+  return A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
+}
+
+// [O3D] TransformationEstimationPointToPoint::ComputeTransformation = Eigen::umeyama(source, target, with_scaling = false) from the
+// point-to-point record (sums instead of demeaned matrices: Sigma = E[q p^T] - E[q] E[p]^T).  Ucm: 4x4 column-major.
+__device__ inline void umeyama_from_record(const double* rec, double Ucm[16]) {
+  const double m = rec[kRecCount], inv = 1.0 / m;
+  const double ms[3] = {rec[9] * inv, rec[10] * inv, rec[11] * inv}, mt[3] = {rec[12] * inv, rec[13] * inv, rec[14] * inv};
+  double S[9];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) S[a * 3 + b] = rec[a * 3 + b] * inv - mt[a] * ms[b];
+  double Um[9], dd[3], Vm[9];
+  svd3_jacobi(S, Um, dd, Vm);
+  const double sgn = det3_rm(Um) * det3_rm(Vm) < 0.0 ? -1.0 : 1.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) Ucm[k] = 0.0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    double Ra[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      Ra[b] = Um[a * 3] * Vm[b * 3] + Um[a * 3 + 1] * Vm[b * 3 + 1] + sgn * Um[a * 3 + 2] * Vm[b * 3 + 2];
+      Ucm[b * 4 + a] = Ra[b];
+    }
+    Ucm[12 + a] = mt[a] - (Ra[0] * ms[0] + Ra[1] * ms[1] + Ra[2] * ms[2]);
+  }
+  Ucm[15] = 1.0;
+}
+
 // [O3D] RegistrationICP loop body after the correspondence pass: convergence test, solve, T <- U*T.
 // Called by every thread of one workgroup (>= 128 threads) with the record in LDS.  This tail is on the critical path of
 // every ICP iteration, so its two dependent chains run on two wavefronts (= two SIMDs) at once and meet at ONE workgroup
@@ -1075,7 +1204,8 @@ __device__ __forceinline__ void solve6_wave(const double* rec, double* x_out, in
 __device__ __forceinline__ void icp_step_block(const double* s_rec, IcpStateDev* st, unsigned long long n_src_total, int max_iter,
                                                double rel_fitness, double rel_rmse, double* s_x /* [8] */, double* s_sc /* unused */,
                                                double* s_U /* [16] */, double* s_T /* [16] */, int* s_go,
-                                               unsigned long long* tr = nullptr /* 8 timestamps, development aid */) {
+                                               unsigned long long* tr = nullptr /* 8 timestamps, development aid */,
+                                               int method = O3DS_ICP_POINT_TO_PLANE) {
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #define O3DS_TSTAMP(k)                                       \
   do {                                                       \
@@ -1088,6 +1218,15 @@ __device__ __forceinline__ void icp_step_block(const double* s_rec, IcpStateDev*
     if (lane < 16) s_T[lane] = st->T[lane];
     if (lane < 8) s_x[lane] = 0.0;
     lds_wave_sync();
+    if (method == O3DS_ICP_POINT_TO_POINT) {  // closed form: U straight from the record, no 6-vector (uniform branch)
+      if (lane == 0) {
+        double Ucm[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        if (count > 0.0) umeyama_from_record(s_rec, Ucm);  // [O3D] corres.empty() -> Identity
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s_U[k] = Ucm[k];
+      }
+      lds_wave_sync();
+    } else {
     if (count > 0.0) {  // empty correspondence set => identity update (x = 0)
       solve6_wave(s_rec, s_x, lane);
       lds_wave_sync();
@@ -1121,6 +1260,7 @@ __device__ __forceinline__ void icp_step_block(const double* s_rec, IcpStateDev*
       s_U[lane] = v;
     }
     lds_wave_sync();
+    }
     if (lane < 16) {  // U * T
       const int c = lane >> 2, r = lane & 3;
 #pragma unroll
@@ -1155,7 +1295,7 @@ __device__ __forceinline__ void icp_step_block(const double* s_rec, IcpStateDev*
 // single-GPU path: reduce the partials and step, one workgroup
 __global__ __launch_bounds__(kUpdBlock) void icp_reduce_update_kernel(const double* __restrict__ partials, int nrows, IcpStateDev* state,
                                                                       unsigned long long n_src_total, int max_iter, double rel_fitness,
-                                                                      double rel_rmse, int debug_mode) {
+                                                                      double rel_rmse, int debug_mode, int method) {
   if (state->done) return;
   if (debug_mode == 1) {  // timing experiment: launch + done check only
     if (threadIdx.x == 0) { state->pass += 1; state->iterations += 1; if (state->iterations > max_iter) state->done = 1; }
@@ -1170,19 +1310,19 @@ __global__ __launch_bounds__(kUpdBlock) void icp_reduce_update_kernel(const doub
     if (threadIdx.x == 0) { state->pass += 1; state->iterations += 1; state->fitness = s_out[28]; if (state->iterations > max_iter) state->done = 1; }
     return;
   }
-  icp_step_block(s_out, state, n_src_total, max_iter, rel_fitness, rel_rmse, s_x, s_sc, s_U, s_T, &s_go);
+  icp_step_block(s_out, state, n_src_total, max_iter, rel_fitness, rel_rmse, s_x, s_sc, s_U, s_T, &s_go, nullptr, method);
 }
 
 // sharded path: the record was all-reduced by the caller
 __global__ __launch_bounds__(128) void icp_update_kernel(const double* __restrict__ record, IcpStateDev* state, unsigned long long n_src_total,
-                                                        int max_iter, double rel_fitness, double rel_rmse) {
+                                                        int max_iter, double rel_fitness, double rel_rmse, int method) {
   if (state->done) return;
   __shared__ double s_out[kRec];
   __shared__ double s_x[8], s_sc[8], s_U[16], s_T[16];
   __shared__ int s_go;
   if (threadIdx.x < kRec) s_out[threadIdx.x] = record[threadIdx.x];
   __syncthreads();
-  icp_step_block(s_out, state, n_src_total, max_iter, rel_fitness, rel_rmse, s_x, s_sc, s_U, s_T, &s_go);
+  icp_step_block(s_out, state, n_src_total, max_iter, rel_fitness, rel_rmse, s_x, s_sc, s_U, s_T, &s_go, nullptr, method);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1264,7 +1404,7 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
     }
     __syncthreads();
     icp_step_block(s_out, &s_st, fa.n_src_total, fa.max_iter, fa.rel_fitness, fa.rel_rmse, s_x, s_sc, s_U, s_T, &s_go,
-                   fa.trace ? fa.trace + (size_t)blockIdx.x * 16 + 8 : nullptr);
+                   fa.trace ? fa.trace + (size_t)blockIdx.x * 16 + 8 : nullptr, fa.pass.method);
     __syncthreads();
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {

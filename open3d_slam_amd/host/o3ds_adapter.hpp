@@ -1,7 +1,7 @@
 // o3ds_adapter.hpp -- C++ host side of the drop-in: the reference's own hot-path classes, re-implemented over the
 // C-ABI of include/o3ds_backend.h.  Same names, members, argument meaning and error behaviour
 // (std::runtime_error where the reference's assert_* / Open3D LogError throw) as:
-//   CloudRegistration / RegistrationIcpPointToPlane / cloudRegistrationFactory
+//   CloudRegistration / RegistrationIcpPointToPlane / RegistrationIcpPointToPoint / RegistrationIcpGeneralized / cloudRegistrationFactory
 //        include/open3d_slam/CloudRegistration.hpp:19-42, src/CloudRegistration.cpp:44-65,85-100
 //   CroppingVolume family / croppingVolumeFactory      include/open3d_slam/croppers.hpp:26-47, src/croppers.cpp
 //   voxelize / voxelizeWithinCroppingVolume / transform include/open3d_slam/helpers.hpp:20-25, src/helpers.cpp:107-183,273-305
@@ -325,6 +325,33 @@ class RegistrationIcpGeneralized : public CloudRegistration {
   open3d::pipelines::registration::ICPConvergenceCriteria icpConvergenceCriteria_;
 };
 
+// RegistrationIcpPointToPoint (CloudRegistration.hpp:30-41, CloudRegistration.cpp:69-81)
+class RegistrationIcpPointToPoint : public CloudRegistration {
+ public:
+  RegistrationResult registerClouds(const PointCloud& source, const PointCloud& target, const Transform& init) const final {
+    o3ds_icp_params p{};
+    p.max_correspondence_distance = maxCorrespondenceDistance_;
+    p.max_iteration = icpConvergenceCriteria_.max_iteration_;
+    p.relative_fitness = icpConvergenceCriteria_.relative_fitness_;
+    p.relative_rmse = icpConvergenceCriteria_.relative_rmse_;
+    o3ds_icp_result r{};
+    o3ds_detail::Handle::check(o3ds_icp_point_to_point(o3ds_detail::Handle::get(), o3ds_detail::xyz(source.points_), source.points_.size(),
+                                                       o3ds_detail::xyz(target.points_), target.points_.size(), o3ds_detail::pose_data(init),
+                                                       &p, &r));
+    return RegistrationIcpPointToPlane::toResult(r);
+  }
+  void estimateNormalsOrCovariancesIfNeeded(PointCloud*) const final {}  // nothing to prepare (CloudRegistration.hpp:26 default)
+  double maxCorrespondenceDistance_ = 1.0;
+  open3d::pipelines::registration::ICPConvergenceCriteria icpConvergenceCriteria_;
+};
+
+inline std::unique_ptr<RegistrationIcpPointToPoint> createPointToPointIcp(const CloudRegistrationParameters& p) {  // CloudRegistration.cpp:76-81
+  auto ret = std::make_unique<RegistrationIcpPointToPoint>();
+  ret->maxCorrespondenceDistance_ = p.icp_.maxCorrespondenceDistance_;
+  ret->icpConvergenceCriteria_.max_iteration_ = p.icp_.maxNumIter_;
+  return ret;
+}
+
 inline std::unique_ptr<RegistrationIcpGeneralized> createGeneralizedIcp(const CloudRegistrationParameters& p) {  // CloudRegistration.cpp:32-39
   auto ret = std::make_unique<RegistrationIcpGeneralized>();
   ret->maxCorrespondenceDistance_ = p.icp_.maxCorrespondenceDistance_;
@@ -350,8 +377,7 @@ inline std::unique_ptr<CloudRegistration> cloudRegistrationFactory(const CloudRe
     case CloudRegistrationType::GeneralizedIcp:
       return createGeneralizedIcp(p);
     case CloudRegistrationType::PointToPointIcp:
-      // next row: in the reference tree this one keeps its Open3D CPU implementation
-      throw std::runtime_error("cloud: PointToPointIcp not available on the HIP backend yet");
+      return createPointToPointIcp(p);
     default:
       throw std::runtime_error("cloud: unknown type of cloud registration");
   }

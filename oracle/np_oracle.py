@@ -67,6 +67,43 @@ def icp_point_to_plane(src, tgt, nrm, max_corr, init=None, max_iter=30, rel_fitn
     return dict(transformation=T, fitness=fit, inlier_rmse=rmse, iterations=it, n_corr=nc)
 
 
+def umeyama_update(P, Q, corr):
+    """Eigen::umeyama(source, target, with_scaling=False) on the matched pairs ([O3D] TransformationEstimationPointToPoint)."""
+    m = corr >= 0
+    if not m.any():
+        return np.eye(4)
+    s, t = P[m], Q[corr[m]]
+    ms, mt = s.mean(0), t.mean(0)
+    sigma = (t - mt).T @ (s - ms) / len(s)
+    U, _, Vt = np.linalg.svd(sigma)
+    S = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+        S[2, 2] = -1.0
+    R = U @ S @ Vt
+    out = np.eye(4)
+    out[:3, :3] = R
+    out[:3, 3] = mt - R @ ms
+    return out
+
+
+def icp_point_to_point(src, tgt, max_corr, init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6):
+    tree = cKDTree(tgt, leafsize=15)
+    T = np.eye(4) if init is None else np.array(init, dtype=np.float64)
+    P = src @ T[:3, :3].T + T[:3, 3]
+    corr, fit, rmse, nc = evaluate(tree, P, max_corr)
+    it = 0
+    for _ in range(max_iter):
+        U = umeyama_update(P, tgt, corr)
+        T = U @ T
+        P = P @ U[:3, :3].T + U[:3, 3]
+        pf, pr = fit, rmse
+        corr, fit, rmse, nc = evaluate(tree, P, max_corr)
+        it += 1
+        if abs(pf - fit) < rel_fitness and abs(pr - rmse) < rel_rmse:
+            break
+    return dict(transformation=T, fitness=fit, inlier_rmse=rmse, iterations=it, n_corr=nc)
+
+
 def estimate_normals(pts, radius, max_nn):
     tree = cKDTree(pts, leafsize=15)
     d, j = tree.query(pts, k=max_nn, distance_upper_bound=radius)

@@ -490,6 +490,177 @@ int orc_icp_point_to_plane(const double* src, size_t n, const double* tgt, const
   return 0;
 }
 
+/* ------------------------------------------------------------------ A.3b point-to-point step
+ * [O3D] TransformationEstimationPointToPoint::ComputeTransformation = Eigen::umeyama(source, target, with_scaling = false)
+ * (call site src/CloudRegistration.cpp:69-74): means, Sigma = (1/m) sum (t - mu_t)(s - mu_s)^T, Sigma = U D V^T (JacobiSVD,
+ * singular values descending), S = diag(1,1,-1) iff det(U) det(V) < 0, R = U S V^T, t = mu_t - R mu_s. */
+static double det3(const double A[9]) { /* row-major */
+  return A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
+}
+
+/* one-sided Jacobi SVD of a 3x3 (row-major): A = U diag(d) V^T, d descending, U and V orthogonal (columns for vanishing
+ * singular values are completed by cross products) */
+void orc_svd3(const double A_in[9], double U[9], double d[3], double V[9]) {
+  double A[9], Vm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  memcpy(A, A_in, sizeof(A));
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        double alpha = 0, beta = 0, gamma = 0;
+        for (int r = 0; r < 3; ++r) {
+          alpha += A[r * 3 + p] * A[r * 3 + p];
+          beta += A[r * 3 + q] * A[r * 3 + q];
+          gamma += A[r * 3 + p] * A[r * 3 + q];
+        }
+        if (fabs(gamma) <= 1e-300 || fabs(gamma) <= 1e-17 * sqrt(alpha * beta)) continue;
+        off += fabs(gamma);
+        const double zeta = (beta - alpha) / (2.0 * gamma);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+        for (int r = 0; r < 3; ++r) {
+          const double ap = A[r * 3 + p], aq = A[r * 3 + q];
+          A[r * 3 + p] = c * ap - sn * aq;
+          A[r * 3 + q] = sn * ap + c * aq;
+          const double vp = Vm[r * 3 + p], vq = Vm[r * 3 + q];
+          Vm[r * 3 + p] = c * vp - sn * vq;
+          Vm[r * 3 + q] = sn * vp + c * vq;
+        }
+      }
+    if (off == 0.0) break;
+  }
+  double nrm[3];
+  int ord[3] = {0, 1, 2};
+  for (int j = 0; j < 3; ++j) nrm[j] = sqrt(A[j] * A[j] + A[3 + j] * A[3 + j] + A[6 + j] * A[6 + j]);
+  for (int a = 0; a < 2; ++a) /* descending */
+    for (int b = a + 1; b < 3; ++b)
+      if (nrm[ord[b]] > nrm[ord[a]]) {
+        const int t = ord[a];
+        ord[a] = ord[b];
+        ord[b] = t;
+      }
+  const double tiny = 1e-14 * (nrm[ord[0]] > 0 ? nrm[ord[0]] : 1.0);
+  for (int j = 0; j < 3; ++j) {
+    const int s = ord[j];
+    d[j] = nrm[s];
+    for (int r = 0; r < 3; ++r) {
+      V[r * 3 + j] = Vm[r * 3 + s];
+      U[r * 3 + j] = nrm[s] > tiny ? A[r * 3 + s] / nrm[s] : 0.0;
+    }
+  }
+  /* complete U for vanishing singular values (rank-deficient Sigma: collinear / coplanar-degenerate correspondences) */
+  if (!(d[0] > tiny)) {
+    const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    memcpy(U, I, sizeof(I));
+  } else {
+    if (!(d[1] > tiny)) { /* any unit vector orthogonal to u0 */
+      const double u0[3] = {U[0], U[3], U[6]};
+      const int k = fabs(u0[0]) <= fabs(u0[1]) ? (fabs(u0[0]) <= fabs(u0[2]) ? 0 : 2) : (fabs(u0[1]) <= fabs(u0[2]) ? 1 : 2);
+      double e[3] = {0, 0, 0}, w[3];
+      e[k] = 1.0;
+      const double dp = u0[k];
+      for (int r = 0; r < 3; ++r) w[r] = e[r] - dp * u0[r];
+      const double wn = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+      for (int r = 0; r < 3; ++r) U[r * 3 + 1] = w[r] / wn;
+    }
+    if (!(d[2] > tiny)) { /* u2 = u0 x u1 */
+      U[2] = U[3] * U[7] - U[6] * U[4];
+      U[5] = U[6] * U[1] - U[0] * U[7];
+      U[8] = U[0] * U[4] - U[3] * U[1];
+    }
+  }
+}
+
+/* U (4x4 column-major) from the matched pairs; returns 0.  P = current (transformed) source points */
+int orc_umeyama_update(const double* P, size_t n, const double* tgt, const int32_t* corr, double Uout[16]) {
+  double ms[3] = {0, 0, 0}, mt[3] = {0, 0, 0};
+  size_t m = 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (corr[i] < 0) continue;
+    const double* q = tgt + 3 * (size_t)corr[i];
+    for (int k = 0; k < 3; ++k) {
+      ms[k] += P[3 * i + k];
+      mt[k] += q[k];
+    }
+    ++m;
+  }
+  double I6[6] = {0, 0, 0, 0, 0, 0};
+  if (m == 0) { /* [O3D] corres.empty() -> Identity */
+    orc_vector6_to_matrix4(I6, Uout);
+    return 0;
+  }
+  const double inv = 1.0 / (double)m;
+  for (int k = 0; k < 3; ++k) {
+    ms[k] *= inv;
+    mt[k] *= inv;
+  }
+  double S[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; /* row-major: S[a][b] = mean (t_a - mt_a)(s_b - ms_b) */
+  for (size_t i = 0; i < n; ++i) {
+    if (corr[i] < 0) continue;
+    const double* q = tgt + 3 * (size_t)corr[i];
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) S[a * 3 + b] += (q[a] - mt[a]) * (P[3 * i + b] - ms[b]);
+  }
+  for (int k = 0; k < 9; ++k) S[k] *= inv;
+  double Um[9], d[3], Vm[9];
+  orc_svd3(S, Um, d, Vm);
+  const double sgn = det3(Um) * det3(Vm) < 0.0 ? -1.0 : 1.0;
+  double R[9];
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) R[a * 3 + b] = Um[a * 3] * Vm[b * 3] + Um[a * 3 + 1] * Vm[b * 3 + 1] + sgn * Um[a * 3 + 2] * Vm[b * 3 + 2];
+  for (int k = 0; k < 16; ++k) Uout[k] = 0.0;
+  for (int a = 0; a < 3; ++a) {
+    for (int b = 0; b < 3; ++b) Uout[b * 4 + a] = R[a * 3 + b]; /* column-major */
+    Uout[12 + a] = mt[a] - (R[a * 3] * ms[0] + R[a * 3 + 1] * ms[1] + R[a * 3 + 2] * ms[2]);
+  }
+  Uout[15] = 1.0;
+  return 0;
+}
+
+/* [O3D] RegistrationICP with TransformationEstimationPointToPoint (src/CloudRegistration.cpp:69-74): same driver as A.1 */
+int orc_icp_point_to_point(const double* src, size_t n, const double* tgt, size_t N, const orc_kdtree* tree, double max_corr,
+                           const double init[16], int max_iter, double rel_fitness, double rel_rmse, orc_icp_result* out) {
+  if (max_corr <= 0.0) return -1;
+  orc_kdtree* own = NULL;
+  if (!tree) {
+    own = orc_kdtree_build(tgt, N);
+    tree = own;
+  }
+  double* P = (double*)malloc(sizeof(double) * 3 * (n ? n : 1));
+  int32_t* corr = (int32_t*)malloc(sizeof(int32_t) * (n ? n : 1));
+  memcpy(P, src, sizeof(double) * 3 * n);
+  double T[16];
+  memcpy(T, init, sizeof(T));
+  if (!is_identity16(init)) orc_transform_points(P, n, init);
+  double fit, rmse;
+  uint64_t nc;
+  orc_evaluate(tree, P, n, max_corr, corr, NULL, &fit, &rmse, &nc);
+  int it = 0, converged = 0;
+  for (int i = 0; i < max_iter; ++i) {
+    double U[16];
+    orc_umeyama_update(P, n, tgt, corr, U);
+    mat4_mul(U, T, T);
+    orc_transform_points(P, n, U);
+    double pf = fit, pr = rmse;
+    orc_evaluate(tree, P, n, max_corr, corr, NULL, &fit, &rmse, &nc);
+    ++it;
+    if (fabs(pf - fit) < rel_fitness && fabs(pr - rmse) < rel_rmse) {
+      converged = 1;
+      break;
+    }
+  }
+  memcpy(out->transformation, T, sizeof(T));
+  out->fitness = fit;
+  out->inlier_rmse = rmse;
+  out->iterations = it;
+  out->converged = converged;
+  out->n_corr = nc;
+  free(P);
+  free(corr);
+  if (own) orc_kdtree_free(own);
+  return 0;
+}
+
 /* ------------------------------------------------------------------ A.8 Generalized ICP
  * [O3D] GeneralizedICP.cpp: GetRotationFromE1ToX, InitializePointCloudForGeneralizedICP,
  * TransformationEstimationForGeneralizedICP::ComputeTransformation; reference call site src/CloudRegistration.cpp:16-21. */

@@ -75,6 +75,14 @@ int orc_icp_point_to_plane(const double* src, size_t n, const double* tgt, const
                            double max_corr, const double init[16], int max_iter, double rel_fitness, double rel_rmse,
                            orc_icp_result* out);
 
+/* A.3b RegistrationICP with TransformationEstimationPointToPoint (call site src/CloudRegistration.cpp:69-74):
+ * Eigen::umeyama without scaling on the matched pairs (closed form, 3x3 SVD), same loop / convergence as A.1. */
+int orc_icp_point_to_point(const double* src, size_t n, const double* tgt, size_t N, const orc_kdtree* tree, double max_corr,
+                           const double init[16], int max_iter, double rel_fitness, double rel_rmse, orc_icp_result* out);
+int orc_umeyama_update(const double* P, size_t n, const double* tgt, const int32_t* corr, double U[16]);
+/* A = U diag(d) V^T (row-major 3x3), d descending */
+void orc_svd3(const double A[9], double U[9], double d[3], double V[9]);
+
 /* A.8 RegistrationGeneralizedICP (call site src/CloudRegistration.cpp:16-21): covariances from normals
  * (C = Rx diag(eps,1,1) Rx^T, Rx = GetRotationFromE1ToX(normal)), per pair M = Ct + R Cs R^T, W = M^-1/2, residual W d (3 rows),
  * Jacobian rows W [-[p]x | I]; same loop / solve / convergence as A.1.  Both clouds must carry normals (as they always do

@@ -65,6 +65,12 @@ def lib():
         L.orc_icp_generalized.restype = C.c_int
         L.orc_icp_generalized.argtypes = [_dp, _dp, C.c_size_t, _dp, _dp, C.c_size_t, C.c_void_p, C.c_double, _dp, C.c_int, C.c_double,
                                           C.c_double, C.c_double, C.POINTER(IcpResult)]
+        L.orc_icp_point_to_point.restype = C.c_int
+        L.orc_icp_point_to_point.argtypes = [_dp, C.c_size_t, _dp, C.c_size_t, C.c_void_p, C.c_double, _dp, C.c_int, C.c_double, C.c_double,
+                                             C.POINTER(IcpResult)]
+        L.orc_umeyama_update.restype = C.c_int
+        L.orc_umeyama_update.argtypes = [_dp, C.c_size_t, _dp, _ip, _dp]
+        L.orc_svd3.argtypes = [_dp, _dp, _dp, _dp]
         L.orc_gicp_jtj_jtr.argtypes = [_dp, _dp, C.c_size_t, _dp, _dp, _ip, _dp, _dp]
         L.orc_covariance_from_normal.argtypes = [_dp, C.c_double, _dp]
         L.orc_estimate_normals.argtypes = [_dp, C.c_size_t, C.c_double, C.c_int, _dp]
@@ -196,6 +202,36 @@ def icp_point_to_plane(src, tgt, nrm, max_corr, init=None, max_iter=30, rel_fitn
         raise RuntimeError(f"orc_icp_point_to_plane rc={rc}")
     return dict(transformation=from_colmajor(out.transformation), fitness=out.fitness, inlier_rmse=out.inlier_rmse,
                 iterations=out.iterations, converged=bool(out.converged), n_corr=int(out.n_corr))
+
+
+def icp_point_to_point(src, tgt, max_corr, init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6, tree: KDTree | None = None):
+    src, sp = _d(src)
+    tgt, tp = _d(tgt)
+    init = np.eye(4) if init is None else init
+    Tc, ip = _d(colmajor(init))
+    out = IcpResult()
+    rc = lib().orc_icp_point_to_point(sp, len(src), tp, len(tgt), tree.h if tree is not None else None, max_corr, ip, max_iter,
+                                      rel_fitness, rel_rmse, C.byref(out))
+    if rc != 0:
+        raise RuntimeError(f"orc_icp_point_to_point rc={rc}")
+    return dict(transformation=from_colmajor(out.transformation), fitness=out.fitness, inlier_rmse=out.inlier_rmse,
+                iterations=out.iterations, converged=bool(out.converged), n_corr=int(out.n_corr))
+
+
+def umeyama_update(P, tgt, corr):
+    P, pp = _d(P)
+    tgt, tp = _d(tgt)
+    corr = np.ascontiguousarray(corr, np.int32)
+    U = np.zeros(16)
+    lib().orc_umeyama_update(pp, len(P), tp, corr.ctypes.data_as(_ip), U.ctypes.data_as(_dp))
+    return from_colmajor(U)
+
+
+def svd3(A):
+    A, ap = _d(np.asarray(A, dtype=np.float64).reshape(9))
+    U, d, V = np.zeros(9), np.zeros(3), np.zeros(9)
+    lib().orc_svd3(ap, U.ctypes.data_as(_dp), d.ctypes.data_as(_dp), V.ctypes.data_as(_dp))
+    return U.reshape(3, 3), d, V.reshape(3, 3)
 
 
 def icp_generalized(src, src_nrm, tgt, tgt_nrm, max_corr, init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6, epsilon=1e-3,

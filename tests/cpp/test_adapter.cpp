@@ -71,7 +71,10 @@ static void noGpuChecks() {
   CHECK(dynamic_cast<RegistrationIcpGeneralized*>(g.get()) != nullptr);
   CHECK(dynamic_cast<RegistrationIcpGeneralized*>(g.get())->icpConvergenceCriteria_.max_iteration_ == 17);
   p.regType_ = CloudRegistrationType::PointToPointIcp;
-  CHECK(throws([&] { cloudRegistrationFactory(p); }));
+  auto pp = cloudRegistrationFactory(p);
+  CHECK(dynamic_cast<RegistrationIcpPointToPoint*>(pp.get()) != nullptr);
+  CHECK(dynamic_cast<RegistrationIcpPointToPoint*>(pp.get())->maxCorrespondenceDistance_ == 0.7);
+  CHECK(dynamic_cast<RegistrationIcpPointToPoint*>(pp.get())->icpConvergenceCriteria_.max_iteration_ == 17);
   p.regType_ = static_cast<CloudRegistrationType>(42);
   CHECK(throws([&] { cloudRegistrationFactory(p); }));
   ScanCroppingParameters cp;

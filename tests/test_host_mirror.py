@@ -33,8 +33,8 @@ def test_cloud_registration_factory_copies_parameters():
     g = cloudRegistrationFactory(p)
     assert type(g).__name__ == "RegistrationIcpGeneralized" and g.maxCorrespondenceDistance_ == 0.7 and g.icpConvergenceCriteria_.max_iteration_ == 17
     p.regType_ = P.CloudRegistrationType.PointToPointIcp
-    with pytest.raises(NotImplementedError):  # next row: fail loudly, never fall back to something else
-        cloudRegistrationFactory(p)
+    pp = cloudRegistrationFactory(p)  # CloudRegistration.cpp:76-81: only the distance and max_iteration_ are taken over
+    assert type(pp).__name__ == "RegistrationIcpPointToPoint" and pp.maxCorrespondenceDistance_ == 0.7 and pp.icpConvergenceCriteria_.max_iteration_ == 17
     p.regType_ = 42
     with pytest.raises(RuntimeError, match="unknown type"):
         cloudRegistrationFactory(p)

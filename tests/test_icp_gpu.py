@@ -395,3 +395,89 @@ def test_gicp_full_size_config2(backend_f32, oracle):
     gt_t, gt_r = syn.se3_error(got["transformation"], T_gt)
     print(f"GICP C2 full: vs oracle {dt:.2e} {dr:.2e}; vs truth {gt_t:.2e} {gt_r:.2e}")
     assert gt_t < 5e-3 and gt_r < 5e-4
+
+
+# ---- point-to-point ICP (SURVEY.md 8f rank 1 "trivial variant": CloudRegistration.cpp:69-81) ------------------------------------
+def test_point_to_point_matches_oracle(backend_f64, backend_f32, oracle, small_c2):
+    """[O3D] RegistrationICP + TransformationEstimationPointToPoint (Eigen::umeyama, no scaling): same loop semantics as the oracle
+    for fixed iteration counts and for the default convergence test, in both storage precisions; no normals needed."""
+    src, tgt, _, _ = small_c2
+    for kw in (dict(max_iter=8, rel_fitness=0.0, rel_rmse=0.0), dict(max_iter=40), dict(max_iter=0), dict(max_iter=1, rel_fitness=0.0, rel_rmse=0.0)):
+        ref = oracle.icp_point_to_point(src, tgt, 1.0, **kw)
+        got = backend_f64.icp_point_to_point(src, tgt, 1.0, **kw)
+        assert got["iterations"] == ref["iterations"] and got["converged"] == ref["converged"], kw
+        assert got["n_corr"] == ref["n_corr"]
+        _check(got, ref, len(src), TOL_T64, TOL_R64)
+        got32 = backend_f32.icp_point_to_point(src, tgt, 1.0, **kw)
+        assert got32["iterations"] == ref["iterations"]
+        _check(got32, ref, len(src), TOL_T, TOL_R)
+    # a non-identity initial guess, and an empty correspondence set (-> identity updates, converges at once)
+    T0 = syn.make_pose((0.1, -0.05, 0.02), (0.5, 0.2, -1.0))
+    ref = oracle.icp_point_to_point(src, tgt, 1.0, init=T0, max_iter=5, rel_fitness=0.0, rel_rmse=0.0)
+    got = backend_f64.icp_point_to_point(src, tgt, 1.0, init=T0, max_iter=5, rel_fitness=0.0, rel_rmse=0.0)
+    _check(got, ref, len(src), TOL_T64, TOL_R64)
+    far = backend_f64.icp_point_to_point(src + 1000.0, tgt, 1.0, max_iter=5)
+    assert far["fitness"] == 0.0 and far["iterations"] == 1 and far["converged"]
+    np.testing.assert_allclose(far["transformation"], np.eye(4), atol=0)
+
+
+def test_point_to_point_device_forms(backend_f32, oracle, small_c2, monkeypatch):
+    """one-shot fused == two-launch == step-wise (bit for bit), the fused map crop, determinism, and a different estimator than
+    point-to-plane (not a silent alias)."""
+    import torch
+
+    src, tgt, nrm, _ = small_c2
+    s, t = backend_f32.upload(src), backend_f32.upload(tgt)  # target without normals
+    backend_f32.build_index(t, 1.0)
+    one = backend_f32.icp_point_to_point_dev(s, t, 1.0, max_iter=6, rel_fitness=0.0, rel_rmse=0.0)
+    again = backend_f32.icp_point_to_point_dev(s, t, 1.0, max_iter=6, rel_fitness=0.0, rel_rmse=0.0)
+    np.testing.assert_array_equal(one["transformation"], again["transformation"])
+    rec = torch.zeros(32, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    backend_f32.icp_begin(s, t, 1.0, max_iter=6, rel_fitness=0.0, rel_rmse=0.0, method=backend.ICP_POINT_TO_POINT)
+    for _ in range(7):
+        backend_f32.icp_accumulate(0, len(src), rec.data_ptr())
+        backend_f32.icp_update(rec.data_ptr(), len(src))
+    step = backend_f32.icp_finish()
+    np.testing.assert_array_equal(step["transformation"], one["transformation"])
+    monkeypatch.setenv("O3DS_ICP_MODE", "launch")
+    be2 = backend.Backend(0, backend.PRECISION_F32)
+    try:
+        two = be2.icp_point_to_point(src, tgt, 1.0, max_iter=6, rel_fitness=0.0, rel_rmse=0.0)
+        np.testing.assert_array_equal(two["transformation"], one["transformation"])
+    finally:
+        be2.close()
+    with pytest.raises(backend.BackendError):  # point-to-plane on the same normal-less target must still fail loudly
+        backend_f32.icp_point_to_plane_dev(s, t, 1.0, max_iter=2)
+    tn = backend_f32.upload(tgt, nrm)
+    p2plane = backend_f32.icp_point_to_plane_dev(s, tn, 1.0, max_iter=6, rel_fitness=0.0, rel_rmse=0.0)
+    assert not np.array_equal(p2plane["transformation"], one["transformation"])
+    crop_o = oracle.make_crop(oracle.CROP_MAX_RADIUS, center=(1.0, -2.0, 0.0), rmax=20.0)
+    keep = oracle.crop_indices(tgt, crop_o)
+    ref = oracle.icp_point_to_point(src, tgt[keep], 1.0, max_iter=5, rel_fitness=0.0, rel_rmse=0.0)
+    crop = backend.make_crop(backend.CROP_MAX_RADIUS, center=(1.0, -2.0, 0.0), rmax=20.0)
+    got = backend_f32.icp_point_to_point_dev(s, t, 1.0, max_iter=5, rel_fitness=0.0, rel_rmse=0.0, target_crop=crop)
+    _check(got, ref, len(src), TOL_T, TOL_R)
+    for c in (s, t, tn):
+        backend_f32.free(c)
+
+
+def test_point_to_point_through_the_reference_named_classes(backend_f32, oracle, small_c2):
+    from open3d_slam_amd import parameters as P
+    from open3d_slam_amd.cloud_registration import cloudRegistrationFactory
+    from open3d_slam_amd.pointcloud import PointCloud
+
+    src, tgt, _, _ = small_c2
+    p = P.CloudRegistrationParameters()
+    p.regType_ = P.CloudRegistrationType.PointToPointIcp
+    p.icp_ = P.IcpParameters(maxNumIter_=25, maxCorrespondenceDistance_=1.0, knn_=20, maxDistanceKnn_=3.0)
+    reg = cloudRegistrationFactory(p)
+    a, b = PointCloud.from_numpy(backend_f32, src), PointCloud.from_numpy(backend_f32, tgt)
+    reg.estimateNormalsOrCovariancesIfNeeded(b)  # no-op for this estimator
+    assert not b.HasNormals()
+    r = reg.registerClouds(a, b, np.eye(4))
+    ref = oracle.icp_point_to_point(src, tgt, 1.0, max_iter=25)
+    dt, dr = syn.se3_error(r.transformation_, ref["transformation"])
+    assert dt <= TOL_T and dr <= TOL_R and abs(r.fitness_ - ref["fitness"]) <= 4.0 / len(src)
+    a.release()
+    b.release()

@@ -325,3 +325,47 @@ def test_gicp_c_oracle_equals_numpy_restatement(oracle):
     np.testing.assert_allclose(b1, b2, rtol=1e-9, atol=1e-9)
     with pytest.raises(RuntimeError):
         oracle.icp_generalized(src, None, tgt, nrm, 1.0)
+
+
+# ---- point-to-point ICP ("trivial variant": CloudRegistration.cpp:69-74) ---------------------------------
+def test_svd3_known_answers(oracle):
+    rng = np.random.default_rng(5)
+    for A in (rng.normal(size=(3, 3)), np.diag([3.0, 2.0, 1.0]), np.outer([1.0, 2.0, 3.0], [0.5, -1.0, 2.0]), np.zeros((3, 3)),
+              np.array([[0.0, 1.0, 0.0], [-1.0, 0.0, 0.0], [0.0, 0.0, 1.0]]) @ np.diag([5.0, 5.0, 1e-12])):
+        U, d, V = oracle.svd3(A)
+        np.testing.assert_allclose(U @ np.diag(d) @ V.T, A, atol=1e-12)
+        np.testing.assert_allclose(U.T @ U, np.eye(3), atol=1e-12)
+        np.testing.assert_allclose(V.T @ V, np.eye(3), atol=1e-12)
+        assert d[0] >= d[1] >= d[2] >= 0.0
+        np.testing.assert_allclose(d, np.linalg.svd(A, compute_uv=False), atol=1e-12)
+
+
+def test_umeyama_recovers_a_known_rigid_motion(oracle):
+    rng = np.random.default_rng(6)
+    P = rng.normal(size=(200, 3)) * 5.0
+    T = syn.make_pose((0.4, -0.3, 0.2), (3.0, -2.0, 5.0))
+    Q = P @ T[:3, :3].T + T[:3, 3]
+    corr = np.arange(200, dtype=np.int32)
+    corr[::7] = -1  # unmatched points are ignored
+    U = oracle.umeyama_update(P, Q, corr)
+    np.testing.assert_allclose(U, T, atol=1e-12)
+    np.testing.assert_allclose(U, no.umeyama_update(P, Q, corr), atol=1e-12)
+    # a reflection-prone case: coplanar points, the det(U) det(V) < 0 branch must still return a rotation
+    Pp = P.copy()
+    Pp[:, 2] = 0.0
+    Qp = Pp @ T[:3, :3].T + T[:3, 3]
+    Up = oracle.umeyama_update(Pp, Qp, corr)
+    assert abs(np.linalg.det(Up[:3, :3]) - 1.0) < 1e-12
+    np.testing.assert_allclose(Up, T, atol=1e-9)
+    assert np.array_equal(oracle.umeyama_update(P, Q, np.full(200, -1, np.int32)), np.eye(4))  # empty set -> identity
+
+
+def test_icp_point_to_point_c_matches_numpy(oracle, small_c2):
+    src, tgt, _, T_gt = small_c2
+    for kw in (dict(max_iter=8, rel_fitness=0.0, rel_rmse=0.0), dict(max_iter=40)):
+        a = oracle.icp_point_to_point(src, tgt, 1.0, **kw)
+        b = no.icp_point_to_point(src, tgt, 1.0, **kw)
+        assert a["iterations"] == b["iterations"] and a["n_corr"] == b["n_corr"]
+        np.testing.assert_allclose(a["transformation"], b["transformation"], atol=1e-9)  # (acos-based angles resolve only ~1e-8)
+    dt, dr = syn.se3_error(a["transformation"], T_gt)
+    assert dt < 0.15 and dr < 0.01  # point-to-point on a sampled map converges more slowly / less tightly than point-to-plane
