@@ -5,14 +5,14 @@ OUT=$R/gpurun_out
 mkdir -p $OUT
 cd $R
 { echo "nproc=$(nproc)"; lscpu | grep -E "Model name|Socket|Core|Thread|MHz" ; } > $OUT/host.txt 2>&1
-timeout 1500 python -m pytest tests -m gpu -q -rA --timeout 900 2>&1 | tail -150 > $OUT/pytest_gpu.log
+timeout 600 python -m pytest tests -m gpu -q -rA --timeout 120 2>&1 | tail -150 > $OUT/pytest_gpu.log
 echo "pytest rc=${PIPESTATUS[0]}" >> $OUT/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/smoke.log
-timeout 600 python bench.py --steps 50 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
+timeout 300 python bench.py --steps 50 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 echo "bench rc=$?" >> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/prof $OUT/pmc_fetch $OUT/pmc_write
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline > $OUT/rocprof_bench.json 2> $OUT/rocprof.err
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline > $OUT/rocprof_bench.json 2> $OUT/rocprof.err
 echo "rocprof rc=$?" >> $OUT/rocprof.err
 python $R/scripts/prof_summary.py $OUT/prof/bench_results.db $OUT/rocprof_stats.txt > /dev/null
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- python $R/bench.py --steps 10 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
