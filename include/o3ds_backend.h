@@ -149,6 +149,14 @@ int o3ds_icp_point_to_point(o3ds_handle h, const double* src_xyz, size_t n_src, 
                             const double init[16], const o3ds_icp_params* params, o3ds_icp_result* out);
 int o3ds_icp_point_to_point_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3ds_crop* target_crop, const double init[16],
                                 const o3ds_icp_params* params, o3ds_icp_result* out);
+/* [O3D] GetInformationMatrixFromPointClouds(source, target, max_correspondence_distance, transformation) (call sites
+ * constraint_builders.cpp:70-73, PlaceRecognition.cpp:148-149): one correspondence pass under T (same exact 1-NN search as the
+ * ICP passes), Lambda = sum over the matched TARGET points q of G^T G, G = [-[q]x | I].  information: 36 doubles; a symmetric
+ * matrix, so row- and column-major coincide (Eigen::Matrix6d::data() can be passed). */
+int o3ds_information_matrix(o3ds_handle h, const double* src_xyz, size_t n_src, const double* tgt_xyz, size_t n_tgt, const double T[16],
+                            double max_correspondence_distance, double information[36]);
+int o3ds_information_matrix_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3ds_crop* target_crop, const double T[16],
+                                double max_correspondence_distance, double information[36]);
 /* epsilon of the plane-to-plane covariance model (default 1e-3, Open3D's default) */
 int o3ds_set_gicp_epsilon(o3ds_handle h, double epsilon);
 

@@ -61,6 +61,8 @@ SIGNATURES = {
                                           C.POINTER(IcpResult)]),
     "o3ds_icp_point_to_plane_dev": (C.c_int, [_H, _CL, _CL, C.POINTER(Crop), _dp, C.POINTER(IcpParams), C.POINTER(IcpResult)]),
     "o3ds_icp_register_dev": (C.c_int, [_H, _CL, _CL, C.POINTER(Crop), _dp, C.POINTER(IcpParams), C.POINTER(IcpResult)]),
+    "o3ds_information_matrix": (C.c_int, [_H, _dp, C.c_size_t, _dp, C.c_size_t, _dp, C.c_double, _dp]),
+    "o3ds_information_matrix_dev": (C.c_int, [_H, _CL, _CL, C.POINTER(Crop), _dp, C.c_double, _dp]),
     "o3ds_icp_point_to_point": (C.c_int, [_H, _dp, C.c_size_t, _dp, C.c_size_t, _dp, C.POINTER(IcpParams), C.POINTER(IcpResult)]),
     "o3ds_icp_point_to_point_dev": (C.c_int, [_H, _CL, _CL, C.POINTER(Crop), _dp, C.POINTER(IcpParams), C.POINTER(IcpResult)]),
     "o3ds_icp_generalized": (C.c_int, [_H, _dp, _dp, C.c_size_t, _dp, _dp, C.c_size_t, _dp, C.POINTER(IcpParams), C.POINTER(IcpResult)]),
@@ -224,6 +226,22 @@ class Backend:
         self._ck(self.lib.o3ds_icp_point_to_plane_dev(self.h, source, target, C.byref(target_crop) if target_crop else None, ip,
                                                       C.byref(p), C.byref(out)))
         return self._result(out)
+
+    def information_matrix(self, src, tgt, max_corr, T=None) -> np.ndarray:
+        """[O3D] GetInformationMatrixFromPointClouds on host buffers."""
+        src, sp = _d(np.asarray(src).reshape(-1, 3))
+        tgt, tp = _d(np.asarray(tgt).reshape(-1, 3))
+        T0, ip = _d(colmajor(np.eye(4) if T is None else T))
+        out = np.zeros(36)
+        self._ck(self.lib.o3ds_information_matrix(self.h, sp, len(src), tp, len(tgt), ip, float(max_corr), out.ctypes.data_as(_dp)))
+        return out.reshape(6, 6)
+
+    def information_matrix_dev(self, source: int, target: int, max_corr, T=None, target_crop: Crop | None = None) -> np.ndarray:
+        T0, ip = _d(colmajor(np.eye(4) if T is None else T))
+        out = np.zeros(36)
+        self._ck(self.lib.o3ds_information_matrix_dev(self.h, source, target, C.byref(target_crop) if target_crop else None, ip,
+                                                      float(max_corr), out.ctypes.data_as(_dp)))
+        return out.reshape(6, 6)
 
     def icp_point_to_point(self, src, tgt, max_corr, init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6):
         src, sp = _d(np.asarray(src).reshape(-1, 3))

@@ -794,6 +794,61 @@ int o3ds_icp_point_to_plane_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud tar
   return o3ds_icp_register_dev(h, source, target, target_crop, init, &p, out);
 }
 
+int o3ds_information_matrix_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3ds_crop* target_crop, const double T[16],
+                                double max_correspondence_distance, double information[36]) {
+  CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
+  if (!T || !information) return fail(h, O3DS_ERR_INVALID_ARG, "information_matrix: null argument");
+  o3ds_icp_params p{};
+  p.max_correspondence_distance = max_correspondence_distance;
+  p.max_iteration = 0;
+  p.method = O3DS_ICP_POINT_TO_POINT;  // validation as for point-to-point: no normals needed
+  int rc = begin_session(h, source, target, target_crop, T, &p);
+  if (rc) return rc;
+  h->session = false;
+  IcpPassArgs a = h->pass;
+  a.method = kMethodInformation;
+  double* d_record = nullptr;
+  TMP_ALLOC(d_record, sizeof(double) * kRec);
+  const int nb = pass_blocks(h, a.count);
+  if (h->session_precision == O3DS_PRECISION_F64)
+    launch_accumulate<P4d>(h, a, h->session_crop, nb);
+  else
+    launch_accumulate<P4f>(h, a, h->session_crop, nb);
+  icp_reduce_kernel<<<1, kUpdBlock, 0, h->stream>>>(h->d_partials, nb, h->d_state, d_record);
+  HIP_TRY(hipGetLastError());
+  double rec[kRec];
+  HIP_TRY(hipMemcpyAsync(rec, d_record, sizeof(rec), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  // Lambda = [[ |q|^2 I - q q^T , [q]x ], [ [q]x^T , I ]] summed over the matched target points
+  const double xx = rec[0], xy = rec[1], xz = rec[2], yy = rec[3], yz = rec[4], zz = rec[5], sx = rec[6], sy = rec[7], sz = rec[8];
+  const double m = rec[kRecCount];
+  const double L[6][6] = {{yy + zz, -xy, -xz, 0.0, -sz, sy}, {-xy, xx + zz, -yz, sz, 0.0, -sx}, {-xz, -yz, xx + yy, -sy, sx, 0.0},
+                          {0.0, sz, -sy, m, 0.0, 0.0},       {-sz, 0.0, sx, 0.0, m, 0.0},      {sy, -sx, 0.0, 0.0, 0.0, m}};
+  for (int r = 0; r < 6; ++r)
+    for (int c = 0; c < 6; ++c) information[r * 6 + c] = L[r][c];
+  return O3DS_OK;
+}
+
+int o3ds_information_matrix(o3ds_handle h, const double* src_xyz, size_t n_src, const double* tgt_xyz, size_t n_tgt, const double T[16],
+                            double max_correspondence_distance, double information[36]) {
+  CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
+  if (!T || !information) return fail(h, O3DS_ERR_INVALID_ARG, "information_matrix: null argument");
+  if (!(max_correspondence_distance > 0.0)) return fail(h, O3DS_ERR_INVALID_ARG, "Invalid max_correspondence_distance.");
+  if (n_tgt == 0) return fail(h, O3DS_ERR_EMPTY, "information_matrix: empty target");
+  o3ds_cloud s = 0, t = 0;
+  int rc = o3ds_cloud_upload(h, src_xyz, nullptr, n_src, &s);
+  if (rc) return rc;
+  rc = o3ds_cloud_upload(h, tgt_xyz, nullptr, n_tgt, &t);
+  if (!rc) rc = o3ds_information_matrix_dev(h, s, t, nullptr, T, max_correspondence_distance, information);
+  const std::string keep = h->err;
+  (void)o3ds_cloud_free(h, s);
+  if (t) (void)o3ds_cloud_free(h, t);
+  if (rc) h->err = keep;
+  return rc;
+}
+
 int o3ds_icp_point_to_point_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3ds_crop* target_crop, const double init[16],
                                 const o3ds_icp_params* params, o3ds_icp_result* out) {
   CHECK_HANDLE(h);

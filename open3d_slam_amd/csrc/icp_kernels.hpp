@@ -543,6 +543,11 @@ __device__ const unsigned char kTermB[kRec] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 
 // d2, 0}; record [0..8] = sum q_a p_b (row a, column b), [9..11] = sum p, [12..14] = sum q, [28] = count, [29] = sum d2.
 __device__ const unsigned char kTermA_p2p[kRec] = {3, 3, 3, 4, 4, 4, 5, 5, 5, 0, 1, 2, 3, 4, 5, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 7, 8, 9, 9};
 __device__ const unsigned char kTermB_p2p[kRec] = {0, 1, 2, 0, 1, 2, 0, 1, 2, 7, 7, 7, 7, 7, 7, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 7, 7, 9, 9};
+// [O3D] GetInformationMatrixFromPointClouds (same slots as point-to-point): record [0..5] = sum of q q^T (xx, xy, xz, yy, yz, zz),
+// [6..8] = sum q, [28] = count, [29] = sum d2; the 6x6 is assembled from these ten numbers on the host.
+constexpr int kMethodInformation = 3;  // internal value of IcpPassArgs::method, not an o3ds_icp_method
+__device__ const unsigned char kTermA_inf[kRec] = {3, 3, 3, 4, 4, 5, 3, 4, 5, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 7, 8, 9, 9};
+__device__ const unsigned char kTermB_inf[kRec] = {3, 4, 5, 4, 5, 5, 7, 7, 7, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 7, 7, 9, 9};
 
 // Workgroup = BLOCK threads = BLOCK/G queries x G lanes for the search, then (32 record terms) x (BLOCK/32 query slices) for the
 // accumulation: one f64 accumulator per thread instead of 30, so the kernel stays small in registers and the chip can
@@ -683,8 +688,10 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
                t13 = to_sgpr(Tm[13]), t23 = to_sgpr(Tm[14]);
   const int gl = threadIdx.x & (kGroup - 1), ql = threadIdx.x / kGroup;
   const int term = threadIdx.x & 31, qs = threadIdx.x >> 5;
-  const bool p2p = a.method == O3DS_ICP_POINT_TO_POINT;  // uniform
-  const int ta = p2p ? kTermA_p2p[term] : kTermA[term], tb = p2p ? kTermB_p2p[term] : kTermB[term];
+  const bool inf = a.method == kMethodInformation;
+  const bool p2p = a.method == O3DS_ICP_POINT_TO_POINT || inf;  // uniform: records built from the points themselves, no normals
+  const int ta = inf ? kTermA_inf[term] : (p2p ? kTermA_p2p[term] : kTermA[term]);
+  const int tb = inf ? kTermB_inf[term] : (p2p ? kTermB_p2p[term] : kTermB[term]);
   double acc = 0.0;
   const size_t n_batches = (a.count + kQPB - 1) / kQPB;
   static_assert(sizeof(FarItem<P4>) <= kStride * sizeof(double), "a parked far query fits its record slot");

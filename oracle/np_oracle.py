@@ -104,6 +104,18 @@ def icp_point_to_point(src, tgt, max_corr, init=None, max_iter=30, rel_fitness=1
     return dict(transformation=T, fitness=fit, inlier_rmse=rmse, iterations=it, n_corr=nc)
 
 
+def information_matrix(src, tgt, max_corr, T=None):
+    """[O3D] GetInformationMatrixFromPointClouds: sum of G^T G over matched target points, G = [-[q]x | I]."""
+    T = np.eye(4) if T is None else np.asarray(T, dtype=np.float64)
+    P = src @ T[:3, :3].T + T[:3, 3]
+    corr, _, _, _ = evaluate(cKDTree(tgt, leafsize=15), P, max_corr)
+    q = tgt[corr[corr >= 0]]
+    x, y, z = q[:, 0], q[:, 1], q[:, 2]
+    o, l = np.zeros_like(x), np.ones_like(x)
+    G = np.stack([np.stack([o, z, -y, l, o, o], 1), np.stack([-z, o, x, o, l, o], 1), np.stack([y, -x, o, o, o, l], 1)], 1)  # m x 3 x 6
+    return np.einsum("mra,mrb->ab", G, G)
+
+
 def estimate_normals(pts, radius, max_nn):
     tree = cKDTree(pts, leafsize=15)
     d, j = tree.query(pts, k=max_nn, distance_upper_bound=radius)

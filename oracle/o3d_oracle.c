@@ -661,6 +661,40 @@ int orc_icp_point_to_point(const double* src, size_t n, const double* tgt, size_
   return 0;
 }
 
+/* ------------------------------------------------------------------ A.9
+ * [O3D] GetInformationMatrixFromPointClouds(source, target, r, T) (call sites src/constraint_builders.cpp:70-73,
+ * src/PlaceRecognition.cpp:148-149): transform the source by T, 1-NN within r as in A.2, then Lambda = sum G^T G over the matched
+ * TARGET points q = (x,y,z), G = [[0,z,-y,1,0,0],[-z,0,x,0,1,0],[y,-x,0,0,0,1]].  out: row-major 6x6. */
+int orc_information_matrix(const double* src, size_t n, const double* tgt, size_t N, const orc_kdtree* tree, double max_corr,
+                           const double T[16], double out[36]) {
+  if (max_corr <= 0.0) return -1;
+  orc_kdtree* own = NULL;
+  if (!tree) {
+    own = orc_kdtree_build(tgt, N);
+    tree = own;
+  }
+  double* P = (double*)malloc(sizeof(double) * 3 * (n ? n : 1));
+  int32_t* corr = (int32_t*)malloc(sizeof(int32_t) * (n ? n : 1));
+  memcpy(P, src, sizeof(double) * 3 * n);
+  if (!is_identity16(T)) orc_transform_points(P, n, T);
+  double fit, rmse;
+  uint64_t nc;
+  orc_evaluate(tree, P, n, max_corr, corr, NULL, &fit, &rmse, &nc);
+  for (int k = 0; k < 36; ++k) out[k] = 0.0;
+  for (size_t i = 0; i < n; ++i) {
+    if (corr[i] < 0) continue;
+    const double* q = tgt + 3 * (size_t)corr[i];
+    const double G[3][6] = {{0, q[2], -q[1], 1, 0, 0}, {-q[2], 0, q[0], 0, 1, 0}, {q[1], -q[0], 0, 0, 0, 1}};
+    for (int r = 0; r < 3; ++r)
+      for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 6; ++b) out[a * 6 + b] += G[r][a] * G[r][b];
+  }
+  free(P);
+  free(corr);
+  if (own) orc_kdtree_free(own);
+  return 0;
+}
+
 /* ------------------------------------------------------------------ A.8 Generalized ICP
  * [O3D] GeneralizedICP.cpp: GetRotationFromE1ToX, InitializePointCloudForGeneralizedICP,
  * TransformationEstimationForGeneralizedICP::ComputeTransformation; reference call site src/CloudRegistration.cpp:16-21. */

@@ -83,6 +83,11 @@ int orc_umeyama_update(const double* P, size_t n, const double* tgt, const int32
 /* A = U diag(d) V^T (row-major 3x3), d descending */
 void orc_svd3(const double A[9], double U[9], double d[3], double V[9]);
 
+/* A.9 GetInformationMatrixFromPointClouds (call sites src/constraint_builders.cpp:70-73, src/PlaceRecognition.cpp:148-149);
+ * out: row-major 6x6 (rotation block first, as Open3D: "I comes first" refers to G = [-[q]x | I]) */
+int orc_information_matrix(const double* src, size_t n, const double* tgt, size_t N, const orc_kdtree* tree, double max_corr,
+                           const double T[16], double out[36]);
+
 /* A.8 RegistrationGeneralizedICP (call site src/CloudRegistration.cpp:16-21): covariances from normals
  * (C = Rx diag(eps,1,1) Rx^T, Rx = GetRotationFromE1ToX(normal)), per pair M = Ct + R Cs R^T, W = M^-1/2, residual W d (3 rows),
  * Jacobian rows W [-[p]x | I]; same loop / solve / convergence as A.1.  Both clouds must carry normals (as they always do

@@ -71,6 +71,8 @@ def lib():
         L.orc_umeyama_update.restype = C.c_int
         L.orc_umeyama_update.argtypes = [_dp, C.c_size_t, _dp, _ip, _dp]
         L.orc_svd3.argtypes = [_dp, _dp, _dp, _dp]
+        L.orc_information_matrix.restype = C.c_int
+        L.orc_information_matrix.argtypes = [_dp, C.c_size_t, _dp, C.c_size_t, C.c_void_p, C.c_double, _dp, _dp]
         L.orc_gicp_jtj_jtr.argtypes = [_dp, _dp, C.c_size_t, _dp, _dp, _ip, _dp, _dp]
         L.orc_covariance_from_normal.argtypes = [_dp, C.c_double, _dp]
         L.orc_estimate_normals.argtypes = [_dp, C.c_size_t, C.c_double, C.c_int, _dp]
@@ -232,6 +234,17 @@ def svd3(A):
     U, d, V = np.zeros(9), np.zeros(3), np.zeros(9)
     lib().orc_svd3(ap, U.ctypes.data_as(_dp), d.ctypes.data_as(_dp), V.ctypes.data_as(_dp))
     return U.reshape(3, 3), d, V.reshape(3, 3)
+
+
+def information_matrix(src, tgt, max_corr, T=None, tree: KDTree | None = None):
+    src, sp = _d(src)
+    tgt, tp = _d(tgt)
+    Tc, ip = _d(colmajor(np.eye(4) if T is None else T))
+    out = np.zeros(36)
+    rc = lib().orc_information_matrix(sp, len(src), tp, len(tgt), tree.h if tree is not None else None, max_corr, ip, out.ctypes.data_as(_dp))
+    if rc != 0:
+        raise RuntimeError(f"orc_information_matrix rc={rc}")
+    return out.reshape(6, 6)
 
 
 def icp_generalized(src, src_nrm, tgt, tgt_nrm, max_corr, init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6, epsilon=1e-3,

@@ -8,8 +8,6 @@ cd $R
 timeout 600 python -m pytest tests -m gpu -q -rA --timeout 120 2>&1 | tail -150 > $OUT/pytest_gpu.log
 echo "pytest rc=${PIPESTATUS[0]}" >> $OUT/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/smoke.log
-timeout 300 python bench.py --steps 50 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
-echo "bench rc=$?" >> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/prof $OUT/pmc_fetch $OUT/pmc_write
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline > $OUT/rocprof_bench.json 2> $OUT/rocprof.err
@@ -18,4 +16,8 @@ python $R/scripts/prof_summary.py $OUT/prof/bench_results.db $OUT/rocprof_stats.
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- python $R/bench.py --steps 10 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- python $R/bench.py --steps 10 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 python $R/scripts/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic.json > /dev/null
+cp $OUT/pmc_traffic.json $R/profiles/pmc_traffic_latest.json  # bench.py reports roofline.traffic from this file
+cd $R
+timeout 300 python bench.py --steps 50 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
+echo "bench rc=$?" >> $OUT/bench.err
 grep -E "passed|failed" $OUT/pytest_gpu.log | tail -3; tail -2 $OUT/smoke.log; cat $OUT/bench.json; tail -2 $OUT/bench.err; head -5 $OUT/rocprof_stats.txt; cat $OUT/pmc_traffic.json

@@ -481,3 +481,27 @@ def test_point_to_point_through_the_reference_named_classes(backend_f32, oracle,
     assert dt <= TOL_T and dr <= TOL_R and abs(r.fitness_ - ref["fitness"]) <= 4.0 / len(src)
     a.release()
     b.release()
+
+
+# ---- information matrix (constraint_builders.cpp:70-73, PlaceRecognition.cpp:148-149) ----------------
+def test_information_matrix_matches_oracle(backend_f64, backend_f32, oracle, small_c2):
+    src, tgt, nrm, T_gt = small_c2
+    for T in (T_gt, np.eye(4)):
+        ref = oracle.information_matrix(src, tgt, 1.0, T)
+        got = backend_f64.information_matrix(src, tgt, 1.0, T)
+        np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-7)  # same correspondences, f64 sums in another order
+        assert got[3, 3] == ref[3, 3]  # the correspondence count is exact
+        got32 = backend_f32.information_matrix(src, tgt, 1.0, T)
+        np.testing.assert_allclose(got32, ref, rtol=0, atol=2e-5 * np.abs(ref).max())  # f32 point storage: relative to the matrix scale
+    s, t = backend_f64.upload(src), backend_f64.upload(tgt, nrm)
+    backend_f64.build_index(t, 1.0)
+    dev = backend_f64.information_matrix_dev(s, t, 1.0, T_gt)
+    np.testing.assert_array_equal(dev, backend_f64.information_matrix(src, tgt, 1.0, T_gt))
+    # a registration before and after leaves it unchanged (the match cache of the ICP loop is not trusted across sessions)
+    backend_f64.icp_point_to_plane_dev(s, t, 1.0, max_iter=3)
+    np.testing.assert_array_equal(backend_f64.information_matrix_dev(s, t, 1.0, T_gt), dev)
+    assert np.array_equal(backend_f64.information_matrix(src + 1000.0, tgt, 1.0), np.zeros((6, 6)))
+    with pytest.raises(backend.BackendError):
+        backend_f64.information_matrix(src, tgt, 0.0)
+    backend_f64.free(s)
+    backend_f64.free(t)

@@ -369,3 +369,19 @@ def test_icp_point_to_point_c_matches_numpy(oracle, small_c2):
         np.testing.assert_allclose(a["transformation"], b["transformation"], atol=1e-9)  # (acos-based angles resolve only ~1e-8)
     dt, dr = syn.se3_error(a["transformation"], T_gt)
     assert dt < 0.15 and dr < 0.01  # point-to-point on a sampled map converges more slowly / less tightly than point-to-plane
+
+
+# ---- information matrix ---------------------------------------------------------------------------------
+def test_information_matrix_c_matches_numpy_and_a_known_answer(oracle, small_c2):
+    src, tgt, _, T_gt = small_c2
+    a = oracle.information_matrix(src, tgt, 1.0, T_gt)
+    b = no.information_matrix(src, tgt, 1.0, T_gt)
+    np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(a, a.T, rtol=0, atol=1e-9)
+    # one pair, q = (1, 2, 3): Lambda = [[|q|^2 I - q q^T, [q]x], [[q]x^T, I]]
+    q = np.array([[1.0, 2.0, 3.0]])
+    L = oracle.information_matrix(q + 0.01, q, 1.0)
+    qx = np.array([[0.0, -3.0, 2.0], [3.0, 0.0, -1.0], [-2.0, 1.0, 0.0]])
+    exp = np.block([[14.0 * np.eye(3) - q.T @ q, qx], [qx.T, np.eye(3)]])
+    np.testing.assert_allclose(L, exp, atol=1e-12)
+    assert np.array_equal(oracle.information_matrix(q + 5.0, q, 1.0), np.zeros((6, 6)))  # no correspondence
