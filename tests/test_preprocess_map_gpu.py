@@ -264,3 +264,56 @@ def test_full_scan_pipeline_config1(backend_f32, oracle):
     assert abs(got["transformation"][0, 3] + 0.3) < 0.05
     for c in (ca, cb, va, vb):
         backend_f32.free(c)
+
+
+def test_full_size_config4_dense_map_fusion_properties(backend_f32):
+    """BASELINE.json configs[4] at full size -- a dense 2 M-point (multi-sensor) scan fused into a map at voxel 0.02 m -- through
+    size-independent properties of Submap::insertScan / voxelizeWithinCroppingVolume (Submap.cpp:54,70-72, helpers.cpp:115-183):
+    the voxel SET equals numpy's, means stay inside their voxels, pass-through points are untouched and come first, the fusion
+    is idempotent, and sum(count x mean) reproduces the input sum (linearity)."""
+    import time
+
+    scene = syn.make_scene()
+    pts, nrm = syn.sample_map(scene, 2_000_000, seed=77)
+    voxel, center, rmax = 0.02, (2.0, -1.0, 0.0), 18.0
+    pts32 = pts.astype(np.float32).astype(np.float64)  # what the device stores
+    m = backend_f32.upload(np.zeros((0, 3)))
+    s = backend_f32.upload(pts, nrm)
+    crop = backend.make_crop(backend.CROP_MAX_RADIUS, center=center, rmax=rmax)
+    backend_f32.synchronize()
+    t0 = time.perf_counter()
+    backend_f32.map_insert_scan(m, s, np.eye(4), voxel, crop, max_corr_hint=0.0)
+    backend_f32.synchronize()
+    dt = time.perf_counter() - t0
+    got, gn = backend_f32.download(m)
+    inside = np.linalg.norm(pts32 - np.array(center), axis=1) <= rmax
+    n_pass = int((~inside).sum())
+    assert 0 < n_pass < len(pts)
+    np.testing.assert_array_equal(got[:n_pass], pts32[~inside])  # pass-through block: first, original order, bit-identical
+    keys_in = np.floor(pts32[inside] * (1.0 / voxel)).astype(np.int64)
+    uniq, inv, cnt = np.unique(keys_in, axis=0, return_inverse=True, return_counts=True)
+    vox = got[n_pass:]
+    assert len(vox) == len(uniq)  # one mean per occupied voxel
+    # a mean of f32 points rounded to f32 can land on a voxel face, so the pairing goes through numpy's exact per-voxel means
+    sums = np.zeros((len(uniq), 3))
+    np.add.at(sums, inv.reshape(-1), pts32[inside])
+    means = sums / cnt[:, None]
+    from scipy.spatial import cKDTree
+
+    d, j = cKDTree(means).query(vox)
+    assert np.array_equal(np.sort(j), np.arange(len(uniq)))  # a bijection onto the occupied voxels
+    assert d.max() < 4e-6  # f32 rounding of a mean of coordinates up to ~40 m
+    # linearity: sum(count x mean) == sum of the inputs (to f32 storage rounding)
+    np.testing.assert_allclose((vox * cnt[j][:, None]).sum(0), pts32[inside].sum(0), rtol=1e-6)
+    # normals are re-normalised means (helpers.cpp:172)
+    nn = np.linalg.norm(gn[n_pass:], axis=1)
+    assert np.all((np.abs(nn - 1.0) < 1e-5) | (nn == 0.0))
+    # idempotence: fusing nothing new leaves the voxel set where it is
+    backend_f32.voxelize_within_volume(m, voxel, crop)
+    again, _ = backend_f32.download(m)
+    assert len(again) == len(got)
+    d2, _ = cKDTree(again[n_pass:]).query(vox)
+    assert d2.max() < 4e-6
+    print(f"config4: {len(pts)} pts -> {len(vox)} voxels + {n_pass} pass-through in {dt*1e3:.2f} ms")
+    backend_f32.free(s)
+    backend_f32.free(m)
