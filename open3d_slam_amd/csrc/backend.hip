@@ -77,7 +77,8 @@ struct o3ds_context {
   bool fused = true;  // O3DS_ICP_MODE=launch selects the two-kernel form (same results bit for bit)
   int* d_nn_cache = nullptr;  // per-query match of the previous pass (bound for the pruned search); grown on demand
   size_t nn_cache_cap = 0;
-  char* d_fused = nullptr;  // [2 states | 2x64 tickets | 2x64 slot records | 2 x kMaxPassBlocks rows]
+  char* d_fused = nullptr;  // [2 states | 3 x kFusedSlots slot records (hi and lo sums)]
+  unsigned long long fused_launches = 0;
   int debug_update = 0;  // O3DS_DEBUG_UPDATE: timing experiments only
   int pass_block = 256;
   int pass_group = 4;
@@ -400,10 +401,9 @@ void launch_accumulate(o3ds_handle h, const IcpPassArgs& a, bool crop, int nbloc
 
 // fused form: byte offsets inside d_fused
 constexpr size_t kFusedStateStride = 256;
-constexpr size_t kFusedTicketsOff = 2 * kFusedStateStride;
-constexpr size_t kFusedSlotsOff = kFusedTicketsOff + 2 * kFusedSlots * sizeof(unsigned int);
-constexpr size_t kFusedRowsOff = kFusedSlotsOff + 2 * (size_t)kFusedSlots * kRec * sizeof(double);
-constexpr size_t kFusedBytes = kFusedRowsOff + 2 * (size_t)kMaxPassBlocks * kRec * sizeof(double);
+constexpr size_t kFusedSlotsOff = 2 * kFusedStateStride;
+constexpr size_t kFusedSlotBufBytes = (size_t)kFusedSlots * kSlotDoubles * sizeof(double);
+constexpr size_t kFusedBytes = kFusedSlotsOff + 3 * kFusedSlotBufBytes;
 static_assert(sizeof(IcpStateDev) <= kFusedStateStride, "state slot too small");
 
 template <typename P4>
@@ -504,6 +504,17 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
   const double r = params->max_correspondence_distance;
   a.r2max = r * r;
   a.method = params->method;
+  {  // bound on the sum of |record terms| -> quantum of the exact record sums (split_exact): 2^53 q_hi >= 8 B
+    const GridDev& g = tgt->grid;
+    const double ex = std::max(std::fabs(g.ox), std::fabs(g.ox + g.nx * g.cell)), ey = std::max(std::fabs(g.oy), std::fabs(g.oy + g.ny * g.cell)),
+                 ez = std::max(std::fabs(g.oz), std::fabs(g.oz + g.nz * g.cell));
+    const double P = std::sqrt(ex * ex + ey * ey + ez * ez) + r;  // a matched source point lies within r of the target's box
+    double B = (double)std::max<size_t>(src->n, 1) * std::max(1.0, P) * std::max(1.0, P) * std::max(1.0, r) * std::max(1.0, r);
+    if (params->method == O3DS_ICP_GENERALIZED) B *= 4.0 * std::max(1.0, 0.5 / h->gicp_epsilon);  // |M^-1| <= 1 / (2 eps)
+    int e = 0;
+    (void)std::frexp(B, &e);             // B < 2^e
+    a.q_hi = std::ldexp(1.0, e + 3 - 53);  // 2^53 q_hi = 8 * 2^e
+  }
   a.kmax = std::max(1, (int)std::ceil(r / tgt->grid.cell));  // a neighbour within r is at most this many cells away
   a.nn_cache = h->d_nn_cache;
   a.n_tgt = (int)tgt->n;
@@ -745,7 +756,7 @@ int o3ds_icp_accumulate(o3ds_handle h, size_t first, size_t count, double* d_rec
       launch_accumulate<P4d>(h, a, h->session_crop, nb);
     else
       launch_accumulate<P4f>(h, a, h->session_crop, nb);
-    icp_reduce_kernel<<<1, kUpdBlock, 0, h->stream>>>(h->d_partials, nb, h->d_state, d_record);
+    icp_reduce_kernel<<<1, kUpdBlock, 0, h->stream>>>(h->d_partials, nb, h->d_state, d_record, a.q_hi);
   }
   HIP_TRY(hipGetLastError());
   return O3DS_OK;
@@ -815,7 +826,7 @@ int o3ds_information_matrix_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud tar
     launch_accumulate<P4d>(h, a, h->session_crop, nb);
   else
     launch_accumulate<P4f>(h, a, h->session_crop, nb);
-  icp_reduce_kernel<<<1, kUpdBlock, 0, h->stream>>>(h->d_partials, nb, h->d_state, d_record);
+  icp_reduce_kernel<<<1, kUpdBlock, 0, h->stream>>>(h->d_partials, nb, h->d_state, d_record, a.q_hi);
   HIP_TRY(hipGetLastError());
   double rec[kRec];
   HIP_TRY(hipMemcpyAsync(rec, d_record, sizeof(rec), hipMemcpyDeviceToHost, h->stream));
@@ -924,7 +935,6 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
     fa.rel_fitness = params->relative_fitness;
     fa.rel_rmse = params->relative_rmse;
     const int nb = std::min(pass_blocks(h, a.count), kMaxPassBlocks);
-    fa.nslots_in = std::min(nb, kFusedSlots);
     fa.init = *h->h_state;
     const int total = params->max_iteration + 2;
     // O3DS_FUSED_TRACE=<file>: phase timestamps of every workgroup of launch 5 (development aid, see scripts/fused_trace.py)
@@ -944,10 +954,11 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
         fa.first = j == 0;
         fa.state_in = last;
         fa.state_out = (IcpStateDev*)(h->d_fused + par * kFusedStateStride);
-        fa.tickets = (unsigned int*)(h->d_fused + kFusedTicketsOff) + par * kFusedSlots;
-        fa.slots_in = (const double*)(h->d_fused + kFusedSlotsOff) + (size_t)(par ^ 1) * kFusedSlots * kRec;
-        fa.slots_out = (double*)(h->d_fused + kFusedSlotsOff) + (size_t)par * kFusedSlots * kRec;
-        fa.rows = (double*)(h->d_fused + kFusedRowsOff) + (size_t)par * kMaxPassBlocks * kRec;
+        // slot buffers rotate with a launch counter that runs across registrations: launch g reads (g-1)%3, adds into g%3, clears (g+1)%3
+        const unsigned long long g = h->fused_launches++;
+        fa.slots_in = (const double*)(h->d_fused + kFusedSlotsOff + ((g + 2) % 3) * kFusedSlotBufBytes);
+        fa.slots_out = (double*)(h->d_fused + kFusedSlotsOff + (g % 3) * kFusedSlotBufBytes);
+        fa.slots_clear = (double*)(h->d_fused + kFusedSlotsOff + ((g + 1) % 3) * kFusedSlotBufBytes);
         const bool tail_only = j == total - 1;
         fa.trace = j == trace_launch ? d_trace : nullptr;
         fa.state_host = k == chunk - 1 ? h->h_state_dev : nullptr;  // the launch the host waits for also writes the pinned copy
@@ -989,7 +1000,7 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
         launch_accumulate<P4f>(h, a, h->session_crop, nb);
       icp_reduce_update_kernel<<<1, kUpdBlock, 0, h->stream>>>(h->d_partials, nb, h->d_state, (unsigned long long)a.count,
                                                             params->max_iteration, params->relative_fitness, params->relative_rmse,
-                                                            h->debug_update, h->session_method);
+                                                            h->debug_update, h->session_method, a.q_hi);
     }
     launched += chunk;
     HIP_TRY(hipGetLastError());

@@ -524,6 +524,7 @@ struct IcpPassArgs {
   CropDev crop;
   double r2max;
   int kmax;          // ceil(r / cell): how many cells away a neighbour within r can be
+  double q_hi;       // quantum of the exact record sums (see split_exact); a power of two
   int method;        // o3ds_icp_method: which record a correspondence contributes (the GICP record is a separate instantiation)
   int* nn_cache;     // [n_src] position (in the sorted target) of each query's match in the previous pass of this registration
   int n_tgt;
@@ -866,41 +867,66 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
 // ----------------------------------------------------------------------------------------------
 constexpr int kUpdBlock = 1024;
 
-// sum the per-block partial records into one 32-double record (fixed order); result in s_out[0..31].
+// ---- order-independent record sums ---------------------------------------------------------------------------------------
+// Every workgroup record value v is split into hi + lo, hi a multiple of q_hi and lo a multiple of q_lo = q_hi * 2^-41, with
+// q_hi a power of two chosen per registration from a bound B on the sum of |v| (2^53 q_hi >= 8 B).  Sums of at most 4096 such hi
+// (resp. lo) values are exactly representable, so f64 additions of them are EXACT and therefore associative: the records can be
+// accumulated with hardware f64 atomics in whatever order the workgroups finish, and the fused, two-launch and step-wise forms
+// agree bit for bit for any launch geometry.  What is dropped is below q_lo / 2 per record, i.e. B * 2^-93: the result is closer to
+// the true sum than a plain f64 summation.  If a caller's data exceed the bound (e.g. normals far from unit length) the split
+// degrades to hi = v, lo = 0 -- ordinary f64 sums, still correct, merely no longer order-independent.
+__device__ __forceinline__ void split_exact(double v, double q_hi, double* hi, double* lo) {
+  const double c_hi = 6755399441055744.0 * q_hi;  // 1.5 * 2^52 * q_hi: (v + c) - c rounds v to a multiple of q_hi (|v| < 2^51 q_hi)
+  const double h = (v + c_hi) - c_hi;
+  const double r = v - h;  // exact
+  const double c_lo = c_hi * 4.547473508864641e-13;  // * 2^-41
+  *hi = h;
+  *lo = (r + c_lo) - c_lo;
+}
+
+// sum the per-block partial records into one 32-double record (order-independent, see above); result in s_out[0..31].
 // The rows were written by other CUs/XCDs and come from memory, so each dependent load round costs ~1 us: all (<= 32) loads
 // of a thread are issued before the first add (measured: an add-per-load loop took 10 us, 8-deep batches 8 us).
-__device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int nrows, double* s_part /* [32][32] */,
+__device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int nrows, double q_hi, double* s_part /* [2][32][32] */,
                                                 double* s_out /* [32] */) {
   constexpr int kParts = kUpdBlock / 32;
   const int col = threadIdx.x & 31, part = threadIdx.x >> 5;  // 32 parts x 32 columns
-  double v = 0.0;
+  double vh = 0.0, vl = 0.0;
   for (int b0 = part; b0 < nrows; b0 += 32 * kParts) {
     double x[32];
 #pragma unroll
-    for (int k = 0; k < 32; ++k) {
+    for (int k = 0; k < 32; ++k) {  // the rows were written by other CUs/XCDs: all loads of a thread in flight before the first add
       const int b = b0 + k * kParts;
       x[k] = b < nrows ? partials[(size_t)b * kRec + col] : 0.0;
     }
 #pragma unroll
-    for (int k = 0; k < 32; ++k) v += x[k];
+    for (int k = 0; k < 32; ++k) {
+      double h, l;
+      split_exact(x[k], q_hi, &h, &l);
+      vh += h;  // exact
+      vl += l;  // exact
+    }
   }
-  s_part[part * kRec + col] = v;
+  s_part[part * kRec + col] = vh;
+  s_part[(kParts + part) * kRec + col] = vl;
   __syncthreads();
   if (threadIdx.x < kRec) {
-    double t = 0.0;
+    double th = 0.0, tl = 0.0;
 #pragma unroll
-    for (int k = 0; k < kParts; ++k) t += s_part[k * kRec + threadIdx.x];
-    s_out[threadIdx.x] = t;
+    for (int k = 0; k < kParts; ++k) {
+      th += s_part[k * kRec + threadIdx.x];
+      tl += s_part[(kParts + k) * kRec + threadIdx.x];
+    }
+    s_out[threadIdx.x] = th + tl;  // the one rounding
   }
   __syncthreads();
 }
-
 __global__ __launch_bounds__(kUpdBlock) void icp_reduce_kernel(const double* __restrict__ partials, int nrows, const IcpStateDev* state,
-                                                               double* __restrict__ record) {
+                                                               double* __restrict__ record, double q_hi) {
   if (state->done) return;
-  __shared__ double s_part[(kUpdBlock / 32) * kRec];
+  __shared__ double s_part[2 * (kUpdBlock / 32) * kRec];
   __shared__ double s_out[kRec];
-  reduce_partials(partials, nrows, s_part, s_out);
+  reduce_partials(partials, nrows, q_hi, s_part, s_out);
   if (threadIdx.x < kRec) record[threadIdx.x] = s_out[threadIdx.x];
 }
 
@@ -1302,17 +1328,17 @@ __device__ __forceinline__ void icp_step_block(const double* s_rec, IcpStateDev*
 // single-GPU path: reduce the partials and step, one workgroup
 __global__ __launch_bounds__(kUpdBlock) void icp_reduce_update_kernel(const double* __restrict__ partials, int nrows, IcpStateDev* state,
                                                                       unsigned long long n_src_total, int max_iter, double rel_fitness,
-                                                                      double rel_rmse, int debug_mode, int method) {
+                                                                      double rel_rmse, int debug_mode, int method, double q_hi) {
   if (state->done) return;
   if (debug_mode == 1) {  // timing experiment: launch + done check only
     if (threadIdx.x == 0) { state->pass += 1; state->iterations += 1; if (state->iterations > max_iter) state->done = 1; }
     return;
   }
-  __shared__ double s_part[(kUpdBlock / 32) * kRec];
+  __shared__ double s_part[2 * (kUpdBlock / 32) * kRec];
   __shared__ double s_out[kRec];
   __shared__ double s_x[8], s_sc[8], s_U[16], s_T[16];
   __shared__ int s_go;
-  reduce_partials(partials, nrows, s_part, s_out);
+  reduce_partials(partials, nrows, q_hi, s_part, s_out);
   if (debug_mode == 2) {  // timing experiment: reduction only
     if (threadIdx.x == 0) { state->pass += 1; state->iterations += 1; state->fitness = s_out[28]; if (state->iterations > max_iter) state->done = 1; }
     return;
@@ -1337,15 +1363,15 @@ __global__ __launch_bounds__(128) void icp_update_kernel(const double* __restric
 // ----------------------------------------------------------------------------------------------
 // The serial tail of pass j-1 (sum the records, convergence test, 6x6 solve, T <- U*T) is executed redundantly in the
 // PROLOGUE of every workgroup of pass j's launch -- identical inputs, identical instruction stream, identical result in
-// every workgroup -- so the dependent chain per iteration is one kernel instead of two (each launch on the chain costs
-// ~5 us of floor + ~3.3 us of boundary on MI355X).  To keep that prologue cheap the 1024 per-workgroup records of a pass
-// are first folded into kFusedSlots (32) slot records: workgroups publish their record with write-through (sc1) stores and
-// take a ticket on their slot's counter; the last arriver of a slot sums the slot's records in ascending workgroup
-// order (sc1 loads) -- deterministic, and no workgroup ever waits for another one.  State, records, slots and tickets are
-// double-buffered by pass parity, so a launch only reads what the previous launch wrote.
-// Visibility follows the CDNA guide's G16/R1 form: sc1 payload stores -> s_waitcnt vmcnt(0) in the storing wave ->
-// relaxed agent-scope ticket; the consumer reads the payload with sc1 loads.
-constexpr int kFusedSlots = 32;  // = the column groups of reduce_partials: fused, two-launch and step-wise forms sum in the SAME order
+// every workgroup -- so the dependent chain per iteration is one kernel instead of two (every kernel on the chain costs
+// >= 4.6 us on MI355X).  To keep that prologue cheap the 1024 per-workgroup records of a pass are accumulated into
+// kFusedSlots slot records with hardware f64 atomics: the addends are split so that the additions are exact (split_exact),
+// hence the order in which workgroups finish does not matter, nobody takes a ticket, nobody waits, and the epilogue is
+// fire-and-forget.  (The first form -- write-through row stores, a ticket per slot, the last arriver folding the slot in
+// ascending order -- was deterministic too but put three dependent memory round trips, 2.4 us, at the end of every pass.)
+// The slot buffers rotate over three launches: launch j reads buffer (j-1)%3, accumulates into j%3 and clears (j+1)%3.
+constexpr int kFusedSlots = 8;   // atomics of 1024 workgroups spread over 8 addresses per term
+constexpr int kSlotDoubles = 2 * kRec;  // [0..31] hi sums, [32..63] lo sums
 
 struct IcpFusedArgs {
   IcpPassArgs pass;               // pass.state / pass.partials are unused here
@@ -1354,15 +1380,13 @@ struct IcpFusedArgs {
   IcpStateDev* state_host;        // null, or pinned host memory that also receives the state (last launch of a chunk): the host
                                   // then only has to wait for the stream, there is no copy on the chain
   IcpStateDev init;               // launch 0: the initial state travels in the kernel arguments (no host-to-device copy)
-  const double* slots_in;         // [kFusedSlots][kRec] of the previous pass
-  double* slots_out;              // [kFusedSlots][kRec] of this pass
-  double* rows;                   // [gridDim.x][kRec] of this pass
-  unsigned int* tickets;          // [kFusedSlots] of this pass; zero on entry, zero again on exit
+  const double* slots_in;         // [kFusedSlots][kSlotDoubles] of the previous pass
+  double* slots_out;              // [kFusedSlots][kSlotDoubles] of this pass (zero on entry)
+  double* slots_clear;            // [kFusedSlots][kSlotDoubles] of the next pass: cleared by workgroup 0
   unsigned long long n_src_total;
   int max_iter;
   double rel_fitness, rel_rmse;
   int first;                      // 1: launch 0 -- there is no previous pass to fold
-  int nslots_in;                  // min(kFusedSlots, workgroups of the previous pass's launch)
   unsigned long long* trace;      // null, or [gridDim.x][16] phase timestamps (100 MHz wall clock) of thread 0 (O3DS_FUSED_TRACE)
 };
 
@@ -1370,14 +1394,15 @@ template <typename P4, bool kCrop, int kPassBlock, int kGroup, bool kGicp>
 __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4))) void icp_fused_kernel(IcpFusedArgs fa) {
   constexpr int kQPB = kPassBlock / kGroup;
   constexpr int kParts = kPassBlock / 32;
-  static_assert(kFusedSlots == kUpdBlock / 32, "slot = row % 32 is the summation order of reduce_partials");
+  static_assert(kFusedSlots * kSlotDoubles <= 2 * kPassBlock, "two slot values per thread in the prologue");
   __shared__ double s_rec[kQPB * (kGicp ? kRec : kRecSlots)];
   __shared__ double s_red[kParts][kRec];
   __shared__ int2 s_seg[kQPB * kSegMax];
   __shared__ double s_out[kRec];
   __shared__ double s_x[8], s_sc[8], s_U[16], s_T[16];
   __shared__ IcpStateDev s_st;
-  __shared__ int s_go, s_last;
+  __shared__ double s_slots[2 * kPassBlock];
+  __shared__ int s_go;
 #define O3DS_STAMP(k)                                                                                  \
   do {                                                                                                 \
     if (fa.trace && threadIdx.x == 0) fa.trace[(size_t)blockIdx.x * 16 + (k)] = wall_clock64();         \
@@ -1387,10 +1412,14 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   const bool use_cache = !fa.first;  // launch j evaluates pass j of the registration
   const QueryPrefetch<P4> qp = prefetch_query<P4, kPassBlock, kGroup>(fa.pass, blockIdx.x, use_cache);
   // ---------------- prologue: this pass's state from the previous state and the previous pass's slot records ----------------
-  double x[kFusedSlots];
-  if (!fa.first && threadIdx.x < kRec) {  // issue the slot loads before the state is looked at: one memory round trip instead of two
-#pragma unroll
-    for (int k = 0; k < kFusedSlots; ++k) x[k] = k < fa.nslots_in ? fa.slots_in[(size_t)k * kRec + threadIdx.x] : 0.0;
+  double x0 = 0.0, x1 = 0.0;  // two of the kFusedSlots x 64 slot values per thread
+  if (!fa.first) {  // issue the slot loads before the state is looked at: one memory round trip instead of two
+    x0 = fa.slots_in[threadIdx.x];
+    x1 = fa.slots_in[kPassBlock + threadIdx.x];
+  }
+  if (blockIdx.x == 0) {  // the buffer of the NEXT pass was last read two launches ago
+    fa.slots_clear[threadIdx.x] = 0.0;
+    fa.slots_clear[kPassBlock + threadIdx.x] = 0.0;
   }
   if (threadIdx.x == 0) s_st = fa.first ? fa.init : *fa.state_in;
   __syncthreads();
@@ -1403,11 +1432,19 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   }
   O3DS_STAMP(1);
   if (!fa.first) {
-    if (threadIdx.x < kRec) {  // slots in ascending order, like the last stage of reduce_partials
-      double t = 0.0;
+    // thread t holds slot values t and kPassBlock + t; value index = slot * 64 + {hi: 0..31, lo: 32..63} + term.  Sums of hi (resp.
+    // lo) values are exact, so any order will do: through LDS, 2 x kFusedSlots values per term
+    s_slots[threadIdx.x] = x0;
+    s_slots[kPassBlock + threadIdx.x] = x1;
+    __syncthreads();
+    if (threadIdx.x < kRec) {
+      double th = 0.0, tl = 0.0;
 #pragma unroll
-      for (int k = 0; k < kFusedSlots; ++k) t += x[k];
-      s_out[threadIdx.x] = t;
+      for (int k = 0; k < kFusedSlots; ++k) {
+        th += s_slots[k * kSlotDoubles + threadIdx.x];
+        tl += s_slots[k * kSlotDoubles + kRec + threadIdx.x];
+      }
+      s_out[threadIdx.x] = th + tl;  // the one rounding, as in reduce_partials
     }
     __syncthreads();
     icp_step_block(s_out, &s_st, fa.n_src_total, fa.max_iter, fa.rel_fitness, fa.rel_rmse, s_x, s_sc, s_U, s_T, &s_go,
@@ -1424,41 +1461,18 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   const double v = icp_pass_body<P4, kCrop, kPassBlock, kGroup, kGicp>(fa.pass, s_st.T, blockIdx.x, gridDim.x, s_rec, s_red, s_seg, use_cache, qp,
                                                                        fa.trace ? fa.trace + (size_t)blockIdx.x * 16 + 13 : nullptr);
   O3DS_STAMP(3);
-  // ---------------- epilogue: publish the record; the last arriver of the slot folds the slot ----------------
+  // ---------------- epilogue: add the record to this workgroup's slot, exactly ----------------
   if (threadIdx.x < kRec) {
-    __hip_atomic_store(fa.rows + (size_t)blockIdx.x * kRec + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    double hi, lo;
+    split_exact(v, fa.pass.q_hi, &hi, &lo);
+    double* slot = fa.slots_out + (size_t)(blockIdx.x % kFusedSlots) * kSlotDoubles;
+    if (hi != 0.0) (void)__hip_atomic_fetch_add(slot + threadIdx.x, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lo != 0.0) (void)__hip_atomic_fetch_add(slot + kRec + threadIdx.x, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __syncthreads();
   O3DS_STAMP(4);
-  const int slot = blockIdx.x % kFusedSlots;
-  const int members = ((int)gridDim.x - slot + kFusedSlots - 1) / kFusedSlots;  // workgroups slot, slot+64, ...
-  if (threadIdx.x == 0) {
-    unsigned int* tk = fa.tickets + slot;
-    const unsigned int t = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (t == (unsigned int)(members - 1));
-    if (s_last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the pass after next
-  }
-  __syncthreads();
   O3DS_STAMP(5);
-  if (s_last && threadIdx.x < kRec) {
-    double acc = 0.0;
-    for (int m0 = 0; m0 < members; m0 += 32) {  // ascending rows of the slot, like the first stage of reduce_partials
-      double y[32];
-#pragma unroll
-      for (int k = 0; k < 32; ++k) {
-        const int m = m0 + k;
-        y[k] = m < members ? __hip_atomic_load(fa.rows + (size_t)(slot + m * kFusedSlots) * kRec + threadIdx.x, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT)
-                           : 0.0;
-      }
-#pragma unroll
-      for (int k = 0; k < 32; ++k) acc += y[k];
-    }
-    fa.slots_out[(size_t)slot * kRec + threadIdx.x] = acc;
-  }
   O3DS_STAMP(6);
-  if (fa.trace && threadIdx.x == 0) fa.trace[(size_t)blockIdx.x * 16 + 7] = (unsigned long long)s_last;
+  if (fa.trace && threadIdx.x == 0) fa.trace[(size_t)blockIdx.x * 16 + 7] = 0ull;
 #undef O3DS_STAMP
 }
 

@@ -1,5 +1,5 @@
 """Phase profile of one steady icp_fused_kernel launch from the O3DS_FUSED_TRACE dump (100 MHz wall clock, thread 0 of each workgroup).
-stamps: 0 start | 1 state+slots loaded | 2 step done | 3 pass body done | 4 record published | 5 ticket taken | 6 end ; col 7 = last arriver"""
+stamps: 0 start | 1 state+slots loaded | 2 step done | 3 pass body done | 4,5 record added to its slot | 6 end ; col 7 = last arriver (older epilogue)"""
 import sys
 import numpy as np
 
@@ -16,7 +16,8 @@ print("phase durations (us): mean / p95 / max")
 for k in range(6):
     print("  %-22s %6.2f %6.2f %6.2f" % (names[k] + "->" + names[k + 1], d[:, k].mean(), np.percentile(d[:, k], 95), d[:, k].max()))
 la = t[:, 7] == 1
-print("last arrivers: ticket->end mean %.2f max %.2f ; others %.2f" % (d[la, 5].mean(), d[la, 5].max(), d[~la, 5].mean()))
+if la.any():  # only the ticket-and-fold epilogue had last arrivers; the exact-atomics epilogue has none
+    print("last arrivers: ticket->end mean %.2f max %.2f ; others %.2f" % (d[la, 5].mean(), d[la, 5].max(), d[~la, 5].mean()))
 st = (t[:, [8, 10, 11, 12]] - t[:, 1:2]) / 100.0
 print("inside the step, us after 'loaded' (mean): enter %.2f | solved %.2f | sincos %.2f | done %.2f" % tuple(st.mean(0)))
 bd = (t[:, 13:16] - t[:, 2:3]) / 100.0
