@@ -1046,7 +1046,9 @@ __host__ __device__ inline void solve6_ldlt(const double* rec, double x[6]) {
 // all remaining rows computed in parallel, back substitution.  Arithmetically this is the L D L^T solve (elimination of the
 // right-hand side is L y = b; back substitution on D L^T is D z = y, L^T w = z fused) with multiplications by the pivots'
 // reciprocals in place of divisions, so it agrees with solve6_ldlt to rounding; it keeps ~30 VGPRs instead of ~90 and has 6 dependent divisions instead of 21, which matters because this
-// tail is on the critical path of every ICP iteration (measured: 3-4 us serial, vs 1 us here).
+// tail is on the critical path of every ICP iteration (measured: 3-4 us serial, 2.1 us here; a Gauss-Jordan variant with one
+// matrix element per lane -- no swaps, no back substitution, reciprocal by Newton steps -- measured 2.5 us: its pivot search lives
+// on the scalar unit and every step ping-pongs between SALU and VALU).
 // broadcast of lane SRC (compile-time constant after unrolling) through v_readlane: a few cycles, where ds_bpermute (__shfl)
 // costs an LDS round trip -- the solve has ~80 of them on the critical path of every ICP iteration
 #define O3DS_BCAST(v, SRC) __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), (SRC)), __builtin_amdgcn_readlane(__double2loint(v), (SRC)))
