@@ -108,6 +108,13 @@ const char* o3ds_version(void);
 /* ---- device clouds ----------------------------------------------------------------------- */
 /* Upload a host cloud (PointCloud::points_, normals_ may be NULL). */
 int o3ds_cloud_upload(o3ds_handle h, const double* xyz, const double* normals, size_t n, o3ds_cloud* out);
+/* The same from a sensor_msgs/PointCloud2-style buffer, without the float -> double -> float detour of
+ * open3d_conversions::rosToOpen3d (open3d_utils/open3d_conversions/src/open3d_conversions.cpp:59-68, which reads the float32
+ * fields x, y, z of every record and widens them): n records of point_step bytes, float32 x / y / z at byte offsets off_x /
+ * off_y / off_z.  The raw buffer is copied to the device as it is and unpacked there; the values stored are exactly those the
+ * double route would store.  Other fields (intensity, ring, t, rgb) are ignored, as on the scan-matching path. */
+int o3ds_cloud_upload_f32(o3ds_handle h, const void* data, size_t n, size_t point_step, size_t off_x, size_t off_y, size_t off_z,
+                          o3ds_cloud* out);
 int o3ds_cloud_free(o3ds_handle h, o3ds_cloud c);
 int o3ds_cloud_size(o3ds_handle h, o3ds_cloud c, size_t* n, int* has_normals);
 /* Download into caller buffers of capacity >= n points (normals may be NULL). */

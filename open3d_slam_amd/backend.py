@@ -53,6 +53,7 @@ SIGNATURES = {
     "o3ds_profile_enable": (C.c_int, [_H, C.c_int]),
     "o3ds_profile_read": (C.c_int, [_H, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     "o3ds_cloud_upload": (C.c_int, [_H, _dp, _dp, C.c_size_t, C.POINTER(_CL)]),
+    "o3ds_cloud_upload_f32": (C.c_int, [_H, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(_CL)]),
     "o3ds_cloud_free": (C.c_int, [_H, _CL]),
     "o3ds_cloud_size": (C.c_int, [_H, _CL, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "o3ds_cloud_download": (C.c_int, [_H, _CL, _dp, _dp, C.c_size_t]),
@@ -171,6 +172,16 @@ class Backend:
         nrm, npp = _d(None if normals is None else np.asarray(normals).reshape(-1, 3))
         cid = _CL()
         self._ck(self.lib.o3ds_cloud_upload(self.h, xp, npp, len(xyz), C.byref(cid)))
+        return cid.value
+
+    def upload_f32(self, records, off_x: int = 0, off_y: int = 4, off_z: int = 8) -> int:
+        """sensor_msgs/PointCloud2-style ingest: `records` is a C-contiguous (n, k) float32 array (x, y, z in the first three
+        columns by default) or any (n,)-shaped structured / (n, step)-byte array with float32 x/y/z at the given byte offsets."""
+        a = np.ascontiguousarray(records)
+        n = a.shape[0]
+        step = a.strides[0] if n else (a.dtype.itemsize * (a.shape[1] if a.ndim > 1 else 1))
+        cid = _CL()
+        self._ck(self.lib.o3ds_cloud_upload_f32(self.h, a.ctypes.data_as(C.c_void_p), n, step, off_x, off_y, off_z, C.byref(cid)))
         return cid.value
 
     def free(self, cid: int):

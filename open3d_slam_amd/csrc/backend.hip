@@ -693,6 +693,35 @@ int o3ds_cloud_upload(o3ds_handle h, const double* xyz, const double* normals, s
   return O3DS_OK;
 }
 
+int o3ds_cloud_upload_f32(o3ds_handle h, const void* data, size_t n, size_t point_step, size_t off_x, size_t off_y, size_t off_z,
+                          o3ds_cloud* out) {
+  CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
+  if (!out || (n > 0 && !data)) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_upload_f32: null argument");
+  if (n > 0x7fffffffull) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_upload_f32: more than 2^31-1 points");
+  if (point_step < 12 || off_x + 4 > point_step || off_y + 4 > point_step || off_z + 4 > point_step)
+    return fail(h, O3DS_ERR_INVALID_ARG, "cloud_upload_f32: x/y/z fields do not fit the point step");
+  HIP_TRY(hipSetDevice(h->device));
+  CloudRec c;
+  c.n = n;
+  c.precision = h->precision;
+  if (n > 0) {
+    unsigned char* d_raw = nullptr;
+    TMP_ALLOC(d_raw, n * point_step);
+    HIP_TRY(hipMemcpyAsync(d_raw, data, n * point_step, hipMemcpyHostToDevice, h->stream));
+    const size_t bytes = (h->precision == O3DS_PRECISION_F64 ? sizeof(P4d) : sizeof(P4f)) * n;
+    HIP_TRY(hipMallocAsync(&c.pts, bytes, h->stream));
+    if (h->precision == O3DS_PRECISION_F64)
+      pack_strided_f32_kernel<P4d><<<grid_for(n), kBlock, 0, h->stream>>>(d_raw, n, point_step, off_x, off_y, off_z, (P4d*)c.pts);
+    else
+      pack_strided_f32_kernel<P4f><<<grid_for(n), kBlock, 0, h->stream>>>(d_raw, n, point_step, off_x, off_y, off_z, (P4f*)c.pts);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));  // `data` may be reused by the caller as soon as this returns
+  }
+  *out = add_cloud(h, std::move(c));
+  return O3DS_OK;
+}
+
 int o3ds_cloud_free(o3ds_handle h, o3ds_cloud id) {
   CHECK_HANDLE(h);
   auto it = h->clouds.find(id);

@@ -25,6 +25,26 @@ __global__ __launch_bounds__(kBlock) void pack_kernel(const double* __restrict__
     out[i] = p;
   }
 }
+// sensor_msgs/PointCloud2-style records: n points of `step` bytes, float32 x / y / z at byte offsets ox / oy / oz
+// (open3d_conversions.cpp:59-68 reads exactly these three fields and widens them to double)
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void pack_strided_f32_kernel(const unsigned char* __restrict__ raw, size_t n, size_t step, size_t ox,
+                                                                  size_t oy, size_t oz, P4* __restrict__ out) {
+  using R = typename Scalar<P4>::type;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const unsigned char* rec = raw + i * step;
+    float x, y, z;  // offsets are 4-byte aligned by the format; memcpy keeps it legal for packed layouts as well
+    __builtin_memcpy(&x, rec + ox, 4);
+    __builtin_memcpy(&y, rec + oy, 4);
+    __builtin_memcpy(&z, rec + oz, 4);
+    P4 p;
+    p.x = (R)x;
+    p.y = (R)y;
+    p.z = (R)z;
+    p.i = (typename Scalar<P4>::index)i;
+    out[i] = p;
+  }
+}
 template <typename P4>
 __global__ __launch_bounds__(kBlock) void unpack_kernel(const P4* __restrict__ in, size_t n, double* __restrict__ xyz) {
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {

@@ -14,6 +14,12 @@ class PointCloud:
     def from_numpy(cls, be, points, normals=None) -> "PointCloud":
         return cls(be, be.upload(np.asarray(points, dtype=np.float64).reshape(-1, 3), normals))
 
+    @classmethod
+    def from_pointcloud2(cls, be, records, off_x: int = 0, off_y: int = 4, off_z: int = 8) -> "PointCloud":
+        """open3d_conversions::rosToOpen3d (open3d_conversions.cpp:59-68) without the host-side widening: float32 x/y/z records go
+        to the device as they are (o3ds_cloud_upload_f32)."""
+        return cls(be, be.upload_f32(records, off_x, off_y, off_z))
+
     def __len__(self) -> int:
         return self.be.size(self.id)[0]
 

@@ -36,7 +36,9 @@ def main():
     op.scanProcessing_.cropper_ = P.ScanCroppingParameters(croppingMinRadius_=2.0, croppingMaxRadius_=30.0, cropperName_="MinMaxRadius")
     scene = syn.make_scene()
     poses = syn.figure_eight_poses(200, 0.1)
-    scans = [syn.os128_scan(scene, poses[k], frame=k, n_az=args.n_az) for k in range(args.frames)]
+    # a lidar driver delivers float32 x/y/z (sensor_msgs/PointCloud2): both loops see those values, the device ingests them directly
+    scans32 = [syn.os128_scan(scene, poses[k], frame=k, n_az=args.n_az).astype(np.float32) for k in range(args.frames)]
+    scans = [s.astype(np.float64) for s in scans32]
 
     be = backend.Backend(0)
     odo = LidarOdometry(be)
@@ -45,9 +47,9 @@ def main():
     mapper.setParameters(mp)
     stage = {"upload": 0.0, "odometry": 0.0, "mapping": 0.0}
     t_all = time.perf_counter()
-    for k, raw in enumerate(scans):
+    for k, raw in enumerate(scans32):
         t0 = time.perf_counter()
-        cloud = PointCloud.from_numpy(be, raw)
+        cloud = PointCloud.from_pointcloud2(be, raw)
         t1 = time.perf_counter()
         ok1 = odo.addRangeScan(cloud, 0.1 * k)
         be.synchronize()

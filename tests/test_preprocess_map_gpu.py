@@ -317,3 +317,29 @@ def test_full_size_config4_dense_map_fusion_properties(backend_f32):
     print(f"config4: {len(pts)} pts -> {len(vox)} voxels + {n_pass} pass-through in {dt*1e3:.2f} ms")
     backend_f32.free(s)
     backend_f32.free(m)
+
+
+def test_pointcloud2_style_f32_upload_equals_the_double_route(backend_f32, backend_f64, scan):
+    """o3ds_cloud_upload_f32 (float32 PointCloud2 -> device without the fp64 host detour of
+    open3d_conversions.cpp:59-68): x/y/z picked out of strided records, every other field ignored; what the device stores is
+    bit-identical to uploading the widened doubles."""
+    n = 5000
+    xyz32 = scan[:n].astype(np.float32)
+    rec = np.zeros(n, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("intensity", "<f4"), ("t", "<u4"), ("ring", "<u2"), ("pad", "<u2")])
+    rec["x"], rec["y"], rec["z"], rec["intensity"], rec["ring"] = xyz32[:, 0], xyz32[:, 1], xyz32[:, 2], 7.0, np.arange(n) % 16
+    shuffled = np.zeros(n, dtype=[("ring", "<u2"), ("pad", "<u2"), ("z", "<f4"), ("x", "<f4"), ("t", "<u4"), ("y", "<f4")])  # another field order
+    shuffled["x"], shuffled["y"], shuffled["z"] = xyz32[:, 0], xyz32[:, 1], xyz32[:, 2]
+    for be in (backend_f32, backend_f64):
+        ref = be.upload(xyz32.astype(np.float64))
+        want = be.download(ref)[0]
+        for arr, offs in ((xyz32, (0, 4, 8)), (rec, (0, 4, 8)), (shuffled, (8, 16, 4))):
+            c = be.upload_f32(arr, *offs)
+            assert be.size(c)[0] == n
+            np.testing.assert_array_equal(be.download(c)[0], want)
+            be.free(c)
+        be.free(ref)
+    e = backend_f32.upload_f32(np.zeros((0, 3), np.float32))
+    assert backend_f32.size(e)[0] == 0
+    backend_f32.free(e)
+    with pytest.raises(backend.BackendError):
+        backend_f32.upload_f32(np.zeros((4, 2), np.float32))  # x/y/z do not fit an 8-byte step
