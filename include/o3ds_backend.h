@@ -215,6 +215,20 @@ int o3ds_cloud_append(o3ds_handle h, o3ds_cloud map, o3ds_cloud add);
 int o3ds_voxelize_within_volume(o3ds_handle h, o3ds_cloud map, double voxel_size, const o3ds_crop* crop);
 /* Submap::insertScan core (Submap.cpp:54,70-72) in one call: map += T*scan; re-voxelize inside crop; rebuild the
  * NN index (max_corr_hint as in o3ds_cloud_build_index; <= 0 skips the rebuild). */
+/* Submap::carve for the sparse map (Submap.cpp:109-125 -> getIdxsOfCarvedPoints, helpers.cpp:235-271; SpaceCarvingParameters,
+ * Parameters.hpp:85-92): the raw scan (sensor frame) is placed with map_to_range_sensor; every ray from the sensor position is
+ * sampled every voxel_size metres while distance < max(voxel_size, min(length - truncation_distance, max_raytracing_length));
+ * map points inside map_builder_crop that share a sampled voxel (key floor(p / voxel_size)) are removed when the map has no
+ * normals or |ray direction . unit normal| > min_dot_product_with_normal.  The surviving points keep their order.  The caller
+ * decides WHEN to carve (nScansInsertedMap_ % carveSpaceEveryNscans_ == 1, Submap.cpp:111). */
+typedef struct {
+  double voxel_size;                  /* 0.1  */
+  double max_raytracing_length;       /* 20.0 */
+  double truncation_distance;         /* 0.1  */
+  double min_dot_product_with_normal; /* 0.5  */
+} o3ds_carving_params;
+int o3ds_map_carve(o3ds_handle h, o3ds_cloud map, o3ds_cloud raw_scan, const double map_to_range_sensor[16],
+                   const o3ds_crop* map_builder_crop, const o3ds_carving_params* params, size_t* n_removed);
 int o3ds_map_insert_scan(o3ds_handle h, o3ds_cloud map, o3ds_cloud scan, const double T[16], double map_voxel_size,
                          const o3ds_crop* map_builder_crop, double max_corr_hint);
 

@@ -41,6 +41,11 @@ _H = C.c_void_p
 _CL = C.c_uint64
 
 # name -> (restype, argtypes); must list every symbol include/o3ds_backend.h declares
+class CarvingParams(C.Structure):  # o3ds_carving_params (SpaceCarvingParameters, Parameters.hpp:85-92)
+    _fields_ = [("voxel_size", C.c_double), ("max_raytracing_length", C.c_double), ("truncation_distance", C.c_double),
+                ("min_dot_product_with_normal", C.c_double)]
+
+
 SIGNATURES = {
     "o3ds_create": (C.c_int, [C.c_int, C.POINTER(_H)]),
     "o3ds_destroy": (C.c_int, [_H]),
@@ -62,6 +67,7 @@ SIGNATURES = {
                                           C.POINTER(IcpResult)]),
     "o3ds_icp_point_to_plane_dev": (C.c_int, [_H, _CL, _CL, C.POINTER(Crop), _dp, C.POINTER(IcpParams), C.POINTER(IcpResult)]),
     "o3ds_icp_register_dev": (C.c_int, [_H, _CL, _CL, C.POINTER(Crop), _dp, C.POINTER(IcpParams), C.POINTER(IcpResult)]),
+    "o3ds_map_carve": (C.c_int, [_H, _CL, _CL, _dp, C.POINTER(Crop), C.POINTER(CarvingParams), C.POINTER(C.c_size_t)]),
     "o3ds_information_matrix": (C.c_int, [_H, _dp, C.c_size_t, _dp, C.c_size_t, _dp, C.c_double, _dp]),
     "o3ds_information_matrix_dev": (C.c_int, [_H, _CL, _CL, C.POINTER(Crop), _dp, C.c_double, _dp]),
     "o3ds_icp_point_to_point": (C.c_int, [_H, _dp, C.c_size_t, _dp, C.c_size_t, _dp, C.POINTER(IcpParams), C.POINTER(IcpResult)]),
@@ -367,6 +373,14 @@ class Backend:
 
     def voxelize_within_volume(self, map_id: int, voxel: float, crop: Crop):
         self._ck(self.lib.o3ds_voxelize_within_volume(self.h, map_id, voxel, C.byref(crop)))
+
+    def map_carve(self, map_id: int, raw_scan_id: int, T, crop: Crop | None, voxel=0.1, max_length=20.0, truncation=0.1, min_dot=0.5) -> int:
+        """Submap::carve on the device-resident sparse map; returns the number of removed points."""
+        Tc, tp = _d(colmajor(T))
+        p = CarvingParams(voxel, max_length, truncation, min_dot)
+        n = C.c_size_t(0)
+        self._ck(self.lib.o3ds_map_carve(self.h, map_id, raw_scan_id, tp, C.byref(crop) if crop else None, C.byref(p), C.byref(n)))
+        return int(n.value)
 
     def map_insert_scan(self, map_id: int, scan_id: int, T, map_voxel: float, crop: Crop, max_corr_hint: float = 0.0):
         Tc, tp = _d(colmajor(T))

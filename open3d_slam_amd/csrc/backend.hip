@@ -1278,6 +1278,78 @@ int transform_t(o3ds_handle h, const CloudRec& in, const double T[16], CloudRec&
   return O3DS_OK;
 }
 
+// Submap::carve (Submap.cpp:109-125): remove from `map` the points that the rays of `scan` (sensor frame, placed by T) see through
+template <typename P4>
+int carve_t(o3ds_handle h, CloudRec& map, const CloudRec& scan, const double T[16], const CropDev& crop, const o3ds_carving_params& cp,
+            size_t* n_removed) {
+  *n_removed = 0;
+  const size_t n = map.n;
+  if (n == 0 || scan.n == 0) return O3DS_OK;
+  unsigned long long *k0 = nullptr, *k1 = nullptr, *tkey = nullptr;
+  uint32_t *v0 = nullptr, *v1 = nullptr;
+  int *head = nullptr, *seg_id = nullptr, *seg_start = nullptr, *tseg = nullptr, *keep = nullptr, *pos = nullptr;
+  TMP_ALLOC(k0, sizeof(unsigned long long) * n);
+  TMP_ALLOC(k1, sizeof(unsigned long long) * n);
+  TMP_ALLOC(v0, sizeof(uint32_t) * n);
+  TMP_ALLOC(v1, sizeof(uint32_t) * n);
+  TMP_ALLOC(head, sizeof(int) * (n + 1));
+  TMP_ALLOC(seg_id, sizeof(int) * (n + 1));
+  // VoxelMap of the map points inside the wide cropping volume (cropper.getIndicesWithinVolume + insertCloud): same key as the merge
+  voxel_key_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>((const P4*)map.pts, n, 1, 0.0, 0.0, 0.0, cp.voxel_size, crop, k0, v0);
+  size_t temp_bytes = 0;
+  HIP_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, k0, k1, v0, v1, n, 0, 64, h->stream));
+  void* temp = nullptr;
+  TMP_ALLOC(temp, temp_bytes ? temp_bytes : 16);
+  HIP_TRY(rocprim::radix_sort_pairs(temp, temp_bytes, k0, k1, v0, v1, n, 0, 64, h->stream));
+  HIP_TRY(hipMemsetAsync(head + n, 0, sizeof(int), h->stream));
+  segment_head_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(k1, n, head);
+  int rc = exclusive_scan_int(h, head, seg_id, n + 1);
+  if (rc) return rc;
+  int n_seg = 0;
+  HIP_TRY(hipMemcpyAsync(&n_seg, seg_id + n, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  TMP_ALLOC(seg_start, sizeof(int) * ((size_t)n_seg + 1));
+  segment_start_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(head, seg_id, n, seg_start);
+  size_t tsize = 1024;
+  while (tsize < 2 * (size_t)n_seg) tsize <<= 1;
+  TMP_ALLOC(tkey, sizeof(unsigned long long) * tsize);
+  TMP_ALLOC(tseg, sizeof(int) * tsize);
+  HIP_TRY(hipMemsetAsync(tkey, 0xFF, sizeof(unsigned long long) * tsize, h->stream));
+  carve_table_insert_kernel<<<grid_for((size_t)n_seg), kBlock, 0, h->stream>>>(k1, seg_start, (size_t)n_seg, tkey, tseg, (unsigned int)(tsize - 1));
+  TMP_ALLOC(keep, sizeof(int) * (n + 1));
+  TMP_ALLOC(pos, sizeof(int) * (n + 1));
+  fill_int_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(keep, n, 1);
+  HIP_TRY(hipMemsetAsync(keep + n, 0, sizeof(int), h->stream));
+  Mat34 M;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) M.m[r * 4 + c] = T[c * 4 + r];
+  carve_rays_kernel<P4><<<grid_for(scan.n), kBlock, 0, h->stream>>>((const P4*)scan.pts, scan.n, M, T[12], T[13], T[14], cp.voxel_size,
+                                                                   cp.max_raytracing_length, cp.truncation_distance,
+                                                                   cp.min_dot_product_with_normal, tkey, tseg, (unsigned int)(tsize - 1), seg_start,
+                                                                   (size_t)n_seg, n, v1, (const P4*)map.nrm, keep);
+  rc = exclusive_scan_int(h, keep, pos, n + 1);
+  if (rc) return rc;
+  int total = 0;
+  HIP_TRY(hipMemcpyAsync(&total, pos + n, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  *n_removed = n - (size_t)total;
+  if (*n_removed == 0) return O3DS_OK;  // removeByIds: nothing to do (helpers.cpp:221-223)
+  void *np = nullptr, *nn = nullptr;
+  if (total > 0) {
+    HIP_TRY(hipMallocAsync(&np, sizeof(P4) * (size_t)total, h->stream));
+    if (map.nrm) HIP_TRY(hipMallocAsync(&nn, sizeof(P4) * (size_t)total, h->stream));
+    compact_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>((const P4*)map.pts, (const P4*)map.nrm, n, keep, pos, 1, (P4*)np, (P4*)nn);
+    HIP_TRY(hipGetLastError());
+  }
+  free_index(h, map);
+  (void)hipFreeAsync(map.pts, h->stream);
+  if (map.nrm) (void)hipFreeAsync(map.nrm, h->stream);
+  map.pts = np;
+  map.nrm = nn;
+  map.n = (size_t)total;
+  return O3DS_OK;
+}
+
 template <typename P4>
 int append_t(o3ds_handle h, CloudRec& map, const CloudRec& add) {
   // [O3D] PointCloud::operator+= : normals survive only if (map empty or map has normals) and add has normals
@@ -1430,6 +1502,23 @@ int o3ds_voxelize_within_volume(o3ds_handle h, o3ds_cloud map, double voxel_size
   free_cloud(h, *m);
   *m = o;
   return O3DS_OK;
+}
+
+int o3ds_map_carve(o3ds_handle h, o3ds_cloud map, o3ds_cloud raw_scan, const double map_to_range_sensor[16], const o3ds_crop* map_builder_crop,
+                   const o3ds_carving_params* params, size_t* n_removed) {
+  CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
+  CloudRec* m = find_cloud(h, map);
+  CloudRec* s = find_cloud(h, raw_scan);
+  if (!m || !s || !map_to_range_sensor || !params || m == s) return fail(h, O3DS_ERR_INVALID_ARG, "map_carve: bad argument");
+  if (!(params->voxel_size > 0.0)) return fail(h, O3DS_ERR_INVALID_ARG, "map_carve: voxel_size must be > 0");
+  if (m->n > 0 && s->n > 0 && m->precision != s->precision) return fail(h, O3DS_ERR_INVALID_ARG, "map_carve: precision mismatch");
+  size_t removed = 0;
+  const CropDev cd = to_dev(map_builder_crop);
+  const int rc = m->precision == O3DS_PRECISION_F64 ? carve_t<P4d>(h, *m, *s, map_to_range_sensor, cd, *params, &removed)
+                                                    : carve_t<P4f>(h, *m, *s, map_to_range_sensor, cd, *params, &removed);
+  if (n_removed) *n_removed = removed;
+  return rc;
 }
 
 int o3ds_map_insert_scan(o3ds_handle h, o3ds_cloud map, o3ds_cloud scan, const double T[16], double map_voxel_size,

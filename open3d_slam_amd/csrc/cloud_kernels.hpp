@@ -395,6 +395,87 @@ __host__ __device__ inline void fast_eigen3x3_min(const double cov[6], double ou
 // the current worst and the maximum is recomputed by one sweep over the k slots.  Only the SET of the k nearest matters
 // (the covariance is a sum), so no ordering is maintained.  Candidate loads are issued four at a time: a load-per-
 // iteration loop with a scratch-resident sorted list measured 3.8 ms for 100 k points; this form is bound by LDS sweeps.
+// ---------------------------------------------------------------------------------------------- space carving (sparse map)
+// Submap::carve -> getIdxsOfCarvedPoints (Submap.cpp:109-125, helpers.cpp:235-271).  The reference keeps a hash map voxel ->
+// indices and lets every scan ray probe it every `voxel` metres under an `omp critical`; here the cropped map points are keyed
+// (voxel_key_kernel, the same floor(p * (1/v)) key), sorted, their segments entered into an open-addressing table
+// (key -> segment) and one thread per ray marches and probes; marking a point is an idempotent store, no atomics.
+constexpr unsigned long long kEmptyKey = ~0ull;
+
+// keys of the map points inside the wide cropping volume, everything else gets the pass-through bit (never probed)
+__global__ __launch_bounds__(kBlock) void carve_table_insert_kernel(const unsigned long long* __restrict__ keys, const int* __restrict__ seg_start,
+                                                                    size_t n_seg, unsigned long long* __restrict__ tkey, int* __restrict__ tseg,
+                                                                    unsigned int mask) {
+  for (size_t s = (size_t)blockIdx.x * kBlock + threadIdx.x; s < n_seg; s += (size_t)gridDim.x * kBlock) {
+    const unsigned long long k = keys[seg_start[s]];
+    if (k & kPassBit) continue;  // segments of points outside the volume
+    unsigned int slot = (unsigned int)((k * 0x9E3779B97F4A7C15ull) >> 32) & mask;
+    while (true) {
+      const unsigned long long prev = atomicCAS(&tkey[slot], kEmptyKey, k);
+      if (prev == kEmptyKey || prev == k) {
+        tseg[slot] = (int)s;
+        break;
+      }
+      slot = (slot + 1) & mask;
+    }
+  }
+}
+
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void carve_rays_kernel(const P4* __restrict__ scan, size_t n_scan, Mat34 M /* map <- sensor */,
+                                                            double sx, double sy, double sz, double voxel, double max_len, double trunc,
+                                                            double min_dot, const unsigned long long* __restrict__ tkey,
+                                                            const int* __restrict__ tseg, unsigned int mask, const int* __restrict__ seg_start,
+                                                            size_t n_seg, size_t n_sorted, const uint32_t* __restrict__ vals,
+                                                            const P4* __restrict__ map_nrm, int* __restrict__ flags) {
+  const double inv = 1.0 / voxel;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n_scan; i += (size_t)gridDim.x * kBlock) {
+    const P4 q = scan[i];
+    // o3d_slam::transform (helpers.cpp:273-305) of the raw scan into the map frame, then the ray from the sensor position
+    const double x = (double)q.x, y = (double)q.y, z = (double)q.z;
+    const double px = M.m[0] * x + M.m[1] * y + M.m[2] * z + M.m[3], py = M.m[4] * x + M.m[5] * y + M.m[6] * z + M.m[7],
+                 pz = M.m[8] * x + M.m[9] * y + M.m[10] * z + M.m[11];
+    const double dx = px - sx, dy = py - sy, dz = pz - sz;
+    const double length = sqrt(dx * dx + dy * dy + dz * dz);
+    if (!(length > 0.0)) continue;
+    const double ux = dx / length, uy = dy / length, uz = dz / length;
+    const double lim = fmax(voxel, fmin(length - trunc, max_len));
+    for (double dist = 0.0; dist < lim; dist += voxel) {
+      const double cx = dist * ux + sx, cy = dist * uy + sy, cz = dist * uz + sz;
+      const unsigned long long k = pack_key((long long)(int)floor(cx * inv), (long long)(int)floor(cy * inv), (long long)(int)floor(cz * inv));
+      unsigned int slot = (unsigned int)((k * 0x9E3779B97F4A7C15ull) >> 32) & mask;
+      int seg = -1;
+      while (true) {
+        const unsigned long long t = tkey[slot];
+        if (t == k) {
+          seg = tseg[slot];
+          break;
+        }
+        if (t == kEmptyKey) break;
+        slot = (slot + 1) & mask;
+      }
+      if (seg < 0) continue;
+      const size_t b = (size_t)seg_start[seg], e = (size_t)seg + 1 < n_seg ? (size_t)seg_start[seg + 1] : n_sorted;
+      for (size_t j = b; j < e; ++j) {
+        const uint32_t id = vals[j];
+        bool rem = true;
+        if (map_nrm) {
+          const P4 nn = map_nrm[id];
+          const double a = (double)nn.x, bb = (double)nn.y, c = (double)nn.z;
+          const double nl = sqrt(a * a + bb * bb + c * c);
+          const double dot = nl > 0.0 ? (ux * a + uy * bb + uz * c) / nl : 0.0;  // Eigen normalized(): the zero vector stays zero
+          rem = fabs(dot) > min_dot;
+        }
+        if (rem) flags[id] = 0;  // flags are "keep" flags: 1 = stays in the map
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void fill_int_kernel(int* __restrict__ p, size_t n, int v) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) p[i] = v;
+}
+
 // normalise, orient towards the sensor origin ([O3D] NormalizeNormals + OrientNormalsTowardsCameraLocation(0,0,0)), store
 template <typename P4>
 __device__ __forceinline__ void finish_normal(const P4& q, double nv[3], P4* out) {

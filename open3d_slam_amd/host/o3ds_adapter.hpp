@@ -423,7 +423,18 @@ class DeviceSubmap {
   }
   DeviceSubmap(const DeviceSubmap&) = delete;
   DeviceSubmap& operator=(const DeviceSubmap&) = delete;
-  // Submap::insertScan core (Submap.cpp:54,70-72); carving is a next row
+  // Submap::carve for the sparse map (Submap.cpp:109-125): the caller applies the every-N-scans gate; returns #removed points
+  size_t carve(const PointCloud& rawScan, const Transform& mapToRangeSensor, const CroppingVolume& mapBuilderCropper, double voxelSize,
+               double maxRaytracingLength, double truncationDistance, double minDotProductWithNormal) {
+    if (rawScan.IsEmpty()) return 0;
+    o3ds_detail::DevCloud s(rawScan);
+    const o3ds_crop c = mapBuilderCropper.toAbi();
+    const o3ds_carving_params cp{voxelSize, maxRaytracingLength, truncationDistance, minDotProductWithNormal};
+    size_t removed = 0;
+    o3ds_detail::Handle::check(o3ds_map_carve(o3ds_detail::Handle::get(), map_, s.id(), o3ds_detail::pose_data(mapToRangeSensor), &c, &cp, &removed));
+    return removed;
+  }
+  // Submap::insertScan core (Submap.cpp:54,70-72)
   bool insertScan(const PointCloud& preProcessedScan, const Transform& mapToRangeSensor, double mapVoxelSize,
                   CroppingVolume* mapBuilderCropper, double maxCorrespondenceDistance) {
     if (preProcessedScan.IsEmpty()) return true;

@@ -66,7 +66,7 @@ class OdometryParameters:  # Parameters.hpp:78-83
 
 
 @dataclasses.dataclass
-class SpaceCarvingParameters:  # Parameters.hpp:85-92 (carving itself is a "next" row)
+class SpaceCarvingParameters:  # Parameters.hpp:85-92
     voxelSize_: float = 0.1
     maxRaytracingLength_: float = 20.0
     truncationDistance_: float = 0.1

@@ -35,12 +35,10 @@ class Submap:
         return self.mapToRangeSensor_
 
     def insertScan(self, rawScan, preProcessedScan: PointCloud, mapToRangeSensor, time=None, isPerformCarving: bool = False) -> bool:
-        """Submap.cpp:39-75 without carving (a 'next' row; the benchmark configs disable it, B7):
-        map += T * scan; re-voxelize inside the map-builder volume centred on the sensor; rebuild the NN index."""
+        """Submap.cpp:39-75: [carve the map with the raw scan,] map += T * scan; re-voxelize inside the map-builder volume centred
+        on the sensor; rebuild the NN index."""
         if preProcessedScan.IsEmpty():
             return True
-        if isPerformCarving:
-            raise NotImplementedError("space carving is a 'next' row (SURVEY.md 8f rank 2)")
         self.mapToRangeSensor_ = np.array(mapToRangeSensor, dtype=np.float64)
         icp = self.params_.scanMatcher_.icp_
         if self.params_.isUseInitialMap_ and self.mapCloud_.IsEmpty():  # Submap.cpp:47-52
@@ -50,8 +48,18 @@ class Submap:
             self.mapCloud_ = PointCloud(self.be, v)
             self.be.build_index(self.mapCloud_.id, icp.maxCorrespondenceDistance_)
             return True
+        if isPerformCarving:  # Submap.cpp:56-60 (the cropper still holds the pose of the previous insertion, as in the reference)
+            self.carve(rawScan, self.mapToRangeSensor_)
         self.mapBuilderCropper_.setPose(self.mapToRangeSensor_)
         self.be.map_insert_scan(self.mapCloud_.id, preProcessedScan.id, self.mapToRangeSensor_, self.params_.mapBuilder_.mapVoxelSize_,
                                 self.mapBuilderCropper_.to_abi(), max_corr_hint=icp.maxCorrespondenceDistance_)
         self.nScansInsertedMap_ += 1
         return True
+
+    def carve(self, rawScan: PointCloud, mapToRangeSensor) -> int:
+        """Submap::carve (Submap.cpp:109-125): only every carveSpaceEveryNscans_-th insertion, never on an empty map."""
+        c = self.params_.mapBuilder_.carving_
+        if self.mapCloud_.IsEmpty() or not (self.nScansInsertedMap_ % c.carveSpaceEveryNscans_ == 1):
+            return 0
+        return self.be.map_carve(self.mapCloud_.id, rawScan.id, mapToRangeSensor, self.mapBuilderCropper_.to_abi(), voxel=c.voxelSize_,
+                                 max_length=c.maxRaytracingLength_, truncation=c.truncationDistance_, min_dot=c.minDotProductWithNormal_)

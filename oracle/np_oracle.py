@@ -116,6 +116,45 @@ def information_matrix(src, tgt, max_corr, T=None):
     return np.einsum("mra,mrb->ab", G, G)
 
 
+def carve_flags(scan, sensor, map_pts, map_nrm, subset, voxel=0.1, max_length=20.0, truncation=0.1, min_dot=0.5):
+    """getIdxsOfCarvedPoints (helpers.cpp:235-271), one ray-marching step for all rays at a time."""
+    sensor = np.asarray(sensor, dtype=np.float64)
+    inv = 1.0 / voxel
+    subset = np.asarray(subset, dtype=np.int64)
+    keys = np.floor(map_pts[subset] * inv).astype(np.int64)
+    table = {}
+    for k, i in zip(map(tuple, keys), subset):
+        table.setdefault(k, []).append(int(i))
+    d = scan - sensor
+    length = np.linalg.norm(d, axis=1)
+    ok = length > 0
+    direction = np.zeros_like(d)
+    direction[ok] = d[ok] / length[ok, None]
+    lim = np.maximum(voxel, np.minimum(length - truncation, max_length))
+    flags = np.zeros(len(map_pts), dtype=bool)
+    unit = None
+    if map_nrm is not None:
+        nl = np.linalg.norm(map_nrm, axis=1)
+        unit = np.where(nl[:, None] > 0, map_nrm / np.where(nl > 0, nl, 1.0)[:, None], 0.0)
+    dist = 0.0
+    active = ok.copy()
+    while True:
+        active &= dist < lim
+        if not active.any():
+            break
+        pos = dist * direction[active] + sensor
+        kk = np.floor(pos * inv).astype(np.int64)
+        for k, dv in zip(map(tuple, kk), direction[active]):
+            ids = table.get(k)
+            if ids is None:
+                continue
+            for i in ids:
+                if unit is None or abs(float(dv @ unit[i])) > min_dot:
+                    flags[i] = True
+        dist += voxel
+    return flags
+
+
 def estimate_normals(pts, radius, max_nn):
     tree = cKDTree(pts, leafsize=15)
     d, j = tree.query(pts, k=max_nn, distance_upper_bound=radius)

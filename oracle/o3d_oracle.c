@@ -695,6 +695,75 @@ int orc_information_matrix(const double* src, size_t n, const double* tgt, size_
   return 0;
 }
 
+/* ------------------------------------------------------------------ space carving of the sparse map
+ * getIdxsOfCarvedPoints (src/helpers.cpp:235-271) as called from Submap::carve (src/Submap.cpp:109-125): a VoxelMap of the map
+ * points listed in `subset` (key = floor(p * (1/v)) per axis, VoxelHashMap.hpp:47-50, Voxel.cpp:123-129); every scan point
+ * (already in the map frame) casts a ray from the sensor position, sampled every v from distance 0 while
+ * distance < max(v, min(length - truncation, max_length)); every map point in a sampled voxel is removed if the map has no
+ * normals or |direction . normalize(normal)| > min_dot.  flags_out[N] is set to 1 for removed ids; returns their number. */
+typedef struct {
+  int64_t key;
+  int64_t idx;
+} carve_item;
+static int carve_cmp(const void* a, const void* b) {
+  const carve_item *x = (const carve_item*)a, *y = (const carve_item*)b;
+  if (x->key != y->key) return x->key < y->key ? -1 : 1;
+  return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
+}
+static int64_t carve_key(const double p[3], double inv) {
+  const int64_t kx = (int64_t)(int)floor(p[0] * inv), ky = (int64_t)(int)floor(p[1] * inv), kz = (int64_t)(int)floor(p[2] * inv);
+  return ((kz + (1ll << 20)) << 42) | ((ky + (1ll << 20)) << 21) | (kx + (1ll << 20)); /* |k| < 2^20 per axis */
+}
+size_t orc_carve_flags(const double* scan, size_t n_scan, const double sensor[3], const double* map_pts, const double* map_nrm, size_t N,
+                       const int64_t* subset, size_t n_subset, double voxel, double max_length, double truncation, double min_dot,
+                       uint8_t* flags_out) {
+  memset(flags_out, 0, N);
+  if (n_subset == 0 || n_scan == 0) return 0;
+  const double inv = 1.0 / voxel;
+  carve_item* items = (carve_item*)malloc(sizeof(carve_item) * n_subset);
+  for (size_t i = 0; i < n_subset; ++i) {
+    items[i].idx = subset[i];
+    items[i].key = carve_key(map_pts + 3 * (size_t)subset[i], inv);
+  }
+  qsort(items, n_subset, sizeof(carve_item), carve_cmp);
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < n_scan; ++i) {
+    const double* p = scan + 3 * i;
+    const double d[3] = {p[0] - sensor[0], p[1] - sensor[1], p[2] - sensor[2]};
+    const double length = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    if (!(length > 0.0)) continue; /* the reference divides by zero here; such a ray samples no voxel */
+    const double dir[3] = {d[0] / length, d[1] / length, d[2] / length};
+    const double lim = fmax(voxel, fmin(length - truncation, max_length));
+    for (double dist = 0.0; dist < lim; dist += voxel) {
+      const double pos[3] = {dist * dir[0] + sensor[0], dist * dir[1] + sensor[1], dist * dir[2] + sensor[2]};
+      const int64_t key = carve_key(pos, inv);
+      size_t lo = 0, hi = n_subset; /* first item with key >= key */
+      while (lo < hi) {
+        const size_t mid = (lo + hi) / 2;
+        if (items[mid].key < key)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      for (size_t j = lo; j < n_subset && items[j].key == key; ++j) {
+        const size_t id = (size_t)items[j].idx;
+        int rem = 1;
+        if (map_nrm) {
+          const double* nn = map_nrm + 3 * id;
+          const double nl = sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
+          const double dot = nl > 0.0 ? (dir[0] * nn[0] + dir[1] * nn[1] + dir[2] * nn[2]) / nl : 0.0; /* Eigen normalized(): 0 stays 0 */
+          rem = fabs(dot) > min_dot;
+        }
+        if (rem) flags_out[id] = 1; /* idempotent, no critical section needed */
+      }
+    }
+  }
+  free(items);
+  size_t cnt = 0;
+  for (size_t i = 0; i < N; ++i) cnt += flags_out[i];
+  return cnt;
+}
+
 /* ------------------------------------------------------------------ A.8 Generalized ICP
  * [O3D] GeneralizedICP.cpp: GetRotationFromE1ToX, InitializePointCloudForGeneralizedICP,
  * TransformationEstimationForGeneralizedICP::ComputeTransformation; reference call site src/CloudRegistration.cpp:16-21. */

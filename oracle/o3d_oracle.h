@@ -88,6 +88,12 @@ void orc_svd3(const double A[9], double U[9], double d[3], double V[9]);
 int orc_information_matrix(const double* src, size_t n, const double* tgt, size_t N, const orc_kdtree* tree, double max_corr,
                            const double T[16], double out[36]);
 
+/* Space carving of the sparse map: getIdxsOfCarvedPoints (helpers.cpp:235-271) for Submap::carve (Submap.cpp:109-125).
+ * scan is already in the map frame; subset = the map indices inside the map builder's cropping volume; flags_out[N]. */
+size_t orc_carve_flags(const double* scan, size_t n_scan, const double sensor[3], const double* map_pts, const double* map_nrm, size_t N,
+                       const int64_t* subset, size_t n_subset, double voxel, double max_length, double truncation, double min_dot,
+                       uint8_t* flags_out);
+
 /* A.8 RegistrationGeneralizedICP (call site src/CloudRegistration.cpp:16-21): covariances from normals
  * (C = Rx diag(eps,1,1) Rx^T, Rx = GetRotationFromE1ToX(normal)), per pair M = Ct + R Cs R^T, W = M^-1/2, residual W d (3 rows),
  * Jacobian rows W [-[p]x | I]; same loop / solve / convergence as A.1.  Both clouds must carry normals (as they always do

@@ -73,6 +73,9 @@ def lib():
         L.orc_svd3.argtypes = [_dp, _dp, _dp, _dp]
         L.orc_information_matrix.restype = C.c_int
         L.orc_information_matrix.argtypes = [_dp, C.c_size_t, _dp, C.c_size_t, C.c_void_p, C.c_double, _dp, _dp]
+        L.orc_carve_flags.restype = C.c_size_t
+        L.orc_carve_flags.argtypes = [_dp, C.c_size_t, _dp, _dp, _dp, C.c_size_t, C.POINTER(C.c_int64), C.c_size_t, C.c_double, C.c_double,
+                                      C.c_double, C.c_double, C.POINTER(C.c_uint8)]
         L.orc_gicp_jtj_jtr.argtypes = [_dp, _dp, C.c_size_t, _dp, _dp, _ip, _dp, _dp]
         L.orc_covariance_from_normal.argtypes = [_dp, C.c_double, _dp]
         L.orc_estimate_normals.argtypes = [_dp, C.c_size_t, C.c_double, C.c_int, _dp]
@@ -245,6 +248,19 @@ def information_matrix(src, tgt, max_corr, T=None, tree: KDTree | None = None):
     if rc != 0:
         raise RuntimeError(f"orc_information_matrix rc={rc}")
     return out.reshape(6, 6)
+
+
+def carve_flags(scan, sensor, map_pts, map_nrm, subset, voxel=0.1, max_length=20.0, truncation=0.1, min_dot=0.5):
+    """getIdxsOfCarvedPoints (helpers.cpp:235-271): boolean mask over the map of the points a scan carves away."""
+    scan, sp = _d(scan)
+    sensor, snp = _d(np.asarray(sensor, dtype=np.float64).reshape(3))
+    mp, mpp = _d(map_pts)
+    mn, mnp = (None, None) if map_nrm is None else _d(map_nrm)
+    subset = np.ascontiguousarray(subset, dtype=np.int64)
+    flags = np.zeros(len(mp), dtype=np.uint8)
+    lib().orc_carve_flags(sp, len(scan), snp, mpp, mnp, len(mp), subset.ctypes.data_as(C.POINTER(C.c_int64)), len(subset), voxel, max_length,
+                          truncation, min_dot, flags.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return flags.astype(bool)
 
 
 def icp_generalized(src, src_nrm, tgt, tgt_nrm, max_corr, init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6, epsilon=1e-3,

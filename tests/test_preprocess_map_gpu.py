@@ -343,3 +343,49 @@ def test_pointcloud2_style_f32_upload_equals_the_double_route(backend_f32, backe
     backend_f32.free(e)
     with pytest.raises(backend.BackendError):
         backend_f32.upload_f32(np.zeros((4, 2), np.float32))  # x/y/z do not fit an 8-byte step
+
+
+def test_map_carve_matches_oracle(backend_f64, backend_f32, oracle):
+    """Submap::carve on the device-resident sparse map (Submap.cpp:109-125, helpers.cpp:235-271) vs the oracle: same removed set,
+    survivors in their original order, points outside the cropping volume untouched, with and without map normals."""
+    rng = np.random.default_rng(11)
+    scene = syn.make_scene()
+    mp, mn = syn.sample_map(scene, 60_000)
+    ghost = rng.uniform([-3.0, -3.0, 0.2], [3.0, 3.0, 1.5], size=(800, 3))  # clutter in free space
+    mp = np.vstack([mp, ghost])
+    mn = np.vstack([mn, rng.normal(size=(800, 3))])
+    pose = syn.make_pose((0.3, -0.2, 0.5), (1.0, -2.0, 10.0))
+    scan = syn.vlp16_scan(scene, pose, n_az=512)
+    scan_w = scan @ pose[:3, :3].T + pose[:3, 3]
+    sensor = pose[:3, 3]
+    rmax = 15.0
+    subset = np.flatnonzero(np.linalg.norm(mp - sensor, axis=1) <= rmax)
+    crop = backend.make_crop(backend.CROP_MAX_RADIUS, center=sensor, rmax=rmax)
+    for nrm, kw in ((mn, {}), (None, {}), (mn, dict(voxel=0.2, max_length=6.0, truncation=0.3, min_dot=0.8))):
+        ref = oracle.carve_flags(scan_w, sensor, mp, nrm, subset, **kw)
+        m = backend_f64.upload(mp, nrm)
+        s = backend_f64.upload(scan)
+        removed = backend_f64.map_carve(m, s, pose, crop, **kw)
+        got_p, got_n = backend_f64.download(m)
+        # the device places the scan with its own f64 transform: a sample within an ulp of a voxel face may fall on the other side
+        assert abs(removed - int(ref.sum())) <= 2
+        if removed == int(ref.sum()):
+            np.testing.assert_array_equal(got_p, mp[~ref])
+            if nrm is not None:
+                np.testing.assert_array_equal(got_n, nrm[~ref])
+        assert 0 < removed < len(mp)
+        # idempotence on what is left is NOT a property (new points become visible), but a second scan-less call is a no-op
+        e = backend_f64.upload(np.zeros((0, 3)))
+        assert backend_f64.map_carve(m, e, pose, crop, **kw) == 0 and backend_f64.size(m)[0] == len(got_p)
+        for c in (m, s, e):
+            backend_f64.free(c)
+    # f32 storage: same clutter goes, the count agrees to a fraction of a percent (voxel keys of f32-rounded points)
+    ref = oracle.carve_flags(scan_w, sensor, mp, mn, subset)
+    m, s = backend_f32.upload(mp, mn), backend_f32.upload(scan)
+    removed = backend_f32.map_carve(m, s, pose, crop)
+    assert abs(removed - int(ref.sum())) <= 0.01 * ref.sum() + 5
+    assert backend_f32.size(m)[0] == len(mp) - removed
+    with pytest.raises(backend.BackendError):
+        backend_f32.map_carve(m, s, pose, crop, voxel=0.0)
+    backend_f32.free(m)
+    backend_f32.free(s)
