@@ -389,3 +389,39 @@ def test_map_carve_matches_oracle(backend_f64, backend_f32, oracle):
         backend_f32.map_carve(m, s, pose, crop, voxel=0.0)
     backend_f32.free(m)
     backend_f32.free(s)
+
+
+def test_submap_mirror_insert_scan_with_carving(backend_f32):
+    """Submap::insertScan(..., isPerformCarving) through the reference-named class: the gate nScansInsertedMap_ % N == 1
+    (Submap.cpp:111) decides when the rays carve; clutter planted in free space is gone afterwards."""
+    from open3d_slam_amd import parameters as P
+    from open3d_slam_amd.pointcloud import PointCloud
+    from open3d_slam_amd.submap import Submap
+
+    scene = syn.make_scene()
+    mp = P.lua_default_mapper_parameters()
+    mp.mapBuilder_.carving_.carveSpaceEveryNscans_ = 2
+    poses = [syn.make_pose((0.2 * k, 0.0, 0.5), (0.0, 0.0, 2.0 * k)) for k in range(3)]
+    removed = []
+    for with_carving in (False, True):
+        sm = Submap(backend_f32)
+        sm.setParameters(mp)
+        for k in range(3):
+            raw = syn.vlp16_scan(scene, poses[k], frame=k, n_az=512)
+            if k == 0:  # plant clutter between the sensor and the walls in the first scan only
+                rng = np.random.default_rng(3)
+                raw = np.vstack([raw, rng.uniform([-2.5, -2.5, -0.3], [2.5, 2.5, 1.0], size=(300, 3))])
+            rawc = PointCloud.from_numpy(backend_f32, raw)
+            pre = PointCloud(backend_f32, backend_f32.voxel_down_sample(rawc.id, 0.1))
+            backend_f32.estimate_normals(pre.id, 3.0, 20)
+            before = len(sm.getMapPointCloud())
+            sm.insertScan(rawc, pre, poses[k], 0.1 * k, isPerformCarving=with_carving)
+            if with_carving:
+                removed.append((sm.nScansInsertedMap_, before))
+            rawc.release()
+            pre.release()
+        n = len(sm.getMapPointCloud())
+        if not with_carving:
+            n_plain = n
+        sm.getMapPointCloud().release()
+    assert n < n_plain - 30  # scan 1 (nScansInsertedMap_ == 1 at that moment) carved the clutter; scans 0 and 2 did not carve
