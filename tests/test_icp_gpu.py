@@ -505,3 +505,26 @@ def test_information_matrix_matches_oracle(backend_f64, backend_f32, oracle, sma
         backend_f64.information_matrix(src, tgt, 0.0)
     backend_f64.free(s)
     backend_f64.free(t)
+
+
+def test_large_coordinates_and_exact_sums(backend_f64, oracle, small_c2):
+    """Clouds far from the origin (UTM-like offsets): the quantum of the exact record sums scales with the target's box, the result still
+    matches the oracle, and it is identical for a different launch geometry (the sums do not depend on how the queries are grouped)."""
+    src, tgt, nrm, _ = small_c2
+    off = np.array([1.0e5, -2.0e5, 50.0])
+    T0 = np.eye(4)
+    T0[:3, 3] = off  # the source stays near the origin, the initial guess carries it to the map
+    ref = oracle.icp_point_to_plane(src, tgt + off, nrm, 1.0, init=T0, max_iter=8, rel_fitness=0.0, rel_rmse=0.0)
+    got = backend_f64.icp_point_to_plane(src, tgt + off, nrm, 1.0, init=T0, max_iter=8, rel_fitness=0.0, rel_rmse=0.0)
+    assert got["iterations"] == ref["iterations"] and got["n_corr"] == ref["n_corr"]
+    dt, dr = syn.se3_error(got["transformation"], ref["transformation"])
+    assert dt <= 2e-4 and dr <= 1e-8, (dt, dr)  # conditioning: the lever arm |p| ~ 2e5 m multiplies every rounding of the rotation
+    os.environ["O3DS_PASS_ROWS"] = "333"
+    try:
+        be = backend.Backend(0, backend.PRECISION_F64)
+        other = be.icp_point_to_plane(src, tgt + off, nrm, 1.0, init=T0, max_iter=8, rel_fitness=0.0, rel_rmse=0.0)
+        be.close()
+    finally:
+        del os.environ["O3DS_PASS_ROWS"]
+    dt, dr = syn.se3_error(other["transformation"], got["transformation"])
+    assert dt <= 2e-4 and dr <= 1e-8, (dt, dr)  # other per-workgroup partial sums (their roundings differ), combined exactly
