@@ -8,8 +8,8 @@ identity, truth = (0.30,-0.20,0.05) m / rpy (0.5,-0.5,2.0) deg.  Clouds and the 
 before the timed region (index build reported separately as index_build_ms).
 
 N GPUs (one process per GPU, launched by torch.distributed.run): rank r holds ITS OWN 1M-pt submap (seed 1235+r)
-and the whole scan; every ICP iteration all-reduces the 32-double normal-equation record over RCCL ("submap"
-partitioning, open3d_slam_amd/sharded.py).  Weak scaling: per-GPU work is fixed; value counts the
+and the whole scan; every ICP iteration is ONE fused kernel plus one 4-KB RCCL all-reduce of the exact hi/lo sums of
+the normal equations ("submap" partitioning, open3d_slam_amd/sharded.py).  Weak scaling: per-GPU work is fixed; value counts the
 scan-vs-submap iterations all ranks processed per second.
 
 Prints ONE JSON line on rank 0.
@@ -176,7 +176,8 @@ def main():
 
     # HBM traffic of the same kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes of this
     # command, corrected as MI355X_MICROARCH.md prescribes); collected by scripts/gpu_round.sh, committed under profiles/
-    pass_kernel = "icp_accumulate_kernel" if (world > 1 or os.environ.get("O3DS_ICP_MODE") == "launch") else "icp_fused_kernel"
+    classic = (world > 1 and os.environ.get("O3DS_SHARDED_FORM") == "classic") or (world == 1 and os.environ.get("O3DS_ICP_MODE") == "launch")
+    pass_kernel = "icp_accumulate_kernel" if classic else "icp_fused_kernel"
     traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
     if os.path.exists(tpath):
@@ -204,7 +205,7 @@ def main():
             "config": {"workload": "configs[1]: point-to-plane ICP, 65536-pt VLP-16 scan vs 1,000,000-pt submap, "
                                    f"max_corr {MAX_CORR} m, {ICP_ITERS} fixed iterations/step (+1 evaluation pass), index prebuilt",
                        "n_src": N_SRC, "n_map_per_gpu": N_MAP, "icp_iterations_per_step": ICP_ITERS,
-                       "parallelism": "1 GPU" if world == 1 else f"{world} submaps x 1 GPU, 256-B RCCL all-reduce / iteration",
+                       "parallelism": "1 GPU" if world == 1 else f"{world} submaps x 1 GPU, one fused kernel + one 4-KB RCCL all-reduce / iteration",
                        "nn_cell_m": args.cell if args.cell > 0 else MAX_CORR / 4},
             "index_build_ms": index_build_ms,
             "scans_per_sec_icp_only": world * args.steps / elapsed,

@@ -184,6 +184,19 @@ int o3ds_icp_accumulate(o3ds_handle h, size_t first, size_t count, double* d_rec
 int o3ds_icp_update(o3ds_handle h, const double* d_record, uint64_t n_src_total);
 int o3ds_icp_finish(o3ds_handle h, o3ds_icp_result* out);
 /* 1 when the device-side loop has terminated (converged or max_iteration reached); synchronises. */
+/* Fused step-wise form -- ONE kernel per iteration plus the caller's collective (the accumulate / reduce / update triple above is
+ * three).  o3ds_icp_pass enqueues launch j of the fused loop over the source range [first, first + count): its prologue folds
+ * d_sums_in (the ALL-REDUCED sums of the previous pass; ignored by the first call of a session) and applies the update, its body
+ * adds this rank's part of pass j to d_sums_out, and it clears d_sums_next.  The three buffers are O3DS_ICP_SUMS_DOUBLES doubles
+ * each, on the device, owned and rotated by the caller (out -> in -> next -> out ...), all zero before the first call.  Between
+ * two calls the caller sums d_sums_out element-wise over the ranks (ncclAllReduce, in place, on o3ds_stream(h)).  The addends are
+ * split so that these sums are exact: the result does not depend on the number of ranks or the reduction order.
+ * o3ds_icp_pass_finish folds the last pass (one-workgroup launch) and returns the result; max_iteration + 1 passes make a full
+ * registration, passes issued after the loop has terminated on the device are no-ops. */
+#define O3DS_ICP_SUMS_DOUBLES 512
+int o3ds_icp_pass(o3ds_handle h, size_t first, size_t count, size_t n_src_total, const double* d_sums_in, double* d_sums_out,
+                  double* d_sums_next);
+int o3ds_icp_pass_finish(o3ds_handle h, size_t n_src_total, const double* d_sums_in, double* d_sums_scratch, o3ds_icp_result* out);
 int o3ds_icp_done(o3ds_handle h, int* done);
 
 /* ---- scan pre-processing: ScanToMapIcp::preprocess (ScanToMapRegistration.cpp:35-40),

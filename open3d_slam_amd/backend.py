@@ -67,6 +67,8 @@ SIGNATURES = {
                                           C.POINTER(IcpResult)]),
     "o3ds_icp_point_to_plane_dev": (C.c_int, [_H, _CL, _CL, C.POINTER(Crop), _dp, C.POINTER(IcpParams), C.POINTER(IcpResult)]),
     "o3ds_icp_register_dev": (C.c_int, [_H, _CL, _CL, C.POINTER(Crop), _dp, C.POINTER(IcpParams), C.POINTER(IcpResult)]),
+    "o3ds_icp_pass": (C.c_int, [_H, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "o3ds_icp_pass_finish": (C.c_int, [_H, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(IcpResult)]),
     "o3ds_map_carve": (C.c_int, [_H, _CL, _CL, _dp, C.POINTER(Crop), C.POINTER(CarvingParams), C.POINTER(C.c_size_t)]),
     "o3ds_information_matrix": (C.c_int, [_H, _dp, C.c_size_t, _dp, C.c_size_t, _dp, C.c_double, _dp]),
     "o3ds_information_matrix_dev": (C.c_int, [_H, _CL, _CL, C.POINTER(Crop), _dp, C.c_double, _dp]),
@@ -296,6 +298,18 @@ class Backend:
         out = IcpResult()
         self._ck(self.lib.o3ds_icp_generalized_dev(self.h, source, target, C.byref(target_crop) if target_crop else None, ip,
                                                    C.byref(p), C.byref(out)))
+        return self._result(out)
+
+    ICP_SUMS_DOUBLES = 512
+
+    def icp_pass(self, first: int, count: int, n_src_total: int, sums_in_ptr: int | None, sums_out_ptr: int, sums_next_ptr: int):
+        """fused step-wise form: one kernel; the caller all-reduces sums_out afterwards (device pointers to 512 doubles each)"""
+        self._ck(self.lib.o3ds_icp_pass(self.h, first, count, n_src_total, C.c_void_p(sums_in_ptr or 0), C.c_void_p(sums_out_ptr),
+                                        C.c_void_p(sums_next_ptr)))
+
+    def icp_pass_finish(self, n_src_total: int, sums_in_ptr: int, sums_scratch_ptr: int):
+        out = IcpResult()
+        self._ck(self.lib.o3ds_icp_pass_finish(self.h, n_src_total, C.c_void_p(sums_in_ptr), C.c_void_p(sums_scratch_ptr), C.byref(out)))
         return self._result(out)
 
     def set_gicp_epsilon(self, eps: float):

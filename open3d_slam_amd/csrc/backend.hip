@@ -59,6 +59,8 @@ struct o3ds_context {
   IcpPassArgs pass{};
   o3ds_icp_params params{};
   size_t session_n_src = 0;
+  int session_launches = 0;                     // fused step-wise form: launches issued in this session
+  const IcpStateDev* session_state = nullptr;   // ... and the state the latest one wrote (null: d_state)
   int session_precision = 0;
   bool session_crop = false;
   int session_method = O3DS_ICP_POINT_TO_PLANE;
@@ -511,6 +513,7 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
     const double P = std::sqrt(ex * ex + ey * ey + ez * ez) + r;  // a matched source point lies within r of the target's box
     double B = (double)std::max<size_t>(src->n, 1) * std::max(1.0, P) * std::max(1.0, P) * std::max(1.0, r) * std::max(1.0, r);
     if (params->method == O3DS_ICP_GENERALIZED) B *= 4.0 * std::max(1.0, 0.5 / h->gicp_epsilon);  // |M^-1| <= 1 / (2 eps)
+    B *= 64.0;  // the sums of up to 64 ranks ("submap" sharding: every rank contributes up to n correspondences) stay exact as well
     int e = 0;
     (void)std::frexp(B, &e);             // B < 2^e
     a.q_hi = std::ldexp(1.0, e + 3 - 53);  // 2^53 q_hi = 8 * 2^e
@@ -527,6 +530,8 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
   h->params = *params;
   h->session = true;
   h->session_n_src = src->n;
+  h->session_launches = 0;
+  h->session_state = nullptr;
   h->session_precision = src->precision;
   h->session_crop = crop && crop->kind != O3DS_CROP_NONE;
   h->session_method = params->method;
@@ -801,10 +806,78 @@ int o3ds_icp_update(o3ds_handle h, const double* d_record, uint64_t n_src_total)
   return O3DS_OK;
 }
 
+int o3ds_icp_pass(o3ds_handle h, size_t first, size_t count, size_t n_src_total, const double* d_sums_in, double* d_sums_out,
+                  double* d_sums_next) {
+  CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
+  if (!h->session) return fail(h, O3DS_ERR_INVALID_ARG, "icp_pass: no session (call o3ds_icp_begin)");
+  if (!d_sums_out || !d_sums_next || (h->session_launches > 0 && !d_sums_in)) return fail(h, O3DS_ERR_INVALID_ARG, "icp_pass: null sums buffer");
+  if (first + count > h->session_n_src) return fail(h, O3DS_ERR_INVALID_ARG, "icp_pass: range outside source");
+  IcpFusedArgs fa{};
+  fa.pass = h->pass;
+  fa.pass.first = first;
+  fa.pass.count = count;
+  fa.n_src_total = (unsigned long long)n_src_total;
+  fa.max_iter = h->params.max_iteration;
+  fa.rel_fitness = h->params.relative_fitness;
+  fa.rel_rmse = h->params.relative_rmse;
+  fa.init = *h->h_state;  // written by begin_session
+  const int j = h->session_launches++;
+  fa.first = j == 0;
+  fa.state_in = h->session_state ? h->session_state : h->d_state;
+  fa.state_out = (IcpStateDev*)(h->d_fused + (size_t)(j & 1) * kFusedStateStride);
+  fa.state_host = nullptr;
+  fa.slots_in = d_sums_in ? d_sums_in : d_sums_next;  // unused by the first launch
+  fa.slots_out = d_sums_out;
+  fa.slots_clear = d_sums_next;
+  fa.trace = nullptr;
+  const int nb = std::min(pass_blocks(h, count), kMaxPassBlocks);
+  if (h->session_precision == O3DS_PRECISION_F64)
+    launch_fused<P4d>(h, fa, h->session_crop, nb, true);
+  else
+    launch_fused<P4f>(h, fa, h->session_crop, nb, true);
+  h->session_state = fa.state_out;
+  HIP_TRY(hipGetLastError());
+  return O3DS_OK;
+}
+
+int o3ds_icp_pass_finish(o3ds_handle h, size_t n_src_total, const double* d_sums_in, double* d_sums_scratch, o3ds_icp_result* out) {
+  CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
+  if (!h->session) return fail(h, O3DS_ERR_INVALID_ARG, "icp_pass_finish: no session");
+  if (!out || !d_sums_in || !d_sums_scratch) return fail(h, O3DS_ERR_INVALID_ARG, "icp_pass_finish: null argument");
+  if (h->session_launches == 0) return fail(h, O3DS_ERR_INVALID_ARG, "icp_pass_finish: no pass was issued");
+  IcpFusedArgs fa{};  // the one-workgroup tail launch: folds the last pass, never reaches the body
+  fa.pass = h->pass;
+  fa.pass.count = 0;
+  fa.n_src_total = (unsigned long long)n_src_total;
+  fa.max_iter = h->params.max_iteration;
+  fa.rel_fitness = h->params.relative_fitness;
+  fa.rel_rmse = h->params.relative_rmse;
+  const int j = h->session_launches++;
+  fa.first = 0;
+  fa.state_in = h->session_state;
+  fa.state_out = (IcpStateDev*)(h->d_fused + (size_t)(j & 1) * kFusedStateStride);
+  fa.state_host = h->h_state_dev;
+  fa.slots_in = d_sums_in;
+  fa.slots_out = d_sums_scratch;  // a launch that still has iterations left would add an (empty) pass here
+  fa.slots_clear = d_sums_scratch;
+  if (h->session_precision == O3DS_PRECISION_F64)
+    launch_fused<P4d>(h, fa, h->session_crop, 1, false);
+  else
+    launch_fused<P4f>(h, fa, h->session_crop, 1, false);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->session = false;
+  h->session_state = nullptr;
+  copy_result(h, out);
+  return O3DS_OK;
+}
+
 int o3ds_icp_done(o3ds_handle h, int* done) {
   CHECK_HANDLE(h);
   if (!h->session) return fail(h, O3DS_ERR_INVALID_ARG, "icp_done: no session");
-  int rc = read_state(h, nullptr);
+  int rc = read_state(h, nullptr, h->session_state);
   if (rc) return rc;
   if (done) *done = h->h_state->done;
   return O3DS_OK;

@@ -1,7 +1,12 @@
 """Multi-GPU scan-to-map registration: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI)
-carrying ONE 32-double all-reduce per ICP iteration -- the only exchange step the path has.
+carrying ONE small all-reduce per ICP iteration -- the only exchange step the path has.
 
-Two partitionings, both expressed through the step-wise C-ABI (o3ds_icp_begin/accumulate/update/finish):
+Per iteration the default ("fused") form enqueues ONE kernel (o3ds_icp_pass: the previous iteration's solve/update in its
+prologue, this rank's correspondence pass, exact hi/lo sums of the normal equations) and one 4-KB all-reduce; the classic
+form (O3DS_SHARDED_FORM=classic: o3ds_icp_accumulate / all-reduce of 32 doubles / o3ds_icp_update) is three kernels plus the
+collective.  The sums of the fused form are exact, so its result does not depend on the number of ranks.
+
+Two partitionings, both expressed through the step-wise C-ABI:
 
 * "source"  : every rank holds the same target (+index); rank r accumulates source points
               [r*n/W, (r+1)*n/W).  Sum of the records == the single-GPU record, so the result is the
@@ -42,6 +47,20 @@ def run_sharded_loop(accumulate: Callable[[], object], all_reduce: Callable[[obj
     return passes
 
 
+def run_sharded_fused_loop(issue_pass: Callable[[int], object], all_reduce: Callable[[object], None], is_done: Callable[[], bool],
+                           max_iteration: int, check_every: int = 4) -> int:
+    """The same loop for the fused step-wise form: `issue_pass(p)` enqueues launch p (update from pass p-1 + pass p) and returns the
+    buffer that holds this rank's sums of pass p; the caller-side all-reduce makes them global before launch p+1 folds them."""
+    passes = 0
+    total = max_iteration + 1
+    while passes < total:
+        all_reduce(issue_pass(passes))
+        passes += 1
+        if passes < total and passes % check_every == 0 and is_done():
+            break
+    return passes
+
+
 class ShardedIcp:
     """GPU driver of run_sharded_loop over a Backend handle and a torch.distributed process group."""
 
@@ -59,8 +78,12 @@ class ShardedIcp:
         # update are stream-ordered, no host sync per iteration (torch's default stream has handle 0 == "NULL = own
         # stream" in o3ds_set_stream, hence an explicit side stream)
         self.tstream = torch.cuda.Stream(device=dev)
+        import os
+
+        self.fused = os.environ.get("O3DS_SHARDED_FORM", "fused") != "classic"
         with torch.cuda.stream(self.tstream):
             self.rec = torch.zeros(32, dtype=torch.float64, device=dev)
+            self.sums = [torch.zeros(be.ICP_SUMS_DOUBLES, dtype=torch.float64, device=dev) for _ in range(3)]
         self.tstream.synchronize()
         be.set_stream(self.tstream.cuda_stream)
 
@@ -88,6 +111,17 @@ class ShardedIcp:
         def update(rec):
             be.icp_update(ptr, n_total)
 
+        def issue_pass(p: int):
+            out, nxt, prev = self.sums[p % 3], self.sums[(p + 1) % 3], self.sums[(p + 2) % 3]
+            be.icp_pass(first, count, n_total, prev.data_ptr() if p > 0 else None, out.data_ptr(), nxt.data_ptr())
+            return out
+
         with self.torch.cuda.stream(self.tstream):
-            run_sharded_loop(accumulate, all_reduce, update, be.icp_done, max_iter, check_every)
-            return be.icp_finish()
+            if not self.fused:
+                run_sharded_loop(accumulate, all_reduce, update, be.icp_done, max_iter, check_every)
+                return be.icp_finish()
+            for t in self.sums:
+                t.zero_()
+            passes = run_sharded_fused_loop(issue_pass, all_reduce, be.icp_done, max_iter, check_every)
+            last = self.sums[(passes - 1) % 3]
+            return be.icp_pass_finish(n_total, last.data_ptr(), self.sums[passes % 3].data_ptr())
