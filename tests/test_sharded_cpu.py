@@ -153,3 +153,32 @@ def test_world2_gloo_matches_single_process(tmp_path, oracle, mode):
         assert int(r["iterations"]) == st.iterations
         dt, dr = syn.se3_error(r["T"], syn.ground_truth_pose())
         assert dt < 5e-3 and dr < 1e-3
+
+
+def test_fused_loop_control_flow():
+    """run_sharded_fused_loop: max_iteration + 1 passes, one all-reduce per pass on the buffer that pass returned, the device's
+    `done` polled every check_every passes only, and never after the last pass."""
+    from open3d_slam_amd.sharded import run_sharded_fused_loop
+
+    log = []
+
+    def issue(p):
+        log.append(("pass", p))
+        return ("buf", p % 3)
+
+    def allred(b):
+        log.append(("allreduce", b))
+
+    polls = []
+
+    def done():
+        polls.append(len([e for e in log if e[0] == "pass"]))
+        return False
+
+    assert run_sharded_fused_loop(issue, allred, done, max_iteration=6, check_every=3) == 7
+    assert [e for e in log if e[0] == "pass"] == [("pass", p) for p in range(7)]
+    assert [e[1] for e in log if e[0] == "allreduce"] == [("buf", p % 3) for p in range(7)]
+    assert polls == [3, 6]
+    stop_at = iter([False, True])
+    log.clear()
+    assert run_sharded_fused_loop(issue, allred, lambda: next(stop_at), max_iteration=50, check_every=2) == 4  # stops at the second poll
