@@ -228,6 +228,13 @@ int o3ds_cloud_append(o3ds_handle h, o3ds_cloud map, o3ds_cloud add);
 int o3ds_voxelize_within_volume(o3ds_handle h, o3ds_cloud map, double voxel_size, const o3ds_crop* crop);
 /* Submap::insertScan core (Submap.cpp:54,70-72) in one call: map += T*scan; re-voxelize inside crop; rebuild the
  * NN index (max_corr_hint as in o3ds_cloud_build_index; <= 0 skips the rebuild). */
+/* computeIndicesOfOverlappingPoints (src/helpers.cpp:307-332; call sites src/PlaceRecognition.cpp:103,
+ * src/constraint_builders.cpp:54): both clouds are binned with the voxel key floor(p / voxel_size) -- the source after being
+ * placed by source_to_target --, and every voxel that holds at least min_points_per_voxel points of EACH cloud contributes all its
+ * source and all its target indices.  idx_source / idx_target: caller buffers with room for every point of the respective cloud;
+ * filled in ascending order (the reference's order is its hash map's iteration order, i.e. unspecified). */
+int o3ds_overlap_indices(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const double source_to_target[16], double voxel_size,
+                         size_t min_points_per_voxel, uint64_t* idx_source, size_t* n_idx_source, uint64_t* idx_target, size_t* n_idx_target);
 /* Submap::carve for the sparse map (Submap.cpp:109-125 -> getIdxsOfCarvedPoints, helpers.cpp:235-271; SpaceCarvingParameters,
  * Parameters.hpp:85-92): the raw scan (sensor frame) is placed with map_to_range_sensor; every ray from the sensor position is
  * sampled every voxel_size metres while distance < max(voxel_size, min(length - truncation_distance, max_raytracing_length));

@@ -69,6 +69,8 @@ SIGNATURES = {
     "o3ds_icp_register_dev": (C.c_int, [_H, _CL, _CL, C.POINTER(Crop), _dp, C.POINTER(IcpParams), C.POINTER(IcpResult)]),
     "o3ds_icp_pass": (C.c_int, [_H, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "o3ds_icp_pass_finish": (C.c_int, [_H, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(IcpResult)]),
+    "o3ds_overlap_indices": (C.c_int, [_H, _CL, _CL, _dp, C.c_double, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_size_t),
+                                       C.POINTER(C.c_uint64), C.POINTER(C.c_size_t)]),
     "o3ds_map_carve": (C.c_int, [_H, _CL, _CL, _dp, C.POINTER(Crop), C.POINTER(CarvingParams), C.POINTER(C.c_size_t)]),
     "o3ds_information_matrix": (C.c_int, [_H, _dp, C.c_size_t, _dp, C.c_size_t, _dp, C.c_double, _dp]),
     "o3ds_information_matrix_dev": (C.c_int, [_H, _CL, _CL, C.POINTER(Crop), _dp, C.c_double, _dp]),
@@ -387,6 +389,16 @@ class Backend:
 
     def voxelize_within_volume(self, map_id: int, voxel: float, crop: Crop):
         self._ck(self.lib.o3ds_voxelize_within_volume(self.h, map_id, voxel, C.byref(crop)))
+
+    def overlap_indices(self, source: int, target: int, T=None, voxel: float = 0.5, min_points: int = 1):
+        """computeIndicesOfOverlappingPoints: (ascending source indices, ascending target indices) as uint64 arrays."""
+        Tc, tp = _d(colmajor(np.eye(4) if T is None else T))
+        ns, nt = self.size(source)[0], self.size(target)[0]
+        i_s, i_t = np.zeros(max(ns, 1), np.uint64), np.zeros(max(nt, 1), np.uint64)
+        c_s, c_t = C.c_size_t(0), C.c_size_t(0)
+        self._ck(self.lib.o3ds_overlap_indices(self.h, source, target, tp, float(voxel), int(min_points), i_s.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                               C.byref(c_s), i_t.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(c_t)))
+        return i_s[: c_s.value].copy(), i_t[: c_t.value].copy()
 
     def map_carve(self, map_id: int, raw_scan_id: int, T, crop: Crop | None, voxel=0.1, max_length=20.0, truncation=0.1, min_dot=0.5) -> int:
         """Submap::carve on the device-resident sparse map; returns the number of removed points."""

@@ -1423,6 +1423,74 @@ int carve_t(o3ds_handle h, CloudRec& map, const CloudRec& scan, const double T[1
   return O3DS_OK;
 }
 
+// computeIndicesOfOverlappingPoints (helpers.cpp:307-332)
+template <typename P4>
+int overlap_t(o3ds_handle h, const CloudRec& src, const CloudRec& tgt, const double T[16], double voxel, size_t min_points,
+              unsigned long long* idx_src, size_t* n_src_out, unsigned long long* idx_tgt, size_t* n_tgt_out) {
+  *n_src_out = *n_tgt_out = 0;
+  const size_t ns = src.n, nt = tgt.n, n = ns + nt;
+  if (ns == 0 || nt == 0) return O3DS_OK;  // no voxel can hold points of both clouds
+  CloudRec moved;
+  int rc = transform_t<P4>(h, src, T, moved);  // sourceTransformed.Transform(sourceToTarget)
+  if (rc) {
+    free_cloud(h, moved);
+    return rc;
+  }
+  unsigned long long *k0 = nullptr, *k1 = nullptr, *d_out = nullptr;
+  uint32_t *v0 = nullptr, *v1 = nullptr;
+  int *head = nullptr, *seg_id = nullptr, *cnt = nullptr, *flag = nullptr, *pos = nullptr;
+  TMP_ALLOC(k0, sizeof(unsigned long long) * n);
+  TMP_ALLOC(k1, sizeof(unsigned long long) * n);
+  TMP_ALLOC(v0, sizeof(uint32_t) * n);
+  TMP_ALLOC(v1, sizeof(uint32_t) * n);
+  TMP_ALLOC(head, sizeof(int) * (n + 1));
+  TMP_ALLOC(seg_id, sizeof(int) * (n + 1));
+  CropDev none{};
+  voxel_key_kernel<P4><<<grid_for(nt), kBlock, 0, h->stream>>>((const P4*)tgt.pts, nt, 1, 0.0, 0.0, 0.0, voxel, none, k0, v0);
+  voxel_key_kernel<P4><<<grid_for(ns), kBlock, 0, h->stream>>>((const P4*)moved.pts, ns, 1, 0.0, 0.0, 0.0, voxel, none, k0 + nt, v0 + nt);
+  overlap_tag_kernel<<<grid_for(ns), kBlock, 0, h->stream>>>(v0 + nt, ns);
+  size_t temp_bytes = 0;
+  HIP_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, k0, k1, v0, v1, n, 0, 64, h->stream));
+  void* temp = nullptr;
+  TMP_ALLOC(temp, temp_bytes ? temp_bytes : 16);
+  HIP_TRY(rocprim::radix_sort_pairs(temp, temp_bytes, k0, k1, v0, v1, n, 0, 64, h->stream));
+  HIP_TRY(hipMemsetAsync(head + n, 0, sizeof(int), h->stream));
+  segment_head_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(k1, n, head);
+  rc = exclusive_scan_int(h, head, seg_id, n + 1);
+  if (rc) {
+    free_cloud(h, moved);
+    return rc;
+  }
+  TMP_ALLOC(cnt, sizeof(int) * 2 * n);  // at most n segments: [0, n) source counts, [n, 2n) target counts
+  HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int) * 2 * n, h->stream));
+  overlap_count_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(v1, head, seg_id, n, cnt, cnt + n);
+  TMP_ALLOC(flag, sizeof(int) * (n + 2));  // [0, ns] source flags (+ terminator), then [ns + 1, ns + 1 + nt] target flags
+  TMP_ALLOC(pos, sizeof(int) * (n + 2));
+  HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int) * (n + 2), h->stream));
+  int* flag_s = flag;
+  int* flag_t = flag + ns + 1;
+  overlap_flag_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(v1, head, seg_id, n, cnt, cnt + n, (int)std::min<size_t>(min_points, 0x7fffffff), flag_s,
+                                                             flag_t);
+  rc = exclusive_scan_int(h, flag_s, pos, ns + 1);
+  if (!rc) rc = exclusive_scan_int(h, flag_t, pos + ns + 1, nt + 1);
+  free_cloud(h, moved);
+  if (rc) return rc;
+  int tot[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(&tot[0], pos + ns, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(&tot[1], pos + ns + 1 + nt, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  TMP_ALLOC(d_out, sizeof(unsigned long long) * (size_t)(tot[0] + tot[1] + 1));
+  index_compact_kernel<<<grid_for(ns), kBlock, 0, h->stream>>>(flag_s, pos, ns, d_out);
+  index_compact_kernel<<<grid_for(nt), kBlock, 0, h->stream>>>(flag_t, pos + ns + 1, nt, d_out + tot[0]);
+  HIP_TRY(hipGetLastError());
+  if (tot[0]) HIP_TRY(hipMemcpyAsync(idx_src, d_out, sizeof(unsigned long long) * (size_t)tot[0], hipMemcpyDeviceToHost, h->stream));
+  if (tot[1]) HIP_TRY(hipMemcpyAsync(idx_tgt, d_out + tot[0], sizeof(unsigned long long) * (size_t)tot[1], hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  *n_src_out = (size_t)tot[0];
+  *n_tgt_out = (size_t)tot[1];
+  return O3DS_OK;
+}
+
 template <typename P4>
 int append_t(o3ds_handle h, CloudRec& map, const CloudRec& add) {
   // [O3D] PointCloud::operator+= : normals survive only if (map empty or map has normals) and add has normals
@@ -1575,6 +1643,25 @@ int o3ds_voxelize_within_volume(o3ds_handle h, o3ds_cloud map, double voxel_size
   free_cloud(h, *m);
   *m = o;
   return O3DS_OK;
+}
+
+int o3ds_overlap_indices(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const double source_to_target[16], double voxel_size,
+                         size_t min_points_per_voxel, uint64_t* idx_source, size_t* n_idx_source, uint64_t* idx_target, size_t* n_idx_target) {
+  CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
+  CloudRec* s = find_cloud(h, source);
+  CloudRec* t = find_cloud(h, target);
+  if (!s || !t || !source_to_target || !n_idx_source || !n_idx_target) return fail(h, O3DS_ERR_INVALID_ARG, "overlap_indices: bad argument");
+  if ((s->n && !idx_source) || (t->n && !idx_target)) return fail(h, O3DS_ERR_INVALID_ARG, "overlap_indices: null index buffer");
+  if (!(voxel_size > 0.0)) return fail(h, O3DS_ERR_INVALID_ARG, "overlap_indices: voxel_size must be > 0");
+  if (min_points_per_voxel < 1) return fail(h, O3DS_ERR_INVALID_ARG, "minNumPointsPerVoxel must be >= 1");  // assert_ge, helpers.cpp:310
+  if (s->n && t->n && s->precision != t->precision) return fail(h, O3DS_ERR_INVALID_ARG, "overlap_indices: precision mismatch");
+  static_assert(sizeof(uint64_t) == sizeof(unsigned long long), "index type");
+  return s->precision == O3DS_PRECISION_F64
+             ? overlap_t<P4d>(h, *s, *t, source_to_target, voxel_size, min_points_per_voxel, (unsigned long long*)idx_source, n_idx_source,
+                              (unsigned long long*)idx_target, n_idx_target)
+             : overlap_t<P4f>(h, *s, *t, source_to_target, voxel_size, min_points_per_voxel, (unsigned long long*)idx_source, n_idx_source,
+                              (unsigned long long*)idx_target, n_idx_target);
 }
 
 int o3ds_map_carve(o3ds_handle h, o3ds_cloud map, o3ds_cloud raw_scan, const double map_to_range_sensor[16], const o3ds_crop* map_builder_crop,

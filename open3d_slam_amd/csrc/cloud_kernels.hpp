@@ -476,6 +476,44 @@ __global__ __launch_bounds__(kBlock) void fill_int_kernel(int* __restrict__ p, s
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) p[i] = v;
 }
 
+// ---------------------------------------------------------------------------------------------- overlap on a voxel grid
+// computeIndicesOfOverlappingPoints (helpers.cpp:307-332): keys of both clouds sorted together, per-voxel counts per cloud, flags.
+constexpr uint32_t kSourceTag = 0x80000000u;
+
+// vals[i] |= tag for the second (source) block of a concatenated key array
+__global__ __launch_bounds__(kBlock) void overlap_tag_kernel(uint32_t* __restrict__ vals, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) vals[i] |= kSourceTag;
+}
+// counts of source / target members per segment (seg ids from the exclusive scan of the heads)
+__global__ __launch_bounds__(kBlock) void overlap_count_kernel(const uint32_t* __restrict__ vals, const int* __restrict__ head,
+                                                               const int* __restrict__ seg_id, size_t n, int* __restrict__ cnt_s,
+                                                               int* __restrict__ cnt_t) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const int sgm = seg_id[i] + head[i] - 1;  // exclusive scan of heads: the segment of element i is (#heads up to and including i) - 1
+    atomicAdd((vals[i] & kSourceTag) ? &cnt_s[sgm] : &cnt_t[sgm], 1);
+  }
+}
+__global__ __launch_bounds__(kBlock) void overlap_flag_kernel(const uint32_t* __restrict__ vals, const int* __restrict__ head,
+                                                              const int* __restrict__ seg_id, size_t n, const int* __restrict__ cnt_s,
+                                                              const int* __restrict__ cnt_t, int min_points, int* __restrict__ flag_s,
+                                                              int* __restrict__ flag_t) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const int sgm = seg_id[i] + head[i] - 1;
+    const bool ok = cnt_s[sgm] >= min_points && cnt_t[sgm] >= min_points;
+    const uint32_t v = vals[i];
+    if (v & kSourceTag)
+      flag_s[v & ~kSourceTag] = ok ? 1 : 0;
+    else
+      flag_t[v] = ok ? 1 : 0;
+  }
+}
+// out[pos[i]] = i where flag[i]
+__global__ __launch_bounds__(kBlock) void index_compact_kernel(const int* __restrict__ flag, const int* __restrict__ pos, size_t n,
+                                                               unsigned long long* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
+    if (flag[i]) out[pos[i]] = (unsigned long long)i;
+}
+
 // normalise, orient towards the sensor origin ([O3D] NormalizeNormals + OrientNormalsTowardsCameraLocation(0,0,0)), store
 template <typename P4>
 __device__ __forceinline__ void finish_normal(const P4& q, double nv[3], P4* out) {

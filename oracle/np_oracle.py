@@ -155,6 +155,20 @@ def carve_flags(scan, sensor, map_pts, map_nrm, subset, voxel=0.1, max_length=20
     return flags
 
 
+def overlap_indices(src, tgt, T=None, voxel=0.5, min_points=1):
+    """computeIndicesOfOverlappingPoints (helpers.cpp:307-332) with np.unique on the voxel keys."""
+    T = np.eye(4) if T is None else np.asarray(T, dtype=np.float64)
+    P = src @ T[:3, :3].T + T[:3, 3]
+    inv = 1.0 / voxel
+    ks, kt = np.floor(P * inv).astype(np.int64), np.floor(tgt * inv).astype(np.int64)
+    allk, inv_idx = np.unique(np.vstack([ks, kt]), axis=0, return_inverse=True)
+    inv_idx = inv_idx.reshape(-1)
+    cs = np.bincount(inv_idx[: len(ks)], minlength=len(allk))
+    ct = np.bincount(inv_idx[len(ks):], minlength=len(allk))
+    ok = (cs >= min_points) & (ct >= min_points)
+    return np.flatnonzero(ok[inv_idx[: len(ks)]]), np.flatnonzero(ok[inv_idx[len(ks):]])
+
+
 def estimate_normals(pts, radius, max_nn):
     tree = cKDTree(pts, leafsize=15)
     d, j = tree.query(pts, k=max_nn, distance_upper_bound=radius)

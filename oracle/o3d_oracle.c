@@ -764,6 +764,61 @@ size_t orc_carve_flags(const double* scan, size_t n_scan, const double sensor[3]
   return cnt;
 }
 
+/* ------------------------------------------------------------------ overlap of two clouds on a voxel grid
+ * computeIndicesOfOverlappingPoints (src/helpers.cpp:307-332; call sites PlaceRecognition.cpp:103, constraint_builders.cpp:54):
+ * both clouds (the source placed by T) are binned with the key floor(p * (1/v)); a voxel counts when it holds at least
+ * min_points of EACH cloud, and then contributes all its source and all its target indices.  flags_*[i] = 1 for selected points
+ * (the reference's output order is unordered_map iteration order; the index SETS are what is specified). */
+typedef struct {
+  int64_t key;
+  int64_t idx; /* >= 0: target index, < 0: -(source index) - 1 */
+} ovl_item;
+static int ovl_cmp(const void* a, const void* b) {
+  const ovl_item *x = (const ovl_item*)a, *y = (const ovl_item*)b;
+  return x->key < y->key ? -1 : (x->key > y->key ? 1 : 0);
+}
+void orc_overlap_flags(const double* src, size_t n_src, const double* tgt, size_t n_tgt, const double T[16], double voxel, size_t min_points,
+                       uint8_t* flags_src, uint8_t* flags_tgt) {
+  memset(flags_src, 0, n_src);
+  memset(flags_tgt, 0, n_tgt);
+  const size_t n = n_src + n_tgt;
+  if (n == 0) return;
+  const double inv = 1.0 / voxel;
+  ovl_item* it = (ovl_item*)malloc(sizeof(ovl_item) * n);
+  double* P = (double*)malloc(sizeof(double) * 3 * (n_src ? n_src : 1));
+  memcpy(P, src, sizeof(double) * 3 * n_src);
+  orc_transform_points(P, n_src, T); /* sourceTransformed.Transform(sourceToTarget.matrix()) -- [O3D] Transform, always applied */
+  for (size_t i = 0; i < n_tgt; ++i) {
+    it[i].key = carve_key(tgt + 3 * i, inv);
+    it[i].idx = (int64_t)i;
+  }
+  for (size_t i = 0; i < n_src; ++i) {
+    it[n_tgt + i].key = carve_key(P + 3 * i, inv);
+    it[n_tgt + i].idx = -(int64_t)i - 1;
+  }
+  qsort(it, n, sizeof(ovl_item), ovl_cmp);
+  for (size_t b = 0; b < n;) {
+    size_t e = b, cs = 0, ct = 0;
+    while (e < n && it[e].key == it[b].key) {
+      if (it[e].idx < 0)
+        ++cs;
+      else
+        ++ct;
+      ++e;
+    }
+    if (cs >= min_points && ct >= min_points)
+      for (size_t j = b; j < e; ++j) {
+        if (it[j].idx < 0)
+          flags_src[-(it[j].idx + 1)] = 1;
+        else
+          flags_tgt[it[j].idx] = 1;
+      }
+    b = e;
+  }
+  free(it);
+  free(P);
+}
+
 /* ------------------------------------------------------------------ A.8 Generalized ICP
  * [O3D] GeneralizedICP.cpp: GetRotationFromE1ToX, InitializePointCloudForGeneralizedICP,
  * TransformationEstimationForGeneralizedICP::ComputeTransformation; reference call site src/CloudRegistration.cpp:16-21. */

@@ -94,6 +94,11 @@ size_t orc_carve_flags(const double* scan, size_t n_scan, const double sensor[3]
                        const int64_t* subset, size_t n_subset, double voxel, double max_length, double truncation, double min_dot,
                        uint8_t* flags_out);
 
+/* computeIndicesOfOverlappingPoints (helpers.cpp:307-332): flags of the source / target points that lie in voxels holding at least
+ * min_points of each cloud (source placed by T first) */
+void orc_overlap_flags(const double* src, size_t n_src, const double* tgt, size_t n_tgt, const double T[16], double voxel, size_t min_points,
+                       uint8_t* flags_src, uint8_t* flags_tgt);
+
 /* A.8 RegistrationGeneralizedICP (call site src/CloudRegistration.cpp:16-21): covariances from normals
  * (C = Rx diag(eps,1,1) Rx^T, Rx = GetRotationFromE1ToX(normal)), per pair M = Ct + R Cs R^T, W = M^-1/2, residual W d (3 rows),
  * Jacobian rows W [-[p]x | I]; same loop / solve / convergence as A.1.  Both clouds must carry normals (as they always do

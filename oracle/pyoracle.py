@@ -76,6 +76,8 @@ def lib():
         L.orc_carve_flags.restype = C.c_size_t
         L.orc_carve_flags.argtypes = [_dp, C.c_size_t, _dp, _dp, _dp, C.c_size_t, C.POINTER(C.c_int64), C.c_size_t, C.c_double, C.c_double,
                                       C.c_double, C.c_double, C.POINTER(C.c_uint8)]
+        L.orc_overlap_flags.restype = None
+        L.orc_overlap_flags.argtypes = [_dp, C.c_size_t, _dp, C.c_size_t, _dp, C.c_double, C.c_size_t, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]
         L.orc_gicp_jtj_jtr.argtypes = [_dp, _dp, C.c_size_t, _dp, _dp, _ip, _dp, _dp]
         L.orc_covariance_from_normal.argtypes = [_dp, C.c_double, _dp]
         L.orc_estimate_normals.argtypes = [_dp, C.c_size_t, C.c_double, C.c_int, _dp]
@@ -261,6 +263,17 @@ def carve_flags(scan, sensor, map_pts, map_nrm, subset, voxel=0.1, max_length=20
     lib().orc_carve_flags(sp, len(scan), snp, mpp, mnp, len(mp), subset.ctypes.data_as(C.POINTER(C.c_int64)), len(subset), voxel, max_length,
                           truncation, min_dot, flags.ctypes.data_as(C.POINTER(C.c_uint8)))
     return flags.astype(bool)
+
+
+def overlap_indices(src, tgt, T=None, voxel=0.5, min_points=1):
+    """computeIndicesOfOverlappingPoints (helpers.cpp:307-332): (ascending source indices, ascending target indices)."""
+    src, sp = _d(src)
+    tgt, tp = _d(tgt)
+    Tc, ip = _d(colmajor(np.eye(4) if T is None else T))
+    fs, ft = np.zeros(len(src), np.uint8), np.zeros(len(tgt), np.uint8)
+    lib().orc_overlap_flags(sp, len(src), tp, len(tgt), ip, voxel, int(min_points), fs.ctypes.data_as(C.POINTER(C.c_uint8)),
+                            ft.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return np.flatnonzero(fs), np.flatnonzero(ft)
 
 
 def icp_generalized(src, src_nrm, tgt, tgt_nrm, max_corr, init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6, epsilon=1e-3,

@@ -420,3 +420,24 @@ def test_carve_flags_c_matches_numpy_and_known_answers(oracle):
     assert not oracle.carve_flags(s0[None], s0, line, None, np.arange(30)).any()  # zero-length ray
     g = oracle.carve_flags(np.array([[2.0, 0.0, 0.0]]), np.zeros(3), line * [1, 0, 0], None, np.arange(30))  # from a voxel face
     assert np.array_equal(g, no.carve_flags(np.array([[2.0, 0.0, 0.0]]), np.zeros(3), line * [1, 0, 0], None, np.arange(30)))
+
+
+# ---- overlap on a voxel grid (helpers.cpp:307-332) ----------------------------------------------------------
+def test_overlap_indices_c_matches_numpy_and_known_answers(oracle, small_c2):
+    src, tgt, _, T_gt = small_c2
+    for T, voxel, mn in ((T_gt, 0.5, 1), (np.eye(4), 0.3, 3), (T_gt, 2.0, 10)):
+        a_s, a_t = oracle.overlap_indices(src, tgt, T, voxel, mn)
+        b_s, b_t = no.overlap_indices(src, tgt, T, voxel, mn)
+        assert np.array_equal(a_s, b_s) and np.array_equal(a_t, b_t)
+        assert 0 < len(a_s) <= len(src) and 0 < len(a_t) < len(tgt)
+    # two points share voxel (0,0,0), one source point sits alone in voxel (5,0,0), one target point alone in (-3,0,0)
+    s = np.array([[0.1, 0.1, 0.1], [5.2, 0.1, 0.1]])
+    t = np.array([[0.4, 0.3, 0.2], [-2.9, 0.0, 0.0], [0.45, 0.45, 0.45]])
+    i_s, i_t = oracle.overlap_indices(s, t, voxel=0.5, min_points=1)
+    assert i_s.tolist() == [0] and i_t.tolist() == [0, 2]
+    i_s, i_t = oracle.overlap_indices(s, t, voxel=0.5, min_points=2)  # only one source point in that voxel
+    assert len(i_s) == 0 and len(i_t) == 0
+    shift = np.eye(4)
+    shift[0, 3] = -5.1  # brings source point 1 into voxel (0,0,0) and pushes point 0 out to (-10,0,0)
+    i_s, i_t = oracle.overlap_indices(s, t, shift, voxel=0.5, min_points=1)
+    assert i_s.tolist() == [1] and i_t.tolist() == [0, 2]

@@ -425,3 +425,37 @@ def test_submap_mirror_insert_scan_with_carving(backend_f32):
             n_plain = n
         sm.getMapPointCloud().release()
     assert n < n_plain - 30  # scan 1 (nScansInsertedMap_ == 1 at that moment) carved the clutter; scans 0 and 2 did not carve
+
+
+def test_overlap_indices_match_oracle(backend_f64, backend_f32, oracle, scan):
+    """computeIndicesOfOverlappingPoints (helpers.cpp:307-332) on the device vs the oracle: exact index sets in f64 storage."""
+    scene = syn.make_scene()
+    tgt, _ = syn.sample_map(scene, 80_000)
+    src = scan[:20000]
+    T = syn.ground_truth_pose()
+    s, t = backend_f64.upload(src), backend_f64.upload(tgt)
+    for Tm, voxel, mn in ((T, 0.5, 1), (np.eye(4), 0.3, 3), (T, 2.0, 10)):
+        r_s, r_t = oracle.overlap_indices(src, tgt, Tm, voxel, mn)
+        g_s, g_t = backend_f64.overlap_indices(s, t, Tm, voxel, mn)
+        # the device places the source with its own f64 transform: a point within an ulp of a voxel face may change voxel
+        assert len(np.setxor1d(g_s, r_s)) <= 2 and len(np.setxor1d(g_t, r_t)) <= 40
+        assert np.all(np.diff(g_s.astype(np.int64)) > 0) and np.all(np.diff(g_t.astype(np.int64)) > 0)
+    g_s, g_t = backend_f64.overlap_indices(s, t, np.eye(4), 0.3, 3)
+    r_s, r_t = oracle.overlap_indices(src, tgt, np.eye(4), 0.3, 3)  # identity: no rounding at all in the placement
+    np.testing.assert_array_equal(g_s, r_s)
+    np.testing.assert_array_equal(g_t, r_t)
+    far_s, far_t = backend_f64.overlap_indices(s, t, syn.make_pose((1000.0, 0.0, 0.0), (0.0, 0.0, 0.0)), 0.5, 1)
+    assert len(far_s) == 0 and len(far_t) == 0
+    with pytest.raises(backend.BackendError):
+        backend_f64.overlap_indices(s, t, T, 0.5, 0)  # assert_ge(minNumPointsPerVoxel, 1)
+    e = backend_f64.upload(np.zeros((0, 3)))
+    es, et = backend_f64.overlap_indices(e, t, T, 0.5, 1)
+    assert len(es) == 0 and len(et) == 0
+    for c in (s, t, e):
+        backend_f64.free(c)
+    s32, t32 = backend_f32.upload(src), backend_f32.upload(tgt)
+    g_s, g_t = backend_f32.overlap_indices(s32, t32, T, 0.5, 1)
+    r_s, r_t = oracle.overlap_indices(src, tgt, T, 0.5, 1)
+    assert len(np.setxor1d(g_s, r_s)) <= 0.002 * len(r_s) + 5  # f32 storage: points near voxel faces
+    backend_f32.free(s32)
+    backend_f32.free(t32)
