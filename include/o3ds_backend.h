@@ -228,6 +228,23 @@ int o3ds_cloud_append(o3ds_handle h, o3ds_cloud map, o3ds_cloud add);
 int o3ds_voxelize_within_volume(o3ds_handle h, o3ds_cloud map, double voxel_size, const o3ds_crop* crop);
 /* Submap::insertScan core (Submap.cpp:54,70-72) in one call: map += T*scan; re-voxelize inside crop; rebuild the
  * NN index (max_corr_hint as in o3ds_cloud_build_index; <= 0 skips the rebuild). */
+/* Dense voxel map = VoxelizedPointCloud (include/open3d_slam/Voxel.hpp:38-76, src/Voxel.cpp:18-114), the "TSDF-style" fusion of
+ * BASELINE configs[4]: a persistent map voxel (key floor(p / voxel_size)) -> {count, sum of positions, sum of normals}.
+ *   insert    : VoxelizedPointCloud::insert of o3d_slam::transform(T, cloud) (Submap::insertScanDenseMap, Submap.cpp:77-92); T may be
+ *               NULL (identity).  The cropping steps of insertScanDenseMap are o3ds_crop_cloud calls of the caller.
+ *   to_cloud  : toPointCloud -- sum / count per voxel (the mean normal is NOT re-normalised, Voxel.cpp:21-23), voxels in ascending key
+ *               order (the reference's order is its hash map's).
+ *   transform : VoxelizedPointCloud::transform (Voxel.cpp:49-64) as written: keys unchanged, the Isometry applied to the sums as
+ *               if they were points (its translation enters the position sum once, and the normal sum too).
+ * Sums are kept in fixed point on the device (2^-30 m / 2^-40), so a map does not depend on the order of concurrent insertions.
+ * Carving of the dense map (getKeysOfCarvedPoints) is not built. */
+typedef uint64_t o3ds_dense_map;
+int o3ds_dense_map_create(o3ds_handle h, double voxel_size, o3ds_dense_map* out);
+int o3ds_dense_map_free(o3ds_handle h, o3ds_dense_map id);
+int o3ds_dense_map_insert(o3ds_handle h, o3ds_dense_map id, o3ds_cloud cloud, const double T[16]);
+int o3ds_dense_map_size(o3ds_handle h, o3ds_dense_map id, size_t* n_voxels);
+int o3ds_dense_map_to_cloud(o3ds_handle h, o3ds_dense_map id, o3ds_cloud* out);
+int o3ds_dense_map_transform(o3ds_handle h, o3ds_dense_map id, const double T[16]);
 /* computeIndicesOfOverlappingPoints (src/helpers.cpp:307-332; call sites src/PlaceRecognition.cpp:103,
  * src/constraint_builders.cpp:54): both clouds are binned with the voxel key floor(p / voxel_size) -- the source after being
  * placed by source_to_target --, and every voxel that holds at least min_points_per_voxel points of EACH cloud contributes all its

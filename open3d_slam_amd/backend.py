@@ -69,6 +69,12 @@ SIGNATURES = {
     "o3ds_icp_register_dev": (C.c_int, [_H, _CL, _CL, C.POINTER(Crop), _dp, C.POINTER(IcpParams), C.POINTER(IcpResult)]),
     "o3ds_icp_pass": (C.c_int, [_H, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "o3ds_icp_pass_finish": (C.c_int, [_H, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(IcpResult)]),
+    "o3ds_dense_map_create": (C.c_int, [_H, C.c_double, C.POINTER(C.c_uint64)]),
+    "o3ds_dense_map_free": (C.c_int, [_H, C.c_uint64]),
+    "o3ds_dense_map_insert": (C.c_int, [_H, C.c_uint64, _CL, _dp]),
+    "o3ds_dense_map_size": (C.c_int, [_H, C.c_uint64, C.POINTER(C.c_size_t)]),
+    "o3ds_dense_map_to_cloud": (C.c_int, [_H, C.c_uint64, C.POINTER(_CL)]),
+    "o3ds_dense_map_transform": (C.c_int, [_H, C.c_uint64, _dp]),
     "o3ds_overlap_indices": (C.c_int, [_H, _CL, _CL, _dp, C.c_double, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_size_t),
                                        C.POINTER(C.c_uint64), C.POINTER(C.c_size_t)]),
     "o3ds_map_carve": (C.c_int, [_H, _CL, _CL, _dp, C.POINTER(Crop), C.POINTER(CarvingParams), C.POINTER(C.c_size_t)]),
@@ -389,6 +395,36 @@ class Backend:
 
     def voxelize_within_volume(self, map_id: int, voxel: float, crop: Crop):
         self._ck(self.lib.o3ds_voxelize_within_volume(self.h, map_id, voxel, C.byref(crop)))
+
+    # -- dense voxel map (VoxelizedPointCloud)
+    def dense_map_create(self, voxel: float) -> int:
+        d = C.c_uint64(0)
+        self._ck(self.lib.o3ds_dense_map_create(self.h, float(voxel), C.byref(d)))
+        return d.value
+
+    def dense_map_free(self, dm: int):
+        self._ck(self.lib.o3ds_dense_map_free(self.h, dm))
+
+    def dense_map_insert(self, dm: int, cloud: int, T=None):
+        if T is None:
+            self._ck(self.lib.o3ds_dense_map_insert(self.h, dm, cloud, None))
+        else:
+            Tc, tp = _d(colmajor(T))
+            self._ck(self.lib.o3ds_dense_map_insert(self.h, dm, cloud, tp))
+
+    def dense_map_size(self, dm: int) -> int:
+        n = C.c_size_t(0)
+        self._ck(self.lib.o3ds_dense_map_size(self.h, dm, C.byref(n)))
+        return int(n.value)
+
+    def dense_map_to_cloud(self, dm: int) -> int:
+        cid = _CL()
+        self._ck(self.lib.o3ds_dense_map_to_cloud(self.h, dm, C.byref(cid)))
+        return cid.value
+
+    def dense_map_transform(self, dm: int, T):
+        Tc, tp = _d(colmajor(T))
+        self._ck(self.lib.o3ds_dense_map_transform(self.h, dm, tp))
 
     def overlap_indices(self, source: int, target: int, T=None, voxel: float = 0.5, min_points: int = 1):
         """computeIndicesOfOverlappingPoints: (ascending source indices, ascending target indices) as uint64 arrays."""

@@ -42,12 +42,22 @@ constexpr size_t kMaxCells = (size_t)1 << 27;  // 512 MiB of cell_start at most
 
 }  // namespace
 
+// dense voxel map (VoxelizedPointCloud): a device hash table, see cloud_kernels.hpp
+struct DenseRec {
+  double voxel = 0.0;
+  size_t cap = 0;          // power of two
+  o3ds::DenseDev dev{};
+  bool has_normals = false;
+  size_t used_upper = 0;   // upper bound on the used slots (exact count fetched only when the table looks too full)
+};
+
 struct o3ds_context {
   int device = 0;
   hipStream_t stream = nullptr;
   int precision = O3DS_PRECISION_F32;
   std::string err;
   std::unordered_map<uint64_t, CloudRec> clouds;
+  std::unordered_map<uint64_t, DenseRec> dense_maps;
   uint64_t next_id = 1;
   // ICP scratch
   double* d_partials = nullptr;     // [kMaxPassBlocks][kRec]
@@ -359,6 +369,127 @@ o3ds_cloud add_cloud(o3ds_handle h, CloudRec&& c) {
   return id;
 }
 
+// ---- dense voxel map helpers -----------------------------------------------------------------------
+void dense_release(o3ds_handle h, DenseRec& d) {
+  if (d.dev.keys) (void)hipFreeAsync(d.dev.keys, h->stream);
+  if (d.dev.cnt) (void)hipFreeAsync(d.dev.cnt, h->stream);
+  if (d.dev.sp) (void)hipFreeAsync(d.dev.sp, h->stream);
+  if (d.dev.sn) (void)hipFreeAsync(d.dev.sn, h->stream);
+  d.dev = o3ds::DenseDev{};
+  d.cap = 0;
+}
+
+int dense_alloc(o3ds_handle h, size_t cap, o3ds::DenseDev* out) {
+  o3ds::DenseDev d{};
+  HIP_TRY(hipMallocAsync((void**)&d.keys, sizeof(unsigned long long) * cap, h->stream));
+  HIP_TRY(hipMallocAsync((void**)&d.cnt, sizeof(int) * cap, h->stream));
+  HIP_TRY(hipMallocAsync((void**)&d.sp, sizeof(long long) * 3 * cap, h->stream));
+  HIP_TRY(hipMallocAsync((void**)&d.sn, sizeof(long long) * 3 * cap, h->stream));
+  HIP_TRY(hipMemsetAsync(d.keys, 0xFF, sizeof(unsigned long long) * cap, h->stream));
+  HIP_TRY(hipMemsetAsync(d.cnt, 0, sizeof(int) * cap, h->stream));
+  HIP_TRY(hipMemsetAsync(d.sp, 0, sizeof(long long) * 3 * cap, h->stream));
+  HIP_TRY(hipMemsetAsync(d.sn, 0, sizeof(long long) * 3 * cap, h->stream));
+  d.mask = (unsigned int)(cap - 1);
+  *out = d;
+  return O3DS_OK;
+}
+
+// number of used voxels (one scan + one 4-byte read back)
+int dense_count(o3ds_handle h, DenseRec& d, size_t* n_used, int** flag_out = nullptr, int** pos_out = nullptr) {
+  *n_used = 0;
+  if (d.cap == 0) return O3DS_OK;
+  int *flag = nullptr, *pos = nullptr;
+  TMP_ALLOC(flag, sizeof(int) * (d.cap + 1));
+  TMP_ALLOC(pos, sizeof(int) * (d.cap + 1));
+  HIP_TRY(hipMemsetAsync(flag + d.cap, 0, sizeof(int), h->stream));
+  dense_used_flag_kernel<<<grid_for(d.cap), kBlock, 0, h->stream>>>(d.dev, d.cap, flag);
+  int rc = exclusive_scan_int(h, flag, pos, d.cap + 1);
+  if (rc) return rc;
+  int total = 0;
+  HIP_TRY(hipMemcpyAsync(&total, pos + d.cap, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  *n_used = (size_t)total;
+  d.used_upper = (size_t)total;
+  if (flag_out) *flag_out = flag;
+  if (pos_out) *pos_out = pos;
+  return O3DS_OK;
+}
+
+// make room for up to n_new more voxels (load factor <= 1/2)
+int dense_reserve(o3ds_handle h, DenseRec& d, size_t n_new) {
+  if (d.cap && (d.used_upper + n_new) * 2 <= d.cap) {
+    d.used_upper += n_new;
+    return O3DS_OK;
+  }
+  size_t used = 0;
+  if (d.cap) {
+    int rc = dense_count(h, d, &used);  // the bound was pessimistic (most points fall into existing voxels): tighten it first
+    if (rc) return rc;
+    if ((used + n_new) * 2 <= d.cap) {
+      d.used_upper = used + n_new;
+      return O3DS_OK;
+    }
+  }
+  size_t cap = 1024;
+  while (cap < 4 * (used + n_new)) cap <<= 1;
+  if (cap > ((size_t)1 << 31)) return fail(h, O3DS_ERR_OOM, "dense map: table would exceed 2^31 slots");
+  o3ds::DenseDev nd{};
+  int rc = dense_alloc(h, cap, &nd);
+  if (rc) return rc;
+  if (d.cap) {
+    dense_rehash_kernel<<<grid_for(d.cap), kBlock, 0, h->stream>>>(d.dev, d.cap, nd);
+    HIP_TRY(hipGetLastError());
+    DenseRec old = d;
+    dense_release(h, old);
+  }
+  d.dev = nd;
+  d.cap = cap;
+  d.used_upper = used + n_new;
+  return O3DS_OK;
+}
+
+template <typename P4>
+int dense_insert_t(o3ds_handle h, DenseRec& d, const CloudRec& c, const double T[16]) {
+  if (c.n == 0) return O3DS_OK;
+  int rc = dense_reserve(h, d, c.n);
+  if (rc) return rc;
+  Mat34 M;
+  for (int r = 0; r < 3; ++r)
+    for (int col = 0; col < 4; ++col) M.m[r * 4 + col] = T ? T[col * 4 + r] : (r == col ? 1.0 : 0.0);
+  dense_insert_kernel<P4><<<grid_for(c.n), kBlock, 0, h->stream>>>((const P4*)c.pts, (const P4*)c.nrm, c.n, M, 1.0 / d.voxel, d.dev);
+  HIP_TRY(hipGetLastError());
+  if (c.nrm) d.has_normals = true;  // isHasNormals_, Voxel.cpp:80-83
+  return O3DS_OK;
+}
+
+template <typename P4>
+int dense_to_cloud_t(o3ds_handle h, DenseRec& d, CloudRec& out) {
+  out.precision = h->precision;
+  out.n = 0;
+  size_t used = 0;
+  int *flag = nullptr, *pos = nullptr;
+  int rc = dense_count(h, d, &used, &flag, &pos);
+  if (rc || used == 0) return rc;
+  unsigned long long *k0 = nullptr, *k1 = nullptr;
+  uint32_t *s0 = nullptr, *s1 = nullptr;
+  TMP_ALLOC(k0, sizeof(unsigned long long) * used);
+  TMP_ALLOC(k1, sizeof(unsigned long long) * used);
+  TMP_ALLOC(s0, sizeof(uint32_t) * used);
+  TMP_ALLOC(s1, sizeof(uint32_t) * used);
+  dense_list_kernel<<<grid_for(d.cap), kBlock, 0, h->stream>>>(d.dev, d.cap, flag, pos, k0, s0);
+  size_t temp_bytes = 0;  // ascending key order: the table order depends on how insertions interleaved, the output must not
+  HIP_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, k0, k1, s0, s1, used, 0, 64, h->stream));
+  void* temp = nullptr;
+  TMP_ALLOC(temp, temp_bytes ? temp_bytes : 16);
+  HIP_TRY(rocprim::radix_sort_pairs(temp, temp_bytes, k0, k1, s0, s1, used, 0, 64, h->stream));
+  out.n = used;
+  HIP_TRY(hipMallocAsync(&out.pts, sizeof(P4) * used, h->stream));
+  if (d.has_normals) HIP_TRY(hipMallocAsync(&out.nrm, sizeof(P4) * used, h->stream));
+  dense_emit_kernel<P4><<<grid_for(used), kBlock, 0, h->stream>>>(d.dev, s1, used, (P4*)out.pts, (P4*)out.nrm);
+  HIP_TRY(hipGetLastError());
+  return O3DS_OK;
+}
+
 // ---- ICP launch helpers -------------------------------------------------------------------------
 template <typename P4>
 void launch_accumulate(o3ds_handle h, const IcpPassArgs& a, bool crop, int nblocks) {
@@ -623,6 +754,7 @@ int o3ds_destroy(o3ds_handle h) {
   (void)hipStreamSynchronize(h->stream);
   (void)hipStreamSynchronize(h->own_stream);
   for (auto& kv : h->clouds) free_cloud(h, kv.second);
+  for (auto& kv : h->dense_maps) dense_release(h, kv.second);
   for (auto& b : h->arena_blocks) (void)hipFreeAsync(b.first, h->stream);
   (void)hipStreamSynchronize(h->stream);
   if (h->d_fused) (void)hipFree(h->d_fused);
@@ -1642,6 +1774,74 @@ int o3ds_voxelize_within_volume(o3ds_handle h, o3ds_cloud map, double voxel_size
   }
   free_cloud(h, *m);
   *m = o;
+  return O3DS_OK;
+}
+
+int o3ds_dense_map_create(o3ds_handle h, double voxel_size, o3ds_dense_map* out) {
+  CHECK_HANDLE(h);
+  if (!out) return fail(h, O3DS_ERR_INVALID_ARG, "dense_map_create: null out");
+  if (!(voxel_size > 0.0)) return fail(h, O3DS_ERR_INVALID_ARG, "dense_map_create: voxel_size must be > 0");
+  DenseRec d;
+  d.voxel = voxel_size;
+  const uint64_t id = h->next_id++;
+  h->dense_maps.emplace(id, d);
+  *out = id;
+  return O3DS_OK;
+}
+
+int o3ds_dense_map_free(o3ds_handle h, o3ds_dense_map id) {
+  CHECK_HANDLE(h);
+  auto it = h->dense_maps.find(id);
+  if (it == h->dense_maps.end()) return fail(h, O3DS_ERR_INVALID_ARG, "dense_map_free: unknown id");
+  (void)hipStreamSynchronize(h->stream);
+  dense_release(h, it->second);
+  h->dense_maps.erase(it);
+  return O3DS_OK;
+}
+
+int o3ds_dense_map_insert(o3ds_handle h, o3ds_dense_map id, o3ds_cloud cloud, const double T[16]) {
+  CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
+  auto it = h->dense_maps.find(id);
+  CloudRec* c = find_cloud(h, cloud);
+  if (it == h->dense_maps.end() || !c) return fail(h, O3DS_ERR_INVALID_ARG, "dense_map_insert: unknown id");
+  return c->precision == O3DS_PRECISION_F64 ? dense_insert_t<P4d>(h, it->second, *c, T) : dense_insert_t<P4f>(h, it->second, *c, T);
+}
+
+int o3ds_dense_map_size(o3ds_handle h, o3ds_dense_map id, size_t* n_voxels) {
+  CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
+  auto it = h->dense_maps.find(id);
+  if (it == h->dense_maps.end() || !n_voxels) return fail(h, O3DS_ERR_INVALID_ARG, "dense_map_size: bad argument");
+  return dense_count(h, it->second, n_voxels);
+}
+
+int o3ds_dense_map_to_cloud(o3ds_handle h, o3ds_dense_map id, o3ds_cloud* out) {
+  CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
+  auto it = h->dense_maps.find(id);
+  if (it == h->dense_maps.end() || !out) return fail(h, O3DS_ERR_INVALID_ARG, "dense_map_to_cloud: bad argument");
+  CloudRec o;
+  const int rc = h->precision == O3DS_PRECISION_F64 ? dense_to_cloud_t<P4d>(h, it->second, o) : dense_to_cloud_t<P4f>(h, it->second, o);
+  if (rc) {
+    free_cloud(h, o);
+    return rc;
+  }
+  *out = add_cloud(h, std::move(o));
+  return O3DS_OK;
+}
+
+int o3ds_dense_map_transform(o3ds_handle h, o3ds_dense_map id, const double T[16]) {
+  CHECK_HANDLE(h);
+  auto it = h->dense_maps.find(id);
+  if (it == h->dense_maps.end() || !T) return fail(h, O3DS_ERR_INVALID_ARG, "dense_map_transform: bad argument");
+  DenseRec& d = it->second;
+  if (d.cap == 0) return O3DS_OK;
+  Mat34 M;
+  for (int r = 0; r < 3; ++r)
+    for (int col = 0; col < 4; ++col) M.m[r * 4 + col] = T[col * 4 + r];
+  dense_transform_kernel<<<grid_for(d.cap), kBlock, 0, h->stream>>>(d.dev, d.cap, M);
+  HIP_TRY(hipGetLastError());
   return O3DS_OK;
 }
 

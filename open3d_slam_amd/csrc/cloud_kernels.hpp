@@ -514,6 +514,127 @@ __global__ __launch_bounds__(kBlock) void index_compact_kernel(const int* __rest
     if (flag[i]) out[pos[i]] = (unsigned long long)i;
 }
 
+// ---------------------------------------------------------------------------------------------- dense voxel map
+// VoxelizedPointCloud (Voxel.hpp:38-76, Voxel.cpp:18-114): a persistent hash map voxel -> {count, sum of positions, sum of normals}.
+// Device form: open addressing on the packed 64-bit voxel key (atomicCAS), counts and sums updated with integer atomics -- the sums
+// are kept in FIXED POINT (2^-30 m for positions, 2^-40 for normals), so they are exact, order-independent and reproducible no matter
+// how the insertions interleave; the quantisation (<= 0.5 nm per inserted point) is far below the f32 / f64 noise of the inputs.
+constexpr double kDensePosQ = 1.0 / 1073741824.0;        // 2^-30
+constexpr double kDenseNrmQ = 1.0 / 1099511627776.0;     // 2^-40
+
+struct DenseDev {
+  unsigned long long* keys;  // [cap], kEmptyKey = free
+  int* cnt;                  // [cap]
+  long long* sp;             // [3 * cap] sum of positions / kDensePosQ
+  long long* sn;             // [3 * cap] sum of normals / kDenseNrmQ
+  unsigned int mask;         // cap - 1
+};
+
+__device__ __forceinline__ unsigned int dense_slot_of(unsigned long long k, unsigned int mask) {
+  return (unsigned int)((k * 0x9E3779B97F4A7C15ull) >> 32) & mask;
+}
+__device__ __forceinline__ unsigned int dense_find_or_insert(const DenseDev& d, unsigned long long k) {
+  unsigned int slot = dense_slot_of(k, d.mask);
+  while (true) {
+    const unsigned long long prev = atomicCAS(&d.keys[slot], kEmptyKey, k);
+    if (prev == kEmptyKey || prev == k) return slot;
+    slot = (slot + 1) & d.mask;
+  }
+}
+
+// VoxelizedPointCloud::insert (Voxel.cpp:66-90) of o3d_slam::transform(T, cloud) (Submap.cpp:81-84)
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void dense_insert_kernel(const P4* __restrict__ pts, const P4* __restrict__ nrm, size_t n, Mat34 M, double inv,
+                                                              DenseDev d) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const P4 p = pts[i];
+    const double x = (double)p.x, y = (double)p.y, z = (double)p.z;
+    const double px = M.m[0] * x + M.m[1] * y + M.m[2] * z + M.m[3], py = M.m[4] * x + M.m[5] * y + M.m[6] * z + M.m[7],
+                 pz = M.m[8] * x + M.m[9] * y + M.m[10] * z + M.m[11];
+    const unsigned long long k = pack_key((long long)(int)floor(px * inv), (long long)(int)floor(py * inv), (long long)(int)floor(pz * inv));
+    const unsigned int slot = dense_find_or_insert(d, k);
+    atomicAdd(&d.cnt[slot], 1);
+    atomicAdd((unsigned long long*)&d.sp[3 * (size_t)slot], (unsigned long long)llrint(px / kDensePosQ));
+    atomicAdd((unsigned long long*)&d.sp[3 * (size_t)slot + 1], (unsigned long long)llrint(py / kDensePosQ));
+    atomicAdd((unsigned long long*)&d.sp[3 * (size_t)slot + 2], (unsigned long long)llrint(pz / kDensePosQ));
+    if (nrm) {
+      const P4 q = nrm[i];
+      const double a = (double)q.x, b = (double)q.y, c = (double)q.z;
+      const double nx = M.m[0] * a + M.m[1] * b + M.m[2] * c, ny = M.m[4] * a + M.m[5] * b + M.m[6] * c, nz = M.m[8] * a + M.m[9] * b + M.m[10] * c;
+      atomicAdd((unsigned long long*)&d.sn[3 * (size_t)slot], (unsigned long long)llrint(nx / kDenseNrmQ));
+      atomicAdd((unsigned long long*)&d.sn[3 * (size_t)slot + 1], (unsigned long long)llrint(ny / kDenseNrmQ));
+      atomicAdd((unsigned long long*)&d.sn[3 * (size_t)slot + 2], (unsigned long long)llrint(nz / kDenseNrmQ));
+    }
+  }
+}
+
+// move every used slot of `from` into `to` (a larger, empty table)
+__global__ __launch_bounds__(kBlock) void dense_rehash_kernel(DenseDev from, size_t from_cap, DenseDev to) {
+  for (size_t s = (size_t)blockIdx.x * kBlock + threadIdx.x; s < from_cap; s += (size_t)gridDim.x * kBlock) {
+    const unsigned long long k = from.keys[s];
+    if (k == kEmptyKey) continue;
+    const unsigned int t = dense_find_or_insert(to, k);  // keys are unique: this thread owns slot t
+    to.cnt[t] = from.cnt[s];
+    for (int c = 0; c < 3; ++c) {
+      to.sp[3 * (size_t)t + c] = from.sp[3 * s + c];
+      to.sn[3 * (size_t)t + c] = from.sn[3 * s + c];
+    }
+  }
+}
+
+// list of used slots: flags for the scan, then (key, slot) pairs
+__global__ __launch_bounds__(kBlock) void dense_used_flag_kernel(DenseDev d, size_t cap, int* __restrict__ flag) {
+  for (size_t s = (size_t)blockIdx.x * kBlock + threadIdx.x; s < cap; s += (size_t)gridDim.x * kBlock)
+    flag[s] = (d.keys[s] != kEmptyKey && d.cnt[s] > 0) ? 1 : 0;
+}
+__global__ __launch_bounds__(kBlock) void dense_list_kernel(DenseDev d, size_t cap, const int* __restrict__ flag, const int* __restrict__ pos,
+                                                            unsigned long long* __restrict__ keys_out, uint32_t* __restrict__ slots_out) {
+  for (size_t s = (size_t)blockIdx.x * kBlock + threadIdx.x; s < cap; s += (size_t)gridDim.x * kBlock)
+    if (flag[s]) {
+      keys_out[pos[s]] = d.keys[s];
+      slots_out[pos[s]] = (uint32_t)s;
+    }
+}
+// VoxelizedPointCloud::toPointCloud (Voxel.cpp:92-114): sum / count per voxel, in the order of `slots` (sorted by key)
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void dense_emit_kernel(DenseDev d, const uint32_t* __restrict__ slots, size_t m, P4* __restrict__ out_pts,
+                                                            P4* __restrict__ out_nrm) {
+  using R = typename Scalar<P4>::type;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (size_t)gridDim.x * kBlock) {
+    const size_t s = slots[i];
+    const double c = (double)d.cnt[s];
+    P4 p;
+    p.x = (R)((double)d.sp[3 * s] * kDensePosQ / c);
+    p.y = (R)((double)d.sp[3 * s + 1] * kDensePosQ / c);
+    p.z = (R)((double)d.sp[3 * s + 2] * kDensePosQ / c);
+    p.i = (typename Scalar<P4>::index)i;
+    out_pts[i] = p;
+    if (out_nrm) {
+      P4 q;
+      q.x = (R)((double)d.sn[3 * s] * kDenseNrmQ / c);
+      q.y = (R)((double)d.sn[3 * s + 1] * kDenseNrmQ / c);
+      q.z = (R)((double)d.sn[3 * s + 2] * kDenseNrmQ / c);
+      q.i = 0;
+      out_nrm[i] = q;
+    }
+  }
+}
+// VoxelizedPointCloud::transform (Voxel.cpp:49-64), quirks included: the keys stay, and the Isometry is applied to the SUMS as if
+// they were points (translation added once to the position sum -- and to the normal sum as well)
+__global__ __launch_bounds__(kBlock) void dense_transform_kernel(DenseDev d, size_t cap, Mat34 M) {
+  for (size_t s = (size_t)blockIdx.x * kBlock + threadIdx.x; s < cap; s += (size_t)gridDim.x * kBlock) {
+    if (d.keys[s] == kEmptyKey || d.cnt[s] <= 0) continue;
+    const double x = (double)d.sp[3 * s] * kDensePosQ, y = (double)d.sp[3 * s + 1] * kDensePosQ, z = (double)d.sp[3 * s + 2] * kDensePosQ;
+    d.sp[3 * s] = llrint((M.m[0] * x + M.m[1] * y + M.m[2] * z + M.m[3]) / kDensePosQ);
+    d.sp[3 * s + 1] = llrint((M.m[4] * x + M.m[5] * y + M.m[6] * z + M.m[7]) / kDensePosQ);
+    d.sp[3 * s + 2] = llrint((M.m[8] * x + M.m[9] * y + M.m[10] * z + M.m[11]) / kDensePosQ);
+    const double a = (double)d.sn[3 * s] * kDenseNrmQ, b = (double)d.sn[3 * s + 1] * kDenseNrmQ, c = (double)d.sn[3 * s + 2] * kDenseNrmQ;
+    d.sn[3 * s] = llrint((M.m[0] * a + M.m[1] * b + M.m[2] * c + M.m[3]) / kDenseNrmQ);
+    d.sn[3 * s + 1] = llrint((M.m[4] * a + M.m[5] * b + M.m[6] * c + M.m[7]) / kDenseNrmQ);
+    d.sn[3 * s + 2] = llrint((M.m[8] * a + M.m[9] * b + M.m[10] * c + M.m[11]) / kDenseNrmQ);
+  }
+}
+
 // normalise, orient towards the sensor origin ([O3D] NormalizeNormals + OrientNormalsTowardsCameraLocation(0,0,0)), store
 template <typename P4>
 __device__ __forceinline__ void finish_normal(const P4& q, double nv[3], P4* out) {

@@ -169,6 +169,21 @@ def overlap_indices(src, tgt, T=None, voxel=0.5, min_points=1):
     return np.flatnonzero(ok[inv_idx[: len(ks)]]), np.flatnonzero(ok[inv_idx[len(ks):]])
 
 
+def dense_fuse(pts, nrm, voxel):
+    """VoxelizedPointCloud (Voxel.cpp:66-114): per-voxel sums / counts; voxels in ascending key order (z, y, x)."""
+    keys = np.floor(pts * (1.0 / voxel)).astype(np.int64)
+    uniq, inv, cnt = np.unique(keys, axis=0, return_inverse=True, return_counts=True)
+    inv = inv.reshape(-1)
+    sp = np.zeros((len(uniq), 3))
+    np.add.at(sp, inv, pts)
+    out_n = None
+    if nrm is not None:
+        sn = np.zeros((len(uniq), 3))
+        np.add.at(sn, inv, nrm)
+        out_n = sn / cnt[:, None]
+    return sp / cnt[:, None], out_n, cnt
+
+
 def estimate_normals(pts, radius, max_nn):
     tree = cKDTree(pts, leafsize=15)
     d, j = tree.query(pts, k=max_nn, distance_upper_bound=radius)

@@ -819,6 +819,62 @@ void orc_overlap_flags(const double* src, size_t n_src, const double* tgt, size_
   free(P);
 }
 
+/* ------------------------------------------------------------------ dense voxel map
+ * VoxelizedPointCloud (include/open3d_slam/Voxel.hpp:38-76, src/Voxel.cpp:18-114): per voxel (key floor(p * (1/v))) the running
+ * sums of position and normal and the point count; toPointCloud emits sum / count per voxel.  The map after inserting a sequence
+ * of clouds equals the fusion of their concatenation, so the oracle is stateless: out arrays sized >= 3n, voxels in
+ * first-occurrence order (the reference's order is its unordered_map's); returns the number of voxels.  counts_out may be NULL. */
+size_t orc_dense_fuse(const double* pts, const double* nrm, size_t n, double voxel, double* out_pts, double* out_nrm, int32_t* counts_out) {
+  if (n == 0) return 0;
+  const double inv = 1.0 / voxel;
+  carve_item* it = (carve_item*)malloc(sizeof(carve_item) * n);
+  for (size_t i = 0; i < n; ++i) {
+    it[i].key = carve_key(pts + 3 * i, inv);
+    it[i].idx = (int64_t)i;
+  }
+  qsort(it, n, sizeof(carve_item), carve_cmp); /* by key, then by index: sums in insertion order within a voxel */
+  /* first-occurrence order of the voxels = ascending smallest member index */
+  size_t m = 0;
+  int64_t* first = (int64_t*)malloc(sizeof(int64_t) * n);
+  size_t* start = (size_t*)malloc(sizeof(size_t) * (n + 1));
+  for (size_t b = 0; b < n;) {
+    size_t e = b;
+    while (e < n && it[e].key == it[b].key) ++e;
+    first[m] = it[b].idx;
+    start[m++] = b;
+    b = e;
+  }
+  start[m] = n;
+  carve_item* ord = (carve_item*)malloc(sizeof(carve_item) * m);
+  for (size_t v = 0; v < m; ++v) {
+    ord[v].key = first[v];
+    ord[v].idx = (int64_t)v;
+  }
+  qsort(ord, m, sizeof(carve_item), carve_cmp);
+  for (size_t o = 0; o < m; ++o) {
+    const size_t v = (size_t)ord[o].idx;
+    double sp[3] = {0, 0, 0}, sn[3] = {0, 0, 0};
+    const size_t cnt = start[v + 1] - start[v];
+    for (size_t j = start[v]; j < start[v + 1]; ++j) {
+      const size_t i = (size_t)it[j].idx;
+      for (int k = 0; k < 3; ++k) {
+        sp[k] += pts[3 * i + k];
+        if (nrm) sn[k] += nrm[3 * i + k];
+      }
+    }
+    for (int k = 0; k < 3; ++k) {
+      out_pts[3 * o + k] = sp[k] / (double)cnt; /* AggregatedVoxel::getAggregatedPosition, Voxel.cpp:18-20 */
+      if (nrm && out_nrm) out_nrm[3 * o + k] = sn[k] / (double)cnt; /* getAggregatedNormal: NOT re-normalised, Voxel.cpp:21-23 */
+    }
+    if (counts_out) counts_out[o] = (int32_t)cnt;
+  }
+  free(it);
+  free(first);
+  free(start);
+  free(ord);
+  return m;
+}
+
 /* ------------------------------------------------------------------ A.8 Generalized ICP
  * [O3D] GeneralizedICP.cpp: GetRotationFromE1ToX, InitializePointCloudForGeneralizedICP,
  * TransformationEstimationForGeneralizedICP::ComputeTransformation; reference call site src/CloudRegistration.cpp:16-21. */

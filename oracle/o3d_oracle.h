@@ -99,6 +99,9 @@ size_t orc_carve_flags(const double* scan, size_t n_scan, const double sensor[3]
 void orc_overlap_flags(const double* src, size_t n_src, const double* tgt, size_t n_tgt, const double T[16], double voxel, size_t min_points,
                        uint8_t* flags_src, uint8_t* flags_tgt);
 
+/* VoxelizedPointCloud::insert + toPointCloud (Voxel.cpp:66-114): per-voxel running sums / counts of everything inserted so far */
+size_t orc_dense_fuse(const double* pts, const double* nrm, size_t n, double voxel, double* out_pts, double* out_nrm, int32_t* counts_out);
+
 /* A.8 RegistrationGeneralizedICP (call site src/CloudRegistration.cpp:16-21): covariances from normals
  * (C = Rx diag(eps,1,1) Rx^T, Rx = GetRotationFromE1ToX(normal)), per pair M = Ct + R Cs R^T, W = M^-1/2, residual W d (3 rows),
  * Jacobian rows W [-[p]x | I]; same loop / solve / convergence as A.1.  Both clouds must carry normals (as they always do

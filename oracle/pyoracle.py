@@ -78,6 +78,8 @@ def lib():
                                       C.c_double, C.c_double, C.POINTER(C.c_uint8)]
         L.orc_overlap_flags.restype = None
         L.orc_overlap_flags.argtypes = [_dp, C.c_size_t, _dp, C.c_size_t, _dp, C.c_double, C.c_size_t, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]
+        L.orc_dense_fuse.restype = C.c_size_t
+        L.orc_dense_fuse.argtypes = [_dp, _dp, C.c_size_t, C.c_double, _dp, _dp, _ip]
         L.orc_gicp_jtj_jtr.argtypes = [_dp, _dp, C.c_size_t, _dp, _dp, _ip, _dp, _dp]
         L.orc_covariance_from_normal.argtypes = [_dp, C.c_double, _dp]
         L.orc_estimate_normals.argtypes = [_dp, C.c_size_t, C.c_double, C.c_int, _dp]
@@ -274,6 +276,16 @@ def overlap_indices(src, tgt, T=None, voxel=0.5, min_points=1):
     lib().orc_overlap_flags(sp, len(src), tp, len(tgt), ip, voxel, int(min_points), fs.ctypes.data_as(C.POINTER(C.c_uint8)),
                             ft.ctypes.data_as(C.POINTER(C.c_uint8)))
     return np.flatnonzero(fs), np.flatnonzero(ft)
+
+
+def dense_fuse(pts, nrm, voxel):
+    """VoxelizedPointCloud insert(s) + toPointCloud (Voxel.cpp:66-114): (voxel means, mean normals or None, counts)."""
+    pts, pp = _d(pts)
+    nr, npp = (None, None) if nrm is None else _d(nrm)
+    op, on, cnt = np.zeros((max(len(pts), 1), 3)), np.zeros((max(len(pts), 1), 3)), np.zeros(max(len(pts), 1), np.int32)
+    m = lib().orc_dense_fuse(pp, npp, len(pts), voxel, op.ctypes.data_as(_dp), on.ctypes.data_as(_dp) if nrm is not None else None,
+                             cnt.ctypes.data_as(_ip))
+    return op[:m].copy(), (on[:m].copy() if nrm is not None else None), cnt[:m].copy()
 
 
 def icp_generalized(src, src_nrm, tgt, tgt_nrm, max_corr, init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6, epsilon=1e-3,

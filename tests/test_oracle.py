@@ -441,3 +441,24 @@ def test_overlap_indices_c_matches_numpy_and_known_answers(oracle, small_c2):
     shift[0, 3] = -5.1  # brings source point 1 into voxel (0,0,0) and pushes point 0 out to (-10,0,0)
     i_s, i_t = oracle.overlap_indices(s, t, shift, voxel=0.5, min_points=1)
     assert i_s.tolist() == [1] and i_t.tolist() == [0, 2]
+
+
+# ---- dense voxel map (Voxel.hpp:38-76, Voxel.cpp:18-114) ---------------------------------------------------
+def test_dense_fuse_c_matches_numpy_and_known_answers(oracle):
+    scene = syn.make_scene()
+    pts, nrm = syn.sample_map(scene, 50_000)
+    for n_in in (nrm, None):
+        a_p, a_n, a_c = oracle.dense_fuse(pts, n_in, 0.1)
+        b_p, b_n, b_c = no.dense_fuse(pts, n_in, 0.1)
+        assert len(a_p) == len(b_p) and a_c.sum() == len(pts)
+        ia, ib = np.lexsort(np.floor(a_p / 0.1).T[::-1].copy()[::-1]), np.lexsort(np.floor(b_p / 0.1).T[::-1].copy()[::-1])
+        np.testing.assert_allclose(a_p[ia], b_p[ib], atol=1e-12)
+        assert np.array_equal(a_c[ia], b_c[ib])
+        if n_in is not None:
+            np.testing.assert_allclose(a_n[ia], b_n[ib], atol=1e-12)
+    p = np.array([[0.01, 0.01, 0.01], [0.26, 0.0, 0.0], [0.03, 0.05, 0.07], [-0.01, 0.0, 0.0]])
+    n = np.array([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0], [0.0, 1.0, 0.0]])
+    op, on, oc = oracle.dense_fuse(p, n, 0.25)
+    assert oc.tolist() == [2, 1, 1]  # first-occurrence order of the voxels (0,0,0), (1,0,0), (-1,0,0)
+    np.testing.assert_allclose(op, [[0.02, 0.03, 0.04], [0.26, 0.0, 0.0], [-0.01, 0.0, 0.0]], atol=1e-15)
+    np.testing.assert_allclose(on[0], [0.5, 0.0, 0.5], atol=1e-15)  # the mean normal is NOT re-normalised (Voxel.cpp:21-23)

@@ -459,3 +459,119 @@ def test_overlap_indices_match_oracle(backend_f64, backend_f32, oracle, scan):
     assert len(np.setxor1d(g_s, r_s)) <= 0.002 * len(r_s) + 5  # f32 storage: points near voxel faces
     backend_f32.free(s32)
     backend_f32.free(t32)
+
+
+def test_dense_voxel_map_matches_oracle(backend_f64, backend_f32, oracle):
+    """VoxelizedPointCloud on the device (Voxel.hpp:38-76, Voxel.cpp:18-114): incremental insertion of several clouds == the oracle's
+    fusion of their concatenation (same voxel set, counts, means and un-normalised mean normals), growth of the table, placement by
+    a pose, the reference's transform() as written, and order-independence (bitwise repeatable)."""
+    from scipy.spatial import cKDTree
+
+    scene = syn.make_scene()
+    voxel = 0.1
+    clouds = [syn.sample_map(scene, n, seed=50 + k) for k, n in enumerate((30_000, 5_000, 120_000))]  # the third insert forces a rehash
+    dm = backend_f64.dense_map_create(voxel)
+    assert backend_f64.dense_map_size(dm) == 0
+    for p, n in clouds:
+        c = backend_f64.upload(p, n)
+        backend_f64.dense_map_insert(dm, c)
+        backend_f64.free(c)
+    allp, alln = np.vstack([c[0] for c in clouds]), np.vstack([c[1] for c in clouds])
+    rp, rn, rc = oracle.dense_fuse(allp, alln, voxel)
+    assert backend_f64.dense_map_size(dm) == len(rp)
+    out = backend_f64.dense_map_to_cloud(dm)
+    gp, gn = backend_f64.download(out)
+    keys = np.floor(gp / voxel).astype(np.int64)
+    assert np.all(np.diff(((keys[:, 2] * (1 << 21) + keys[:, 1]) * (1 << 21) + keys[:, 0])) > 0)  # ascending voxel key, every voxel once
+    d, j = cKDTree(rp).query(gp)
+    assert np.array_equal(np.sort(j), np.arange(len(rp))) and d.max() < 1e-8  # fixed-point sums: 1 nm per inserted point
+    np.testing.assert_allclose(gn, rn[j], atol=1e-9)
+    again = backend_f64.dense_map_to_cloud(dm)
+    np.testing.assert_array_equal(backend_f64.download(again)[0], gp)
+    # a second map built in another insertion order holds bit-identical sums
+    dm2 = backend_f64.dense_map_create(voxel)
+    for p, n in reversed(clouds):
+        c = backend_f64.upload(p, n)
+        backend_f64.dense_map_insert(dm2, c)
+        backend_f64.free(c)
+    o2 = backend_f64.dense_map_to_cloud(dm2)
+    p2, n2 = backend_f64.download(o2)
+    np.testing.assert_array_equal(p2, gp)
+    np.testing.assert_array_equal(n2, gn)
+    # placement by a pose (Submap::insertScanDenseMap) -- voxel membership can flip for a point within an ulp of a face
+    T = syn.make_pose((1.5, -0.7, 0.2), (2.0, -1.0, 30.0))
+    dm3 = backend_f64.dense_map_create(voxel)
+    c = backend_f64.upload(*clouds[0])
+    backend_f64.dense_map_insert(dm3, c, T)
+    tp3 = clouds[0][0] @ T[:3, :3].T + T[:3, 3]
+    rp3, _, _ = oracle.dense_fuse(tp3, clouds[0][1] @ T[:3, :3].T, voxel)
+    assert abs(backend_f64.dense_map_size(dm3) - len(rp3)) <= 2
+    # VoxelizedPointCloud::transform as written: keys stay, sums are moved like points (translation once; normals too)
+    dm4 = backend_f64.dense_map_create(1.0)
+    c4 = backend_f64.upload(np.array([[0.2, 0.2, 0.2], [0.4, 0.6, 0.8]]), np.array([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]))
+    backend_f64.dense_map_insert(dm4, c4)
+    Tq = syn.make_pose((10.0, 20.0, 30.0), (0.0, 0.0, 90.0))
+    backend_f64.dense_map_transform(dm4, Tq)
+    o4 = backend_f64.dense_map_to_cloud(dm4)
+    p4, n4 = backend_f64.download(o4)
+    np.testing.assert_allclose(p4, [(Tq[:3, :3] @ np.array([0.6, 0.8, 1.0]) + Tq[:3, 3]) / 2.0], atol=1e-8)
+    np.testing.assert_allclose(n4, [(Tq[:3, :3] @ np.array([1.0, 1.0, 0.0]) + Tq[:3, 3]) / 2.0], atol=1e-8)
+    for cid in (out, again, o2, c, o4, c4):
+        backend_f64.free(cid)
+    for d_ in (dm, dm2, dm3, dm4):
+        backend_f64.dense_map_free(d_)
+    # f32 storage: same voxel count up to points sitting on faces after rounding to f32, no normals at all
+    dmf = backend_f32.dense_map_create(voxel)
+    cf = backend_f32.upload(clouds[0][0])
+    backend_f32.dense_map_insert(dmf, cf)
+    r32, _, _ = oracle.dense_fuse(clouds[0][0].astype(np.float32).astype(np.float64), None, voxel)
+    assert backend_f32.dense_map_size(dmf) == len(r32)
+    of = backend_f32.dense_map_to_cloud(dmf)
+    assert backend_f32.size(of) == (len(r32), False)
+    backend_f32.free(of)
+    backend_f32.free(cf)
+    backend_f32.dense_map_free(dmf)
+    with pytest.raises(backend.BackendError):
+        backend_f32.dense_map_create(0.0)
+
+
+def test_full_size_config4_dense_voxel_map(backend_f32):
+    """BASELINE.json configs[4] with the reference's own dense map (VoxelizedPointCloud, the 'TSDF-style' running sums): 2 M points at
+    voxel 0.02 m in four insertions; voxel SET equals numpy's, total count is conserved through the means (linearity), and a second
+    identical insertion doubles every count without moving any mean (idempotence of the means)."""
+    import time
+
+    from scipy.spatial import cKDTree
+
+    scene = syn.make_scene()
+    pts, _ = syn.sample_map(scene, 2_000_000, seed=78)
+    pts32 = pts.astype(np.float32).astype(np.float64)
+    voxel = 0.02
+    dm = backend_f32.dense_map_create(voxel)
+    chunks = np.array_split(np.arange(len(pts)), 4)
+    ids = [backend_f32.upload(pts[c]) for c in chunks]
+    backend_f32.synchronize()
+    t0 = time.perf_counter()
+    for c in ids:
+        backend_f32.dense_map_insert(dm, c)
+    backend_f32.synchronize()
+    dt = time.perf_counter() - t0
+    uniq, inv, cnt = np.unique(np.floor(pts32 * (1.0 / voxel)).astype(np.int64), axis=0, return_inverse=True, return_counts=True)
+    assert backend_f32.dense_map_size(dm) == len(uniq)
+    out = backend_f32.dense_map_to_cloud(dm)
+    vox = backend_f32.download(out)[0]
+    sums = np.zeros((len(uniq), 3))
+    np.add.at(sums, inv.reshape(-1), pts32)
+    means = sums / cnt[:, None]
+    d, j = cKDTree(means).query(vox)
+    assert np.array_equal(np.sort(j), np.arange(len(uniq))) and d.max() < 4e-6
+    np.testing.assert_allclose((vox * cnt[j][:, None]).sum(0), pts32.sum(0), rtol=1e-6)
+    for c in ids:  # everything once more: same voxels, same means
+        backend_f32.dense_map_insert(dm, c)
+    assert backend_f32.dense_map_size(dm) == len(uniq)
+    out2 = backend_f32.dense_map_to_cloud(dm)
+    np.testing.assert_array_equal(backend_f32.download(out2)[0], vox)
+    print(f"config4 dense map: {len(pts)} pts -> {len(uniq)} voxels in {dt*1e3:.2f} ms")
+    for c in ids + [out, out2]:
+        backend_f32.free(c)
+    backend_f32.dense_map_free(dm)
