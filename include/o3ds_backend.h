@@ -228,6 +228,13 @@ int o3ds_cloud_append(o3ds_handle h, o3ds_cloud map, o3ds_cloud add);
 int o3ds_voxelize_within_volume(o3ds_handle h, o3ds_cloud map, double voxel_size, const o3ds_crop* crop);
 /* Submap::insertScan core (Submap.cpp:54,70-72) in one call: map += T*scan; re-voxelize inside crop; rebuild the
  * NN index (max_corr_hint as in o3ds_cloud_build_index; <= 0 skips the rebuild). */
+/* ConstantVelocityMotionCompensation::undistortInputPointCloud (src/MotionCompensation.cpp:64-139), in place on a device cloud in
+ * the sensor frame: every point is moved by the motion accumulated over phase * scan_duration at the given constant velocity
+ * (phase = azimuth / 2 pi, or 1 - that for spinning_clockwise; angular velocity as roll / pitch / yaw rates, R = Rz Ry Rx).  The
+ * velocities are estimated from the pose buffer by the caller (estimateLinearAndAngularVelocity, :33-58).  Normals and the NN index
+ * of the cloud, if any, are dropped (the reference de-skews raw scans). */
+int o3ds_cloud_undistort(o3ds_handle h, o3ds_cloud cloud, const double linear_velocity[3], const double angular_velocity_rpy[3],
+                         double scan_duration, int spinning_clockwise);
 /* Dense voxel map = VoxelizedPointCloud (include/open3d_slam/Voxel.hpp:38-76, src/Voxel.cpp:18-114), the "TSDF-style" fusion of
  * BASELINE configs[4]: a persistent map voxel (key floor(p / voxel_size)) -> {count, sum of positions, sum of normals}.
  *   insert    : VoxelizedPointCloud::insert of o3d_slam::transform(T, cloud) (Submap::insertScanDenseMap, Submap.cpp:77-92); T may be

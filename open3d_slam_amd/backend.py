@@ -69,6 +69,7 @@ SIGNATURES = {
     "o3ds_icp_register_dev": (C.c_int, [_H, _CL, _CL, C.POINTER(Crop), _dp, C.POINTER(IcpParams), C.POINTER(IcpResult)]),
     "o3ds_icp_pass": (C.c_int, [_H, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "o3ds_icp_pass_finish": (C.c_int, [_H, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(IcpResult)]),
+    "o3ds_cloud_undistort": (C.c_int, [_H, _CL, _dp, _dp, C.c_double, C.c_int]),
     "o3ds_dense_map_create": (C.c_int, [_H, C.c_double, C.POINTER(C.c_uint64)]),
     "o3ds_dense_map_free": (C.c_int, [_H, C.c_uint64]),
     "o3ds_dense_map_insert": (C.c_int, [_H, C.c_uint64, _CL, _dp]),
@@ -395,6 +396,12 @@ class Backend:
 
     def voxelize_within_volume(self, map_id: int, voxel: float, crop: Crop):
         self._ck(self.lib.o3ds_voxelize_within_volume(self.h, map_id, voxel, C.byref(crop)))
+
+    def undistort(self, cid: int, lin_vel, ang_vel_rpy, scan_duration: float, clockwise: bool = False):
+        """ConstantVelocityMotionCompensation::undistortInputPointCloud, in place on the device cloud."""
+        v, vp = _d(np.asarray(lin_vel, dtype=np.float64).reshape(3))
+        w, wp = _d(np.asarray(ang_vel_rpy, dtype=np.float64).reshape(3))
+        self._ck(self.lib.o3ds_cloud_undistort(self.h, cid, vp, wp, float(scan_duration), int(bool(clockwise))))
 
     # -- dense voxel map (VoxelizedPointCloud)
     def dense_map_create(self, voxel: float) -> int:

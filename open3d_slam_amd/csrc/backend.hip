@@ -1777,6 +1777,30 @@ int o3ds_voxelize_within_volume(o3ds_handle h, o3ds_cloud map, double voxel_size
   return O3DS_OK;
 }
 
+int o3ds_cloud_undistort(o3ds_handle h, o3ds_cloud cloud, const double linear_velocity[3], const double angular_velocity_rpy[3],
+                         double scan_duration, int spinning_clockwise) {
+  CHECK_HANDLE(h);
+  CloudRec* c = find_cloud(h, cloud);
+  if (!c || !linear_velocity || !angular_velocity_rpy) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_undistort: bad argument");
+  if (!(scan_duration > 0.0)) return fail(h, O3DS_ERR_INVALID_ARG, "lidar scanDuration_: must be > 0");  // MotionCompensation.cpp:62
+  if (c->n == 0) return O3DS_OK;
+  const double* v = linear_velocity;
+  const double* w = angular_velocity_rpy;
+  if (c->precision == O3DS_PRECISION_F64)
+    undistort_kernel<P4d><<<grid_for(c->n), kBlock, 0, h->stream>>>((P4d*)c->pts, c->n, v[0], v[1], v[2], w[0], w[1], w[2], scan_duration,
+                                                                  spinning_clockwise);
+  else
+    undistort_kernel<P4f><<<grid_for(c->n), kBlock, 0, h->stream>>>((P4f*)c->pts, c->n, v[0], v[1], v[2], w[0], w[1], w[2], scan_duration,
+                                                                  spinning_clockwise);
+  HIP_TRY(hipGetLastError());
+  if (c->nrm) {
+    (void)hipFreeAsync(c->nrm, h->stream);
+    c->nrm = nullptr;
+  }
+  free_index(h, *c);
+  return O3DS_OK;
+}
+
 int o3ds_dense_map_create(o3ds_handle h, double voxel_size, o3ds_dense_map* out) {
   CHECK_HANDLE(h);
   if (!out) return fail(h, O3DS_ERR_INVALID_ARG, "dense_map_create: null out");

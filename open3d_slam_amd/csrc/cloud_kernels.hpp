@@ -121,6 +121,37 @@ __global__ __launch_bounds__(kBlock) void transform_kernel(const P4* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------------------- constant-velocity de-skew
+// ConstantVelocityMotionCompensation::undistortInputPointCloud (MotionCompensation.cpp:64-139), in place: the phase of a point is
+// its azimuth / 2 pi (1 - that for a clockwise sensor, 0 at azimuth exactly 0), its motion T(phase * D * v, Rz Ry Rx(phase * D * w)).
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void undistort_kernel(P4* __restrict__ pts, size_t n, double vx, double vy, double vz, double wr, double wp,
+                                                           double wy, double scan_duration, int clockwise) {
+  using R = typename Scalar<P4>::type;
+  const double kTwoPi = 6.283185307179586476925286766559;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    P4 p = pts[i];
+    const double x = (double)p.x, y = (double)p.y, z = (double)p.z;
+    const double angle = atan2(y, x);
+    const double wrapped = angle < 0.0 ? angle + kTwoPi : angle;
+    double phase = 0.0;
+    if (wrapped != 0.0) phase = clockwise ? 1.0 - wrapped / kTwoPi : wrapped / kTwoPi;
+    const double s = phase * scan_duration;
+    double sa, ca, sb, cb, sg, cg;
+    sincos(s * wr, &sa, &ca);  // roll
+    sincos(s * wp, &sb, &cb);  // pitch
+    sincos(s * wy, &sg, &cg);  // yaw
+    // R = Rz(yaw) Ry(pitch) Rx(roll) (fromRPY, math.cpp:32-37)
+    const double r00 = cg * cb, r01 = cg * sb * sa - sg * ca, r02 = cg * sb * ca + sg * sa;
+    const double r10 = sg * cb, r11 = sg * sb * sa + cg * ca, r12 = sg * sb * ca - cg * sa;
+    const double r20 = -sb, r21 = cb * sa, r22 = cb * ca;
+    p.x = (R)(r00 * x + r01 * y + r02 * z + s * vx);
+    p.y = (R)(r10 * x + r11 * y + r12 * z + s * vy);
+    p.z = (R)(r20 * x + r21 * y + r22 * z + s * vz);
+    pts[i] = p;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- voxel reduction
 // Voxel keys are packed into one sortable u64: 21 bits per axis, biased by 2^20 (|k| < 2^20 voxels per axis;
 // at the 0.02 m dense-map voxel that is +-20 km).  Points outside the crop volume get a pass-through key

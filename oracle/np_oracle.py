@@ -184,6 +184,20 @@ def dense_fuse(pts, nrm, voxel):
     return sp / cnt[:, None], out_n, cnt
 
 
+def undistort(pts, lin_vel, ang_vel_rpy, scan_duration, clockwise=False):
+    """MotionCompensation.cpp:64-139, vectorised."""
+    lin_vel, ang = np.asarray(lin_vel, dtype=np.float64), np.asarray(ang_vel_rpy, dtype=np.float64)
+    a = np.arctan2(pts[:, 1], pts[:, 0])
+    w = np.where(a < 0, a + 2 * np.pi, a)
+    phase = np.where(w == 0.0, 0.0, (1.0 - w / (2 * np.pi)) if clockwise else w / (2 * np.pi))
+    s = phase * scan_duration
+    out = np.empty_like(pts)
+    for i in range(len(pts)):
+        U = vector6_to_matrix4(np.concatenate([s[i] * ang, s[i] * lin_vel]))
+        out[i] = U[:3, :3] @ pts[i] + U[:3, 3]
+    return out
+
+
 def estimate_normals(pts, radius, max_nn):
     tree = cKDTree(pts, leafsize=15)
     d, j = tree.query(pts, k=max_nn, distance_upper_bound=radius)

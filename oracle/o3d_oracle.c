@@ -875,6 +875,31 @@ size_t orc_dense_fuse(const double* pts, const double* nrm, size_t n, double vox
   return m;
 }
 
+/* ------------------------------------------------------------------ constant-velocity de-skew
+ * ConstantVelocityMotionCompensation::undistortInputPointCloud (src/MotionCompensation.cpp:64-118) with computePhase (:120-139):
+ * phase = azimuth / 2 pi in [0, 1] (1 - that for a clockwise-spinning sensor; 0 for azimuth exactly 0), every point is moved by
+ * the motion accumulated over phase * scan_duration at constant velocity: p' = T(phase * D * v, Rz Ry Rx(phase * D * w)) p.
+ * The velocities come from the pose buffer on the host (estimateLinearAndAngularVelocity, :33-58) and are inputs here. */
+void orc_undistort(double* pts, size_t n, const double lin_vel[3], const double ang_vel_rpy[3], double scan_duration, int clockwise) {
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < n; ++i) {
+    double* p = pts + 3 * i;
+    const double angle = atan2(p[1], p[0]);
+    const double kPi = 3.14159265358979323846; /* M_PI: not in strict C11 */
+    const double wrapped = angle < 0.0 ? angle + 2.0 * kPi : angle;
+    double phase = 0.0;
+    if (wrapped != 0.0) phase = clockwise ? 1.0 - wrapped / (2.0 * kPi) : wrapped / (2.0 * kPi);
+    const double s = phase * scan_duration;
+    const double x6[6] = {s * ang_vel_rpy[0], s * ang_vel_rpy[1], s * ang_vel_rpy[2], s * lin_vel[0], s * lin_vel[1], s * lin_vel[2]};
+    double U[16];
+    orc_vector6_to_matrix4(x6, U); /* R = Rz(yaw) Ry(pitch) Rx(roll) = fromRPY (math.cpp:32-37), t = xyz */
+    const double x = p[0], y = p[1], z = p[2];
+    p[0] = U[0] * x + U[4] * y + U[8] * z + U[12];
+    p[1] = U[1] * x + U[5] * y + U[9] * z + U[13];
+    p[2] = U[2] * x + U[6] * y + U[10] * z + U[14];
+  }
+}
+
 /* ------------------------------------------------------------------ A.8 Generalized ICP
  * [O3D] GeneralizedICP.cpp: GetRotationFromE1ToX, InitializePointCloudForGeneralizedICP,
  * TransformationEstimationForGeneralizedICP::ComputeTransformation; reference call site src/CloudRegistration.cpp:16-21. */

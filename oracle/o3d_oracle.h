@@ -102,6 +102,9 @@ void orc_overlap_flags(const double* src, size_t n_src, const double* tgt, size_
 /* VoxelizedPointCloud::insert + toPointCloud (Voxel.cpp:66-114): per-voxel running sums / counts of everything inserted so far */
 size_t orc_dense_fuse(const double* pts, const double* nrm, size_t n, double voxel, double* out_pts, double* out_nrm, int32_t* counts_out);
 
+/* ConstantVelocityMotionCompensation::undistortInputPointCloud (MotionCompensation.cpp:64-139), in place */
+void orc_undistort(double* pts, size_t n, const double lin_vel[3], const double ang_vel_rpy[3], double scan_duration, int clockwise);
+
 /* A.8 RegistrationGeneralizedICP (call site src/CloudRegistration.cpp:16-21): covariances from normals
  * (C = Rx diag(eps,1,1) Rx^T, Rx = GetRotationFromE1ToX(normal)), per pair M = Ct + R Cs R^T, W = M^-1/2, residual W d (3 rows),
  * Jacobian rows W [-[p]x | I]; same loop / solve / convergence as A.1.  Both clouds must carry normals (as they always do

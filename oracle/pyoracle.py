@@ -80,6 +80,8 @@ def lib():
         L.orc_overlap_flags.argtypes = [_dp, C.c_size_t, _dp, C.c_size_t, _dp, C.c_double, C.c_size_t, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]
         L.orc_dense_fuse.restype = C.c_size_t
         L.orc_dense_fuse.argtypes = [_dp, _dp, C.c_size_t, C.c_double, _dp, _dp, _ip]
+        L.orc_undistort.restype = None
+        L.orc_undistort.argtypes = [_dp, C.c_size_t, _dp, _dp, C.c_double, C.c_int]
         L.orc_gicp_jtj_jtr.argtypes = [_dp, _dp, C.c_size_t, _dp, _dp, _ip, _dp, _dp]
         L.orc_covariance_from_normal.argtypes = [_dp, C.c_double, _dp]
         L.orc_estimate_normals.argtypes = [_dp, C.c_size_t, C.c_double, C.c_int, _dp]
@@ -286,6 +288,15 @@ def dense_fuse(pts, nrm, voxel):
     m = lib().orc_dense_fuse(pp, npp, len(pts), voxel, op.ctypes.data_as(_dp), on.ctypes.data_as(_dp) if nrm is not None else None,
                              cnt.ctypes.data_as(_ip))
     return op[:m].copy(), (on[:m].copy() if nrm is not None else None), cnt[:m].copy()
+
+
+def undistort(pts, lin_vel, ang_vel_rpy, scan_duration, clockwise=False):
+    """ConstantVelocityMotionCompensation::undistortInputPointCloud (MotionCompensation.cpp:64-139); returns the moved copy."""
+    out = np.array(pts, dtype=np.float64, order="C", copy=True).reshape(-1, 3)
+    v, vp = _d(np.asarray(lin_vel, dtype=np.float64).reshape(3))
+    w, wp = _d(np.asarray(ang_vel_rpy, dtype=np.float64).reshape(3))
+    lib().orc_undistort(out.ctypes.data_as(_dp), len(out), vp, wp, float(scan_duration), int(bool(clockwise)))
+    return out
 
 
 def icp_generalized(src, src_nrm, tgt, tgt_nrm, max_corr, init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6, epsilon=1e-3,

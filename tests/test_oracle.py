@@ -462,3 +462,19 @@ def test_dense_fuse_c_matches_numpy_and_known_answers(oracle):
     assert oc.tolist() == [2, 1, 1]  # first-occurrence order of the voxels (0,0,0), (1,0,0), (-1,0,0)
     np.testing.assert_allclose(op, [[0.02, 0.03, 0.04], [0.26, 0.0, 0.0], [-0.01, 0.0, 0.0]], atol=1e-15)
     np.testing.assert_allclose(on[0], [0.5, 0.0, 0.5], atol=1e-15)  # the mean normal is NOT re-normalised (Voxel.cpp:21-23)
+
+
+# ---- constant-velocity de-skew (MotionCompensation.cpp:64-139) ------------------------------------------------
+def test_undistort_c_matches_numpy_and_known_answers(oracle):
+    rng = np.random.default_rng(21)
+    pts = rng.normal(size=(2000, 3)) * [10.0, 10.0, 1.0]
+    v, w = np.array([1.5, -0.4, 0.1]), np.array([0.02, -0.05, 0.6])
+    for cw in (False, True):
+        np.testing.assert_allclose(oracle.undistort(pts, v, w, 0.1, cw), no.undistort(pts, v, w, 0.1, cw), atol=1e-12)
+    # azimuth exactly 0 -> phase 0 -> untouched; azimuth pi -> half a scan of pure translation
+    p = np.array([[5.0, 0.0, 0.3], [-5.0, 0.0, 0.3]])
+    out = oracle.undistort(p, [2.0, 0.0, 0.0], [0.0, 0.0, 0.0], 0.1)
+    np.testing.assert_allclose(out, [[5.0, 0.0, 0.3], [-5.0 + 0.5 * 0.1 * 2.0, 0.0, 0.3]], atol=1e-15)
+    out = oracle.undistort(p, [2.0, 0.0, 0.0], [0.0, 0.0, 0.0], 0.1, clockwise=True)  # clockwise: phase(pi) is 1/2 as well, phase(0) stays 0
+    np.testing.assert_allclose(out[1], [-4.9, 0.0, 0.3], atol=1e-15)
+    assert np.array_equal(oracle.undistort(pts, [0, 0, 0], [0, 0, 0], 0.1), pts)  # no motion, no change

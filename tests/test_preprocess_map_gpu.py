@@ -575,3 +575,21 @@ def test_full_size_config4_dense_voxel_map(backend_f32):
     for c in ids + [out, out2]:
         backend_f32.free(c)
     backend_f32.dense_map_free(dm)
+
+
+def test_undistort_matches_oracle(backend_f64, backend_f32, oracle, scan):
+    """o3ds_cloud_undistort = ConstantVelocityMotionCompensation::undistortInputPointCloud (MotionCompensation.cpp:64-139)."""
+    v, w = np.array([1.5, -0.4, 0.1]), np.array([0.02, -0.05, 0.6])
+    for cw in (False, True):
+        ref = oracle.undistort(scan, v, w, 0.1, cw)
+        c = backend_f64.upload(scan)
+        backend_f64.undistort(c, v, w, 0.1, cw)
+        np.testing.assert_allclose(backend_f64.download(c)[0], ref, atol=1e-12)
+        backend_f64.free(c)
+    c = backend_f32.upload(scan)
+    backend_f32.undistort(c, v, w, 0.1)
+    np.testing.assert_allclose(backend_f32.download(c)[0], oracle.undistort(scan.astype(np.float32).astype(np.float64), v, w, 0.1), atol=4e-6)
+    backend_f32.undistort(c, [0, 0, 0], [0, 0, 0], 0.1)  # no motion: a no-op
+    with pytest.raises(backend.BackendError):
+        backend_f32.undistort(c, v, w, 0.0)
+    backend_f32.free(c)
