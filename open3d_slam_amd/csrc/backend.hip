@@ -490,6 +490,12 @@ int dense_to_cloud_t(o3ds_handle h, DenseRec& d, CloudRec& out) {
   return O3DS_OK;
 }
 
+inline QuantumTable quantum_table(const IcpPassArgs& a) {
+  QuantumTable t;
+  for (int k = 0; k < kRec; ++k) t.q[k] = a.q_hi[k];
+  return t;
+}
+
 // ---- ICP launch helpers -------------------------------------------------------------------------
 template <typename P4>
 void launch_accumulate(o3ds_handle h, const IcpPassArgs& a, bool crop, int nblocks) {
@@ -637,17 +643,52 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
   const double r = params->max_correspondence_distance;
   a.r2max = r * r;
   a.method = params->method;
-  {  // bound on the sum of |record terms| -> quantum of the exact record sums (split_exact): 2^53 q_hi >= 8 B
+  {  // per-term bounds on the sums of |record terms| -> per-term quanta of the exact record sums (split_exact): 2^53 q >= 8 B_k
     const GridDev& g = tgt->grid;
     const double ex = std::max(std::fabs(g.ox), std::fabs(g.ox + g.nx * g.cell)), ey = std::max(std::fabs(g.oy), std::fabs(g.oy + g.ny * g.cell)),
                  ez = std::max(std::fabs(g.oz), std::fabs(g.oz + g.nz * g.cell));
-    const double P = std::sqrt(ex * ex + ey * ey + ez * ez) + r;  // a matched source point lies within r of the target's box
-    double B = (double)std::max<size_t>(src->n, 1) * std::max(1.0, P) * std::max(1.0, P) * std::max(1.0, r) * std::max(1.0, r);
-    if (params->method == O3DS_ICP_GENERALIZED) B *= 4.0 * std::max(1.0, 0.5 / h->gicp_epsilon);  // |M^-1| <= 1 / (2 eps)
-    B *= 64.0;  // the sums of up to 64 ranks ("submap" sharding: every rank contributes up to n correspondences) stay exact as well
-    int e = 0;
-    (void)std::frexp(B, &e);             // B < 2^e
-    a.q_hi = std::ldexp(1.0, e + 3 - 53);  // 2^53 q_hi = 8 * 2^e
+    const double P = std::max(1.0, std::sqrt(ex * ex + ey * ey + ez * ez) + r);  // a matched source point lies within r of the target's box
+    const double rr = std::max(r, 1e-3);
+    // headroom: 64 ranks of a sharded run may add up ("submap" mode: every rank contributes up to n correspondences)
+    const double nn = 64.0 * (double)std::max<size_t>(src->n, 1);
+    double bound[kRec];
+    if (params->method == O3DS_ICP_GENERALIZED) {
+      const double gw = 4.0 * std::max(1.0, 0.5 / h->gicp_epsilon);  // |M^-1| <= 1 / (2 eps)
+      int k = 0;
+      for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j) bound[k++] = gw * (i < 3 ? P : 1.0) * (j < 3 ? P : 1.0);  // A^T M^-1 A, A = [-[p]x | I]
+      for (int i = 0; i < 6; ++i) bound[21 + i] = gw * (i < 3 ? P : 1.0) * rr;                 // A^T M^-1 d
+      bound[27] = gw * rr * rr;
+      bound[28] = 1.0;
+      bound[29] = rr * rr;
+      bound[30] = bound[31] = 1.0;
+    } else {
+      // the record terms are products of two per-query slots; slot magnitudes per method (icp_kernels.hpp, kTermA/B tables)
+      double slot[10];
+      const unsigned char *ta, *tb;
+      static const unsigned char A0[kRec] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9};
+      static const unsigned char B0[kRec] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5, 6, 6, 6, 6, 6, 6, 6, 7, 7, 9, 9};
+      static const unsigned char A1[kRec] = {3, 3, 3, 4, 4, 4, 5, 5, 5, 0, 1, 2, 3, 4, 5, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 7, 8, 9, 9};
+      static const unsigned char B1[kRec] = {0, 1, 2, 0, 1, 2, 0, 1, 2, 7, 7, 7, 7, 7, 7, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 7, 7, 9, 9};
+      if (params->method == O3DS_ICP_POINT_TO_POINT) {  // also the information-matrix pass (same slots, q q^T terms bounded by p q^T's)
+        for (int i = 0; i < 6; ++i) slot[i] = P;  // p, q
+        slot[6] = 0.0, slot[7] = 1.0, slot[8] = rr * rr, slot[9] = 0.0;
+        ta = A1, tb = B1;
+      } else {
+        for (int i = 0; i < 3; ++i) slot[i] = P, slot[3 + i] = 1.0;  // J = [p x n ; n], unit normals
+        slot[6] = rr, slot[7] = 1.0, slot[8] = rr * rr, slot[9] = 0.0;
+        ta = A0, tb = B0;
+      }
+      for (int k = 0; k < kRec; ++k) bound[k] = std::max(slot[ta[k]] * slot[tb[k]], 1e-30);
+      if (params->method == O3DS_ICP_POINT_TO_POINT)
+        for (int k = 0; k < 9; ++k) bound[k] = P * P;  // information matrix: terms 0..8 are q_a q_b or q_a (<= P^2 either way)
+    }
+    const bool no_split = getenv("O3DS_SUM_NO_SPLIT") != nullptr;  // diagnostic: plain f64 sums
+    for (int k = 0; k < kRec; ++k) {
+      int e = 0;
+      (void)std::frexp(nn * bound[k], &e);                      // n * bound < 2^e
+      a.q_hi[k] = no_split ? 0.0 : std::ldexp(1.0, e + 3 - 53);  // 2^53 q = 8 * 2^e
+    }
   }
   a.kmax = std::max(1, (int)std::ceil(r / tgt->grid.cell));  // a neighbour within r is at most this many cells away
   a.nn_cache = h->d_nn_cache;
@@ -922,7 +963,7 @@ int o3ds_icp_accumulate(o3ds_handle h, size_t first, size_t count, double* d_rec
       launch_accumulate<P4d>(h, a, h->session_crop, nb);
     else
       launch_accumulate<P4f>(h, a, h->session_crop, nb);
-    icp_reduce_kernel<<<1, kUpdBlock, 0, h->stream>>>(h->d_partials, nb, h->d_state, d_record, a.q_hi);
+    icp_reduce_kernel<<<1, kUpdBlock, 0, h->stream>>>(h->d_partials, nb, h->d_state, d_record, quantum_table(a));
   }
   HIP_TRY(hipGetLastError());
   return O3DS_OK;
@@ -1060,7 +1101,7 @@ int o3ds_information_matrix_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud tar
     launch_accumulate<P4d>(h, a, h->session_crop, nb);
   else
     launch_accumulate<P4f>(h, a, h->session_crop, nb);
-  icp_reduce_kernel<<<1, kUpdBlock, 0, h->stream>>>(h->d_partials, nb, h->d_state, d_record, a.q_hi);
+  icp_reduce_kernel<<<1, kUpdBlock, 0, h->stream>>>(h->d_partials, nb, h->d_state, d_record, quantum_table(a));
   HIP_TRY(hipGetLastError());
   double rec[kRec];
   HIP_TRY(hipMemcpyAsync(rec, d_record, sizeof(rec), hipMemcpyDeviceToHost, h->stream));
@@ -1234,7 +1275,7 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
         launch_accumulate<P4f>(h, a, h->session_crop, nb);
       icp_reduce_update_kernel<<<1, kUpdBlock, 0, h->stream>>>(h->d_partials, nb, h->d_state, (unsigned long long)a.count,
                                                             params->max_iteration, params->relative_fitness, params->relative_rmse,
-                                                            h->debug_update, h->session_method, a.q_hi);
+                                                            h->debug_update, h->session_method, quantum_table(a));
     }
     launched += chunk;
     HIP_TRY(hipGetLastError());

@@ -515,6 +515,10 @@ __device__ __forceinline__ void nn_search_wave_far(const GridDev& g, const P4* _
 // ----------------------------------------------------------------------------------------------
 // one ICP pass: transform -> 1-NN -> residual/Jacobian -> block-reduced normal equations
 // ----------------------------------------------------------------------------------------------
+struct QuantumTable {
+  double q[kRec];
+};
+
 struct IcpPassArgs {
   const void* src;   // P4[n_src]
   size_t first, count;
@@ -524,7 +528,7 @@ struct IcpPassArgs {
   CropDev crop;
   double r2max;
   int kmax;          // ceil(r / cell): how many cells away a neighbour within r can be
-  double q_hi;       // quantum of the exact record sums (see split_exact); a power of two
+  double q_hi[kRec]; // per-term quantum of the exact record sums (see split_exact); powers of two, from per-term bounds
   int method;        // o3ds_icp_method: which record a correspondence contributes (the GICP record is a separate instantiation)
   int* nn_cache;     // [n_src] position (in the sorted target) of each query's match in the previous pass of this registration
   int n_tgt;
@@ -869,12 +873,15 @@ constexpr int kUpdBlock = 1024;
 
 // ---- order-independent record sums ---------------------------------------------------------------------------------------
 // Every workgroup record value v is split into hi + lo, hi a multiple of q_hi and lo a multiple of q_lo = q_hi * 2^-41, with
-// q_hi a power of two chosen per registration from a bound B on the sum of |v| (2^53 q_hi >= 8 B).  Sums of at most 4096 such hi
-// (resp. lo) values are exactly representable, so f64 additions of them are EXACT and therefore associative: the records can be
-// accumulated with hardware f64 atomics in whatever order the workgroups finish, and the fused, two-launch and step-wise forms
-// agree bit for bit for any launch geometry.  What is dropped is below q_lo / 2 per record, i.e. B * 2^-93: the result is closer to
-// the true sum than a plain f64 summation.  If a caller's data exceed the bound (e.g. normals far from unit length) the split
-// degrades to hi = v, lo = 0 -- ordinary f64 sums, still correct, merely no longer order-independent.
+// q_hi a power of two chosen PER RECORD TERM from a bound B_k on the sum of |v| for that term (2^53 q_hi >= 8 B_k).  Sums of at
+// most 4096 such hi (resp. lo) values are exactly representable, so f64 additions of them are EXACT and therefore associative: the
+// records can be accumulated with hardware f64 atomics in whatever order the workgroups finish, and the fused, two-launch and
+// step-wise forms agree bit for bit for any launch geometry.  What is dropped is below q_lo / 2 per record, i.e. ~B_k * 2^-93
+// RELATIVE TO THAT TERM'S OWN BOUND -- which is why the bound has to be per term: the 32 terms of one record span ten orders of
+// magnitude when the clouds are far from the origin (rot-rot ~ n |p|^2, translational J^T r ~ n r), and one global quantum cost
+// 4.4e-4 m of pose accuracy at |p| = 2e5 m where plain f64 sums give 1.7e-5 (tests/test_icp_gpu.py::test_large_coordinates_*).
+// If a caller's data exceed a bound (e.g. normals far from unit length) the split degrades to hi = v, lo = 0 -- ordinary f64 sums,
+// still correct, merely no longer order-independent.
 __device__ __forceinline__ void split_exact(double v, double q_hi, double* hi, double* lo) {
   const double c_hi = 6755399441055744.0 * q_hi;  // 1.5 * 2^52 * q_hi: (v + c) - c rounds v to a multiple of q_hi (|v| < 2^51 q_hi)
   const double h = (v + c_hi) - c_hi;
@@ -887,11 +894,12 @@ __device__ __forceinline__ void split_exact(double v, double q_hi, double* hi, d
 // sum the per-block partial records into one 32-double record (order-independent, see above); result in s_out[0..31].
 // The rows were written by other CUs/XCDs and come from memory, so each dependent load round costs ~1 us: all (<= 32) loads
 // of a thread are issued before the first add (measured: an add-per-load loop took 10 us, 8-deep batches 8 us).
-__device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int nrows, double q_hi, double* s_part /* [2][32][32] */,
+__device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int nrows, const double* q_hi /* [32] */, double* s_part /* [2][32][32] */,
                                                 double* s_out /* [32] */) {
   constexpr int kParts = kUpdBlock / 32;
   const int col = threadIdx.x & 31, part = threadIdx.x >> 5;  // 32 parts x 32 columns
   double vh = 0.0, vl = 0.0;
+  const double qc = q_hi[col];
   for (int b0 = part; b0 < nrows; b0 += 32 * kParts) {
     double x[32];
 #pragma unroll
@@ -902,7 +910,7 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
 #pragma unroll
     for (int k = 0; k < 32; ++k) {
       double h, l;
-      split_exact(x[k], q_hi, &h, &l);
+      split_exact(x[k], qc, &h, &l);
       vh += h;  // exact
       vl += l;  // exact
     }
@@ -922,11 +930,11 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
   __syncthreads();
 }
 __global__ __launch_bounds__(kUpdBlock) void icp_reduce_kernel(const double* __restrict__ partials, int nrows, const IcpStateDev* state,
-                                                               double* __restrict__ record, double q_hi) {
+                                                               double* __restrict__ record, QuantumTable qt) {
   if (state->done) return;
   __shared__ double s_part[2 * (kUpdBlock / 32) * kRec];
   __shared__ double s_out[kRec];
-  reduce_partials(partials, nrows, q_hi, s_part, s_out);
+  reduce_partials(partials, nrows, qt.q, s_part, s_out);
   if (threadIdx.x < kRec) record[threadIdx.x] = s_out[threadIdx.x];
 }
 
@@ -1330,7 +1338,7 @@ __device__ __forceinline__ void icp_step_block(const double* s_rec, IcpStateDev*
 // single-GPU path: reduce the partials and step, one workgroup
 __global__ __launch_bounds__(kUpdBlock) void icp_reduce_update_kernel(const double* __restrict__ partials, int nrows, IcpStateDev* state,
                                                                       unsigned long long n_src_total, int max_iter, double rel_fitness,
-                                                                      double rel_rmse, int debug_mode, int method, double q_hi) {
+                                                                      double rel_rmse, int debug_mode, int method, QuantumTable qt) {
   if (state->done) return;
   if (debug_mode == 1) {  // timing experiment: launch + done check only
     if (threadIdx.x == 0) { state->pass += 1; state->iterations += 1; if (state->iterations > max_iter) state->done = 1; }
@@ -1340,7 +1348,7 @@ __global__ __launch_bounds__(kUpdBlock) void icp_reduce_update_kernel(const doub
   __shared__ double s_out[kRec];
   __shared__ double s_x[8], s_sc[8], s_U[16], s_T[16];
   __shared__ int s_go;
-  reduce_partials(partials, nrows, q_hi, s_part, s_out);
+  reduce_partials(partials, nrows, qt.q, s_part, s_out);
   if (debug_mode == 2) {  // timing experiment: reduction only
     if (threadIdx.x == 0) { state->pass += 1; state->iterations += 1; state->fitness = s_out[28]; if (state->iterations > max_iter) state->done = 1; }
     return;
@@ -1466,7 +1474,7 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   // ---------------- epilogue: add the record to this workgroup's slot, exactly ----------------
   if (threadIdx.x < kRec) {
     double hi, lo;
-    split_exact(v, fa.pass.q_hi, &hi, &lo);
+    split_exact(v, fa.pass.q_hi[threadIdx.x], &hi, &lo);
     double* slot = fa.slots_out + (size_t)(blockIdx.x % kFusedSlots) * kSlotDoubles;
     if (hi != 0.0) (void)__hip_atomic_fetch_add(slot + threadIdx.x, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (lo != 0.0) (void)__hip_atomic_fetch_add(slot + kRec + threadIdx.x, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

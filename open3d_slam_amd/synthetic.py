@@ -223,5 +223,11 @@ def se3_error(Ta: np.ndarray, Tb: np.ndarray):
     """(|dt| in m, rotation angle of dR in rad) between two 4x4 poses."""
     dT = np.linalg.inv(Ta) @ Tb
     dt = float(np.linalg.norm(dT[:3, 3]))
-    c = (np.trace(dT[:3, :3]) - 1.0) / 2.0
+    R = dT[:3, :3]
+    # sin(theta) from the skew part resolves small angles (acos of the trace is quantised at ~2e-8 rad near identity: one ulp of
+    # the trace); acos only for large angles, where the skew part loses the branch
+    s = float(np.linalg.norm([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])) / 2.0
+    c = (np.trace(R) - 1.0) / 2.0
+    if c > 0.5:
+        return dt, float(math.asin(min(1.0, s)))
     return dt, float(math.acos(max(-1.0, min(1.0, c))))

@@ -20,4 +20,11 @@ cp $OUT/pmc_traffic.json $R/profiles/pmc_traffic_latest.json  # bench.py reports
 cd $R
 timeout 300 python bench.py --steps 50 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 echo "bench rc=$?" >> $OUT/bench.err
+timeout 400 python scripts/bench_stream.py --frames 40 --cpu-frames 5 > $OUT/bench_stream.json 2> $OUT/bench_stream.err
+O3DS_FUSED_TRACE=$OUT/fused_trace.txt timeout 60 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+O3DS_FUSED_TRACE_LAUNCH=0 O3DS_FUSED_TRACE=$OUT/fused_trace0.txt timeout 60 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+cd /tmp; rm -rf $OUT/prof_stream
+timeout 200 rocprofv3 --kernel-trace --stats -d $OUT/prof_stream -o s -- python $R/scripts/bench_stream.py --frames 20 --cpu-frames 0 > /dev/null 2>&1
+python $R/scripts/prof_summary.py $OUT/prof_stream/s_results.db $OUT/rocprof_stats_stream.txt > /dev/null
+cd $R
 grep -E "passed|failed" $OUT/pytest_gpu.log | tail -3; tail -2 $OUT/smoke.log; cat $OUT/bench.json; tail -2 $OUT/bench.err; head -5 $OUT/rocprof_stats.txt; cat $OUT/pmc_traffic.json

@@ -508,23 +508,37 @@ def test_information_matrix_matches_oracle(backend_f64, backend_f32, oracle, sma
 
 
 def test_large_coordinates_and_exact_sums(backend_f64, oracle, small_c2):
-    """Clouds far from the origin (UTM-like offsets): the quantum of the exact record sums scales with the target's box, the result still
-    matches the oracle, and it is identical for a different launch geometry (the sums do not depend on how the queries are grouped)."""
+    """Clouds far from the origin (UTM-like offsets).  The problem is ill-conditioned by construction -- a 2.2e5 m lever arm lets
+    rotation and translation trade against each other -- so the yardstick is the reference algorithm's own f64 noise floor on the
+    SAME inputs: the disagreement between the C oracle and the independent numpy restatement (measured: 2.9e-5 m / 4.7e-9 rad; the C
+    oracle differs from itself by 1.4e-5 m / 1.0e-8 rad between 1 and 16 threads; near the origin the pair agrees to 2e-16 m).  The
+    GPU must sit within 3x of that floor.  History: with ONE global quantum for the exact record sums this registration was off by
+    4.4e-4 m / 7e-8 rad (plain f64 sums: 1.7e-5 m), which is why the quanta are per record term; this test would have caught it.
+    Second half: a different launch geometry (other per-workgroup partial sums) lands within the same floor."""
+    from oracle import np_oracle
+
     src, tgt, nrm, _ = small_c2
     off = np.array([1.0e5, -2.0e5, 50.0])
     T0 = np.eye(4)
     T0[:3, 3] = off  # the source stays near the origin, the initial guess carries it to the map
-    ref = oracle.icp_point_to_plane(src, tgt + off, nrm, 1.0, init=T0, max_iter=8, rel_fitness=0.0, rel_rmse=0.0)
-    got = backend_f64.icp_point_to_plane(src, tgt + off, nrm, 1.0, init=T0, max_iter=8, rel_fitness=0.0, rel_rmse=0.0)
+    kw = dict(init=T0, max_iter=8, rel_fitness=0.0, rel_rmse=0.0)
+    ref = oracle.icp_point_to_plane(src, tgt + off, nrm, 1.0, **kw)
+    ref2 = np_oracle.icp_point_to_plane(src, tgt + off, nrm, 1.0, **kw)
+    floor_t, floor_r = syn.se3_error(ref["transformation"], ref2["transformation"])
+    assert 1e-7 < floor_t < 1e-3 and floor_r < 1e-6, (floor_t, floor_r)  # the premise: this input IS ill-conditioned, mildly
+    lim_t, lim_r = 3.0 * max(floor_t, 1e-5), 3.0 * max(floor_r, 5e-9)
+    got = backend_f64.icp_point_to_plane(src, tgt + off, nrm, 1.0, **kw)
     assert got["iterations"] == ref["iterations"] and got["n_corr"] == ref["n_corr"]
     dt, dr = syn.se3_error(got["transformation"], ref["transformation"])
-    assert dt <= 2e-4 and dr <= 1e-8, (dt, dr)  # conditioning: the lever arm |p| ~ 2e5 m multiplies every rounding of the rotation
+    assert dt <= lim_t and dr <= lim_r, (dt, dr, lim_t, lim_r)
+    again = backend_f64.icp_point_to_plane(src, tgt + off, nrm, 1.0, **kw)
+    np.testing.assert_array_equal(again["transformation"], got["transformation"])  # and it is reproducible, unlike the CPU reduction
     os.environ["O3DS_PASS_ROWS"] = "333"
     try:
         be = backend.Backend(0, backend.PRECISION_F64)
-        other = be.icp_point_to_plane(src, tgt + off, nrm, 1.0, init=T0, max_iter=8, rel_fitness=0.0, rel_rmse=0.0)
+        other = be.icp_point_to_plane(src, tgt + off, nrm, 1.0, **kw)
         be.close()
     finally:
         del os.environ["O3DS_PASS_ROWS"]
     dt, dr = syn.se3_error(other["transformation"], got["transformation"])
-    assert dt <= 2e-4 and dr <= 1e-8, (dt, dr)  # other per-workgroup partial sums (their roundings differ), combined exactly
+    assert dt <= lim_t and dr <= lim_r, (dt, dr, lim_t, lim_r)

@@ -478,3 +478,11 @@ def test_undistort_c_matches_numpy_and_known_answers(oracle):
     out = oracle.undistort(p, [2.0, 0.0, 0.0], [0.0, 0.0, 0.0], 0.1, clockwise=True)  # clockwise: phase(pi) is 1/2 as well, phase(0) stays 0
     np.testing.assert_allclose(out[1], [-4.9, 0.0, 0.3], atol=1e-15)
     assert np.array_equal(oracle.undistort(pts, [0, 0, 0], [0, 0, 0], 0.1), pts)  # no motion, no change
+
+
+def test_se3_error_resolves_small_angles():
+    """the pose metric used by every parity test: small rotations must not be quantised (acos of the trace steps by ~2e-8 rad)"""
+    for ang in (0.0, 1e-12, 3e-10, 1e-8, 1e-3, 0.5, 2.0, 3.0):
+        T = syn.make_pose((0.0, 0.0, 0.0), (0.0, 0.0, math.degrees(ang)))
+        _, dr = syn.se3_error(np.eye(4), T)
+        assert abs(dr - ang) <= 1e-15 + 1e-9 * ang, (ang, dr)
