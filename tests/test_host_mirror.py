@@ -87,3 +87,43 @@ def test_scan_to_map_factory_and_type_mapping():
     p.scanMatcher_.scanToMapRegType_ = 42
     with pytest.raises(RuntimeError):
         scanToMapRegistrationFactory(p)
+
+
+def test_split_exact_makes_f64_sums_order_independent():
+    """The arithmetic behind the order-independent record sums (icp_kernels.hpp: split_exact), emulated in numpy float64: values split
+    into hi + lo with hi a multiple of q and lo a multiple of q * 2^-41 add up EXACTLY, so any summation order gives the same bits,
+    and hi + lo reproduces v to within q * 2^-42."""
+    import numpy as np
+
+    rng = np.random.default_rng(0)
+    n = 4096
+    v = rng.normal(size=n) * np.exp(rng.uniform(-20, 5, size=n))  # many magnitudes, both signs
+    bound = np.abs(v).sum()
+    q = 2.0 ** (int(np.ceil(np.log2(bound))) + 3 - 53)  # 2^53 q >= 8 * bound
+
+    def split(x):
+        c_hi = 6755399441055744.0 * q
+        h = (x + c_hi) - c_hi
+        r = x - h
+        c_lo = c_hi * 2.0 ** -41
+        return h, (r + c_lo) - c_lo
+
+    hi, lo = split(v)
+    assert np.all(np.abs(v - (hi + lo)) <= q * 2.0 ** -42)
+    sums = set()
+    for _ in range(20):
+        perm = rng.permutation(n)
+        sh = 0.0
+        sl = 0.0
+        for k in perm:  # strictly sequential f64 adds in a random order
+            sh += hi[k]
+            sl += lo[k]
+        sums.add((sh, sl))
+    assert len(sums) == 1  # bit-identical whatever the order
+    sh, sl = next(iter(sums))
+    import math
+
+    assert abs((sh + sl) - math.fsum(v)) <= n * q * 2.0 ** -42 + 2.0 ** -52 * abs(math.fsum(v))
+    # plain f64 summation of the same values is NOT order-independent (the reason for the split)
+    plain = {float(np.add.reduce(v[rng.permutation(n)])) for _ in range(20)}
+    assert len(plain) > 1
