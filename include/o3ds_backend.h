@@ -252,6 +252,10 @@ int o3ds_dense_map_insert(o3ds_handle h, o3ds_dense_map id, o3ds_cloud cloud, co
 int o3ds_dense_map_size(o3ds_handle h, o3ds_dense_map id, size_t* n_voxels);
 int o3ds_dense_map_to_cloud(o3ds_handle h, o3ds_dense_map id, o3ds_cloud* out);
 int o3ds_dense_map_transform(o3ds_handle h, o3ds_dense_map id, const double T[16]);
+/* Number of points of `cloud` (placed by T; NULL = identity) that fall into an occupied voxel of the map:
+ * VoxelHashMap::hasVoxelContainingPoint per point, the count behind SubmapCollection::isSwitchingSubmapsConsistant
+ * (src/SubmapCollection.cpp:352-364: fitness = hits / scan size, compared with adjacencyBasedRevisitingMinFitness_). */
+int o3ds_dense_map_count_occupied(o3ds_handle h, o3ds_dense_map id, o3ds_cloud cloud, const double T[16], size_t* n_hits);
 /* computeIndicesOfOverlappingPoints (src/helpers.cpp:307-332; call sites src/PlaceRecognition.cpp:103,
  * src/constraint_builders.cpp:54): both clouds are binned with the voxel key floor(p / voxel_size) -- the source after being
  * placed by source_to_target --, and every voxel that holds at least min_points_per_voxel points of EACH cloud contributes all its

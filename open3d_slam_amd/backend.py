@@ -76,6 +76,7 @@ SIGNATURES = {
     "o3ds_dense_map_size": (C.c_int, [_H, C.c_uint64, C.POINTER(C.c_size_t)]),
     "o3ds_dense_map_to_cloud": (C.c_int, [_H, C.c_uint64, C.POINTER(_CL)]),
     "o3ds_dense_map_transform": (C.c_int, [_H, C.c_uint64, _dp]),
+    "o3ds_dense_map_count_occupied": (C.c_int, [_H, C.c_uint64, _CL, _dp, C.POINTER(C.c_size_t)]),
     "o3ds_overlap_indices": (C.c_int, [_H, _CL, _CL, _dp, C.c_double, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_size_t),
                                        C.POINTER(C.c_uint64), C.POINTER(C.c_size_t)]),
     "o3ds_map_carve": (C.c_int, [_H, _CL, _CL, _dp, C.POINTER(Crop), C.POINTER(CarvingParams), C.POINTER(C.c_size_t)]),
@@ -428,6 +429,16 @@ class Backend:
         cid = _CL()
         self._ck(self.lib.o3ds_dense_map_to_cloud(self.h, dm, C.byref(cid)))
         return cid.value
+
+    def dense_map_count_occupied(self, dm: int, cloud: int, T=None) -> int:
+        """points of the placed cloud that fall into an occupied voxel (isSwitchingSubmapsConsistant's numerator)"""
+        n = C.c_size_t(0)
+        if T is None:
+            self._ck(self.lib.o3ds_dense_map_count_occupied(self.h, dm, cloud, None, C.byref(n)))
+        else:
+            Tc, tp = _d(colmajor(T))
+            self._ck(self.lib.o3ds_dense_map_count_occupied(self.h, dm, cloud, tp, C.byref(n)))
+        return int(n.value)
 
     def dense_map_transform(self, dm: int, T):
         Tc, tp = _d(colmajor(T))

@@ -1910,6 +1910,33 @@ int o3ds_dense_map_transform(o3ds_handle h, o3ds_dense_map id, const double T[16
   return O3DS_OK;
 }
 
+int o3ds_dense_map_count_occupied(o3ds_handle h, o3ds_dense_map id, o3ds_cloud cloud, const double T[16], size_t* n_hits) {
+  CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
+  auto it = h->dense_maps.find(id);
+  CloudRec* c = find_cloud(h, cloud);
+  if (it == h->dense_maps.end() || !c || !n_hits) return fail(h, O3DS_ERR_INVALID_ARG, "dense_map_count_occupied: bad argument");
+  *n_hits = 0;
+  DenseRec& d = it->second;
+  if (d.cap == 0 || c->n == 0) return O3DS_OK;
+  Mat34 M;
+  for (int r = 0; r < 3; ++r)
+    for (int col = 0; col < 4; ++col) M.m[r * 4 + col] = T ? T[col * 4 + r] : (r == col ? 1.0 : 0.0);
+  unsigned long long* d_hits = nullptr;
+  TMP_ALLOC(d_hits, sizeof(unsigned long long));
+  HIP_TRY(hipMemsetAsync(d_hits, 0, sizeof(unsigned long long), h->stream));
+  if (c->precision == O3DS_PRECISION_F64)
+    dense_probe_kernel<P4d><<<grid_for(c->n), kBlock, 0, h->stream>>>((const P4d*)c->pts, c->n, M, 1.0 / d.voxel, d.dev, d_hits);
+  else
+    dense_probe_kernel<P4f><<<grid_for(c->n), kBlock, 0, h->stream>>>((const P4f*)c->pts, c->n, M, 1.0 / d.voxel, d.dev, d_hits);
+  HIP_TRY(hipGetLastError());
+  unsigned long long hits = 0;
+  HIP_TRY(hipMemcpyAsync(&hits, d_hits, sizeof(hits), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  *n_hits = (size_t)hits;
+  return O3DS_OK;
+}
+
 int o3ds_overlap_indices(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const double source_to_target[16], double voxel_size,
                          size_t min_points_per_voxel, uint64_t* idx_source, size_t* n_idx_source, uint64_t* idx_target, size_t* n_idx_target) {
   CHECK_HANDLE(h);

@@ -599,6 +599,32 @@ __global__ __launch_bounds__(kBlock) void dense_insert_kernel(const P4* __restri
   }
 }
 
+// VoxelHashMap::hasVoxelContainingPoint (VoxelHashMap.hpp:110-114) for every point of a placed cloud: number of hits
+// (SubmapCollection::isSwitchingSubmapsConsistant, SubmapCollection.cpp:352-364, divides it by the cloud size)
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void dense_probe_kernel(const P4* __restrict__ pts, size_t n, Mat34 M, double inv, DenseDev d,
+                                                             unsigned long long* __restrict__ hits) {
+  unsigned int mine = 0;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const P4 p = pts[i];
+    const double x = (double)p.x, y = (double)p.y, z = (double)p.z;
+    const double px = M.m[0] * x + M.m[1] * y + M.m[2] * z + M.m[3], py = M.m[4] * x + M.m[5] * y + M.m[6] * z + M.m[7],
+                 pz = M.m[8] * x + M.m[9] * y + M.m[10] * z + M.m[11];
+    const unsigned long long k = pack_key((long long)(int)floor(px * inv), (long long)(int)floor(py * inv), (long long)(int)floor(pz * inv));
+    unsigned int slot = dense_slot_of(k, d.mask);
+    while (true) {
+      const unsigned long long t = d.keys[slot];
+      if (t == k) {
+        mine += d.cnt[slot] > 0 ? 1u : 0u;
+        break;
+      }
+      if (t == kEmptyKey) break;
+      slot = (slot + 1) & d.mask;
+    }
+  }
+  if (mine) atomicAdd(hits, (unsigned long long)mine);
+}
+
 // move every used slot of `from` into `to` (a larger, empty table)
 __global__ __launch_bounds__(kBlock) void dense_rehash_kernel(DenseDev from, size_t from_cap, DenseDev to) {
   for (size_t s = (size_t)blockIdx.x * kBlock + threadIdx.x; s < from_cap; s += (size_t)gridDim.x * kBlock) {

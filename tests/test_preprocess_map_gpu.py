@@ -593,3 +593,33 @@ def test_undistort_matches_oracle(backend_f64, backend_f32, oracle, scan):
     with pytest.raises(backend.BackendError):
         backend_f32.undistort(c, v, w, 0.0)
     backend_f32.free(c)
+
+
+def test_dense_map_count_occupied_matches_numpy(backend_f64, scan):
+    """the numerator of SubmapCollection::isSwitchingSubmapsConsistant (SubmapCollection.cpp:352-364): scan points (placed by the
+    pose) whose voxel is occupied in the candidate submap's voxel map -- against a numpy set lookup on the same keys."""
+    scene = syn.make_scene()
+    mp, _ = syn.sample_map(scene, 150_000)
+    voxel = 0.25
+    dm = backend_f64.dense_map_create(voxel)
+    m = backend_f64.upload(mp)
+    backend_f64.dense_map_insert(dm, m)
+    occ = {tuple(k) for k in np.floor(mp * (1.0 / voxel)).astype(np.int64)}
+    s = backend_f64.upload(scan)
+    hits_id = backend_f64.dense_map_count_occupied(dm, s)  # identity placement: no rounding in between
+    want = sum(tuple(k) in occ for k in np.floor(scan * (1.0 / voxel)).astype(np.int64))
+    assert hits_id == want and 0 < want <= len(scan)
+    T = syn.ground_truth_pose()
+    hits = backend_f64.dense_map_count_occupied(dm, s, T)
+    want_T = sum(tuple(k) in occ for k in np.floor((scan @ T[:3, :3].T + T[:3, 3]) * (1.0 / voxel)).astype(np.int64))
+    # the device places the points with its own f64 transform: a point within an ulp of a voxel face may land on the other side
+    assert abs(hits - want_T) <= 3, (hits, want_T)
+    assert 0 < want_T < want  # (this fixture is taken at the identity pose, so moving it lowers the overlap: 10686 -> 8574 of 32768)
+    far = backend_f64.dense_map_count_occupied(dm, s, syn.make_pose((500.0, 0.0, 0.0), (0.0, 0.0, 0.0)))
+    assert far == 0
+    e = backend_f64.dense_map_create(voxel)
+    assert backend_f64.dense_map_count_occupied(e, s) == 0  # empty map
+    for c in (m, s):
+        backend_f64.free(c)
+    backend_f64.dense_map_free(dm)
+    backend_f64.dense_map_free(e)
