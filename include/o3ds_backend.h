@@ -244,7 +244,13 @@ int o3ds_cloud_undistort(o3ds_handle h, o3ds_cloud cloud, const double linear_ve
  *   transform : VoxelizedPointCloud::transform (Voxel.cpp:49-64) as written: keys unchanged, the Isometry applied to the sums as
  *               if they were points (its translation enters the position sum once, and the normal sum too).
  * Sums are kept in fixed point on the device (2^-30 m / 2^-40), so a map does not depend on the order of concurrent insertions.
- * Carving of the dense map (getKeysOfCarvedPoints) is not built. */
+ *   carve     : Submap::carve for the dense map (Submap.cpp:126-136): the scan (placed by scan_pose, NULL = identity -- NB the
+ *               reference passes the RAW scan, i.e. sensor-frame points, together with the map-frame sensor position, Submap.cpp:88)
+ *               is reduced to the first point of every voxel (removeDuplicatePointsWithinSameVoxels, Voxel.cpp:162-191); every kept
+ *               point casts a ray from sensor_position sampled every 2 * neighborhood_radius while
+ *               distance < max(2 * radius, min(length - truncation, max_length)); at every sample the voxels of
+ *               getVoxelsWithinPointNeighborhood (VoxelHashMap.cpp:13-44) are removed (helpers.cpp:347-377).
+ *               neighborhood_radius must be > 0: with 0 the reference's own ray loop (step 2 * radius) never terminates. */
 typedef uint64_t o3ds_dense_map;
 int o3ds_dense_map_create(o3ds_handle h, double voxel_size, o3ds_dense_map* out);
 int o3ds_dense_map_free(o3ds_handle h, o3ds_dense_map id);
@@ -252,6 +258,8 @@ int o3ds_dense_map_insert(o3ds_handle h, o3ds_dense_map id, o3ds_cloud cloud, co
 int o3ds_dense_map_size(o3ds_handle h, o3ds_dense_map id, size_t* n_voxels);
 int o3ds_dense_map_to_cloud(o3ds_handle h, o3ds_dense_map id, o3ds_cloud* out);
 int o3ds_dense_map_transform(o3ds_handle h, o3ds_dense_map id, const double T[16]);
+int o3ds_dense_map_carve(o3ds_handle h, o3ds_dense_map id, o3ds_cloud scan, const double scan_pose[16], const double sensor_position[3],
+                         double neighborhood_radius, double max_raytracing_length, double truncation_distance, size_t* n_removed);
 /* Number of points of `cloud` (placed by T; NULL = identity) that fall into an occupied voxel of the map:
  * VoxelHashMap::hasVoxelContainingPoint per point, the count behind SubmapCollection::isSwitchingSubmapsConsistant
  * (src/SubmapCollection.cpp:352-364: fitness = hits / scan size, compared with adjacencyBasedRevisitingMinFitness_). */

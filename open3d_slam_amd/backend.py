@@ -76,6 +76,7 @@ SIGNATURES = {
     "o3ds_dense_map_size": (C.c_int, [_H, C.c_uint64, C.POINTER(C.c_size_t)]),
     "o3ds_dense_map_to_cloud": (C.c_int, [_H, C.c_uint64, C.POINTER(_CL)]),
     "o3ds_dense_map_transform": (C.c_int, [_H, C.c_uint64, _dp]),
+    "o3ds_dense_map_carve": (C.c_int, [_H, C.c_uint64, _CL, _dp, _dp, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_size_t)]),
     "o3ds_dense_map_count_occupied": (C.c_int, [_H, C.c_uint64, _CL, _dp, C.POINTER(C.c_size_t)]),
     "o3ds_overlap_indices": (C.c_int, [_H, _CL, _CL, _dp, C.c_double, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_size_t),
                                        C.POINTER(C.c_uint64), C.POINTER(C.c_size_t)]),
@@ -429,6 +430,17 @@ class Backend:
         cid = _CL()
         self._ck(self.lib.o3ds_dense_map_to_cloud(self.h, dm, C.byref(cid)))
         return cid.value
+
+    def dense_map_carve(self, dm: int, scan: int, sensor_position, scan_pose=None, radius=0.1, max_length=20.0, truncation=0.1) -> int:
+        """Submap::carve for the dense map; returns the number of removed voxels."""
+        sp, spp = _d(np.asarray(sensor_position, dtype=np.float64).reshape(3))
+        n = C.c_size_t(0)
+        if scan_pose is None:
+            self._ck(self.lib.o3ds_dense_map_carve(self.h, dm, scan, None, spp, radius, max_length, truncation, C.byref(n)))
+        else:
+            Tc, tp = _d(colmajor(scan_pose))
+            self._ck(self.lib.o3ds_dense_map_carve(self.h, dm, scan, tp, spp, radius, max_length, truncation, C.byref(n)))
+        return int(n.value)
 
     def dense_map_count_occupied(self, dm: int, cloud: int, T=None) -> int:
         """points of the placed cloud that fall into an occupied voxel (isSwitchingSubmapsConsistant's numerator)"""

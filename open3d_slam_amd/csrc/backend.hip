@@ -369,6 +369,8 @@ o3ds_cloud add_cloud(o3ds_handle h, CloudRec&& c) {
   return id;
 }
 
+const double kIdentity16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+
 // ---- dense voxel map helpers -----------------------------------------------------------------------
 void dense_release(o3ds_handle h, DenseRec& d) {
   if (d.dev.keys) (void)hipFreeAsync(d.dev.keys, h->stream);
@@ -1907,6 +1909,74 @@ int o3ds_dense_map_transform(o3ds_handle h, o3ds_dense_map id, const double T[16
     for (int col = 0; col < 4; ++col) M.m[r * 4 + col] = T[col * 4 + r];
   dense_transform_kernel<<<grid_for(d.cap), kBlock, 0, h->stream>>>(d.dev, d.cap, M);
   HIP_TRY(hipGetLastError());
+  return O3DS_OK;
+}
+
+int o3ds_dense_map_carve(o3ds_handle h, o3ds_dense_map id, o3ds_cloud scan, const double scan_pose[16], const double sensor_position[3],
+                         double neighborhood_radius, double max_raytracing_length, double truncation_distance, size_t* n_removed) {
+  CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
+  auto it = h->dense_maps.find(id);
+  CloudRec* c = find_cloud(h, scan);
+  if (it == h->dense_maps.end() || !c || !sensor_position) return fail(h, O3DS_ERR_INVALID_ARG, "dense_map_carve: bad argument");
+  if (!(neighborhood_radius > 0.0))
+    return fail(h, O3DS_ERR_INVALID_ARG, "dense_map_carve: neighborhood radius must be > 0 (the ray step is 2 * radius)");
+  if (n_removed) *n_removed = 0;
+  DenseRec& d = it->second;
+  const size_t n = c->n;
+  if (d.cap == 0 || n == 0) return O3DS_OK;  // cloud->empty() (Submap.cpp:128)
+  Mat34 M;
+  for (int r = 0; r < 3; ++r)
+    for (int col = 0; col < 4; ++col) M.m[r * 4 + col] = scan_pose ? scan_pose[col * 4 + r] : (r == col ? 1.0 : 0.0);
+  // removeDuplicatePointsWithinSameVoxels on the PLACED scan: keys of the placed points, stable sort, heads of the key segments
+  CloudRec placed;
+  int rc = c->precision == O3DS_PRECISION_F64 ? transform_t<P4d>(h, *c, scan_pose ? scan_pose : kIdentity16, placed)
+                                              : transform_t<P4f>(h, *c, scan_pose ? scan_pose : kIdentity16, placed);
+  if (rc) {
+    free_cloud(h, placed);
+    return rc;
+  }
+  unsigned long long *k0 = nullptr, *k1 = nullptr, *d_removed = nullptr;
+  uint32_t *v0 = nullptr, *v1 = nullptr;
+  int *first = nullptr, *mark = nullptr;
+  TMP_ALLOC(k0, sizeof(unsigned long long) * n);
+  TMP_ALLOC(k1, sizeof(unsigned long long) * n);
+  TMP_ALLOC(v0, sizeof(uint32_t) * n);
+  TMP_ALLOC(v1, sizeof(uint32_t) * n);
+  TMP_ALLOC(first, sizeof(int) * n);
+  TMP_ALLOC(mark, sizeof(int) * d.cap);
+  TMP_ALLOC(d_removed, sizeof(unsigned long long));
+  CropDev none{};
+  if (c->precision == O3DS_PRECISION_F64)
+    voxel_key_kernel<P4d><<<grid_for(n), kBlock, 0, h->stream>>>((const P4d*)placed.pts, n, 1, 0.0, 0.0, 0.0, d.voxel, none, k0, v0);
+  else
+    voxel_key_kernel<P4f><<<grid_for(n), kBlock, 0, h->stream>>>((const P4f*)placed.pts, n, 1, 0.0, 0.0, 0.0, d.voxel, none, k0, v0);
+  size_t temp_bytes = 0;
+  HIP_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, k0, k1, v0, v1, n, 0, 64, h->stream));
+  void* temp = nullptr;
+  TMP_ALLOC(temp, temp_bytes ? temp_bytes : 16);
+  HIP_TRY(rocprim::radix_sort_pairs(temp, temp_bytes, k0, k1, v0, v1, n, 0, 64, h->stream));
+  first_of_voxel_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(k1, v1, n, first);
+  HIP_TRY(hipMemsetAsync(mark, 0, sizeof(int) * d.cap, h->stream));
+  HIP_TRY(hipMemsetAsync(d_removed, 0, sizeof(unsigned long long), h->stream));
+  // rays are cast from the ALREADY PLACED points (identity here), so that the de-duplication and the rays see the same coordinates
+  Mat34 I;
+  for (int r = 0; r < 3; ++r)
+    for (int col = 0; col < 4; ++col) I.m[r * 4 + col] = r == col ? 1.0 : 0.0;
+  const double* sp = sensor_position;
+  if (c->precision == O3DS_PRECISION_F64)
+    dense_carve_kernel<P4d><<<grid_for(n), kBlock, 0, h->stream>>>((const P4d*)placed.pts, first, n, I, sp[0], sp[1], sp[2], d.voxel,
+                                                                  neighborhood_radius, max_raytracing_length, truncation_distance, d.dev, mark);
+  else
+    dense_carve_kernel<P4f><<<grid_for(n), kBlock, 0, h->stream>>>((const P4f*)placed.pts, first, n, I, sp[0], sp[1], sp[2], d.voxel,
+                                                                  neighborhood_radius, max_raytracing_length, truncation_distance, d.dev, mark);
+  dense_erase_marked_kernel<<<grid_for(d.cap), kBlock, 0, h->stream>>>(d.dev, d.cap, mark, d_removed);
+  HIP_TRY(hipGetLastError());
+  unsigned long long removed = 0;
+  HIP_TRY(hipMemcpyAsync(&removed, d_removed, sizeof(removed), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  free_cloud(h, placed);
+  if (n_removed) *n_removed = (size_t)removed;
   return O3DS_OK;
 }
 

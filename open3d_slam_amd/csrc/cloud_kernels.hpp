@@ -625,6 +625,80 @@ __global__ __launch_bounds__(kBlock) void dense_probe_kernel(const P4* __restric
   if (mine) atomicAdd(hits, (unsigned long long)mine);
 }
 
+// Carving of the dense map: Submap::carve (Submap.cpp:126-136) = removeDuplicatePointsWithinSameVoxels (Voxel.cpp:162-191; done by the
+// caller of this kernel through a key sort: `first[i]` = point i is the first of its voxel) + getKeysOfCarvedPoints
+// (helpers.cpp:347-377) + getVoxelsWithinPointNeighborhood (VoxelHashMap.cpp:13-44, keys by DIVISION floor(p / v) as written there).
+// One thread per kept scan point; marking a slot is an idempotent store.
+__device__ __forceinline__ void dense_mark(const DenseDev& d, unsigned long long k, int* __restrict__ mark) {
+  unsigned int slot = dense_slot_of(k, d.mask);
+  while (true) {
+    const unsigned long long t = d.keys[slot];
+    if (t == k) {
+      if (d.cnt[slot] > 0) mark[slot] = 1;
+      return;
+    }
+    if (t == kEmptyKey) return;
+    slot = (slot + 1) & d.mask;
+  }
+}
+__device__ __forceinline__ unsigned long long key_by_division(double x, double y, double z, double v) {
+  return pack_key((long long)(int)floor(x / v), (long long)(int)floor(y / v), (long long)(int)floor(z / v));
+}
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void dense_carve_kernel(const P4* __restrict__ scan, const int* __restrict__ first, size_t n, Mat34 M,
+                                                             double sx, double sy, double sz, double v, double radius, double max_len,
+                                                             double trunc, DenseDev d, int* __restrict__ mark) {
+  const double step = 2.0 * radius;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    if (!first[i]) continue;
+    const P4 q = scan[i];
+    const double x = (double)q.x, y = (double)q.y, z = (double)q.z;
+    const double px = M.m[0] * x + M.m[1] * y + M.m[2] * z + M.m[3], py = M.m[4] * x + M.m[5] * y + M.m[6] * z + M.m[7],
+                 pz = M.m[8] * x + M.m[9] * y + M.m[10] * z + M.m[11];
+    const double dx0 = px - sx, dy0 = py - sy, dz0 = pz - sz;
+    const double length = sqrt(dx0 * dx0 + dy0 * dy0 + dz0 * dz0);
+    if (!(length > 0.0)) continue;
+    const double ux = dx0 / length, uy = dy0 / length, uz = dz0 / length;
+    const double lim = fmax(step, fmin(length - trunc, max_len));
+    for (double dist = 0.0; dist < lim; dist += step) {
+      const double cx = dist * ux + sx, cy = dist * uy + sy, cz = dist * uz + sz;
+      const unsigned long long ck = key_by_division(cx, cy, cz, v);
+      bool center_added = false;
+      for (double ax = -radius; ax <= radius; ax += v)
+        for (double ay = -radius; ay <= radius; ay += v)
+          for (double az = -radius; az <= radius; az += v) {
+            const double tx = cx + ax, ty = cy + ay, tz = cz + az;
+            const double ex = tx - (floor(tx / v) * v + v * 0.5), ey = ty - (floor(ty / v) * v + v * 0.5), ez = tz - (floor(tz / v) * v + v * 0.5);
+            if (sqrt(ex * ex + ey * ey + ez * ez) <= radius) {
+              const unsigned long long k = key_by_division(tx, ty, tz, v);
+              center_added |= k == ck;
+              dense_mark(d, k, mark);
+            }
+          }
+      if (!center_added) dense_mark(d, ck, mark);
+    }
+  }
+}
+// first[i] = 1 iff point vals[j] heads its key segment in the sorted order (lowest index of its voxel: the sort is stable)
+__global__ __launch_bounds__(kBlock) void first_of_voxel_kernel(const unsigned long long* __restrict__ keys_sorted, const uint32_t* __restrict__ vals,
+                                                                size_t n, int* __restrict__ first) {
+  for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += (size_t)gridDim.x * kBlock)
+    first[vals[j]] = (j == 0 || keys_sorted[j] != keys_sorted[j - 1]) ? 1 : 0;
+}
+// VoxelHashMap::removeKey for every marked slot: the slot stays as a tombstone with count 0 (skipped by toPointCloud / transform,
+// "not present" for hasVoxelWithKey, re-usable by a later insert); *removed += number of voxels that had points
+__global__ __launch_bounds__(kBlock) void dense_erase_marked_kernel(DenseDev d, size_t cap, const int* __restrict__ mark,
+                                                                    unsigned long long* __restrict__ removed) {
+  unsigned int mine = 0;
+  for (size_t s = (size_t)blockIdx.x * kBlock + threadIdx.x; s < cap; s += (size_t)gridDim.x * kBlock) {
+    if (!mark[s] || d.cnt[s] <= 0) continue;
+    d.cnt[s] = 0;
+    for (int c = 0; c < 3; ++c) d.sp[3 * s + c] = 0, d.sn[3 * s + c] = 0;
+    ++mine;
+  }
+  if (mine) atomicAdd(removed, (unsigned long long)mine);
+}
+
 // move every used slot of `from` into `to` (a larger, empty table)
 __global__ __launch_bounds__(kBlock) void dense_rehash_kernel(DenseDev from, size_t from_cap, DenseDev to) {
   for (size_t s = (size_t)blockIdx.x * kBlock + threadIdx.x; s < from_cap; s += (size_t)gridDim.x * kBlock) {

@@ -198,6 +198,66 @@ def undistort(pts, lin_vel, ang_vel_rpy, scan_duration, clockwise=False):
     return out
 
 
+def dense_carve(scan, sensor, voxel_points, voxel, radius=0.1, max_length=20.0, truncation=0.1):
+    """Voxel.cpp:162-191 + helpers.cpp:347-377 + VoxelHashMap.cpp:13-44 with python sets (small inputs only)."""
+    if not (radius > 0.0 and voxel > 0.0):
+        raise ValueError("dense_carve: radius and voxel must be > 0 (the reference's ray step 2 * radius would be zero)")
+    sensor = np.asarray(sensor, dtype=np.float64)
+    inv = 1.0 / voxel
+    occ = {tuple(k): i for i, k in enumerate(np.floor(np.asarray(voxel_points) * inv).astype(np.int64))}
+    removed = np.zeros(len(voxel_points), dtype=bool)
+    seen = set()
+    step = 2.0 * radius
+
+    def key_div(p):
+        return tuple(int(math.floor(c / voxel)) for c in p)
+
+    import math
+
+    for p in scan:
+        k = tuple(np.floor(p * inv).astype(np.int64))
+        if k in seen:  # removeDuplicatePointsWithinSameVoxels keeps the first point of a voxel
+            continue
+        seen.add(k)
+        d = p - sensor
+        length = float(np.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]))
+        if not length > 0.0:
+            continue
+        direction = d / length
+        lim = max(step, min(length - truncation, max_length))
+        dist = 0.0
+        while dist < lim:
+            pos = dist * direction + sensor
+            ck = key_div(pos)
+            keys = []
+            if True:
+                added = False
+                dx = -radius
+                while dx <= radius:
+                    dy = -radius
+                    while dy <= radius:
+                        dz = -radius
+                        while dz <= radius:
+                            tp = pos + np.array([dx, dy, dz])
+                            kk = key_div(tp)
+                            c = np.array(kk, dtype=np.float64) * voxel + voxel * 0.5
+                            e = tp - c
+                            if math.sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) <= radius:
+                                keys.append(kk)
+                                added = added or kk == ck
+                            dz += voxel
+                        dy += voxel
+                    dx += voxel
+                if not added:
+                    keys.append(ck)
+            for kk in keys:
+                i = occ.get(kk)
+                if i is not None:
+                    removed[i] = True
+            dist += step
+    return removed
+
+
 def estimate_normals(pts, radius, max_nn):
     tree = cKDTree(pts, leafsize=15)
     d, j = tree.query(pts, k=max_nn, distance_upper_bound=radius)

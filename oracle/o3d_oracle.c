@@ -900,6 +900,96 @@ void orc_undistort(double* pts, size_t n, const double lin_vel[3], const double 
   }
 }
 
+/* ------------------------------------------------------------------ carving of the dense voxel map
+ * Submap::carve for the VoxelizedPointCloud (src/Submap.cpp:126-136) = removeDuplicatePointsWithinSameVoxels (src/Voxel.cpp:162-191,
+ * first point of every voxel, key floor(p * (1/v))) + getKeysOfCarvedPoints (src/helpers.cpp:347-377): every kept scan point casts
+ * a ray from the sensor position, sampled every 2 * radius while distance < max(2 * radius, min(length - truncation, max_length));
+ * at every sample the voxels of getVoxelsWithinPointNeighborhood (src/VoxelHashMap.cpp:13-44: test points on a lattice of pitch v
+ * in [-radius, radius]^3 around the sample, kept when they lie within radius of the centre of their OWN voxel -- keys by
+ * floor(p / v), the dividing variant --, plus the sample's own voxel) are removed from the map if present.
+ * map_keys: packed keys (carve_key layout) of the occupied voxels, any order; removed_out[n_keys] = 1 for removed voxels. */
+static int64_t carve_key_div(const double p[3], double v) {
+  const int64_t kx = (int64_t)(int)floor(p[0] / v), ky = (int64_t)(int)floor(p[1] / v), kz = (int64_t)(int)floor(p[2] / v);
+  return ((kz + (1ll << 20)) << 42) | ((ky + (1ll << 20)) << 21) | (kx + (1ll << 20));
+}
+int64_t orc_voxel_key(const double p[3], double voxel) { return carve_key(p, 1.0 / voxel); }
+/* mk: map keys sorted ascending with their original positions; marks the voxel `key` as removed if the map has it (idempotent) */
+static void dense_mark_removed(const carve_item* mk, size_t n_keys, int64_t key, uint8_t* removed_out) {
+  size_t lo = 0, hi = n_keys;
+  while (lo < hi) {
+    const size_t mid = (lo + hi) / 2;
+    if (mk[mid].key < key)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  if (lo < n_keys && mk[lo].key == key) removed_out[mk[lo].idx] = 1;
+}
+
+size_t orc_dense_carve(const double* scan, size_t n_scan, const double sensor[3], const int64_t* map_keys, size_t n_keys, double voxel,
+                       double radius, double max_length, double truncation, uint8_t* removed_out) {
+  memset(removed_out, 0, n_keys);
+  /* radius <= 0 makes the ray step 2 * radius zero: the reference's own while loop (helpers.cpp:356-372) then never terminates.
+   * Not a usable input there, rejected here (SIZE_MAX). */
+  if (!(radius > 0.0) || !(voxel > 0.0)) return (size_t)-1;
+  if (n_keys == 0 || n_scan == 0) return 0;
+  const double inv = 1.0 / voxel;
+  /* sorted copy of the map keys for the lookups */
+  carve_item* mk = (carve_item*)malloc(sizeof(carve_item) * n_keys);
+  for (size_t i = 0; i < n_keys; ++i) {
+    mk[i].key = map_keys[i];
+    mk[i].idx = (int64_t)i;
+  }
+  qsort(mk, n_keys, sizeof(carve_item), carve_cmp);
+  /* removeDuplicatePointsWithinSameVoxels: first occurrence per voxel */
+  carve_item* sk = (carve_item*)malloc(sizeof(carve_item) * n_scan);
+  for (size_t i = 0; i < n_scan; ++i) {
+    sk[i].key = carve_key(scan + 3 * i, inv);
+    sk[i].idx = (int64_t)i;
+  }
+  qsort(sk, n_scan, sizeof(carve_item), carve_cmp); /* by key then index */
+  uint8_t* keep = (uint8_t*)calloc(n_scan, 1);
+  for (size_t i = 0; i < n_scan; ++i)
+    if (i == 0 || sk[i].key != sk[i - 1].key) keep[sk[i].idx] = 1;
+  const double step = 2.0 * radius;
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < n_scan; ++i) {
+    if (!keep[i]) continue;
+    const double* p = scan + 3 * i;
+    const double d[3] = {p[0] - sensor[0], p[1] - sensor[1], p[2] - sensor[2]};
+    const double length = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    if (!(length > 0.0)) continue; /* the reference divides by zero here */
+    const double dir[3] = {d[0] / length, d[1] / length, d[2] / length};
+    const double lim = fmax(step, fmin(length - truncation, max_length));
+    for (double dist = 0.0; dist < lim; dist += step) {
+      const double pos[3] = {dist * dir[0] + sensor[0], dist * dir[1] + sensor[1], dist * dir[2] + sensor[2]};
+      const int64_t center_key = carve_key_div(pos, voxel);
+      int center_added = 0; /* (the radius <= 0 branch of getVoxelsWithinPointNeighborhood is unreachable from here, see above) */
+      for (double dx = -radius; dx <= radius; dx += voxel)
+        for (double dy = -radius; dy <= radius; dy += voxel)
+          for (double dz = -radius; dz <= radius; dz += voxel) {
+            const double tp[3] = {pos[0] + dx, pos[1] + dy, pos[2] + dz};
+            /* getCenterOfCorrespondingVoxel: key (by division) * v + v / 2 */
+            const double c[3] = {floor(tp[0] / voxel) * voxel + voxel * 0.5, floor(tp[1] / voxel) * voxel + voxel * 0.5,
+                                 floor(tp[2] / voxel) * voxel + voxel * 0.5};
+            const double e[3] = {tp[0] - c[0], tp[1] - c[1], tp[2] - c[2]};
+            if (sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) <= radius) {
+              const int64_t key = carve_key_div(tp, voxel);
+              if (key == center_key) center_added = 1;
+              dense_mark_removed(mk, n_keys, key, removed_out);
+            }
+          }
+      if (!center_added) dense_mark_removed(mk, n_keys, center_key, removed_out); /* VoxelHashMap.cpp:40-42 */
+    }
+  }
+  free(mk);
+  free(sk);
+  free(keep);
+  size_t cnt = 0;
+  for (size_t i = 0; i < n_keys; ++i) cnt += removed_out[i];
+  return cnt;
+}
+
 /* ------------------------------------------------------------------ A.8 Generalized ICP
  * [O3D] GeneralizedICP.cpp: GetRotationFromE1ToX, InitializePointCloudForGeneralizedICP,
  * TransformationEstimationForGeneralizedICP::ComputeTransformation; reference call site src/CloudRegistration.cpp:16-21. */

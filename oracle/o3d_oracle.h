@@ -105,6 +105,13 @@ size_t orc_dense_fuse(const double* pts, const double* nrm, size_t n, double vox
 /* ConstantVelocityMotionCompensation::undistortInputPointCloud (MotionCompensation.cpp:64-139), in place */
 void orc_undistort(double* pts, size_t n, const double lin_vel[3], const double ang_vel_rpy[3], double scan_duration, int clockwise);
 
+/* Carving of the dense voxel map: removeDuplicatePointsWithinSameVoxels (Voxel.cpp:162-191) + getKeysOfCarvedPoints
+ * (helpers.cpp:347-377) + getVoxelsWithinPointNeighborhood (VoxelHashMap.cpp:13-44).  map_keys: orc_voxel_key of the occupied voxels;
+ * removed_out[n_keys]; returns the number of removed voxels. */
+int64_t orc_voxel_key(const double p[3], double voxel);
+size_t orc_dense_carve(const double* scan, size_t n_scan, const double sensor[3], const int64_t* map_keys, size_t n_keys, double voxel,
+                       double radius, double max_length, double truncation, uint8_t* removed_out);
+
 /* A.8 RegistrationGeneralizedICP (call site src/CloudRegistration.cpp:16-21): covariances from normals
  * (C = Rx diag(eps,1,1) Rx^T, Rx = GetRotationFromE1ToX(normal)), per pair M = Ct + R Cs R^T, W = M^-1/2, residual W d (3 rows),
  * Jacobian rows W [-[p]x | I]; same loop / solve / convergence as A.1.  Both clouds must carry normals (as they always do

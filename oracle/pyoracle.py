@@ -82,6 +82,11 @@ def lib():
         L.orc_dense_fuse.argtypes = [_dp, _dp, C.c_size_t, C.c_double, _dp, _dp, _ip]
         L.orc_undistort.restype = None
         L.orc_undistort.argtypes = [_dp, C.c_size_t, _dp, _dp, C.c_double, C.c_int]
+        L.orc_voxel_key.restype = C.c_int64
+        L.orc_voxel_key.argtypes = [_dp, C.c_double]
+        L.orc_dense_carve.restype = C.c_size_t
+        L.orc_dense_carve.argtypes = [_dp, C.c_size_t, _dp, C.POINTER(C.c_int64), C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double,
+                                      C.POINTER(C.c_uint8)]
         L.orc_gicp_jtj_jtr.argtypes = [_dp, _dp, C.c_size_t, _dp, _dp, _ip, _dp, _dp]
         L.orc_covariance_from_normal.argtypes = [_dp, C.c_double, _dp]
         L.orc_estimate_normals.argtypes = [_dp, C.c_size_t, C.c_double, C.c_int, _dp]
@@ -297,6 +302,21 @@ def undistort(pts, lin_vel, ang_vel_rpy, scan_duration, clockwise=False):
     w, wp = _d(np.asarray(ang_vel_rpy, dtype=np.float64).reshape(3))
     lib().orc_undistort(out.ctypes.data_as(_dp), len(out), vp, wp, float(scan_duration), int(bool(clockwise)))
     return out
+
+
+def dense_carve(scan, sensor, voxel_points, voxel, radius=0.1, max_length=20.0, truncation=0.1):
+    """Submap::carve for the dense map (Submap.cpp:126-136): boolean mask over `voxel_points` (one representative point per occupied
+    voxel of the map, e.g. the voxel means) of the voxels a scan removes."""
+    scan, sp = _d(scan)
+    sensor, snp = _d(np.asarray(sensor, dtype=np.float64).reshape(3))
+    vp = np.ascontiguousarray(voxel_points, dtype=np.float64).reshape(-1, 3)
+    keys = np.array([lib().orc_voxel_key(vp[i].ctypes.data_as(_dp), voxel) for i in range(len(vp))], dtype=np.int64)
+    rem = np.zeros(len(vp), np.uint8)
+    rc = lib().orc_dense_carve(sp, len(scan), snp, keys.ctypes.data_as(C.POINTER(C.c_int64)), len(keys), voxel, radius, max_length, truncation,
+                               rem.ctypes.data_as(C.POINTER(C.c_uint8)))
+    if rc == 2 ** 64 - 1:
+        raise ValueError("dense_carve: radius and voxel must be > 0 (a zero radius makes the reference's ray step zero: it never terminates)")
+    return rem.astype(bool)
 
 
 def icp_generalized(src, src_nrm, tgt, tgt_nrm, max_corr, init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6, epsilon=1e-3,

@@ -486,3 +486,36 @@ def test_se3_error_resolves_small_angles():
         T = syn.make_pose((0.0, 0.0, 0.0), (0.0, 0.0, math.degrees(ang)))
         _, dr = syn.se3_error(np.eye(4), T)
         assert abs(dr - ang) <= 1e-15 + 1e-9 * ang, (ang, dr)
+
+
+# ---- carving of the dense voxel map (Submap.cpp:126-136, helpers.cpp:347-377, VoxelHashMap.cpp:13-44) ------
+def test_dense_carve_c_matches_numpy_and_known_answers(oracle):
+    rng = np.random.default_rng(5)
+    voxel = 0.1
+    # occupied voxels: a wall at x = 3 and clutter in front of it; one representative point per voxel
+    wall = np.stack(np.meshgrid([3.05], np.arange(-1.0, 1.0, 0.1) + 0.05, np.arange(0.0, 1.5, 0.1) + 0.05, indexing="ij"), -1).reshape(-1, 3)
+    clutter = np.unique(np.floor(rng.uniform([0.5, -0.8, 0.2], [2.5, 0.8, 1.2], size=(150, 3)) / voxel), axis=0) * voxel + 0.05
+    behind = wall + [0.3, 0.0, 0.0]  # a layer three voxels behind the wall: no sample (they stop `truncation` before the hit) reaches it
+    vox = np.vstack([wall, clutter, behind])
+    sensor = np.array([0.013, -0.021, 0.71])
+    scan = wall[rng.choice(len(wall), 120, replace=False)] + rng.normal(scale=0.004, size=(120, 3))
+    scan = np.vstack([scan, scan[:10]])  # duplicates inside the same voxel are dropped by removeDuplicatePointsWithinSameVoxels
+    for kw in (dict(radius=0.1), dict(radius=0.05, truncation=0.3), dict(radius=0.17, max_length=2.0)):
+        a = oracle.dense_carve(scan, sensor, vox, voxel, **kw)
+        b = no.dense_carve(scan, sensor, vox, voxel, **kw)
+        assert np.array_equal(a, b), kw
+    a = oracle.dense_carve(scan, sensor, vox, voxel, radius=0.1)
+    nw, nc = len(wall), len(clutter)
+    assert not a[nw + nc:].any()          # out of reach: last sample <= hit - 0.1, neighbourhood <= one voxel around the sample
+    assert a[nw: nw + nc].any()           # clutter in the line of sight is carved
+    # (about half of the wall's own voxels go as well: with truncation = radius = one voxel and a ray step of two voxels the last
+    # sample lands in the voxel next to the wall every other time -- the reference's behaviour, reproduced by both restatements)
+    # a zero neighbourhood radius makes the ray step (2 * radius) zero -- the reference's loop would never end; both restatements refuse
+    for bad in (oracle.dense_carve, no.dense_carve):
+        with pytest.raises(ValueError):
+            bad(scan, sensor, vox, voxel, radius=0.0)
+    # one ray along +x: sensor inside voxel 0, point at x = 1.0 -> samples at 0, 0.2, .., 0.8 (truncation 0.1)
+    line = np.stack([np.arange(15) * 0.1 + 0.05, np.full(15, 0.025), np.full(15, 0.025)], 1)
+    s0 = np.array([0.025, 0.025, 0.025])
+    f = oracle.dense_carve(s0 + [[1.0, 0.0, 0.0]], s0, line, voxel, radius=0.1)
+    assert set(np.flatnonzero(f).tolist()) >= {0, 2, 4, 6, 8} and not f[11:].any()

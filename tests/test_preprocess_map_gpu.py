@@ -623,3 +623,48 @@ def test_dense_map_count_occupied_matches_numpy(backend_f64, scan):
         backend_f64.free(c)
     backend_f64.dense_map_free(dm)
     backend_f64.dense_map_free(e)
+
+
+def test_dense_map_carve_matches_oracle(backend_f64, oracle):
+    """Submap::carve for the dense map (Submap.cpp:126-136, helpers.cpp:347-377, VoxelHashMap.cpp:13-44) on the device table vs the
+    oracle: the same set of removed voxels, voxels out of reach untouched, removed voxels gone from to_cloud / count_occupied and
+    usable again by a later insert; a zero neighbourhood radius is refused (the reference's ray step would be zero)."""
+    rng = np.random.default_rng(5)
+    voxel = 0.1
+    wall = np.stack(np.meshgrid([3.05], np.arange(-1.0, 1.0, 0.1) + 0.05, np.arange(0.0, 1.5, 0.1) + 0.05, indexing="ij"), -1).reshape(-1, 3)
+    clutter = np.unique(np.floor(rng.uniform([0.5, -0.8, 0.2], [2.5, 0.8, 1.2], size=(400, 3)) / voxel), axis=0) * voxel + 0.05
+    behind = wall + [0.3, 0.0, 0.0]
+    pts = np.vstack([wall, clutter, behind]) + rng.uniform(-0.03, 0.03, size=(len(wall) * 2 + len(clutter), 3))  # anywhere inside the voxels
+    sensor = np.array([0.013, -0.021, 0.71])
+    scan = wall[rng.choice(len(wall), 200, replace=True)] + rng.normal(scale=0.004, size=(200, 3))
+    for kw in (dict(radius=0.1), dict(radius=0.05, truncation=0.3), dict(radius=0.17, max_length=2.0)):
+        dm = backend_f64.dense_map_create(voxel)
+        m = backend_f64.upload(pts)
+        backend_f64.dense_map_insert(dm, m)
+        before_id = backend_f64.dense_map_to_cloud(dm)
+        before = backend_f64.download(before_id)[0]  # one mean per voxel, ascending key order
+        ref = oracle.dense_carve(scan, sensor, before, voxel, **kw)
+        s = backend_f64.upload(scan)
+        removed = backend_f64.dense_map_carve(dm, s, sensor, **kw)
+        assert removed == int(ref.sum()) and 0 < removed < len(before), (kw, removed, int(ref.sum()))
+        after_id = backend_f64.dense_map_to_cloud(dm)
+        after = backend_f64.download(after_id)[0]
+        np.testing.assert_array_equal(after, before[~ref])  # exactly the oracle's voxels are gone, the rest untouched and in order
+        assert backend_f64.dense_map_size(dm) == len(before) - removed
+        assert backend_f64.dense_map_carve(dm, s, sensor, **kw) == 0  # same rays, same reach, and everything in reach is already gone
+        # a removed voxel can be filled again and then counts from one
+        gone = before[ref][:1]
+        g = backend_f64.upload(gone)
+        assert backend_f64.dense_map_count_occupied(dm, g) == 0
+        backend_f64.dense_map_insert(dm, g)
+        assert backend_f64.dense_map_count_occupied(dm, g) == 1 and backend_f64.dense_map_size(dm) == len(before) - removed + 1
+        for cid in (m, s, g, before_id, after_id):
+            backend_f64.free(cid)
+        backend_f64.dense_map_free(dm)
+    dm = backend_f64.dense_map_create(voxel)
+    s = backend_f64.upload(scan)
+    assert backend_f64.dense_map_carve(dm, s, sensor) == 0  # empty map: nothing to do (Submap.cpp:128)
+    with pytest.raises(backend.BackendError):
+        backend_f64.dense_map_carve(dm, s, sensor, radius=0.0)
+    backend_f64.free(s)
+    backend_f64.dense_map_free(dm)
