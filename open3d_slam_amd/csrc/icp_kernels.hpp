@@ -1,13 +1,15 @@
-// icp_kernels.hpp -- nearest-neighbour index build and the fused point-to-plane ICP pass for gfx950.
+// icp_kernels.hpp -- nearest-neighbour index build and the ICP pass kernels for gfx950.
 //
-// Replaces, for the reference's registerClouds seam (CloudRegistration.cpp:44-48), the Open3D v0.15.1 routines
+// Replaces, for the reference's registerClouds seams (CloudRegistration.cpp:16-21, 44-48, 69-74), the Open3D v0.15.1 routines
 //   KDTreeFlann::SetGeometry              -> grid index build  (bbox -> cell count -> scan -> scatter)
 //   GetRegistrationResultAndCorrespondences
 //   + PointCloud::Transform
-//   + TransformationEstimationPointToPlane::ComputeTransformation (ComputeJTJandJTr)
-//                                         -> ONE kernel per pass: icp_accumulate_kernel
-//   SolveJacobianSystemAndObtainExtrinsicMatrix + convergence test
-//                                         -> icp_update_kernel (one workgroup, on device: no host round trip)
+//   + TransformationEstimationPointToPlane / ...ForGeneralizedICP / ...PointToPoint ::ComputeTransformation (the reductions)
+//   + SolveJacobianSystemAndObtainExtrinsicMatrix (or Eigen::umeyama) + the convergence test of the PREVIOUS iteration
+//                                         -> ONE kernel per iteration: icp_fused_kernel (default form)
+//   the same split in two / three kernels -> icp_accumulate_kernel + icp_reduce_update_kernel (O3DS_ICP_MODE=launch),
+//                                            icp_accumulate_kernel + icp_reduce_kernel + icp_update_kernel (classic sharded form)
+// Record sums are order-independent (split_exact), so all forms agree bit for bit.  DESIGN.md section 4 has the measurements.
 #pragma once
 #include "common.hpp"
 
