@@ -80,7 +80,7 @@ struct o3ds_context {
   std::vector<std::pair<char*, size_t>> arena_blocks;
   size_t arena_cur = 0, arena_off = 0;
   int arena_depth = 0;
-  // launch geometry of the ICP pass kernel (tunable through O3DS_PASS_BLOCK / O3DS_PASS_ROWS for experiments)
+  // rows (workgroups) per pass are capped at pass_rows (O3DS_PASS_ROWS, for experiments and the geometry-independence test)
   // ONE launch per pass with the previous pass's tail in its prologue (O3DS_ICP_MODE=fused), see icp_fused_kernel
   // normal estimation: remembered cell size of the ring search (see normals_t)
   double nrm_cell = 0.0, nrm_radius = 0.0;
@@ -92,8 +92,6 @@ struct o3ds_context {
   char* d_fused = nullptr;  // [2 states | 3 x kFusedSlots slot records (hi and lo sums)]
   unsigned long long fused_launches = 0;
   int debug_update = 0;  // O3DS_DEBUG_UPDATE: timing experiments only
-  int pass_block = 256;
-  int pass_group = 4;
   int pass_rows = 1024;
   // profiling (bench.py roofline): event pairs around every accumulate launch
   bool profiling = false;
@@ -517,25 +515,18 @@ void launch_accumulate(o3ds_handle h, const IcpPassArgs& a, bool crop, int nbloc
       (void)hipEventRecord(e0, h->stream);
     }
   }
-#define O3DS_LAUNCH_PASS(BLK, GRP, GICP)                                                              \
-  do {                                                                                                \
-    if (crop)                                                                                         \
-      icp_accumulate_kernel<P4, true, BLK, GRP, GICP><<<nblocks, BLK, 0, h->stream>>>(a);            \
-    else                                                                                              \
-      icp_accumulate_kernel<P4, false, BLK, GRP, GICP><<<nblocks, BLK, 0, h->stream>>>(a);           \
-  } while (0)
+  // one geometry: 256 threads = 64 queries x 4 lanes (G = 2 / 8 and 512-thread variants were swept and dropped)
   if (h->session_method == O3DS_ICP_GENERALIZED) {
-    O3DS_LAUNCH_PASS(256, 4, true);
+    if (crop)
+      icp_accumulate_kernel<P4, true, 256, 4, true><<<nblocks, 256, 0, h->stream>>>(a);
+    else
+      icp_accumulate_kernel<P4, false, 256, 4, true><<<nblocks, 256, 0, h->stream>>>(a);
   } else {
-    const int key = h->pass_block * 100 + h->pass_group;
-    switch (key) {
-      case 25602: O3DS_LAUNCH_PASS(256, 2, false); break;
-      case 25608: O3DS_LAUNCH_PASS(256, 8, false); break;
-      case 51204: O3DS_LAUNCH_PASS(512, 4, false); break;
-      default: O3DS_LAUNCH_PASS(256, 4, false); break;
-    }
+    if (crop)
+      icp_accumulate_kernel<P4, true, 256, 4, false><<<nblocks, 256, 0, h->stream>>>(a);
+    else
+      icp_accumulate_kernel<P4, false, 256, 4, false><<<nblocks, 256, 0, h->stream>>>(a);
   }
-#undef O3DS_LAUNCH_PASS
   if (e1) (void)hipEventRecord(e1, h->stream);
 }
 
@@ -580,10 +571,7 @@ void launch_fused(o3ds_handle h, const IcpFusedArgs& fa, bool crop, int nblocks,
 }
 
 int pass_blocks(o3ds_handle h, size_t count) {
-  const bool gicp = h->session_method == O3DS_ICP_GENERALIZED;
-  const int blk = gicp ? 256 : (h->pass_block == 512 && h->pass_group == 4 ? 512 : 256);
-  const int grp = gicp ? 4 : ((h->pass_block == 256 && (h->pass_group == 2 || h->pass_group == 8)) ? h->pass_group : 4);
-  const size_t qpb = (size_t)blk / grp;  // one batch of BLOCK/G queries per workgroup iteration
+  const size_t qpb = 64;  // one batch of 256 / 4 queries per workgroup iteration
   size_t g = (count + qpb - 1) / qpb;
   if (g < 1) g = 1;
   if (g > (size_t)h->pass_rows) g = h->pass_rows;
@@ -781,11 +769,6 @@ int o3ds_create(int device_id, o3ds_handle* out) {
     }
   }
   if (const char* e = getenv("O3DS_DEBUG_UPDATE")) h->debug_update = atoi(e);
-  if (const char* e = getenv("O3DS_PASS_BLOCK")) h->pass_block = atoi(e) == 512 ? 512 : 256;
-  if (const char* e = getenv("O3DS_PASS_GROUP")) {
-    const int g = atoi(e);
-    h->pass_group = (g == 2 || g == 4 || g == 8) ? g : 4;
-  }
   if (const char* e = getenv("O3DS_PASS_ROWS")) h->pass_rows = std::min(std::max(atoi(e), 1), kMaxPassBlocks);
   *out = h;
   return O3DS_OK;
