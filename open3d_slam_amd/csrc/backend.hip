@@ -48,7 +48,8 @@ struct DenseRec {
   size_t cap = 0;          // power of two
   o3ds::DenseDev dev{};
   bool has_normals = false;
-  size_t used_upper = 0;   // upper bound on the used slots (exact count fetched only when the table looks too full)
+  size_t used_upper = 0;   // upper bound on the OCCUPIED slots = live voxels + tombstones (exact count fetched only when the table
+                           // looks too full); the load factor of the open-addressing table is about these, not about live voxels
 };
 
 struct o3ds_context {
@@ -394,44 +395,52 @@ int dense_alloc(o3ds_handle h, size_t cap, o3ds::DenseDev* out) {
   return O3DS_OK;
 }
 
-// number of used voxels (one scan + one 4-byte read back)
-int dense_count(o3ds_handle h, DenseRec& d, size_t* n_used, int** flag_out = nullptr, int** pos_out = nullptr) {
-  *n_used = 0;
+// number of live voxels and of occupied slots (one scan + two small read backs)
+int dense_count(o3ds_handle h, DenseRec& d, size_t* n_live, int** flag_out = nullptr, int** pos_out = nullptr, size_t* n_occupied = nullptr) {
+  *n_live = 0;
+  if (n_occupied) *n_occupied = 0;
   if (d.cap == 0) return O3DS_OK;
   int *flag = nullptr, *pos = nullptr;
+  unsigned long long* d_occ = nullptr;
   TMP_ALLOC(flag, sizeof(int) * (d.cap + 1));
   TMP_ALLOC(pos, sizeof(int) * (d.cap + 1));
+  TMP_ALLOC(d_occ, sizeof(unsigned long long));
   HIP_TRY(hipMemsetAsync(flag + d.cap, 0, sizeof(int), h->stream));
-  dense_used_flag_kernel<<<grid_for(d.cap), kBlock, 0, h->stream>>>(d.dev, d.cap, flag);
+  HIP_TRY(hipMemsetAsync(d_occ, 0, sizeof(unsigned long long), h->stream));
+  dense_used_flag_kernel<<<grid_for(d.cap), kBlock, 0, h->stream>>>(d.dev, d.cap, flag, d_occ);
   int rc = exclusive_scan_int(h, flag, pos, d.cap + 1);
   if (rc) return rc;
   int total = 0;
+  unsigned long long occ = 0;
   HIP_TRY(hipMemcpyAsync(&total, pos + d.cap, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(&occ, d_occ, sizeof(occ), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  *n_used = (size_t)total;
-  d.used_upper = (size_t)total;
+  *n_live = (size_t)total;
+  if (n_occupied) *n_occupied = (size_t)occ;
+  d.used_upper = (size_t)occ;  // exact now
   if (flag_out) *flag_out = flag;
   if (pos_out) *pos_out = pos;
   return O3DS_OK;
 }
 
-// make room for up to n_new more voxels (load factor <= 1/2)
+// make room for up to n_new more voxels: occupied slots (live + tombstones) stay <= cap / 2, so a probe always finds a free slot
 int dense_reserve(o3ds_handle h, DenseRec& d, size_t n_new) {
   if (d.cap && (d.used_upper + n_new) * 2 <= d.cap) {
     d.used_upper += n_new;
     return O3DS_OK;
   }
-  size_t used = 0;
+  size_t live = 0, occupied = 0;
   if (d.cap) {
-    int rc = dense_count(h, d, &used);  // the bound was pessimistic (most points fall into existing voxels): tighten it first
+    int rc = dense_count(h, d, &live, nullptr, nullptr, &occupied);  // the bound was pessimistic (most points fall into existing voxels)
     if (rc) return rc;
-    if ((used + n_new) * 2 <= d.cap) {
-      d.used_upper = used + n_new;
+    if ((occupied + n_new) * 2 <= d.cap) {
+      d.used_upper = occupied + n_new;
       return O3DS_OK;
     }
   }
+  // rehash: only live voxels move, tombstones are dropped -- so the new table may even be the same size as the old one
   size_t cap = 1024;
-  while (cap < 4 * (used + n_new)) cap <<= 1;
+  while (cap < 4 * (live + n_new)) cap <<= 1;
   if (cap > ((size_t)1 << 31)) return fail(h, O3DS_ERR_OOM, "dense map: table would exceed 2^31 slots");
   o3ds::DenseDev nd{};
   int rc = dense_alloc(h, cap, &nd);
@@ -444,7 +453,7 @@ int dense_reserve(o3ds_handle h, DenseRec& d, size_t n_new) {
   }
   d.dev = nd;
   d.cap = cap;
-  d.used_upper = used + n_new;
+  d.used_upper = live + n_new;
   return O3DS_OK;
 }
 

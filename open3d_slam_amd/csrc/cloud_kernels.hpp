@@ -703,7 +703,7 @@ __global__ __launch_bounds__(kBlock) void dense_erase_marked_kernel(DenseDev d, 
 __global__ __launch_bounds__(kBlock) void dense_rehash_kernel(DenseDev from, size_t from_cap, DenseDev to) {
   for (size_t s = (size_t)blockIdx.x * kBlock + threadIdx.x; s < from_cap; s += (size_t)gridDim.x * kBlock) {
     const unsigned long long k = from.keys[s];
-    if (k == kEmptyKey) continue;
+    if (k == kEmptyKey || from.cnt[s] <= 0) continue;    // free slots, and tombstones left by carving: dropped here
     const unsigned int t = dense_find_or_insert(to, k);  // keys are unique: this thread owns slot t
     to.cnt[t] = from.cnt[s];
     for (int c = 0; c < 3; ++c) {
@@ -713,10 +713,17 @@ __global__ __launch_bounds__(kBlock) void dense_rehash_kernel(DenseDev from, siz
   }
 }
 
-// list of used slots: flags for the scan, then (key, slot) pairs
-__global__ __launch_bounds__(kBlock) void dense_used_flag_kernel(DenseDev d, size_t cap, int* __restrict__ flag) {
-  for (size_t s = (size_t)blockIdx.x * kBlock + threadIdx.x; s < cap; s += (size_t)gridDim.x * kBlock)
-    flag[s] = (d.keys[s] != kEmptyKey && d.cnt[s] > 0) ? 1 : 0;
+// list of used slots: flags for the scan, then (key, slot) pairs.  *occupied counts every slot whose key is taken -- live voxels
+// AND the count-0 tombstones carving leaves behind: that, not the number of live voxels, is what the load factor is about
+__global__ __launch_bounds__(kBlock) void dense_used_flag_kernel(DenseDev d, size_t cap, int* __restrict__ flag,
+                                                                 unsigned long long* __restrict__ occupied) {
+  unsigned int mine = 0;
+  for (size_t s = (size_t)blockIdx.x * kBlock + threadIdx.x; s < cap; s += (size_t)gridDim.x * kBlock) {
+    const bool taken = d.keys[s] != kEmptyKey;
+    flag[s] = (taken && d.cnt[s] > 0) ? 1 : 0;
+    mine += taken ? 1u : 0u;
+  }
+  if (mine) atomicAdd(occupied, (unsigned long long)mine);
 }
 __global__ __launch_bounds__(kBlock) void dense_list_kernel(DenseDev d, size_t cap, const int* __restrict__ flag, const int* __restrict__ pos,
                                                             unsigned long long* __restrict__ keys_out, uint32_t* __restrict__ slots_out) {

@@ -668,3 +668,32 @@ def test_dense_map_carve_matches_oracle(backend_f64, oracle):
         backend_f64.dense_map_carve(dm, s, sensor, radius=0.0)
     backend_f64.free(s)
     backend_f64.dense_map_free(dm)
+
+
+def test_dense_map_survives_many_carve_insert_cycles(backend_f64):
+    """Carving leaves count-0 tombstones in the open-addressing table.  The load factor must be accounted in OCCUPIED slots (live +
+    tombstones) and tombstones dropped on rehash, otherwise repeated carve / insert cycles fill the table and a probe never finds a
+    free slot (a hang).  60 cycles, each inserting ~1000 fresh voxels into a small table and carving most of them away again."""
+    voxel = 0.1
+    dm = backend_f64.dense_map_create(voxel)
+    sensor = np.array([0.013, -0.021, 0.013])
+    live_expected = None
+    for cycle in range(60):
+        # a fresh slab of voxels at a new height every cycle, in front of the sensor
+        ys, xs = np.meshgrid(np.arange(-1.5, 1.5, 0.1) + 0.05, np.arange(1.0, 4.0, 0.1) + 0.05, indexing="ij")
+        slab = np.stack([xs.ravel(), ys.ravel(), np.full(xs.size, 0.05 + 0.1 * cycle)], 1)
+        c = backend_f64.upload(slab)
+        backend_f64.dense_map_insert(dm, c)
+        n_before = backend_f64.dense_map_size(dm)
+        # rays to a row of points beyond the slab at the same height sweep most of it away
+        far = np.stack([np.full(60, 6.0), np.linspace(-2.2, 2.2, 60), np.full(60, 0.05 + 0.1 * cycle)], 1)
+        s = backend_f64.upload(far)
+        removed = backend_f64.dense_map_carve(dm, s, sensor + [0.0, 0.0, 0.1 * cycle], radius=0.1, max_length=10.0)
+        assert removed > 0 and backend_f64.dense_map_size(dm) == n_before - removed
+        live_expected = n_before - removed
+        backend_f64.free(c)
+        backend_f64.free(s)
+    out = backend_f64.dense_map_to_cloud(dm)
+    assert backend_f64.size(out)[0] == live_expected
+    backend_f64.free(out)
+    backend_f64.dense_map_free(dm)
