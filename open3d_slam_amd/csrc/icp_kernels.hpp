@@ -621,7 +621,7 @@ __device__ __forceinline__ size_t query_index(size_t count, size_t b, int ql, bo
   // a wavefront takes kQPW / kRun runs of kRun consecutive queries, the runs count/(kQPW/kRun) apart (a wavefront serves its
   // far queries one after the other, so the mix has to hold per wavefront, not just per workgroup; runs keep some of the
   // cache-line sharing of neighbouring queries) ...
-  constexpr int kRun = 1, kRuns = kQPW / kRun;  // runs of 4 consecutive queries: body mean 37 -> 32 us but slowest workgroup 55 -> 58 us
+  constexpr int kRun = 1, kRuns = kQPW / kRun;  // runs of 4: body mean 37 -> 32 us but slowest workgroup 55 -> 58 us; runs of 16 (a whole wavefront): group search 10 us but slowest workgroup 66 us, 38.9k it/s
   static_assert(kQPW % kRun == 0, "runs tile a wavefront");
   const size_t n_run = (count + kRun - 1) / kRun;         // runs in the scan
   const size_t n_off = (n_run + kRuns - 1) / kRuns;       // offsets: one per wavefront slot
