@@ -187,6 +187,22 @@ def main():
         except Exception:
             pass
 
+    # measured device copy bandwidth on this box (report against the vendor peak AND a measured copy kernel):
+    # 1 GiB device-to-device copy, read + write counted, hipEvent-timed, after the timed region
+    copy_gbs = None
+    if rank == 0:
+        nb = 1 << 30
+        a_, b_ = torch.empty(nb, dtype=torch.uint8, device=f"cuda:{local_rank}"), torch.empty(nb, dtype=torch.uint8, device=f"cuda:{local_rank}")
+        b_.copy_(a_)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            b_.copy_(a_)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 5 * 2 * nb / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a_, b_
+
     if rank == 0:
         dt_gt, dr_gt = syn.se3_error(res["transformation"], T_gt)
         out = {
@@ -213,7 +229,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                          "kernel": pass_kernel, "launches": n_launch, "avg_launch_us": avg_kernel_s * 1e6,
-                         "algorithmic_bytes_per_launch": algo_bytes},
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "measured_copy_gbs": copy_gbs, "frac_of_measured_copy": achieved_gbs / copy_gbs if copy_gbs else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             cb, cres = cpu_baseline(src, tgt, nrm, args.cpu_budget)

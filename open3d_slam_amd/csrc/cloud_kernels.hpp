@@ -846,6 +846,13 @@ __device__ __forceinline__ void normal_one_lane(const P4& q, const GridDev& g, c
     }
   };
 
+  // Distance (in cells) from the query to the slab of cells at offset d along one axis; f = the query's fraction inside its own
+  // cell.  A row (dz, dy) holds no candidate when gap_z^2 + gap_y^2 already reaches the bound, and inside a row only the cells
+  // whose x-gap fits under what is left can; both tests are deflated by 1e-6 against the rounding of the f32 distances, and the
+  // bound (`worst`: r^2, then the current max_nn-th best) only ever shrinks, so a skipped cell stays skipped.
+  const double frx = fx - floor(fx), fry = fy - floor(fy), frz = fz - floor(fz);
+  auto gap = [](int d, double f) { return d > 0 ? (double)d - f : d < 0 ? f - (double)(d + 1) : 0.0; };
+  const double cell2 = g.cell * g.cell * (1.0 - 2e-6);
   for (int ring = 0; ring <= rmax_cells; ++ring) {
     if (ring >= 1) {
       const double lb = g.cell * ((double)(ring - 1) + mf) * (1.0 - 1e-6);
@@ -854,18 +861,24 @@ __device__ __forceinline__ void normal_one_lane(const P4& q, const GridDev& g, c
     for (int dz = -ring; dz <= ring; ++dz) {
       const int z = iz + dz;
       if ((unsigned)z >= (unsigned)g.nz) continue;
+      const double gz = gap(dz, frz);
+      if (gz * gz * cell2 >= (double)worst) continue;
       for (int dy = -ring; dy <= ring; ++dy) {
         const int y = iy + dy;
         if ((unsigned)y >= (unsigned)g.ny) continue;
+        const double gy = gap(dy, fry);
+        const double left = (double)worst - (gz * gz + gy * gy) * cell2;  // what the x-offset may still use
+        if (left <= 0.0) continue;
+        const double wx = sqrt(left) * g.inv_cell * (1.0 + 1e-6);         // in cells
         const int row = (z * g.ny + y) * g.nx;
         const bool shell = (dz == -ring || dz == ring || dy == -ring || dy == ring);
         if (shell || ring == 0) {
-          const int x0 = max(ix - ring, 0), x1 = min(ix + ring, g.nx - 1);
+          const int x0 = max(max(ix - ring, 0), (int)floor(fx - wx)), x1 = min(min(ix + ring, g.nx - 1), (int)floor(fx + wx));
           if (x0 <= x1) scan(cs[row + x0], cs[row + x1 + 1]);
         } else {  // interior rows: only the two end cells are new
           const int xl = ix - ring, xr = ix + ring;
-          if ((unsigned)xl < (unsigned)g.nx) scan(cs[row + xl], cs[row + xl + 1]);
-          if ((unsigned)xr < (unsigned)g.nx) scan(cs[row + xr], cs[row + xr + 1]);
+          if ((unsigned)xl < (unsigned)g.nx && gap(-ring, frx) < wx) scan(cs[row + xl], cs[row + xl + 1]);
+          if ((unsigned)xr < (unsigned)g.nx && gap(ring, frx) < wx) scan(cs[row + xr], cs[row + xr + 1]);
         }
       }
     }
@@ -917,11 +930,14 @@ __global__ __launch_bounds__(BLK) void normals_kernel(const P4* __restrict__ pts
   __shared__ R s_d[KMAX][BLK];
   __shared__ int s_p[KMAX][BLK];
   const int tid = threadIdx.x;
-  for (size_t i = (size_t)blockIdx.x * BLK + tid; i < n; i += (size_t)gridDim.x * BLK) {
-    const P4 q = pts[i];
+  // queries are taken in CELL order (sp), so the lanes of a wavefront walk the same few cells: their candidate loads hit the same
+  // cache lines and their ring loops end together; the normal goes back to the point's original slot (sp[j].i)
+  (void)pts;
+  for (size_t j = (size_t)blockIdx.x * BLK + tid; j < n; j += (size_t)gridDim.x * BLK) {
+    const P4 q = sp[j];
     double nv[3];
     normal_one_lane<P4>(q, g, sp, radius, max_nn, rmax_cells, &s_d[0][tid], &s_p[0][tid], BLK, nv);
-    finish_normal<P4>(q, nv, &out_nrm[i]);
+    finish_normal<P4>(q, nv, &out_nrm[(size_t)q.i]);
   }
 }
 
