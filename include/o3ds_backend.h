@@ -119,6 +119,16 @@ int o3ds_cloud_free(o3ds_handle h, o3ds_cloud c);
 int o3ds_cloud_size(o3ds_handle h, o3ds_cloud c, size_t* n, int* has_normals);
 /* Download into caller buffers of capacity >= n points (normals may be NULL). */
 int o3ds_cloud_download(o3ds_handle h, o3ds_cloud c, double* xyz, double* normals, size_t capacity);
+/* The way out, again without a double detour: write the cloud as n records of point_step bytes with float32 x / y / z at byte
+ * offsets off_x / off_y / off_z and, unless off_normal == O3DS_NO_FIELD, the normal as three float32 at off_normal, +4, +8; every
+ * other byte of the records is zero.  point_step 16, offsets 0 / 4 / 8 is the sensor_msgs/PointCloud2 layout that
+ * open3d_conversions::open3dToRos produces for a cloud without colours (open3d_utils/open3d_conversions/src/open3d_conversions.cpp:
+ * 19-53: `*ros_pc2_x = point(0)`, a double -> float narrowing); point_step 24, offsets 0 / 4 / 8 / 12 is the row of a binary PCD
+ * with FIELDS x y z normal_x normal_y normal_z as [O3D] io::WritePointCloudToPCD writes it for saveToFile
+ * (open3d_slam/open3d_slam/src/output.cpp:39-47).  data must hold capacity >= n records. */
+#define O3DS_NO_FIELD ((size_t)-1)
+int o3ds_cloud_download_f32(o3ds_handle h, o3ds_cloud c, void* data, size_t capacity, size_t point_step, size_t off_x, size_t off_y,
+                            size_t off_z, size_t off_normal);
 /* Build the nearest-neighbour index of a cloud (replaces [O3D] KDTreeFlann::SetGeometry(target), which
  * RegistrationICP does on every call).  cell_size <= 0 selects max_corr_hint/4.  Idempotent per cell size. */
 int o3ds_cloud_build_index(o3ds_handle h, o3ds_cloud c, double max_corr_hint, double cell_size);

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libo3ds_backend.so")
 
 OK = 0
 ERR_INVALID_ARG, ERR_NO_NORMALS, ERR_OOM, ERR_HIP, ERR_BAD_HANDLE, ERR_EMPTY, ERR_CAPACITY = -1, -2, -3, -4, -5, -6, -7
+NO_FIELD = C.c_size_t(-1).value  # O3DS_NO_FIELD
 PRECISION_F32, PRECISION_F64 = 0, 1
 ICP_POINT_TO_PLANE, ICP_GENERALIZED, ICP_POINT_TO_POINT = 0, 1, 2
 CROP_NONE, CROP_MAX_RADIUS, CROP_MIN_RADIUS, CROP_MIN_MAX_RADIUS, CROP_CYLINDER = range(5)
@@ -62,6 +63,7 @@ SIGNATURES = {
     "o3ds_cloud_free": (C.c_int, [_H, _CL]),
     "o3ds_cloud_size": (C.c_int, [_H, _CL, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "o3ds_cloud_download": (C.c_int, [_H, _CL, _dp, _dp, C.c_size_t]),
+    "o3ds_cloud_download_f32": (C.c_int, [_H, _CL, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]),
     "o3ds_cloud_build_index": (C.c_int, [_H, _CL, C.c_double, C.c_double]),
     "o3ds_icp_point_to_plane": (C.c_int, [_H, _dp, C.c_size_t, _dp, _dp, C.c_size_t, _dp, C.POINTER(IcpParams),
                                           C.POINTER(IcpResult)]),
@@ -218,6 +220,15 @@ class Backend:
         self._ck(self.lib.o3ds_cloud_download(self.h, cid, xyz.ctypes.data_as(_dp),
                                               nrm.ctypes.data_as(_dp) if hn else None, n))
         return xyz, nrm
+
+    def download_f32(self, cid: int, point_step: int = 16, off_x: int = 0, off_y: int = 4, off_z: int = 8, off_normal: int | None = None):
+        """The cloud as (n, point_step) bytes of float32 records (o3ds_cloud_download_f32): PointCloud2 'xyz' layout by default;
+        point_step 24 with off_normal 12 is the row of a binary PCD with normals."""
+        n, _ = self.size(cid)
+        buf = np.zeros((n, point_step), dtype=np.uint8)
+        self._ck(self.lib.o3ds_cloud_download_f32(self.h, cid, buf.ctypes.data_as(C.c_void_p), n, point_step, off_x, off_y, off_z,
+                                                  NO_FIELD if off_normal is None else off_normal))
+        return buf
 
     def build_index(self, cid: int, max_corr_hint: float, cell_size: float = 0.0):
         self._ck(self.lib.o3ds_cloud_build_index(self.h, cid, max_corr_hint, cell_size))

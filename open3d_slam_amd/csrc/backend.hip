@@ -922,6 +922,39 @@ int o3ds_cloud_download(o3ds_handle h, o3ds_cloud id, double* xyz, double* norma
   return c->precision == O3DS_PRECISION_F64 ? download_t<P4d>(h, *c, xyz, normals) : download_t<P4f>(h, *c, xyz, normals);
 }
 
+int o3ds_cloud_download_f32(o3ds_handle h, o3ds_cloud id, void* data, size_t capacity, size_t point_step, size_t off_x, size_t off_y,
+                            size_t off_z, size_t off_normal) {
+  CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
+  CloudRec* c = find_cloud(h, id);
+  if (!c) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_download_f32: unknown cloud id");
+  if (capacity < c->n) return fail(h, O3DS_ERR_CAPACITY, "cloud_download_f32: capacity < cloud size");
+  if (c->n > 0 && !data) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_download_f32: null buffer");
+  if (point_step < 12 || off_x + 4 > point_step || off_y + 4 > point_step || off_z + 4 > point_step)
+    return fail(h, O3DS_ERR_INVALID_ARG, "cloud_download_f32: x/y/z fields do not fit the point step");
+  if (off_normal != O3DS_NO_FIELD) {
+    if (off_normal + 12 > point_step) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_download_f32: normal fields do not fit the point step");
+    if (!c->nrm) return fail(h, O3DS_ERR_NO_NORMALS, "cloud_download_f32: normals requested but the cloud has none");
+  }
+  if (c->n == 0) return O3DS_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  unsigned char* d_raw = nullptr;
+  const size_t bytes = c->n * point_step;
+  TMP_ALLOC(d_raw, bytes);
+  HIP_TRY(hipMemsetAsync(d_raw, 0, bytes, h->stream));  // padding and the fields this path does not carry
+  const size_t on = off_normal == O3DS_NO_FIELD ? kNoField : off_normal;
+  if (c->precision == O3DS_PRECISION_F64)
+    unpack_strided_f32_kernel<P4d><<<grid_for(c->n), kBlock, 0, h->stream>>>((const P4d*)c->pts, (const P4d*)c->nrm, c->n, point_step, off_x, off_y,
+                                                                            off_z, on, d_raw);
+  else
+    unpack_strided_f32_kernel<P4f><<<grid_for(c->n), kBlock, 0, h->stream>>>((const P4f*)c->pts, (const P4f*)c->nrm, c->n, point_step, off_x, off_y,
+                                                                            off_z, on, d_raw);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(data, d_raw, bytes, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return O3DS_OK;
+}
+
 int o3ds_cloud_build_index(o3ds_handle h, o3ds_cloud id, double max_corr_hint, double cell_size) {
   CHECK_HANDLE(h);
   ArenaScope arena_scope(h);

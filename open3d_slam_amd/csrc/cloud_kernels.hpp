@@ -45,6 +45,29 @@ __global__ __launch_bounds__(kBlock) void pack_strided_f32_kernel(const unsigned
     out[i] = p;
   }
 }
+// the way back (open3d_conversions.cpp:19-53 open3dToRos, and the float32 rows of a binary PCD): record i gets float32 x / y / z
+// at byte offsets ox / oy / oz and, when `on` is a valid offset, the normal at on, on + 4, on + 8; the other bytes of the
+// (pre-zeroed) record are left alone.  double -> float is the same round-to-nearest narrowing `*ros_pc2_x = point(0)` does.
+constexpr size_t kNoField = ~(size_t)0;
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void unpack_strided_f32_kernel(const P4* __restrict__ pts, const P4* __restrict__ nrm, size_t n, size_t step,
+                                                                    size_t ox, size_t oy, size_t oz, size_t on, unsigned char* __restrict__ raw) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    unsigned char* rec = raw + i * step;
+    const P4 p = pts[i];
+    const float x = (float)p.x, y = (float)p.y, z = (float)p.z;
+    __builtin_memcpy(rec + ox, &x, 4);
+    __builtin_memcpy(rec + oy, &y, 4);
+    __builtin_memcpy(rec + oz, &z, 4);
+    if (on != kNoField && nrm) {
+      const P4 q = nrm[i];
+      const float a = (float)q.x, b = (float)q.y, c = (float)q.z;
+      __builtin_memcpy(rec + on, &a, 4);
+      __builtin_memcpy(rec + on + 4, &b, 4);
+      __builtin_memcpy(rec + on + 8, &c, 4);
+    }
+  }
+}
 template <typename P4>
 __global__ __launch_bounds__(kBlock) void unpack_kernel(const P4* __restrict__ in, size_t n, double* __restrict__ xyz) {
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {

@@ -6,10 +6,12 @@
 //   CroppingVolume family / croppingVolumeFactory      include/open3d_slam/croppers.hpp:26-47, src/croppers.cpp
 //   voxelize / voxelizeWithinCroppingVolume / transform include/open3d_slam/helpers.hpp:20-25, src/helpers.cpp:107-183,273-305
 //   ScanToMapIcp (device-resident map variant)          src/ScanToMapRegistration.cpp:35-62, src/Submap.cpp:39-75
+//   saveToFile                                          include/open3d_slam/output.hpp, src/output.cpp:39-47
 // Header-only; link with -lo3ds_backend.  One backend handle per calling thread (thread_local), because the reference
 // calls registerClouds concurrently from odometry / mapping / loop-closure threads (SlamWrapper.cpp:258-347,406-448).
 #pragma once
 #include <cmath>
+#include <cstdio>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -479,8 +481,44 @@ class DeviceSubmap {
     return n;
   }
 
+  // saveToFile (output.cpp:39-47) of the device-resident map, rows narrowed on the device
+  bool saveToFile(const std::string& filename) const;
+
  private:
   o3ds_cloud map_ = 0;
 };
+
+// ---- egress: saveToFile (src/output.cpp:39-47) -----------------------------------------------------------------------
+// The reference copies the cloud and calls [O3D] io::WritePointCloudToPCD with default options: binary, uncompressed PCD v0.7,
+// float32 x y z (+ normal_x normal_y normal_z when present; colours are not carried on this path).  The device writes those
+// rows itself (o3ds_cloud_download_f32), so a map that lives in HBM is saved without the fp64 host copy.  Returns false when the
+// file cannot be written, as WritePointCloudToPCD does.
+inline bool saveDeviceCloudToFile(const std::string& filename, o3ds_cloud cloud) {
+  const std::string name = filename.find(".pcd") == std::string::npos ? filename + ".pcd" : filename;
+  size_t n = 0;
+  int hn = 0;
+  o3ds_detail::Handle::check(o3ds_cloud_size(o3ds_detail::Handle::get(), cloud, &n, &hn));
+  const size_t step = hn ? 24 : 12;
+  std::vector<unsigned char> rows(n * step);
+  o3ds_detail::Handle::check(
+      o3ds_cloud_download_f32(o3ds_detail::Handle::get(), cloud, rows.data(), n, step, 0, 4, 8, hn ? (size_t)12 : O3DS_NO_FIELD));
+  std::FILE* f = std::fopen(name.c_str(), "wb");
+  if (!f) return false;
+  const char* fields = hn ? "x y z normal_x normal_y normal_z" : "x y z";
+  const char* fours = hn ? "4 4 4 4 4 4" : "4 4 4";
+  const char* types = hn ? "F F F F F F" : "F F F";
+  const char* ones = hn ? "1 1 1 1 1 1" : "1 1 1";
+  bool ok = std::fprintf(f,
+                         "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS %s\nSIZE %s\nTYPE %s\nCOUNT %s\nWIDTH %zu\nHEIGHT 1\n"
+                         "VIEWPOINT 0 0 0 1 0 0 0\nPOINTS %zu\nDATA binary\n",
+                         fields, fours, types, ones, n, n) > 0;
+  ok = ok && std::fwrite(rows.data(), 1, rows.size(), f) == rows.size();
+  return std::fclose(f) == 0 && ok;
+}
+inline bool saveToFile(const std::string& filename, const PointCloud& cloud) {
+  o3ds_detail::DevCloud d(cloud);
+  return saveDeviceCloudToFile(filename, d.id());
+}
+inline bool DeviceSubmap::saveToFile(const std::string& filename) const { return saveDeviceCloudToFile(filename, map_); }
 
 }  // namespace o3d_slam

@@ -37,6 +37,10 @@ class Mapper:
     def getActiveSubmap(self) -> Submap:
         return self.submap_
 
+    def getAssembledMapPointCloud(self) -> PointCloud:  # Mapper.cpp:183-208 (this harness holds one submap)
+        from .output import assembleMapPointCloud
+        return assembleMapPointCloud(self.be, [self.submap_])
+
     def getMapToRangeSensor(self) -> np.ndarray:
         return self.mapToRangeSensor_
 

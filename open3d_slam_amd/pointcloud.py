@@ -20,6 +20,11 @@ class PointCloud:
         to the device as they are (o3ds_cloud_upload_f32)."""
         return cls(be, be.upload_f32(records, off_x, off_y, off_z))
 
+    def to_pointcloud2(self) -> np.ndarray:
+        """open3d_conversions::open3dToRos for a cloud without colours (open3d_conversions.cpp:19-53): the `data` member of the
+        message, (n, 16) bytes = float32 x, y, z + 4 bytes of padding per point, narrowed on the device."""
+        return self.be.download_f32(self.id, 16, 0, 4, 8, None)
+
     def __len__(self) -> int:
         return self.be.size(self.id)[0]
 

@@ -7,6 +7,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <random>
+#include <string>
+#include <vector>
 
 #include "../../open3d_slam_amd/host/o3ds_adapter.hpp"
 
@@ -169,6 +171,28 @@ static void gpuChecks() {
   CHECK(r2.fitness_ > 0.99 && std::fabs(r2.transformation_[12] - 0.03) < 2e-3);
   DeviceSubmap emptyMap;
   CHECK(throws([&] { emptyMap.scanToMapRegistration(source, &matchCrop, Transform::Identity(), Transform::Identity(), *p2p); }));
+  // saveToFile: header + float32 rows; the suffix rule of output.cpp:41-45
+  {
+    const char* dir = std::getenv("O3DS_TEST_TMPDIR");
+    const std::string base = std::string(dir ? dir : "/tmp") + "/adapter_map";
+    CHECK(saveToFile(base, flat));
+    CHECK(sub.saveToFile(base + "_sub.pcd"));
+    std::FILE* f = std::fopen((base + ".pcd").c_str(), "rb");
+    CHECK(f != nullptr);
+    std::vector<char> blob(1 << 20);
+    const size_t got = std::fread(blob.data(), 1, blob.size(), f);
+    std::fclose(f);
+    const std::string text(blob.data(), got);
+    const size_t at = text.find("DATA binary\n");
+    CHECK(at != std::string::npos && text.find("FIELDS x y z normal_x normal_y normal_z\n") != std::string::npos);
+    CHECK(text.find("POINTS " + std::to_string(flat.points_.size()) + "\n") != std::string::npos);
+    CHECK(got == at + 12 + flat.points_.size() * 24);
+    float row[6];
+    std::memcpy(row, blob.data() + at + 12 + 7 * 24, sizeof(row));
+    CHECK(row[0] == (float)flat.points_[7][0] && row[1] == (float)flat.points_[7][1] && row[2] == (float)flat.points_[7][2]);
+    CHECK(row[3] == (float)flat.normals_[7][0] && row[5] == (float)flat.normals_[7][2]);
+    CHECK(!saveToFile("/no/such/directory/x", flat));
+  }
   std::puts("gpu checks ok");
 }
 

@@ -27,7 +27,7 @@ def test_adapter_compiles_and_device_free_checks(adapter_exe):
 
 
 @pytest.mark.gpu
-def test_adapter_on_gpu(adapter_exe):
-    out = subprocess.run([adapter_exe], capture_output=True, text=True, timeout=300)
+def test_adapter_on_gpu(adapter_exe, tmp_path):
+    out = subprocess.run([adapter_exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, O3DS_TEST_TMPDIR=str(tmp_path)))
     assert out.returncode == 0, out.stdout + out.stderr
     assert "gpu checks ok" in out.stdout

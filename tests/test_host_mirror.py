@@ -127,3 +127,49 @@ def test_split_exact_makes_f64_sums_order_independent():
     # plain f64 summation of the same values is NOT order-independent (the reason for the split)
     plain = {float(np.add.reduce(v[rng.permutation(n)])) for _ in range(20)}
     assert len(plain) > 1
+
+
+def test_pcd_writer_header_and_round_trip(tmp_path):
+    """saveToFile (output.cpp:39-47) on the host side alone: a stand-in backend that packs the rows with numpy (the statement of
+    what o3ds_cloud_download_f32 must produce) -> header known answer, '.pcd' suffix rule, readPcd round trip."""
+    import numpy as np
+    from open3d_slam_amd import output
+
+    rng = np.random.default_rng(5)
+    pts, nrm = rng.normal(size=(37, 3)) * 20, rng.normal(size=(37, 3))
+
+    class _Be:
+        def __init__(self, normals):
+            self.normals = normals
+
+        def size(self, cid):
+            return len(pts), self.normals is not None
+
+        def download_f32(self, cid, step, ox, oy, oz, on):
+            rows = np.zeros((len(pts), step), np.uint8)
+            for col, off in enumerate((ox, oy, oz)):
+                rows[:, off:off + 4] = pts[:, col].astype("<f4").reshape(-1, 1).view(np.uint8)
+            if on is not None:
+                for col in range(3):
+                    rows[:, on + 4 * col:on + 4 * col + 4] = self.normals[:, col].astype("<f4").reshape(-1, 1).view(np.uint8)
+            return rows
+
+    class _Cloud:
+        def __init__(self, be):
+            self.be, self.id = be, 1
+
+        def HasNormals(self):
+            return self.be.normals is not None
+
+    assert output._pcd_header(5, False) == (b"# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\n"
+                                            b"COUNT 1 1 1\nWIDTH 5\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS 5\nDATA binary\n")
+    assert output.saveToFile(str(tmp_path / "a"), _Cloud(_Be(nrm)))
+    p, q = output.readPcd(str(tmp_path / "a.pcd"))
+    np.testing.assert_array_equal(p, pts.astype(np.float32))
+    np.testing.assert_array_equal(q, nrm.astype(np.float32))
+    assert (tmp_path / "a.pcd").stat().st_size == len(output._pcd_header(37, True)) + 37 * 24
+    assert output.saveToFile(str(tmp_path / "b.pcd"), _Cloud(_Be(None)))
+    p, q = output.readPcd(str(tmp_path / "b.pcd"))
+    assert q is None and (tmp_path / "b.pcd").stat().st_size == len(output._pcd_header(37, False)) + 37 * 12
+    np.testing.assert_array_equal(p, pts.astype(np.float32))
+    assert not output.saveToFile(str(tmp_path / "no_such_dir" / "c"), _Cloud(_Be(None)))  # false, not an exception (WritePointCloudToPCD)

@@ -697,3 +697,89 @@ def test_dense_map_survives_many_carve_insert_cycles(backend_f64):
     assert backend_f64.size(out)[0] == live_expected
     backend_f64.free(out)
     backend_f64.dense_map_free(dm)
+
+
+@pytest.mark.gpu
+def test_f32_egress_records_pcd_and_assembled_map(backend_f32, backend_f64, scan, tmp_path):
+    """o3ds_cloud_download_f32 (the way out): float32 records in the PointCloud2 layout of
+    open3d_conversions::open3dToRos (open3d_conversions.cpp:19-53) and in the row layout of the binary PCD that saveToFile
+    (output.cpp:39-47) writes; bit-exact against the numpy narrowing of what the double route downloads.  Then saveToFile /
+    readPcd and Mapper::getAssembledMapPointCloud (Mapper.cpp:183-208) on device clouds."""
+    from open3d_slam_amd import output
+    from open3d_slam_amd.pointcloud import PointCloud
+
+    n = 4097
+    pts = scan[:n]
+    for be in (backend_f32, backend_f64):
+        c = be.upload(pts)
+        v = be.voxel_down_sample(c, 0.3)
+        be.estimate_normals(v, 2.0, 20)
+        xyz, nrm = be.download(v)
+        m = len(xyz)
+        # PointCloud2 'xyz': 16-byte step, 4 bytes of zero padding
+        pc2 = be.download_f32(v)
+        assert pc2.shape == (m, 16) and pc2.dtype == np.uint8
+        np.testing.assert_array_equal(pc2[:, :12].copy().view(np.float32).reshape(m, 3), xyz.astype(np.float32))
+        assert not pc2[:, 12:].any()
+        # an arbitrary layout with normals and unused bytes in between
+        rec = be.download_f32(v, 40, 20, 4, 12, 24)
+        f = rec.copy().view(np.float32).reshape(m, 10)
+        np.testing.assert_array_equal(f[:, [5, 1, 3]], xyz.astype(np.float32))
+        np.testing.assert_array_equal(f[:, 6:9], nrm.astype(np.float32))
+        assert not f[:, [0, 2, 4, 9]].any()
+        # the round trip through the f32 ingest is the identity on the f32 values
+        back = be.upload_f32(pc2)
+        np.testing.assert_array_equal(be.download(back)[0].astype(np.float32), xyz.astype(np.float32))
+        be.free(back)
+        # PCD file
+        cloud = PointCloud(be, v, owns=False)
+        assert output.saveToFile(str(tmp_path / "map"), cloud)             # '.pcd' appended
+        assert output.saveToFile(str(tmp_path / "map2.pcd"), cloud)        # kept
+        for name in ("map.pcd", "map2.pcd"):
+            p, q = output.readPcd(str(tmp_path / name))
+            np.testing.assert_array_equal(p, xyz.astype(np.float32))
+            np.testing.assert_array_equal(q, nrm.astype(np.float32))
+        head = open(tmp_path / "map.pcd", "rb").read(400).split(b"DATA binary\n")[0].decode()
+        assert head.splitlines()[:3] == ["# .PCD v0.7 - Point Cloud Data file format", "VERSION 0.7", "FIELDS x y z normal_x normal_y normal_z"]
+        assert f"WIDTH {m}" in head and "HEIGHT 1" in head and f"POINTS {m}" in head
+        bare = PointCloud(be, c, owns=False)                                # no normals: x y z rows only
+        assert output.saveToFile(str(tmp_path / "raw.pcd"), bare)
+        p, q = output.readPcd(str(tmp_path / "raw.pcd"))
+        assert q is None
+        np.testing.assert_array_equal(p, pts.astype(np.float32))
+        # error behaviour
+        with pytest.raises(backend.BackendError) as ei:
+            be.download_f32(c, 24, 0, 4, 8, 12)                             # normals requested, cloud has none
+        assert ei.value.code == -2
+        with pytest.raises(backend.BackendError):
+            be.download_f32(v, 20, 0, 4, 8, 12)                             # normal fields do not fit the step
+        with pytest.raises(backend.BackendError):
+            be.download_f32(v, 8)                                           # x/y/z do not fit
+
+        # assembled map of two submaps = their clouds, concatenated in order; display voxelisation = plain voxel_down_sample
+        class _Sub:  # the one member of Submap the assembly touches
+            def __init__(self, cloud):
+                self._c = cloud
+
+            def getMapPointCloud(self):
+                return self._c
+
+        c2 = be.upload(scan[n:2 * n])
+        v2 = be.voxel_down_sample(c2, 0.3)
+        be.estimate_normals(v2, 2.0, 20)
+        xyz2, nrm2 = be.download(v2)
+        whole = output.assembleMapPointCloud(be, [_Sub(PointCloud(be, v, owns=False)), _Sub(PointCloud(be, v2, owns=False))])
+        wp, wn = be.download(whole.id)
+        np.testing.assert_array_equal(wp, np.vstack([xyz, xyz2]))
+        np.testing.assert_array_equal(wn, np.vstack([nrm, nrm2]))
+        np.testing.assert_array_equal(be.download(v)[0], xyz)               # the submaps themselves are untouched
+        shown = output.voxelize(be, 0.5, whole)
+        ref = be.voxel_down_sample(whole.id, 0.5)
+        np.testing.assert_array_equal(be.download(shown.id)[0], be.download(ref)[0])
+        assert output.voxelize(be, 0.0, whole) is whole
+        empty = output.assembleMapPointCloud(be, [])
+        assert len(empty) == 0 and be.download_f32(empty.id).shape == (0, 16)
+        for x in (shown, whole, empty):
+            x.release()
+        for x in (ref, c, v, c2, v2):
+            be.free(x)
