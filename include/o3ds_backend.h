@@ -120,15 +120,35 @@ int o3ds_cloud_size(o3ds_handle h, o3ds_cloud c, size_t* n, int* has_normals);
 /* Download into caller buffers of capacity >= n points (normals may be NULL). */
 int o3ds_cloud_download(o3ds_handle h, o3ds_cloud c, double* xyz, double* normals, size_t capacity);
 /* The way out, again without a double detour: write the cloud as n records of point_step bytes with float32 x / y / z at byte
- * offsets off_x / off_y / off_z and, unless off_normal == O3DS_NO_FIELD, the normal as three float32 at off_normal, +4, +8; every
- * other byte of the records is zero.  point_step 16, offsets 0 / 4 / 8 is the sensor_msgs/PointCloud2 layout that
- * open3d_conversions::open3dToRos produces for a cloud without colours (open3d_utils/open3d_conversions/src/open3d_conversions.cpp:
- * 19-53: `*ros_pc2_x = point(0)`, a double -> float narrowing); point_step 24, offsets 0 / 4 / 8 / 12 is the row of a binary PCD
- * with FIELDS x y z normal_x normal_y normal_z as [O3D] io::WritePointCloudToPCD writes it for saveToFile
- * (open3d_slam/open3d_slam/src/output.cpp:39-47).  data must hold capacity >= n records. */
+ * offsets off_x / off_y / off_z; unless off_normal == O3DS_NO_FIELD, the normal as three float32 at off_normal, +4, +8; unless
+ * off_rgb == O3DS_NO_FIELD, the colour as the packed `rgb` field (bytes b, g, r, 0 at off_rgb, +1, +2, +3); every other byte of the
+ * records is zero.  point_step 16, offsets 0 / 4 / 8 is the sensor_msgs/PointCloud2 layout that open3d_conversions::open3dToRos
+ * produces for a cloud without colours, point_step 32 with rgb at 16 the one for a coloured cloud
+ * (open3d_utils/open3d_conversions/src/open3d_conversions.cpp:19-53: `*ros_pc2_x = point(0)`, a double -> float narrowing, and
+ * `*ros_pc2_r = (int)(255 * color(0))` = rgb_rounding 0); point_step 24, offsets 0 / 4 / 8 / 12 is the row of a binary PCD with FIELDS
+ * x y z normal_x normal_y normal_z as [O3D] io::WritePointCloudToPCD writes it for saveToFile
+ * (open3d_slam/open3d_slam/src/output.cpp:39-47), whose rgb field uses [O3D] utility::ColorToUint8 (clamp, scale, round = rgb_rounding
+ * 1).  data must hold capacity >= n records. */
 #define O3DS_NO_FIELD ((size_t)-1)
 int o3ds_cloud_download_f32(o3ds_handle h, o3ds_cloud c, void* data, size_t capacity, size_t point_step, size_t off_x, size_t off_y,
-                            size_t off_z, size_t off_normal);
+                            size_t off_z, size_t off_normal, size_t off_rgb, int rgb_rounding);
+/* Colours of an ingested cloud, read from the same PointCloud2 records as rosToOpen3d does when skip_colors is false -- which is how
+ * every caller in the reference invokes it (OnlineRangeDataProcessorRos.cpp:40, RosbagRangeDataProcessorRos.cpp:129,
+ * SlamMapInitializer.cpp:124): O3DS_COLOR_FIELD_RGB = a fourth field named "rgb" at byte offset off_field (r, g, b = bytes +2, +1, +0,
+ * each / 255.0; open3d_conversions.cpp:71-80); O3DS_COLOR_FIELD_INTENSITY = a fourth field named "intensity", which the reference reads
+ * through a uint8 iterator: the FIRST byte of the field, unscaled, for all three channels (open3d_conversions.cpp:81-86).  The cloud
+ * must have been made from the same n records (o3ds_cloud_upload_f32). */
+enum { O3DS_COLOR_FIELD_RGB = 0, O3DS_COLOR_FIELD_INTENSITY = 1 };
+int o3ds_cloud_set_colors_from_records(o3ds_handle h, o3ds_cloud c, const void* data, size_t point_step, size_t off_field, int kind);
+/* PointCloud::colors_ (3n doubles in [0, 1]) of a device cloud.  Registration never reads them; the cloud operations carry them
+ * the way the reference does: crop / select / carve keep the colours of the kept points, transform copies them, append follows
+ * [O3D] PointCloud::operator+= (kept only if the map is empty or coloured AND the added cloud is coloured), o3ds_voxel_down_sample
+ * averages them ([O3D] VoxelDownSample), and the map merge o3ds_voxelize_within_volume / o3ds_map_insert_scan gives a voxel the
+ * colour of its LAST point in cloud order (AccumulatedPoint::AddPoint assigns, helpers.cpp:40-42,61-63; isValidColor,
+ * helpers.cpp:83-85, holds for every value).  rgb == NULL clears.  get_colors returns O3DS_ERR_EMPTY for an uncoloured cloud. */
+int o3ds_cloud_set_colors(o3ds_handle h, o3ds_cloud c, const double* rgb);
+int o3ds_cloud_has_colors(o3ds_handle h, o3ds_cloud c, int* has_colors);
+int o3ds_cloud_get_colors(o3ds_handle h, o3ds_cloud c, double* rgb, size_t capacity);
 /* Build the nearest-neighbour index of a cloud (replaces [O3D] KDTreeFlann::SetGeometry(target), which
  * RegistrationICP does on every call).  cell_size <= 0 selects max_corr_hint/4.  Idempotent per cell size. */
 int o3ds_cloud_build_index(o3ds_handle h, o3ds_cloud c, double max_corr_hint, double cell_size);

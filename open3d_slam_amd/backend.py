@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libo3ds_backend.so")
 OK = 0
 ERR_INVALID_ARG, ERR_NO_NORMALS, ERR_OOM, ERR_HIP, ERR_BAD_HANDLE, ERR_EMPTY, ERR_CAPACITY = -1, -2, -3, -4, -5, -6, -7
 NO_FIELD = C.c_size_t(-1).value  # O3DS_NO_FIELD
+COLOR_FIELD_RGB, COLOR_FIELD_INTENSITY = 0, 1
 PRECISION_F32, PRECISION_F64 = 0, 1
 ICP_POINT_TO_PLANE, ICP_GENERALIZED, ICP_POINT_TO_POINT = 0, 1, 2
 CROP_NONE, CROP_MAX_RADIUS, CROP_MIN_RADIUS, CROP_MIN_MAX_RADIUS, CROP_CYLINDER = range(5)
@@ -63,7 +64,12 @@ SIGNATURES = {
     "o3ds_cloud_free": (C.c_int, [_H, _CL]),
     "o3ds_cloud_size": (C.c_int, [_H, _CL, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "o3ds_cloud_download": (C.c_int, [_H, _CL, _dp, _dp, C.c_size_t]),
-    "o3ds_cloud_download_f32": (C.c_int, [_H, _CL, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]),
+    "o3ds_cloud_set_colors": (C.c_int, [_H, _CL, _dp]),
+    "o3ds_cloud_has_colors": (C.c_int, [_H, _CL, C.POINTER(C.c_int)]),
+    "o3ds_cloud_get_colors": (C.c_int, [_H, _CL, _dp, C.c_size_t]),
+    "o3ds_cloud_download_f32": (C.c_int, [_H, _CL, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,
+                                          C.c_size_t, C.c_int]),
+    "o3ds_cloud_set_colors_from_records": (C.c_int, [_H, _CL, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]),
     "o3ds_cloud_build_index": (C.c_int, [_H, _CL, C.c_double, C.c_double]),
     "o3ds_icp_point_to_plane": (C.c_int, [_H, _dp, C.c_size_t, _dp, _dp, C.c_size_t, _dp, C.POINTER(IcpParams),
                                           C.POINTER(IcpResult)]),
@@ -221,14 +227,51 @@ class Backend:
                                               nrm.ctypes.data_as(_dp) if hn else None, n))
         return xyz, nrm
 
-    def download_f32(self, cid: int, point_step: int = 16, off_x: int = 0, off_y: int = 4, off_z: int = 8, off_normal: int | None = None):
-        """The cloud as (n, point_step) bytes of float32 records (o3ds_cloud_download_f32): PointCloud2 'xyz' layout by default;
-        point_step 24 with off_normal 12 is the row of a binary PCD with normals."""
+    def download_f32(self, cid: int, point_step: int = 16, off_x: int = 0, off_y: int = 4, off_z: int = 8, off_normal: int | None = None,
+                     off_rgb: int | None = None, rgb_rounding: int = 0):
+        """The cloud as (n, point_step) bytes of float32 records (o3ds_cloud_download_f32): PointCloud2 'xyz' layout by default
+        (point_step 32 with off_rgb 16 for a coloured cloud); point_step 24 with off_normal 12 is the row of a binary PCD with
+        normals.  rgb_rounding 0 = (int)(255 c) as open3dToRos, 1 = clamp / round as [O3D] ColorToUint8 (PCD)."""
         n, _ = self.size(cid)
         buf = np.zeros((n, point_step), dtype=np.uint8)
         self._ck(self.lib.o3ds_cloud_download_f32(self.h, cid, buf.ctypes.data_as(C.c_void_p), n, point_step, off_x, off_y, off_z,
-                                                  NO_FIELD if off_normal is None else off_normal))
+                                                  NO_FIELD if off_normal is None else off_normal, NO_FIELD if off_rgb is None else off_rgb,
+                                                  rgb_rounding))
         return buf
+
+    def set_colors_from_records(self, cid: int, records, off_field: int, kind: int):
+        """colours from the PointCloud2 records the cloud was uploaded from (rosToOpen3d with skip_colors = false):
+        kind COLOR_FIELD_RGB or COLOR_FIELD_INTENSITY, the field at byte offset off_field"""
+        a = np.ascontiguousarray(records)
+        n, _ = self.size(cid)
+        if a.shape[0] != n:
+            raise ValueError("set_colors_from_records: one record per point")
+        step = a.strides[0] if n else 16
+        self._ck(self.lib.o3ds_cloud_set_colors_from_records(self.h, cid, a.ctypes.data_as(C.c_void_p), step, off_field, kind))
+
+    def set_colors(self, cid: int, rgb):
+        """PointCloud::colors_ of a device cloud ((n, 3) doubles; None clears)."""
+        if rgb is None:
+            self._ck(self.lib.o3ds_cloud_set_colors(self.h, cid, None))
+            return
+        n, _ = self.size(cid)
+        a, ap = _d(np.asarray(rgb).reshape(-1, 3))
+        if len(a) != n:
+            raise ValueError("set_colors: one colour per point")
+        self._ck(self.lib.o3ds_cloud_set_colors(self.h, cid, ap))
+
+    def has_colors(self, cid: int) -> bool:
+        hc = C.c_int()
+        self._ck(self.lib.o3ds_cloud_has_colors(self.h, cid, C.byref(hc)))
+        return bool(hc.value)
+
+    def get_colors(self, cid: int):
+        if not self.has_colors(cid):
+            return None
+        n, _ = self.size(cid)
+        rgb = np.empty((n, 3))
+        self._ck(self.lib.o3ds_cloud_get_colors(self.h, cid, rgb.ctypes.data_as(_dp), n))
+        return rgb
 
     def build_index(self, cid: int, max_corr_hint: float, cell_size: float = 0.0):
         self._ck(self.lib.o3ds_cloud_build_index(self.h, cid, max_corr_hint, cell_size))

@@ -29,6 +29,7 @@ struct CloudRec {
   int precision = 0;
   void* pts = nullptr;  // P4[n]
   void* nrm = nullptr;  // P4[n] or null
+  void* col = nullptr;  // P4[n] or null: PointCloud::colors_ (carried by the cloud operations, never read by registration)
   // nearest-neighbour index
   bool has_index = false;
   GridDev grid{};
@@ -48,6 +49,7 @@ struct DenseRec {
   size_t cap = 0;          // power of two
   o3ds::DenseDev dev{};
   bool has_normals = false;
+  bool has_colors = false;
   size_t used_upper = 0;   // upper bound on the OCCUPIED slots = live voxels + tombstones (exact count fetched only when the table
                            // looks too full); the load factor of the open-addressing table is about these, not about live voxels
 };
@@ -215,7 +217,8 @@ void free_cloud(o3ds_handle h, CloudRec& c) {
   free_index(h, c);
   if (c.pts) (void)hipFreeAsync(c.pts, h->stream);
   if (c.nrm) (void)hipFreeAsync(c.nrm, h->stream);
-  c.pts = c.nrm = nullptr;
+  if (c.col) (void)hipFreeAsync(c.col, h->stream);
+  c.pts = c.nrm = c.col = nullptr;
   c.n = 0;
 }
 
@@ -376,6 +379,7 @@ void dense_release(o3ds_handle h, DenseRec& d) {
   if (d.dev.cnt) (void)hipFreeAsync(d.dev.cnt, h->stream);
   if (d.dev.sp) (void)hipFreeAsync(d.dev.sp, h->stream);
   if (d.dev.sn) (void)hipFreeAsync(d.dev.sn, h->stream);
+  if (d.dev.sc) (void)hipFreeAsync(d.dev.sc, h->stream);
   d.dev = o3ds::DenseDev{};
   d.cap = 0;
 }
@@ -386,10 +390,12 @@ int dense_alloc(o3ds_handle h, size_t cap, o3ds::DenseDev* out) {
   HIP_TRY(hipMallocAsync((void**)&d.cnt, sizeof(int) * cap, h->stream));
   HIP_TRY(hipMallocAsync((void**)&d.sp, sizeof(long long) * 3 * cap, h->stream));
   HIP_TRY(hipMallocAsync((void**)&d.sn, sizeof(long long) * 3 * cap, h->stream));
+  HIP_TRY(hipMallocAsync((void**)&d.sc, sizeof(long long) * 3 * cap, h->stream));
   HIP_TRY(hipMemsetAsync(d.keys, 0xFF, sizeof(unsigned long long) * cap, h->stream));
   HIP_TRY(hipMemsetAsync(d.cnt, 0, sizeof(int) * cap, h->stream));
   HIP_TRY(hipMemsetAsync(d.sp, 0, sizeof(long long) * 3 * cap, h->stream));
   HIP_TRY(hipMemsetAsync(d.sn, 0, sizeof(long long) * 3 * cap, h->stream));
+  HIP_TRY(hipMemsetAsync(d.sc, 0, sizeof(long long) * 3 * cap, h->stream));
   d.mask = (unsigned int)(cap - 1);
   *out = d;
   return O3DS_OK;
@@ -465,9 +471,10 @@ int dense_insert_t(o3ds_handle h, DenseRec& d, const CloudRec& c, const double T
   Mat34 M;
   for (int r = 0; r < 3; ++r)
     for (int col = 0; col < 4; ++col) M.m[r * 4 + col] = T ? T[col * 4 + r] : (r == col ? 1.0 : 0.0);
-  dense_insert_kernel<P4><<<grid_for(c.n), kBlock, 0, h->stream>>>((const P4*)c.pts, (const P4*)c.nrm, c.n, M, 1.0 / d.voxel, d.dev);
+  dense_insert_kernel<P4><<<grid_for(c.n), kBlock, 0, h->stream>>>((const P4*)c.pts, (const P4*)c.nrm, (const P4*)c.col, c.n, M, 1.0 / d.voxel, d.dev);
   HIP_TRY(hipGetLastError());
   if (c.nrm) d.has_normals = true;  // isHasNormals_, Voxel.cpp:80-83
+  if (c.col) d.has_colors = true;   // isHasColors_, Voxel.cpp:84-87
   return O3DS_OK;
 }
 
@@ -494,7 +501,8 @@ int dense_to_cloud_t(o3ds_handle h, DenseRec& d, CloudRec& out) {
   out.n = used;
   HIP_TRY(hipMallocAsync(&out.pts, sizeof(P4) * used, h->stream));
   if (d.has_normals) HIP_TRY(hipMallocAsync(&out.nrm, sizeof(P4) * used, h->stream));
-  dense_emit_kernel<P4><<<grid_for(used), kBlock, 0, h->stream>>>(d.dev, s1, used, (P4*)out.pts, (P4*)out.nrm);
+  if (d.has_colors) HIP_TRY(hipMallocAsync(&out.col, sizeof(P4) * used, h->stream));
+  dense_emit_kernel<P4><<<grid_for(used), kBlock, 0, h->stream>>>(d.dev, s1, used, (P4*)out.pts, (P4*)out.nrm, (P4*)out.col);
   HIP_TRY(hipGetLastError());
   return O3DS_OK;
 }
@@ -923,7 +931,7 @@ int o3ds_cloud_download(o3ds_handle h, o3ds_cloud id, double* xyz, double* norma
 }
 
 int o3ds_cloud_download_f32(o3ds_handle h, o3ds_cloud id, void* data, size_t capacity, size_t point_step, size_t off_x, size_t off_y,
-                            size_t off_z, size_t off_normal) {
+                            size_t off_z, size_t off_normal, size_t off_rgb, int rgb_rounding) {
   CHECK_HANDLE(h);
   ArenaScope arena_scope(h);
   CloudRec* c = find_cloud(h, id);
@@ -936,6 +944,11 @@ int o3ds_cloud_download_f32(o3ds_handle h, o3ds_cloud id, void* data, size_t cap
     if (off_normal + 12 > point_step) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_download_f32: normal fields do not fit the point step");
     if (!c->nrm) return fail(h, O3DS_ERR_NO_NORMALS, "cloud_download_f32: normals requested but the cloud has none");
   }
+  if (off_rgb != O3DS_NO_FIELD) {
+    if (off_rgb + 4 > point_step) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_download_f32: rgb field does not fit the point step");
+    if (!c->col) return fail(h, O3DS_ERR_EMPTY, "cloud_download_f32: rgb requested but the cloud has no colours");
+    if (rgb_rounding != 0 && rgb_rounding != 1) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_download_f32: rgb_rounding must be 0 or 1");
+  }
   if (c->n == 0) return O3DS_OK;
   HIP_TRY(hipSetDevice(h->device));
   unsigned char* d_raw = nullptr;
@@ -943,14 +956,90 @@ int o3ds_cloud_download_f32(o3ds_handle h, o3ds_cloud id, void* data, size_t cap
   TMP_ALLOC(d_raw, bytes);
   HIP_TRY(hipMemsetAsync(d_raw, 0, bytes, h->stream));  // padding and the fields this path does not carry
   const size_t on = off_normal == O3DS_NO_FIELD ? kNoField : off_normal;
+  const size_t oc = off_rgb == O3DS_NO_FIELD ? kNoField : off_rgb;
   if (c->precision == O3DS_PRECISION_F64)
-    unpack_strided_f32_kernel<P4d><<<grid_for(c->n), kBlock, 0, h->stream>>>((const P4d*)c->pts, (const P4d*)c->nrm, c->n, point_step, off_x, off_y,
-                                                                            off_z, on, d_raw);
+    unpack_strided_f32_kernel<P4d><<<grid_for(c->n), kBlock, 0, h->stream>>>((const P4d*)c->pts, (const P4d*)c->nrm, (const P4d*)c->col, c->n,
+                                                                            point_step, off_x, off_y, off_z, on, oc, rgb_rounding, d_raw);
   else
-    unpack_strided_f32_kernel<P4f><<<grid_for(c->n), kBlock, 0, h->stream>>>((const P4f*)c->pts, (const P4f*)c->nrm, c->n, point_step, off_x, off_y,
-                                                                            off_z, on, d_raw);
+    unpack_strided_f32_kernel<P4f><<<grid_for(c->n), kBlock, 0, h->stream>>>((const P4f*)c->pts, (const P4f*)c->nrm, (const P4f*)c->col, c->n,
+                                                                            point_step, off_x, off_y, off_z, on, oc, rgb_rounding, d_raw);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(data, d_raw, bytes, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return O3DS_OK;
+}
+
+int o3ds_cloud_set_colors_from_records(o3ds_handle h, o3ds_cloud id, const void* data, size_t point_step, size_t off_field, int kind) {
+  CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
+  CloudRec* c = find_cloud(h, id);
+  if (!c) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_set_colors_from_records: unknown cloud id");
+  if (kind != O3DS_COLOR_FIELD_RGB && kind != O3DS_COLOR_FIELD_INTENSITY)
+    return fail(h, O3DS_ERR_INVALID_ARG, "cloud_set_colors_from_records: unknown field kind");
+  if (off_field + 4 > point_step) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_set_colors_from_records: the field does not fit the point step");
+  if (c->n > 0 && !data) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_set_colors_from_records: null buffer");
+  HIP_TRY(hipSetDevice(h->device));
+  if (c->col) HIP_TRY(hipFreeAsync(c->col, h->stream));
+  c->col = nullptr;
+  if (c->n == 0) return O3DS_OK;
+  unsigned char* d_raw = nullptr;
+  TMP_ALLOC(d_raw, c->n * point_step);
+  HIP_TRY(hipMemcpyAsync(d_raw, data, c->n * point_step, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMallocAsync(&c->col, p4_size(c->precision) * c->n, h->stream));
+  if (c->precision == O3DS_PRECISION_F64)
+    colors_from_records_kernel<P4d><<<grid_for(c->n), kBlock, 0, h->stream>>>(d_raw, c->n, point_step, off_field, kind, (P4d*)c->col);
+  else
+    colors_from_records_kernel<P4f><<<grid_for(c->n), kBlock, 0, h->stream>>>(d_raw, c->n, point_step, off_field, kind, (P4f*)c->col);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));  // `data` may be reused by the caller
+  return O3DS_OK;
+}
+
+int o3ds_cloud_set_colors(o3ds_handle h, o3ds_cloud id, const double* rgb) {
+  CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
+  CloudRec* c = find_cloud(h, id);
+  if (!c) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_set_colors: unknown cloud id");
+  HIP_TRY(hipSetDevice(h->device));
+  if (c->col) HIP_TRY(hipFreeAsync(c->col, h->stream));
+  c->col = nullptr;
+  if (!rgb || c->n == 0) return O3DS_OK;  // colors_.clear()
+  double* stage = nullptr;
+  TMP_ALLOC(stage, sizeof(double) * 3 * c->n);
+  HIP_TRY(hipMemcpyAsync(stage, rgb, sizeof(double) * 3 * c->n, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMallocAsync(&c->col, p4_size(c->precision) * c->n, h->stream));
+  if (c->precision == O3DS_PRECISION_F64)
+    pack_kernel<P4d><<<grid_for(c->n), kBlock, 0, h->stream>>>(stage, c->n, (P4d*)c->col);
+  else
+    pack_kernel<P4f><<<grid_for(c->n), kBlock, 0, h->stream>>>(stage, c->n, (P4f*)c->col);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));  // rgb may be released by the caller
+  return O3DS_OK;
+}
+
+int o3ds_cloud_has_colors(o3ds_handle h, o3ds_cloud id, int* has_colors) {
+  CHECK_HANDLE(h);
+  CloudRec* c = find_cloud(h, id);
+  if (!c || !has_colors) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_has_colors: bad argument");
+  *has_colors = c->col != nullptr;
+  return O3DS_OK;
+}
+
+int o3ds_cloud_get_colors(o3ds_handle h, o3ds_cloud id, double* rgb, size_t capacity) {
+  CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
+  CloudRec* c = find_cloud(h, id);
+  if (!c || !rgb) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_get_colors: bad argument");
+  if (!c->col) return fail(h, O3DS_ERR_EMPTY, "cloud_get_colors: the cloud has no colours");
+  if (capacity < c->n) return fail(h, O3DS_ERR_CAPACITY, "cloud_get_colors: capacity < cloud size");
+  double* stage = nullptr;
+  TMP_ALLOC(stage, sizeof(double) * 3 * c->n);
+  if (c->precision == O3DS_PRECISION_F64)
+    unpack_kernel<P4d><<<grid_for(c->n), kBlock, 0, h->stream>>>((const P4d*)c->col, c->n, stage);
+  else
+    unpack_kernel<P4f><<<grid_for(c->n), kBlock, 0, h->stream>>>((const P4f*)c->col, c->n, stage);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(rgb, stage, sizeof(double) * 3 * c->n, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return O3DS_OK;
 }
@@ -1391,6 +1480,10 @@ int crop_t(o3ds_handle h, const CloudRec& in, const CropDev& crop, CloudRec& out
     if (in.nrm) HIP_TRY(hipMallocAsync((void**)&out.nrm, sizeof(P4) * out.n, h->stream));
     compact_kernel<P4><<<grid_for(in.n), kBlock, 0, h->stream>>>((const P4*)in.pts, (const P4*)in.nrm, in.n, flags, pos, 1, (P4*)out.pts,
                                                                (P4*)out.nrm);
+    if (in.col) {  // colours ride along as a second attribute array through the same kernel
+      HIP_TRY(hipMallocAsync((void**)&out.col, sizeof(P4) * out.n, h->stream));
+      compact_kernel<P4><<<grid_for(in.n), kBlock, 0, h->stream>>>((const P4*)in.col, nullptr, in.n, flags, pos, 1, (P4*)out.col, nullptr);
+    }
     HIP_TRY(hipGetLastError());
   }
   dbg_sync(h, 4);
@@ -1449,6 +1542,14 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
   if (in.nrm) HIP_TRY(hipMallocAsync((void**)&out.nrm, sizeof(P4) * out.n, h->stream));
   segment_mean_kernel<P4><<<grid_for(out.n), kBlock, 0, h->stream>>>((const P4*)in.pts, (const P4*)in.nrm, k1, v1, seg_start, out.n, n,
                                                                     mode == 1 ? 1 : 0, n_pass, (P4*)out.pts, (P4*)out.nrm);
+  if (in.col) {
+    HIP_TRY(hipMallocAsync((void**)&out.col, sizeof(P4) * out.n, h->stream));
+    if (mode == 0)  // [O3D] VoxelDownSample: AccumulatedPoint averages the colours
+      segment_mean_kernel<P4><<<grid_for(out.n), kBlock, 0, h->stream>>>((const P4*)in.col, nullptr, k1, v1, seg_start, out.n, n, 0, n_pass,
+                                                                        (P4*)out.col, nullptr);
+    else  // the map merge keeps the colour of the LAST point of a voxel (helpers.cpp:40-42,61-63: `color_ = ...`, not `+=`)
+      segment_last_kernel<P4><<<grid_for(out.n), kBlock, 0, h->stream>>>((const P4*)in.col, k1, v1, seg_start, out.n, n, n_pass, (P4*)out.col);
+  }
   HIP_TRY(hipGetLastError());
   dbg_sync(h, 8);
   return O3DS_OK;
@@ -1547,6 +1648,10 @@ int transform_t(o3ds_handle h, const CloudRec& in, const double T[16], CloudRec&
   if (in.nrm) HIP_TRY(hipMallocAsync((void**)&out.nrm, sizeof(P4) * in.n, h->stream));
   transform_kernel<P4><<<grid_for(in.n), kBlock, 0, h->stream>>>((const P4*)in.pts, (const P4*)in.nrm, in.n, M, T[3], T[7], T[11], T[15],
                                                                (P4*)out.pts, (P4*)out.nrm, 0);
+  if (in.col) {
+    HIP_TRY(hipMallocAsync((void**)&out.col, sizeof(P4) * in.n, h->stream));
+    HIP_TRY(hipMemcpyAsync(out.col, in.col, sizeof(P4) * in.n, hipMemcpyDeviceToDevice, h->stream));
+  }
   HIP_TRY(hipGetLastError());
   return O3DS_OK;
 }
@@ -1607,18 +1712,24 @@ int carve_t(o3ds_handle h, CloudRec& map, const CloudRec& scan, const double T[1
   HIP_TRY(hipStreamSynchronize(h->stream));
   *n_removed = n - (size_t)total;
   if (*n_removed == 0) return O3DS_OK;  // removeByIds: nothing to do (helpers.cpp:221-223)
-  void *np = nullptr, *nn = nullptr;
+  void *np = nullptr, *nn = nullptr, *nc = nullptr;
   if (total > 0) {
     HIP_TRY(hipMallocAsync(&np, sizeof(P4) * (size_t)total, h->stream));
     if (map.nrm) HIP_TRY(hipMallocAsync(&nn, sizeof(P4) * (size_t)total, h->stream));
     compact_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>((const P4*)map.pts, (const P4*)map.nrm, n, keep, pos, 1, (P4*)np, (P4*)nn);
+    if (map.col) {
+      HIP_TRY(hipMallocAsync(&nc, sizeof(P4) * (size_t)total, h->stream));
+      compact_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>((const P4*)map.col, nullptr, n, keep, pos, 1, (P4*)nc, nullptr);
+    }
     HIP_TRY(hipGetLastError());
   }
   free_index(h, map);
   (void)hipFreeAsync(map.pts, h->stream);
   if (map.nrm) (void)hipFreeAsync(map.nrm, h->stream);
+  if (map.col) (void)hipFreeAsync(map.col, h->stream);
   map.pts = np;
   map.nrm = nn;
+  map.col = nc;
   map.n = (size_t)total;
   return O3DS_OK;
 }
@@ -1695,25 +1806,31 @@ template <typename P4>
 int append_t(o3ds_handle h, CloudRec& map, const CloudRec& add) {
   // [O3D] PointCloud::operator+= : normals survive only if (map empty or map has normals) and add has normals
   const bool keep_nrm = (map.n == 0 || map.nrm) && add.nrm;
+  const bool keep_col = (map.n == 0 || map.col) && add.col;  // the same rule for colors_
   const size_t n = map.n + add.n;
-  void *np = nullptr, *nn = nullptr;
+  void *np = nullptr, *nn = nullptr, *nc = nullptr;
   if (n > 0) HIP_TRY(hipMallocAsync((void**)&np, sizeof(P4) * n, h->stream));
   if (keep_nrm && n > 0) HIP_TRY(hipMallocAsync((void**)&nn, sizeof(P4) * n, h->stream));
+  if (keep_col && n > 0) HIP_TRY(hipMallocAsync((void**)&nc, sizeof(P4) * n, h->stream));
   if (map.n) {
     HIP_TRY(hipMemcpyAsync(np, map.pts, sizeof(P4) * map.n, hipMemcpyDeviceToDevice, h->stream));
     if (keep_nrm) HIP_TRY(hipMemcpyAsync(nn, map.nrm, sizeof(P4) * map.n, hipMemcpyDeviceToDevice, h->stream));
+    if (keep_col) HIP_TRY(hipMemcpyAsync(nc, map.col, sizeof(P4) * map.n, hipMemcpyDeviceToDevice, h->stream));
   }
   if (add.n) {
     reindex_copy_kernel<P4><<<grid_for(add.n), kBlock, 0, h->stream>>>((const P4*)add.pts, add.n, (P4*)np, map.n, 1);
     if (keep_nrm) reindex_copy_kernel<P4><<<grid_for(add.n), kBlock, 0, h->stream>>>((const P4*)add.nrm, add.n, (P4*)nn, map.n, 0);
+    if (keep_col) reindex_copy_kernel<P4><<<grid_for(add.n), kBlock, 0, h->stream>>>((const P4*)add.col, add.n, (P4*)nc, map.n, 0);
   }
   HIP_TRY(hipGetLastError());
   dbg_sync(h, 32);
   free_index(h, map);
   if (map.pts) HIP_TRY(hipFreeAsync(map.pts, h->stream));
   if (map.nrm) HIP_TRY(hipFreeAsync(map.nrm, h->stream));
+  if (map.col) HIP_TRY(hipFreeAsync(map.col, h->stream));
   map.pts = np;
   map.nrm = nn;
+  map.col = nc;
   map.n = n;
   return O3DS_OK;
 }
@@ -1794,6 +1911,13 @@ int o3ds_select_by_index(o3ds_handle h, o3ds_cloud in, const uint32_t* keep_idx,
       gather_kernel<P4d><<<grid_for(m), kBlock, 0, h->stream>>>((const P4d*)c->pts, (const P4d*)c->nrm, d_idx, m, (P4d*)o.pts, (P4d*)o.nrm);
     else
       gather_kernel<P4f><<<grid_for(m), kBlock, 0, h->stream>>>((const P4f*)c->pts, (const P4f*)c->nrm, d_idx, m, (P4f*)o.pts, (P4f*)o.nrm);
+    if (c->col) {
+      HIP_TRY(hipMallocAsync((void**)&o.col, psz * m, h->stream));
+      if (c->precision == O3DS_PRECISION_F64)
+        gather_kernel<P4d><<<grid_for(m), kBlock, 0, h->stream>>>((const P4d*)c->col, nullptr, d_idx, m, (P4d*)o.col, nullptr);
+      else
+        gather_kernel<P4f><<<grid_for(m), kBlock, 0, h->stream>>>((const P4f*)c->col, nullptr, d_idx, m, (P4f*)o.col, nullptr);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));  // keep_idx may be released by the caller
   }

@@ -49,9 +49,17 @@ __global__ __launch_bounds__(kBlock) void pack_strided_f32_kernel(const unsigned
 // at byte offsets ox / oy / oz and, when `on` is a valid offset, the normal at on, on + 4, on + 8; the other bytes of the
 // (pre-zeroed) record are left alone.  double -> float is the same round-to-nearest narrowing `*ros_pc2_x = point(0)` does.
 constexpr size_t kNoField = ~(size_t)0;
+// colour byte of a [0, 1] double: mode 0 = `(int)(255 * c)` stored to a uint8 (open3dToRos, open3d_conversions.cpp:41-43),
+// mode 1 = clamp, scale, round ([O3D] utility::ColorToUint8, which the PCD writer uses)
+__device__ __forceinline__ unsigned char color_byte(double c, int mode) {
+  if (mode == 0) return (unsigned char)(int)(255.0 * c);
+  return (unsigned char)rint(fmin(1.0, fmax(0.0, c)) * 255.0);
+}
 template <typename P4>
-__global__ __launch_bounds__(kBlock) void unpack_strided_f32_kernel(const P4* __restrict__ pts, const P4* __restrict__ nrm, size_t n, size_t step,
-                                                                    size_t ox, size_t oy, size_t oz, size_t on, unsigned char* __restrict__ raw) {
+__global__ __launch_bounds__(kBlock) void unpack_strided_f32_kernel(const P4* __restrict__ pts, const P4* __restrict__ nrm,
+                                                                    const P4* __restrict__ col, size_t n, size_t step, size_t ox, size_t oy,
+                                                                    size_t oz, size_t on, size_t oc, int color_mode,
+                                                                    unsigned char* __restrict__ raw) {
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
     unsigned char* rec = raw + i * step;
     const P4 p = pts[i];
@@ -66,6 +74,33 @@ __global__ __launch_bounds__(kBlock) void unpack_strided_f32_kernel(const P4* __
       __builtin_memcpy(rec + on + 4, &b, 4);
       __builtin_memcpy(rec + on + 8, &c, 4);
     }
+    if (oc != kNoField && col) {  // the packed `rgb` field: bytes b, g, r, 0 (PointCloud2 sub-fields b / g / r at +0 / +1 / +2)
+      const P4 c = col[i];
+      rec[oc] = color_byte((double)c.z, color_mode);
+      rec[oc + 1] = color_byte((double)c.y, color_mode);
+      rec[oc + 2] = color_byte((double)c.x, color_mode);
+      rec[oc + 3] = 0;
+    }
+  }
+}
+// colours the way rosToOpen3d reads them (open3d_conversions.cpp:70-86): kind 0 = an `rgb` field at byte offset `off` (r, g, b bytes
+// at +2, +1, +0, each / 255.0); kind 1 = an `intensity` field read through a uint8 iterator, i.e. its FIRST byte, unscaled, three times
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void colors_from_records_kernel(const unsigned char* __restrict__ raw, size_t n, size_t step, size_t off,
+                                                                     int kind, P4* __restrict__ out) {
+  using R = typename Scalar<P4>::type;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const unsigned char* f = raw + i * step + off;
+    P4 c;
+    if (kind == 0) {
+      c.x = (R)((double)(int)f[2] / 255.0);
+      c.y = (R)((double)(int)f[1] / 255.0);
+      c.z = (R)((double)(int)f[0] / 255.0);
+    } else {
+      c.x = c.y = c.z = (R)(double)f[0];
+    }
+    c.i = 0;
+    out[i] = c;
   }
 }
 template <typename P4>
@@ -449,6 +484,22 @@ __host__ __device__ inline void fast_eigen3x3_min(const double cov[6], double ou
 // the current worst and the maximum is recomputed by one sweep over the k slots.  Only the SET of the k nearest matters
 // (the covariance is a sum), so no ordering is maintained.  Candidate loads are issued four at a time: a load-per-
 // iteration loop with a scratch-resident sorted list measured 3.8 ms for 100 k points; this form is bound by LDS sweeps.
+// colours in the map merge: AccumulatedPoint::AddPoint ASSIGNS the colour (helpers.cpp:40-42; isValidColor, helpers.cpp:83-85, is
+// true for every value), so a voxel ends up with the colour of its last point in cloud order; same output placement as
+// segment_mean_kernel (pass-through points first, their own colour)
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void segment_last_kernel(const P4* __restrict__ col, const unsigned long long* __restrict__ keys,
+                                                              const uint32_t* __restrict__ vals, const int* __restrict__ seg_start, size_t n_seg,
+                                                              size_t n, size_t n_pass, P4* __restrict__ out_col) {
+  for (size_t s = (size_t)blockIdx.x * kBlock + threadIdx.x; s < n_seg; s += (size_t)gridDim.x * kBlock) {
+    const size_t b = (size_t)seg_start[s], e = (s + 1 < n_seg) ? (size_t)seg_start[s + 1] : n;
+    const bool pass = (keys[b] & kPassBit) != 0;
+    const size_t n_vox = n_seg - n_pass;
+    const size_t o = pass ? (s - n_vox) : (n_pass + s);
+    out_col[o] = col[vals[e - 1]];  // vals ascend inside a segment (stable sort of ascending indices)
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- space carving (sparse map)
 // Submap::carve -> getIdxsOfCarvedPoints (Submap.cpp:109-125, helpers.cpp:235-271).  The reference keeps a hash map voxel ->
 // indices and lets every scan ray probe it every `voxel` metres under an `omp critical`; here the cropped map points are keyed
@@ -575,12 +626,14 @@ __global__ __launch_bounds__(kBlock) void index_compact_kernel(const int* __rest
 // how the insertions interleave; the quantisation (<= 0.5 nm per inserted point) is far below the f32 / f64 noise of the inputs.
 constexpr double kDensePosQ = 1.0 / 1073741824.0;        // 2^-30
 constexpr double kDenseNrmQ = 1.0 / 1099511627776.0;     // 2^-40
+constexpr double kDenseColQ = 1.0 / 16777216.0;          // 2^-24: colours reach 255 when they come from an intensity byte (open3d_conversions.cpp:81-86)
 
 struct DenseDev {
   unsigned long long* keys;  // [cap], kEmptyKey = free
   int* cnt;                  // [cap]
   long long* sp;             // [3 * cap] sum of positions / kDensePosQ
   long long* sn;             // [3 * cap] sum of normals / kDenseNrmQ
+  long long* sc;             // [3 * cap] sum of colours / kDenseColQ (AggregatedVoxel::aggregateColor, Voxel.cpp:33-35)
   unsigned int mask;         // cap - 1
 };
 
@@ -598,8 +651,8 @@ __device__ __forceinline__ unsigned int dense_find_or_insert(const DenseDev& d, 
 
 // VoxelizedPointCloud::insert (Voxel.cpp:66-90) of o3d_slam::transform(T, cloud) (Submap.cpp:81-84)
 template <typename P4>
-__global__ __launch_bounds__(kBlock) void dense_insert_kernel(const P4* __restrict__ pts, const P4* __restrict__ nrm, size_t n, Mat34 M, double inv,
-                                                              DenseDev d) {
+__global__ __launch_bounds__(kBlock) void dense_insert_kernel(const P4* __restrict__ pts, const P4* __restrict__ nrm, const P4* __restrict__ col,
+                                                              size_t n, Mat34 M, double inv, DenseDev d) {
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
     const P4 p = pts[i];
     const double x = (double)p.x, y = (double)p.y, z = (double)p.z;
@@ -618,6 +671,12 @@ __global__ __launch_bounds__(kBlock) void dense_insert_kernel(const P4* __restri
       atomicAdd((unsigned long long*)&d.sn[3 * (size_t)slot], (unsigned long long)llrint(nx / kDenseNrmQ));
       atomicAdd((unsigned long long*)&d.sn[3 * (size_t)slot + 1], (unsigned long long)llrint(ny / kDenseNrmQ));
       atomicAdd((unsigned long long*)&d.sn[3 * (size_t)slot + 2], (unsigned long long)llrint(nz / kDenseNrmQ));
+    }
+    if (col) {  // colours are not rotated (o3d_slam::transform leaves colors_ alone)
+      const P4 c = col[i];
+      atomicAdd((unsigned long long*)&d.sc[3 * (size_t)slot], (unsigned long long)llrint((double)c.x / kDenseColQ));
+      atomicAdd((unsigned long long*)&d.sc[3 * (size_t)slot + 1], (unsigned long long)llrint((double)c.y / kDenseColQ));
+      atomicAdd((unsigned long long*)&d.sc[3 * (size_t)slot + 2], (unsigned long long)llrint((double)c.z / kDenseColQ));
     }
   }
 }
@@ -716,7 +775,7 @@ __global__ __launch_bounds__(kBlock) void dense_erase_marked_kernel(DenseDev d, 
   for (size_t s = (size_t)blockIdx.x * kBlock + threadIdx.x; s < cap; s += (size_t)gridDim.x * kBlock) {
     if (!mark[s] || d.cnt[s] <= 0) continue;
     d.cnt[s] = 0;
-    for (int c = 0; c < 3; ++c) d.sp[3 * s + c] = 0, d.sn[3 * s + c] = 0;
+    for (int c = 0; c < 3; ++c) d.sp[3 * s + c] = 0, d.sn[3 * s + c] = 0, d.sc[3 * s + c] = 0;
     ++mine;
   }
   if (mine) atomicAdd(removed, (unsigned long long)mine);
@@ -732,6 +791,7 @@ __global__ __launch_bounds__(kBlock) void dense_rehash_kernel(DenseDev from, siz
     for (int c = 0; c < 3; ++c) {
       to.sp[3 * (size_t)t + c] = from.sp[3 * s + c];
       to.sn[3 * (size_t)t + c] = from.sn[3 * s + c];
+      to.sc[3 * (size_t)t + c] = from.sc[3 * s + c];
     }
   }
 }
@@ -759,7 +819,7 @@ __global__ __launch_bounds__(kBlock) void dense_list_kernel(DenseDev d, size_t c
 // VoxelizedPointCloud::toPointCloud (Voxel.cpp:92-114): sum / count per voxel, in the order of `slots` (sorted by key)
 template <typename P4>
 __global__ __launch_bounds__(kBlock) void dense_emit_kernel(DenseDev d, const uint32_t* __restrict__ slots, size_t m, P4* __restrict__ out_pts,
-                                                            P4* __restrict__ out_nrm) {
+                                                            P4* __restrict__ out_nrm, P4* __restrict__ out_col) {
   using R = typename Scalar<P4>::type;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (size_t)gridDim.x * kBlock) {
     const size_t s = slots[i];
@@ -777,6 +837,14 @@ __global__ __launch_bounds__(kBlock) void dense_emit_kernel(DenseDev d, const ui
       q.z = (R)((double)d.sn[3 * s + 2] * kDenseNrmQ / c);
       q.i = 0;
       out_nrm[i] = q;
+    }
+    if (out_col) {
+      P4 q;
+      q.x = (R)((double)d.sc[3 * s] * kDenseColQ / c);
+      q.y = (R)((double)d.sc[3 * s + 1] * kDenseColQ / c);
+      q.z = (R)((double)d.sc[3 * s + 2] * kDenseColQ / c);
+      q.i = 0;
+      out_col[i] = q;
     }
   }
 }

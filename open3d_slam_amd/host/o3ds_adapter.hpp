@@ -98,6 +98,7 @@ class DevCloud {
   DevCloud() = default;
   explicit DevCloud(const PointCloud& c) {
     Handle::check(o3ds_cloud_upload(Handle::get(), xyz(c.points_), c.HasNormals() ? xyz(c.normals_) : nullptr, c.points_.size(), &id_));
+    if (c.HasColors()) Handle::check(o3ds_cloud_set_colors(Handle::get(), id_, xyz(c.colors_)));  // ride along (never read by registration)
   }
   explicit DevCloud(o3ds_cloud id) : id_(id) {}
   DevCloud(const DevCloud&) = delete;
@@ -134,6 +135,10 @@ class DevCloud {
     if (n)
       Handle::check(o3ds_cloud_download(Handle::get(), id_, reinterpret_cast<double*>(out->points_.data()),
                                         hn ? reinterpret_cast<double*>(out->normals_.data()) : nullptr, n));
+    int hc = 0;
+    Handle::check(o3ds_cloud_has_colors(Handle::get(), id_, &hc));
+    out->colors_.resize(hc ? n : 0);
+    if (n && hc) Handle::check(o3ds_cloud_get_colors(Handle::get(), id_, reinterpret_cast<double*>(out->colors_.data()), n));
   }
 
  private:
@@ -490,28 +495,31 @@ class DeviceSubmap {
 
 // ---- egress: saveToFile (src/output.cpp:39-47) -----------------------------------------------------------------------
 // The reference copies the cloud and calls [O3D] io::WritePointCloudToPCD with default options: binary, uncompressed PCD v0.7,
-// float32 x y z (+ normal_x normal_y normal_z when present; colours are not carried on this path).  The device writes those
+// float32 x y z (+ normal_x normal_y normal_z, + the packed rgb field, when present).  The device writes those
 // rows itself (o3ds_cloud_download_f32), so a map that lives in HBM is saved without the fp64 host copy.  Returns false when the
 // file cannot be written, as WritePointCloudToPCD does.
 inline bool saveDeviceCloudToFile(const std::string& filename, o3ds_cloud cloud) {
   const std::string name = filename.find(".pcd") == std::string::npos ? filename + ".pcd" : filename;
   size_t n = 0;
-  int hn = 0;
+  int hn = 0, hc = 0;
   o3ds_detail::Handle::check(o3ds_cloud_size(o3ds_detail::Handle::get(), cloud, &n, &hn));
-  const size_t step = hn ? 24 : 12;
+  o3ds_detail::Handle::check(o3ds_cloud_has_colors(o3ds_detail::Handle::get(), cloud, &hc));
+  const size_t step = 12 + (hn ? 12 : 0) + (hc ? 4 : 0);
   std::vector<unsigned char> rows(n * step);
-  o3ds_detail::Handle::check(
-      o3ds_cloud_download_f32(o3ds_detail::Handle::get(), cloud, rows.data(), n, step, 0, 4, 8, hn ? (size_t)12 : O3DS_NO_FIELD));
+  o3ds_detail::Handle::check(o3ds_cloud_download_f32(o3ds_detail::Handle::get(), cloud, rows.data(), n, step, 0, 4, 8, hn ? (size_t)12 : O3DS_NO_FIELD,
+                                                     hc ? step - 4 : O3DS_NO_FIELD, 1));
   std::FILE* f = std::fopen(name.c_str(), "wb");
   if (!f) return false;
-  const char* fields = hn ? "x y z normal_x normal_y normal_z" : "x y z";
-  const char* fours = hn ? "4 4 4 4 4 4" : "4 4 4";
-  const char* types = hn ? "F F F F F F" : "F F F";
-  const char* ones = hn ? "1 1 1 1 1 1" : "1 1 1";
+  std::string fields = "x y z", fours = "4 4 4", types = "F F F", ones = "1 1 1";
+  for (int k = 0; k < (hn ? 3 : 0) + (hc ? 1 : 0); ++k) {
+    static const char* const extra[] = {" normal_x", " normal_y", " normal_z"};
+    fields += (k < (hn ? 3 : 0)) ? extra[k] : " rgb";
+    fours += " 4", types += " F", ones += " 1";
+  }
   bool ok = std::fprintf(f,
                          "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS %s\nSIZE %s\nTYPE %s\nCOUNT %s\nWIDTH %zu\nHEIGHT 1\n"
                          "VIEWPOINT 0 0 0 1 0 0 0\nPOINTS %zu\nDATA binary\n",
-                         fields, fours, types, ones, n, n) > 0;
+                         fields.c_str(), fours.c_str(), types.c_str(), ones.c_str(), n, n) > 0;
   ok = ok && std::fwrite(rows.data(), 1, rows.size(), f) == rows.size();
   return std::fclose(f) == 0 && ok;
 }

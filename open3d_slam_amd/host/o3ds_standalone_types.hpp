@@ -12,8 +12,10 @@ namespace geometry {
 struct PointCloud {  // open3d::geometry::PointCloud members used on this path (typedefs.hpp:24)
   std::vector<std::array<double, 3>> points_;
   std::vector<std::array<double, 3>> normals_;
+  std::vector<std::array<double, 3>> colors_;
   bool HasPoints() const { return !points_.empty(); }
   bool HasNormals() const { return !points_.empty() && normals_.size() == points_.size(); }
+  bool HasColors() const { return !points_.empty() && colors_.size() == points_.size(); }
   bool IsEmpty() const { return points_.empty(); }
 };
 }  // namespace geometry

@@ -11,18 +11,31 @@ class PointCloud:
         self.be, self.id, self._owns = be, cid, owns
 
     @classmethod
-    def from_numpy(cls, be, points, normals=None) -> "PointCloud":
-        return cls(be, be.upload(np.asarray(points, dtype=np.float64).reshape(-1, 3), normals))
+    def from_numpy(cls, be, points, normals=None, colors=None) -> "PointCloud":
+        cloud = cls(be, be.upload(np.asarray(points, dtype=np.float64).reshape(-1, 3), normals))
+        if colors is not None:
+            be.set_colors(cloud.id, colors)
+        return cloud
 
     @classmethod
-    def from_pointcloud2(cls, be, records, off_x: int = 0, off_y: int = 4, off_z: int = 8) -> "PointCloud":
-        """open3d_conversions::rosToOpen3d (open3d_conversions.cpp:59-68) without the host-side widening: float32 x/y/z records go
-        to the device as they are (o3ds_cloud_upload_f32)."""
-        return cls(be, be.upload_f32(records, off_x, off_y, off_z))
+    def from_pointcloud2(cls, be, records, off_x: int = 0, off_y: int = 4, off_z: int = 8, fourth_field: tuple | None = None) -> "PointCloud":
+        """open3d_conversions::rosToOpen3d (open3d_conversions.cpp:59-88) without the host-side widening: float32 x/y/z records go
+        to the device as they are (o3ds_cloud_upload_f32).  fourth_field = ("rgb" | "intensity", byte offset) reproduces what the
+        reference does with a fourth field when skip_colors is false (every caller): colours from the rgb bytes / 255, or the first
+        byte of the intensity field three times."""
+        cloud = cls(be, be.upload_f32(records, off_x, off_y, off_z))
+        if fourth_field is not None:
+            name, off = fourth_field
+            kind = {"rgb": 0, "intensity": 1}[name]
+            be.set_colors_from_records(cloud.id, records, off, kind)
+        return cloud
 
     def to_pointcloud2(self) -> np.ndarray:
-        """open3d_conversions::open3dToRos for a cloud without colours (open3d_conversions.cpp:19-53): the `data` member of the
-        message, (n, 16) bytes = float32 x, y, z + 4 bytes of padding per point, narrowed on the device."""
+        """open3d_conversions::open3dToRos (open3d_conversions.cpp:19-53): the `data` member of the message, narrowed on the device.
+        Without colours (n, 16) bytes = float32 x, y, z + 4 bytes of padding (fields "xyz"); with colours (n, 32) bytes, the packed
+        rgb field at 16 (fields "xyz", "rgb"), bytes = (int)(255 * colour)."""
+        if self.HasColors():
+            return self.be.download_f32(self.id, 32, 0, 4, 8, None, 16, 0)
         return self.be.download_f32(self.id, 16, 0, 4, 8, None)
 
     def __len__(self) -> int:
@@ -34,6 +47,13 @@ class PointCloud:
     def HasNormals(self) -> bool:
         n, hn = self.be.size(self.id)
         return n > 0 and hn
+
+    def HasColors(self) -> bool:
+        return len(self) > 0 and self.be.has_colors(self.id)
+
+    @property
+    def colors_(self):
+        return self.be.get_colors(self.id)
 
     @property
     def points_(self) -> np.ndarray:

@@ -371,3 +371,14 @@ def icp_generalized(src, src_nrm, tgt, tgt_nrm, max_corr, init=None, max_iter=30
         if abs(pf - fit) < rel_fitness and abs(pr - rmse) < rel_rmse:
             break
     return dict(transformation=T, fitness=fit, inlier_rmse=rmse, iterations=it, n_corr=nc)
+
+
+def merge_last_colors(pts, col, voxel):
+    """Colours of the map merge for points that are all inside the cropping volume (helpers.cpp:40-42,61-63): per world-anchored
+    voxel floor(p / v) the colour of the LAST point in cloud order; returns (voxel keys (m,3) sorted, colours (m,3))."""
+    keys = np.floor(np.asarray(pts) * (1.0 / voxel)).astype(np.int64)
+    uk, inv = np.unique(keys, axis=0, return_inverse=True)
+    inv = inv.reshape(-1)
+    last = np.full(len(uk), -1, dtype=np.int64)
+    np.maximum.at(last, inv, np.arange(len(keys)))
+    return uk, np.asarray(col)[last]

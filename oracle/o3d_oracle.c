@@ -1622,3 +1622,38 @@ size_t orc_voxelize_within_volume(const double* pts, const double* nrm, size_t n
   if (n_pass) *n_pass = np;
   return np + m;
 }
+
+/* The colours of the same merge (helpers.cpp:40-42,61-63,155-181): out_col is ordered like out_pts of orc_voxelize_within_volume
+ * (pass-through points first, then the voxels in first-occurrence order).  AccumulatedPoint::AddPoint ASSIGNS `color_ =
+ * cloud.colors_[index]` whenever isValidColor holds, and isValidColor (helpers.cpp:83-85: `c.array().all() >= 0.0 && ... <= 1.0`,
+ * a bool compared with a double) holds for every colour, so a voxel carries the colour of its LAST point in cloud order and
+ * GetAverageColor returns it undivided. */
+size_t orc_voxelize_within_volume_colors(const double* pts, const double* col, size_t n, double voxel, const orc_crop* c, double* out_col) {
+  if (voxel <= 0.0) {
+    memcpy(out_col, col, sizeof(double) * 3 * n);
+    return n;
+  }
+  const double inv = 1.0 / voxel;
+  vhash h;
+  vhash_init(&h, n);
+  double* last = (double*)malloc(sizeof(double) * 3 * (n ? n : 1));
+  size_t m = 0, np = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const double* p = pts + 3 * i;
+    if (within_volume(p, c)) {
+      int32_t k[3];
+      for (int d = 0; d < 3; ++d) k[d] = (int32_t)floor(p[d] * inv);
+      int is_new;
+      int64_t s = vhash_get(&h, k[0], k[1], k[2], (int64_t)m, &is_new);
+      if (is_new) ++m;
+      for (int d = 0; d < 3; ++d) last[3 * (size_t)s + d] = col[3 * i + d];
+    } else {
+      for (int d = 0; d < 3; ++d) out_col[3 * np + d] = col[3 * i + d];
+      ++np;
+    }
+  }
+  memcpy(out_col + 3 * np, last, sizeof(double) * 3 * m);
+  free(last);
+  vhash_free(&h);
+  return np + m;
+}

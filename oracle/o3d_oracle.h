@@ -142,6 +142,10 @@ size_t orc_crop_indices(const double* pts, size_t n, const orc_crop* c, int64_t*
 size_t orc_voxelize_within_volume(const double* pts, const double* nrm, size_t n, double voxel, const orc_crop* c, double* out_pts,
                                   double* out_nrm, size_t* n_pass);
 
+/* colours of that merge, ordered like its out_pts: a voxel keeps the colour of its LAST point (helpers.cpp:40-42,61-63,83-85).
+ * ([O3D] VoxelDownSample averages colours exactly as it averages normals: use orc_voxel_down_sample with the colours as `nrm`.) */
+size_t orc_voxelize_within_volume_colors(const double* pts, const double* col, size_t n, double voxel, const orc_crop* c, double* out_col);
+
 #ifdef __cplusplus
 }
 #endif

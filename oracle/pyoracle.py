@@ -98,6 +98,8 @@ def lib():
         L.orc_voxelize_within_volume.restype = C.c_size_t
         L.orc_voxelize_within_volume.argtypes = [_dp, _dp, C.c_size_t, C.c_double, C.POINTER(Crop), _dp, _dp,
                                                  C.POINTER(C.c_size_t)]
+        L.orc_voxelize_within_volume_colors.restype = C.c_size_t
+        L.orc_voxelize_within_volume_colors.argtypes = [_dp, _dp, C.c_size_t, C.c_double, C.POINTER(Crop), _dp]
         L.orc_num_threads.restype = C.c_int
         L.orc_set_num_threads.argtypes = [C.c_int]
         _lib = L
@@ -402,3 +404,13 @@ def voxelize_within_volume(pts, nrm, voxel, crop: Crop):
         return out[:m].copy(), on[:m].copy(), int(npass.value)
     m = lib().orc_voxelize_within_volume(pp, None, n, voxel, C.byref(crop), out.ctypes.data_as(_dp), None, C.byref(npass))
     return out[:m].copy(), None, int(npass.value)
+
+
+def voxelize_within_volume_colors(pts, col, voxel, crop: Crop):
+    """colours of voxelize_within_volume's output, in its order (last point of a voxel wins)"""
+    pts, pp = _d(pts)
+    col, cp = _d(col)
+    n = len(pts)
+    out = np.empty((max(n, 1), 3))
+    m = lib().orc_voxelize_within_volume_colors(pp, cp, n, voxel, C.byref(crop), out.ctypes.data_as(_dp))
+    return out[:m].copy()

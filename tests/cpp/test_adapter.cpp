@@ -156,6 +156,39 @@ static void gpuChecks() {
   size_t expect = 0;
   for (auto& p : flat.points_) expect += std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) <= 2.0;
   CHECK(cropped->points_.size() == expect && cropped->normals_.size() == expect);
+  // colours ride along: kept by the cropper, averaged by voxelize, written as the packed rgb field of the PCD
+  {
+    PointCloud tinted = flat;
+    tinted.colors_.resize(tinted.points_.size());
+    for (size_t i = 0; i < tinted.points_.size(); ++i) tinted.colors_[i] = {(double)(i % 5) / 4.0, 0.5, 1.0};
+    auto kept = ball.crop(tinted);
+    CHECK(kept->HasColors() && kept->colors_.size() == expect);
+    size_t k = 0;
+    for (size_t i = 0; i < tinted.points_.size() && k < 3; ++i) {
+      const auto& p = tinted.points_[i];
+      if (std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) <= 2.0) {
+        CHECK(kept->colors_[k][0] == tinted.colors_[i][0] && kept->colors_[k][2] == 1.0);
+        ++k;
+      }
+    }
+    PointCloud small = tinted;
+    voxelize(0.5, &small);
+    CHECK(small.HasColors());
+    for (auto& c : small.colors_) CHECK(c[0] >= 0.0 && c[0] <= 1.0 && std::fabs(c[1] - 0.5) < 1e-6 && std::fabs(c[2] - 1.0) < 1e-6);
+    const char* dir = std::getenv("O3DS_TEST_TMPDIR");
+    const std::string name = std::string(dir ? dir : "/tmp") + "/adapter_tinted.pcd";
+    CHECK(saveToFile(name, tinted));
+    std::FILE* f = std::fopen(name.c_str(), "rb");
+    CHECK(f != nullptr);
+    std::vector<char> blob(1 << 20);
+    const size_t got = std::fread(blob.data(), 1, blob.size(), f);
+    std::fclose(f);
+    const std::string text(blob.data(), got);
+    const size_t at = text.find("DATA binary\n");
+    CHECK(text.find("FIELDS x y z normal_x normal_y normal_z rgb\n") != std::string::npos && got == at + 12 + tinted.points_.size() * 28);
+    const unsigned char* row3 = reinterpret_cast<const unsigned char*>(blob.data()) + at + 12 + 3 * 28 + 24;
+    CHECK(row3[0] == 255 && row3[1] == 128 && row3[2] == 191 && row3[3] == 0);  // b = 1.0, g = 0.5 (rounds to 128), r = 0.75 (191.25 -> 191)
+  }
   // voxelize / transform
   PointCloud v = flat;
   voxelize(0.5, &v);

@@ -145,7 +145,10 @@ def test_pcd_writer_header_and_round_trip(tmp_path):
         def size(self, cid):
             return len(pts), self.normals is not None
 
-        def download_f32(self, cid, step, ox, oy, oz, on):
+        def has_colors(self, cid):
+            return False
+
+        def download_f32(self, cid, step, ox, oy, oz, on, orgb=None, rounding=0):
             rows = np.zeros((len(pts), step), np.uint8)
             for col, off in enumerate((ox, oy, oz)):
                 rows[:, off:off + 4] = pts[:, col].astype("<f4").reshape(-1, 1).view(np.uint8)
@@ -161,15 +164,18 @@ def test_pcd_writer_header_and_round_trip(tmp_path):
         def HasNormals(self):
             return self.be.normals is not None
 
+        def HasColors(self):
+            return False
+
     assert output._pcd_header(5, False) == (b"# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\n"
                                             b"COUNT 1 1 1\nWIDTH 5\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS 5\nDATA binary\n")
     assert output.saveToFile(str(tmp_path / "a"), _Cloud(_Be(nrm)))
-    p, q = output.readPcd(str(tmp_path / "a.pcd"))
+    p, q, _ = output.readPcd(str(tmp_path / "a.pcd"))
     np.testing.assert_array_equal(p, pts.astype(np.float32))
     np.testing.assert_array_equal(q, nrm.astype(np.float32))
     assert (tmp_path / "a.pcd").stat().st_size == len(output._pcd_header(37, True)) + 37 * 24
     assert output.saveToFile(str(tmp_path / "b.pcd"), _Cloud(_Be(None)))
-    p, q = output.readPcd(str(tmp_path / "b.pcd"))
+    p, q, _ = output.readPcd(str(tmp_path / "b.pcd"))
     assert q is None and (tmp_path / "b.pcd").stat().st_size == len(output._pcd_header(37, False)) + 37 * 12
     np.testing.assert_array_equal(p, pts.astype(np.float32))
     assert not output.saveToFile(str(tmp_path / "no_such_dir" / "c"), _Cloud(_Be(None)))  # false, not an exception (WritePointCloudToPCD)

@@ -519,3 +519,30 @@ def test_dense_carve_c_matches_numpy_and_known_answers(oracle):
     s0 = np.array([0.025, 0.025, 0.025])
     f = oracle.dense_carve(s0 + [[1.0, 0.0, 0.0]], s0, line, voxel, radius=0.1)
     assert set(np.flatnonzero(f).tolist()) >= {0, 2, 4, 6, 8} and not f[11:].any()
+
+
+def test_merge_colours_last_point_wins_c_matches_numpy(oracle):
+    """helpers.cpp:40-42,61-63,83-85: the merge ASSIGNS colours (isValidColor is vacuous), so a voxel shows its last point's colour;
+    pass-through points keep theirs.  C oracle vs the numpy restatement + a hand-made case."""
+    rng = np.random.default_rng(21)
+    pts = rng.uniform(-3, 3, (4000, 3))
+    col = rng.uniform(0, 1, (4000, 3))
+    col[::7] = [1.5, -0.2, 0.3]  # "invalid" values are assigned all the same
+    crop = oracle.make_crop(oracle.CROP_MAX_RADIUS, center=(0.5, 0, 0), rmax=2.0)
+    out, _, npass = oracle.voxelize_within_volume(pts, None, 0.25, crop)
+    oc = oracle.voxelize_within_volume_colors(pts, col, 0.25, crop)
+    inside = np.linalg.norm(pts - [0.5, 0, 0], axis=1) <= 2.0
+    assert len(oc) == len(out)
+    np.testing.assert_array_equal(oc[:npass], col[~inside])
+    uk, want = no.merge_last_colors(pts[inside], col[inside], 0.25)
+    got_keys = np.floor(out[npass:] * 4.0).astype(np.int64)   # voxel means stay in their voxel
+    order = np.lexsort((got_keys[:, 2], got_keys[:, 1], got_keys[:, 0]))
+    np.testing.assert_array_equal(got_keys[order], uk)        # np.unique sorts rows lexicographically as well
+    np.testing.assert_array_equal(oc[npass:][order], want)
+    # three points in one voxel, one outside the volume
+    p = np.array([[0.01, 0.01, 0.01], [9.0, 9.0, 9.0], [0.02, 0.02, 0.02], [0.03, 0.01, 0.02]])
+    c = np.array([[1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0], [0.25, 0.5, 0.75]])
+    oc = oracle.voxelize_within_volume_colors(p, c, 0.1, oracle.make_crop(oracle.CROP_MAX_RADIUS, rmax=1.0))
+    np.testing.assert_array_equal(oc, [[0, 1.0, 0], [0.25, 0.5, 0.75]])
+    # voxel_size <= 0: untouched
+    np.testing.assert_array_equal(oracle.voxelize_within_volume_colors(p, c, 0.0, crop), c)

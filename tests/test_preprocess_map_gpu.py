@@ -736,7 +736,8 @@ def test_f32_egress_records_pcd_and_assembled_map(backend_f32, backend_f64, scan
         assert output.saveToFile(str(tmp_path / "map"), cloud)             # '.pcd' appended
         assert output.saveToFile(str(tmp_path / "map2.pcd"), cloud)        # kept
         for name in ("map.pcd", "map2.pcd"):
-            p, q = output.readPcd(str(tmp_path / name))
+            p, q, rgb = output.readPcd(str(tmp_path / name))
+            assert rgb is None
             np.testing.assert_array_equal(p, xyz.astype(np.float32))
             np.testing.assert_array_equal(q, nrm.astype(np.float32))
         head = open(tmp_path / "map.pcd", "rb").read(400).split(b"DATA binary\n")[0].decode()
@@ -744,9 +745,41 @@ def test_f32_egress_records_pcd_and_assembled_map(backend_f32, backend_f64, scan
         assert f"WIDTH {m}" in head and "HEIGHT 1" in head and f"POINTS {m}" in head
         bare = PointCloud(be, c, owns=False)                                # no normals: x y z rows only
         assert output.saveToFile(str(tmp_path / "raw.pcd"), bare)
-        p, q = output.readPcd(str(tmp_path / "raw.pcd"))
-        assert q is None
+        p, q, rgb = output.readPcd(str(tmp_path / "raw.pcd"))
+        assert q is None and rgb is None
         np.testing.assert_array_equal(p, pts.astype(np.float32))
+        # colours: the packed rgb field, (int)(255 c) for PointCloud2 and clamp / round for the PCD
+        colc = np.random.default_rng(9).uniform(-0.1, 1.1, xyz.shape)
+        be.set_colors(v, colc)
+        pc2c = cloud.to_pointcloud2()
+        assert pc2c.shape == (m, 32)
+        np.testing.assert_array_equal(pc2c[:, :12].copy().view(np.float32).reshape(m, 3), xyz.astype(np.float32))
+        stored = be.get_colors(v)  # what the device holds (f32-rounded in f32 storage)
+        np.testing.assert_array_equal(pc2c[:, [18, 17, 16]], (255.0 * stored).astype(np.int64).astype(np.uint8))
+        assert not pc2c[:, 12:16].any() and not pc2c[:, 19:].any()
+        assert output.saveToFile(str(tmp_path / "col.pcd"), cloud)
+        p, q, rgb = output.readPcd(str(tmp_path / "col.pcd"))
+        np.testing.assert_array_equal(p, xyz.astype(np.float32))
+        np.testing.assert_array_equal(q, nrm.astype(np.float32))
+        np.testing.assert_array_equal(rgb, np.rint(np.clip(stored, 0.0, 1.0) * 255.0).astype(np.uint8))
+        assert b"FIELDS x y z normal_x normal_y normal_z rgb\n" in open(tmp_path / "col.pcd", "rb").read(300)
+        with pytest.raises(backend.BackendError) as ei:
+            be.download_f32(c, 16, 0, 4, 8, None, 12, 0)                    # rgb requested, cloud has no colours
+        assert ei.value.code == -6
+        # ... and in: rosToOpen3d with a fourth field
+        recs = np.zeros(m, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("pad", "<f4"), ("rgb", "<u4")])
+        recs["x"], recs["y"], recs["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+        recs["rgb"] = pc2c[:, 16:20].copy().view("<u4").reshape(m)
+        back = PointCloud.from_pointcloud2(be, recs, fourth_field=("rgb", 16))
+        np.testing.assert_allclose(back.colors_, pc2c[:, [18, 17, 16]] / 255.0, rtol=0, atol=1e-7 if be is backend_f32 else 0)
+        lidar = np.zeros(m, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("intensity", "<f4")])
+        lidar["x"], lidar["y"], lidar["z"], lidar["intensity"] = xyz[:, 0], xyz[:, 1], xyz[:, 2], np.linspace(0.0, 300.0, m)
+        li = PointCloud.from_pointcloud2(be, lidar, fourth_field=("intensity", 12))
+        first_byte = lidar["intensity"].copy().view(np.uint8).reshape(m, 4)[:, 0].astype(np.float64)  # the reference's uint8 iterator
+        np.testing.assert_array_equal(li.colors_, np.repeat(first_byte[:, None], 3, axis=1))
+        back.release()
+        li.release()
+        be.set_colors(v, None)
         # error behaviour
         with pytest.raises(backend.BackendError) as ei:
             be.download_f32(c, 24, 0, 4, 8, 12)                             # normals requested, cloud has none
@@ -783,3 +816,161 @@ def test_f32_egress_records_pcd_and_assembled_map(backend_f32, backend_f64, scan
             x.release()
         for x in (ref, c, v, c2, v2):
             be.free(x)
+
+
+def test_colours_ride_along_like_the_reference(backend_f64, backend_f32, oracle, scan):
+    """PointCloud::colors_ through the cloud operations (o3ds_cloud_set_colors & co.): kept by crop / select / carve, copied by
+    transform, [O3D] operator+= rule on append, MEAN in VoxelDownSample, LAST point's colour in the map merge
+    (helpers.cpp:40-42,61-63,83-85) -- each against the oracle; f64 storage exact, f32 storage to f32 rounding."""
+    rng = np.random.default_rng(3)
+    pts = scan[:20000]
+    nrm = np.roll(pts, 1, axis=1)
+    col = rng.uniform(0, 1, pts.shape)
+    for be, tol in ((backend_f64, 0.0), (backend_f32, 1e-7)):
+        def same(a, b):
+            np.testing.assert_allclose(a, b, rtol=0, atol=tol)
+
+        c = be.upload(pts, nrm)
+        assert not be.has_colors(c) and be.get_colors(c) is None
+        with pytest.raises(backend.BackendError) as ei:  # the raw entry point says EMPTY for an uncoloured cloud
+            be._ck(be.lib.o3ds_cloud_get_colors(be.h, c, np.empty((len(pts), 3)).ctypes.data_as(backend._dp), len(pts)))
+        assert ei.value.code == -6
+        with pytest.raises(ValueError):
+            be.set_colors(c, col[:5])
+        be.set_colors(c, col)
+        assert be.has_colors(c)
+        same(be.get_colors(c), col)
+        # crop, select: the colours of the kept points, in order
+        crop = backend.make_crop(backend.CROP_MIN_MAX_RADIUS, center=(0.5, -0.25, 0.1), rmin=3.0, rmax=20.0)
+        keep = oracle.crop_indices(pts, oracle.make_crop(oracle.CROP_MIN_MAX_RADIUS, center=(0.5, -0.25, 0.1), rmin=3.0, rmax=20.0))
+        out = be.crop_cloud(c, crop)
+        if tol == 0.0:
+            np.testing.assert_array_equal(be.download(out)[0], pts[keep])
+            same(be.get_colors(out), col[keep])
+        else:  # f32-rounded points may change sides of a radius; the colours still belong to the points that were kept
+            gp, gc = be.download(out)[0], be.get_colors(out)
+            d, j = __import__("scipy.spatial", fromlist=["cKDTree"]).cKDTree(pts).query(gp)
+            assert d.max() < 1e-5
+            same(gc, col[j])
+        idx = rng.choice(len(pts), 777, replace=False)
+        sel = be.select_by_index(c, idx)
+        same(be.get_colors(sel), col[idx])
+        # transform: untouched
+        T = syn.make_pose((1.0, 2.0, 0.5), (3.0, -2.0, 40.0))
+        moved = be.transform_cloud(c, T)
+        same(be.get_colors(moved), col)
+        # VoxelDownSample: mean colour per voxel ([O3D] averages colours exactly like normals)
+        v = be.voxel_down_sample(c, 0.4)
+        ref_p, ref_c = oracle.voxel_down_sample(pts, 0.4, col)
+        gp, gc = be.download(v)[0], be.get_colors(v)
+        if tol == 0.0:
+            j = _match(gp, ref_p, 1e-12)
+            np.testing.assert_allclose(gc[j], ref_c, atol=1e-12)
+        else:
+            assert abs(len(gp) - len(ref_p)) <= 0.002 * len(ref_p) and gc.min() >= 0.0 and gc.max() <= 1.0
+        assert be.size(v)[1] and be.has_colors(v)
+        # append: colours survive only when both sides have them (or the map is empty)
+        empty = be.upload(np.zeros((0, 3)))
+        be.cloud_append(empty, sel)
+        same(be.get_colors(empty), col[idx])
+        be.cloud_append(empty, out)
+        same(be.get_colors(empty)[:777], col[idx])
+        assert len(be.get_colors(empty)) == 777 + be.size(out)[0]
+        plain = be.upload(pts[:10], nrm[:10])
+        be.cloud_append(empty, plain)
+        assert not be.has_colors(empty) and be.size(empty) == (777 + be.size(out)[0] + 10, True)
+        plain2 = be.upload(pts[:10], nrm[:10])
+        be.cloud_append(plain2, sel)  # uncoloured map + coloured cloud: still uncoloured
+        assert not be.has_colors(plain2)
+        # map merge: pass-through points keep their colour, a voxel shows its LAST point's colour
+        center = (3.0, -4.0, 0.0)
+        m = be.upload(pts, nrm)
+        be.set_colors(m, col)
+        be.voxelize_within_volume(m, 0.5, backend.make_crop(backend.CROP_MAX_RADIUS, center=center, rmax=12.0))
+        ocrop = oracle.make_crop(oracle.CROP_MAX_RADIUS, center=center, rmax=12.0)
+        ref_p, _, npass = oracle.voxelize_within_volume(pts, nrm, 0.5, ocrop)
+        ref_c = oracle.voxelize_within_volume_colors(pts, col, 0.5, ocrop)
+        gp, gc = be.download(m)[0], be.get_colors(m)
+        if tol == 0.0:
+            assert len(gp) == len(ref_p) and 0 < npass < len(ref_p)
+            np.testing.assert_array_equal(gc[:npass], ref_c[:npass])
+            j = _match(gp[npass:], ref_p[npass:], 1e-12)
+            np.testing.assert_array_equal(gc[npass:][j], ref_c[npass:])
+        else:  # every colour of the merged map is one of the input colours (assigned, never blended)
+            d, _ = __import__("scipy.spatial", fromlist=["cKDTree"]).cKDTree(col).query(gc)
+            assert d.max() <= 2e-7
+        # insertScan = transform + append + merge, colours included
+        m2 = be.upload(np.zeros((0, 3)))
+        be.map_insert_scan(m2, c, T, 0.5, backend.make_crop(backend.CROP_MAX_RADIUS, center=T[:3, 3], rmax=12.0))
+        assert be.has_colors(m2)
+        if tol == 0.0:
+            tp = oracle.transform_points(pts, T)
+            oc2 = oracle.make_crop(oracle.CROP_MAX_RADIUS, center=T[:3, 3], rmax=12.0)
+            rp, _, np2 = oracle.voxelize_within_volume(tp, oracle.transform_normals(nrm, T), 0.5, oc2)
+            rc = oracle.voxelize_within_volume_colors(tp, col, 0.5, oc2)
+            gp2, gc2 = be.download(m2)[0], be.get_colors(m2)
+            np.testing.assert_array_equal(gc2[:np2], rc[:np2])
+            j = _match(gp2[np2:], rp[np2:], 1e-10)
+            np.testing.assert_array_equal(gc2[np2:][j], rc[np2:])
+        # clearing
+        be.set_colors(c, None)
+        assert not be.has_colors(c)
+        for x in (c, out, sel, moved, v, empty, plain, plain2, m, m2):
+            be.free(x)
+    # dense voxel map: colour sums / count, like the normals (Voxel.cpp:24-26,33-35,84-87); uncoloured + coloured inserts set the flag;
+    # a placed insert does not rotate colours; carving and a rehash keep them
+    from scipy.spatial import cKDTree
+
+    scene = syn.make_scene()
+    clouds = [syn.sample_map(scene, n, seed=70 + k) for k, n in enumerate((20_000, 90_000))]  # the second insert forces a rehash
+    cols = [rng.uniform(0, 255, c[0].shape) for c in clouds]                                 # intensity-byte colours reach 255
+    dm = backend_f64.dense_map_create(0.2)
+    for (p, n), cc in zip(clouds, cols):
+        c = backend_f64.upload(p, n)
+        backend_f64.set_colors(c, cc)
+        backend_f64.dense_map_insert(dm, c)
+        backend_f64.free(c)
+    rp, rcol, _ = oracle.dense_fuse(np.vstack([c[0] for c in clouds]), np.vstack(cols), 0.2)
+    out = backend_f64.dense_map_to_cloud(dm)
+    gp, gcol = backend_f64.download(out)[0], backend_f64.get_colors(out)
+    d, j = cKDTree(rp).query(gp)
+    assert np.array_equal(np.sort(j), np.arange(len(rp))) and d.max() < 1e-8
+    np.testing.assert_allclose(gcol, rcol[j], rtol=0, atol=1e-6)  # fixed-point colour sums: 2^-24 per inserted point
+    assert backend_f64.size(out)[1]
+    T = syn.make_pose((1.0, -2.0, 0.3), (5.0, -3.0, 60.0))
+    dm2 = backend_f64.dense_map_create(0.2)
+    c = backend_f64.upload(clouds[0][0], clouds[0][1])
+    backend_f64.set_colors(c, cols[0])
+    backend_f64.dense_map_insert(dm2, c, T)
+    o2 = backend_f64.dense_map_to_cloud(dm2)
+    rp2, rc2, _ = oracle.dense_fuse(oracle.transform_points(clouds[0][0], T), cols[0], 0.2)
+    d, j = cKDTree(rp2).query(backend_f64.download(o2)[0])
+    assert d.max() < 1e-8
+    np.testing.assert_allclose(backend_f64.get_colors(o2), rc2[j], rtol=0, atol=1e-6)
+    plain = backend_f64.dense_map_create(0.2)
+    c2 = backend_f64.upload(clouds[0][0])
+    backend_f64.dense_map_insert(plain, c2)
+    o3 = backend_f64.dense_map_to_cloud(plain)
+    assert not backend_f64.has_colors(o3) and not backend_f64.size(o3)[1]
+    for x in (out, o2, o3, c, c2):
+        backend_f64.free(x)
+    for x in (dm, dm2, plain):
+        backend_f64.dense_map_free(x)
+    # carve keeps the colours of the survivors
+    scene = syn.make_scene()
+    mp, mn = syn.sample_map(scene, 30_000)
+    ghost = rng.uniform([-3.0, -3.0, 0.2], [3.0, 3.0, 1.5], size=(400, 3))
+    mp, mn = np.vstack([mp, ghost]), np.vstack([mn, rng.normal(size=(400, 3))])
+    mc = rng.uniform(0, 1, mp.shape)
+    pose = syn.make_pose((0.3, -0.2, 0.5), (1.0, -2.0, 10.0))
+    raw = syn.vlp16_scan(scene, pose, n_az=512)
+    m, s = backend_f64.upload(mp, mn), backend_f64.upload(raw)
+    backend_f64.set_colors(m, mc)
+    removed = backend_f64.map_carve(m, s, pose, backend.make_crop(backend.CROP_MAX_RADIUS, center=pose[:3, 3], rmax=15.0))
+    gp, gc = backend_f64.download(m)[0], backend_f64.get_colors(m)
+    assert removed > 0 and len(gc) == len(mp) - removed
+    d, j = __import__("scipy.spatial", fromlist=["cKDTree"]).cKDTree(mp).query(gp)
+    assert d.max() == 0.0
+    np.testing.assert_array_equal(gc, mc[j])
+    backend_f64.free(m)
+    backend_f64.free(s)
