@@ -5,15 +5,18 @@
 //        include/open3d_slam/CloudRegistration.hpp:19-42, src/CloudRegistration.cpp:44-65,85-100
 //   CroppingVolume family / croppingVolumeFactory      include/open3d_slam/croppers.hpp:26-47, src/croppers.cpp
 //   voxelize / voxelizeWithinCroppingVolume / transform include/open3d_slam/helpers.hpp:20-25, src/helpers.cpp:107-183,273-305
-//   ScanToMapIcp (device-resident map variant)          src/ScanToMapRegistration.cpp:35-62, src/Submap.cpp:39-75
+//   DeviceSubmap: the submap resident in HBM            src/ScanToMapRegistration.cpp:55-62, src/Submap.cpp:39-75,94-125
+//   (ScanToMapIcp, Submap, VoxelizedPointCloud and the remaining helpers over it: o3ds_mapping.hpp)
 //   saveToFile                                          include/open3d_slam/output.hpp, src/output.cpp:39-47
-// Header-only; link with -lo3ds_backend.  One backend handle per calling thread (thread_local), because the reference
-// calls registerClouds concurrently from odometry / mapping / loop-closure threads (SlamWrapper.cpp:258-347,406-448).
+// Header-only; link with -lo3ds_backend.  One backend handle per calling thread (thread_local) for the stateless calls, because the
+// reference calls registerClouds concurrently from odometry / mapping / loop-closure threads (SlamWrapper.cpp:258-347,406-448);
+// objects that keep device state (DeviceSubmap, VoxelizedPointCloud) own a handle of their own.
 #pragma once
 #include <cmath>
 #include <cstdio>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -23,6 +26,7 @@
 #include <open3d/geometry/PointCloud.h>
 #include <open3d/pipelines/registration/Registration.h>
 #include "open3d_slam/Transform.hpp"
+#include "open3d_slam/time.hpp"
 #else
 #include "o3ds_standalone_types.hpp"
 #endif
@@ -70,18 +74,12 @@ class Handle {
     thread_local Handle h;
     return h.h_;
   }
+  // o3ds_last_error(NULL) is the last error of the calling thread, whichever handle raised it
   static void check(int rc) {
-    if (rc != O3DS_OK) throw std::runtime_error(std::string("o3ds: ") + o3ds_last_error(rc == O3DS_ERR_BAD_HANDLE ? nullptr : get_nothrow()));
+    if (rc != O3DS_OK) throw std::runtime_error(std::string("o3ds: ") + o3ds_last_error(nullptr));
   }
 
  private:
-  static o3ds_handle get_nothrow() {
-    try {
-      return get();
-    } catch (...) {
-      return nullptr;
-    }
-  }
   Handle() {
     const int rc = o3ds_create(0, &h_);
     if (rc != O3DS_OK) throw std::runtime_error(std::string("o3ds_create: ") + o3ds_last_error(nullptr));
@@ -92,30 +90,57 @@ class Handle {
   o3ds_handle h_ = nullptr;
 };
 
-// scoped device cloud
+// A handle that belongs to an OBJECT instead of a thread: device clouds belong to the handle that made them, and the reference's
+// Submap is built on one thread, filled by mappingWorker, read by the dense-map and visualisation threads
+// (SlamWrapper.cpp:290-347,363-386; Submap.cpp:69,187-190) -- so a device-resident map owns its handle (one stream + scratch) and
+// the mutex the reference guards mapCloud_ with.  Created lazily: constructing the owner needs no device.
+class OwnedHandle {
+ public:
+  OwnedHandle() = default;
+  OwnedHandle(const OwnedHandle&) = delete;
+  OwnedHandle& operator=(const OwnedHandle&) = delete;
+  ~OwnedHandle() {
+    if (h_) o3ds_destroy(h_);
+  }
+  o3ds_handle get() const {
+    if (!h_) {
+      const int rc = o3ds_create(0, &h_);
+      if (rc != O3DS_OK) throw std::runtime_error(std::string("o3ds_create: ") + o3ds_last_error(nullptr));
+    }
+    return h_;
+  }
+  bool created() const { return h_ != nullptr; }
+
+ private:
+  mutable o3ds_handle h_ = nullptr;
+};
+
+// scoped device cloud (on the calling thread's handle unless another one is named)
 class DevCloud {
  public:
   DevCloud() = default;
-  explicit DevCloud(const PointCloud& c) {
-    Handle::check(o3ds_cloud_upload(Handle::get(), xyz(c.points_), c.HasNormals() ? xyz(c.normals_) : nullptr, c.points_.size(), &id_));
-    if (c.HasColors()) Handle::check(o3ds_cloud_set_colors(Handle::get(), id_, xyz(c.colors_)));  // ride along (never read by registration)
+  explicit DevCloud(const PointCloud& c, o3ds_handle h = nullptr) : h_(h ? h : Handle::get()) {
+    Handle::check(o3ds_cloud_upload(h_, xyz(c.points_), c.HasNormals() ? xyz(c.normals_) : nullptr, c.points_.size(), &id_));
+    if (c.HasColors()) Handle::check(o3ds_cloud_set_colors(h_, id_, xyz(c.colors_)));  // ride along (never read by registration)
   }
-  explicit DevCloud(o3ds_cloud id) : id_(id) {}
+  explicit DevCloud(o3ds_cloud id, o3ds_handle h = nullptr) : h_(h ? h : Handle::get()), id_(id) {}
   DevCloud(const DevCloud&) = delete;
   DevCloud& operator=(const DevCloud&) = delete;
-  DevCloud(DevCloud&& o) noexcept : id_(o.id_) { o.id_ = 0; }
+  DevCloud(DevCloud&& o) noexcept : h_(o.h_), id_(o.id_) { o.id_ = 0; }
   DevCloud& operator=(DevCloud&& o) noexcept {
     reset();
+    h_ = o.h_;
     id_ = o.id_;
     o.id_ = 0;
     return *this;
   }
   ~DevCloud() { reset(); }
   void reset() {
-    if (id_) o3ds_cloud_free(Handle::get(), id_);
+    if (id_) o3ds_cloud_free(h_, id_);
     id_ = 0;
   }
   o3ds_cloud id() const { return id_; }
+  o3ds_handle handle() const { return h_; }
   o3ds_cloud release() {  // forget the id without freeing it (borrowed clouds)
     const o3ds_cloud i = id_;
     id_ = 0;
@@ -123,25 +148,32 @@ class DevCloud {
   }
   size_t size() const {
     size_t n = 0;
-    Handle::check(o3ds_cloud_size(Handle::get(), id_, &n, nullptr));
+    Handle::check(o3ds_cloud_size(h_, id_, &n, nullptr));
     return n;
+  }
+  bool hasNormals() const {
+    size_t n = 0;
+    int hn = 0;
+    Handle::check(o3ds_cloud_size(h_, id_, &n, &hn));
+    return hn != 0;
   }
   void download(PointCloud* out) const {
     size_t n = 0;
     int hn = 0;
-    Handle::check(o3ds_cloud_size(Handle::get(), id_, &n, &hn));
+    Handle::check(o3ds_cloud_size(h_, id_, &n, &hn));
     out->points_.resize(n);
     out->normals_.resize(hn ? n : 0);
     if (n)
-      Handle::check(o3ds_cloud_download(Handle::get(), id_, reinterpret_cast<double*>(out->points_.data()),
+      Handle::check(o3ds_cloud_download(h_, id_, reinterpret_cast<double*>(out->points_.data()),
                                         hn ? reinterpret_cast<double*>(out->normals_.data()) : nullptr, n));
     int hc = 0;
-    Handle::check(o3ds_cloud_has_colors(Handle::get(), id_, &hc));
+    Handle::check(o3ds_cloud_has_colors(h_, id_, &hc));
     out->colors_.resize(hc ? n : 0);
-    if (n && hc) Handle::check(o3ds_cloud_get_colors(Handle::get(), id_, reinterpret_cast<double*>(out->colors_.data()), n));
+    if (n && hc) Handle::check(o3ds_cloud_get_colors(h_, id_, reinterpret_cast<double*>(out->colors_.data()), n));
   }
 
  private:
+  o3ds_handle h_ = nullptr;
   o3ds_cloud id_ = 0;
 };
 
@@ -255,18 +287,34 @@ class CloudRegistration {
   CloudRegistration() = default;
   virtual ~CloudRegistration() = default;
   virtual RegistrationResult registerClouds(const PointCloud& source, const PointCloud& target, const Transform& init) const = 0;
-  virtual void estimateNormalsOrCovariancesIfNeeded(PointCloud* cloud) const {}
+  virtual void estimateNormalsOrCovariancesIfNeeded(PointCloud* /*cloud*/) const {}
+  // -- two hooks for the device-resident scan-to-map path (o3ds_mapping.hpp); not part of the reference interface.  A registration
+  // the backend does not know returns false and the caller falls back to the two virtuals above on host clouds.
+  virtual bool toAbi(o3ds_icp_params*) const { return false; }  // parameters + estimator for o3ds_icp_register_dev
+  virtual bool estimateNormalsOrCovariancesIfNeededDev(o3ds_handle, o3ds_cloud) const { return false; }  // the same, in place on a device cloud
 };
+
+namespace o3ds_detail {
+inline o3ds_icp_params icpParams(int method, double maxCorrespondenceDistance, const open3d::pipelines::registration::ICPConvergenceCriteria& c) {
+  o3ds_icp_params p{};
+  p.max_correspondence_distance = maxCorrespondenceDistance;
+  p.max_iteration = c.max_iteration_;
+  p.method = method;
+  p.relative_fitness = c.relative_fitness_;
+  p.relative_rmse = c.relative_rmse_;
+  return p;
+}
+inline void checkNormalEstimationParameters(double maxRadius, int knn) {  // assert_gt x2, CloudRegistration.cpp:23-24,50-51
+  if (!(maxRadius > 0.0)) throw std::runtime_error("maxRadiusNormalEstimation_");
+  if (!(knn > 0)) throw std::runtime_error("knnNormalEstimation_");
+}
+}  // namespace o3ds_detail
 
 class RegistrationIcpPointToPlane : public CloudRegistration {
  public:
   // CloudRegistration.cpp:44-48: RegistrationICP(source, target, maxCorrespondenceDistance_, init, pointToPlane_, criteria)
   RegistrationResult registerClouds(const PointCloud& source, const PointCloud& target, const Transform& init) const final {
-    o3ds_icp_params p{};
-    p.max_correspondence_distance = maxCorrespondenceDistance_;
-    p.max_iteration = icpConvergenceCriteria_.max_iteration_;
-    p.relative_fitness = icpConvergenceCriteria_.relative_fitness_;
-    p.relative_rmse = icpConvergenceCriteria_.relative_rmse_;
+    const o3ds_icp_params p = o3ds_detail::icpParams(O3DS_ICP_POINT_TO_PLANE, maxCorrespondenceDistance_, icpConvergenceCriteria_);
     o3ds_icp_result r{};
     o3ds_detail::Handle::check(o3ds_icp_point_to_plane(o3ds_detail::Handle::get(), o3ds_detail::xyz(source.points_), source.points_.size(),
                                                        o3ds_detail::xyz(target.points_),
@@ -276,14 +324,20 @@ class RegistrationIcpPointToPlane : public CloudRegistration {
   }
   // CloudRegistration.cpp:49-56
   void estimateNormalsOrCovariancesIfNeeded(PointCloud* cloud) const final {
-    if (!(maxRadiusNormalEstimation_ > 0.0)) throw std::runtime_error("maxRadiusNormalEstimation_");  // assert_gt
-    if (!(knnNormalEstimation_ > 0)) throw std::runtime_error("knnNormalEstimation_");
+    o3ds_detail::checkNormalEstimationParameters(maxRadiusNormalEstimation_, knnNormalEstimation_);
     if (cloud->points_.empty()) return;
-    PointCloud bare;
-    bare.points_ = cloud->points_;
-    o3ds_detail::DevCloud d(bare);
-    o3ds_detail::Handle::check(o3ds_estimate_normals(o3ds_detail::Handle::get(), d.id(), maxRadiusNormalEstimation_, knnNormalEstimation_));
+    o3ds_detail::DevCloud d(*cloud);  // colours ride along; existing normals are overwritten, as [O3D] EstimateNormals does
+    o3ds_detail::Handle::check(o3ds_estimate_normals(d.handle(), d.id(), maxRadiusNormalEstimation_, knnNormalEstimation_));
     d.download(cloud);
+  }
+  bool toAbi(o3ds_icp_params* p) const final {
+    *p = o3ds_detail::icpParams(O3DS_ICP_POINT_TO_PLANE, maxCorrespondenceDistance_, icpConvergenceCriteria_);
+    return true;
+  }
+  bool estimateNormalsOrCovariancesIfNeededDev(o3ds_handle h, o3ds_cloud c) const final {
+    o3ds_detail::checkNormalEstimationParameters(maxRadiusNormalEstimation_, knnNormalEstimation_);
+    o3ds_detail::Handle::check(o3ds_estimate_normals(h, c, maxRadiusNormalEstimation_, knnNormalEstimation_));
+    return true;
   }
   static RegistrationResult toResult(const o3ds_icp_result& r) {
     RegistrationResult out;
@@ -307,11 +361,7 @@ class RegistrationIcpPointToPlane : public CloudRegistration {
 class RegistrationIcpGeneralized : public CloudRegistration {
  public:
   RegistrationResult registerClouds(const PointCloud& source, const PointCloud& target, const Transform& init) const final {
-    o3ds_icp_params p{};
-    p.max_correspondence_distance = maxCorrespondenceDistance_;
-    p.max_iteration = icpConvergenceCriteria_.max_iteration_;
-    p.relative_fitness = icpConvergenceCriteria_.relative_fitness_;
-    p.relative_rmse = icpConvergenceCriteria_.relative_rmse_;
+    const o3ds_icp_params p = o3ds_detail::icpParams(O3DS_ICP_GENERALIZED, maxCorrespondenceDistance_, icpConvergenceCriteria_);
     o3ds_icp_result r{};
     o3ds_detail::Handle::check(o3ds_icp_generalized(o3ds_detail::Handle::get(), o3ds_detail::xyz(source.points_),
                                                     source.HasNormals() ? o3ds_detail::xyz(source.normals_) : nullptr, source.points_.size(),
@@ -326,6 +376,15 @@ class RegistrationIcpGeneralized : public CloudRegistration {
     tmp.maxRadiusNormalEstimation_ = maxRadiusNormalEstimation_;
     tmp.estimateNormalsOrCovariancesIfNeeded(cloud);
   }
+  bool toAbi(o3ds_icp_params* p) const final {
+    *p = o3ds_detail::icpParams(O3DS_ICP_GENERALIZED, maxCorrespondenceDistance_, icpConvergenceCriteria_);
+    return true;
+  }
+  bool estimateNormalsOrCovariancesIfNeededDev(o3ds_handle h, o3ds_cloud c) const final {
+    o3ds_detail::checkNormalEstimationParameters(maxRadiusNormalEstimation_, knnNormalEstimation_);
+    o3ds_detail::Handle::check(o3ds_estimate_normals(h, c, maxRadiusNormalEstimation_, knnNormalEstimation_));
+    return true;
+  }
   double maxCorrespondenceDistance_ = 1.0;
   int knnNormalEstimation_ = 10;
   double maxRadiusNormalEstimation_ = 2.0;
@@ -336,11 +395,7 @@ class RegistrationIcpGeneralized : public CloudRegistration {
 class RegistrationIcpPointToPoint : public CloudRegistration {
  public:
   RegistrationResult registerClouds(const PointCloud& source, const PointCloud& target, const Transform& init) const final {
-    o3ds_icp_params p{};
-    p.max_correspondence_distance = maxCorrespondenceDistance_;
-    p.max_iteration = icpConvergenceCriteria_.max_iteration_;
-    p.relative_fitness = icpConvergenceCriteria_.relative_fitness_;
-    p.relative_rmse = icpConvergenceCriteria_.relative_rmse_;
+    const o3ds_icp_params p = o3ds_detail::icpParams(O3DS_ICP_POINT_TO_POINT, maxCorrespondenceDistance_, icpConvergenceCriteria_);
     o3ds_icp_result r{};
     o3ds_detail::Handle::check(o3ds_icp_point_to_point(o3ds_detail::Handle::get(), o3ds_detail::xyz(source.points_), source.points_.size(),
                                                        o3ds_detail::xyz(target.points_), target.points_.size(), o3ds_detail::pose_data(init),
@@ -348,6 +403,11 @@ class RegistrationIcpPointToPoint : public CloudRegistration {
     return RegistrationIcpPointToPlane::toResult(r);
   }
   void estimateNormalsOrCovariancesIfNeeded(PointCloud*) const final {}  // nothing to prepare (CloudRegistration.hpp:26 default)
+  bool toAbi(o3ds_icp_params* p) const final {
+    *p = o3ds_detail::icpParams(O3DS_ICP_POINT_TO_POINT, maxCorrespondenceDistance_, icpConvergenceCriteria_);
+    return true;
+  }
+  bool estimateNormalsOrCovariancesIfNeededDev(o3ds_handle, o3ds_cloud) const final { return true; }
   double maxCorrespondenceDistance_ = 1.0;
   open3d::pipelines::registration::ICPConvergenceCriteria icpConvergenceCriteria_;
 };
@@ -421,57 +481,84 @@ inline std::shared_ptr<PointCloud> transform(const Transform& T, const PointClou
 
 // ---- device-resident scan-to-map (ScanToMapRegistration.cpp:55-62 + Submap.cpp:39-75) ------------------------------
 // The reference keeps mapCloud_ on the host, re-crops it and rebuilds a KD-tree for every scan; this keeps the submap and
-// its index in HBM across scans, so scanToMapRegistration moves only the scan (<= 1.5 MB) over PCIe.
+// its index in HBM across scans, so scanToMapRegistration moves only the scan (<= 1.5 MB) over PCIe.  The map owns its backend
+// handle and a mutex (the reference's mapPointCloudMutex_, Submap.cpp:69), so it may be built, filled and read from different
+// threads.  o3d_slam::Submap (o3ds_mapping.hpp) wraps this in the reference's own class.
 class DeviceSubmap {
  public:
-  DeviceSubmap() { o3ds_detail::Handle::check(o3ds_cloud_upload(o3ds_detail::Handle::get(), nullptr, nullptr, 0, &map_)); }
+  DeviceSubmap() = default;
   ~DeviceSubmap() {
-    if (map_) o3ds_cloud_free(o3ds_detail::Handle::get(), map_);
+    if (map_) o3ds_cloud_free(h_.get(), map_);
   }
   DeviceSubmap(const DeviceSubmap&) = delete;
   DeviceSubmap& operator=(const DeviceSubmap&) = delete;
   // Submap::carve for the sparse map (Submap.cpp:109-125): the caller applies the every-N-scans gate; returns #removed points
   size_t carve(const PointCloud& rawScan, const Transform& mapToRangeSensor, const CroppingVolume& mapBuilderCropper, double voxelSize,
                double maxRaytracingLength, double truncationDistance, double minDotProductWithNormal) {
-    if (rawScan.IsEmpty()) return 0;
-    o3ds_detail::DevCloud s(rawScan);
+    std::lock_guard<std::mutex> lck(mutex_);
+    if (rawScan.IsEmpty() || sizeLocked() == 0) return 0;
+    o3ds_detail::DevCloud s(rawScan, h_.get());
     const o3ds_crop c = mapBuilderCropper.toAbi();
     const o3ds_carving_params cp{voxelSize, maxRaytracingLength, truncationDistance, minDotProductWithNormal};
     size_t removed = 0;
-    o3ds_detail::Handle::check(o3ds_map_carve(o3ds_detail::Handle::get(), map_, s.id(), o3ds_detail::pose_data(mapToRangeSensor), &c, &cp, &removed));
+    o3ds_detail::Handle::check(o3ds_map_carve(h_.get(), id(), s.id(), o3ds_detail::pose_data(mapToRangeSensor), &c, &cp, &removed));
+    ++version_;
     return removed;
   }
   // Submap::insertScan core (Submap.cpp:54,70-72)
   bool insertScan(const PointCloud& preProcessedScan, const Transform& mapToRangeSensor, double mapVoxelSize,
                   CroppingVolume* mapBuilderCropper, double maxCorrespondenceDistance) {
     if (preProcessedScan.IsEmpty()) return true;
-    o3ds_detail::DevCloud s(preProcessedScan);
+    std::lock_guard<std::mutex> lck(mutex_);
+    o3ds_detail::DevCloud s(preProcessedScan, h_.get());
     mapBuilderCropper->setPose(mapToRangeSensor);
     const o3ds_crop c = mapBuilderCropper->toAbi();
-    o3ds_detail::Handle::check(o3ds_map_insert_scan(o3ds_detail::Handle::get(), map_, s.id(), o3ds_detail::pose_data(mapToRangeSensor),
-                                                    mapVoxelSize, &c, maxCorrespondenceDistance));
+    o3ds_detail::Handle::check(o3ds_map_insert_scan(h_.get(), id(), s.id(), o3ds_detail::pose_data(mapToRangeSensor), mapVoxelSize, &c,
+                                                    maxCorrespondenceDistance));
+    ++version_;
     return true;
   }
-  // ScanToMapIcp::scanToMapRegistration (ScanToMapRegistration.cpp:55-62): crop volume fused into the search
-  RegistrationResult scanToMapRegistration(const PointCloud& scan, CroppingVolume* scanMatcherCropper, const Transform& mapToRangeSensor,
-                                           const Transform& initialGuess, const RegistrationIcpPointToPlane& reg) const {
-    size_t n = 0;
-    o3ds_detail::Handle::check(o3ds_cloud_size(o3ds_detail::Handle::get(), map_, &n, nullptr));
-    if (n == 0) throw std::runtime_error("map patch size is zero");  // assert_gt, ScanToMapRegistration.cpp:60
-    scanMatcherCropper->setPose(mapToRangeSensor);
-    const o3ds_crop c = scanMatcherCropper->toAbi();
-    o3ds_detail::DevCloud s(scan);
-    o3ds_icp_params p{};
-    p.max_correspondence_distance = reg.maxCorrespondenceDistance_;
-    p.max_iteration = reg.icpConvergenceCriteria_.max_iteration_;
-    p.relative_fitness = reg.icpConvergenceCriteria_.relative_fitness_;
-    p.relative_rmse = reg.icpConvergenceCriteria_.relative_rmse_;
+  // the isUseInitialMap_ branch of Submap::insertScan (Submap.cpp:47-52): map = voxelize(scan), no transform, no crop volume
+  void setInitialMap(const PointCloud& preProcessedScan, double mapVoxelSize, double maxCorrespondenceDistance) {
+    std::lock_guard<std::mutex> lck(mutex_);
+    o3ds_detail::DevCloud s(preProcessedScan, h_.get());
+    o3ds_cloud v = 0;
+    o3ds_detail::Handle::check(o3ds_voxel_down_sample(h_.get(), s.id(), mapVoxelSize, &v));  // voxel <= 0 returns a copy (helpers.cpp:108-110)
+    adopt(v, maxCorrespondenceDistance);
+  }
+  // mapCloud_.Transform(T) (Submap::transform, Submap.cpp:94-107); the NN index is rebuilt for the moved points
+  void transform(const Transform& T, double maxCorrespondenceDistance) {
+    std::lock_guard<std::mutex> lck(mutex_);
+    if (sizeLocked() == 0) return;
+    o3ds_cloud moved = 0;
+    o3ds_detail::Handle::check(o3ds_transform_cloud(h_.get(), id(), o3ds_detail::pose_data(T), &moved));
+    adopt(moved, maxCorrespondenceDistance);
+  }
+  // cloudRegistration->registerClouds(scan, crop(map), initialGuess) with the crop volume fused into the search
+  // (ScanToMapIcp::scanToMapRegistration, ScanToMapRegistration.cpp:55-62); params.method selects the estimator
+  RegistrationResult registerScan(const PointCloud& scan, const o3ds_crop& scanMatcherCrop, const Transform& initialGuess,
+                                  const o3ds_icp_params& params) const {
+    std::lock_guard<std::mutex> lck(mutex_);
+    if (sizeLocked() == 0) throw std::runtime_error("map patch size is zero");  // assert_gt, ScanToMapRegistration.cpp:60
+    o3ds_detail::DevCloud s(scan, h_.get());
     o3ds_icp_result r{};
-    o3ds_detail::Handle::check(o3ds_icp_point_to_plane_dev(o3ds_detail::Handle::get(), s.id(), map_, &c, o3ds_detail::pose_data(initialGuess), &p, &r));
+    o3ds_detail::Handle::check(o3ds_icp_register_dev(h_.get(), s.id(), map_, &scanMatcherCrop, o3ds_detail::pose_data(initialGuess), &params, &r));
     return RegistrationIcpPointToPlane::toResult(r);
   }
+  RegistrationResult scanToMapRegistration(const PointCloud& scan, CroppingVolume* scanMatcherCropper, const Transform& mapToRangeSensor,
+                                           const Transform& initialGuess, const CloudRegistration& reg) const {
+    o3ds_icp_params p{};
+    if (!reg.toAbi(&p)) throw std::runtime_error("scanToMapRegistration: this CloudRegistration is not known to the backend");
+    scanMatcherCropper->setPose(mapToRangeSensor);
+    return registerScan(scan, scanMatcherCropper->toAbi(), initialGuess, p);
+  }
   void getMapPointCloud(PointCloud* out) const {
-    o3ds_detail::DevCloud borrowed(map_);
+    std::lock_guard<std::mutex> lck(mutex_);
+    if (!map_) {
+      *out = PointCloud();
+      return;
+    }
+    o3ds_detail::DevCloud borrowed(map_, h_.get());
     try {
       borrowed.download(out);
     } catch (...) {
@@ -481,16 +568,38 @@ class DeviceSubmap {
     borrowed.release();
   }
   size_t size() const {
-    size_t n = 0;
-    o3ds_detail::Handle::check(o3ds_cloud_size(o3ds_detail::Handle::get(), map_, &n, nullptr));
-    return n;
+    std::lock_guard<std::mutex> lck(mutex_);
+    return sizeLocked();
+  }
+  // bumped by every mutation: lets a caller keep a host mirror and refresh it only when the device map changed
+  uint64_t version() const {
+    std::lock_guard<std::mutex> lck(mutex_);
+    return version_;
   }
 
   // saveToFile (output.cpp:39-47) of the device-resident map, rows narrowed on the device
   bool saveToFile(const std::string& filename) const;
 
  private:
+  o3ds_cloud id() {  // the (initially empty) device cloud, made on first use so that constructing a map needs no device
+    if (!map_) o3ds_detail::Handle::check(o3ds_cloud_upload(h_.get(), nullptr, nullptr, 0, &map_));
+    return map_;
+  }
+  size_t sizeLocked() const {
+    size_t n = 0;
+    if (map_) o3ds_detail::Handle::check(o3ds_cloud_size(h_.get(), map_, &n, nullptr));
+    return n;
+  }
+  void adopt(o3ds_cloud fresh, double maxCorrespondenceDistance) {
+    if (map_) o3ds_cloud_free(h_.get(), map_);
+    map_ = fresh;
+    if (maxCorrespondenceDistance > 0.0) o3ds_detail::Handle::check(o3ds_cloud_build_index(h_.get(), map_, maxCorrespondenceDistance, 0.0));
+    ++version_;
+  }
+  o3ds_detail::OwnedHandle h_;
+  mutable std::mutex mutex_;
   o3ds_cloud map_ = 0;
+  uint64_t version_ = 0;
 };
 
 // ---- egress: saveToFile (src/output.cpp:39-47) -----------------------------------------------------------------------
@@ -498,15 +607,16 @@ class DeviceSubmap {
 // float32 x y z (+ normal_x normal_y normal_z, + the packed rgb field, when present).  The device writes those
 // rows itself (o3ds_cloud_download_f32), so a map that lives in HBM is saved without the fp64 host copy.  Returns false when the
 // file cannot be written, as WritePointCloudToPCD does.
-inline bool saveDeviceCloudToFile(const std::string& filename, o3ds_cloud cloud) {
+inline bool saveDeviceCloudToFile(const std::string& filename, o3ds_cloud cloud, o3ds_handle h = nullptr) {
+  if (!h) h = o3ds_detail::Handle::get();
   const std::string name = filename.find(".pcd") == std::string::npos ? filename + ".pcd" : filename;
   size_t n = 0;
   int hn = 0, hc = 0;
-  o3ds_detail::Handle::check(o3ds_cloud_size(o3ds_detail::Handle::get(), cloud, &n, &hn));
-  o3ds_detail::Handle::check(o3ds_cloud_has_colors(o3ds_detail::Handle::get(), cloud, &hc));
+  o3ds_detail::Handle::check(o3ds_cloud_size(h, cloud, &n, &hn));
+  o3ds_detail::Handle::check(o3ds_cloud_has_colors(h, cloud, &hc));
   const size_t step = 12 + (hn ? 12 : 0) + (hc ? 4 : 0);
   std::vector<unsigned char> rows(n * step);
-  o3ds_detail::Handle::check(o3ds_cloud_download_f32(o3ds_detail::Handle::get(), cloud, rows.data(), n, step, 0, 4, 8, hn ? (size_t)12 : O3DS_NO_FIELD,
+  o3ds_detail::Handle::check(o3ds_cloud_download_f32(h, cloud, rows.data(), n, step, 0, 4, 8, hn ? (size_t)12 : O3DS_NO_FIELD,
                                                      hc ? step - 4 : O3DS_NO_FIELD, 1));
   std::FILE* f = std::fopen(name.c_str(), "wb");
   if (!f) return false;
@@ -525,8 +635,12 @@ inline bool saveDeviceCloudToFile(const std::string& filename, o3ds_cloud cloud)
 }
 inline bool saveToFile(const std::string& filename, const PointCloud& cloud) {
   o3ds_detail::DevCloud d(cloud);
-  return saveDeviceCloudToFile(filename, d.id());
+  return saveDeviceCloudToFile(filename, d.id(), d.handle());
 }
-inline bool DeviceSubmap::saveToFile(const std::string& filename) const { return saveDeviceCloudToFile(filename, map_); }
+inline bool DeviceSubmap::saveToFile(const std::string& filename) const {
+  std::lock_guard<std::mutex> lck(mutex_);
+  if (!map_) return o3d_slam::saveToFile(filename, PointCloud());
+  return saveDeviceCloudToFile(filename, map_, h_.get());
+}
 
 }  // namespace o3d_slam

@@ -4,7 +4,10 @@
 // (identical memory layout: std::vector<Eigen::Vector3d> is a contiguous double[3n]; Matrix4d is column-major).
 #pragma once
 #include <array>
+#include <chrono>
 #include <cstddef>
+#include <cstdint>
+#include <ratio>
 #include <vector>
 
 namespace open3d {
@@ -43,5 +46,25 @@ struct Transform {  // stand-in for Eigen::Isometry3d (Transform.hpp:15): column
   double tx() const { return m[12]; }
   double ty() const { return m[13]; }
   double tz() const { return m[14]; }
+  std::array<double, 3> translation() const { return {{m[12], m[13], m[14]}}; }
+  Transform operator*(const Transform& o) const {  // Isometry3d composition: (*this) * o
+    Transform r;
+    for (int c = 0; c < 4; ++c)
+      for (int row = 0; row < 4; ++row) {
+        double s = 0.0;
+        for (int k = 0; k < 4; ++k) s += m[k * 4 + row] * o.m[c * 4 + k];
+        r.m[c * 4 + row] = s;
+      }
+    return r;
+  }
 };
+// time.hpp:40-49: the 100-ns universal time scale the reference stamps scans with
+struct UniversalTimeScaleClock {
+  using rep = int64_t;
+  using period = std::ratio<1, 10000000>;
+  using duration = std::chrono::duration<rep, period>;
+  using time_point = std::chrono::time_point<UniversalTimeScaleClock>;
+  static constexpr bool is_steady = true;
+};
+using Time = UniversalTimeScaleClock::time_point;
 }  // namespace o3d_slam

@@ -1,5 +1,6 @@
-"""C++ host adapter (open3d_slam_amd/host/o3ds_adapter.hpp): the reference-named classes over the C-ABI.
-CPU: it compiles with plain g++ and its device-free checks pass.  GPU: the full self-checking program runs."""
+"""C++ host side (open3d_slam_amd/host/o3ds_adapter.hpp: CloudRegistration family, croppers, helpers, DeviceSubmap;
+o3ds_mapping.hpp: ScanToMapIcp, Submap, VoxelizedPointCloud and the remaining helpers): the reference-named classes over the C-ABI.
+CPU: both programs compile with plain g++ (-Wall -Wextra -Werror) and their device-free checks pass.  GPU: the full self-checking programs run."""
 import os
 import subprocess
 
@@ -9,15 +10,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIBDIR = os.path.join(ROOT, "open3d_slam_amd", "lib")
 
 
-@pytest.fixture(scope="module")
-def adapter_exe(tmp_path_factory):
+def _compile(tmp_path_factory, name):
     from open3d_slam_amd import build
 
     build.build_backend()
-    exe = str(tmp_path_factory.mktemp("adapter") / "test_adapter")
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_adapter.cpp"),
-                           "-L" + LIBDIR, "-lo3ds_backend", "-Wl,-rpath," + LIBDIR])
+    exe = str(tmp_path_factory.mktemp(name) / name)
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-pthread", "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-L" + LIBDIR, "-lo3ds_backend", "-Wl,-rpath," + LIBDIR])
     return exe
+
+
+@pytest.fixture(scope="module")
+def adapter_exe(tmp_path_factory):
+    return _compile(tmp_path_factory, "test_adapter")
+
+
+@pytest.fixture(scope="module")
+def mapping_exe(tmp_path_factory):
+    return _compile(tmp_path_factory, "test_mapping")
 
 
 def test_adapter_compiles_and_device_free_checks(adapter_exe):
@@ -29,5 +39,18 @@ def test_adapter_compiles_and_device_free_checks(adapter_exe):
 @pytest.mark.gpu
 def test_adapter_on_gpu(adapter_exe, tmp_path):
     out = subprocess.run([adapter_exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, O3DS_TEST_TMPDIR=str(tmp_path)))
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "gpu checks ok" in out.stdout
+
+
+def test_mapping_compiles_and_device_free_checks(mapping_exe):
+    out = subprocess.run([mapping_exe, "--no-gpu"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "no-gpu checks ok" in out.stdout
+
+
+@pytest.mark.gpu
+def test_mapping_on_gpu(mapping_exe, tmp_path):
+    out = subprocess.run([mapping_exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, O3DS_TEST_TMPDIR=str(tmp_path)))
     assert out.returncode == 0, out.stdout + out.stderr
     assert "gpu checks ok" in out.stdout
