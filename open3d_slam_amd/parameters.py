@@ -96,6 +96,8 @@ class MapperParameters:  # Parameters.hpp:158-178 (hot-path subset)
     minMovementBetweenMappingSteps_: float = 0.0
     isIgnoreMinRefinementFitness_: bool = False
     mapBuilder_: MapBuilderParameters = dataclasses.field(default_factory=MapBuilderParameters)
+    denseMapBuilder_: MapBuilderParameters = dataclasses.field(default_factory=MapBuilderParameters)
+    isBuildDenseMap_: bool = True
     isUseInitialMap_: bool = False
     isMergeScansIntoMap_: bool = True
 

@@ -1,4 +1,6 @@
-"""Submap map-fusion core (include/open3d_slam/Submap.hpp:38-39,71-90, src/Submap.cpp:39-75,138-144) on a device map."""
+"""Submap map-fusion core (include/open3d_slam/Submap.hpp:38-39,71-90, src/Submap.cpp:39-149) on a device map: the sparse map
+(insertScan, carve, transform) and the dense voxel map (insertScanDenseMap and its carving).  The C++ twin of this class is
+open3d_slam_amd/host/o3ds_mapping.hpp."""
 from __future__ import annotations
 
 import numpy as np
@@ -16,14 +18,70 @@ class Submap:
         self.mapCloud_ = PointCloud.from_numpy(be, np.zeros((0, 3)))
         self.mapToRangeSensor_ = np.eye(4)
         self.nScansInsertedMap_ = 0
+        self.nScansInsertedDenseMap_ = 0
+        self._denseMap = None  # o3ds_dense_map id, made on first use (Submap::update move-assigns a fresh VoxelizedPointCloud, Submap.cpp:211)
         self.update(self.params_)
 
     def setParameters(self, p: MapperParameters):  # Submap.cpp:146-149
         self.params_ = p
         self.update(p)
 
-    def update(self, p: MapperParameters):
+    def update(self, p: MapperParameters):  # Submap.cpp:208-216
         self.mapBuilderCropper_ = croppingVolumeFactory(p.mapBuilder_.cropper_)
+        self.denseMapCropper_ = croppingVolumeFactory(p.denseMapBuilder_.cropper_)
+        if self._denseMap is not None:
+            self.be.dense_map_free(self._denseMap)
+            self._denseMap = None
+
+    def _dense(self) -> int:
+        if self._denseMap is None:
+            self._denseMap = self.be.dense_map_create(self.params_.denseMapBuilder_.mapVoxelSize_)
+        return self._denseMap
+
+    def getDenseMapSize(self) -> int:
+        return 0 if self._denseMap is None else self.be.dense_map_size(self._denseMap)
+
+    def getDenseMapPointCloud(self) -> PointCloud:
+        """getDenseMap().toPointCloud() (Voxel.cpp:18-36): voxel means, ascending key order."""
+        return PointCloud(self.be, self.be.dense_map_to_cloud(self._dense()))
+
+    def insertScanDenseMap(self, rawScan: PointCloud, mapToRangeSensor, time=None, isPerformCarving: bool = False) -> bool:
+        """Submap.cpp:77-92: crop the raw scan with the dense-map volume (sensor frame), drop colours outside [0, 1]^3 (ColorRangeCropper,
+        default bounds), insert T * scan into the voxel map; every carveSpaceEveryNscans_-th call carve with the RAW scan (sensor
+        frame, as the reference passes it) from the map-frame sensor position (Submap.cpp:88,126-136)."""
+        be = self.be
+        T = np.array(mapToRangeSensor, dtype=np.float64)
+        self.denseMapCropper_.setPose(np.eye(4))
+        cropped = self.denseMapCropper_.crop(rawScan)
+        if cropped.HasColors():
+            col = cropped.colors_
+            ok = np.flatnonzero(np.all((col >= 0.0) & (col <= 1.0), axis=1)).astype(np.uint32)
+            if len(ok) != len(col):
+                kept = PointCloud(be, be.select_by_index(cropped.id, ok))
+                cropped.release()
+                cropped = kept
+        if not cropped.IsEmpty():
+            be.dense_map_insert(self._dense(), cropped.id, T)
+        cropped.release()
+        c = self.params_.denseMapBuilder_.carving_
+        if isPerformCarving and self.getDenseMapSize() > 0 and self.nScansInsertedDenseMap_ % c.carveSpaceEveryNscans_ == 1:
+            be.dense_map_carve(self._dense(), rawScan.id, T[:3, 3], None, radius=c.neighborhoodRadiusDenseMap_,
+                               max_length=c.maxRaytracingLength_, truncation=c.truncationDistance_)
+        self.nScansInsertedDenseMap_ += 1
+        return True
+
+    def transform(self, T):
+        """Submap::transform (Submap.cpp:94-107): the sparse map (its NN index is rebuilt), the dense map as VoxelizedPointCloud::transform
+        is written, mapToRangeSensor_ = mapToRangeSensor_ * T."""
+        T = np.array(T, dtype=np.float64)
+        if not self.mapCloud_.IsEmpty():
+            moved = PointCloud(self.be, self.be.transform_cloud(self.mapCloud_.id, T))
+            self.mapCloud_.release()
+            self.mapCloud_ = moved
+            self.be.build_index(self.mapCloud_.id, self.params_.scanMatcher_.icp_.maxCorrespondenceDistance_)
+        if self._denseMap is not None:
+            self.be.dense_map_transform(self._denseMap, T)
+        self.mapToRangeSensor_ = self.mapToRangeSensor_ @ T
 
     def getMapPointCloud(self) -> PointCloud:
         return self.mapCloud_
