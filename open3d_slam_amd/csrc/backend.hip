@@ -1617,16 +1617,41 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn) {
     const P4* p_sp = (const P4*)tmp.spts;
     P4* p_out = (P4*)c.nrm;
     constexpr bool kWide = sizeof(P4) > 16;  // f64 storage: half the threads per workgroup for the same LDS footprint
+    unsigned int* d_stats = nullptr;
+#ifdef O3DS_NRM_STATS
+    if (getenv("O3DS_NRM_STATS_FILE")) {
+      HIP_TRY(hipMalloc((void**)&d_stats, sizeof(unsigned int) * 8 * c.n));
+      HIP_TRY(hipMemset(d_stats, 0, sizeof(unsigned int) * 8 * c.n));
+    }
+#endif
+#define O3DS_NRM_LAUNCH(K, B, CAP)                                                                                  \
+  normals_kernel<P4, K, B><<<(int)std::min<size_t>((c.n + (B) - 1) / (B), (CAP)), B, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, \
+                                                                                                     max_nn, rmax, p_out, d_stats)
     if (max_nn <= 20) {  // the shipped configs' knn: 40 KB of LDS per workgroup instead of 64 KB, twice the wavefronts per SIMD
       constexpr int B = kWide ? 128 : 256;
-      normals_kernel<P4, 20, B><<<(int)std::min<size_t>((c.n + B - 1) / B, 8192), B, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, p_out);
+      O3DS_NRM_LAUNCH(20, B, 8192);
     } else if (max_nn <= 32) {
       constexpr int B = kWide ? 128 : 256;
-      normals_kernel<P4, 32, B><<<(int)std::min<size_t>((c.n + B - 1) / B, 8192), B, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, p_out);
+      O3DS_NRM_LAUNCH(32, B, 8192);
     } else {
-      constexpr int B = kWide ? 64 : 64;
-      normals_kernel<P4, 128, B><<<(int)std::min<size_t>((c.n + B - 1) / B, 16384), B, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, p_out);
+      constexpr int B = 64;
+      O3DS_NRM_LAUNCH(128, B, 16384);
     }
+#undef O3DS_NRM_LAUNCH
+#ifdef O3DS_NRM_STATS
+    if (d_stats) {
+      std::vector<unsigned int> hs(8 * c.n);
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      HIP_TRY(hipMemcpy(hs.data(), d_stats, sizeof(unsigned int) * hs.size(), hipMemcpyDeviceToHost));
+      (void)hipFree(d_stats);
+      if (FILE* f = fopen(getenv("O3DS_NRM_STATS_FILE"), "wb")) {
+        const double meta[2] = {tmp.grid.cell, (double)c.n};
+        fwrite(meta, sizeof(double), 2, f);
+        fwrite(hs.data(), sizeof(unsigned int), hs.size(), f);
+        fclose(f);
+      }
+    }
+#endif
   }
   HIP_TRY(hipGetLastError());
   dbg_sync(h, 16);

@@ -225,6 +225,10 @@ __host__ __device__ __forceinline__ unsigned long long pack_key(long long kx, lo
 }
 
 // mode 0: data-anchored ([O3D] VoxelDownSample: floor((p - origin)/v));  mode 1: world-anchored (floor(p * (1/v)))
+// (Packing the voxel coordinates relative to a known box -- the cloud's bounding box, or the box around a bounded cropping volume --
+// into ~30 bits and sorting those with Onesweep, 4 passes, instead of letting rocPRIM merge-sort the 63-bit keys (its choice below
+// 1 M elements, ~30 launches for the 700 k-point map) was measured and dropped: a 20 us Onesweep pass plus the memset of its
+// look-back state per pass made map_insert_scan 0.86 ms instead of 0.82 ms and voxel_down_sample 0.24 ms instead of 0.18 ms.)
 template <typename P4>
 __global__ __launch_bounds__(kBlock) void voxel_key_kernel(const P4* __restrict__ pts, size_t n, int mode, double ox, double oy, double oz, double v,
                                                            CropDev crop, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
@@ -268,10 +272,10 @@ __global__ __launch_bounds__(kBlock) void segment_mean_kernel(const P4* __restri
   using R = typename Scalar<P4>::type;
   for (size_t s = (size_t)blockIdx.x * kBlock + threadIdx.x; s < n_seg; s += (size_t)gridDim.x * kBlock) {
     const size_t b = (size_t)seg_start[s], e = (s + 1 < n_seg) ? (size_t)seg_start[s + 1] : n;
-    const bool pass = (keys[b] & kPassBit) != 0;
     // reference order: pass-through points first, voxel means after (helpers.cpp:151-181).  Sorted order has the
     // voxel segments first (n_seg - n_pass of them), pass-through segments (one point each, by original index) last.
     const size_t n_vox = n_seg - n_pass;
+    const bool pass = s >= n_vox;
     const size_t o = pass ? (s - n_vox) : (n_pass + s);
     double sx = 0, sy = 0, sz = 0, nx = 0, ny = 0, nz = 0;
     for (size_t j = b; j < e; ++j) {
@@ -493,8 +497,8 @@ __global__ __launch_bounds__(kBlock) void segment_last_kernel(const P4* __restri
                                                               size_t n, size_t n_pass, P4* __restrict__ out_col) {
   for (size_t s = (size_t)blockIdx.x * kBlock + threadIdx.x; s < n_seg; s += (size_t)gridDim.x * kBlock) {
     const size_t b = (size_t)seg_start[s], e = (s + 1 < n_seg) ? (size_t)seg_start[s + 1] : n;
-    const bool pass = (keys[b] & kPassBit) != 0;
     const size_t n_vox = n_seg - n_pass;
+    const bool pass = s >= n_vox;  // the pass-through segments (one point each) sort after all voxel segments
     const size_t o = pass ? (s - n_vox) : (n_pass + s);
     out_col[o] = col[vals[e - 1]];  // vals ascend inside a segment (stable sort of ascending indices)
   }
@@ -887,11 +891,19 @@ __device__ __forceinline__ void finish_normal(const P4& q, double nv[3], P4* out
 
 // One lane walks the rings around its point and keeps the max_nn-best SET in LDS slots sd[j * stride], sp_[j * stride]
 // (only the set matters for a covariance); nv = eigenvector of the smallest eigenvalue, not normalised.
-template <typename P4>
+template <typename P4, int KU>
 __device__ __forceinline__ void normal_one_lane(const P4& q, const GridDev& g, const P4* __restrict__ sp, double radius, int max_nn,
-                                                int rmax_cells, typename Scalar<P4>::type* sd, int* sp_, int stride, double nv[3]) {
+                                                int rmax_cells, typename Scalar<P4>::type* sd, int* sp_, int stride, double nv[3],
+                                                unsigned int* stats = nullptr) {
   using R = typename Scalar<P4>::type;
   const int* __restrict__ cs = g.cell_start;
+#ifdef O3DS_NRM_STATS  // development aid (scripts/normals_stats.py): per-point work counters and wavefront clocks
+  unsigned int st_cand = 0, st_acc = 0, st_rows = 0, st_ring = 0;
+  const unsigned long long st_t0 = clock64();
+#define O3DS_ST(x) x
+#else
+#define O3DS_ST(x)
+#endif
   const R qx = q.x, qy = q.y, qz = q.z;
   int cnt = 0, worst_slot = 0;
   R worst = (R)(radius * radius);  // candidates need d2 < worst
@@ -902,7 +914,9 @@ __device__ __forceinline__ void normal_one_lane(const P4& q, const GridDev& g, c
   mf = fmin(mf, fmin(fz - floor(fz), 1.0 - (fz - floor(fz))));
 
   auto offer = [&](R d2, int p, bool ok) {
+    O3DS_ST(st_cand += ok);
     if (ok && d2 < worst) {
+      O3DS_ST(++st_acc);
       const int slot = cnt < max_nn ? cnt : worst_slot;
       sd[slot * stride] = d2;
       sp_[slot * stride] = p;
@@ -910,11 +924,27 @@ __device__ __forceinline__ void normal_one_lane(const P4& q, const GridDev& g, c
       if (cnt == max_nn) {  // list full: the bound becomes the current maximum
         R m = sd[0];
         int ms = 0;
-        for (int j = 1; j < max_nn; ++j) {
-          const R v = sd[j * stride];
-          if (v > m) {
-            m = v;
-            ms = j;
+        if constexpr (KU > 0) {
+          // all KU slot reads go out back to back (constant LDS offsets) and are waited for once; with a run-time trip count the
+          // loop was one LDS round trip per slot, and since a wavefront sweeps whenever ANY of its lanes accepts a candidate --
+          // practically at every candidate -- those ~2400 clocks per sweep were 80 % of the kernel (scripts/normals_stats.py)
+          R v[KU > 0 ? KU : 1];
+#pragma unroll
+          for (int j = 1; j < KU; ++j) v[j] = sd[j * stride];
+#pragma unroll
+          for (int j = 1; j < KU; ++j) {
+            if (j < max_nn && v[j] > m) {
+              m = v[j];
+              ms = j;
+            }
+          }
+        } else {
+          for (int j = 1; j < max_nn; ++j) {
+            const R v = sd[j * stride];
+            if (v > m) {
+              m = v;
+              ms = j;
+            }
           }
         }
         worst = m;
@@ -949,6 +979,7 @@ __device__ __forceinline__ void normal_one_lane(const P4& q, const GridDev& g, c
       const double lb = g.cell * ((double)(ring - 1) + mf) * (1.0 - 1e-6);
       if ((double)worst <= lb * lb) break;  // the k-th best (or r^2) already lies inside the searched block
     }
+    O3DS_ST(st_ring = ring);
     for (int dz = -ring; dz <= ring; ++dz) {
       const int z = iz + dz;
       if ((unsigned)z >= (unsigned)g.nz) continue;
@@ -962,6 +993,7 @@ __device__ __forceinline__ void normal_one_lane(const P4& q, const GridDev& g, c
         if (left <= 0.0) continue;
         const double wx = sqrt(left) * g.inv_cell * (1.0 + 1e-6);         // in cells
         const int row = (z * g.ny + y) * g.nx;
+        O3DS_ST(++st_rows);
         const bool shell = (dz == -ring || dz == ring || dy == -ring || dy == ring);
         if (shell || ring == 0) {
           const int x0 = max(max(ix - ring, 0), (int)floor(fx - wx)), x1 = min(min(ix + ring, g.nx - 1), (int)floor(fx + wx));
@@ -974,6 +1006,7 @@ __device__ __forceinline__ void normal_one_lane(const P4& q, const GridDev& g, c
       }
     }
   }
+  O3DS_ST(const unsigned long long st_t1 = clock64());
   double cov[6] = {1, 0, 0, 1, 0, 1};
   if (cnt >= 3) {
     double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1007,16 +1040,28 @@ __device__ __forceinline__ void normal_one_lane(const P4& q, const GridDev& g, c
     cov[5] = c[8] - c[2] * c[2];
   }
   fast_eigen3x3_min(cov, nv);
+#ifdef O3DS_NRM_STATS
+  if (stats) {
+    const unsigned long long st_t2 = clock64();
+    stats[0] = st_ring, stats[1] = st_rows, stats[2] = st_cand, stats[3] = st_acc;
+    stats[4] = (unsigned int)(st_t1 - st_t0), stats[5] = (unsigned int)(st_t2 - st_t1), stats[6] = (unsigned int)cnt;
+    stats[7] = (unsigned int)(st_t0 & 0xffffffffu);
+  }
+#endif
+#undef O3DS_ST
 }
 
-// One thread per point.  (A variant with 8 lanes per point -- candidates of the 3x3x3 block collected into LDS stacks, the
+// One thread per point.  (Fetching the cell_start pairs of 4 or 8 rows of a ring in one batch instead of one dependent round trip per
+// row -- for all rings, or only from ring 2 on, where a sparse neighbourhood walks 200+ mostly empty rows -- measured slower: 0.284 /
+// 0.300 ms vs 0.254 ms; the row extents of a batch come from a staler bound and the slowest wavefront got slower, not faster.)
+// (A variant with 8 lanes per point -- candidates of the 3x3x3 block collected into LDS stacks, the
 // max_nn-th distance found by bisection on the float bit pattern, lane-parallel cumulants -- was exact but slower on the
 // ~100 k-point voxel-filtered scans of the config-2 stream: 0.73 ms vs 0.38 ms; at that size this kernel already fills the
 // chip and the selection overhead dominates.  Removed.)
 template <typename P4, int KMAX, int BLK>
 __global__ __launch_bounds__(BLK) void normals_kernel(const P4* __restrict__ pts /* original order */, size_t n, GridDev g,
                                                       const P4* __restrict__ sp /* sorted by cell */, double radius, int max_nn, int rmax_cells,
-                                                      P4* __restrict__ out_nrm) {
+                                                      P4* __restrict__ out_nrm, unsigned int* __restrict__ stats = nullptr) {
   using R = typename Scalar<P4>::type;
   __shared__ R s_d[KMAX][BLK];
   __shared__ int s_p[KMAX][BLK];
@@ -1027,7 +1072,7 @@ __global__ __launch_bounds__(BLK) void normals_kernel(const P4* __restrict__ pts
   for (size_t j = (size_t)blockIdx.x * BLK + tid; j < n; j += (size_t)gridDim.x * BLK) {
     const P4 q = sp[j];
     double nv[3];
-    normal_one_lane<P4>(q, g, sp, radius, max_nn, rmax_cells, &s_d[0][tid], &s_p[0][tid], BLK, nv);
+    normal_one_lane<P4, (KMAX <= 32 ? KMAX : 0)>(q, g, sp, radius, max_nn, rmax_cells, &s_d[0][tid], &s_p[0][tid], BLK, nv, stats ? stats + 8 * j : nullptr);
     finish_normal<P4>(q, nv, &out_nrm[(size_t)q.i]);
   }
 }
