@@ -991,17 +991,25 @@ __device__ __forceinline__ void normal_one_lane(const P4& q, const GridDev& g, c
         const double gy = gap(dy, fry);
         const double left = (double)worst - (gz * gz + gy * gy) * cell2;  // what the x-offset may still use
         if (left <= 0.0) continue;
-        const double wx = sqrt(left) * g.inv_cell * (1.0 + 1e-6);         // in cells
         const int row = (z * g.ny + y) * g.nx;
         O3DS_ST(++st_rows);
         const bool shell = (dz == -ring || dz == ring || dy == -ring || dy == ring);
         if (shell || ring == 0) {
+          const double wx = sqrt(left) * g.inv_cell * (1.0 + 1e-6);  // in cells
           const int x0 = max(max(ix - ring, 0), (int)floor(fx - wx)), x1 = min(min(ix + ring, g.nx - 1), (int)floor(fx + wx));
           if (x0 <= x1) scan(cs[row + x0], cs[row + x1 + 1]);
-        } else {  // interior rows: only the two end cells are new
+        } else {
+          // interior rows: only the two end cells are new.  Both ends are tested on squared gaps (no square root) and their four
+          // cell_start values are fetched in one batch: at ring 5-6 of a sparse neighbourhood a lane walks 150+ such rows, nearly
+          // all empty, and one memory round trip per end was what the slowest wavefronts of the kernel spent their time on.
           const int xl = ix - ring, xr = ix + ring;
-          if ((unsigned)xl < (unsigned)g.nx && gap(-ring, frx) < wx) scan(cs[row + xl], cs[row + xl + 1]);
-          if ((unsigned)xr < (unsigned)g.nx && gap(ring, frx) < wx) scan(cs[row + xr], cs[row + xr + 1]);
+          const double w2 = left * g.inv_cell * g.inv_cell * (1.0 + 4e-6);  // (x-reach in cells)^2, inflated like wx above
+          const double gl = gap(-ring, frx), gr = gap(ring, frx);
+          const bool okl = (unsigned)xl < (unsigned)g.nx && gl * gl < w2, okr = (unsigned)xr < (unsigned)g.nx && gr * gr < w2;
+          const int il = okl ? row + xl : 0, ir = okr ? row + xr : 0;
+          const int sl = cs[il], el = cs[il + 1], sr = cs[ir], er = cs[ir + 1];
+          if (okl) scan(sl, el);
+          if (okr) scan(sr, er);
         }
       }
     }
@@ -1053,7 +1061,11 @@ __device__ __forceinline__ void normal_one_lane(const P4& q, const GridDev& g, c
 
 // One thread per point.  (Fetching the cell_start pairs of 4 or 8 rows of a ring in one batch instead of one dependent round trip per
 // row -- for all rings, or only from ring 2 on, where a sparse neighbourhood walks 200+ mostly empty rows -- measured slower: 0.284 /
-// 0.300 ms vs 0.254 ms; the row extents of a batch come from a staler bound and the slowest wavefront got slower, not faster.)
+// 0.300 ms vs 0.254 ms; the row extents of a batch come from a staler bound and the slowest wavefront got slower, not faster.
+// Queuing the segments a lane finds (8 or 16 per lane in LDS) and scanning the queue at the end of a ring, so that the lanes scan their
+// k-th own segment together instead of the wavefront scanning at every row any lane found something in: 0.286 / 0.254 ms vs 0.259 ms.
+// What the slowest wavefronts pay for is neither the row walk nor the scattered scans but the sweep after every accepted candidate:
+// with 64 lanes some lane accepts at practically every candidate -- see scripts/normals_stats.py.)
 // (A variant with 8 lanes per point -- candidates of the 3x3x3 block collected into LDS stacks, the
 // max_nn-th distance found by bisection on the float bit pattern, lane-parallel cumulants -- was exact but slower on the
 // ~100 k-point voxel-filtered scans of the config-2 stream: 0.73 ms vs 0.38 ms; at that size this kernel already fills the
@@ -1072,7 +1084,8 @@ __global__ __launch_bounds__(BLK) void normals_kernel(const P4* __restrict__ pts
   for (size_t j = (size_t)blockIdx.x * BLK + tid; j < n; j += (size_t)gridDim.x * BLK) {
     const P4 q = sp[j];
     double nv[3];
-    normal_one_lane<P4, (KMAX <= 32 ? KMAX : 0)>(q, g, sp, radius, max_nn, rmax_cells, &s_d[0][tid], &s_p[0][tid], BLK, nv, stats ? stats + 8 * j : nullptr);
+    normal_one_lane<P4, (KMAX <= 32 ? KMAX : 0)>(q, g, sp, radius, max_nn, rmax_cells, &s_d[0][tid], &s_p[0][tid], BLK, nv,
+                                                 stats ? stats + 8 * j : nullptr);
     finish_normal<P4>(q, nv, &out_nrm[(size_t)q.i]);
   }
 }
