@@ -229,7 +229,9 @@ int exclusive_scan_int(o3ds_handle h, const int* in, int* out, size_t m) {
   int* sums = nullptr;
   TMP_ALLOC(sums, sizeof(int) * (size_t)nb);
   scan_local_kernel<<<nb, kBlock, 0, h->stream>>>(in, out, sums, m);
-  if (nb > 1) {
+  if (nb > 1 && nb <= kScanFusedBlocks) {
+    scan_add_fused_kernel<<<nb, kBlock, 0, h->stream>>>(out, sums, m);
+  } else if (nb > 1) {
     scan_sums_kernel<<<1, kBlock, 0, h->stream>>>(sums, nb);
     scan_add_kernel<<<nb, kBlock, 0, h->stream>>>(out, sums, m);
   }
@@ -290,14 +292,13 @@ int build_grid_t(o3ds_handle h, const P4* pts, const P4* nrm, size_t n, double c
   g.nz = (int)nz;
   int *counts = nullptr, *cursor = nullptr, *cell_id = nullptr, *cell_start = nullptr;
   void *spts = nullptr, *snrm = nullptr;
-  TMP_ALLOC(counts, sizeof(int) * (ncell + 1));
-  TMP_ALLOC(cursor, sizeof(int) * ncell);
+  TMP_ALLOC(counts, sizeof(int) * (2 * ncell + 1));  // [counts: ncell + 1 | cursor: ncell], cleared by one memset
+  cursor = counts + ncell + 1;
   TMP_ALLOC(cell_id, sizeof(int) * n);
   HIP_TRY(hipMallocAsync((void**)&cell_start, sizeof(int) * (ncell + 1 + 4), h->stream));  // +4: the search reads rows as unaligned 16-B vectors
   HIP_TRY(hipMallocAsync((void**)&spts, sizeof(P4) * n, h->stream));
   if (nrm) HIP_TRY(hipMallocAsync((void**)&snrm, sizeof(P4) * n, h->stream));
-  HIP_TRY(hipMemsetAsync(counts, 0, sizeof(int) * (ncell + 1), h->stream));
-  HIP_TRY(hipMemsetAsync(cursor, 0, sizeof(int) * ncell, h->stream));
+  HIP_TRY(hipMemsetAsync(counts, 0, sizeof(int) * (2 * ncell + 1), h->stream));
   cell_count_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(pts, n, g, counts, cell_id);
   rc = exclusive_scan_int(h, counts, cell_start, ncell + 1);
   if (rc) return rc;
@@ -1467,8 +1468,7 @@ int crop_t(o3ds_handle h, const CloudRec& in, const CropDev& crop, CloudRec& out
   int *flags = nullptr, *pos = nullptr;
   TMP_ALLOC(flags, sizeof(int) * (in.n + 1));
   TMP_ALLOC(pos, sizeof(int) * (in.n + 1));
-  HIP_TRY(hipMemsetAsync(flags + in.n, 0, sizeof(int), h->stream));
-  crop_flag_kernel<P4><<<grid_for(in.n), kBlock, 0, h->stream>>>((const P4*)in.pts, in.n, crop, flags);
+  crop_flag_kernel<P4><<<grid_for(in.n), kBlock, 0, h->stream>>>((const P4*)in.pts, in.n, crop, flags);  // also writes the sentinel flags[n] = 0
   int rc = exclusive_scan_int(h, flags, pos, in.n + 1);
   if (rc) return rc;
   int total = 0;
@@ -1524,8 +1524,7 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
   void* temp = nullptr;
   TMP_ALLOC(temp, temp_bytes ? temp_bytes : 16);
   HIP_TRY(rocprim::radix_sort_pairs(temp, temp_bytes, k0, k1, v0, v1, n, 0, 64, h->stream));
-  HIP_TRY(hipMemsetAsync(head + n, 0, sizeof(int), h->stream));
-  segment_head_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(k1, n, head);
+  segment_head_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(k1, n, head);  // also writes the sentinel head[n] = 0
   first_pass_kernel<<<1, 64, 0, h->stream>>>(k1, n, d_scalar);
   int rc = exclusive_scan_int(h, head, seg_id, n + 1);
   if (rc) return rc;

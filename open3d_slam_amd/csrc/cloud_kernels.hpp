@@ -121,6 +121,7 @@ __global__ __launch_bounds__(kBlock) void crop_flag_kernel(const P4* __restrict_
     const P4 p = pts[i];
     flags[i] = crop_contains(crop, (double)p.x, (double)p.y, (double)p.z) ? 1 : 0;
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0) flags[n] = 0;  // sentinel: the exclusive scan of n + 1 flags ends with the total
 }
 // stable compaction: out[pos[i]] = in[i] where flags[i]; `want` selects flag value 1 (inside) or 0 (outside, pos = i - pos[i])
 template <typename P4>
@@ -253,6 +254,7 @@ __global__ __launch_bounds__(kBlock) void voxel_key_kernel(const P4* __restrict_
 __global__ __launch_bounds__(kBlock) void segment_head_kernel(const unsigned long long* __restrict__ keys, size_t n, int* __restrict__ head) {
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
     head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) head[n] = 0;  // sentinel: the exclusive scan of n + 1 heads ends with the segment count
 }
 // seg_start[seg_id] = i for every head (seg ids from the exclusive scan of head)
 __global__ __launch_bounds__(kBlock) void segment_start_kernel(const int* __restrict__ head, const int* __restrict__ seg_id, size_t n,

@@ -144,6 +144,26 @@ __global__ __launch_bounds__(kBlock) void scan_sums_kernel(int* __restrict__ sum
     off += v;
   }
 }
+// phases 2 and 3 in one launch for up to kScanFusedBlocks blocks: every block adds up the block sums in front of it itself (at most
+// a few thousand ints, read once per block and L2-resident) instead of waiting for a one-block scan of them -- a launch less per
+// scan, and the per-scan pipeline of a lidar frame runs ten scans
+constexpr int kScanFusedBlocks = 4096;
+__global__ __launch_bounds__(kBlock) void scan_add_fused_kernel(int* __restrict__ out, const int* __restrict__ sums, size_t m) {
+  __shared__ int s_part[kBlock / 64];
+  int t = 0;
+  for (int i = threadIdx.x; i < (int)blockIdx.x; i += kBlock) t += sums[i];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = t;
+  __syncthreads();
+  int off = 0;
+#pragma unroll
+  for (int k = 0; k < kBlock / 64; ++k) off += s_part[k];
+  const size_t base = (size_t)blockIdx.x * kScanPerBlock + (size_t)threadIdx.x * 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (base + k < m) out[base + k] += off;
+}
 __global__ __launch_bounds__(kBlock) void scan_add_kernel(int* __restrict__ out, const int* __restrict__ sums, size_t m) {
   const size_t base = (size_t)blockIdx.x * kScanPerBlock + (size_t)threadIdx.x * 4;
   const int off = sums[blockIdx.x];
