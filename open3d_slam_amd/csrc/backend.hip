@@ -36,7 +36,47 @@ struct CloudRec {
   int* cell_start = nullptr;
   void* spts = nullptr;
   void* snrm = nullptr;
+  // A box that is known to contain every point (not necessarily tight): set where a bounding box has been computed anyway
+  // (VoxelDownSample, an index build) and carried to clouds derived from it (subsets, voxel means, rigid placements, unions), so
+  // that the next index build of the per-scan pipeline does not pay a reduction kernel + read-back + host sync for it again.
+  bool has_box = false;
+  double bmn[3] = {0, 0, 0}, bmx[3] = {0, 0, 0};
 };
+
+void box_inflate(CloudRec& c) {  // stored values are rounded (f32 storage, f64 -> f32 of means / placements): keep the box conservative
+  for (int a = 0; a < 3; ++a) {
+    const double pad = 1e-5 * (std::fabs(c.bmn[a]) + std::fabs(c.bmx[a]) + (c.bmx[a] - c.bmn[a])) + 1e-9;
+    c.bmn[a] -= pad;
+    c.bmx[a] += pad;
+  }
+}
+void box_copy(CloudRec& to, const CloudRec& from) {
+  to.has_box = from.has_box;
+  for (int a = 0; a < 3; ++a) to.bmn[a] = from.bmn[a], to.bmx[a] = from.bmx[a];
+}
+void box_union(CloudRec& to, const CloudRec& a, const CloudRec& b) {  // of two non-empty clouds; an empty one contributes nothing
+  if (a.n == 0) return box_copy(to, b);
+  if (b.n == 0) return box_copy(to, a);
+  to.has_box = a.has_box && b.has_box;
+  for (int k = 0; k < 3; ++k) to.bmn[k] = std::min(a.bmn[k], b.bmn[k]), to.bmx[k] = std::max(a.bmx[k], b.bmx[k]);
+}
+void box_transform(CloudRec& to, const CloudRec& from, const double T[16]) {  // box of the 8 placed corners, inflated
+  to.has_box = from.has_box;
+  if (!from.has_box) return;
+  for (int a = 0; a < 3; ++a) to.bmn[a] = 1e300, to.bmx[a] = -1e300;
+  for (int k = 0; k < 8; ++k) {
+    const double x = (k & 1) ? from.bmx[0] : from.bmn[0], y = (k & 2) ? from.bmx[1] : from.bmn[1], z = (k & 4) ? from.bmx[2] : from.bmn[2];
+    const double w = T[3] * x + T[7] * y + T[11] * z + T[15];
+    for (int a = 0; a < 3; ++a) {
+      const double v = (T[a] * x + T[4 + a] * y + T[8 + a] * z + T[12 + a]) / w;
+      to.bmn[a] = std::min(to.bmn[a], v);
+      to.bmx[a] = std::max(to.bmx[a], v);
+    }
+  }
+  for (int a = 0; a < 3; ++a)
+    if (!std::isfinite(to.bmn[a]) || !std::isfinite(to.bmx[a])) to.has_box = false;
+  if (to.has_box) box_inflate(to);
+}
 
 constexpr int kMaxPassBlocks = 4096;  // capacity of the partial-record buffer (rows per pass <= pass_rows <= this)
 constexpr size_t kMaxCells = (size_t)1 << 27;  // 512 MiB of cell_start at most
@@ -265,11 +305,21 @@ int bbox_of(o3ds_handle h, const P4* pts, size_t n, double mn[3], double mx[3]) 
 // given) re-stored in cell order.  Output buffers are allocated here; the caller owns them.
 template <typename P4>
 int build_grid_t(o3ds_handle h, const P4* pts, const P4* nrm, size_t n, double cell, GridDev* out_grid, int** out_cell_start, void** out_spts,
-                 void** out_snrm) {
+                 void** out_snrm, CloudRec* box /* in: a known box, if has_box; out: the box used */) {
   if (n == 0) return fail(h, O3DS_ERR_EMPTY, "build_index: empty cloud");
   double mn[3], mx[3];
-  int rc = bbox_of<P4>(h, pts, n, mn, mx);
-  if (rc) return rc;
+  int rc = O3DS_OK;
+  static const bool no_box_cache = getenv("O3DS_NO_BOX_CACHE") != nullptr;  // debugging aid: always reduce
+  if (box && box->has_box && !no_box_cache) {
+    for (int a = 0; a < 3; ++a) mn[a] = box->bmn[a], mx[a] = box->bmx[a];
+  } else {
+    rc = bbox_of<P4>(h, pts, n, mn, mx);
+    if (rc) return rc;
+    if (box) {
+      box->has_box = true;
+      for (int a = 0; a < 3; ++a) box->bmn[a] = mn[a], box->bmx[a] = mx[a];
+    }
+  }
   for (int a = 0; a < 3; ++a)
     if (!std::isfinite(mn[a]) || !std::isfinite(mx[a])) return fail(h, O3DS_ERR_INVALID_ARG, "build_index: non-finite coordinates");
   size_t nx, ny, nz;
@@ -316,7 +366,7 @@ int build_grid_t(o3ds_handle h, const P4* pts, const P4* nrm, size_t n, double c
 template <typename P4>
 int build_index_t(o3ds_handle h, CloudRec& c, double cell) {
   free_index(h, c);
-  int rc = build_grid_t<P4>(h, (const P4*)c.pts, (const P4*)c.nrm, c.n, cell, &c.grid, &c.cell_start, &c.spts, &c.snrm);
+  int rc = build_grid_t<P4>(h, (const P4*)c.pts, (const P4*)c.nrm, c.n, cell, &c.grid, &c.cell_start, &c.spts, &c.snrm, &c);
   if (rc) return rc;
   c.has_index = true;
   return O3DS_OK;
@@ -1464,6 +1514,7 @@ template <typename P4>
 int crop_t(o3ds_handle h, const CloudRec& in, const CropDev& crop, CloudRec& out) {
   out.precision = in.precision;
   out.n = 0;
+  box_copy(out, in);  // a subset
   if (in.n == 0) return O3DS_OK;
   int *flags = nullptr, *pos = nullptr;
   TMP_ALLOC(flags, sizeof(int) * (in.n + 1));
@@ -1507,7 +1558,13 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
     ox = mn[0] - voxel * 0.5;
     oy = mn[1] - voxel * 0.5;
     oz = mn[2] - voxel * 0.5;
+    out.has_box = true;  // voxel means lie in the box of the points they average
+    for (int a = 0; a < 3; ++a) out.bmn[a] = mn[a], out.bmx[a] = mx[a];
+    if (!std::isfinite(mn[0] + mn[1] + mn[2] + mx[0] + mx[1] + mx[2])) out.has_box = false;
+  } else {
+    box_copy(out, in);
   }
+  if (out.has_box) box_inflate(out);
   unsigned long long *k0 = nullptr, *k1 = nullptr, *d_scalar = nullptr;
   uint32_t *v0 = nullptr, *v1 = nullptr;
   int *head = nullptr, *seg_id = nullptr, *seg_start = nullptr;
@@ -1565,6 +1622,7 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn) {
   tmp.n = c.n;
   tmp.precision = c.precision;
   tmp.pts = c.pts;  // borrowed
+  box_copy(tmp, c);
   int rc = O3DS_OK;
   const bool reuse = h->nrm_cell > 0.0 && h->nrm_radius == radius && h->nrm_knn == max_nn && h->nrm_age < 32 &&
                      (double)c.n <= 1.25 * (double)h->nrm_n && (double)c.n >= 0.75 * (double)h->nrm_n;
@@ -1656,6 +1714,7 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn) {
   dbg_sync(h, 16);
   tmp.pts = nullptr;
   free_index(h, tmp);
+  box_copy(c, tmp);  // the box an index build reduced is kept for the cloud's next index
   free_index(h, c);  // the cloud's own index (if any) no longer matches its normals
   return O3DS_OK;
 }
@@ -1664,6 +1723,7 @@ template <typename P4>
 int transform_t(o3ds_handle h, const CloudRec& in, const double T[16], CloudRec& out) {
   out.precision = in.precision;
   out.n = in.n;
+  box_transform(out, in, T);
   if (in.n == 0) return O3DS_OK;
   Mat34 M;
   for (int r = 0; r < 3; ++r)
@@ -1832,6 +1892,8 @@ int append_t(o3ds_handle h, CloudRec& map, const CloudRec& add) {
   const bool keep_nrm = (map.n == 0 || map.nrm) && add.nrm;
   const bool keep_col = (map.n == 0 || map.col) && add.col;  // the same rule for colors_
   const size_t n = map.n + add.n;
+  CloudRec joined;
+  box_union(joined, map, add);
   void *np = nullptr, *nn = nullptr, *nc = nullptr;
   if (n > 0) HIP_TRY(hipMallocAsync((void**)&np, sizeof(P4) * n, h->stream));
   if (keep_nrm && n > 0) HIP_TRY(hipMallocAsync((void**)&nn, sizeof(P4) * n, h->stream));
@@ -1856,6 +1918,7 @@ int append_t(o3ds_handle h, CloudRec& map, const CloudRec& add) {
   map.nrm = nn;
   map.col = nc;
   map.n = n;
+  box_copy(map, joined);
   return O3DS_OK;
 }
 
@@ -1924,6 +1987,7 @@ int o3ds_select_by_index(o3ds_handle h, o3ds_cloud in, const uint32_t* keep_idx,
   CloudRec o;
   o.precision = c->precision;
   o.n = m;
+  box_copy(o, *c);  // a subset
   if (m) {
     uint32_t* d_idx = nullptr;
     const size_t psz = p4_size(c->precision);
@@ -2014,6 +2078,7 @@ int o3ds_cloud_undistort(o3ds_handle h, o3ds_cloud cloud, const double linear_ve
     c->nrm = nullptr;
   }
   free_index(h, *c);
+  c->has_box = false;  // the points moved
   return O3DS_OK;
 }
 
