@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <mutex>
@@ -106,6 +107,7 @@ struct o3ds_context {
   double* d_partials = nullptr;     // [kMaxPassBlocks][kRec]
   IcpStateDev* d_state = nullptr;
   IcpStateDev* h_state = nullptr;   // pinned, mapped
+  char* h_pin = nullptr;            // pinned block the small device -> host read-backs land in (read_back)
   IcpStateDev* h_state_dev = nullptr;  // the device's view of h_state
   // step-wise ICP session
   bool session = false;
@@ -160,6 +162,32 @@ int fail(o3ds_handle h, int code, const std::string& msg) {
 
 #define CHECK_HANDLE(h) \
   if (!(h)) return fail(nullptr, O3DS_ERR_BAD_HANDLE, "null handle")
+
+// ---- small read-backs ---------------------------------------------------------------------------------------------
+// Sizes, counts and bounding boxes that the host needs go through a pinned block owned by the handle: a D2H copy into pageable
+// memory is staged and waited for inside the runtime (tens of microseconds for four bytes -- a dozen of them per lidar frame);
+// into pinned memory it is an ordinary stream operation, and one synchronisation serves all items of a call.
+constexpr size_t kPinBytes = 64 << 10;
+struct D2H {
+  void* dst;
+  const void* src;
+  size_t bytes;
+};
+int read_back(o3ds_handle h, std::initializer_list<D2H> items) {
+  size_t off = 0;
+  for (const D2H& it : items) {
+    if (off + it.bytes > kPinBytes) return fail(h, O3DS_ERR_INVALID_ARG, "read_back: item list exceeds the pinned block");
+    HIP_TRY(hipMemcpyAsync(h->h_pin + off, it.src, it.bytes, hipMemcpyDeviceToHost, h->stream));
+    off += (it.bytes + 15) & ~(size_t)15;
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  off = 0;
+  for (const D2H& it : items) {
+    memcpy(it.dst, h->h_pin + off, it.bytes);
+    off += (it.bytes + 15) & ~(size_t)15;
+  }
+  return O3DS_OK;
+}
 
 // ---- scratch arena ------------------------------------------------------------------------------------------------
 // Temporaries (scan block sums, flags, sort buffers, staging copies ...) are bump-allocated from blocks that persist
@@ -287,8 +315,8 @@ int bbox_of(o3ds_handle h, const P4* pts, size_t n, double mn[3], double mx[3]) 
   TMP_ALLOC(d, sizeof(double) * 6 * (size_t)g);
   bbox_kernel<P4><<<g, kBlock, 0, h->stream>>>(pts, n, d);
   std::vector<double> hb(6 * (size_t)g);
-  HIP_TRY(hipMemcpyAsync(hb.data(), d, sizeof(double) * hb.size(), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  int rb = read_back(h, {{hb.data(), d, sizeof(double) * hb.size()}});
+  if (rb) return rb;
   for (int a = 0; a < 3; ++a) {
     mn[a] = 1e300;
     mx[a] = -1e300;
@@ -469,9 +497,8 @@ int dense_count(o3ds_handle h, DenseRec& d, size_t* n_live, int** flag_out = nul
   if (rc) return rc;
   int total = 0;
   unsigned long long occ = 0;
-  HIP_TRY(hipMemcpyAsync(&total, pos + d.cap, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipMemcpyAsync(&occ, d_occ, sizeof(occ), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  rc = read_back(h, {{&total, pos + d.cap, sizeof(int)}, {&occ, d_occ, sizeof(occ)}});
+  if (rc) return rc;
   *n_live = (size_t)total;
   if (n_occupied) *n_occupied = (size_t)occ;
   d.used_upper = (size_t)occ;  // exact now
@@ -816,7 +843,8 @@ int o3ds_create(int device_id, o3ds_handle* out) {
       (h->own_stream = h->stream, false) || hipMalloc(&h->d_partials, sizeof(double) * kRec * kMaxPassBlocks) != hipSuccess ||
       hipMalloc(&h->d_state, sizeof(IcpStateDev)) != hipSuccess ||
       hipHostMalloc((void**)&h->h_state, sizeof(IcpStateDev), hipHostMallocMapped) != hipSuccess ||
-      hipHostGetDevicePointer((void**)&h->h_state_dev, h->h_state, 0) != hipSuccess) {
+      hipHostGetDevicePointer((void**)&h->h_state_dev, h->h_state, 0) != hipSuccess ||
+      hipHostMalloc((void**)&h->h_pin, kPinBytes, hipHostMallocDefault) != hipSuccess) {
     delete h;
     return fail(nullptr, O3DS_ERR_HIP, "o3ds_create: device initialisation failed");
   }
@@ -856,6 +884,7 @@ int o3ds_destroy(o3ds_handle h) {
   if (h->d_partials) (void)hipFree(h->d_partials);
   if (h->d_state) (void)hipFree(h->d_state);
   if (h->h_state) (void)hipHostFree(h->h_state);
+  if (h->h_pin) (void)hipHostFree(h->h_pin);
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
@@ -1271,8 +1300,8 @@ int o3ds_information_matrix_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud tar
   icp_reduce_kernel<<<1, kUpdBlock, 0, h->stream>>>(h->d_partials, nb, h->d_state, d_record, quantum_table(a));
   HIP_TRY(hipGetLastError());
   double rec[kRec];
-  HIP_TRY(hipMemcpyAsync(rec, d_record, sizeof(rec), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  rc = read_back(h, {{rec, d_record, sizeof(rec)}});
+  if (rc) return rc;
   // Lambda = [[ |q|^2 I - q q^T , [q]x ], [ [q]x^T , I ]] summed over the matched target points
   const double xx = rec[0], xy = rec[1], xz = rec[2], yy = rec[3], yz = rec[4], zz = rec[5], sx = rec[6], sy = rec[7], sz = rec[8];
   const double m = rec[kRecCount];
@@ -1523,8 +1552,8 @@ int crop_t(o3ds_handle h, const CloudRec& in, const CropDev& crop, CloudRec& out
   int rc = exclusive_scan_int(h, flags, pos, in.n + 1);
   if (rc) return rc;
   int total = 0;
-  HIP_TRY(hipMemcpyAsync(&total, pos + in.n, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  rc = read_back(h, {{&total, pos + in.n, sizeof(int)}});
+  if (rc) return rc;
   out.n = (size_t)total;
   if (total > 0) {
     HIP_TRY(hipMallocAsync((void**)&out.pts, sizeof(P4) * out.n, h->stream));
@@ -1587,9 +1616,8 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
   if (rc) return rc;
   int n_seg = 0;
   unsigned long long n_inside = 0;
-  HIP_TRY(hipMemcpyAsync(&n_seg, seg_id + n, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipMemcpyAsync(&n_inside, d_scalar, sizeof(n_inside), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  rc = read_back(h, {{&n_seg, seg_id + n, sizeof(int)}, {&n_inside, d_scalar, sizeof(n_inside)}});
+  if (rc) return rc;
   const size_t n_pass = n - (size_t)n_inside;
   TMP_ALLOC(seg_start, sizeof(int) * ((size_t)n_seg + 1));
   segment_start_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(head, seg_id, n, seg_start);
@@ -1647,8 +1675,12 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn) {
     HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), h->stream));
     count_occupied_kernel<<<grid_for(ncell), kBlock, 0, h->stream>>>(tmp.cell_start, ncell, d_cnt);
     unsigned long long occ = 0;
-    HIP_TRY(hipMemcpyAsync(&occ, d_cnt, sizeof(occ), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    rc = read_back(h, {{&occ, d_cnt, sizeof(occ)}});
+    if (rc) {
+      tmp.pts = nullptr;
+      free_index(h, tmp);
+      return rc;
+    }
     const double avg = occ ? (double)c.n / (double)occ : 1.0;
     double cell = tmp.grid.cell * std::sqrt(std::max(1.0, (double)max_nn) / (3.14159265358979 * avg));
     cell = std::min(std::max(cell, radius / 64.0), radius);
@@ -1768,8 +1800,8 @@ int carve_t(o3ds_handle h, CloudRec& map, const CloudRec& scan, const double T[1
   int rc = exclusive_scan_int(h, head, seg_id, n + 1);
   if (rc) return rc;
   int n_seg = 0;
-  HIP_TRY(hipMemcpyAsync(&n_seg, seg_id + n, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  rc = read_back(h, {{&n_seg, seg_id + n, sizeof(int)}});
+  if (rc) return rc;
   TMP_ALLOC(seg_start, sizeof(int) * ((size_t)n_seg + 1));
   segment_start_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(head, seg_id, n, seg_start);
   size_t tsize = 1024;
@@ -1792,8 +1824,8 @@ int carve_t(o3ds_handle h, CloudRec& map, const CloudRec& scan, const double T[1
   rc = exclusive_scan_int(h, keep, pos, n + 1);
   if (rc) return rc;
   int total = 0;
-  HIP_TRY(hipMemcpyAsync(&total, pos + n, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  rc = read_back(h, {{&total, pos + n, sizeof(int)}});
+  if (rc) return rc;
   *n_removed = n - (size_t)total;
   if (*n_removed == 0) return O3DS_OK;  // removeByIds: nothing to do (helpers.cpp:221-223)
   void *np = nullptr, *nn = nullptr, *nc = nullptr;
@@ -1871,9 +1903,8 @@ int overlap_t(o3ds_handle h, const CloudRec& src, const CloudRec& tgt, const dou
   free_cloud(h, moved);
   if (rc) return rc;
   int tot[2] = {0, 0};
-  HIP_TRY(hipMemcpyAsync(&tot[0], pos + ns, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipMemcpyAsync(&tot[1], pos + ns + 1 + nt, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  rc = read_back(h, {{&tot[0], pos + ns, sizeof(int)}, {&tot[1], pos + ns + 1 + nt, sizeof(int)}});
+  if (rc) return rc;
   TMP_ALLOC(d_out, sizeof(unsigned long long) * (size_t)(tot[0] + tot[1] + 1));
   index_compact_kernel<<<grid_for(ns), kBlock, 0, h->stream>>>(flag_s, pos, ns, d_out);
   index_compact_kernel<<<grid_for(nt), kBlock, 0, h->stream>>>(flag_t, pos + ns + 1, nt, d_out + tot[0]);
@@ -2211,8 +2242,13 @@ int o3ds_dense_map_carve(o3ds_handle h, o3ds_dense_map id, o3ds_cloud scan, cons
   dense_erase_marked_kernel<<<grid_for(d.cap), kBlock, 0, h->stream>>>(d.dev, d.cap, mark, d_removed);
   HIP_TRY(hipGetLastError());
   unsigned long long removed = 0;
-  HIP_TRY(hipMemcpyAsync(&removed, d_removed, sizeof(removed), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  {
+    const int rb = read_back(h, {{&removed, d_removed, sizeof(removed)}});
+    if (rb) {
+      free_cloud(h, placed);
+      return rb;
+    }
+  }
   free_cloud(h, placed);
   if (n_removed) *n_removed = (size_t)removed;
   return O3DS_OK;
@@ -2239,8 +2275,10 @@ int o3ds_dense_map_count_occupied(o3ds_handle h, o3ds_dense_map id, o3ds_cloud c
     dense_probe_kernel<P4f><<<grid_for(c->n), kBlock, 0, h->stream>>>((const P4f*)c->pts, c->n, M, 1.0 / d.voxel, d.dev, d_hits);
   HIP_TRY(hipGetLastError());
   unsigned long long hits = 0;
-  HIP_TRY(hipMemcpyAsync(&hits, d_hits, sizeof(hits), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  {
+    const int rb = read_back(h, {{&hits, d_hits, sizeof(hits)}});
+    if (rb) return rb;
+  }
   *n_hits = (size_t)hits;
   return O3DS_OK;
 }
