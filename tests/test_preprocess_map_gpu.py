@@ -974,3 +974,41 @@ def test_colours_ride_along_like_the_reference(backend_f64, backend_f32, oracle,
     np.testing.assert_array_equal(gc, mc[j])
     backend_f64.free(m)
     backend_f64.free(s)
+
+
+def test_carried_bounding_boxes_never_lose_a_neighbour(backend_f64, backend_f32, oracle, scan):
+    """Index builds take the bounding box that travels with a device cloud (set by VoxelDownSample / a previous index build, carried
+    through crop, select, rigid placement and append) instead of reducing one.  A box that missed a point would put it in the wrong
+    cell and the search would lose neighbours, so: build the chain voxel filter -> crop -> placement by a large rotation -> append ->
+    select, and compare the exact 1-NN distances and the normals computed on the carried box with the oracle's on the downloaded
+    points (f64 storage: to rounding; f32 storage: the placement rounds the stored values, which the box must absorb)."""
+    from scipy.spatial import cKDTree
+
+    T = syn.make_pose((40.0, -25.0, 3.0), (20.0, -35.0, 130.0))
+    for be, tol in ((backend_f64, 1e-9), (backend_f32, 1e-4)):
+        raw = be.upload(scan)
+        vox = be.voxel_down_sample(raw, 0.2)                                   # sets the box
+        inner = be.crop_cloud(vox, backend.make_crop(backend.CROP_MAX_RADIUS, rmax=25.0))  # subset: same box
+        placed = be.transform_cloud(inner, T)                                  # box of the 8 placed corners
+        other = be.transform_cloud(inner, syn.make_pose((-60.0, 10.0, -2.0), (0.0, 0.0, 45.0)))
+        be.cloud_append(placed, other)                                         # union of two boxes
+        n = be.size(placed)[0]
+        keep = np.arange(0, n, 2, dtype=np.uint32)
+        half = be.select_by_index(placed, keep)                                # subset again
+        pts = be.download(half)[0]
+        # (a) exact 1-NN of a shifted copy against the cloud indexed on its carried box
+        q = pts[::7] + np.array([0.03, -0.02, 0.01])
+        qc = be.upload(q)
+        be.build_index(half, 0.5)
+        be.estimate_normals(half, 1.0, 10)                                     # (drops and rebuilds the index: both on the carried box)
+        r = be.icp_point_to_point_dev(qc, half, 0.5, max_iter=0)  # one correspondence pass: fitness and rmse of the exact 1-NN
+        d_ref, _ = cKDTree(pts).query(q)
+        assert r["fitness"] == 1.0
+        np.testing.assert_allclose(r["inlier_rmse"], np.sqrt(np.mean(d_ref ** 2)), rtol=1e-6, atol=tol)
+        # (b) normals of every point: the neighbour sets are the oracle's
+        got = be.download(half)[1]
+        ref = oracle.estimate_normals(pts, 1.0, 10)
+        dots = np.abs(np.einsum("ij,ij->i", got, ref))
+        assert (dots > 1 - 1e-6).mean() > 0.95, (dots > 1 - 1e-6).mean()
+        for cid in (raw, vox, inner, placed, other, half, qc):
+            be.free(cid)
