@@ -54,3 +54,12 @@ def test_mapping_on_gpu(mapping_exe, tmp_path):
     out = subprocess.run([mapping_exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, O3DS_TEST_TMPDIR=str(tmp_path)))
     assert out.returncode == 0, out.stdout + out.stderr
     assert "gpu checks ok" in out.stdout
+
+
+@pytest.mark.gpu
+def test_stream_mapping_through_the_cpp_classes():
+    """tests/cpp/stream_mapping.cpp: eight OS-128-like scans along the figure-eight through ScanToMapIcp + Submap with host clouds at
+    the seam; the program checks the fitness gate of every frame and the final pose against the truth (5 cm) itself."""
+    out = subprocess.run(["python", os.path.join(ROOT, "scripts", "bench_stream_cpp.py"), "--frames", "8"], capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "scans_per_sec_mapping_only" in out.stdout
