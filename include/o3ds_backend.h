@@ -237,6 +237,11 @@ int o3ds_crop_cloud(o3ds_handle h, o3ds_cloud in, const o3ds_crop* crop, o3ds_cl
  * per-voxel mean of points (and normals).  Output order: ascending voxel key (the reference's order is
  * unordered_map iteration order, i.e. unspecified).  voxel <= 0 returns a copy. */
 int o3ds_voxel_down_sample(o3ds_handle h, o3ds_cloud in, double voxel_size, o3ds_cloud* out);
+/* The first two steps of ScanToMapIcp::preprocess (ScanToMapRegistration.cpp:36-37) and LidarOdometry::preprocess (Odometry.cpp:26-27),
+ * `cropped = cropper->crop(in); voxelize(voxelSize, cropped)`, as one call: the same cloud o3ds_crop_cloud followed by
+ * o3ds_voxel_down_sample returns, bit for bit (grid anchored at the bounding box of the points INSIDE the volume, voxel means summed
+ * in the same order), without materialising the cropped cloud.  voxel_size <= 0 is o3ds_crop_cloud. */
+int o3ds_crop_voxel_down_sample(o3ds_handle h, o3ds_cloud in, const o3ds_crop* crop, double voxel_size, o3ds_cloud* out);
 /* RegistrationIcpPointToPlane::estimateNormalsOrCovariancesIfNeeded (CloudRegistration.cpp:49-56):
  * [O3D] EstimateNormals(KDTreeSearchParamHybrid(radius,max_nn)) + NormalizeNormals +
  * OrientNormalsTowardsCameraLocation(0,0,0).  In place (adds/overwrites the cloud's normals). */

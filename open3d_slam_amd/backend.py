@@ -103,6 +103,7 @@ SIGNATURES = {
     "o3ds_icp_done": (C.c_int, [_H, C.POINTER(C.c_int)]),
     "o3ds_crop_cloud": (C.c_int, [_H, _CL, C.POINTER(Crop), C.POINTER(_CL)]),
     "o3ds_voxel_down_sample": (C.c_int, [_H, _CL, C.c_double, C.POINTER(_CL)]),
+    "o3ds_crop_voxel_down_sample": (C.c_int, [_H, _CL, C.POINTER(Crop), C.c_double, C.POINTER(_CL)]),
     "o3ds_estimate_normals": (C.c_int, [_H, _CL, C.c_double, C.c_int]),
     "o3ds_select_by_index": (C.c_int, [_H, _CL, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(_CL)]),
     "o3ds_transform_cloud": (C.c_int, [_H, _CL, _dp, C.POINTER(_CL)]),
@@ -429,6 +430,12 @@ class Backend:
     def voxel_down_sample(self, cid: int, voxel: float) -> int:
         out = _CL()
         self._ck(self.lib.o3ds_voxel_down_sample(self.h, cid, voxel, C.byref(out)))
+        return out.value
+
+    def crop_voxel_down_sample(self, cid: int, crop: Crop, voxel: float) -> int:
+        """crop_cloud followed by voxel_down_sample, bit for bit, in one call (the first two steps of both preprocess chains)."""
+        out = _CL()
+        self._ck(self.lib.o3ds_crop_voxel_down_sample(self.h, cid, C.byref(crop), voxel, C.byref(out)))
         return out.value
 
     def estimate_normals(self, cid: int, radius: float, max_nn: int):

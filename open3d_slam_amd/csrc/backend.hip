@@ -309,11 +309,12 @@ int exclusive_scan_int(o3ds_handle h, const int* in, int* out, size_t m) {
 }
 
 template <typename P4>
-int bbox_of(o3ds_handle h, const P4* pts, size_t n, double mn[3], double mx[3]) {
+int bbox_of(o3ds_handle h, const P4* pts, size_t n, double mn[3], double mx[3], const CropDev* crop = nullptr) {
   const int g = grid_for(n, 1024);
   double* d = nullptr;
   TMP_ALLOC(d, sizeof(double) * 6 * (size_t)g);
-  bbox_kernel<P4><<<g, kBlock, 0, h->stream>>>(pts, n, d);
+  CropDev all{};
+  bbox_kernel<P4><<<g, kBlock, 0, h->stream>>>(pts, n, crop ? *crop : all, d);
   std::vector<double> hb(6 * (size_t)g);
   int rb = read_back(h, {{hb.data(), d, sizeof(double) * hb.size()}});
   if (rb) return rb;
@@ -1575,7 +1576,10 @@ int crop_t(o3ds_handle h, const CloudRec& in, const CropDev& crop, CloudRec& out
 
 // shared by VoxelDownSample (mode 0) and voxelizeWithinCroppingVolume (mode 1)
 template <typename P4>
-int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, const CropDev& crop, CloudRec& out) {
+int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, const CropDev& crop, CloudRec& out, bool filter = false) {
+  // filter (mode 0 only): CroppingVolume::crop followed by VoxelDownSample in one go -- the points outside `crop` are keyed as
+  // pass-through, sort behind the voxels and are not emitted; same grid anchor (the box of the INSIDE points), same keys, same
+  // summation order as cropping first, without the compaction, its scan and its size read-back
   out.precision = in.precision;
   out.n = 0;
   const size_t n = in.n;
@@ -1583,8 +1587,9 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
   double ox = 0, oy = 0, oz = 0;
   if (mode == 0) {  // [O3D] voxel_min_bound = GetMinBound() - voxel_size * 0.5
     double mn[3], mx[3];
-    int rc = bbox_of<P4>(h, (const P4*)in.pts, n, mn, mx);
+    int rc = bbox_of<P4>(h, (const P4*)in.pts, n, mn, mx, filter ? &crop : nullptr);
     if (rc) return rc;
+    if (filter && mn[0] > mx[0]) return O3DS_OK;  // nothing inside the volume: an empty cloud
     if (voxel * 2147483647.0 < std::max({mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]}) + voxel)
       return fail(h, O3DS_ERR_INVALID_ARG, "[VoxelDownSample] voxel_size is too small.");
     ox = mn[0] - voxel * 0.5;
@@ -1607,7 +1612,7 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
   TMP_ALLOC(head, sizeof(int) * (n + 1));
   TMP_ALLOC(seg_id, sizeof(int) * (n + 1));
   TMP_ALLOC(d_scalar, sizeof(unsigned long long));
-  voxel_key_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>((const P4*)in.pts, n, mode, ox, oy, oz, voxel, crop, k0, v0);
+  voxel_key_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>((const P4*)in.pts, n, mode, ox, oy, oz, voxel, crop, k0, v0, filter ? 1 : 0);
   size_t temp_bytes = 0;
   HIP_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, k0, k1, v0, v1, n, 0, 64, h->stream));
   void* temp = nullptr;
@@ -1624,16 +1629,18 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
   const size_t n_pass = n - (size_t)n_inside;
   TMP_ALLOC(seg_start, sizeof(int) * ((size_t)n_seg + 1));
   segment_start_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(head, seg_id, n, seg_start);
-  out.n = (size_t)n_seg;
+  const int drop = filter ? 1 : 0;
+  out.n = filter ? (size_t)n_seg - n_pass : (size_t)n_seg;
+  if (out.n == 0) return O3DS_OK;
   HIP_TRY(hipMallocAsync((void**)&out.pts, sizeof(P4) * out.n, h->stream));
   if (in.nrm) HIP_TRY(hipMallocAsync((void**)&out.nrm, sizeof(P4) * out.n, h->stream));
-  segment_mean_kernel<P4><<<grid_for(out.n), kBlock, 0, h->stream>>>((const P4*)in.pts, (const P4*)in.nrm, k1, v1, seg_start, out.n, n,
-                                                                    mode == 1 ? 1 : 0, n_pass, (P4*)out.pts, (P4*)out.nrm);
+  segment_mean_kernel<P4><<<grid_for((size_t)n_seg), kBlock, 0, h->stream>>>((const P4*)in.pts, (const P4*)in.nrm, k1, v1, seg_start, (size_t)n_seg, n,
+                                                                            mode == 1 ? 1 : 0, n_pass, (P4*)out.pts, (P4*)out.nrm, drop);
   if (in.col) {
     HIP_TRY(hipMallocAsync((void**)&out.col, sizeof(P4) * out.n, h->stream));
     if (mode == 0)  // [O3D] VoxelDownSample: AccumulatedPoint averages the colours
-      segment_mean_kernel<P4><<<grid_for(out.n), kBlock, 0, h->stream>>>((const P4*)in.col, nullptr, k1, v1, seg_start, out.n, n, 0, n_pass,
-                                                                        (P4*)out.col, nullptr);
+      segment_mean_kernel<P4><<<grid_for((size_t)n_seg), kBlock, 0, h->stream>>>((const P4*)in.col, nullptr, k1, v1, seg_start, (size_t)n_seg, n, 0, n_pass,
+                                                                                (P4*)out.col, nullptr, drop);
     else  // the map merge keeps the colour of the LAST point of a voxel (helpers.cpp:40-42,61-63: `color_ = ...`, not `+=`)
       segment_last_kernel<P4><<<grid_for(out.n), kBlock, 0, h->stream>>>((const P4*)in.col, k1, v1, seg_start, out.n, n, n_pass, (P4*)out.col);
   }
@@ -1992,6 +1999,23 @@ int o3ds_voxel_down_sample(o3ds_handle h, o3ds_cloud in, double voxel_size, o3ds
     CropDev none{};
     rc = DISPATCH(c->precision, voxel_reduce_t, h, *c, 0, voxel_size, none, o);
   }
+  if (rc) {
+    free_cloud(h, o);
+    return rc;
+  }
+  *out = add_cloud(h, std::move(o));
+  return O3DS_OK;
+}
+
+int o3ds_crop_voxel_down_sample(o3ds_handle h, o3ds_cloud in, const o3ds_crop* crop, double voxel_size, o3ds_cloud* out) {
+  CHECK_HANDLE(h);
+  if (!(voxel_size > 0.0)) return o3ds_crop_cloud(h, in, crop, out);  // o3d_slam::voxelize leaves the cropped cloud as it is
+  ArenaScope arena_scope(h);
+  CloudRec* c = find_cloud(h, in);
+  if (!c || !out) return fail(h, O3DS_ERR_INVALID_ARG, "crop_voxel_down_sample: bad argument");
+  CloudRec o;
+  const CropDev cd = to_dev(crop);
+  const int rc = DISPATCH(c->precision, voxel_reduce_t, h, *c, 0, voxel_size, cd, o, true);
   if (rc) {
     free_cloud(h, o);
     return rc;

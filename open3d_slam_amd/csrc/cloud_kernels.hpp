@@ -232,13 +232,14 @@ __host__ __device__ __forceinline__ unsigned long long pack_key(long long kx, lo
 // look-back state per pass made map_insert_scan 0.86 ms instead of 0.82 ms and voxel_down_sample 0.24 ms instead of 0.18 ms.)
 template <typename P4>
 __global__ __launch_bounds__(kBlock) void voxel_key_kernel(const P4* __restrict__ pts, size_t n, int mode, double ox, double oy, double oz, double v,
-                                                           CropDev crop, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                                           CropDev crop, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                           int filter = 0 /* mode 0 only: points outside `crop` get pass-through keys too */) {
   const double inv = 1.0 / v;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
     const P4 p = pts[i];
     const double x = (double)p.x, y = (double)p.y, z = (double)p.z;
     unsigned long long k;
-    if (mode == 1 && !crop_contains(crop, x, y, z)) {
+    if ((mode == 1 || filter) && !crop_contains(crop, x, y, z)) {
       k = kPassBit | (unsigned long long)i;
     } else if (mode == 0) {
       k = pack_key((long long)floor((x - ox) / v), (long long)floor((y - oy) / v), (long long)floor((z - oz) / v));
@@ -270,7 +271,8 @@ template <typename P4>
 __global__ __launch_bounds__(kBlock) void segment_mean_kernel(const P4* __restrict__ pts, const P4* __restrict__ nrm,
                                                               const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                               const int* __restrict__ seg_start, size_t n_seg, size_t n, int renorm,
-                                                              size_t n_pass, P4* __restrict__ out_pts, P4* __restrict__ out_nrm) {
+                                                              size_t n_pass, P4* __restrict__ out_pts, P4* __restrict__ out_nrm,
+                                                              int drop_pass = 0 /* emit the voxel means only (crop + VoxelDownSample in one) */) {
   using R = typename Scalar<P4>::type;
   for (size_t s = (size_t)blockIdx.x * kBlock + threadIdx.x; s < n_seg; s += (size_t)gridDim.x * kBlock) {
     const size_t b = (size_t)seg_start[s], e = (s + 1 < n_seg) ? (size_t)seg_start[s + 1] : n;
@@ -278,7 +280,8 @@ __global__ __launch_bounds__(kBlock) void segment_mean_kernel(const P4* __restri
     // voxel segments first (n_seg - n_pass of them), pass-through segments (one point each, by original index) last.
     const size_t n_vox = n_seg - n_pass;
     const bool pass = s >= n_vox;
-    const size_t o = pass ? (s - n_vox) : (n_pass + s);
+    if (pass && drop_pass) continue;
+    const size_t o = drop_pass ? s : (pass ? (s - n_vox) : (n_pass + s));
     double sx = 0, sy = 0, sz = 0, nx = 0, ny = 0, nz = 0;
     for (size_t j = b; j < e; ++j) {
       const uint32_t id = vals[j];

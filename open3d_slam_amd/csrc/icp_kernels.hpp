@@ -39,12 +39,13 @@ __device__ __forceinline__ float wave_max(float v) {
 // ----------------------------------------------------------------------------------------------
 // index build
 // ----------------------------------------------------------------------------------------------
-// per-block bounding boxes: out[block*6 + {0..2}] = min, {3..5} = max
+// per-block bounding boxes of the points inside `crop` (O3DS_CROP_NONE: all): out[block*6 + {0..2}] = min, {3..5} = max
 template <typename P4>
-__global__ __launch_bounds__(kBlock) void bbox_kernel(const P4* __restrict__ pts, size_t n, double* __restrict__ out) {
+__global__ __launch_bounds__(kBlock) void bbox_kernel(const P4* __restrict__ pts, size_t n, CropDev crop, double* __restrict__ out) {
   double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
     const P4 p = pts[i];
+    if (!crop_contains(crop, (double)p.x, (double)p.y, (double)p.z)) continue;
     mn[0] = fmin(mn[0], (double)p.x);
     mn[1] = fmin(mn[1], (double)p.y);
     mn[2] = fmin(mn[2], (double)p.z);

@@ -477,13 +477,10 @@ class ScanToMapIcp : public ScanToMapRegistration {
     const o3ds_handle h = raw.handle();
     const o3ds_crop c = mapBuilderCropper_->toAbi();
     o3ds_cloud id = 0;
-    o3ds_detail::Handle::check(o3ds_crop_cloud(h, raw.id(), &c, &id));  // mapBuilderCropper_->crop(in)
+    // mapBuilderCropper_->crop(in) and o3d_slam::voxelize (helpers.cpp:107-113) in one call, the same cloud bit for bit
+    o3ds_detail::Handle::check(o3ds_crop_voxel_down_sample(h, raw.id(), &c, params_.scanProcessing_.voxelSize_, &id));
     o3ds_detail::DevCloud cropped(id, h);
     raw.reset();
-    if (params_.scanProcessing_.voxelSize_ > 0.0 && cropped.size() > 0) {  // o3d_slam::voxelize (helpers.cpp:107-113)
-      o3ds_detail::Handle::check(o3ds_voxel_down_sample(h, cropped.id(), params_.scanProcessing_.voxelSize_, &id));
-      cropped = o3ds_detail::DevCloud(id, h);
-    }
     if (cropped.size() > 0 && !cloudRegistration_->estimateNormalsOrCovariancesIfNeededDev(h, cropped.id())) {
       PointCloud host;  // unknown registration: its own host-side hook, then back to the device
       cropped.download(&host);

@@ -28,9 +28,8 @@ class LidarOdometry:
         self.cloudRegistration_ = cloudRegistrationFactory(p.scanMatcher_)
 
     def preprocess(self, cloud: PointCloud) -> PointCloud:  # Odometry.cpp:25-30
-        cropped = self.cropper_.crop(cloud)
-        vox = PointCloud(self.be, self.be.voxel_down_sample(cropped.id, self.params_.scanProcessing_.voxelSize_))
-        cropped.release()
+        # cropper_->crop(in) then voxelize(voxelSize_, cropped) (Odometry.cpp:26-27) as one call, same result bit for bit
+        vox = PointCloud(self.be, self.be.crop_voxel_down_sample(cloud.id, self.cropper_.to_abi(), self.params_.scanProcessing_.voxelSize_))
         self.cloudRegistration_.estimateNormalsOrCovariancesIfNeeded(vox)
         # RandomDownSample(ratio): ratio = 1 in every benchmark config (non-reproducible otherwise)
         if self.params_.scanProcessing_.downSamplingRatio_ < 1.0:

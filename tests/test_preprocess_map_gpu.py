@@ -1012,3 +1012,32 @@ def test_carried_bounding_boxes_never_lose_a_neighbour(backend_f64, backend_f32,
         assert (dots > 1 - 1e-6).mean() > 0.95, (dots > 1 - 1e-6).mean()
         for cid in (raw, vox, inner, placed, other, half, qc):
             be.free(cid)
+
+
+def test_crop_voxel_down_sample_is_crop_then_voxel_bit_for_bit(backend_f64, backend_f32, scan):
+    """o3ds_crop_voxel_down_sample = the first two steps of both preprocess chains (ScanToMapRegistration.cpp:36-37, Odometry.cpp:26-27)
+    in one call: identical to o3ds_crop_cloud followed by o3ds_voxel_down_sample -- points, normals and colours, every volume kind,
+    an empty result, and voxel <= 0 (crop only)."""
+    rng = np.random.default_rng(3)
+    nrm = rng.normal(size=scan.shape)
+    col = rng.uniform(size=scan.shape)
+    for be in (backend_f64, backend_f32):
+        c = be.upload(scan, nrm)
+        be.set_colors(c, col)
+        for kind, kw, voxel in ((backend.CROP_MIN_MAX_RADIUS, dict(rmin=2.0, rmax=30.0), 0.1), (backend.CROP_MAX_RADIUS, dict(rmax=9.0), 0.25),
+                                (backend.CROP_CYLINDER, dict(rmax=15.0, zmin=-1.0, zmax=3.0, invert=True), 0.1), (backend.CROP_NONE, dict(), 0.3),
+                                (backend.CROP_MIN_RADIUS, dict(rmin=1e6), 0.1), (backend.CROP_MAX_RADIUS, dict(rmax=12.0), 0.0)):
+            crop = backend.make_crop(kind, center=(0.5, -0.25, 0.1), **kw)
+            a = be.crop_cloud(c, crop)
+            two = be.voxel_down_sample(a, voxel) if be.size(a)[0] else be.upload(np.zeros((0, 3)))
+            one = be.crop_voxel_down_sample(c, crop, voxel)
+            assert be.size(one)[0] == be.size(two)[0], (kind, kw)
+            if be.size(one)[0]:
+                p1, n1 = be.download(one)
+                p2, n2 = be.download(two)
+                np.testing.assert_array_equal(p1, p2)
+                np.testing.assert_array_equal(n1, n2)
+                np.testing.assert_array_equal(be.get_colors(one), be.get_colors(two))
+            for cid in (a, two, one):
+                be.free(cid)
+        be.free(c)
