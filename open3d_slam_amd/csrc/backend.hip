@@ -108,6 +108,8 @@ struct o3ds_context {
   IcpStateDev* d_state = nullptr;
   IcpStateDev* h_state = nullptr;   // pinned, mapped
   char* h_pin = nullptr;            // pinned block the small device -> host read-backs land in (read_back)
+  char* h_stage[2] = {nullptr, nullptr};  // pinned ring the large host <-> device copies of caller buffers go through (staged_copy)
+  hipEvent_t stage_ev[2] = {nullptr, nullptr};
   IcpStateDev* h_state_dev = nullptr;  // the device's view of h_state
   // step-wise ICP session
   bool session = false;
@@ -185,6 +187,61 @@ int read_back(o3ds_handle h, std::initializer_list<D2H> items) {
   for (const D2H& it : items) {
     memcpy(it.dst, h->h_pin + off, it.bytes);
     off += (it.bytes + 15) & ~(size_t)15;
+  }
+  return O3DS_OK;
+}
+
+// ---- large copies of caller buffers ------------------------------------------------------------------------------
+// A caller's cloud is pageable memory (std::vector<Eigen::Vector3d>, a numpy array).  What the runtime does with a multi-megabyte
+// pageable copy depends on its mood: seen on the same box, the same 3 MB download took 0.3 ms in one process and 8 ms in the next
+// (tests/cpp/stream_mapping.cpp: 0.9 vs 24 ms per scan).  So copies above kStageMin go through two pinned buffers owned by the
+// handle: memcpy into / out of the ring on the host, DMA between the ring and the device, one chunk in flight while the other is
+// copied.  The host-to-device form returns with the last DMA queued (callers synchronise as before); device-to-host is complete.
+constexpr size_t kStageBytes = 1 << 20, kStageMin = 128 << 10;  // 1 MB chunks: a 3 MB cloud is three chunks, DMA and host memcpy overlap
+int stage_init(o3ds_handle h) {
+  for (int k = 0; k < 2; ++k) {
+    if (!h->h_stage[k]) HIP_TRY(hipHostMalloc((void**)&h->h_stage[k], kStageBytes, hipHostMallocDefault));
+    if (!h->stage_ev[k]) HIP_TRY(hipEventCreateWithFlags(&h->stage_ev[k], hipEventDisableTiming));
+  }
+  return O3DS_OK;
+}
+int h2d_copy(o3ds_handle h, void* d_dst, const void* h_src, size_t bytes) {
+  if (bytes < kStageMin) {
+    HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, h->stream));
+    return O3DS_OK;
+  }
+  int rc = stage_init(h);
+  if (rc) return rc;
+  int k = 0;
+  for (size_t off = 0; off < bytes; off += kStageBytes, k ^= 1) {
+    const size_t n = std::min(kStageBytes, bytes - off);
+    HIP_TRY(hipEventSynchronize(h->stage_ev[k]));  // the DMA that last read this buffer is done (a fresh event is complete)
+    memcpy(h->h_stage[k], (const char*)h_src + off, n);
+    HIP_TRY(hipMemcpyAsync((char*)d_dst + off, h->h_stage[k], n, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipEventRecord(h->stage_ev[k], h->stream));
+  }
+  return O3DS_OK;
+}
+int d2h_copy(o3ds_handle h, void* h_dst, const void* d_src, size_t bytes) {  // synchronous: h_dst is filled on return
+  if (bytes < kStageMin) {
+    HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return O3DS_OK;
+  }
+  int rc = stage_init(h);
+  if (rc) return rc;
+  const size_t chunks = (bytes + kStageBytes - 1) / kStageBytes;
+  for (size_t c = 0; c <= chunks; ++c) {
+    if (c < chunks) {  // queue chunk c into buffer c & 1 (its previous content, chunk c - 2, was copied out one step ago)
+      const size_t off = c * kStageBytes, n = std::min(kStageBytes, bytes - off);
+      HIP_TRY(hipMemcpyAsync(h->h_stage[c & 1], (const char*)d_src + off, n, hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipEventRecord(h->stage_ev[c & 1], h->stream));
+    }
+    if (c > 0) {  // while it flies, hand chunk c - 1 to the caller
+      const size_t off = (c - 1) * kStageBytes, n = std::min(kStageBytes, bytes - off);
+      HIP_TRY(hipEventSynchronize(h->stage_ev[(c - 1) & 1]));
+      memcpy((char*)h_dst + off, h->h_stage[(c - 1) & 1], n);
+    }
   }
   return O3DS_OK;
 }
@@ -413,12 +470,14 @@ int upload_t(o3ds_handle h, const double* xyz, const double* normals, size_t n, 
   double *stage = nullptr, *stage_n = nullptr;
   TMP_ALLOC(stage, sizeof(double) * 3 * n);
   HIP_TRY(hipMallocAsync((void**)&c.pts, sizeof(P4) * n, h->stream));
-  HIP_TRY(hipMemcpyAsync(stage, xyz, sizeof(double) * 3 * n, hipMemcpyHostToDevice, h->stream));
+  int rcc = h2d_copy(h, stage, xyz, sizeof(double) * 3 * n);
+  if (rcc) return rcc;
   pack_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(stage, n, (P4*)c.pts);
   if (normals) {
     TMP_ALLOC(stage_n, sizeof(double) * 3 * n);
     HIP_TRY(hipMallocAsync((void**)&c.nrm, sizeof(P4) * n, h->stream));
-    HIP_TRY(hipMemcpyAsync(stage_n, normals, sizeof(double) * 3 * n, hipMemcpyHostToDevice, h->stream));
+    rcc = h2d_copy(h, stage_n, normals, sizeof(double) * 3 * n);
+    if (rcc) return rcc;
     pack_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(stage_n, n, (P4*)c.nrm);
   }
   HIP_TRY(hipGetLastError());
@@ -433,13 +492,13 @@ int download_t(o3ds_handle h, const CloudRec& c, double* xyz, double* normals) {
   TMP_ALLOC(stage, sizeof(double) * 3 * c.n);
   if (xyz) {
     unpack_kernel<P4><<<grid_for(c.n), kBlock, 0, h->stream>>>((const P4*)c.pts, c.n, stage);
-    HIP_TRY(hipMemcpyAsync(xyz, stage, sizeof(double) * 3 * c.n, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    const int rcc = d2h_copy(h, xyz, stage, sizeof(double) * 3 * c.n);
+    if (rcc) return rcc;
   }
   if (normals && c.nrm) {
     unpack_kernel<P4><<<grid_for(c.n), kBlock, 0, h->stream>>>((const P4*)c.nrm, c.n, stage);
-    HIP_TRY(hipMemcpyAsync(normals, stage, sizeof(double) * 3 * c.n, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    const int rcc = d2h_copy(h, normals, stage, sizeof(double) * 3 * c.n);
+    if (rcc) return rcc;
   }
   HIP_TRY(hipGetLastError());
   return O3DS_OK;
@@ -886,6 +945,10 @@ int o3ds_destroy(o3ds_handle h) {
   if (h->d_state) (void)hipFree(h->d_state);
   if (h->h_state) (void)hipHostFree(h->h_state);
   if (h->h_pin) (void)hipHostFree(h->h_pin);
+  for (int k = 0; k < 2; ++k) {
+    if (h->h_stage[k]) (void)hipHostFree(h->h_stage[k]);
+    if (h->stage_ev[k]) (void)hipEventDestroy(h->stage_ev[k]);
+  }
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
@@ -969,7 +1032,10 @@ int o3ds_cloud_upload_f32(o3ds_handle h, const void* data, size_t n, size_t poin
   if (n > 0) {
     unsigned char* d_raw = nullptr;
     TMP_ALLOC(d_raw, n * point_step);
-    HIP_TRY(hipMemcpyAsync(d_raw, data, n * point_step, hipMemcpyHostToDevice, h->stream));
+    {
+      const int rcc = h2d_copy(h, d_raw, data, n * point_step);
+      if (rcc) return rcc;
+    }
     const size_t bytes = (h->precision == O3DS_PRECISION_F64 ? sizeof(P4d) : sizeof(P4f)) * n;
     HIP_TRY(hipMallocAsync(&c.pts, bytes, h->stream));
     if (h->precision == O3DS_PRECISION_F64)
@@ -1048,9 +1114,7 @@ int o3ds_cloud_download_f32(o3ds_handle h, o3ds_cloud id, void* data, size_t cap
     unpack_strided_f32_kernel<P4f><<<grid_for(c->n), kBlock, 0, h->stream>>>((const P4f*)c->pts, (const P4f*)c->nrm, (const P4f*)c->col, c->n,
                                                                             point_step, off_x, off_y, off_z, on, oc, rgb_rounding, d_raw);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(data, d_raw, bytes, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  return O3DS_OK;
+  return d2h_copy(h, data, d_raw, bytes);
 }
 
 int o3ds_cloud_set_colors_from_records(o3ds_handle h, o3ds_cloud id, const void* data, size_t point_step, size_t off_field, int kind) {
@@ -1068,7 +1132,10 @@ int o3ds_cloud_set_colors_from_records(o3ds_handle h, o3ds_cloud id, const void*
   if (c->n == 0) return O3DS_OK;
   unsigned char* d_raw = nullptr;
   TMP_ALLOC(d_raw, c->n * point_step);
-  HIP_TRY(hipMemcpyAsync(d_raw, data, c->n * point_step, hipMemcpyHostToDevice, h->stream));
+  {
+    const int rcc = h2d_copy(h, d_raw, data, c->n * point_step);
+    if (rcc) return rcc;
+  }
   HIP_TRY(hipMallocAsync(&c->col, p4_size(c->precision) * c->n, h->stream));
   if (c->precision == O3DS_PRECISION_F64)
     colors_from_records_kernel<P4d><<<grid_for(c->n), kBlock, 0, h->stream>>>(d_raw, c->n, point_step, off_field, kind, (P4d*)c->col);
@@ -1090,7 +1157,10 @@ int o3ds_cloud_set_colors(o3ds_handle h, o3ds_cloud id, const double* rgb) {
   if (!rgb || c->n == 0) return O3DS_OK;  // colors_.clear()
   double* stage = nullptr;
   TMP_ALLOC(stage, sizeof(double) * 3 * c->n);
-  HIP_TRY(hipMemcpyAsync(stage, rgb, sizeof(double) * 3 * c->n, hipMemcpyHostToDevice, h->stream));
+  {
+    const int rcc = h2d_copy(h, stage, rgb, sizeof(double) * 3 * c->n);
+    if (rcc) return rcc;
+  }
   HIP_TRY(hipMallocAsync(&c->col, p4_size(c->precision) * c->n, h->stream));
   if (c->precision == O3DS_PRECISION_F64)
     pack_kernel<P4d><<<grid_for(c->n), kBlock, 0, h->stream>>>(stage, c->n, (P4d*)c->col);
@@ -1123,9 +1193,7 @@ int o3ds_cloud_get_colors(o3ds_handle h, o3ds_cloud id, double* rgb, size_t capa
   else
     unpack_kernel<P4f><<<grid_for(c->n), kBlock, 0, h->stream>>>((const P4f*)c->col, c->n, stage);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(rgb, stage, sizeof(double) * 3 * c->n, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  return O3DS_OK;
+  return d2h_copy(h, rgb, stage, sizeof(double) * 3 * c->n);
 }
 
 int o3ds_cloud_build_index(o3ds_handle h, o3ds_cloud id, double max_corr_hint, double cell_size) {
