@@ -761,7 +761,6 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
     rc = build_index(h, *tgt, params->max_correspondence_distance / 4.0);
     if (rc) return rc;
   }
-  const double r_corr = params->max_correspondence_distance;
   if (src->n > h->nn_cache_cap) {
     if (h->d_nn_cache) {
       HIP_TRY(hipStreamSynchronize(h->stream));

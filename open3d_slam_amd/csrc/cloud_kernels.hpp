@@ -274,6 +274,7 @@ __global__ __launch_bounds__(kBlock) void segment_mean_kernel(const P4* __restri
                                                               size_t n_pass, P4* __restrict__ out_pts, P4* __restrict__ out_nrm,
                                                               int drop_pass = 0 /* emit the voxel means only (crop + VoxelDownSample in one) */) {
   using R = typename Scalar<P4>::type;
+  (void)keys;  // segments are told apart by position (voxel segments sort first)
   for (size_t s = (size_t)blockIdx.x * kBlock + threadIdx.x; s < n_seg; s += (size_t)gridDim.x * kBlock) {
     const size_t b = (size_t)seg_start[s], e = (s + 1 < n_seg) ? (size_t)seg_start[s + 1] : n;
     // reference order: pass-through points first, voxel means after (helpers.cpp:151-181).  Sorted order has the
@@ -500,8 +501,9 @@ template <typename P4>
 __global__ __launch_bounds__(kBlock) void segment_last_kernel(const P4* __restrict__ col, const unsigned long long* __restrict__ keys,
                                                               const uint32_t* __restrict__ vals, const int* __restrict__ seg_start, size_t n_seg,
                                                               size_t n, size_t n_pass, P4* __restrict__ out_col) {
+  (void)keys;  // segments are told apart by position (voxel segments sort first)
   for (size_t s = (size_t)blockIdx.x * kBlock + threadIdx.x; s < n_seg; s += (size_t)gridDim.x * kBlock) {
-    const size_t b = (size_t)seg_start[s], e = (s + 1 < n_seg) ? (size_t)seg_start[s + 1] : n;
+    const size_t e = (s + 1 < n_seg) ? (size_t)seg_start[s + 1] : n;
     const size_t n_vox = n_seg - n_pass;
     const bool pass = s >= n_vox;  // the pass-through segments (one point each) sort after all voxel segments
     const size_t o = pass ? (s - n_vox) : (n_pass + s);
@@ -902,6 +904,7 @@ __device__ __forceinline__ void normal_one_lane(const P4& q, const GridDev& g, c
                                                 unsigned int* stats = nullptr) {
   using R = typename Scalar<P4>::type;
   const int* __restrict__ cs = g.cell_start;
+  (void)stats;
 #ifdef O3DS_NRM_STATS  // development aid (scripts/normals_stats.py): per-point work counters and wavefront clocks
   unsigned int st_cand = 0, st_acc = 0, st_rows = 0, st_ring = 0;
   const unsigned long long st_t0 = clock64();

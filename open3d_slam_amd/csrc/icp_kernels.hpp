@@ -707,8 +707,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
   constexpr int kStride = kGicp ? kRec : kRecSlots;  // doubles per query record
   static_assert((64 / kGroup) * kSegMax >= kFarList, "a wavefront's share of s_seg holds the stage-3 list");
   using R = typename Scalar<P4>::type;
-  const P4* __restrict__ src = (const P4*)a.src;
-  const P4* __restrict__ tp = (const P4*)a.tpts;
+  const P4* __restrict__ tp = (const P4*)a.tpts;  // (the source points arrive through the prefetch)
   const P4* __restrict__ tn = (const P4*)a.tnrm;
   // the pose is wave-uniform: keep it in scalar registers (it arrives through LDS in the persistent kernel)
   const double t00 = to_sgpr(Tm[0]), t10 = to_sgpr(Tm[1]), t20 = to_sgpr(Tm[2]), t01 = to_sgpr(Tm[4]), t11 = to_sgpr(Tm[5]),
@@ -1273,6 +1272,7 @@ __device__ __forceinline__ void icp_step_block(const double* s_rec, IcpStateDev*
                                                unsigned long long* tr = nullptr /* 8 timestamps, development aid */,
                                                int method = O3DS_ICP_POINT_TO_PLANE) {
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  (void)s_sc;
 #define O3DS_TSTAMP(k)                                       \
   do {                                                       \
     if (tr && threadIdx.x == 0) tr[k] = wall_clock64();      \
