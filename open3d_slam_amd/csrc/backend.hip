@@ -199,6 +199,8 @@ int read_back(o3ds_handle h, std::initializer_list<D2H> items) {
 // copied.  The host-to-device form returns with the last DMA queued (callers synchronise as before); device-to-host is complete.
 constexpr size_t kStageBytes = 1 << 20, kStageMin = 128 << 10;  // 1 MB chunks: a 3 MB cloud is three chunks, DMA and host memcpy overlap
 int stage_init(o3ds_handle h) {
+  if (h->h_stage[1] && h->stage_ev[1]) return O3DS_OK;
+  HIP_TRY(hipSetDevice(h->device));  // the events must belong to the device of the handle's stream
   for (int k = 0; k < 2; ++k) {
     if (!h->h_stage[k]) HIP_TRY(hipHostMalloc((void**)&h->h_stage[k], kStageBytes, hipHostMallocDefault));
     if (!h->stage_ev[k]) HIP_TRY(hipEventCreateWithFlags(&h->stage_ev[k], hipEventDisableTiming));
