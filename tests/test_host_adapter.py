@@ -56,6 +56,11 @@ def test_mapping_on_gpu(mapping_exe, tmp_path):
     assert "gpu checks ok" in out.stdout
 
 
+def test_stream_mapping_program_compiles(tmp_path_factory):
+    """tests/cpp/stream_mapping.cpp (the config-2 stream through the C++ classes) builds warning-free; it needs a device to run."""
+    _compile(tmp_path_factory, "stream_mapping")
+
+
 @pytest.mark.gpu
 def test_stream_mapping_through_the_cpp_classes():
     """tests/cpp/stream_mapping.cpp: eight OS-128-like scans along the figure-eight through ScanToMapIcp + Submap with host clouds at

@@ -20,6 +20,19 @@ def test_parameter_defaults_match_reference_structs():
     assert lua.scanProcessing_.cropper_.cropperName_ == "MinMaxRadius"
 
 
+def test_dense_map_builder_parameters_default_like_the_reference():
+    """MapperParameters::denseMapBuilder_ / isBuildDenseMap_ (Parameters.hpp:164-165) and SpaceCarvingParameters (:85-92)."""
+    from open3d_slam_amd import parameters as P
+
+    m = P.MapperParameters()
+    assert m.isBuildDenseMap_ is True
+    assert m.denseMapBuilder_.mapVoxelSize_ == 0.03 and m.denseMapBuilder_.cropper_.cropperName_ == "MaxRadius"
+    c = m.denseMapBuilder_.carving_
+    assert (c.voxelSize_, c.maxRaytracingLength_, c.truncationDistance_, c.carveSpaceEveryNscans_, c.minDotProductWithNormal_,
+            c.neighborhoodRadiusDenseMap_) == (0.1, 20.0, 0.1, 10, 0.5, 0.1)
+    assert m.denseMapBuilder_ is not m.mapBuilder_  # independent structs, as in the reference
+
+
 def test_cloud_registration_factory_copies_parameters():
     p = P.CloudRegistrationParameters()
     p.icp_ = P.IcpParameters(maxNumIter_=17, maxCorrespondenceDistance_=0.7, knn_=9, maxDistanceKnn_=1.5)
