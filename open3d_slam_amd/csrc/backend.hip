@@ -41,10 +41,14 @@ struct CloudRec {
   // (VoxelDownSample, an index build) and carried to clouds derived from it (subsets, voxel means, rigid placements, unions), so
   // that the next index build of the per-scan pipeline does not pay a reduction kernel + read-back + host sync for it again.
   bool has_box = false;
+  bool box_padded = false;  // the box already has a margin against the rounding of derived values (never padded twice: a map is
+                            // re-voxelised at every insertion and its box must not creep outwards over a long mission)
   double bmn[3] = {0, 0, 0}, bmx[3] = {0, 0, 0};
 };
 
 void box_inflate(CloudRec& c) {  // stored values are rounded (f32 storage, f64 -> f32 of means / placements): keep the box conservative
+  if (c.box_padded) return;
+  c.box_padded = true;
   for (int a = 0; a < 3; ++a) {
     const double pad = 1e-5 * (std::fabs(c.bmn[a]) + std::fabs(c.bmx[a]) + (c.bmx[a] - c.bmn[a])) + 1e-9;
     c.bmn[a] -= pad;
@@ -53,16 +57,19 @@ void box_inflate(CloudRec& c) {  // stored values are rounded (f32 storage, f64 
 }
 void box_copy(CloudRec& to, const CloudRec& from) {
   to.has_box = from.has_box;
+  to.box_padded = from.box_padded;
   for (int a = 0; a < 3; ++a) to.bmn[a] = from.bmn[a], to.bmx[a] = from.bmx[a];
 }
 void box_union(CloudRec& to, const CloudRec& a, const CloudRec& b) {  // of two non-empty clouds; an empty one contributes nothing
   if (a.n == 0) return box_copy(to, b);
   if (b.n == 0) return box_copy(to, a);
   to.has_box = a.has_box && b.has_box;
+  to.box_padded = a.box_padded && b.box_padded;
   for (int k = 0; k < 3; ++k) to.bmn[k] = std::min(a.bmn[k], b.bmn[k]), to.bmx[k] = std::max(a.bmx[k], b.bmx[k]);
 }
 void box_transform(CloudRec& to, const CloudRec& from, const double T[16]) {  // box of the 8 placed corners, inflated
   to.has_box = from.has_box;
+  to.box_padded = false;  // the placed values are rounded again
   if (!from.has_box) return;
   for (int a = 0; a < 3; ++a) to.bmn[a] = 1e300, to.bmx[a] = -1e300;
   for (int k = 0; k < 8; ++k) {
@@ -405,6 +412,7 @@ int build_grid_t(o3ds_handle h, const P4* pts, const P4* nrm, size_t n, double c
     if (rc) return rc;
     if (box) {
       box->has_box = true;
+      box->box_padded = false;  // exact bounds of the stored values
       for (int a = 0; a < 3; ++a) box->bmn[a] = mn[a], box->bmx[a] = mx[a];
     }
   }
@@ -1665,6 +1673,7 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
     oy = mn[1] - voxel * 0.5;
     oz = mn[2] - voxel * 0.5;
     out.has_box = true;  // voxel means lie in the box of the points they average
+    out.box_padded = false;
     for (int a = 0; a < 3; ++a) out.bmn[a] = mn[a], out.bmx[a] = mx[a];
     if (!std::isfinite(mn[0] + mn[1] + mn[2] + mx[0] + mx[1] + mx[2])) out.has_box = false;
   } else {
