@@ -1,8 +1,8 @@
 """Back-to-back calls of every preprocessing / map op with varying sizes: results must be identical run to run -- points and
-sizes exactly; normals up to the summation order of the covariance (the ring search's cell size is remembered across calls and
-refreshed now and then, so the neighbours of a point are visited, and summed, in a different order from one call to the next:
-differences of 1e-10, and a visibly different normal on the one or two points of a cloud whose two smallest eigenvalues nearly
-coincide, are that; anything else is a bug)."""
+sizes exactly; normals up to the summation order of the covariance.  (The index build places the points of a cell with an atomic
+cursor, so their order inside the cell is the arrival order of that launch, and the normals kernel sums a point's neighbours in
+that order -- DESIGN.md section 6: differences of 1e-10, and a visibly different normal on the one or two points of a cloud whose
+two smallest eigenvalues nearly coincide, are that; anything else is a bug.)"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
