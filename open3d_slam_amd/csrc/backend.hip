@@ -1801,9 +1801,18 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn) {
       HIP_TRY(hipMemset(d_stats, 0, sizeof(unsigned int) * 8 * c.n));
     }
 #endif
-#define O3DS_NRM_LAUNCH(K, B, CAP)                                                                                  \
-  normals_kernel<P4, K, B><<<(int)std::min<size_t>((c.n + (B) - 1) / (B), (CAP)), B, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, \
-                                                                                                     max_nn, rmax, p_out, d_stats)
+    // O3DS_NRM_EXACT=1: order-independent (fixed-point) covariance sums -- bit-reproducible normals, see normal_one_lane; off by default
+    // until it has had its own parity round
+    static const bool want_exact = getenv("O3DS_NRM_EXACT") != nullptr && atoi(getenv("O3DS_NRM_EXACT")) != 0;
+    const bool exact = want_exact && radius <= 200.0;
+#define O3DS_NRM_LAUNCH(K, B, CAP)                                                                                                    \
+  do {                                                                                                                                \
+    const int gsz = (int)std::min<size_t>((c.n + (B) - 1) / (B), (CAP));                                                               \
+    if (exact)                                                                                                                        \
+      normals_kernel<P4, K, B, true><<<gsz, B, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, p_out, d_stats);      \
+    else                                                                                                                              \
+      normals_kernel<P4, K, B, false><<<gsz, B, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, p_out, d_stats);     \
+  } while (0)
     if (max_nn <= 20) {  // the shipped configs' knn: 40 KB of LDS per workgroup instead of 64 KB, twice the wavefronts per SIMD
       constexpr int B = kWide ? 128 : 256;
       O3DS_NRM_LAUNCH(20, B, 8192);

@@ -898,7 +898,7 @@ __device__ __forceinline__ void finish_normal(const P4& q, double nv[3], P4* out
 
 // One lane walks the rings around its point and keeps the max_nn-best SET in LDS slots sd[j * stride], sp_[j * stride]
 // (only the set matters for a covariance); nv = eigenvector of the smallest eigenvalue, not normalised.
-template <typename P4, int KU>
+template <typename P4, int KU, bool EXACT>
 __device__ __forceinline__ void normal_one_lane(const P4& q, const GridDev& g, const P4* __restrict__ sp, double radius, int max_nn,
                                                 int rmax_cells, typename Scalar<P4>::type* sd, int* sp_, int stride, double nv[3],
                                                 unsigned int* stats = nullptr) {
@@ -1025,6 +1025,42 @@ __device__ __forceinline__ void normal_one_lane(const P4& q, const GridDev& g, c
   O3DS_ST(const unsigned long long st_t1 = clock64());
   double cov[6] = {1, 0, 0, 1, 0, 1};
   if (cnt >= 3) {
+    if constexpr (EXACT) {
+      // Order-independent cumulants (O3DS_NRM_EXACT=1): the neighbours sit in the slots in the order the walk met
+      // them, which is the order an atomic scatter gave the points of a cell -- different from one launch to the next.  Coordinates
+      // relative to the query in units of 2^-20 m as integers, sums of them and of their products in int64: exact, so any order gives
+      // the same bits (|d| <= radius <= 200 m: products < 2^56, 128 of them < 2^63).  The covariance does not depend on the origin.
+      long long si[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (int j = 0; j < cnt; j += 4) {
+        const bool v1 = j + 1 < cnt, v2 = j + 2 < cnt, v3 = j + 3 < cnt;
+        const P4 t[4] = {sp[sp_[j * stride]], sp[sp_[(v1 ? j + 1 : j) * stride]], sp[sp_[(v2 ? j + 2 : j) * stride]],
+                         sp[sp_[(v3 ? j + 3 : j) * stride]]};
+        const bool ok[4] = {true, v1, v2, v3};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (!ok[u]) continue;
+          const long long X = llrint(((double)t[u].x - (double)qx) * 1048576.0), Y = llrint(((double)t[u].y - (double)qy) * 1048576.0),
+                          Z = llrint(((double)t[u].z - (double)qz) * 1048576.0);
+          si[0] += X;
+          si[1] += Y;
+          si[2] += Z;
+          si[3] += X * X;
+          si[4] += X * Y;
+          si[5] += X * Z;
+          si[6] += Y * Y;
+          si[7] += Y * Z;
+          si[8] += Z * Z;
+        }
+      }
+      const double u1 = 1.0 / 1048576.0 / (double)cnt, u2 = u1 / 1048576.0;
+      const double m0 = (double)si[0] * u1, m1 = (double)si[1] * u1, m2 = (double)si[2] * u1;
+      cov[0] = (double)si[3] * u2 - m0 * m0;
+      cov[1] = (double)si[4] * u2 - m0 * m1;
+      cov[2] = (double)si[5] * u2 - m0 * m2;
+      cov[3] = (double)si[6] * u2 - m1 * m1;
+      cov[4] = (double)si[7] * u2 - m1 * m2;
+      cov[5] = (double)si[8] * u2 - m2 * m2;
+    } else {
     double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int j = 0; j < cnt; j += 4) {  // re-gather the neighbours, four loads in flight
       const bool v1 = j + 1 < cnt, v2 = j + 2 < cnt, v3 = j + 3 < cnt;
@@ -1054,6 +1090,7 @@ __device__ __forceinline__ void normal_one_lane(const P4& q, const GridDev& g, c
     cov[3] = c[6] - c[1] * c[1];
     cov[4] = c[7] - c[1] * c[2];
     cov[5] = c[8] - c[2] * c[2];
+    }
   }
   fast_eigen3x3_min(cov, nv);
 #ifdef O3DS_NRM_STATS
@@ -1078,7 +1115,7 @@ __device__ __forceinline__ void normal_one_lane(const P4& q, const GridDev& g, c
 // max_nn-th distance found by bisection on the float bit pattern, lane-parallel cumulants -- was exact but slower on the
 // ~100 k-point voxel-filtered scans of the config-2 stream: 0.73 ms vs 0.38 ms; at that size this kernel already fills the
 // chip and the selection overhead dominates.  Removed.)
-template <typename P4, int KMAX, int BLK>
+template <typename P4, int KMAX, int BLK, bool EXACT>
 __global__ __launch_bounds__(BLK) void normals_kernel(const P4* __restrict__ pts /* original order */, size_t n, GridDev g,
                                                       const P4* __restrict__ sp /* sorted by cell */, double radius, int max_nn, int rmax_cells,
                                                       P4* __restrict__ out_nrm, unsigned int* __restrict__ stats = nullptr) {
@@ -1092,7 +1129,7 @@ __global__ __launch_bounds__(BLK) void normals_kernel(const P4* __restrict__ pts
   for (size_t j = (size_t)blockIdx.x * BLK + tid; j < n; j += (size_t)gridDim.x * BLK) {
     const P4 q = sp[j];
     double nv[3];
-    normal_one_lane<P4, (KMAX <= 32 ? KMAX : 0)>(q, g, sp, radius, max_nn, rmax_cells, &s_d[0][tid], &s_p[0][tid], BLK, nv,
+    normal_one_lane<P4, (KMAX <= 32 ? KMAX : 0), EXACT>(q, g, sp, radius, max_nn, rmax_cells, &s_d[0][tid], &s_p[0][tid], BLK, nv,
                                                  stats ? stats + 8 * j : nullptr);
     finish_normal<P4>(q, nv, &out_nrm[(size_t)q.i]);
   }
