@@ -899,7 +899,8 @@ __device__ __forceinline__ void finish_normal(const P4& q, double nv[3], P4* out
 // One lane walks the rings around its point and keeps the max_nn-best SET in LDS slots sd[j * stride], sp_[j * stride]
 // (only the set matters for a covariance); nv = eigenvector of the smallest eigenvalue, not normalised.
 template <typename P4, int KU, bool EXACT>
-__device__ __forceinline__ void normal_one_lane(const P4& q, const GridDev& g, const P4* __restrict__ sp, double radius, int max_nn,
+__device__ __forceinline__ void normal_one_lane(const P4& q, const GridDev& g, const P4* __restrict__ sp, const P4* __restrict__ pts_orig,
+                                                double radius, int max_nn,
                                                 int rmax_cells, typename Scalar<P4>::type* sd, int* sp_, int stride, double nv[3],
                                                 unsigned int* stats = nullptr) {
   using R = typename Scalar<P4>::type;
@@ -921,13 +922,19 @@ __device__ __forceinline__ void normal_one_lane(const P4& q, const GridDev& g, c
   mf = fmin(mf, fmin(fy - floor(fy), 1.0 - (fy - floor(fy))));
   mf = fmin(mf, fmin(fz - floor(fz), 1.0 - (fz - floor(fz))));
 
-  auto offer = [&](R d2, int p, bool ok) {
+  // EXACT: the set kept is the max_nn smallest by (d2, original index) -- a tie at the max_nn-th distance (two candidates with the
+  // same f32 d2: about one point per 50 k-point cloud has one) otherwise goes to whichever candidate the walk meets first, and the
+  // order inside a cell is the arrival order of the index build's atomic scatter.  The slots then hold ORIGINAL indices.
+  int worst_oi = 0;
+  auto offer = [&](R d2, int p, bool ok, int oi) {
     O3DS_ST(st_cand += ok);
-    if (ok && d2 < worst) {
+    bool take = ok && d2 < worst;
+    if constexpr (EXACT) take = take || (ok && cnt == max_nn && d2 == worst && oi < worst_oi);
+    if (take) {
       O3DS_ST(++st_acc);
       const int slot = cnt < max_nn ? cnt : worst_slot;
       sd[slot * stride] = d2;
-      sp_[slot * stride] = p;
+      sp_[slot * stride] = EXACT ? oi : p;
       if (cnt < max_nn) ++cnt;
       if (cnt == max_nn) {  // list full: the bound becomes the current maximum
         R m = sd[0];
@@ -946,12 +953,37 @@ __device__ __forceinline__ void normal_one_lane(const P4& q, const GridDev& g, c
               ms = j;
             }
           }
+          if constexpr (EXACT) {  // among the slots that hold the maximum, the one to evict next has the LARGEST original index
+            worst_oi = sp_[ms * stride];
+#pragma unroll
+            for (int j = 1; j < KU; ++j) {
+              if (j < max_nn && j != ms && v[j] == m) {  // rare: only then is the second LDS read paid
+                const int oj = sp_[j * stride];
+                if (oj > worst_oi) {
+                  worst_oi = oj;
+                  ms = j;
+                }
+              }
+            }
+          }
         } else {
           for (int j = 1; j < max_nn; ++j) {
             const R v = sd[j * stride];
             if (v > m) {
               m = v;
               ms = j;
+            }
+          }
+          if constexpr (EXACT) {
+            worst_oi = sp_[ms * stride];
+            for (int j = 0; j < max_nn; ++j) {
+              if (j != ms && sd[j * stride] == m) {
+                const int oj = sp_[j * stride];
+                if (oj > worst_oi) {
+                  worst_oi = oj;
+                  ms = j;
+                }
+              }
             }
           }
         }
@@ -968,10 +1000,10 @@ __device__ __forceinline__ void normal_one_lane(const P4& q, const GridDev& g, c
       const R a1 = t1.x - qx, b1 = t1.y - qy, c1 = t1.z - qz;
       const R a2 = t2.x - qx, b2 = t2.y - qy, c2 = t2.z - qz;
       const R a3 = t3.x - qx, b3 = t3.y - qy, c3 = t3.z - qz;
-      offer(a0 * a0 + b0 * b0 + c0 * c0, p, true);
-      offer(a1 * a1 + b1 * b1 + c1 * c1, p + 1, v1);
-      offer(a2 * a2 + b2 * b2 + c2 * c2, p + 2, v2);
-      offer(a3 * a3 + b3 * b3 + c3 * c3, p + 3, v3);
+      offer(a0 * a0 + b0 * b0 + c0 * c0, p, true, (int)t0.i);
+      offer(a1 * a1 + b1 * b1 + c1 * c1, p + 1, v1, (int)t1.i);
+      offer(a2 * a2 + b2 * b2 + c2 * c2, p + 2, v2, (int)t2.i);
+      offer(a3 * a3 + b3 * b3 + c3 * c3, p + 3, v3, (int)t3.i);
     }
   };
 
@@ -1031,10 +1063,10 @@ __device__ __forceinline__ void normal_one_lane(const P4& q, const GridDev& g, c
       // relative to the query in units of 2^-20 m as integers, sums of them and of their products in int64: exact, so any order gives
       // the same bits (|d| <= radius <= 200 m: products < 2^56, 128 of them < 2^63).  The covariance does not depend on the origin.
       long long si[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-      for (int j = 0; j < cnt; j += 4) {
+      for (int j = 0; j < cnt; j += 4) {  // the slots hold original indices here: gather from the cloud in its own order
         const bool v1 = j + 1 < cnt, v2 = j + 2 < cnt, v3 = j + 3 < cnt;
-        const P4 t[4] = {sp[sp_[j * stride]], sp[sp_[(v1 ? j + 1 : j) * stride]], sp[sp_[(v2 ? j + 2 : j) * stride]],
-                         sp[sp_[(v3 ? j + 3 : j) * stride]]};
+        const P4 t[4] = {pts_orig[sp_[j * stride]], pts_orig[sp_[(v1 ? j + 1 : j) * stride]], pts_orig[sp_[(v2 ? j + 2 : j) * stride]],
+                         pts_orig[sp_[(v3 ? j + 3 : j) * stride]]};
         const bool ok[4] = {true, v1, v2, v3};
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -1125,11 +1157,10 @@ __global__ __launch_bounds__(BLK) void normals_kernel(const P4* __restrict__ pts
   const int tid = threadIdx.x;
   // queries are taken in CELL order (sp), so the lanes of a wavefront walk the same few cells: their candidate loads hit the same
   // cache lines and their ring loops end together; the normal goes back to the point's original slot (sp[j].i)
-  (void)pts;
   for (size_t j = (size_t)blockIdx.x * BLK + tid; j < n; j += (size_t)gridDim.x * BLK) {
     const P4 q = sp[j];
     double nv[3];
-    normal_one_lane<P4, (KMAX <= 32 ? KMAX : 0), EXACT>(q, g, sp, radius, max_nn, rmax_cells, &s_d[0][tid], &s_p[0][tid], BLK, nv,
+    normal_one_lane<P4, (KMAX <= 32 ? KMAX : 0), EXACT>(q, g, sp, pts, radius, max_nn, rmax_cells, &s_d[0][tid], &s_p[0][tid], BLK, nv,
                                                  stats ? stats + 8 * j : nullptr);
     finish_normal<P4>(q, nv, &out_nrm[(size_t)q.i]);
   }

@@ -1,7 +1,8 @@
 """Back-to-back calls of every preprocessing / map op with varying sizes: results must be identical run to run -- points and
-sizes exactly.  Normals are known NOT to repeat to the last bit (open): differences of 1e-10, and a visibly
-different normal on the one or two points of a cloud whose two smallest eigenvalues nearly coincide, are reported separately as
-"summation order / neighbour order"; anything else is a bug."""
+sizes exactly.  Normals repeat to the last bit only with O3DS_NRM_EXACT=1 (by default a tie at the max_nn-th
+distance and the covariance sums follow the order an atomic scatter gave the points of a cell): differences of 1e-10, and a visibly
+different normal on the one or two points of a cloud whose two smallest eigenvalues nearly coincide, are reported separately;
+anything else is a bug."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -43,4 +44,4 @@ for rep in range(8):
                     print("MISMATCH rep", rep, "scan", k, "stage", ["crop", "voxel+normals", "transform", "map"][j], a.shape, "max|dpts|", dp, "max|dnrm|", dn, "#nrm>1e-6", nbad)
         for x in (c, cr, v, t, m):
             be.free(x)
-print("done, mismatches:", bad, " clouds whose normals differ in the last bits (known, open):", tiny)
+print("done, mismatches:", bad, " clouds whose normals differ in the last bits (default mode, see docstring):", tiny)
