@@ -178,6 +178,7 @@ class Backend:
         if precision != PRECISION_F32:
             self._ck(self.lib.o3ds_set_precision(self.h, precision))
         self.device_id = device_id
+        self.precision = precision
 
     def close(self):
         if getattr(self, "h", None):

@@ -125,3 +125,92 @@ class ShardedIcp:
             passes = run_sharded_fused_loop(issue_pass, all_reduce, be.icp_done, max_iter, check_every)
             last = self.sums[(passes - 1) % 3]
             return be.icp_pass_finish(n_total, last.data_ptr(), self.sums[passes % 3].data_ptr())
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Multi-GPU fusion of ONE dense voxel map (BASELINE configs[4]; SURVEY.md 8e "map fusion across GPUs").  The path has one exchange
+# step: a voxel's running sums must live on one rank, so every insertion routes each point to the owner of its voxel -- one
+# all-to-all of the scan's points (a few MB; direct, not a ring: xGMI is point-to-point) -- and the owner fuses what it receives
+# into its local table.  No other collective: the union of the per-rank tables IS the map, a voxel never straddles ranks.
+
+
+def voxel_owner(points, voxel: float, world: int, storage="f64"):
+    """Rank that owns the voxel of every point: the voxel index is the reference's floor(p * (1 / voxel)) (VoxelHashMap.hpp:47-50),
+    the owner its hash x + 17191 y + 17191^2 z (VoxelHashMap.hpp:25-35, as a 32-bit unsigned) modulo the world size.  `storage`
+    ("f32" / "f64") is the precision the fusing backend stores points in: the owner has to be decided on the value the device will
+    bin, or a point that f32 rounding moves across a voxel face would found the same voxel on two ranks."""
+    import numpy as np
+
+    p = np.asarray(points, dtype=np.float64)
+    if storage == "f32":
+        p = p.astype(np.float32).astype(np.float64)
+    k = np.floor(p * (1.0 / voxel)).astype(np.int64)
+    h = (k[:, 0] + 17191 * k[:, 1] + 17191 * 17191 * k[:, 2]) & 0xFFFFFFFF
+    return (h % world).astype(np.int64)
+
+
+def exchange_by_owner(points, normals, voxel: float, group=None, device=None, storage="f64"):
+    """One insertion's exchange step: returns the rows (points, normals or None) whose voxels this rank owns, gathered from all
+    ranks.  Counts go first (all_to_all of world ints), then one all_to_all of the rows, sorted by destination.  `device`: where the
+    collective's tensors live (None = CPU for gloo; the rank's GPU for nccl / RCCL)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    points = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    cols = 3 if normals is None else 6
+    rows = points if normals is None else np.hstack([points, np.ascontiguousarray(normals, dtype=np.float64).reshape(-1, 3)])
+    if world == 1:
+        return points, normals
+    owner = voxel_owner(points, voxel, world, storage)
+    order = np.argsort(owner, kind="stable")  # rows grouped by destination, original order kept inside a group
+    send_counts = np.bincount(owner, minlength=world).astype(np.int64)
+    t_send_counts = torch.from_numpy(send_counts).to(device) if device is not None else torch.from_numpy(send_counts)
+    t_recv_counts = torch.empty_like(t_send_counts)
+    dist.all_to_all_single(t_recv_counts, t_send_counts, group=group)
+    recv_counts = t_recv_counts.cpu().numpy()
+    t_send = torch.from_numpy(np.ascontiguousarray(rows[order]))
+    if device is not None:
+        t_send = t_send.to(device)
+    t_recv = torch.empty((int(recv_counts.sum()), cols), dtype=torch.float64, device=t_send.device)
+    dist.all_to_all_single(t_recv, t_send, output_split_sizes=[int(c) for c in recv_counts], input_split_sizes=[int(c) for c in send_counts],
+                           group=group)
+    got = t_recv.cpu().numpy()
+    return got[:, :3].copy(), (None if normals is None else got[:, 3:].copy())
+
+
+class ShardedDenseMap:
+    """One VoxelizedPointCloud (Voxel.hpp:59-76) spread over the ranks of a process group by voxel owner.  insert() takes THIS rank's
+    share of a scan (e.g. the sensors attached to this GPU) already placed in the map frame, exchanges, and fuses the received rows
+    into the local device table (o3ds_dense_map_insert); size() is the global voxel count.  The exchange goes through torch tensors
+    on `device` (plumbing); the fusion is the backend's.  Host-staged: the rows come from / go to numpy on either side of the
+    collective -- an o3ds entry point that exports / imports device rows would remove two PCIe hops per insertion (not built)."""
+
+    def __init__(self, be, voxel: float, group=None, device=None):
+        self.be, self.voxel, self.group, self.device = be, float(voxel), group, device
+        self.storage = "f64" if getattr(be, "precision", 0) == 1 else "f32"  # backend.PRECISION_F64 == 1
+        self.dm = be.dense_map_create(self.voxel)
+
+    def insert(self, points, normals=None):
+        p, n = exchange_by_owner(points, normals, self.voxel, self.group, self.device, self.storage)
+        if len(p):
+            c = self.be.upload(p, n)
+            self.be.dense_map_insert(self.dm, c)
+            self.be.free(c)
+        return len(p)
+
+    def local_size(self) -> int:
+        return self.be.dense_map_size(self.dm)
+
+    def size(self) -> int:
+        import torch
+        import torch.distributed as dist
+
+        t = torch.tensor([self.local_size()], dtype=torch.int64, device=self.device)
+        if dist.is_initialized():
+            dist.all_reduce(t, group=self.group)
+        return int(t.item())
+
+    def close(self):
+        self.be.dense_map_free(self.dm)

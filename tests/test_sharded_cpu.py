@@ -182,3 +182,72 @@ def test_fused_loop_control_flow():
     stop_at = iter([False, True])
     log.clear()
     assert run_sharded_fused_loop(issue, allred, lambda: next(stop_at), max_iteration=50, check_every=2) == 4  # stops at the second poll
+
+
+# ---- one dense voxel map over two ranks: the exchange step of the fusion (sharded.exchange_by_owner) -------------------------------
+def _fusion_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    from oracle import pyoracle as oracle
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scene = syn.make_scene()
+    voxel = 0.1
+    means, counts = {}, {}
+    received = 0
+    for ins in range(3):  # three insertions; every rank contributes its own share of each (different sizes: ragged all-to-all)
+        pts, nrm = syn.sample_map(scene, 20_000 + 5_000 * rank + 1_000 * ins, seed=100 + 10 * ins + rank)
+        p, n = sharded.exchange_by_owner(pts, nrm, voxel, None, None)
+        assert np.all(sharded.voxel_owner(p, voxel, world) == rank)  # only voxels this rank owns arrive here
+        received += len(p)
+        means.setdefault("p", []).append(p)
+        means.setdefault("n", []).append(n)
+    allp, alln = np.vstack(means["p"]), np.vstack(means["n"])
+    fp, fn, fc = oracle.dense_fuse(allp, alln, voxel)  # the local fusion, played by the oracle (no GPU here)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), p=fp, n=fn, c=fc, received=received)
+    empty_p, empty_n = sharded.exchange_by_owner(np.zeros((0, 3)), None, voxel, None, None)  # a rank with nothing to send still takes part
+    assert empty_p.shape == (0, 3) and empty_n is None
+    dist.destroy_process_group()
+
+
+def test_voxel_owner_is_a_function_of_the_voxel():
+    rng = np.random.default_rng(0)
+    p = rng.uniform(-30, 30, size=(5000, 3))
+    for world in (1, 2, 3, 8):
+        o = sharded.voxel_owner(p, 0.1, world)
+        assert o.min() >= 0 and o.max() < world
+        jitter = p + rng.uniform(0.0, 1e-9, size=p.shape) * (np.floor((p + 1e-9) * 10) == np.floor(p * 10))  # stays inside the voxel
+        np.testing.assert_array_equal(sharded.voxel_owner(jitter, 0.1, world), o)
+    # the owner is decided on the value the device will store: 0.7 is voxel 7 as a double and voxel 6 once rounded to float32
+    edge = np.array([[0.7, 0.05, 0.05]])
+    k64 = np.floor(edge * 10.0)[0, 0]
+    k32 = np.floor(edge.astype(np.float32).astype(np.float64) * 10.0)[0, 0]
+    assert (k64, k32) == (7.0, 6.0)
+    assert sharded.voxel_owner(edge, 0.1, 1 << 20, "f64")[0] != sharded.voxel_owner(edge, 0.1, 1 << 20, "f32")[0]
+    counts = np.bincount(sharded.voxel_owner(p, 0.1, 8), minlength=8)
+    assert counts.min() > 0.6 * counts.mean()  # the reference's hash spreads a room's voxels over 8 owners reasonably evenly
+
+
+def test_world2_gloo_dense_map_fusion_equals_single_map(tmp_path, oracle):
+    """Two ranks, three ragged insertions each: after the exchange every voxel lives on exactly one rank, and the union of the per-rank
+    fusions is the fusion of all points on one rank -- same voxel set, same counts, same means."""
+    mp.spawn(_fusion_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    parts = [np.load(str(tmp_path / f"rank{r}.npz")) for r in range(2)]
+    scene = syn.make_scene()
+    clouds = [syn.sample_map(scene, 20_000 + 5_000 * r + 1_000 * ins, seed=100 + 10 * ins + r) for ins in range(3) for r in range(2)]
+    allp, alln = np.vstack([c[0] for c in clouds]), np.vstack([c[1] for c in clouds])
+    assert sum(int(p["received"]) for p in parts) == len(allp)  # nothing lost, nothing duplicated
+    rp, rn, rc = oracle.dense_fuse(allp, alln, 0.1)
+    key = lambda a: np.floor(a * 10.0 + 1e-9 * 0).astype(np.int64)  # means lie inside their voxels
+    got_p, got_n, got_c = np.vstack([p["p"] for p in parts]), np.vstack([p["n"] for p in parts]), np.concatenate([p["c"] for p in parts])
+    assert len(got_p) == len(rp) and int(got_c.sum()) == int(rc.sum()) == len(allp)
+    from scipy.spatial import cKDTree
+
+    d, j = cKDTree(rp).query(got_p)
+    assert len(np.unique(j)) == len(rp) and d.max() < 1e-9  # a bijection between the sharded voxels and the single map's
+    np.testing.assert_array_equal(got_c, rc[j])
+    np.testing.assert_allclose(got_n, rn[j], atol=1e-9)
+    # and no voxel on both ranks
+    k0, k1 = set(map(tuple, key(parts[0]["p"]))), set(map(tuple, key(parts[1]["p"])))
+    assert not (k0 & k1)
