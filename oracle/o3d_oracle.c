@@ -168,15 +168,24 @@ void orc_kdtree_free(orc_kdtree* t) {
 
 typedef struct {
   int k, count;
-  double worst; /* candidates must satisfy d2 < worst (strict) */
+  double worst;     /* candidates must satisfy d2 < worst (strict) ... */
+  int32_t worst_id; /* ... or, once k are held, tie the k-th distance with a smaller original index */
   int32_t* idx;
   double* d2;
 } knn_state;
 
+/* Order of equal distances.  nanoflann's KNNResultSet keeps equal distances in the order the tree walk met them and lets
+ * the first one met keep the k-th place, i.e. [O3D] leaves ties to the shape of its tree.  The oracle fixes what [O3D] leaves
+ * open: neighbours are ordered by (d2, original index) -- a total order that does not depend on any tree (or grid), so that a
+ * result can be reproduced bit for bit by an implementation with a different search structure. */
+static inline int knn_accepts(const knn_state* s, double d2, int32_t id) {
+  return d2 < s->worst || (s->count == s->k && d2 == s->worst && id < s->worst_id);
+}
+
 static inline void knn_push(knn_state* s, double d2, int32_t id) {
-  /* insertion into ascending list of at most k entries */
+  /* insertion into a list of at most k entries, ascending by (d2, id) */
   int pos = s->count < s->k ? s->count : s->k - 1;
-  while (pos > 0 && s->d2[pos - 1] > d2) {
+  while (pos > 0 && (s->d2[pos - 1] > d2 || (s->d2[pos - 1] == d2 && s->idx[pos - 1] > id))) {
     s->d2[pos] = s->d2[pos - 1];
     s->idx[pos] = s->idx[pos - 1];
     --pos;
@@ -184,7 +193,10 @@ static inline void knn_push(knn_state* s, double d2, int32_t id) {
   s->d2[pos] = d2;
   s->idx[pos] = id;
   if (s->count < s->k) ++s->count;
-  if (s->count == s->k) s->worst = s->d2[s->k - 1];
+  if (s->count == s->k) {
+    s->worst = s->d2[s->k - 1];
+    s->worst_id = s->idx[s->k - 1];
+  }
 }
 
 static void search_rec(const orc_kdtree* t, int32_t node, const double q[3], knn_state* s) {
@@ -194,7 +206,7 @@ static void search_rec(const orc_kdtree* t, int32_t node, const double q[3], knn
       const double* p = t->pts + 3 * (size_t)i;
       double dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
       double d2 = dx * dx + dy * dy + dz * dz;
-      if (d2 < s->worst) knn_push(s, d2, t->idx[i]);
+      if (knn_accepts(s, d2, t->idx[i])) knn_push(s, d2, t->idx[i]);
     }
     return;
   }
@@ -202,7 +214,7 @@ static void search_rec(const orc_kdtree* t, int32_t node, const double q[3], knn
   int32_t near = diff < 0 ? nd->left : nd->right;
   int32_t far = diff < 0 ? nd->right : nd->left;
   search_rec(t, near, q, s);
-  if (diff * diff < s->worst) search_rec(t, far, q, s);
+  if (diff * diff <= s->worst) search_rec(t, far, q, s); /* <=: a tie on the far side may carry a smaller index */
 }
 
 int orc_kdtree_search_hybrid(const orc_kdtree* t, const double q[3], double radius, int max_nn, int32_t* idx, double* d2) {
@@ -211,6 +223,7 @@ int orc_kdtree_search_hybrid(const orc_kdtree* t, const double q[3], double radi
   s.k = max_nn;
   s.count = 0;
   s.worst = radius * radius; /* [O3D] kNN then keep entries with d2 < r^2 (lower_bound) */
+  s.worst_id = 0;
   s.idx = idx;
   s.d2 = d2;
   search_rec(t, 0, q, &s);
@@ -223,6 +236,7 @@ int orc_kdtree_search_knn(const orc_kdtree* t, const double q[3], int k, int32_t
   s.k = k;
   s.count = 0;
   s.worst = DBL_MAX;
+  s.worst_id = 0;
   s.idx = idx;
   s.d2 = d2;
   search_rec(t, 0, q, &s);
@@ -1198,6 +1212,65 @@ int orc_icp_generalized(const double* src, const double* src_nrm, size_t n, cons
 /* ------------------------------------------------------------------ A.5
  * [O3D] FastEigen3x3 (Geometric Tools "robust eigensolver for 3x3 symmetric
  * matrices"): returns the eigenvector of the smallest eigenvalue. */
+/* std::acos / std::cos of FastEigen3x3, made portable.  [O3D] calls the platform's libm, whose last bit differs between
+ * platforms (and from a GPU's math library); where two eigenvalues of a neighbourhood nearly coincide that bit decides which
+ * eigenvector comes out.  The oracle therefore spells the two functions out with +, -, *, / and sqrt only (IEEE-754: the same
+ * bits on every conforming machine when compiled without contraction, -ffp-contract=off): Taylor / binomial series in Horner
+ * form on reduced arguments, coefficients = exact rationals rounded to double (scripts/gen_det_trig.py).  Within 2 ulp of libm
+ * (tests/test_oracle.py::test_portable_acos_cos_agree_with_libm).  The device code evaluates the same expressions in the same
+ * order (open3d_slam_amd/csrc/det_math.hpp). */
+static const double kAsinC[27] = {
+    0x1.5555555555555p-3, 0x1.3333333333333p-4, 0x1.6db6db6db6db7p-5, 0x1.f1c71c71c71c7p-6, 0x1.6e8ba2e8ba2e9p-6, 0x1.1c4ec4ec4ec4fp-6,
+    0x1.c99999999999ap-7, 0x1.7a87878787878p-7, 0x1.3fde50d79435ep-7, 0x1.12ef3cf3cf3cfp-7, 0x1.df3bd37a6f4dfp-8, 0x1.a6863d70a3d71p-8,
+    0x1.782dda12f684cp-8, 0x1.51ba308d3dcb1p-8, 0x1.31683bdef7bdfp-8, 0x1.15ee9d45d1746p-8, 0x1.fcaf8fb6db6dbp-9, 0x1.d3d2a8e0dd67dp-9,
+    0x1.b026f57b13b14p-9, 0x1.90cb77f60c7cep-9, 0x1.750de64d7d05fp-9, 0x1.5c5f56efaaaabp-9, 0x1.464c0950f7d47p-9, 0x1.3275586c5f2f0p-9,
+    0x1.208d3570ae5a6p-9, 0x1.1052bc5fa960ap-9, 0x1.018f963c229bfp-9};
+static const double kCosC[11] = {-0x1.0000000000000p-1, 0x1.5555555555555p-5,  -0x1.6c16c16c16c17p-10, 0x1.a01a01a01a01ap-16,
+                                 -0x1.27e4fb7789f5cp-22, 0x1.1eed8eff8d898p-29, -0x1.93974a8c07c9dp-37, 0x1.ae7f3e733b81fp-45,
+                                 -0x1.6827863b97d97p-53, 0x1.e542ba4020225p-62, -0x1.0ce396db7f853p-70};
+static const double kSinC[10] = {-0x1.5555555555555p-3,  0x1.1111111111111p-7,  -0x1.a01a01a01a01ap-13, 0x1.71de3a556c734p-19,
+                                 -0x1.ae64567f544e4p-26, 0x1.6124613a86d09p-33, -0x1.ae7f3e733b81fp-41, 0x1.952c77030ad4ap-49,
+                                 -0x1.2f49b46814157p-57, 0x1.71b8ef6dcf572p-66};
+#define ORC_PIO2_HI 0x1.921fb54442d18p+0
+#define ORC_PIO2_LO 0x1.1a62633145c07p-54
+#define ORC_PI_HI 0x1.921fb54442d18p+1
+#define ORC_PI_LO 0x1.1a62633145c07p-53
+#define ORC_PIO4 0x1.921fb54442d18p-1
+#define ORC_PI3O4 0x1.2d97c7f3321d2p+1
+
+static double asin_tail(double z) { /* P(z): asin(s) = s + s*z*P(z), z = s*s <= 1/4 */
+  double p = kAsinC[26];
+  for (int k = 25; k >= 0; --k) p = p * z + kAsinC[k];
+  return p;
+}
+double orc_acos(double x) { /* x in [-1, 1] */
+  if (x >= 0.5) {
+    double z = (1.0 - x) * 0.5, s = sqrt(z);
+    return 2.0 * (s + s * z * asin_tail(z));
+  }
+  if (x <= -0.5) {
+    double z = (1.0 + x) * 0.5, s = sqrt(z);
+    return (ORC_PI_HI - 2.0 * (s + s * z * asin_tail(z))) + ORC_PI_LO;
+  }
+  double z = x * x;
+  return (ORC_PIO2_HI - (x + x * z * asin_tail(z))) + ORC_PIO2_LO;
+}
+static double cos_series(double y) { /* |y| <= pi/4 */
+  double w = y * y, p = kCosC[10];
+  for (int k = 9; k >= 0; --k) p = p * w + kCosC[k];
+  return 1.0 + w * p;
+}
+static double sin_series(double y) { /* |y| <= pi/4 */
+  double w = y * y, p = kSinC[9];
+  for (int k = 8; k >= 0; --k) p = p * w + kSinC[k];
+  return y + y * w * p;
+}
+double orc_cos(double x) { /* x in [0, pi] */
+  if (x <= ORC_PIO4) return cos_series(x);
+  if (x < ORC_PI3O4) return sin_series((ORC_PIO2_HI - x) + ORC_PIO2_LO);
+  return -cos_series((ORC_PI_HI - x) + ORC_PI_LO);
+}
+
 static void cross3(const double a[3], const double b[3], double c[3]) {
   c[0] = a[1] * b[2] - a[2] * b[1];
   c[1] = a[2] * b[0] - a[0] * b[2];
@@ -1303,10 +1376,10 @@ void orc_fast_eigen3x3_min_evec(const double cov[9], double out[3]) {
     double half_det = det * 0.5;
     if (half_det < -1.0) half_det = -1.0;
     if (half_det > 1.0) half_det = 1.0;
-    double angle = acos(half_det) / 3.0;
+    double angle = orc_acos(half_det) / 3.0;
     const double two_thirds_pi = 2.09439510239319549;
-    double beta2 = cos(angle) * 2.0;
-    double beta0 = cos(angle + two_thirds_pi) * 2.0;
+    double beta2 = orc_cos(angle) * 2.0;
+    double beta0 = orc_cos(angle + two_thirds_pi) * 2.0;
     double beta1 = -(beta0 + beta2);
     double e0 = q + p * beta0, e1 = q + p * beta1, e2 = q + p * beta2;
     double v0[3], v1[3], v2[3];

@@ -128,6 +128,9 @@ void orc_covariance_from_normal(const double nrm[3], double epsilon, double cov[
  * (call site open3d_slam/src/CloudRegistration.cpp:49-56).  normals out: 3n */
 void orc_estimate_normals(const double* pts, size_t n, double radius, int max_nn, double* normals);
 void orc_fast_eigen3x3_min_evec(const double cov[9], double out[3]);
+/* portable restatements of std::acos on [-1,1] and std::cos on [0,pi] used by it (see o3d_oracle.c) */
+double orc_acos(double x);
+double orc_cos(double x);
 
 /* A.6 VoxelDownSample (data-anchored grid); out arrays sized >= 3n; returns m; output order = first occurrence.
  * nrm/out_nrm may be NULL */

@@ -91,6 +91,10 @@ def lib():
         L.orc_covariance_from_normal.argtypes = [_dp, C.c_double, _dp]
         L.orc_estimate_normals.argtypes = [_dp, C.c_size_t, C.c_double, C.c_int, _dp]
         L.orc_fast_eigen3x3_min_evec.argtypes = [_dp, _dp]
+        L.orc_acos.restype = C.c_double
+        L.orc_acos.argtypes = [C.c_double]
+        L.orc_cos.restype = C.c_double
+        L.orc_cos.argtypes = [C.c_double]
         L.orc_voxel_down_sample.restype = C.c_size_t
         L.orc_voxel_down_sample.argtypes = [_dp, _dp, C.c_size_t, C.c_double, _dp, _dp]
         L.orc_crop_indices.restype = C.c_size_t

@@ -185,6 +185,38 @@ def test_fast_eigen_matches_eigh(oracle):
     assert list(oracle.fast_eigen3x3_min_evec(np.eye(3))) == [0, 0, 1]
 
 
+def test_portable_acos_cos_agree_with_libm(oracle):
+    """FastEigen3x3's acos / cos are spelled out in IEEE basic operations (the same bits on the CPU and the GPU); they must
+    stay within 2 ulp of libm, which is what [O3D] calls."""
+    import ctypes as C
+    L = oracle.lib()
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([rng.uniform(-1, 1, 20000), [-1.0, -0.5, 0.0, 0.5, 1.0, 1 - 1e-16, -1 + 1e-16], 1 - np.logspace(-16, -1, 200),
+                         -1 + np.logspace(-16, -1, 200)])
+    got = np.array([L.orc_acos(C.c_double(x)) for x in xs])
+    ref = np.arccos(xs)
+    assert np.all(np.abs(got - ref) <= 2 * np.spacing(np.maximum(ref, 1e-300)) + 0), np.max(np.abs(got - ref) / np.spacing(np.maximum(ref, 1e-300)))
+    ang = np.concatenate([rng.uniform(0, np.pi, 20000), [0.0, np.pi / 4, np.pi / 2, 3 * np.pi / 4, np.pi, np.pi / 3, np.pi / 3 + 2.09439510239319549]])
+    gc = np.array([L.orc_cos(C.c_double(a)) for a in ang])
+    rc = np.cos(ang)
+    assert np.all(np.abs(gc - rc) <= 2.0 ** -52), np.max(np.abs(gc - rc))
+
+
+def test_neighbours_are_ordered_by_distance_then_index(oracle):
+    """The oracle fixes the order [O3D] leaves to its tree: (d2, original index) -- lattice points give plenty of exact ties."""
+    g = np.arange(-3, 4, dtype=float)
+    pts = np.array([[x, y, z] for x in g for y in g for z in g])
+    rng = np.random.default_rng(0)
+    pts = pts[rng.permutation(len(pts))]
+    tree = oracle.KDTree(pts)
+    q = np.zeros(3)
+    for k in (1, 5, 7, 20, 27):
+        idx, d2 = tree.search_hybrid(q, 10.0, k)
+        full = np.einsum("ij,ij->i", pts - q, pts - q)
+        order = np.lexsort((np.arange(len(pts)), full))[:k]
+        assert list(idx) == list(order) and np.array_equal(d2, full[order])
+
+
 def test_c_oracle_equals_numpy_restatement(oracle, small_c2):
     src, tgt, nrm, _ = small_c2
     a = oracle.icp_point_to_plane(src, tgt, nrm, 1.0, max_iter=10, rel_fitness=0.0, rel_rmse=0.0)
