@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libo3ds_backend.so")
+LIB_PATH = os.environ.get("O3DS_BACKEND_LIB") or os.path.join(_PKG, "lib", "libo3ds_backend.so")  # the override is a development aid (instrumented builds)
 
 OK = 0
 ERR_INVALID_ARG, ERR_NO_NORMALS, ERR_OOM, ERR_HIP, ERR_BAD_HANDLE, ERR_EMPTY, ERR_CAPACITY = -1, -2, -3, -4, -5, -6, -7

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <initializer_list>
+#include <map>
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <mutex>
@@ -18,6 +19,7 @@
 #include "cloud_kernels.hpp"
 #include "common.hpp"
 #include "icp_kernels.hpp"
+#include "normals_kernel.hpp"
 
 using namespace o3ds;
 
@@ -130,6 +132,10 @@ struct o3ds_context {
   int session_method = O3DS_ICP_POINT_TO_PLANE;
   double gicp_epsilon = 1e-3;  // [O3D] TransformationEstimationForGeneralizedICP default
   hipStream_t own_stream = nullptr;
+  // device memory of the handle: a caching allocator over hipMalloc (dev_alloc / dev_free below)
+  std::multimap<size_t, void*> pool_free;        // cached blocks by size
+  std::unordered_map<void*, size_t> pool_size;   // every block this handle obtained from hipMalloc -> its size
+  size_t pool_bytes = 0;
   // bump arena for the temporaries of one top-level ABI call (stream-ordered reuse: everything runs on one stream)
   std::vector<std::pair<char*, size_t>> arena_blocks;
   size_t arena_cur = 0, arena_off = 0;
@@ -169,8 +175,11 @@ int fail(o3ds_handle h, int code, const std::string& msg) {
                   std::string(#expr) + ": " + hipGetErrorString(_e) + " @" + __FILE__ + ":" + std::to_string(__LINE__)); \
   } while (0)
 
-#define CHECK_HANDLE(h) \
-  if (!(h)) return fail(nullptr, O3DS_ERR_BAD_HANDLE, "null handle")
+// Every entry point makes the handle's device the calling thread's current device: the current device is per thread and defaults to
+// 0, handles are shared across the caller's worker threads (host/o3ds_mapping.hpp) and one process may drive one handle per GPU.
+#define CHECK_HANDLE(h)                                                        \
+  if (!(h)) return fail(nullptr, O3DS_ERR_BAD_HANDLE, "null handle");          \
+  if (hipSetDevice((h)->device) != hipSuccess) return fail((h), O3DS_ERR_HIP, "hipSetDevice failed")
 
 // ---- small read-backs ---------------------------------------------------------------------------------------------
 // Sizes, counts and bounding boxes that the host needs go through a pinned block owned by the handle: a D2H copy into pageable
@@ -255,6 +264,58 @@ int d2h_copy(o3ds_handle h, void* h_dst, const void* d_src, size_t bytes) {  // 
   return O3DS_OK;
 }
 
+// ---- device memory -------------------------------------------------------------------------------------------------
+// Every device buffer of a handle (clouds, indices, arena blocks) comes from this cache over plain hipMalloc.  All work of a handle
+// is ordered on ONE stream (o3ds_set_stream synchronises the stream it leaves), so a block handed back by dev_free may be handed out
+// again at once: whatever still reads it was enqueued earlier on the same stream -- the semantics of a stream-ordered pool without
+// the runtime's.  Round 1 used hipMallocAsync / hipFreeAsync; under alloc / free churn of blocks of tens to hundreds of MB
+// (estimate_normals with a fine pilot grid: a 150 MB scratch block, 40 MB cell tables per call) ROCm 7.2's pool intermittently
+// handed out memory whose contents were then lost -- cell_start came back zeroed from some cell on, or the GPU faulted on it
+// (scripts/stress_normals.py with O3DS_NRM_DEBUG=1 shows the broken table before the kernel that reads it runs; the scratch arena
+// had met the same thing in round 1 and stopped returning its blocks).  Sizes are rounded up to 1/8 of their power of two, so the
+// slowly varying sizes of a lidar stream hit the same classes; blocks go back to the driver only when the handle is destroyed.
+hipError_t dev_alloc(o3ds_handle h, void** out, size_t bytes) {
+  if (bytes < 256) bytes = 256;
+  size_t gran = 256;
+  while (gran * 8 < bytes) gran <<= 1;
+  const size_t want = (bytes + gran - 1) / gran * gran;
+  auto it = h->pool_free.lower_bound(want);
+  if (it != h->pool_free.end() && it->first <= want + want / 4) {
+    *out = it->second;
+    h->pool_free.erase(it);
+    return hipSuccess;
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, want);
+  if (e != hipSuccess && !h->pool_free.empty()) {  // out of memory: give the cached blocks back and retry
+    (void)hipStreamSynchronize(h->stream);
+    for (auto& b : h->pool_free) {
+      h->pool_bytes -= b.first;
+      h->pool_size.erase(b.second);
+      (void)hipFree(b.second);
+    }
+    h->pool_free.clear();
+    e = hipMalloc(&p, want);
+  }
+  if (e != hipSuccess) return e;
+  h->pool_size.emplace(p, want);
+  h->pool_bytes += want;
+  *out = p;
+  return hipSuccess;
+}
+void dev_free(o3ds_handle h, void* p) {
+  if (!p) return;
+  auto it = h->pool_size.find(p);
+  if (it == h->pool_size.end()) return;  // not ours (never happens)
+  h->pool_free.emplace(it->second, p);
+}
+void dev_release_all(o3ds_handle h) {  // o3ds_destroy: the stream has been synchronised
+  for (auto& b : h->pool_size) (void)hipFree(b.first);
+  h->pool_size.clear();
+  h->pool_free.clear();
+  h->pool_bytes = 0;
+}
+
 // ---- scratch arena ------------------------------------------------------------------------------------------------
 // Temporaries (scan block sums, flags, sort buffers, staging copies ...) are bump-allocated from blocks that persist
 // for the life of the handle: a per-scan pipeline makes ~120 allocations otherwise (4.6 us each + free).  The bump
@@ -266,7 +327,7 @@ int arena_alloc(o3ds_handle h, void** out, size_t bytes) {
   static const bool no_reuse = getenv("O3DS_NO_ARENA") != nullptr;  // debugging aid: every temporary is its own pool allocation
   if (no_reuse) {
     char* p = nullptr;
-    if (hipMallocAsync((void**)&p, bytes, h->stream) != hipSuccess) return fail(h, O3DS_ERR_OOM, "arena: out of memory");
+    if (dev_alloc(h, (void**)&p, bytes) != hipSuccess) return fail(h, O3DS_ERR_OOM, "arena: out of memory");
     h->arena_blocks.emplace_back(p, 0);
     *out = p;
     return O3DS_OK;
@@ -287,7 +348,7 @@ int arena_alloc(o3ds_handle h, void** out, size_t bytes) {
     size_t want = std::max<size_t>(bytes, first_mb << 20);
     if (!h->arena_blocks.empty()) want = std::max(want, 2 * h->arena_blocks.back().second);
     char* p = nullptr;
-    hipError_t e = hipMallocAsync((void**)&p, want, h->stream);
+    hipError_t e = dev_alloc(h, (void**)&p, want);
     if (e != hipSuccess) return fail(h, O3DS_ERR_OOM, std::string("arena: ") + hipGetErrorString(e));
     h->arena_blocks.emplace_back(p, want);
     if (getenv("O3DS_ARENA_LOG"))
@@ -299,7 +360,7 @@ struct ArenaScope {
   explicit ArenaScope(o3ds_handle hh) : h(hh) {
     if (h && h->arena_depth++ == 0) {
       if (getenv("O3DS_NO_ARENA")) {
-        for (auto& b : h->arena_blocks) (void)hipFreeAsync(b.first, h->stream);
+        for (auto& b : h->arena_blocks) dev_free(h, b.first);
         h->arena_blocks.clear();
       }
       // Blocks are never returned or merged while the handle lives: they grow geometrically, so there are at most a
@@ -340,18 +401,18 @@ CloudRec* find_cloud(o3ds_handle h, o3ds_cloud id) {
 }
 
 void free_index(o3ds_handle h, CloudRec& c) {
-  if (c.cell_start) (void)hipFreeAsync(c.cell_start, h->stream);
-  if (c.spts) (void)hipFreeAsync(c.spts, h->stream);
-  if (c.snrm) (void)hipFreeAsync(c.snrm, h->stream);
+  if (c.cell_start) dev_free(h, c.cell_start);
+  if (c.spts) dev_free(h, c.spts);
+  if (c.snrm) dev_free(h, c.snrm);
   c.cell_start = nullptr;
   c.spts = c.snrm = nullptr;
   c.has_index = false;
 }
 void free_cloud(o3ds_handle h, CloudRec& c) {
   free_index(h, c);
-  if (c.pts) (void)hipFreeAsync(c.pts, h->stream);
-  if (c.nrm) (void)hipFreeAsync(c.nrm, h->stream);
-  if (c.col) (void)hipFreeAsync(c.col, h->stream);
+  if (c.pts) dev_free(h, c.pts);
+  if (c.nrm) dev_free(h, c.nrm);
+  if (c.col) dev_free(h, c.col);
   c.pts = c.nrm = c.col = nullptr;
   c.n = 0;
 }
@@ -441,9 +502,9 @@ int build_grid_t(o3ds_handle h, const P4* pts, const P4* nrm, size_t n, double c
   TMP_ALLOC(counts, sizeof(int) * (2 * ncell + 1));  // [counts: ncell + 1 | cursor: ncell], cleared by one memset
   cursor = counts + ncell + 1;
   TMP_ALLOC(cell_id, sizeof(int) * n);
-  HIP_TRY(hipMallocAsync((void**)&cell_start, sizeof(int) * (ncell + 1 + 4), h->stream));  // +4: the search reads rows as unaligned 16-B vectors
-  HIP_TRY(hipMallocAsync((void**)&spts, sizeof(P4) * n, h->stream));
-  if (nrm) HIP_TRY(hipMallocAsync((void**)&snrm, sizeof(P4) * n, h->stream));
+  HIP_TRY(dev_alloc(h, (void**)&cell_start, sizeof(int) * (ncell + 1 + 4)));  // +4: the search reads rows as unaligned 16-B vectors
+  HIP_TRY(dev_alloc(h, (void**)&spts, sizeof(P4) * n));
+  if (nrm) HIP_TRY(dev_alloc(h, (void**)&snrm, sizeof(P4) * n));
   HIP_TRY(hipMemsetAsync(counts, 0, sizeof(int) * (2 * ncell + 1), h->stream));
   cell_count_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(pts, n, g, counts, cell_id);
   rc = exclusive_scan_int(h, counts, cell_start, ncell + 1);
@@ -479,13 +540,13 @@ int upload_t(o3ds_handle h, const double* xyz, const double* normals, size_t n, 
   if (n == 0) return O3DS_OK;
   double *stage = nullptr, *stage_n = nullptr;
   TMP_ALLOC(stage, sizeof(double) * 3 * n);
-  HIP_TRY(hipMallocAsync((void**)&c.pts, sizeof(P4) * n, h->stream));
+  HIP_TRY(dev_alloc(h, (void**)&c.pts, sizeof(P4) * n));
   int rcc = h2d_copy(h, stage, xyz, sizeof(double) * 3 * n);
   if (rcc) return rcc;
   pack_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(stage, n, (P4*)c.pts);
   if (normals) {
     TMP_ALLOC(stage_n, sizeof(double) * 3 * n);
-    HIP_TRY(hipMallocAsync((void**)&c.nrm, sizeof(P4) * n, h->stream));
+    HIP_TRY(dev_alloc(h, (void**)&c.nrm, sizeof(P4) * n));
     rcc = h2d_copy(h, stage_n, normals, sizeof(double) * 3 * n);
     if (rcc) return rcc;
     pack_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(stage_n, n, (P4*)c.nrm);
@@ -524,22 +585,22 @@ const double kIdentity16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
 
 // ---- dense voxel map helpers -----------------------------------------------------------------------
 void dense_release(o3ds_handle h, DenseRec& d) {
-  if (d.dev.keys) (void)hipFreeAsync(d.dev.keys, h->stream);
-  if (d.dev.cnt) (void)hipFreeAsync(d.dev.cnt, h->stream);
-  if (d.dev.sp) (void)hipFreeAsync(d.dev.sp, h->stream);
-  if (d.dev.sn) (void)hipFreeAsync(d.dev.sn, h->stream);
-  if (d.dev.sc) (void)hipFreeAsync(d.dev.sc, h->stream);
+  if (d.dev.keys) dev_free(h, d.dev.keys);
+  if (d.dev.cnt) dev_free(h, d.dev.cnt);
+  if (d.dev.sp) dev_free(h, d.dev.sp);
+  if (d.dev.sn) dev_free(h, d.dev.sn);
+  if (d.dev.sc) dev_free(h, d.dev.sc);
   d.dev = o3ds::DenseDev{};
   d.cap = 0;
 }
 
 int dense_alloc(o3ds_handle h, size_t cap, o3ds::DenseDev* out) {
   o3ds::DenseDev d{};
-  HIP_TRY(hipMallocAsync((void**)&d.keys, sizeof(unsigned long long) * cap, h->stream));
-  HIP_TRY(hipMallocAsync((void**)&d.cnt, sizeof(int) * cap, h->stream));
-  HIP_TRY(hipMallocAsync((void**)&d.sp, sizeof(long long) * 3 * cap, h->stream));
-  HIP_TRY(hipMallocAsync((void**)&d.sn, sizeof(long long) * 3 * cap, h->stream));
-  HIP_TRY(hipMallocAsync((void**)&d.sc, sizeof(long long) * 3 * cap, h->stream));
+  HIP_TRY(dev_alloc(h, (void**)&d.keys, sizeof(unsigned long long) * cap));
+  HIP_TRY(dev_alloc(h, (void**)&d.cnt, sizeof(int) * cap));
+  HIP_TRY(dev_alloc(h, (void**)&d.sp, sizeof(long long) * 3 * cap));
+  HIP_TRY(dev_alloc(h, (void**)&d.sn, sizeof(long long) * 3 * cap));
+  HIP_TRY(dev_alloc(h, (void**)&d.sc, sizeof(long long) * 3 * cap));
   HIP_TRY(hipMemsetAsync(d.keys, 0xFF, sizeof(unsigned long long) * cap, h->stream));
   HIP_TRY(hipMemsetAsync(d.cnt, 0, sizeof(int) * cap, h->stream));
   HIP_TRY(hipMemsetAsync(d.sp, 0, sizeof(long long) * 3 * cap, h->stream));
@@ -647,9 +708,9 @@ int dense_to_cloud_t(o3ds_handle h, DenseRec& d, CloudRec& out) {
   TMP_ALLOC(temp, temp_bytes ? temp_bytes : 16);
   HIP_TRY(rocprim::radix_sort_pairs(temp, temp_bytes, k0, k1, s0, s1, used, 0, 64, h->stream));
   out.n = used;
-  HIP_TRY(hipMallocAsync(&out.pts, sizeof(P4) * used, h->stream));
-  if (d.has_normals) HIP_TRY(hipMallocAsync(&out.nrm, sizeof(P4) * used, h->stream));
-  if (d.has_colors) HIP_TRY(hipMallocAsync(&out.col, sizeof(P4) * used, h->stream));
+  HIP_TRY(dev_alloc(h, (void**)&out.pts, sizeof(P4) * used));
+  if (d.has_normals) HIP_TRY(dev_alloc(h, (void**)&out.nrm, sizeof(P4) * used));
+  if (d.has_colors) HIP_TRY(dev_alloc(h, (void**)&out.col, sizeof(P4) * used));
   dense_emit_kernel<P4><<<grid_for(used), kBlock, 0, h->stream>>>(d.dev, s1, used, (P4*)out.pts, (P4*)out.nrm, (P4*)out.col);
   HIP_TRY(hipGetLastError());
   return O3DS_OK;
@@ -917,13 +978,6 @@ int o3ds_create(int device_id, o3ds_handle* out) {
     delete h;
     return fail(nullptr, O3DS_ERR_HIP, "o3ds_create: device initialisation failed");
   }
-  {  // stream-ordered allocations come from the device pool; keep freed blocks cached instead of returning them to the driver
-    hipMemPool_t pool = nullptr;
-    if (hipDeviceGetDefaultMemPool(&pool, device_id) == hipSuccess && pool) {
-      uint64_t keep = UINT64_MAX;
-      (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-    }
-  }
   {
     if (hipMalloc((void**)&h->d_fused, kFusedBytes) != hipSuccess || hipMemset(h->d_fused, 0, kFusedBytes) != hipSuccess) {
       o3ds_destroy(h);
@@ -946,8 +1000,9 @@ int o3ds_destroy(o3ds_handle h) {
   (void)hipStreamSynchronize(h->own_stream);
   for (auto& kv : h->clouds) free_cloud(h, kv.second);
   for (auto& kv : h->dense_maps) dense_release(h, kv.second);
-  for (auto& b : h->arena_blocks) (void)hipFreeAsync(b.first, h->stream);
+  for (auto& b : h->arena_blocks) dev_free(h, b.first);
   (void)hipStreamSynchronize(h->stream);
+  dev_release_all(h);
   if (h->d_fused) (void)hipFree(h->d_fused);
   if (h->d_nn_cache) (void)hipFree(h->d_nn_cache);
   if (h->d_partials) (void)hipFree(h->d_partials);
@@ -1046,7 +1101,7 @@ int o3ds_cloud_upload_f32(o3ds_handle h, const void* data, size_t n, size_t poin
       if (rcc) return rcc;
     }
     const size_t bytes = (h->precision == O3DS_PRECISION_F64 ? sizeof(P4d) : sizeof(P4f)) * n;
-    HIP_TRY(hipMallocAsync(&c.pts, bytes, h->stream));
+    HIP_TRY(dev_alloc(h, (void**)&c.pts, bytes));
     if (h->precision == O3DS_PRECISION_F64)
       pack_strided_f32_kernel<P4d><<<grid_for(n), kBlock, 0, h->stream>>>(d_raw, n, point_step, off_x, off_y, off_z, (P4d*)c.pts);
     else
@@ -1136,7 +1191,7 @@ int o3ds_cloud_set_colors_from_records(o3ds_handle h, o3ds_cloud id, const void*
   if (off_field + 4 > point_step) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_set_colors_from_records: the field does not fit the point step");
   if (c->n > 0 && !data) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_set_colors_from_records: null buffer");
   HIP_TRY(hipSetDevice(h->device));
-  if (c->col) HIP_TRY(hipFreeAsync(c->col, h->stream));
+  if (c->col) dev_free(h, c->col);
   c->col = nullptr;
   if (c->n == 0) return O3DS_OK;
   unsigned char* d_raw = nullptr;
@@ -1145,7 +1200,7 @@ int o3ds_cloud_set_colors_from_records(o3ds_handle h, o3ds_cloud id, const void*
     const int rcc = h2d_copy(h, d_raw, data, c->n * point_step);
     if (rcc) return rcc;
   }
-  HIP_TRY(hipMallocAsync(&c->col, p4_size(c->precision) * c->n, h->stream));
+  HIP_TRY(dev_alloc(h, (void**)&c->col, p4_size(c->precision) * c->n));
   if (c->precision == O3DS_PRECISION_F64)
     colors_from_records_kernel<P4d><<<grid_for(c->n), kBlock, 0, h->stream>>>(d_raw, c->n, point_step, off_field, kind, (P4d*)c->col);
   else
@@ -1161,7 +1216,7 @@ int o3ds_cloud_set_colors(o3ds_handle h, o3ds_cloud id, const double* rgb) {
   CloudRec* c = find_cloud(h, id);
   if (!c) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_set_colors: unknown cloud id");
   HIP_TRY(hipSetDevice(h->device));
-  if (c->col) HIP_TRY(hipFreeAsync(c->col, h->stream));
+  if (c->col) dev_free(h, c->col);
   c->col = nullptr;
   if (!rgb || c->n == 0) return O3DS_OK;  // colors_.clear()
   double* stage = nullptr;
@@ -1170,7 +1225,7 @@ int o3ds_cloud_set_colors(o3ds_handle h, o3ds_cloud id, const double* rgb) {
     const int rcc = h2d_copy(h, stage, rgb, sizeof(double) * 3 * c->n);
     if (rcc) return rcc;
   }
-  HIP_TRY(hipMallocAsync(&c->col, p4_size(c->precision) * c->n, h->stream));
+  HIP_TRY(dev_alloc(h, (void**)&c->col, p4_size(c->precision) * c->n));
   if (c->precision == O3DS_PRECISION_F64)
     pack_kernel<P4d><<<grid_for(c->n), kBlock, 0, h->stream>>>(stage, c->n, (P4d*)c->col);
   else
@@ -1637,12 +1692,12 @@ int crop_t(o3ds_handle h, const CloudRec& in, const CropDev& crop, CloudRec& out
   if (rc) return rc;
   out.n = (size_t)total;
   if (total > 0) {
-    HIP_TRY(hipMallocAsync((void**)&out.pts, sizeof(P4) * out.n, h->stream));
-    if (in.nrm) HIP_TRY(hipMallocAsync((void**)&out.nrm, sizeof(P4) * out.n, h->stream));
+    HIP_TRY(dev_alloc(h, (void**)&out.pts, sizeof(P4) * out.n));
+    if (in.nrm) HIP_TRY(dev_alloc(h, (void**)&out.nrm, sizeof(P4) * out.n));
     compact_kernel<P4><<<grid_for(in.n), kBlock, 0, h->stream>>>((const P4*)in.pts, (const P4*)in.nrm, in.n, flags, pos, 1, (P4*)out.pts,
                                                                (P4*)out.nrm);
     if (in.col) {  // colours ride along as a second attribute array through the same kernel
-      HIP_TRY(hipMallocAsync((void**)&out.col, sizeof(P4) * out.n, h->stream));
+      HIP_TRY(dev_alloc(h, (void**)&out.col, sizeof(P4) * out.n));
       compact_kernel<P4><<<grid_for(in.n), kBlock, 0, h->stream>>>((const P4*)in.col, nullptr, in.n, flags, pos, 1, (P4*)out.col, nullptr);
     }
     HIP_TRY(hipGetLastError());
@@ -1710,12 +1765,12 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
   const int drop = filter ? 1 : 0;
   out.n = filter ? (size_t)n_seg - n_pass : (size_t)n_seg;
   if (out.n == 0) return O3DS_OK;
-  HIP_TRY(hipMallocAsync((void**)&out.pts, sizeof(P4) * out.n, h->stream));
-  if (in.nrm) HIP_TRY(hipMallocAsync((void**)&out.nrm, sizeof(P4) * out.n, h->stream));
+  HIP_TRY(dev_alloc(h, (void**)&out.pts, sizeof(P4) * out.n));
+  if (in.nrm) HIP_TRY(dev_alloc(h, (void**)&out.nrm, sizeof(P4) * out.n));
   segment_mean_kernel<P4><<<grid_for((size_t)n_seg), kBlock, 0, h->stream>>>((const P4*)in.pts, (const P4*)in.nrm, k1, v1, seg_start, (size_t)n_seg, n,
                                                                             mode == 1 ? 1 : 0, n_pass, (P4*)out.pts, (P4*)out.nrm, drop);
   if (in.col) {
-    HIP_TRY(hipMallocAsync((void**)&out.col, sizeof(P4) * out.n, h->stream));
+    HIP_TRY(dev_alloc(h, (void**)&out.col, sizeof(P4) * out.n));
     if (mode == 0)  // [O3D] VoxelDownSample: AccumulatedPoint averages the colours
       segment_mean_kernel<P4><<<grid_for((size_t)n_seg), kBlock, 0, h->stream>>>((const P4*)in.col, nullptr, k1, v1, seg_start, (size_t)n_seg, n, 0, n_pass,
                                                                                 (P4*)out.col, nullptr, drop);
@@ -1786,61 +1841,64 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn) {
     h->nrm_n = c.n;
     h->nrm_age = 0;
   }
-  if (!c.nrm) HIP_TRY(hipMallocAsync((void**)&c.nrm, sizeof(P4) * c.n, h->stream));
+  if (!c.nrm) HIP_TRY(dev_alloc(h, (void**)&c.nrm, sizeof(P4) * c.n));
   const int rmax = std::max(1, (int)std::ceil(radius / tmp.grid.cell));
-  // the k-best lists live in LDS ([slot][thread]); pick the instantiation by max_nn so that ~64 KB serve one workgroup
+  static const bool nrm_debug = getenv("O3DS_NRM_DEBUG") != nullptr;  // debugging aid: where a fault happens
+  if (nrm_debug) {
+    const hipError_t e = hipStreamSynchronize(h->stream);
+    fprintf(stderr, "[normals] n %zu radius %g max_nn %d reuse %d grid %d x %d x %d cell %g rmax %d (index built: %s)\n", c.n, radius, max_nn, (int)reuse,
+            tmp.grid.nx, tmp.grid.ny, tmp.grid.nz, tmp.grid.cell, rmax, hipGetErrorString(e));
+    const size_t ncell = (size_t)tmp.grid.nx * tmp.grid.ny * tmp.grid.nz;
+    std::vector<int> hcs(ncell + 1);
+    (void)hipMemcpy(hcs.data(), tmp.cell_start, sizeof(int) * (ncell + 1), hipMemcpyDeviceToHost);
+    size_t bad = 0, first = 0;
+    for (size_t i = 0; i < ncell; ++i)
+      if (hcs[i + 1] < hcs[i]) {
+        if (!bad) first = i;
+        ++bad;
+      }
+    fprintf(stderr, "[normals] cell_start: first %d last %d (n %zu), descents %zu", hcs[0], hcs[ncell], c.n, bad);
+    if (bad) fprintf(stderr, " first at cell %zu (block %zu): %d -> %d", first, (first + 1) / 1024, hcs[first], hcs[first + 1]);
+    fprintf(stderr, "\n");
+  }
+  // 16 lanes per point, 16 points per 64-thread workgroup (normals_kernel.hpp); the instantiation is picked by max_nn
   {
     const P4* p_pts = (const P4*)c.pts;
     const P4* p_sp = (const P4*)tmp.spts;
     P4* p_out = (P4*)c.nrm;
-    constexpr bool kWide = sizeof(P4) > 16;  // f64 storage: half the threads per workgroup for the same LDS footprint
-    unsigned int* d_stats = nullptr;
-#ifdef O3DS_NRM_STATS
-    if (getenv("O3DS_NRM_STATS_FILE")) {
-      HIP_TRY(hipMalloc((void**)&d_stats, sizeof(unsigned int) * 8 * c.n));
-      HIP_TRY(hipMemset(d_stats, 0, sizeof(unsigned int) * 8 * c.n));
-    }
-#endif
-    // O3DS_NRM_EXACT=1: order-independent (fixed-point) covariance sums -- bit-reproducible normals, see normal_one_lane; off by default
-    // until it has had its own parity round
-    static const bool want_exact = getenv("O3DS_NRM_EXACT") != nullptr && atoi(getenv("O3DS_NRM_EXACT")) != 0;
-    const bool exact = want_exact && radius <= 200.0;
-#define O3DS_NRM_LAUNCH(K, B, CAP)                                                                                                    \
-  do {                                                                                                                                \
-    const int gsz = (int)std::min<size_t>((c.n + (B) - 1) / (B), (CAP));                                                               \
-    if (exact)                                                                                                                        \
-      normals_kernel<P4, K, B, true><<<gsz, B, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, p_out, d_stats);      \
-    else                                                                                                                              \
-      normals_kernel<P4, K, B, false><<<gsz, B, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, p_out, d_stats);     \
-  } while (0)
-    if (max_nn <= 20) {  // the shipped configs' knn: 40 KB of LDS per workgroup instead of 64 KB, twice the wavefronts per SIMD
-      constexpr int B = kWide ? 128 : 256;
-      O3DS_NRM_LAUNCH(20, B, 8192);
-    } else if (max_nn <= 32) {
-      constexpr int B = kWide ? 128 : 256;
-      O3DS_NRM_LAUNCH(32, B, 8192);
-    } else {
-      constexpr int B = 64;
-      O3DS_NRM_LAUNCH(128, B, 16384);
-    }
-#undef O3DS_NRM_LAUNCH
-#ifdef O3DS_NRM_STATS
-    if (d_stats) {
-      std::vector<unsigned int> hs(8 * c.n);
-      HIP_TRY(hipStreamSynchronize(h->stream));
-      HIP_TRY(hipMemcpy(hs.data(), d_stats, sizeof(unsigned int) * hs.size(), hipMemcpyDeviceToHost));
-      (void)hipFree(d_stats);
-      if (FILE* f = fopen(getenv("O3DS_NRM_STATS_FILE"), "wb")) {
-        const double meta[2] = {tmp.grid.cell, (double)c.n};
-        fwrite(meta, sizeof(double), 2, f);
-        fwrite(hs.data(), sizeof(unsigned int), hs.size(), f);
-        fclose(f);
-      }
-    }
-#endif
+    const unsigned int gsz = (unsigned int)((c.n + 15) / 16);
+    if (max_nn <= 32)  // the shipped configs' knn is 20
+      normals_kernel<P4, 32><<<gsz, 64, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, p_out);
+    else
+      normals_kernel<P4, 128><<<gsz, 64, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, p_out);
   }
   HIP_TRY(hipGetLastError());
   dbg_sync(h, 16);
+  if (nrm_debug) {
+    fprintf(stderr, "[normals] kernel done: %s\n", hipGetErrorString(hipStreamSynchronize(h->stream)));
+#ifdef O3DS_NRM_CHECK
+    unsigned int dbg[8] = {0};
+    (void)hipMemcpyFromSymbol(dbg, HIP_SYMBOL(o3ds::g_nrm_dbg), sizeof(dbg));
+    fprintf(stderr, "[normals] violations: unsorted %u, bad p %u, bad oi %u, bad segment %u, bad T %u, survivor met twice %u, survivor == kept %u\n", dbg[0], dbg[1],
+            dbg[2], dbg[3], dbg[4], dbg[5], dbg[6]);
+    if (dbg[5]) {
+      int info[16];
+      (void)hipMemcpyFromSymbol(info, HIP_SYMBOL(o3ds::g_nrm_info), sizeof(info));
+      fprintf(stderr, "[normals] first: ring %d tbase %d f0 %d T %d stot %d cnt %d eq %d idx %d lane %d c %d j %d cell %d %d %d seg %d %d\n", info[0], info[1], info[2],
+              info[3], info[4], info[5], info[6], info[7], info[8], info[9], info[10], info[11], info[12], info[13], info[14], info[15]);
+      int segs[256];
+      double qq[8];
+      (void)hipMemcpyFromSymbol(segs, HIP_SYMBOL(o3ds::g_nrm_segs), sizeof(segs));
+      (void)hipMemcpyFromSymbol(qq, HIP_SYMBOL(o3ds::g_nrm_q), sizeof(qq));
+      fprintf(stderr, "[normals] f %.9g %.9g %.9g worst %.9g q %.9g %.9g %.9g; grid origin %.9g %.9g %.9g\n", qq[0], qq[1], qq[2], qq[3], qq[4], qq[5], qq[6], tmp.grid.ox,
+              tmp.grid.oy, tmp.grid.oz);
+      const int g0 = (info[15] / 16) * 16;
+      for (int a = g0; a < g0 + 16; ++a) fprintf(stderr, "[normals]   lane %d: [%d,%d) [%d,%d)\n", a, segs[4 * a], segs[4 * a + 1], segs[4 * a + 2], segs[4 * a + 3]);
+    }
+    const unsigned int zero[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(o3ds::g_nrm_dbg), zero, sizeof(zero));
+#endif
+  }
   tmp.pts = nullptr;
   free_index(h, tmp);
   box_copy(c, tmp);  // the box an index build reduced is kept for the cloud's next index
@@ -1857,12 +1915,12 @@ int transform_t(o3ds_handle h, const CloudRec& in, const double T[16], CloudRec&
   Mat34 M;
   for (int r = 0; r < 3; ++r)
     for (int c = 0; c < 4; ++c) M.m[r * 4 + c] = T[c * 4 + r];
-  HIP_TRY(hipMallocAsync((void**)&out.pts, sizeof(P4) * in.n, h->stream));
-  if (in.nrm) HIP_TRY(hipMallocAsync((void**)&out.nrm, sizeof(P4) * in.n, h->stream));
+  HIP_TRY(dev_alloc(h, (void**)&out.pts, sizeof(P4) * in.n));
+  if (in.nrm) HIP_TRY(dev_alloc(h, (void**)&out.nrm, sizeof(P4) * in.n));
   transform_kernel<P4><<<grid_for(in.n), kBlock, 0, h->stream>>>((const P4*)in.pts, (const P4*)in.nrm, in.n, M, T[3], T[7], T[11], T[15],
                                                                (P4*)out.pts, (P4*)out.nrm, 0);
   if (in.col) {
-    HIP_TRY(hipMallocAsync((void**)&out.col, sizeof(P4) * in.n, h->stream));
+    HIP_TRY(dev_alloc(h, (void**)&out.col, sizeof(P4) * in.n));
     HIP_TRY(hipMemcpyAsync(out.col, in.col, sizeof(P4) * in.n, hipMemcpyDeviceToDevice, h->stream));
   }
   HIP_TRY(hipGetLastError());
@@ -1927,19 +1985,19 @@ int carve_t(o3ds_handle h, CloudRec& map, const CloudRec& scan, const double T[1
   if (*n_removed == 0) return O3DS_OK;  // removeByIds: nothing to do (helpers.cpp:221-223)
   void *np = nullptr, *nn = nullptr, *nc = nullptr;
   if (total > 0) {
-    HIP_TRY(hipMallocAsync(&np, sizeof(P4) * (size_t)total, h->stream));
-    if (map.nrm) HIP_TRY(hipMallocAsync(&nn, sizeof(P4) * (size_t)total, h->stream));
+    HIP_TRY(dev_alloc(h, (void**)&np, sizeof(P4) * (size_t)total));
+    if (map.nrm) HIP_TRY(dev_alloc(h, (void**)&nn, sizeof(P4) * (size_t)total));
     compact_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>((const P4*)map.pts, (const P4*)map.nrm, n, keep, pos, 1, (P4*)np, (P4*)nn);
     if (map.col) {
-      HIP_TRY(hipMallocAsync(&nc, sizeof(P4) * (size_t)total, h->stream));
+      HIP_TRY(dev_alloc(h, (void**)&nc, sizeof(P4) * (size_t)total));
       compact_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>((const P4*)map.col, nullptr, n, keep, pos, 1, (P4*)nc, nullptr);
     }
     HIP_TRY(hipGetLastError());
   }
   free_index(h, map);
-  (void)hipFreeAsync(map.pts, h->stream);
-  if (map.nrm) (void)hipFreeAsync(map.nrm, h->stream);
-  if (map.col) (void)hipFreeAsync(map.col, h->stream);
+  dev_free(h, map.pts);
+  if (map.nrm) dev_free(h, map.nrm);
+  if (map.col) dev_free(h, map.col);
   map.pts = np;
   map.nrm = nn;
   map.col = nc;
@@ -2023,9 +2081,9 @@ int append_t(o3ds_handle h, CloudRec& map, const CloudRec& add) {
   CloudRec joined;
   box_union(joined, map, add);
   void *np = nullptr, *nn = nullptr, *nc = nullptr;
-  if (n > 0) HIP_TRY(hipMallocAsync((void**)&np, sizeof(P4) * n, h->stream));
-  if (keep_nrm && n > 0) HIP_TRY(hipMallocAsync((void**)&nn, sizeof(P4) * n, h->stream));
-  if (keep_col && n > 0) HIP_TRY(hipMallocAsync((void**)&nc, sizeof(P4) * n, h->stream));
+  if (n > 0) HIP_TRY(dev_alloc(h, (void**)&np, sizeof(P4) * n));
+  if (keep_nrm && n > 0) HIP_TRY(dev_alloc(h, (void**)&nn, sizeof(P4) * n));
+  if (keep_col && n > 0) HIP_TRY(dev_alloc(h, (void**)&nc, sizeof(P4) * n));
   if (map.n) {
     HIP_TRY(hipMemcpyAsync(np, map.pts, sizeof(P4) * map.n, hipMemcpyDeviceToDevice, h->stream));
     if (keep_nrm) HIP_TRY(hipMemcpyAsync(nn, map.nrm, sizeof(P4) * map.n, hipMemcpyDeviceToDevice, h->stream));
@@ -2039,9 +2097,9 @@ int append_t(o3ds_handle h, CloudRec& map, const CloudRec& add) {
   HIP_TRY(hipGetLastError());
   dbg_sync(h, 32);
   free_index(h, map);
-  if (map.pts) HIP_TRY(hipFreeAsync(map.pts, h->stream));
-  if (map.nrm) HIP_TRY(hipFreeAsync(map.nrm, h->stream));
-  if (map.col) HIP_TRY(hipFreeAsync(map.col, h->stream));
+  if (map.pts) dev_free(h, map.pts);
+  if (map.nrm) dev_free(h, map.nrm);
+  if (map.col) dev_free(h, map.col);
   map.pts = np;
   map.nrm = nn;
   map.col = nc;
@@ -2138,14 +2196,14 @@ int o3ds_select_by_index(o3ds_handle h, o3ds_cloud in, const uint32_t* keep_idx,
     const size_t psz = p4_size(c->precision);
     TMP_ALLOC(d_idx, sizeof(uint32_t) * m);
     HIP_TRY(hipMemcpyAsync(d_idx, keep_idx, sizeof(uint32_t) * m, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMallocAsync((void**)&o.pts, psz * m, h->stream));
-    if (c->nrm) HIP_TRY(hipMallocAsync((void**)&o.nrm, psz * m, h->stream));
+    HIP_TRY(dev_alloc(h, (void**)&o.pts, psz * m));
+    if (c->nrm) HIP_TRY(dev_alloc(h, (void**)&o.nrm, psz * m));
     if (c->precision == O3DS_PRECISION_F64)
       gather_kernel<P4d><<<grid_for(m), kBlock, 0, h->stream>>>((const P4d*)c->pts, (const P4d*)c->nrm, d_idx, m, (P4d*)o.pts, (P4d*)o.nrm);
     else
       gather_kernel<P4f><<<grid_for(m), kBlock, 0, h->stream>>>((const P4f*)c->pts, (const P4f*)c->nrm, d_idx, m, (P4f*)o.pts, (P4f*)o.nrm);
     if (c->col) {
-      HIP_TRY(hipMallocAsync((void**)&o.col, psz * m, h->stream));
+      HIP_TRY(dev_alloc(h, (void**)&o.col, psz * m));
       if (c->precision == O3DS_PRECISION_F64)
         gather_kernel<P4d><<<grid_for(m), kBlock, 0, h->stream>>>((const P4d*)c->col, nullptr, d_idx, m, (P4d*)o.col, nullptr);
       else
@@ -2219,7 +2277,7 @@ int o3ds_cloud_undistort(o3ds_handle h, o3ds_cloud cloud, const double linear_ve
                                                                   spinning_clockwise);
   HIP_TRY(hipGetLastError());
   if (c->nrm) {
-    (void)hipFreeAsync(c->nrm, h->stream);
+    dev_free(h, c->nrm);
     c->nrm = nullptr;
   }
   free_index(h, *c);

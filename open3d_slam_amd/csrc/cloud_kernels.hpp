@@ -338,162 +338,7 @@ __global__ __launch_bounds__(kBlock) void segment_mean_kernel(const P4* __restri
   }
 }
 
-// ---------------------------------------------------------------------------------------------- normal estimation
-// k nearest within radius on the same grid index (self included), population covariance from 9 cumulants,
-// eigenvector of the smallest eigenvalue by the Geometric-Tools closed form ([O3D] FastEigen3x3).
-__host__ __device__ inline void cross3(const double a[3], const double b[3], double c[3]) {
-  c[0] = a[1] * b[2] - a[2] * b[1];
-  c[1] = a[2] * b[0] - a[0] * b[2];
-  c[2] = a[0] * b[1] - a[1] * b[0];
-}
-__host__ __device__ inline double dot3(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
-
-__host__ __device__ inline void eigvec0(const double A[6] /* a00 a01 a02 a11 a12 a22 */, double ev, double out[3]) {
-  const double r0[3] = {A[0] - ev, A[1], A[2]}, r1[3] = {A[1], A[3] - ev, A[4]}, r2[3] = {A[2], A[4], A[5] - ev};
-  double c01[3], c02[3], c12[3];
-  cross3(r0, r1, c01);
-  cross3(r0, r2, c02);
-  cross3(r1, r2, c12);
-  const double d0 = dot3(c01, c01), d1 = dot3(c02, c02), d2 = dot3(c12, c12);
-  double dm = d0;
-  int im = 0;
-  if (d1 > dm) {
-    dm = d1;
-    im = 1;
-  }
-  if (d2 > dm) {
-    dm = d2;
-    im = 2;
-  }
-  const double s = 1.0 / sqrt(dm);
-  const double* b = im == 0 ? c01 : (im == 1 ? c02 : c12);
-  out[0] = b[0] * s;
-  out[1] = b[1] * s;
-  out[2] = b[2] * s;
-}
-
-__host__ __device__ inline void eigvec1(const double A[6], const double e0[3], double ev, double out[3]) {
-  double U[3], V[3];
-  if (fabs(e0[0]) > fabs(e0[1])) {
-    const double inv = 1.0 / sqrt(e0[0] * e0[0] + e0[2] * e0[2]);
-    U[0] = -e0[2] * inv;
-    U[1] = 0.0;
-    U[2] = e0[0] * inv;
-  } else {
-    const double inv = 1.0 / sqrt(e0[1] * e0[1] + e0[2] * e0[2]);
-    U[0] = 0.0;
-    U[1] = e0[2] * inv;
-    U[2] = -e0[1] * inv;
-  }
-  cross3(e0, U, V);
-  const double AU[3] = {A[0] * U[0] + A[1] * U[1] + A[2] * U[2], A[1] * U[0] + A[3] * U[1] + A[4] * U[2],
-                        A[2] * U[0] + A[4] * U[1] + A[5] * U[2]};
-  const double AV[3] = {A[0] * V[0] + A[1] * V[1] + A[2] * V[2], A[1] * V[0] + A[3] * V[1] + A[4] * V[2],
-                        A[2] * V[0] + A[4] * V[1] + A[5] * V[2]};
-  double m00 = dot3(U, AU) - ev, m01 = dot3(U, AV), m11 = dot3(V, AV) - ev;
-  const double a00 = fabs(m00), a01 = fabs(m01), a11 = fabs(m11);
-  if (a00 >= a11) {
-    if (fmax(a00, a01) > 0.0) {
-      if (a00 >= a01) {
-        m01 /= m00;
-        m00 = 1.0 / sqrt(1.0 + m01 * m01);
-        m01 *= m00;
-      } else {
-        m00 /= m01;
-        m01 = 1.0 / sqrt(1.0 + m00 * m00);
-        m00 *= m01;
-      }
-      for (int i = 0; i < 3; ++i) out[i] = m01 * U[i] - m00 * V[i];
-    } else {
-      for (int i = 0; i < 3; ++i) out[i] = U[i];
-    }
-  } else {
-    if (fmax(a11, a01) > 0.0) {
-      if (a11 >= a01) {
-        m01 /= m11;
-        m11 = 1.0 / sqrt(1.0 + m01 * m01);
-        m01 *= m11;
-      } else {
-        m11 /= m01;
-        m01 = 1.0 / sqrt(1.0 + m11 * m11);
-        m11 *= m01;
-      }
-      for (int i = 0; i < 3; ++i) out[i] = m11 * U[i] - m01 * V[i];
-    } else {
-      for (int i = 0; i < 3; ++i) out[i] = U[i];
-    }
-  }
-}
-
-// cov = {c00 c01 c02 c11 c12 c22}; returns the (unnormalised-sign) eigenvector of the smallest eigenvalue
-__host__ __device__ inline void fast_eigen3x3_min(const double cov[6], double out[3]) {
-  double mc = cov[0];
-  for (int i = 1; i < 6; ++i) mc = cov[i] > mc ? cov[i] : mc;
-  if (mc == 0.0) {
-    out[0] = out[1] = out[2] = 0.0;
-    return;
-  }
-  double A[6];
-  for (int i = 0; i < 6; ++i) A[i] = cov[i] / mc;
-  const double norm = A[1] * A[1] + A[2] * A[2] + A[4] * A[4];
-  if (norm > 0.0) {
-    const double q = (A[0] + A[3] + A[5]) / 3.0;
-    const double b00 = A[0] - q, b11 = A[3] - q, b22 = A[5] - q;
-    const double p = sqrt((b00 * b00 + b11 * b11 + b22 * b22 + norm * 2.0) / 6.0);
-    const double c00 = b11 * b22 - A[4] * A[4];
-    const double c01 = A[1] * b22 - A[4] * A[2];
-    const double c02 = A[1] * A[4] - b11 * A[2];
-    const double det = (b00 * c00 - A[1] * c01 + A[2] * c02) / (p * p * p);
-    double half_det = det * 0.5;
-    half_det = fmin(fmax(half_det, -1.0), 1.0);
-    const double angle = acos(half_det) / 3.0;
-    const double two_thirds_pi = 2.09439510239319549;
-    const double beta2 = cos(angle) * 2.0;
-    const double beta0 = cos(angle + two_thirds_pi) * 2.0;
-    const double beta1 = -(beta0 + beta2);
-    const double e0 = q + p * beta0, e1 = q + p * beta1, e2 = q + p * beta2;
-    double v0[3], v1[3], v2[3];
-    if (half_det >= 0.0) {
-      eigvec0(A, e2, v2);
-      if (e2 < e0 && e2 < e1) {
-        out[0] = v2[0], out[1] = v2[1], out[2] = v2[2];
-        return;
-      }
-      eigvec1(A, v2, e1, v1);
-      if (e1 < e0 && e1 < e2) {
-        out[0] = v1[0], out[1] = v1[1], out[2] = v1[2];
-        return;
-      }
-      cross3(v1, v2, out);
-    } else {
-      eigvec0(A, e0, v0);
-      if (e0 < e1 && e0 < e2) {
-        out[0] = v0[0], out[1] = v0[1], out[2] = v0[2];
-        return;
-      }
-      eigvec1(A, v0, e1, v1);
-      if (e1 < e0 && e1 < e2) {
-        out[0] = v1[0], out[1] = v1[1], out[2] = v1[2];
-        return;
-      }
-      cross3(v0, v1, out);
-    }
-  } else {
-    if (cov[0] < cov[3] && cov[0] < cov[5]) {
-      out[0] = 1, out[1] = 0, out[2] = 0;
-    } else if (cov[3] < cov[0] && cov[3] < cov[5]) {
-      out[0] = 0, out[1] = 1, out[2] = 0;
-    } else {
-      out[0] = 0, out[1] = 0, out[2] = 1;
-    }
-  }
-}
-
-// One thread per point; the grid index is over the cloud itself.  The k-best list of every thread lives in LDS
-// (slot-major, [slot][thread] => conflict-free) as an UNSORTED set with a tracked maximum: a closer candidate overwrites
-// the current worst and the maximum is recomputed by one sweep over the k slots.  Only the SET of the k nearest matters
-// (the covariance is a sum), so no ordering is maintained.  Candidate loads are issued four at a time: a load-per-
-// iteration loop with a scratch-resident sorted list measured 3.8 ms for 100 k points; this form is bound by LDS sweeps.
+// (normal estimation: normals_kernel.hpp + det_math.hpp)
 // colours in the map merge: AccumulatedPoint::AddPoint ASSIGNS the colour (helpers.cpp:40-42; isValidColor, helpers.cpp:83-85, is
 // true for every value), so a voxel ends up with the colour of its last point in cloud order; same output placement as
 // segment_mean_kernel (pass-through points first, their own colour)
@@ -872,297 +717,6 @@ __global__ __launch_bounds__(kBlock) void dense_transform_kernel(DenseDev d, siz
     d.sn[3 * s] = llrint((M.m[0] * a + M.m[1] * b + M.m[2] * c + M.m[3]) / kDenseNrmQ);
     d.sn[3 * s + 1] = llrint((M.m[4] * a + M.m[5] * b + M.m[6] * c + M.m[7]) / kDenseNrmQ);
     d.sn[3 * s + 2] = llrint((M.m[8] * a + M.m[9] * b + M.m[10] * c + M.m[11]) / kDenseNrmQ);
-  }
-}
-
-// normalise, orient towards the sensor origin ([O3D] NormalizeNormals + OrientNormalsTowardsCameraLocation(0,0,0)), store
-template <typename P4>
-__device__ __forceinline__ void finish_normal(const P4& q, double nv[3], P4* out) {
-  using R = typename Scalar<P4>::type;
-  double nn = sqrt(dot3(nv, nv));
-  if (nn == 0.0) {
-    nv[0] = 0, nv[1] = 0, nv[2] = 1;
-    nn = 1.0;
-  }
-  nv[0] /= nn, nv[1] /= nn, nv[2] /= nn;
-  if (isnan(nv[0])) nv[0] = 0, nv[1] = 0, nv[2] = 1;
-  // flip when n . (0 - p) < 0
-  if (nv[0] * -(double)q.x + nv[1] * -(double)q.y + nv[2] * -(double)q.z < 0.0) nv[0] = -nv[0], nv[1] = -nv[1], nv[2] = -nv[2];
-  P4 o;
-  o.x = (R)nv[0];
-  o.y = (R)nv[1];
-  o.z = (R)nv[2];
-  o.i = 0;
-  *out = o;
-}
-
-// One lane walks the rings around its point and keeps the max_nn-best SET in LDS slots sd[j * stride], sp_[j * stride]
-// (only the set matters for a covariance); nv = eigenvector of the smallest eigenvalue, not normalised.
-template <typename P4, int KU, bool EXACT>
-__device__ __forceinline__ void normal_one_lane(const P4& q, const GridDev& g, const P4* __restrict__ sp, const P4* __restrict__ pts_orig,
-                                                double radius, int max_nn,
-                                                int rmax_cells, typename Scalar<P4>::type* sd, int* sp_, int stride, double nv[3],
-                                                unsigned int* stats = nullptr) {
-  using R = typename Scalar<P4>::type;
-  const int* __restrict__ cs = g.cell_start;
-  (void)stats;
-#ifdef O3DS_NRM_STATS  // development aid (scripts/normals_stats.py): per-point work counters and wavefront clocks
-  unsigned int st_cand = 0, st_acc = 0, st_rows = 0, st_ring = 0;
-  const unsigned long long st_t0 = clock64();
-#define O3DS_ST(x) x
-#else
-#define O3DS_ST(x)
-#endif
-  const R qx = q.x, qy = q.y, qz = q.z;
-  int cnt = 0, worst_slot = 0;
-  R worst = (R)(radius * radius);  // candidates need d2 < worst
-  const double fx = ((double)qx - g.ox) * g.inv_cell, fy = ((double)qy - g.oy) * g.inv_cell, fz = ((double)qz - g.oz) * g.inv_cell;
-  const int ix = (int)floor(fx), iy = (int)floor(fy), iz = (int)floor(fz);
-  double mf = fmin(fx - floor(fx), 1.0 - (fx - floor(fx)));
-  mf = fmin(mf, fmin(fy - floor(fy), 1.0 - (fy - floor(fy))));
-  mf = fmin(mf, fmin(fz - floor(fz), 1.0 - (fz - floor(fz))));
-
-  // EXACT: the set kept is the max_nn smallest by (d2, original index) -- a tie at the max_nn-th distance (two candidates with the
-  // same f32 d2: about one point per 50 k-point cloud has one) otherwise goes to whichever candidate the walk meets first, and the
-  // order inside a cell is the arrival order of the index build's atomic scatter.  The slots then hold ORIGINAL indices.
-  int worst_oi = 0;
-  auto offer = [&](R d2, int p, bool ok, int oi) {
-    O3DS_ST(st_cand += ok);
-    bool take = ok && d2 < worst;
-    if constexpr (EXACT) take = take || (ok && cnt == max_nn && d2 == worst && oi < worst_oi);
-    if (take) {
-      O3DS_ST(++st_acc);
-      const int slot = cnt < max_nn ? cnt : worst_slot;
-      sd[slot * stride] = d2;
-      sp_[slot * stride] = EXACT ? oi : p;
-      if (cnt < max_nn) ++cnt;
-      if (cnt == max_nn) {  // list full: the bound becomes the current maximum
-        R m = sd[0];
-        int ms = 0;
-        if constexpr (KU > 0) {
-          // all KU slot reads go out back to back (constant LDS offsets) and are waited for once; with a run-time trip count the
-          // loop was one LDS round trip per slot, and since a wavefront sweeps whenever ANY of its lanes accepts a candidate --
-          // practically at every candidate -- those ~2400 clocks per sweep were 80 % of the kernel (scripts/normals_stats.py)
-          R v[KU > 0 ? KU : 1];
-#pragma unroll
-          for (int j = 1; j < KU; ++j) v[j] = sd[j * stride];
-#pragma unroll
-          for (int j = 1; j < KU; ++j) {
-            if (j < max_nn && v[j] > m) {
-              m = v[j];
-              ms = j;
-            }
-          }
-          if constexpr (EXACT) {  // among the slots that hold the maximum, the one to evict next has the LARGEST original index
-            worst_oi = sp_[ms * stride];
-#pragma unroll
-            for (int j = 1; j < KU; ++j) {
-              if (j < max_nn && j != ms && v[j] == m) {  // rare: only then is the second LDS read paid
-                const int oj = sp_[j * stride];
-                if (oj > worst_oi) {
-                  worst_oi = oj;
-                  ms = j;
-                }
-              }
-            }
-          }
-        } else {
-          for (int j = 1; j < max_nn; ++j) {
-            const R v = sd[j * stride];
-            if (v > m) {
-              m = v;
-              ms = j;
-            }
-          }
-          if constexpr (EXACT) {
-            worst_oi = sp_[ms * stride];
-            for (int j = 0; j < max_nn; ++j) {
-              if (j != ms && sd[j * stride] == m) {
-                const int oj = sp_[j * stride];
-                if (oj > worst_oi) {
-                  worst_oi = oj;
-                  ms = j;
-                }
-              }
-            }
-          }
-        }
-        worst = m;
-        worst_slot = ms;
-      }
-    }
-  };
-  auto scan = [&](int s, int e) {
-    for (int p = s; p < e; p += 4) {
-      const bool v1 = p + 1 < e, v2 = p + 2 < e, v3 = p + 3 < e;
-      const P4 t0 = sp[p], t1 = sp[v1 ? p + 1 : p], t2 = sp[v2 ? p + 2 : p], t3 = sp[v3 ? p + 3 : p];
-      const R a0 = t0.x - qx, b0 = t0.y - qy, c0 = t0.z - qz;
-      const R a1 = t1.x - qx, b1 = t1.y - qy, c1 = t1.z - qz;
-      const R a2 = t2.x - qx, b2 = t2.y - qy, c2 = t2.z - qz;
-      const R a3 = t3.x - qx, b3 = t3.y - qy, c3 = t3.z - qz;
-      offer(a0 * a0 + b0 * b0 + c0 * c0, p, true, (int)t0.i);
-      offer(a1 * a1 + b1 * b1 + c1 * c1, p + 1, v1, (int)t1.i);
-      offer(a2 * a2 + b2 * b2 + c2 * c2, p + 2, v2, (int)t2.i);
-      offer(a3 * a3 + b3 * b3 + c3 * c3, p + 3, v3, (int)t3.i);
-    }
-  };
-
-  // Distance (in cells) from the query to the slab of cells at offset d along one axis; f = the query's fraction inside its own
-  // cell.  A row (dz, dy) holds no candidate when gap_z^2 + gap_y^2 already reaches the bound, and inside a row only the cells
-  // whose x-gap fits under what is left can; both tests are deflated by 1e-6 against the rounding of the f32 distances, and the
-  // bound (`worst`: r^2, then the current max_nn-th best) only ever shrinks, so a skipped cell stays skipped.
-  const double frx = fx - floor(fx), fry = fy - floor(fy), frz = fz - floor(fz);
-  auto gap = [](int d, double f) { return d > 0 ? (double)d - f : d < 0 ? f - (double)(d + 1) : 0.0; };
-  const double cell2 = g.cell * g.cell * (1.0 - 2e-6);
-  for (int ring = 0; ring <= rmax_cells; ++ring) {
-    if (ring >= 1) {
-      const double lb = g.cell * ((double)(ring - 1) + mf) * (1.0 - 1e-6);
-      if ((double)worst <= lb * lb) break;  // the k-th best (or r^2) already lies inside the searched block
-    }
-    O3DS_ST(st_ring = ring);
-    for (int dz = -ring; dz <= ring; ++dz) {
-      const int z = iz + dz;
-      if ((unsigned)z >= (unsigned)g.nz) continue;
-      const double gz = gap(dz, frz);
-      if (gz * gz * cell2 >= (double)worst) continue;
-      for (int dy = -ring; dy <= ring; ++dy) {
-        const int y = iy + dy;
-        if ((unsigned)y >= (unsigned)g.ny) continue;
-        const double gy = gap(dy, fry);
-        const double left = (double)worst - (gz * gz + gy * gy) * cell2;  // what the x-offset may still use
-        if (left <= 0.0) continue;
-        const int row = (z * g.ny + y) * g.nx;
-        O3DS_ST(++st_rows);
-        const bool shell = (dz == -ring || dz == ring || dy == -ring || dy == ring);
-        if (shell || ring == 0) {
-          const double wx = sqrt(left) * g.inv_cell * (1.0 + 1e-6);  // in cells
-          const int x0 = max(max(ix - ring, 0), (int)floor(fx - wx)), x1 = min(min(ix + ring, g.nx - 1), (int)floor(fx + wx));
-          if (x0 <= x1) scan(cs[row + x0], cs[row + x1 + 1]);
-        } else {
-          // interior rows: only the two end cells are new.  Both ends are tested on squared gaps (no square root) and their four
-          // cell_start values are fetched in one batch: at ring 5-6 of a sparse neighbourhood a lane walks 150+ such rows, nearly
-          // all empty, and one memory round trip per end was what the slowest wavefronts of the kernel spent their time on.
-          const int xl = ix - ring, xr = ix + ring;
-          const double w2 = left * g.inv_cell * g.inv_cell * (1.0 + 4e-6);  // (x-reach in cells)^2, inflated like wx above
-          const double gl = gap(-ring, frx), gr = gap(ring, frx);
-          const bool okl = (unsigned)xl < (unsigned)g.nx && gl * gl < w2, okr = (unsigned)xr < (unsigned)g.nx && gr * gr < w2;
-          const int il = okl ? row + xl : 0, ir = okr ? row + xr : 0;
-          const int sl = cs[il], el = cs[il + 1], sr = cs[ir], er = cs[ir + 1];
-          if (okl) scan(sl, el);
-          if (okr) scan(sr, er);
-        }
-      }
-    }
-  }
-  O3DS_ST(const unsigned long long st_t1 = clock64());
-  double cov[6] = {1, 0, 0, 1, 0, 1};
-  if (cnt >= 3) {
-    if constexpr (EXACT) {
-      // Order-independent cumulants (O3DS_NRM_EXACT=1): the neighbours sit in the slots in the order the walk met
-      // them, which is the order an atomic scatter gave the points of a cell -- different from one launch to the next.  Coordinates
-      // relative to the query in units of 2^-20 m as integers, sums of them and of their products in int64: exact, so any order gives
-      // the same bits (|d| <= radius <= 200 m: products < 2^56, 128 of them < 2^63).  The covariance does not depend on the origin.
-      long long si[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-      for (int j = 0; j < cnt; j += 4) {  // the slots hold original indices here: gather from the cloud in its own order
-        const bool v1 = j + 1 < cnt, v2 = j + 2 < cnt, v3 = j + 3 < cnt;
-        const P4 t[4] = {pts_orig[sp_[j * stride]], pts_orig[sp_[(v1 ? j + 1 : j) * stride]], pts_orig[sp_[(v2 ? j + 2 : j) * stride]],
-                         pts_orig[sp_[(v3 ? j + 3 : j) * stride]]};
-        const bool ok[4] = {true, v1, v2, v3};
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (!ok[u]) continue;
-          const long long X = llrint(((double)t[u].x - (double)qx) * 1048576.0), Y = llrint(((double)t[u].y - (double)qy) * 1048576.0),
-                          Z = llrint(((double)t[u].z - (double)qz) * 1048576.0);
-          si[0] += X;
-          si[1] += Y;
-          si[2] += Z;
-          si[3] += X * X;
-          si[4] += X * Y;
-          si[5] += X * Z;
-          si[6] += Y * Y;
-          si[7] += Y * Z;
-          si[8] += Z * Z;
-        }
-      }
-      const double u1 = 1.0 / 1048576.0 / (double)cnt, u2 = u1 / 1048576.0;
-      const double m0 = (double)si[0] * u1, m1 = (double)si[1] * u1, m2 = (double)si[2] * u1;
-      cov[0] = (double)si[3] * u2 - m0 * m0;
-      cov[1] = (double)si[4] * u2 - m0 * m1;
-      cov[2] = (double)si[5] * u2 - m0 * m2;
-      cov[3] = (double)si[6] * u2 - m1 * m1;
-      cov[4] = (double)si[7] * u2 - m1 * m2;
-      cov[5] = (double)si[8] * u2 - m2 * m2;
-    } else {
-    double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int j = 0; j < cnt; j += 4) {  // re-gather the neighbours, four loads in flight
-      const bool v1 = j + 1 < cnt, v2 = j + 2 < cnt, v3 = j + 3 < cnt;
-      const P4 t[4] = {sp[sp_[j * stride]], sp[sp_[(v1 ? j + 1 : j) * stride]], sp[sp_[(v2 ? j + 2 : j) * stride]],
-                       sp[sp_[(v3 ? j + 3 : j) * stride]]};
-      const bool ok[4] = {true, v1, v2, v3};
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (!ok[u]) continue;
-        const double x = (double)t[u].x, y = (double)t[u].y, z = (double)t[u].z;
-        c[0] += x;
-        c[1] += y;
-        c[2] += z;
-        c[3] += x * x;
-        c[4] += x * y;
-        c[5] += x * z;
-        c[6] += y * y;
-        c[7] += y * z;
-        c[8] += z * z;
-      }
-    }
-    const double inv = 1.0 / (double)cnt;
-    for (int j = 0; j < 9; ++j) c[j] *= inv;
-    cov[0] = c[3] - c[0] * c[0];
-    cov[1] = c[4] - c[0] * c[1];
-    cov[2] = c[5] - c[0] * c[2];
-    cov[3] = c[6] - c[1] * c[1];
-    cov[4] = c[7] - c[1] * c[2];
-    cov[5] = c[8] - c[2] * c[2];
-    }
-  }
-  fast_eigen3x3_min(cov, nv);
-#ifdef O3DS_NRM_STATS
-  if (stats) {
-    const unsigned long long st_t2 = clock64();
-    stats[0] = st_ring, stats[1] = st_rows, stats[2] = st_cand, stats[3] = st_acc;
-    stats[4] = (unsigned int)(st_t1 - st_t0), stats[5] = (unsigned int)(st_t2 - st_t1), stats[6] = (unsigned int)cnt;
-    stats[7] = (unsigned int)(st_t0 & 0xffffffffu);
-  }
-#endif
-#undef O3DS_ST
-}
-
-// One thread per point.  (Fetching the cell_start pairs of 4 or 8 rows of a ring in one batch instead of one dependent round trip per
-// row -- for all rings, or only from ring 2 on, where a sparse neighbourhood walks 200+ mostly empty rows -- measured slower: 0.284 /
-// 0.300 ms vs 0.254 ms; the row extents of a batch come from a staler bound and the slowest wavefront got slower, not faster.
-// Queuing the segments a lane finds (8 or 16 per lane in LDS) and scanning the queue at the end of a ring, so that the lanes scan their
-// k-th own segment together instead of the wavefront scanning at every row any lane found something in: 0.286 / 0.254 ms vs 0.259 ms.
-// What the slowest wavefronts pay for is neither the row walk nor the scattered scans but the sweep after every accepted candidate:
-// with 64 lanes some lane accepts at practically every candidate -- see scripts/normals_stats.py.)
-// (A variant with 8 lanes per point -- candidates of the 3x3x3 block collected into LDS stacks, the
-// max_nn-th distance found by bisection on the float bit pattern, lane-parallel cumulants -- was exact but slower on the
-// ~100 k-point voxel-filtered scans of the config-2 stream: 0.73 ms vs 0.38 ms; at that size this kernel already fills the
-// chip and the selection overhead dominates.  Removed.)
-template <typename P4, int KMAX, int BLK, bool EXACT>
-__global__ __launch_bounds__(BLK) void normals_kernel(const P4* __restrict__ pts /* original order */, size_t n, GridDev g,
-                                                      const P4* __restrict__ sp /* sorted by cell */, double radius, int max_nn, int rmax_cells,
-                                                      P4* __restrict__ out_nrm, unsigned int* __restrict__ stats = nullptr) {
-  using R = typename Scalar<P4>::type;
-  __shared__ R s_d[KMAX][BLK];
-  __shared__ int s_p[KMAX][BLK];
-  const int tid = threadIdx.x;
-  // queries are taken in CELL order (sp), so the lanes of a wavefront walk the same few cells: their candidate loads hit the same
-  // cache lines and their ring loops end together; the normal goes back to the point's original slot (sp[j].i)
-  for (size_t j = (size_t)blockIdx.x * BLK + tid; j < n; j += (size_t)gridDim.x * BLK) {
-    const P4 q = sp[j];
-    double nv[3];
-    normal_one_lane<P4, (KMAX <= 32 ? KMAX : 0), EXACT>(q, g, sp, pts, radius, max_nn, rmax_cells, &s_d[0][tid], &s_p[0][tid], BLK, nv,
-                                                 stats ? stats + 8 * j : nullptr);
-    finish_normal<P4>(q, nv, &out_nrm[(size_t)q.i]);
   }
 }
 

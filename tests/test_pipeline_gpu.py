@@ -81,18 +81,18 @@ class _OracleLoop:
         self.Tprev = self.T.copy()
 
 
-def test_odometry_mapper_loop_matches_oracle(backend_f64, oracle):
-    be = backend_f64
+def _run_loop(be, oracle, n_frames, n_az, tol_t, tol_r, tol_odo, size_tol):
     mp, op = _params()
     scene = syn.make_scene()
-    poses = syn.figure_eight_poses(200, 0.1)[:N_FRAMES]
+    poses = syn.figure_eight_poses(200, 0.1)[:n_frames]
     odo = LidarOdometry(be)
     odo.setParameters(op)
     mapper = Mapper(be, odo)
     mapper.setParameters(mp)
     ref = _OracleLoop(oracle, mp, op)
-    for k in range(N_FRAMES):
-        raw = syn.os128_scan(scene, poses[k], frame=k, n_az=N_AZ)
+    worst = [0.0, 0.0, 0.0, 0.0]
+    for k in range(n_frames):
+        raw = syn.os128_scan(scene, poses[k], frame=k, n_az=n_az)
         t = 0.1 * k
         cloud = PointCloud.from_numpy(be, raw)
         assert odo.addRangeScan(cloud, t)
@@ -102,20 +102,38 @@ def test_odometry_mapper_loop_matches_oracle(backend_f64, oracle):
         ref.mapping(raw, t)
         dt, dr = syn.se3_error(mapper.getMapToRangeSensor(), ref.T)
         do_t, do_r = syn.se3_error(odo.odomToRangeSensorCumulative_, ref.odom)
-        print(f"frame {k}: map pose vs oracle {dt:.2e} m {dr:.2e} rad; odom {do_t:.2e} {do_r:.2e}; map size {len(mapper.getActiveSubmap().getMapPointCloud())}/{len(ref.map_p)}")
-        # Scan-to-scan odometry agrees to round-off.  The mapping poses agree to the stated SE(3) tolerance only: ~0.6 % of the
-        # scan normals are not defined by the data (collinear neighbourhoods, planes through the sensor whose orientation sign
-        # is decided by rounding -- measured 115 of 18 702 at frame 0), they enter the map by voxel averaging, and from
-        # then on the two maps -- and hence the poses -- differ slightly (7e-8 m at frame 1, <1e-3 m afterwards); the same
-        # happens between two runs of the reference itself (OpenMP summation order).
-        assert do_t < 1e-6 and do_r < 1e-6
-        assert dt < 5e-3 and dr < 1e-3, (k, dt, dr)
         n_dev, n_ref = len(mapper.getActiveSubmap().getMapPointCloud()), len(ref.map_p)
-        assert abs(n_dev - n_ref) <= 0.005 * n_ref
+        print(f"frame {k}: map pose vs oracle {dt:.2e} m {dr:.2e} rad; odom {do_t:.2e} {do_r:.2e}; map size {n_dev}/{n_ref}")
+        worst = [max(worst[0], dt), max(worst[1], dr), max(worst[2], do_t), max(worst[3], do_r)]
+        assert do_t <= tol_odo and do_r <= tol_odo, (k, do_t, do_r)
+        assert dt <= tol_t and dr <= tol_r, (k, dt, dr)
+        assert abs(n_dev - n_ref) <= size_tol * n_ref, (k, n_dev, n_ref)
+    print(f"worst over {n_frames} frames: map pose {worst[0]:.2e} m {worst[1]:.2e} rad, odometry {worst[2]:.2e} m {worst[3]:.2e} rad")
     # and against ground truth: the loop tracks the trajectory (relative to the first pose)
-    T_gt = np.linalg.inv(poses[0]) @ poses[N_FRAMES - 1]
+    T_gt = np.linalg.inv(poses[0]) @ poses[n_frames - 1]
     gt_t, gt_r = syn.se3_error(mapper.getMapToRangeSensor(), T_gt)
     assert gt_t < 0.05 and gt_r < 0.01, (gt_t, gt_r)
+
+
+def test_odometry_mapper_loop_matches_oracle(backend_f64, oracle):
+    """f64 storage, 6 frames x 32 768 points: every stage of a frame is the oracle's arithmetic (crop and voxel keys exact, voxel
+    means summed in cloud order, normals bit for bit -- test_estimate_normals_matches_oracle), so the two loops differ only by the
+    summation order of the 6x6 normal equations: poses agree to 1e-9, three orders inside the stated f64 tolerance (1e-6 m / rad;
+    SURVEY 8c).  Round 1 measured 2.98e-3 m here: its normals disagreed with the oracle where the data do not define them."""
+    _run_loop(backend_f64, oracle, N_FRAMES, N_AZ, 1e-6, 1e-6, 1e-6, 0.0)
+
+
+def test_full_size_stream_matches_oracle_f64(backend_f64, oracle):
+    """BASELINE configs[2] at full scan size (131 072 points per frame), 40 frames, f64 storage: 1e-6 m / 1e-6 rad at EVERY frame."""
+    _run_loop(backend_f64, oracle, 40, 1024, 1e-6, 1e-6, 1e-6, 0.0)
+
+
+def test_full_size_stream_matches_oracle_f32(backend_f32, oracle):
+    """The same stream with f32 point storage (the layout bench.py measures): the stated SE(3) tolerance for f32 storage,
+    1e-3 m / 1e-3 rad, at every one of 40 frames.  The oracle works on the f64 scan; the device rounds the scan, every voxel mean
+    and every normal to f32, so neighbourhoods whose normal is not defined by the data come out differently -- that, not the
+    registration, is what the tolerance is spent on."""
+    _run_loop(backend_f32, oracle, 40, 1024, 1e-3, 1e-3, 1e-3, 0.005)
 
 
 @pytest.mark.gpu

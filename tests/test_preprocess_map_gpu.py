@@ -106,24 +106,49 @@ def _eig_gap(pts, radius, knn):
 
 
 def test_estimate_normals_matches_oracle(backend_f64, oracle, scan):
-    pts = oracle.voxel_down_sample(scan, 0.1)[::3]  # thinned: keeps the python eig-gap loop short
+    """f64 storage: EVERY normal equals the oracle's bit for bit -- the neighbour set is the max_nn smallest by (d2, original
+    index), the nine cumulants are summed in that order, and the eigen-solver / normalisation / orientation arithmetic is the
+    oracle's operation by operation (csrc/det_math.hpp) -- degenerate neighbourhoods (collinear ring segments, planes through the
+    sensor whose orientation sign hangs on the last bit) included.  (2.0, 48) runs the max_nn > 32 instantiation."""
+    pts = oracle.voxel_down_sample(scan, 0.1)
     c = backend_f64.upload(pts)
-    for radius, knn in ((3.0, 20), (1.0, 5), (0.5, 30)):
+    for radius, knn in ((3.0, 20), (1.0, 5), (0.5, 30), (2.0, 48)):
         backend_f64.estimate_normals(c, radius, knn)
         _, got = backend_f64.download(c)
         ref = oracle.estimate_normals(pts, radius, knn)
-        dots = np.einsum("ij,ij->i", got, ref)
-        view = np.abs(np.einsum("ij,ij->i", ref, pts / np.linalg.norm(pts, axis=1, keepdims=True)))
-        well = _eig_gap(pts, radius, knn) > 1e-3  # direction defined by the data
-        # well-conditioned neighbourhoods: same direction to 1e-6 (the eigenvector error scales with eps/gap), and the same
-        # orientation unless the plane passes through the sensor origin (n.p ~ 0, sign decided by rounding)
-        assert well.mean() > 0.5
-        assert (np.abs(dots[well]) > 1 - 1e-6).all(), (radius, knn, np.abs(dots[well]).min())
-        assert (dots[well & (view > 1e-6)] > 1 - 1e-6).all()
-        # everywhere: unit length, and the overall agreement stays high even counting ill-conditioned points
-        np.testing.assert_allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-12)
-        assert (np.abs(dots) > 1 - 1e-6).mean() > 0.98
+        differ = np.flatnonzero(np.any(got != ref, axis=1))
+        assert len(differ) == 0, (radius, knn, len(differ), differ[:5], got[differ[:3]], ref[differ[:3]])
     backend_f64.free(c)
+
+
+def test_estimate_normals_f32_storage_and_repeatability(backend_f32, oracle, scan):
+    """f32 storage: distances are f32, so the neighbour set may differ from the f64 oracle's where two candidates tie within f32
+    rounding; where the data define the direction it agrees to 1e-5.  And the result is a function of the cloud alone: it repeats
+    bit for bit when the device pool has been disturbed in between (the index build's atomic scatter then orders the points of a
+    cell differently -- which is what made the round-1 kernel irreproducible)."""
+    import hashlib
+
+    pts = oracle.voxel_down_sample(scan, 0.1)[::3]  # thinned: keeps the python eig-gap loop short
+    c = backend_f32.upload(pts)
+    stored, _ = backend_f32.download(c)
+    for radius, knn in ((3.0, 20), (1.0, 5)):
+        backend_f32.estimate_normals(c, radius, knn)
+        _, got = backend_f32.download(c)
+        junk = [backend_f32.upload(np.random.default_rng(i).normal(size=(150_000 + 777 * i, 3))) for i in range(3)]
+        for j in junk:
+            backend_f32.free(j)
+        backend_f32.estimate_normals(c, radius, knn)
+        _, again = backend_f32.download(c)
+        assert hashlib.sha1(got.tobytes()).hexdigest() == hashlib.sha1(again.tobytes()).hexdigest()
+        ref = oracle.estimate_normals(stored, radius, knn)  # the oracle on the values the device stores
+        dots = np.einsum("ij,ij->i", got, ref)
+        view = np.abs(np.einsum("ij,ij->i", ref, stored / np.linalg.norm(stored, axis=1, keepdims=True)))
+        well = _eig_gap(stored, radius, knn) > 1e-3
+        assert well.mean() > 0.5
+        assert (np.abs(dots[well]) > 1 - 1e-5).mean() > 0.999, (radius, knn, (np.abs(dots[well]) > 1 - 1e-5).mean())
+        assert (dots[well & (view > 1e-4)] > 0).mean() > 0.999
+        np.testing.assert_allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-6)
+    backend_f32.free(c)
 
 
 def test_normals_few_neighbours_and_errors(backend_f64):
