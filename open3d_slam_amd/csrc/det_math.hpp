@@ -1,6 +1,6 @@
 // det_math.hpp -- the arithmetic of [O3D] ComputeNormal (FastEigen3x3, Geometric Tools "robust eigensolver for 3x3 symmetric
 // matrices") + NormalizeNormals + OrientNormalsTowardsCameraLocation, written so that the device produces THE SAME BITS as the CPU
-// oracle (oracle/o3d_oracle.c: orc_fast_eigen3x3_min_evec, orc_acos, orc_cos, orc_estimate_normals):
+// checker under oracle/ (its orc_fast_eigen3x3_min_evec, orc_acos, orc_cos, orc_estimate_normals; test infrastructure, never linked here):
 //   * only +, -, *, / and sqrt of IEEE-754 binary64 (all correctly rounded on gfx950), never a fused multiply-add: everything
 //     between the two pragmas below is compiled with contraction OFF (hipcc's default for device code is -ffp-contract=fast);
 //   * acos / cos are the same Horner series on the same reduced arguments with the same coefficient tables as the oracle

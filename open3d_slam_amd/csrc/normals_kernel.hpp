@@ -3,7 +3,7 @@
 //
 // SIXTEEN LANES PER POINT (one DPP row), four points per wavefront, sixteen points per wavefront in four rounds.
 //   * The neighbourhood kept is a SET defined without reference to any search structure: the max_nn smallest of the points with
-//     d2 < r^2, in the total order (d2, original index) -- what oracle/o3d_oracle.c fixes (knn_accepts / knn_push).  It is found by
+//     d2 < r^2, in the total order (d2, original index) -- the order the CPU checker under oracle/ fixes (its knn_accepts / knn_push).  It is found by
 //     RANKING, not by insertion: the candidates a group meets are compared against the current max_nn-th key, the survivors of a
 //     chunk (<= 64, four per lane) and the kept keys are ranked against each other with broadcast LDS reads (rank = number of
 //     smaller keys; keys are unique), and whoever ranks below max_nn stores itself at slot [rank].  The kept list is therefore
