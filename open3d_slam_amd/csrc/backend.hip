@@ -1825,15 +1825,14 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn) {
       return rc;
     }
     const double avg = occ ? (double)c.n / (double)occ : 1.0;
-    double cell = tmp.grid.cell * std::sqrt(std::max(1.0, (double)max_nn) / (3.14159265358979 * avg));
+    static const double cell_scale = getenv("O3DS_NRM_CELL_SCALE") ? atof(getenv("O3DS_NRM_CELL_SCALE")) : 1.0;  // tuning experiments
+    double cell = cell_scale * tmp.grid.cell * std::sqrt(std::max(1.0, (double)max_nn) / (3.14159265358979 * avg));
     cell = std::min(std::max(cell, radius / 64.0), radius);
-    if (std::fabs(cell - tmp.grid.cell) > 0.05 * tmp.grid.cell) {
-      rc = build_index_t<P4>(h, tmp, cell);
-      if (rc) {
-        tmp.pts = nullptr;
-        free_index(h, tmp);
-        return rc;
-      }
+    rc = build_index_t<P4>(h, tmp, cell);
+    if (rc) {
+      tmp.pts = nullptr;
+      free_index(h, tmp);
+      return rc;
     }
     h->nrm_cell = tmp.grid.cell;
     h->nrm_radius = radius;
@@ -1861,40 +1860,53 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn) {
     if (bad) fprintf(stderr, " first at cell %zu (block %zu): %d -> %d", first, (first + 1) / 1024, hcs[first], hcs[first + 1]);
     fprintf(stderr, "\n");
   }
-  // 16 lanes per point, 16 points per 64-thread workgroup (normals_kernel.hpp); the instantiation is picked by max_nn
+  // 16 lanes per point, 16 points per 256-thread workgroup (normals_kernel.hpp), then a thread per point for the eigen-solve; the instantiation is picked by max_nn
   {
     const P4* p_pts = (const P4*)c.pts;
     const P4* p_sp = (const P4*)tmp.spts;
     P4* p_out = (P4*)c.nrm;
     const unsigned int gsz = (unsigned int)((c.n + 15) / 16);
+#ifdef O3DS_NRM_CHECK
+    unsigned long long* d_ws = nullptr;
+    if (getenv("O3DS_NRM_STATS_FILE")) {
+      HIP_TRY(hipMalloc((void**)&d_ws, sizeof(unsigned long long) * 6 * 4 * gsz));
+      HIP_TRY(hipMemset(d_ws, 0, sizeof(unsigned long long) * 6 * 4 * gsz));
+    }
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(o3ds::g_nrm_wave_stats), &d_ws, sizeof(d_ws)));
+#endif
+    double* d_sums = nullptr;
+    int* d_cnts = nullptr;
+    TMP_ALLOC(d_sums, sizeof(double) * 9 * c.n);
+    TMP_ALLOC(d_cnts, sizeof(int) * c.n);
     if (max_nn <= 32)  // the shipped configs' knn is 20
-      normals_kernel<P4, 32><<<gsz, 64, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, p_out);
+      normals_kernel<P4, 32><<<gsz, 256, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, d_sums, d_cnts);
     else
-      normals_kernel<P4, 128><<<gsz, 64, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, p_out);
+      normals_kernel<P4, 128><<<gsz, 256, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, d_sums, d_cnts);
+    normals_finish_kernel<P4><<<(unsigned int)((c.n + 255) / 256), 256, 0, h->stream>>>(p_sp, c.n, d_sums, d_cnts, p_out);
   }
   HIP_TRY(hipGetLastError());
   dbg_sync(h, 16);
+#ifdef O3DS_NRM_CHECK
+  if (const char* sf = getenv("O3DS_NRM_STATS_FILE")) {
+    const unsigned int gsz = (unsigned int)((c.n + 15) / 16);
+    unsigned long long* d_ws = nullptr;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpyFromSymbol(&d_ws, HIP_SYMBOL(o3ds::g_nrm_wave_stats), sizeof(d_ws)));
+    std::vector<unsigned long long> ws((size_t)6 * 4 * gsz);
+    HIP_TRY(hipMemcpy(ws.data(), d_ws, sizeof(unsigned long long) * ws.size(), hipMemcpyDeviceToHost));
+    (void)hipFree(d_ws);
+    if (FILE* f = fopen(sf, "wb")) {
+      fwrite(ws.data(), sizeof(unsigned long long), ws.size(), f);
+      fclose(f);
+    }
+  }
+#endif
   if (nrm_debug) {
     fprintf(stderr, "[normals] kernel done: %s\n", hipGetErrorString(hipStreamSynchronize(h->stream)));
 #ifdef O3DS_NRM_CHECK
     unsigned int dbg[8] = {0};
     (void)hipMemcpyFromSymbol(dbg, HIP_SYMBOL(o3ds::g_nrm_dbg), sizeof(dbg));
-    fprintf(stderr, "[normals] violations: unsorted %u, bad p %u, bad oi %u, bad segment %u, bad T %u, survivor met twice %u, survivor == kept %u\n", dbg[0], dbg[1],
-            dbg[2], dbg[3], dbg[4], dbg[5], dbg[6]);
-    if (dbg[5]) {
-      int info[16];
-      (void)hipMemcpyFromSymbol(info, HIP_SYMBOL(o3ds::g_nrm_info), sizeof(info));
-      fprintf(stderr, "[normals] first: ring %d tbase %d f0 %d T %d stot %d cnt %d eq %d idx %d lane %d c %d j %d cell %d %d %d seg %d %d\n", info[0], info[1], info[2],
-              info[3], info[4], info[5], info[6], info[7], info[8], info[9], info[10], info[11], info[12], info[13], info[14], info[15]);
-      int segs[256];
-      double qq[8];
-      (void)hipMemcpyFromSymbol(segs, HIP_SYMBOL(o3ds::g_nrm_segs), sizeof(segs));
-      (void)hipMemcpyFromSymbol(qq, HIP_SYMBOL(o3ds::g_nrm_q), sizeof(qq));
-      fprintf(stderr, "[normals] f %.9g %.9g %.9g worst %.9g q %.9g %.9g %.9g; grid origin %.9g %.9g %.9g\n", qq[0], qq[1], qq[2], qq[3], qq[4], qq[5], qq[6], tmp.grid.ox,
-              tmp.grid.oy, tmp.grid.oz);
-      const int g0 = (info[15] / 16) * 16;
-      for (int a = g0; a < g0 + 16; ++a) fprintf(stderr, "[normals]   lane %d: [%d,%d) [%d,%d)\n", a, segs[4 * a], segs[4 * a + 1], segs[4 * a + 2], segs[4 * a + 3]);
-    }
+    fprintf(stderr, "[normals] violations: unsorted %u, bad p %u, bad oi %u\n", dbg[0], dbg[1], dbg[2]);
     const unsigned int zero[8] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(o3ds::g_nrm_dbg), zero, sizeof(zero));
 #endif

@@ -1,7 +1,7 @@
 // normals_kernel.hpp -- [O3D] EstimateNormals(KDTreeSearchParamHybrid(radius, max_nn)) + NormalizeNormals +
 // OrientNormalsTowardsCameraLocation(0,0,0); call site CloudRegistration.cpp:49-56 (estimateNormals).
 //
-// SIXTEEN LANES PER POINT (one DPP row), four points per wavefront, sixteen points per wavefront in four rounds.
+// SIXTEEN LANES PER POINT (one DPP row), four points per wavefront; a second kernel turns the cumulants into normals.
 //   * The neighbourhood kept is a SET defined without reference to any search structure: the max_nn smallest of the points with
 //     d2 < r^2, in the total order (d2, original index) -- the order the CPU checker under oracle/ fixes (its knn_accepts / knn_push).  It is found by
 //     RANKING, not by insertion: the candidates a group meets are compared against the current max_nn-th key, the survivors of a
@@ -17,10 +17,11 @@
 //   * The nine cumulants are summed by nine lanes, each over the kept list IN ITS SORTED ORDER, in binary64 without contraction:
 //     with f64 storage the covariance, the eigenvector (det_math.hpp) and the orientation test are the oracle's bit for bit; with
 //     f32 storage the distances are f32 and everything after the selection is the same f64 arithmetic on the stored values.
-//   * The closed-form eigen-solve is ~1200 instructions of f64 per point; it runs once per wavefront for its 16 points on 16 lanes.
+//   * The closed-form eigen-solve is ~1200 instructions of f64 per point and needs one lane: normals_finish_kernel, a thread per point.
 #pragma once
 #include "common.hpp"
 #include "det_math.hpp"
+#include <type_traits>
 
 namespace o3ds {
 
@@ -36,10 +37,8 @@ namespace o3ds {
 #endif
 #ifdef O3DS_NRM_CHECK  // development aid: invariant violations counted in a device array (o3ds_debug_counters)
 __device__ unsigned int g_nrm_dbg[8];
-__device__ int g_nrm_info[16];
-__device__ int g_nrm_segs[64 * 4];
-__device__ double g_nrm_q[8];
 #define O3DS_NRM_BAD(k) atomicAdd(&g_nrm_dbg[k], 1u)
+__device__ unsigned long long* g_nrm_wave_stats;  // per wavefront: {clocks, start, rounds, max ring, chunks, merges} when set
 #else
 #define O3DS_NRM_BAD(k) ((void)0)
 #endif
@@ -55,14 +54,18 @@ __device__ __forceinline__ int row_incl_scan(int v) {
 __device__ __forceinline__ int row_last(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x15f, 0xf, 0xf, true); }  // row_newbcast:15
 
 template <bool WIDE, int KMAX, typename R>
-struct NrmGroupLds {
+struct alignas(16) NrmGroupLds {
   unsigned long long Kk[KMAX];  // kept keys, ascending by (key, index)
-  unsigned long long Sk[64];    // survivors of the current chunk
-  int Ki[WIDE ? KMAX : 1];      // original indices (f64 storage; with f32 storage the index is the key's low word)
-  int Si[WIDE ? 64 : 1];
-  int seg_off[32];   // first flat candidate number of each segment of the round
-  int seg_base[32];  // position in the sorted cloud minus seg_off
-  R X[KMAX][4];      // x y z 1 of the kept points, for the cumulants
+  int Ki[WIDE ? KMAX : 4];      // original indices (f64 storage; with f32 storage the index is the key's low word)
+  union {
+    struct {
+      unsigned long long Sk[64];  // survivors of the current chunk
+      int Si[WIDE ? 64 : 4];
+      int seg_off[128];   // first flat candidate number of each segment of the round (8 per lane: up to 4 rows of 2 segments)
+      int seg_base[128];  // position in the sorted cloud minus seg_off
+    };
+    R X[KMAX][4];  // x y z 1 of the kept points, for the cumulants (after the search)
+  };
 };
 
 // squared distance exactly as the oracle's search_rec forms it: ((dx*dx + dy*dy) + dz*dz), every operation rounded on its own
@@ -86,26 +89,27 @@ __device__ __forceinline__ bool nrm_less(unsigned long long ak, int ai, unsigned
 }
 
 template <typename P4, int KMAX>
-__global__ __launch_bounds__(64) void normals_kernel(const P4* __restrict__ pts /* original order */, size_t n, GridDev g,
-                                                     const P4* __restrict__ sp /* sorted by cell */, double radius, int max_nn, int rmax_cells,
-                                                     P4* __restrict__ out_nrm) {
+__global__ __launch_bounds__(256) void normals_kernel(const P4* __restrict__ pts /* original order */, size_t n, GridDev g,
+                                                      const P4* __restrict__ sp /* sorted by cell */, double radius, int max_nn, int rmax_cells,
+                                                      double* __restrict__ out_sums /* [n][9], cell order */, int* __restrict__ out_cnt /* [n] */) {
   using R = typename Scalar<P4>::type;
   constexpr bool WIDE = sizeof(P4) > 16;
   constexpr int KPL = (KMAX + 15) / 16;  // kept keys per lane
-  constexpr int PW = 16;                 // points per wavefront
-  __shared__ NrmGroupLds<WIDE, KMAX, R> s_grp[4];
-  __shared__ double s_sum[PW][9];
-  __shared__ int s_cnt[PW];
-#ifdef O3DS_NRM_CHECK
-  __shared__ int s_dbg[64][4];
-#endif
-  const int lane = threadIdx.x, l = lane & 15, grp = lane >> 4;
-  NrmGroupLds<WIDE, KMAX, R>& L = s_grp[grp];
-  const int* __restrict__ cs = g.cell_start;
-  const size_t base = (size_t)blockIdx.x * PW;
-  const double cell2 = g.cell * g.cell * (1.0 - 2e-6);
+  constexpr int PW = 4;                  // points per wavefront: one group of 16 lanes each
+  constexpr int PB = 4 * PW;             // points per workgroup (four wavefronts)
+  constexpr unsigned long long kNever = ~0ull;  // a key no candidate is smaller than (masks table entries past the end)
+  __shared__ NrmGroupLds<WIDE, KMAX, R> s_grp[16];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l = lane & 15, grp = lane >> 4;
+  NrmGroupLds<WIDE, KMAX, R>& L = s_grp[wv * 4 + grp];
+  const size_t base = (size_t)blockIdx.x * PB + (size_t)wv * PW;
   auto gap = [](int d, double f) { return d > 0 ? (double)d - f : d < 0 ? f - (double)(d + 1) : 0.0; };
 
+#ifdef O3DS_NRM_CHECK
+  const unsigned long long st_t0 = wall_clock64();
+  unsigned int st_rounds = 0, st_ring = 0, st_chunks = 0, st_cand = 0;
+#endif
+  const int* __restrict__ cs = g.cell_start;
+  const double cell2 = g.cell * g.cell * (1.0 - 2e-6);
   // queries are taken in CELL order (sp), so the four points of a wavefront walk the same few cells
   for (int it = 0; it < PW / 4; ++it) {
     const size_t j = base + (size_t)(it * 4 + grp);
@@ -117,98 +121,210 @@ __global__ __launch_bounds__(64) void normals_kernel(const P4* __restrict__ pts 
     const double frx = fx - floor(fx), fry = fy - floor(fy), frz = fz - floor(fz);
     const double mf = fmin(fmin(fmin(frx, 1.0 - frx), fmin(fry, 1.0 - fry)), fmin(frz, 1.0 - frz));
 
-    // group state (the same value in all 16 lanes)
+    // group state (the same value in all 16 lanes) ...
     int cnt = 0;
     const R r2 = (R)(radius * radius);
     unsigned long long tau_k = nrm_key(r2, 0);  // accept iff (key, idx) < (tau_k, tau_i): d2 < r^2 until the list is full
     int tau_i = 0;
     double worst = (double)r2;
-    int ring = 1, tbase = 0, ntask = 9;  // ring 1 = the whole 3x3x3 block (rings 0 and 1 of the old walk)
+    int ring = 1, ntask = 9;  // ring 1 = the whole 3x3x3 block (rings 0 and 1 of a ring-by-ring walk)
+    float inv_w = 1.0f / 3.0f;
     bool active = have;
+    // ... and this lane's cursor: it owns the rows t = l, l + 16, ... of the ring
+    int tnext = l;
 
-    while (__ballot(active) != 0ull) {
-      // ---- this lane's row of the round: up to two segments [s0,e0) [s1,e1) of the sorted cloud
-      int s0 = 0, e0 = 0, s1 = 0, e1 = 0;
-      const int t = tbase + l;
-      if (active && t < ntask) {
-        const int w = 2 * ring + 1;
-        const int tz = t / w;
-        const int dz = tz - ring, dy = t - tz * w - ring;
-        const int z = iz + dz, y = iy + dy;
-        if ((unsigned)z < (unsigned)g.nz && (unsigned)y < (unsigned)g.ny) {
+    for (;;) {
+      // ---- find work: every lane moves to its next row that the current bound does not rule out (arithmetic only: at ring 5-6 of a
+      // sparse neighbourhood nearly all of the 100-200 rows are ruled out); when no lane of the group has one left the ring is done.
+      // A lane takes up to FOUR rows per round (their cell_start loads are in flight together): a walk to ring 6 of a neighbourhood
+      // that never fills its list -- 31 rounds of 16 rows, each a chain of two memory round trips -- becomes 10 rounds.
+      int ss[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ee[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      auto next_row = [&](int& row, int& dzf, int& dyf, double& left) -> bool {
+        while (tnext < ntask) {
+          const int w = 2 * ring + 1;
+          const int tz = (int)(((float)tnext + 0.5f) * inv_w);  // exact for these sizes
+          const int dz = tz - ring, dy = tnext - tz * w - ring;
+          const int z = iz + dz, y = iy + dy;
+          tnext += 16;
+          if ((unsigned)z >= (unsigned)g.nz || (unsigned)y >= (unsigned)g.ny) continue;
           const double gz = gap(dz, frz), gy = gap(dy, fry);
-          const double left = worst - (gz * gz + gy * gy) * cell2;  // what the x-offset may still use; the bound only ever shrinks
-          if (left > 0.0) {
-            const int row = (z * g.ny + y) * g.nx;
-            const bool full = ring == 1 || dz == -ring || dz == ring || dy == -ring || dy == ring;
-            if (full) {
-              const double wx = sqrt(left) * g.inv_cell * (1.0 + 1e-6);  // in cells
-              const int x0 = max(max(ix - ring, 0), (int)floor(fx - wx)), x1 = min(min(ix + ring, g.nx - 1), (int)floor(fx + wx));
-              if (x0 <= x1) {
-                s0 = cs[row + x0];
-                e0 = cs[row + x1 + 1];
-              }
-            } else {  // interior rows: only the two end cells are new
-              const int xl = ix - ring, xr = ix + ring;
-              const double w2 = left * g.inv_cell * g.inv_cell * (1.0 + 4e-6);
-              const double gl = gap(-ring, frx), gr = gap(ring, frx);
-              const bool okl = (unsigned)xl < (unsigned)g.nx && gl * gl < w2, okr = (unsigned)xr < (unsigned)g.nx && gr * gr < w2;
-              const int il = okl ? row + xl : 0, ir = okr ? row + xr : 0;
-              const int sl = cs[il], el = cs[il + 1], sr = cs[ir], er = cs[ir + 1];
-              if (okl) s0 = sl, e0 = el;
-              if (okr) s1 = sr, e1 = er;
-            }
+          left = worst - (gz * gz + gy * gy) * cell2;  // what the x-offset may still use; the bound only ever shrinks
+          if (left <= 0.0) continue;
+          row = (z * g.ny + y) * g.nx;
+          dzf = dz, dyf = dy;
+          return true;
+        }
+        return false;
+      };
+      // up to two segments of the sorted cloud for one row
+      auto load_row = [&](int row, int dzf, int dyf, double left, int& s0, int& e0, int& s1, int& e1) {
+        const bool full = ring == 1 || dzf == -ring || dzf == ring || dyf == -ring || dyf == ring;
+        if (full) {
+          const double wx = sqrt(left) * g.inv_cell * (1.0 + 1e-6);  // in cells
+          const int x0 = max(max(ix - ring, 0), (int)floor(fx - wx)), x1 = min(min(ix + ring, g.nx - 1), (int)floor(fx + wx));
+          if (x0 <= x1) {
+            s0 = cs[row + x0];
+            e0 = cs[row + x1 + 1];
+          }
+        } else {  // interior rows: only the two end cells are new
+          const int xl = ix - ring, xr = ix + ring;
+          const double w2 = left * g.inv_cell * g.inv_cell * (1.0 + 4e-6);
+          const double gl = gap(-ring, frx), gr = gap(ring, frx);
+          const bool okl = (unsigned)xl < (unsigned)g.nx && gl * gl < w2, okr = (unsigned)xr < (unsigned)g.nx && gr * gr < w2;
+          const int il = okl ? row + xl : 0, ir = okr ? row + xr : 0;
+          const int sl = cs[il], el = cs[il + 1], sr = cs[ir], er = cs[ir + 1];
+          if (okl) s0 = sl, e0 = el;
+          if (okr) s1 = sr, e1 = er;
+        }
+      };
+      bool found = false;
+      int row = 0, dzf = 0, dyf = 0;
+      double left = 0.0;
+      for (;;) {
+        if (active && !found) found = next_row(row, dzf, dyf, left);
+        const unsigned int mine = (unsigned int)(__ballot(found) >> (grp * 16)) & 0xffffu;
+        const bool next_ring = active && mine == 0u;
+        if (__ballot(next_ring) == 0ull) break;
+        if (next_ring) {
+          ring += 1;
+          ntask = (2 * ring + 1) * (2 * ring + 1);
+          inv_w = 1.0f / (float)(2 * ring + 1);
+          tnext = l;
+          if (ring > rmax_cells) {
+            active = false;
+          } else {
+            const double lb = g.cell * ((double)(ring - 1) + mf) * (1.0 - 1e-6);
+            if (worst <= lb * lb) active = false;  // the max_nn-th best (or r^2) already lies inside the searched block
           }
         }
       }
+      if (__ballot(found) == 0ull) break;  // no group has anything left
 #ifdef O3DS_NRM_CHECK
-      if (g_nrm_dbg[5] == 0u) {  // until the first offence: remember the last round of every lane of this wavefront
-        s_dbg[lane][0] = s0, s_dbg[lane][1] = e0, s_dbg[lane][2] = s1, s_dbg[lane][3] = e1;
-      }
+      ++st_rounds;
+      st_ring = max(st_ring, (unsigned int)__builtin_amdgcn_readfirstlane(ring));
 #endif
+      if (found) load_row(row, dzf, dyf, left, ss[0], ee[0], ss[1], ee[1]);
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {  // further rows of the same ring for this lane
+        if (__ballot(found && tnext < ntask) == 0ull) break;
+        if (found) found = next_row(row, dzf, dyf, left);
+        if (found) load_row(row, dzf, dyf, left, ss[2 * k], ee[2 * k], ss[2 * k + 1], ee[2 * k + 1]);
+      }
       // ---- lay the segments of the 16 lanes end to end
-      const int len0 = e0 - s0, len1 = e1 - s1;
-      const int incl = row_incl_scan(len0 + len1);
-      const int off = incl - (len0 + len1);
+      int tot = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) tot += ee[k] - ss[k];
+      const int incl = row_incl_scan(tot);
       const int T = row_last(incl);
-      L.seg_off[2 * l] = off;
-      L.seg_base[2 * l] = s0 - off;
-      L.seg_off[2 * l + 1] = off + len0;
-      L.seg_base[2 * l + 1] = s1 - (off + len0);
+      {
+        int run = incl - tot;
+        int so[8], sb[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          so[k] = run;
+          sb[k] = ss[k] - run;
+          run += ee[k] - ss[k];
+        }
+        int4* po = reinterpret_cast<int4*>(&L.seg_off[8 * l]);
+        int4* pb = reinterpret_cast<int4*>(&L.seg_base[8 * l]);
+        po[0] = make_int4(so[0], so[1], so[2], so[3]);
+        po[1] = make_int4(so[4], so[5], so[6], so[7]);
+        pb[0] = make_int4(sb[0], sb[1], sb[2], sb[3]);
+        pb[1] = make_int4(sb[4], sb[5], sb[6], sb[7]);
+      }
       O3DS_WAVE_SYNC();
 
       for (int f0 = 0; __ballot(f0 < T) != 0ull; f0 += 64) {
-        // ---- four candidates per lane
+        // ---- four candidates per lane (fewer when the round has few left: nslot is wavefront-uniform): flat number -> segment by a
+        // 7-step search of the table, the searches of a lane in step
+#ifdef O3DS_NRM_CHECK
+        ++st_chunks;
+#endif
+        const int nslot = __ballot(T - f0 > 48) != 0ull ? 4 : __ballot(T - f0 > 32) != 0ull ? 3 : __ballot(T - f0 > 16) != 0ull ? 2 : 1;
+        int pos[4] = {0, 0, 0, 0};  // last segment whose first candidate number is <= f (empty segments share their successor's)
+#pragma unroll
+        for (int step = 64; step >= 1; step >>= 1) {
+          int v[4] = {0, 0, 0, 0};
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (c < nslot) v[c] = L.seg_off[pos[c] + step];
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (c < nslot && v[c] <= f0 + l + 16 * c) pos[c] += step;
+        }
+        int sb[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < nslot) sb[c] = L.seg_base[pos[c]];
+        P4 cand[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int f = f0 + l + 16 * c;
+          int p = f < T ? sb[c] + f : 0;
+#ifdef O3DS_NRM_CHECK
+          if ((size_t)(unsigned)p >= n) {
+            O3DS_NRM_BAD(1);
+            p = 0;
+          }
+#endif
+          if (c < nslot)
+            cand[c] = sp[p];
+          else
+            cand[c] = q;
+        }
+        R cd[4];
         unsigned long long ck[4];
         int ci[4];
         bool sv[4];
         int ns = 0;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const int f = f0 + l + 16 * c;
-          const bool valid = f < T;
-          int pos = 0;  // last segment whose first candidate number is <= f (empty segments share their successor's number)
-#pragma unroll
-          for (int step = 16; step >= 1; step >>= 1)
-            if (L.seg_off[pos + step] <= f) pos += step;
-          int p = valid ? L.seg_base[pos] + f : 0;
-#ifdef O3DS_NRM_CHECK
-          if ((size_t)(unsigned)p >= n || p < 0) {
-            O3DS_NRM_BAD(1);
-            p = 0;
-          }
-          if (valid && !(L.seg_off[pos] <= f && (pos == 31 || L.seg_off[pos + 1] > f))) O3DS_NRM_BAD(3);
-#endif
-          const P4 cand = sp[p];
-          const R d2 = nrm_d2<R>(cand.x, cand.y, cand.z, qx, qy, qz);
-          ci[c] = (int)cand.i;
-          ck[c] = nrm_key(d2, ci[c]);
-          sv[c] = valid && nrm_less<WIDE>(ck[c], ci[c], tau_k, tau_i);
+          cd[c] = nrm_d2<R>(cand[c].x, cand[c].y, cand[c].z, qx, qy, qz);
+          ci[c] = (int)cand[c].i;
+          ck[c] = nrm_key(cd[c], ci[c]);
+          sv[c] = (f0 + l + 16 * c < T) && nrm_less<WIDE>(ck[c], ci[c], tau_k, tau_i);
           ns += sv[c] ? 1 : 0;
         }
-        const int sincl = row_incl_scan(ns);
-        const int stot = row_last(sincl);
+        int sincl = row_incl_scan(ns);
+        int stot = row_last(sincl);
         if (__ballot(stot > 0) == 0ull) continue;
+        // ---- a first chunk usually brings 40-60 candidates inside the radius for max_nn places, and ranking costs (survivors)^2.
+        // So the bound is tightened first: a distance t with max_nn <= #{d2 < t} <= max_nn + 8 is found by regula falsi on the COUNT
+        // (on a surface the count grows like t) -- a few compare-and-count steps -- and only candidates with d2 < t are ranked.  At
+        // least max_nn candidates are below t, so the max_nn smallest by (d2, index) all are: the result is the same set.
+        {
+          const bool refine0 = cnt == 0 && stot > max_nn + 8;
+          if (__ballot(refine0) != 0ull) {
+            bool refine = refine0;
+            R t_lo = (R)0, t_hi = WIDE ? (R)__longlong_as_double((long long)tau_k) : (R)__uint_as_float((unsigned int)(tau_k >> 32));
+            int c_lo = 0, c_hi = stot;
+            for (int stepn = 0; stepn < 6 && __ballot(refine) != 0ull; ++stepn) {
+              const R t = t_lo + (t_hi - t_lo) * ((R)(max_nn + 4 - c_lo) * (R)__builtin_amdgcn_rcpf((float)(c_hi - c_lo)));  // any t in between will do
+              int cl = 0;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) cl += (sv[c] && cd[c] < t) ? 1 : 0;
+              const int ctot = row_last(row_incl_scan(cl));
+              if (refine) {
+                if (ctot < max_nn) {
+                  t_lo = t, c_lo = ctot;
+                } else {
+                  t_hi = t, c_hi = ctot;
+                  if (ctot <= max_nn + 8) refine = false;
+                }
+              }
+            }
+            if (refine0) {  // t_hi always has at least max_nn candidates below it
+              ns = 0;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                sv[c] = sv[c] && cd[c] < t_hi;
+                ns += sv[c] ? 1 : 0;
+              }
+            }
+            sincl = row_incl_scan(ns);
+            stot = row_last(sincl);
+          }
+        }
         {
           int slot = sincl - ns;
 #pragma unroll
@@ -220,77 +336,102 @@ __global__ __launch_bounds__(64) void normals_kernel(const P4* __restrict__ pts 
             }
         }
         O3DS_WAVE_SYNC();
-        // ---- rank survivors and kept keys against each other
-        unsigned long long kk[KPL];
-        int ki[KPL], rk[KPL];
-        bool kv[KPL];
+        // ---- rank survivors and kept keys against each other: lane l owns survivors l, l + 16, ... and kept keys l, l + 16, ...
+        // Table entries are read four at a time (one wait per four); entries past the end are replaced by a key nothing is
+        // smaller than.  The number of owned survivors per lane (1..4) is a wavefront-uniform switch.
+        auto merge = [&](auto nu_tag, auto kept_tag) {
+          constexpr int NU = decltype(nu_tag)::value;
+          constexpr bool KEPT = decltype(kept_tag)::value;
+          unsigned long long ok[NU], kk[KPL];
+          int oi[NU], ki[KPL], rs[NU], rk[KPL];
 #pragma unroll
-        for (int u = 0; u < KPL; ++u) {
-          const int idx = l + 16 * u;
-          kv[u] = idx < cnt;
-          kk[u] = L.Kk[idx < KMAX ? idx : 0];
-          ki[u] = 0;
-          if constexpr (WIDE) ki[u] = L.Ki[idx < KMAX ? idx : 0];
-          rk[u] = idx;
-        }
-        int rs[4] = {0, 0, 0, 0};
-#ifdef O3DS_NRM_CHECK
-        int eqs[4] = {0, 0, 0, 0};
-#endif
-        for (int jj = 0; __ballot(jj < stot) != 0ull; ++jj) {
-          const bool in = jj < stot;
-          const unsigned long long sk = L.Sk[jj];
-          int si = 0;
-          if constexpr (WIDE) si = L.Si[jj];
+          for (int u = 0; u < NU; ++u) {
+            const int idx = l + 16 * u;
+            ok[u] = idx < stot ? L.Sk[idx] : kNever;
+            oi[u] = 0;
+            if constexpr (WIDE) oi[u] = L.Si[idx];
+            rs[u] = 0;
+          }
 #pragma unroll
-          for (int c = 0; c < 4; ++c) rs[c] += (in && nrm_less<WIDE>(sk, si, ck[c], ci[c])) ? 1 : 0;
+          for (int u = 0; u < KPL; ++u) {
+            const int idx = l + 16 * u;
+            kk[u] = (KEPT && idx < cnt) ? L.Kk[idx] : kNever;
+            ki[u] = 0;
+            if constexpr (WIDE && KEPT) ki[u] = L.Ki[idx < KMAX ? idx : 0];
+            rk[u] = idx;
+          }
+          for (int jj = 0; __ballot(jj < stot) != 0ull; jj += 4) {
+            const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(&L.Sk[jj]), b = *reinterpret_cast<const ulonglong2*>(&L.Sk[jj + 2]);
+            unsigned long long sk[4] = {a.x, a.y, b.x, b.y};
+            int si[4] = {0, 0, 0, 0};
+            if constexpr (WIDE) {
+              const int4 t4 = *reinterpret_cast<const int4*>(&L.Si[jj]);
+              si[0] = t4.x, si[1] = t4.y, si[2] = t4.z, si[3] = t4.w;
+            }
 #pragma unroll
-          for (int u = 0; u < KPL; ++u) rk[u] += (in && nrm_less<WIDE>(sk, si, kk[u], ki[u])) ? 1 : 0;
-#ifdef O3DS_NRM_CHECK
+            for (int e = 0; e < 4; ++e) {
+              if (jj + e >= stot) sk[e] = kNever;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) eqs[c] += (in && sk == ck[c] && si == (WIDE ? ci[c] : 0)) ? 1 : 0;
+              for (int u = 0; u < NU; ++u) rs[u] += nrm_less<WIDE>(sk[e], si[e], ok[u], oi[u]) ? 1 : 0;
+              if constexpr (KEPT) {
 #pragma unroll
-          for (int u = 0; u < KPL; ++u)
-            if (in && kv[u] && sk == kk[u] && si == ki[u]) O3DS_NRM_BAD(6);
-#endif
-        }
-#ifdef O3DS_NRM_CHECK
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          if (sv[c] && eqs[c] != 1) {
-            if (atomicAdd(&g_nrm_dbg[5], 1u) == 0u) {
-              g_nrm_info[0] = ring, g_nrm_info[1] = tbase, g_nrm_info[2] = f0, g_nrm_info[3] = T, g_nrm_info[4] = stot, g_nrm_info[5] = cnt;
-              g_nrm_info[6] = eqs[c], g_nrm_info[7] = (int)(ck[c] & 0xffffffffu), g_nrm_info[8] = l, g_nrm_info[9] = c, g_nrm_info[10] = (int)j;
-              g_nrm_info[11] = ix, g_nrm_info[12] = iy, g_nrm_info[13] = iz, g_nrm_info[14] = s0, g_nrm_info[15] = e0;
-              g_nrm_info[15] = lane;
-              for (int a = 0; a < 64; ++a)
-                for (int b = 0; b < 4; ++b) g_nrm_segs[4 * a + b] = s_dbg[a][b];
-              g_nrm_q[0] = fx, g_nrm_q[1] = fy, g_nrm_q[2] = fz, g_nrm_q[3] = worst, g_nrm_q[4] = (double)qx, g_nrm_q[5] = (double)qy, g_nrm_q[6] = (double)qz;
+                for (int u = 0; u < KPL; ++u) rk[u] += nrm_less<WIDE>(sk[e], si[e], kk[u], ki[u]) ? 1 : 0;
+              }
             }
           }
-#endif
-        for (int jj = 0; __ballot(jj < cnt) != 0ull; ++jj) {
-          const bool in = jj < cnt;
-          const unsigned long long sk = L.Kk[jj];
-          int si = 0;
-          if constexpr (WIDE) si = L.Ki[jj];
+          if constexpr (KEPT) {
+            for (int jj = 0; __ballot(jj < cnt) != 0ull; jj += 4) {
+              const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(&L.Kk[jj]), b = *reinterpret_cast<const ulonglong2*>(&L.Kk[jj + 2]);
+              unsigned long long sk[4] = {a.x, a.y, b.x, b.y};
+              int si[4] = {0, 0, 0, 0};
+              if constexpr (WIDE) {
+                const int4 t4 = *reinterpret_cast<const int4*>(&L.Ki[jj]);
+                si[0] = t4.x, si[1] = t4.y, si[2] = t4.z, si[3] = t4.w;
+              }
 #pragma unroll
-          for (int c = 0; c < 4; ++c) rs[c] += (in && nrm_less<WIDE>(sk, si, ck[c], ci[c])) ? 1 : 0;
-        }
-        O3DS_WAVE_SYNC();
-        if (stot > 0) {
+              for (int e = 0; e < 4; ++e) {
+                if (jj + e >= cnt) sk[e] = kNever;
 #pragma unroll
-          for (int u = 0; u < KPL; ++u)
-            if (kv[u] && rk[u] < max_nn) {
-              L.Kk[rk[u]] = kk[u];
-              if constexpr (WIDE) L.Ki[rk[u]] = ki[u];
+                for (int u = 0; u < NU; ++u) rs[u] += nrm_less<WIDE>(sk[e], si[e], ok[u], oi[u]) ? 1 : 0;
+              }
+            }
+          }
+          O3DS_WAVE_SYNC();
+          if (stot > 0) {
+            if constexpr (KEPT) {
+#pragma unroll
+              for (int u = 0; u < KPL; ++u)
+                if (l + 16 * u < cnt && rk[u] < max_nn) {
+                  L.Kk[rk[u]] = kk[u];
+                  if constexpr (WIDE) L.Ki[rk[u]] = ki[u];
+                }
             }
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
-            if (sv[c] && rs[c] < max_nn) {
-              L.Kk[rs[c]] = ck[c];
-              if constexpr (WIDE) L.Ki[rs[c]] = ci[c];
-            }
+            for (int u = 0; u < NU; ++u)
+              if (l + 16 * u < stot && rs[u] < max_nn) {
+                L.Kk[rs[u]] = ok[u];
+                if constexpr (WIDE) L.Ki[rs[u]] = oi[u];
+              }
+          }
+        };
+        {
+          const bool any_kept = __ballot(cnt > 0 && stot > 0) != 0ull;
+          const bool n2 = __ballot(stot > 16) != 0ull, n3 = __ballot(stot > 32) != 0ull, n4 = __ballot(stot > 48) != 0ull;
+          using T1 = std::integral_constant<int, 1>;
+          using T2 = std::integral_constant<int, 2>;
+          using T3 = std::integral_constant<int, 3>;
+          using T4 = std::integral_constant<int, 4>;
+          if (any_kept) {
+            if (n4) merge(T4{}, std::true_type{});
+            else if (n3) merge(T3{}, std::true_type{});
+            else if (n2) merge(T2{}, std::true_type{});
+            else merge(T1{}, std::true_type{});
+          } else {
+            if (n4) merge(T4{}, std::false_type{});
+            else if (n3) merge(T3{}, std::false_type{});
+            else if (n2) merge(T2{}, std::false_type{});
+            else merge(T1{}, std::false_type{});
+          }
         }
         O3DS_WAVE_SYNC();
         cnt = min(cnt + stot, max_nn);
@@ -304,7 +445,6 @@ __global__ __launch_bounds__(64) void normals_kernel(const P4* __restrict__ pts 
             if (!nrm_less<WIDE>(L.Kk[idx], i0, L.Kk[idx + 1], i1)) O3DS_NRM_BAD(0);
           }
         }
-        if (T != __shfl(incl, (lane & 48) | 15)) O3DS_NRM_BAD(4);
 #endif
         if (cnt == max_nn) {  // list full: the bound becomes the max_nn-th key
           tau_k = L.Kk[max_nn - 1];
@@ -314,21 +454,6 @@ __global__ __launch_bounds__(64) void normals_kernel(const P4* __restrict__ pts 
           } else {
             tau_i = 0;
             worst = (double)__uint_as_float((unsigned int)(tau_k >> 32));
-          }
-        }
-      }
-      // ---- next round / next ring / done
-      if (active) {
-        tbase += 16;
-        if (tbase >= ntask) {
-          ring += 1;
-          tbase = 0;
-          ntask = (2 * ring + 1) * (2 * ring + 1);
-          if (ring > rmax_cells) {
-            active = false;
-          } else {
-            const double lb = g.cell * ((double)(ring - 1) + mf) * (1.0 - 1e-6);
-            if (worst <= lb * lb) active = false;  // the max_nn-th best (or r^2) already lies inside the searched block
           }
         }
       }
@@ -360,29 +485,52 @@ __global__ __launch_bounds__(64) void normals_kernel(const P4* __restrict__ pts 
     }
     O3DS_WAVE_SYNC();
     {
-      // lane t < 9 sums term t = {x y z xx xy xz yy yz zz}[t] as X[.][ia] * X[.][ib] (x = x * 1 exactly)
+      // lane t < 9 sums term t = {x y z xx xy xz yy yz zz}[t] as X[.][ia] * X[.][ib] (x = x * 1 exactly), one after the other in
+      // list order (the additions are a chain by definition; the operands of four steps are fetched together)
       const int ia = l < 3 ? l : (l < 6 ? 0 : (l < 8 ? 1 : 2));
       const int ib = l < 3 ? 3 : (l < 6 ? l - 3 : (l < 8 ? l - 5 : 2));
       double acc = 0.0;
-      if (l < 9) {
+      if (l < 9 && have) {
 #pragma clang fp contract(off)
-        for (int jj = 0; jj < cnt; ++jj) acc += (double)L.X[jj][ia] * (double)L.X[jj][ib];
-        s_sum[it * 4 + grp][l] = acc;
+        int jj = 0;
+        for (; jj + 4 <= cnt; jj += 4) {
+          const double a0 = (double)L.X[jj][ia], b0 = (double)L.X[jj][ib], a1 = (double)L.X[jj + 1][ia], b1 = (double)L.X[jj + 1][ib];
+          const double a2 = (double)L.X[jj + 2][ia], b2 = (double)L.X[jj + 2][ib], a3 = (double)L.X[jj + 3][ia], b3 = (double)L.X[jj + 3][ib];
+          acc += a0 * b0;
+          acc += a1 * b1;
+          acc += a2 * b2;
+          acc += a3 * b3;
+        }
+        for (; jj < cnt; ++jj) acc += (double)L.X[jj][ia] * (double)L.X[jj][ib];
+        out_sums[9 * j + l] = acc;
       }
-      if (l == 0) s_cnt[it * 4 + grp] = cnt;
+      if (l == 0 && have) out_cnt[j] = cnt;
     }
     O3DS_WAVE_SYNC();
   }
+#ifdef O3DS_NRM_CHECK
+  if (g_nrm_wave_stats && lane == 0) {
+    unsigned long long* o = g_nrm_wave_stats + 6 * ((size_t)blockIdx.x * 4 + wv);
+    o[0] = wall_clock64() - st_t0, o[1] = st_t0, o[2] = st_rounds, o[3] = st_ring, o[4] = st_chunks, o[5] = 0;
+  }
+#endif
+}
 
-  // ---- covariance, eigenvector of the smallest eigenvalue, normalise, orient: one lane per point
-  if (lane < PW && base + (size_t)lane < n) {
-    const P4 q = sp[base + (size_t)lane];
-    const int k = s_cnt[lane];
+// Covariance from the cumulants, eigenvector of the smallest eigenvalue, normalise, orient: ~1200 instructions of f64 per point that
+// need one lane each -- run as a kernel of their own, one thread per point, rather than on 4 of the 64 lanes of a search wavefront
+template <typename P4>
+__global__ __launch_bounds__(256) void normals_finish_kernel(const P4* __restrict__ sp /* sorted by cell */, size_t n, const double* __restrict__ sums,
+                                                             const int* __restrict__ cnts, P4* __restrict__ out_nrm) {
+  using R = typename Scalar<P4>::type;
+  const size_t pj = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (pj < n) {
+    const P4 q = sp[pj];
+    const int k = cnts[pj];
     double cov[6] = {1, 0, 0, 1, 0, 1};
     if (k >= 3) {
       double s[9];
 #pragma unroll
-      for (int t = 0; t < 9; ++t) s[t] = s_sum[lane][t];
+      for (int t = 0; t < 9; ++t) s[t] = sums[9 * pj + t];
       det::cov_from_cumulants(s, k, cov);
     }
     double nv[3];
