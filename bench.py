@@ -1,18 +1,23 @@
 #!/usr/bin/env python
-"""bench.py -- ICP iterations/s of the scan-to-map hot path on MI355X (BASELINE.json metric).
+"""bench.py -- BASELINE.json's metric on MI355X: ICP iterations/s (64k scan vs 1M-pt map) + scans/s, in ONE JSON line on rank 0.
 
-One STEP = one registerClouds-equivalent (CloudRegistration.cpp:44-48): point-to-plane ICP of a 65 536-pt
-VLP-16-like scan against a 1 000 000-pt submap with normals (BASELINE.json configs[1]), FIXED 10 iterations
-(relative_fitness = relative_rmse = 0 so the convergence test never fires), initial guess =
-identity, truth = (0.30,-0.20,0.05) m / rpy (0.5,-0.5,2.0) deg.  Clouds and the target index are resident in HBM
-before the timed region (index build reported separately as index_build_ms).
+M1 (`value`): one STEP = one registerClouds-equivalent (CloudRegistration.cpp:44-48): point-to-plane ICP of a 65 536-pt VLP-16-like
+scan against a 1 000 000-pt submap with normals (BASELINE.json configs[1]), FIXED 10 iterations (relative_fitness = relative_rmse =
+0 so the convergence test never fires), initial guess identity, truth (0.30,-0.20,0.05) m / rpy (0.5,-0.5,2.0) deg.
+Clouds and the target index are resident in HBM before the timed region (index build reported as index_build_ms).  Measured with
+f32 point storage (`value`) and with f64 storage (`m1_f64`), each with the roofline of the dominant kernel from hipEvent brackets
+around every launch.
 
-N GPUs (one process per GPU, launched by torch.distributed.run): rank r holds ITS OWN 1M-pt submap (seed 1235+r)
-and the whole scan; every ICP iteration is ONE fused kernel plus one 4-KB RCCL all-reduce of the exact hi/lo sums of
-the normal equations ("submap" partitioning, open3d_slam_amd/sharded.py).  Weak scaling: per-GPU work is fixed; value counts the
-scan-vs-submap iterations all ranks processed per second.
+M2 (`scans_per_sec`): BASELINE.json configs[2] -- the full per-scan stack, LidarOdometry::addRangeScan + Mapper::addRangeMeasurement
+(Mapper.cpp:101-181 -> ScanToMapRegistration.cpp:35-62 -> Submap.cpp:39-75) on a 200-frame OS-128-like stream (131 072 points per
+scan, float32 records as a lidar driver delivers them) through the reference-named host classes, the submap growing to ~1 M points;
+`cpu_baseline` beside it = the same loop on the CPU oracle for the first frames; `calls` = per-call table (hipEvent spans on the
+handle's stream) of algorithmic bytes (SURVEY.md 8d formulas) / time / 8 TB/s.
 
-Prints ONE JSON line on rank 0.
+N GPUs (one process per GPU, torch.distributed.run): rank r holds ITS OWN 1M-pt submap (seed 1235+r) and the whole scan; every ICP
+iteration is ONE fused kernel plus one 4-KB RCCL all-reduce of the exact hi/lo sums of the normal equations ("submap" partitioning,
+open3d_slam_amd/sharded.py).  Weak scaling: per-GPU work is fixed.  `value` = iterations/s of the JOINT registration (one registration
+over N submaps, not N registrations); the aggregate work is `point_queries_per_sec` (source points searched per second over all ranks).
 """
 from __future__ import annotations
 
@@ -32,12 +37,47 @@ N_SRC, N_MAP = 65536, 1_000_000
 MAX_CORR = 1.0
 ALGO_BYTES_PER_POINT = 228  # 12 src + 16*12 NN candidates + 12 matched point + 12 matched normal
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
+TAG_NORMALS, TAG_INSERT, TAG_VOXEL, TAG_ICP, TAG_UPLOAD = 1, 2, 3, 4, 5  # caller span tags; 8 / 9 are the library's own (normals kernels, index build)
 
 
-def cpu_baseline(src, tgt, nrm, budget_s=20.0):
+# ------------------------------------------------------------------------------------------------ synthetic inputs
+def _scan_job(k):
+    from open3d_slam_amd import synthetic as syn
+
+    scene = syn.make_scene()
+    poses = syn.figure_eight_poses(200, 0.1)
+    return syn.os128_scan(scene, poses[k], frame=k).astype(np.float32)
+
+
+def make_stream(frames):
+    """OS-128-like scans of the C3 trajectory, ray-cast on the host cores in parallel; called BEFORE any GPU runtime
+    is initialised in this process (fork)."""
+    import multiprocessing as mp
+
+    procs = max(1, min(32, (os.cpu_count() or 2) // 2, frames))
+    if procs == 1:
+        return [_scan_job(k) for k in range(frames)]
+    with mp.get_context("fork").Pool(procs) as pool:
+        return pool.map(_scan_job, range(frames), chunksize=max(1, frames // (4 * procs)))
+
+
+def stream_parameters(max_iter=50):
+    from open3d_slam_amd import parameters as P
+
+    mp = P.lua_default_mapper_parameters()
+    mp.scanMatcher_.icp_.maxNumIter_ = max_iter
+    op = P.OdometryParameters()
+    op.scanMatcher_.icp_ = P.IcpParameters(maxNumIter_=max_iter, maxCorrespondenceDistance_=1.0, knn_=20, maxDistanceKnn_=3.0)
+    op.scanProcessing_.voxelSize_ = 0.1
+    op.scanProcessing_.cropper_ = P.ScanCroppingParameters(croppingMinRadius_=2.0, croppingMaxRadius_=30.0, cropperName_="MinMaxRadius")
+    return mp, op
+
+
+# ------------------------------------------------------------------------------------------------ CPU baselines (oracle = checker)
+def cpu_baseline_m1(src, tgt, nrm, budget_s=16.0):
     """CPU restatement of Open3D v0.15.1 (the oracle, 'port'), timed on this box's host cores.  The thread count is the
-    best of a short sweep: on the 2x64-core EPYC host of the MI355X boxes the OpenMP loops peak at 32 threads (1.2 k it/s)
-    and collapse beyond the physical cores (3 it/s at 256), so 'all cores' would flatter the GPU."""
+    best of a short sweep: on the 2x64-core EPYC host of the MI355X boxes the OpenMP loops peak at 16-32 threads
+    and collapse beyond the physical cores, so 'all cores' would flatter the GPU."""
     from oracle import pyoracle as po
 
     ncpu = os.cpu_count() or 1
@@ -59,7 +99,6 @@ def cpu_baseline(src, tgt, nrm, budget_s=20.0):
                 break
         return reps, spent, res
 
-    # sustained (>= 1 s) rate per thread count: single repetitions are erratic beyond ~32 threads on this host
     cands = [t for t in (8, 16, 32, 64, 128) if t <= ncpu] or [ncpu]
     sweep, best_t, best_rate = {}, cands[0], 0.0
     for th in cands:
@@ -77,24 +116,204 @@ def cpu_baseline(src, tgt, nrm, budget_s=20.0):
                 sample=f"{reps} x (64k scan vs 1M map, {ICP_ITERS} iters, KD-tree prebuilt) = {spent:.1f}s at the best thread count of the sweep "
                        f"{sweep} it/s (host has {ncpu} hardware threads); KD-tree build {build_s*1e3:.0f} ms -> "
                        f"{ICP_ITERS/(per_reg+build_s):.2f} it/s when rebuilt per call as the reference does; "
-                       f"CPU restatement of Open3D v0.15.1, {best_t} OpenMP threads"), res
+                       f"CPU restatement of Open3D v0.15.1, {best_t} OpenMP threads"), res, best_t
+
+
+def cpu_baseline_m2(scans32, frames, threads):
+    """The same odometry + mapping loop on the CPU oracle (oracle/pipeline.py), first `frames` frames of the stream."""
+    from oracle import pyoracle as po
+    from oracle.pipeline import OracleLoop
+
+    mp, op = stream_parameters()
+    po.lib().orc_set_num_threads(threads)
+    ref = OracleLoop(po, mp, op)
+    cpu = {"odometry": 0.0, "mapping": 0.0}
+    for k in range(frames):
+        raw = scans32[k].astype(np.float64)
+        t0 = time.perf_counter()
+        ref.odometry(raw, 0.1 * k)
+        t1 = time.perf_counter()
+        ref.mapping(raw, 0.1 * k)
+        t2 = time.perf_counter()
+        if k > 0:
+            cpu["odometry"] += t1 - t0
+            cpu["mapping"] += t2 - t1
+    m = frames - 1
+    return dict(value=m / (cpu["odometry"] + cpu["mapping"]), unit="scans/s", cores=int(po.lib().orc_num_threads()), kind="port",
+                mapping_only_scans_per_sec=m / cpu["mapping"], ms_per_scan={k: 1e3 * v / m for k, v in cpu.items()},
+                map_points=int(len(ref.map_p)),
+                sample=f"frames 1..{frames - 1} of the same stream (the map holds {len(ref.map_p)} points at the end; the GPU leg runs all "
+                       f"frames, its map grows further and its later frames cost more), CPU restatement of Open3D v0.15.1, KD-tree of the "
+                       f"map patch rebuilt per registration as the reference does"), ref
+
+
+# ------------------------------------------------------------------------------------------------ M2: the config-2 stream
+def _wrap_spans(backend):
+    """hipEvent spans around the ABI calls a frame is made of, with the sizes the byte formulas need (restored by the caller)."""
+    B = backend.Backend
+    saved, sizes = {}, {"normals": [], "insert": [], "voxel": [], "icp": [], "upload": []}
+
+    def wrap(name, tag, note):
+        fn = getattr(B, name)
+        saved[name] = fn
+
+        def w(self, *a, **k):
+            pre = note(self, a, None)
+            with self.span(tag):
+                r = fn(self, *a, **k)
+            note(self, a, (pre, r))
+            return r
+
+        setattr(B, name, w)
+
+    def n_of(be, cid):
+        return be.size(cid)[0]
+
+    def note_normals(be, a, done):
+        if done is not None:
+            sizes["normals"].append((n_of(be, a[0]), a[2]))
+
+    def note_insert(be, a, done):
+        if done is None:
+            return (n_of(be, a[0]), n_of(be, a[1]))
+        sizes["insert"].append(done[0] + (n_of(be, a[0]),))
+
+    def note_voxel(be, a, done):
+        if done is None:
+            return n_of(be, a[0])
+        sizes["voxel"].append((done[0], n_of(be, done[1])))
+
+    def note_icp(be, a, done):
+        if done is not None:
+            sizes["icp"].append((n_of(be, a[0]), done[1]["iterations"]))
+
+    def note_upload(be, a, done):
+        if done is not None:
+            sizes["upload"].append(n_of(be, done[1]))
+
+    wrap("estimate_normals", TAG_NORMALS, note_normals)
+    wrap("map_insert_scan", TAG_INSERT, note_insert)
+    wrap("crop_voxel_down_sample", TAG_VOXEL, note_voxel)
+    wrap("icp_point_to_plane_dev", TAG_ICP, note_icp)
+    wrap("upload_f32", TAG_UPLOAD, note_upload)
+    return saved, sizes
+
+
+def run_stream(be, scans32, profile=False):
+    """frames through the reference-named host classes; returns rates, per-stage wall times and (profile) the per-call table"""
+    from open3d_slam_amd import backend, synthetic as syn
+    from open3d_slam_amd.mapper import Mapper
+    from open3d_slam_amd.odometry import LidarOdometry
+    from open3d_slam_amd.pointcloud import PointCloud
+
+    mp, op = stream_parameters()
+    odo = LidarOdometry(be)
+    odo.setParameters(op)
+    mapper = Mapper(be, odo)
+    mapper.setParameters(mp)
+    saved, sizes = ({}, None)
+    if profile:
+        saved, sizes = _wrap_spans(backend)
+        be.profile_enable(True)
+    stage = {"upload": 0.0, "odometry": 0.0, "mapping": 0.0}
+    frames = len(scans32)
+    try:
+        for k, raw in enumerate(scans32):
+            t0 = time.perf_counter()
+            cloud = PointCloud.from_pointcloud2(be, raw)
+            t1 = time.perf_counter()
+            ok1 = odo.addRangeScan(cloud, 0.1 * k)
+            be.synchronize()
+            t2 = time.perf_counter()
+            ok2 = mapper.addRangeMeasurement(cloud, 0.1 * k)
+            be.synchronize()
+            t3 = time.perf_counter()
+            cloud.release()
+            assert ok1 and ok2, (k, ok1, ok2)
+            if k > 0:  # frame 0 only initialises
+                stage["upload"] += t1 - t0
+                stage["odometry"] += t2 - t1
+                stage["mapping"] += t3 - t2
+    finally:
+        for name, fn in saved.items():
+            setattr(backend.Backend, name, fn)
+    n = frames - 1
+    poses = syn.figure_eight_poses(200, 0.1)
+    dt, dr = syn.se3_error(mapper.getMapToRangeSensor(), np.linalg.inv(poses[0]) @ poses[frames - 1])
+    out = {"scans_per_sec": n / (stage["odometry"] + stage["mapping"] + stage["upload"]),
+           "mapping_only_scans_per_sec": n / stage["mapping"], "ms_per_scan": {k: 1e3 * v / n for k, v in stage.items()},
+           "frames": frames, "map_points": len(mapper.getActiveSubmap().getMapPointCloud()),
+           "final_pose_error_vs_truth": {"dt_m": dt, "dr_rad": dr}, "pose": mapper.getMapToRangeSensor().copy()}
+    if profile:
+        def row(tag, nbytes, what):
+            cnt, ms = be.span_read(tag)
+            if cnt == 0:
+                return None
+            gbs = nbytes / (ms * 1e-3) / 1e9
+            return {"calls": cnt, "avg_us": 1e3 * ms / cnt, "algorithmic_bytes_per_call": nbytes / cnt, "achieved_gbs": gbs,
+                    "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "bytes": what}
+
+        knn = 20
+        n_nrm = sum(m for m, _ in sizes["normals"])
+        calls = {
+            "estimate_normals (index build + search kernel + eigen kernel)": row(TAG_NORMALS, n_nrm * (12 + knn * 12 + 12), "m x (12 + knn x 12) read + m x 12 written"),
+            "normals kernels alone": row(8, n_nrm * (12 + knn * 12 + 12), "same bytes, the two kernels only"),
+            "map_insert_scan (transform + append + voxelizeWithinCroppingVolume + index rebuild)": row(
+                TAG_INSERT, sum((N + m) * 24 + N2 * 24 + N2 * 56 for N, m, N2 in sizes["insert"]), "(N + m) x 24 read + N' x 24 written + index build N' x 56"),
+            "crop + VoxelDownSample": row(TAG_VOXEL, sum(nr * (12 + 16) + m * 12 for nr, m in sizes["voxel"]), "n_raw x 12 read + keys n_raw x 16 + m x 12 written"),
+            "registerClouds (device clouds, index kept by the submap)": row(TAG_ICP, sum(n_ * ALGO_BYTES_PER_POINT * (it + 1) for n_, it in sizes["icp"]),
+                                                                             "n x 228 per correspondence pass, iterations + 1 passes"),
+            "PointCloud2 float32 ingest": row(TAG_UPLOAD, sum(n_ * 16 * 2 for n_ in sizes["upload"]), "n x 16 read + n x 16 written (PCIe copy inside the span)"),
+            "index build kernels (every build of the stream)": row(9, 0, "see map_insert_scan / estimate_normals"),
+        }
+        icp_launches, icp_ms = be.profile_read()
+        if icp_launches:
+            calls["icp_fused_kernel launches of the stream"] = {"calls": icp_launches, "avg_us": 1e3 * icp_ms / icp_launches}
+        be.profile_enable(False)
+        out["calls"] = {k: v for k, v in calls.items() if v}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ M1
+def run_m1(be, world, s_id, t_id, steps, warmup, barrier, drv):
+    if drv is not None:
+        def step():
+            return drv.register(s_id, t_id, N_SRC, MAX_CORR, max_iter=ICP_ITERS, rel_fitness=0.0, rel_rmse=0.0, check_every=ICP_ITERS + 2)
+    else:
+        def step():
+            return be.icp_point_to_plane_dev(s_id, t_id, MAX_CORR, max_iter=ICP_ITERS, rel_fitness=0.0, rel_rmse=0.0)
+    res = None
+    for _ in range(warmup):
+        res = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    assert res["iterations"] == ICP_ITERS
+    # roofline of the dominant kernel (icp_fused_kernel: one ICP pass + the previous pass's solve/update in its prologue): the same
+    # steps re-run with hipEvent brackets around every launch on the launch stream (outside the timed region above)
+    be.profile_enable(True)
+    for _ in range(min(steps, 100)):
+        step()
+    n_launch, kern_ms = be.profile_read()
+    be.profile_enable(False)
+    return res, elapsed, n_launch, kern_ms
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--precision", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--cell", type=float, default=0.0, help="NN grid cell size (0 = max_corr/4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=16.0)
+    ap.add_argument("--m2-frames", type=int, default=200, help="frames of the configs[2] stream (0: skip M2)")
+    ap.add_argument("--m2-cpu-frames", type=int, default=40)
+    ap.add_argument("--no-f64", action="store_true")
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-
-    from open3d_slam_amd import backend, sharded, synthetic as syn
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -104,6 +323,14 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                              "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         args.gpus = world
+    do_m2 = world == 1 and args.m2_frames > 1
+    scans32 = make_stream(args.m2_frames) if do_m2 else None  # before the GPU runtime exists in this process (fork)
+
+    import torch
+    import torch.distributed as dist
+
+    from open3d_slam_amd import backend, sharded, synthetic as syn
+
     # one rank per GPU; O3DS_BENCH_BACKEND=gloo lets the N>1 path be smoke-tested on a box with fewer GPUs than ranks
     dist_backend = os.environ.get("O3DS_BENCH_BACKEND", "nccl")
     if dist_backend != "nccl":
@@ -116,79 +343,42 @@ def main():
         else:
             dist.init_process_group(dist_backend, rank=rank, world_size=world)
 
-    # ---- synthetic workload (seeded)
-    scene = syn.make_scene()
-    T_gt = syn.ground_truth_pose()
-    src = syn.vlp16_scan(scene, T_gt)
-    tgt, nrm = syn.sample_map(scene, N_MAP, seed=syn.SEED_MAP + rank)
-    assert len(src) == N_SRC
-
-    prec = backend.PRECISION_F64 if args.precision == "f64" else backend.PRECISION_F32
-    be = backend.Backend(local_rank, prec)
-    s_id = be.upload(src)
-    t_id = be.upload(tgt, nrm)
-    t0 = time.perf_counter()
-    be.build_index(t_id, MAX_CORR, args.cell)
-    be.synchronize()
-    index_build_ms = (time.perf_counter() - t0) * 1e3
-
-    if world > 1:
-        drv = sharded.ShardedIcp(be, mode="submap")
-
-        def step():
-            return drv.register(s_id, t_id, N_SRC, MAX_CORR, max_iter=ICP_ITERS, rel_fitness=0.0, rel_rmse=0.0,
-                                check_every=ICP_ITERS + 2)
-    else:
-        def step():
-            return be.icp_point_to_plane_dev(s_id, t_id, MAX_CORR, max_iter=ICP_ITERS, rel_fitness=0.0, rel_rmse=0.0)
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    res = None
-    for _ in range(args.warmup):
-        res = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    assert res["iterations"] == ICP_ITERS
-
-    # ---- roofline of the dominant kernel (icp_fused_kernel: one ICP pass + the previous pass's solve/update in its prologue;
-    # icp_accumulate_kernel when O3DS_ICP_MODE=launch or on the sharded step-wise path): same K steps re-run with hipEvent brackets around
-    # every launch on the launch stream (kept out of the timed region above so the brackets do not perturb `value`)
-    be.profile_enable(True)
-    for _ in range(args.steps):
-        step()
-    n_launch, kern_ms = be.profile_read()
-    be.profile_enable(False)
-    avg_kernel_s = kern_ms * 1e-3 / max(n_launch, 1)
+    # ---- M1 workload (seeded)
+    scene = syn.make_scene()
+    T_gt = syn.ground_truth_pose()
+    src = syn.vlp16_scan(scene, T_gt)
+    tgt, nrm = syn.sample_map(scene, N_MAP, seed=syn.SEED_MAP + rank)
+    assert len(src) == N_SRC
     algo_bytes = N_SRC * ALGO_BYTES_PER_POINT
-    achieved_gbs = algo_bytes / avg_kernel_s / 1e9
 
-    # HBM traffic of the same kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes of this
-    # command, corrected as MI355X_MICROARCH.md prescribes); collected by scripts/gpu_round.sh, committed under profiles/
-    classic = (world > 1 and os.environ.get("O3DS_SHARDED_FORM") == "classic") or (world == 1 and os.environ.get("O3DS_ICP_MODE") == "launch")
-    pass_kernel = "icp_accumulate_kernel" if classic else "icp_fused_kernel"
-    traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))[pass_kernel]
-            traffic, traffic_src = tj["hbm_bytes_per_launch_corrected"], "profiles/pmc_traffic_latest.json (rocprofv3 --pmc, separate passes)"
-        except Exception:
-            pass
+    def m1(prec, steps, warmup):
+        be = backend.Backend(local_rank, prec)
+        s_id = be.upload(src)
+        t_id = be.upload(tgt, nrm)
+        t0 = time.perf_counter()
+        be.build_index(t_id, MAX_CORR, args.cell)
+        be.synchronize()
+        index_build_ms = (time.perf_counter() - t0) * 1e3
+        drv = sharded.ShardedIcp(be, mode="submap") if world > 1 else None
+        res, elapsed, n_launch, kern_ms = run_m1(be, world, s_id, t_id, steps, warmup, barrier, drv)
+        if world > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        be.close()
+        avg_kernel_s = kern_ms * 1e-3 / max(n_launch, 1)
+        gbs = algo_bytes / avg_kernel_s / 1e9
+        return dict(res=res, elapsed=elapsed, index_build_ms=index_build_ms, n_launch=n_launch, avg_kernel_s=avg_kernel_s, gbs=gbs)
 
-    # measured device copy bandwidth on this box (report against the vendor peak AND a measured copy kernel):
-    # 1 GiB device-to-device copy, read + write counted, hipEvent-timed, after the timed region
+    r32 = m1(backend.PRECISION_F32, args.steps, args.warmup)
+    r64 = None if args.no_f64 else m1(backend.PRECISION_F64, max(args.steps // 2, 1), args.warmup)
+
+    # measured device copy bandwidth on this box (report against the vendor peak AND a measured copy kernel)
     copy_gbs = None
     if rank == 0:
         nb = 1 << 30
@@ -203,43 +393,84 @@ def main():
         copy_gbs = 5 * 2 * nb / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del a_, b_
 
+    # ---- M2: the configs[2] stream, once untouched for the rates and once with event spans for the per-call table
+    m2 = None
+    if do_m2:
+        be2 = backend.Backend(local_rank)
+        run_stream(be2, scans32[: min(12, len(scans32))])  # warm the allocator and the code paths
+        be2.close()
+        be2 = backend.Backend(local_rank)
+        m2 = run_stream(be2, scans32)
+        be2.close()
+        be2 = backend.Backend(local_rank)
+        prof = run_stream(be2, scans32, profile=True)
+        be2.close()
+        m2["calls"] = prof["calls"]
+        m2["pose_repeats_bitwise_between_the_two_runs"] = bool(np.array_equal(m2["pose"], prof["pose"]))
+        del m2["pose"]
+
     if rank == 0:
+        res, elapsed = r32["res"], r32["elapsed"]
+        classic = (world > 1 and os.environ.get("O3DS_SHARDED_FORM") == "classic") or (world == 1 and os.environ.get("O3DS_ICP_MODE") == "launch")
+        pass_kernel = "icp_accumulate_kernel" if classic else "icp_fused_kernel"
         dt_gt, dr_gt = syn.se3_error(res["transformation"], T_gt)
+
+        def roof(r):
+            return {"bound": "hbm", "achieved": r["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["gbs"] / HBM_PEAK_GBS,
+                    "traffic": None,  # FETCH_SIZE is calibrated for coalesced streaming reads only; this kernel gathers 16-B records from a
+                                      # working set inside the 256 MiB Infinity Cache -- no calibrated HBM byte count exists for it
+                    "kernel": pass_kernel, "launches": r["n_launch"], "avg_launch_us": r["avg_kernel_s"] * 1e6,
+                    "algorithmic_bytes_per_launch": algo_bytes, "measured_copy_gbs": copy_gbs,
+                    "frac_of_measured_copy": r["gbs"] / copy_gbs if copy_gbs else None}
+
+        steps = args.steps
         out = {
             "metric": "icp_iterations_per_sec",
-            "value": world * ICP_ITERS * args.steps / elapsed,
+            "value": ICP_ITERS * steps / elapsed,
             "unit": "icp_iterations/s",
             "n_gpus": world,
-            "steps": args.steps,
+            "steps": steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 points, f64 accumulate" if prec == backend.PRECISION_F32 else "f64",
+            "dtype": "f32 points, f64 accumulate",
             "data": "synthetic",
             "config": {"workload": "configs[1]: point-to-plane ICP, 65536-pt VLP-16 scan vs 1,000,000-pt submap, "
                                    f"max_corr {MAX_CORR} m, {ICP_ITERS} fixed iterations/step (+1 evaluation pass), index prebuilt",
                        "n_src": N_SRC, "n_map_per_gpu": N_MAP, "icp_iterations_per_step": ICP_ITERS,
-                       "parallelism": "1 GPU" if world == 1 else f"{world} submaps x 1 GPU, one fused kernel + one 4-KB RCCL all-reduce / iteration",
+                       "parallelism": "1 GPU" if world == 1 else f"ONE joint registration over {world} submaps x 1 GPU: one fused kernel + one 4-KB RCCL "
+                                                                  "all-reduce per iteration (value counts the joint iterations once)",
                        "nn_cell_m": args.cell if args.cell > 0 else MAX_CORR / 4},
-            "index_build_ms": index_build_ms,
-            "scans_per_sec_icp_only": world * args.steps / elapsed,
+            "index_build_ms": r32["index_build_ms"],
+            "point_queries_per_sec": world * N_SRC * (ICP_ITERS + 1) * steps / elapsed,
+            "registrations_per_sec": steps / elapsed,
             "pose_error_vs_truth": {"dt_m": dt_gt, "dr_rad": dr_gt, "fitness": res["fitness"], "inlier_rmse": res["inlier_rmse"]},
-            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                         "kernel": pass_kernel, "launches": n_launch, "avg_launch_us": avg_kernel_s * 1e6,
-                         "algorithmic_bytes_per_launch": algo_bytes,
-                         "measured_copy_gbs": copy_gbs, "frac_of_measured_copy": achieved_gbs / copy_gbs if copy_gbs else None},
+            "roofline": roof(r32),
         }
+        if r64 is not None:
+            s64 = max(args.steps // 2, 1)
+            d64 = syn.se3_error(r64["res"]["transformation"], res["transformation"])
+            out["m1_f64"] = {"value": ICP_ITERS * s64 / r64["elapsed"], "unit": "icp_iterations/s", "steps": s64, "ms_per_step": r64["elapsed"] / s64 * 1e3,
+                             "dtype": "f64", "index_build_ms": r64["index_build_ms"], "roofline": roof(r64),
+                             "pose_vs_f32_storage": {"dt_m": d64[0], "dr_rad": d64[1]}}
+        if m2 is not None:
+            out["scans_per_sec"] = {"workload": f"configs[2]: OS-128-like stream, {len(scans32[0])} raw float32 points/scan, {args.m2_frames} frames, "
+                                                "LidarOdometry::addRangeScan + Mapper::addRangeMeasurement through the host classes (voxel 0.1, knn 20 / r 3, "
+                                                "default ICP criteria, map voxel 0.1); upload included", **m2}
+        cres, best_t = None, min(32, os.cpu_count() or 1)
         if world == 1 and not args.no_cpu_baseline:
-            cb, cres = cpu_baseline(src, tgt, nrm, args.cpu_budget)
+            cb, cres, best_t = cpu_baseline_m1(src, tgt, nrm, args.cpu_budget)
             out["cpu_baseline"] = cb
             dt, dr = syn.se3_error(res["transformation"], cres["transformation"])
             out["parity_vs_cpu"] = {"dt_m": dt, "dr_rad": dr, "fitness_gpu": res["fitness"], "fitness_cpu": cres["fitness"]}
             out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
+            if m2 is not None and args.m2_cpu_frames > 1:
+                cb2, _ = cpu_baseline_m2(scans32, min(args.m2_cpu_frames, len(scans32)), min(32, os.cpu_count() or 1))
+                out["scans_per_sec"]["cpu_baseline"] = cb2
+                out["scans_per_sec"]["speedup_vs_cpu_baseline"] = out["scans_per_sec"]["scans_per_sec"] / cb2["value"]
         print(json.dumps(out), flush=True)
-    be.close()
     if world > 1:
         dist.destroy_process_group()
 

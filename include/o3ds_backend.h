@@ -102,6 +102,12 @@ int o3ds_set_stream(o3ds_handle h, void* hip_stream);
  * returns the number of bracketed launches and their summed duration (ms), and resets the counters. */
 int o3ds_profile_enable(o3ds_handle h, int on);
 int o3ds_profile_read(o3ds_handle h, uint64_t* n_launches, double* total_ms);
+/* Tagged spans for bench.py's per-call table: while profiling is enabled, o3ds_profile_span(h, tag, 0) / (h, tag, 1) record a pair
+ * of hipEvents on the handle's stream around whatever the caller enqueues in between (tags 0..7).  Tags 8 (the two kernels of
+ * normal estimation) and 9 (the kernels of an index build) are marked inside the library.  span_read synchronises, returns the
+ * number of complete spans of a tag and their summed duration (ms) and resets that tag. */
+int o3ds_profile_span(o3ds_handle h, int tag, int end);
+int o3ds_profile_span_read(o3ds_handle h, int tag, uint64_t* n_spans, double* total_ms);
 /* library / kernel identification string (arch, build flags) */
 const char* o3ds_version(void);
 

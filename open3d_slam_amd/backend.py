@@ -59,6 +59,8 @@ SIGNATURES = {
     "o3ds_set_stream": (C.c_int, [_H, C.c_void_p]),
     "o3ds_profile_enable": (C.c_int, [_H, C.c_int]),
     "o3ds_profile_read": (C.c_int, [_H, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
+    "o3ds_profile_span": (C.c_int, [_H, C.c_int, C.c_int]),
+    "o3ds_profile_span_read": (C.c_int, [_H, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     "o3ds_cloud_upload": (C.c_int, [_H, _dp, _dp, C.c_size_t, C.POINTER(_CL)]),
     "o3ds_cloud_upload_f32": (C.c_int, [_H, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(_CL)]),
     "o3ds_cloud_free": (C.c_int, [_H, _CL]),
@@ -416,6 +418,25 @@ class Backend:
     def profile_read(self):
         n, ms = C.c_uint64(), C.c_double()
         self._ck(self.lib.o3ds_profile_read(self.h, C.byref(n), C.byref(ms)))
+        return int(n.value), float(ms.value)
+
+    def span(self, tag: int):
+        """context manager: a tagged pair of hipEvents on the handle's stream around the calls inside (profiling enabled)"""
+        be = self
+
+        class _Span:
+            def __enter__(self_inner):
+                be._ck(be.lib.o3ds_profile_span(be.h, tag, 0))
+
+            def __exit__(self_inner, *exc):
+                be._ck(be.lib.o3ds_profile_span(be.h, tag, 1))
+                return False
+
+        return _Span()
+
+    def span_read(self, tag: int):
+        n, ms = C.c_uint64(), C.c_double()
+        self._ck(self.lib.o3ds_profile_span_read(self.h, tag, C.byref(n), C.byref(ms)))
         return int(n.value), float(ms.value)
 
     @property

@@ -157,6 +157,10 @@ struct o3ds_context {
   bool profiling = false;
   std::vector<hipEvent_t> ev;
   size_t ev_used = 0;
+  // ... and tagged spans (o3ds_profile_span): pairs of events around whatever the caller -- or, for the internal tags, a kernel
+  // sequence inside a call -- encloses
+  std::vector<hipEvent_t> span_ev[16];
+  size_t span_used[16] = {0};
 };
 
 namespace {
@@ -380,6 +384,19 @@ inline void dbg_sync(o3ds_handle h, int bit) {
   static const int mask = getenv("O3DS_SYNC_MASK") ? atoi(getenv("O3DS_SYNC_MASK")) : 0;
   if (mask & bit) (void)hipStreamSynchronize(h->stream);
 }
+// tagged span marks on the handle's stream (only while profiling is enabled): begin and end alternate per tag
+void span_mark(o3ds_handle h, int tag) {
+  if (!h->profiling || tag < 0 || tag >= 16) return;
+  auto& v = h->span_ev[tag];
+  if (h->span_used[tag] >= v.size()) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    v.push_back(e);
+  }
+  (void)hipEventRecord(v[h->span_used[tag]++], h->stream);
+}
+constexpr int kSpanNormalsKernels = 8, kSpanIndexBuild = 9;  // internal tags
+
 #define TMP_ALLOC(ptr, bytes)                                   \
   do {                                                          \
     int _rc = arena_alloc(h, (void**)&(ptr), (size_t)(bytes));  \
@@ -505,11 +522,13 @@ int build_grid_t(o3ds_handle h, const P4* pts, const P4* nrm, size_t n, double c
   HIP_TRY(dev_alloc(h, (void**)&cell_start, sizeof(int) * (ncell + 1 + 4)));  // +4: the search reads rows as unaligned 16-B vectors
   HIP_TRY(dev_alloc(h, (void**)&spts, sizeof(P4) * n));
   if (nrm) HIP_TRY(dev_alloc(h, (void**)&snrm, sizeof(P4) * n));
+  span_mark(h, kSpanIndexBuild);
   HIP_TRY(hipMemsetAsync(counts, 0, sizeof(int) * (2 * ncell + 1), h->stream));
   cell_count_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(pts, n, g, counts, cell_id);
   rc = exclusive_scan_int(h, counts, cell_start, ncell + 1);
   if (rc) return rc;
   scatter_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(pts, nrm, n, cell_id, cell_start, cursor, (P4*)spts, (P4*)snrm);
+  span_mark(h, kSpanIndexBuild);
   HIP_TRY(hipGetLastError());
   dbg_sync(h, 2);
   g.cell_start = cell_start;
@@ -1014,6 +1033,8 @@ int o3ds_destroy(o3ds_handle h) {
     if (h->stage_ev[k]) (void)hipEventDestroy(h->stage_ev[k]);
   }
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+  for (auto& v : h->span_ev)
+    for (hipEvent_t e : v) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return O3DS_OK;
@@ -1046,6 +1067,32 @@ int o3ds_profile_enable(o3ds_handle h, int on) {
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->profiling = on != 0;
   h->ev_used = 0;
+  for (auto& u : h->span_used) u = 0;
+  return O3DS_OK;
+}
+
+int o3ds_profile_span(o3ds_handle h, int tag, int end) {
+  CHECK_HANDLE(h);
+  if (tag < 0 || tag >= 8) return fail(h, O3DS_ERR_INVALID_ARG, "profile_span: caller tags are 0..7");
+  if ((int)(h->span_used[tag] & 1) != (end ? 1 : 0)) return fail(h, O3DS_ERR_INVALID_ARG, "profile_span: begin / end out of order");
+  span_mark(h, tag);
+  return O3DS_OK;
+}
+
+int o3ds_profile_span_read(o3ds_handle h, int tag, uint64_t* n_spans, double* total_ms) {
+  CHECK_HANDLE(h);
+  if (tag < 0 || tag >= 16) return fail(h, O3DS_ERR_INVALID_ARG, "profile_span_read: bad tag");
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  double tot = 0.0;
+  const size_t used = h->span_used[tag] & ~(size_t)1;
+  for (size_t i = 0; i + 1 < used; i += 2) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, h->span_ev[tag][i], h->span_ev[tag][i + 1]));
+    tot += (double)ms;
+  }
+  if (n_spans) *n_spans = used / 2;
+  if (total_ms) *total_ms = tot;
+  h->span_used[tag] = 0;
   return O3DS_OK;
 }
 
@@ -1878,11 +1925,13 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn) {
     int* d_cnts = nullptr;
     TMP_ALLOC(d_sums, sizeof(double) * 9 * c.n);
     TMP_ALLOC(d_cnts, sizeof(int) * c.n);
+    span_mark(h, kSpanNormalsKernels);
     if (max_nn <= 32)  // the shipped configs' knn is 20
       normals_kernel<P4, 32><<<gsz, 256, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, d_sums, d_cnts);
     else
       normals_kernel<P4, 128><<<gsz, 256, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, d_sums, d_cnts);
     normals_finish_kernel<P4><<<(unsigned int)((c.n + 255) / 256), 256, 0, h->stream>>>(p_sp, c.n, d_sums, d_cnts, p_out);
+    span_mark(h, kSpanNormalsKernels);
   }
   HIP_TRY(hipGetLastError());
   dbg_sync(h, 16);

@@ -1,0 +1,62 @@
+"""TEST INFRASTRUCTURE (checker, never shipped or measured as the product): the orchestration of one lidar frame -- odometry
+(Odometry.cpp:25-79) and mapping (Mapper.cpp:101-181, ScanToMapRegistration.cpp:35-62, Submap.cpp:39-75) -- played on the CPU oracle.
+Used by tests/test_pipeline_gpu.py as the reference loop and by bench.py as the cpu_baseline leg of the scans/s metric."""
+import numpy as np
+
+
+class OracleLoop:
+    """The same orchestration (Odometry.cpp:25-79, Mapper.cpp:101-181, ScanToMapRegistration.cpp:35-62, Submap.cpp:39-75) on
+    the CPU oracle."""
+
+    def __init__(self, oracle, mp, op):
+        self.o, self.mp, self.op = oracle, mp, op
+        self.map_p = np.zeros((0, 3))
+        self.map_n = np.zeros((0, 3))
+        self.T = np.eye(4)
+        self.Tprev = np.eye(4)
+        self.odom = np.eye(4)
+        self.odom_at = {}
+        self.prev = None
+        self.last_t = None
+
+    def _pre(self, raw, crop_p, voxel, icp):
+        o = self.o
+        keep = o.crop_indices(raw, o.make_crop(o.CROP_MIN_MAX_RADIUS, rmin=crop_p.croppingMinRadius_, rmax=crop_p.croppingMaxRadius_))
+        v = o.voxel_down_sample(raw[keep], voxel)
+        return v, o.estimate_normals(v, icp.maxDistanceKnn_, icp.knn_)
+
+    def odometry(self, raw, t):
+        icp = self.op.scanMatcher_.icp_
+        v, n = self._pre(raw, self.op.scanProcessing_.cropper_, self.op.scanProcessing_.voxelSize_, icp)
+        if self.prev is not None:
+            r = self.o.icp_point_to_plane(self.prev, v, n, icp.maxCorrespondenceDistance_, max_iter=icp.maxNumIter_)
+            assert r["fitness"] > 0.1
+            self.odom = self.odom @ np.linalg.inv(r["transformation"])
+        self.prev = v
+        self.odom_at[t] = self.odom.copy()
+
+    def mapping(self, raw, t):
+        o, mp = self.o, self.mp
+        icp = mp.scanMatcher_.icp_
+        v, n = self._pre(raw, mp.mapBuilder_.cropper_, mp.scanProcessing_.voxelSize_, icp)
+        sc = mp.scanProcessing_.cropper_
+        keep = o.crop_indices(v, o.make_crop(o.CROP_MIN_MAX_RADIUS, rmin=sc.croppingMinRadius_, rmax=sc.croppingMaxRadius_))
+        match = v[keep]
+        if len(self.map_p) == 0:
+            T_ins = np.eye(4)
+        else:
+            est = self.Tprev @ (np.linalg.inv(self.odom_at[self.last_t]) @ self.odom_at[t])
+            patch = o.crop_indices(self.map_p, o.make_crop(o.CROP_MIN_MAX_RADIUS, center=self.T[:3, 3], rmin=sc.croppingMinRadius_,
+                                                            rmax=sc.croppingMaxRadius_))
+            r = o.icp_point_to_plane(match, self.map_p[patch], self.map_n[patch], icp.maxCorrespondenceDistance_, init=est,
+                                     max_iter=icp.maxNumIter_)
+            assert r["fitness"] >= mp.scanMatcher_.minRefinementFitness_
+            self.T = r["transformation"]
+            T_ins = self.T
+        tp, tn = o.transform_points(v, T_ins), o.transform_normals(n, T_ins)
+        mc = mp.mapBuilder_.cropper_
+        crop = o.make_crop(o.CROP_MIN_MAX_RADIUS, center=T_ins[:3, 3], rmin=mc.croppingMinRadius_, rmax=mc.croppingMaxRadius_)
+        self.map_p, self.map_n, _ = o.voxelize_within_volume(np.vstack([self.map_p, tp]), np.vstack([self.map_n, tn]),
+                                                             mp.mapBuilder_.mapVoxelSize_, crop)
+        self.last_t = t
+        self.Tprev = self.T.copy()
