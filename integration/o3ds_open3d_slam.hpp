@@ -1,0 +1,308 @@
+// o3ds_open3d_slam.hpp -- what integration/open3d_slam_o3ds.patch makes open3d_slam's own sources call.
+//
+// The patch keeps every class, header and signature of open3d_slam and replaces only the BODIES on the scan-matching / map-fusion
+// path (CloudRegistration.cpp, ScanToMapRegistration.cpp, Submap.cpp) with calls into libo3ds_backend.so (include/o3ds_backend.h,
+// a C ABI).  This header is the thin C++ between the two: it speaks open3d::geometry::PointCloud / Eigen::Isometry3d on one side
+// and plain pointers on the other, and defines nothing in namespace o3d_slam (no clash with the reference's declarations).
+//   Seam 1  CloudRegistration::registerClouds / estimateNormalsOrCovariancesIfNeeded  -> o3ds::registerClouds, o3ds::estimateNormals
+//   Seam 2  ScanToMapIcp::scanToMapRegistration                                       -> o3ds::DeviceSubmap::registerScan
+//   Seam 3  Submap::insertScan / carve / transform / copy                             -> o3ds::DeviceSubmap
+// Threads: a backend handle is one HIP stream plus scratch and is not re-entrant.  The stateless calls use one handle per calling
+// thread; a DeviceSubmap owns a handle and a mutex (the reference guards mapCloud_ with mapPointCloudMutex_ in the same places).
+#pragma once
+#include <cstdint>
+#include <cstdlib>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+
+#include <open3d/geometry/PointCloud.h>
+#include <open3d/pipelines/registration/Registration.h>
+#include <Eigen/Dense>
+
+#include "o3ds_backend.h"
+#include "open3d_slam/Parameters.hpp"
+
+namespace o3ds {
+
+using PointCloud = open3d::geometry::PointCloud;
+using RegistrationResult = open3d::pipelines::registration::RegistrationResult;
+using ICPConvergenceCriteria = open3d::pipelines::registration::ICPConvergenceCriteria;
+
+inline void check(o3ds_handle h, int rc) {
+  if (rc != O3DS_OK) throw std::runtime_error(std::string("o3ds backend: ") + o3ds_last_error(h));
+}
+
+// one backend handle, destroyed with its owner
+class OwnedHandle {
+ public:
+  OwnedHandle() = default;
+  OwnedHandle(const OwnedHandle&) = delete;
+  OwnedHandle& operator=(const OwnedHandle&) = delete;
+  ~OwnedHandle() {
+    if (h_) o3ds_destroy(h_);
+  }
+  o3ds_handle get() const {  // created on first use, so constructing the owner needs no device
+    if (!h_) {
+      int device = 0;
+      if (const char* e = std::getenv("O3DS_DEVICE")) device = std::atoi(e);
+      check(nullptr, o3ds_create(device, &h_));
+    }
+    return h_;
+  }
+
+ private:
+  mutable o3ds_handle h_ = nullptr;
+};
+inline o3ds_handle threadHandle() {  // the stateless calls: one handle per calling thread (odometry, mapping, loop-closure workers)
+  static thread_local OwnedHandle h;
+  return h.get();
+}
+
+// CroppingVolume in the ABI's form.  croppingVolumeFactory (croppers.cpp:23-47) picks which parameters a named volume uses; only the
+// translation of the pose enters the predicates (croppers.cpp:121-165).
+inline o3ds_crop makeCrop(const o3d_slam::ScanCroppingParameters& p, const Eigen::Isometry3d& pose) {
+  o3ds_crop c{};
+  if (p.cropperName_ == "MaxRadius")
+    c.kind = O3DS_CROP_MAX_RADIUS;
+  else if (p.cropperName_ == "MinRadius")
+    c.kind = O3DS_CROP_MIN_RADIUS;
+  else if (p.cropperName_ == "MinMaxRadius")
+    c.kind = O3DS_CROP_MIN_MAX_RADIUS;
+  else if (p.cropperName_ == "Cylinder")
+    c.kind = O3DS_CROP_CYLINDER;
+  else
+    throw std::runtime_error("Unknown cropper type");  // croppers.cpp:45
+  c.invert = 0;
+  for (int a = 0; a < 3; ++a) c.center[a] = pose.translation()(a);
+  c.rmin = p.croppingMinRadius_;
+  c.rmax = p.croppingMaxRadius_;
+  c.zmin = p.croppingMinZ_;
+  c.zmax = p.croppingMaxZ_;
+  return c;
+}
+
+// a PointCloud on the device for the duration of a call
+class DeviceCloud {
+ public:
+  DeviceCloud(o3ds_handle h, const PointCloud& c) : h_(h) {
+    const double* nrm = c.HasNormals() ? reinterpret_cast<const double*>(c.normals_.data()) : nullptr;
+    check(h_, o3ds_cloud_upload(h_, reinterpret_cast<const double*>(c.points_.data()), nrm, c.points_.size(), &id_));
+  }
+  DeviceCloud(const DeviceCloud&) = delete;
+  DeviceCloud& operator=(const DeviceCloud&) = delete;
+  ~DeviceCloud() {
+    if (id_) o3ds_cloud_free(h_, id_);
+  }
+  o3ds_cloud id() const { return id_; }
+
+ private:
+  o3ds_handle h_;
+  o3ds_cloud id_ = 0;
+};
+
+inline void downloadCloud(o3ds_handle h, o3ds_cloud id, PointCloud* out) {
+  size_t n = 0;
+  int hasNormals = 0;
+  check(h, o3ds_cloud_size(h, id, &n, &hasNormals));
+  out->points_.resize(n);
+  out->normals_.resize(hasNormals ? n : 0);
+  out->colors_.clear();
+  out->covariances_.clear();
+  if (n == 0) return;
+  check(h, o3ds_cloud_download(h, id, reinterpret_cast<double*>(out->points_.data()),
+                               hasNormals ? reinterpret_cast<double*>(out->normals_.data()) : nullptr, n));
+}
+
+inline RegistrationResult toResult(const o3ds_icp_result& r) {
+  RegistrationResult out(Eigen::Map<const Eigen::Matrix4d>(r.transformation));
+  out.fitness_ = r.fitness;
+  out.inlier_rmse_ = r.inlier_rmse;
+  return out;  // correspondence_set_ is never read for ICP results in open3d_slam and is not materialised
+}
+inline o3ds_icp_params icpParams(int method, double maxCorrespondenceDistance, const ICPConvergenceCriteria& c) {
+  o3ds_icp_params p{};
+  p.max_correspondence_distance = maxCorrespondenceDistance;
+  p.max_iteration = c.max_iteration_;
+  p.method = method;
+  p.relative_fitness = c.relative_fitness_;
+  p.relative_rmse = c.relative_rmse_;
+  return p;
+}
+
+// Seam 1: [O3D] RegistrationICP / RegistrationGeneralizedICP on host clouds (CloudRegistration.cpp:16-21,44-48,69-73).  The target's
+// search index is built per call, as the reference builds its KD-tree per call.
+inline RegistrationResult registerClouds(int method /* o3ds_icp_method */, const PointCloud& source, const PointCloud& target,
+                                         const Eigen::Matrix4d& init, double maxCorrespondenceDistance, const ICPConvergenceCriteria& criteria) {
+  const o3ds_handle h = threadHandle();
+  DeviceCloud s(h, source), t(h, target);
+  check(h, o3ds_cloud_build_index(h, t.id(), maxCorrespondenceDistance, 0.0));
+  const o3ds_icp_params p = icpParams(method, maxCorrespondenceDistance, criteria);
+  o3ds_icp_result r{};
+  check(h, o3ds_icp_register_dev(h, s.id(), t.id(), nullptr, init.data(), &p, &r));
+  return toResult(r);
+}
+
+// Seam 1b: EstimateNormals(Hybrid) + NormalizeNormals + OrientNormalsTowardsCameraLocation (CloudRegistration.cpp:22-30,49-56)
+inline void estimateNormals(PointCloud* cloud, double maxRadius, int knn) {
+  if (cloud->points_.empty()) return;
+  const o3ds_handle h = threadHandle();
+  DeviceCloud c(h, *cloud);
+  check(h, o3ds_estimate_normals(h, c.id(), maxRadius, knn));
+  cloud->normals_.resize(cloud->points_.size());
+  check(h, o3ds_cloud_download(h, c.id(), nullptr, reinterpret_cast<double*>(cloud->normals_.data()), cloud->points_.size()));
+}
+
+// Seam 3: Submap's mapCloud_, resident in HBM together with its search index.  Value semantics, because open3d_slam keeps its
+// submaps in a std::vector<Submap> and copies them (SubmapCollection.hpp:79, SubmapCollection.cpp:139): copies share the device map
+// until one of them changes it (copy on write), so a vector that grows does not move maps through host memory.
+class DeviceSubmap {
+ public:
+  DeviceSubmap() : s_(std::make_shared<State>()) {}
+  DeviceSubmap(const DeviceSubmap& o) : s_(o.shared()) {}
+  DeviceSubmap& operator=(const DeviceSubmap& o) {
+    if (this != &o) {
+      std::shared_ptr<State> keep = o.shared();
+      std::lock_guard<std::mutex> lck(ptrMutex_);
+      s_ = keep;
+    }
+    return *this;
+  }
+
+  bool empty() const { return size() == 0; }
+  size_t size() const {
+    auto s = shared();
+    std::lock_guard<std::mutex> lck(s->m);
+    return s->size();
+  }
+  // changes with every mutation: lets Submap keep mapCloud_ as a host mirror and refresh it only when the device map changed
+  uint64_t version() const {
+    auto s = shared();
+    std::lock_guard<std::mutex> lck(s->m);
+    return s->version;
+  }
+
+  // the isUseInitialMap_ branch of Submap::insertScan (Submap.cpp:47-52): map = voxelize(scan), no transform, no crop volume
+  void setInitialMap(const PointCloud& preProcessedScan, double mapVoxelSize, double maxCorrespondenceDistance) {
+    auto s = unique();
+    std::lock_guard<std::mutex> lck(s->m);
+    DeviceCloud in(s->h.get(), preProcessedScan);
+    o3ds_cloud v = 0;
+    check(s->h.get(), o3ds_voxel_down_sample(s->h.get(), in.id(), mapVoxelSize, &v));  // voxel <= 0: a copy (helpers.cpp:108-110)
+    s->adopt(v, maxCorrespondenceDistance);
+  }
+  // Submap::insertScan's tail (Submap.cpp:54,69-72): transform, mapCloud_ +=, voxelizeWithinCroppingVolume, search index
+  void insertScan(const PointCloud& preProcessedScan, const Eigen::Isometry3d& mapToRangeSensor, double mapVoxelSize,
+                  const o3ds_crop& mapBuilderCrop, double maxCorrespondenceDistance) {
+    if (preProcessedScan.IsEmpty()) return;
+    auto s = unique();
+    std::lock_guard<std::mutex> lck(s->m);
+    DeviceCloud in(s->h.get(), preProcessedScan);
+    check(s->h.get(), o3ds_map_insert_scan(s->h.get(), s->id(), in.id(), mapToRangeSensor.matrix().data(), mapVoxelSize, &mapBuilderCrop,
+                                           maxCorrespondenceDistance));
+    ++s->version;
+  }
+  // Submap::carve for the sparse map (Submap.cpp:109-125 -> getIdxsOfCarvedPoints); the caller applies the every-N-scans gate
+  size_t carve(const PointCloud& rawScan, const Eigen::Isometry3d& mapToRangeSensor, const o3ds_crop& mapBuilderCrop,
+               const o3d_slam::SpaceCarvingParameters& p) {
+    auto s = unique();
+    std::lock_guard<std::mutex> lck(s->m);
+    if (rawScan.IsEmpty() || s->size() == 0) return 0;
+    DeviceCloud in(s->h.get(), rawScan);
+    const o3ds_carving_params cp{p.voxelSize_, p.maxRaytracingLength_, p.truncationDistance_, p.minDotProductWithNormal_};
+    size_t removed = 0;
+    check(s->h.get(), o3ds_map_carve(s->h.get(), s->id(), in.id(), mapToRangeSensor.matrix().data(), &mapBuilderCrop, &cp, &removed));
+    ++s->version;
+    return removed;
+  }
+  // mapCloud_.Transform(T) (Submap::transform, Submap.cpp:94-107); the index is rebuilt for the moved points
+  void transform(const Eigen::Isometry3d& T, double maxCorrespondenceDistance) {
+    auto s = unique();
+    std::lock_guard<std::mutex> lck(s->m);
+    if (s->size() == 0) return;
+    o3ds_cloud moved = 0;
+    check(s->h.get(), o3ds_transform_cloud(s->h.get(), s->id(), T.matrix().data(), &moved));
+    s->adopt(moved, maxCorrespondenceDistance);
+  }
+  // Seam 2: cloudRegistration->registerClouds(scan, scanMatcherCropper_->crop(map), initialGuess) (ScanToMapRegistration.cpp:55-62)
+  // with the crop volume as a predicate inside the search and the index the last insertion left behind
+  RegistrationResult registerScan(int method, const PointCloud& scan, const o3ds_crop& scanMatcherCrop, const Eigen::Isometry3d& initialGuess,
+                                  double maxCorrespondenceDistance, const ICPConvergenceCriteria& criteria) const {
+    auto s = shared();
+    std::lock_guard<std::mutex> lck(s->m);
+    if (s->size() == 0) throw std::runtime_error("map patch size is zero");  // assert_gt, ScanToMapRegistration.cpp:60
+    DeviceCloud in(s->h.get(), scan);
+    const o3ds_icp_params p = icpParams(method, maxCorrespondenceDistance, criteria);
+    o3ds_icp_result r{};
+    check(s->h.get(), o3ds_icp_register_dev(s->h.get(), in.id(), s->map, &scanMatcherCrop, initialGuess.matrix().data(), &p, &r));
+    return toResult(r);
+  }
+  void download(PointCloud* out) const {
+    auto s = shared();
+    std::lock_guard<std::mutex> lck(s->m);
+    if (!s->map) {
+      *out = PointCloud();
+      return;
+    }
+    downloadCloud(s->h.get(), s->map, out);
+  }
+
+ private:
+  struct State {
+    OwnedHandle h;
+    std::mutex m;
+    o3ds_cloud map = 0;
+    uint64_t version = 0;
+    double maxCorr = 0.0;
+    ~State() {
+      if (map) o3ds_cloud_free(h.get(), map);
+    }
+    o3ds_cloud id() {  // the (initially empty) device cloud, made on first use
+      if (!map) check(h.get(), o3ds_cloud_upload(h.get(), nullptr, nullptr, 0, &map));
+      return map;
+    }
+    size_t size() const {
+      size_t n = 0;
+      if (map) check(h.get(), o3ds_cloud_size(h.get(), map, &n, nullptr));
+      return n;
+    }
+    void adopt(o3ds_cloud fresh, double maxCorrespondenceDistance) {
+      if (map) o3ds_cloud_free(h.get(), map);
+      map = fresh;
+      maxCorr = maxCorrespondenceDistance;
+      if (maxCorrespondenceDistance > 0.0) check(h.get(), o3ds_cloud_build_index(h.get(), map, maxCorrespondenceDistance, 0.0));
+      ++version;
+    }
+  };
+  std::shared_ptr<State> shared() const {
+    std::lock_guard<std::mutex> lck(ptrMutex_);
+    return s_;
+  }
+  // the state for a mutation: this object's own copy (clouds belong to the handle that made them, so a clone goes through host memory)
+  std::shared_ptr<State> unique() {
+    std::lock_guard<std::mutex> lck(ptrMutex_);
+    if (s_.use_count() > 1) {
+      auto fresh = std::make_shared<State>();
+      {
+        std::lock_guard<std::mutex> l2(s_->m);
+        if (s_->map && s_->size() > 0) {
+          PointCloud host;
+          downloadCloud(s_->h.get(), s_->map, &host);
+          DeviceCloud up(fresh->h.get(), host);
+          o3ds_cloud copy = 0;
+          const double identity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+          check(fresh->h.get(), o3ds_transform_cloud(fresh->h.get(), up.id(), identity, &copy));
+          fresh->adopt(copy, s_->maxCorr);
+        }
+        fresh->version = s_->version + 1;
+      }
+      s_ = fresh;
+    }
+    return s_;
+  }
+  mutable std::mutex ptrMutex_;
+  std::shared_ptr<State> s_;
+};
+
+}  // namespace o3ds

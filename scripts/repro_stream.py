@@ -1,6 +1,6 @@
-"""Is the config-2 stream reproducible to the last bit?  Runs it twice in one process (two fresh handles), hashes what every ABI
+"""Is the config-2 stream reproducible to the last bit?  Runs it several times in one process (fresh handles), hashes what every ABI
 call produced (clouds that come back, clouds changed in place, registration results) and reports the first call whose hash differs
-between the runs -- the tool for the open item of DESIGN.md section 6 (the final pose varies in its 9th digit from run to run).
+between the runs (round 1: the first estimate_normals; since round 2 none -- tests/test_repro_gpu.py asserts it).
     python scripts/repro_stream.py [--frames 12]"""
 import argparse, hashlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -68,34 +68,47 @@ def run(frames, scans, mp, op):
     return out, marks, T
 
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--frames", type=int, default=12)
-ap.add_argument("--runs", type=int, default=3)
-ap.add_argument("--dirty-pool", action="store_true", help="fill and free a large device buffer before the first run: if the first run then "
-                "agrees with the later ones, something reads memory it has not written")
-args = ap.parse_args()
-mp = P.lua_default_mapper_parameters()
-op = P.OdometryParameters()
-op.scanMatcher_.icp_ = P.IcpParameters(maxNumIter_=50, maxCorrespondenceDistance_=1.0, knn_=20, maxDistanceKnn_=3.0)
-op.scanProcessing_.voxelSize_ = 0.1
-op.scanProcessing_.cropper_ = P.ScanCroppingParameters(croppingMinRadius_=2.0, croppingMaxRadius_=30.0, cropperName_="MinMaxRadius")
-scene = syn.make_scene()
-poses = syn.figure_eight_poses(200, 0.1)
-scans = [syn.os128_scan(scene, poses[k], frame=k).astype(np.float32) for k in range(args.frames)]
-if args.dirty_pool:
-    be0 = backend.Backend(0)
-    ids = [be0.upload(np.full((2_000_000, 3), np.nan), np.full((2_000_000, 3), np.nan)) for _ in range(3)]
-    for i in ids:
-        be0.free(i)
-    be0.close()
-ref, marks, T0 = run(args.frames, scans, mp, op)
-print("calls per run:", len(ref))
-for r in range(1, args.runs):
-    cur, _, T = run(args.frames, scans, mp, op)
-    first = next((i for i, (a, b) in enumerate(zip(ref, cur)) if a != b), None)
-    if first is None and len(cur) == len(ref):
-        print("run %d: identical to run 0 (%d calls), final pose bitwise equal: %s" % (r, len(cur), np.array_equal(T, T0)))
-    else:
-        frame = max(k for k, m in enumerate(marks) if m <= (first if first is not None else 0))
-        print("run %d: first difference at call %s (frame %d): %s vs %s; previous call: %s" %
-              (r, first, frame, ref[first] if first is not None else None, cur[first] if first is not None else None, ref[first - 1] if first else None))
+def check(frames=12, runs=3, dirty_pool=False, n_az=1024, verbose=True):
+    """runs the stream `runs` times on fresh handles; returns [(run, first differing call or None, frame, pose bitwise equal)]"""
+    mp = P.lua_default_mapper_parameters()
+    op = P.OdometryParameters()
+    op.scanMatcher_.icp_ = P.IcpParameters(maxNumIter_=50, maxCorrespondenceDistance_=1.0, knn_=20, maxDistanceKnn_=3.0)
+    op.scanProcessing_.voxelSize_ = 0.1
+    op.scanProcessing_.cropper_ = P.ScanCroppingParameters(croppingMinRadius_=2.0, croppingMaxRadius_=30.0, cropperName_="MinMaxRadius")
+    scene = syn.make_scene()
+    poses = syn.figure_eight_poses(200, 0.1)
+    scans = [syn.os128_scan(scene, poses[k], frame=k, n_az=n_az).astype(np.float32) for k in range(frames)]
+    ref, marks, T0 = run(frames, scans, mp, op)
+    if verbose:
+        print("calls per run:", len(ref))
+    out = []
+    for r in range(1, runs):
+        if dirty_pool:  # fill and free large device buffers on another handle and on this process's pools: the addresses, and with
+            be0 = backend.Backend(0)  # them the arrival order of every atomic scatter, change
+            ids = [be0.upload(np.full((500_000 + 333_333 * i, 3), np.nan), np.full((500_000 + 333_333 * i, 3), np.nan)) for i in range(3)]
+            for i in ids:
+                be0.free(i)
+            be0.close()
+        cur, _, T = run(frames, scans, mp, op)
+        first = next((i for i, (a, b) in enumerate(zip(ref, cur)) if a != b), None)
+        if first is None and len(cur) != len(ref):
+            first = min(len(cur), len(ref))
+        same_pose = bool(np.array_equal(T, T0))
+        frame = None if first is None else max(k for k, m in enumerate(marks) if m <= first)
+        out.append((r, first, frame, same_pose))
+        if verbose:
+            if first is None:
+                print("run %d: identical to run 0 (%d calls), final pose bitwise equal: %s" % (r, len(cur), same_pose))
+            else:
+                print("run %d: first difference at call %s (frame %d): %s vs %s; previous call: %s" %
+                      (r, first, frame, ref[first] if first < len(ref) else None, cur[first] if first < len(cur) else None, ref[first - 1] if first else None))
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=12)
+    ap.add_argument("--runs", type=int, default=3)
+    ap.add_argument("--dirty-pool", action="store_true", help="disturb the device allocations between the runs")
+    args = ap.parse_args()
+    check(args.frames, args.runs, args.dirty_pool)

@@ -8,6 +8,7 @@ namespace geometry {
 class PointCloud {
  public:
   std::vector<Eigen::Vector3d> points_, normals_, colors_;
+  std::vector<Eigen::Matrix3d> covariances_;
   bool HasPoints() const { return !points_.empty(); }
   bool HasNormals() const { return !points_.empty() && normals_.size() == points_.size(); }
   bool HasColors() const { return !points_.empty() && colors_.size() == points_.size(); }

@@ -6,6 +6,8 @@ namespace pipelines {
 namespace registration {
 class RegistrationResult {
  public:
+  RegistrationResult() = default;
+  RegistrationResult(const Eigen::Matrix4d& T) : transformation_(T) {}
   Eigen::Matrix4d transformation_;
   double fitness_ = 0.0, inlier_rmse_ = 0.0;
 };

@@ -76,3 +76,22 @@ def test_stream_mapping_through_the_cpp_classes():
     out = subprocess.run(["python", os.path.join(ROOT, "scripts", "bench_stream_cpp.py"), "--frames", "8"], capture_output=True, text=True, timeout=400)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "scans_per_sec_mapping_only" in out.stdout
+
+
+# ---- integration/o3ds_open3d_slam.hpp: the header the open3d_slam patch calls into (tests/test_integration_patch.py applies the patch)
+@pytest.fixture(scope="module")
+def integration_exe(tmp_path_factory):
+    return _compile(tmp_path_factory, "test_integration", extra=("-I" + os.path.join(ROOT, "tests", "cpp", "open3d_shim"), "-I" + os.path.join(ROOT, "include")))
+
+
+def test_integration_header_compiles_and_device_free_checks(integration_exe):
+    out = subprocess.run([integration_exe, "--no-gpu"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "no-gpu checks ok" in out.stdout
+
+
+@pytest.mark.gpu
+def test_integration_header_on_gpu(integration_exe):
+    out = subprocess.run([integration_exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "gpu checks ok" in out.stdout
