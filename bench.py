@@ -302,6 +302,57 @@ def run_m1(be, world, s_id, t_id, steps, warmup, barrier, drv):
     return res, elapsed, n_launch, kern_ms
 
 
+def run_config4(args, world, rank, local_rank, barrier):
+    """BASELINE.json configs[4]: ONE dense voxel map (VoxelizedPointCloud, Voxel.cpp:18-114) over the GPUs of the node.  A STEP = every
+    rank contributes a 2 M-point placed scan (16 OS-128 frames fused; voxel 0.02 m): rows grouped by voxel owner on the
+    device, one all-to-all between the GPUs, fusion into the local table.  Weak scaling; value = points fused per second over all ranks."""
+    import torch
+    import torch.distributed as dist
+
+    from open3d_slam_amd import backend, sharded, synthetic as syn
+
+    scene = syn.make_scene()
+    poses = syn.figure_eight_poses(200, 0.1)
+    frames = [syn.os128_scan(scene, poses[(16 * rank + k) % 200], frame=16 * rank + k) @ poses[(16 * rank + k) % 200][:3, :3].T
+              + poses[(16 * rank + k) % 200][:3, 3] for k in range(16)]
+    scan = np.vstack(frames)  # 2 097 152 points in the map frame
+    be = backend.Backend(local_rank)
+    dm = sharded.ShardedDenseMap(be, 0.02, has_normals=False)
+    cid = be.upload(scan)
+    steps, warmup = min(args.steps, 50), min(args.warmup, 5)
+    for _ in range(warmup):
+        dm.insert(cid)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        dm.insert(cid)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    voxels = dm.size()
+    if rank == 0:
+        n = len(scan)
+        algo = n * (12 + 40)  # SURVEY.md 8d C5 (no normals): 12 B xyz read + 40 B voxel record read-modify-write per point
+        gbs = world * steps * algo / elapsed / 1e9
+        print(json.dumps({
+            "metric": "dense_fusion_points_per_sec", "value": world * steps * n / elapsed, "unit": "points/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 points, int64 fixed-point sums", "data": "synthetic",
+            "config": {"workload": f"configs[4]: one dense voxel map over {world} GPU(s), {n} placed points per GPU per step (16 OS-128 frames), voxel 0.02 m, "
+                                   "rows grouped by voxel owner on the device + one all-to-all + hash fusion", "points_per_gpu_per_step": n,
+                       "voxel_m": 0.02, "parallelism": "1 GPU" if world == 1 else f"voxel-owner sharding over {world} GPUs, one all_to_all_single per step"},
+            "global_voxels": voxels,
+            "roofline": {"bound": "hbm", "achieved": gbs / world, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / world / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "whole step per GPU (owner count + scatter, all-to-all, import, dense_insert_kernel)",
+                         "algorithmic_bytes_per_point": 52}}), flush=True)
+    be.free(cid)
+    dm.close()
+    be.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -313,6 +364,11 @@ def main():
     ap.add_argument("--m2-frames", type=int, default=200, help="frames of the configs[2] stream (0: skip M2)")
     ap.add_argument("--m2-cpu-frames", type=int, default=40)
     ap.add_argument("--no-f64", action="store_true")
+    ap.add_argument("--config", default="auto", choices=["auto", "1", "3", "3u", "4"],
+                    help="BASELINE.json configs: 1 = scan vs 1M map on one GPU (+ M2); 3 = joint registration over one submap per GPU (sum of the "
+                         "per-submap normal equations); 3u = ONE map split over the GPUs, union-equivalent (key MIN all-reduce + record sum); "
+                         "4 = one dense voxel map over the GPUs, 2M-pt scan per GPU per step, voxel 0.02 (all-to-all of rows by voxel owner). "
+                         "auto = 1 at N = 1, 3 at N > 1")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -323,7 +379,9 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                              "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         args.gpus = world
-    do_m2 = world == 1 and args.m2_frames > 1
+    if args.config == "auto":
+        args.config = "1" if world == 1 else "3"
+    do_m2 = world == 1 and args.m2_frames > 1 and args.config == "1"
     scans32 = make_stream(args.m2_frames) if do_m2 else None  # before the GPU runtime exists in this process (fork)
 
     import torch
@@ -348,6 +406,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.config == "4":
+        run_config4(args, world, rank, local_rank, barrier)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
     # ---- M1 workload (seeded)
     scene = syn.make_scene()
     T_gt = syn.ground_truth_pose()
@@ -364,7 +428,7 @@ def main():
         be.build_index(t_id, MAX_CORR, args.cell)
         be.synchronize()
         index_build_ms = (time.perf_counter() - t0) * 1e3
-        drv = sharded.ShardedIcp(be, mode="submap") if world > 1 else None
+        drv = sharded.ShardedIcp(be, mode="union" if args.config == "3u" else "submap") if (world > 1 or args.config == "3u") else None
         res, elapsed, n_launch, kern_ms = run_m1(be, world, s_id, t_id, steps, warmup, barrier, drv)
         if world > 1:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
@@ -440,8 +504,12 @@ def main():
             "config": {"workload": "configs[1]: point-to-plane ICP, 65536-pt VLP-16 scan vs 1,000,000-pt submap, "
                                    f"max_corr {MAX_CORR} m, {ICP_ITERS} fixed iterations/step (+1 evaluation pass), index prebuilt",
                        "n_src": N_SRC, "n_map_per_gpu": N_MAP, "icp_iterations_per_step": ICP_ITERS,
-                       "parallelism": "1 GPU" if world == 1 else f"ONE joint registration over {world} submaps x 1 GPU: one fused kernel + one 4-KB RCCL "
-                                                                  "all-reduce per iteration (value counts the joint iterations once)",
+                       "parallelism": "1 GPU" if world == 1 and args.config != "3u" else (
+                           f"configs[3], union-equivalent: ONE map of {world} x {N_MAP} points split over {world} GPUs; per iteration a search kernel, "
+                           f"one MIN all-reduce of {N_SRC} 64-bit keys (512 KB), an accumulate kernel, one 256-B sum all-reduce, an update kernel"
+                           if args.config == "3u" else
+                           f"configs[3]: ONE joint registration over {world} submaps x 1 GPU: one fused kernel + one 4-KB RCCL "
+                           "all-reduce per iteration (value counts the joint iterations once)"),
                        "nn_cell_m": args.cell if args.cell > 0 else MAX_CORR / 4},
             "index_build_ms": r32["index_build_ms"],
             "point_queries_per_sec": world * N_SRC * (ICP_ITERS + 1) * steps / elapsed,

@@ -219,6 +219,18 @@ int o3ds_icp_begin(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3
 int o3ds_icp_accumulate(o3ds_handle h, size_t first, size_t count, double* d_record);
 int o3ds_icp_update(o3ds_handle h, const double* d_record, uint64_t n_src_total);
 int o3ds_icp_finish(o3ds_handle h, o3ds_icp_result* out);
+/* Target-sharded registration against ONE map whose points are split over up to 16 GPUs (SURVEY.md 8e
+ * Partitioning B) -- the sharding that reproduces the reference's registration against a single cloud (Mapper.cpp:141,
+ * ScanToMapRegistration.cpp:57-61).  Per iteration, inside an o3ds_icp_begin session on this rank's shard:
+ *   o3ds_icp_nn_keys(h, 0, n, rank, d_keys)      every query's best match in THIS shard as a key: float bits of d2 << 32 | rank << 28 |
+ *                                                position in the shard's index; INT64_MAX when nothing lies within the radius (keys order as signed or unsigned)
+ *   ncclAllReduce(d_keys, n, uint64, min)        non-negative float bit patterns order like the floats: the minimum is the match in
+ *                                                the union of the shards (equal distances: lower rank, then lower position)
+ *   o3ds_icp_accumulate_keys(h, 0, n, rank, d_keys, d_record)   the queries whose winning key names this rank contribute their rows
+ *   ncclAllReduce(d_record, 32, double, sum)  ->  o3ds_icp_update(h, d_record, n)
+ * and o3ds_icp_finish as usual.  d2 enters the key as a float: distances that differ only beyond float precision tie. */
+int o3ds_icp_nn_keys(o3ds_handle h, size_t first, size_t count, int rank, unsigned long long* d_keys);
+int o3ds_icp_accumulate_keys(o3ds_handle h, size_t first, size_t count, int rank, const unsigned long long* d_keys, double* d_record);
 /* 1 when the device-side loop has terminated (converged or max_iteration reached); synchronises. */
 /* Fused step-wise form -- ONE kernel per iteration plus the caller's collective (the accumulate / reduce / update triple above is
  * three).  o3ds_icp_pass enqueues launch j of the fused loop over the source range [first, first + count): its prologue folds
@@ -304,6 +316,15 @@ int o3ds_dense_map_carve(o3ds_handle h, o3ds_dense_map id, o3ds_cloud scan, cons
 /* Number of points of `cloud` (placed by T; NULL = identity) that fall into an occupied voxel of the map:
  * VoxelHashMap::hasVoxelContainingPoint per point, the count behind SubmapCollection::isSwitchingSubmapsConsistant
  * (src/SubmapCollection.cpp:352-364: fitness = hits / scan size, compared with adjacencyBasedRevisitingMinFitness_). */
+/* ONE dense voxel map over several GPUs (BASELINE.json configs[4]; SURVEY.md 8e "map fusion across GPUs"): a voxel lives on the rank
+ * hash(voxel) mod world, with the reference's own hash (VoxelHashMap.hpp:25-35).  export places the cloud by T (NULL: as it is), rounds
+ * to the storage type, drops non-finite points and writes the rows [x y z nx ny nz] (doubles; zeros when the cloud has no normals)
+ * grouped by owner into d_rows (device memory, capacity cloud size x 6) and the group sizes into d_counts (device memory, world
+ * entries) -- the send buffer and split sizes of one all-to-all.  import turns received rows into a cloud of this handle, ready for
+ * o3ds_dense_map_insert.  No host copy on either side of the collective. */
+int o3ds_cloud_export_rows_by_owner(o3ds_handle h, o3ds_cloud cloud, const double T[16], double voxel_size, int world, double* d_rows,
+                                    long long* d_counts);
+int o3ds_cloud_import_rows(o3ds_handle h, const double* d_rows, size_t n, int has_normals, o3ds_cloud* out);
 int o3ds_dense_map_count_occupied(o3ds_handle h, o3ds_dense_map id, o3ds_cloud cloud, const double T[16], size_t* n_hits);
 /* computeIndicesOfOverlappingPoints (src/helpers.cpp:307-332; call sites src/PlaceRecognition.cpp:103,
  * src/constraint_builders.cpp:54): both clouds are binned with the voxel key floor(p / voxel_size) -- the source after being

@@ -59,6 +59,10 @@ SIGNATURES = {
     "o3ds_set_stream": (C.c_int, [_H, C.c_void_p]),
     "o3ds_profile_enable": (C.c_int, [_H, C.c_int]),
     "o3ds_profile_read": (C.c_int, [_H, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
+    "o3ds_cloud_export_rows_by_owner": (C.c_int, [_H, _CL, C.POINTER(C.c_double), C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
+    "o3ds_cloud_import_rows": (C.c_int, [_H, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(_CL)]),
+    "o3ds_icp_nn_keys": (C.c_int, [_H, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]),
+    "o3ds_icp_accumulate_keys": (C.c_int, [_H, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
     "o3ds_profile_span": (C.c_int, [_H, C.c_int, C.c_int]),
     "o3ds_profile_span_read": (C.c_int, [_H, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     "o3ds_cloud_upload": (C.c_int, [_H, _dp, _dp, C.c_size_t, C.POINTER(_CL)]),
@@ -393,6 +397,12 @@ class Backend:
     def icp_accumulate(self, first: int, count: int, d_record_ptr: int):
         self._ck(self.lib.o3ds_icp_accumulate(self.h, first, count, C.c_void_p(d_record_ptr)))
 
+    def icp_nn_keys(self, first: int, count: int, rank: int, d_keys_ptr: int):
+        self._ck(self.lib.o3ds_icp_nn_keys(self.h, first, count, rank, C.c_void_p(d_keys_ptr)))
+
+    def icp_accumulate_keys(self, first: int, count: int, rank: int, d_keys_ptr: int, d_record_ptr: int):
+        self._ck(self.lib.o3ds_icp_accumulate_keys(self.h, first, count, rank, C.c_void_p(d_keys_ptr), C.c_void_p(d_record_ptr)))
+
     def icp_update(self, d_record_ptr: int, n_src_total: int):
         self._ck(self.lib.o3ds_icp_update(self.h, C.c_void_p(d_record_ptr), n_src_total))
 
@@ -503,6 +513,16 @@ class Backend:
         else:
             Tc, tp = _d(colmajor(T))
             self._ck(self.lib.o3ds_dense_map_insert(self.h, dm, cloud, tp))
+
+    def export_rows_by_owner(self, cid: int, T, voxel: float, world: int, d_rows_ptr: int, d_counts_ptr: int):
+        """rows [x y z nx ny nz] of the (placed) cloud grouped by voxel owner into device memory, group sizes into device memory"""
+        Tm = None if T is None else colmajor(T).ctypes.data_as(C.POINTER(C.c_double))
+        self._ck(self.lib.o3ds_cloud_export_rows_by_owner(self.h, cid, Tm, float(voxel), int(world), C.c_void_p(d_rows_ptr), C.c_void_p(d_counts_ptr)))
+
+    def import_rows(self, d_rows_ptr: int, n: int, has_normals: bool) -> int:
+        out = _CL()
+        self._ck(self.lib.o3ds_cloud_import_rows(self.h, C.c_void_p(d_rows_ptr), int(n), int(bool(has_normals)), C.byref(out)))
+        return int(out.value)
 
     def dense_map_size(self, dm: int) -> int:
         n = C.c_size_t(0)

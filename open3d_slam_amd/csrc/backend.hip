@@ -1348,6 +1348,53 @@ int o3ds_icp_accumulate(o3ds_handle h, size_t first, size_t count, double* d_rec
   return O3DS_OK;
 }
 
+// Partitioning B (one map split over the GPUs of a node): search pass -> keys; the caller MIN-all-reduces them; accumulate pass
+int o3ds_icp_nn_keys(o3ds_handle h, size_t first, size_t count, int rank, unsigned long long* d_keys) {
+  CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
+  if (!h->session) return fail(h, O3DS_ERR_INVALID_ARG, "icp_nn_keys: no session (call o3ds_icp_begin)");
+  if (!d_keys) return fail(h, O3DS_ERR_INVALID_ARG, "icp_nn_keys: null keys");
+  if (rank < 0 || rank > 15) return fail(h, O3DS_ERR_INVALID_ARG, "icp_nn_keys: rank must be 0..15 (4 bits of the key)");
+  if (first + count > h->session_n_src) return fail(h, O3DS_ERR_INVALID_ARG, "icp_nn_keys: range outside source");
+  if ((size_t)h->pass.n_tgt > ((size_t)1 << 28)) return fail(h, O3DS_ERR_INVALID_ARG, "icp_nn_keys: more than 2^28 target points per shard");
+  IcpPassArgs a = h->pass;
+  a.first = first;
+  a.count = count;
+  a.keys_mode = 1;
+  a.keys_rank = rank;
+  a.keys = d_keys;
+  const int nb = pass_blocks(h, count);
+  if (h->session_precision == O3DS_PRECISION_F64)
+    launch_accumulate<P4d>(h, a, h->session_crop, nb);
+  else
+    launch_accumulate<P4f>(h, a, h->session_crop, nb);
+  HIP_TRY(hipGetLastError());
+  return O3DS_OK;
+}
+
+int o3ds_icp_accumulate_keys(o3ds_handle h, size_t first, size_t count, int rank, const unsigned long long* d_keys, double* d_record) {
+  CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
+  if (!h->session) return fail(h, O3DS_ERR_INVALID_ARG, "icp_accumulate_keys: no session (call o3ds_icp_begin)");
+  if (!d_keys || !d_record) return fail(h, O3DS_ERR_INVALID_ARG, "icp_accumulate_keys: null argument");
+  if (rank < 0 || rank > 15) return fail(h, O3DS_ERR_INVALID_ARG, "icp_accumulate_keys: rank must be 0..15");
+  if (first + count > h->session_n_src) return fail(h, O3DS_ERR_INVALID_ARG, "icp_accumulate_keys: range outside source");
+  IcpPassArgs a = h->pass;
+  a.first = first;
+  a.count = count;
+  a.keys_mode = 2;
+  a.keys_rank = rank;
+  a.keys = const_cast<unsigned long long*>(d_keys);
+  const int nb = pass_blocks(h, count);
+  if (h->session_precision == O3DS_PRECISION_F64)
+    launch_accumulate<P4d>(h, a, h->session_crop, nb);
+  else
+    launch_accumulate<P4f>(h, a, h->session_crop, nb);
+  icp_reduce_kernel<<<1, kUpdBlock, 0, h->stream>>>(h->d_partials, nb, h->d_state, d_record, quantum_table(a));
+  HIP_TRY(hipGetLastError());
+  return O3DS_OK;
+}
+
 int o3ds_icp_update(o3ds_handle h, const double* d_record, uint64_t n_src_total) {
   CHECK_HANDLE(h);
   if (!h->session) return fail(h, O3DS_ERR_INVALID_ARG, "icp_update: no session");
@@ -2375,6 +2422,65 @@ int o3ds_dense_map_insert(o3ds_handle h, o3ds_dense_map id, o3ds_cloud cloud, co
   CloudRec* c = find_cloud(h, cloud);
   if (it == h->dense_maps.end() || !c) return fail(h, O3DS_ERR_INVALID_ARG, "dense_map_insert: unknown id");
   return c->precision == O3DS_PRECISION_F64 ? dense_insert_t<P4d>(h, it->second, *c, T) : dense_insert_t<P4f>(h, it->second, *c, T);
+}
+
+extern "C++" {
+namespace {
+template <typename P4>
+int export_rows_t(o3ds_handle h, const CloudRec& c, const double T[16], double voxel, int world, double* d_rows, long long* d_counts) {
+  Mat34 M{};
+  if (T)
+    for (int r = 0; r < 3; ++r)
+      for (int col = 0; col < 4; ++col) M.m[r * 4 + col] = T[col * 4 + r];
+  HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof(long long) * (size_t)world, h->stream));
+  if (c.n == 0) return O3DS_OK;
+  int* owner = nullptr;
+  unsigned long long* offsets = nullptr;
+  TMP_ALLOC(owner, sizeof(int) * c.n);
+  TMP_ALLOC(offsets, sizeof(unsigned long long) * 2 * (size_t)world);
+  owner_count_kernel<P4><<<grid_for(c.n), kBlock, 0, h->stream>>>((const P4*)c.pts, c.n, M, T ? 1 : 0, 1.0 / voxel, world, owner, d_counts);
+  owner_offsets_kernel<<<1, 64, 0, h->stream>>>(d_counts, world, offsets);
+  owner_scatter_kernel<P4><<<grid_for(c.n), kBlock, 0, h->stream>>>((const P4*)c.pts, (const P4*)c.nrm, c.n, M, T ? 1 : 0, world, owner, offsets, d_rows);
+  HIP_TRY(hipGetLastError());
+  return O3DS_OK;
+}
+template <typename P4>
+int import_rows_t(o3ds_handle h, const double* d_rows, size_t n, int has_normals, CloudRec& out) {
+  out.n = n;
+  out.precision = h->precision;
+  if (n == 0) return O3DS_OK;
+  HIP_TRY(dev_alloc(h, (void**)&out.pts, sizeof(P4) * n));
+  if (has_normals) HIP_TRY(dev_alloc(h, (void**)&out.nrm, sizeof(P4) * n));
+  rows_to_cloud_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(d_rows, n, (P4*)out.pts, (P4*)out.nrm);
+  HIP_TRY(hipGetLastError());
+  return O3DS_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+int o3ds_cloud_export_rows_by_owner(o3ds_handle h, o3ds_cloud cloud, const double T[16], double voxel_size, int world, double* d_rows,
+                                    long long* d_counts) {
+  CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
+  CloudRec* c = find_cloud(h, cloud);
+  if (!c) return fail(h, O3DS_ERR_INVALID_ARG, "export_rows_by_owner: unknown cloud id");
+  if (!(voxel_size > 0.0) || world < 1 || world > 64 || !d_counts || (c->n && !d_rows))
+    return fail(h, O3DS_ERR_INVALID_ARG, "export_rows_by_owner: voxel_size > 0, 1 <= world <= 64, non-null buffers");
+  return c->precision == O3DS_PRECISION_F64 ? export_rows_t<P4d>(h, *c, T, voxel_size, world, d_rows, d_counts)
+                                            : export_rows_t<P4f>(h, *c, T, voxel_size, world, d_rows, d_counts);
+}
+
+int o3ds_cloud_import_rows(o3ds_handle h, const double* d_rows, size_t n, int has_normals, o3ds_cloud* out) {
+  CHECK_HANDLE(h);
+  if (!out || (n && !d_rows)) return fail(h, O3DS_ERR_INVALID_ARG, "import_rows: null argument");
+  CloudRec c;
+  const int rc = h->precision == O3DS_PRECISION_F64 ? import_rows_t<P4d>(h, d_rows, n, has_normals, c) : import_rows_t<P4f>(h, d_rows, n, has_normals, c);
+  if (rc) {
+    free_cloud(h, c);
+    return rc;
+  }
+  *out = add_cloud(h, std::move(c));
+  return O3DS_OK;
 }
 
 int o3ds_dense_map_size(o3ds_handle h, o3ds_dense_map id, size_t* n_voxels) {

@@ -537,6 +537,138 @@ __global__ __launch_bounds__(kBlock) void dense_insert_kernel(const P4* __restri
   }
 }
 
+// ---- one dense map over several GPUs: rows of a placed scan grouped by the rank that owns their voxel -----------------------------
+// owner = the reference's voxel hash (x + 17191 y + 17191^2 z as a 32-bit unsigned, VoxelHashMap.hpp:25-35) of the voxel index the
+// importing rank will bin (floor(value * (1 / voxel)) of the value ROUNDED TO THE STORAGE TYPE, as dense_insert_kernel computes it on
+// the imported cloud), modulo the number of ranks.  Non-finite points have no owner and are dropped (the reference drops NaN returns in
+// its cropper before they reach the map).  Rows are [x y z nx ny nz] doubles; the order inside a destination is the arrival order of
+// an atomic -- irrelevant, the fusion sums are fixed point.
+template <typename P4>
+__device__ __forceinline__ void placed_point(const P4& p, const Mat34& M, bool place, typename Scalar<P4>::type out[3]) {
+  using R = typename Scalar<P4>::type;
+  const double x = (double)p.x, y = (double)p.y, z = (double)p.z;
+  out[0] = place ? (R)(M.m[0] * x + M.m[1] * y + M.m[2] * z + M.m[3]) : p.x;
+  out[1] = place ? (R)(M.m[4] * x + M.m[5] * y + M.m[6] * z + M.m[7]) : p.y;
+  out[2] = place ? (R)(M.m[8] * x + M.m[9] * y + M.m[10] * z + M.m[11]) : p.z;
+}
+// all lanes of the wavefront that hold the same small integer act through one of them: returns the number of lanes with my value
+// (`cnt`), my rank among them (`rank`) and whether I am their first lane -- one atomic per (wavefront, value) instead of one per lane
+__device__ __forceinline__ void wave_group_by(int v, bool valid, int* cnt, int* rank, bool* first) {
+  *cnt = 0, *rank = 0, *first = false;
+  unsigned long long todo = __ballot(valid);
+  const int lane = threadIdx.x & 63;
+  while (todo) {  // uniform: one round per distinct value present
+    const int lead = __ffsll((long long)todo) - 1;
+    const int val = __builtin_amdgcn_readlane(v, lead);
+    const unsigned long long same = __ballot(valid && v == val);
+    if (valid && v == val) {
+      *cnt = __popcll(same);
+      *rank = __popcll(same & ((1ull << lane) - 1ull));
+      *first = lane == lead;
+    }
+    todo &= ~same;
+  }
+}
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void owner_count_kernel(const P4* __restrict__ pts, size_t n, Mat34 M, int place, double inv, int world,
+                                                             int* __restrict__ owner, long long* __restrict__ counts) {
+  __shared__ unsigned int s_hist[64];
+  if (threadIdx.x < 64) s_hist[threadIdx.x] = 0;
+  __syncthreads();
+  const size_t n_up = (n + 63) / 64 * 64;  // whole wavefronts stay in the loop together (the grouping uses wave-wide ballots)
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n_up; i += (size_t)gridDim.x * kBlock) {
+    int o = -1;
+    if (i < n) {
+      typename Scalar<P4>::type q[3];
+      placed_point<P4>(pts[i], M, place != 0, q);
+      if (isfinite((double)q[0]) && isfinite((double)q[1]) && isfinite((double)q[2])) {
+        const long long kx = (long long)(int)floor((double)q[0] * inv), ky = (long long)(int)floor((double)q[1] * inv),
+                        kz = (long long)(int)floor((double)q[2] * inv);
+        const unsigned long long hsh = (unsigned long long)(kx + 17191ll * ky + 17191ll * 17191ll * kz) & 0xffffffffull;
+        o = (int)(hsh % (unsigned long long)world);
+      }
+      owner[i] = o;
+    }
+    int cnt, rank;
+    bool first;
+    wave_group_by(o, o >= 0, &cnt, &rank, &first);
+    if (first) atomicAdd(&s_hist[o], (unsigned int)cnt);
+  }
+  __syncthreads();
+  if (threadIdx.x < world && s_hist[threadIdx.x]) atomicAdd((unsigned long long*)&counts[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
+}
+__global__ void owner_offsets_kernel(const long long* __restrict__ counts, int world, unsigned long long* __restrict__ offsets /* [world] then cursors [world] */) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    unsigned long long run = 0;
+    for (int r = 0; r < world; ++r) {
+      offsets[r] = run;
+      offsets[world + r] = 0;
+      run += (unsigned long long)counts[r];
+    }
+  }
+}
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void owner_scatter_kernel(const P4* __restrict__ pts, const P4* __restrict__ nrm, size_t n, Mat34 M, int place,
+                                                               int world, const int* __restrict__ owner, unsigned long long* __restrict__ offsets,
+                                                               double* __restrict__ rows) {
+  const size_t n_up = (n + 63) / 64 * 64;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n_up; i += (size_t)gridDim.x * kBlock) {
+    const int o = i < n ? owner[i] : -1;
+    int cnt, rank;
+    bool first;
+    wave_group_by(o, o >= 0, &cnt, &rank, &first);
+    unsigned long long base = 0;
+    if (first) base = atomicAdd(&offsets[world + o], (unsigned long long)cnt);  // one reservation per (wavefront, owner)
+    // everyone of the group reads the leader's base: the leader is the group's first lane
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(o >= 0);
+    unsigned long long mybase = 0;
+    while (todo) {
+      const int lead = __ffsll((long long)todo) - 1;
+      const int val = __builtin_amdgcn_readlane(o, lead);
+      const unsigned long long b = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(base >> 32), lead) << 32) |
+                                   (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(base & 0xffffffffull), lead);
+      const unsigned long long same = __ballot(o == val && o >= 0);
+      if (o == val) mybase = b;
+      todo &= ~same;
+    }
+    (void)lane;
+    if (o < 0) continue;
+    const unsigned long long pos = offsets[o] + mybase + (unsigned long long)rank;
+    typename Scalar<P4>::type q[3];
+    placed_point<P4>(pts[i], M, place != 0, q);
+    double* r = rows + 6 * pos;
+    r[0] = (double)q[0], r[1] = (double)q[1], r[2] = (double)q[2];
+    double a = 0.0, b = 0.0, c = 0.0;
+    if (nrm) {
+      const P4 v = nrm[i];
+      a = (double)v.x, b = (double)v.y, c = (double)v.z;
+      if (place) {  // normals rotate with the cloud (o3d_slam::transform, helpers.cpp:273-305)
+        const double x = a, y = b, z = c;
+        a = M.m[0] * x + M.m[1] * y + M.m[2] * z, b = M.m[4] * x + M.m[5] * y + M.m[6] * z, c = M.m[8] * x + M.m[9] * y + M.m[10] * z;
+      }
+    }
+    r[3] = a, r[4] = b, r[5] = c;
+  }
+}
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void rows_to_cloud_kernel(const double* __restrict__ rows, size_t n, P4* __restrict__ pts, P4* __restrict__ nrm) {
+  using R = typename Scalar<P4>::type;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const double* r = rows + 6 * i;
+    P4 p;
+    p.x = (R)r[0], p.y = (R)r[1], p.z = (R)r[2];
+    p.i = (typename Scalar<P4>::index)i;
+    pts[i] = p;
+    if (nrm) {
+      P4 q;
+      q.x = (R)r[3], q.y = (R)r[4], q.z = (R)r[5];
+      q.i = 0;
+      nrm[i] = q;
+    }
+  }
+}
+
 // VoxelHashMap::hasVoxelContainingPoint (VoxelHashMap.hpp:110-114) for every point of a placed cloud: number of hits
 // (SubmapCollection::isSwitchingSubmapsConsistant, SubmapCollection.cpp:352-364, divides it by the cloud size)
 template <typename P4>

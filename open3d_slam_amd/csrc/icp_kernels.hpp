@@ -542,6 +542,7 @@ struct QuantumTable {
   double q[kRec];
 };
 
+constexpr unsigned long long kNoKey = 0x7fffffffffffffffull;  // "no match" of the target-sharded search (see keys_mode)
 struct IcpPassArgs {
   const void* src;   // P4[n_src]
   size_t first, count;
@@ -560,6 +561,13 @@ struct IcpPassArgs {
   const IcpStateDev* state;
   double* partials;  // [gridDim.x][kRec]
   int debug;         // timing experiments only (O3DS_DEBUG_ACC): 1 = exit after prologue, 2 = no search, 3 = no winner gather
+  // Target-sharded registration against ONE map split over several GPUs (SURVEY.md 8e Partitioning B): keys_mode 1 = search only,
+  // this rank's best match of every query goes out as a 64-bit key (float bits of d2 << 32 | rank << 28 | position in this rank's
+  // sorted target; 0x7fff...f = none within the radius, so that the keys also order as SIGNED 64-bit integers) -- non-negative float bit patterns order like the floats, so an element-wise MIN
+  // over the ranks (one all-reduce) is the argmin over the union of the shards; keys_mode 2 = no search, a query contributes its
+  // record iff the winning key names this rank.  0 = the ordinary pass.
+  int keys_mode, keys_rank;
+  unsigned long long* keys;  // [n_src]
 };
 
 // Per-query record staged in LDS: {J0..J5, r, one, d2, 0}.  Every entry of the 32-double normal-equation record is a
@@ -745,6 +753,13 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
       if (a.debug == 2) {
         nn.pos = (int)(i % 1000);
         nn.idx = nn.pos;
+      } else if (a.keys_mode == 2) {  // the match was decided by the all-reduce: mine iff the key names this rank
+        const unsigned long long key = a.keys[a.first + i];
+        if (key != kNoKey && (int)((key >> 28) & 0xfu) == a.keys_rank) {
+          nn.pos = (int)(key & 0x0fffffffu);
+          nn.idx = nn.pos;
+          nn.d2 = (R)__uint_as_float((unsigned int)(key >> 32));
+        }
       } else
         nn = nn_search_group<P4, kCrop, kGroup>(a.grid, tp, (R)px, (R)py, (R)pz, (R)a.r2max, a.kmax, a.crop, gl, s_seg + ql * kSegMax, qp.prev, qp.tprev, &resolved);
       unresolved = !resolved;
@@ -795,9 +810,13 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
     }
     if (tr && threadIdx.x == 0) tr[1] = wall_clock64();
     if (gl == 0) {
-      if (i < a.count) a.nn_cache[a.first + i] = nn.pos;
+      if (i < a.count && a.keys_mode != 2) a.nn_cache[a.first + i] = nn.pos;
+      if (a.keys_mode == 1 && i < a.count)
+        a.keys[a.first + i] = nn.pos == -1 ? kNoKey
+                                           : ((unsigned long long)__float_as_uint((float)nn.d2) << 32) |
+                                                 ((unsigned long long)(a.keys_rank & 0xf) << 28) | (unsigned long long)(nn.pos & 0x0fffffff);
       double* rec = s_rec_flat + ql * kStride;
-      if (nn.pos != -1) {
+      if (nn.pos != -1 && a.keys_mode != 1) {
         if (a.debug == 3) nn.pos = (int)(i % 1000);
         const P4 q = tp[nn.pos];
         const double dx = px - (double)q.x, dy = py - (double)q.y, dz = pz - (double)q.z;

@@ -14,6 +14,11 @@ Two partitionings, both expressed through the step-wise C-ABI:
 * "submap"  : every rank holds ITS OWN target submap and the whole source; the summed record is the joint
               point-to-plane problem over all submaps (north_star: "RCCL all-reduce of the per-submap 6x6
               normal equations").  Fitness is the mean per-submap fitness (n_src_total = W * n).
+* "union"   : ONE map split over the ranks (spatial shards); every rank holds the whole source.  Per iteration every rank
+              searches its shard and writes a 64-bit key per query (distance bits | rank | position), one element-wise MIN
+              all-reduce (n x 8 B) picks each query's match in the union of the shards, the owning rank contributes its rows, and
+              the 32-double records are summed (SURVEY.md 8e Partitioning B).  This is the sharding that reproduces the reference's
+              registration against a single cloud (Mapper.cpp:141): equal to the one-GPU registration against the whole map.
 
 All ranks apply the identical update to identical state, so no broadcast is needed.
 The reference has no multi-device code at all; this is a new design, not a translation.
@@ -68,7 +73,7 @@ class ShardedIcp:
         import torch
         import torch.distributed as dist
 
-        assert mode in ("source", "submap")
+        assert mode in ("source", "submap", "union")
         self.be, self.mode, self.group = be, mode, group
         self.dist, self.torch = dist, torch
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -84,12 +89,15 @@ class ShardedIcp:
         with torch.cuda.stream(self.tstream):
             self.rec = torch.zeros(32, dtype=torch.float64, device=dev)
             self.sums = [torch.zeros(be.ICP_SUMS_DOUBLES, dtype=torch.float64, device=dev) for _ in range(3)]
+            self.keys = None  # "union": one int64 key per source point, grown on demand
         self.tstream.synchronize()
         be.set_stream(self.tstream.cuda_stream)
 
     def register(self, source: int, target: int, n_src: int, max_corr: float, init=None, max_iter: int = 30,
                  rel_fitness: float = 1e-6, rel_rmse: float = 1e-6, target_crop=None, check_every: int = 4) -> dict:
         be, dist = self.be, self.dist
+        if self.mode == "union":
+            return self._register_union(source, target, n_src, max_corr, init, max_iter, rel_fitness, rel_rmse, target_crop, check_every)
         if self.mode == "source":
             first, count = shard_range(n_src, self.rank, self.world)
             n_total = n_src
@@ -127,6 +135,31 @@ class ShardedIcp:
             return be.icp_pass_finish(n_total, last.data_ptr(), self.sums[passes % 3].data_ptr())
 
 
+    def _register_union(self, source, target, n_src, max_corr, init, max_iter, rel_fitness, rel_rmse, target_crop, check_every):
+        be, dist, torch = self.be, self.dist, self.torch
+        assert self.world <= 16, "the key carries the rank in 4 bits"
+        with torch.cuda.stream(self.tstream):
+            if self.keys is None or self.keys.numel() < n_src:
+                self.keys = torch.empty(n_src, dtype=torch.int64, device=self.rec.device)
+            keys = self.keys[:n_src]
+            be.icp_begin(source, target, max_corr, init=init, max_iter=max_iter, rel_fitness=rel_fitness, rel_rmse=rel_rmse, target_crop=target_crop)
+            kptr, rptr = keys.data_ptr(), self.rec.data_ptr()
+
+            def accumulate():
+                be.icp_nn_keys(0, n_src, self.rank, kptr)
+                if self.world > 1:
+                    dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=self.group)
+                be.icp_accumulate_keys(0, n_src, self.rank, kptr, rptr)
+                return self.rec
+
+            def all_reduce(rec):
+                if self.world > 1:
+                    dist.all_reduce(rec, op=dist.ReduceOp.SUM, group=self.group)
+
+            run_sharded_loop(accumulate, all_reduce, lambda rec: be.icp_update(rptr, n_src), be.icp_done, max_iter, check_every)
+            return be.icp_finish()
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------
 # Multi-GPU fusion of ONE dense voxel map (BASELINE configs[4]; SURVEY.md 8e "map fusion across GPUs").  The path has one exchange
 # step: a voxel's running sums must live on one rank, so every insertion routes each point to the owner of its voxel -- one
@@ -145,24 +178,32 @@ def voxel_owner(points, voxel: float, world: int, storage="f64"):
     if storage == "f32":
         p = p.astype(np.float32).astype(np.float64)
     k = np.floor(p * (1.0 / voxel)).astype(np.int64)
+    assert len(k) == 0 or np.abs(k).max() < (1 << 20), "voxel indices beyond 2^20: the device table packs 21 bits per axis"
     h = (k[:, 0] + 17191 * k[:, 1] + 17191 * 17191 * k[:, 2]) & 0xFFFFFFFF
     return (h % world).astype(np.int64)
 
 
-def exchange_by_owner(points, normals, voxel: float, group=None, device=None, storage="f64"):
-    """One insertion's exchange step: returns the rows (points, normals or None) whose voxels this rank owns, gathered from all
-    ranks.  Counts go first (all_to_all of world ints), then one all_to_all of the rows, sorted by destination.  `device`: where the
-    collective's tensors live (None = CPU for gloo; the rank's GPU for nccl / RCCL)."""
+def exchange_by_owner(points, normals, voxel: float, group=None, device=None, storage="f64", has_normals=None):
+    """One insertion's exchange step, HOST-STAGED (numpy rows; the CPU / gloo form that tests/test_sharded_cpu.py drives with the oracle
+    as the local fusion -- ShardedDenseMap on a GPU uses the device form below): returns the rows (points, normals or None) whose voxels
+    this rank owns, gathered from all ranks.  Counts go first (all_to_all of world ints), then one all_to_all of the rows, sorted by
+    destination.  Every rank sends SIX columns whatever its own arguments are -- `has_normals` is a property of the map, fixed by the
+    caller for all ranks (a rank whose share of a scan is empty has no normals array to infer it from) -- and rows that are not finite
+    are dropped before the owner is computed, as the device form does."""
     import numpy as np
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if has_normals is None:
+        has_normals = normals is not None
     points = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
-    cols = 3 if normals is None else 6
-    rows = points if normals is None else np.hstack([points, np.ascontiguousarray(normals, dtype=np.float64).reshape(-1, 3)])
+    nrm = np.zeros_like(points) if normals is None else np.ascontiguousarray(normals, dtype=np.float64).reshape(-1, 3)
+    keep = np.isfinite(points).all(axis=1)
+    points, nrm = points[keep], nrm[keep]
     if world == 1:
-        return points, normals
+        return points, (nrm if has_normals else None)
+    rows = np.hstack([points, nrm])
     owner = voxel_owner(points, voxel, world, storage)
     order = np.argsort(owner, kind="stable")  # rows grouped by destination, original order kept inside a group
     send_counts = np.bincount(owner, minlength=world).astype(np.int64)
@@ -173,44 +214,72 @@ def exchange_by_owner(points, normals, voxel: float, group=None, device=None, st
     t_send = torch.from_numpy(np.ascontiguousarray(rows[order]))
     if device is not None:
         t_send = t_send.to(device)
-    t_recv = torch.empty((int(recv_counts.sum()), cols), dtype=torch.float64, device=t_send.device)
+    t_recv = torch.empty((int(recv_counts.sum()), 6), dtype=torch.float64, device=t_send.device)
     dist.all_to_all_single(t_recv, t_send, output_split_sizes=[int(c) for c in recv_counts], input_split_sizes=[int(c) for c in send_counts],
                            group=group)
     got = t_recv.cpu().numpy()
-    return got[:, :3].copy(), (None if normals is None else got[:, 3:].copy())
+    return got[:, :3].copy(), (got[:, 3:].copy() if has_normals else None)
 
 
 class ShardedDenseMap:
     """One VoxelizedPointCloud (Voxel.hpp:59-76) spread over the ranks of a process group by voxel owner.  insert() takes THIS rank's
-    share of a scan (e.g. the sensors attached to this GPU) already placed in the map frame, exchanges, and fuses the received rows
-    into the local device table (o3ds_dense_map_insert); size() is the global voxel count.  The exchange goes through torch tensors
-    on `device` (plumbing); the fusion is the backend's.  Host-staged: the rows come from / go to numpy on either side of the
-    collective -- an o3ds entry point that exports / imports device rows would remove two PCIe hops per insertion (not built)."""
+    share of a scan as a device cloud (or host arrays, uploaded first) and the pose that places it in the map frame.  On the device:
+    o3ds_cloud_export_rows_by_owner groups the placed rows by owner into a torch tensor, the group sizes travel first (world ints),
+    then ONE all_to_all_single of the rows between the GPUs (direct, not a ring: xGMI is point-to-point), o3ds_cloud_import_rows turns
+    what arrived into a cloud and o3ds_dense_map_insert fuses it into the local table.  Nothing goes through host memory except the
+    split sizes, which torch.distributed needs as Python ints.  size() is the global voxel count."""
 
-    def __init__(self, be, voxel: float, group=None, device=None):
-        self.be, self.voxel, self.group, self.device = be, float(voxel), group, device
-        self.storage = "f64" if getattr(be, "precision", 0) == 1 else "f32"  # backend.PRECISION_F64 == 1
+    def __init__(self, be, voxel: float, group=None, has_normals: bool = True):
+        import torch
+        import torch.distributed as dist
+
+        self.be, self.voxel, self.group, self.has_normals = be, float(voxel), group, bool(has_normals)
+        self.torch, self.dist = torch, dist
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.device = torch.device(f"cuda:{be.device_id}")
         self.dm = be.dense_map_create(self.voxel)
+        # the backend's kernels and the collective share one torch stream, as in ShardedIcp
+        self.tstream = torch.cuda.Stream(device=self.device)
+        be.set_stream(self.tstream.cuda_stream)
 
-    def insert(self, points, normals=None):
-        p, n = exchange_by_owner(points, normals, self.voxel, self.group, self.device, self.storage)
-        if len(p):
-            c = self.be.upload(p, n)
-            self.be.dense_map_insert(self.dm, c)
-            self.be.free(c)
-        return len(p)
+    def insert(self, cloud, T=None, normals=None) -> int:
+        """cloud: a device cloud id of this backend, or host points (n x 3) [+ normals].  Returns the number of rows this rank fused."""
+        be, torch, dist = self.be, self.torch, self.dist
+        own = not isinstance(cloud, int)
+        cid = be.upload(cloud, normals) if own else cloud
+        n = be.size(cid)[0]
+        with torch.cuda.stream(self.tstream):
+            rows = torch.empty((max(n, 1), 6), dtype=torch.float64, device=self.device)
+            counts = torch.zeros(self.world, dtype=torch.int64, device=self.device)
+            be.export_rows_by_owner(cid, T, self.voxel, self.world, rows.data_ptr(), counts.data_ptr())
+            if self.world > 1:
+                recv_counts = torch.empty_like(counts)
+                dist.all_to_all_single(recv_counts, counts, group=self.group)
+                send_split = [int(c) for c in counts.cpu()]
+                recv_split = [int(c) for c in recv_counts.cpu()]
+                got = torch.empty((sum(recv_split), 6), dtype=torch.float64, device=self.device)
+                dist.all_to_all_single(got, rows[: sum(send_split)], output_split_sizes=recv_split, input_split_sizes=send_split, group=self.group)
+            else:
+                got = rows[: int(counts.sum().item())]
+            m = int(got.shape[0])
+            if m:
+                c = be.import_rows(got.data_ptr(), m, self.has_normals)
+                be.dense_map_insert(self.dm, c)
+                be.free(c)
+            self.tstream.synchronize()  # `rows` / `got` go back to torch's allocator when this returns
+        if own:
+            be.free(cid)
+        return m
 
     def local_size(self) -> int:
         return self.be.dense_map_size(self.dm)
 
     def size(self) -> int:
-        import torch
-        import torch.distributed as dist
-
-        t = torch.tensor([self.local_size()], dtype=torch.int64, device=self.device)
-        if dist.is_initialized():
-            dist.all_reduce(t, group=self.group)
+        t = self.torch.tensor([self.local_size()], dtype=self.torch.int64, device=self.device)
+        if self.dist.is_initialized() and self.world > 1:
+            self.dist.all_reduce(t, group=self.group)
         return int(t.item())
 
     def close(self):
         self.be.dense_map_free(self.dm)
+        self.be.set_stream(None)

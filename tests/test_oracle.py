@@ -578,3 +578,43 @@ def test_merge_colours_last_point_wins_c_matches_numpy(oracle):
     np.testing.assert_array_equal(oc, [[0, 1.0, 0], [0.25, 0.5, 0.75]])
     # voxel_size <= 0: untouched
     np.testing.assert_array_equal(oracle.voxelize_within_volume_colors(p, c, 0.0, crop), c)
+
+
+# ---- the pin against the real Open3D v0.15.1 (oracle/pin_against_open3d.py): one command on any machine that has the wheel
+def _vectors_from_numpy_restatement():
+    """the arrays pin_against_open3d.open3d_vectors() takes from Open3D, produced here by the numpy restatement instead: exercises the
+    comparison code of the recipe (and is itself the C-oracle == numpy check on those workloads)"""
+    from open3d_slam_amd import synthetic as syn
+    from oracle import np_oracle as no
+
+    src, tgt, nrm, _ = syn.config2_inputs(n_map=50_000, n_az=128)
+    r = no.icp_point_to_plane(src, tgt, nrm, 1.0, max_iter=10, rel_fitness=0.0, rel_rmse=0.0)
+    rc = no.icp_point_to_plane(src, tgt, nrm, 1.0, max_iter=30)
+    rp = no.icp_point_to_point(src, tgt, 1.0, max_iter=10, rel_fitness=0.0, rel_rmse=0.0)
+    vec = dict(g1_T10=r["transformation"], g1_fitness10=r["fitness"], g1_rmse10=r["inlier_rmse"], g1_Tconv=rc["transformation"],
+               g1_fitness_conv=rc["fitness"], g1_rmse_conv=rc["inlier_rmse"], g1_p2p_T10=rp["transformation"], g1_p2p_fitness10=rp["fitness"],
+               g1_p2p_rmse10=rp["inlier_rmse"], g1_info=no.information_matrix(src, tgt, 0.3, rc["transformation"]))
+    a, b = syn.config1_inputs(n_az=256)
+    av, _ = no.voxel_down_sample(a, 0.1)
+    bv, _ = no.voxel_down_sample(b, 0.1)
+    an, bn = no.estimate_normals(av, 3.0, 20), no.estimate_normals(bv, 3.0, 20)
+    r2 = no.icp_point_to_plane(av, bv, bn, 1.0, max_iter=10, rel_fitness=0.0, rel_rmse=0.0)
+    rg = no.icp_generalized(av, an, bv, bn, 1.0, max_iter=10, rel_fitness=0.0, rel_rmse=0.0)
+    vec.update(g2_av=av, g2_bv=bv, g2_bn=bn, g2_an=an, g2_T10=r2["transformation"], g2_fitness10=r2["fitness"], g2_rmse10=r2["inlier_rmse"],
+               g2_gicp_T10=rg["transformation"], g2_gicp_fitness10=rg["fitness"], g2_gicp_rmse10=rg["inlier_rmse"])
+    return vec
+
+
+def test_pin_recipe_runs_and_both_restatements_agree_on_its_workloads(oracle):
+    from oracle import pin_against_open3d as pin
+
+    assert pin.compare(_vectors_from_numpy_restatement(), verbose=False) == []
+
+
+def test_oracle_pinned_against_open3d(oracle):
+    """PARITY PIN: every golden array regenerated from Open3D itself.  Skipped where Open3D cannot be imported (this image)."""
+    from oracle import pin_against_open3d as pin
+
+    if not pin.have_open3d():
+        pytest.skip("open3d is not importable in this image: parity stays unpinned (python oracle/pin_against_open3d.py is the recipe)")
+    assert pin.compare(pin.open3d_vectors(), verbose=True) == []

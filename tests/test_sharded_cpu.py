@@ -155,6 +155,72 @@ def test_world2_gloo_matches_single_process(tmp_path, oracle, mode):
         assert dt < 5e-3 and dr < 1e-3
 
 
+# ---- Partitioning B ("union"): ONE map split over the ranks, the per-query argmin decided by a MIN all-reduce of 64-bit keys
+def _union_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    from oracle import pyoracle as oracle
+
+    oracle.lib().orc_set_num_threads(2)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scene = syn.make_scene()
+    src = syn.vlp16_scan(scene, syn.ground_truth_pose(), n_az=128)
+    tgt_all, nrm_all = syn.sample_map(scene, 40_000)
+    mine = np.flatnonzero((tgt_all[:, 0] < 0.0) == (rank == 0))  # two spatial shards: x < 0 and x >= 0
+    tgt, nrm = tgt_all[mine], nrm_all[mine]
+    tree = oracle.KDTree(tgt)
+    st = _HostIcpState(np.eye(4), 30, 1e-6, 1e-6)
+    rec_t = torch.zeros(32, dtype=torch.float64)
+    NO_KEY = np.int64(0x7FFFFFFFFFFFFFFF)
+
+    def accumulate():
+        P = src @ st.T[:3, :3].T + st.T[:3, 3]
+        corr, d2, _, _, _ = oracle.evaluate(tree, P, 1.0)
+        # the key of include/o3ds_backend.h (o3ds_icp_nn_keys): float bits of d2 << 32 | rank << 28 | position in this shard
+        bits = np.asarray(d2, dtype=np.float32).view(np.uint32).astype(np.int64)
+        keys = np.where(corr >= 0, (bits << 32) | (np.int64(rank) << 28) | corr.astype(np.int64), NO_KEY)
+        kt = torch.from_numpy(keys.copy())
+        dist.all_reduce(kt, op=dist.ReduceOp.MIN)
+        win = kt.numpy()
+        won = (win != NO_KEY) & (((win >> 28) & 0xF) == rank)
+        c2 = np.where(won, win & 0x0FFFFFFF, -1).astype(corr.dtype)
+        rec = np.zeros(32)
+        if won.any():
+            JTJ, JTr, r2 = oracle.compute_jtj_jtr(P, tgt, nrm, c2)
+            rec[:21] = JTJ[np.triu_indices(6)]
+            rec[21:27] = JTr
+            d = P[won] - tgt[c2[won]]
+            rec[27], rec[28], rec[29] = r2, won.sum(), np.einsum("ij,ij->", d, d)
+        rec_t.copy_(torch.from_numpy(rec))
+        return rec_t
+
+    sharded.run_sharded_loop(accumulate, lambda r: dist.all_reduce(r), lambda r: st.step(r.numpy(), len(src), oracle), lambda: st.done, 30,
+                             check_every=1)
+    Ts = [torch.zeros(16, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(Ts, torch.from_numpy(st.T.ravel().copy()))
+    if rank == 0:
+        np.savez(out_path, T=st.T, fitness=st.fitness, rmse=st.rmse, iterations=st.iterations, converged=st.converged,
+                 all_T=np.stack([t.numpy() for t in Ts]))
+    dist.destroy_process_group()
+
+
+def test_world2_union_equals_registration_against_the_whole_map(tmp_path, oracle):
+    """the key exchange reproduces the reference's registration against ONE cloud (Mapper.cpp:141): pose, fitness, rmse and iteration
+    count of the two-shard run equal the oracle's ICP against the concatenated map"""
+    out = str(tmp_path / "union.npz")
+    mp.spawn(_union_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r = np.load(out)
+    np.testing.assert_array_equal(r["all_T"][0], r["all_T"][1])
+    scene = syn.make_scene()
+    src = syn.vlp16_scan(scene, syn.ground_truth_pose(), n_az=128)
+    tgt, nrm = syn.sample_map(scene, 40_000)
+    ref = oracle.icp_point_to_plane(src, tgt, nrm, 1.0, max_iter=30)
+    np.testing.assert_allclose(r["T"], ref["transformation"], atol=1e-9)
+    assert int(r["iterations"]) == ref["iterations"] and bool(r["converged"]) == ref["converged"]
+    assert abs(float(r["fitness"]) - ref["fitness"]) < 1e-12 and abs(float(r["rmse"]) - ref["inlier_rmse"]) < 1e-9
+
+
 def test_fused_loop_control_flow():
     """run_sharded_fused_loop: max_iteration + 1 passes, one all-reduce per pass on the buffer that pass returned, the device's
     `done` polled every check_every passes only, and never after the last pass."""
@@ -208,6 +274,18 @@ def _fusion_worker(rank, world, port, out_dir):
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), p=fp, n=fn, c=fc, received=received)
     empty_p, empty_n = sharded.exchange_by_owner(np.zeros((0, 3)), None, voxel, None, None)  # a rank with nothing to send still takes part
     assert empty_p.shape == (0, 3) and empty_n is None
+    # the map has normals, but rank 1's share of this scan is empty and it has no normals array to pass; rank 0's share has a NaN return:
+    # six columns travel from everybody (no mismatched row sizes), the NaN row goes nowhere
+    if rank == 0:
+        pts, nrm = syn.sample_map(scene, 3_000, seed=777)
+        pts[5] = np.nan
+        p, n = sharded.exchange_by_owner(pts, nrm, voxel, None, None, has_normals=True)
+    else:
+        p, n = sharded.exchange_by_owner(np.zeros((0, 3)), None, voxel, None, None, has_normals=True)
+    assert n is not None and n.shape == p.shape and np.isfinite(p).all()
+    tot = torch.tensor([len(p)])
+    dist.all_reduce(tot)
+    assert int(tot.item()) == 2_999
     dist.destroy_process_group()
 
 

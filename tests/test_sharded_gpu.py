@@ -34,6 +34,9 @@ def _worker(rank, world, port, mode, out_path):
     scene = syn.make_scene()
     src = syn.vlp16_scan(scene, syn.ground_truth_pose(), n_az=512)
     tgt, nrm = syn.sample_map(scene, 100_000, seed=syn.SEED_MAP + (rank if mode == "submap" else 0))
+    if mode == "union":  # ONE map in two spatial shards
+        mine = (tgt[:, 0] < 0.0) == (rank == 0)
+        tgt, nrm = tgt[mine], nrm[mine]
     be = backend.Backend(0, backend.PRECISION_F64)
     s, t = be.upload(src), be.upload(tgt, nrm)
     be.build_index(t, 1.0)
@@ -48,7 +51,7 @@ def _worker(rank, world, port, mode, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["source", "submap"])
+@pytest.mark.parametrize("mode", ["source", "submap", "union"])
 def test_two_ranks_one_gpu(tmp_path, backend_f64, oracle, mode):
     import torch.multiprocessing as mp
 
@@ -60,10 +63,10 @@ def test_two_ranks_one_gpu(tmp_path, backend_f64, oracle, mode):
     np.testing.assert_array_equal(r["all_T"][0], r["all_T"][1])  # identical pose on every rank, no broadcast
     scene = syn.make_scene()
     src = syn.vlp16_scan(scene, syn.ground_truth_pose(), n_az=512)
-    if mode == "source":
+    if mode in ("source", "union"):  # both equal the one-GPU registration against the whole map
         tgt, nrm = syn.sample_map(scene, 100_000)
         one = backend_f64.icp_point_to_plane(src, tgt, nrm, 1.0, max_iter=30)
-        np.testing.assert_allclose(r["T"], one["transformation"], atol=1e-10)
+        np.testing.assert_allclose(r["T"], one["transformation"], atol=1e-10 if mode == "source" else 1e-8)
         assert int(r["iterations"]) == one["iterations"] and bool(r["converged"]) == one["converged"]
         assert abs(float(r["fitness"]) - one["fitness"]) < 1e-12
     else:
@@ -71,3 +74,83 @@ def test_two_ranks_one_gpu(tmp_path, backend_f64, oracle, mode):
         # compare with the truth instead (the CPU gloo test checks the joint algebra against the oracle)
         dt, dr = syn.se3_error(r["T"], syn.ground_truth_pose())
         assert dt < 5e-3 and dr < 1e-3 and bool(r["converged"])
+
+
+# ---- ONE dense voxel map over two ranks, rows exchanged between device buffers (sharded.ShardedDenseMap; BASELINE configs[4]) ----------
+def _dense_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from open3d_slam_amd import backend, sharded, synthetic as syn
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scene = syn.make_scene()
+    be = backend.Backend(0, backend.PRECISION_F64)
+    dm = sharded.ShardedDenseMap(be, 0.1, has_normals=True)
+    fused = 0
+    for ins in range(3):  # ragged shares, one of them empty, one with a NaN return, each placed by its own pose
+        n = 0 if (rank == 1 and ins == 1) else 20_000 + 5_000 * rank + 1_000 * ins
+        pts, nrm = syn.sample_map(scene, max(n, 1), seed=100 + 10 * ins + rank)
+        pts, nrm = pts[:n], nrm[:n]
+        if rank == 0 and ins == 2:
+            pts = pts.copy()
+            pts[7] = np.nan
+        T = syn.make_pose((0.3 * ins, -0.2 * rank, 0.05), (0.0, 0.0, 5.0 * ins))
+        if n:
+            c = be.upload(pts, nrm)
+            fused += dm.insert(c, T)
+            be.free(c)
+        else:
+            fused += dm.insert(np.zeros((0, 3)), T)
+    total = dm.size()
+    c = be.dense_map_to_cloud(dm.dm)
+    vp, vn = be.download(c)
+    np.savez(os.path.join(out_dir, f"dense{rank}.npz"), p=vp, n=vn, fused=fused, total=total)
+    dm.close()
+    be.close()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_dense_map_fusion_on_device(tmp_path, backend_f64):
+    import torch.multiprocessing as mp
+    from scipy.spatial import cKDTree
+
+    from open3d_slam_amd import synthetic as syn
+
+    mp.spawn(_dense_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    parts = [np.load(str(tmp_path / f"dense{r}.npz")) for r in range(2)]
+    # the same insertions into ONE map on one rank
+    scene = syn.make_scene()
+    be = backend_f64
+    one = be.dense_map_create(0.1)
+    n_all = 0
+    for ins in range(3):
+        for rank in range(2):
+            n = 0 if (rank == 1 and ins == 1) else 20_000 + 5_000 * rank + 1_000 * ins
+            if not n:
+                continue
+            pts, nrm = syn.sample_map(scene, n, seed=100 + 10 * ins + rank)
+            if rank == 0 and ins == 2:
+                pts, nrm = np.delete(pts, 7, axis=0), np.delete(nrm, 7, axis=0)  # the NaN return never reaches a map
+            c = be.upload(pts, nrm)
+            be.dense_map_insert(one, c, syn.make_pose((0.3 * ins, -0.2 * rank, 0.05), (0.0, 0.0, 5.0 * ins)))
+            be.free(c)
+            n_all += len(pts)
+    c = be.dense_map_to_cloud(one)
+    rp, rn = be.download(c)
+    be.free(c)
+    be.dense_map_free(one)
+    assert sum(int(p["fused"]) for p in parts) == n_all  # nothing lost, nothing duplicated, the NaN row dropped
+    assert int(parts[0]["total"]) == int(parts[1]["total"]) == len(rp)
+    got_p, got_n = np.vstack([p["p"] for p in parts]), np.vstack([p["n"] for p in parts])
+    d, j = cKDTree(rp).query(got_p)
+    assert len(np.unique(j)) == len(rp) and d.max() < 1e-9  # a bijection between the sharded voxels and the single map's
+    np.testing.assert_allclose(got_n, rn[j], atol=1e-9)
+    # no voxel on both ranks: the two ranks' voxels map to disjoint voxels of the single map, and together they are all of them
+    # (keys are not recomputed from the means here: the room's walls lie ON voxel faces and a mean may sit 1e-9 beside its face)
+    n0 = len(parts[0]["p"])
+    assert len(got_p) == len(rp) and not (set(j[:n0].tolist()) & set(j[n0:].tolist()))
