@@ -364,6 +364,7 @@ def main():
     ap.add_argument("--m2-frames", type=int, default=200, help="frames of the configs[2] stream (0: skip M2)")
     ap.add_argument("--m2-cpu-frames", type=int, default=40)
     ap.add_argument("--no-f64", action="store_true")
+    ap.add_argument("--concurrent", type=int, default=4, help="registrations in flight at once for the `concurrent` line (0 / 1: skip)")
     ap.add_argument("--config", default="auto", choices=["auto", "1", "3", "3u", "4"],
                     help="BASELINE.json configs: 1 = scan vs 1M map on one GPU (+ M2); 3 = joint registration over one submap per GPU (sum of the "
                          "per-submap normal equations); 3u = ONE map split over the GPUs, union-equivalent (key MIN all-reduce + record sum); "
@@ -440,6 +441,44 @@ def main():
         return dict(res=res, elapsed=elapsed, index_build_ms=index_build_ms, n_launch=n_launch, avg_kernel_s=avg_kernel_s, gbs=gbs)
 
     r32 = m1(backend.PRECISION_F32, args.steps, args.warmup)
+
+    # ---- the same registration from several host threads at once, one handle (= one HIP stream) each: how open3d_slam calls it
+    # (odometry, mapping and loop-closure workers register concurrently, SlamWrapper.cpp:258-347).  One 64k-query grid is a single wave of
+    # workgroups and a registration is a chain of dependent launches, so one stream leaves most of the chip idle most of the time.
+    conc = None
+    if world == 1 and args.config == "1" and args.concurrent > 1:
+        import threading
+
+        K = args.concurrent
+        bes = [backend.Backend(local_rank) for _ in range(K)]
+        ids = []
+        for b in bes:
+            s_id, t_id = b.upload(src), b.upload(tgt, nrm)
+            b.build_index(t_id, MAX_CORR, args.cell)
+            ids.append((s_id, t_id))
+        steps_c = max(args.steps // 2, 1)
+
+        def work(b, s_id, t_id, n):
+            for _ in range(n):
+                b.icp_point_to_plane_dev(s_id, t_id, MAX_CORR, max_iter=ICP_ITERS, rel_fitness=0.0, rel_rmse=0.0)
+
+        for b, (s_id, t_id) in zip(bes, ids):
+            work(b, s_id, t_id, 3)
+        torch.cuda.synchronize()
+        th = [threading.Thread(target=work, args=(b, s_id, t_id, steps_c)) for b, (s_id, t_id) in zip(bes, ids)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        conc = {"streams": K, "value": K * steps_c * ICP_ITERS / el, "unit": "icp_iterations/s (sum over the streams)", "steps_per_stream": steps_c,
+                "ms_per_step_per_stream": el / steps_c * 1e3,
+                "algorithmic_gbs": K * steps_c * (ICP_ITERS + 1) * algo_bytes / el / 1e9,
+                "frac_of_hbm_peak_over_wall_time": K * steps_c * (ICP_ITERS + 1) * algo_bytes / el / 1e9 / HBM_PEAK_GBS}
+        for b in bes:
+            b.close()
     r64 = None if args.no_f64 else m1(backend.PRECISION_F64, max(args.steps // 2, 1), args.warmup)
 
     # measured device copy bandwidth on this box (report against the vendor peak AND a measured copy kernel)
@@ -523,6 +562,8 @@ def main():
             out["m1_f64"] = {"value": ICP_ITERS * s64 / r64["elapsed"], "unit": "icp_iterations/s", "steps": s64, "ms_per_step": r64["elapsed"] / s64 * 1e3,
                              "dtype": "f64", "index_build_ms": r64["index_build_ms"], "roofline": roof(r64),
                              "pose_vs_f32_storage": {"dt_m": d64[0], "dr_rad": d64[1]}}
+        if conc is not None:
+            out["concurrent"] = conc
         if m2 is not None:
             out["scans_per_sec"] = {"workload": f"configs[2]: OS-128-like stream, {len(scans32[0])} raw float32 points/scan, {args.m2_frames} frames, "
                                                 "LidarOdometry::addRangeScan + Mapper::addRangeMeasurement through the host classes (voxel 0.1, knn 20 / r 3, "

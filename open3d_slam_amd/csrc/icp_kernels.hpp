@@ -1145,8 +1145,11 @@ __device__ __forceinline__ void solve6_wave(const double* rec, double* x_out, in
     }
     const double d = O3DS_BCAST(a[s], s);
     const double bs = O3DS_BCAST(b, s);
-    rd[s] = 1.0 / d;
-    const double l = a[s] * rd[s];
+    // Eigen's LDLT, which [O3D] SolveLinearSystemPSD uses: a column under an exactly zero pivot is left undivided (ldlt_inplace:
+    // pivot_is_valid), and the solve zeroes the components of pivots not above the smallest normal double (_solve_impl) -- a scene of
+    // one plane, or fewer than six independent correspondences, gives a finite update instead of inf / NaN
+    rd[s] = fabs(d) > 2.2250738585072014e-308 ? 1.0 / d : 0.0;
+    const double l = d != 0.0 ? a[s] * (1.0 / d) : a[s];
     const bool below = lane > s && lane < 6;
 #pragma unroll
     for (int j = s + 1; j < 6; ++j) {
@@ -1162,7 +1165,9 @@ __device__ __forceinline__ void solve6_wave(const double* rec, double* x_out, in
     double num = b;
 #pragma unroll
     for (int j = i + 1; j < 6; ++j) num -= a[j] * xs[j];
-    const double xi = num * rd[i];  // a[i] of lane i is pivot i
+    // a[i] of lane i is pivot i; after the elimination a[j] (j > i) of lane i is D_i L_ji (L_ji itself under an invalid pivot), so
+    // with z_i = y_i / D_i (0 under an invalid pivot): w_i = z_i - sum_j L_ji w_j
+    const double xi = rd[i] != 0.0 ? num * rd[i] : num - b;
     xs[i] = O3DS_BCAST(xi, i);
     if (lane == i) mine = xi;
   }

@@ -385,8 +385,11 @@ int orc_solve_update(const double JTJ[36], const double JTr[6], double U[16], do
       perm[piv] = tp;
     }
     double d = A[k][k];
+    /* Eigen ldlt_inplace: "pivot_is_valid = abs(realAkk) > 0; if (pivot_is_valid) A21 /= realAkk" -- a column under an exactly
+     * zero pivot is left undivided (it is zero itself for a PSD matrix: e.g. a scene of one plane, whose in-plane translations and
+     * the rotation about its normal have all-zero rows in J^T J) */
     for (int i = k + 1; i < 6; ++i) {
-      double l = A[i][k] / d;
+      double l = d != 0.0 ? A[i][k] / d : A[i][k];
       for (int j = k + 1; j < 6; ++j) A[i][j] -= l * A[k][j];
       A[i][k] = l; /* store L */
     }
@@ -401,7 +404,9 @@ int orc_solve_update(const double JTJ[36], const double JTr[6], double U[16], do
   /* D z = y ; L^T w = z */
   double w[6];
   for (int i = 5; i >= 0; --i) {
-    double s = y[i] / A[i][i];
+    /* Eigen LDLT::_solve_impl: "if (abs(vecD(i)) > (numeric_limits<double>::min)()) dst.row(i) /= vecD(i); else dst.row(i).setZero()":
+     * the components a (near-)null pivot leaves undetermined come out as zero, not as inf / NaN */
+    double s = fabs(A[i][i]) > DBL_MIN ? y[i] / A[i][i] : 0.0;
     for (int j = i + 1; j < 6; ++j) s -= A[j][i] * w[j];
     w[i] = s;
   }

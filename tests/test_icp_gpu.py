@@ -542,3 +542,22 @@ def test_large_coordinates_and_exact_sums(backend_f64, oracle, small_c2):
         del os.environ["O3DS_PASS_ROWS"]
     dt, dr = syn.se3_error(other["transformation"], got["transformation"])
     assert dt <= lim_t and dr <= lim_r, (dt, dr, lim_t, lim_r)
+
+
+def test_rank_deficient_normal_equations_follow_eigen_ldlt(backend_f64, oracle):
+    """A scene of ONE plane leaves x / y translation and yaw unobservable (exactly zero rows of J^T J), and one or two correspondences
+    leave most of the six unknowns free.  [O3D] solves with Eigen's LDLT, which returns zero for the components of null pivots; the
+    device's solve does the same (icp_kernels.hpp solve6_wave) -- finite poses equal to the oracle's, never inf / NaN."""
+    rng = np.random.default_rng(11)
+    g = np.stack(np.meshgrid(np.arange(-8, 8, 0.25), np.arange(-8, 8, 0.25)), -1).reshape(-1, 2)
+    tgt = np.c_[g, np.zeros(len(g))]
+    nrm = np.tile([0.0, 0.0, 1.0], (len(tgt), 1))
+    src = np.c_[rng.uniform(-6, 6, (500, 2)), 0.04 + 0.02 * rng.uniform(-1, 1, 500)]
+    for s in (src, src[:2], src[:1]):
+        got = backend_f64.icp_point_to_plane(s, tgt, nrm, 0.5, max_iter=5, rel_fitness=0.0, rel_rmse=0.0)
+        ref = oracle.icp_point_to_plane(s, tgt, nrm, 0.5, max_iter=5, rel_fitness=0.0, rel_rmse=0.0)
+        assert np.isfinite(got["transformation"]).all() and np.isfinite(ref["transformation"]).all()
+        np.testing.assert_allclose(got["transformation"], ref["transformation"], atol=1e-9)
+        T = got["transformation"]
+        # the unobservable motions get no update of their own (what little x / y appears is the tilt acting on the z offset)
+        assert abs(T[0, 3]) < 1e-6 and abs(T[1, 3]) < 1e-6 and abs(T[1, 0]) < 1e-6

@@ -618,3 +618,23 @@ def test_oracle_pinned_against_open3d(oracle):
     if not pin.have_open3d():
         pytest.skip("open3d is not importable in this image: parity stays unpinned (python oracle/pin_against_open3d.py is the recipe)")
     assert pin.compare(pin.open3d_vectors(), verbose=True) == []
+
+
+def test_solve_update_with_null_pivots_follows_eigen_ldlt(oracle):
+    """[O3D] SolveLinearSystemPSD = Eigen's LDLT: a column under an exactly zero pivot is left undivided and the solve sets the
+    components of (near-)null pivots to zero.  A scene of ONE plane (all normals +z) makes x / y translation and yaw unobservable:
+    their rows of J^T J are exactly zero, and the update must leave them at zero instead of returning inf / NaN."""
+    rng = np.random.default_rng(5)
+    P = np.c_[rng.uniform(-5, 5, (200, 2)), 0.03 + 0.01 * rng.uniform(-1, 1, 200)]  # points a little above the plane z = 0
+    Q = np.c_[P[:, :2], np.zeros(200)]
+    N = np.tile([0.0, 0.0, 1.0], (200, 1))
+    JTJ, JTr, _ = oracle.compute_jtj_jtr(P, Q, N, np.arange(200, dtype=np.int64))
+    assert np.all(JTJ[2] == 0) and np.all(JTJ[3] == 0) and np.all(JTJ[4] == 0)  # yaw, tx, ty: exactly null
+    U, x = oracle.solve_update(JTJ, JTr)
+    assert np.isfinite(U).all() and np.isfinite(x).all()
+    assert x[2] == 0.0 and x[3] == 0.0 and x[4] == 0.0
+    keep = [0, 1, 5]
+    np.testing.assert_allclose(JTJ[np.ix_(keep, keep)] @ x[keep], -JTr[keep], rtol=1e-9, atol=1e-12)  # the observable part is solved
+    # all-zero system (no correspondence): the zero update
+    U0, x0 = oracle.solve_update(np.zeros((6, 6)), np.zeros(6))
+    assert np.array_equal(x0, np.zeros(6)) and np.array_equal(U0, np.eye(4))
