@@ -42,6 +42,10 @@ struct CloudRec {
   // A box that is known to contain every point (not necessarily tight): set where a bounding box has been computed anyway
   // (VoxelDownSample, an index build) and carried to clouds derived from it (subsets, voxel means, rigid placements, unions), so
   // that the next index build of the per-scan pipeline does not pay a reduction kernel + read-back + host sync for it again.
+  // layout left by the map merge: [pass-through block | voxel block in ascending key order]; vox_first < 0 = unknown (any other
+  // operation that reorders or moves points resets it), see voxel_reduce_t
+  long long vox_first = -1;
+  size_t vox_count = 0;
   bool has_box = false;
   bool box_padded = false;  // the box already has a margin against the rounding of derived values (never padded twice: a map is
                             // re-voxelised at every insertion and its box must not creep outwards over a long mission)
@@ -435,22 +439,24 @@ void free_cloud(o3ds_handle h, CloudRec& c) {
 }
 
 // exclusive scan of m ints (in -> out) with the hand-written 3-phase scan; in may alias out
-int exclusive_scan_int(o3ds_handle h, const int* in, int* out, size_t m) {
+template <typename T>
+int exclusive_scan_t(o3ds_handle h, const T* in, T* out, size_t m) {
   if (m == 0) return O3DS_OK;
   const int nb = (int)((m + kScanPerBlock - 1) / kScanPerBlock);
-  int* sums = nullptr;
-  TMP_ALLOC(sums, sizeof(int) * (size_t)nb);
-  scan_local_kernel<<<nb, kBlock, 0, h->stream>>>(in, out, sums, m);
+  T* sums = nullptr;
+  TMP_ALLOC(sums, sizeof(T) * (size_t)nb);
+  scan_local_kernel<T><<<nb, kBlock, 0, h->stream>>>(in, out, sums, m);
   if (nb > 1 && nb <= kScanFusedBlocks) {
-    scan_add_fused_kernel<<<nb, kBlock, 0, h->stream>>>(out, sums, m);
+    scan_add_fused_kernel<T><<<nb, kBlock, 0, h->stream>>>(out, sums, m);
   } else if (nb > 1) {
-    scan_sums_kernel<<<1, kBlock, 0, h->stream>>>(sums, nb);
-    scan_add_kernel<<<nb, kBlock, 0, h->stream>>>(out, sums, m);
+    scan_sums_kernel<T><<<1, kBlock, 0, h->stream>>>(sums, nb);
+    scan_add_kernel<T><<<nb, kBlock, 0, h->stream>>>(out, sums, m);
   }
   HIP_TRY(hipGetLastError());
   dbg_sync(h, 1);
   return O3DS_OK;  // results are stream-ordered; callers that need a value on the host copy it back and synchronise
 }
+int exclusive_scan_int(o3ds_handle h, const int* in, int* out, size_t m) { return exclusive_scan_t<int>(h, in, out, m); }
 
 template <typename P4>
 int bbox_of(o3ds_handle h, const P4* pts, size_t n, double mn[3], double mx[3], const CropDev* crop = nullptr) {
@@ -1802,7 +1808,9 @@ int crop_t(o3ds_handle h, const CloudRec& in, const CropDev& crop, CloudRec& out
 
 // shared by VoxelDownSample (mode 0) and voxelizeWithinCroppingVolume (mode 1)
 template <typename P4>
-int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, const CropDev& crop, CloudRec& out, bool filter = false) {
+int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, const CropDev& crop, CloudRec& out, bool filter = false,
+                   long long merge_np = -1 /* >= 0: `in` is [pass block: merge_np | voxel block in key order: merge_nv | new points] */,
+                   size_t merge_nv = 0) {
   // filter (mode 0 only): CroppingVolume::crop followed by VoxelDownSample in one go -- the points outside `crop` are keyed as
   // pass-through, sort behind the voxels and are not emitted; same grid anchor (the box of the INSIDE points), same keys, same
   // summation order as cropping first, without the compaction, its scan and its size read-back
@@ -1831,6 +1839,7 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
   if (out.has_box) box_inflate(out);
   unsigned long long *k0 = nullptr, *k1 = nullptr, *d_scalar = nullptr;
   uint32_t *v0 = nullptr, *v1 = nullptr;
+  size_t merged_n_inside = 0;
   int *head = nullptr, *seg_id = nullptr, *seg_start = nullptr;
   TMP_ALLOC(k0, sizeof(unsigned long long) * n);
   TMP_ALLOC(k1, sizeof(unsigned long long) * n);
@@ -1839,21 +1848,86 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
   TMP_ALLOC(head, sizeof(int) * (n + 1));
   TMP_ALLOC(seg_id, sizeof(int) * (n + 1));
   TMP_ALLOC(d_scalar, sizeof(unsigned long long));
-  voxel_key_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>((const P4*)in.pts, n, mode, ox, oy, oz, voxel, crop, k0, v0, filter ? 1 : 0);
-  size_t temp_bytes = 0;
-  HIP_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, k0, k1, v0, v1, n, 0, 64, h->stream));
-  void* temp = nullptr;
-  TMP_ALLOC(temp, temp_bytes ? temp_bytes : 16);
-  HIP_TRY(rocprim::radix_sort_pairs(temp, temp_bytes, k0, k1, v0, v1, n, 0, 64, h->stream));
+  // The sorted (key, index) list: by merging when the input is a map the previous merge left in key order plus new points (only the
+  // new keys are sorted), by one radix sort of everything otherwise.  Same arrays either way (cloud_kernels.hpp, merge_class_kernel).
+  static const bool no_incremental = getenv("O3DS_NO_INCREMENTAL_MERGE") != nullptr;  // A/B and debugging
+  bool merged = false;
+  if (mode == 1 && !filter && merge_np >= 0 && !no_incremental && n < ((size_t)1 << 21) && (size_t)merge_np + merge_nv <= n) {
+    const size_t np = (size_t)merge_np, nv = merge_nv;
+    unsigned long long *cls = nullptr, *rank = nullptr, *vk = nullptr, *xk = nullptr, *xk2 = nullptr;
+    uint32_t *vv = nullptr, *xv = nullptr, *xv2 = nullptr;
+    int* d_unsorted = nullptr;
+    const size_t nx_cap = n - nv;  // the pass block and the new points
+    TMP_ALLOC(cls, sizeof(unsigned long long) * (n + 1));
+    TMP_ALLOC(rank, sizeof(unsigned long long) * (n + 1));
+    TMP_ALLOC(vk, sizeof(unsigned long long) * (nv + 1));
+    TMP_ALLOC(vv, sizeof(uint32_t) * (nv + 1));
+    TMP_ALLOC(xk, sizeof(unsigned long long) * (nx_cap + 1));
+    TMP_ALLOC(xv, sizeof(uint32_t) * (nx_cap + 1));
+    TMP_ALLOC(d_unsorted, sizeof(int));
+    HIP_TRY(hipMemsetAsync(d_unsorted, 0, sizeof(int), h->stream));
+    merge_class_kernel<P4><<<grid_for(n + 1), kBlock, 0, h->stream>>>((const P4*)in.pts, n, voxel, crop, np, nv, k0, cls, d_unsorted);
+    int rcs = exclusive_scan_t<unsigned long long>(h, cls, rank, n + 1);
+    if (rcs) return rcs;
+    unsigned long long tot = 0;
+    int unsorted = 0;
+    rcs = read_back(h, {{&tot, rank + n, sizeof(tot)}, {&unsorted, d_unsorted, sizeof(int)}});
+    if (rcs) return rcs;
+    if (!unsorted) {
+      const size_t npass_ = (size_t)(tot & kCntMask), nvin = (size_t)((tot >> 21) & kCntMask), nx = (size_t)((tot >> 42) & kCntMask);
+      merge_split_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(k0, rank, n, np, nv, k1, v1, vk, vv, xk, xv);
+      const unsigned long long* xks = xk;
+      const uint32_t* xvs = xv;
+      if (nx > 1) {  // the only sort: the points that are new to the volume
+        TMP_ALLOC(xk2, sizeof(unsigned long long) * nx);
+        TMP_ALLOC(xv2, sizeof(uint32_t) * nx);
+        size_t tb = 0;
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, xk, xk2, xv, xv2, nx, 0, 63, h->stream));
+        void* tmp = nullptr;
+        TMP_ALLOC(tmp, tb ? tb : 16);
+        HIP_TRY(rocprim::radix_sort_pairs(tmp, tb, xk, xk2, xv, xv2, nx, 0, 63, h->stream));
+        xks = xk2, xvs = xv2;
+      }
+      int *xpos = nullptr, *cnt = nullptr, *before = nullptr;
+      TMP_ALLOC(xpos, sizeof(int) * (nx + 1));
+      TMP_ALLOC(cnt, sizeof(int) * (nvin + 2));
+      TMP_ALLOC(before, sizeof(int) * (nvin + 2));
+      HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int) * (nvin + 2), h->stream));
+      if (nx) merge_rank_kernel<<<grid_for(nx), kBlock, 0, h->stream>>>(xks, xvs, nx, vk, nvin, np, xpos, cnt);
+      rcs = exclusive_scan_int(h, cnt, before, nvin + 2);
+      if (rcs) return rcs;
+      if (nvin + nx) merge_place_kernel<<<grid_for(nvin + nx), kBlock, 0, h->stream>>>(vk, vv, nvin, before, xks, xvs, xpos, nx, k1, v1);
+      (void)npass_;
+      merged = true;
+      merged_n_inside = nvin + nx;
+    }
+  }
+  if (!merged) {
+    voxel_key_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>((const P4*)in.pts, n, mode, ox, oy, oz, voxel, crop, k0, v0, filter ? 1 : 0);
+    size_t temp_bytes = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, k0, k1, v0, v1, n, 0, 64, h->stream));
+    void* temp = nullptr;
+    TMP_ALLOC(temp, temp_bytes ? temp_bytes : 16);
+    HIP_TRY(rocprim::radix_sort_pairs(temp, temp_bytes, k0, k1, v0, v1, n, 0, 64, h->stream));
+  }
   segment_head_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(k1, n, head);  // also writes the sentinel head[n] = 0
-  first_pass_kernel<<<1, 64, 0, h->stream>>>(k1, n, d_scalar);
+  if (!merged) first_pass_kernel<<<1, 64, 0, h->stream>>>(k1, n, d_scalar);
   int rc = exclusive_scan_int(h, head, seg_id, n + 1);
   if (rc) return rc;
   int n_seg = 0;
   unsigned long long n_inside = 0;
-  rc = read_back(h, {{&n_seg, seg_id + n, sizeof(int)}, {&n_inside, d_scalar, sizeof(n_inside)}});
+  if (merged) {
+    rc = read_back(h, {{&n_seg, seg_id + n, sizeof(int)}});
+    n_inside = merged_n_inside;
+  } else {
+    rc = read_back(h, {{&n_seg, seg_id + n, sizeof(int)}, {&n_inside, d_scalar, sizeof(n_inside)}});
+  }
   if (rc) return rc;
   const size_t n_pass = n - (size_t)n_inside;
+  if (mode == 1 && !filter) {  // the layout the next merge can rely on
+    out.vox_first = (long long)n_pass;
+    out.vox_count = (size_t)n_seg - n_pass;
+  }
   TMP_ALLOC(seg_start, sizeof(int) * ((size_t)n_seg + 1));
   segment_start_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(head, seg_id, n, seg_start);
   const int drop = filter ? 1 : 0;
@@ -2350,15 +2424,17 @@ int o3ds_cloud_append(o3ds_handle h, o3ds_cloud map, o3ds_cloud add) {
   return DISPATCH(m->precision, append_t, h, *m, *a);
 }
 
-int o3ds_voxelize_within_volume(o3ds_handle h, o3ds_cloud map, double voxel_size, const o3ds_crop* crop) {
-  CHECK_HANDLE(h);
-  ArenaScope arena_scope(h);
+}  // extern "C" (a helper with default arguments follows)
+namespace {
+// voxelizeWithinCroppingVolume of a device cloud in place; merge_np >= 0: the cloud is [pass block | voxel block in key order | new points]
+int voxelize_within_volume_impl(o3ds_handle h, o3ds_cloud map, double voxel_size, const o3ds_crop* crop, long long merge_np = -1, size_t merge_nv = 0) {
   CloudRec* m = find_cloud(h, map);
   if (!m) return fail(h, O3DS_ERR_INVALID_ARG, "voxelize_within_volume: unknown cloud id");
   if (voxel_size <= 0.0 || m->n == 0) return O3DS_OK;  // helpers.cpp:119-123 / Submap.cpp:139: unchanged
   CloudRec o;
   const CropDev cd = to_dev(crop);
-  int rc = DISPATCH(m->precision, voxel_reduce_t, h, *m, 1, voxel_size, cd, o);
+  int rc = m->precision == O3DS_PRECISION_F64 ? voxel_reduce_t<P4d>(h, *m, 1, voxel_size, cd, o, false, merge_np, merge_nv)
+                                              : voxel_reduce_t<P4f>(h, *m, 1, voxel_size, cd, o, false, merge_np, merge_nv);
   if (rc) {
     free_cloud(h, o);
     return rc;
@@ -2366,6 +2442,14 @@ int o3ds_voxelize_within_volume(o3ds_handle h, o3ds_cloud map, double voxel_size
   free_cloud(h, *m);
   *m = o;
   return O3DS_OK;
+}
+}  // namespace
+extern "C" {
+
+int o3ds_voxelize_within_volume(o3ds_handle h, o3ds_cloud map, double voxel_size, const o3ds_crop* crop) {
+  CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
+  return voxelize_within_volume_impl(h, map, voxel_size, crop);
 }
 
 int o3ds_cloud_undistort(o3ds_handle h, o3ds_cloud cloud, const double linear_velocity[3], const double angular_velocity_rpy[3],
@@ -2384,6 +2468,7 @@ int o3ds_cloud_undistort(o3ds_handle h, o3ds_cloud cloud, const double linear_ve
     undistort_kernel<P4f><<<grid_for(c->n), kBlock, 0, h->stream>>>((P4f*)c->pts, c->n, v[0], v[1], v[2], w[0], w[1], w[2], scan_duration,
                                                                   spinning_clockwise);
   HIP_TRY(hipGetLastError());
+  c->vox_first = -1;  // the points moved
   if (c->nrm) {
     dev_free(h, c->nrm);
     c->nrm = nullptr;
@@ -2655,6 +2740,7 @@ int o3ds_map_carve(o3ds_handle h, o3ds_cloud map, o3ds_cloud raw_scan, const dou
   const int rc = m->precision == O3DS_PRECISION_F64 ? carve_t<P4d>(h, *m, *s, map_to_range_sensor, cd, *params, &removed)
                                                     : carve_t<P4f>(h, *m, *s, map_to_range_sensor, cd, *params, &removed);
   if (n_removed) *n_removed = removed;
+  if (removed) m->vox_first = -1;  // the blocks shrank by unknown amounts: the next insertion sorts once and re-establishes the layout
   return rc;
 }
 
@@ -2668,12 +2754,16 @@ int o3ds_map_insert_scan(o3ds_handle h, o3ds_cloud map, o3ds_cloud scan, const d
   if (s->n == 0) return O3DS_OK;  // Submap.cpp:41-43: empty pre-processed scan is a no-op
   if (m->n == 0) m->precision = s->precision;
   if (m->precision != s->precision) return fail(h, O3DS_ERR_INVALID_ARG, "map_insert_scan: precision mismatch");
+  // the layout the previous insertion left (pass-through block, then the voxel block in key order): the merge below re-bins by merging
+  const bool known = m->vox_first >= 0 && (size_t)m->vox_first + m->vox_count == m->n;
+  const long long merge_np = known ? m->vox_first : -1;
+  const size_t merge_nv = known ? m->vox_count : 0;
   CloudRec t;
   int rc = DISPATCH(s->precision, transform_t, h, *s, T, t);  // Submap.cpp:54
   if (!rc) rc = DISPATCH(m->precision, append_t, h, *m, t);   // Submap.cpp:70
   free_cloud(h, t);
   if (rc) return rc;
-  rc = o3ds_voxelize_within_volume(h, map, map_voxel_size, map_builder_crop);  // Submap.cpp:71-72
+  rc = voxelize_within_volume_impl(h, map, map_voxel_size, map_builder_crop, merge_np, merge_nv);  // Submap.cpp:71-72
   if (rc) return rc;
   m = find_cloud(h, map);
   if (max_corr_hint > 0.0) {

@@ -251,6 +251,102 @@ __global__ __launch_bounds__(kBlock) void voxel_key_kernel(const P4* __restrict_
   }
 }
 
+// ---- the sorted (key, value) list of a map merge WITHOUT sorting the map ---------------------------------------------------------------
+// voxelizeWithinCroppingVolume (helpers.cpp:115-183) of mapCloud_ += scan re-bins the whole map at every insertion.  The map the previous
+// insertion left is [pass-through block | voxel block in ascending key order] and its voxel block is still sorted: the stable sort of
+// all n = N + m keys is a MERGE of that block (minus what left the volume) with the few keys that are new to the volume -- the scan's
+// points and pass-through points that re-entered -- followed by the outside points in index order.  The kernels below produce exactly
+// the arrays rocPRIM's radix sort would (same keys, same tie order: ascending index), so everything after them is unchanged and the
+// result is bit-identical; only the m new keys are sorted.
+constexpr unsigned long long kCntPass = 1ull, kCntV = 1ull << 21, kCntX = 1ull << 42, kCntMask = (1ull << 21) - 1ull;
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void merge_class_kernel(const P4* __restrict__ pts, size_t n, double v, CropDev crop, size_t np, size_t nv,
+                                                             unsigned long long* __restrict__ keys, unsigned long long* __restrict__ cls,
+                                                             int* __restrict__ unsorted) {
+  const double inv = 1.0 / v;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i <= n; i += (size_t)gridDim.x * kBlock) {
+    if (i == n) {
+      cls[n] = 0;  // sentinel: the exclusive scan of n + 1 entries ends with the three totals
+      continue;
+    }
+    const P4 p = pts[i];
+    const double x = (double)p.x, y = (double)p.y, z = (double)p.z;
+    const unsigned long long vk = pack_key((long long)floor(x * inv), (long long)floor(y * inv), (long long)floor(z * inv));
+    const bool inside = crop_contains(crop, x, y, z);
+    const bool in_v = i >= np && i < np + nv;
+    keys[i] = inside ? vk : (kPassBit | (unsigned long long)i);
+    cls[i] = inside ? (in_v ? kCntV : kCntX) : kCntPass;
+    if (in_v && i > np) {  // the voxel block must still be in key order (a mean that rounding put on the far side of a face breaks it)
+      const P4 q = pts[i - 1];
+      const unsigned long long pk = pack_key((long long)floor((double)q.x * inv), (long long)floor((double)q.y * inv), (long long)floor((double)q.z * inv));
+      if (vk < pk) atomicOr(unsorted, 1);
+    }
+  }
+}
+// ranks -> the three lists: outside points straight into the tail of the sorted arrays, kept voxel-block entries and new entries apart
+__global__ __launch_bounds__(kBlock) void merge_split_kernel(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ rank,
+                                                             size_t n, size_t np, size_t nv, unsigned long long* __restrict__ k_sorted,
+                                                             uint32_t* __restrict__ v_sorted, unsigned long long* __restrict__ vk, uint32_t* __restrict__ vv,
+                                                             unsigned long long* __restrict__ xk, uint32_t* __restrict__ xv) {
+  const unsigned long long tot = rank[n];
+  const size_t n_in = (size_t)((tot >> 21) & kCntMask) + (size_t)((tot >> 42) & kCntMask);
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const unsigned long long k = keys[i], r = rank[i];
+    if (k & kPassBit) {
+      const size_t o = n_in + (size_t)(r & kCntMask);
+      k_sorted[o] = k;
+      v_sorted[o] = (uint32_t)i;
+    } else if (i >= np && i < np + nv) {
+      const size_t o = (size_t)((r >> 21) & kCntMask);
+      vk[o] = k;
+      vv[o] = (uint32_t)i;
+    } else {
+      const size_t o = (size_t)((r >> 42) & kCntMask);
+      xk[o] = k;
+      xv[o] = (uint32_t)i;
+    }
+  }
+}
+// a sorted new entry goes in front of the kept entries with the same key if it comes from the pass-through block (smaller index),
+// behind them if it comes from the scan: xpos = number of kept entries in front of it; cnt[xpos] counts the insertions per gap
+__global__ __launch_bounds__(kBlock) void merge_rank_kernel(const unsigned long long* __restrict__ xk, const uint32_t* __restrict__ xv, size_t nx,
+                                                            const unsigned long long* __restrict__ vk, size_t nvin, size_t np,
+                                                            int* __restrict__ xpos, int* __restrict__ cnt) {
+  for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < nx; j += (size_t)gridDim.x * kBlock) {
+    const unsigned long long k = xk[j];
+    const bool before = (size_t)xv[j] < np;
+    size_t lo = 0, hi = nvin;
+    while (lo < hi) {
+      const size_t mid = (lo + hi) >> 1;
+      const unsigned long long m = vk[mid];
+      if (before ? m < k : m <= k)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    xpos[j] = (int)lo;
+    atomicAdd(&cnt[lo], 1);
+  }
+}
+__global__ __launch_bounds__(kBlock) void merge_place_kernel(const unsigned long long* __restrict__ vk, const uint32_t* __restrict__ vv, size_t nvin,
+                                                             const int* __restrict__ before /* exclusive scan of cnt, nvin + 2 entries */,
+                                                             const unsigned long long* __restrict__ xk, const uint32_t* __restrict__ xv,
+                                                             const int* __restrict__ xpos, size_t nx, unsigned long long* __restrict__ k_sorted,
+                                                             uint32_t* __restrict__ v_sorted) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nvin + nx; i += (size_t)gridDim.x * kBlock) {
+    if (i < nvin) {
+      const size_t o = i + (size_t)before[i + 1];  // new entries with xpos <= i lie in front of kept entry i
+      k_sorted[o] = vk[i];
+      v_sorted[o] = vv[i];
+    } else {
+      const size_t j = i - nvin;
+      const size_t o = j + (size_t)xpos[j];
+      k_sorted[o] = xk[j];
+      v_sorted[o] = xv[j];
+    }
+  }
+}
+
 // after sorting (key, val): head[i] = 1 where a new segment starts
 __global__ __launch_bounds__(kBlock) void segment_head_kernel(const unsigned long long* __restrict__ keys, size_t n, int* __restrict__ head) {
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)

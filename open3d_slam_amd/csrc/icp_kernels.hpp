@@ -98,29 +98,30 @@ __global__ __launch_bounds__(kBlock) void cell_count_kernel(const P4* __restrict
   }
 }
 
-// 3-phase exclusive scan over `m` ints, 1024 elements per block (4 per thread)
+// 3-phase exclusive scan over `m` values (int, or unsigned long long for packed multi-counter scans), 1024 elements per block
+// (4 per thread)
 constexpr int kScanPerBlock = 1024;
-__global__ __launch_bounds__(kBlock) void scan_local_kernel(const int* __restrict__ in, int* __restrict__ out, int* __restrict__ block_sums,
-                                                            size_t m) {
-  __shared__ int s_wave[kBlock / 64];
+template <typename T>
+__global__ __launch_bounds__(kBlock) void scan_local_kernel(const T* __restrict__ in, T* __restrict__ out, T* __restrict__ block_sums, size_t m) {
+  __shared__ T s_wave[kBlock / 64];
   const size_t base = (size_t)blockIdx.x * kScanPerBlock + (size_t)threadIdx.x * 4;
-  int v[4];
+  T v[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) v[k] = (base + k < m) ? in[base + k] : 0;
-  const int tsum = v[0] + v[1] + v[2] + v[3];
+  for (int k = 0; k < 4; ++k) v[k] = (base + k < m) ? in[base + k] : (T)0;
+  const T tsum = v[0] + v[1] + v[2] + v[3];
   // inclusive scan of tsum across the wave
-  int x = tsum;
+  T x = tsum;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
-    const int y = __shfl_up(x, d, 64);
+    const T y = __shfl_up(x, d, 64);
     if (lane >= d) x += y;
   }
   if (lane == 63) s_wave[w] = x;
   __syncthreads();
-  int woff = 0;
+  T woff = 0;
   for (int k = 0; k < w; ++k) woff += s_wave[k];
-  int excl = woff + x - tsum;
+  T excl = woff + x - tsum;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     if (base + k < m) out[base + k] = excl;
@@ -129,35 +130,37 @@ __global__ __launch_bounds__(kBlock) void scan_local_kernel(const int* __restric
   if (threadIdx.x == kBlock - 1) block_sums[blockIdx.x] = woff + x;
 }
 // single block: exclusive scan of block sums in place (nb <= 1<<20 handled serially per thread chunk)
-__global__ __launch_bounds__(kBlock) void scan_sums_kernel(int* __restrict__ sums, int nb) {
-  __shared__ int s_tot[kBlock];
+template <typename T>
+__global__ __launch_bounds__(kBlock) void scan_sums_kernel(T* __restrict__ sums, int nb) {
+  __shared__ T s_tot[kBlock];
   const int per = (nb + kBlock - 1) / kBlock;
   const int b = threadIdx.x * per, e = min(nb, b + per);
-  int t = 0;
+  T t = 0;
   for (int i = b; i < e; ++i) t += sums[i];
   s_tot[threadIdx.x] = t;
   __syncthreads();
-  int off = 0;
+  T off = 0;
   for (int k = 0; k < (int)threadIdx.x; ++k) off += s_tot[k];
   for (int i = b; i < e; ++i) {
-    const int v = sums[i];
+    const T v = sums[i];
     sums[i] = off;
     off += v;
   }
 }
 // phases 2 and 3 in one launch for up to kScanFusedBlocks blocks: every block adds up the block sums in front of it itself (at most
-// a few thousand ints, read once per block and L2-resident) instead of waiting for a one-block scan of them -- a launch less per
+// a few thousand values, read once per block and L2-resident) instead of waiting for a one-block scan of them -- a launch less per
 // scan, and the per-scan pipeline of a lidar frame runs ten scans
 constexpr int kScanFusedBlocks = 4096;
-__global__ __launch_bounds__(kBlock) void scan_add_fused_kernel(int* __restrict__ out, const int* __restrict__ sums, size_t m) {
-  __shared__ int s_part[kBlock / 64];
-  int t = 0;
+template <typename T>
+__global__ __launch_bounds__(kBlock) void scan_add_fused_kernel(T* __restrict__ out, const T* __restrict__ sums, size_t m) {
+  __shared__ T s_part[kBlock / 64];
+  T t = 0;
   for (int i = threadIdx.x; i < (int)blockIdx.x; i += kBlock) t += sums[i];
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
   if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = t;
   __syncthreads();
-  int off = 0;
+  T off = 0;
 #pragma unroll
   for (int k = 0; k < kBlock / 64; ++k) off += s_part[k];
   const size_t base = (size_t)blockIdx.x * kScanPerBlock + (size_t)threadIdx.x * 4;
@@ -165,9 +168,10 @@ __global__ __launch_bounds__(kBlock) void scan_add_fused_kernel(int* __restrict_
   for (int k = 0; k < 4; ++k)
     if (base + k < m) out[base + k] += off;
 }
-__global__ __launch_bounds__(kBlock) void scan_add_kernel(int* __restrict__ out, const int* __restrict__ sums, size_t m) {
+template <typename T>
+__global__ __launch_bounds__(kBlock) void scan_add_kernel(T* __restrict__ out, const T* __restrict__ sums, size_t m) {
   const size_t base = (size_t)blockIdx.x * kScanPerBlock + (size_t)threadIdx.x * 4;
-  const int off = sums[blockIdx.x];
+  const T off = sums[blockIdx.x];
 #pragma unroll
   for (int k = 0; k < 4; ++k)
     if (base + k < m) out[base + k] += off;

@@ -557,6 +557,8 @@ def test_rank_deficient_normal_equations_follow_eigen_ldlt(backend_f64, oracle):
         got = backend_f64.icp_point_to_plane(s, tgt, nrm, 0.5, max_iter=5, rel_fitness=0.0, rel_rmse=0.0)
         ref = oracle.icp_point_to_plane(s, tgt, nrm, 0.5, max_iter=5, rel_fitness=0.0, rel_rmse=0.0)
         assert np.isfinite(got["transformation"]).all() and np.isfinite(ref["transformation"]).all()
+        if len(s) < 3:  # the observable 3x3 block is itself singular: its last pivot is rounding residue, on both sides, and so is
+            continue    # the "solution" -- what is guaranteed (and what Eigen guarantees) is a finite one
         np.testing.assert_allclose(got["transformation"], ref["transformation"], atol=1e-9)
         T = got["transformation"]
         # the unobservable motions get no update of their own (what little x / y appears is the tilt acting on the z offset)

@@ -1,4 +1,6 @@
 """Scan pre-processing and map-fusion kernels vs the CPU oracle, through the C-ABI (needs an MI355X)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1066,3 +1068,56 @@ def test_crop_voxel_down_sample_is_crop_then_voxel_bit_for_bit(backend_f64, back
             for cid in (a, two, one):
                 be.free(cid)
         be.free(c)
+
+
+def _insert_sequence(be, n_frames, rmax, voxel, carve_at=()):
+    """a short mapping run: scans along an out-and-back path (points leave the map builder's volume and come back), returns the map
+    after every insertion as raw bytes"""
+    scene = syn.make_scene()
+    m = be.upload(np.zeros((0, 3)))
+    out = []
+    for k in range(n_frames):
+        t = k if k < n_frames // 2 else n_frames - 1 - k  # out and back
+        T = syn.make_pose([1.5 * t, 0.4 * t, 0.0], [0.0, 0.0, 4.0 * t])
+        raw = syn.vlp16_scan(scene, T, frame=k, n_az=256)
+        s = be.upload(raw)
+        v = be.voxel_down_sample(s, 0.1)
+        be.estimate_normals(v, 2.0, 10)
+        crop = backend.make_crop(backend.CROP_MIN_MAX_RADIUS, center=T[:3, 3], rmin=0.0, rmax=rmax)
+        if k in carve_at:
+            be.map_carve(m, s, T, crop)
+        be.map_insert_scan(m, v, T, voxel, crop, max_corr_hint=1.0)
+        p, n = be.download(m)
+        out.append((p.tobytes(), n.tobytes(), len(p)))
+        be.free(s)
+        be.free(v)
+    be.free(m)
+    return out
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_map_merge_by_merging_is_bitwise_the_full_sort(prec, monkeypatch):
+    """Submap::insertScan re-bins the whole map at every scan (helpers.cpp:115-183).  The backend builds the sorted voxel-key list of
+    map + scan by MERGING the still-sorted voxel block of the previous insertion with the few keys that are new to the volume
+    (voxel_reduce_t / merge_class_kernel) instead of sorting N + m keys; O3DS_NO_INCREMENTAL_MERGE=1 forces the sort.  Both must give
+    the same map byte for byte after every one of 14 insertions along an out-and-back path with a small builder volume (points leave
+    the volume, become pass-through, and re-enter on the way back), with a carve in between (which resets the layout)."""
+    p = backend.PRECISION_F64 if prec == "f64" else backend.PRECISION_F32
+    import subprocess
+    import sys
+
+    # the switch is read once per process: the reference run goes to a child process
+    code = ("import sys, pickle; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_preprocess_map_gpu as t; from open3d_slam_amd import backend; "
+            "be = backend.Backend(0, %d); sys.stdout.buffer.write(pickle.dumps(t._insert_sequence(be, 14, 12.0, 0.2, carve_at=(9,))))"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), p))
+    import pickle
+
+    ref = pickle.loads(subprocess.run([sys.executable, "-c", code], capture_output=True, check=True,
+                                      env=dict(os.environ, O3DS_NO_INCREMENTAL_MERGE="1")).stdout)
+    be = backend.Backend(0, p)
+    got = _insert_sequence(be, 14, 12.0, 0.2, carve_at=(9,))
+    be.close()
+    assert [g[2] for g in got] == [r[2] for r in ref]
+    for k, (g, r) in enumerate(zip(got, ref)):
+        assert g[0] == r[0] and g[1] == r[1], k
+    assert got[-1][2] > 5000
