@@ -324,6 +324,22 @@ void dev_release_all(o3ds_handle h) {  // o3ds_destroy: the stream has been sync
   h->pool_bytes = 0;
 }
 
+// device blocks obtained in a function that may still fail: handed back to the cache on every early return, kept on release()
+struct DevGuard {
+  o3ds_handle h;
+  std::vector<void**> held;
+  explicit DevGuard(o3ds_handle hh) : h(hh) {}
+  ~DevGuard() {
+    for (void** q : held)
+      if (*q) {
+        dev_free(h, *q);
+        *q = nullptr;
+      }
+  }
+  void add(void** q) { held.push_back(q); }
+  void release() { held.clear(); }
+};
+
 // ---- scratch arena ------------------------------------------------------------------------------------------------
 // Temporaries (scan block sums, flags, sort buffers, staging copies ...) are bump-allocated from blocks that persist
 // for the life of the handle: a per-scan pipeline makes ~120 allocations otherwise (4.6 us each + free).  The bump
@@ -437,6 +453,17 @@ void free_cloud(o3ds_handle h, CloudRec& c) {
   c.pts = c.nrm = c.col = nullptr;
   c.n = 0;
 }
+
+// a cloud under construction in a function that may still fail: freed on every early return, handed over by release()
+struct CloudGuard {
+  o3ds_handle h;
+  CloudRec* c;
+  CloudGuard(o3ds_handle hh, CloudRec& cc) : h(hh), c(&cc) {}
+  ~CloudGuard() {
+    if (c) free_cloud(h, *c);
+  }
+  void release() { c = nullptr; }
+};
 
 // exclusive scan of m ints (in -> out) with the hand-written 3-phase scan; in may alias out
 template <typename T>
@@ -1000,7 +1027,7 @@ int o3ds_create(int device_id, o3ds_handle* out) {
       hipHostMalloc((void**)&h->h_state, sizeof(IcpStateDev), hipHostMallocMapped) != hipSuccess ||
       hipHostGetDevicePointer((void**)&h->h_state_dev, h->h_state, 0) != hipSuccess ||
       hipHostMalloc((void**)&h->h_pin, kPinBytes, hipHostMallocDefault) != hipSuccess) {
-    delete h;
+    o3ds_destroy(h);  // frees whatever part of the context exists (every member is null-checked there)
     return fail(nullptr, O3DS_ERR_HIP, "o3ds_create: device initialisation failed");
   }
   {
@@ -1144,6 +1171,7 @@ int o3ds_cloud_upload_f32(o3ds_handle h, const void* data, size_t n, size_t poin
     return fail(h, O3DS_ERR_INVALID_ARG, "cloud_upload_f32: x/y/z fields do not fit the point step");
   HIP_TRY(hipSetDevice(h->device));
   CloudRec c;
+  CloudGuard c_guard(h, c);
   c.n = n;
   c.precision = h->precision;
   if (n > 0) {
@@ -1162,6 +1190,7 @@ int o3ds_cloud_upload_f32(o3ds_handle h, const void* data, size_t n, size_t poin
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));  // `data` may be reused by the caller as soon as this returns
   }
+  c_guard.release();
   *out = add_cloud(h, std::move(c));
   return O3DS_OK;
 }
@@ -1675,8 +1704,18 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
           launch_fused<P4f>(h, fa, h->session_crop, tail_only ? 1 : nb, !tail_only);
         last = fa.state_out;
       }
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(hipStreamSynchronize(h->stream));
+      {
+        // a failed launch or stream breaks the "slot buffer g % 3 was cleared by launch g - 1" rotation: clear all three and restart
+        // the counter, so that the next registration does not add into records that were never cleared
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) {
+          (void)hipMemset(h->d_fused + kFusedSlotsOff, 0, 3 * kFusedSlotBufBytes);
+          h->fused_launches = 0;
+          if (d_trace) (void)hipFree(d_trace);
+          return fail(h, O3DS_ERR_HIP, std::string("icp (fused loop): ") + hipGetErrorString(e));
+        }
+      }
       copy_result(h, out);
       if (h->h_state->done) break;
     }
@@ -2263,6 +2302,8 @@ int append_t(o3ds_handle h, CloudRec& map, const CloudRec& add) {
   CloudRec joined;
   box_union(joined, map, add);
   void *np = nullptr, *nn = nullptr, *nc = nullptr;
+  DevGuard guard(h);
+  guard.add(&np), guard.add(&nn), guard.add(&nc);
   if (n > 0) HIP_TRY(dev_alloc(h, (void**)&np, sizeof(P4) * n));
   if (keep_nrm && n > 0) HIP_TRY(dev_alloc(h, (void**)&nn, sizeof(P4) * n));
   if (keep_col && n > 0) HIP_TRY(dev_alloc(h, (void**)&nc, sizeof(P4) * n));
@@ -2278,6 +2319,7 @@ int append_t(o3ds_handle h, CloudRec& map, const CloudRec& add) {
   }
   HIP_TRY(hipGetLastError());
   dbg_sync(h, 32);
+  guard.release();
   free_index(h, map);
   if (map.pts) dev_free(h, map.pts);
   if (map.nrm) dev_free(h, map.nrm);
@@ -2370,6 +2412,7 @@ int o3ds_select_by_index(o3ds_handle h, o3ds_cloud in, const uint32_t* keep_idx,
   for (size_t i = 0; i < m; ++i)
     if (keep_idx[i] >= c->n) return fail(h, O3DS_ERR_INVALID_ARG, "select_by_index: index out of range");
   CloudRec o;
+  CloudGuard o_guard(h, o);
   o.precision = c->precision;
   o.n = m;
   box_copy(o, *c);  // a subset
@@ -2394,6 +2437,7 @@ int o3ds_select_by_index(o3ds_handle h, o3ds_cloud in, const uint32_t* keep_idx,
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));  // keep_idx may be released by the caller
   }
+  o_guard.release();
   *out = add_cloud(h, std::move(o));
   return O3DS_OK;
 }

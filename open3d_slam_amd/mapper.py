@@ -50,6 +50,8 @@ class Mapper:
             processed = self.scan2MapReg_.processForScanMatchingAndMerging(rawScan, self.mapToRangeSensor_)
             self.submap_.insertScan(rawScan, processed.merge_, np.eye(4), timestamp)
             self.mapToRangeSensorBuffer_.append((timestamp, self.mapToRangeSensor_.copy()))
+            # (the reference leaves lastMeasurementTimestamp_ at the epoch here and lets TransformInterpolationBuffer clamp the lookup of
+            # the next frame to the earliest odometry sample; this harness looks stamps up exactly, so it records the first stamp)
             self.lastMeasurementTimestamp_ = timestamp
             self._release(processed)
             return True

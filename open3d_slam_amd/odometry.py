@@ -57,6 +57,8 @@ class LidarOdometry:
             if not pre.IsEmpty():
                 self.cloudPrev_.release()
                 self.cloudPrev_ = pre
+            else:
+                pre.release()  # nothing to keep: give the (empty) device cloud back
             return False
         self.odomToRangeSensorCumulative_ = self.odomToRangeSensorCumulative_ @ np.linalg.inv(result.transformation_)
         self.cloudPrev_.release()
