@@ -794,7 +794,19 @@ void launch_accumulate(o3ds_handle h, const IcpPassArgs& a, bool crop, int nbloc
     }
   }
   // one geometry: 256 threads = 64 queries x 4 lanes (G = 2 / 8 and 512-thread variants were swept and dropped)
-  if (h->session_method == O3DS_ICP_GENERALIZED) {
+  if (a.keys_mode != 0) {  // target-sharded registration (o3ds_icp_nn_keys / o3ds_icp_accumulate_keys): the instantiation with the key code
+    if (h->session_method == O3DS_ICP_GENERALIZED) {
+      if (crop)
+        icp_accumulate_kernel<P4, true, 256, 4, true, true><<<nblocks, 256, 0, h->stream>>>(a);
+      else
+        icp_accumulate_kernel<P4, false, 256, 4, true, true><<<nblocks, 256, 0, h->stream>>>(a);
+    } else {
+      if (crop)
+        icp_accumulate_kernel<P4, true, 256, 4, false, true><<<nblocks, 256, 0, h->stream>>>(a);
+      else
+        icp_accumulate_kernel<P4, false, 256, 4, false, true><<<nblocks, 256, 0, h->stream>>>(a);
+    }
+  } else if (h->session_method == O3DS_ICP_GENERALIZED) {
     if (crop)
       icp_accumulate_kernel<P4, true, 256, 4, true><<<nblocks, 256, 0, h->stream>>>(a);
     else

@@ -710,7 +710,7 @@ struct FarItem {
   int pos;
 };
 
-template <typename P4, bool kCrop, int kPassBlock, int kGroup, bool kGicp>
+template <typename P4, bool kCrop, int kPassBlock, int kGroup, bool kGicp, bool kKeys = false /* the keys_mode code (classic kernel only) */>
 __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const double* Tm, int wg, int nwg, double* s_rec_flat,
                                                 double (*s_red)[kRec], int2* s_seg /* [kPassBlock / kGroup][kSegMax] */,
                                                 bool use_cache, const QueryPrefetch<P4>& first_batch,
@@ -757,7 +757,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
       if (a.debug == 2) {
         nn.pos = (int)(i % 1000);
         nn.idx = nn.pos;
-      } else if (a.keys_mode == 2) {  // the match was decided by the all-reduce: mine iff the key names this rank
+      } else if (kKeys && a.keys_mode == 2) {  // the match was decided by the all-reduce: mine iff the key names this rank
         const unsigned long long key = a.keys[a.first + i];
         if (key != kNoKey && (int)((key >> 28) & 0xfu) == a.keys_rank) {
           nn.pos = (int)(key & 0x0fffffffu);
@@ -814,13 +814,13 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
     }
     if (tr && threadIdx.x == 0) tr[1] = wall_clock64();
     if (gl == 0) {
-      if (i < a.count && a.keys_mode != 2) a.nn_cache[a.first + i] = nn.pos;
-      if (a.keys_mode == 1 && i < a.count)
+      if (i < a.count && !(kKeys && a.keys_mode == 2)) a.nn_cache[a.first + i] = nn.pos;
+      if (kKeys && a.keys_mode == 1 && i < a.count)
         a.keys[a.first + i] = nn.pos == -1 ? kNoKey
                                            : ((unsigned long long)__float_as_uint((float)nn.d2) << 32) |
                                                  ((unsigned long long)(a.keys_rank & 0xf) << 28) | (unsigned long long)(nn.pos & 0x0fffffff);
       double* rec = s_rec_flat + ql * kStride;
-      if (nn.pos != -1 && a.keys_mode != 1) {
+      if (nn.pos != -1 && !(kKeys && a.keys_mode == 1)) {
         if (a.debug == 3) nn.pos = (int)(i % 1000);
         const P4 q = tp[nn.pos];
         const double dx = px - (double)q.x, dy = py - (double)q.y, dz = pz - (double)q.z;
@@ -894,7 +894,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
 // Workgroup = BLOCK threads = BLOCK/G queries x G lanes for the search, then (32 record terms) x (BLOCK/32 query slices) for the
 // accumulation: one f64 accumulator per thread instead of 30, so the kernel stays small in registers and the chip can
 // keep enough wavefronts in flight to hide the dependent-load latency of the search.
-template <typename P4, bool kCrop, int kPassBlock, int kGroup, bool kGicp>
+template <typename P4, bool kCrop, int kPassBlock, int kGroup, bool kGicp, bool kKeys = false>
 __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4))) void icp_accumulate_kernel(IcpPassArgs a) {
   constexpr int kQPB = kPassBlock / kGroup;
   if (a.state->done) return;  // device-side loop already terminated: keep the previous partials
@@ -907,7 +907,7 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   }
   const bool use_cache = a.state->pass > 0;
   const QueryPrefetch<P4> qp = prefetch_query<P4, kPassBlock, kGroup>(a, blockIdx.x, use_cache);
-  const double v = icp_pass_body<P4, kCrop, kPassBlock, kGroup, kGicp>(a, a.state->T, blockIdx.x, gridDim.x, s_rec, s_red, s_seg, use_cache, qp);
+  const double v = icp_pass_body<P4, kCrop, kPassBlock, kGroup, kGicp, kKeys>(a, a.state->T, blockIdx.x, gridDim.x, s_rec, s_red, s_seg, use_cache, qp);
   if (threadIdx.x < kRec) a.partials[(size_t)blockIdx.x * kRec + threadIdx.x] = v;
 }
 
