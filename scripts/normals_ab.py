@@ -1,4 +1,4 @@
-"""A/B of the normal-estimation kernel variants (O3DS_NRM_ROWS, read once per process): time on the voxel-filtered OS-128-like scan
+"""A/B of normal-estimation builds or settings (e.g. O3DS_NRM_CELL_SCALE, read once per process): time on the voxel-filtered OS-128-like scan
 of the config-2 stream and a checksum of the result, so that variants can be compared bit for bit across processes."""
 import hashlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,6 +23,6 @@ for name, pose in (("origin", syn.make_pose((0.0, 0.0, 0.5), (0.0, 0.0, 0.0))), 
             be.synchronize(); t0 = time.perf_counter(); be.estimate_normals(v, 1.0, 5); be.synchronize(); t5.append((time.perf_counter() - t0) * 1e3)
         _, nrm5 = be.download(v)
         h5 = hashlib.sha1(np.ascontiguousarray(nrm5).tobytes()).hexdigest()[:12]
-        out.append(f"rows={os.environ.get('O3DS_NRM_ROWS','default')} {name} {pname} n={n} knn20/r3: min {min(ts):.3f} ms med {sorted(ts)[len(ts)//2]:.3f} sha {h} | knn5/r1: min {min(t5):.3f} sha {h5}")
+        out.append(f"cell_scale={os.environ.get('O3DS_NRM_CELL_SCALE','1')} {name} {pname} n={n} knn20/r3: min {min(ts):.3f} ms med {sorted(ts)[len(ts)//2]:.3f} sha {h} | knn5/r1: min {min(t5):.3f} sha {h5}")
         be.close()
 print("\n".join(out))

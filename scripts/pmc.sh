@@ -10,7 +10,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -o pmc -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/p$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -o pmc -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --m2-frames 0 --concurrent 0 > $OUT/p$i.log 2>&1
   echo "set $i ($set) rc=$?"
 done
 python - <<PY
