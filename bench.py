@@ -31,6 +31,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the CPU baseline's OpenMP threads stay on their cores (read by libgomp when it is first loaded, i.e. before torch is imported);
+# without it the best thread count of the sweep was 16 of 256 hardware threads and the rate halved by 64
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "cores")
 
 ICP_ITERS = 10
 N_SRC, N_MAP = 65536, 1_000_000

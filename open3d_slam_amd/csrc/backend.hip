@@ -1211,7 +1211,7 @@ int o3ds_cloud_free(o3ds_handle h, o3ds_cloud id) {
   CHECK_HANDLE(h);
   auto it = h->clouds.find(id);
   if (it == h->clouds.end()) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_free: unknown cloud id");
-  // no host synchronisation: the buffers go back to the stream-ordered pool behind whatever still reads them on this stream
+  // no host synchronisation: the buffers go back to the handle's allocator behind whatever still reads them on this stream
   // (o3ds_set_stream synchronises the stream it leaves).  O3DS_SYNC_ON_FREE=1 restores the wait (six of them per lidar frame).
   static const bool sync_on_free = getenv("O3DS_SYNC_ON_FREE") != nullptr;
   if (sync_on_free) (void)hipStreamSynchronize(h->stream);

@@ -1121,3 +1121,23 @@ def test_map_merge_by_merging_is_bitwise_the_full_sort(prec, monkeypatch):
     for k, (g, r) in enumerate(zip(got, ref)):
         assert g[0] == r[0] and g[1] == r[1], k
     assert got[-1][2] > 5000
+
+
+def test_normals_with_exact_ties_duplicates_and_tiny_clouds(backend_f64, oracle):
+    """The neighbour order (d2, original index) decides everything where distances tie EXACTLY: a regular lattice (every point has
+    whole shells of equidistant neighbours, so the max_nn-th place is always tied), duplicated points (d2 = 0 several times), and
+    clouds smaller than max_nn / smaller than three points.  f64 storage must still equal the oracle bit for bit."""
+    g = np.stack(np.meshgrid(np.arange(12) * 0.25, np.arange(12) * 0.25, np.arange(3) * 0.25, indexing="ij"), -1).reshape(-1, 3) + [3.0, -2.0, 1.0]
+    rng = np.random.default_rng(3)
+    dup = np.vstack([g, g[rng.choice(len(g), 40, replace=False)], g[:5], g[:5]])  # exact duplicates, some of them three times
+    shuffled = dup[rng.permutation(len(dup))]
+    for pts, cases in ((g, ((0.6, 7), (1.0, 20), (0.3, 30))), (shuffled, ((0.6, 7), (0.26, 5), (2.0, 40))),
+                       (g[:2], ((1.0, 20),)), (g[:1], ((1.0, 5),)), (g[:7], ((5.0, 20),))):
+        c = backend_f64.upload(pts)
+        for radius, knn in cases:
+            backend_f64.estimate_normals(c, radius, knn)
+            _, got = backend_f64.download(c)
+            ref = oracle.estimate_normals(pts, radius, knn)
+            differ = np.flatnonzero(np.any(got != ref, axis=1))
+            assert len(differ) == 0, (len(pts), radius, knn, len(differ), differ[:5], got[differ[:3]], ref[differ[:3]])
+        backend_f64.free(c)
