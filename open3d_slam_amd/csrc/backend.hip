@@ -139,7 +139,8 @@ struct o3ds_context {
   // device memory of the handle: a caching allocator over hipMalloc (dev_alloc / dev_free below)
   std::multimap<size_t, void*> pool_free;        // cached blocks by size
   std::unordered_map<void*, size_t> pool_size;   // every block this handle obtained from hipMalloc -> its size
-  size_t pool_bytes = 0;
+  size_t pool_bytes = 0;   // everything obtained from hipMalloc
+  size_t pool_cached = 0;  // of which in the free lists
   // bump arena for the temporaries of one top-level ABI call (stream-ordered reuse: everything runs on one stream)
   std::vector<std::pair<char*, size_t>> arena_blocks;
   size_t arena_cur = 0, arena_off = 0;
@@ -290,6 +291,7 @@ hipError_t dev_alloc(o3ds_handle h, void** out, size_t bytes) {
   auto it = h->pool_free.lower_bound(want);
   if (it != h->pool_free.end() && it->first <= want + want / 4) {
     *out = it->second;
+    h->pool_cached -= it->first;
     h->pool_free.erase(it);
     return hipSuccess;
   }
@@ -303,6 +305,7 @@ hipError_t dev_alloc(o3ds_handle h, void** out, size_t bytes) {
       (void)hipFree(b.second);
     }
     h->pool_free.clear();
+    h->pool_cached = 0;
     e = hipMalloc(&p, want);
   }
   if (e != hipSuccess) return e;
@@ -316,12 +319,28 @@ void dev_free(o3ds_handle h, void* p) {
   auto it = h->pool_size.find(p);
   if (it == h->pool_size.end()) return;  // not ours (never happens)
   h->pool_free.emplace(it->second, p);
+  h->pool_cached += it->second;
+  // The cache is bounded: size classes drift as a map grows, and blocks of outgrown classes are never asked for again.  Beyond the cap
+  // (O3DS_POOL_CAP_MB, default 32 GB of the 288) everything cached goes back to the driver -- after a stream synchronisation, because a
+  // cached block may still be read by work enqueued before its dev_free.
+  static const size_t cap = (getenv("O3DS_POOL_CAP_MB") ? (size_t)atoll(getenv("O3DS_POOL_CAP_MB")) : (size_t)32768) << 20;
+  if (h->pool_cached > cap) {
+    (void)hipStreamSynchronize(h->stream);
+    for (auto& b : h->pool_free) {
+      h->pool_bytes -= b.first;
+      h->pool_size.erase(b.second);
+      (void)hipFree(b.second);
+    }
+    h->pool_free.clear();
+    h->pool_cached = 0;
+  }
 }
 void dev_release_all(o3ds_handle h) {  // o3ds_destroy: the stream has been synchronised
   for (auto& b : h->pool_size) (void)hipFree(b.first);
   h->pool_size.clear();
   h->pool_free.clear();
   h->pool_bytes = 0;
+  h->pool_cached = 0;
 }
 
 // device blocks obtained in a function that may still fail: handed back to the cache on every early return, kept on release()

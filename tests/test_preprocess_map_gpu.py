@@ -1141,3 +1141,19 @@ def test_normals_with_exact_ties_duplicates_and_tiny_clouds(backend_f64, oracle)
             differ = np.flatnonzero(np.any(got != ref, axis=1))
             assert len(differ) == 0, (len(pts), radius, knn, len(differ), differ[:5], got[differ[:3]], ref[differ[:3]])
         backend_f64.free(c)
+
+
+def test_allocator_cache_is_bounded_and_survives_a_trim():
+    """The handle's caching allocator gives everything cached back to the driver beyond O3DS_POOL_CAP_MB (size classes drift as a map
+    grows); a tiny cap forces that path on every few calls -- results must not change."""
+    import subprocess
+    import sys
+
+    code = ("import sys, hashlib; sys.path.insert(0, %r); import numpy as np; from open3d_slam_amd import backend, synthetic as syn; "
+            "be = backend.Backend(0); scene = syn.make_scene(); h = hashlib.sha1(); "
+            "[ (lambda c: (be.estimate_normals(c, 2.0, 10), h.update(be.download(c)[1].tobytes()), be.free(c)))"
+            "(be.voxel_down_sample(be.upload(syn.vlp16_scan(scene, syn.make_pose([0.3 * k, 0, 0], [0, 0, 2.0 * k]), frame=k, n_az=256 + 64 * (k %% 3))), 0.1)) "
+            "for k in range(8) ]; print(h.hexdigest())" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    outs = [subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True, env=dict(os.environ, O3DS_POOL_CAP_MB=cap)).stdout.strip()
+            for cap in ("32768", "1")]
+    assert outs[0] == outs[1] and len(outs[0]) == 40
