@@ -1907,6 +1907,48 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
     box_copy(out, in);
   }
   if (out.has_box) box_inflate(out);
+  // VoxelDownSample proper: no sort (cloud_kernels.hpp, VoxTable); O3DS_VOXEL_SORT=1 keeps the sort-based path below for A/B runs
+  static const bool voxel_sort = getenv("O3DS_VOXEL_SORT") != nullptr;
+  if (mode == 0 && !voxel_sort && n < ((size_t)1 << 30)) {
+    size_t cap = 1024;
+    while (cap < 2 * n) cap <<= 1;
+    unsigned char* tab = nullptr;
+    int *slot_of = nullptr, *flag = nullptr, *rank = nullptr, *seg_cnt = nullptr, *seg_start = nullptr;
+    uint32_t* members = nullptr;
+    TMP_ALLOC(tab, 16 * cap);
+    TMP_ALLOC(slot_of, sizeof(int) * n);
+    TMP_ALLOC(flag, sizeof(int) * (n + 1));
+    TMP_ALLOC(rank, sizeof(int) * (n + 1));
+    TMP_ALLOC(members, sizeof(uint32_t) * n);
+    VoxTable t{(unsigned long long*)tab, (unsigned int*)(tab + 8 * cap), (unsigned int*)(tab + 12 * cap), (unsigned int)(cap - 1)};
+    HIP_TRY(hipMemsetAsync(tab, 0xff, 16 * cap, h->stream));
+    vox_insert_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>((const P4*)in.pts, n, ox, oy, oz, voxel, crop, filter ? 1 : 0, t, slot_of);
+    vox_flag_kernel<<<grid_for(n + 1), kBlock, 0, h->stream>>>(slot_of, n, t, flag);
+    int rc = exclusive_scan_int(h, flag, rank, n + 1);
+    if (rc) return rc;
+    int m = 0;
+    rc = read_back(h, {{&m, rank + n, sizeof(int)}});
+    if (rc) return rc;
+    out.n = (size_t)m;
+    if (m == 0) return O3DS_OK;
+    TMP_ALLOC(seg_cnt, sizeof(int) * ((size_t)m + 1));
+    TMP_ALLOC(seg_start, sizeof(int) * ((size_t)m + 1));
+    vox_number_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(slot_of, flag, rank, n, (size_t)m, t, seg_cnt);
+    rc = exclusive_scan_int(h, seg_cnt, seg_start, (size_t)m + 1);
+    if (rc) return rc;
+    vox_gather_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(slot_of, n, t, seg_start, members);
+    HIP_TRY(dev_alloc(h, (void**)&out.pts, sizeof(P4) * out.n));
+    if (in.nrm) HIP_TRY(dev_alloc(h, (void**)&out.nrm, sizeof(P4) * out.n));
+    vox_mean_kernel<P4><<<grid_for(out.n), kBlock, 0, h->stream>>>((const P4*)in.pts, (const P4*)in.nrm, seg_start, out.n, members, 0, (P4*)out.pts,
+                                                                  (P4*)out.nrm);
+    if (in.col) {  // [O3D] VoxelDownSample: AccumulatedPoint averages the colours
+      HIP_TRY(dev_alloc(h, (void**)&out.col, sizeof(P4) * out.n));
+      vox_mean_kernel<P4><<<grid_for(out.n), kBlock, 0, h->stream>>>((const P4*)in.col, nullptr, seg_start, out.n, members, 1, (P4*)out.col, nullptr);
+    }
+    HIP_TRY(hipGetLastError());
+    dbg_sync(h, 8);
+    return O3DS_OK;
+  }
   unsigned long long *k0 = nullptr, *k1 = nullptr, *d_scalar = nullptr;
   uint32_t *v0 = nullptr, *v1 = nullptr;
   size_t merged_n_inside = 0;

@@ -459,6 +459,160 @@ __global__ __launch_bounds__(kBlock) void segment_last_kernel(const P4* __restri
 // (key -> segment) and one thread per ray marches and probes; marking a point is an idempotent store, no atomics.
 constexpr unsigned long long kEmptyKey = ~0ull;
 
+// ---- VoxelDownSample without a sort -------------------------------------------------------------------------------------------------------
+// [O3D] VoxelDownSample walks the points once and keeps an unordered_map voxel -> AccumulatedPoint, so a voxel's sum runs over its points
+// in cloud order.  Same thing here: an open-addressing table finds the voxels (which thread claims a slot is a race, what is READ from the
+// table is not: the set of keys, a voxel's smallest point index and its count), the voxels are numbered in order of first appearance
+// by a scan over "I am the first point of my voxel" flags, the members of a voxel are gathered and put in ascending index order, then
+// summed.  Four small kernels and two scans instead of a 64-bit radix sort of every point; output order = first appearance, which is
+// also the order the oracle emits.  One 0xff memset initialises the table: empty keys, first = UINT_MAX, and the counter holds ~count.
+struct VoxTable {
+  unsigned long long* key;  // [cap]
+  unsigned int* first;      // [cap] smallest point index of the voxel; after vox_number_kernel: the voxel's output position
+  unsigned int* ncnt;       // [cap] ~(number of points)
+  unsigned int mask;
+};
+
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void vox_insert_kernel(const P4* __restrict__ pts, size_t n, double ox, double oy, double oz, double v,
+                                                            CropDev crop, int filter, VoxTable t, int* __restrict__ slot_of) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const P4 p = pts[i];
+    const double x = (double)p.x, y = (double)p.y, z = (double)p.z;
+    if (filter && !crop_contains(crop, x, y, z)) {
+      slot_of[i] = -1;
+      continue;
+    }
+    const unsigned long long k = pack_key((long long)floor((x - ox) / v), (long long)floor((y - oy) / v), (long long)floor((z - oz) / v));
+    unsigned int slot = (unsigned int)((k * 0x9E3779B97F4A7C15ull) >> 32) & t.mask;
+    while (true) {
+      const unsigned long long prev = atomicCAS(&t.key[slot], kEmptyKey, k);
+      if (prev == kEmptyKey || prev == k) break;
+      slot = (slot + 1) & t.mask;
+    }
+    slot_of[i] = (int)slot;
+    atomicMin(&t.first[slot], (unsigned int)i);
+    atomicSub(&t.ncnt[slot], 1u);
+  }
+}
+
+// flag[i] = point i opens its voxel; flag[n] = 0 (the scan's sentinel)
+__global__ __launch_bounds__(kBlock) void vox_flag_kernel(const int* __restrict__ slot_of, size_t n, VoxTable t, int* __restrict__ flag) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i <= n; i += (size_t)gridDim.x * kBlock) {
+    int f = 0;
+    if (i < n) {
+      const int s = slot_of[i];
+      f = s >= 0 && t.first[s] == (unsigned int)i;
+    }
+    flag[i] = f;
+  }
+}
+
+// the first point of voxel number r writes the voxel's size and leaves r in the table for the other members
+__global__ __launch_bounds__(kBlock) void vox_number_kernel(const int* __restrict__ slot_of, const int* __restrict__ flag, const int* __restrict__ rank,
+                                                            size_t n, size_t m, VoxTable t, int* __restrict__ seg_cnt) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    if (i == 0) seg_cnt[m] = 0;
+    if (!flag[i]) continue;
+    const int s = slot_of[i];
+    const int r = rank[i];
+    seg_cnt[r] = (int)~t.ncnt[s];
+    t.first[s] = (unsigned int)r;
+  }
+}
+
+// members[seg_start[r] ..] = the point indices of voxel r, in whatever order the atomics hand out (put in order by vox_mean_kernel).
+// The counter still holds ~count: the j-th increment returns ~count + j.
+__global__ __launch_bounds__(kBlock) void vox_gather_kernel(const int* __restrict__ slot_of, size_t n, VoxTable t, const int* __restrict__ seg_start,
+                                                            uint32_t* __restrict__ members) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const int s = slot_of[i];
+    if (s < 0) continue;
+    const unsigned int r = t.first[s];
+    const int b = seg_start[r], cnt = seg_start[r + 1] - b;
+    const unsigned int j = atomicAdd(&t.ncnt[s], 1u) + (unsigned int)cnt + 1u;  // old - ~cnt
+    members[(size_t)b + j] = (uint32_t)i;
+  }
+}
+
+// ascending order of a short list kept in global memory: insertion sort, heap sort beyond 16 entries (a voxel next to the sensor
+// can hold a hundred returns)
+__device__ inline void sort_indices(uint32_t* a, int k) {
+  if (k <= 16) {
+    for (int i = 1; i < k; ++i) {
+      const uint32_t x = a[i];
+      int j = i - 1;
+      while (j >= 0 && a[j] > x) {
+        a[j + 1] = a[j];
+        --j;
+      }
+      a[j + 1] = x;
+    }
+    return;
+  }
+  auto sift = [&](int root, int end) {
+    const uint32_t x = a[root];
+    while (true) {
+      int c = 2 * root + 1;
+      if (c >= end) break;
+      if (c + 1 < end && a[c + 1] > a[c]) ++c;
+      if (a[c] <= x) break;
+      a[root] = a[c];
+      root = c;
+    }
+    a[root] = x;
+  };
+  for (int i = k / 2 - 1; i >= 0; --i) sift(i, k);
+  for (int e = k - 1; e > 0; --e) {
+    const uint32_t x = a[0];
+    a[0] = a[e];
+    a[e] = x;
+    sift(0, e);
+  }
+}
+
+// AccumulatedPoint::GetAveragePoint / GetAverageNormal / GetAverageColor ([O3D] PointCloud.cpp VoxelDownSample): sums in cloud order,
+// divided by the count; normals are averaged, not re-normalised.  attr_only: `members` is already in order (the colour pass).
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void vox_mean_kernel(const P4* __restrict__ pts, const P4* __restrict__ nrm, const int* __restrict__ seg_start,
+                                                          size_t m, uint32_t* __restrict__ members, int attr_only, P4* __restrict__ out_pts,
+                                                          P4* __restrict__ out_nrm) {
+  using R = typename Scalar<P4>::type;
+  for (size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x; r < m; r += (size_t)gridDim.x * kBlock) {
+    const int b = seg_start[r], e = seg_start[r + 1];
+    if (!attr_only) sort_indices(members + b, e - b);
+    double sx = 0, sy = 0, sz = 0, nx = 0, ny = 0, nz = 0;
+    for (int j = b; j < e; ++j) {
+      const uint32_t id = members[j];
+      const P4 p = pts[id];
+      sx += (double)p.x;
+      sy += (double)p.y;
+      sz += (double)p.z;
+      if (nrm) {
+        const P4 q = nrm[id];
+        nx += (double)q.x;
+        ny += (double)q.y;
+        nz += (double)q.z;
+      }
+    }
+    const double cnt = (double)(e - b);
+    P4 op;
+    op.x = (R)(sx / cnt);
+    op.y = (R)(sy / cnt);
+    op.z = (R)(sz / cnt);
+    op.i = (typename Scalar<P4>::index)r;
+    out_pts[r] = op;
+    if (nrm) {
+      P4 on;
+      on.x = (R)(nx / cnt);
+      on.y = (R)(ny / cnt);
+      on.z = (R)(nz / cnt);
+      on.i = 0;
+      out_nrm[r] = on;
+    }
+  }
+}
+
 // keys of the map points inside the wide cropping volume, everything else gets the pass-through bit (never probed)
 __global__ __launch_bounds__(kBlock) void carve_table_insert_kernel(const unsigned long long* __restrict__ keys, const int* __restrict__ seg_start,
                                                                     size_t n_seg, unsigned long long* __restrict__ tkey, int* __restrict__ tseg,
