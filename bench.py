@@ -278,6 +278,65 @@ def run_stream(be, scans32, profile=False):
     return out
 
 
+def run_stream_pipelined(device, scans32, depth=4):
+    """the same frames with odometry and mapping on two host threads, as the reference runs them (SlamWrapper.cpp:228-229 odometryWorker /
+    mappingWorker, a bounded buffer between them): LidarOdometry on one backend handle (its own stream), Mapper on another, each ingesting
+    the raw scan into its own handle (handles do not share clouds).  The mapper only reads the odometry pose of a frame that is already
+    through, so the poses are those of the serial loop, bit for bit (checked by the caller)."""
+    import queue
+    import threading
+
+    from open3d_slam_amd import backend, synthetic as syn
+    from open3d_slam_amd.mapper import Mapper
+    from open3d_slam_amd.odometry import LidarOdometry
+    from open3d_slam_amd.pointcloud import PointCloud
+
+    mp, op = stream_parameters()
+    be_o, be_m = backend.Backend(device), backend.Backend(device)
+    odo = LidarOdometry(be_o)
+    odo.setParameters(op)
+    mapper = Mapper(be_m, odo)
+    mapper.setParameters(mp)
+    q = queue.Queue(maxsize=depth)
+    err = []
+
+    def odometry_worker():
+        try:
+            for k, raw in enumerate(scans32):
+                cloud = PointCloud.from_pointcloud2(be_o, raw)
+                ok = odo.addRangeScan(cloud, 0.1 * k)
+                be_o.synchronize()
+                cloud.release()
+                assert ok, k
+                q.put(k)
+        except BaseException as e:  # noqa: BLE001 -- handed to the main thread
+            err.append(e)
+            q.put(-1)
+
+    th = threading.Thread(target=odometry_worker, daemon=True)
+    t_start = None
+    th.start()
+    frames = len(scans32)
+    for _ in range(frames):
+        k = q.get()
+        if k < 0:
+            raise err[0]
+        cloud = PointCloud.from_pointcloud2(be_m, scans32[k])
+        ok = mapper.addRangeMeasurement(cloud, 0.1 * k)
+        be_m.synchronize()
+        cloud.release()
+        assert ok, k
+        if k == 0:  # frame 0 only initialises (as in run_stream)
+            t_start = time.perf_counter()
+    elapsed = time.perf_counter() - t_start
+    th.join()
+    out = {"scans_per_sec": (frames - 1) / elapsed, "pose": mapper.getMapToRangeSensor().copy(),
+           "map_points": len(mapper.getActiveSubmap().getMapPointCloud())}
+    be_o.close()
+    be_m.close()
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ M1
 def run_m1(be, world, s_id, t_id, steps, warmup, barrier, drv):
     if drv is not None:
@@ -514,6 +573,11 @@ def main():
         be2.close()
         m2["calls"] = prof["calls"]
         m2["pose_repeats_bitwise_between_the_two_runs"] = bool(np.array_equal(m2["pose"], prof["pose"]))
+        run_stream_pipelined(local_rank, scans32[: min(12, len(scans32))])
+        pl = run_stream_pipelined(local_rank, scans32)
+        m2["pipelined"] = {"scans_per_sec": pl["scans_per_sec"], "map_points": pl["map_points"],
+                           "pose_equals_serial_bitwise": bool(np.array_equal(m2["pose"], pl["pose"])),
+                           "what": "odometry and mapping on two host threads and two backend handles (SlamWrapper.cpp:228-229), raw scan ingested by both"}
         del m2["pose"]
 
     if rank == 0:
