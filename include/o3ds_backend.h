@@ -177,8 +177,9 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
 /* RegistrationIcpGeneralized::registerClouds (CloudRegistration.cpp:16-21) = [O3D] RegistrationGeneralizedICP with a
  * default TransformationEstimationForGeneralizedICP (epsilon 1e-3): per-point covariances C = Rx diag(eps,1,1) Rx^T built from
  * the clouds' (unit) normals, residual (Ct + R Cs R^T)^-1/2 (p - q), same loop / solve / convergence test as point-to-plane.
- * BOTH clouds must carry normals -- open3d_slam always calls estimateNormalsOrCovariancesIfNeeded first
- * (CloudRegistration.cpp:22-30; Open3D itself would estimate them with KNN(20) when absent, which this backend does not). */
+ * open3d_slam always calls estimateNormalsOrCovariancesIfNeeded first (CloudRegistration.cpp:22-30); a cloud that still has no
+ * normals (null pointer / device cloud without normals) gets [O3D] InitializePointCloudForGeneralizedICP's treatment:
+ * EstimateNormals(KDTreeSearchParamKNN(20)) on a copy, the caller's cloud is left as it was. */
 int o3ds_icp_generalized(o3ds_handle h, const double* src_xyz, const double* src_normals, size_t n_src, const double* tgt_xyz,
                          const double* tgt_normals, size_t n_tgt, const double init[16], const o3ds_icp_params* params, o3ds_icp_result* out);
 int o3ds_icp_generalized_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3ds_crop* target_crop, const double init[16],

@@ -1036,6 +1036,11 @@ int read_state(o3ds_handle h, o3ds_icp_result* out, const IcpStateDev* d_from = 
 }  // namespace
 
 // =================================================================================================
+
+namespace {
+int gicp_knn_normals(o3ds_handle h, CloudRec& c);  // defined after normals_t
+}
+
 extern "C" {
 
 const char* o3ds_version(void) { return "o3ds_backend 0.1 (gfx950, hip, f32/f64 storage, f64 accumulate)"; }
@@ -1661,7 +1666,27 @@ int o3ds_icp_generalized_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target
   if (!params) return fail(h, O3DS_ERR_INVALID_ARG, "icp: null params");
   o3ds_icp_params p = *params;
   p.method = O3DS_ICP_GENERALIZED;
-  return o3ds_icp_register_dev(h, source, target, target_crop, init, &p, out);
+  // [O3D] InitializePointCloudForGeneralizedICP (call site CloudRegistration.cpp:16-21): a cloud that carries no normals gets
+  // EstimateNormals(KDTreeSearchParamKNN(20)) on a COPY -- the caller's cloud stays without normals
+  o3ds_cloud use[2] = {source, target}, own[2] = {0, 0};
+  int rc = O3DS_OK;
+  static const double kIdentity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  for (int k = 0; k < 2 && !rc; ++k) {
+    const CloudRec* c = find_cloud(h, use[k]);
+    if (!c || c->n == 0 || c->nrm) continue;
+    rc = o3ds_transform_cloud(h, use[k], kIdentity, &own[k]);  // x * 1 + 0: a bit-exact copy
+    if (rc) break;
+    use[k] = own[k];
+    CloudRec* cc = find_cloud(h, own[k]);
+    ArenaScope arena_scope(h);
+    rc = gicp_knn_normals(h, *cc);
+  }
+  if (!rc) rc = o3ds_icp_register_dev(h, use[0], use[1], target_crop, init, &p, out);
+  const std::string keep = h->err;
+  for (int k = 0; k < 2; ++k)
+    if (own[k]) (void)o3ds_cloud_free(h, own[k]);
+  if (rc) h->err = keep;
+  return rc;
 }
 
 int o3ds_icp_generalized(o3ds_handle h, const double* src_xyz, const double* src_normals, size_t n_src, const double* tgt_xyz,
@@ -1671,7 +1696,6 @@ int o3ds_icp_generalized(o3ds_handle h, const double* src_xyz, const double* src
   if (!params || !out || !init) return fail(h, O3DS_ERR_INVALID_ARG, "icp: null argument");
   if (!(params->max_correspondence_distance > 0.0)) return fail(h, O3DS_ERR_INVALID_ARG, "Invalid max_correspondence_distance.");
   if (n_tgt == 0) return fail(h, O3DS_ERR_EMPTY, "icp: empty target (map patch size is zero)");
-  if (!tgt_normals || (n_src > 0 && !src_normals)) return fail(h, O3DS_ERR_NO_NORMALS, "generalized ICP: both clouds need normals");
   o3ds_cloud s = 0, t = 0;
   int rc = o3ds_cloud_upload(h, src_xyz, src_normals, n_src, &s);
   if (rc) return rc;
@@ -2063,8 +2087,16 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
 }
 
 template <typename P4>
-int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn) {
+int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn, bool knn_raw = false) {
   if (c.n == 0) return O3DS_OK;
+  if (knn_raw) {  // [O3D] EstimateNormals(KDTreeSearchParamKNN(max_nn)) and nothing after it: a radius no pair of points exceeds
+    double mn[3], mx[3];
+    const int rb = bbox_of<P4>(h, (const P4*)c.pts, c.n, mn, mx);
+    if (rb) return rb;
+    const double dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+    radius = std::sqrt(dx * dx + dy * dy + dz * dz) * 1.001 + 1e-3;
+    if (!std::isfinite(radius)) return fail(h, O3DS_ERR_INVALID_ARG, "estimate_normals: non-finite points");
+  }
   // The cell size only steers the cost of the (exact) ring search: aim at max_nn / pi points per occupied cell, so that the
   // max_nn-th neighbour typically lies inside the first 3x3x3 ring.  The density comes from a pilot grid at radius/8 -- one
   // extra index build, one counting kernel and a host round trip -- so it is remembered per (radius, max_nn) and reused
@@ -2163,7 +2195,7 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn) {
       normals_kernel<P4, 32><<<gsz, 256, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, d_sums, d_cnts);
     else
       normals_kernel<P4, 128><<<gsz, 256, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, d_sums, d_cnts);
-    normals_finish_kernel<P4><<<(unsigned int)((c.n + 255) / 256), 256, 0, h->stream>>>(p_sp, c.n, d_sums, d_cnts, p_out);
+    normals_finish_kernel<P4><<<(unsigned int)((c.n + 255) / 256), 256, 0, h->stream>>>(p_sp, c.n, d_sums, d_cnts, p_out, knn_raw ? 1 : 0);
     span_mark(h, kSpanNormalsKernels);
   }
   HIP_TRY(hipGetLastError());
@@ -2198,6 +2230,10 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn) {
   box_copy(c, tmp);  // the box an index build reduced is kept for the cloud's next index
   free_index(h, c);  // the cloud's own index (if any) no longer matches its normals
   return O3DS_OK;
+}
+
+int gicp_knn_normals(o3ds_handle h, CloudRec& c) {
+  return c.precision == O3DS_PRECISION_F64 ? normals_t<P4d>(h, c, 0.0, 20, true) : normals_t<P4f>(h, c, 0.0, 20, true);
 }
 
 template <typename P4>

@@ -229,12 +229,14 @@ __device__ __forceinline__ void cov_from_cumulants(const double s[9], int k, dou
 }
 
 // ComputeNormal's result -> NormalizeNormals -> OrientNormalsTowardsCameraLocation(0,0,0), for the point (px,py,pz)
-__device__ __forceinline__ void normalize_orient(double nv[3], double px, double py, double pz) {
+// raw: [O3D] EstimateNormals alone (a zero vector becomes (0,0,1), nothing else) -- what InitializePointCloudForGeneralizedICP uses
+__device__ __forceinline__ void normalize_orient(double nv[3], double px, double py, double pz, bool raw = false) {
   double nn = sqrt(dot3(nv, nv));
   if (nn == 0.0) {
     nv[0] = 0, nv[1] = 0, nv[2] = 1;
     nn = 1.0;
   }
+  if (raw) return;
   nv[0] /= nn, nv[1] /= nn, nv[2] /= nn;
   if (nv[0] != nv[0]) nv[0] = 0, nv[1] = 0, nv[2] = 1;
   const double ref[3] = {-px, -py, -pz};

@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256) void normals_kernel(const P4* __restrict__ pts
 // need one lane each -- run as a kernel of their own, one thread per point, rather than on 4 of the 64 lanes of a search wavefront
 template <typename P4>
 __global__ __launch_bounds__(256) void normals_finish_kernel(const P4* __restrict__ sp /* sorted by cell */, size_t n, const double* __restrict__ sums,
-                                                             const int* __restrict__ cnts, P4* __restrict__ out_nrm) {
+                                                             const int* __restrict__ cnts, P4* __restrict__ out_nrm, int raw = 0) {
   using R = typename Scalar<P4>::type;
   const size_t pj = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (pj < n) {
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256) void normals_finish_kernel(const P4* __restric
     }
     double nv[3];
     det::fast_eigen3x3_min(cov, nv);
-    det::normalize_orient(nv, (double)q.x, (double)q.y, (double)q.z);
+    det::normalize_orient(nv, (double)q.x, (double)q.y, (double)q.z, raw != 0);
     P4 o;
     o.x = (R)nv[0];
     o.y = (R)nv[1];

@@ -1434,7 +1434,15 @@ void orc_fast_eigen3x3_min_evec(const double cov[9], double out[3]) {
 
 /* [O3D] EstimatePerPointCovariances + ComputeNormal + NormalizeNormals +
  * OrientNormalsTowardsCameraLocation(0,0,0); call site src/CloudRegistration.cpp:49-56 */
+void orc_estimate_normals_ex(const double* pts, size_t n, double radius, int max_nn, int raw, double* normals);
 void orc_estimate_normals(const double* pts, size_t n, double radius, int max_nn, double* normals) {
+  orc_estimate_normals_ex(pts, n, radius, max_nn, 0, normals);
+}
+
+/* radius <= 0: KDTreeSearchParamKNN(max_nn) instead of the hybrid search.  raw != 0: [O3D] EstimateNormals alone (ComputeNormal's vector,
+ * (0,0,1) when it is zero) without NormalizeNormals / OrientNormalsTowardsCameraLocation -- what
+ * InitializePointCloudForGeneralizedICP does to a cloud that has no normals (KNN(20)), call site src/CloudRegistration.cpp:16-21 */
+void orc_estimate_normals_ex(const double* pts, size_t n, double radius, int max_nn, int raw, double* normals) {
   orc_kdtree* t = orc_kdtree_build(pts, n);
 #pragma omp parallel
   {
@@ -1443,7 +1451,7 @@ void orc_estimate_normals(const double* pts, size_t n, double radius, int max_nn
 #pragma omp for schedule(static)
     for (long i = 0; i < (long)n; ++i) {
       const double* p = pts + 3 * (size_t)i;
-      int k = orc_kdtree_search_hybrid(t, p, radius, max_nn, idx, d2);
+      int k = radius > 0.0 ? orc_kdtree_search_hybrid(t, p, radius, max_nn, idx, d2) : orc_kdtree_search_knn(t, p, max_nn, idx, d2);
       double cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
       if (k >= 3) {
         double c[9] = {0};
@@ -1475,6 +1483,12 @@ void orc_estimate_normals(const double* pts, size_t n, double radius, int max_nn
         nv[1] = 0;
         nv[2] = 1;
         nn = 1.0;
+      }
+      if (raw) {
+        normals[3 * (size_t)i] = nv[0];
+        normals[3 * (size_t)i + 1] = nv[1];
+        normals[3 * (size_t)i + 2] = nv[2];
+        continue;
       }
       /* NormalizeNormals */
       nv[0] /= nn;

@@ -90,6 +90,8 @@ def lib():
         L.orc_gicp_jtj_jtr.argtypes = [_dp, _dp, C.c_size_t, _dp, _dp, _ip, _dp, _dp]
         L.orc_covariance_from_normal.argtypes = [_dp, C.c_double, _dp]
         L.orc_estimate_normals.argtypes = [_dp, C.c_size_t, C.c_double, C.c_int, _dp]
+        L.orc_estimate_normals_ex.argtypes = [_dp, C.c_size_t, C.c_double, C.c_int, C.c_int, _dp]
+        L.orc_estimate_normals_ex.restype = None
         L.orc_fast_eigen3x3_min_evec.argtypes = [_dp, _dp]
         L.orc_acos.restype = C.c_double
         L.orc_acos.argtypes = [C.c_double]
@@ -365,6 +367,14 @@ def estimate_normals(pts, radius, max_nn):
     pts, pp = _d(pts)
     out = np.empty_like(pts)
     lib().orc_estimate_normals(pp, len(pts), radius, max_nn, out.ctypes.data_as(_dp))
+    return out
+
+
+def estimate_normals_knn_raw(pts, max_nn=20):
+    """[O3D] EstimateNormals(KDTreeSearchParamKNN(max_nn)) alone -- InitializePointCloudForGeneralizedICP on a cloud without normals"""
+    pts, pp = _d(pts)
+    out = np.empty_like(pts)
+    lib().orc_estimate_normals_ex(pp, len(pts), 0.0, max_nn, 1, out.ctypes.data_as(_dp))
     return out
 
 

@@ -376,13 +376,32 @@ def test_gicp_device_forms_and_errors(backend_f32, oracle, small_c2):
     got = backend_f32.icp_generalized_dev(s, t, 1.0, max_iter=4, rel_fitness=0.0, rel_rmse=0.0,
                                           target_crop=backend.make_crop(backend.CROP_MAX_RADIUS, center=(1.0, -2.0, 0.0), rmax=20.0))
     _check(got, ref, len(src), TOL_T, TOL_R)
-    bare = backend_f32.upload(src)
-    with pytest.raises(backend.BackendError) as e:
-        backend_f32.icp_generalized_dev(bare, t, 1.0)
-    assert e.value.code == backend.ERR_NO_NORMALS
     with pytest.raises(backend.BackendError):
         backend_f32.set_gicp_epsilon(0.0)
-    for c in (s, t, bare):
+    for c in (s, t):
+        backend_f32.free(c)
+
+
+def test_gicp_without_normals_estimates_them_like_open3d(backend_f64, backend_f32, oracle, small_c2):
+    """[O3D] InitializePointCloudForGeneralizedICP (call site CloudRegistration.cpp:16-21): a cloud that has no normals gets
+    EstimateNormals(KDTreeSearchParamKNN(20)) -- no NormalizeNormals, no orientation -- on a copy"""
+    src, tgt, nrm, _ = small_c2
+    sn, tn = oracle.estimate_normals_knn_raw(src, 20), oracle.estimate_normals_knn_raw(tgt, 20)
+    kw = dict(max_iter=6, rel_fitness=0.0, rel_rmse=0.0)
+    ref = oracle.icp_generalized(src, sn, tgt, tn, 1.0, **kw)
+    got = backend_f64.icp_generalized(src, None, tgt, None, 1.0, **kw)
+    assert got["n_corr"] == ref["n_corr"]
+    _check(got, ref, len(src), TOL_T64, TOL_R64)
+    # one side only: the given normals are used as they are, the other side is estimated
+    ref1 = oracle.icp_generalized(src, sn, tgt, nrm, 1.0, **kw)
+    got1 = backend_f64.icp_generalized(src, None, tgt, nrm, 1.0, **kw)
+    _check(got1, ref1, len(src), TOL_T64, TOL_R64)
+    # device form: the caller's clouds stay without normals
+    s, t = backend_f32.upload(src), backend_f32.upload(tgt)
+    got32 = backend_f32.icp_generalized_dev(s, t, 1.0, **kw)
+    _check(got32, ref, len(src), TOL_T, TOL_R)
+    assert backend_f32.size(s) == (len(src), False) and backend_f32.size(t) == (len(tgt), False)
+    for c in (s, t):
         backend_f32.free(c)
 
 
