@@ -35,6 +35,8 @@ struct CloudRec {
   void* col = nullptr;  // P4[n] or null: PointCloud::colors_ (carried by the cloud operations, never read by registration)
   // nearest-neighbour index
   bool has_index = false;
+  bool index_byproduct = false;  // the index was left by the normal estimation (its cell size suits THAT search): a registration
+                                 // keeps it if the cell is within [r / 8, 0.75 r] of its own radius and rebuilds otherwise
   GridDev grid{};
   int* cell_start = nullptr;
   void* spts = nullptr;
@@ -463,6 +465,7 @@ void free_index(o3ds_handle h, CloudRec& c) {
   c.cell_start = nullptr;
   c.spts = c.snrm = nullptr;
   c.has_index = false;
+  c.index_byproduct = false;
 }
 void free_cloud(o3ds_handle h, CloudRec& c) {
   free_index(h, c);
@@ -911,7 +914,9 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
   CloudRec* tgt = find_cloud(h, target);
   int rc = validate_icp(h, src, tgt, params);
   if (rc) return rc;
-  if (!tgt->has_index || (tgt->nrm && !tgt->snrm)) {
+  const double r_hint = params->max_correspondence_distance;
+  static const double reuse_max = getenv("O3DS_INDEX_REUSE_MAX") ? atof(getenv("O3DS_INDEX_REUSE_MAX")) : 0.75;  // tuning experiments
+  if (!tgt->has_index || (tgt->nrm && !tgt->snrm) || (tgt->index_byproduct && (tgt->grid.cell < r_hint / 8.0 || tgt->grid.cell > r_hint * reuse_max))) {
     rc = build_index(h, *tgt, params->max_correspondence_distance / 4.0);
     if (rc) return rc;
   }
@@ -2195,7 +2200,14 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn, bool knn_ra
       normals_kernel<P4, 32><<<gsz, 256, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, d_sums, d_cnts);
     else
       normals_kernel<P4, 128><<<gsz, 256, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, d_sums, d_cnts);
-    normals_finish_kernel<P4><<<(unsigned int)((c.n + 255) / 256), 256, 0, h->stream>>>(p_sp, c.n, d_sums, d_cnts, p_out, knn_raw ? 1 : 0);
+    // the grid, the cell-ordered points and (written here) the cell-ordered normals are a complete nearest-neighbour index of the cloud:
+    // kept, so that a registration against this cloud (scan-to-scan odometry: the previous scan) does not build another one
+    if (dev_alloc(h, (void**)&tmp.snrm, sizeof(P4) * c.n) != hipSuccess) {
+      tmp.pts = nullptr;
+      free_index(h, tmp);
+      return fail(h, O3DS_ERR_OOM, "estimate_normals: out of device memory");
+    }
+    normals_finish_kernel<P4><<<(unsigned int)((c.n + 255) / 256), 256, 0, h->stream>>>(p_sp, c.n, d_sums, d_cnts, p_out, knn_raw ? 1 : 0, (P4*)tmp.snrm);
     span_mark(h, kSpanNormalsKernels);
   }
   HIP_TRY(hipGetLastError());
@@ -2226,9 +2238,11 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn, bool knn_ra
 #endif
   }
   tmp.pts = nullptr;
-  free_index(h, tmp);
-  box_copy(c, tmp);  // the box an index build reduced is kept for the cloud's next index
+  box_copy(c, tmp);  // the box an index build reduced is kept for the cloud
   free_index(h, c);  // the cloud's own index (if any) no longer matches its normals
+  c.grid = tmp.grid, c.cell_start = tmp.cell_start, c.spts = tmp.spts, c.snrm = tmp.snrm;
+  c.has_index = true;
+  c.index_byproduct = true;
   return O3DS_OK;
 }
 

@@ -520,7 +520,8 @@ __global__ __launch_bounds__(256) void normals_kernel(const P4* __restrict__ pts
 // need one lane each -- run as a kernel of their own, one thread per point, rather than on 4 of the 64 lanes of a search wavefront
 template <typename P4>
 __global__ __launch_bounds__(256) void normals_finish_kernel(const P4* __restrict__ sp /* sorted by cell */, size_t n, const double* __restrict__ sums,
-                                                             const int* __restrict__ cnts, P4* __restrict__ out_nrm, int raw = 0) {
+                                                             const int* __restrict__ cnts, P4* __restrict__ out_nrm, int raw = 0,
+                                                             P4* __restrict__ out_sorted = nullptr /* the same normals in cell order */) {
   using R = typename Scalar<P4>::type;
   const size_t pj = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (pj < n) {
@@ -542,6 +543,7 @@ __global__ __launch_bounds__(256) void normals_finish_kernel(const P4* __restric
     o.z = (R)nv[2];
     o.i = 0;
     out_nrm[(size_t)q.i] = o;
+    if (out_sorted) out_sorted[pj] = o;
   }
 }
 

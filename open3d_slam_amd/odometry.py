@@ -50,7 +50,7 @@ class LidarOdometry:
             return False  # measurements came out of order
         pre = self.preprocess(cloud)
         # B3: registers PREVIOUS -> CURRENT and integrates the inverse; the target normals are the current scan's
-        self.be.build_index(pre.id, self.cloudRegistration_.maxCorrespondenceDistance_)
+        # (the grid the normal estimation just built for `pre` is kept with the cloud and serves as the registration's target index)
         result = self.cloudRegistration_.registerClouds(self.cloudPrev_, pre, np.eye(4))
         ok = result.fitness_ > 0.1  # Odometry.cpp:51 ("todo magic")
         if not ok:
