@@ -603,6 +603,12 @@ int build_index_t(o3ds_handle h, CloudRec& c, double cell) {
   return O3DS_OK;
 }
 
+// grid cell of a registration target = max_correspondence_distance / this (O3DS_INDEX_CELL_DIV: tuning experiments)
+double index_cell_div() {
+  static const double d = getenv("O3DS_INDEX_CELL_DIV") ? std::max(1.0, atof(getenv("O3DS_INDEX_CELL_DIV"))) : 4.0;
+  return d;
+}
+
 int build_index(o3ds_handle h, CloudRec& c, double cell) {
   return c.precision == O3DS_PRECISION_F64 ? build_index_t<P4d>(h, c, cell) : build_index_t<P4f>(h, c, cell);
 }
@@ -917,7 +923,7 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
   const double r_hint = params->max_correspondence_distance;
   static const double reuse_max = getenv("O3DS_INDEX_REUSE_MAX") ? atof(getenv("O3DS_INDEX_REUSE_MAX")) : 0.75;  // tuning experiments
   if (!tgt->has_index || (tgt->nrm && !tgt->snrm) || (tgt->index_byproduct && (tgt->grid.cell < r_hint / 8.0 || tgt->grid.cell > r_hint * reuse_max))) {
-    rc = build_index(h, *tgt, params->max_correspondence_distance / 4.0);
+    rc = build_index(h, *tgt, params->max_correspondence_distance / index_cell_div());
     if (rc) return rc;
   }
   if (src->n > h->nn_cache_cap) {
@@ -1388,7 +1394,7 @@ int o3ds_cloud_build_index(o3ds_handle h, o3ds_cloud id, double max_corr_hint, d
   ArenaScope arena_scope(h);
   CloudRec* c = find_cloud(h, id);
   if (!c) return fail(h, O3DS_ERR_INVALID_ARG, "build_index: unknown cloud id");
-  double cell = cell_size > 0.0 ? cell_size : max_corr_hint / 4.0;
+  double cell = cell_size > 0.0 ? cell_size : max_corr_hint / index_cell_div();
   if (!(cell > 0.0)) return fail(h, O3DS_ERR_INVALID_ARG, "build_index: need cell_size > 0 or max_corr_hint > 0");
   int rc = build_index(h, *c, cell);
   return rc;
@@ -2934,7 +2940,7 @@ int o3ds_map_insert_scan(o3ds_handle h, o3ds_cloud map, o3ds_cloud scan, const d
   if (rc) return rc;
   m = find_cloud(h, map);
   if (max_corr_hint > 0.0) {
-    rc = build_index(h, *m, max_corr_hint / 4.0);
+    rc = build_index(h, *m, max_corr_hint / index_cell_div());
   }
   return rc;
 }
