@@ -78,6 +78,22 @@ def stream_parameters(max_iter=50):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baselines (oracle = checker)
+def cpu_quota():
+    """CPUs this container may use at once (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited: the GPU boxes expose all 256
+    hardware threads of the host but allow 16 CPUs' worth of time, which is why the OpenMP sweep peaks at 16 threads there"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:
+        return None
+
+
 def cpu_baseline_m1(src, tgt, nrm, budget_s=16.0):
     """CPU restatement of Open3D v0.15.1 (the oracle, 'port'), timed on this box's host cores.  The thread count is the
     best of a short sweep: on the 2x64-core EPYC host of the MI355X boxes the OpenMP loops peak at 16-32 threads
@@ -103,7 +119,9 @@ def cpu_baseline_m1(src, tgt, nrm, budget_s=16.0):
                 break
         return reps, spent, res
 
-    cands = [t for t in (8, 16, 32, 64, 128) if t <= ncpu] or [ncpu]
+    quota = cpu_quota()
+    limit = min(ncpu, int(2 * quota)) if quota else ncpu  # threads far beyond the container's CPU allowance are throttled, not faster
+    cands = [t for t in (8, 16, 32, 64, 128) if t <= limit] or [min(ncpu, 8)]
     sweep, best_t, best_rate = {}, cands[0], 0.0
     for th in cands:
         po.lib().orc_set_num_threads(th)
@@ -116,9 +134,10 @@ def cpu_baseline_m1(src, tgt, nrm, budget_s=16.0):
     one()
     reps, spent, res = sustained(budget_s / 2.0)
     per_reg = spent / reps
-    return dict(value=ICP_ITERS / per_reg, unit="icp_iterations/s", cores=best_t, kind="port",
+    return dict(value=ICP_ITERS / per_reg, unit="icp_iterations/s", cores=best_t, kind="port", cpu_quota=quota,
                 sample=f"{reps} x (64k scan vs 1M map, {ICP_ITERS} iters, KD-tree prebuilt) = {spent:.1f}s at the best thread count of the sweep "
-                       f"{sweep} it/s (host has {ncpu} hardware threads); KD-tree build {build_s*1e3:.0f} ms -> "
+                       f"{sweep} it/s (host has {ncpu} hardware threads, this container's CPU allowance (cgroup cpu.max) is "
+                       f"{quota if quota else 'unlimited'}); KD-tree build {build_s*1e3:.0f} ms -> "
                        f"{ICP_ITERS/(per_reg+build_s):.2f} it/s when rebuilt per call as the reference does; "
                        f"CPU restatement of Open3D v0.15.1, {best_t} OpenMP threads"), res, best_t
 
@@ -644,7 +663,7 @@ def main():
             out["parity_vs_cpu"] = {"dt_m": dt, "dr_rad": dr, "fitness_gpu": res["fitness"], "fitness_cpu": cres["fitness"]}
             out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
             if m2 is not None and args.m2_cpu_frames > 1:
-                cb2, _ = cpu_baseline_m2(scans32, min(args.m2_cpu_frames, len(scans32)), min(32, os.cpu_count() or 1))
+                cb2, _ = cpu_baseline_m2(scans32, min(args.m2_cpu_frames, len(scans32)), best_t)  # the thread count the M1 sweep found best
                 out["scans_per_sec"]["cpu_baseline"] = cb2
                 out["scans_per_sec"]["speedup_vs_cpu_baseline"] = out["scans_per_sec"]["scans_per_sec"] / cb2["value"]
         print(json.dumps(out), flush=True)

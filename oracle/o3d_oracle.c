@@ -11,6 +11,9 @@
 
 #include <float.h>
 #include <math.h>
+#ifndef ORC_SEARCH_SCHEDULE
+#define ORC_SEARCH_SCHEDULE schedule(dynamic, 128)
+#endif
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -250,21 +253,23 @@ void orc_evaluate(const orc_kdtree* t, const double* src, size_t n, double max_c
   double err2 = 0.0;
   uint64_t cnt = 0;
   if (max_corr > 0.0) {
-#pragma omp parallel for schedule(static) reduction(+ : err2, cnt)
+    /* the searches are independent and of very uneven cost (a query without a neighbour within r visits the most nodes): dealt out
+     * dynamically; the squared distances are summed afterwards in index order, so the result does not depend on the thread count */
+    double* d2v = d2_out ? d2_out : (double*)malloc(sizeof(double) * (n ? n : 1));
+#pragma omp parallel for ORC_SEARCH_SCHEDULE
     for (long i = 0; i < (long)n; ++i) {
       int32_t id;
       double d2;
       int k = orc_kdtree_search_hybrid(t, src + 3 * (size_t)i, max_corr, 1, &id, &d2);
-      if (k > 0) {
-        corr[i] = id;
-        if (d2_out) d2_out[i] = d2;
-        err2 += d2;
-        cnt += 1;
-      } else {
-        corr[i] = -1;
-        if (d2_out) d2_out[i] = -1.0;
-      }
+      corr[i] = k > 0 ? id : -1;
+      d2v[i] = k > 0 ? d2 : -1.0;
     }
+    for (size_t i = 0; i < n; ++i)
+      if (corr[i] >= 0) {
+        err2 += d2v[i];
+        cnt += 1;
+      }
+    if (!d2_out) free(d2v);
   } else {
     for (size_t i = 0; i < n; ++i) corr[i] = -1;
   }
