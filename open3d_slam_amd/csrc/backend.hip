@@ -2192,8 +2192,8 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn, bool knn_ra
 #ifdef O3DS_NRM_CHECK
     unsigned long long* d_ws = nullptr;
     if (getenv("O3DS_NRM_STATS_FILE")) {
-      HIP_TRY(hipMalloc((void**)&d_ws, sizeof(unsigned long long) * 6 * 4 * gsz));
-      HIP_TRY(hipMemset(d_ws, 0, sizeof(unsigned long long) * 6 * 4 * gsz));
+      HIP_TRY(hipMalloc((void**)&d_ws, sizeof(unsigned long long) * o3ds::kNrmStatWords * 4 * gsz));
+      HIP_TRY(hipMemset(d_ws, 0, sizeof(unsigned long long) * o3ds::kNrmStatWords * 4 * gsz));
     }
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(o3ds::g_nrm_wave_stats), &d_ws, sizeof(d_ws)));
 #endif
@@ -2224,7 +2224,7 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn, bool knn_ra
     unsigned long long* d_ws = nullptr;
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpyFromSymbol(&d_ws, HIP_SYMBOL(o3ds::g_nrm_wave_stats), sizeof(d_ws)));
-    std::vector<unsigned long long> ws((size_t)6 * 4 * gsz);
+    std::vector<unsigned long long> ws((size_t)o3ds::kNrmStatWords * 4 * gsz);
     HIP_TRY(hipMemcpy(ws.data(), d_ws, sizeof(unsigned long long) * ws.size(), hipMemcpyDeviceToHost));
     (void)hipFree(d_ws);
     if (FILE* f = fopen(sf, "wb")) {

@@ -35,9 +35,24 @@ namespace o3ds {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
   } while (0)
 #endif
+#ifdef O3DS_NRM_PHASES  // development aid: shader-clock cycles per phase of the kernel, per wavefront (implies O3DS_NRM_CHECK)
+#define O3DS_PH(k)                      \
+  do {                                  \
+    const long long _t = clock64();     \
+    st_ph[k] += _t - st_last;           \
+    st_last = _t;                       \
+  } while (0)
+#else
+#define O3DS_PH(k) ((void)0)
+#endif
 #ifdef O3DS_NRM_CHECK  // development aid: invariant violations counted in a device array (o3ds_debug_counters)
 __device__ unsigned int g_nrm_dbg[8];
 #define O3DS_NRM_BAD(k) atomicAdd(&g_nrm_dbg[k], 1u)
+#ifdef O3DS_NRM_PHASES
+constexpr int kNrmStatWords = 16;
+#else
+constexpr int kNrmStatWords = 6;
+#endif
 __device__ unsigned long long* g_nrm_wave_stats;  // per wavefront: {clocks, start, rounds, max ring, chunks, merges} when set
 #else
 #define O3DS_NRM_BAD(k) ((void)0)
@@ -108,6 +123,9 @@ __global__ __launch_bounds__(256) void normals_kernel(const P4* __restrict__ pts
   const unsigned long long st_t0 = wall_clock64();
   unsigned int st_rounds = 0, st_ring = 0, st_chunks = 0, st_cand = 0;
 #endif
+#ifdef O3DS_NRM_PHASES
+  long long st_ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = clock64();
+#endif
   const int* __restrict__ cs = g.cell_start;
   const double cell2 = g.cell * g.cell * (1.0 - 2e-6);
   // queries are taken in CELL order (sp), so the four points of a wavefront walk the same few cells
@@ -133,6 +151,7 @@ __global__ __launch_bounds__(256) void normals_kernel(const P4* __restrict__ pts
     // ... and this lane's cursor: it owns the rows t = l, l + 16, ... of the ring
     int tnext = l;
 
+    O3DS_PH(0);  // set-up
     for (;;) {
       // ---- find work: every lane moves to its next row that the current bound does not rule out (arithmetic only: at ring 5-6 of a
       // sparse neighbourhood nearly all of the 100-200 rows are ruled out); when no lane of the group has one left the ring is done.
@@ -198,6 +217,7 @@ __global__ __launch_bounds__(256) void normals_kernel(const P4* __restrict__ pts
           }
         }
       }
+      O3DS_PH(1);  // find work (arithmetic only)
       if (__ballot(found) == 0ull) break;  // no group has anything left
 #ifdef O3DS_NRM_CHECK
       ++st_rounds;
@@ -233,6 +253,7 @@ __global__ __launch_bounds__(256) void normals_kernel(const P4* __restrict__ pts
         pb[1] = make_int4(sb[4], sb[5], sb[6], sb[7]);
       }
       O3DS_WAVE_SYNC();
+      O3DS_PH(2);  // row bounds (cell_start loads) + segment table
 
       for (int f0 = 0; __ballot(f0 < T) != 0ull; f0 += 64) {
         // ---- four candidates per lane (fewer when the round has few left: nslot is wavefront-uniform): flat number -> segment by a
@@ -256,6 +277,7 @@ __global__ __launch_bounds__(256) void normals_kernel(const P4* __restrict__ pts
 #pragma unroll
         for (int c = 0; c < 4; ++c)
           if (c < nslot) sb[c] = L.seg_base[pos[c]];
+        O3DS_PH(3);  // flat number -> segment
         P4 cand[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -287,6 +309,7 @@ __global__ __launch_bounds__(256) void normals_kernel(const P4* __restrict__ pts
         }
         int sincl = row_incl_scan(ns);
         int stot = row_last(sincl);
+        O3DS_PH(4);  // candidate loads, distances, keys, first test
         if (__ballot(stot > 0) == 0ull) continue;
         // ---- a first chunk usually brings 40-60 candidates inside the radius for max_nn places, and ranking costs (survivors)^2.
         // So the bound is tightened first: a distance t with max_nn <= #{d2 < t} <= max_nn + 8 is found by regula falsi on the COUNT
@@ -325,6 +348,7 @@ __global__ __launch_bounds__(256) void normals_kernel(const P4* __restrict__ pts
             stot = row_last(sincl);
           }
         }
+        O3DS_PH(5);  // regula falsi on the count
         {
           int slot = sincl - ns;
 #pragma unroll
@@ -334,8 +358,17 @@ __global__ __launch_bounds__(256) void normals_kernel(const P4* __restrict__ pts
               if constexpr (WIDE) L.Si[slot] = ci[c];
               ++slot;
             }
+          // the ranking loops run to the longest table of the wavefront's four groups, four entries at a time: fill this group's up to
+          // there with a key nothing is smaller than
+          const int smax = max(max(__builtin_amdgcn_readlane(stot, 0), __builtin_amdgcn_readlane(stot, 16)),
+                               max(__builtin_amdgcn_readlane(stot, 32), __builtin_amdgcn_readlane(stot, 48)));
+          const int send = (smax + 3) & ~3;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (stot + l + 16 * k < send) L.Sk[stot + l + 16 * k] = kNever;
         }
         O3DS_WAVE_SYNC();
+        O3DS_PH(6);  // compaction
         // ---- rank survivors and kept keys against each other: lane l owns survivors l, l + 16, ... and kept keys l, l + 16, ...
         // Table entries are read four at a time (one wait per four); entries past the end are replaced by a key nothing is
         // smaller than.  The number of owned survivors per lane (1..4) is a wavefront-uniform switch.
@@ -370,7 +403,6 @@ __global__ __launch_bounds__(256) void normals_kernel(const P4* __restrict__ pts
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              if (jj + e >= stot) sk[e] = kNever;
 #pragma unroll
               for (int u = 0; u < NU; ++u) rs[u] += nrm_less<WIDE>(sk[e], si[e], ok[u], oi[u]) ? 1 : 0;
               if constexpr (KEPT) {
@@ -390,7 +422,6 @@ __global__ __launch_bounds__(256) void normals_kernel(const P4* __restrict__ pts
               }
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                if (jj + e >= cnt) sk[e] = kNever;
 #pragma unroll
                 for (int u = 0; u < NU; ++u) rs[u] += nrm_less<WIDE>(sk[e], si[e], ok[u], oi[u]) ? 1 : 0;
               }
@@ -435,6 +466,14 @@ __global__ __launch_bounds__(256) void normals_kernel(const P4* __restrict__ pts
         }
         O3DS_WAVE_SYNC();
         cnt = min(cnt + stot, max_nn);
+        {  // same fill for the kept list
+          const int cmax = max(max(__builtin_amdgcn_readlane(cnt, 0), __builtin_amdgcn_readlane(cnt, 16)),
+                               max(__builtin_amdgcn_readlane(cnt, 32), __builtin_amdgcn_readlane(cnt, 48)));
+          const int cend = (cmax + 3) & ~3;
+#pragma unroll
+          for (int k = 0; k < KPL; ++k)
+            if (cnt + l + 16 * k < cend) L.Kk[cnt + l + 16 * k] = kNever;
+        }
 #ifdef O3DS_NRM_CHECK
 #pragma unroll
         for (int u = 0; u < KPL; ++u) {
@@ -456,6 +495,7 @@ __global__ __launch_bounds__(256) void normals_kernel(const P4* __restrict__ pts
             worst = (double)__uint_as_float((unsigned int)(tau_k >> 32));
           }
         }
+        O3DS_PH(7);  // ranking + new bound
       }
       O3DS_WAVE_SYNC();  // the segment table is rewritten by the next round
     }
@@ -507,11 +547,15 @@ __global__ __launch_bounds__(256) void normals_kernel(const P4* __restrict__ pts
       if (l == 0 && have) out_cnt[j] = cnt;
     }
     O3DS_WAVE_SYNC();
+    O3DS_PH(8);  // cumulants
   }
 #ifdef O3DS_NRM_CHECK
   if (g_nrm_wave_stats && lane == 0) {
-    unsigned long long* o = g_nrm_wave_stats + 6 * ((size_t)blockIdx.x * 4 + wv);
+    unsigned long long* o = g_nrm_wave_stats + kNrmStatWords * ((size_t)blockIdx.x * 4 + wv);
     o[0] = wall_clock64() - st_t0, o[1] = st_t0, o[2] = st_rounds, o[3] = st_ring, o[4] = st_chunks, o[5] = 0;
+#ifdef O3DS_NRM_PHASES
+    for (int k = 0; k < 10; ++k) o[6 + k] = (unsigned long long)st_ph[k];
+#endif
   }
 #endif
 }

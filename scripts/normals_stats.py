@@ -15,7 +15,9 @@ v = be.voxel_down_sample(c, 0.1)
 for rep in range(3):
     be.estimate_normals(v, radius, knn)
 be.synchronize()
-w = np.fromfile(path, dtype=np.uint64).reshape(-1, 6).astype(np.float64)
+raw = np.fromfile(path, dtype=np.uint64)
+words = 16 if os.environ.get("O3DS_NRM_PHASES") else 6  # a -DO3DS_NRM_PHASES build also stores shader-clock cycles per phase
+w = raw.reshape(-1, words).astype(np.float64)
 w = w[w[:, 0] > 0]
 clk, start, rounds, ring, chunks = w[:, 0] / 100.0, (w[:, 1] - w[:, 1].min()) / 100.0, w[:, 2], w[:, 3], w[:, 4]  # us
 pc = lambda a: "mean %8.1f p50 %8.1f p90 %8.1f p99 %8.1f max %8.1f" % (a.mean(), *np.percentile(a, [50, 90, 99]), a.max())
@@ -35,3 +37,13 @@ print("corr(duration, rounds) %.2f  corr(duration, chunks) %.2f" % (np.corrcoef(
 slow = np.argsort(-clk)[:8]
 for i in slow:
     print("  slow wavefront %5d: %7.1f us rounds %3d ring %d chunks %3d start %7.1f" % (i, clk[i], rounds[i], ring[i], chunks[i], start[i]))
+
+if words == 16:
+    names = ["set-up", "find work (row arithmetic)", "row bounds + segment table", "flat number -> segment", "candidate loads + distances + first test",
+             "regula falsi on the count", "compaction", "ranking + new bound", "cumulants + output", "-"]
+    ph = w[:, 6:16]
+    tot = ph.sum()
+    print("shader-clock cycles per wavefront by phase (mean; share of the total):")
+    for k, nm in enumerate(names[:9]):
+        print("  %-44s %9.0f  %5.1f %%" % (nm, ph[:, k].mean(), 100.0 * ph[:, k].sum() / tot))
+    print("  %-44s %9.0f" % ("all phases", ph.sum(1).mean()))
