@@ -158,6 +158,7 @@ struct o3ds_context {
   size_t nn_cache_cap = 0;
   char* d_fused = nullptr;  // [2 states | 3 x kFusedSlots slot records (hi and lo sums)]
   unsigned long long fused_launches = 0;
+  int fused_chunk_hint = 12;  // launches queued before the host first looks at the state: what the previous registration needed, plus one
   int debug_update = 0;  // O3DS_DEBUG_UPDATE: timing experiments only
   int pass_rows = 1024;
   // profiling (bench.py roofline): event pairs around every accumulate launch
@@ -1750,7 +1751,10 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
     int j = 0;
     const IcpStateDev* last = h->d_state;
     while (j < total) {
-      const int chunk = std::min(total - j, j == 0 ? 12 : 8);
+      // A launch after the loop has ended costs its launch (~4.6 us each, a dozen of them per registration of a stream whose scans
+      // converge in four or five iterations), a look at the state costs a host round trip: queue what the previous registration on this
+      // handle needed plus one, then four at a time
+      const int chunk = std::min(total - j, j == 0 ? h->fused_chunk_hint : 4);
       for (int k = 0; k < chunk; ++k, ++j) {
         const int par = j & 1;
         fa.first = j == 0;
@@ -1785,6 +1789,7 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
       copy_result(h, out);
       if (h->h_state->done) break;
     }
+    h->fused_chunk_hint = std::min(std::max(h->h_state->iterations + 3, 4), 12);  // iterations + 2 launches were needed
     if (d_trace) {
       std::vector<unsigned long long> t((size_t)16 * nb);
       (void)hipMemcpy(t.data(), d_trace, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
