@@ -16,12 +16,13 @@ timeout 300 python bench.py --config 4 2>/dev/null | tail -1 > $OUT/bench_config
 O3DS_BENCH_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --config 3u --steps 20 --warmup 2 --no-f64 2>/dev/null | tail -1 > $OUT/bench_config3u_2ranks_one_gpu_gloo.json
 O3DS_BENCH_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 2 --config 4 --steps 5 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_config4_2ranks_one_gpu_gloo.json
 timeout 300 python scripts/check_normals.py > $OUT/check_normals.log 2>&1
-( cd open3d_slam_amd && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DO3DS_NRM_CHECK -o lib/libo3ds_check.so csrc/backend.hip 2>/dev/null )
-O3DS_BACKEND_LIB=$R/open3d_slam_amd/lib/libo3ds_check.so timeout 200 python scripts/normals_stats.py 3.0 20 > $OUT/normals_stats.txt 2>&1
+( cd open3d_slam_amd && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DO3DS_NRM_CHECK -DO3DS_NRM_PHASES -o lib/libo3ds_check.so csrc/backend.hip 2>/dev/null )
+O3DS_NRM_PHASES=1 O3DS_BACKEND_LIB=$R/open3d_slam_amd/lib/libo3ds_check.so timeout 200 python scripts/normals_stats.py 3.0 20 > $OUT/normals_stats.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/prof
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python $R/bench.py --no-cpu-baseline > $OUT/rocprof_bench.json 2> $OUT/rocprof.err
 echo "rocprof rc=$?" >> $OUT/rocprof.err
 python $R/scripts/prof_summary.py $OUT/prof/bench_results.db $OUT/rocprof_stats.txt > /dev/null
+bash $R/scripts/gpu_stream_prof.sh > /dev/null 2>&1
 cd $R
 grep -E "passed|failed" $OUT/pytest_gpu.log | tail -3; tail -2 $OUT/smoke.log; tail -1 $OUT/bench.err; tail -1 $OUT/check_normals.log; head -8 $OUT/normals_stats.txt; head -14 $OUT/rocprof_stats.txt | cut -c1-80,100-170
