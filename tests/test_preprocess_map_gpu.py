@@ -67,11 +67,40 @@ def test_voxel_down_sample_f64_exact_set(backend_f64, oracle, scan):
     out = backend_f64.voxel_down_sample(c, 0.1)
     got, _ = backend_f64.download(out)
     ref = oracle.voxel_down_sample(scan, 0.1)
-    _match(got, ref, 1e-12)  # same voxel set; sums reassociated
+    # voxels in order of first appearance, each sum in cloud order, binary64: the oracle's array, bit for bit
+    np.testing.assert_array_equal(got, ref)
     # voxel <= 0: unchanged copy (helpers.cpp:108-110)
     same = backend_f64.voxel_down_sample(c, 0.0)
     np.testing.assert_array_equal(backend_f64.download(same)[0], scan)
     for x in (c, out, same):
+        backend_f64.free(x)
+
+
+def test_voxel_down_sample_crowded_voxels_bit_identical(backend_f64, oracle):
+    """voxels holding 1 ... 300 points (the member lists of more than 16 entries are heap-sorted), members scattered through the cloud,
+    normals averaged without re-normalisation: equal to the oracle's output in values and order"""
+    rng = np.random.default_rng(11)
+    centres = rng.uniform(-20, 20, (400, 3))
+    counts = rng.integers(1, 40, 400)
+    counts[:6] = [300, 150, 64, 17, 16, 33]
+    pts = np.vstack([c + rng.uniform(-0.049, 0.049, (k, 3)) for c, k in zip(centres, counts)])
+    pts = pts[rng.permutation(len(pts))]
+    nrm = rng.normal(size=pts.shape)
+    c = backend_f64.upload(pts, nrm)
+    out = backend_f64.voxel_down_sample(c, 0.1)
+    got, gn = backend_f64.download(out)
+    ref, rn = oracle.voxel_down_sample(pts, 0.1, nrm)
+    np.testing.assert_array_equal(got, ref)
+    np.testing.assert_array_equal(gn, rn)
+    # crop + VoxelDownSample in one call = crop, then VoxelDownSample (grid anchored at the box of the INSIDE points)
+    crop = backend.make_crop(backend.CROP_MIN_MAX_RADIUS, center=(1.0, 2.0, 0.0), rmin=3.0, rmax=17.0)
+    keep = oracle.crop_indices(pts, oracle.make_crop(oracle.CROP_MIN_MAX_RADIUS, center=(1.0, 2.0, 0.0), rmin=3.0, rmax=17.0))
+    ref2, rn2 = oracle.voxel_down_sample(pts[keep], 0.1, nrm[keep])
+    out2 = backend_f64.crop_voxel_down_sample(c, crop, 0.1)
+    got2, gn2 = backend_f64.download(out2)
+    np.testing.assert_array_equal(got2, ref2)
+    np.testing.assert_array_equal(gn2, rn2)
+    for x in (c, out, out2):
         backend_f64.free(x)
 
 
