@@ -415,13 +415,14 @@ __global__ __launch_bounds__(kBlock) void segment_mean_kernel(const P4* __restri
         nx /= cnt;
         ny /= cnt;
         nz /= cnt;
-        if (renorm) {  // Eigen normalized(): unchanged when the squared norm is 0
-          const double z2 = nx * nx + ny * ny + nz * nz;
+        if (renorm) {  // Eigen normalized(): v / sqrt(v . v), unchanged when the squared norm is 0 -- spelled as the oracle spells it
+#pragma clang fp contract(off)
+          const double z2 = (nx * nx + ny * ny) + nz * nz;
           if (z2 > 0.0) {
-            const double inv = 1.0 / sqrt(z2);
-            nx *= inv;
-            ny *= inv;
-            nz *= inv;
+            const double nn = sqrt(z2);
+            nx /= nn;
+            ny /= nn;
+            nz /= nn;
           }
         }
         on.x = (R)nx;
