@@ -158,6 +158,15 @@ struct o3ds_context {
   size_t nn_cache_cap = 0;
   char* d_fused = nullptr;  // [2 states | 3 x kFusedSlots slot records (hi and lo sums)]
   unsigned long long fused_launches = 0;
+  // Scratch that its users leave the way they found it, so that no launch is spent on clearing it: the per-cell counters of an index
+  // build (the scatter counts them back down to zero) and the voxel table of VoxelDownSample (vox_mean_kernel empties the slots it
+  // used).  `*_clean` is false while an operation is in flight or after one failed: the next user clears the block first.
+  int* d_cells = nullptr;
+  size_t cells_cap = 0;
+  bool cells_clean = false;
+  unsigned char* d_voxtab = nullptr;
+  size_t voxtab_cap = 0;  // slots
+  bool voxtab_clean = false;
   int fused_chunk_hint = 12;  // launches queued before the host first looks at the state: what the previous registration needed, plus one
   int debug_update = 0;  // O3DS_DEBUG_UPDATE: timing experiments only
   int pass_rows = 1024;
@@ -570,22 +579,38 @@ int build_grid_t(o3ds_handle h, const P4* pts, const P4* nrm, size_t n, double c
   g.nx = (int)nx;
   g.ny = (int)ny;
   g.nz = (int)nz;
-  int *counts = nullptr, *cursor = nullptr, *cell_id = nullptr, *cell_start = nullptr;
+  int *counts = nullptr, *cell_id = nullptr, *cell_start = nullptr;
   void *spts = nullptr, *snrm = nullptr;
-  TMP_ALLOC(counts, sizeof(int) * (2 * ncell + 1));  // [counts: ncell + 1 | cursor: ncell], cleared by one memset
-  cursor = counts + ncell + 1;
+  // per-cell counters: the handle's block of zeros (ncell + 1: the scan's sentinel stays zero); counted up by cell_count_kernel, read
+  // by the scan, counted back down to zero by scatter_kernel
+  if (h->cells_cap < ncell + 1) {
+    if (h->d_cells) {
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      (void)hipFree(h->d_cells);
+      h->d_cells = nullptr;
+      h->cells_cap = 0;
+    }
+    const size_t cap = ncell + 1 + ncell / 4;
+    if (hipMalloc((void**)&h->d_cells, sizeof(int) * cap) != hipSuccess) return fail(h, O3DS_ERR_OOM, "build_index: cell counters allocation failed");
+    h->cells_cap = cap;
+    h->cells_clean = false;
+  }
+  static const bool always_clear = getenv("O3DS_ALWAYS_CLEAR") != nullptr;  // debugging / A/B aid: do not rely on self-cleaning scratch
+  if (!h->cells_clean || always_clear) HIP_TRY(hipMemsetAsync(h->d_cells, 0, sizeof(int) * h->cells_cap, h->stream));
+  h->cells_clean = false;
+  counts = h->d_cells;
   TMP_ALLOC(cell_id, sizeof(int) * n);
   HIP_TRY(dev_alloc(h, (void**)&cell_start, sizeof(int) * (ncell + 1 + 4)));  // +4: the search reads rows as unaligned 16-B vectors
   HIP_TRY(dev_alloc(h, (void**)&spts, sizeof(P4) * n));
   if (nrm) HIP_TRY(dev_alloc(h, (void**)&snrm, sizeof(P4) * n));
   span_mark(h, kSpanIndexBuild);
-  HIP_TRY(hipMemsetAsync(counts, 0, sizeof(int) * (2 * ncell + 1), h->stream));
   cell_count_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(pts, n, g, counts, cell_id);
   rc = exclusive_scan_int(h, counts, cell_start, ncell + 1);
   if (rc) return rc;
-  scatter_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(pts, nrm, n, cell_id, cell_start, cursor, (P4*)spts, (P4*)snrm);
+  scatter_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(pts, nrm, n, cell_id, cell_start, counts, (P4*)spts, (P4*)snrm);
   span_mark(h, kSpanIndexBuild);
   HIP_TRY(hipGetLastError());
+  h->cells_clean = true;  // (stream order: whoever counts next runs after the scatter)
   dbg_sync(h, 2);
   g.cell_start = cell_start;
   *out_grid = g;
@@ -1105,6 +1130,8 @@ int o3ds_destroy(o3ds_handle h) {
   dev_release_all(h);
   if (h->d_fused) (void)hipFree(h->d_fused);
   if (h->d_nn_cache) (void)hipFree(h->d_nn_cache);
+  if (h->d_cells) (void)hipFree(h->d_cells);
+  if (h->d_voxtab) (void)hipFree(h->d_voxtab);
   if (h->d_partials) (void)hipFree(h->d_partials);
   if (h->d_state) (void)hipFree(h->d_state);
   if (h->h_state) (void)hipHostFree(h->h_state);
@@ -1952,16 +1979,30 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
   if (mode == 0 && !voxel_sort && n < ((size_t)1 << 30)) {
     size_t cap = 1024;
     while (cap < 2 * n) cap <<= 1;
-    unsigned char* tab = nullptr;
-    int *slot_of = nullptr, *flag = nullptr, *rank = nullptr, *seg_cnt = nullptr, *seg_start = nullptr;
+    // the handle's table: all 0xff between calls (vox_mean_kernel empties the slots a call used), grown to the largest cloud seen
+    if (h->voxtab_cap < cap) {
+      if (h->d_voxtab) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        (void)hipFree(h->d_voxtab);
+        h->d_voxtab = nullptr;
+        h->voxtab_cap = 0;
+      }
+      if (hipMalloc((void**)&h->d_voxtab, 16 * cap) != hipSuccess) return fail(h, O3DS_ERR_OOM, "VoxelDownSample: voxel table allocation failed");
+      h->voxtab_cap = cap;
+      h->voxtab_clean = false;
+    }
+    cap = h->voxtab_cap;
+    unsigned char* tab = h->d_voxtab;
+    int *slot_of = nullptr, *flag = nullptr, *rank = nullptr, *seg_cnt = nullptr, *seg_start = nullptr, *vox_slot = nullptr;
     uint32_t* members = nullptr;
-    TMP_ALLOC(tab, 16 * cap);
     TMP_ALLOC(slot_of, sizeof(int) * n);
     TMP_ALLOC(flag, sizeof(int) * (n + 1));
     TMP_ALLOC(rank, sizeof(int) * (n + 1));
     TMP_ALLOC(members, sizeof(uint32_t) * n);
     VoxTable t{(unsigned long long*)tab, (unsigned int*)(tab + 8 * cap), (unsigned int*)(tab + 12 * cap), (unsigned int)(cap - 1)};
-    HIP_TRY(hipMemsetAsync(tab, 0xff, 16 * cap, h->stream));
+    static const bool always_clear = getenv("O3DS_ALWAYS_CLEAR") != nullptr;
+    if (!h->voxtab_clean || always_clear) HIP_TRY(hipMemsetAsync(tab, 0xff, 16 * cap, h->stream));
+    h->voxtab_clean = false;
     vox_insert_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>((const P4*)in.pts, n, ox, oy, oz, voxel, crop, filter ? 1 : 0, t, slot_of);
     vox_flag_kernel<<<grid_for(n + 1), kBlock, 0, h->stream>>>(slot_of, n, t, flag);
     int rc = exclusive_scan_int(h, flag, rank, n + 1);
@@ -1970,17 +2011,22 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
     rc = read_back(h, {{&m, rank + n, sizeof(int)}});
     if (rc) return rc;
     out.n = (size_t)m;
-    if (m == 0) return O3DS_OK;
+    if (m == 0) {  // every point outside the volume: nothing was entered
+      h->voxtab_clean = true;
+      return O3DS_OK;
+    }
     TMP_ALLOC(seg_cnt, sizeof(int) * ((size_t)m + 1));
     TMP_ALLOC(seg_start, sizeof(int) * ((size_t)m + 1));
-    vox_number_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(slot_of, flag, rank, n, (size_t)m, t, seg_cnt);
+    TMP_ALLOC(vox_slot, sizeof(int) * (size_t)m);
+    vox_number_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(slot_of, flag, rank, n, (size_t)m, t, seg_cnt, vox_slot);
     rc = exclusive_scan_int(h, seg_cnt, seg_start, (size_t)m + 1);
     if (rc) return rc;
     vox_gather_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(slot_of, n, t, seg_start, members);
     HIP_TRY(dev_alloc(h, (void**)&out.pts, sizeof(P4) * out.n));
     if (in.nrm) HIP_TRY(dev_alloc(h, (void**)&out.nrm, sizeof(P4) * out.n));
     vox_mean_kernel<P4><<<grid_for(out.n), kBlock, 0, h->stream>>>((const P4*)in.pts, (const P4*)in.nrm, seg_start, out.n, members, 0, (P4*)out.pts,
-                                                                  (P4*)out.nrm);
+                                                                  (P4*)out.nrm, t, vox_slot);
+    h->voxtab_clean = true;
     if (in.col) {  // [O3D] VoxelDownSample: AccumulatedPoint averages the colours
       HIP_TRY(dev_alloc(h, (void**)&out.col, sizeof(P4) * out.n));
       vox_mean_kernel<P4><<<grid_for(out.n), kBlock, 0, h->stream>>>((const P4*)in.col, nullptr, seg_start, out.n, members, 1, (P4*)out.col, nullptr);

@@ -511,7 +511,7 @@ __global__ __launch_bounds__(kBlock) void vox_flag_kernel(const int* __restrict_
 
 // the first point of voxel number r writes the voxel's size and leaves r in the table for the other members
 __global__ __launch_bounds__(kBlock) void vox_number_kernel(const int* __restrict__ slot_of, const int* __restrict__ flag, const int* __restrict__ rank,
-                                                            size_t n, size_t m, VoxTable t, int* __restrict__ seg_cnt) {
+                                                            size_t n, size_t m, VoxTable t, int* __restrict__ seg_cnt, int* __restrict__ vox_slot) {
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
     if (i == 0) seg_cnt[m] = 0;
     if (!flag[i]) continue;
@@ -519,6 +519,7 @@ __global__ __launch_bounds__(kBlock) void vox_number_kernel(const int* __restric
     const int r = rank[i];
     seg_cnt[r] = (int)~t.ncnt[s];
     t.first[s] = (unsigned int)r;
+    vox_slot[r] = s;  // for vox_mean_kernel, which hands the slot back empty
   }
 }
 
@@ -577,11 +578,17 @@ __device__ inline void sort_indices(uint32_t* a, int k) {
 template <typename P4>
 __global__ __launch_bounds__(kBlock) void vox_mean_kernel(const P4* __restrict__ pts, const P4* __restrict__ nrm, const int* __restrict__ seg_start,
                                                           size_t m, uint32_t* __restrict__ members, int attr_only, P4* __restrict__ out_pts,
-                                                          P4* __restrict__ out_nrm) {
+                                                          P4* __restrict__ out_nrm, VoxTable t = VoxTable{}, const int* __restrict__ vox_slot = nullptr) {
   using R = typename Scalar<P4>::type;
   for (size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x; r < m; r += (size_t)gridDim.x * kBlock) {
     const int b = seg_start[r], e = seg_start[r + 1];
     if (!attr_only) sort_indices(members + b, e - b);
+    if (vox_slot) {  // the table is done with (vox_gather_kernel has run): leave the slot as the 0xff fill left it, for the next call
+      const int s = vox_slot[r];
+      t.key[s] = kEmptyKey;
+      t.first[s] = ~0u;
+      t.ncnt[s] = ~0u;
+    }
     double sx = 0, sy = 0, sz = 0, nx = 0, ny = 0, nz = 0;
     for (int j = b; j < e; ++j) {
       const uint32_t id = members[j];

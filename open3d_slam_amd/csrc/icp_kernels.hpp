@@ -177,14 +177,16 @@ __global__ __launch_bounds__(kBlock) void scan_add_kernel(T* __restrict__ out, c
     if (base + k < m) out[base + k] += off;
 }
 
-// sorted[pos] = pts[i] (+ normals), pos = cell_start[cell] + cursor[cell]++
+// sorted[pos] = pts[i] (+ normals), pos = cell_start[cell] + --counts[cell]: the counters of cell_count_kernel double as the cursors
+// and are back at zero when every point is placed (the block of zeros they came from needs no clearing for the next build).  The order
+// of the points inside a cell is the order the atomics are served in; nothing downstream depends on it.
 template <typename P4>
 __global__ __launch_bounds__(kBlock) void scatter_kernel(const P4* __restrict__ pts, const P4* __restrict__ nrm, size_t n,
                                                          const int* __restrict__ cell_id, const int* __restrict__ cell_start,
-                                                         int* __restrict__ cursor, P4* __restrict__ spts, P4* __restrict__ snrm) {
+                                                         int* __restrict__ counts, P4* __restrict__ spts, P4* __restrict__ snrm) {
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
     const int c = cell_id[i];
-    const int pos = cell_start[c] + atomicAdd(&cursor[c], 1);
+    const int pos = cell_start[c] + atomicSub(&counts[c], 1) - 1;
     P4 p = pts[i];
     p.i = (typename Scalar<P4>::index)i;
     spts[pos] = p;
