@@ -123,6 +123,8 @@ struct o3ds_context {
   IcpStateDev* d_state = nullptr;
   IcpStateDev* h_state = nullptr;   // pinned, mapped
   char* h_pin = nullptr;            // pinned block the small device -> host read-backs land in (read_back)
+  char* h_pin_dev = nullptr;        // the same block as kernels address it: a kernel that produces a size / count / box the host is about
+                                    // to wait for stores it here itself (no copy on the stream, the host only synchronises)
   char* h_stage[2] = {nullptr, nullptr};  // pinned ring the large host <-> device copies of caller buffers go through (staged_copy)
   hipEvent_t stage_ev[2] = {nullptr, nullptr};
   IcpStateDev* h_state_dev = nullptr;  // the device's view of h_state
@@ -207,6 +209,7 @@ int fail(o3ds_handle h, int code, const std::string& msg) {
 // memory is staged and waited for inside the runtime (tens of microseconds for four bytes -- a dozen of them per lidar frame);
 // into pinned memory it is an ordinary stream operation, and one synchronisation serves all items of a call.
 constexpr size_t kPinBytes = 64 << 10;
+constexpr size_t kPubOff = kPinBytes - 256;  // the last 256 bytes: slots for values kernels publish themselves (pub_slot)
 struct D2H {
   void* dst;
   const void* src;
@@ -215,7 +218,7 @@ struct D2H {
 int read_back(o3ds_handle h, std::initializer_list<D2H> items) {
   size_t off = 0;
   for (const D2H& it : items) {
-    if (off + it.bytes > kPinBytes) return fail(h, O3DS_ERR_INVALID_ARG, "read_back: item list exceeds the pinned block");
+    if (off + it.bytes > kPubOff) return fail(h, O3DS_ERR_INVALID_ARG, "read_back: item list exceeds the pinned block");
     HIP_TRY(hipMemcpyAsync(h->h_pin + off, it.src, it.bytes, hipMemcpyDeviceToHost, h->stream));
     off += (it.bytes + 15) & ~(size_t)15;
   }
@@ -498,35 +501,46 @@ struct CloudGuard {
 };
 
 // exclusive scan of m ints (in -> out) with the hand-written 3-phase scan; in may alias out
+// pub: null, or a device-visible address (the handle's pinned block) that also receives out[m - 1] -- the total, when the input ends in a
+// zero sentinel -- from the kernel that finishes that element
 template <typename T>
-int exclusive_scan_t(o3ds_handle h, const T* in, T* out, size_t m) {
+int exclusive_scan_t(o3ds_handle h, const T* in, T* out, size_t m, T* pub = nullptr) {
   if (m == 0) return O3DS_OK;
   const int nb = (int)((m + kScanPerBlock - 1) / kScanPerBlock);
   T* sums = nullptr;
   TMP_ALLOC(sums, sizeof(T) * (size_t)nb);
-  scan_local_kernel<T><<<nb, kBlock, 0, h->stream>>>(in, out, sums, m);
+  scan_local_kernel<T><<<nb, kBlock, 0, h->stream>>>(in, out, sums, m, nb == 1 ? pub : nullptr);
   if (nb > 1 && nb <= kScanFusedBlocks) {
-    scan_add_fused_kernel<T><<<nb, kBlock, 0, h->stream>>>(out, sums, m);
+    scan_add_fused_kernel<T><<<nb, kBlock, 0, h->stream>>>(out, sums, m, pub);
   } else if (nb > 1) {
     scan_sums_kernel<T><<<1, kBlock, 0, h->stream>>>(sums, nb);
-    scan_add_kernel<T><<<nb, kBlock, 0, h->stream>>>(out, sums, m);
+    scan_add_kernel<T><<<nb, kBlock, 0, h->stream>>>(out, sums, m, pub);
   }
   HIP_TRY(hipGetLastError());
   dbg_sync(h, 1);
   return O3DS_OK;  // results are stream-ordered; callers that need a value on the host copy it back and synchronise
 }
-int exclusive_scan_int(o3ds_handle h, const int* in, int* out, size_t m) { return exclusive_scan_t<int>(h, in, out, m); }
+int exclusive_scan_int(o3ds_handle h, const int* in, int* out, size_t m, int* pub = nullptr) { return exclusive_scan_t<int>(h, in, out, m, pub); }
+
+// slots of the pinned block for values kernels publish themselves (the front of the block belongs to bbox_of / read_back)
+template <typename T>
+T* pub_slot(o3ds_handle h, int k) { return (T*)(h->h_pin_dev + kPubOff + 16 * (size_t)k); }
+template <typename T>
+T pub_value(o3ds_handle h, int k) { return *(const volatile T*)(h->h_pin + kPubOff + 16 * (size_t)k); }
+int wait_stream(o3ds_handle h) {
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return O3DS_OK;
+}
 
 template <typename P4>
 int bbox_of(o3ds_handle h, const P4* pts, size_t n, double mn[3], double mx[3], const CropDev* crop = nullptr) {
-  const int g = grid_for(n, 1024);
-  double* d = nullptr;
-  TMP_ALLOC(d, sizeof(double) * 6 * (size_t)g);
+  const int g = grid_for(n, 1024);  // 1024 x 48 B fit the pinned block below the published slots
+  static_assert(1024 * 6 * sizeof(double) <= kPinBytes - 256, "bbox partials fit the pinned block");
   CropDev all{};
-  bbox_kernel<P4><<<g, kBlock, 0, h->stream>>>(pts, n, crop ? *crop : all, d);
-  std::vector<double> hb(6 * (size_t)g);
-  int rb = read_back(h, {{hb.data(), d, sizeof(double) * hb.size()}});
-  if (rb) return rb;
+  bbox_kernel<P4><<<g, kBlock, 0, h->stream>>>(pts, n, crop ? *crop : all, (double*)h->h_pin_dev);  // every block stores its box there itself
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const double* hb = (const double*)h->h_pin;
   for (int a = 0; a < 3; ++a) {
     mn[a] = 1e300;
     mx[a] = -1e300;
@@ -1099,7 +1113,8 @@ int o3ds_create(int device_id, o3ds_handle* out) {
       hipMalloc(&h->d_state, sizeof(IcpStateDev)) != hipSuccess ||
       hipHostMalloc((void**)&h->h_state, sizeof(IcpStateDev), hipHostMallocMapped) != hipSuccess ||
       hipHostGetDevicePointer((void**)&h->h_state_dev, h->h_state, 0) != hipSuccess ||
-      hipHostMalloc((void**)&h->h_pin, kPinBytes, hipHostMallocDefault) != hipSuccess) {
+      hipHostMalloc((void**)&h->h_pin, kPinBytes, hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&h->h_pin_dev, h->h_pin, 0) != hipSuccess) {
     o3ds_destroy(h);  // frees whatever part of the context exists (every member is null-checked there)
     return fail(nullptr, O3DS_ERR_HIP, "o3ds_create: device initialisation failed");
   }
@@ -1922,11 +1937,11 @@ int crop_t(o3ds_handle h, const CloudRec& in, const CropDev& crop, CloudRec& out
   TMP_ALLOC(flags, sizeof(int) * (in.n + 1));
   TMP_ALLOC(pos, sizeof(int) * (in.n + 1));
   crop_flag_kernel<P4><<<grid_for(in.n), kBlock, 0, h->stream>>>((const P4*)in.pts, in.n, crop, flags);  // also writes the sentinel flags[n] = 0
-  int rc = exclusive_scan_int(h, flags, pos, in.n + 1);
+  int rc = exclusive_scan_int(h, flags, pos, in.n + 1, pub_slot<int>(h, 0));
   if (rc) return rc;
-  int total = 0;
-  rc = read_back(h, {{&total, pos + in.n, sizeof(int)}});
+  rc = wait_stream(h);
   if (rc) return rc;
+  const int total = pub_value<int>(h, 0);
   out.n = (size_t)total;
   if (total > 0) {
     HIP_TRY(dev_alloc(h, (void**)&out.pts, sizeof(P4) * out.n));
@@ -2005,11 +2020,11 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
     h->voxtab_clean = false;
     vox_insert_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>((const P4*)in.pts, n, ox, oy, oz, voxel, crop, filter ? 1 : 0, t, slot_of);
     vox_flag_kernel<<<grid_for(n + 1), kBlock, 0, h->stream>>>(slot_of, n, t, flag);
-    int rc = exclusive_scan_int(h, flag, rank, n + 1);
+    int rc = exclusive_scan_int(h, flag, rank, n + 1, pub_slot<int>(h, 0));  // the number of voxels goes straight to the pinned block
     if (rc) return rc;
-    int m = 0;
-    rc = read_back(h, {{&m, rank + n, sizeof(int)}});
+    rc = wait_stream(h);
     if (rc) return rc;
+    const int m = pub_value<int>(h, 0);
     out.n = (size_t)m;
     if (m == 0) {  // every point outside the volume: nothing was entered
       h->voxtab_clean = true;
@@ -2062,15 +2077,17 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
     TMP_ALLOC(vv, sizeof(uint32_t) * (nv + 1));
     TMP_ALLOC(xk, sizeof(unsigned long long) * (nx_cap + 1));
     TMP_ALLOC(xv, sizeof(uint32_t) * (nx_cap + 1));
-    TMP_ALLOC(d_unsorted, sizeof(int));
-    HIP_TRY(hipMemsetAsync(d_unsorted, 0, sizeof(int), h->stream));
+    // the "not in key order" flag and the three totals are stored into the pinned block by the kernels themselves (slot 2: the host
+    // clears it here -- nothing is in flight that writes it, every use ends in a synchronisation)
+    d_unsorted = pub_slot<int>(h, 2);
+    *(volatile int*)(h->h_pin + kPubOff + 32) = 0;
     merge_class_kernel<P4><<<grid_for(n + 1), kBlock, 0, h->stream>>>((const P4*)in.pts, n, voxel, crop, np, nv, k0, cls, d_unsorted);
-    int rcs = exclusive_scan_t<unsigned long long>(h, cls, rank, n + 1);
+    int rcs = exclusive_scan_t<unsigned long long>(h, cls, rank, n + 1, pub_slot<unsigned long long>(h, 1));
     if (rcs) return rcs;
-    unsigned long long tot = 0;
-    int unsorted = 0;
-    rcs = read_back(h, {{&tot, rank + n, sizeof(tot)}, {&unsorted, d_unsorted, sizeof(int)}});
+    rcs = wait_stream(h);
     if (rcs) return rcs;
+    const unsigned long long tot = pub_value<unsigned long long>(h, 1);
+    const int unsorted = pub_value<int>(h, 2);
     if (!unsorted) {
       const size_t npass_ = (size_t)(tot & kCntMask), nvin = (size_t)((tot >> 21) & kCntMask), nx = (size_t)((tot >> 42) & kCntMask);
       merge_split_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(k0, rank, n, np, nv, k1, v1, vk, vv, xk, xv);
@@ -2109,18 +2126,14 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
     HIP_TRY(rocprim::radix_sort_pairs(temp, temp_bytes, k0, k1, v0, v1, n, 0, 64, h->stream));
   }
   segment_head_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(k1, n, head);  // also writes the sentinel head[n] = 0
-  if (!merged) first_pass_kernel<<<1, 64, 0, h->stream>>>(k1, n, d_scalar);
-  int rc = exclusive_scan_int(h, head, seg_id, n + 1);
+  if (!merged) first_pass_kernel<<<1, 64, 0, h->stream>>>(k1, n, pub_slot<unsigned long long>(h, 3));
+  int rc = exclusive_scan_int(h, head, seg_id, n + 1, pub_slot<int>(h, 0));
   if (rc) return rc;
-  int n_seg = 0;
-  unsigned long long n_inside = 0;
-  if (merged) {
-    rc = read_back(h, {{&n_seg, seg_id + n, sizeof(int)}});
-    n_inside = merged_n_inside;
-  } else {
-    rc = read_back(h, {{&n_seg, seg_id + n, sizeof(int)}, {&n_inside, d_scalar, sizeof(n_inside)}});
-  }
+  rc = wait_stream(h);
   if (rc) return rc;
+  const int n_seg = pub_value<int>(h, 0);
+  const unsigned long long n_inside = merged ? (unsigned long long)merged_n_inside : pub_value<unsigned long long>(h, 3);
+  (void)d_scalar;
   const size_t n_pass = n - (size_t)n_inside;
   if (mode == 1 && !filter) {  // the layout the next merge can rely on
     out.vox_first = (long long)n_pass;

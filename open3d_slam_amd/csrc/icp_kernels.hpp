@@ -102,7 +102,8 @@ __global__ __launch_bounds__(kBlock) void cell_count_kernel(const P4* __restrict
 // (4 per thread)
 constexpr int kScanPerBlock = 1024;
 template <typename T>
-__global__ __launch_bounds__(kBlock) void scan_local_kernel(const T* __restrict__ in, T* __restrict__ out, T* __restrict__ block_sums, size_t m) {
+__global__ __launch_bounds__(kBlock) void scan_local_kernel(const T* __restrict__ in, T* __restrict__ out, T* __restrict__ block_sums, size_t m,
+                                                            T* __restrict__ pub = nullptr /* single-block scans: where out[m - 1] also goes */) {
   __shared__ T s_wave[kBlock / 64];
   const size_t base = (size_t)blockIdx.x * kScanPerBlock + (size_t)threadIdx.x * 4;
   T v[4];
@@ -125,6 +126,7 @@ __global__ __launch_bounds__(kBlock) void scan_local_kernel(const T* __restrict_
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     if (base + k < m) out[base + k] = excl;
+    if (pub && base + k == m - 1) *pub = excl;
     excl += v[k];
   }
   if (threadIdx.x == kBlock - 1) block_sums[blockIdx.x] = woff + x;
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(kBlock) void scan_sums_kernel(T* __restrict__ sums,
 // scan, and the per-scan pipeline of a lidar frame runs ten scans
 constexpr int kScanFusedBlocks = 4096;
 template <typename T>
-__global__ __launch_bounds__(kBlock) void scan_add_fused_kernel(T* __restrict__ out, const T* __restrict__ sums, size_t m) {
+__global__ __launch_bounds__(kBlock) void scan_add_fused_kernel(T* __restrict__ out, const T* __restrict__ sums, size_t m, T* __restrict__ pub = nullptr) {
   __shared__ T s_part[kBlock / 64];
   T t = 0;
   for (int i = threadIdx.x; i < (int)blockIdx.x; i += kBlock) t += sums[i];
@@ -166,15 +168,23 @@ __global__ __launch_bounds__(kBlock) void scan_add_fused_kernel(T* __restrict__ 
   const size_t base = (size_t)blockIdx.x * kScanPerBlock + (size_t)threadIdx.x * 4;
 #pragma unroll
   for (int k = 0; k < 4; ++k)
-    if (base + k < m) out[base + k] += off;
+    if (base + k < m) {
+      const T v = out[base + k] + off;
+      out[base + k] = v;
+      if (pub && base + k == m - 1) *pub = v;
+    }
 }
 template <typename T>
-__global__ __launch_bounds__(kBlock) void scan_add_kernel(T* __restrict__ out, const T* __restrict__ sums, size_t m) {
+__global__ __launch_bounds__(kBlock) void scan_add_kernel(T* __restrict__ out, const T* __restrict__ sums, size_t m, T* __restrict__ pub = nullptr) {
   const size_t base = (size_t)blockIdx.x * kScanPerBlock + (size_t)threadIdx.x * 4;
   const T off = sums[blockIdx.x];
 #pragma unroll
   for (int k = 0; k < 4; ++k)
-    if (base + k < m) out[base + k] += off;
+    if (base + k < m) {
+      const T v = out[base + k] + off;
+      out[base + k] = v;
+      if (pub && base + k == m - 1) *pub = v;
+    }
 }
 
 // sorted[pos] = pts[i] (+ normals), pos = cell_start[cell] + --counts[cell]: the counters of cell_count_kernel double as the cursors
