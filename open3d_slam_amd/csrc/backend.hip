@@ -2002,26 +2002,41 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
         h->d_voxtab = nullptr;
         h->voxtab_cap = 0;
       }
-      if (hipMalloc((void**)&h->d_voxtab, 16 * cap) != hipSuccess) return fail(h, O3DS_ERR_OOM, "VoxelDownSample: voxel table allocation failed");
+      if (hipMalloc((void**)&h->d_voxtab, 16 * cap + 16) != hipSuccess) return fail(h, O3DS_ERR_OOM, "VoxelDownSample: voxel table allocation failed");
       h->voxtab_cap = cap;
       h->voxtab_clean = false;
     }
     cap = h->voxtab_cap;
     unsigned char* tab = h->d_voxtab;
-    int *slot_of = nullptr, *flag = nullptr, *rank = nullptr, *seg_cnt = nullptr, *seg_start = nullptr, *vox_slot = nullptr;
+    int *slot_of = nullptr, *rank = nullptr, *seg_cnt = nullptr, *seg_start = nullptr, *vox_slot = nullptr;
     uint32_t* members = nullptr;
     TMP_ALLOC(slot_of, sizeof(int) * n);
-    TMP_ALLOC(flag, sizeof(int) * (n + 1));
     TMP_ALLOC(rank, sizeof(int) * (n + 1));
     TMP_ALLOC(members, sizeof(uint32_t) * n);
-    VoxTable t{(unsigned long long*)tab, (unsigned int*)(tab + 8 * cap), (unsigned int*)(tab + 12 * cap), (unsigned int)(cap - 1)};
+    VoxTable t{(unsigned long long*)tab, (unsigned int*)(tab + 8 * cap), (unsigned int*)(tab + 12 * cap), (unsigned int*)(tab + 16 * cap),
+               (unsigned int)(cap - 1)};
     static const bool always_clear = getenv("O3DS_ALWAYS_CLEAR") != nullptr;
-    if (!h->voxtab_clean || always_clear) HIP_TRY(hipMemsetAsync(tab, 0xff, 16 * cap, h->stream));
+    if (!h->voxtab_clean || always_clear) HIP_TRY(hipMemsetAsync(tab, 0xff, 16 * cap + 16, h->stream));
     h->voxtab_clean = false;
     vox_insert_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>((const P4*)in.pts, n, ox, oy, oz, voxel, crop, filter ? 1 : 0, t, slot_of);
-    vox_flag_kernel<<<grid_for(n + 1), kBlock, 0, h->stream>>>(slot_of, n, t, flag);
-    int rc = exclusive_scan_int(h, flag, rank, n + 1, pub_slot<int>(h, 0));  // the number of voxels goes straight to the pinned block
-    if (rc) return rc;
+    // voxels numbered in order of first appearance: scan over "point i opens its voxel", the flag computed as the scan loads it; the
+    // number of voxels goes straight to the pinned block
+    int rc = O3DS_OK;
+    {
+      const size_t ms = n + 1;
+      const int nbs = (int)((ms + kScanPerBlock - 1) / kScanPerBlock);
+      int* sums = nullptr;
+      TMP_ALLOC(sums, sizeof(int) * (size_t)nbs);
+      int* pub = pub_slot<int>(h, 0);
+      scan_local_fn_kernel<int, VoxFirstFlag><<<nbs, kBlock, 0, h->stream>>>(VoxFirstFlag{slot_of, n, t}, rank, sums, ms, nbs == 1 ? pub : nullptr);
+      if (nbs > 1 && nbs <= kScanFusedBlocks) {
+        scan_add_fused_kernel<int><<<nbs, kBlock, 0, h->stream>>>(rank, sums, ms, pub);
+      } else if (nbs > 1) {
+        scan_sums_kernel<int><<<1, kBlock, 0, h->stream>>>(sums, nbs);
+        scan_add_kernel<int><<<nbs, kBlock, 0, h->stream>>>(rank, sums, ms, pub);
+      }
+      HIP_TRY(hipGetLastError());
+    }
     rc = wait_stream(h);
     if (rc) return rc;
     const int m = pub_value<int>(h, 0);
@@ -2030,21 +2045,19 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
       h->voxtab_clean = true;
       return O3DS_OK;
     }
-    TMP_ALLOC(seg_cnt, sizeof(int) * ((size_t)m + 1));
-    TMP_ALLOC(seg_start, sizeof(int) * ((size_t)m + 1));
+    TMP_ALLOC(seg_cnt, sizeof(int) * (size_t)m);
+    TMP_ALLOC(seg_start, sizeof(int) * (size_t)m);
     TMP_ALLOC(vox_slot, sizeof(int) * (size_t)m);
-    vox_number_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(slot_of, flag, rank, n, (size_t)m, t, seg_cnt, vox_slot);
-    rc = exclusive_scan_int(h, seg_cnt, seg_start, (size_t)m + 1);
-    if (rc) return rc;
-    vox_gather_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(slot_of, n, t, seg_start, members);
+    vox_number_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(slot_of, rank, n, t, seg_start, seg_cnt, vox_slot);
+    vox_gather_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(slot_of, n, t, seg_start, seg_cnt, members);
     HIP_TRY(dev_alloc(h, (void**)&out.pts, sizeof(P4) * out.n));
     if (in.nrm) HIP_TRY(dev_alloc(h, (void**)&out.nrm, sizeof(P4) * out.n));
-    vox_mean_kernel<P4><<<grid_for(out.n), kBlock, 0, h->stream>>>((const P4*)in.pts, (const P4*)in.nrm, seg_start, out.n, members, 0, (P4*)out.pts,
-                                                                  (P4*)out.nrm, t, vox_slot);
+    vox_mean_kernel<P4><<<grid_for(out.n), kBlock, 0, h->stream>>>((const P4*)in.pts, (const P4*)in.nrm, seg_start, seg_cnt, out.n, members, 0,
+                                                                  (P4*)out.pts, (P4*)out.nrm, t, vox_slot);
     h->voxtab_clean = true;
     if (in.col) {  // [O3D] VoxelDownSample: AccumulatedPoint averages the colours
       HIP_TRY(dev_alloc(h, (void**)&out.col, sizeof(P4) * out.n));
-      vox_mean_kernel<P4><<<grid_for(out.n), kBlock, 0, h->stream>>>((const P4*)in.col, nullptr, seg_start, out.n, members, 1, (P4*)out.col, nullptr);
+      vox_mean_kernel<P4><<<grid_for(out.n), kBlock, 0, h->stream>>>((const P4*)in.col, nullptr, seg_start, seg_cnt, out.n, members, 1, (P4*)out.col, nullptr);
     }
     HIP_TRY(hipGetLastError());
     dbg_sync(h, 8);

@@ -471,8 +471,51 @@ struct VoxTable {
   unsigned long long* key;  // [cap]
   unsigned int* first;      // [cap] smallest point index of the voxel; after vox_number_kernel: the voxel's output position
   unsigned int* ncnt;       // [cap] ~(number of points)
+  unsigned int* cursor;     // one word behind the table: (next free entry of the member list) - 1, i.e. 0xffffffff like everything else
   unsigned int mask;
 };
+
+// "point i opens its voxel" as the input of a scan (no flag array, no kernel to fill it): entry n is the zero sentinel
+struct VoxFirstFlag {
+  const int* slot_of;
+  size_t n;
+  VoxTable t;
+  __device__ __forceinline__ int operator()(size_t i) const {
+    if (i >= n) return 0;
+    const int s = slot_of[i];
+    return s >= 0 && t.first[s] == (unsigned int)i;
+  }
+};
+
+// scan_local_kernel (icp_kernels.hpp) with its input computed on the fly
+template <typename T, typename Load>
+__global__ __launch_bounds__(kBlock) void scan_local_fn_kernel(Load in, T* __restrict__ out, T* __restrict__ block_sums, size_t m, T* __restrict__ pub) {
+  __shared__ T s_wave[kBlock / 64];
+  const size_t base = (size_t)blockIdx.x * kScanPerBlock + (size_t)threadIdx.x * 4;
+  T v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = (base + k < m) ? (T)in(base + k) : (T)0;
+  const T tsum = v[0] + v[1] + v[2] + v[3];
+  T x = tsum;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const T y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  if (lane == 63) s_wave[w] = x;
+  __syncthreads();
+  T woff = 0;
+  for (int k = 0; k < w; ++k) woff += s_wave[k];
+  T excl = woff + x - tsum;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (base + k < m) out[base + k] = excl;
+    if (pub && base + k == m - 1) *pub = excl;
+    excl += v[k];
+  }
+  if (threadIdx.x == kBlock - 1) block_sums[blockIdx.x] = woff + x;
+}
 
 template <typename P4>
 __global__ __launch_bounds__(kBlock) void vox_insert_kernel(const P4* __restrict__ pts, size_t n, double ox, double oy, double oz, double v,
@@ -497,41 +540,62 @@ __global__ __launch_bounds__(kBlock) void vox_insert_kernel(const P4* __restrict
   }
 }
 
-// flag[i] = point i opens its voxel; flag[n] = 0 (the scan's sentinel)
-__global__ __launch_bounds__(kBlock) void vox_flag_kernel(const int* __restrict__ slot_of, size_t n, VoxTable t, int* __restrict__ flag) {
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i <= n; i += (size_t)gridDim.x * kBlock) {
-    int f = 0;
+// The first point of voxel number r (r = its rank among the first points, from the scan) gives the voxel its piece of the member list --
+// one atomic per wavefront: the sizes of a wavefront's voxels are scanned across its lanes -- and leaves r in the table for the other
+// members.  Where a voxel's piece lies in the list does not matter, only that the pieces do not overlap.
+__global__ __launch_bounds__(kBlock) void vox_number_kernel(const int* __restrict__ slot_of, const int* __restrict__ rank, size_t n, VoxTable t,
+                                                            int* __restrict__ seg_start, int* __restrict__ seg_cnt, int* __restrict__ vox_slot) {
+  const int lane = threadIdx.x & 63;
+  for (size_t i0 = (size_t)blockIdx.x * kBlock; i0 < n; i0 += (size_t)gridDim.x * kBlock) {  // whole wavefronts iterate together
+    const size_t i = i0 + threadIdx.x;
+    int s = -1;
+    bool f = false;
     if (i < n) {
-      const int s = slot_of[i];
+      s = slot_of[i];
       f = s >= 0 && t.first[s] == (unsigned int)i;
     }
-    flag[i] = f;
-  }
-}
-
-// the first point of voxel number r writes the voxel's size and leaves r in the table for the other members
-__global__ __launch_bounds__(kBlock) void vox_number_kernel(const int* __restrict__ slot_of, const int* __restrict__ flag, const int* __restrict__ rank,
-                                                            size_t n, size_t m, VoxTable t, int* __restrict__ seg_cnt, int* __restrict__ vox_slot) {
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
-    if (i == 0) seg_cnt[m] = 0;
-    if (!flag[i]) continue;
-    const int s = slot_of[i];
-    const int r = rank[i];
-    seg_cnt[r] = (int)~t.ncnt[s];
-    t.first[s] = (unsigned int)r;
-    vox_slot[r] = s;  // for vox_mean_kernel, which hands the slot back empty
+    const int cnt = f ? (int)~t.ncnt[s] : 0;
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int y = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += y;
+    }
+    // one atomic per WORKGROUP (2 k same-address atomics, one per wavefront of a 131 k-point scan, took 25 us)
+    __shared__ int s_tot[kBlock / 64];
+    __shared__ unsigned int s_base;
+    const int w = threadIdx.x >> 6;
+    if (lane == 63) s_tot[w] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int all = 0;
+#pragma unroll
+      for (int k = 0; k < kBlock / 64; ++k) all += s_tot[k];
+      s_base = all > 0 ? atomicAdd(t.cursor, (unsigned int)all) + 1u : 0u;
+    }
+    __syncthreads();
+    unsigned int base = s_base;
+    for (int k = 0; k < w; ++k) base += (unsigned int)s_tot[k];
+    __syncthreads();  // s_tot / s_base are rewritten by the next iteration
+    if (f) {
+      const int r = rank[i];
+      seg_start[r] = (int)base + incl - cnt;
+      seg_cnt[r] = cnt;
+      vox_slot[r] = s;  // for vox_mean_kernel, which hands the slot back empty
+      t.first[s] = (unsigned int)r;
+    }
   }
 }
 
 // members[seg_start[r] ..] = the point indices of voxel r, in whatever order the atomics hand out (put in order by vox_mean_kernel).
 // The counter still holds ~count: the j-th increment returns ~count + j.
 __global__ __launch_bounds__(kBlock) void vox_gather_kernel(const int* __restrict__ slot_of, size_t n, VoxTable t, const int* __restrict__ seg_start,
-                                                            uint32_t* __restrict__ members) {
+                                                            const int* __restrict__ seg_cnt, uint32_t* __restrict__ members) {
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
     const int s = slot_of[i];
     if (s < 0) continue;
     const unsigned int r = t.first[s];
-    const int b = seg_start[r], cnt = seg_start[r + 1] - b;
+    const int b = seg_start[r], cnt = seg_cnt[r];
     const unsigned int j = atomicAdd(&t.ncnt[s], 1u) + (unsigned int)cnt + 1u;  // old - ~cnt
     members[(size_t)b + j] = (uint32_t)i;
   }
@@ -577,17 +641,19 @@ __device__ inline void sort_indices(uint32_t* a, int k) {
 // divided by the count; normals are averaged, not re-normalised.  attr_only: `members` is already in order (the colour pass).
 template <typename P4>
 __global__ __launch_bounds__(kBlock) void vox_mean_kernel(const P4* __restrict__ pts, const P4* __restrict__ nrm, const int* __restrict__ seg_start,
-                                                          size_t m, uint32_t* __restrict__ members, int attr_only, P4* __restrict__ out_pts,
-                                                          P4* __restrict__ out_nrm, VoxTable t = VoxTable{}, const int* __restrict__ vox_slot = nullptr) {
+                                                          const int* __restrict__ seg_cnt, size_t m, uint32_t* __restrict__ members, int attr_only,
+                                                          P4* __restrict__ out_pts, P4* __restrict__ out_nrm, VoxTable t = VoxTable{},
+                                                          const int* __restrict__ vox_slot = nullptr) {
   using R = typename Scalar<P4>::type;
   for (size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x; r < m; r += (size_t)gridDim.x * kBlock) {
-    const int b = seg_start[r], e = seg_start[r + 1];
+    const int b = seg_start[r], e = b + seg_cnt[r];
     if (!attr_only) sort_indices(members + b, e - b);
     if (vox_slot) {  // the table is done with (vox_gather_kernel has run): leave the slot as the 0xff fill left it, for the next call
       const int s = vox_slot[r];
       t.key[s] = kEmptyKey;
       t.first[s] = ~0u;
       t.ncnt[s] = ~0u;
+      if (r == 0) *t.cursor = ~0u;
     }
     double sx = 0, sy = 0, sz = 0, nx = 0, ny = 0, nz = 0;
     for (int j = b; j < e; ++j) {
