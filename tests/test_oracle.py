@@ -253,6 +253,29 @@ def test_c_normals_and_voxel_equal_numpy(oracle):
     assert (dots[view > 1e-6] > 1 - 1e-6).mean() > 0.999
 
 
+def test_knn_raw_normals_equal_numpy(oracle):
+    """[O3D] EstimateNormals(KDTreeSearchParamKNN(20)) alone -- what InitializePointCloudForGeneralizedICP gives a cloud without normals:
+    pure k-nearest neighbourhoods (no radius), unit eigenvector of the smallest eigenvalue, no orientation pass"""
+    from scipy.spatial import cKDTree
+
+    a, _ = syn.config1_inputs(n_az=96)
+    av = oracle.voxel_down_sample(a, 0.2)
+    n1 = oracle.estimate_normals_knn_raw(av, 20)
+    _, j = cKDTree(av).query(av, k=20)
+    for i in range(0, len(av), 7):
+        nb = av[j[i]]
+        mu = nb.mean(0)
+        w, v = np.linalg.eigh(nb.T @ nb / 20 - np.outer(mu, mu))
+        if (w[1] - w[0]) / max(w[2], 1e-300) < 1e-6:
+            continue  # direction not defined by the data
+        assert abs(abs(n1[i] @ v[:, 0]) - 1.0) < 1e-8, i
+    np.testing.assert_allclose(np.linalg.norm(n1, axis=1), 1.0, atol=1e-12)
+    # the hybrid search with a radius that holds every pair is the same neighbourhood; NormalizeNormals / orientation only flip signs
+    n2 = oracle.estimate_normals(av, 1e3, 20)
+    assert np.all(np.abs(np.abs(np.einsum("ij,ij->i", n1, n2)) - 1.0) < 1e-12)
+    assert (np.einsum("ij,ij->i", n1, n2) < 0).any()  # ... which it does for some points: raw is not oriented
+
+
 def test_map_merge_matches_numpy(oracle):
     rng = np.random.default_rng(11)
     pts = rng.uniform(-3, 3, (5000, 3))
