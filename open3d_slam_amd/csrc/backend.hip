@@ -169,7 +169,7 @@ struct o3ds_context {
   unsigned char* d_voxtab = nullptr;
   size_t voxtab_cap = 0;  // slots
   bool voxtab_clean = false;
-  int fused_chunk_hint = 12;  // launches queued before the host first looks at the state: what the previous registration needed, plus one
+  int fused_chunk_hint[2] = {12, 12};  // [registration against a cropped target?]: scan-to-map and scan-to-scan alternate on a handle  // launches queued before the host first looks at the state: what the previous registration needed, plus one
   int debug_update = 0;  // O3DS_DEBUG_UPDATE: timing experiments only
   int pass_rows = 1024;
   // profiling (bench.py roofline): event pairs around every accumulate launch
@@ -1796,7 +1796,7 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
       // A launch after the loop has ended costs its launch (~4.6 us each, a dozen of them per registration of a stream whose scans
       // converge in four or five iterations), a look at the state costs a host round trip: queue what the previous registration on this
       // handle needed plus one, then four at a time
-      const int chunk = std::min(total - j, j == 0 ? h->fused_chunk_hint : 4);
+      const int chunk = std::min(total - j, j == 0 ? h->fused_chunk_hint[target_crop ? 1 : 0] : 4);
       for (int k = 0; k < chunk; ++k, ++j) {
         const int par = j & 1;
         fa.first = j == 0;
@@ -1831,7 +1831,7 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
       copy_result(h, out);
       if (h->h_state->done) break;
     }
-    h->fused_chunk_hint = std::min(std::max(h->h_state->iterations + 3, 4), 12);  // iterations + 2 launches were needed
+    h->fused_chunk_hint[target_crop ? 1 : 0] = std::min(std::max(h->h_state->iterations + 3, 4), 12);  // iterations + 2 launches were needed
     if (d_trace) {
       std::vector<unsigned long long> t((size_t)16 * nb);
       (void)hipMemcpy(t.data(), d_trace, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
