@@ -253,8 +253,8 @@ int o3ds_icp_done(o3ds_handle h, int* done);
 /* CroppingVolume::crop (croppers.cpp:76-106): stable compaction of points (+normals) inside the volume. */
 int o3ds_crop_cloud(o3ds_handle h, o3ds_cloud in, const o3ds_crop* crop, o3ds_cloud* out);
 /* o3d_slam::voxelize (helpers.cpp:107-113) -> [O3D] PointCloud::VoxelDownSample: data-anchored grid,
- * per-voxel mean of points (and normals).  Output order: ascending voxel key (the reference's order is
- * unordered_map iteration order, i.e. unspecified).  voxel <= 0 returns a copy. */
+ * per-voxel mean of points (and normals), each sum taken in cloud order.  Output order: voxels in order of their first point in the
+ * cloud (the reference's order is unordered_map iteration order, i.e. unspecified).  voxel <= 0 returns a copy. */
 int o3ds_voxel_down_sample(o3ds_handle h, o3ds_cloud in, double voxel_size, o3ds_cloud* out);
 /* The first two steps of ScanToMapIcp::preprocess (ScanToMapRegistration.cpp:36-37) and LidarOdometry::preprocess (Odometry.cpp:26-27),
  * `cropped = cropper->crop(in); voxelize(voxelSize, cropped)`, as one call: the same cloud o3ds_crop_cloud followed by
