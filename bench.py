@@ -592,11 +592,14 @@ def main():
         be2.close()
         m2["calls"] = prof["calls"]
         m2["pose_repeats_bitwise_between_the_two_runs"] = bool(np.array_equal(m2["pose"], prof["pose"]))
-        run_stream_pipelined(local_rank, scans32[: min(12, len(scans32))])
-        pl = run_stream_pipelined(local_rank, scans32)
-        m2["pipelined"] = {"scans_per_sec": pl["scans_per_sec"], "map_points": pl["map_points"],
-                           "pose_equals_serial_bitwise": bool(np.array_equal(m2["pose"], pl["pose"])),
-                           "what": "odometry and mapping on two host threads and two backend handles (SlamWrapper.cpp:228-229), raw scan ingested by both"}
+        try:  # an extra line of the report: it must not take the measured lines above down with it
+            run_stream_pipelined(local_rank, scans32[: min(12, len(scans32))])
+            pl = run_stream_pipelined(local_rank, scans32)
+            m2["pipelined"] = {"scans_per_sec": pl["scans_per_sec"], "map_points": pl["map_points"],
+                               "pose_equals_serial_bitwise": bool(np.array_equal(m2["pose"], pl["pose"])),
+                               "what": "odometry and mapping on two host threads and two backend handles (SlamWrapper.cpp:228-229), raw scan ingested by both"}
+        except Exception as e:  # noqa: BLE001
+            m2["pipelined"] = {"error": repr(e)}
         del m2["pose"]
 
     if rank == 0:
