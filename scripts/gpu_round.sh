@@ -24,5 +24,10 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python $R/
 echo "rocprof rc=$?" >> $OUT/rocprof.err
 python $R/scripts/prof_summary.py $OUT/prof/bench_results.db $OUT/rocprof_stats.txt > /dev/null
 bash $R/scripts/gpu_stream_prof.sh > /dev/null 2>&1
+# configs[1] alone (the registrations `value` and `roofline` are quoted on): the fused kernel's average here is the bench line's avg_launch_us
+# once the one prologue-only launch per registration (the ~6 us dispatches of the detail list) is set aside
+cd /tmp; rm -rf $OUT/prof_m1
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_m1 -o m1 -- python $R/bench.py --no-cpu-baseline --no-f64 --concurrent 0 --m2-frames 0 > $OUT/rocprof_m1.json 2> /dev/null
+python $R/scripts/prof_summary.py $OUT/prof_m1/m1_results.db $OUT/rocprof_stats_m1.txt > /dev/null
 cd $R
 grep -E "passed|failed" $OUT/pytest_gpu.log | tail -3; tail -2 $OUT/smoke.log; tail -1 $OUT/bench.err; tail -1 $OUT/check_normals.log; head -8 $OUT/normals_stats.txt; head -14 $OUT/rocprof_stats.txt | cut -c1-80,100-170
