@@ -16,8 +16,10 @@ handle's stream) of algorithmic bytes (SURVEY.md 8d formulas) / time / 8 TB/s.
 
 N GPUs (one process per GPU, torch.distributed.run): rank r holds ITS OWN 1M-pt submap (seed 1235+r) and the whole scan; every ICP
 iteration is ONE fused kernel plus one 4-KB RCCL all-reduce of the exact hi/lo sums of the normal equations ("submap" partitioning,
-open3d_slam_amd/sharded.py).  Weak scaling: per-GPU work is fixed.  `value` = iterations/s of the JOINT registration (one registration
-over N submaps, not N registrations); the aggregate work is `point_queries_per_sec` (source points searched per second over all ranks).
+open3d_slam_amd/sharded.py).  Weak scaling: per-GPU work is fixed.  `value` = the units all ranks processed per second, the unit being
+BASELINE.json's -- one ICP iteration of the 64k scan against one 1M-point submap -- i.e. N per iteration of the joint registration;
+`joint_registration_iterations_per_sec` (= value / N: the registration over N submaps is ONE registration, not N) and
+`point_queries_per_sec` (source points searched per second over all ranks) stand beside it.
 """
 from __future__ import annotations
 
@@ -619,7 +621,7 @@ def main():
         steps = args.steps
         out = {
             "metric": "icp_iterations_per_sec",
-            "value": ICP_ITERS * steps / elapsed,
+            "value": world * ICP_ITERS * steps / elapsed,  # N = 1: the registration's iterations/s; N > 1: summed over the N submaps (docstring)
             "unit": "icp_iterations/s",
             "n_gpus": world,
             "steps": steps,
@@ -638,10 +640,12 @@ def main():
                            f"one MIN all-reduce of {N_SRC} 64-bit keys (512 KB), an accumulate kernel, one 256-B sum all-reduce, an update kernel"
                            if args.config == "3u" else
                            f"configs[3]: ONE joint registration over {world} submaps x 1 GPU: one fused kernel + one 4-KB RCCL "
-                           "all-reduce per iteration (value counts the joint iterations once)"),
+                           "all-reduce per iteration (value = scan-vs-one-submap iterations per second summed over the GPUs; "
+                           "joint_registration_iterations_per_sec counts the joint iterations once)"),
                        "nn_cell_m": args.cell if args.cell > 0 else MAX_CORR / 4},
             "index_build_ms": r32["index_build_ms"],
             "point_queries_per_sec": world * N_SRC * (ICP_ITERS + 1) * steps / elapsed,
+            "joint_registration_iterations_per_sec": ICP_ITERS * steps / elapsed,
             "registrations_per_sec": steps / elapsed,
             "pose_error_vs_truth": {"dt_m": dt_gt, "dr_rad": dr_gt, "fitness": res["fitness"], "inlier_rmse": res["inlier_rmse"]},
             "roofline": roof(r32),
