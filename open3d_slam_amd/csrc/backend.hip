@@ -2078,7 +2078,7 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
   // new keys are sorted), by one radix sort of everything otherwise.  Same arrays either way (cloud_kernels.hpp, merge_class_kernel).
   static const bool no_incremental = getenv("O3DS_NO_INCREMENTAL_MERGE") != nullptr;  // A/B and debugging
   bool merged = false;
-  if (mode == 1 && !filter && merge_np >= 0 && !no_incremental && n < ((size_t)1 << 21) && (size_t)merge_np + merge_nv <= n) {
+  if (mode == 1 && !filter && merge_np >= 0 && !no_incremental && n < ((size_t)1 << 31) && (size_t)merge_np + merge_nv <= n) {
     const size_t np = (size_t)merge_np, nv = merge_nv;
     unsigned long long *cls = nullptr, *rank = nullptr, *vk = nullptr, *xk = nullptr, *xk2 = nullptr;
     uint32_t *vv = nullptr, *xv = nullptr, *xv2 = nullptr;
@@ -2102,7 +2102,7 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
     const unsigned long long tot = pub_value<unsigned long long>(h, 1);
     const int unsorted = pub_value<int>(h, 2);
     if (!unsorted) {
-      const size_t npass_ = (size_t)(tot & kCntMask), nvin = (size_t)((tot >> 21) & kCntMask), nx = (size_t)((tot >> 42) & kCntMask);
+      const size_t npass_ = (size_t)(tot & kCntMask), nvin = (size_t)(tot >> 32), nx = n - npass_ - nvin;
       merge_split_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(k0, rank, n, np, nv, k1, v1, vk, vv, xk, xv);
       const unsigned long long* xks = xk;
       const uint32_t* xvs = xv;

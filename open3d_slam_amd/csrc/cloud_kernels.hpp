@@ -258,7 +258,9 @@ __global__ __launch_bounds__(kBlock) void voxel_key_kernel(const P4* __restrict_
 // points and pass-through points that re-entered -- followed by the outside points in index order.  The kernels below produce exactly
 // the arrays rocPRIM's radix sort would (same keys, same tie order: ascending index), so everything after them is unchanged and the
 // result is bit-identical; only the m new keys are sorted.
-constexpr unsigned long long kCntPass = 1ull, kCntV = 1ull << 21, kCntX = 1ull << 42, kCntMask = (1ull << 21) - 1ull;
+// two counters in one 64-bit scan: points outside the volume (low word) and kept voxel-block entries (high word); every entry is one of
+// outside / kept / new, so the number of new entries in front of entry i is i minus the other two
+constexpr unsigned long long kCntPass = 1ull, kCntV = 1ull << 32, kCntMask = 0xffffffffull;
 template <typename P4>
 __global__ __launch_bounds__(kBlock) void merge_class_kernel(const P4* __restrict__ pts, size_t n, double v, CropDev crop, size_t np, size_t nv,
                                                              unsigned long long* __restrict__ keys, unsigned long long* __restrict__ cls,
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(kBlock) void merge_class_kernel(const P4* __restric
     const bool inside = crop_contains(crop, x, y, z);
     const bool in_v = i >= np && i < np + nv;
     keys[i] = inside ? vk : (kPassBit | (unsigned long long)i);
-    cls[i] = inside ? (in_v ? kCntV : kCntX) : kCntPass;
+    cls[i] = inside ? (in_v ? kCntV : 0ull) : kCntPass;
     if (in_v && i > np) {  // the voxel block must still be in key order (a mean that rounding put on the far side of a face breaks it)
       const P4 q = pts[i - 1];
       const unsigned long long pk = pack_key((long long)floor((double)q.x * inv), (long long)floor((double)q.y * inv), (long long)floor((double)q.z * inv));
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(kBlock) void merge_split_kernel(const unsigned long
                                                              uint32_t* __restrict__ v_sorted, unsigned long long* __restrict__ vk, uint32_t* __restrict__ vv,
                                                              unsigned long long* __restrict__ xk, uint32_t* __restrict__ xv) {
   const unsigned long long tot = rank[n];
-  const size_t n_in = (size_t)((tot >> 21) & kCntMask) + (size_t)((tot >> 42) & kCntMask);
+  const size_t n_in = n - (size_t)(tot & kCntMask);
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
     const unsigned long long k = keys[i], r = rank[i];
     if (k & kPassBit) {
@@ -297,11 +299,11 @@ __global__ __launch_bounds__(kBlock) void merge_split_kernel(const unsigned long
       k_sorted[o] = k;
       v_sorted[o] = (uint32_t)i;
     } else if (i >= np && i < np + nv) {
-      const size_t o = (size_t)((r >> 21) & kCntMask);
+      const size_t o = (size_t)(r >> 32);
       vk[o] = k;
       vv[o] = (uint32_t)i;
     } else {
-      const size_t o = (size_t)((r >> 42) & kCntMask);
+      const size_t o = i - (size_t)(r & kCntMask) - (size_t)(r >> 32);
       xk[o] = k;
       xv[o] = (uint32_t)i;
     }

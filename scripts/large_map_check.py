@@ -1,5 +1,5 @@
-"""One-off size check beyond the bench configurations: an 8 M-point map (index build, voxel merge by the full-sort path -- the merging path
-packs three 21-bit counters and covers maps below 2 M points -- registration of a 64k scan) against the CPU oracle on the same inputs."""
+"""One-off size check beyond the bench configurations: an 8 M-point map (index build, registration of a 64k scan, voxel merge of a cloud
+without a known layout: the full-sort path) against the CPU oracle on the same inputs."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1125,6 +1125,47 @@ def _insert_sequence(be, n_frames, rmax, voxel, carve_at=()):
     return out
 
 
+def _big_map_inserts(be):
+    """a 3 M-point map (beyond 2^21 entries) and three scans inserted into it; checksum of the map after each insertion"""
+    import hashlib
+
+    scene = syn.make_scene()
+    pts, nrm = syn.sample_map(scene, 3_000_000, seed=21)
+    m = be.upload(pts, nrm)
+    out = []
+    for k in range(3):
+        T = syn.make_pose([0.8 * k, -0.3 * k, 0.0], [0.0, 0.0, 3.0 * k])
+        s = be.upload(syn.vlp16_scan(scene, T, frame=k, n_az=512))
+        v = be.voxel_down_sample(s, 0.1)
+        be.estimate_normals(v, 2.0, 10)
+        crop = backend.make_crop(backend.CROP_MIN_MAX_RADIUS, center=T[:3, 3], rmin=0.0, rmax=18.0)
+        be.map_insert_scan(m, v, T, 0.05, crop, max_corr_hint=1.0)
+        p, n = be.download(m)
+        out.append((len(p), hashlib.sha1(p.tobytes()).hexdigest(), hashlib.sha1(n.tobytes()).hexdigest()))
+        be.free(s)
+        be.free(v)
+    be.free(m)
+    return out
+
+
+def test_map_merge_by_merging_beyond_two_million_points():
+    """the merging path counts the three classes of entries with two 32-bit counters in one 64-bit scan (the third is the remainder), so it
+    holds for maps of any size the 32-bit point indices allow; checked against the full sort on a 3 M-point map"""
+    import pickle
+    import subprocess
+    import sys
+
+    code = ("import sys, pickle; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_preprocess_map_gpu as t; from open3d_slam_amd import backend; "
+            "be = backend.Backend(0); sys.stdout.buffer.write(pickle.dumps(t._big_map_inserts(be)))"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
+    ref = pickle.loads(subprocess.run([sys.executable, "-c", code], capture_output=True, check=True,
+                                      env=dict(os.environ, O3DS_NO_INCREMENTAL_MERGE="1")).stdout)
+    be = backend.Backend(0)
+    got = _big_map_inserts(be)
+    be.close()
+    assert got == ref and got[-1][0] > (1 << 21), (got, ref)
+
+
 @pytest.mark.parametrize("prec", ["f64", "f32"])
 def test_map_merge_by_merging_is_bitwise_the_full_sort(prec, monkeypatch):
     """Submap::insertScan re-bins the whole map at every scan (helpers.cpp:115-183).  The backend builds the sorted voxel-key list of
