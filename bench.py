@@ -153,6 +153,7 @@ def cpu_baseline_m2(scans32, frames, threads):
     po.lib().orc_set_num_threads(threads)
     ref = OracleLoop(po, mp, op)
     cpu = {"odometry": 0.0, "mapping": 0.0}
+    ref.poses_per_frame = []
     for k in range(frames):
         raw = scans32[k].astype(np.float64)
         t0 = time.perf_counter()
@@ -160,6 +161,7 @@ def cpu_baseline_m2(scans32, frames, threads):
         t1 = time.perf_counter()
         ref.mapping(raw, 0.1 * k)
         t2 = time.perf_counter()
+        ref.poses_per_frame.append((ref.T.copy(), len(ref.map_p)))
         if k > 0:
             cpu["odometry"] += t1 - t0
             cpu["mapping"] += t2 - t1
@@ -167,9 +169,9 @@ def cpu_baseline_m2(scans32, frames, threads):
     return dict(value=m / (cpu["odometry"] + cpu["mapping"]), unit="scans/s", cores=int(po.lib().orc_num_threads()), kind="port",
                 mapping_only_scans_per_sec=m / cpu["mapping"], ms_per_scan={k: 1e3 * v / m for k, v in cpu.items()},
                 map_points=int(len(ref.map_p)),
-                sample=f"frames 1..{frames - 1} of the same stream (the map holds {len(ref.map_p)} points at the end; the GPU leg runs all "
-                       f"frames, its map grows further and its later frames cost more), CPU restatement of Open3D v0.15.1, KD-tree of the "
-                       f"map patch rebuilt per registration as the reference does"), ref
+                sample=f"frames 1..{frames - 1} of the same {len(scans32)}-frame stream (the map holds {len(ref.map_p)} points at the end"
+                       + ("" if frames == len(scans32) else "; the GPU leg runs all frames, its map grows further and its later frames cost more")
+                       + "), CPU restatement of Open3D v0.15.1, KD-tree of the map patch rebuilt per registration as the reference does"), ref
 
 
 # ------------------------------------------------------------------------------------------------ M2: the config-2 stream
@@ -242,6 +244,7 @@ def run_stream(be, scans32, profile=False):
         be.profile_enable(True)
     stage = {"upload": 0.0, "odometry": 0.0, "mapping": 0.0}
     frames = len(scans32)
+    per_frame = []
     try:
         for k, raw in enumerate(scans32):
             t0 = time.perf_counter()
@@ -255,6 +258,7 @@ def run_stream(be, scans32, profile=False):
             t3 = time.perf_counter()
             cloud.release()
             assert ok1 and ok2, (k, ok1, ok2)
+            per_frame.append(mapper.getMapToRangeSensor().copy())
             if k > 0:  # frame 0 only initialises
                 stage["upload"] += t1 - t0
                 stage["odometry"] += t2 - t1
@@ -268,7 +272,7 @@ def run_stream(be, scans32, profile=False):
     out = {"scans_per_sec": n / (stage["odometry"] + stage["mapping"] + stage["upload"]),
            "mapping_only_scans_per_sec": n / stage["mapping"], "ms_per_scan": {k: 1e3 * v / n for k, v in stage.items()},
            "frames": frames, "map_points": len(mapper.getActiveSubmap().getMapPointCloud()),
-           "final_pose_error_vs_truth": {"dt_m": dt, "dr_rad": dr}, "pose": mapper.getMapToRangeSensor().copy()}
+           "final_pose_error_vs_truth": {"dt_m": dt, "dr_rad": dr}, "pose": mapper.getMapToRangeSensor().copy(), "poses_per_frame": per_frame}
     if profile:
         def row(tag, nbytes, what):
             cnt, ms = be.span_read(tag)
@@ -446,7 +450,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=16.0)
     ap.add_argument("--m2-frames", type=int, default=200, help="frames of the configs[2] stream (0: skip M2)")
-    ap.add_argument("--m2-cpu-frames", type=int, default=40)
+    ap.add_argument("--m2-cpu-frames", type=int, default=200, help="frames of the stream the CPU oracle loop plays (all of them by default: like for like)")
+    ap.add_argument("--no-host-seam", action="store_true", help="skip the configs[2] run through the integration header with host clouds at the seams")
     ap.add_argument("--no-f64", action="store_true")
     ap.add_argument("--concurrent", type=int, default=4, help="registrations in flight at once for the `concurrent` line (0 / 1: skip)")
     ap.add_argument("--config", default="auto", choices=["auto", "1", "3", "3u", "4"],
@@ -461,8 +466,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+            # started bare (`python bench.py --gpus N`): become the launcher -- one rank per GPU through torch.distributed.run, same
+            # arguments, rank 0 prints the JSON line, the launcher passes its exit status on
+            import socket
+            import subprocess
+
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            env = dict(os.environ)
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+                   "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            raise SystemExit(subprocess.call(cmd, env=env))
         args.gpus = world
     if args.config == "auto":
         args.config = "1" if world == 1 else "3"
@@ -603,6 +619,35 @@ def main():
         except Exception as e:  # noqa: BLE001
             m2["pipelined"] = {"error": repr(e)}
         del m2["pose"]
+        m2_poses = m2.pop("poses_per_frame")
+        prof.pop("poses_per_frame", None)
+        if not args.no_host_seam:
+            # the same stream through integration/o3ds_open3d_slam.hpp -- the functions the open3d_slam patch calls -- with HOST clouds at
+            # every seam: what a patched open3d_slam gets; never `value`
+            try:
+                import importlib.util
+                import tempfile
+
+                spec = importlib.util.spec_from_file_location("stream_integration", os.path.join(ROOT, "scripts", "stream_integration.py"))
+                si = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(si)
+                with tempfile.TemporaryDirectory() as tmp:
+                    path = os.path.join(tmp, "scans.bin")
+                    si.write_scans(path, scans32, syn.figure_eight_poses(200, 0.1)[: len(scans32)])
+                    exe = si.compile_program(tmp, werror=False)
+                    hs = si.run(exe, path, "serial", os.path.join(tmp, "poses.bin"))
+                    hp, _ = si.read_poses(os.path.join(tmp, "poses.bin"), len(scans32))
+                    worst = max(max(syn.se3_error(a, b)) for a, b in zip(hp, m2_poses))
+                    ht = si.run(exe, path, "threads")
+                m2["host_seam"] = {"scans_per_sec": hs["scans_per_sec"], "mapping_only_scans_per_sec": hs["scans_per_sec_mapping_only"],
+                                   "ms_per_scan": hs["ms_per_scan"], "map_points": hs["map_points"],
+                                   "two_threads_scans_per_sec": ht["scans_per_sec"],
+                                   "worst_pose_difference_vs_device_resident_loop": worst,
+                                   "what": "C++ through integration/o3ds_open3d_slam.hpp (tests/cpp/stream_integration.cpp): every raw scan arrives as a host "
+                                           "PointCloud of doubles, every pre-processed cloud is downloaded for its readers; a scan the previous seam put on "
+                                           "the device is not uploaded again (o3ds::ScanOnDevice)"}
+            except Exception as e:  # noqa: BLE001
+                m2["host_seam"] = {"error": repr(e)[:600]}
 
     if rank == 0:
         res, elapsed = r32["res"], r32["elapsed"]
@@ -670,9 +715,15 @@ def main():
             out["parity_vs_cpu"] = {"dt_m": dt, "dr_rad": dr, "fitness_gpu": res["fitness"], "fitness_cpu": cres["fitness"]}
             out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
             if m2 is not None and args.m2_cpu_frames > 1:
-                cb2, _ = cpu_baseline_m2(scans32, min(args.m2_cpu_frames, len(scans32)), best_t)  # the thread count the M1 sweep found best
+                n_cpu = min(args.m2_cpu_frames, len(scans32))
+                cb2, ref2 = cpu_baseline_m2(scans32, n_cpu, best_t)  # the thread count the M1 sweep found best
                 out["scans_per_sec"]["cpu_baseline"] = cb2
                 out["scans_per_sec"]["speedup_vs_cpu_baseline"] = out["scans_per_sec"]["scans_per_sec"] / cb2["value"]
+                # parity of the two legs, frame by frame (f32 storage on the device: stated tolerance 1e-3 m / 1e-3 rad)
+                errs = [syn.se3_error(m2_poses[k], ref2.poses_per_frame[k][0]) for k in range(n_cpu)]
+                out["scans_per_sec"]["parity_vs_cpu"] = {"frames_compared": n_cpu, "worst_dt_m": max(e[0] for e in errs), "worst_dr_rad": max(e[1] for e in errs),
+                                                         "map_points_gpu": out["scans_per_sec"]["map_points"], "map_points_cpu": cb2["map_points"],
+                                                         "within_stated_tolerance": bool(max(max(e) for e in errs) <= 1e-3)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

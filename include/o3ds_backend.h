@@ -275,6 +275,13 @@ int o3ds_select_by_index(o3ds_handle h, o3ds_cloud in, const uint32_t* keep_idx,
 int o3ds_transform_cloud(o3ds_handle h, o3ds_cloud in, const double T[16], o3ds_cloud* out);
 /* mapCloud_ += cloud (Submap.cpp:70; [O3D] PointCloud::operator+=). Appends `add` to `map` in place. */
 int o3ds_cloud_append(o3ds_handle h, o3ds_cloud map, o3ds_cloud add);
+/* A copy of a cloud of handle `src` as a cloud of handle `dst` (same device, same storage precision), device to device: points,
+ * normals, colours and the known bounding box; the search index is not copied.  This is how a scan that one worker pre-processed
+ * (ScanToMapIcp::processForScanMatchingAndMerging on the mapping thread's handle, ScanToMapRegistration.cpp:42-54) reaches the
+ * handle that owns the submap (Submap::insertScan, Submap.cpp:39-75; ScanToMapIcp::scanToMapRegistration, :55-62) without a second
+ * trip through host memory -- the reference passes the same host PointCloud to both.  `dst`'s stream waits for what `src` queued;
+ * neither handle may be in use by another thread during the call; returns when the copy is complete. */
+int o3ds_cloud_copy_across(o3ds_handle dst, o3ds_handle src, o3ds_cloud src_cloud, o3ds_cloud* out);
 /* voxelizeWithinCroppingVolume (helpers.cpp:115-183) via Submap::voxelizeInsideCroppingVolume (Submap.cpp:138-144):
  * points outside the volume pass through (original order, first); points inside are replaced by per-voxel means on
  * the WORLD-anchored grid key = floor(p * (1/voxel)) (VoxelHashMap.hpp:47-50), normals averaged (NaN skipped) and

@@ -5,17 +5,28 @@
 // a C ABI).  This header is the thin C++ between the two: it speaks open3d::geometry::PointCloud / Eigen::Isometry3d on one side
 // and plain pointers on the other, and defines nothing in namespace o3d_slam (no clash with the reference's declarations).
 //   Seam 1  CloudRegistration::registerClouds / estimateNormalsOrCovariancesIfNeeded  -> o3ds::registerClouds, o3ds::estimateNormals
-//   Seam 2  ScanToMapIcp::scanToMapRegistration                                       -> o3ds::DeviceSubmap::registerScan
+//   Seam 2  ScanToMapIcp::preprocess / processForScanMatchingAndMerging,
+//           LidarOdometry::preprocess                                                 -> o3ds::preprocessScan, o3ds::cropScan
+//           ScanToMapIcp::scanToMapRegistration                                       -> o3ds::DeviceSubmap::registerScan
 //   Seam 3  Submap::insertScan / carve / transform / copy                             -> o3ds::DeviceSubmap
+// A scan is uploaded ONCE per worker: preprocessScan returns the reference's PointCloudPtr pointing at a ScanOnDevice -- an ordinary
+// open3d PointCloud (host points and normals filled in, every caller may read it) that also remembers its copy in HBM.  The calls that
+// follow in the reference's flow (registerClouds in LidarOdometry::addRangeScan, scanToMapRegistration and Submap::insertScan in
+// Mapper::addRangeMeasurement) recognise it and use the device copy instead of uploading the host one again.
 // Threads: a backend handle is one HIP stream plus scratch and is not re-entrant.  The stateless calls use one handle per calling
 // thread; a DeviceSubmap owns a handle and a mutex (the reference guards mapCloud_ with mapPointCloudMutex_ in the same places).
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <memory>
 #include <mutex>
+#include <numeric>
+#include <random>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include <open3d/geometry/PointCloud.h>
 #include <open3d/pipelines/registration/Registration.h>
@@ -55,9 +66,14 @@ class OwnedHandle {
  private:
   mutable o3ds_handle h_ = nullptr;
 };
-inline o3ds_handle threadHandle() {  // the stateless calls: one handle per calling thread (odometry, mapping, loop-closure workers)
-  static thread_local OwnedHandle h;
-  return h.get();
+// a handle and the lock that serialises its users: the stateless calls take their calling thread's box, a DeviceSubmap owns one
+struct HandleBox {
+  OwnedHandle h;
+  std::recursive_mutex m;  // recursive: the last reference to a device scan may be dropped inside a call that holds the lock
+};
+inline std::shared_ptr<HandleBox> threadBox() {  // one per calling thread (odometry, mapping, loop-closure workers), created on first use
+  static thread_local std::shared_ptr<HandleBox> box = std::make_shared<HandleBox>();
+  return box;
 }
 
 // CroppingVolume in the ABI's form.  croppingVolumeFactory (croppers.cpp:23-47) picks which parameters a named volume uses; only the
@@ -83,6 +99,60 @@ inline o3ds_crop makeCrop(const o3d_slam::ScanCroppingParameters& p, const Eigen
   return c;
 }
 
+inline o3ds_crop noCrop() {  // the base CroppingVolume (croppers.cpp:49-51): everything is inside
+  o3ds_crop c{};
+  c.kind = O3DS_CROP_NONE;
+  return c;
+}
+
+// ---- a pre-processed scan that is still on the device ------------------------------------------------------------------------------
+// The device copy belongs to the handle (box) of the thread that made it and is freed with the last PointCloud that refers to it.
+struct DeviceRef {
+  std::shared_ptr<HandleBox> box;
+  o3ds_cloud id = 0;
+  size_t n = 0;
+  uint64_t stamp = 0;  // fingerprint of the host arrays when the copy was made (see fingerprint)
+  DeviceRef() = default;
+  DeviceRef(const DeviceRef&) = delete;
+  DeviceRef& operator=(const DeviceRef&) = delete;
+  ~DeviceRef() {
+    if (id && box) {
+      std::lock_guard<std::recursive_mutex> lck(box->m);
+      o3ds_cloud_free(box->h.get(), id);
+    }
+  }
+};
+// what the seams hand out instead of a plain PointCloud: the same object for every reader, plus the device copy
+class ScanOnDevice : public PointCloud {
+ public:
+  std::shared_ptr<const DeviceRef> device_;
+};
+// Guards against a caller that edits the host arrays after the device copy was made (the copy would be stale): size, presence of
+// normals and the bits of up to 64 evenly spaced points and normals.  Not a proof of equality; open3d_slam's own flow never edits a
+// pre-processed scan between the seams, and an edited cloud that still matches in all 64 samples is not a case worth a full pass.
+inline uint64_t fingerprint(const PointCloud& c) {
+  uint64_t f = 0x9e3779b97f4a7c15ull ^ (uint64_t)c.points_.size() ^ ((uint64_t)c.normals_.size() << 32);
+  const size_t n = c.points_.size();
+  if (n == 0) return f;
+  const size_t step = n > 64 ? n / 64 : 1;
+  for (size_t i = 0; i < n; i += step) {
+    uint64_t w[3];
+    std::memcpy(w, c.points_[i].data(), sizeof(w));
+    f = (f << 7 | f >> 57) ^ w[0] ^ (w[1] << 1) ^ (w[2] << 2);
+    if (c.normals_.size() == n) {
+      std::memcpy(w, c.normals_[i].data(), sizeof(w));
+      f = (f << 11 | f >> 53) ^ w[0] ^ (w[1] << 3) ^ (w[2] << 5);
+    }
+  }
+  return f;
+}
+inline std::shared_ptr<const DeviceRef> deviceCopyOf(const PointCloud& c) {
+  const ScanOnDevice* s = dynamic_cast<const ScanOnDevice*>(&c);
+  if (!s || !s->device_ || s->device_->n != c.points_.size() || c.points_.empty()) return nullptr;
+  if (std::getenv("O3DS_NO_DEVICE_SCANS")) return nullptr;  // A/B switch: always upload, as round 2 did
+  return s->device_->stamp == fingerprint(c) ? s->device_ : nullptr;
+}
+
 // a PointCloud on the device for the duration of a call
 class DeviceCloud {
  public:
@@ -90,16 +160,39 @@ class DeviceCloud {
     const double* nrm = c.HasNormals() ? reinterpret_cast<const double*>(c.normals_.data()) : nullptr;
     check(h_, o3ds_cloud_upload(h_, reinterpret_cast<const double*>(c.points_.data()), nrm, c.points_.size(), &id_));
   }
+  // The cloud on handle h, whose lock the caller holds: borrowed if its device copy already lives on this handle (`mine` is the
+  // box h belongs to, null for a handle no ScanOnDevice can belong to), copied device to device if it lives on another handle,
+  // uploaded from the host arrays otherwise.
+  DeviceCloud(o3ds_handle h, const HandleBox* mine, const PointCloud& c) : h_(h) {
+    if (std::shared_ptr<const DeviceRef> ref = deviceCopyOf(c)) {
+      if (ref->box.get() == mine) {
+        id_ = ref->id;
+        borrowed_ = ref;  // keeps the copy alive; nothing to free here
+        return;
+      }
+      std::unique_lock<std::recursive_mutex> other(ref->box->m, std::try_to_lock);  // never wait for a second handle while holding one
+      if (other.owns_lock()) {
+        check(h_, o3ds_cloud_copy_across(h_, ref->box->h.get(), ref->id, &id_));
+        fromDevice_ = true;
+        return;
+      }
+    }
+    const double* nrm = c.HasNormals() ? reinterpret_cast<const double*>(c.normals_.data()) : nullptr;
+    check(h_, o3ds_cloud_upload(h_, reinterpret_cast<const double*>(c.points_.data()), nrm, c.points_.size(), &id_));
+  }
   DeviceCloud(const DeviceCloud&) = delete;
   DeviceCloud& operator=(const DeviceCloud&) = delete;
   ~DeviceCloud() {
-    if (id_) o3ds_cloud_free(h_, id_);
+    if (id_ && !borrowed_) o3ds_cloud_free(h_, id_);
   }
   o3ds_cloud id() const { return id_; }
+  bool uploaded() const { return !borrowed_ && !fromDevice_; }
 
  private:
   o3ds_handle h_;
   o3ds_cloud id_ = 0;
+  std::shared_ptr<const DeviceRef> borrowed_;
+  bool fromDevice_ = false;
 };
 
 inline void downloadCloud(o3ds_handle h, o3ds_cloud id, PointCloud* out) {
@@ -131,13 +224,17 @@ inline o3ds_icp_params icpParams(int method, double maxCorrespondenceDistance, c
   return p;
 }
 
-// Seam 1: [O3D] RegistrationICP / RegistrationGeneralizedICP on host clouds (CloudRegistration.cpp:16-21,44-48,69-73).  The target's
-// search index is built per call, as the reference builds its KD-tree per call.
+// Seam 1: [O3D] RegistrationICP / RegistrationGeneralizedICP (CloudRegistration.cpp:16-21,44-48,69-73).  A cloud that is still on the
+// device (ScanOnDevice) is used where it is -- LidarOdometry::addRangeScan then registers two resident clouds, the target with the
+// search grid its normal estimation left behind; a host cloud is uploaded and its index built per call, as the reference builds its
+// KD-tree per call.
 inline RegistrationResult registerClouds(int method /* o3ds_icp_method */, const PointCloud& source, const PointCloud& target,
                                          const Eigen::Matrix4d& init, double maxCorrespondenceDistance, const ICPConvergenceCriteria& criteria) {
-  const o3ds_handle h = threadHandle();
-  DeviceCloud s(h, source), t(h, target);
-  check(h, o3ds_cloud_build_index(h, t.id(), maxCorrespondenceDistance, 0.0));
+  const std::shared_ptr<HandleBox> box = threadBox();
+  std::lock_guard<std::recursive_mutex> lck(box->m);
+  const o3ds_handle h = box->h.get();
+  DeviceCloud s(h, box.get(), source), t(h, box.get(), target);
+  if (t.uploaded()) check(h, o3ds_cloud_build_index(h, t.id(), maxCorrespondenceDistance, 0.0));  // otherwise o3ds_icp_register_dev keeps or builds it
   const o3ds_icp_params p = icpParams(method, maxCorrespondenceDistance, criteria);
   o3ds_icp_result r{};
   check(h, o3ds_icp_register_dev(h, s.id(), t.id(), nullptr, init.data(), &p, &r));
@@ -147,11 +244,98 @@ inline RegistrationResult registerClouds(int method /* o3ds_icp_method */, const
 // Seam 1b: EstimateNormals(Hybrid) + NormalizeNormals + OrientNormalsTowardsCameraLocation (CloudRegistration.cpp:22-30,49-56)
 inline void estimateNormals(PointCloud* cloud, double maxRadius, int knn) {
   if (cloud->points_.empty()) return;
-  const o3ds_handle h = threadHandle();
+  const std::shared_ptr<HandleBox> box = threadBox();
+  std::lock_guard<std::recursive_mutex> lck(box->m);
+  const o3ds_handle h = box->h.get();
   DeviceCloud c(h, *cloud);
   check(h, o3ds_estimate_normals(h, c.id(), maxRadius, knn));
   cloud->normals_.resize(cloud->points_.size());
   check(h, o3ds_cloud_download(h, c.id(), nullptr, reinterpret_cast<double*>(cloud->normals_.data()), cloud->points_.size()));
+}
+
+// ---- Seam 2, first half: the scan chain ---------------------------------------------------------------------------------------------
+// [O3D] RandomDownSample draws from std::mt19937 seeded by std::random_device, per call; setRandomDownSampleSeed pins the generator of
+// the calling thread (tests, reproducible runs).
+inline std::mt19937& downSampleGenerator() {
+  static thread_local std::mt19937 g{std::random_device{}()};
+  return g;
+}
+inline void setRandomDownSampleSeed(uint32_t seed) { downSampleGenerator().seed(seed); }
+
+struct ScanChain {
+  o3ds_crop crop;                // cropper of the chain in the sensor frame (noCrop() for the base CroppingVolume)
+  double voxelSize = 0.0;        // o3d_slam::voxelize: <= 0 skips (helpers.cpp:108-110)
+  bool estimateNormals = true;   // the registration type's estimateNormalsOrCovariancesIfNeeded (no-op for point-to-point)
+  double normalRadius = 0.0;
+  int normalKnn = 0;
+  double downSamplingRatio = 1.0;
+};
+inline std::shared_ptr<PointCloud> adopt(const std::shared_ptr<HandleBox>& box, o3ds_cloud id) {  // box->m held; takes over `id`
+  auto ref = std::make_shared<DeviceRef>();
+  auto out = std::make_shared<ScanOnDevice>();
+  downloadCloud(box->h.get(), id, out.get());  // may throw: `id` is still the caller's then
+  ref->box = box;
+  ref->id = id;
+  ref->n = out->points_.size();
+  ref->stamp = fingerprint(*out);
+  out->device_ = ref;
+  return out;
+}
+// ScanToMapIcp::preprocess (ScanToMapRegistration.cpp:35-40) and LidarOdometry::preprocess (Odometry.cpp:25-30):
+//   cropper->crop(in); voxelize(voxelSize, cropped); estimateNormalsOrCovariancesIfNeeded(cropped); cropped->RandomDownSample(ratio)
+// One upload of the raw scan, the chain on the device, one download; the result stays on the device behind the returned cloud.
+// With ratio >= 1 Open3D's RandomDownSample returns a permutation of the cloud; here the cloud keeps its order (same points, only
+// summation orders downstream differ), which saves a 60 k-element host shuffle per scan.
+inline std::shared_ptr<PointCloud> preprocessScan(const PointCloud& raw, const ScanChain& p) {
+  if (p.estimateNormals) {
+    if (!(p.normalRadius > 0.0)) throw std::runtime_error("maxRadiusNormalEstimation_");  // assert_gt, CloudRegistration.cpp:50-51
+    if (!(p.normalKnn > 0)) throw std::runtime_error("knnNormalEstimation_");
+  }
+  if (p.downSamplingRatio < 0.0 || p.downSamplingRatio > 1.0)
+    throw std::runtime_error("[RandomDownSample] Illegal sampling_ratio, sampling_ratio must be between 0 and 1.");  // [O3D]
+  const std::shared_ptr<HandleBox> box = threadBox();
+  std::lock_guard<std::recursive_mutex> lck(box->m);
+  const o3ds_handle h = box->h.get();
+  if (raw.points_.empty()) return std::make_shared<PointCloud>();
+  DeviceCloud in(h, box.get(), raw);
+  o3ds_cloud cur = 0;
+  check(h, o3ds_crop_voxel_down_sample(h, in.id(), &p.crop, p.voxelSize, &cur));
+  try {
+    size_t n = 0;
+    check(h, o3ds_cloud_size(h, cur, &n, nullptr));
+    if (p.estimateNormals && n > 0) check(h, o3ds_estimate_normals(h, cur, p.normalRadius, p.normalKnn));
+    if (p.downSamplingRatio < 1.0 && n > 0) {
+      std::vector<uint32_t> idx(n);
+      std::iota(idx.begin(), idx.end(), 0u);
+      std::shuffle(idx.begin(), idx.end(), downSampleGenerator());
+      idx.resize((size_t)(int)(p.downSamplingRatio * (double)n));
+      o3ds_cloud kept = 0;
+      check(h, o3ds_select_by_index(h, cur, idx.data(), idx.size(), &kept));
+      o3ds_cloud_free(h, cur);
+      cur = kept;
+    }
+    return adopt(box, cur);
+  } catch (...) {
+    o3ds_cloud_free(h, cur);
+    throw;
+  }
+}
+// CroppingVolume::crop (croppers.cpp:76-106) of a pre-processed scan: the narrow crop of processForScanMatchingAndMerging
+// (ScanToMapRegistration.cpp:47-48), on the device when the scan is still there
+inline std::shared_ptr<PointCloud> cropScan(const PointCloud& cloud, const o3ds_crop& crop) {
+  const std::shared_ptr<HandleBox> box = threadBox();
+  std::lock_guard<std::recursive_mutex> lck(box->m);
+  const o3ds_handle h = box->h.get();
+  if (cloud.points_.empty()) return std::make_shared<PointCloud>();
+  DeviceCloud in(h, box.get(), cloud);
+  o3ds_cloud out = 0;
+  check(h, o3ds_crop_cloud(h, in.id(), &crop, &out));
+  try {
+    return adopt(box, out);
+  } catch (...) {
+    o3ds_cloud_free(h, out);
+    throw;
+  }
 }
 
 // Seam 3: Submap's mapCloud_, resident in HBM together with its search index.  Value semantics, because open3d_slam keeps its
@@ -187,7 +371,7 @@ class DeviceSubmap {
   void setInitialMap(const PointCloud& preProcessedScan, double mapVoxelSize, double maxCorrespondenceDistance) {
     auto s = unique();
     std::lock_guard<std::mutex> lck(s->m);
-    DeviceCloud in(s->h.get(), preProcessedScan);
+    DeviceCloud in(s->h.get(), nullptr, preProcessedScan);
     o3ds_cloud v = 0;
     check(s->h.get(), o3ds_voxel_down_sample(s->h.get(), in.id(), mapVoxelSize, &v));  // voxel <= 0: a copy (helpers.cpp:108-110)
     s->adopt(v, maxCorrespondenceDistance);
@@ -198,7 +382,7 @@ class DeviceSubmap {
     if (preProcessedScan.IsEmpty()) return;
     auto s = unique();
     std::lock_guard<std::mutex> lck(s->m);
-    DeviceCloud in(s->h.get(), preProcessedScan);
+    DeviceCloud in(s->h.get(), nullptr, preProcessedScan);
     check(s->h.get(), o3ds_map_insert_scan(s->h.get(), s->id(), in.id(), mapToRangeSensor.matrix().data(), mapVoxelSize, &mapBuilderCrop,
                                            maxCorrespondenceDistance));
     ++s->version;
@@ -232,7 +416,7 @@ class DeviceSubmap {
     auto s = shared();
     std::lock_guard<std::mutex> lck(s->m);
     if (s->size() == 0) throw std::runtime_error("map patch size is zero");  // assert_gt, ScanToMapRegistration.cpp:60
-    DeviceCloud in(s->h.get(), scan);
+    DeviceCloud in(s->h.get(), nullptr, scan);
     const o3ds_icp_params p = icpParams(method, maxCorrespondenceDistance, criteria);
     o3ds_icp_result r{};
     check(s->h.get(), o3ds_icp_register_dev(s->h.get(), in.id(), s->map, &scanMatcherCrop, initialGuess.matrix().data(), &p, &r));

@@ -114,6 +114,7 @@ SIGNATURES = {
     "o3ds_select_by_index": (C.c_int, [_H, _CL, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(_CL)]),
     "o3ds_transform_cloud": (C.c_int, [_H, _CL, _dp, C.POINTER(_CL)]),
     "o3ds_cloud_append": (C.c_int, [_H, _CL, _CL]),
+    "o3ds_cloud_copy_across": (C.c_int, [_H, _H, _CL, C.POINTER(_CL)]),
     "o3ds_voxelize_within_volume": (C.c_int, [_H, _CL, C.c_double, C.POINTER(Crop)]),
     "o3ds_map_insert_scan": (C.c_int, [_H, _CL, _CL, _dp, C.c_double, C.POINTER(Crop), C.c_double]),
 }
@@ -488,6 +489,12 @@ class Backend:
 
     def cloud_append(self, map_id: int, add_id: int):
         self._ck(self.lib.o3ds_cloud_append(self.h, map_id, add_id))
+
+    def copy_from(self, other: "Backend", cid: int) -> int:
+        """a cloud of another handle on the same device as a cloud of this one (device-to-device copy)"""
+        out = _CL()
+        self._ck(self.lib.o3ds_cloud_copy_across(self.h, other.h, cid, C.byref(out)))
+        return out.value
 
     def voxelize_within_volume(self, map_id: int, voxel: float, crop: Crop):
         self._ck(self.lib.o3ds_voxelize_within_volume(self.h, map_id, voxel, C.byref(crop)))

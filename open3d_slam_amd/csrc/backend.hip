@@ -2674,6 +2674,48 @@ int o3ds_cloud_append(o3ds_handle h, o3ds_cloud map, o3ds_cloud add) {
   return DISPATCH(m->precision, append_t, h, *m, *a);
 }
 
+int o3ds_cloud_copy_across(o3ds_handle dst, o3ds_handle src, o3ds_cloud src_cloud, o3ds_cloud* out) {
+  o3ds_handle h = dst;
+  CHECK_HANDLE(h);
+  if (!src || !out) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_copy_across: bad argument");
+  if (src == dst) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_copy_across: source and destination handle are the same (use the cloud itself)");
+  if (src->device != dst->device) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_copy_across: the handles live on different devices");
+  CloudRec* c = find_cloud(src, src_cloud);
+  if (!c) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_copy_across: unknown cloud id on the source handle");
+  if (c->n && c->precision != dst->precision) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_copy_across: the handles store points in different precisions");
+  CloudRec o;
+  CloudGuard o_guard(h, o);
+  o.precision = c->n ? c->precision : dst->precision;
+  o.n = c->n;
+  box_copy(o, *c);
+  if (c->n) {
+    // what the source handle queued for this cloud must have happened before the copy reads it: the destination stream waits for
+    // an event on the source stream (no host wait); the source cloud must stay alive until the destination stream passed the copy,
+    // which the synchronisation below guarantees before this returns
+    hipEvent_t ev = nullptr;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, src->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(dst->stream, ev, 0);
+    (void)hipEventDestroy(ev);  // released once it has completed
+    HIP_TRY(e);
+    const size_t bytes = p4_size(c->precision) * c->n;
+    HIP_TRY(dev_alloc(h, (void**)&o.pts, bytes));
+    HIP_TRY(hipMemcpyAsync(o.pts, c->pts, bytes, hipMemcpyDeviceToDevice, h->stream));
+    if (c->nrm) {
+      HIP_TRY(dev_alloc(h, (void**)&o.nrm, bytes));
+      HIP_TRY(hipMemcpyAsync(o.nrm, c->nrm, bytes, hipMemcpyDeviceToDevice, h->stream));
+    }
+    if (c->col) {
+      HIP_TRY(dev_alloc(h, (void**)&o.col, bytes));
+      HIP_TRY(hipMemcpyAsync(o.col, c->col, bytes, hipMemcpyDeviceToDevice, h->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  o_guard.release();
+  *out = add_cloud(h, std::move(o));
+  return O3DS_OK;
+}
+
 }  // extern "C" (a helper with default arguments follows)
 namespace {
 // voxelizeWithinCroppingVolume of a device cloud in place; merge_np >= 0: the cloud is [pass block | voxel block in key order | new points]

@@ -8,7 +8,7 @@ import numpy as np
 from .cloud_registration import cloudRegistrationFactory
 from .croppers import CroppingVolume, croppingVolumeFactory
 from .parameters import OdometryParameters
-from .pointcloud import PointCloud
+from .pointcloud import PointCloud, random_down_sample
 
 
 class LidarOdometry:
@@ -21,6 +21,8 @@ class LidarOdometry:
         self.odomToRangeSensorCumulative_ = np.eye(4)
         self.odomToRangeSensorBuffer_: list[tuple[float, np.ndarray]] = []
         self.lastMeasurementTimestamp_ = None
+        self._downsample_rng = None
+        self._shuffle_at_full_ratio = False
 
     def setParameters(self, p: OdometryParameters):  # Odometry.cpp:96-100
         self.params_ = p
@@ -31,14 +33,12 @@ class LidarOdometry:
         # cropper_->crop(in) then voxelize(voxelSize_, cropped) (Odometry.cpp:26-27) as one call, same result bit for bit
         vox = PointCloud(self.be, self.be.crop_voxel_down_sample(cloud.id, self.cropper_.to_abi(), self.params_.scanProcessing_.voxelSize_))
         self.cloudRegistration_.estimateNormalsOrCovariancesIfNeeded(vox)
-        # RandomDownSample(ratio): ratio = 1 in every benchmark config (non-reproducible otherwise)
-        if self.params_.scanProcessing_.downSamplingRatio_ < 1.0:
-            n = len(vox)
-            keep = np.random.default_rng().permutation(n)[: int(self.params_.scanProcessing_.downSamplingRatio_ * n)]
-            sub = PointCloud(self.be, self.be.select_by_index(vox.id, keep))
-            vox.release()
-            vox = sub
-        return vox
+        # RandomDownSample(ratio) (Odometry.cpp:29); setDownSampleSeed pins the kept-index lists
+        return random_down_sample(vox, self.params_.scanProcessing_.downSamplingRatio_, self._downsample_rng, self._shuffle_at_full_ratio)
+
+    def setDownSampleSeed(self, seed: int | None, shuffle_at_full_ratio: bool = False):
+        self._downsample_rng = None if seed is None else np.random.default_rng(seed)
+        self._shuffle_at_full_ratio = bool(shuffle_at_full_ratio)
 
     def addRangeScan(self, cloud: PointCloud, timestamp: float) -> bool:  # Odometry.cpp:32-79
         if self.cloudPrev_ is None or self.cloudPrev_.IsEmpty():

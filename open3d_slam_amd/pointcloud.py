@@ -77,3 +77,20 @@ class PointCloud:
                 self.release()
         except Exception:
             pass
+
+
+def random_down_sample(cloud: "PointCloud", ratio: float, rng=None, shuffle_at_full_ratio: bool = False) -> "PointCloud":
+    """[O3D] PointCloud::RandomDownSample as open3d_slam calls it (Odometry.cpp:29, ScanToMapRegistration.cpp:39): shuffle the
+    indices 0..n-1, keep the first int(ratio * n), SelectByIndex (output in shuffled order).  Open3D seeds a fresh mt19937 from
+    std::random_device per call, so the reference is not reproducible here; `rng` (a numpy Generator) pins the list.
+    With ratio >= 1 Open3D still returns a PERMUTATION of the cloud; that only changes summation orders downstream, so the default
+    leaves the cloud alone and `shuffle_at_full_ratio` reproduces the permutation when a test wants it.  Consumes `cloud`."""
+    n = len(cloud)
+    if n == 0 or (ratio >= 1.0 and not shuffle_at_full_ratio):
+        return cloud
+    if rng is None:
+        rng = np.random.default_rng()
+    keep = rng.permutation(n)[: int(min(ratio, 1.0) * n)]
+    out = PointCloud(cloud.be, cloud.be.select_by_index(cloud.id, keep))
+    cloud.release()
+    return out

@@ -9,7 +9,7 @@ from .cloud_registration import RegistrationResult, cloudRegistrationFactory
 from .croppers import croppingVolumeFactory
 from .parameters import (CloudRegistrationParameters, CloudRegistrationType, MapperParameters, ScanToMapRegistrationParameters,
                          ScanToMapRegistrationType)
-from .pointcloud import PointCloud
+from .pointcloud import PointCloud, random_down_sample
 
 
 @dataclasses.dataclass
@@ -60,20 +60,14 @@ class ScanToMapIcp(ScanToMapRegistration):  # ScanToMapRegistration.hpp:40-59
         self.scanMatcherCropper_ = croppingVolumeFactory(self.params_.scanProcessing_.cropper_)
         self.cloudRegistration = cloudRegistrationFactory(toCloudRegistrationType(p.scanMatcher_))
 
-    def setDownSampleSeed(self, seed: int | None):
+    def setDownSampleSeed(self, seed: int | None, shuffle_at_full_ratio: bool = False):
         """The reference's RandomDownSample is seeded from std::random_device (non-reproducible, SURVEY 0.5); a seed makes
-        the kept-index list reproducible.  ratio >= 1 never subsamples."""
+        the kept-index lists reproducible (one generator, advanced once per scan)."""
         self._downsample_rng = None if seed is None else np.random.default_rng(seed)
+        self._shuffle_at_full_ratio = bool(shuffle_at_full_ratio)
 
     def _random_down_sample(self, cloud: PointCloud, ratio: float) -> PointCloud:
-        n = len(cloud)
-        if ratio >= 1.0 or n == 0:
-            return cloud
-        rng = self._downsample_rng or np.random.default_rng()
-        keep = rng.permutation(n)[: int(ratio * n)]  # [O3D] shuffle, keep the first int(ratio*size), SelectByIndex
-        out = PointCloud(cloud.be, cloud.be.select_by_index(cloud.id, keep))
-        cloud.release()
-        return out
+        return random_down_sample(cloud, ratio, self._downsample_rng, getattr(self, "_shuffle_at_full_ratio", False))
 
     def preprocess(self, cloud: PointCloud) -> PointCloud:  # ScanToMapRegistration.cpp:35-40
         be = cloud.be  # mapBuilderCropper_->crop(in) then voxelize(voxelSize_, cropped) (.cpp:36-37) as one call, same result bit for bit

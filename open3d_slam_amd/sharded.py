@@ -69,7 +69,7 @@ def run_sharded_fused_loop(issue_pass: Callable[[int], object], all_reduce: Call
 class ShardedIcp:
     """GPU driver of run_sharded_loop over a Backend handle and a torch.distributed process group."""
 
-    def __init__(self, be, mode: str = "source", group=None):
+    def __init__(self, be, mode: str = "source", group=None, always_collective: bool = False):
         import torch
         import torch.distributed as dist
 
@@ -78,6 +78,9 @@ class ShardedIcp:
         self.dist, self.torch = dist, torch
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # a group of one rank skips its collectives; `always_collective` issues them anyway (they are the identity), so that the
+        # RCCL launch path and its ordering with the backend's kernels on the shared stream run on a one-GPU box
+        self.collective = self.world > 1 or (always_collective and dist.is_initialized())
         dev = torch.device(f"cuda:{be.device_id}")
         # a dedicated torch stream shared by the backend's kernels and the collective: accumulate -> all_reduce ->
         # update are stream-ordered, no host sync per iteration (torch's default stream has handle 0 == "NULL = own
@@ -113,7 +116,7 @@ class ShardedIcp:
             return self.rec
 
         def all_reduce(rec):
-            if self.world > 1:
+            if self.collective:
                 dist.all_reduce(rec, op=dist.ReduceOp.SUM, group=self.group)
 
         def update(rec):
@@ -147,13 +150,13 @@ class ShardedIcp:
 
             def accumulate():
                 be.icp_nn_keys(0, n_src, self.rank, kptr)
-                if self.world > 1:
+                if self.collective:
                     dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=self.group)
                 be.icp_accumulate_keys(0, n_src, self.rank, kptr, rptr)
                 return self.rec
 
             def all_reduce(rec):
-                if self.world > 1:
+                if self.collective:
                     dist.all_reduce(rec, op=dist.ReduceOp.SUM, group=self.group)
 
             run_sharded_loop(accumulate, all_reduce, lambda rec: be.icp_update(rptr, n_src), be.icp_done, max_iter, check_every)
@@ -229,13 +232,14 @@ class ShardedDenseMap:
     what arrived into a cloud and o3ds_dense_map_insert fuses it into the local table.  Nothing goes through host memory except the
     split sizes, which torch.distributed needs as Python ints.  size() is the global voxel count."""
 
-    def __init__(self, be, voxel: float, group=None, has_normals: bool = True):
+    def __init__(self, be, voxel: float, group=None, has_normals: bool = True, always_collective: bool = False):
         import torch
         import torch.distributed as dist
 
         self.be, self.voxel, self.group, self.has_normals = be, float(voxel), group, bool(has_normals)
         self.torch, self.dist = torch, dist
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.collective = self.world > 1 or (always_collective and dist.is_initialized())  # as in ShardedIcp
         self.device = torch.device(f"cuda:{be.device_id}")
         self.dm = be.dense_map_create(self.voxel)
         # the backend's kernels and the collective share one torch stream, as in ShardedIcp
@@ -252,7 +256,7 @@ class ShardedDenseMap:
             rows = torch.empty((max(n, 1), 6), dtype=torch.float64, device=self.device)
             counts = torch.zeros(self.world, dtype=torch.int64, device=self.device)
             be.export_rows_by_owner(cid, T, self.voxel, self.world, rows.data_ptr(), counts.data_ptr())
-            if self.world > 1:
+            if self.collective:
                 recv_counts = torch.empty_like(counts)
                 dist.all_to_all_single(recv_counts, counts, group=self.group)
                 send_split = [int(c) for c in counts.cpu()]

@@ -18,6 +18,22 @@ class OracleLoop:
         self.odom_at = {}
         self.prev = None
         self.last_t = None
+        self.rng_odo = self.rng_map = None  # RandomDownSample keep lists (see set_down_sample_seeds)
+        self.shuffle_at_full_ratio = False
+
+    def set_down_sample_seeds(self, odo_seed, map_seed, shuffle_at_full_ratio=False):
+        """[O3D] RandomDownSample (Odometry.cpp:29, ScanToMapRegistration.cpp:39) shuffles with a generator seeded from
+        std::random_device; the test hands both sides the same numpy generators, advanced once per scan, so both keep the same
+        index list: permutation(n)[: int(ratio * n)], output in shuffled order."""
+        self.rng_odo = np.random.default_rng(odo_seed)
+        self.rng_map = np.random.default_rng(map_seed)
+        self.shuffle_at_full_ratio = shuffle_at_full_ratio
+
+    def _down(self, v, n, ratio, rng):
+        if len(v) == 0 or (ratio >= 1.0 and not self.shuffle_at_full_ratio):
+            return v, n
+        keep = (rng or np.random.default_rng()).permutation(len(v))[: int(min(ratio, 1.0) * len(v))]
+        return v[keep], n[keep]
 
     def _pre(self, raw, crop_p, voxel, icp):
         o = self.o
@@ -28,6 +44,7 @@ class OracleLoop:
     def odometry(self, raw, t):
         icp = self.op.scanMatcher_.icp_
         v, n = self._pre(raw, self.op.scanProcessing_.cropper_, self.op.scanProcessing_.voxelSize_, icp)
+        v, n = self._down(v, n, self.op.scanProcessing_.downSamplingRatio_, self.rng_odo)
         if self.prev is not None:
             r = self.o.icp_point_to_plane(self.prev, v, n, icp.maxCorrespondenceDistance_, max_iter=icp.maxNumIter_)
             assert r["fitness"] > 0.1
@@ -39,6 +56,7 @@ class OracleLoop:
         o, mp = self.o, self.mp
         icp = mp.scanMatcher_.icp_
         v, n = self._pre(raw, mp.mapBuilder_.cropper_, mp.scanProcessing_.voxelSize_, icp)
+        v, n = self._down(v, n, mp.scanProcessing_.downSamplingRatio_, self.rng_map)
         sc = mp.scanProcessing_.cropper_
         keep = o.crop_indices(v, o.make_crop(o.CROP_MIN_MAX_RADIUS, rmin=sc.croppingMinRadius_, rmax=sc.croppingMaxRadius_))
         match = v[keep]

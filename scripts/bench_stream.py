@@ -19,6 +19,7 @@ be = backend.Backend(0)
 out = bench.run_stream(be, scans, profile=args.profile)
 be.close()
 out.pop("pose")
+out.pop("poses_per_frame", None)
 if args.cpu_frames > 1:
     out["cpu_baseline"], _ = bench.cpu_baseline_m2(scans, min(args.cpu_frames, len(scans)), min(16, os.cpu_count() or 1))
 print(json.dumps(out))

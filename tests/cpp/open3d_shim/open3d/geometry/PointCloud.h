@@ -7,6 +7,7 @@ namespace open3d {
 namespace geometry {
 class PointCloud {
  public:
+  virtual ~PointCloud() = default;  // open3d::geometry::Geometry is polymorphic
   std::vector<Eigen::Vector3d> points_, normals_, colors_;
   std::vector<Eigen::Matrix3d> covariances_;
   bool HasPoints() const { return !points_.empty(); }

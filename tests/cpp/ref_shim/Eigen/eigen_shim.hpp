@@ -126,6 +126,7 @@ class Matrix {
   Matrix& operator+=(const Matrix&);
   Matrix& operator-=(const Matrix&);
   Matrix& operator*=(S);
+  Matrix& operator*=(const Matrix<S, C, C>&);
   Matrix& operator/=(S);
   Matrix operator*(S) const;
   Matrix operator/(S) const;

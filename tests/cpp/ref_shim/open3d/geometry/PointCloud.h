@@ -36,6 +36,7 @@ class PointCloud {
  public:
   PointCloud();
   explicit PointCloud(const std::vector<Eigen::Vector3d>& points);
+  virtual ~PointCloud() = default;  // open3d::geometry::Geometry is polymorphic (virtual destructor, Clear, IsEmpty, ...)
   std::vector<Eigen::Vector3d> points_, normals_, colors_;
   std::vector<Eigen::Matrix3d> covariances_;
   bool HasPoints() const;

@@ -2,12 +2,14 @@
 // spelling and memory layout of the Open3D / Eigen types (tests/cpp/open3d_shim).
 //   test_integration --no-gpu : construction, copies, cropper names
 //   test_integration          : Seam 1 (registerClouds, estimateNormals), Seam 2 (registerScan), Seam 3 (insertScan, copy on write,
-//                               transform, carve) on the GPU, self-checked against each other and against analytic truth
+//                               transform, carve) on the GPU, self-checked against each other and against analytic truth; the scan
+//                               chain (preprocessScan, cropScan) and scans that stay on the device between the seams (ScanOnDevice)
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
 #include <string>
+#include <thread>
 
 #include "../../integration/o3ds_open3d_slam.hpp"
 
@@ -135,6 +137,81 @@ int main(int argc, char** argv) {
   const uint64_t vc = copy.version();
   const size_t removed = copy.carve(s1, I, everything, sc);
   CHECK(copy.size() == before - removed && copy.size() > before / 4 && copy.version() != vc);
+  // ---- Seam 2, first half: the scan chain, and scans that stay on the device between the seams -------------------------------------
+  {
+    PointCloud raw = cornerScan(60000, 7, 3.0, 3.0, 1.5);
+    o3ds::ScanChain chain;
+    chain.crop = o3ds::makeCrop(cp, I);
+    chain.voxelSize = 0.1;
+    chain.estimateNormals = true;
+    chain.normalRadius = 1.0;
+    chain.normalKnn = 20;
+    std::shared_ptr<PointCloud> pre = o3ds::preprocessScan(raw, chain);
+    CHECK(pre->points_.size() > 1000 && pre->points_.size() < raw.points_.size() && pre->HasNormals());
+    CHECK(dynamic_cast<o3ds::ScanOnDevice*>(pre.get()) != nullptr);
+    CHECK(o3ds::deviceCopyOf(*pre) != nullptr);
+    // the same chain seam by seam on host clouds (what round 2's patch left to the CPU, here through the stateless calls)
+    const PointCloud plain = *pre;  // sliced: an ordinary host cloud, no device copy
+    CHECK(o3ds::deviceCopyOf(plain) == nullptr);
+    // narrow crop: on the device copy and on the host copy -- same points, bit for bit
+    o3d_slam::ScanCroppingParameters narrowP = cp;
+    narrowP.croppingMinRadius_ = 1.0;
+    narrowP.croppingMaxRadius_ = 6.0;
+    const o3ds_crop narrowCrop = o3ds::makeCrop(narrowP, I);
+    auto n1c = o3ds::cropScan(*pre, narrowCrop), n2c = o3ds::cropScan(plain, narrowCrop);
+    CHECK(n1c->points_.size() == n2c->points_.size() && n1c->points_.size() > 100 && n1c->points_.size() < pre->points_.size());
+    for (size_t i = 0; i < n1c->points_.size(); ++i)
+      for (int a = 0; a < 3; ++a) CHECK(n1c->points_[i][a] == n2c->points_[i][a] && n1c->normals_[i][a] == n2c->normals_[i][a]);
+    // registration of resident clouds == registration of their host copies (LidarOdometry::addRangeScan as patched)
+    PointCloud raw2 = cornerScan(60000, 8, 3.05, 2.95, 1.52);
+    std::shared_ptr<PointCloud> pre2 = o3ds::preprocessScan(raw2, chain);
+    const PointCloud plain2 = *pre2;
+    const auto ra = o3ds::registerClouds(O3DS_ICP_POINT_TO_PLANE, *pre, *pre2, I.matrix(), maxCorr, crit);
+    const auto rb = o3ds::registerClouds(O3DS_ICP_POINT_TO_PLANE, plain, plain2, I.matrix(), maxCorr, crit);
+    CHECK(ra.fitness_ > 0.9);
+    CHECK(translationError(ra.transformation_, rb.transformation_) < 1e-9);
+    CHECK(std::fabs(ra.transformation_(0, 3) - 0.05) < 0.02 && std::fabs(ra.transformation_(1, 3) + 0.05) < 0.02);
+    // a caller that edits the host arrays invalidates the device copy: the edited values are what gets used
+    o3ds::ScanOnDevice edited = *dynamic_cast<o3ds::ScanOnDevice*>(pre.get());
+    CHECK(o3ds::deviceCopyOf(edited) != nullptr);  // a copy of the object shares the device copy
+    for (auto& q : edited.points_) q[0] += 0.25;
+    CHECK(o3ds::deviceCopyOf(edited) == nullptr);
+    const auto rc = o3ds::registerClouds(O3DS_ICP_POINT_TO_PLANE, edited, *pre2, I.matrix(), maxCorr, crit);
+    CHECK(std::fabs(rc.transformation_(0, 3) - ra.transformation_(0, 3) + 0.25) < 0.02);
+    // Seam 3 / Seam 2 second half with a resident scan (Mapper::addRangeMeasurement as patched): the map handle takes the scan
+    // device to device; same map and same registration as with the host copy
+    o3ds::DeviceSubmap mA, mB;
+    mA.insertScan(*pre, I, mapVoxel, everything, maxCorr);
+    mB.insertScan(plain, I, mapVoxel, everything, maxCorr);
+    PointCloud hA, hB;
+    mA.download(&hA);
+    mB.download(&hB);
+    CHECK(hA.points_.size() == hB.points_.size() && hA.points_.size() > 1000);
+    for (size_t i = 0; i < hA.points_.size(); ++i)
+      for (int a = 0; a < 3; ++a) CHECK(hA.points_[i][a] == hB.points_[i][a] && hA.normals_[i][a] == hB.normals_[i][a]);
+    const auto sA = mA.registerScan(O3DS_ICP_POINT_TO_PLANE, *pre2, everything, I, maxCorr, crit);
+    const auto sB = mB.registerScan(O3DS_ICP_POINT_TO_PLANE, plain2, everything, I, maxCorr, crit);
+    CHECK(sA.fitness_ > 0.9 && translationError(sA.transformation_, sB.transformation_) < 1e-9);
+    // down-sampling inside the chain: int(ratio * n) points, every one of them a point of the full result, pinned by the seed
+    chain.downSamplingRatio = 0.5;
+    o3ds::setRandomDownSampleSeed(42);
+    auto half = o3ds::preprocessScan(raw, chain);
+    o3ds::setRandomDownSampleSeed(42);
+    auto half2 = o3ds::preprocessScan(raw, chain);
+    CHECK(half->points_.size() == (size_t)(int)(0.5 * (double)pre->points_.size()));
+    CHECK(half2->points_.size() == half->points_.size());
+    for (size_t i = 0; i < half->points_.size(); ++i)
+      for (int a = 0; a < 3; ++a) CHECK(half->points_[i][a] == half2->points_[i][a]);
+    // point-to-point chains skip the normals; the base CroppingVolume keeps everything
+    chain.downSamplingRatio = 1.0;
+    chain.estimateNormals = false;
+    chain.crop = o3ds::noCrop();
+    auto bare = o3ds::preprocessScan(raw, chain);
+    CHECK(!bare->HasNormals() && bare->points_.size() >= pre->points_.size());
+    // the device copy dies with the last cloud that refers to it, also on another thread
+    std::shared_ptr<PointCloud> keep = o3ds::preprocessScan(raw2, chain);
+    std::thread([moved = std::move(keep)]() mutable { moved.reset(); }).join();
+  }
   std::printf("gpu checks ok\n");
   return 0;
 }
