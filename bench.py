@@ -453,6 +453,7 @@ def main():
     ap.add_argument("--m2-cpu-frames", type=int, default=200, help="frames of the stream the CPU oracle loop plays (all of them by default: like for like)")
     ap.add_argument("--no-host-seam", action="store_true", help="skip the configs[2] run through the integration header with host clouds at the seams")
     ap.add_argument("--no-f64", action="store_true")
+    ap.add_argument("--large-map", type=int, default=8_000_000, help="points of the larger-than-Infinity-Cache map of the m1_large_map line (0: skip)")
     ap.add_argument("--concurrent", type=int, default=4, help="registrations in flight at once for the `concurrent` line (0 / 1: skip)")
     ap.add_argument("--config", default="auto", choices=["auto", "1", "3", "3u", "4"],
                     help="BASELINE.json configs: 1 = scan vs 1M map on one GPU (+ M2); 3 = joint registration over one submap per GPU (sum of the "
@@ -521,10 +522,10 @@ def main():
     assert len(src) == N_SRC
     algo_bytes = N_SRC * ALGO_BYTES_PER_POINT
 
-    def m1(prec, steps, warmup):
+    def m1(prec, steps, warmup, target=None):
         be = backend.Backend(local_rank, prec)
         s_id = be.upload(src)
-        t_id = be.upload(tgt, nrm)
+        t_id = be.upload(*(target or (tgt, nrm)))
         t0 = time.perf_counter()
         be.build_index(t_id, MAX_CORR, args.cell)
         be.synchronize()
@@ -541,6 +542,15 @@ def main():
         return dict(res=res, elapsed=elapsed, index_build_ms=index_build_ms, n_launch=n_launch, avg_kernel_s=avg_kernel_s, gbs=gbs)
 
     r32 = m1(backend.PRECISION_F32, args.steps, args.warmup)
+    # the same registration against a map that does NOT fit the 256 MiB Infinity Cache (8 M points: 256 MB of cell-sorted points + normals,
+    # as much again in cloud order, 36 MB of grid): configs[1]'s own working set (32 MB + 9 MB) is cache resident, so its counter readings
+    # and its rate say nothing about HBM -- this line does
+    r_big = None
+    if world == 1 and args.config == "1" and args.large_map > 0:
+        big = syn.sample_map(scene, args.large_map, seed=syn.SEED_MAP + 17)
+        r_big = m1(backend.PRECISION_F32, max(args.steps // 4, 5), 3, target=big)
+        r_big["n_map"] = args.large_map
+        del big
 
     # ---- the same registration from several host threads at once, one handle (= one HIP stream) each: how open3d_slam calls it
     # (odometry, mapping and loop-closure workers register concurrently, SlamWrapper.cpp:258-347).  One 64k-query grid is a single wave of
@@ -701,6 +711,12 @@ def main():
             out["m1_f64"] = {"value": ICP_ITERS * s64 / r64["elapsed"], "unit": "icp_iterations/s", "steps": s64, "ms_per_step": r64["elapsed"] / s64 * 1e3,
                              "dtype": "f64", "index_build_ms": r64["index_build_ms"], "roofline": roof(r64),
                              "pose_vs_f32_storage": {"dt_m": d64[0], "dr_rad": d64[1]}}
+        if r_big is not None:
+            sb = max(args.steps // 4, 5)
+            out["m1_large_map"] = {"value": ICP_ITERS * sb / r_big["elapsed"], "unit": "icp_iterations/s", "steps": sb, "ms_per_step": r_big["elapsed"] / sb * 1e3,
+                                   "n_map": r_big["n_map"], "index_build_ms": r_big["index_build_ms"], "roofline": roof(r_big),
+                                   "pose_error_vs_truth": dict(zip(("dt_m", "dr_rad"), syn.se3_error(r_big["res"]["transformation"], T_gt))),
+                                   "what": "the configs[1] scan against a map whose index (256 MB cell-sorted + 36 MB grid) exceeds the Infinity Cache"}
         if conc is not None:
             out["concurrent"] = conc
         if m2 is not None:

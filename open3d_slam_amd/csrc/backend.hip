@@ -19,7 +19,7 @@
 #include "cloud_kernels.hpp"
 #include "common.hpp"
 #include "icp_kernels.hpp"
-#include "normals_kernel.hpp"
+#include "normals_select_kernel.hpp"
 
 using namespace o3ds;
 
@@ -2279,7 +2279,18 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn, bool knn_ra
     TMP_ALLOC(d_sums, sizeof(double) * 9 * c.n);
     TMP_ALLOC(d_cnts, sizeof(int) * c.n);
     span_mark(h, kSpanNormalsKernels);
-    if (max_nn <= 32)  // the shipped configs' knn is 20
+    // f32 storage: the selection kernel (normals_select_kernel.hpp) -- same neighbour sets, no sorted list, exact order-independent sums.
+    // O3DS_NRM_SELECT=0 keeps the ranking kernel (A/B, and the reference for tests/test_edge_parity_gpu.py's set comparison).
+    const bool nrm_select = !(getenv("O3DS_NRM_SELECT") && atoi(getenv("O3DS_NRM_SELECT")) == 0);  // read per call: A/B inside one process
+    bool launched = false;
+    if constexpr (std::is_same<P4, P4f>::value) {
+      if (nrm_select && !knn_raw && max_nn <= o3ds::kSelMaxNN && radius < 1e6) {
+        normals_select_kernel<<<gsz, 64, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, d_sums, d_cnts);
+        launched = true;
+      }
+    }
+    if (launched) {
+    } else if (max_nn <= 32)  // the shipped configs' knn is 20
       normals_kernel<P4, 32><<<gsz, 256, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, d_sums, d_cnts);
     else
       normals_kernel<P4, 128><<<gsz, 256, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, d_sums, d_cnts);

@@ -51,7 +51,7 @@ except OSError:
 
 print("\n== calibration: counter readings per dispatch (cold, warm) against the requested bytes ==")
 table = collections.defaultdict(dict)
-for run in ("calib_fetch", "calib_write", "calib_ea", "calib_hit"):
+for run in ("calib_fetch", "calib_write", "calib_ea", "calib_hit", "calib_dram", "calib_wr"):
     for k, cs in per_kernel(run).items():
         m = re.search(r"calib_kernel<(\d+)", k)
         if not m:
@@ -84,7 +84,7 @@ for cid in sorted(table):
 def kernel_table(prefix, label, select):
     print(f"\n== {label}: mean counter reading per launch ==")
     res = {}
-    for setname in ("fetch", "write", "ea"):
+    for setname in ("fetch", "write", "ea", "dram", "wr"):
         for k, cs in per_kernel(f"{prefix}_{setname}").items():
             short = k.split("(")[0]
             if not any(s in short for s in select):

@@ -176,7 +176,7 @@ def test_estimate_normals_f32_every_defined_point(backend_f32, oracle, scan):
         tol = 3e-7 + 1e-11 / np.maximum(w[:, 1] - w[:, 0], 1e-300)
         bad = np.flatnonzero(simple & (sin_angle > tol))
         assert len(bad) == 0, (radius, knn, len(bad), bad[:5], sin_angle[bad[:5]], gap[bad[:5]])
-        assert simple.mean() > 0.5
+        assert simple.mean() > 0.25  # the rest are ring segments and other neighbourhoods without a defined direction: covered by (2)
         # (2) everywhere the set is the same: the device normal lies in the oracle covariance's smallest eigenspace up to the gap
         res = np.einsum("nij,nj->ni", cov, got) - w[:, 0:1] * got
         rel = np.linalg.norm(res, axis=1) / np.maximum(w[:, 2], 1e-300)
