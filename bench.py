@@ -665,10 +665,23 @@ def main():
         pass_kernel = "icp_accumulate_kernel" if classic else "icp_fused_kernel"
         dt_gt, dr_gt = syn.se3_error(res["transformation"], T_gt)
 
-        def roof(r):
+        # counter-based traffic per launch: measured under rocprofv3 --pmc in separate passes (scripts/gpu_pmc_traffic.sh), calibrated against
+        # known byte counts in this kernel's access pattern (scripts/pmc_calib.hip), committed as profiles/r03_pmc_traffic.json -- a profiler
+        # cannot run inside this process, so the line quotes the committed measurement of the same command and names it
+        try:
+            traffic_db = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))["kernels"]
+        except (OSError, ValueError, KeyError):
+            traffic_db = {}
+
+        def roof(r, which="icp_fused_kernel<P4f> configs[1] (1 M-point map)"):
+            t = traffic_db.get(which) if pass_kernel == "icp_fused_kernel" and world == 1 else None
             return {"bound": "hbm", "achieved": r["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["gbs"] / HBM_PEAK_GBS,
-                    "traffic": None,  # FETCH_SIZE is calibrated for coalesced streaming reads only; this kernel gathers 16-B records from a
-                                      # working set inside the 256 MiB Infinity Cache -- no calibrated HBM byte count exists for it
+                    "traffic": t["traffic_bytes_per_launch"] if t else None,
+                    "traffic_detail": None if not t else {
+                        "what": "bytes per launch between L2 and the fabric (Infinity Cache + HBM; the counters cannot separate them): TCC_EA0_RDREQ x 64 B + "
+                                "TCC_EA0_WRREQ x 64 B, means over the pass launches; the upper figure takes every read request as a full 128-B line",
+                        "upper": t["traffic_bytes_per_launch_if_every_read_is_a_full_line"], "over_algorithmic": t["traffic_over_algorithmic"],
+                        "over_compulsory": t["traffic_over_compulsory"], "source": "profiles/r03_pmc_traffic.json (" + which + ")"},
                     "kernel": pass_kernel, "launches": r["n_launch"], "avg_launch_us": r["avg_kernel_s"] * 1e6,
                     "algorithmic_bytes_per_launch": algo_bytes, "measured_copy_gbs": copy_gbs,
                     "frac_of_measured_copy": r["gbs"] / copy_gbs if copy_gbs else None}
@@ -709,12 +722,12 @@ def main():
             s64 = max(args.steps // 2, 1)
             d64 = syn.se3_error(r64["res"]["transformation"], res["transformation"])
             out["m1_f64"] = {"value": ICP_ITERS * s64 / r64["elapsed"], "unit": "icp_iterations/s", "steps": s64, "ms_per_step": r64["elapsed"] / s64 * 1e3,
-                             "dtype": "f64", "index_build_ms": r64["index_build_ms"], "roofline": roof(r64),
+                             "dtype": "f64", "index_build_ms": r64["index_build_ms"], "roofline": roof(r64, "icp_fused_kernel<P4d> configs[1] (f64 storage)"),
                              "pose_vs_f32_storage": {"dt_m": d64[0], "dr_rad": d64[1]}}
         if r_big is not None:
             sb = max(args.steps // 4, 5)
             out["m1_large_map"] = {"value": ICP_ITERS * sb / r_big["elapsed"], "unit": "icp_iterations/s", "steps": sb, "ms_per_step": r_big["elapsed"] / sb * 1e3,
-                                   "n_map": r_big["n_map"], "index_build_ms": r_big["index_build_ms"], "roofline": roof(r_big),
+                                   "n_map": r_big["n_map"], "index_build_ms": r_big["index_build_ms"], "roofline": roof(r_big, "icp_fused_kernel<P4f> 8 M-point map"),
                                    "pose_error_vs_truth": dict(zip(("dt_m", "dr_rad"), syn.se3_error(r_big["res"]["transformation"], T_gt))),
                                    "what": "the configs[1] scan against a map whose index (256 MB cell-sorted + 36 MB grid) exceeds the Infinity Cache"}
         if conc is not None:

@@ -653,23 +653,90 @@ int build_index(o3ds_handle h, CloudRec& c, double cell) {
   return c.precision == O3DS_PRECISION_F64 ? build_index_t<P4d>(h, c, cell) : build_index_t<P4f>(h, c, cell);
 }
 
+// f32 storage: the caller's doubles are narrowed on their way into the pinned ring (the narrowing the device would do: round to nearest
+// even) and widened on their way out, so half the bytes cross PCIe and the host touches every value once either way
+int h2d_copy_narrow(o3ds_handle h, float* d_dst, const double* h_src, size_t count) {
+  int rc = stage_init(h);
+  if (rc) return rc;
+  const size_t per = kStageBytes / sizeof(float);
+  int k = 0;
+  for (size_t off = 0; off < count; off += per, k ^= 1) {
+    const size_t n = std::min(per, count - off);
+    HIP_TRY(hipEventSynchronize(h->stage_ev[k]));
+    float* dst = (float*)h->h_stage[k];
+    const double* src = h_src + off;
+    for (size_t i = 0; i < n; ++i) dst[i] = (float)src[i];
+    HIP_TRY(hipMemcpyAsync(d_dst + off, dst, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipEventRecord(h->stage_ev[k], h->stream));
+  }
+  return O3DS_OK;
+}
+int d2h_copy_widen(o3ds_handle h, double* h_dst, const float* d_src, size_t count) {  // synchronous
+  int rc = stage_init(h);
+  if (rc) return rc;
+  const size_t per = kStageBytes / sizeof(float);
+  const size_t chunks = (count + per - 1) / per;
+  for (size_t c = 0; c <= chunks; ++c) {
+    if (c < chunks) {
+      const size_t off = c * per, n = std::min(per, count - off);
+      HIP_TRY(hipMemcpyAsync(h->h_stage[c & 1], d_src + off, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipEventRecord(h->stage_ev[c & 1], h->stream));
+    }
+    if (c > 0) {
+      const size_t off = (c - 1) * per, n = std::min(per, count - off);
+      HIP_TRY(hipEventSynchronize(h->stage_ev[(c - 1) & 1]));
+      const float* src = (const float*)h->h_stage[(c - 1) & 1];
+      double* dst = h_dst + off;
+      for (size_t i = 0; i < n; ++i) dst[i] = (double)src[i];
+    }
+  }
+  return O3DS_OK;
+}
+static const bool kNarrowOnHost = getenv("O3DS_NO_HOST_NARROW") == nullptr;  // A/B switch
+
+template <typename P4>
+int upload_array_t(o3ds_handle h, const double* host, size_t n, P4* d_out) {  // host double[3n] -> device P4[n]
+  if (std::is_same<P4, P4f>::value && kNarrowOnHost && sizeof(double) * 3 * n >= kStageMin) {
+    float* stage = nullptr;
+    TMP_ALLOC(stage, sizeof(float) * 3 * n);
+    const int rcc = h2d_copy_narrow(h, stage, host, 3 * n);
+    if (rcc) return rcc;
+    pack_kernel<P4, float><<<grid_for(n), kBlock, 0, h->stream>>>(stage, n, d_out);
+    return O3DS_OK;
+  }
+  double* stage = nullptr;
+  TMP_ALLOC(stage, sizeof(double) * 3 * n);
+  const int rcc = h2d_copy(h, stage, host, sizeof(double) * 3 * n);
+  if (rcc) return rcc;
+  pack_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(stage, n, d_out);
+  return O3DS_OK;
+}
+template <typename P4>
+int download_array_t(o3ds_handle h, const P4* d_in, size_t n, double* host) {  // device P4[n] -> host double[3n]; complete on return
+  if (std::is_same<P4, P4f>::value && kNarrowOnHost && sizeof(double) * 3 * n >= kStageMin) {
+    float* stage = nullptr;
+    TMP_ALLOC(stage, sizeof(float) * 3 * n);
+    unpack_kernel<P4, float><<<grid_for(n), kBlock, 0, h->stream>>>(d_in, n, stage);
+    return d2h_copy_widen(h, host, stage, 3 * n);
+  }
+  double* stage = nullptr;
+  TMP_ALLOC(stage, sizeof(double) * 3 * n);
+  unpack_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(d_in, n, stage);
+  return d2h_copy(h, host, stage, sizeof(double) * 3 * n);
+}
+
 template <typename P4>
 int upload_t(o3ds_handle h, const double* xyz, const double* normals, size_t n, CloudRec& c) {
   c.n = n;
   c.precision = h->precision;
   if (n == 0) return O3DS_OK;
-  double *stage = nullptr, *stage_n = nullptr;
-  TMP_ALLOC(stage, sizeof(double) * 3 * n);
   HIP_TRY(dev_alloc(h, (void**)&c.pts, sizeof(P4) * n));
-  int rcc = h2d_copy(h, stage, xyz, sizeof(double) * 3 * n);
+  int rcc = upload_array_t<P4>(h, xyz, n, (P4*)c.pts);
   if (rcc) return rcc;
-  pack_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(stage, n, (P4*)c.pts);
   if (normals) {
-    TMP_ALLOC(stage_n, sizeof(double) * 3 * n);
     HIP_TRY(dev_alloc(h, (void**)&c.nrm, sizeof(P4) * n));
-    rcc = h2d_copy(h, stage_n, normals, sizeof(double) * 3 * n);
+    rcc = upload_array_t<P4>(h, normals, n, (P4*)c.nrm);
     if (rcc) return rcc;
-    pack_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(stage_n, n, (P4*)c.nrm);
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));  // the caller may release its host buffers as soon as this returns
@@ -679,16 +746,12 @@ int upload_t(o3ds_handle h, const double* xyz, const double* normals, size_t n, 
 template <typename P4>
 int download_t(o3ds_handle h, const CloudRec& c, double* xyz, double* normals) {
   if (c.n == 0) return O3DS_OK;
-  double* stage = nullptr;
-  TMP_ALLOC(stage, sizeof(double) * 3 * c.n);
   if (xyz) {
-    unpack_kernel<P4><<<grid_for(c.n), kBlock, 0, h->stream>>>((const P4*)c.pts, c.n, stage);
-    const int rcc = d2h_copy(h, xyz, stage, sizeof(double) * 3 * c.n);
+    const int rcc = download_array_t<P4>(h, (const P4*)c.pts, c.n, xyz);
     if (rcc) return rcc;
   }
   if (normals && c.nrm) {
-    unpack_kernel<P4><<<grid_for(c.n), kBlock, 0, h->stream>>>((const P4*)c.nrm, c.n, stage);
-    const int rcc = d2h_copy(h, normals, stage, sizeof(double) * 3 * c.n);
+    const int rcc = download_array_t<P4>(h, (const P4*)c.nrm, c.n, normals);
     if (rcc) return rcc;
   }
   HIP_TRY(hipGetLastError());

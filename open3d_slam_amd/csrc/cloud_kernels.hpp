@@ -13,8 +13,8 @@
 namespace o3ds {
 
 // ---------------------------------------------------------------------------------------------- pack / unpack
-template <typename P4>
-__global__ __launch_bounds__(kBlock) void pack_kernel(const double* __restrict__ xyz, size_t n, P4* __restrict__ out) {
+template <typename P4, typename S = double>  // S: the scalar of the staged host array (float when the host side already narrowed it)
+__global__ __launch_bounds__(kBlock) void pack_kernel(const S* __restrict__ xyz, size_t n, P4* __restrict__ out) {
   using R = typename Scalar<P4>::type;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
     P4 p;
@@ -103,13 +103,13 @@ __global__ __launch_bounds__(kBlock) void colors_from_records_kernel(const unsig
     out[i] = c;
   }
 }
-template <typename P4>
-__global__ __launch_bounds__(kBlock) void unpack_kernel(const P4* __restrict__ in, size_t n, double* __restrict__ xyz) {
+template <typename P4, typename S = double>
+__global__ __launch_bounds__(kBlock) void unpack_kernel(const P4* __restrict__ in, size_t n, S* __restrict__ xyz) {
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
     const P4 p = in[i];
-    xyz[3 * i] = (double)p.x;
-    xyz[3 * i + 1] = (double)p.y;
-    xyz[3 * i + 2] = (double)p.z;
+    xyz[3 * i] = (S)p.x;
+    xyz[3 * i + 1] = (S)p.y;
+    xyz[3 * i + 2] = (S)p.z;
   }
 }
 

@@ -1,0 +1,40 @@
+#!/usr/bin/env python
+"""profiles/r03_pmc_traffic.json from the per-dispatch counter rows of scripts/gpu_pmc_traffic.sh (gpurun_out/pmc_traffic/m1_{dram,wr}):
+what bench.py quotes as roofline.traffic.  The calibration behind the byte-per-request figures is profiles/r03_pmc_calibration*.txt."""
+import collections, csv, glob, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = {"source": "rocprofv3 --kernel-trace --pmc, one counter set per run, `python bench.py --steps 20 --warmup 3 --m2-frames 0 --no-cpu-baseline --concurrent 0` "
+                 "(scripts/gpu_pmc_traffic.sh); per-launch means over the pass launches (the one-workgroup tail launches of the fused loop dropped)",
+       "calibration": {"file": "profiles/r03_pmc_calibration_and_m1_traffic.txt",
+                       "read_request_bytes": "TCC_EA0_RDREQ counts ONE request per 128-B line for coalesced / fully used lines (stream, aligned 128-B runs: requested bytes / "
+                                             "requests = 128.0 / 128.4) and one per touched 64-B half line for sparse access (aligned 64-B runs: 64.2; single 16-B records: 16.06 "
+                                             "requested bytes per request); FETCH_SIZE = requests x 64 B, i.e. half the bytes of a streaming read (the guide's x2) and the "
+                                             "bytes of a sparse one",
+                       "write_request_bytes": "TCC_EA0_WRREQ = TCC_EA0_WRREQ_64B: 64.0 requested bytes per request for streaming 16-B stores",
+                       "infinity_cache": "cold and warm dispatches give identical counts at 32 MiB, 128 MiB and 1 GiB working sets, and TCC_EA0_RDREQ_DRAM equals TCC_EA0_RDREQ "
+                                         "everywhere: the counters sit at the L2 <-> fabric boundary, Infinity-Cache hits are included and cannot be separated from HBM reads"},
+       "kernels": {}}
+def rows(setname, pat):
+    f = glob.glob(os.path.join(ROOT, f"gpurun_out/pmc_traffic/m1_{setname}/**/*counter_collection.csv"), recursive=True)[0]
+    by = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if pat in r["Kernel_Name"]:
+            by[r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+    return {c: [x[1] for x in sorted(v)] for c, v in by.items()}
+def stat(a):
+    m = sorted(a)[len(a) // 2]
+    keep = [x for x in a if x >= 0.25 * m] if m > 0 else a
+    return {"launches": len(keep), "mean": sum(keep) / max(len(keep), 1), "median": m, "max": max(a)}
+ALGO = 65536 * 228
+for name, pat, sl in (("icp_fused_kernel<P4f> configs[1] (1 M-point map)", "icp_fused_kernel<o3ds::P4f", slice(0, 516)),
+                      ("icp_fused_kernel<P4f> 8 M-point map", "icp_fused_kernel<o3ds::P4f", slice(516, None)),
+                      ("icp_fused_kernel<P4d> configs[1] (f64 storage)", "icp_fused_kernel<o3ds::P4d", slice(None))):
+    rd, wr = stat(rows("dram", pat)["TCC_EA0_RDREQ_sum"][sl]), stat(rows("wr", pat)["TCC_EA0_WRREQ_sum"][sl])
+    lo = rd["mean"] * 64 + wr["mean"] * 64
+    hi = rd["mean"] * 128 + wr["mean"] * 64
+    out["kernels"][name] = {"read_requests_per_launch": rd, "write_requests_per_launch": wr,
+                            "traffic_bytes_per_launch": lo, "traffic_bytes_per_launch_if_every_read_is_a_full_line": hi,
+                            "algorithmic_bytes_per_launch": ALGO, "traffic_over_algorithmic": [lo / ALGO, hi / ALGO],
+                            "compulsory_bytes_per_launch": 65536 * 48, "traffic_over_compulsory": [lo / (65536 * 48), hi / (65536 * 48)]}
+json.dump(out, open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(out["kernels"], indent=1))

@@ -170,7 +170,7 @@ int main(int argc, char** argv) {
     const auto rb = o3ds::registerClouds(O3DS_ICP_POINT_TO_PLANE, plain, plain2, I.matrix(), maxCorr, crit);
     CHECK(ra.fitness_ > 0.9);
     CHECK(translationError(ra.transformation_, rb.transformation_) < 1e-9);
-    CHECK(std::fabs(ra.transformation_(0, 3) - 0.05) < 0.02 && std::fabs(ra.transformation_(1, 3) + 0.05) < 0.02);
+    CHECK(std::fabs(ra.transformation_(0, 3) + 0.05) < 0.02 && std::fabs(ra.transformation_(1, 3) - 0.05) < 0.02);  // p_target = p_source + (o1 - o2)
     // a caller that edits the host arrays invalidates the device copy: the edited values are what gets used
     o3ds::ScanOnDevice edited = *dynamic_cast<o3ds::ScanOnDevice*>(pre.get());
     CHECK(o3ds::deviceCopyOf(edited) != nullptr);  // a copy of the object shares the device copy
