@@ -19,7 +19,7 @@
 #include "cloud_kernels.hpp"
 #include "common.hpp"
 #include "icp_kernels.hpp"
-#include "normals_select_kernel.hpp"
+#include "normals_kernel.hpp"
 
 using namespace o3ds;
 
@@ -2169,15 +2169,28 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
       merge_split_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(k0, rank, n, np, nv, k1, v1, vk, vv, xk, xv);
       const unsigned long long* xks = xk;
       const uint32_t* xvs = xv;
-      if (nx > 1) {  // the only sort: the points that are new to the volume
+      if (nx > 1) {  // the only sort: the points that are new to the volume -- tile sort in LDS, then merge passes (cloud_kernels.hpp)
         TMP_ALLOC(xk2, sizeof(unsigned long long) * nx);
         TMP_ALLOC(xv2, sizeof(uint32_t) * nx);
-        size_t tb = 0;
-        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, xk, xk2, xv, xv2, nx, 0, 63, h->stream));
-        void* tmp = nullptr;
-        TMP_ALLOC(tmp, tb ? tb : 16);
-        HIP_TRY(rocprim::radix_sort_pairs(tmp, tb, xk, xk2, xv, xv2, nx, 0, 63, h->stream));
-        xks = xk2, xvs = xv2;
+        static const bool lib_sort = getenv("O3DS_MERGE_LIBRARY_SORT") != nullptr;  // A/B: rocPRIM's radix sort of the same pairs
+        if (lib_sort) {
+          size_t tb = 0;
+          HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, xk, xk2, xv, xv2, nx, 0, 63, h->stream));
+          void* tmp = nullptr;
+          TMP_ALLOC(tmp, tb ? tb : 16);
+          HIP_TRY(rocprim::radix_sort_pairs(tmp, tb, xk, xk2, xv, xv2, nx, 0, 63, h->stream));
+          xks = xk2, xvs = xv2;
+        } else {
+          unsigned long long *ka = xk2, *kb = xk;  // the tile sort reads xk / xv and writes the second pair of buffers; passes ping-pong
+          uint32_t *va = xv2, *vb = xv;
+          sort_tile_kernel<<<(unsigned int)((nx + kSortTile - 1) / kSortTile), kBlock, 0, h->stream>>>(xk, xv, nx, ka, va);
+          for (size_t width = kSortTile; width < nx; width <<= 1) {
+            sort_merge_pass_kernel<<<grid_for(nx), kBlock, 0, h->stream>>>(ka, va, nx, width, kb, vb);
+            std::swap(ka, kb);
+            std::swap(va, vb);
+          }
+          xks = ka, xvs = va;
+        }
       }
       int *xpos = nullptr, *cnt = nullptr, *before = nullptr;
       TMP_ALLOC(xpos, sizeof(int) * (nx + 1));
@@ -2342,18 +2355,7 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn, bool knn_ra
     TMP_ALLOC(d_sums, sizeof(double) * 9 * c.n);
     TMP_ALLOC(d_cnts, sizeof(int) * c.n);
     span_mark(h, kSpanNormalsKernels);
-    // f32 storage: the selection kernel (normals_select_kernel.hpp) -- same neighbour sets, no sorted list, exact order-independent sums.
-    // O3DS_NRM_SELECT=0 keeps the ranking kernel (A/B, and the reference for tests/test_edge_parity_gpu.py's set comparison).
-    const bool nrm_select = !(getenv("O3DS_NRM_SELECT") && atoi(getenv("O3DS_NRM_SELECT")) == 0);  // read per call: A/B inside one process
-    bool launched = false;
-    if constexpr (std::is_same<P4, P4f>::value) {
-      if (nrm_select && !knn_raw && max_nn <= o3ds::kSelMaxNN && radius < 1e6) {
-        normals_select_kernel<<<gsz, 64, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, d_sums, d_cnts);
-        launched = true;
-      }
-    }
-    if (launched) {
-    } else if (max_nn <= 32)  // the shipped configs' knn is 20
+    if (max_nn <= 32)  // the shipped configs' knn is 20
       normals_kernel<P4, 32><<<gsz, 256, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, d_sums, d_cnts);
     else
       normals_kernel<P4, 128><<<gsz, 256, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, d_sums, d_cnts);

@@ -349,6 +349,75 @@ __global__ __launch_bounds__(kBlock) void merge_place_kernel(const unsigned long
   }
 }
 
+// ---- sort of the (key, index) pairs that are NEW to the volume in a map merge (tens of thousands per inserted scan): hand-written, two
+// kernels.  The pairs are unique, so ordering by (key, index) is the stable order by key of a list whose indices ascend.
+//   sort_tile_kernel        one workgroup per tile of 2048 pairs: bitonic network in LDS
+//   sort_merge_pass_kernel  runs of `width` pairs -> runs of 2 width: every pair finds its rank in the partner run by binary search
+//                           (the runs sit in L2) and writes itself to its final place of the pass; log2(n / 2048) passes
+constexpr int kSortTile = 2048;
+__device__ __forceinline__ bool kv_less(unsigned long long ka, uint32_t va, unsigned long long kb, uint32_t vb) {
+  return ka < kb || (ka == kb && va < vb);
+}
+__global__ __launch_bounds__(kBlock) void sort_tile_kernel(const unsigned long long* __restrict__ kin, const uint32_t* __restrict__ vin, size_t n,
+                                                           unsigned long long* __restrict__ kout, uint32_t* __restrict__ vout) {
+  __shared__ unsigned long long sk[kSortTile];
+  __shared__ uint32_t sv[kSortTile];
+  const size_t base = (size_t)blockIdx.x * kSortTile;
+  for (int i = threadIdx.x; i < kSortTile; i += kBlock) {
+    const size_t gi = base + i;
+    sk[i] = gi < n ? kin[gi] : ~0ull;  // padding sorts behind every real pair
+    sv[i] = gi < n ? vin[gi] : 0xffffffffu;
+  }
+  __syncthreads();
+  for (int size = 2; size <= kSortTile; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < kSortTile / 2; t += kBlock) {
+        const int lo = 2 * t - (t & (stride - 1));  // (t / stride) * 2 stride + t % stride
+        const int hi = lo + stride;
+        const bool ascending = (lo & size) == 0;
+        const unsigned long long ka = sk[lo], kb = sk[hi];
+        const uint32_t va = sv[lo], vb = sv[hi];
+        if (kv_less(kb, vb, ka, va) == ascending) {
+          sk[lo] = kb, sv[lo] = vb;
+          sk[hi] = ka, sv[hi] = va;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < kSortTile; i += kBlock) {
+    const size_t gi = base + i;
+    if (gi < n) {
+      kout[gi] = sk[i];
+      vout[gi] = sv[i];
+    }
+  }
+}
+__global__ __launch_bounds__(kBlock) void sort_merge_pass_kernel(const unsigned long long* __restrict__ kin, const uint32_t* __restrict__ vin, size_t n,
+                                                                 size_t width, unsigned long long* __restrict__ kout, uint32_t* __restrict__ vout) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const size_t run = i / width, start = run * width, partner = (run ^ 1) * width;
+    const unsigned long long k = kin[i];
+    const uint32_t v = vin[i];
+    if (partner >= n) {  // the last run of an odd count has nobody to merge with
+      kout[i] = k;
+      vout[i] = v;
+      continue;
+    }
+    size_t lo = partner, hi = partner + width < n ? partner + width : n;
+    while (lo < hi) {  // pairs of the partner run in front of this one (no two pairs are equal)
+      const size_t mid = (lo + hi) >> 1;
+      if (kv_less(kin[mid], vin[mid], k, v))
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    const size_t o = (start < partner ? start : partner) + (i - start) + (lo - partner);
+    kout[o] = k;
+    vout[o] = v;
+  }
+}
+
 // after sorting (key, val): head[i] = 1 where a new segment starts
 __global__ __launch_bounds__(kBlock) void segment_head_kernel(const unsigned long long* __restrict__ keys, size_t n, int* __restrict__ head) {
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)

@@ -18,7 +18,7 @@ for name in ${SETS:-dram wr}; do
   ( cd $R && timeout 300 rocprofv3 --kernel-trace --pmc ${SET[$name]} --output-format csv -d $OUT/m1_$name -o pmc -- python bench.py --steps 20 --warmup 3 --m2-frames 0 --no-cpu-baseline --concurrent 0 > $OUT/m1_$name.log 2>&1 ); echo "m1 $name rc=$?"
 done
 for name in ${STREAM_SETS:-dram}; do
-  ( cd $R && timeout 240 rocprofv3 --kernel-trace --pmc ${SET[$name]} --output-format csv -d $OUT/stream_$name -o pmc -- python scripts/bench_stream.py --frames 5 > $OUT/stream_$name.log 2>&1 ); echo "stream $name rc=$?"
+  ( cd $R && timeout 240 rocprofv3 --kernel-trace --pmc ${SET[$name]} --output-format csv -d $OUT/stream_$name -o pmc -- python scripts/stream_few_frames.py 3 > $OUT/stream_$name.log 2>&1 ); echo "stream $name rc=$?"
 done
 ( cd $R && python scripts/pmc_traffic_summary.py $OUT --json > $R/gpurun_out/pmc_traffic.txt 2>&1 ); echo "summary rc=$?"
 find $OUT -name "*.csv" -size +8M -delete
