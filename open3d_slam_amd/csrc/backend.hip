@@ -2184,8 +2184,17 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
           unsigned long long *ka = xk2, *kb = xk;  // the tile sort reads xk / xv and writes the second pair of buffers; passes ping-pong
           uint32_t *va = xv2, *vb = xv;
           sort_tile_kernel<<<(unsigned int)((nx + kSortTile - 1) / kSortTile), kBlock, 0, h->stream>>>(xk, xv, nx, ka, va);
-          for (size_t width = kSortTile; width < nx; width <<= 1) {
-            sort_merge_pass_kernel<<<grid_for(nx), kBlock, 0, h->stream>>>(ka, va, nx, width, kb, vb);
+          static const int ways = getenv("O3DS_SORT_WAYS") ? atoi(getenv("O3DS_SORT_WAYS")) : kSortWays;  // tuning experiments: 2, 4, 8, 16
+          for (size_t width = kSortTile; width < nx; width *= (size_t)ways) {  // nx < 2^31 on this path
+            const unsigned int gsz = (unsigned int)grid_for(nx);
+            if (ways == 2)
+              sort_merge_pass_kernel<2><<<gsz, kBlock, 0, h->stream>>>(ka, va, (uint32_t)nx, (uint32_t)width, kb, vb);
+            else if (ways == 4)
+              sort_merge_pass_kernel<4><<<gsz, kBlock, 0, h->stream>>>(ka, va, (uint32_t)nx, (uint32_t)width, kb, vb);
+            else if (ways == 16)
+              sort_merge_pass_kernel<16><<<gsz, kBlock, 0, h->stream>>>(ka, va, (uint32_t)nx, (uint32_t)width, kb, vb);
+            else
+              sort_merge_pass_kernel<8><<<gsz, kBlock, 0, h->stream>>>(ka, va, (uint32_t)nx, (uint32_t)width, kb, vb);
             std::swap(ka, kb);
             std::swap(va, vb);
           }

@@ -351,10 +351,17 @@ __global__ __launch_bounds__(kBlock) void merge_place_kernel(const unsigned long
 
 // ---- sort of the (key, index) pairs that are NEW to the volume in a map merge (tens of thousands per inserted scan): hand-written, two
 // kernels.  The pairs are unique, so ordering by (key, index) is the stable order by key of a list whose indices ascend.
-//   sort_tile_kernel        one workgroup per tile of 2048 pairs: bitonic network in LDS
-//   sort_merge_pass_kernel  runs of `width` pairs -> runs of 2 width: every pair finds its rank in the partner run by binary search
-//                           (the runs sit in L2) and writes itself to its final place of the pass; log2(n / 2048) passes
-constexpr int kSortTile = 2048;
+//   sort_tile_kernel        one workgroup per tile of 256 pairs: every pair counts the smaller pairs of its tile (broadcast LDS reads) and
+//                           writes itself to that place -- 256 compares per thread, no network, no barrier after the load
+//   sort_merge_pass_kernel  4 runs of `width` pairs -> one run: every pair finds its rank in the three other runs by binary search (the
+//                           runs sit in L2) and writes itself to its final place of the pass; four passes for up to 65 536 pairs
+// Measured on the stream (60 k pairs per call, rocprofv3): tile sort 9.0 us; a pass 6.2 us 2-way (8 passes), 8.2 us 4-way (4), 11.6 us 8-way
+// (3), 32 us 16-way (2: 154 VGPRs) -- 42 us per call 4-way, against 50 us for rocPRIM's radix sort of the same pairs (six merge-sort launches
+// and a 16 us block sort).  A first version sorted tiles of 2048 with a bitonic network in LDS: 66 barrier-separated stages on 30 workgroups
+// took 52 us per call by themselves (profiles/r03_rocprof_kernel_stats_stream_bitonic_tiles.txt).
+constexpr int kSortTile = 256;
+constexpr int kSortWays = 4;
+static_assert(kSortTile == kBlock, "one pair per thread in the tile sort");
 __device__ __forceinline__ bool kv_less(unsigned long long ka, uint32_t va, unsigned long long kb, uint32_t vb) {
   return ka < kb || (ka == kb && va < vb);
 }
@@ -362,57 +369,67 @@ __global__ __launch_bounds__(kBlock) void sort_tile_kernel(const unsigned long l
                                                            unsigned long long* __restrict__ kout, uint32_t* __restrict__ vout) {
   __shared__ unsigned long long sk[kSortTile];
   __shared__ uint32_t sv[kSortTile];
-  const size_t base = (size_t)blockIdx.x * kSortTile;
-  for (int i = threadIdx.x; i < kSortTile; i += kBlock) {
-    const size_t gi = base + i;
-    sk[i] = gi < n ? kin[gi] : ~0ull;  // padding sorts behind every real pair
-    sv[i] = gi < n ? vin[gi] : 0xffffffffu;
-  }
+  const size_t base = (size_t)blockIdx.x * kSortTile, gi = base + threadIdx.x;
+  const unsigned long long k = gi < n ? kin[gi] : ~0ull;  // padding sorts behind every real pair
+  const uint32_t v = gi < n ? vin[gi] : 0xffffffffu;
+  sk[threadIdx.x] = k;
+  sv[threadIdx.x] = v;
   __syncthreads();
-  for (int size = 2; size <= kSortTile; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = threadIdx.x; t < kSortTile / 2; t += kBlock) {
-        const int lo = 2 * t - (t & (stride - 1));  // (t / stride) * 2 stride + t % stride
-        const int hi = lo + stride;
-        const bool ascending = (lo & size) == 0;
-        const unsigned long long ka = sk[lo], kb = sk[hi];
-        const uint32_t va = sv[lo], vb = sv[hi];
-        if (kv_less(kb, vb, ka, va) == ascending) {
-          sk[lo] = kb, sv[lo] = vb;
-          sk[hi] = ka, sv[hi] = va;
-        }
-      }
-      __syncthreads();
-    }
-  }
-  for (int i = threadIdx.x; i < kSortTile; i += kBlock) {
-    const size_t gi = base + i;
-    if (gi < n) {
-      kout[gi] = sk[i];
-      vout[gi] = sv[i];
-    }
+  int rank = 0;
+#pragma unroll 8
+  for (int j = 0; j < kSortTile; ++j) rank += kv_less(sk[j], sv[j], k, v) ? 1 : 0;
+  if (gi < n) {
+    kout[base + rank] = k;
+    vout[base + rank] = v;
   }
 }
-__global__ __launch_bounds__(kBlock) void sort_merge_pass_kernel(const unsigned long long* __restrict__ kin, const uint32_t* __restrict__ vin, size_t n,
-                                                                 size_t width, unsigned long long* __restrict__ kout, uint32_t* __restrict__ vout) {
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
-    const size_t run = i / width, start = run * width, partner = (run ^ 1) * width;
+// kWays runs of `width` pairs -> one run: a pair's place is its offset in its own run plus the number of smaller pairs in each of the other
+// runs of its group -- kWays - 1 binary searches, advanced together so that their loads are in flight at the same time (the depth of the
+// dependent chain is that of ONE search)
+template <int kWays>
+__global__ __launch_bounds__(kBlock) void sort_merge_pass_kernel(const unsigned long long* __restrict__ kin, const uint32_t* __restrict__ vin, uint32_t n,
+                                                                 uint32_t width, unsigned long long* __restrict__ kout, uint32_t* __restrict__ vout) {
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const uint32_t run = i / width, start = run * width, gstart = (run / kWays) * kWays * width;
     const unsigned long long k = kin[i];
     const uint32_t v = vin[i];
-    if (partner >= n) {  // the last run of an odd count has nobody to merge with
-      kout[i] = k;
-      vout[i] = v;
-      continue;
+    uint32_t lo[kWays], hi[kWays];
+#pragma unroll
+    for (int r = 0; r < kWays; ++r) {
+      const unsigned long long rs = (unsigned long long)gstart + (unsigned long long)r * width;
+      lo[r] = rs < n ? (uint32_t)rs : n;
+      hi[r] = rs + width < n ? (uint32_t)(rs + width) : n;
+      if (rs == start) hi[r] = lo[r];  // the pair's own run: nothing to search
     }
-    size_t lo = partner, hi = partner + width < n ? partner + width : n;
-    while (lo < hi) {  // pairs of the partner run in front of this one (no two pairs are equal)
-      const size_t mid = (lo + hi) >> 1;
-      if (kv_less(kin[mid], vin[mid], k, v))
-        lo = mid + 1;
-      else
-        hi = mid;
+    for (;;) {
+      bool any = false;
+      unsigned long long km[kWays];
+      uint32_t vm[kWays], mid[kWays];
+#pragma unroll
+      for (int r = 0; r < kWays; ++r) {
+        mid[r] = lo[r] + ((hi[r] - lo[r]) >> 1);
+        if (lo[r] < hi[r]) {
+          km[r] = kin[mid[r]];
+          vm[r] = vin[mid[r]];
+          any = true;
+        }
+      }
+      if (!any) break;
+#pragma unroll
+      for (int r = 0; r < kWays; ++r)
+        if (lo[r] < hi[r]) {
+          if (kv_less(km[r], vm[r], k, v))
+            lo[r] = mid[r] + 1;
+          else
+            hi[r] = mid[r];
+        }
     }
-    const size_t o = (start < partner ? start : partner) + (i - start) + (lo - partner);
+    uint32_t o = gstart + (i - start);
+#pragma unroll
+    for (int r = 0; r < kWays; ++r) {
+      const unsigned long long rs = (unsigned long long)gstart + (unsigned long long)r * width;
+      if (rs != start && rs < n) o += lo[r] - (uint32_t)rs;  // pairs of run r in front of this one (no two pairs are equal)
+    }
     kout[o] = k;
     vout[o] = v;
   }

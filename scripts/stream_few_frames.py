@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from open3d_slam_amd import backend
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-scans = bench.make_stream(frames)
+scans = [bench._scan_job(k) for k in range(frames)]  # no worker pool: forked children hang under rocprofv3
 be = backend.Backend(0)
 out = bench.run_stream(be, scans)
 be.close()
