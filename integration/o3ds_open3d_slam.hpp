@@ -99,6 +99,27 @@ inline o3ds_crop makeCrop(const o3d_slam::ScanCroppingParameters& p, const Eigen
   return c;
 }
 
+// every point `inner` keeps is kept by `outer` too (same kind, same centre, neither inverted, radii nested): cropping inner's output with
+// outer returns it unchanged -- crop(crop(x, V1), V2) = crop(x, V1) for V1 inside V2
+inline bool cropContains(const o3ds_crop& outer, const o3ds_crop& inner) {
+  if (outer.kind == O3DS_CROP_NONE && !outer.invert) return true;
+  if (outer.kind != inner.kind || outer.invert || inner.invert) return false;
+  for (int a = 0; a < 3; ++a)
+    if (outer.center[a] != inner.center[a]) return false;
+  switch (outer.kind) {
+    case O3DS_CROP_MAX_RADIUS:
+      return outer.rmax >= inner.rmax;
+    case O3DS_CROP_MIN_RADIUS:
+      return outer.rmin <= inner.rmin;
+    case O3DS_CROP_MIN_MAX_RADIUS:
+      return outer.rmin <= inner.rmin && outer.rmax >= inner.rmax;
+    case O3DS_CROP_CYLINDER:
+      return outer.rmax >= inner.rmax && outer.zmin <= inner.zmin && outer.zmax >= inner.zmax;
+    default:
+      return false;
+  }
+}
+
 inline o3ds_crop noCrop() {  // the base CroppingVolume (croppers.cpp:49-51): everything is inside
   o3ds_crop c{};
   c.kind = O3DS_CROP_NONE;

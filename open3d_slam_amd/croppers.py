@@ -67,6 +67,26 @@ class CroppingVolume:
         """CroppingVolume::crop (croppers.cpp:76-106): stable compaction of points (+normals)."""
         return PointCloud(cloud.be, cloud.be.crop_cloud(cloud.id, self.to_abi()))
 
+    def contains(self, other: "CroppingVolume") -> bool:
+        """True when every point `other` keeps is kept by this volume too (same kind, same centre, neither inverted, radii nested): then
+        cropping `other`'s output with this volume returns it unchanged -- crop(crop(x, V1), V2) = crop(x, V1) for V1 inside V2."""
+        if self._kind == _b.CROP_NONE:
+            return True  # the base volume keeps everything (croppers.cpp:49-51; isInvertVolume_ is ignored for it, as in to_abi / the ABI)
+        if type(self) is not type(other) or self.isInvertVolume_ or other.isInvertVolume_:
+            return False
+        if not np.array_equal(self.pose_[:3, 3], other.pose_[:3, 3]):
+            return False
+        a, b = self._radii(), other._radii()
+        if self._kind == _b.CROP_MAX_RADIUS:
+            return a["rmax"] >= b["rmax"]
+        if self._kind == _b.CROP_MIN_RADIUS:
+            return a["rmin"] <= b["rmin"]
+        if self._kind == _b.CROP_MIN_MAX_RADIUS:
+            return a["rmin"] <= b["rmin"] and a["rmax"] >= b["rmax"]
+        if self._kind == _b.CROP_CYLINDER:
+            return a["rmax"] >= b["rmax"] and a["zmin"] <= b["zmin"] and a["zmax"] >= b["zmax"]
+        return False
+
 
 class MinMaxRadiusCroppingVolume(CroppingVolume):  # croppers.cpp:119-128
     _kind = _b.CROP_MIN_MAX_RADIUS

@@ -78,7 +78,9 @@ class ScanToMapIcp(ScanToMapRegistration):  # ScanToMapRegistration.hpp:40-59
     def processForScanMatchingAndMerging(self, cloud: PointCloud, mapToRangeSensor) -> ProcessedScans:  # .cpp:42-54
         wide = self.preprocess(cloud)
         self.scanMatcherCropper_.setPose(np.eye(4))
-        narrow = self.scanMatcherCropper_.crop(wide)
+        # the scan-matcher volume of the shipped configurations is the map-builder volume (or contains it): cropping what the latter kept
+        # returns it unchanged, so the second cloud is the first (no kernels, no size read-back)
+        narrow = wide if self.scanMatcherCropper_.contains(self.mapBuilderCropper_) else self.scanMatcherCropper_.crop(wide)
         if not len(narrow) > 0:
             raise RuntimeError("ScanToMapIcp::narrow cropped size is zero")  # assert_gt
         if not len(wide) > 0:

@@ -106,7 +106,8 @@ struct Mapping {
   bool add(const PointCloud& raw, const M4& odomNow) {
     const auto t0 = Clock::now();
     auto wide = o3ds::preprocessScan(raw, s.chain());
-    auto narrow = o3ds::cropScan(*wide, o3ds::makeCrop(s.cropper, Eigen::Isometry3d::Identity()));
+    const o3ds_crop narrowCrop = o3ds::makeCrop(s.cropper, Eigen::Isometry3d::Identity()), wideCrop = s.chain().crop;  // scan-matcher / map-builder volume
+    auto narrow = o3ds::cropContains(narrowCrop, wideCrop) ? wide : o3ds::cropScan(*wide, narrowCrop);  // as the patched processForScanMatchingAndMerging
     if (narrow->points_.empty() || wide->points_.empty()) return false;
     const auto t1 = Clock::now();
     tPre += ms(t0, t1);

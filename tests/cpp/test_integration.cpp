@@ -162,6 +162,8 @@ int main(int argc, char** argv) {
     CHECK(n1c->points_.size() == n2c->points_.size() && n1c->points_.size() > 100 && n1c->points_.size() < pre->points_.size());
     for (size_t i = 0; i < n1c->points_.size(); ++i)
       for (int a = 0; a < 3; ++a) CHECK(n1c->points_[i][a] == n2c->points_[i][a] && n1c->normals_[i][a] == n2c->normals_[i][a]);
+    CHECK(o3ds::cropContains(everything, narrowCrop) && !o3ds::cropContains(narrowCrop, everything) && o3ds::cropContains(narrowCrop, narrowCrop));
+    CHECK(o3ds::cropContains(o3ds::noCrop(), everything) && !o3ds::cropContains(everything, o3ds::noCrop()));
     // registration of resident clouds == registration of their host copies (LidarOdometry::addRangeScan as patched)
     PointCloud raw2 = cornerScan(60000, 8, 3.05, 2.95, 1.52);
     std::shared_ptr<PointCloud> pre2 = o3ds::preprocessScan(raw2, chain);

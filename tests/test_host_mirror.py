@@ -192,3 +192,39 @@ def test_pcd_writer_header_and_round_trip(tmp_path):
     assert q is None and (tmp_path / "b.pcd").stat().st_size == len(output._pcd_header(37, False)) + 37 * 12
     np.testing.assert_array_equal(p, pts.astype(np.float32))
     assert not output.saveToFile(str(tmp_path / "no_such_dir" / "c"), _Cloud(_Be(None)))  # false, not an exception (WritePointCloudToPCD)
+
+
+def test_cropper_containment_is_what_makes_the_narrow_crop_a_no_op(oracle):
+    """crop(crop(x, V1), V2) = crop(x, V1) when V2 contains V1: ScanToMapIcp::processForScanMatchingAndMerging then hands out ONE cloud
+    (ScanToMapRegistration.cpp:46-48; the shipped configurations use the same volume twice).  `contains` must only say yes when that holds
+    -- checked on random points against the oracle's croppers, both directions."""
+    import numpy as np
+
+    from open3d_slam_amd import croppers as C
+
+    rng = np.random.default_rng(4)
+    pts = rng.uniform(-40, 40, size=(20000, 3))
+    vols = [C.MaxRadiusCroppingVolume(20.0), C.MaxRadiusCroppingVolume(30.0), C.MinRadiusCroppingVolume(2.0), C.MinRadiusCroppingVolume(5.0),
+            C.MinMaxRadiusCroppingVolume(2.0, 30.0), C.MinMaxRadiusCroppingVolume(3.0, 25.0), C.CylinderCroppingVolume(15.0, -1.0, 3.0),
+            C.CylinderCroppingVolume(20.0, -2.0, 3.0), C.CroppingVolume()]
+    shifted = C.MaxRadiusCroppingVolume(30.0)
+    shifted.setPose(np.array([[1, 0, 0, 0.5], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1.0]]))
+    inverted = C.MaxRadiusCroppingVolume(30.0)
+    inverted.setIsInvertVolume(True)
+    vols += [shifted, inverted]
+
+    def keep(v):
+        a = v.to_abi()
+        return set(oracle.crop_indices(pts, oracle.make_crop(a.kind, center=tuple(a.center), rmin=a.rmin, rmax=a.rmax, zmin=a.zmin, zmax=a.zmax,
+                                                             invert=bool(a.invert))).tolist())
+
+    kept = [keep(v) for v in vols]
+    said_yes = 0
+    for i, outer in enumerate(vols):
+        for j, inner in enumerate(vols):
+            if outer.contains(inner):
+                said_yes += 1
+                assert kept[j] <= kept[i], (i, j)  # never a false yes
+    assert said_yes >= 12  # every volume contains itself (but the inverted one), the nested pairs, everything inside the base volume
+    assert vols[4].contains(vols[4]) and vols[4].contains(vols[5]) and not vols[5].contains(vols[4])
+    assert vols[8].contains(vols[0]) and not vols[0].contains(vols[8]) and not shifted.contains(vols[0]) and not inverted.contains(inverted)
