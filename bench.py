@@ -548,6 +548,7 @@ def main():
         return dict(res=res, elapsed=elapsed, index_build_ms=index_build_ms, n_launch=n_launch, avg_kernel_s=avg_kernel_s, gbs=gbs)
 
     r32 = m1(backend.PRECISION_F32, args.steps, args.warmup)
+    r64 = None if args.no_f64 else m1(backend.PRECISION_F64, max(args.steps // 2, 1), args.warmup)
     # the same registration against a map that does NOT fit the 256 MiB Infinity Cache (8 M points: 256 MB of cell-sorted points + normals,
     # as much again in cloud order, 36 MB of grid): configs[1]'s own working set (32 MB + 9 MB) is cache resident, so its counter readings
     # and its rate say nothing about HBM -- this line does
@@ -595,8 +596,6 @@ def main():
                 "frac_of_hbm_peak_over_wall_time": K * steps_c * (ICP_ITERS + 1) * algo_bytes / el / 1e9 / HBM_PEAK_GBS}
         for b in bes:
             b.close()
-    r64 = None if args.no_f64 else m1(backend.PRECISION_F64, max(args.steps // 2, 1), args.warmup)
-
     # measured device copy bandwidth on this box (report against the vendor peak AND a measured copy kernel)
     copy_gbs = None
     if rank == 0:

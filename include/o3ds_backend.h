@@ -355,6 +355,10 @@ typedef struct {
 } o3ds_carving_params;
 int o3ds_map_carve(o3ds_handle h, o3ds_cloud map, o3ds_cloud raw_scan, const double map_to_range_sensor[16],
                    const o3ds_crop* map_builder_crop, const o3ds_carving_params* params, size_t* n_removed);
+/* The same, and the carved points come back as a cloud of their own (map order; empty when nothing was carved): what Submap::carve keeps in
+ * its toRemove_ member for the visualisation (Submap.cpp:119, `toRemove_ = *map->SelectByIndex(idxsToRemove)`).  removed_out may be NULL. */
+int o3ds_map_carve_removed(o3ds_handle h, o3ds_cloud map, o3ds_cloud raw_scan, const double map_to_range_sensor[16],
+                           const o3ds_crop* map_builder_crop, const o3ds_carving_params* params, size_t* n_removed, o3ds_cloud* removed_out);
 int o3ds_map_insert_scan(o3ds_handle h, o3ds_cloud map, o3ds_cloud scan, const double T[16], double map_voxel_size,
                          const o3ds_crop* map_builder_crop, double max_corr_hint);
 

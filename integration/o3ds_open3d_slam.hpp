@@ -408,17 +408,31 @@ class DeviceSubmap {
                                            maxCorrespondenceDistance));
     ++s->version;
   }
-  // Submap::carve for the sparse map (Submap.cpp:109-125 -> getIdxsOfCarvedPoints); the caller applies the every-N-scans gate
+  // Submap::carve for the sparse map (Submap.cpp:109-125 -> getIdxsOfCarvedPoints); the caller applies the every-N-scans gate.  toRemove /
+  // scanRef receive what the reference keeps in its members of those names for the visualisation (Submap.cpp:119-120): the carved points
+  // and the placed scan
   size_t carve(const PointCloud& rawScan, const Eigen::Isometry3d& mapToRangeSensor, const o3ds_crop& mapBuilderCrop,
-               const o3d_slam::SpaceCarvingParameters& p) {
+               const o3d_slam::SpaceCarvingParameters& p, PointCloud* toRemove = nullptr, PointCloud* scanRef = nullptr) {
     auto s = unique();
     std::lock_guard<std::mutex> lck(s->m);
     if (rawScan.IsEmpty() || s->size() == 0) return 0;
-    DeviceCloud in(s->h.get(), rawScan);
+    const o3ds_handle h = s->h.get();
+    DeviceCloud in(h, rawScan);
     const o3ds_carving_params cp{p.voxelSize_, p.maxRaytracingLength_, p.truncationDistance_, p.minDotProductWithNormal_};
     size_t removed = 0;
-    check(s->h.get(), o3ds_map_carve(s->h.get(), s->id(), in.id(), mapToRangeSensor.matrix().data(), &mapBuilderCrop, &cp, &removed));
+    o3ds_cloud gone = 0;
+    check(h, o3ds_map_carve_removed(h, s->id(), in.id(), mapToRangeSensor.matrix().data(), &mapBuilderCrop, &cp, &removed, toRemove ? &gone : nullptr));
     ++s->version;
+    if (toRemove) {
+      downloadCloud(h, gone, toRemove);
+      o3ds_cloud_free(h, gone);
+    }
+    if (scanRef) {
+      o3ds_cloud placed = 0;
+      check(h, o3ds_transform_cloud(h, in.id(), mapToRangeSensor.matrix().data(), &placed));
+      downloadCloud(h, placed, scanRef);
+      o3ds_cloud_free(h, placed);
+    }
     return removed;
   }
   // mapCloud_.Transform(T) (Submap::transform, Submap.cpp:94-107); the index is rebuilt for the moved points

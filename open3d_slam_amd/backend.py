@@ -95,6 +95,7 @@ SIGNATURES = {
     "o3ds_overlap_indices": (C.c_int, [_H, _CL, _CL, _dp, C.c_double, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_size_t),
                                        C.POINTER(C.c_uint64), C.POINTER(C.c_size_t)]),
     "o3ds_map_carve": (C.c_int, [_H, _CL, _CL, _dp, C.POINTER(Crop), C.POINTER(CarvingParams), C.POINTER(C.c_size_t)]),
+    "o3ds_map_carve_removed": (C.c_int, [_H, _CL, _CL, _dp, C.POINTER(Crop), C.POINTER(CarvingParams), C.POINTER(C.c_size_t), C.POINTER(_CL)]),
     "o3ds_information_matrix": (C.c_int, [_H, _dp, C.c_size_t, _dp, C.c_size_t, _dp, C.c_double, _dp]),
     "o3ds_information_matrix_dev": (C.c_int, [_H, _CL, _CL, C.POINTER(Crop), _dp, C.c_double, _dp]),
     "o3ds_icp_point_to_point": (C.c_int, [_H, _dp, C.c_size_t, _dp, C.c_size_t, _dp, C.POINTER(IcpParams), C.POINTER(IcpResult)]),
@@ -583,6 +584,14 @@ class Backend:
         n = C.c_size_t(0)
         self._ck(self.lib.o3ds_map_carve(self.h, map_id, raw_scan_id, tp, C.byref(crop) if crop else None, C.byref(p), C.byref(n)))
         return int(n.value)
+
+    def map_carve_removed(self, map_id: int, raw_scan_id: int, T, crop: Crop | None, voxel=0.1, max_length=20.0, truncation=0.1, min_dot=0.5):
+        """Submap::carve with its toRemove_ cloud: (number of removed points, device cloud of the removed points in map order)."""
+        Tc, tp = _d(colmajor(T))
+        p = CarvingParams(voxel, max_length, truncation, min_dot)
+        n, gone = C.c_size_t(0), _CL()
+        self._ck(self.lib.o3ds_map_carve_removed(self.h, map_id, raw_scan_id, tp, C.byref(crop) if crop else None, C.byref(p), C.byref(n), C.byref(gone)))
+        return int(n.value), gone.value
 
     def map_insert_scan(self, map_id: int, scan_id: int, T, map_voxel: float, crop: Crop, max_corr_hint: float = 0.0):
         Tc, tp = _d(colmajor(T))

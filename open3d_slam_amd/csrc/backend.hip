@@ -2442,7 +2442,7 @@ int transform_t(o3ds_handle h, const CloudRec& in, const double T[16], CloudRec&
 // Submap::carve (Submap.cpp:109-125): remove from `map` the points that the rays of `scan` (sensor frame, placed by T) see through
 template <typename P4>
 int carve_t(o3ds_handle h, CloudRec& map, const CloudRec& scan, const double T[16], const CropDev& crop, const o3ds_carving_params& cp,
-            size_t* n_removed) {
+            size_t* n_removed, CloudRec* removed = nullptr /* the carved points, in map order (Submap::toRemove_) */) {
   *n_removed = 0;
   const size_t n = map.n;
   if (n == 0 || scan.n == 0) return O3DS_OK;
@@ -2495,6 +2495,18 @@ int carve_t(o3ds_handle h, CloudRec& map, const CloudRec& scan, const double T[1
   if (rc) return rc;
   *n_removed = n - (size_t)total;
   if (*n_removed == 0) return O3DS_OK;  // removeByIds: nothing to do (helpers.cpp:221-223)
+  if (removed) {  // map->SelectByIndex(idxsToRemove) (Submap.cpp:119): the same flags and positions, the other side of the compaction
+    removed->precision = map.precision;
+    removed->n = *n_removed;
+    HIP_TRY(dev_alloc(h, (void**)&removed->pts, sizeof(P4) * removed->n));
+    if (map.nrm) HIP_TRY(dev_alloc(h, (void**)&removed->nrm, sizeof(P4) * removed->n));
+    compact_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>((const P4*)map.pts, (const P4*)map.nrm, n, keep, pos, 0, (P4*)removed->pts, (P4*)removed->nrm);
+    if (map.col) {
+      HIP_TRY(dev_alloc(h, (void**)&removed->col, sizeof(P4) * removed->n));
+      compact_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>((const P4*)map.col, nullptr, n, keep, pos, 0, (P4*)removed->col, nullptr);
+    }
+    box_copy(*removed, map);
+  }
   void *np = nullptr, *nn = nullptr, *nc = nullptr;
   if (total > 0) {
     HIP_TRY(dev_alloc(h, (void**)&np, sizeof(P4) * (size_t)total));
@@ -3105,6 +3117,11 @@ int o3ds_overlap_indices(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, co
 
 int o3ds_map_carve(o3ds_handle h, o3ds_cloud map, o3ds_cloud raw_scan, const double map_to_range_sensor[16], const o3ds_crop* map_builder_crop,
                    const o3ds_carving_params* params, size_t* n_removed) {
+  return o3ds_map_carve_removed(h, map, raw_scan, map_to_range_sensor, map_builder_crop, params, n_removed, nullptr);
+}
+
+int o3ds_map_carve_removed(o3ds_handle h, o3ds_cloud map, o3ds_cloud raw_scan, const double map_to_range_sensor[16], const o3ds_crop* map_builder_crop,
+                           const o3ds_carving_params* params, size_t* n_removed, o3ds_cloud* removed_out) {
   CHECK_HANDLE(h);
   ArenaScope arena_scope(h);
   CloudRec* m = find_cloud(h, map);
@@ -3114,11 +3131,19 @@ int o3ds_map_carve(o3ds_handle h, o3ds_cloud map, o3ds_cloud raw_scan, const dou
   if (m->n > 0 && s->n > 0 && m->precision != s->precision) return fail(h, O3DS_ERR_INVALID_ARG, "map_carve: precision mismatch");
   size_t removed = 0;
   const CropDev cd = to_dev(map_builder_crop);
-  const int rc = m->precision == O3DS_PRECISION_F64 ? carve_t<P4d>(h, *m, *s, map_to_range_sensor, cd, *params, &removed)
-                                                    : carve_t<P4f>(h, *m, *s, map_to_range_sensor, cd, *params, &removed);
+  CloudRec gone;
+  CloudGuard gone_guard(h, gone);
+  gone.precision = m->precision;
+  const int rc = m->precision == O3DS_PRECISION_F64 ? carve_t<P4d>(h, *m, *s, map_to_range_sensor, cd, *params, &removed, removed_out ? &gone : nullptr)
+                                                    : carve_t<P4f>(h, *m, *s, map_to_range_sensor, cd, *params, &removed, removed_out ? &gone : nullptr);
   if (n_removed) *n_removed = removed;
   if (removed) m->vox_first = -1;  // the blocks shrank by unknown amounts: the next insertion sorts once and re-establishes the layout
-  return rc;
+  if (rc) return rc;
+  if (removed_out) {
+    gone_guard.release();
+    *removed_out = add_cloud(h, std::move(gone));  // an empty cloud when nothing was carved
+  }
+  return O3DS_OK;
 }
 
 int o3ds_map_insert_scan(o3ds_handle h, o3ds_cloud map, o3ds_cloud scan, const double T[16], double map_voxel_size,

@@ -135,8 +135,30 @@ int main(int argc, char** argv) {
   o3d_slam::SpaceCarvingParameters sc;
   const size_t before = copy.size();
   const uint64_t vc = copy.version();
-  const size_t removed = copy.carve(s1, I, everything, sc);
+  PointCloud mapBefore, toRemove, scanRef, mapAfter;
+  copy.download(&mapBefore);
+  const size_t removed = copy.carve(s1, I, everything, sc, &toRemove, &scanRef);  // Submap::toRemove_ / scanRef_ (Submap.cpp:119-120)
   CHECK(copy.size() == before - removed && copy.size() > before / 4 && copy.version() != vc);
+  copy.download(&mapAfter);
+  CHECK(toRemove.points_.size() == removed && removed > 0 && toRemove.normals_.size() == removed);
+  CHECK(scanRef.points_.size() == s1.points_.size());
+  {  // the carved points and the survivors, interleaved back in map order, are the map as it was (both keep their order)
+    size_t a = 0, b = 0;
+    for (size_t i = 0; i < mapBefore.points_.size(); ++i) {
+      const bool isKept = a < mapAfter.points_.size() && mapAfter.points_[a][0] == mapBefore.points_[i][0] && mapAfter.points_[a][1] == mapBefore.points_[i][1] &&
+                          mapAfter.points_[a][2] == mapBefore.points_[i][2];
+      const bool isGone = b < removed && toRemove.points_[b][0] == mapBefore.points_[i][0] && toRemove.points_[b][1] == mapBefore.points_[i][1] &&
+                          toRemove.points_[b][2] == mapBefore.points_[i][2];
+      CHECK(isKept || isGone);
+      if (isKept)
+        ++a;
+      else
+        ++b;
+    }
+    CHECK(a == mapAfter.points_.size() && b == removed);
+    for (size_t i = 0; i < scanRef.points_.size(); i += 997)  // identity pose: the placed scan is the scan (f32 storage)
+      for (int k = 0; k < 3; ++k) CHECK(std::fabs(scanRef.points_[i][k] - s1.points_[i][k]) < 1e-5);
+  }
   // ---- Seam 2, first half: the scan chain, and scans that stay on the device between the seams -------------------------------------
   {
     PointCloud raw = cornerScan(60000, 7, 3.0, 3.0, 1.5);

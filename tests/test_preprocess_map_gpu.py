@@ -431,9 +431,24 @@ def test_map_carve_matches_oracle(backend_f64, backend_f32, oracle):
             if nrm is not None:
                 np.testing.assert_array_equal(got_n, nrm[~ref])
         assert 0 < removed < len(mp)
+        # the same call that also hands back the carved points (Submap::toRemove_, Submap.cpp:119): the complement, in map order
+        m2 = backend_f64.upload(mp, nrm)
+        removed2, gone = backend_f64.map_carve_removed(m2, s, pose, crop, **kw)
+        gone_p, gone_n = backend_f64.download(gone)
+        assert removed2 == removed and len(gone_p) == removed
+        np.testing.assert_array_equal(backend_f64.download(m2)[0], got_p)
+        if removed == int(ref.sum()):
+            np.testing.assert_array_equal(gone_p, mp[ref])
+            if nrm is not None:
+                np.testing.assert_array_equal(gone_n, nrm[ref])
+        backend_f64.free(m2)
+        backend_f64.free(gone)
         # idempotence on what is left is NOT a property (new points become visible), but a second scan-less call is a no-op
         e = backend_f64.upload(np.zeros((0, 3)))
         assert backend_f64.map_carve(m, e, pose, crop, **kw) == 0 and backend_f64.size(m)[0] == len(got_p)
+        n0, empty = backend_f64.map_carve_removed(m, e, pose, crop, **kw)  # nothing carved: an empty cloud comes back
+        assert n0 == 0 and backend_f64.size(empty)[0] == 0
+        backend_f64.free(empty)
         for c in (m, s, e):
             backend_f64.free(c)
     # f32 storage: same clutter goes, the count agrees to a fraction of a percent (voxel keys of f32-rounded points)
