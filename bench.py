@@ -60,7 +60,9 @@ def make_stream(frames):
     is initialised in this process (fork)."""
     import multiprocessing as mp
 
-    procs = max(1, min(32, (os.cpu_count() or 2) // 2, frames))
+    # no more workers than the CPU allowance (cgroup cpu.max): beyond it the pool is throttled, not faster
+    q = cpu_quota()
+    procs = max(1, min(32, (os.cpu_count() or 2) // 2, int(q) - 2 if q else 32, frames))
     if procs == 1:
         return [_scan_job(k) for k in range(frames)]
     with mp.get_context("fork").Pool(procs) as pool:
@@ -94,6 +96,16 @@ def cpu_quota():
         return None if q <= 0 else q / per
     except Exception:
         return None
+
+
+def host_cpu():
+    """logical CPU the calling thread runs on right now (-1 when the C library has no sched_getcpu)"""
+    try:
+        import ctypes
+
+        return int(ctypes.CDLL(None).sched_getcpu())
+    except Exception:
+        return -1
 
 
 def cpu_baseline_m1(src, tgt, nrm, budget_s=16.0):
@@ -245,6 +257,9 @@ def run_stream(be, scans32, profile=False):
     stage = {"upload": 0.0, "odometry": 0.0, "mapping": 0.0}
     frames = len(scans32)
     per_frame = []
+    import gc
+
+    gc.collect()
     try:
         for k, raw in enumerate(scans32):
             t0 = time.perf_counter()
@@ -374,12 +389,24 @@ def run_m1(be, world, s_id, t_id, steps, warmup, barrier, drv):
     for _ in range(warmup):
         res = step()
     barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    import gc
+
+    gc_log = []
+    def on_gc(phase, info):
+        gc_log.append((phase, info.get("generation"), time.perf_counter()))
+    gc.callbacks.append(on_gc)
+    gc.collect()  # cheap once main() has frozen the interpreter's long-lived objects
+    marks = [0.0] * (steps + 1)
+    t0 = marks[0] = time.perf_counter()
+    for k in range(steps):
         res = step()
+        marks[k + 1] = time.perf_counter()  # every registration ends with its result on the host, so these are step boundaries
     barrier()
     elapsed = time.perf_counter() - t0
     assert res["iterations"] == ICP_ITERS
+    gc.callbacks.remove(on_gc)
+    run_m1.step_us = np.diff(np.array(marks)) * 1e6
+    run_m1.gc = [(g, round((b - a) * 1e3, 2), round((a - t0) * 1e3, 2)) for (p0, g, a), (p1, _, b) in zip(gc_log[::2], gc_log[1::2])]
     # roofline of the dominant kernel (icp_fused_kernel: one ICP pass + the previous pass's solve/update in its prologue): the same
     # steps re-run with hipEvent brackets around every launch on the launch stream (outside the timed region above)
     be.profile_enable(True)
@@ -410,6 +437,9 @@ def run_config4(args, world, rank, local_rank, barrier, emit=True):
     steps, warmup = min(args.steps, 50), min(args.warmup, 5)
     for _ in range(warmup):
         dm.insert(cid)
+    import gc
+
+    gc.collect()
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -512,6 +542,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The interpreter's long-lived objects (about a million after `import torch`) leave the garbage collector's sight: a full collection
+    # over them takes 30-40 ms, it falls wherever the allocation counters happen to trip -- step 14 of a 50-ms timed region, measured
+    # (22.6 k instead of 40.2 k it/s on the line, the steps themselves untouched at 248 us median) -- and it has nothing to
+    # do with the work being timed.  The collector stays ON; every timed region starts from a collected heap.
+    import gc
+
+    gc.collect()
+    gc.freeze()
+
     if args.config == "4":
         run_config4(args, world, rank, local_rank, barrier)
         if world > 1:
@@ -545,7 +584,10 @@ def main():
         be.close()
         avg_kernel_s = kern_ms * 1e-3 / max(n_launch, 1)
         gbs = algo_bytes / avg_kernel_s / 1e9
-        return dict(res=res, elapsed=elapsed, index_build_ms=index_build_ms, n_launch=n_launch, avg_kernel_s=avg_kernel_s, gbs=gbs)
+        su = run_m1.step_us
+        spread = {"median": float(np.median(su)), "p10": float(np.percentile(su, 10)), "p90": float(np.percentile(su, 90)), "max": float(su.max()),
+                  "host_cpu": host_cpu(), "argmax": int(np.argmax(su)), "gc": run_m1.gc}
+        return dict(res=res, elapsed=elapsed, index_build_ms=index_build_ms, n_launch=n_launch, avg_kernel_s=avg_kernel_s, gbs=gbs, step_us=spread)
 
     r32 = m1(backend.PRECISION_F32, args.steps, args.warmup)
     r64 = None if args.no_f64 else m1(backend.PRECISION_F64, max(args.steps // 2, 1), args.warmup)
@@ -722,12 +764,13 @@ def main():
             "registrations_per_sec": steps / elapsed,
             "pose_error_vs_truth": {"dt_m": dt_gt, "dr_rad": dr_gt, "fitness": res["fitness"], "inlier_rmse": res["inlier_rmse"]},
             "roofline": roof(r32),
+            "step_us": r32["step_us"],  # spread of the timed steps on the host clock: a wide one means the enqueueing host thread was disturbed
         }
         if r64 is not None:
             s64 = max(args.steps // 2, 1)
             d64 = syn.se3_error(r64["res"]["transformation"], res["transformation"])
             out["m1_f64"] = {"value": ICP_ITERS * s64 / r64["elapsed"], "unit": "icp_iterations/s", "steps": s64, "ms_per_step": r64["elapsed"] / s64 * 1e3,
-                             "dtype": "f64", "index_build_ms": r64["index_build_ms"], "roofline": roof(r64, "icp_fused_kernel<P4d> configs[1] (f64 storage)"),
+                             "dtype": "f64", "index_build_ms": r64["index_build_ms"], "step_us": r64["step_us"], "roofline": roof(r64, "icp_fused_kernel<P4d> configs[1] (f64 storage)"),
                              "pose_vs_f32_storage": {"dt_m": d64[0], "dr_rad": d64[1]}}
         if r_big is not None:
             sb = max(args.steps // 4, 5)
