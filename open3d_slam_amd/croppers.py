@@ -71,7 +71,7 @@ class CroppingVolume:
         """True when every point `other` keeps is kept by this volume too (same kind, same centre, neither inverted, radii nested): then
         cropping `other`'s output with this volume returns it unchanged -- crop(crop(x, V1), V2) = crop(x, V1) for V1 inside V2."""
         if self._kind == _b.CROP_NONE:
-            return True  # the base volume keeps everything (croppers.cpp:49-51; isInvertVolume_ is ignored for it, as in to_abi / the ABI)
+            return not self.isInvertVolume_  # the base volume keeps everything (croppers.cpp:49-55), inverted nothing
         if type(self) is not type(other) or self.isInvertVolume_ or other.isInvertVolume_:
             return False
         if not np.array_equal(self.pose_[:3, 3], other.pose_[:3, 3]):

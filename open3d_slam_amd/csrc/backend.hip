@@ -1117,7 +1117,7 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
   h->session_launches = 0;
   h->session_state = nullptr;
   h->session_precision = src->precision;
-  h->session_crop = crop && crop->kind != O3DS_CROP_NONE;
+  h->session_crop = crop && (crop->kind != O3DS_CROP_NONE || crop->invert);
   h->session_method = params->method;
   return O3DS_OK;
 }

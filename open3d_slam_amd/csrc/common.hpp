@@ -60,7 +60,7 @@ __host__ __device__ inline bool crop_contains(const CropDev& c, double x, double
       in = z >= c.zmin && z <= c.zmax && sqrt(dx * dx + dy * dy) <= c.rmax;
       break;
     default:
-      return true;  // O3DS_CROP_NONE: no volume, invert ignored
+      return !c.invert;  // O3DS_CROP_NONE = the base CroppingVolume (croppers.cpp:49-55): everything is inside, so inverted nothing is
   }
   return c.invert ? !in : in;
 }

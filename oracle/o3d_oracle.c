@@ -1,5 +1,5 @@
 /*
- * o3d_oracle.c -- CPU ORACLE (test infrastructure only; PARITY UNPINNED, see o3d_oracle.h).
+ * o3d_oracle.c -- CPU ORACLE (test infrastructure only; Open3D parts PARITY UNPINNED, open3d_slam's own parts pinned: see o3d_oracle.h).
  *
  * Restates, in plain C + OpenMP, the algorithm of the reference's scan-to-map
  * point-to-plane ICP / map-fusion hot path.  In-tree citations are relative to

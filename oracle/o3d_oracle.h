@@ -5,15 +5,22 @@
  * bench.py's cpu_baseline leg may load this library.  The product
  * (open3d_slam_amd/, include/o3ds_backend.h) never links, imports or calls it.
  *
- * PARITY UNPINNED: the arithmetic of this path lives in Open3D v0.15.1
- * (pinned by /root/reference/open3d_catkin/CMakeLists.txt:116-118), which is
- * neither vendored under /root/reference nor installed in this image, and the
+ * PARITY UNPINNED for everything whose arithmetic lives in Open3D v0.15.1
+ * (registration, normals, VoxelDownSample, KD-tree; pinned by
+ * /root/reference/open3d_catkin/CMakeLists.txt:116-118), which is neither
+ * vendored under /root/reference nor installed in this image, and the
  * reference's own tests never touch the path, so
- * there are no golden vectors to pin against.  This file restates the
- * published Open3D v0.15.1 algorithm and the in-tree
- * open3d_slam code it is called from; it is cross-checked against an
+ * there are no golden vectors to pin those parts against.  This file restates
+ * the published Open3D v0.15.1 algorithm and the
+ * in-tree open3d_slam code it is called from; it is cross-checked against an
  * independent numpy/scipy restatement (oracle/np_oracle.py) and analytic
  * known-answer tests (tests/test_oracle.py).
+ * PINNED (round 3) for the in-tree open3d_slam code -- croppers,
+ * voxelizeWithinCroppingVolume, o3d_slam::transform, space carving, the dense
+ * voxel map, voxel overlap, constant-velocity de-skew: those reference sources
+ * are compiled unchanged and run (oracle/ref_build -> oracle/_ref), and this
+ * file equals them bit for bit (tests/test_oracle_vs_reference.py,
+ * tests/golden/ref_units.npz).
  *
  * Conventions: clouds are flat double[3*n] (the memory layout of
  * std::vector<Eigen::Vector3d>), poses are double[16] COLUMN-MAJOR (the layout

@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
 bench.py's cpu_baseline leg -- never from the product package.
-PARITY UNPINNED (see oracle/o3d_oracle.h).
+PARITY UNPINNED for the Open3D algorithms, pinned for open3d_slam's own code (see oracle/o3d_oracle.h, oracle/ref_build/README.md).
 """
 from __future__ import annotations
 

@@ -1,0 +1,244 @@
+// C entry points into open3d_slam's OWN sources (croppers.cpp, helpers.cpp, Voxel.cpp, VoxelHashMap.cpp, MotionCompensation.cpp, ...),
+// compiled unchanged from /root/reference against the stand-in headers of oracle/ref_build/shim (oracle/ref_build/Makefile ->
+// oracle/_ref/libo3dslam_ref.so).  This file only marshals plain arrays into the reference's types and calls the reference's functions;
+// it holds no algorithm of its own.  tests/test_oracle_vs_reference.py checks oracle/o3d_oracle.c against it; scripts under
+// tests/golden/ turn its outputs into fixtures for the GPU tests.  Test infrastructure only.
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "open3d_slam/MotionCompensation.hpp"
+#include "open3d_slam/Parameters.hpp"
+#include "open3d_slam/TransformInterpolationBuffer.hpp"
+#include "open3d_slam/Voxel.hpp"
+#include "open3d_slam/croppers.hpp"
+#include "open3d_slam/helpers.hpp"
+#include "open3d_slam/math.hpp"
+#include "open3d_slam/time.hpp"
+
+using open3d::geometry::PointCloud;
+
+namespace {
+PointCloud make_cloud(const double* pts, const double* nrm, const double* col, size_t n) {
+  PointCloud c;
+  c.points_.resize(n);
+  for (size_t i = 0; i < n; ++i) c.points_[i] = Eigen::Vector3d(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+  if (nrm) {
+    c.normals_.resize(n);
+    for (size_t i = 0; i < n; ++i) c.normals_[i] = Eigen::Vector3d(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]);
+  }
+  if (col) {
+    c.colors_.resize(n);
+    for (size_t i = 0; i < n; ++i) c.colors_[i] = Eigen::Vector3d(col[3 * i], col[3 * i + 1], col[3 * i + 2]);
+  }
+  return c;
+}
+void store(const std::vector<Eigen::Vector3d>& v, double* out) {
+  if (!out) return;
+  for (size_t i = 0; i < v.size(); ++i)
+    for (int a = 0; a < 3; ++a) out[3 * i + a] = v[i](a);
+}
+Eigen::Matrix4d matrix_from_colmajor(const double T[16]) {
+  Eigen::Matrix4d M;
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) M(r, c) = T[c * 4 + r];
+  return M;
+}
+// kind: 0 = CroppingVolume (the base class: everything is inside), 1 MaxRadius, 2 MinRadius, 3 MinMaxRadius, 4 Cylinder (oracle numbering)
+std::unique_ptr<o3d_slam::CroppingVolume> make_cropper(int kind, double rmin, double rmax, double zmin, double zmax, const double pose[16], int invert) {
+  o3d_slam::ScanCroppingParameters p;
+  p.croppingMinRadius_ = rmin;
+  p.croppingMaxRadius_ = rmax;
+  p.croppingMinZ_ = zmin;
+  p.croppingMaxZ_ = zmax;
+  std::unique_ptr<o3d_slam::CroppingVolume> c;
+  switch (kind) {
+    case 0:
+      c = std::make_unique<o3d_slam::CroppingVolume>();
+      break;
+    case 1:
+      p.cropperName_ = "MaxRadius";
+      c = o3d_slam::croppingVolumeFactory(p);
+      break;
+    case 2:
+      p.cropperName_ = "MinRadius";
+      c = o3d_slam::croppingVolumeFactory(p);
+      break;
+    case 3:
+      p.cropperName_ = "MinMaxRadius";
+      c = o3d_slam::croppingVolumeFactory(p);
+      break;
+    default:
+      p.cropperName_ = "Cylinder";
+      c = o3d_slam::croppingVolumeFactory(p);
+      break;
+  }
+  c->setPose(Eigen::Isometry3d(matrix_from_colmajor(pose)));
+  c->setIsInvertVolume(invert != 0);
+  return c;
+}
+}  // namespace
+
+extern "C" {
+
+// CroppingVolume::getIndicesWithinVolume + CroppingVolume::crop (croppers.cpp:65-106); returns the kept count
+size_t ref_crop(int kind, double rmin, double rmax, double zmin, double zmax, const double pose[16], int invert, const double* pts, const double* nrm,
+                const double* col, size_t n, int64_t* out_idx, double* out_pts, double* out_nrm, double* out_col) {
+  const auto cropper = make_cropper(kind, rmin, rmax, zmin, zmax, pose, invert);
+  const PointCloud cloud = make_cloud(pts, nrm, col, n);
+  const auto idx = cropper->getIndicesWithinVolume(cloud);
+  const auto cropped = cropper->crop(cloud);
+  if (cropped->points_.size() != idx.size()) return (size_t)-1;
+  if (out_idx)
+    for (size_t i = 0; i < idx.size(); ++i) out_idx[i] = (int64_t)idx[i];
+  store(cropped->points_, out_pts);
+  if (nrm) store(cropped->normals_, out_nrm);
+  if (col) store(cropped->colors_, out_col);
+  return idx.size();
+}
+
+// voxelizeWithinCroppingVolume (helpers.cpp:115-183); output in the reference's own order (pass-through points, then the hash map's
+// iteration order); returns the count
+size_t ref_voxelize_within_cropping_volume(double voxel, int kind, double rmin, double rmax, double zmin, double zmax, const double pose[16], int invert,
+                                           const double* pts, const double* nrm, const double* col, size_t n, double* out_pts, double* out_nrm,
+                                           double* out_col) {
+  const auto cropper = make_cropper(kind, rmin, rmax, zmin, zmax, pose, invert);
+  const PointCloud cloud = make_cloud(pts, nrm, col, n);
+  const auto out = o3d_slam::voxelizeWithinCroppingVolume(voxel, *cropper, cloud);
+  store(out->points_, out_pts);
+  if (nrm) store(out->normals_, out_nrm);
+  if (col) store(out->colors_, out_col);
+  return out->points_.size();
+}
+
+// o3d_slam::transform (helpers.cpp:273-305); the out arrays hold 2 n points: for a T within 1e-4 of the identity the reference returns the
+// input cloud FOLLOWED by the transformed points (helpers.cpp:276-279 copies the cloud and the loop then appends to it).  Returns the
+// number of points; *has_colors_out = whether the result still counts as coloured (its colour array keeps n entries)
+size_t ref_transform(const double T[16], const double* pts, const double* nrm, const double* col, size_t n, double* out_pts, double* out_nrm,
+                     int* has_colors_out) {
+  const auto out = o3d_slam::transform(matrix_from_colmajor(T), make_cloud(pts, nrm, col, n));
+  store(out->points_, out_pts);
+  if (nrm) store(out->normals_, out_nrm);
+  if (has_colors_out) *has_colors_out = out->HasColors() ? 1 : 0;
+  return out->points_.size();
+}
+
+// getIdxsOfCarvedPoints (helpers.cpp:221-271); subset may be null (all map points); returns the number of ids (unordered)
+size_t ref_carved_idxs(const double* scan, size_t n_scan, const double sensor[3], const double* map_pts, const double* map_nrm, size_t N,
+                       const int64_t* subset, size_t n_subset, double voxel, double max_length, double truncation, double min_dot, int64_t* out_ids) {
+  o3d_slam::SpaceCarvingParameters p;
+  p.voxelSize_ = voxel;
+  p.maxRaytracingLength_ = max_length;
+  p.truncationDistance_ = truncation;
+  p.minDotProductWithNormal_ = min_dot;
+  const PointCloud s = make_cloud(scan, nullptr, nullptr, n_scan), m = make_cloud(map_pts, map_nrm, nullptr, N);
+  const Eigen::Vector3d sp(sensor[0], sensor[1], sensor[2]);
+  std::vector<size_t> ids;
+  if (subset) {
+    std::vector<size_t> sub(subset, subset + n_subset);
+    ids = o3d_slam::getIdxsOfCarvedPoints(s, m, sp, sub, p);
+  } else {
+    ids = o3d_slam::getIdxsOfCarvedPoints(s, m, sp, p);
+  }
+  for (size_t i = 0; i < ids.size(); ++i) out_ids[i] = (int64_t)ids[i];
+  return ids.size();
+}
+
+// computeIndicesOfOverlappingPoints (helpers.cpp:307-332); the index lists in the reference's order
+void ref_overlap(const double* src, size_t n_src, const double* tgt, size_t n_tgt, const double T[16], double voxel, size_t min_points, int64_t* out_src,
+                 size_t* n_out_src, int64_t* out_tgt, size_t* n_out_tgt) {
+  std::vector<size_t> is, it;
+  o3d_slam::computeIndicesOfOverlappingPoints(make_cloud(src, nullptr, nullptr, n_src), make_cloud(tgt, nullptr, nullptr, n_tgt),
+                                              o3d_slam::Transform(matrix_from_colmajor(T)), voxel, min_points, &is, &it);
+  for (size_t i = 0; i < is.size(); ++i) out_src[i] = (int64_t)is[i];
+  for (size_t i = 0; i < it.size(); ++i) out_tgt[i] = (int64_t)it[i];
+  *n_out_src = is.size();
+  *n_out_tgt = it.size();
+}
+
+// VoxelizedPointCloud::insert (n_batches consecutive ranges of the input, as consecutive scans) + toPointCloud (Voxel.cpp:66-114), plus the
+// voxel keys and counts in the same (hash map) order; returns the number of voxels
+size_t ref_dense_fuse(const double* pts, const double* nrm, size_t n, double voxel, int n_batches, double* out_pts, double* out_nrm, int32_t* out_counts,
+                      int32_t* out_keys) {
+  o3d_slam::VoxelizedPointCloud map(Eigen::Vector3d::Constant(voxel));
+  if (n_batches < 1) n_batches = 1;
+  for (int b = 0; b < n_batches; ++b) {
+    const size_t lo = n * (size_t)b / (size_t)n_batches, hi = n * (size_t)(b + 1) / (size_t)n_batches;
+    map.insert(make_cloud(pts + 3 * lo, nrm ? nrm + 3 * lo : nullptr, nullptr, hi - lo));
+  }
+  const PointCloud out = map.toPointCloud();
+  store(out.points_, out_pts);
+  if (nrm) store(out.normals_, out_nrm);
+  size_t k = 0;
+  for (const auto& v : map.voxels_) {
+    if (v.second.numAggregatedPoints_ > 0) {
+      if (out_counts) out_counts[k] = v.second.numAggregatedPoints_;
+      if (out_keys)
+        for (int a = 0; a < 3; ++a) out_keys[3 * k + a] = v.first(a);
+      ++k;
+    }
+  }
+  return out.points_.size() == k ? k : (size_t)-1;
+}
+
+// Submap::carve for the dense map (Submap.cpp:126-136): removeDuplicatePointsWithinSameVoxels (Voxel.cpp:162-191) on the scan, then
+// getKeysOfCarvedPoints (helpers.cpp:347-377) against a VoxelizedPointCloud holding map_pts; returns the number of keys (3 ints each)
+size_t ref_dense_carve_keys(const double* scan, size_t n_scan, const double sensor[3], const double* map_pts, size_t N, double voxel, double radius,
+                            double max_length, double truncation, int dedup_scan, int32_t* out_keys, size_t cap) {
+  o3d_slam::SpaceCarvingParameters p;
+  p.maxRaytracingLength_ = max_length;
+  p.truncationDistance_ = truncation;
+  p.neighborhoodRadiusDenseMap_ = radius;
+  o3d_slam::VoxelizedPointCloud map(Eigen::Vector3d::Constant(voxel));
+  map.insert(make_cloud(map_pts, nullptr, nullptr, N));
+  PointCloud s = make_cloud(scan, nullptr, nullptr, n_scan);
+  if (dedup_scan) s = *o3d_slam::removeDuplicatePointsWithinSameVoxels(s, Eigen::Vector3d::Constant(voxel));
+  const auto keys = o3d_slam::getKeysOfCarvedPoints(s, map, Eigen::Vector3d(sensor[0], sensor[1], sensor[2]), p);
+  for (size_t i = 0; i < keys.size() && i < cap; ++i)
+    for (int a = 0; a < 3; ++a) out_keys[3 * i + a] = keys[i](a);
+  return keys.size();
+}
+
+// getVoxelIdx (VoxelHashMap.hpp:47-50), the world-anchored voxel index every map structure of the reference uses
+void ref_voxel_idx(const double p[3], double voxel, int32_t out[3]) {
+  const auto k = o3d_slam::getVoxelIdx(Eigen::Vector3d(p[0], p[1], p[2]), o3d_slam::fromVoxelSize(Eigen::Vector3d::Constant(voxel)));
+  for (int a = 0; a < 3; ++a) out[a] = k(a);
+}
+
+int ref_is_valid_color(const double c[3]) { return o3d_slam::isValidColor(Eigen::Vector3d(c[0], c[1], c[2])) ? 1 : 0; }
+double ref_icp_max_correspondence_distance(double voxel) { return o3d_slam::icpMaxCorrespondenceDistance(voxel); }
+double ref_information_matrix_max_correspondence_distance(double voxel) { return o3d_slam::informationMatrixMaxCorrespondenceDistance(voxel); }
+
+// ConstantVelocityMotionCompensation::undistortInputPointCloud (MotionCompensation.cpp:64-139) with the velocity it would estimate from
+// two buffered poses `dt` apart (estimateLinearAndAngularVelocity, :27-57): start = identity, finish = (xyz, rpy); out = the moved points,
+// vel_out = {linear velocity, angular velocity (rpy)} as estimated
+void ref_undistort(const double* pts, size_t n, const double finish_xyz[3], const double finish_rpy[3], double dt, double scan_duration, int clockwise,
+                   double* out_pts, double vel_out[6]) {
+  o3d_slam::TransformInterpolationBuffer buffer;
+  const o3d_slam::Time t0 = o3d_slam::fromUniversal(1000000);
+  const o3d_slam::Time t1 = t0 + o3d_slam::fromSeconds(dt);
+  buffer.push(t0, o3d_slam::Transform::Identity());
+  buffer.push(t1, o3d_slam::fromXYZandRPY(Eigen::Vector3d(finish_xyz[0], finish_xyz[1], finish_xyz[2]),
+                                          Eigen::Vector3d(finish_rpy[0], finish_rpy[1], finish_rpy[2])));
+  o3d_slam::ConstantVelocityMotionCompensation mc(buffer);
+  o3d_slam::ConstantVelocityMotionCompensationParameters p;
+  p.scanDuration_ = scan_duration;
+  p.isSpinningClockwise_ = clockwise != 0;
+  p.numPosesVelocityEstimation_ = 1;
+  mc.setParameters(p);
+  const auto out = mc.undistortInputPointCloud(make_cloud(pts, nullptr, nullptr, n), t1 + o3d_slam::fromSeconds(0.05));
+  store(out->points_, out_pts);
+  if (vel_out) {
+    // the same estimate, through the public pieces it is made of (the method itself is private)
+    const auto finish = buffer.latest_measurement();
+    const auto start = buffer.latest_measurement(1);
+    const o3d_slam::Transform dT = start.transform_.inverse() * finish.transform_;
+    const double d = o3d_slam::toSeconds(finish.time_ - start.time_);
+    const Eigen::Vector3d lin = dT.translation() / (d + 1e-6);
+    const Eigen::Vector3d ang = o3d_slam::toRPY(Eigen::Quaterniond(dT.rotation()).normalized()) / (d + 1e-6);
+    for (int a = 0; a < 3; ++a) vel_out[a] = lin(a), vel_out[3 + a] = ang(a);
+  }
+}
+}  // extern "C"
