@@ -12,6 +12,12 @@
 
 namespace o3ds {
 
+// Everything in this header is streaming work whose results are compared with the reference's (and the oracle's) plain double
+// arithmetic: a*b + c is two roundings there, so it is two roundings here -- no fused multiply-add (hipcc's default for device code is
+// -ffp-contract=fast).  That is what makes o3d_slam::transform, the ray samples of the carving and every boundary decision of a cropper
+// come out with the reference's bits and not merely close to them.  None of these kernels is arithmetic-bound.
+#pragma clang fp contract(off)
+
 // ---------------------------------------------------------------------------------------------- pack / unpack
 template <typename P4, typename S = double>  // S: the scalar of the staged host array (float when the host side already narrowed it)
 __global__ __launch_bounds__(kBlock) void pack_kernel(const S* __restrict__ xyz, size_t n, P4* __restrict__ out) {
@@ -1263,5 +1269,7 @@ __global__ __launch_bounds__(kBlock) void dense_transform_kernel(DenseDev d, siz
     d.sn[3 * s + 2] = llrint((M.m[8] * a + M.m[9] * b + M.m[10] * c + M.m[11]) / kDenseNrmQ);
   }
 }
+
+#pragma clang fp contract(fast)
 
 }  // namespace o3ds

@@ -41,6 +41,7 @@ struct CropDev {
   double zmin, zmax;
 };
 
+#pragma clang fp contract(off)  // the distances below round as the reference's do (see cloud_kernels.hpp)
 __host__ __device__ inline bool crop_contains(const CropDev& c, double x, double y, double z) {
   bool in = true;
   const double dx = x - c.cx, dy = y - c.cy, dz = z - c.cz;
@@ -64,6 +65,7 @@ __host__ __device__ inline bool crop_contains(const CropDev& c, double x, double
   }
   return c.invert ? !in : in;
 }
+#pragma clang fp contract(fast)
 
 inline CropDev to_dev(const o3ds_crop* c) {
   CropDev d{};

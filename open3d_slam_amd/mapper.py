@@ -48,7 +48,7 @@ class Mapper:
         p = self.params_
         if self.submap_.isEmpty():  # Mapper.cpp:105-114: insert the first scan at identity
             processed = self.scan2MapReg_.processForScanMatchingAndMerging(rawScan, self.mapToRangeSensor_)
-            self.submap_.insertScan(rawScan, processed.merge_, np.eye(4), timestamp)
+            self.submap_.insertScan(rawScan, processed.merge_, np.eye(4), timestamp, isPerformCarving=True)
             self.mapToRangeSensorBuffer_.append((timestamp, self.mapToRangeSensor_.copy()))
             # (the reference leaves lastMeasurementTimestamp_ at the epoch here and lets TransformInterpolationBuffer clamp the lookup of
             # the next frame to the earliest odometry sample; this harness looks stamps up exactly, so it records the first stamp)
@@ -73,7 +73,9 @@ class Mapper:
         self.mapToRangeSensorBuffer_.append((timestamp, self.mapToRangeSensor_.copy()))
         motion = np.linalg.inv(self.mapToRangeSensorLastScanInsertion_) @ self.mapToRangeSensor_
         if not (np.linalg.norm(motion[:3, 3]) < p.minMovementBetweenMappingSteps_):  # Mapper.cpp:170-176
-            self.submap_.insertScan(rawScan, processed.merge_, self.mapToRangeSensor_, timestamp)
+            # SubmapCollection::insertScan (SubmapCollection.cpp:178,189,203) always asks the submap to carve; Submap::carve applies the
+            # every-N-scans gate itself (Submap.cpp:111)
+            self.submap_.insertScan(rawScan, processed.merge_, self.mapToRangeSensor_, timestamp, isPerformCarving=True)
             self.mapToRangeSensorLastScanInsertion_ = self.mapToRangeSensor_.copy()
         self.lastMeasurementTimestamp_ = timestamp
         self.mapToRangeSensorPrev_ = self.mapToRangeSensor_.copy()

@@ -19,6 +19,9 @@ class OracleLoop:
         self.prev = None
         self.last_t = None
         self.rng_odo = self.rng_map = None  # RandomDownSample keep lists (see set_down_sample_seeds)
+        self.carving = True  # as the reference: SubmapCollection::insertScan passes isPerformCarving = true
+        self.n_inserted, self.n_carved = 0, 0
+        self.T_inserted = np.eye(4)  # pose of the last insertion = the map builder cropper's pose until the next one
         self.shuffle_at_full_ratio = False
 
     def set_down_sample_seeds(self, odo_seed, map_seed, shuffle_at_full_ratio=False):
@@ -73,6 +76,21 @@ class OracleLoop:
             T_ins = self.T
         tp, tn = o.transform_points(v, T_ins), o.transform_normals(n, T_ins)
         mc = mp.mapBuilder_.cropper_
+        # Submap::insertScan (Submap.cpp:54-72): SubmapCollection::insertScan always asks for carving (SubmapCollection.cpp:178,189,203);
+        # Submap::carve (Submap.cpp:109-125) acts when the map is not empty and nScansInsertedMap_ % carveSpaceEveryNscans_ == 1, with
+        # the RAW scan placed by the new pose, on the map points inside the map builder's volume -- whose pose is still that of the
+        # PREVIOUS insertion (setPose follows, Submap.cpp:71)
+        cv = mp.mapBuilder_.carving_
+        if self.carving and len(self.map_p) and self.n_inserted % cv.carveSpaceEveryNscans_ == 1:
+            inside = o.crop_indices(self.map_p, o.make_crop(o.CROP_MIN_MAX_RADIUS, center=self.T_inserted[:3, 3], rmin=mc.croppingMinRadius_,
+                                                             rmax=mc.croppingMaxRadius_))
+            gone = o.carve_flags(o.transform_points(np.asarray(raw, dtype=np.float64), T_ins), T_ins[:3, 3], self.map_p, self.map_n, inside,
+                                 voxel=cv.voxelSize_, max_length=cv.maxRaytracingLength_, truncation=cv.truncationDistance_,
+                                 min_dot=cv.minDotProductWithNormal_)
+            self.map_p, self.map_n = self.map_p[~gone], self.map_n[~gone]
+            self.n_carved += int(gone.sum())
+        self.n_inserted += 1
+        self.T_inserted = T_ins.copy()
         crop = o.make_crop(o.CROP_MIN_MAX_RADIUS, center=T_ins[:3, 3], rmin=mc.croppingMinRadius_, rmax=mc.croppingMaxRadius_)
         self.map_p, self.map_n, _ = o.voxelize_within_volume(np.vstack([self.map_p, tp]), np.vstack([self.map_n, tn]),
                                                              mp.mapBuilder_.mapVoxelSize_, crop)

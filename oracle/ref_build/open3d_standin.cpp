@@ -1,6 +1,6 @@
 // Definitions behind oracle/ref_build/shim/open3d/*: the container members of open3d::geometry::PointCloud that open3d_slam's own
-// sources call, restated from Open3D v0.15.1's documented behaviour ([O3D]), and ABORTING stubs for the Open3D
-// algorithms, which are not under /root/reference.  Test infrastructure only.
+// sources call, restated from Open3D v0.15.1's documented behaviour ([O3D]), and ABORTING stubs for the KD-tree searches (the
+// algorithms the reference's glue calls are in open3d_served_by_oracle.cpp).  Test infrastructure only.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -112,12 +112,13 @@ Eigen::Vector3d PointCloud::GetMaxBound() const {
   return m;
 }
 
-std::shared_ptr<PointCloud> PointCloud::VoxelDownSample(double) const { not_here("PointCloud::VoxelDownSample"); }
-std::shared_ptr<PointCloud> PointCloud::RandomDownSample(double) const { not_here("PointCloud::RandomDownSample"); }
-void PointCloud::EstimateNormals(const KDTreeSearchParam&, bool) { not_here("PointCloud::EstimateNormals"); }
-void PointCloud::EstimateCovariances(const KDTreeSearchParam&) { not_here("PointCloud::EstimateCovariances"); }
-void PointCloud::OrientNormalsTowardsCameraLocation(const Eigen::Vector3d&) { not_here("PointCloud::OrientNormalsTowardsCameraLocation"); }
-PointCloud& PointCloud::NormalizeNormals() { not_here("PointCloud::NormalizeNormals"); }
+Eigen::Vector3d PointCloud::GetCenter() const {
+  Eigen::Vector3d c(0.0, 0.0, 0.0);
+  if (points_.empty()) return c;
+  for (const auto& p : points_) c += p;
+  return c / double(points_.size());
+}
+
 bool KDTreeFlann::SetGeometry(const PointCloud&) { not_here("KDTreeFlann::SetGeometry"); }
 int KDTreeFlann::SearchKNN(const Eigen::Vector3d&, int, std::vector<int>&, std::vector<double>&) const { not_here("KDTreeFlann::SearchKNN"); }
 int KDTreeFlann::SearchRadius(const Eigen::Vector3d&, double, std::vector<int>&, std::vector<double>&) const { not_here("KDTreeFlann::SearchRadius"); }

@@ -9,7 +9,10 @@
 #include <string>
 #include <vector>
 
+#include "open3d_slam/Mapper.hpp"
 #include "open3d_slam/MotionCompensation.hpp"
+#include "open3d_slam/Odometry.hpp"
+#include "open3d_slam/SubmapCollection.hpp"
 #include "open3d_slam/Parameters.hpp"
 #include "open3d_slam/TransformInterpolationBuffer.hpp"
 #include "open3d_slam/Voxel.hpp"
@@ -240,5 +243,110 @@ void ref_undistort(const double* pts, size_t n, const double finish_xyz[3], cons
     const Eigen::Vector3d ang = o3d_slam::toRPY(Eigen::Quaterniond(dT.rotation()).normalized()) / (d + 1e-6);
     for (int a = 0; a < 3; ++a) vel_out[a] = lin(a), vel_out[3 + a] = ang(a);
   }
+}
+
+// ---- the reference's own frame loop: LidarOdometry::addRangeScan (Odometry.cpp:32-79) then Mapper::addRangeMeasurement (Mapper.cpp:101-181)
+// per scan, wired as SlamWrapper wires them (SlamWrapper.cpp:179-186: the mapper reads the odometry's pose buffer), one worker after the
+// other.  All of it is the reference's code; the Open3D algorithms underneath are served by the oracle (open3d_served_by_oracle.cpp).
+struct ref_slam_params {
+  // odometry (OdometryParameters): scan processing + ICP
+  double odo_voxel, odo_ratio, odo_rmin, odo_rmax, odo_max_corr, odo_knn_radius;
+  int32_t odo_knn, odo_max_iter;
+  // mapper (MapperParameters): scan processing, scan matcher, map builder
+  double map_voxel, map_ratio, map_rmin, map_rmax, map_max_corr, map_knn_radius, min_refinement_fitness, min_movement;
+  int32_t map_knn, map_max_iter;
+  double builder_voxel, builder_rmin, builder_rmax;
+  // carving (SpaceCarvingParameters) and submaps
+  double carve_voxel, carve_max_length, carve_truncation, carve_min_dot;
+  int32_t carve_every_n_scans;
+  double submap_radius;
+};
+struct RefSlam {
+  std::shared_ptr<o3d_slam::LidarOdometry> odometry;
+  std::shared_ptr<o3d_slam::SubmapCollection> submaps;
+  std::shared_ptr<o3d_slam::Mapper> mapper;
+};
+
+void* ref_slam_create(const ref_slam_params* q) {
+  o3d_slam::OdometryParameters op;
+  op.scanProcessing_.voxelSize_ = q->odo_voxel;
+  op.scanProcessing_.downSamplingRatio_ = q->odo_ratio;
+  op.scanProcessing_.cropper_.cropperName_ = "MinMaxRadius";
+  op.scanProcessing_.cropper_.croppingMinRadius_ = q->odo_rmin;
+  op.scanProcessing_.cropper_.croppingMaxRadius_ = q->odo_rmax;
+  op.scanMatcher_.regType_ = o3d_slam::CloudRegistrationType::PointToPlaneIcp;
+  op.scanMatcher_.icp_.maxCorrespondenceDistance_ = q->odo_max_corr;
+  op.scanMatcher_.icp_.maxDistanceKnn_ = q->odo_knn_radius;
+  op.scanMatcher_.icp_.knn_ = q->odo_knn;
+  op.scanMatcher_.icp_.maxNumIter_ = q->odo_max_iter;
+  o3d_slam::MapperParameters mp;
+  mp.scanProcessing_.voxelSize_ = q->map_voxel;
+  mp.scanProcessing_.downSamplingRatio_ = q->map_ratio;
+  mp.scanProcessing_.cropper_.cropperName_ = "MinMaxRadius";
+  mp.scanProcessing_.cropper_.croppingMinRadius_ = q->map_rmin;
+  mp.scanProcessing_.cropper_.croppingMaxRadius_ = q->map_rmax;
+  mp.scanMatcher_.scanToMapRegType_ = o3d_slam::ScanToMapRegistrationType::PointToPlaneIcp;
+  mp.scanMatcher_.minRefinementFitness_ = q->min_refinement_fitness;
+  mp.scanMatcher_.icp_.maxCorrespondenceDistance_ = q->map_max_corr;
+  mp.scanMatcher_.icp_.maxDistanceKnn_ = q->map_knn_radius;
+  mp.scanMatcher_.icp_.knn_ = q->map_knn;
+  mp.scanMatcher_.icp_.maxNumIter_ = q->map_max_iter;
+  mp.minMovementBetweenMappingSteps_ = q->min_movement;
+  mp.mapBuilder_.mapVoxelSize_ = q->builder_voxel;
+  mp.mapBuilder_.cropper_.cropperName_ = "MinMaxRadius";
+  mp.mapBuilder_.cropper_.croppingMinRadius_ = q->builder_rmin;
+  mp.mapBuilder_.cropper_.croppingMaxRadius_ = q->builder_rmax;
+  mp.mapBuilder_.carving_.voxelSize_ = q->carve_voxel;
+  mp.mapBuilder_.carving_.maxRaytracingLength_ = q->carve_max_length;
+  mp.mapBuilder_.carving_.truncationDistance_ = q->carve_truncation;
+  mp.mapBuilder_.carving_.minDotProductWithNormal_ = q->carve_min_dot;
+  mp.mapBuilder_.carving_.carveSpaceEveryNscans_ = q->carve_every_n_scans;
+  mp.submaps_.radius_ = q->submap_radius;
+  mp.isBuildDenseMap_ = false;
+  mp.isAttemptLoopClosures_ = false;
+  mp.isPrintTimingStatistics_ = false;
+  auto* s = new RefSlam();
+  s->odometry = std::make_shared<o3d_slam::LidarOdometry>();
+  s->odometry->setParameters(op);
+  s->submaps = std::make_shared<o3d_slam::SubmapCollection>();
+  s->mapper = std::make_shared<o3d_slam::Mapper>(s->odometry->getBuffer(), s->submaps);
+  s->mapper->setParameters(mp);
+  return s;
+}
+void ref_slam_free(void* h) { delete static_cast<RefSlam*>(h); }
+
+// one scan through both workers; poses out column-major; returns 1 if both accepted the scan, 0 if the odometry refused it, -1 if the mapper did
+int ref_slam_add_scan(void* h, const double* pts, size_t n, double t_seconds, double odom_to_sensor[16], double map_to_sensor[16], size_t* map_points,
+                      size_t* n_submaps) {
+  auto* s = static_cast<RefSlam*>(h);
+  const PointCloud cloud = make_cloud(pts, nullptr, nullptr, n);
+  const o3d_slam::Time t = o3d_slam::fromUniversal(0) + o3d_slam::fromSeconds(1000.0 + t_seconds);
+  int rc = 1;
+  if (!s->odometry->addRangeScan(cloud, t))
+    rc = 0;
+  else if (!s->mapper->addRangeMeasurement(cloud, t))
+    rc = -1;
+  const Eigen::Matrix4d O = s->odometry->getOdomToRangeSensor(t).matrix(), M = s->mapper->getMapToRangeSensor(t).matrix();
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) odom_to_sensor[c * 4 + r] = O(r, c), map_to_sensor[c * 4 + r] = M(r, c);
+  *map_points = s->mapper->getActiveSubmap().getMapPointCloud().points_.size();
+  *n_submaps = s->submaps->getNumSubmaps();
+  return rc;
+}
+// the active submap's cloud (points, normals); returns its size (call with null outputs first)
+size_t ref_slam_map(void* h, double* out_pts, double* out_nrm) {
+  auto* s = static_cast<RefSlam*>(h);
+  const PointCloud& m = s->mapper->getActiveSubmap().getMapPointCloud();
+  store(m.points_, out_pts);
+  if (m.HasNormals()) store(m.normals_, out_nrm);
+  return m.points_.size();
+}
+// the scan the mapper matched last (ScanToMapIcp::processForScanMatchingAndMerging's match_) -- for checking the pre-processing chain
+size_t ref_slam_preprocessed_scan(void* h, double* out_pts, double* out_nrm) {
+  auto* s = static_cast<RefSlam*>(h);
+  const PointCloud& m = s->mapper->getPreprocessedScan();
+  store(m.points_, out_pts);
+  if (m.HasNormals()) store(m.normals_, out_nrm);
+  return m.points_.size();
 }
 }  // extern "C"

@@ -213,7 +213,7 @@ class Matrix {
     static_assert(N == 3, "cross product of 3-vectors");
     return Matrix(v[1] * o.v[2] - v[2] * o.v[1], v[2] * o.v[0] - v[0] * o.v[2], v[0] * o.v[1] - v[1] * o.v[0]);
   }
-  Matrix<S, C, R> transpose() const {
+  const Matrix<S, C, R> transpose() const {
     Matrix<S, C, R> t;
     for (int i = 0; i < R; ++i)
       for (int j = 0; j < C; ++j) t(j, i) = (*this)(i, j);
@@ -237,26 +237,28 @@ class Matrix {
       if (v[i] != v[i]) return true;
     return false;
   }
+  // (sub-matrix accessors return CONST values: writing through one -- which real Eigen allows and this stand-in could only drop --
+  //  then fails to compile instead of silently doing nothing)
   template <int BR, int BC>
-  Matrix<S, BR, BC> block(Index r0, Index c0) const {
+  const Matrix<S, BR, BC> block(Index r0, Index c0) const {
     Matrix<S, BR, BC> b;
     for (int i = 0; i < BR; ++i)
       for (int j = 0; j < BC; ++j) b(i, j) = (*this)(r0 + i, c0 + j);
     return b;
   }
   template <int K>
-  Matrix<S, K, 1> head() const {
+  const Matrix<S, K, 1> head() const {
     Matrix<S, K, 1> h;
     for (int i = 0; i < K; ++i) h.v[i] = v[i];
     return h;
   }
   template <int K>
-  Matrix<S, K, 1> tail() const {
+  const Matrix<S, K, 1> tail() const {
     Matrix<S, K, 1> h;
     for (int i = 0; i < K; ++i) h.v[i] = v[N - K + i];
     return h;
   }
-  Matrix<S, R, 1> col(Index j) const {
+  const Matrix<S, R, 1> col(Index j) const {
     Matrix<S, R, 1> c;
     for (int i = 0; i < R; ++i) c.v[i] = (*this)(i, j);
     return c;
@@ -300,6 +302,7 @@ class Matrix {
     return *this / (S)s;
   }
   Matrix& operator*=(S s) { return *this = *this * s; }
+  Matrix& operator*=(const Matrix<S, C, C>& o) { return *this = *this * o; }
   Matrix& operator/=(S s) { return *this = *this / s; }
   template <int C2>
   Matrix<S, R, C2> operator*(const Matrix<S, C, C2>& o) const {
@@ -312,6 +315,44 @@ class Matrix {
       }
     return r;
   }
+  // general inverse by Gauss-Jordan elimination with partial pivoting (Eigen uses cofactors up to 4x4: same value, other rounding)
+  const Matrix inverse() const {
+    static_assert(R == C, "square");
+    Matrix a = *this, inv = Identity();
+    for (int c = 0; c < C; ++c) {
+      int piv = c;
+      for (int r = c + 1; r < R; ++r)
+        if (std::fabs((double)a(r, c)) > std::fabs((double)a(piv, c))) piv = r;
+      if (piv != c)
+        for (int k = 0; k < C; ++k) {
+          std::swap(a(c, k), a(piv, k));
+          std::swap(inv(c, k), inv(piv, k));
+        }
+      const S d = a(c, c);
+      for (int k = 0; k < C; ++k) {
+        a(c, k) = a(c, k) / d;
+        inv(c, k) = inv(c, k) / d;
+      }
+      for (int r = 0; r < R; ++r)
+        if (r != c) {
+          const S f = a(r, c);
+          for (int k = 0; k < C; ++k) {
+            a(r, k) = a(r, k) - f * a(c, k);
+            inv(r, k) = inv(r, k) - f * inv(c, k);
+          }
+        }
+    }
+    return inv;
+  }
+  bool isApprox(const Matrix& o, S prec = S(1e-12)) const {  // Eigen: ||a - b||^2 <= prec^2 min(||a||^2, ||b||^2)
+    return (*this - o).squaredNorm() <= prec * prec * std::min(squaredNorm(), o.squaredNorm());
+  }
+  S trace() const {
+    S t = S(0);
+    for (int i = 0; i < (R < C ? R : C); ++i) t = t + (*this)(i, i);
+    return t;
+  }
+  S mean() const { return sum() / S(N); }
   bool operator==(const Matrix& o) const {
     for (int i = 0; i < N; ++i)
       if (!(v[i] == o.v[i])) return false;
@@ -382,6 +423,7 @@ typedef Matrix<double, 2, 2> Matrix2d;
 typedef Matrix<double, 3, 3> Matrix3d;
 typedef Matrix<double, 4, 4> Matrix4d;
 typedef Matrix<float, 4, 4> Matrix4f;
+typedef Matrix<double, 6, 6> Matrix6d;  // (open3d/utility/Eigen.h puts Matrix6d / Vector6d into namespace Eigen)
 
 // ---- rotations: Hamilton quaternion (w, x, y, z), as much as math.cpp / Transform.cpp / MotionCompensation.cpp use
 template <typename S>
@@ -536,7 +578,7 @@ class Transform {
     }
     return *this;
   }
-  Matrix<S, D + 1, D + 1> matrix() const {
+  const Matrix<S, D + 1, D + 1> matrix() const {
     Matrix<S, D + 1, D + 1> m = Matrix<S, D + 1, D + 1>::Identity();
     for (int i = 0; i < D; ++i) {
       for (int j = 0; j < D; ++j) m(i, j) = lin_(i, j);
@@ -544,11 +586,24 @@ class Transform {
     }
     return m;
   }
+  // matrix() of a non-const transform is writable in Eigen (`T.matrix() *= M`, `T.matrix() = M`): here a copy that is written back into
+  // the transform when the full expression ends
+  struct MatrixAccess : Matrix<S, D + 1, D + 1> {
+    Transform* owner;
+    MatrixAccess(Transform* o, const Matrix<S, D + 1, D + 1>& m) : Matrix<S, D + 1, D + 1>(m), owner(o) {}
+    MatrixAccess(const MatrixAccess&) = delete;
+    ~MatrixAccess() { *owner = static_cast<const Matrix<S, D + 1, D + 1>&>(*this); }
+    MatrixAccess& operator=(const Matrix<S, D + 1, D + 1>& m) {
+      Matrix<S, D + 1, D + 1>::operator=(m);
+      return *this;
+    }
+  };
+  MatrixAccess matrix() { return MatrixAccess(this, static_cast<const Transform*>(this)->matrix()); }
   Matrix<S, D, 1>& translation() { return t_; }
   const Matrix<S, D, 1>& translation() const { return t_; }
   Matrix<S, D, D>& linear() { return lin_; }
   const Matrix<S, D, D>& linear() const { return lin_; }
-  Matrix<S, D, D> rotation() const { return lin_; }  // Isometry: the linear part IS the rotation
+  const Matrix<S, D, D> rotation() const { return lin_; }  // Isometry: the linear part IS the rotation
   Transform inverse() const {  // Isometry: [R t]^-1 = [R^T  -R^T t]
     Transform r;
     r.lin_ = lin_.transpose();
@@ -582,6 +637,14 @@ class Transform {
     return *this;
   }
   S operator()(Index i, Index j) const { return matrix()(i, j); }
+  bool isApprox(const Transform& o, S prec = S(1e-12)) const { return matrix().isApprox(o.matrix(), prec); }
+  template <typename T2>
+  Transform<T2, D, Mode> cast() const {
+    Transform<T2, D, Mode> r;
+    r.lin_ = lin_.template cast<T2>();
+    r.t_ = t_.template cast<T2>();
+    return r;
+  }
 };
 template <typename S, int D>
 Transform<S, D, Isometry> operator*(const Translation<S, D>& t, const Quaternion<S>& q) {

@@ -1,8 +1,9 @@
 // NOT Open3D.  open3d::geometry::PointCloud (v0.15.1) as a plain container with the members open3d_slam's own sources touch, so that
 // those sources can be compiled and run (see ../../Eigen/mini_eigen.hpp, ../../../README.md).  The trivial members are written out
 // ([O3D] marks what restates Open3D behaviour from its documentation / SURVEY.md App. A); the ALGORITHMS (VoxelDownSample,
-// EstimateNormals, RandomDownSample, KD-tree searches, registration) are declared only and abort when called: they are not part of
-// /root/reference, so nothing executed from this build can say anything about them.
+// EstimateNormals, registration) are declared here and SERVED BY THE CPU ORACLE's restatement (open3d_served_by_oracle.cpp), so that
+// the reference's glue around them can run; KD-tree searches and a RandomDownSample that actually drops points abort.  They are not part
+// of /root/reference, so nothing executed from this build can say anything about Open3D itself.
 #pragma once
 #include <memory>
 #include <tuple>
@@ -38,6 +39,9 @@ class PointCloud {
   virtual ~PointCloud() = default;
   std::vector<Eigen::Vector3d> points_, normals_, colors_;
   std::vector<Eigen::Matrix3d> covariances_;
+  // set by this stand-in's EstimateNormals: the oracle's routine it delegates to already normalises and orients (it restates the three
+  // calls the reference always makes together, CloudRegistration.cpp:25-27,53-55), so the two follow-up calls then leave the normals alone
+  bool normals_final_ = false;
   bool HasPoints() const { return points_.size() > 0; }
   bool HasNormals() const { return points_.size() > 0 && normals_.size() == points_.size(); }
   bool HasColors() const { return points_.size() > 0 && colors_.size() == points_.size(); }
@@ -53,6 +57,7 @@ class PointCloud {
   std::shared_ptr<PointCloud> SelectByIndex(const std::vector<size_t>& indices, bool invert = false) const;  // [O3D]
   Eigen::Vector3d GetMinBound() const;
   Eigen::Vector3d GetMaxBound() const;
+  Eigen::Vector3d GetCenter() const;  // [O3D] ComputeCenter: mean of the points (zero for an empty cloud)
   // algorithms: NOT available (abort)
   std::shared_ptr<PointCloud> VoxelDownSample(double voxel_size) const;
   std::shared_ptr<PointCloud> RandomDownSample(double ratio) const;

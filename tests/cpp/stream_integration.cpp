@@ -102,7 +102,23 @@ struct Mapping {
   o3ds::DeviceSubmap map;
   M4 T = M4::Identity(), Tprev = M4::Identity(), odomPrev = M4::Identity();
   bool first = true;
-  double tPre = 0, tReg = 0, tIns = 0, minFitness = 1.0;
+  double tPre = 0, tReg = 0, tIns = 0, tCarve = 0, minFitness = 1.0;
+  int nScansInsertedMap = 0;            // Submap::nScansInsertedMap_
+  size_t nCarved = 0;
+  M4 Tinserted = M4::Identity();        // pose the map builder's cropper still holds when Submap::carve runs (Submap.cpp:56-71)
+  o3d_slam::SpaceCarvingParameters carving;  // Parameters.hpp:85-92 defaults: voxel 0.1, 20 m rays, truncation 0.1, every 10 scans
+  // Submap::insertScan as patched (Submap.cpp:54-72): SubmapCollection::insertScan always asks for carving; Submap::carve acts when the
+  // map is not empty and nScansInsertedMap_ % carveSpaceEveryNscans_ == 1, with the RAW scan
+  void insert(const PointCloud& raw, const PointCloud& wide, const M4& pose) {
+    if (map.size() > 0 && nScansInsertedMap % carving.carveSpaceEveryNscans_ == 1) {
+      const auto t0 = Clock::now();
+      nCarved += map.carve(raw, Eigen::Isometry3d(pose), o3ds::makeCrop(s.cropper, Eigen::Isometry3d(Tinserted)), carving);
+      tCarve += ms(t0, Clock::now());
+    }
+    map.insertScan(wide, Eigen::Isometry3d(pose), s.mapVoxel, o3ds::makeCrop(s.cropper, Eigen::Isometry3d(pose)), s.maxCorr);
+    ++nScansInsertedMap;
+    Tinserted = pose;
+  }
   bool add(const PointCloud& raw, const M4& odomNow) {
     const auto t0 = Clock::now();
     auto wide = o3ds::preprocessScan(raw, s.chain());
@@ -112,7 +128,7 @@ struct Mapping {
     const auto t1 = Clock::now();
     tPre += ms(t0, t1);
     if (first) {
-      map.insertScan(*wide, Eigen::Isometry3d::Identity(), s.mapVoxel, o3ds::makeCrop(s.cropper, Eigen::Isometry3d::Identity()), s.maxCorr);
+      insert(raw, *wide, M4::Identity());
       tIns += ms(t1, Clock::now());
       first = false;
       odomPrev = odomNow;
@@ -126,7 +142,7 @@ struct Mapping {
     if (r.fitness_ < s.minRefinementFitness) return false;
     minFitness = std::min(minFitness, r.fitness_);
     T = r.transformation_;
-    map.insertScan(*wide, Eigen::Isometry3d(T), s.mapVoxel, o3ds::makeCrop(s.cropper, Eigen::Isometry3d(T)), s.maxCorr);
+    insert(raw, *wide, T);
     tIns += ms(t2, Clock::now());
     Tprev = T;
     odomPrev = odomNow;
@@ -224,10 +240,10 @@ int main(int argc, char** argv) {
   std::printf(
       "{\"workload\": \"integration header (what the open3d_slam patch calls), host clouds at every seam, %d raw pts/scan, %d frames, %s\", "
       "\"scans_per_sec\": %.1f, \"scans_per_sec_mapping_only\": %.1f, \"ms_per_scan\": {\"odometry_preprocess\": %.3f, \"odometry_registration\": %.3f, "
-      "\"mapping_preprocess\": %.3f, \"mapping_registration\": %.3f, \"insert\": %.3f}, \"map_points\": %zu, \"min_fitness\": %.4f, "
+      "\"mapping_preprocess\": %.3f, \"mapping_registration\": %.3f, \"insert\": %.3f, \"carve_within_insert\": %.3f}, \"map_points\": %zu, \"carved_points\": %zu, \"min_fitness\": %.4f, "
       "\"final_translation_error_m\": %.5f}\n",
       npts, frames, threads ? "odometry and mapping on two worker threads" : "one thread", 1e3 * frames / total,
       1e3 * frames / (mapping.tPre + mapping.tReg + mapping.tIns), odo.tPre / frames, odo.tReg / frames, mapping.tPre / frames, mapping.tReg / frames,
-      mapping.tIns / frames, mapping.map.size(), mapping.minFitness, dt);
+      mapping.tIns / frames, mapping.tCarve / frames, mapping.map.size(), mapping.nCarved, mapping.minFitness, dt);
   return dt < 0.05 ? 0 : 1;
 }

@@ -76,7 +76,7 @@ int main(int argc, char** argv) {
       for (int i = 0; i < 16; ++i) mapToRangeSensor.m[i] = r.transformation_[i];
     }
     const auto t2 = Clock::now();
-    submap.insertScan(scans[k], *ps.merge_, mapToRangeSensor, Time(), false);
+    submap.insertScan(scans[k], *ps.merge_, mapToRangeSensor, Time(), true);  // SubmapCollection::insertScan always asks for carving (SubmapCollection.cpp:178,189,203)
     const auto t3 = Clock::now();
     if (k > 0) tPre += ms(t0, t1), tReg += ms(t1, t2), tIns += ms(t2, t3);
   }

@@ -239,3 +239,49 @@ def test_constant_velocity_deskew_agrees_with_the_reference(clockwise):
     mine = po.undistort(p, vel[:3], vel[3:], 0.1, clockwise)
     assert np.abs(mine - out).max() <= 2e-14
     assert np.abs(out - p).max() > 1e-3  # it did move something
+
+
+@pytest.mark.parametrize("carve_every", [3, 10])
+def test_the_reference_s_own_frame_loop_agrees_with_the_oracle_loop(carve_every):
+    """Row a10, the glue: LidarOdometry::addRangeScan (Odometry.cpp:32-79) and Mapper::addRangeMeasurement (Mapper.cpp:101-181) with
+    ScanToMapIcp (ScanToMapRegistration.cpp:35-62), SubmapCollection::insertScan (SubmapCollection.cpp:172-207) and Submap::insertScan /
+    carve (Submap.cpp:39-125) -- the reference's code, compiled unchanged and run scan by scan -- against oracle/pipeline.py, the loop
+    the GPU stream is held to (tests/test_pipeline_gpu.py).  The Open3D calls underneath are served by the same oracle on both sides, so
+    what is compared is the orchestration: which volume crops what, the odometry prior of the scan matcher, the map patch it registers
+    against, the fitness gates, when a scan is inserted and when the map is carved (always asked for; every carveSpaceEveryNscans_-th
+    insertion counted from the second).  Same map size after every frame, poses within 1e-10 m / rad (they differ by the rounding of a
+    4x4 inverse and of the first insertion's duplicated points, SURVEY B4, amplified by the registrations), same final map."""
+    import bench
+    from oracle.pipeline import OracleLoop
+
+    mp, op = bench.stream_parameters()
+    mp.mapBuilder_.carving_.carveSpaceEveryNscans_ = carve_every
+    scene = syn.make_scene()
+    poses = syn.figure_eight_poses(200, 0.1)
+    frames = 13 if carve_every == 10 else 8
+    scans = [np.asarray(syn.os128_scan(scene, poses[k], frame=k), dtype=np.float64)[::8] for k in range(frames)]
+    R = ref.ReferenceSlam(mp, op, carve_every_n_scans=carve_every)
+    O = OracleLoop(po, mp, op)
+    worst = 0.0
+    for k, s in enumerate(scans):
+        rc, odom, T, n_map, n_sub = R.add_scan(s, 0.1 * k)
+        O.odometry(s, k)
+        O.mapping(s, k)
+        assert rc == 1 and n_sub == 1
+        assert n_map == len(O.map_p), (k, n_map, len(O.map_p))
+        worst = max(worst, *syn.se3_error(T, O.T), *syn.se3_error(odom, O.odom))
+    assert worst < 1e-10, worst
+    assert O.n_carved > 0  # the carving did act
+    rp, rn = R.map()
+    a, b = _key_order(rp, 0.1), _key_order(O.map_p, 0.1)
+    assert np.abs(rp[a] - O.map_p[b]).max() < 1e-10
+    well = np.abs(rn[a] - O.map_n[b]).max(axis=1) < 1e-9  # a voxel whose normals nearly cancel amplifies the last bits of the pose
+    assert well.mean() > 0.995
+    # the scan the reference's mapper matched last = crop + VoxelDownSample + normals + narrow crop of the oracle's chain, bit for bit
+    mpts, mnrm = R.preprocessed_scan()
+    icp = mp.scanMatcher_.icp_
+    v, n = O._pre(scans[-1], mp.mapBuilder_.cropper_, mp.scanProcessing_.voxelSize_, icp)
+    sc = mp.scanProcessing_.cropper_
+    keep = po.crop_indices(v, po.make_crop(po.CROP_MIN_MAX_RADIUS, rmin=sc.croppingMinRadius_, rmax=sc.croppingMaxRadius_))
+    assert np.array_equal(mpts, v[keep]) and np.array_equal(mnrm, n[keep])
+    R.close()
