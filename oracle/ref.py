@@ -16,6 +16,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "_ref", "libo3dslam_ref.so")
+# the same units with integration/open3d_slam_o3ds.patch applied, linked against the HIP backend: needs a GPU to run
+LIB_PATCHED = os.path.join(HERE, "_ref", "libo3dslam_ref_patched.so")
 REFERENCE = os.environ.get("O3DS_REFERENCE_DIR", "/root/reference")
 
 CROP_NONE, CROP_MAX_RADIUS, CROP_MIN_RADIUS, CROP_MIN_MAX_RADIUS, CROP_CYLINDER = 0, 1, 2, 3, 4  # the oracle's numbering
@@ -225,10 +227,19 @@ class SlamParams(C.Structure):
 class ReferenceSlam:
     """LidarOdometry + Mapper of the reference, fed one scan at a time (SlamWrapper's two workers, one after the other)."""
 
-    def __init__(self, mp, op, carve_every_n_scans=10, submap_radius=20.0, min_movement=0.0, carving=(0.1, 20.0, 0.1, 0.5)):
+    def __init__(self, mp, op, carve_every_n_scans=10, submap_radius=20.0, min_movement=0.0, carving=(0.1, 20.0, 0.1, 0.5), patched=False):
         """mp / op: open3d_slam_amd.parameters.MapperParameters / OdometryParameters (MinMaxRadius croppers, point-to-plane);
-        carving = (voxel, max ray length, truncation, min dot) of SpaceCarvingParameters (Parameters.hpp:85-92 defaults)"""
-        L = lib()
+        carving = (voxel, max ray length, truncation, min dot) of SpaceCarvingParameters (Parameters.hpp:85-92 defaults);
+        patched: the build with integration/open3d_slam_o3ds.patch applied, whose registration / pre-processing / map fusion run on the
+        GPU through libo3ds_backend.so (GPU box only)"""
+        if patched:
+            if not os.path.isfile(LIB_PATCHED):
+                build()
+            L = C.CDLL(LIB_PATCHED)
+        else:
+            L = lib()
+        L.ref_slam_run_stream.restype = C.c_int
+        L.ref_slam_run_stream.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.c_int, C.c_double, C.c_int, _dp, _dp, C.POINTER(C.c_size_t)]
         L.ref_slam_create.restype = C.c_void_p
         L.ref_slam_create.argtypes = [C.POINTER(SlamParams)]
         L.ref_slam_free.argtypes = [C.c_void_p]
@@ -276,3 +287,16 @@ class ReferenceSlam:
         p, nn = np.empty((max(n, 1), 3)), np.empty((max(n, 1), 3))
         self.L.ref_slam_preprocessed_scan(self.h, p.ctypes.data_as(_dp), nn.ctypes.data_as(_dp))
         return p[:n].copy(), nn[:n].copy()
+
+    def run_stream(self, scans32, dt=0.1, threads=False):
+        """all frames through the reference's two workers, timed inside the library: (accepted frames, per-frame mapToRangeSensor,
+        per-frame odomToRangeSensor, total ms, points in the active submap)"""
+        a = np.ascontiguousarray(np.stack([np.asarray(s, dtype=np.float32).reshape(-1, 3) for s in scans32]))
+        f, n = a.shape[0], a.shape[1]
+        poses = np.empty((f, 32))
+        ms, n_map = C.c_double(), C.c_size_t()
+        ok = self.L.ref_slam_run_stream(self.h, a.ctypes.data_as(C.POINTER(C.c_float)), n, f, float(dt), int(bool(threads)), poses.ctypes.data_as(_dp),
+                                        C.byref(ms), C.byref(n_map))
+        M = poses[:, :16].reshape(f, 4, 4).transpose(0, 2, 1).copy()
+        O = poses[:, 16:].reshape(f, 4, 4).transpose(0, 2, 1).copy()
+        return ok, M, O, float(ms.value), int(n_map.value)

@@ -3,7 +3,11 @@
 // oracle/_ref/libo3dslam_ref.so).  This file only marshals plain arrays into the reference's types and calls the reference's functions;
 // it holds no algorithm of its own.  tests/test_oracle_vs_reference.py checks oracle/o3d_oracle.c against it; scripts under
 // tests/golden/ turn its outputs into fixtures for the GPU tests.  Test infrastructure only.
+#include <chrono>
+#include <condition_variable>
 #include <cstdint>
+#include <mutex>
+#include <thread>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -348,5 +352,68 @@ size_t ref_slam_preprocessed_scan(void* h, double* out_pts, double* out_nrm) {
   store(m.points_, out_pts);
   if (m.HasNormals()) store(m.normals_, out_nrm);
   return m.points_.size();
+}
+
+// A whole stream through the two workers, timed inside (the scans are converted to PointClouds of doubles first, untimed: that is the
+// ROS callback's job in the reference).  threads = 0: one worker after the other per scan; 1: odometry and mapping on two threads as
+// SlamWrapper runs them (SlamWrapper.cpp:228-229), the mapper waiting for the odometry of its scan.  poses_out: per frame 16 doubles
+// mapToRangeSensor + 16 doubles odomToRangeSensor (column-major).  Returns the number of frames both workers accepted.
+int ref_slam_run_stream(void* h, const float* scans, size_t n_pts, int n_frames, double dt, int threads, double* poses_out, double* ms_total,
+                        size_t* map_points) {
+  auto* s = static_cast<RefSlam*>(h);
+  std::vector<PointCloud> clouds((size_t)n_frames);
+  for (int k = 0; k < n_frames; ++k) {
+    clouds[k].points_.resize(n_pts);
+    const float* p = scans + (size_t)k * n_pts * 3;
+    for (size_t i = 0; i < n_pts; ++i) clouds[k].points_[i] = Eigen::Vector3d(p[3 * i], p[3 * i + 1], p[3 * i + 2]);
+  }
+  auto stamp = [&](int k) { return o3d_slam::fromUniversal(0) + o3d_slam::fromSeconds(1000.0 + dt * k); };
+  auto record = [&](int k) {
+    const Eigen::Matrix4d M = s->mapper->getMapToRangeSensor(stamp(k)).matrix(), O = s->odometry->getOdomToRangeSensor(stamp(k)).matrix();
+    for (int c = 0; c < 4; ++c)
+      for (int r = 0; r < 4; ++r) poses_out[(size_t)k * 32 + c * 4 + r] = M(r, c), poses_out[(size_t)k * 32 + 16 + c * 4 + r] = O(r, c);
+  };
+  int ok = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  if (!threads) {
+    for (int k = 0; k < n_frames; ++k) {
+      const bool a = s->odometry->addRangeScan(clouds[k], stamp(k));
+      const bool b = a && s->mapper->addRangeMeasurement(clouds[k], stamp(k));
+      record(k);
+      ok += (a && b) ? 1 : 0;
+    }
+  } else {
+    std::mutex m;
+    std::condition_variable cv;
+    int odomDone = 0;
+    std::vector<char> odomOk((size_t)n_frames, 0);
+    std::thread odometryWorker([&] {
+      for (int k = 0; k < n_frames; ++k) {
+        const bool a = s->odometry->addRangeScan(clouds[k], stamp(k));
+        std::lock_guard<std::mutex> l(m);
+        odomOk[k] = a ? 1 : 0;
+        odomDone = k + 1;
+        cv.notify_all();
+      }
+    });
+    std::thread mappingWorker([&] {
+      for (int k = 0; k < n_frames; ++k) {
+        bool a;
+        {
+          std::unique_lock<std::mutex> l(m);
+          cv.wait(l, [&] { return odomDone > k; });
+          a = odomOk[k] != 0;
+        }
+        const bool b = a && s->mapper->addRangeMeasurement(clouds[k], stamp(k));
+        record(k);
+        ok += (a && b) ? 1 : 0;
+      }
+    });
+    odometryWorker.join();
+    mappingWorker.join();
+  }
+  *ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  *map_points = s->mapper->getActiveSubmap().getMapPointCloud().points_.size();
+  return ok;
 }
 }  // extern "C"

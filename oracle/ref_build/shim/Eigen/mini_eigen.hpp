@@ -411,6 +411,17 @@ class Matrix<S, Dynamic, 1> {
   const S& operator()(Index i) const { return v[i]; }
 };
 
+// Eigen::Map<const M>(ptr): a read-only view in Eigen, a copy here (the writable Map<M> is deliberately left undefined)
+template <typename T>
+class Map;
+template <typename S, int R, int C>
+class Map<const Matrix<S, R, C>> : public Matrix<S, R, C> {
+ public:
+  explicit Map(const S* p) {
+    for (int i = 0; i < R * C; ++i) this->v[i] = p[i];
+  }
+};
+
 typedef Matrix<double, 2, 1> Vector2d;
 typedef Matrix<double, 3, 1> Vector3d;
 typedef Matrix<double, 4, 1> Vector4d;

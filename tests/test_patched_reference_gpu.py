@@ -1,0 +1,114 @@
+"""open3d_slam's OWN Odometry.cpp / Mapper.cpp / ScanToMapRegistration.cpp / Submap.cpp / SubmapCollection.cpp with
+integration/open3d_slam_o3ds.patch applied, compiled (oracle/ref_build, where the checkout is) and RUN here against libo3ds_backend.so:
+the patched reference driving the MI355X -- what a maintainer who applies the patch gets, as far as this image allows (Eigen and the
+open3d::geometry::PointCloud container are stand-ins, oracle/ref_build/shim; every Open3D ALGORITHM on the path is replaced by the
+patch and runs on the device).  Checked against (a) the device-resident Python loop, (b) the CPU oracle loop -- which itself agrees with
+the UNPATCHED reference's loop (tests/test_oracle_vs_reference.py) -- and timed: the scans/s of the patched reference's own two workers.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from open3d_slam_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _patched_available():
+    from oracle import ref
+
+    return os.path.isfile(ref.LIB_PATCHED) or ref.sources_present()
+
+
+def _scans(frames, stride=1):
+    scene = syn.make_scene()
+    poses = syn.figure_eight_poses(200, 0.1)
+    return [np.asarray(syn.os128_scan(scene, poses[k], frame=k), dtype=np.float32)[::stride] for k in range(frames)], poses
+
+
+def _device_resident_loop(scans, mp, op):
+    from open3d_slam_amd import backend
+    from open3d_slam_amd.mapper import Mapper
+    from open3d_slam_amd.odometry import LidarOdometry
+    from open3d_slam_amd.pointcloud import PointCloud
+
+    be = backend.Backend(0)
+    odo = LidarOdometry(be)
+    odo.setParameters(op)
+    mapper = Mapper(be, odo)
+    mapper.setParameters(mp)
+    out = []
+    for k, raw in enumerate(scans):
+        cloud = PointCloud.from_pointcloud2(be, raw)
+        assert odo.addRangeScan(cloud, 0.1 * k) and mapper.addRangeMeasurement(cloud, 0.1 * k)
+        cloud.release()
+        out.append((mapper.getMapToRangeSensor().copy(), odo.getOdomToRangeSensor(0.1 * k).copy()))
+    n_map = len(mapper.getActiveSubmap().getMapPointCloud())
+    be.close()
+    return out, n_map
+
+
+@pytest.mark.skipif(not _patched_available(), reason="oracle/_ref/libo3dslam_ref_patched.so is neither built nor buildable here")
+def test_the_patched_reference_runs_on_the_gpu_and_matches_the_device_loop_and_the_oracle():
+    import bench
+    from oracle import pyoracle as po
+    from oracle import ref
+    from oracle.pipeline import OracleLoop
+
+    mp, op = bench.stream_parameters()
+    frames = 24  # carving acts at the 2nd, 12th and 22nd insertion
+    scans, truth = _scans(frames)
+    R = ref.ReferenceSlam(mp, op, patched=True)
+    ok, M, O, ms, n_map = R.run_stream(scans)
+    R.close()
+    assert ok == frames
+    dev, dev_map = _device_resident_loop(scans, mp, op)
+    worst = max(max(*syn.se3_error(M[k], dev[k][0]), *syn.se3_error(O[k], dev[k][1])) for k in range(frames))
+    assert worst <= 1e-9, worst  # the same kernels on the same values, by way of host clouds of doubles at every seam
+    assert n_map == dev_map
+    loop = OracleLoop(po, mp, op)
+    worst_cpu = 0.0
+    for k, s in enumerate(scans):
+        s64 = np.asarray(s, dtype=np.float64)
+        loop.odometry(s64, k)
+        loop.mapping(s64, k)
+        worst_cpu = max(worst_cpu, *syn.se3_error(M[k], loop.T))
+    assert worst_cpu <= 1e-3, worst_cpu  # f32 storage on the device (BASELINE tolerance); measured ~1e-5
+    assert abs(n_map - len(loop.map_p)) <= 0.002 * n_map
+    rel = np.linalg.inv(truth[0]) @ truth[frames - 1]
+    assert np.linalg.norm(M[-1][:3, 3] - rel[:3, 3]) < 0.05
+
+
+@pytest.mark.skipif(not _patched_available(), reason="oracle/_ref/libo3dslam_ref_patched.so is neither built nor buildable here")
+def test_scans_per_second_of_the_patched_reference(record_property):
+    """200 full-size frames through the patched reference's two workers, serial and on two threads (timed inside the library; the raw
+    scans are host PointClouds of doubles, as rosToOpen3d hands them over).  Writes gpurun_out/patched_reference_stream.json."""
+    import bench
+    from oracle import ref
+
+    mp, op = bench.stream_parameters()
+    scans, truth = _scans(200)
+    out = {}
+    for name, threads in (("serial", False), ("two_threads", True)):
+        warm = ref.ReferenceSlam(mp, op, patched=True)
+        warm.run_stream(scans[:8], threads=threads)
+        warm.close()
+        R = ref.ReferenceSlam(mp, op, patched=True)
+        ok, M, O, ms, n_map = R.run_stream(scans, threads=threads)
+        R.close()
+        rel = np.linalg.inv(truth[0]) @ truth[-1]
+        err = float(np.linalg.norm(M[-1][:3, 3] - rel[:3, 3]))
+        assert ok == 200 and err < 0.05, (ok, err)
+        out[name] = {"scans_per_sec": 200e3 / ms, "ms_total": ms, "map_points": n_map, "final_translation_error_m": err}
+        record_property(f"patched_reference_{name}_scans_per_sec", 200e3 / ms)
+    out["what"] = ("open3d_slam's own LidarOdometry::addRangeScan + Mapper::addRangeMeasurement (reference sources with "
+                   "integration/open3d_slam_o3ds.patch applied, stand-in Eigen / PointCloud container) on libo3ds_backend.so, 200 frames x "
+                   "131072 points, carving every 10th insertion as the reference does")
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "patched_reference_stream.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    assert out["serial"]["scans_per_sec"] > 100
