@@ -35,7 +35,7 @@ def sources_present() -> bool:
 def build(force: bool = False) -> str | None:
     """compile the reference's units where they lie (only when the checkout is present); returns the library path or None"""
     if sources_present():
-        cmd = ["make", "-C", os.path.join(HERE, "ref_build"), f"REF={REFERENCE}"] + (["-B"] if force else [])
+        cmd = ["make", "-j", str(min(8, os.cpu_count() or 1)), "-C", os.path.join(HERE, "ref_build"), f"REF={REFERENCE}"] + (["-B"] if force else [])
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("oracle/_ref build failed:\n" + r.stdout[-2000:] + r.stderr[-4000:])
