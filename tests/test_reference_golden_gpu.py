@@ -158,3 +158,37 @@ def test_constant_velocity_deskew_agrees_with_the_reference(backend_f64, g, cloc
     got = be.download(c)[0]
     assert np.abs(got - g[f"deskew_out_{clockwise}"]).max() < 1e-8
     be.free(c)
+
+
+def test_the_reference_s_own_conversion_tests_hold_on_the_device_path(backend_f32, backend_f64):
+    """The only tests the reference ships that touch a row of the path: open3d_utils/open3d_conversions/test/
+    test_open3d_conversions.cpp :31 open3dToRos_uncolored, :50 open3dToRos_colored, :77 rosToOpen3d_uncolored, :110 rosToOpen3d_colored --
+    five points (0.5 i, i^2, 10.5 i), colours (2 i, 5 i, 10 i) / 255, exact EXPECT_EQ on float fields and uint8 colours.  Here the same
+    vectors go through the device ingest / egress of row f4 (o3ds_cloud_upload_f32, o3ds_cloud_set_colors_from_records,
+    o3ds_cloud_download_f32), which stand where rosToOpen3d / open3dToRos stand."""
+    i = np.arange(5, dtype=np.float64)
+    pts = np.stack([0.5 * i, i * i, 10.5 * i], axis=1)
+    col = np.stack([2 * i / 255.0, 5 * i / 255.0, 10 * i / 255.0], axis=1)
+    for be in (backend_f32, backend_f64):
+        # open3dToRos, uncolored and colored: float32 x y z at 0 / 4 / 8; "rgb" packed b g r in the bytes of the float at 16, step 32
+        c = be.upload(pts)
+        rec = be.download_f32(c, point_step=16)
+        assert np.array_equal(rec.view(np.float32).reshape(5, 4)[:, :3], pts.astype(np.float32))
+        be.set_colors(c, col)
+        rec = be.download_f32(c, point_step=32, off_rgb=16, rgb_rounding=0)
+        assert np.array_equal(rec.view(np.float32).reshape(5, 8)[:, :3], pts.astype(np.float32))
+        assert np.array_equal(rec[:, 18], (2 * i).astype(np.uint8)) and np.array_equal(rec[:, 17], (5 * i).astype(np.uint8))  # r, g
+        assert np.array_equal(rec[:, 16], (10 * i).astype(np.uint8))  # b
+        be.free(c)
+        # rosToOpen3d, uncolored and colored
+        wire = np.zeros((5, 32), dtype=np.uint8)
+        wire[:, :12] = pts.astype(np.float32).view(np.uint8).reshape(5, 12)
+        wire[:, 18], wire[:, 17], wire[:, 16] = (2 * i).astype(np.uint8), (5 * i).astype(np.uint8), (10 * i).astype(np.uint8)
+        c = be.upload_f32(wire)
+        got = be.download(c)[0]
+        assert np.array_equal(got, pts) and not be.has_colors(c)  # every value of the vector is a float32
+        be.set_colors_from_records(c, wire, 16, backend.COLOR_FIELD_RGB)
+        assert be.has_colors(c)
+        want = col if be is backend_f64 else col.astype(np.float32).astype(np.float64)  # f32 storage keeps the colour as a float32
+        assert np.array_equal(be.get_colors(c), want)
+        be.free(c)
