@@ -2034,7 +2034,20 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
   const size_t n = in.n;
   if (n == 0) return O3DS_OK;
   double ox = 0, oy = 0, oz = 0;
-  if (mode == 0) {  // [O3D] voxel_min_bound = GetMinBound() - voxel_size * 0.5
+  // VoxelDownSample proper: no sort (cloud_kernels.hpp, VoxTable); O3DS_VOXEL_SORT=1 keeps the sort-based path below for A/B runs
+  static const bool voxel_sort = getenv("O3DS_VOXEL_SORT") != nullptr;
+  const bool table_path = mode == 0 && !voxel_sort && n < ((size_t)1 << 30);
+  double* d_box = nullptr;  // table path: the box stays on the device until the call's one synchronisation (bbox_final_kernel)
+  if (table_path) {
+    const int g = grid_for(n, 1024);
+    double* d_blocks = nullptr;
+    TMP_ALLOC(d_blocks, sizeof(double) * 6 * (size_t)g);
+    TMP_ALLOC(d_box, sizeof(double) * 6);
+    CropDev all{};
+    bbox_kernel<P4><<<g, kBlock, 0, h->stream>>>((const P4*)in.pts, n, filter ? crop : all, d_blocks);
+    bbox_final_kernel<<<1, 64, 0, h->stream>>>(d_blocks, g, d_box, (double*)h->h_pin_dev);
+    HIP_TRY(hipGetLastError());
+  } else if (mode == 0) {  // [O3D] voxel_min_bound = GetMinBound() - voxel_size * 0.5
     double mn[3], mx[3];
     int rc = bbox_of<P4>(h, (const P4*)in.pts, n, mn, mx, filter ? &crop : nullptr);
     if (rc) return rc;
@@ -2052,9 +2065,7 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
     box_copy(out, in);
   }
   if (out.has_box) box_inflate(out);
-  // VoxelDownSample proper: no sort (cloud_kernels.hpp, VoxTable); O3DS_VOXEL_SORT=1 keeps the sort-based path below for A/B runs
-  static const bool voxel_sort = getenv("O3DS_VOXEL_SORT") != nullptr;
-  if (mode == 0 && !voxel_sort && n < ((size_t)1 << 30)) {
+  if (table_path) {
     size_t cap = 1024;
     while (cap < 2 * n) cap <<= 1;
     // the handle's table: all 0xff between calls (vox_mean_kernel empties the slots a call used), grown to the largest cloud seen
@@ -2081,7 +2092,7 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
     static const bool always_clear = getenv("O3DS_ALWAYS_CLEAR") != nullptr;
     if (!h->voxtab_clean || always_clear) HIP_TRY(hipMemsetAsync(tab, 0xff, 16 * cap + 16, h->stream));
     h->voxtab_clean = false;
-    vox_insert_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>((const P4*)in.pts, n, ox, oy, oz, voxel, crop, filter ? 1 : 0, t, slot_of);
+    vox_insert_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>((const P4*)in.pts, n, d_box, voxel, crop, filter ? 1 : 0, t, slot_of);
     // voxels numbered in order of first appearance: scan over "point i opens its voxel", the flag computed as the scan loads it; the
     // number of voxels goes straight to the pinned block
     int rc = O3DS_OK;
@@ -2107,6 +2118,16 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
     if (m == 0) {  // every point outside the volume: nothing was entered
       h->voxtab_clean = true;
       return O3DS_OK;
+    }
+    {  // the box the grid was anchored at, now that the host may look: the checks and the bookkeeping the sort path does up front
+      const double* hb = (const double*)h->h_pin;
+      const double mn[3] = {hb[0], hb[1], hb[2]}, mx[3] = {hb[3], hb[4], hb[5]};
+      if (voxel * 2147483647.0 < std::max({mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]}) + voxel)
+        return fail(h, O3DS_ERR_INVALID_ARG, "[VoxelDownSample] voxel_size is too small.");  // (the table is cleared before its next use)
+      out.has_box = std::isfinite(mn[0] + mn[1] + mn[2] + mx[0] + mx[1] + mx[2]);  // voxel means lie in the box of the points they average
+      out.box_padded = false;
+      for (int a = 0; a < 3; ++a) out.bmn[a] = mn[a], out.bmx[a] = mx[a];
+      if (out.has_box) box_inflate(out);
     }
     TMP_ALLOC(seg_cnt, sizeof(int) * (size_t)m);
     TMP_ALLOC(seg_start, sizeof(int) * (size_t)m);

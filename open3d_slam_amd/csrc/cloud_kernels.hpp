@@ -611,9 +611,36 @@ __global__ __launch_bounds__(kBlock) void scan_local_fn_kernel(Load in, T* __res
   if (threadIdx.x == kBlock - 1) block_sums[blockIdx.x] = woff + x;
 }
 
+// The g per-block boxes of bbox_kernel folded into one: {min x y z, max x y z} to device memory (the next kernel reads the grid origin from
+// there) and to the handle's pinned block (the host reads it after the call's one synchronisation) -- so that a bounding box that only
+// anchors a voxel grid costs a 4-us launch on the chain instead of a host round trip
+__global__ __launch_bounds__(64) void bbox_final_kernel(const double* __restrict__ blocks, int g, double* __restrict__ dev_out, double* __restrict__ host_out) {
+  double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+  for (int b = threadIdx.x; b < g; b += 64)
+    for (int a = 0; a < 3; ++a) {
+      mn[a] = fmin(mn[a], blocks[(size_t)b * 6 + a]);
+      mx[a] = fmax(mx[a], blocks[(size_t)b * 6 + 3 + a]);
+    }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      mn[a] = fmin(mn[a], __shfl_xor(mn[a], m, 64));
+      mx[a] = fmax(mx[a], __shfl_xor(mx[a], m, 64));
+    }
+  }
+  if (threadIdx.x == 0)
+    for (int a = 0; a < 3; ++a) {
+      dev_out[a] = host_out[a] = mn[a];
+      dev_out[3 + a] = host_out[3 + a] = mx[a];
+    }
+}
+
+// box: {min x y z, ...} of the points the grid is anchored at; [O3D] voxel_min_bound = GetMinBound() - voxel_size * 0.5
 template <typename P4>
-__global__ __launch_bounds__(kBlock) void vox_insert_kernel(const P4* __restrict__ pts, size_t n, double ox, double oy, double oz, double v,
+__global__ __launch_bounds__(kBlock) void vox_insert_kernel(const P4* __restrict__ pts, size_t n, const double* __restrict__ box, double v,
                                                             CropDev crop, int filter, VoxTable t, int* __restrict__ slot_of) {
+  const double ox = box[0] - v * 0.5, oy = box[1] - v * 0.5, oz = box[2] - v * 0.5;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
     const P4 p = pts[i];
     const double x = (double)p.x, y = (double)p.y, z = (double)p.z;
