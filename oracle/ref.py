@@ -64,7 +64,7 @@ def lib():
         L.ref_overlap.restype = None
         L.ref_overlap.argtypes = [_dp, C.c_size_t, _dp, C.c_size_t, _dp, C.c_double, C.c_size_t, _i64p, C.POINTER(C.c_size_t), _i64p, C.POINTER(C.c_size_t)]
         L.ref_dense_fuse.restype = C.c_size_t
-        L.ref_dense_fuse.argtypes = [_dp, _dp, C.c_size_t, C.c_double, C.c_int, _dp, _dp, _i32p, _i32p]
+        L.ref_dense_fuse.argtypes = [_dp, _dp, C.c_size_t, C.c_double, C.c_int, _dp, _dp, _dp, _i32p, _i32p]
         L.ref_dense_carve_keys.restype = C.c_size_t
         L.ref_dense_carve_keys.argtypes = [_dp, C.c_size_t, _dp, _dp, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, _i32p, C.c_size_t]
         L.ref_voxel_idx.restype = None
@@ -167,16 +167,17 @@ def overlap_indices(src, tgt, T=None, voxel=0.5, min_points=1):
     return np.sort(os_[: ns.value]), np.sort(ot[: nt.value])
 
 
-def dense_fuse(pts, nrm, voxel, batches=1):
-    """VoxelizedPointCloud::insert (as `batches` consecutive scans) + toPointCloud (Voxel.cpp:66-114), in the hash map's order:
-    (means, mean normals | None, counts, voxel keys)"""
+def dense_fuse(pts, nrm, voxel, batches=1, T_after=None):
+    """VoxelizedPointCloud::insert (as `batches` consecutive scans) [+ ::transform(T_after)] + toPointCloud (Voxel.cpp:49-114), in the hash
+    map's order: (means, mean normals | None, counts, voxel keys -- which a transform leaves as they were)"""
     pts, pp = _d(pts)
     nr, np_ = _opt(nrm)
     n = len(pts)
     op, on = np.empty((max(n, 1), 3)), np.empty((max(n, 1), 3))
     cnt, keys = np.empty(max(n, 1), np.int32), np.empty((max(n, 1), 3), np.int32)
-    m = lib().ref_dense_fuse(pp, np_, n, voxel, int(batches), op.ctypes.data_as(_dp), on.ctypes.data_as(_dp), cnt.ctypes.data_as(_i32p),
-                             keys.ctypes.data_as(_i32p))
+    Tp = None if T_after is None else _pose(T_after)
+    m = lib().ref_dense_fuse(pp, np_, n, voxel, int(batches), None if Tp is None else Tp[1], op.ctypes.data_as(_dp), on.ctypes.data_as(_dp),
+                             cnt.ctypes.data_as(_i32p), keys.ctypes.data_as(_i32p))
     assert m != 2 ** 64 - 1
     return op[:m].copy(), (on[:m].copy() if nrm is not None else None), cnt[:m].copy(), keys[:m].copy()
 
@@ -191,6 +192,26 @@ def dense_carve_keys(scan, sensor, map_pts, voxel, radius=0.1, max_length=20.0, 
     k = lib().ref_dense_carve_keys(sp, len(scan), snp, mpp, len(mp), voxel, radius, max_length, truncation, int(bool(dedup_scan)), out.ctypes.data_as(_i32p), cap)
     assert k <= cap
     return out[:k].copy()
+
+
+def submap_dense(scans, poses, voxel=0.1, crop_rmax=15.0, carve_every=10, radius=0.1, max_length=20.0, truncation=0.1, T_after=None):
+    """Submap::insertScanDenseMap over raw scans (equal sizes, sensor frame) at the given poses, carving asked for every time [+ Submap::transform]:
+    (voxel means sorted by key, keys, counts, number of voxels after every scan)"""
+    L = lib()
+    L.ref_submap_dense.restype = C.c_size_t
+    L.ref_submap_dense.argtypes = [_dp, C.c_size_t, C.c_int, _dp, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double, _dp, _dp, _i32p, _i32p,
+                                   C.POINTER(C.c_size_t), C.c_size_t]
+    a = np.ascontiguousarray(np.stack([np.asarray(s, dtype=np.float64).reshape(-1, 3) for s in scans]))
+    f, n = a.shape[0], a.shape[1]
+    P = np.ascontiguousarray(np.stack([np.asarray(T, dtype=np.float64).reshape(4, 4).T.reshape(-1) for T in poses]))
+    cap = f * n + 16
+    op, ok, oc = np.empty((cap, 3)), np.empty((cap, 3), np.int32), np.empty(cap, np.int32)
+    sizes = (C.c_size_t * f)()
+    Tp = None if T_after is None else _pose(T_after)
+    m = L.ref_submap_dense(a.ctypes.data_as(_dp), n, f, P.ctypes.data_as(_dp), voxel, crop_rmax, int(carve_every), radius, max_length, truncation,
+                           None if Tp is None else Tp[1], op.ctypes.data_as(_dp), ok.ctypes.data_as(_i32p), oc.ctypes.data_as(_i32p), sizes, cap)
+    o = np.lexsort((ok[:m, 2], ok[:m, 1], ok[:m, 0]))
+    return op[:m][o], ok[:m][o], oc[:m][o], [int(x) for x in sizes]
 
 
 def voxel_idx(p, voxel):

@@ -16,6 +16,7 @@
 #include "open3d_slam/Mapper.hpp"
 #include "open3d_slam/MotionCompensation.hpp"
 #include "open3d_slam/Odometry.hpp"
+#include "open3d_slam/Submap.hpp"
 #include "open3d_slam/SubmapCollection.hpp"
 #include "open3d_slam/Parameters.hpp"
 #include "open3d_slam/TransformInterpolationBuffer.hpp"
@@ -165,16 +166,17 @@ void ref_overlap(const double* src, size_t n_src, const double* tgt, size_t n_tg
   *n_out_tgt = it.size();
 }
 
-// VoxelizedPointCloud::insert (n_batches consecutive ranges of the input, as consecutive scans) + toPointCloud (Voxel.cpp:66-114), plus the
+// VoxelizedPointCloud::insert (n_batches consecutive ranges of the input, as consecutive scans) [+ ::transform] + toPointCloud (Voxel.cpp:49-114), plus the
 // voxel keys and counts in the same (hash map) order; returns the number of voxels
-size_t ref_dense_fuse(const double* pts, const double* nrm, size_t n, double voxel, int n_batches, double* out_pts, double* out_nrm, int32_t* out_counts,
-                      int32_t* out_keys) {
+size_t ref_dense_fuse(const double* pts, const double* nrm, size_t n, double voxel, int n_batches, const double* T_after /* may be null */, double* out_pts,
+                      double* out_nrm, int32_t* out_counts, int32_t* out_keys) {
   o3d_slam::VoxelizedPointCloud map(Eigen::Vector3d::Constant(voxel));
   if (n_batches < 1) n_batches = 1;
   for (int b = 0; b < n_batches; ++b) {
     const size_t lo = n * (size_t)b / (size_t)n_batches, hi = n * (size_t)(b + 1) / (size_t)n_batches;
     map.insert(make_cloud(pts + 3 * lo, nrm ? nrm + 3 * lo : nullptr, nullptr, hi - lo));
   }
+  if (T_after) map.transform(o3d_slam::Transform(matrix_from_colmajor(T_after)));  // VoxelizedPointCloud::transform (Voxel.cpp:49-64), as written
   const PointCloud out = map.toPointCloud();
   store(out.points_, out_pts);
   if (nrm) store(out.normals_, out_nrm);
@@ -415,5 +417,41 @@ int ref_slam_run_stream(void* h, const float* scans, size_t n_pts, int n_frames,
   *ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   *map_points = s->mapper->getActiveSubmap().getMapPointCloud().points_.size();
   return ok;
+}
+
+// Submap::insertScanDenseMap (Submap.cpp:77-92) for a sequence of raw scans (n_pts each, sensor frame) at the given poses, carving asked
+// for every time as SlamWrapper's dense-map worker does (the every-N-scans gate is Submap::carve's, :126-136); then, optionally,
+// Submap::transform (Submap.cpp:94-107).  Out: the dense map as toPointCloud gives it, with the voxel keys; sizes_out[k] = voxels after scan k.
+size_t ref_submap_dense(const double* scans, size_t n_pts, int n_scans, const double* poses /* n_scans x 16, column-major */, double voxel, double crop_rmax,
+                        int carve_every, double radius, double max_length, double truncation, const double* T_after, double* out_pts, int32_t* out_keys,
+                        int32_t* out_counts, size_t* sizes_out, size_t cap) {
+  o3d_slam::MapperParameters mp;
+  mp.denseMapBuilder_.mapVoxelSize_ = voxel;
+  mp.denseMapBuilder_.cropper_.cropperName_ = "MaxRadius";
+  mp.denseMapBuilder_.cropper_.croppingMaxRadius_ = crop_rmax;
+  mp.denseMapBuilder_.carving_.carveSpaceEveryNscans_ = carve_every;
+  mp.denseMapBuilder_.carving_.neighborhoodRadiusDenseMap_ = radius;
+  mp.denseMapBuilder_.carving_.maxRaytracingLength_ = max_length;
+  mp.denseMapBuilder_.carving_.truncationDistance_ = truncation;
+  o3d_slam::Submap sub(0, 0);
+  sub.setParameters(mp);
+  for (int k = 0; k < n_scans; ++k) {
+    const PointCloud raw = make_cloud(scans + (size_t)k * n_pts * 3, nullptr, nullptr, n_pts);
+    sub.insertScanDenseMap(raw, o3d_slam::Transform(matrix_from_colmajor(poses + 16 * k)), o3d_slam::fromUniversal(1000 + k), true);
+    if (sizes_out) sizes_out[k] = sub.getDenseMap().size();
+  }
+  if (T_after) sub.transform(o3d_slam::Transform(matrix_from_colmajor(T_after)));
+  const auto& map = sub.getDenseMap();
+  size_t k = 0;
+  for (const auto& v : map.voxels_) {
+    if (v.second.numAggregatedPoints_ <= 0) continue;
+    if (k < cap) {
+      const Eigen::Vector3d p = v.second.getAggregatedPosition();
+      for (int a = 0; a < 3; ++a) out_pts[3 * k + a] = p(a), out_keys[3 * k + a] = v.first(a);
+      out_counts[k] = v.second.numAggregatedPoints_;
+    }
+    ++k;
+  }
+  return k;
 }
 }  // extern "C"

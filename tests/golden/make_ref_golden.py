@@ -95,6 +95,11 @@ def main():
     o = np.lexsort((fk[:, 2], fk[:, 1], fk[:, 0]))
     g["dense_pts"], g["dense_nrm"], g["dense_voxel"] = dp, dn, np.array([0.25])
     g["dense_out_pts"], g["dense_out_nrm"], g["dense_out_cnt"], g["dense_out_keys"] = fp[o], fn[o], fc[o], fk[o]
+    # ... and moved as Submap::transform moves it (VoxelizedPointCloud::transform, Voxel.cpp:49-64: keys stay, the isometry is applied to the SUMS)
+    tp_, tn_, tc_, tk_ = ref.dense_fuse(dp.astype(np.float64), dn.astype(np.float64), 0.25, batches=3, T_after=A)
+    o2 = np.lexsort((tk_[:, 2], tk_[:, 1], tk_[:, 0]))
+    assert np.array_equal(tk_[o2], fk[o])
+    g["dense_tf_out_pts"], g["dense_tf_out_nrm"] = tp_[o2], tn_[o2]
     dscan = f32(rng.normal(size=(400, 3)) * [1.5, 1.5, 0.4])
     keys = ref.dense_carve_keys(dscan.astype(np.float64), np.zeros(3), dp.astype(np.float64), 0.25, radius=0.25, max_length=10.0, truncation=0.2,
                                 dedup_scan=True)

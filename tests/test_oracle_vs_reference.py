@@ -285,3 +285,41 @@ def test_the_reference_s_own_frame_loop_agrees_with_the_oracle_loop(carve_every)
     keep = po.crop_indices(v, po.make_crop(po.CROP_MIN_MAX_RADIUS, rmin=sc.croppingMinRadius_, rmax=sc.croppingMaxRadius_))
     assert np.array_equal(mpts, v[keep]) and np.array_equal(mnrm, n[keep])
     R.close()
+
+
+def test_submap_dense_map_insertion_and_carving_follow_the_reference():
+    """Submap::insertScanDenseMap (Submap.cpp:77-92) run from the reference: crop the raw scan in the SENSOR frame (the cropper is put at
+    the identity), place it with o3d_slam::transform, fuse; carving asked for on every scan and performed when nScansInsertedDenseMap_ %
+    carveSpaceEveryNscans_ == 1, with the RAW (sensor-frame) scan against the map-frame sensor position (Submap.cpp:88 -- as written).
+    The oracle's dense_fuse / dense_carve, called in that order with those arguments (what tests/test_pipeline_gpu.py holds the device
+    mirror to), give the same voxels and the same means."""
+    scene = syn.make_scene()
+    poses = syn.figure_eight_poses(200, 0.1)[10:14]
+    scans = [np.asarray(syn.vlp16_scan(scene, T), dtype=np.float64)[::4] for T in poses]
+    voxel, rmax, every = 0.1, 15.0, 2
+    rp, rk, rc, sizes = ref.submap_dense(scans, poses, voxel=voxel, crop_rmax=rmax, carve_every=every)
+    # the same sequence on the oracle: a dict voxel key -> (sum, count)
+    acc = {}
+    n_inserted = 0
+    mine_sizes = []
+    for raw, T in zip(scans, poses):
+        inside = raw[np.linalg.norm(raw, axis=1) <= rmax]
+        placed = po.transform_points(inside, T)
+        for p in placed:
+            k = tuple(np.floor(p * (1.0 / voxel)).astype(np.int64))
+            s, c = acc.get(k, (np.zeros(3), 0))
+            acc[k] = (s + p, c + 1)
+        if acc and n_inserted % every == 1:
+            keys = list(acc.keys())
+            means = np.array([acc[k][0] / acc[k][1] for k in keys])
+            gone = po.dense_carve(raw, T[:3, 3], means, voxel, radius=0.1, max_length=20.0, truncation=0.1)
+            for k, g in zip(keys, gone):
+                if g:
+                    del acc[k]
+        n_inserted += 1
+        mine_sizes.append(len(acc))
+    assert mine_sizes == sizes and sizes[1] < sizes[0] + len(scans[1])  # the carving did remove voxels at the second scan
+    keys = sorted(acc.keys())
+    assert np.array_equal(np.array(keys, dtype=np.int64), rk.astype(np.int64))
+    means = np.array([acc[k][0] / acc[k][1] for k in keys])
+    assert np.array_equal(means, rp) and np.array_equal(np.array([acc[k][1] for k in keys]), rc)

@@ -136,6 +136,20 @@ def test_dense_voxel_map_fuses_and_carves_like_the_reference(backend_f64, g):
     keys = np.floor(gp * (1.0 / voxel)).astype(np.int64)
     assert np.array_equal(keys, g["dense_out_keys"].astype(np.int64))
     assert np.abs(gp - g["dense_out_pts"]).max() < 1e-8 and np.abs(gn - g["dense_out_nrm"]).max() < 1e-8
+    # Submap::transform's dense part (VoxelizedPointCloud::transform, Voxel.cpp:49-64) on a copy of the map: keys stay, sums are moved as points
+    dm2 = be.dense_map_create(voxel)
+    c = be.upload(pts, nrm)
+    be.dense_map_insert(dm2, c)
+    be.free(c)
+    before_id = be.dense_map_to_cloud(dm2)
+    o2 = _key_order(be.download(before_id)[0], voxel)
+    be.dense_map_transform(dm2, g["tf_T"])
+    moved_id = be.dense_map_to_cloud(dm2)
+    mp_, mn_ = be.download(moved_id)
+    assert np.abs(mp_[o2] - g["dense_tf_out_pts"]).max() < 1e-7 and np.abs(mn_[o2] - g["dense_tf_out_nrm"]).max() < 1e-7
+    for cid in (before_id, moved_id):
+        be.free(cid)
+    be.dense_map_free(dm2)
     radius, max_len, trunc = g["dense_carve_params"]
     s = be.upload(_f64(g["dense_carve_scan"]))
     removed = be.dense_map_carve(dm, s, np.zeros(3), radius=float(radius), max_length=float(max_len), truncation=float(trunc))
