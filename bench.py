@@ -414,8 +414,8 @@ def run_m1(be, world, s_id, t_id, steps, warmup, barrier, drv):
     elapsed = time.perf_counter() - t0
     assert res["iterations"] == ICP_ITERS
     gc.callbacks.remove(on_gc)
-    run_m1.step_us = np.diff(np.array(marks)) * 1e6
-    run_m1.gc = [(g, round((b - a) * 1e3, 2), round((a - t0) * 1e3, 2)) for (p0, g, a), (p1, _, b) in zip(gc_log[::2], gc_log[1::2])]
+    step_us = np.diff(np.array(marks)) * 1e6
+    collections = [(g, round((b - a) * 1e3, 2), round((a - t0) * 1e3, 2)) for (p0, g, a), (p1, _, b) in zip(gc_log[::2], gc_log[1::2])]
     # roofline of the dominant kernel (icp_fused_kernel: one ICP pass + the previous pass's solve/update in its prologue): the same
     # steps re-run with hipEvent brackets around every launch on the launch stream (outside the timed region above)
     be.profile_enable(True)
@@ -423,7 +423,7 @@ def run_m1(be, world, s_id, t_id, steps, warmup, barrier, drv):
         step()
     n_launch, kern_ms = be.profile_read()
     be.profile_enable(False)
-    return res, elapsed, n_launch, kern_ms
+    return res, elapsed, n_launch, kern_ms, step_us, collections
 
 
 def run_config4(args, world, rank, local_rank, barrier, emit=True):
@@ -585,7 +585,7 @@ def main():
         if mode is None:
             mode = "union" if args.config == "3u" else "submap"
         drv = sharded.ShardedIcp(be, mode=mode) if (world > 1 or args.config == "3u") else None
-        res, elapsed, n_launch, kern_ms = run_m1(be, world, s_id, t_id, steps, warmup, barrier, drv)
+        res, elapsed, n_launch, kern_ms, su, collections = run_m1(be, world, s_id, t_id, steps, warmup, barrier, drv)
         if world > 1:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -593,9 +593,8 @@ def main():
         be.close()
         avg_kernel_s = kern_ms * 1e-3 / max(n_launch, 1)
         gbs = algo_bytes / avg_kernel_s / 1e9
-        su = run_m1.step_us
         spread = {"median": float(np.median(su)), "p10": float(np.percentile(su, 10)), "p90": float(np.percentile(su, 90)), "max": float(su.max()),
-                  "host_cpu": host_cpu(), "argmax": int(np.argmax(su)), "gc": run_m1.gc}
+                  "host_cpu": host_cpu(), "argmax": int(np.argmax(su)), "gc": collections}
         return dict(res=res, elapsed=elapsed, index_build_ms=index_build_ms, n_launch=n_launch, avg_kernel_s=avg_kernel_s, gbs=gbs, step_us=spread)
 
     r32 = m1(backend.PRECISION_F32, args.steps, args.warmup)
