@@ -186,3 +186,57 @@ def test_submap_dense_map_and_transform_match_oracle(backend_f64, oracle):
     moved_scan = PointCloud.from_numpy(be, sub.getMapPointCloud().points_[::10])  # points of the moved map itself
     r = be.icp_point_to_plane_dev(moved_scan.id, sub.getMapPointCloud().id, 1.0, max_iter=5)
     assert r["fitness"] == 1.0 and np.allclose(r["transformation"], np.eye(4), atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_handles_give_their_device_memory_back():
+    """A handle owns a block cache, a scratch arena, staging rings, per-handle tables; o3ds_destroy must hand all of it back.  Twelve
+    handles in a row, each playing a few frames of the stream (every per-frame allocation path), leave the device's free memory where it
+    was; and within one handle the cache does not grow once the clouds stop growing (the same frames replayed into a fresh submap)."""
+    import torch
+
+    from open3d_slam_amd import backend
+    from open3d_slam_amd.mapper import Mapper
+    from open3d_slam_amd.odometry import LidarOdometry
+    from open3d_slam_amd.pointcloud import PointCloud
+    import bench
+
+    mp, op = bench.stream_parameters()
+    scene = syn.make_scene()
+    poses = syn.figure_eight_poses(200, 0.1)
+    scans = [np.asarray(syn.os128_scan(scene, poses[k], frame=k), dtype=np.float32)[::2] for k in range(6)]
+
+    def play(be):
+        odo = LidarOdometry(be)
+        odo.setParameters(op)
+        mapper = Mapper(be, odo)
+        mapper.setParameters(mp)
+        for k, raw in enumerate(scans):
+            cloud = PointCloud.from_pointcloud2(be, raw)
+            assert odo.addRangeScan(cloud, 0.1 * k) and mapper.addRangeMeasurement(cloud, 0.1 * k)
+            cloud.release()
+        be.synchronize()
+
+    torch.cuda.synchronize()
+    warm = backend.Backend(0)
+    play(warm)
+    warm.close()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(12):
+        be = backend.Backend(0)
+        play(be)
+        be.close()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, (free0, free1)  # nothing accumulates from handle to handle (the runtime may keep a little)
+    be = backend.Backend(0)
+    play(be)
+    torch.cuda.synchronize()
+    held0 = torch.cuda.mem_get_info()[0]
+    for _ in range(4):
+        play(be)  # new odometry / mapper objects on the same handle: the old ones' clouds went back to the handle's cache
+    torch.cuda.synchronize()
+    held1 = torch.cuda.mem_get_info()[0]
+    be.close()
+    assert held0 - held1 < 256 << 20, (held0, held1)
