@@ -81,6 +81,17 @@ def test_the_patched_reference_runs_on_the_gpu_and_matches_the_device_loop_and_t
     assert abs(n_map - len(loop.map_p)) <= 0.002 * n_map
     rel = np.linalg.inv(truth[0]) @ truth[frames - 1]
     assert np.linalg.norm(M[-1][:3, 3] - rel[:3, 3]) < 0.05
+    # and the reference BEFORE the patch (the same sources unpatched, Open3D calls served by the CPU oracle), fed the same scans: what the
+    # patch changes is where the work runs, not what comes out
+    R0 = ref.ReferenceSlam(mp, op, patched=False)
+    ok0, M0, O0, ms0, n_map0 = R0.run_stream(scans)
+    R0.close()
+    assert ok0 == frames
+    worst_ref = max(max(*syn.se3_error(M[k], M0[k]), *syn.se3_error(O[k], O0[k])) for k in range(frames))
+    assert worst_ref <= 1e-3, worst_ref  # f32 storage on the device against f64 on the CPU; measured ~1e-5
+    assert abs(n_map - n_map0) <= 0.002 * n_map0
+    print(f"patched vs unpatched reference over {frames} frames: worst pose difference {worst_ref:.2e}, map {n_map} vs {n_map0} points "
+          f"(unpatched, on this box's CPU allowance: {ms0 / frames:.0f} ms per frame)")
 
 
 @pytest.mark.skipif(not _patched_available(), reason="oracle/_ref/libo3dslam_ref_patched.so is neither built nor buildable here")
