@@ -156,11 +156,51 @@ def cpu_baseline_m1(src, tgt, nrm, budget_s=16.0):
                        f"CPU restatement of Open3D v0.15.1, {best_t} OpenMP threads"), res, best_t
 
 
+def cpu_baseline_m2_reference_loop(scans32, frames, threads):
+    """The CPU leg of the scans/s metric on the REFERENCE'S OWN frame loop: open3d_slam's Odometry.cpp / Mapper.cpp / ScanToMapRegistration.cpp /
+    Submap.cpp / SubmapCollection.cpp compiled unchanged (oracle/ref_build -> oracle/_ref/libo3dslam_ref.so), the Open3D algorithms they call
+    served by the oracle's C restatement.  Returns None when that library is neither built nor buildable (then the Python loop is used)."""
+    from oracle import pyoracle as po
+    from oracle import ref
+
+    try:
+        if not ref.available():
+            return None
+        mp, op = stream_parameters()
+        po.lib().orc_set_num_threads(threads)  # the same shared library the reference build is linked to
+        R = ref.ReferenceSlam(mp, op, carve_every_n_scans=mp.mapBuilder_.carving_.carveSpaceEveryNscans_, patched=False)
+        ok, M, O, ms, n_map = R.run_stream(scans32[:frames])
+        workers = dict(R.ms_workers)
+        R.close()
+    except Exception as e:  # noqa: BLE001 -- a reported baseline must not take the line down
+        sys.stderr.write(f"reference-loop CPU leg unavailable ({e!r}); falling back to the Python loop\n")
+        return None
+    if ok != frames:
+        return None
+    m = frames - 1
+    busy = (workers["odometry"] + workers["mapping"]) * 1e-3
+
+    class Loop:  # what the caller reads of a loop object
+        poses_per_frame = [(M[k], None) for k in range(frames)]
+
+    return dict(value=m / busy, unit="scans/s", cores=int(po.lib().orc_num_threads()), kind="port",
+                glue="reference: open3d_slam's own Odometry / Mapper / Submap sources compiled unchanged (oracle/_ref); only the Open3D algorithms are the port",
+                mapping_only_scans_per_sec=m / (workers["mapping"] * 1e-3), ms_per_scan={k: v / m for k, v in workers.items()}, map_points=int(n_map),
+                sample=f"frames 1..{frames - 1} of the same {len(scans32)}-frame stream through open3d_slam's OWN LidarOdometry::addRangeScan + "
+                       f"Mapper::addRangeMeasurement (reference sources compiled unchanged, oracle/ref_build; the map holds {n_map} points at the end), "
+                       "the Open3D algorithms underneath = CPU restatement of Open3D v0.15.1 (the port), KD-tree of the map patch rebuilt per "
+                       "registration as the reference does, carving every 10th insertion"), Loop
+
+
 def cpu_baseline_m2(scans32, frames, threads):
-    """The same odometry + mapping loop on the CPU oracle (oracle/pipeline.py), first `frames` frames of the stream."""
+    """The same odometry + mapping loop on the CPU: the reference's own compiled frame loop when oracle/_ref is there, else the oracle's Python
+    loop (oracle/pipeline.py; the two agree to 1e-10, tests/test_oracle_vs_reference.py); first `frames` frames of the stream."""
     from oracle import pyoracle as po
     from oracle.pipeline import OracleLoop
 
+    got = cpu_baseline_m2_reference_loop(scans32, frames, threads)
+    if got is not None:
+        return got
     mp, op = stream_parameters()
     po.lib().orc_set_num_threads(threads)
     ref = OracleLoop(po, mp, op)

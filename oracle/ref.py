@@ -260,7 +260,7 @@ class ReferenceSlam:
         else:
             L = lib()
         L.ref_slam_run_stream.restype = C.c_int
-        L.ref_slam_run_stream.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.c_int, C.c_double, C.c_int, _dp, _dp, C.POINTER(C.c_size_t)]
+        L.ref_slam_run_stream.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.c_int, C.c_double, C.c_int, _dp, _dp, C.POINTER(C.c_size_t), _dp]
         L.ref_slam_create.restype = C.c_void_p
         L.ref_slam_create.argtypes = [C.POINTER(SlamParams)]
         L.ref_slam_free.argtypes = [C.c_void_p]
@@ -316,8 +316,10 @@ class ReferenceSlam:
         f, n = a.shape[0], a.shape[1]
         poses = np.empty((f, 32))
         ms, n_map = C.c_double(), C.c_size_t()
+        workers = np.zeros(2)
         ok = self.L.ref_slam_run_stream(self.h, a.ctypes.data_as(C.POINTER(C.c_float)), n, f, float(dt), int(bool(threads)), poses.ctypes.data_as(_dp),
-                                        C.byref(ms), C.byref(n_map))
+                                        C.byref(ms), C.byref(n_map), workers.ctypes.data_as(_dp))
+        self.ms_workers = {"odometry": float(workers[0]), "mapping": float(workers[1])}  # serial mode, frames 1..
         M = poses[:, :16].reshape(f, 4, 4).transpose(0, 2, 1).copy()
         O = poses[:, 16:].reshape(f, 4, 4).transpose(0, 2, 1).copy()
         return ok, M, O, float(ms.value), int(n_map.value)

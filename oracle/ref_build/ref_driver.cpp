@@ -361,7 +361,7 @@ size_t ref_slam_preprocessed_scan(void* h, double* out_pts, double* out_nrm) {
 // SlamWrapper runs them (SlamWrapper.cpp:228-229), the mapper waiting for the odometry of its scan.  poses_out: per frame 16 doubles
 // mapToRangeSensor + 16 doubles odomToRangeSensor (column-major).  Returns the number of frames both workers accepted.
 int ref_slam_run_stream(void* h, const float* scans, size_t n_pts, int n_frames, double dt, int threads, double* poses_out, double* ms_total,
-                        size_t* map_points) {
+                        size_t* map_points, double* ms_workers /* may be null; serial mode: {odometry, mapping} summed over frames 1.. */) {
   auto* s = static_cast<RefSlam*>(h);
   std::vector<PointCloud> clouds((size_t)n_frames);
   for (int k = 0; k < n_frames; ++k) {
@@ -377,10 +377,18 @@ int ref_slam_run_stream(void* h, const float* scans, size_t n_pts, int n_frames,
   };
   int ok = 0;
   const auto t0 = std::chrono::steady_clock::now();
+  double msOdo = 0.0, msMap = 0.0;
   if (!threads) {
     for (int k = 0; k < n_frames; ++k) {
+      const auto a0 = std::chrono::steady_clock::now();
       const bool a = s->odometry->addRangeScan(clouds[k], stamp(k));
+      const auto a1 = std::chrono::steady_clock::now();
       const bool b = a && s->mapper->addRangeMeasurement(clouds[k], stamp(k));
+      const auto a2 = std::chrono::steady_clock::now();
+      if (k > 0) {
+        msOdo += std::chrono::duration<double, std::milli>(a1 - a0).count();
+        msMap += std::chrono::duration<double, std::milli>(a2 - a1).count();
+      }
       record(k);
       ok += (a && b) ? 1 : 0;
     }
@@ -415,6 +423,7 @@ int ref_slam_run_stream(void* h, const float* scans, size_t n_pts, int n_frames,
     mappingWorker.join();
   }
   *ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (ms_workers) ms_workers[0] = msOdo, ms_workers[1] = msMap;
   *map_points = s->mapper->getActiveSubmap().getMapPointCloud().points_.size();
   return ok;
 }
