@@ -248,17 +248,20 @@ class SlamParams(C.Structure):
 class ReferenceSlam:
     """LidarOdometry + Mapper of the reference, fed one scan at a time (SlamWrapper's two workers, one after the other)."""
 
-    def __init__(self, mp, op, carve_every_n_scans=10, submap_radius=20.0, min_movement=0.0, carving=(0.1, 20.0, 0.1, 0.5), patched=False):
+    def __init__(self, mp, op, carve_every_n_scans=10, submap_radius=20.0, min_movement=0.0, carving=(0.1, 20.0, 0.1, 0.5), patched=False, quiet=True):
         """mp / op: open3d_slam_amd.parameters.MapperParameters / OdometryParameters (MinMaxRadius croppers, point-to-plane);
         carving = (voxel, max ray length, truncation, min dot) of SpaceCarvingParameters (Parameters.hpp:85-92 defaults);
         patched: the build with integration/open3d_slam_o3ds.patch applied, whose registration / pre-processing / map fusion run on the
-        GPU through libo3ds_backend.so (GPU box only)"""
+        GPU through libo3ds_backend.so (GPU box only); quiet: open3d_slam's own std::cout reports are dropped"""
         if patched:
             if not os.path.isfile(LIB_PATCHED):
                 build()
             L = C.CDLL(LIB_PATCHED)
         else:
             L = lib()
+        L.ref_set_quiet.restype = None
+        L.ref_set_quiet.argtypes = [C.c_int]
+        L.ref_set_quiet(1 if quiet else 0)
         L.ref_slam_run_stream.restype = C.c_int
         L.ref_slam_run_stream.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.c_int, C.c_double, C.c_int, _dp, _dp, C.POINTER(C.c_size_t), _dp]
         L.ref_slam_create.restype = C.c_void_p

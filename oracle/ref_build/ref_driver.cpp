@@ -9,6 +9,7 @@
 #include <mutex>
 #include <thread>
 #include <cstring>
+#include <iostream>
 #include <memory>
 #include <string>
 #include <vector>
@@ -272,6 +273,15 @@ struct RefSlam {
   std::shared_ptr<o3d_slam::SubmapCollection> submaps;
   std::shared_ptr<o3d_slam::Mapper> mapper;
 };
+
+// open3d_slam reports on std::cout ("Created submap ...", carving statistics): silenced for a caller whose own standard output is a contract
+// (bench.py prints one JSON line); 0 restores it
+void ref_set_quiet(int on) {
+  if (on)
+    std::cout.setstate(std::ios_base::failbit);
+  else
+    std::cout.clear();
+}
 
 void* ref_slam_create(const ref_slam_params* q) {
   o3d_slam::OdometryParameters op;
