@@ -21,6 +21,8 @@ class OracleLoop:
         self.rng_odo = self.rng_map = None  # RandomDownSample keep lists (see set_down_sample_seeds)
         self.carving = True  # as the reference: SubmapCollection::insertScan passes isPerformCarving = true
         self.n_inserted, self.n_carved = 0, 0
+        self.strict = True  # a failed fitness gate is an error (the streams of this repository never fail one); False: follow the reference's rejection paths
+        self.n_rejected, self.n_not_inserted = 0, 0
         self.T_inserted = np.eye(4)  # pose of the last insertion = the map builder cropper's pose until the next one
         self.shuffle_at_full_ratio = False
 
@@ -50,10 +52,15 @@ class OracleLoop:
         v, n = self._down(v, n, self.op.scanProcessing_.downSamplingRatio_, self.rng_odo)
         if self.prev is not None:
             r = self.o.icp_point_to_plane(self.prev, v, n, icp.maxCorrespondenceDistance_, max_iter=icp.maxNumIter_)
-            assert r["fitness"] > 0.1
+            if not r["fitness"] > 0.1:  # Odometry.cpp:52-67: the new scan still becomes the one to match against, nothing else moves
+                assert not self.strict, ("odometry fitness", r["fitness"])
+                if len(v):
+                    self.prev = v
+                return False
             self.odom = self.odom @ np.linalg.inv(r["transformation"])
         self.prev = v
         self.odom_at[t] = self.odom.copy()
+        return True
 
     def mapping(self, raw, t):
         o, mp = self.o, self.mp
@@ -71,9 +78,21 @@ class OracleLoop:
                                                             rmax=sc.croppingMaxRadius_))
             r = o.icp_point_to_plane(match, self.map_p[patch], self.map_n[patch], icp.maxCorrespondenceDistance_, init=est,
                                      max_iter=icp.maxNumIter_)
-            assert r["fitness"] >= mp.scanMatcher_.minRefinementFitness_
+            if not mp.isIgnoreMinRefinementFitness_ and r["fitness"] < mp.scanMatcher_.minRefinementFitness_:
+                # Mapper.cpp:151-156: the refinement is skipped -- no pose update, no insertion, and lastMeasurementTimestamp_ /
+                # mapToRangeSensorPrev_ stay where they were, so the next prior spans the odometry motion since the last ACCEPTED scan
+                assert not self.strict, ("scan-to-map fitness", r["fitness"])
+                self.n_rejected += 1
+                return False
             self.T = r["transformation"]
             T_ins = self.T
+            # Mapper.cpp:170-176: a sensor that has not moved minMovementBetweenMappingSteps_ since the last insertion does not insert
+            motion = np.linalg.inv(self.T_inserted) @ self.T
+            if np.linalg.norm(motion[:3, 3]) < mp.minMovementBetweenMappingSteps_:
+                self.n_not_inserted += 1
+                self.last_t = t
+                self.Tprev = self.T.copy()
+                return True
         tp, tn = o.transform_points(v, T_ins), o.transform_normals(n, T_ins)
         mc = mp.mapBuilder_.cropper_
         # Submap::insertScan (Submap.cpp:54-72): SubmapCollection::insertScan always asks for carving (SubmapCollection.cpp:178,189,203);
@@ -96,3 +115,4 @@ class OracleLoop:
                                                              mp.mapBuilder_.mapVoxelSize_, crop)
         self.last_t = t
         self.Tprev = self.T.copy()
+        return True

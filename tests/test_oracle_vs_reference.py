@@ -323,3 +323,42 @@ def test_submap_dense_map_insertion_and_carving_follow_the_reference():
     assert np.array_equal(np.array(keys, dtype=np.int64), rk.astype(np.int64))
     means = np.array([acc[k][0] / acc[k][1] for k in keys])
     assert np.array_equal(means, rp) and np.array_equal(np.array([acc[k][1] for k in keys]), rc)
+
+
+def test_the_mapper_s_gates_follow_the_reference():
+    """Mapper.cpp:151-156 (a scan whose refinement fitness is below minRefinementFitness_ changes nothing: no pose, no insertion, and the next
+    prior spans the odometry motion since the last ACCEPTED scan) and Mapper.cpp:170-176 (no insertion while the sensor has moved less than
+    minMovementBetweenMappingSteps_ since the last one; the pose is still refined), plus Odometry.cpp:52-67 (a scan the odometry cannot
+    register -- fitness <= 0.1 -- still replaces the scan to match against).  One stream with a corrupted scan in it, through the reference's
+    own loop and through the oracle loop in non-strict mode: same verdict for every scan, same map sizes, same poses."""
+    import bench
+    from oracle.pipeline import OracleLoop
+
+    mp, op = bench.stream_parameters()
+    mp.minMovementBetweenMappingSteps_ = 0.25  # the sensor moves ~0.14 m per frame: every second scan is inserted
+    mp.scanMatcher_.minRefinementFitness_ = 0.8
+    scene = syn.make_scene()
+    poses = syn.figure_eight_poses(200, 0.1)
+    scans = [np.asarray(syn.os128_scan(scene, poses[k], frame=k), dtype=np.float64)[::8] for k in range(9)]
+    bad = scans[4].copy()  # half of the scan lifted into the air: the odometry still finds enough of it (> 0.1), the mapper does not (< 0.8)
+    bad[::2] += [0.0, 0.0, 6.0]
+    scans[4] = bad
+    rng = np.random.default_rng(2)
+    scans[7] = rng.uniform(-15.0, 15.0, size=scans[7].shape) * [1, 1, 0.1] + [0, 0, 20.0]  # a slab 20 m up, nothing of the scene: the odometry refuses it
+    R = ref.ReferenceSlam(mp, op, min_movement=mp.minMovementBetweenMappingSteps_)
+    O = OracleLoop(po, mp, op)
+    O.strict = False
+    verdicts = []
+    for k, s in enumerate(scans):
+        rc, odom, T, n_map, n_sub = R.add_scan(s, 0.1 * k)
+        ok_o = O.odometry(s, k)
+        ok_m = O.mapping(s, k) if ok_o else None
+        mine = 1 if (ok_o and ok_m) else (0 if not ok_o else -1)
+        verdicts.append((rc, mine))
+        assert rc == mine, (k, verdicts)
+        assert n_map == len(O.map_p), (k, n_map, len(O.map_p))
+        if k > 0:
+            assert max(*syn.se3_error(T, O.T)) < 1e-9, (k, syn.se3_error(T, O.T))
+    assert [v[0] for v in verdicts].count(-1) >= 1 and [v[0] for v in verdicts].count(0) >= 1, verdicts  # both rejections did happen
+    assert O.n_not_inserted >= 2 and O.n_rejected >= 1
+    R.close()

@@ -240,3 +240,49 @@ def test_handles_give_their_device_memory_back():
     held1 = torch.cuda.mem_get_info()[0]
     be.close()
     assert held0 - held1 < 256 << 20, (held0, held1)
+
+
+@pytest.mark.gpu
+def test_the_gates_of_the_loop_follow_the_oracle_loop(backend_f64, oracle):
+    """The rejection paths of the frame loop -- Mapper.cpp:151-156 (refinement fitness below minRefinementFitness_: nothing changes),
+    Mapper.cpp:170-176 (no insertion before the sensor has moved minMovementBetweenMappingSteps_), Odometry.cpp:52-67 (a scan the odometry
+    cannot register) -- through the device mirror, on the stream tests/test_oracle_vs_reference.py plays through the REFERENCE's own loop and
+    the oracle loop (which agree): same verdict for every scan, same map sizes, poses within the f64 tolerance."""
+    import bench
+    from oracle.pipeline import OracleLoop
+
+    from open3d_slam_amd.mapper import Mapper
+    from open3d_slam_amd.odometry import LidarOdometry
+    from open3d_slam_amd.pointcloud import PointCloud
+
+    mp, op = bench.stream_parameters()
+    mp.minMovementBetweenMappingSteps_ = 0.25
+    mp.scanMatcher_.minRefinementFitness_ = 0.8
+    scene = syn.make_scene()
+    poses = syn.figure_eight_poses(200, 0.1)
+    scans = [np.asarray(syn.os128_scan(scene, poses[k], frame=k), dtype=np.float64)[::8] for k in range(9)]
+    bad = scans[4].copy()
+    bad[::2] += [0.0, 0.0, 6.0]
+    scans[4] = bad
+    rng = np.random.default_rng(2)
+    scans[7] = rng.uniform(-15.0, 15.0, size=scans[7].shape) * [1, 1, 0.1] + [0, 0, 20.0]
+    be = backend_f64
+    odo = LidarOdometry(be)
+    odo.setParameters(op)
+    mapper = Mapper(be, odo)
+    mapper.setParameters(mp)
+    O = OracleLoop(oracle, mp, op)
+    O.strict = False
+    seen = []
+    for k, s in enumerate(scans):
+        cloud = PointCloud.from_numpy(be, s)
+        ok_o = odo.addRangeScan(cloud, 0.1 * k)
+        ok_m = mapper.addRangeMeasurement(cloud, 0.1 * k) if ok_o else None
+        cloud.release()
+        ref_o = O.odometry(s, 0.1 * k)
+        ref_m = O.mapping(s, 0.1 * k) if ref_o else None
+        seen.append((ok_o, ok_m))
+        assert (ok_o, ok_m) == (ref_o, ref_m), (k, seen)
+        assert len(mapper.getActiveSubmap().getMapPointCloud()) == len(O.map_p), k
+        assert max(*syn.se3_error(mapper.getMapToRangeSensor(), O.T)) < 1e-6, k
+    assert (True, False) in seen and (False, None) in seen and O.n_not_inserted >= 2
