@@ -362,3 +362,20 @@ def test_the_mapper_s_gates_follow_the_reference():
     assert [v[0] for v in verdicts].count(-1) >= 1 and [v[0] for v in verdicts].count(0) >= 1, verdicts  # both rejections did happen
     assert O.n_not_inserted >= 2 and O.n_rejected >= 1
     R.close()
+
+
+def test_the_eigen_stand_in_checks_itself(tmp_path):
+    """tests/cpp/test_mini_eigen.cpp: the pieces of the stand-in whose silent failure would make a reference run meaningless (write-back of
+    `T.matrix() *= M`, inverses, quaternions, the voxel-index expressions), compiled warning-free and run"""
+    import shutil
+    import subprocess
+
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "test_mini_eigen")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-Wall", "-Wextra", "-Werror", "-o", exe,
+                        os.path.join(root, "tests", "cpp", "test_mini_eigen.cpp")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
