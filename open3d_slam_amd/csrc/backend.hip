@@ -158,6 +158,11 @@ struct o3ds_context {
   bool fused = true;  // O3DS_ICP_MODE=launch selects the two-kernel form (same results bit for bit)
   int* d_nn_cache = nullptr;  // per-query match of the previous pass (bound for the pruned search); grown on demand
   size_t nn_cache_cap = 0;
+  // candidate sets of the fused loop (icp_kernels.hpp, Collect): one allocation of nn_cache_cap x (kSetCap ints + {p_ref, L} at f64 width)
+  int* d_set_pos = nullptr;
+  void* d_set_ref = nullptr;
+  bool sets = true;                                      // O3DS_ICP_SETS=0: every pass searches (same results bit for bit)
+  float set_gain = 2.0f, set_min = 1e-3f, set_cap = 0.04f;  // O3DS_SET_GAIN / _MIN / _CAP (metres)
   char* d_fused = nullptr;  // [2 states | 3 x kFusedSlots slot records (hi and lo sums)]
   unsigned long long fused_launches = 0;
   // Scratch that its users leave the way they found it, so that no launch is spent on clearing it: the per-cell counters of an index
@@ -1036,8 +1041,17 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
       h->d_nn_cache = nullptr;
       h->nn_cache_cap = 0;
     }
-    const size_t cap = std::max<size_t>(src->n + src->n / 4, 1 << 16);
+    const size_t cap = (std::max<size_t>(src->n + src->n / 4, 1 << 16) + 7) & ~(size_t)7;
     if (hipMalloc((void**)&h->d_nn_cache, cap * sizeof(int)) != hipSuccess) return fail(h, O3DS_ERR_OOM, "icp: match cache allocation failed");
+    if (h->d_set_pos) (void)hipFree(h->d_set_pos);
+    h->d_set_pos = nullptr;
+    h->d_set_ref = nullptr;
+    if (hipMalloc((void**)&h->d_set_pos, cap * (kSetCap * sizeof(int) + 4 * sizeof(double))) != hipSuccess) {
+      (void)hipFree(h->d_nn_cache);
+      h->d_nn_cache = nullptr;
+      return fail(h, O3DS_ERR_OOM, "icp: candidate-set allocation failed");
+    }
+    h->d_set_ref = (char*)h->d_set_pos + cap * kSetCap * sizeof(int);  // (cap is a multiple of 4: 32-byte aligned)
     h->nn_cache_cap = cap;
   }
   IcpStateDev st{};
@@ -1104,6 +1118,11 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
   }
   a.kmax = std::max(1, (int)std::ceil(r / tgt->grid.cell));  // a neighbour within r is at most this many cells away
   a.nn_cache = h->d_nn_cache;
+  a.set_pos = h->fused && h->sets ? h->d_set_pos : nullptr;
+  a.set_ref = h->d_set_ref;
+  a.set_gain = h->set_gain;
+  a.set_min = h->set_min;
+  a.set_cap = h->set_cap;
   a.n_tgt = (int)tgt->n;
   a.snrm = src->nrm;
   a.gicp_k = 1.0 - h->gicp_epsilon;
@@ -1186,6 +1205,10 @@ int o3ds_create(int device_id, o3ds_handle* out) {
       o3ds_destroy(h);
       return fail(nullptr, O3DS_ERR_OOM, "o3ds_create: scratch allocation failed");
     }
+    if (const char* e = getenv("O3DS_ICP_SETS")) h->sets = atoi(e) != 0;
+    if (const char* e = getenv("O3DS_SET_GAIN")) h->set_gain = (float)atof(e);
+    if (const char* e = getenv("O3DS_SET_MIN")) h->set_min = (float)atof(e);
+    if (const char* e = getenv("O3DS_SET_CAP")) h->set_cap = (float)atof(e);
     if (const char* e = getenv("O3DS_ICP_MODE")) {
       h->fused = std::string(e) != "launch";
     }
@@ -1208,6 +1231,7 @@ int o3ds_destroy(o3ds_handle h) {
   dev_release_all(h);
   if (h->d_fused) (void)hipFree(h->d_fused);
   if (h->d_nn_cache) (void)hipFree(h->d_nn_cache);
+  if (h->d_set_pos) (void)hipFree(h->d_set_pos);
   if (h->d_cells) (void)hipFree(h->d_cells);
   if (h->d_voxtab) (void)hipFree(h->d_voxtab);
   if (h->d_partials) (void)hipFree(h->d_partials);
@@ -1853,6 +1877,14 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
       HIP_TRY(hipMalloc((void**)&d_trace, sizeof(unsigned long long) * 16 * nb));
       HIP_TRY(hipMemset(d_trace, 0, sizeof(unsigned long long) * 16 * nb));
     }
+    // O3DS_ICP_STATS=1: per-launch counters of how the queries were served (verified from their candidate set / searched / sets left /
+    // stage-3 queries), printed to stderr after the registration (development aid)
+    static const bool want_stats = getenv("O3DS_ICP_STATS") != nullptr;
+    unsigned long long* d_stats = nullptr;
+    if (want_stats) {
+      HIP_TRY(hipMalloc((void**)&d_stats, sizeof(unsigned long long) * 4 * (size_t)total));
+      HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof(unsigned long long) * 4 * (size_t)total, h->stream));
+    }
     int j = 0;
     const IcpStateDev* last = h->d_state;
     while (j < total) {
@@ -1872,6 +1904,7 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
         fa.slots_clear = (double*)(h->d_fused + kFusedSlotsOff + ((g + 1) % 3) * kFusedSlotBufBytes);
         const bool tail_only = j == total - 1;
         fa.trace = j == trace_launch ? d_trace : nullptr;
+        fa.pass.stats = d_stats ? d_stats + 4 * (size_t)j : nullptr;
         fa.state_host = k == chunk - 1 ? h->h_state_dev : nullptr;  // the launch the host waits for also writes the pinned copy
         if (h->session_precision == O3DS_PRECISION_F64)
           launch_fused<P4d>(h, fa, h->session_crop, tail_only ? 1 : nb, !tail_only);
@@ -1895,6 +1928,14 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
       if (h->h_state->done) break;
     }
     h->fused_chunk_hint[target_crop ? 1 : 0] = std::min(std::max(h->h_state->iterations + 3, 4), 12);  // iterations + 2 launches were needed
+    if (d_stats) {
+      std::vector<unsigned long long> t((size_t)4 * total);
+      (void)hipMemcpy(t.data(), d_stats, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+      (void)hipFree(d_stats);
+      fprintf(stderr, "icp stats (n_src %zu):", (size_t)a.count);
+      for (int k = 0; k < j; ++k) fprintf(stderr, " [%d v%llu s%llu k%llu f%llu]", k, t[4 * k], t[4 * k + 1], t[4 * k + 2], t[4 * k + 3]);
+      fprintf(stderr, "\n");
+    }
     if (d_trace) {
       std::vector<unsigned long long> t((size_t)16 * nb);
       (void)hipMemcpy(t.data(), d_trace, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);

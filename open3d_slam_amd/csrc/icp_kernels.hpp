@@ -223,8 +223,9 @@ struct NNBest {
 
 // branch-free candidate test (the crop predicate, when compiled in, is only evaluated for would-be winners)
 template <typename P4, bool kCrop>
-__device__ __forceinline__ void consider(const P4& t, int p, bool valid, typename Scalar<P4>::type qx, typename Scalar<P4>::type qy,
-                                         typename Scalar<P4>::type qz, const CropDev& crop, NNBest<P4>& best) {
+__device__ __forceinline__ typename Scalar<P4>::type consider(const P4& t, int p, bool valid, typename Scalar<P4>::type qx,
+                                                              typename Scalar<P4>::type qy, typename Scalar<P4>::type qz,
+                                                              const CropDev& crop, NNBest<P4>& best) {
   using R = typename Scalar<P4>::type;
   const R dx = t.x - qx, dy = t.y - qy, dz = t.z - qz;
   const R d2 = dx * dx + dy * dy + dz * dz;
@@ -236,13 +237,40 @@ __device__ __forceinline__ void consider(const P4& t, int p, bool valid, typenam
   best.d2 = better ? d2 : best.d2;
   best.pos = better ? p : best.pos;
   best.idx = better ? t.i : best.idx;
+  return d2;
+}
+
+// ---- candidate sets ("the neighbourhood a query's match was proven in") ---------------------------------------------------------
+// A search that runs with a margin m > 0 trims every row with the ball of radius (current bound + m) and lists every scanned point
+// closer than tau = (distance to the bound it STARTED from) + m in the query's LDS list.  The bound only shrinks, so when the
+// search ends with the nearest neighbour at distance d1, every target point that is NOT listed is at least
+//     L = min(d1 + m, cell * (k + distance to the nearest cell face))          (k = the block radius the search reached)
+// away from the query position p_ref: scanned and not listed => >= tau >= d1 + m; trimmed away => beyond the ball of the bound of
+// that moment + m >= d1 + m; outside the block => beyond the block.  The NEXT pass of the registration moves the query by
+// delta = |p_new - p_ref| (millimetres near convergence); if the best listed point is closer to p_new than L - delta, it is the
+// nearest neighbour of p_new among ALL target points (ties are impossible: everything else is strictly farther), and the pass
+// needs no search at all -- the listed points and their normals are fetched BEFORE the pose is known, while the previous pass's
+// 6x6 system is being solved (icp_pass_body, "verified match").  A list holds at most kSetCap points (one per lane of the query's
+// group); a longer one, or a margin of zero, means "no set": that query searches again next pass, from the bound it has.
+constexpr int kSetCap = 4;
+template <typename R>
+struct Collect {
+  R tau2;     // scanned candidates with d2 < tau2 are listed; 0 = off
+  int* cnt;   // LDS: listed so far (beyond kSetCap = overflow, the set is dropped)
+  int* list;  // LDS: [kSetCap] positions in the cell-sorted target
+};
+template <typename R>
+__device__ __forceinline__ void collect_push(const Collect<R>& c, int p) {
+  const int k = atomicAdd(c.cnt, 1);
+  if (k < kSetCap) c.list[k] = p;
 }
 
 // candidates s+lane, s+lane+stride, ... of [s,e): four loads issued before the first is consumed
 template <typename P4, bool kCrop>
 __device__ __forceinline__ void scan_strided(const P4* __restrict__ tp, int s, int e, int lane, int stride, typename Scalar<P4>::type qx,
                                              typename Scalar<P4>::type qy, typename Scalar<P4>::type qz, const CropDev& crop,
-                                             NNBest<P4>& best) {
+                                             NNBest<P4>& best, const Collect<typename Scalar<P4>::type>& col) {
+  using R = typename Scalar<P4>::type;
   for (int p = s + lane; p < e; p += 4 * stride) {
     const int p1 = p + stride, p2 = p + 2 * stride, p3 = p + 3 * stride;
     const bool v1 = p1 < e, v2 = p2 < e, v3 = p3 < e;
@@ -250,10 +278,14 @@ __device__ __forceinline__ void scan_strided(const P4* __restrict__ tp, int s, i
     const P4 t1 = tp[v1 ? p1 : p];  // clamped, not predicated: branches around the loads measured slower
     const P4 t2 = tp[v2 ? p2 : p];
     const P4 t3 = tp[v3 ? p3 : p];
-    consider<P4, kCrop>(t0, p, true, qx, qy, qz, crop, best);
-    consider<P4, kCrop>(t1, p1, v1, qx, qy, qz, crop, best);
-    consider<P4, kCrop>(t2, p2, v2, qx, qy, qz, crop, best);
-    consider<P4, kCrop>(t3, p3, v3, qx, qy, qz, crop, best);
+    const R d0 = consider<P4, kCrop>(t0, p, true, qx, qy, qz, crop, best);
+    if (d0 < col.tau2) collect_push(col, p);  // the candidate-set list (rare: a handful of points per query lie inside tau; tau2 = 0: off)
+    const R d1 = consider<P4, kCrop>(t1, p1, v1, qx, qy, qz, crop, best);
+    if (v1 & (d1 < col.tau2)) collect_push(col, p1);
+    const R d2 = consider<P4, kCrop>(t2, p2, v2, qx, qy, qz, crop, best);
+    if (v2 & (d2 < col.tau2)) collect_push(col, p2);
+    const R d3 = consider<P4, kCrop>(t3, p3, v3, qx, qy, qz, crop, best);
+    if (v3 & (d3 < col.tau2)) collect_push(col, p3);
   }
 }
 
@@ -348,24 +380,32 @@ __device__ __forceinline__ bool row_extent(float b2, float rowd2, float ux, int*
   return true;
 }
 
-// squared bound in cell units, inflated so that rounding never culls a needed cell
+// (d + m)^2 for a squared distance d2 and a margin m (metres); m = 0 leaves d2 as it is
 template <typename R>
-__device__ __forceinline__ float bound_cells2(R d2, const GridDev& g) {
+__device__ __forceinline__ float widen2(R d2, R m) {
+  float v = (float)d2;
+  if (m > (R)0) {
+    const float d = sqrtf(v) + (float)m;
+    v = d * d;
+  }
+  return v;
+}
+// squared bound in cell units, inflated so that rounding never culls a needed cell; m = the candidate-set margin (see Collect)
+template <typename R>
+__device__ __forceinline__ float bound_cells2(R d2, R m, const GridDev& g) {
   const float ic = (float)g.inv_cell;
-  return (float)d2 * ic * ic * (1.0f + 1e-4f) + 1e-6f;
+  return widen2(d2, m) * ic * ic * (1.0f + 1e-4f) + 1e-6f;
 }
 
-// All G lanes of a group call this with the same query; every lane returns the same winner.
+// All G lanes of a group call this with the same query and the same starting bound `best` (any eligible target point, or {r^2, -1,
+// -1}); every lane returns the same winner.  m / col: the candidate-set margin and list (m = 0, col.tau2 = 0: off); *kdone = the
+// block radius (cells) the search covered.
 template <typename P4, bool kCrop, int G>
 __device__ __forceinline__ NNBest<P4> nn_search_group(const GridDev& g, const P4* __restrict__ tp, typename Scalar<P4>::type qx,
-                                                      typename Scalar<P4>::type qy, typename Scalar<P4>::type qz,
-                                                      typename Scalar<P4>::type r2max, int kmax, const CropDev& crop, int gl,
-                                                      int2* seg /* this group's kSegMax entries */, int prev, const P4& tprev,
-                                                      bool* resolved) {
-  NNBest<P4> best;
-  best.d2 = r2max;
-  best.pos = -1;
-  best.idx = -1;
+                                                      typename Scalar<P4>::type qy, typename Scalar<P4>::type qz, int kmax,
+                                                      const CropDev& crop, int gl, int2* seg /* this group's kSegMax entries */,
+                                                      NNBest<P4> best, typename Scalar<P4>::type m,
+                                                      const Collect<typename Scalar<P4>::type>& col, bool* resolved, int* kdone) {
   const QueryCell c = locate(g, (double)qx, (double)qy, (double)qz);
   const int* __restrict__ cs = g.cell_start;
   // ---- one batch, issued before the bound is even computed: the 4 cell_start values of each of this lane's rows of the 3x3
@@ -383,10 +423,9 @@ __device__ __forceinline__ NNBest<P4> nn_search_group(const GridDev& g, const P4
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[k][j] = rv[k] ? cs[row + min(xlo + j, xhi + 1)] : 0;
   }
-  consider<P4, kCrop>(tprev, prev, prev >= 0, qx, qy, qz, crop, best);
   // ---- stage 1: the 3x3x3 block, trimmed by the bound
   {
-    const float b2 = bound_cells2(best.d2, g);
+    const float b2 = bound_cells2(best.d2, m, g);
     int ss[kOwn], ee[kOwn];
     int cnt = 0;
 #pragma unroll
@@ -414,20 +453,22 @@ __device__ __forceinline__ NNBest<P4> nn_search_group(const GridDev& g, const P4
     lds_wave_sync();
     for (int t = 0; t < total; ++t) {
       const int2 se = seg[t];
-      scan_strided<P4, kCrop>(tp, se.x, se.y, gl, G, qx, qy, qz, crop, best);
+      scan_strided<P4, kCrop>(tp, se.x, se.y, gl, G, qx, qy, qz, crop, best, col);
     }
     lds_wave_sync();  // the list is rewritten by stage 2
     lanes_min<P4, G>(best);
   }
   // proven exact if nothing outside the scanned block can be nearer: best <= (cell * (k + face distance))^2, tested with margin
+  // (with a candidate-set margin: if the ball of best + m lies inside the block)
   const float ic2 = (float)(g.inv_cell * g.inv_cell) * (1.0f + 1e-4f);
-  bool proven = kmax <= 1 || (float)best.d2 * ic2 <= (1.0f + c.mf) * (1.0f + c.mf);
+  bool proven = kmax <= 1 || widen2(best.d2, m) * ic2 <= (1.0f + c.mf) * (1.0f + c.mf);
+  *kdone = 1;
   // ---- stage 2: the 5x5x5 shell, trimmed by the bound (group-uniform branch), rows in two batches
   if (!proven) {
     constexpr int kHalf = 13, kOwn2 = (kHalf + G - 1) / G;
 #pragma unroll 1
     for (int r0 = 0; r0 < 25; r0 += kHalf) {
-      const float b2 = bound_cells2(best.d2, g);
+      const float b2 = bound_cells2(best.d2, m, g);
       int s2[2 * kOwn2], e2[2 * kOwn2];
 #pragma unroll
       for (int k = 0; k < kOwn2; ++k) {
@@ -467,12 +508,13 @@ __device__ __forceinline__ NNBest<P4> nn_search_group(const GridDev& g, const P4
       lds_wave_sync();
       for (int t = 0; t < total; ++t) {
         const int2 se = seg[t];
-        scan_strided<P4, kCrop>(tp, se.x, se.y, gl, G, qx, qy, qz, crop, best);
+        scan_strided<P4, kCrop>(tp, se.x, se.y, gl, G, qx, qy, qz, crop, best, col);
       }
       lds_wave_sync();
       lanes_min<P4, G>(best);
     }
-    proven = kmax <= 2 || (float)best.d2 * ic2 <= (2.0f + c.mf) * (2.0f + c.mf);
+    proven = kmax <= 2 || widen2(best.d2, m) * ic2 <= (2.0f + c.mf) * (2.0f + c.mf);
+    *kdone = 2;
   }
   *resolved = proven;
   return best;
@@ -486,11 +528,12 @@ __device__ __forceinline__ NNBest<P4> nn_search_group(const GridDev& g, const P4
 template <typename P4, bool kCrop>
 __device__ __forceinline__ void nn_search_wave_far(const GridDev& g, const P4* __restrict__ tp, typename Scalar<P4>::type qx,
                                                    typename Scalar<P4>::type qy, typename Scalar<P4>::type qz, int K,
-                                                   const CropDev& crop, NNBest<P4>& best, int lane, int2* s_list /* kFarList entries */) {
+                                                   const CropDev& crop, NNBest<P4>& best, int lane, int2* s_list /* kFarList entries */,
+                                                   typename Scalar<P4>::type m, const Collect<typename Scalar<P4>::type>& col) {
   constexpr int kdone = 2;  // cells within offset 2 were scanned by the group stages
   constexpr int kPer = 4;   // half-rows per lane and round: all their bounds are fetched in one batch
   const QueryCell c = locate(g, (double)qx, (double)qy, (double)qz);
-  const float b2 = bound_cells2(best.d2, g);
+  const float b2 = bound_cells2(best.d2, m, g);
   const int* __restrict__ cs = g.cell_start;
   const int side = 2 * K + 1, entries = 2 * side * side;
   NNBest<P4> mine = best;
@@ -543,7 +586,7 @@ __device__ __forceinline__ void nn_search_wave_far(const GridDev& g, const P4* _
     const int grp = lane / W, gl = lane % W;
     for (int t = grp; t < total; t += groups) {
       const int2 se = s_list[t];
-      scan_strided<P4, kCrop>(tp, se.x, se.y, gl, W, qx, qy, qz, crop, mine);
+      scan_strided<P4, kCrop>(tp, se.x, se.y, gl, W, qx, qy, qz, crop, mine, col);
     }
     lds_wave_sync();  // s_list is rewritten by the next round
   }
@@ -584,6 +627,13 @@ struct IcpPassArgs {
   // record iff the winning key names this rank.  0 = the ordinary pass.
   int keys_mode, keys_rank;
   unsigned long long* keys;  // [n_src]
+  // Candidate sets (see Collect): per query the <= kSetCap listed positions (set_pos[4 i + k], -1 = unused; without a set entry 0 is
+  // the match itself, the next search's bound) and {p_ref.xyz, L} in storage precision (set_ref[4 i + 0..3]; L = 0: no set).
+  // Fused kernel only (the margin comes from the update the launch's prologue has just computed); null = off.
+  int* set_pos;
+  void* set_ref;
+  float set_gain, set_min, set_cap;  // margin m = gain * (|R - I|_F |p| + |t|) of the last update, at least set_min; above set_cap: no set
+  unsigned long long* stats;  // null, or per-launch counters [launch][4]: verified matches, searches, sets left behind, stage-3 queries (O3DS_ICP_STATS)
 };
 
 // Per-query record staged in LDS: {J0..J5, r, one, d2, 0}.  Every entry of the 32-double normal-equation record is a
@@ -688,22 +738,43 @@ template <typename P4>
 struct QueryPrefetch {
   P4 s, tprev;
   int prev;
+  // candidate-set mode: THIS LANE's listed point (prev / tprev above) and its normal, and the set's reference {p_ref, L}
+  P4 nprev;
+  typename Scalar<P4>::type rx, ry, rz, rL;
+};
+
+template <typename P4>
+struct alignas(4 * sizeof(typename Scalar<P4>::type)) SetRef {
+  typename Scalar<P4>::type x, y, z, L;
 };
 
 template <typename P4, int kPassBlock, int kGroup>
 __device__ __forceinline__ QueryPrefetch<P4> prefetch_query(const IcpPassArgs& a, size_t batch, bool use_cache) {
   constexpr int kQPB = kPassBlock / kGroup;
+  using R = typename Scalar<P4>::type;
   QueryPrefetch<P4> q;
   q.prev = -1;
   q.s = P4{};
+  q.nprev = P4{};
+  q.rx = q.ry = q.rz = q.rL = (R)0;
+  const bool sets = use_cache && a.set_pos != nullptr;
   const size_t i = query_index<kQPB, 64 / kGroup>(a.count, batch, threadIdx.x / kGroup, !use_cache);
   if (i < a.count) {
     q.s = ((const P4*)a.src)[a.first + i];
-    int prev = use_cache ? a.nn_cache[a.first + i] : -1;
+    int prev = -1;
+    if (sets) {
+      static_assert(kGroup == kSetCap, "one listed point per lane of the group");
+      prev = a.set_pos[(a.first + i) * kSetCap + (threadIdx.x & (kGroup - 1))];
+      const SetRef<P4> r = ((const SetRef<P4>*)a.set_ref)[a.first + i];
+      q.rx = r.x, q.ry = r.y, q.rz = r.z, q.rL = r.L;
+    } else if (use_cache) {
+      prev = a.nn_cache[a.first + i];
+    }
     if (prev >= a.n_tgt) prev = -1;  // never trust the cache with an address
     q.prev = prev;
   }
   q.tprev = ((const P4*)a.tpts)[max(q.prev, 0)];
+  if (sets && a.tnrm) q.nprev = ((const P4*)a.tnrm)[max(q.prev, 0)];
   return q;
 }
 
@@ -717,16 +788,66 @@ __device__ __forceinline__ int wave_pop(int* counter, int lane) {
 // an unresolved query parked for stage 3
 template <typename P4>
 struct FarItem {
-  typename Scalar<P4>::type x, y, z, d2;
+  typename Scalar<P4>::type x, y, z, d2, m, tau2;
   typename Scalar<P4>::index idx;
   int pos;
 };
+
+// What the prologue of a fused launch knows about the update it has just applied (the candidate-set margin is derived from it per
+// query); unit = off.
+struct SetMargin {
+  float w, t;  // |R - I|_F and |t| of the last update U; w < 0: no sets this pass
+};
+
+// The record of ONE correspondence (query at p, matched target point q with normal nq) into its 10 (or, generalized ICP, 32) LDS slots.
+template <typename P4, bool kGicp>
+__device__ __forceinline__ void write_record(const IcpPassArgs& a, double* rec, bool p2p, double px, double py, double pz, const P4& q,
+                                             const P4& nq, size_t i, double t00, double t01, double t02, double t10, double t11,
+                                             double t12, double t20, double t21, double t22) {
+  const double dx = px - (double)q.x, dy = py - (double)q.y, dz = pz - (double)q.z;
+  if (!kGicp && p2p) {
+    rec[0] = px;
+    rec[1] = py;
+    rec[2] = pz;
+    rec[3] = (double)q.x;
+    rec[4] = (double)q.y;
+    rec[5] = (double)q.z;
+    rec[6] = 0.0;
+    rec[7] = 1.0;
+    rec[8] = dx * dx + dy * dy + dz * dz;
+    rec[9] = 0.0;
+    return;
+  }
+  const double nx = (double)nq.x, ny = (double)nq.y, nz = (double)nq.z;
+  if (kGicp) {
+    const P4 ns = ((const P4*)a.snrm)[a.first + i];
+    double sa[3] = {(double)ns.x, (double)ns.y, (double)ns.z};
+    if (sa[0] < -0.99) sa[0] = 1.0, sa[1] = 0.0, sa[2] = 0.0;  // GetRotationFromE1ToX special case (decided on the stored normal)
+    const double av[3] = {t00 * sa[0] + t01 * sa[1] + t02 * sa[2], t10 * sa[0] + t11 * sa[1] + t12 * sa[2],
+                          t20 * sa[0] + t21 * sa[1] + t22 * sa[2]};  // covariance rotates with the cloud
+    double bv[3] = {nx, ny, nz};
+    if (bv[0] < -0.99) bv[0] = 1.0, bv[1] = 0.0, bv[2] = 0.0;
+    gicp_record(px, py, pz, dx, dy, dz, av, bv, a.gicp_k, rec);
+  } else {
+    rec[0] = py * nz - pz * ny;  // J = [p x n ; n]
+    rec[1] = pz * nx - px * nz;
+    rec[2] = px * ny - py * nx;
+    rec[3] = nx;
+    rec[4] = ny;
+    rec[5] = nz;
+    rec[6] = dx * nx + dy * ny + dz * nz;  // r = (p - q) . n
+    rec[7] = 1.0;
+    rec[8] = dx * dx + dy * dy + dz * dz;
+    rec[9] = 0.0;
+  }
+}
 
 template <typename P4, bool kCrop, int kPassBlock, int kGroup, bool kGicp, bool kKeys = false /* the keys_mode code (classic kernel only) */>
 __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const double* Tm, int wg, int nwg, double* s_rec_flat,
                                                 double (*s_red)[kRec], int2* s_seg /* [kPassBlock / kGroup][kSegMax] */,
                                                 bool use_cache, const QueryPrefetch<P4>& first_batch,
-                                                unsigned long long* tr = nullptr /* 3 timestamps, development aid */) {
+                                                unsigned long long* tr = nullptr /* 3 timestamps, development aid */,
+                                                SetMargin sm = SetMargin{-1.0f, 0.0f}, int* s_set = nullptr /* [kQPB][1 + kSetCap] */) {
   constexpr int kQPB = kPassBlock / kGroup;
   constexpr int kStride = kGicp ? kRec : kRecSlots;  // doubles per query record
   static_assert((64 / kGroup) * kSegMax >= kFarList, "a wavefront's share of s_seg holds the stage-3 list");
@@ -743,6 +864,12 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
   const bool p2p = a.method == O3DS_ICP_POINT_TO_POINT || inf;  // uniform: records built from the points themselves, no normals
   const int ta = inf ? kTermA_inf[term] : (p2p ? kTermA_p2p[term] : kTermA[term]);
   const int tb = inf ? kTermB_inf[term] : (p2p ? kTermB_p2p[term] : kTermB[term]);
+  // candidate sets: read (verified matches) whenever the previous pass left them, written whenever this pass has a margin
+  const bool sets = !kKeys && a.set_pos != nullptr && s_set != nullptr;
+  const bool sets_in = sets && use_cache;
+  const bool sets_out = sets && sm.w >= 0.0f;
+  const R rmax = (R)sqrt(a.r2max);
+  int* my_set = sets ? s_set + ql * (1 + kSetCap) : nullptr;
   double acc = 0.0;
   const size_t n_batches = (a.count + kQPB - 1) / kQPB;
   static_assert(sizeof(FarItem<P4>) <= kStride * sizeof(double), "a parked far query fits its record slot");
@@ -758,13 +885,18 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
     nn.idx = -1;
     nn.d2 = (R)0;
     bool unresolved = false;
+    bool verified = false;   // the match was proven inside the prefetched candidate set: the winner's lane holds point and normal
+    int kdone = 0;           // block radius (cells) the search of this query covered; 0 = no search ran
+    R m = (R)0;  // candidate-set margin of this query's search (0: the search leaves no set)
     const QueryPrefetch<P4> qp = b == (size_t)wg ? first_batch : prefetch_query<P4, kPassBlock, kGroup>(a, b, use_cache);
+    if (sets && gl == 0) my_set[0] = 0;  // (same wavefront as its readers and writers below; the far stage is behind a barrier)
     if (i < a.count) {  // uniform across the lanes of a group
       const P4 s = qp.s;
       // [O3D] PointCloud::Transform: rigid 4x4 (bottom row 0 0 0 1 for every pose the reference passes)
       px = t00 * (double)s.x + t01 * (double)s.y + t02 * (double)s.z + t03;
       py = t10 * (double)s.x + t11 * (double)s.y + t12 * (double)s.z + t13;
       pz = t20 * (double)s.x + t21 * (double)s.y + t22 * (double)s.z + t23;
+      const R qx = (R)px, qy = (R)py, qz = (R)pz;
       bool resolved = true;
       if (a.debug == 2) {
         nn.pos = (int)(i % 1000);
@@ -776,8 +908,68 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
           nn.idx = nn.pos;
           nn.d2 = (R)__uint_as_float((unsigned int)(key >> 32));
         }
-      } else
-        nn = nn_search_group<P4, kCrop, kGroup>(a.grid, tp, (R)px, (R)py, (R)pz, (R)a.r2max, a.kmax, a.crop, gl, s_seg + ql * kSegMax, qp.prev, qp.tprev, &resolved);
+      } else {
+        // the starting bound: the cached match (every lane the same point) or, with candidate sets, the best of the listed points
+        // (every lane its own; a set without a list keeps the match in entry 0)
+        NNBest<P4> best;
+        best.d2 = (R)a.r2max;
+        best.pos = -1;
+        best.idx = -1;
+        consider<P4, kCrop>(qp.tprev, qp.prev, qp.prev >= 0, qx, qy, qz, a.crop, best);
+        if (sets_in) {
+          lanes_min<P4, kGroup>(best);
+          // verified match: everything that is not listed is at least L away from p_ref, hence at least L - |p - p_ref| from p
+          const R ex = qx - qp.rx, ey = qy - qp.ry, ez = qz - qp.rz;
+          const R delta = (R)sqrt(ex * ex + ey * ey + ez * ez);
+          const R dcmp = best.pos != -1 ? (R)sqrt(best.d2) : rmax;
+          verified = (qp.rL - delta) * (R)0.99998 > dcmp;  // (false for L = 0 = no set, and for NaN)
+          if (a.debug == 64) verified = false;
+        }
+        if (verified) {
+          // the lane that holds the winner writes the record now (point and normal are in its registers); no match: lane 0, zeros
+          nn = best;
+          if (nn.pos != -1 ? qp.prev == nn.pos : gl == 0) {
+            a.nn_cache[a.first + i] = nn.pos;
+            double* rec = s_rec_flat + ql * kStride;
+            if (nn.pos != -1) {
+              write_record<P4, kGicp>(a, rec, p2p, px, py, pz, qp.tprev, qp.nprev, i, t00, t01, t02, t10, t11, t12, t20, t21, t22);
+            } else {
+#pragma unroll
+              for (int k = 0; k < kStride; ++k) rec[k] = 0.0;
+            }
+          }
+        } else {
+          R tau2 = (R)0;
+          if (sets_out) {  // margin of this query's search from the update just applied: the next update is smaller
+            const float pn = sqrtf((float)(px * px + py * py + pz * pz));
+            const float mm = a.set_gain * (sm.w * pn + sm.t);
+            if (mm <= a.set_cap) {
+              m = (R)fmaxf(mm, a.set_min);
+              const R tau = (R)sqrt(best.d2) + m;
+              tau2 = tau * tau;
+            }
+          }
+          Collect<R> col;
+          col.tau2 = tau2;
+          col.cnt = my_set;
+          col.list = my_set + 1;
+          // (the lane's row offsets are recomputed per batch: hoisted out of the batch loop they cost a dozen registers, i.e. spills)
+          int gl_b = gl;
+          asm volatile("" : "+v"(gl_b));
+          nn = nn_search_group<P4, kCrop, kGroup>(a.grid, tp, qx, qy, qz, a.kmax, a.crop, gl_b, s_seg + ql * kSegMax, best, m, col, &resolved, &kdone);
+          if (!resolved && gl == 0) {  // park the query for stage 3 (its record slot is still unused)
+            FarItem<P4>* mine_item = (FarItem<P4>*)(s_rec_flat + ql * kStride);
+            mine_item->x = qx;
+            mine_item->y = qy;
+            mine_item->z = qz;
+            mine_item->d2 = nn.d2;
+            mine_item->m = m;
+            mine_item->tau2 = tau2;
+            mine_item->idx = nn.idx;
+            mine_item->pos = nn.pos;
+          }
+        }
+      }
       unresolved = !resolved;
     }
     if (tr && threadIdx.x == 0) tr[0] = wall_clock64();
@@ -791,12 +983,6 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
       if (unresolved && gl == 0) {
         const int k = atomicAdd(&s_far[0], 1);
         s_far[2 + k] = ql;
-        mine_item->x = (R)px;
-        mine_item->y = (R)py;
-        mine_item->z = (R)pz;
-        mine_item->d2 = nn.d2;
-        mine_item->idx = nn.idx;
-        mine_item->pos = nn.pos;
       }
       __syncthreads();
       const int n_far = __builtin_amdgcn_readfirstlane(s_far[0]);
@@ -804,12 +990,17 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
         const int lane = threadIdx.x & 63;
         int2* list = s_seg + (threadIdx.x >> 6) * (64 / kGroup) * kSegMax;
         for (int k = wave_pop(&s_far[1], lane); k < n_far; k = wave_pop(&s_far[1], lane)) {  // k is scalar: a uniform loop
-          FarItem<P4>* it = (FarItem<P4>*)(s_rec_flat + s_far[2 + k] * kStride);
+          const int slot = s_far[2 + k];
+          FarItem<P4>* it = (FarItem<P4>*)(s_rec_flat + slot * kStride);
           NNBest<P4> bq;
           bq.d2 = it->d2;
           bq.pos = it->pos;
           bq.idx = it->idx;
-          if (a.debug != 32) nn_search_wave_far<P4, kCrop>(a.grid, tp, it->x, it->y, it->z, a.kmax, a.crop, bq, lane, list);
+          Collect<R> col;
+          col.tau2 = it->tau2;
+          col.cnt = sets ? s_set + slot * (1 + kSetCap) : nullptr;
+          col.list = col.cnt + 1;
+          if (a.debug != 32) nn_search_wave_far<P4, kCrop>(a.grid, tp, it->x, it->y, it->z, a.kmax, a.crop, bq, lane, list, it->m, col);
           // every lane holds the same winner and stores it (same address, same value): no lane-0 branch inside this loop --
           // with one, the structurised code re-ran the body for the other lanes forever (seen on ROCm 7.2)
           it->d2 = bq.d2;
@@ -817,64 +1008,67 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
           it->idx = bq.idx;
         }
         __syncthreads();
-        if (unresolved && gl == 0) {
+        if (unresolved) {  // (all lanes of the group: the set below is written by all of them)
           nn.d2 = mine_item->d2;
           nn.pos = mine_item->pos;
           nn.idx = mine_item->idx;
+          kdone = a.kmax;
         }
       }
     }
     if (tr && threadIdx.x == 0) tr[1] = wall_clock64();
-    if (gl == 0) {
-      if (i < a.count && !(kKeys && a.keys_mode == 2)) a.nn_cache[a.first + i] = nn.pos;
-      if (kKeys && a.keys_mode == 1 && i < a.count)
-        a.keys[a.first + i] = nn.pos == -1 ? kNoKey
-                                           : ((unsigned long long)__float_as_uint((float)nn.d2) << 32) |
-                                                 ((unsigned long long)(a.keys_rank & 0xf) << 28) | (unsigned long long)(nn.pos & 0x0fffffff);
-      double* rec = s_rec_flat + ql * kStride;
-      if (nn.pos != -1 && !(kKeys && a.keys_mode == 1)) {
-        if (a.debug == 3) nn.pos = (int)(i % 1000);
-        const P4 q = tp[nn.pos];
-        const double dx = px - (double)q.x, dy = py - (double)q.y, dz = pz - (double)q.z;
-        if (!kGicp && p2p) {
-          rec[0] = px;
-          rec[1] = py;
-          rec[2] = pz;
-          rec[3] = (double)q.x;
-          rec[4] = (double)q.y;
-          rec[5] = (double)q.z;
-          rec[6] = 0.0;
-          rec[7] = 1.0;
-          rec[8] = dx * dx + dy * dy + dz * dz;
-          rec[9] = 0.0;
-        } else {
-        const P4 nq = tn[nn.pos];
-        const double nx = (double)nq.x, ny = (double)nq.y, nz = (double)nq.z;
-        if (kGicp) {
-          const P4 ns = ((const P4*)a.snrm)[a.first + i];
-          double sa[3] = {(double)ns.x, (double)ns.y, (double)ns.z};
-          if (sa[0] < -0.99) sa[0] = 1.0, sa[1] = 0.0, sa[2] = 0.0;  // GetRotationFromE1ToX special case (decided on the stored normal)
-          const double av[3] = {t00 * sa[0] + t01 * sa[1] + t02 * sa[2], t10 * sa[0] + t11 * sa[1] + t12 * sa[2],
-                                t20 * sa[0] + t21 * sa[1] + t22 * sa[2]};  // covariance rotates with the cloud
-          double bv[3] = {nx, ny, nz};
-          if (bv[0] < -0.99) bv[0] = 1.0, bv[1] = 0.0, bv[2] = 0.0;
-          gicp_record(px, py, pz, dx, dy, dz, av, bv, a.gicp_k, rec);
-        } else {
-        rec[0] = py * nz - pz * ny;  // J = [p x n ; n]
-        rec[1] = pz * nx - px * nz;
-        rec[2] = px * ny - py * nx;
-        rec[3] = nx;
-        rec[4] = ny;
-        rec[5] = nz;
-        rec[6] = dx * nx + dy * ny + dz * nz;  // r = (p - q) . n
-        rec[7] = 1.0;
-        rec[8] = dx * dx + dy * dy + dz * dz;
-        rec[9] = 0.0;
+    if (a.stats) {  // development aid: how the queries of this launch were served
+      const bool q0 = gl == 0 && i < a.count;
+      const unsigned long long nv = __popcll(__ballot(q0 && verified)), ns = __popcll(__ballot(q0 && !verified)),
+                               nk = __popcll(__ballot(q0 && !verified && m > (R)0 && sets && s_set[ql * (1 + kSetCap)] <= kSetCap)),
+                               nf = __popcll(__ballot(q0 && unresolved));
+      if ((threadIdx.x & 63) == 0) {
+        atomicAdd(a.stats + 0, nv);
+        atomicAdd(a.stats + 1, ns);
+        atomicAdd(a.stats + 2, nk);
+        atomicAdd(a.stats + 3, nf);
+      }
+    }
+    // ---- the candidate set this query's search leaves for the next pass (a verified match keeps the one it has)
+    if (sets && i < a.count && !verified && a.debug != 2) {
+      const int n_listed = my_set[0];
+      const bool have = m > (R)0 && n_listed <= kSetCap;
+      int pos_out = have ? (gl < n_listed ? my_set[1 + gl] : -1) : (gl == 0 ? nn.pos : -1);
+      a.set_pos[(a.first + i) * kSetCap + gl] = pos_out;
+      if (gl == 0) {
+        const R qx = (R)px, qy = (R)py, qz = (R)pz;
+        SetRef<P4> r;
+        r.x = qx, r.y = qy, r.z = qz;
+        r.L = (R)0;
+        if (have) {
+          // L = min(d1 + m, block reach): see Collect.  The block reach is cell * (k + distance to the nearest face), from the
+          // same f32 cell-relative quantities the search's own "proven" tests use, shrunk by their margin
+          const QueryCell c = locate(a.grid, (double)qx, (double)qy, (double)qz);
+          const R d1 = nn.pos != -1 ? (R)sqrt(nn.d2) : rmax;
+          const R reach = (R)(a.grid.cell * (double)(((float)kdone + c.mf) * (1.0f - 2e-4f)));
+          r.L = (R)fmin((double)(d1 + m), (double)reach);
         }
-        }
-      } else {
+        ((SetRef<P4>*)a.set_ref)[a.first + i] = r;
+      }
+    }
+    // ---- records
+    if (!verified && gl == 0) {
+      {
+        if (i < a.count && !(kKeys && a.keys_mode == 2)) a.nn_cache[a.first + i] = nn.pos;
+        if (kKeys && a.keys_mode == 1 && i < a.count)
+          a.keys[a.first + i] = nn.pos == -1 ? kNoKey
+                                             : ((unsigned long long)__float_as_uint((float)nn.d2) << 32) |
+                                                   ((unsigned long long)(a.keys_rank & 0xf) << 28) | (unsigned long long)(nn.pos & 0x0fffffff);
+        double* rec = s_rec_flat + ql * kStride;
+        if (nn.pos != -1 && !(kKeys && a.keys_mode == 1)) {
+          if (a.debug == 3) nn.pos = (int)(i % 1000);
+          const P4 q = tp[nn.pos];
+          const P4 nq = (!kGicp && p2p) ? P4{} : tn[nn.pos];
+          write_record<P4, kGicp>(a, rec, p2p, px, py, pz, q, nq, i, t00, t01, t02, t10, t11, t12, t20, t21, t22);
+        } else {
 #pragma unroll
-        for (int k = 0; k < kStride; ++k) rec[k] = 0.0;
+          for (int k = 0; k < kStride; ++k) rec[k] = 0.0;
+        }
       }
     }
     __syncthreads();
@@ -1310,7 +1504,8 @@ __device__ __forceinline__ void icp_step_block(const double* s_rec, IcpStateDev*
                                                double rel_fitness, double rel_rmse, double* s_x /* [8] */, double* s_sc /* unused */,
                                                double* s_U /* [16] */, double* s_T /* [16] */, int* s_go,
                                                unsigned long long* tr = nullptr /* 8 timestamps, development aid */,
-                                               int method = O3DS_ICP_POINT_TO_PLANE) {
+                                               int method = O3DS_ICP_POINT_TO_PLANE,
+                                               float* s_margin = nullptr /* [2]: |R - I|_F and |t| of the update (candidate-set margin) */) {
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   (void)s_sc;
 #define O3DS_TSTAMP(k)                                       \
@@ -1394,6 +1589,20 @@ __device__ __forceinline__ void icp_step_block(const double* s_rec, IcpStateDev*
     if (lane < 16) st->T[lane] = tnew;
     if (lane == 0) st->iterations += 1;
   }
+  if (s_margin && wv == 2 && lane == 0) {  // how far the update moves a point p: at most |R - I|_F |p| + |t| (an idle wavefront's work)
+    double w2 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const double d = s_U[c * 4 + r] - (r == c ? 1.0 : 0.0);
+        w2 += d * d;
+      }
+      t2 += s_U[12 + c] * s_U[12 + c];
+    }
+    s_margin[0] = sqrtf((float)w2);
+    s_margin[1] = sqrtf((float)t2);
+  }
   O3DS_TSTAMP(4);
 #undef O3DS_TSTAMP
 }
@@ -1463,38 +1672,88 @@ struct IcpFusedArgs {
   unsigned long long* trace;      // null, or [gridDim.x][16] phase timestamps (100 MHz wall clock) of thread 0 (O3DS_FUSED_TRACE)
 };
 
+// Kernel arguments live in a kernarg segment the scalar cache has never seen when a wavefront starts; the compiler fetches each
+// field where it is first used and waits for it there, so a kernel with ~900 bytes of arguments pays one cold miss per 64-byte line it
+// touches, one after the other (seven of them before this kernel's first global load, read off the ISA).  One scalar load per line,
+// all in flight together, turns that into ONE miss; everything after it hits.
+template <int kBytes>
+__device__ __forceinline__ void kernarg_warm() {
+  static_assert(kBytes > 0 && kBytes <= 16 * 64, "at most 16 lines");
+  constexpr int kLines = (kBytes + 63) / 64;
+  const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+  int t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11, t12, t13, t14, t15;
+  // (offsets beyond the last line repeat the last dword of the segment: never past its end)
+#define O3DS_KA(k) ((k) < kLines - 1 ? (k) * 64 : kBytes - 4)
+  asm volatile(
+      "s_load_dword %0, %16, %17\n\ts_load_dword %1, %16, %18\n\ts_load_dword %2, %16, %19\n\ts_load_dword %3, %16, %20\n\t"
+      "s_load_dword %4, %16, %21\n\ts_load_dword %5, %16, %22\n\ts_load_dword %6, %16, %23\n\ts_load_dword %7, %16, %24\n\t"
+      "s_load_dword %8, %16, %25\n\ts_load_dword %9, %16, %26\n\ts_load_dword %10, %16, %27\n\ts_load_dword %11, %16, %28\n\t"
+      "s_load_dword %12, %16, %29\n\ts_load_dword %13, %16, %30\n\ts_load_dword %14, %16, %31\n\ts_load_dword %15, %16, %32\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7), "=&s"(t8), "=&s"(t9), "=&s"(t10),
+        "=&s"(t11), "=&s"(t12), "=&s"(t13), "=&s"(t14), "=&s"(t15)
+      : "s"(ka), "n"(O3DS_KA(0)), "n"(O3DS_KA(1)), "n"(O3DS_KA(2)), "n"(O3DS_KA(3)), "n"(O3DS_KA(4)), "n"(O3DS_KA(5)), "n"(O3DS_KA(6)),
+        "n"(O3DS_KA(7)), "n"(O3DS_KA(8)), "n"(O3DS_KA(9)), "n"(O3DS_KA(10)), "n"(O3DS_KA(11)), "n"(O3DS_KA(12)), "n"(O3DS_KA(13)),
+        "n"(O3DS_KA(14)), "n"(O3DS_KA(15))
+      : "memory");
+#undef O3DS_KA
+}
+
 template <typename P4, bool kCrop, int kPassBlock, int kGroup, bool kGicp>
 __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4))) void icp_fused_kernel(IcpFusedArgs fa) {
   constexpr int kQPB = kPassBlock / kGroup;
   constexpr int kParts = kPassBlock / 32;
-  static_assert(kFusedSlots * kSlotDoubles <= 2 * kPassBlock, "two slot values per thread in the prologue");
   __shared__ double s_rec[kQPB * (kGicp ? kRec : kRecSlots)];
   __shared__ double s_red[kParts][kRec];
   __shared__ int2 s_seg[kQPB * kSegMax];
   __shared__ double s_out[kRec];
   __shared__ double s_x[8], s_sc[8], s_U[16], s_T[16];
   __shared__ IcpStateDev s_st;
-  __shared__ double s_slots[2 * kPassBlock];
+  __shared__ int s_set[kQPB * (1 + kSetCap)];
+  __shared__ float s_margin[2];
   __shared__ int s_go;
+  kernarg_warm<(int)sizeof(IcpFusedArgs)>();
 #define O3DS_STAMP(k)                                                                                  \
   do {                                                                                                 \
     if (fa.trace && threadIdx.x == 0) fa.trace[(size_t)blockIdx.x * 16 + (k)] = wall_clock64();         \
   } while (0)
   O3DS_STAMP(0);
-  // pose-independent loads of this workgroup's queries go out first; they land while the tail of the previous pass is computed
   const bool use_cache = !fa.first;  // launch j evaluates pass j of the registration
-  const QueryPrefetch<P4> qp = prefetch_query<P4, kPassBlock, kGroup>(fa.pass, blockIdx.x, use_cache);
   // ---------------- prologue: this pass's state from the previous state and the previous pass's slot records ----------------
-  double x0 = 0.0, x1 = 0.0;  // two of the kFusedSlots x 64 slot values per thread
-  if (!fa.first) {  // issue the slot loads before the state is looked at: one memory round trip instead of two
-    x0 = fa.slots_in[threadIdx.x];
-    x1 = fa.slots_in[kPassBlock + threadIdx.x];
+  // The loads the serial tail waits for go out FIRST (the memory pipeline returns in order): the previous state (thread 0) and the
+  // kFusedSlots x 64 slot values, 16 per lane of the first half-wavefront (value index = slot * 64 + {hi: 0..31, lo: 32..63} + term).
+  // wavefront 0: lane l holds dword l of the state and slot values l, 64 + l, ..., 448 + l (the hi sums of term l, or the lo sums of
+  // term l - 32, of the eight slots)
+  constexpr int kStateWords = (int)(sizeof(IcpStateDev) / sizeof(unsigned));
+  static_assert(sizeof(IcpStateDev) % sizeof(unsigned) == 0 && kStateWords <= 64, "one dword of the state per lane");
+  unsigned st_word = 0u;
+  double sv[kFusedSlots];
+  if (!fa.first && threadIdx.x < 64) {
+    if (threadIdx.x < kStateWords) st_word = ((const unsigned*)fa.state_in)[threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < kFusedSlots; ++k) sv[k] = fa.slots_in[k * kSlotDoubles + threadIdx.x];
   }
+  __builtin_amdgcn_sched_barrier(0);
+  // pose-independent loads of this workgroup's queries: source point, cached match or candidate set (points AND normals); they land
+  // while the tail of the previous pass is computed
+  const QueryPrefetch<P4> qp = prefetch_query<P4, kPassBlock, kGroup>(fa.pass, blockIdx.x, use_cache);
   if (blockIdx.x == 0) {  // the buffer of the NEXT pass was last read two launches ago
+    static_assert(kFusedSlots * kSlotDoubles == 2 * kPassBlock, "two slot values per thread");
     fa.slots_clear[threadIdx.x] = 0.0;
     fa.slots_clear[kPassBlock + threadIdx.x] = 0.0;
   }
-  if (threadIdx.x == 0) s_st = fa.first ? fa.init : *fa.state_in;
+  if (fa.first) {
+    if (threadIdx.x == 0) s_st = fa.init;
+  } else if (threadIdx.x < 64) {
+    if (threadIdx.x < kStateWords) ((unsigned*)&s_st)[threadIdx.x] = st_word;
+    // sums of hi (resp. lo) values are exact, so any order will do
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < kFusedSlots; ++k) t += sv[k];
+    const double tl = __shfl_down(t, 32, 64);
+    if (threadIdx.x < kRec) s_out[threadIdx.x] = t + tl;  // the one rounding, as in reduce_partials
+  }
+  if (threadIdx.x < 2) s_margin[threadIdx.x] = threadIdx.x == 0 ? -1.0f : 0.0f;
   __syncthreads();
   if (s_st.done) {  // loop already terminated: hand the final state on
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1505,23 +1764,8 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   }
   O3DS_STAMP(1);
   if (!fa.first) {
-    // thread t holds slot values t and kPassBlock + t; value index = slot * 64 + {hi: 0..31, lo: 32..63} + term.  Sums of hi (resp.
-    // lo) values are exact, so any order will do: through LDS, 2 x kFusedSlots values per term
-    s_slots[threadIdx.x] = x0;
-    s_slots[kPassBlock + threadIdx.x] = x1;
-    __syncthreads();
-    if (threadIdx.x < kRec) {
-      double th = 0.0, tl = 0.0;
-#pragma unroll
-      for (int k = 0; k < kFusedSlots; ++k) {
-        th += s_slots[k * kSlotDoubles + threadIdx.x];
-        tl += s_slots[k * kSlotDoubles + kRec + threadIdx.x];
-      }
-      s_out[threadIdx.x] = th + tl;  // the one rounding, as in reduce_partials
-    }
-    __syncthreads();
     icp_step_block(s_out, &s_st, fa.n_src_total, fa.max_iter, fa.rel_fitness, fa.rel_rmse, s_x, s_sc, s_U, s_T, &s_go,
-                   fa.trace ? fa.trace + (size_t)blockIdx.x * 16 + 8 : nullptr, fa.pass.method);
+                   fa.trace ? fa.trace + (size_t)blockIdx.x * 16 + 8 : nullptr, fa.pass.method, s_margin);
     __syncthreads();
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1531,8 +1775,11 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   if (s_st.done) return;
   O3DS_STAMP(2);
   // ---------------- body: correspondence + reduction pass under the new pose ----------------
+  SetMargin sm;
+  sm.w = s_margin[0];
+  sm.t = s_margin[1];
   const double v = icp_pass_body<P4, kCrop, kPassBlock, kGroup, kGicp>(fa.pass, s_st.T, blockIdx.x, gridDim.x, s_rec, s_red, s_seg, use_cache, qp,
-                                                                       fa.trace ? fa.trace + (size_t)blockIdx.x * 16 + 13 : nullptr);
+                                                                       fa.trace ? fa.trace + (size_t)blockIdx.x * 16 + 13 : nullptr, sm, s_set);
   O3DS_STAMP(3);
   // ---------------- epilogue: add the record to this workgroup's slot, exactly ----------------
   if (threadIdx.x < kRec) {

@@ -1,0 +1,37 @@
+#!/bin/bash
+# Round 4, GPU visit A: the candidate-set fused kernel against the round-3 library (kept as lib/libo3ds_backend_r3.so, untracked):
+# the ICP tests, configs[1] alone per variant (rate, phase trace of launch 5, per-launch counters of how queries were served).
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/r4a
+mkdir -p $OUT
+cd $R
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+M1="python bench.py --no-cpu-baseline --no-f64 --concurrent 0 --m2-frames 0 --large-map 0 --no-host-seam"
+one() {  # tag, env...
+  tag=$1; shift
+  env "$@" $M1 --steps 100 --warmup 10 2>$OUT/$tag.err | grep '^{' | tail -1 > $OUT/$tag.json
+  python - <<PY
+import json
+try:
+    d=json.load(open("$OUT/$tag.json")); print("$tag", round(d["value"]), "it/s", round(d["ms_per_step"]*1e3,1), "us/step frac", round(d["roofline"]["frac"],4))
+except Exception as e: print("$tag FAILED", e)
+PY
+  env "$@" O3DS_FUSED_TRACE=$OUT/$tag.trace5 O3DS_FUSED_TRACE_LAUNCH=5 $M1 --steps 2 --warmup 1 >/dev/null 2>&1
+  env "$@" O3DS_FUSED_TRACE=$OUT/$tag.trace0 O3DS_FUSED_TRACE_LAUNCH=0 $M1 --steps 2 --warmup 1 >/dev/null 2>&1
+  for k in 0 5; do [ -f $OUT/$tag.trace$k ] && python scripts/fused_trace.py $OUT/$tag.trace$k > $OUT/$tag.trace$k.txt 2>&1; done
+}
+timeout 900 python -m pytest tests/test_icp_gpu.py tests/test_edge_parity_gpu.py -m gpu -q -x 2>&1 | grep -v "amdgpu.ids\|socket.cpp" | tail -15 > $OUT/pytest_icp.log
+tail -3 $OUT/pytest_icp.log
+one r3 O3DS_BACKEND_LIB=$R/open3d_slam_amd/lib/libo3ds_backend_r3.so
+one r3_devkernarg O3DS_BACKEND_LIB=$R/open3d_slam_amd/lib/libo3ds_backend_r3.so HIP_FORCE_DEV_KERNARG=1
+one new_sets_off O3DS_ICP_SETS=0
+one new_sets_on O3DS_ICP_SETS=1
+one new_sets_on_devkernarg O3DS_ICP_SETS=1 HIP_FORCE_DEV_KERNARG=1
+one new_sets_gain4 O3DS_SET_GAIN=4
+one new_sets_min3mm O3DS_SET_MIN=0.003
+O3DS_ICP_STATS=1 $M1 --steps 1 --warmup 1 2>&1 >/dev/null | grep "icp stats" | tail -2 > $OUT/stats_default.txt
+O3DS_ICP_STATS=1 O3DS_SET_GAIN=4 $M1 --steps 1 --warmup 1 2>&1 >/dev/null | grep "icp stats" | tail -1 > $OUT/stats_gain4.txt
+O3DS_ICP_STATS=1 O3DS_SET_MIN=0.003 $M1 --steps 1 --warmup 1 2>&1 >/dev/null | grep "icp stats" | tail -1 > $OUT/stats_min3mm.txt
+cat $OUT/stats_*.txt
+for t in r3 new_sets_off new_sets_on; do echo "== $t trace5"; tail -12 $OUT/$t.trace5.txt; done
+echo "== new_sets_on trace0"; tail -6 $OUT/new_sets_on.trace0.txt

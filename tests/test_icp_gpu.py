@@ -582,3 +582,49 @@ def test_rank_deficient_normal_equations_follow_eigen_ldlt(backend_f64, oracle):
         T = got["transformation"]
         # the unobservable motions get no update of their own (what little x / y appears is the tilt acting on the z offset)
         assert abs(T[0, 3]) < 1e-6 and abs(T[1, 3]) < 1e-6 and abs(T[1, 0]) < 1e-6
+
+
+# ---- candidate sets: a steady pass verifies its matches instead of searching (icp_kernels.hpp, Collect) ----------------------
+def _set_variants(monkeypatch, env):
+    for k in ("O3DS_ICP_SETS", "O3DS_SET_GAIN", "O3DS_SET_MIN", "O3DS_SET_CAP"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+
+
+@pytest.mark.parametrize("prec", [backend.PRECISION_F32, backend.PRECISION_F64])
+def test_candidate_sets_do_not_change_a_single_bit(small_c2, oracle, monkeypatch, prec):
+    """A pass that proves its matches inside the candidate sets the previous pass left (no search) yields the SAME correspondences as
+    the search, hence bit-identical sums, poses, fitness and rmse -- for every margin policy: off, default, margins so small that
+    nearly every verification fails, margins so large that the lists overflow.  Point-to-plane with and without a map crop,
+    generalized, point-to-point; fixed iterations and the default convergence criteria."""
+    src, tgt, nrm, _ = small_c2
+    sn = oracle.estimate_normals(src, 3.0, 20)
+    crop = backend.make_crop(backend.CROP_MAX_RADIUS, center=(1.0, -2.0, 0.0), rmax=22.0)
+    policies = [{"O3DS_ICP_SETS": "0"}, {}, {"O3DS_SET_MIN": "1e-6", "O3DS_SET_GAIN": "0.01"}, {"O3DS_SET_MIN": "0.04", "O3DS_SET_CAP": "10", "O3DS_SET_GAIN": "8"},
+                {"O3DS_SET_MIN": "0.3", "O3DS_SET_CAP": "10"}]
+    results = []
+    for env in policies:
+        _set_variants(monkeypatch, env)
+        be = backend.Backend(0, prec)
+        try:
+            out = []
+            s_id, t_id = be.upload(src, sn), be.upload(tgt, nrm)
+            for kw in (dict(max_iter=12, rel_fitness=0.0, rel_rmse=0.0), dict(max_iter=30)):
+                out.append(be.icp_point_to_plane_dev(s_id, t_id, 1.0, **kw))
+                out.append(be.icp_point_to_plane_dev(s_id, t_id, 1.0, target_crop=crop, **kw))
+                out.append(be.icp_generalized_dev(s_id, t_id, 1.0, **kw))
+                out.append(be.icp_point_to_point_dev(s_id, t_id, 1.0, **kw))
+            # a second registration on the same handle from another start: the sets of the first must not leak into it
+            T0 = syn.make_pose([0.1, 0.05, -0.02], [0.2, 0.1, -0.5])
+            out.append(be.icp_point_to_plane_dev(s_id, t_id, 1.0, init=T0, max_iter=12, rel_fitness=0.0, rel_rmse=0.0))
+            results.append(out)
+        finally:
+            be.close()
+    base = results[0]
+    assert base[0]["iterations"] == 12 and base[0]["fitness"] > 0.5
+    for env, out in zip(policies[1:], results[1:]):
+        for a, b in zip(base, out):
+            np.testing.assert_array_equal(a["transformation"], b["transformation"], err_msg=str(env))
+            assert (a["iterations"], a["converged"], a["n_corr"], a["fitness"], a["inlier_rmse"]) == (
+                b["iterations"], b["converged"], b["n_corr"], b["fitness"], b["inlier_rmse"]), env
