@@ -996,6 +996,11 @@ void launch_fused(o3ds_handle h, const IcpFusedArgs& fa, bool crop, int nblocks,
   if (e1) (void)hipEventRecord(e1, h->stream);
 }
 
+// the fused kernel serves ONE batch of 64 queries per workgroup (no batch loop: icp_pass_body, kSingle); its records go to slot
+// blockIdx % kFusedSlots, so the grid has no capacity to respect
+constexpr size_t kFusedMaxQueries = (size_t)4096 * 64;
+int fused_blocks(size_t count) { return (int)std::max<size_t>((count + 63) / 64, 1); }
+
 int pass_blocks(o3ds_handle h, size_t count) {
   const size_t qpb = 64;  // one batch of 256 / 4 queries per workgroup iteration
   size_t g = (count + qpb - 1) / qpb;
@@ -1624,6 +1629,7 @@ int o3ds_icp_pass(o3ds_handle h, size_t first, size_t count, size_t n_src_total,
   if (!h->session) return fail(h, O3DS_ERR_INVALID_ARG, "icp_pass: no session (call o3ds_icp_begin)");
   if (!d_sums_out || !d_sums_next || (h->session_launches > 0 && !d_sums_in)) return fail(h, O3DS_ERR_INVALID_ARG, "icp_pass: null sums buffer");
   if (first + count > h->session_n_src) return fail(h, O3DS_ERR_INVALID_ARG, "icp_pass: range outside source");
+  if (count > kFusedMaxQueries) return fail(h, O3DS_ERR_CAPACITY, "icp_pass: at most 262144 source points per call (split the range, or use o3ds_icp_accumulate)");
   IcpFusedArgs fa{};
   fa.pass = h->pass;
   fa.pass.first = first;
@@ -1642,7 +1648,7 @@ int o3ds_icp_pass(o3ds_handle h, size_t first, size_t count, size_t n_src_total,
   fa.slots_out = d_sums_out;
   fa.slots_clear = d_sums_next;
   fa.trace = nullptr;
-  const int nb = std::min(pass_blocks(h, count), kMaxPassBlocks);
+  const int nb = fused_blocks(count);
   if (h->session_precision == O3DS_PRECISION_F64)
     launch_fused<P4d>(h, fa, h->session_crop, nb, true);
   else
@@ -1854,11 +1860,15 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
   CHECK_HANDLE(h);
   ArenaScope arena_scope(h);
   if (!init || !out) return fail(h, O3DS_ERR_INVALID_ARG, "icp: null init/out");
-  int rc = begin_session(h, source, target, target_crop, init, params, !h->fused);
+  // the fused loop runs one workgroup per 64 queries; its exact record sums are order-independent for up to 4096 workgroup records
+  // (split_exact), so sources beyond kFusedMaxQueries points take the two-launch form (same results, looped pass kernel)
+  const CloudRec* src_rec = find_cloud(h, source);
+  const bool use_fused = h->fused && src_rec && src_rec->n <= kFusedMaxQueries;
+  int rc = begin_session(h, source, target, target_crop, init, params, !use_fused);
   if (rc) return rc;
   h->session = false;  // the loop below owns the state
   const IcpPassArgs a = h->pass;
-  if (h->fused) {
+  if (use_fused) {
     // launch j = [tail of pass j-1 in every workgroup's prologue] + pass j; launch max_iter+1 is prologue-only (one workgroup)
     IcpFusedArgs fa{};
     fa.pass = a;
@@ -1866,7 +1876,7 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
     fa.max_iter = params->max_iteration;
     fa.rel_fitness = params->relative_fitness;
     fa.rel_rmse = params->relative_rmse;
-    const int nb = std::min(pass_blocks(h, a.count), kMaxPassBlocks);
+    const int nb = fused_blocks(a.count);
     fa.init = *h->h_state;
     const int total = params->max_iteration + 2;
     // O3DS_FUSED_TRACE=<file>: phase timestamps of every workgroup of launch 5 (development aid, see scripts/fused_trace.py)

@@ -266,7 +266,7 @@ __device__ __forceinline__ void collect_push(const Collect<R>& c, int p) {
 }
 
 // candidates s+lane, s+lane+stride, ... of [s,e): four loads issued before the first is consumed
-template <typename P4, bool kCrop>
+template <typename P4, bool kCrop, bool kCollect>
 __device__ __forceinline__ void scan_strided(const P4* __restrict__ tp, int s, int e, int lane, int stride, typename Scalar<P4>::type qx,
                                              typename Scalar<P4>::type qy, typename Scalar<P4>::type qz, const CropDev& crop,
                                              NNBest<P4>& best, const Collect<typename Scalar<P4>::type>& col) {
@@ -279,13 +279,19 @@ __device__ __forceinline__ void scan_strided(const P4* __restrict__ tp, int s, i
     const P4 t2 = tp[v2 ? p2 : p];
     const P4 t3 = tp[v3 ? p3 : p];
     const R d0 = consider<P4, kCrop>(t0, p, true, qx, qy, qz, crop, best);
-    if (d0 < col.tau2) collect_push(col, p);  // the candidate-set list (rare: a handful of points per query lie inside tau; tau2 = 0: off)
     const R d1 = consider<P4, kCrop>(t1, p1, v1, qx, qy, qz, crop, best);
-    if (v1 & (d1 < col.tau2)) collect_push(col, p1);
     const R d2 = consider<P4, kCrop>(t2, p2, v2, qx, qy, qz, crop, best);
-    if (v2 & (d2 < col.tau2)) collect_push(col, p2);
     const R d3 = consider<P4, kCrop>(t3, p3, v3, qx, qy, qz, crop, best);
-    if (v3 & (d3 < col.tau2)) collect_push(col, p3);
+    if (kCollect) {
+      // the candidate-set list: a handful of points per query lie inside tau, so ONE test per four candidates (a clamped load
+      // repeats candidate p, so the minimum needs no masks; the flags sort it out inside)
+      if (min(min(d0, d1), min(d2, d3)) < col.tau2) {
+        if (d0 < col.tau2) collect_push(col, p);
+        if (v1 & (d1 < col.tau2)) collect_push(col, p1);
+        if (v2 & (d2 < col.tau2)) collect_push(col, p2);
+        if (v3 & (d3 < col.tau2)) collect_push(col, p3);
+      }
+    }
   }
 }
 
@@ -400,7 +406,7 @@ __device__ __forceinline__ float bound_cells2(R d2, R m, const GridDev& g) {
 // All G lanes of a group call this with the same query and the same starting bound `best` (any eligible target point, or {r^2, -1,
 // -1}); every lane returns the same winner.  m / col: the candidate-set margin and list (m = 0, col.tau2 = 0: off); *kdone = the
 // block radius (cells) the search covered.
-template <typename P4, bool kCrop, int G>
+template <typename P4, bool kCrop, int G, bool kCollect>
 __device__ __forceinline__ NNBest<P4> nn_search_group(const GridDev& g, const P4* __restrict__ tp, typename Scalar<P4>::type qx,
                                                       typename Scalar<P4>::type qy, typename Scalar<P4>::type qz, int kmax,
                                                       const CropDev& crop, int gl, int2* seg /* this group's kSegMax entries */,
@@ -453,7 +459,7 @@ __device__ __forceinline__ NNBest<P4> nn_search_group(const GridDev& g, const P4
     lds_wave_sync();
     for (int t = 0; t < total; ++t) {
       const int2 se = seg[t];
-      scan_strided<P4, kCrop>(tp, se.x, se.y, gl, G, qx, qy, qz, crop, best, col);
+      scan_strided<P4, kCrop, kCollect>(tp, se.x, se.y, gl, G, qx, qy, qz, crop, best, col);
     }
     lds_wave_sync();  // the list is rewritten by stage 2
     lanes_min<P4, G>(best);
@@ -508,7 +514,7 @@ __device__ __forceinline__ NNBest<P4> nn_search_group(const GridDev& g, const P4
       lds_wave_sync();
       for (int t = 0; t < total; ++t) {
         const int2 se = seg[t];
-        scan_strided<P4, kCrop>(tp, se.x, se.y, gl, G, qx, qy, qz, crop, best, col);
+        scan_strided<P4, kCrop, kCollect>(tp, se.x, se.y, gl, G, qx, qy, qz, crop, best, col);
       }
       lds_wave_sync();
       lanes_min<P4, G>(best);
@@ -525,7 +531,7 @@ __device__ __forceinline__ NNBest<P4> nn_search_group(const GridDev& g, const P4
 // of the current bound and were not scanned by stages 0-2 are dealt to the lanes (one cell_start pair each), compacted
 // through the wavefront's LDS list (mbcnt rank), and the lanes regroup so that every listed half-row gets
 // 64 / pow2(#rows) (>= 4) lanes striding over it.
-template <typename P4, bool kCrop>
+template <typename P4, bool kCrop, bool kCollect>
 __device__ __forceinline__ void nn_search_wave_far(const GridDev& g, const P4* __restrict__ tp, typename Scalar<P4>::type qx,
                                                    typename Scalar<P4>::type qy, typename Scalar<P4>::type qz, int K,
                                                    const CropDev& crop, NNBest<P4>& best, int lane, int2* s_list /* kFarList entries */,
@@ -586,7 +592,7 @@ __device__ __forceinline__ void nn_search_wave_far(const GridDev& g, const P4* _
     const int grp = lane / W, gl = lane % W;
     for (int t = grp; t < total; t += groups) {
       const int2 se = s_list[t];
-      scan_strided<P4, kCrop>(tp, se.x, se.y, gl, W, qx, qy, qz, crop, mine, col);
+      scan_strided<P4, kCrop, kCollect>(tp, se.x, se.y, gl, W, qx, qy, qz, crop, mine, col);
     }
     lds_wave_sync();  // s_list is rewritten by the next round
   }
@@ -639,17 +645,34 @@ struct IcpPassArgs {
 // Per-query record staged in LDS: {J0..J5, r, one, d2, 0}.  Every entry of the 32-double normal-equation record is a
 // product of two slots: JtJ[a][b] = J[a]*J[b], Jtr[a] = J[a]*r, sum r^2 = r*r, count = one*one, sum d^2 = d2*one.
 constexpr int kRecSlots = 10;
-__device__ const unsigned char kTermA[kRec] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9};
-__device__ const unsigned char kTermB[kRec] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5, 6, 6, 6, 6, 6, 6, 6, 7, 7, 9, 9};
+constexpr unsigned char kTermA[kRec] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9};
+constexpr unsigned char kTermB[kRec] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5, 6, 6, 6, 6, 6, 6, 6, 7, 7, 9, 9};
 // Point-to-point ([O3D] TransformationEstimationPointToPoint = Eigen::umeyama without scaling): per-query slots {p[3], q[3], 0, one,
 // d2, 0}; record [0..8] = sum q_a p_b (row a, column b), [9..11] = sum p, [12..14] = sum q, [28] = count, [29] = sum d2.
-__device__ const unsigned char kTermA_p2p[kRec] = {3, 3, 3, 4, 4, 4, 5, 5, 5, 0, 1, 2, 3, 4, 5, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 7, 8, 9, 9};
-__device__ const unsigned char kTermB_p2p[kRec] = {0, 1, 2, 0, 1, 2, 0, 1, 2, 7, 7, 7, 7, 7, 7, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 7, 7, 9, 9};
+constexpr unsigned char kTermA_p2p[kRec] = {3, 3, 3, 4, 4, 4, 5, 5, 5, 0, 1, 2, 3, 4, 5, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 7, 8, 9, 9};
+constexpr unsigned char kTermB_p2p[kRec] = {0, 1, 2, 0, 1, 2, 0, 1, 2, 7, 7, 7, 7, 7, 7, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 7, 7, 9, 9};
 // [O3D] GetInformationMatrixFromPointClouds (same slots as point-to-point): record [0..5] = sum of q q^T (xx, xy, xz, yy, yz, zz),
 // [6..8] = sum q, [28] = count, [29] = sum d2; the 6x6 is assembled from these ten numbers on the host.
 constexpr int kMethodInformation = 3;  // internal value of IcpPassArgs::method, not an o3ds_icp_method
-__device__ const unsigned char kTermA_inf[kRec] = {3, 3, 3, 4, 4, 5, 3, 4, 5, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 7, 8, 9, 9};
-__device__ const unsigned char kTermB_inf[kRec] = {3, 4, 5, 4, 5, 5, 7, 7, 7, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 7, 7, 9, 9};
+constexpr unsigned char kTermA_inf[kRec] = {3, 3, 3, 4, 4, 5, 3, 4, 5, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 7, 8, 9, 9};
+constexpr unsigned char kTermB_inf[kRec] = {3, 4, 5, 4, 5, 5, 7, 7, 7, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 7, 7, 9, 9};
+
+struct TermPack {
+  unsigned long long lo, hi;  // terms 0..15, 16..31, four bits each
+};
+constexpr TermPack pack_terms(const unsigned char (&t)[kRec]) {
+  TermPack p{0ull, 0ull};
+  for (int k = 0; k < 16; ++k) {
+    p.lo |= (unsigned long long)(t[k] & 15) << (4 * k);
+    p.hi |= (unsigned long long)(t[16 + k] & 15) << (4 * k);
+  }
+  return p;
+}
+constexpr TermPack kPackA = pack_terms(kTermA), kPackB = pack_terms(kTermB), kPackA_p2p = pack_terms(kTermA_p2p),
+                   kPackB_p2p = pack_terms(kTermB_p2p), kPackA_inf = pack_terms(kTermA_inf), kPackB_inf = pack_terms(kTermB_inf);
+__device__ __forceinline__ int term_slot(const TermPack& p, int term) {
+  return (int)(((term & 16) ? p.hi : p.lo) >> (4 * (term & 15))) & 15;
+}
 
 // Workgroup = BLOCK threads = BLOCK/G queries x G lanes for the search, then (32 record terms) x (BLOCK/32 query slices) for the
 // accumulation: one f64 accumulator per thread instead of 30, so the kernel stays small in registers and the chip can
@@ -667,6 +690,10 @@ __device__ __forceinline__ double to_sgpr(double v) {
 // special case), so M = Ct + R Cs R^T = 2I - k (a a^T + b b^T).  With A = [-[p]x | I] and W = M^-1/2 the three residual rows
 // W d and Jacobian rows W A contribute  J^T J = A^T M^-1 A  and  J^T r = A^T M^-1 d : only M^-1 is needed (3x3 cofactors).
 // Writes the 21 + 6 + 3 record values of ONE correspondence.
+// (gicp_record and write_record are compiled WITHOUT fused multiply-add contraction: a record is written from two places -- the
+// verified match and the searched one -- and both must round alike for the pass to be bit-identical whichever served a query; it is
+// also how the reference's own build rounds, -O3 without -march)
+#pragma clang fp contract(off)
 __device__ __forceinline__ void gicp_record(double px, double py, double pz, double dx, double dy, double dz, const double a[3],
                                             const double b[3], double k, double* rec) {
   const double m00 = 2.0 - k * (a[0] * a[0] + b[0] * b[0]), m01 = -k * (a[0] * a[1] + b[0] * b[1]), m02 = -k * (a[0] * a[2] + b[0] * b[2]);
@@ -705,6 +732,7 @@ __device__ __forceinline__ void gicp_record(double px, double py, double pz, dou
   rec[30] = 0.0;
   rec[31] = 0.0;
 }
+#pragma clang fp contract(fast)
 
 // Which query slot ql of batch b serves.  Passes that have a cached match per query take CONSECUTIVE queries (neighbours on a
 // scan ring share cells and cache lines).  Pass 0 of a registration has no bound, so queries whose neighbour is far are
@@ -800,6 +828,7 @@ struct SetMargin {
 };
 
 // The record of ONE correspondence (query at p, matched target point q with normal nq) into its 10 (or, generalized ICP, 32) LDS slots.
+#pragma clang fp contract(off)
 template <typename P4, bool kGicp>
 __device__ __forceinline__ void write_record(const IcpPassArgs& a, double* rec, bool p2p, double px, double py, double pz, const P4& q,
                                              const P4& nq, size_t i, double t00, double t01, double t02, double t10, double t11,
@@ -841,8 +870,13 @@ __device__ __forceinline__ void write_record(const IcpPassArgs& a, double* rec, 
     rec[9] = 0.0;
   }
 }
+#pragma clang fp contract(fast)
 
-template <typename P4, bool kCrop, int kPassBlock, int kGroup, bool kGicp, bool kKeys = false /* the keys_mode code (classic kernel only) */>
+template <typename P4, bool kCrop, int kPassBlock, int kGroup, bool kGicp, bool kKeys = false /* the keys_mode code (classic kernel only) */,
+          bool kCollect = false /* the searches of this pass list candidate sets (see Collect) */,
+          bool kSingle = false /* ONE batch per workgroup (wg < number of batches): without the batch loop the compiler neither hoists a
+                                  dozen per-lane constants out of it nor keeps the first batch's prefetch alive through it -- 112
+                                  registers instead of 128 + spills */>
 __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const double* Tm, int wg, int nwg, double* s_rec_flat,
                                                 double (*s_red)[kRec], int2* s_seg /* [kPassBlock / kGroup][kSegMax] */,
                                                 bool use_cache, const QueryPrefetch<P4>& first_batch,
@@ -862,12 +896,14 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
   const int term = threadIdx.x & 31, qs = threadIdx.x >> 5;
   const bool inf = a.method == kMethodInformation;
   const bool p2p = a.method == O3DS_ICP_POINT_TO_POINT || inf;  // uniform: records built from the points themselves, no normals
-  const int ta = inf ? kTermA_inf[term] : (p2p ? kTermA_p2p[term] : kTermA[term]);
-  const int tb = inf ? kTermB_inf[term] : (p2p ? kTermB_p2p[term] : kTermB[term]);
+  // which two slots a record term multiplies: from the tables above, packed four bits per term into literals (a table in memory would
+  // be a load whose latency the verified-match path has nothing to hide behind)
+  const int ta = term_slot(inf ? kPackA_inf : (p2p ? kPackA_p2p : kPackA), term);
+  const int tb = term_slot(inf ? kPackB_inf : (p2p ? kPackB_p2p : kPackB), term);
   // candidate sets: read (verified matches) whenever the previous pass left them, written whenever this pass has a margin
   const bool sets = !kKeys && a.set_pos != nullptr && s_set != nullptr;
   const bool sets_in = sets && use_cache;
-  const bool sets_out = sets && sm.w >= 0.0f;
+  const bool sets_out = kCollect && sets;
   const R rmax = (R)sqrt(a.r2max);
   int* my_set = sets ? s_set + ql * (1 + kSetCap) : nullptr;
   double acc = 0.0;
@@ -877,7 +913,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
   int* s_far = (int*)&s_red[0][0];  // [0] count, [1] next, [2..] query slots; s_red itself is only used after the loop
   if (threadIdx.x == 0) s_far[0] = s_far[1] = 0;
   __syncthreads();
-  for (size_t b = (size_t)wg; b < n_batches; b += (size_t)nwg) {
+  for (size_t b = (size_t)wg; b < n_batches; b += kSingle ? n_batches : (size_t)nwg) {
     const size_t i = query_index<kQPB, 64 / kGroup>(a.count, b, ql, !use_cache);
     double px = 0, py = 0, pz = 0;
     NNBest<P4> nn;
@@ -888,7 +924,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
     bool verified = false;   // the match was proven inside the prefetched candidate set: the winner's lane holds point and normal
     int kdone = 0;           // block radius (cells) the search of this query covered; 0 = no search ran
     R m = (R)0;  // candidate-set margin of this query's search (0: the search leaves no set)
-    const QueryPrefetch<P4> qp = b == (size_t)wg ? first_batch : prefetch_query<P4, kPassBlock, kGroup>(a, b, use_cache);
+    const QueryPrefetch<P4> qp = (kSingle || b == (size_t)wg) ? first_batch : prefetch_query<P4, kPassBlock, kGroup>(a, b, use_cache);
     if (sets && gl == 0) my_set[0] = 0;  // (same wavefront as its readers and writers below; the far stage is behind a barrier)
     if (i < a.count) {  // uniform across the lanes of a group
       const P4 s = qp.s;
@@ -956,7 +992,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
           // (the lane's row offsets are recomputed per batch: hoisted out of the batch loop they cost a dozen registers, i.e. spills)
           int gl_b = gl;
           asm volatile("" : "+v"(gl_b));
-          nn = nn_search_group<P4, kCrop, kGroup>(a.grid, tp, qx, qy, qz, a.kmax, a.crop, gl_b, s_seg + ql * kSegMax, best, m, col, &resolved, &kdone);
+          nn = nn_search_group<P4, kCrop, kGroup, kCollect>(a.grid, tp, qx, qy, qz, a.kmax, a.crop, gl_b, s_seg + ql * kSegMax, best, m, col, &resolved, &kdone);
           if (!resolved && gl == 0) {  // park the query for stage 3 (its record slot is still unused)
             FarItem<P4>* mine_item = (FarItem<P4>*)(s_rec_flat + ql * kStride);
             mine_item->x = qx;
@@ -1000,7 +1036,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
           col.tau2 = it->tau2;
           col.cnt = sets ? s_set + slot * (1 + kSetCap) : nullptr;
           col.list = col.cnt + 1;
-          if (a.debug != 32) nn_search_wave_far<P4, kCrop>(a.grid, tp, it->x, it->y, it->z, a.kmax, a.crop, bq, lane, list, it->m, col);
+          if (a.debug != 32) nn_search_wave_far<P4, kCrop, kCollect>(a.grid, tp, it->x, it->y, it->z, a.kmax, a.crop, bq, lane, list, it->m, col);
           // every lane holds the same winner and stores it (same address, same value): no lane-0 branch inside this loop --
           // with one, the structurised code re-ran the body for the other lanes forever (seen on ROCm 7.2)
           it->d2 = bq.d2;
@@ -1733,6 +1769,7 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
 #pragma unroll
     for (int k = 0; k < kFusedSlots; ++k) sv[k] = fa.slots_in[k * kSlotDoubles + threadIdx.x];
   }
+  const double q_hi_mine = threadIdx.x < kRec ? fa.pass.q_hi[threadIdx.x] : 0.0;  // (a per-lane load of a kernel argument: not at the very end)
   __builtin_amdgcn_sched_barrier(0);
   // pose-independent loads of this workgroup's queries: source point, cached match or candidate set (points AND normals); they land
   // while the tail of the previous pass is computed
@@ -1778,13 +1815,19 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   SetMargin sm;
   sm.w = s_margin[0];
   sm.t = s_margin[1];
-  const double v = icp_pass_body<P4, kCrop, kPassBlock, kGroup, kGicp>(fa.pass, s_st.T, blockIdx.x, gridDim.x, s_rec, s_red, s_seg, use_cache, qp,
-                                                                       fa.trace ? fa.trace + (size_t)blockIdx.x * 16 + 13 : nullptr, sm, s_set);
+  // a launch whose update was too large for any query to get a margin under the cap runs the pass without the list code (a second copy
+  // of the pass body: one test per four candidates is a quarter of the search's instructions)
+  const bool collect = fa.pass.set_pos != nullptr && sm.w >= 0.0f && fa.pass.set_gain * sm.t <= fa.pass.set_cap;
+  unsigned long long* const trb = fa.trace ? fa.trace + (size_t)blockIdx.x * 16 + 13 : nullptr;
+  const double v = collect ? icp_pass_body<P4, kCrop, kPassBlock, kGroup, kGicp, false, true, true>(fa.pass, s_st.T, blockIdx.x, gridDim.x, s_rec, s_red, s_seg,
+                                                                                              use_cache, qp, trb, sm, s_set)
+                           : icp_pass_body<P4, kCrop, kPassBlock, kGroup, kGicp, false, false, true>(fa.pass, s_st.T, blockIdx.x, gridDim.x, s_rec, s_red, s_seg,
+                                                                                               use_cache, qp, trb, sm, s_set);
   O3DS_STAMP(3);
   // ---------------- epilogue: add the record to this workgroup's slot, exactly ----------------
   if (threadIdx.x < kRec) {
     double hi, lo;
-    split_exact(v, fa.pass.q_hi[threadIdx.x], &hi, &lo);
+    split_exact(v, q_hi_mine, &hi, &lo);
     double* slot = fa.slots_out + (size_t)(blockIdx.x % kFusedSlots) * kSlotDoubles;
     if (hi != 0.0) (void)__hip_atomic_fetch_add(slot + threadIdx.x, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (lo != 0.0) (void)__hip_atomic_fetch_add(slot + kRec + threadIdx.x, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
