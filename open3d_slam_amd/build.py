@@ -32,12 +32,53 @@ def build_backend(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB,
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Rpass-analysis=kernel-resource-usage", "-o", LIB,
            os.path.join(CSRC, "backend.hip")]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    if p.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + p.stderr[-4000:])
+    _write_resources(p.stderr)
     return LIB
+
+
+RESOURCES = os.path.join(LIB_DIR, "kernel_resources.txt")  # one line per kernel: name vgpr sgpr scratch_bytes lds_bytes occupancy
+
+
+def _write_resources(remarks: str) -> None:
+    """The compiler's per-kernel resource remarks, condensed.  tests/test_abi.py holds the registration kernels to ZERO scratch: the
+    compiler places VGPR spills inside divergent regions (store under a narrow EXEC mask, reload under a wider one), which once fed a
+    garbage quantum to the exact record sums of the f64-storage kernel (round 4)."""
+    import re
+
+    rows, cur = [], None
+    for line in remarks.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = {"name": m.group(1)}
+            rows.append(cur)
+            continue
+        if cur is None:
+            continue
+        for key, pat in (("sgpr", r"TotalSGPRs: (\d+)"), ("vgpr", r" VGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"),
+                         ("occ", r"Occupancy \[waves/SIMD\]: (\d+)"), ("lds", r"LDS Size \[bytes/block\]: (\d+)")):
+            m = re.search(pat, line)
+            if m:
+                cur[key] = int(m.group(1))
+    with open(RESOURCES, "w") as f:
+        for r in rows:
+            f.write("%s vgpr %d sgpr %d scratch %d lds %d occupancy %d\n" % (r["name"], r.get("vgpr", -1), r.get("sgpr", -1), r.get("scratch", -1),
+                                                                          r.get("lds", -1), r.get("occ", -1)))
+
+
+def kernel_resources() -> dict:
+    out = {}
+    if os.path.exists(RESOURCES):
+        for line in open(RESOURCES):
+            t = line.split()
+            out[t[0]] = {t[k]: int(t[k + 1]) for k in range(1, len(t) - 1, 2)}
+    return out
 
 
 if __name__ == "__main__":

@@ -265,31 +265,38 @@ __device__ __forceinline__ void collect_push(const Collect<R>& c, int p) {
   if (k < kSetCap) c.list[k] = p;
 }
 
-// candidates s+lane, s+lane+stride, ... of [s,e): four loads issued before the first is consumed
+// candidates s+lane, s+lane+stride, ... of [s,e): four loads issued before the first is consumed (two with f64 storage: a
+// candidate is eight registers there, and four in flight pushed the kernel over its register budget -- spills that the compiler
+// places inside divergent regions, which is not safe: a value stored under a narrow EXEC mask and reloaded under a wider one)
 template <typename P4, bool kCrop, bool kCollect>
 __device__ __forceinline__ void scan_strided(const P4* __restrict__ tp, int s, int e, int lane, int stride, typename Scalar<P4>::type qx,
                                              typename Scalar<P4>::type qy, typename Scalar<P4>::type qz, const CropDev& crop,
                                              NNBest<P4>& best, const Collect<typename Scalar<P4>::type>& col) {
   using R = typename Scalar<P4>::type;
-  for (int p = s + lane; p < e; p += 4 * stride) {
-    const int p1 = p + stride, p2 = p + 2 * stride, p3 = p + 3 * stride;
-    const bool v1 = p1 < e, v2 = p2 < e, v3 = p3 < e;
-    const P4 t0 = tp[p];
-    const P4 t1 = tp[v1 ? p1 : p];  // clamped, not predicated: branches around the loads measured slower
-    const P4 t2 = tp[v2 ? p2 : p];
-    const P4 t3 = tp[v3 ? p3 : p];
-    const R d0 = consider<P4, kCrop>(t0, p, true, qx, qy, qz, crop, best);
-    const R d1 = consider<P4, kCrop>(t1, p1, v1, qx, qy, qz, crop, best);
-    const R d2 = consider<P4, kCrop>(t2, p2, v2, qx, qy, qz, crop, best);
-    const R d3 = consider<P4, kCrop>(t3, p3, v3, qx, qy, qz, crop, best);
+  constexpr int kInFlight = sizeof(R) == 8 ? (kCrop ? 1 : 2) : 4;
+  for (int p = s + lane; p < e; p += kInFlight * stride) {
+    int pk[kInFlight];
+    bool vk[kInFlight];
+    P4 tk[kInFlight];
+    R dk[kInFlight];
+#pragma unroll
+    for (int k = 0; k < kInFlight; ++k) {
+      pk[k] = p + k * stride;
+      vk[k] = pk[k] < e;
+      tk[k] = tp[vk[k] ? pk[k] : p];  // clamped, not predicated: branches around the loads measured slower
+    }
+#pragma unroll
+    for (int k = 0; k < kInFlight; ++k) dk[k] = consider<P4, kCrop>(tk[k], pk[k], vk[k], qx, qy, qz, crop, best);
     if (kCollect) {
-      // the candidate-set list: a handful of points per query lie inside tau, so ONE test per four candidates (a clamped load
+      // the candidate-set list: a handful of points per query lie inside tau, so ONE test per batch of candidates (a clamped load
       // repeats candidate p, so the minimum needs no masks; the flags sort it out inside)
-      if (min(min(d0, d1), min(d2, d3)) < col.tau2) {
-        if (d0 < col.tau2) collect_push(col, p);
-        if (v1 & (d1 < col.tau2)) collect_push(col, p1);
-        if (v2 & (d2 < col.tau2)) collect_push(col, p2);
-        if (v3 & (d3 < col.tau2)) collect_push(col, p3);
+      R dmin = dk[0];
+#pragma unroll
+      for (int k = 1; k < kInFlight; ++k) dmin = min(dmin, dk[k]);
+      if (dmin < col.tau2) {
+#pragma unroll
+        for (int k = 0; k < kInFlight; ++k)
+          if (vk[k] & (dk[k] < col.tau2)) collect_push(col, pk[k]);
       }
     }
   }
@@ -777,7 +784,7 @@ struct alignas(4 * sizeof(typename Scalar<P4>::type)) SetRef {
 };
 
 template <typename P4, int kPassBlock, int kGroup>
-__device__ __forceinline__ QueryPrefetch<P4> prefetch_query(const IcpPassArgs& a, size_t batch, bool use_cache) {
+__device__ __forceinline__ QueryPrefetch<P4> prefetch_query(const IcpPassArgs& a, size_t batch, bool use_cache, bool use_sets = false) {
   constexpr int kQPB = kPassBlock / kGroup;
   using R = typename Scalar<P4>::type;
   QueryPrefetch<P4> q;
@@ -785,7 +792,7 @@ __device__ __forceinline__ QueryPrefetch<P4> prefetch_query(const IcpPassArgs& a
   q.s = P4{};
   q.nprev = P4{};
   q.rx = q.ry = q.rz = q.rL = (R)0;
-  const bool sets = use_cache && a.set_pos != nullptr;
+  const bool sets = use_cache && use_sets && a.set_pos != nullptr;  // (use_sets: the fused kernel only, see icp_pass_body)
   const size_t i = query_index<kQPB, 64 / kGroup>(a.count, batch, threadIdx.x / kGroup, !use_cache);
   if (i < a.count) {
     q.s = ((const P4*)a.src)[a.first + i];
@@ -898,8 +905,14 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
   const bool p2p = a.method == O3DS_ICP_POINT_TO_POINT || inf;  // uniform: records built from the points themselves, no normals
   // which two slots a record term multiplies: from the tables above, packed four bits per term into literals (a table in memory would
   // be a load whose latency the verified-match path has nothing to hide behind)
+#ifdef O3DS_DBG_OLD_TABLES
+  static __device__ const unsigned char dA[kRec] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9};
+  static __device__ const unsigned char dB[kRec] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5, 6, 6, 6, 6, 6, 6, 6, 7, 7, 9, 9};
+  const int ta = dA[term], tb = dB[term];
+#else
   const int ta = term_slot(inf ? kPackA_inf : (p2p ? kPackA_p2p : kPackA), term);
   const int tb = term_slot(inf ? kPackB_inf : (p2p ? kPackB_p2p : kPackB), term);
+#endif
   // candidate sets: read (verified matches) whenever the previous pass left them, written whenever this pass has a margin
   const bool sets = !kKeys && a.set_pos != nullptr && s_set != nullptr;
   const bool sets_in = sets && use_cache;
@@ -924,7 +937,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
     bool verified = false;   // the match was proven inside the prefetched candidate set: the winner's lane holds point and normal
     int kdone = 0;           // block radius (cells) the search of this query covered; 0 = no search ran
     R m = (R)0;  // candidate-set margin of this query's search (0: the search leaves no set)
-    const QueryPrefetch<P4> qp = (kSingle || b == (size_t)wg) ? first_batch : prefetch_query<P4, kPassBlock, kGroup>(a, b, use_cache);
+    const QueryPrefetch<P4> qp = (kSingle || b == (size_t)wg) ? first_batch : prefetch_query<P4, kPassBlock, kGroup>(a, b, use_cache, sets);
     if (sets && gl == 0) my_set[0] = 0;  // (same wavefront as its readers and writers below; the far stage is behind a barrier)
     if (i < a.count) {  // uniform across the lanes of a group
       const P4 s = qp.s;
@@ -1748,7 +1761,9 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   __shared__ int s_set[kQPB * (1 + kSetCap)];
   __shared__ float s_margin[2];
   __shared__ int s_go;
+#ifndef O3DS_DBG_NO_WARM
   kernarg_warm<(int)sizeof(IcpFusedArgs)>();
+#endif
 #define O3DS_STAMP(k)                                                                                  \
   do {                                                                                                 \
     if (fa.trace && threadIdx.x == 0) fa.trace[(size_t)blockIdx.x * 16 + (k)] = wall_clock64();         \
@@ -1762,10 +1777,11 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   // term l - 32, of the eight slots)
   constexpr int kStateWords = (int)(sizeof(IcpStateDev) / sizeof(unsigned));
   static_assert(sizeof(IcpStateDev) % sizeof(unsigned) == 0 && kStateWords <= 64, "one dword of the state per lane");
+  typedef unsigned __attribute__((may_alias)) word_alias;  // the state's doubles and ints travel as dwords: tell the compiler these accesses alias them
   unsigned st_word = 0u;
   double sv[kFusedSlots];
   if (!fa.first && threadIdx.x < 64) {
-    if (threadIdx.x < kStateWords) st_word = ((const unsigned*)fa.state_in)[threadIdx.x];
+    if (threadIdx.x < kStateWords) st_word = ((const word_alias*)fa.state_in)[threadIdx.x];
 #pragma unroll
     for (int k = 0; k < kFusedSlots; ++k) sv[k] = fa.slots_in[k * kSlotDoubles + threadIdx.x];
   }
@@ -1773,7 +1789,7 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   __builtin_amdgcn_sched_barrier(0);
   // pose-independent loads of this workgroup's queries: source point, cached match or candidate set (points AND normals); they land
   // while the tail of the previous pass is computed
-  const QueryPrefetch<P4> qp = prefetch_query<P4, kPassBlock, kGroup>(fa.pass, blockIdx.x, use_cache);
+  const QueryPrefetch<P4> qp = prefetch_query<P4, kPassBlock, kGroup>(fa.pass, blockIdx.x, use_cache, true);
   if (blockIdx.x == 0) {  // the buffer of the NEXT pass was last read two launches ago
     static_assert(kFusedSlots * kSlotDoubles == 2 * kPassBlock, "two slot values per thread");
     fa.slots_clear[threadIdx.x] = 0.0;
@@ -1782,7 +1798,7 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   if (fa.first) {
     if (threadIdx.x == 0) s_st = fa.init;
   } else if (threadIdx.x < 64) {
-    if (threadIdx.x < kStateWords) ((unsigned*)&s_st)[threadIdx.x] = st_word;
+    if (threadIdx.x < kStateWords) ((word_alias*)&s_st)[threadIdx.x] = st_word;
     // sums of hi (resp. lo) values are exact, so any order will do
     double t = 0.0;
 #pragma unroll
@@ -1827,7 +1843,11 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   // ---------------- epilogue: add the record to this workgroup's slot, exactly ----------------
   if (threadIdx.x < kRec) {
     double hi, lo;
+#ifdef O3DS_DBG_QHI_LATE
+    split_exact(v, fa.pass.q_hi[threadIdx.x], &hi, &lo);
+#else
     split_exact(v, q_hi_mine, &hi, &lo);
+#endif
     double* slot = fa.slots_out + (size_t)(blockIdx.x % kFusedSlots) * kSlotDoubles;
     if (hi != 0.0) (void)__hip_atomic_fetch_add(slot + threadIdx.x, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (lo != 0.0) (void)__hip_atomic_fetch_add(slot + kRec + threadIdx.x, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -72,3 +72,21 @@ def test_no_product_import_of_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "pyoracle" not in txt and "np_oracle" not in txt and "o3d_oracle" not in txt, os.path.join(dp, f)
+
+
+def test_no_hand_written_kernel_spills_registers():
+    """Every kernel of this backend keeps its working set in registers (scratch 0).  Not a performance nicety: the compiler places VGPR
+    spill stores inside divergent regions and reloads them under a wider EXEC mask, which in round 4 handed lanes a garbage quantum for
+    the exact record sums (f64-storage fused kernel, 32 bytes of scratch) -- wrong poses, not slow ones.  The build records the
+    compiler's own resource remarks; rocPRIM's library kernels are not ours to hold to this."""
+    from open3d_slam_amd import build
+
+    if not os.path.exists(build.RESOURCES):
+        build.build_backend(force=True)
+    res = build.kernel_resources()
+    ours = {k: v for k, v in res.items() if "4o3ds" in k and "rocprim" not in k}
+    assert len(ours) > 100, len(ours)
+    spilling = {k: v["scratch"] for k, v in ours.items() if v["scratch"] != 0}
+    assert not spilling, spilling
+    fused = [v for k, v in ours.items() if "icp_fused_kernel" in k]
+    assert len(fused) == 8 and all(v["vgpr"] <= 128 and v["occupancy"] >= 4 for v in fused), fused
