@@ -13,6 +13,14 @@
 #pragma once
 #include "common.hpp"
 
+// NO implicit fused multiply-add contraction in this file: whether a*b+c becomes one rounding or two is otherwise the compiler's choice
+// per inlined copy, and the same source runs in several kernels (fused / two-launch / step-wise) and, inside one kernel, in several
+// copies (a correspondence is served by the search or by its verified candidate set) that must agree bit for bit.  Unfused is also how
+// the reference rounds (-O3 without -march: DESIGN.md section 2), so the transform, the residuals and the Jacobian rows are the
+// reference's arithmetic; the spots where a fused operation is wanted (the f32 candidate distance, the per-workgroup accumulation, the
+// 6x6 solve) say fma() explicitly.
+#pragma clang fp contract(off)
+
 namespace o3ds {
 
 constexpr int kBlock = 256;  // 4 wavefronts of 64
@@ -221,6 +229,11 @@ struct NNBest {
   typename Scalar<P4>::index idx;
 };
 
+// squared candidate distance: with f32 storage two fused steps (this is the innermost loop of the search); with f64 storage the three
+// products and two sums the reference's k-d tree forms (nanoflann's L2 adaptor, built without FMA)
+__device__ __forceinline__ float dist2(float dx, float dy, float dz) { return fmaf(dz, dz, fmaf(dy, dy, dx * dx)); }
+__device__ __forceinline__ double dist2(double dx, double dy, double dz) { return dx * dx + dy * dy + dz * dz; }
+
 // branch-free candidate test (the crop predicate, when compiled in, is only evaluated for would-be winners)
 template <typename P4, bool kCrop>
 __device__ __forceinline__ typename Scalar<P4>::type consider(const P4& t, int p, bool valid, typename Scalar<P4>::type qx,
@@ -228,7 +241,7 @@ __device__ __forceinline__ typename Scalar<P4>::type consider(const P4& t, int p
                                                               const CropDev& crop, NNBest<P4>& best) {
   using R = typename Scalar<P4>::type;
   const R dx = t.x - qx, dy = t.y - qy, dz = t.z - qz;
-  const R d2 = dx * dx + dy * dy + dz * dz;
+  const R d2 = dist2(dx, dy, dz);
   // strict d2 < best (initially r^2); ties broken towards the smaller original index
   bool better = valid & ((d2 < best.d2) | ((d2 == best.d2) & (t.i < best.idx)));
   if (kCrop) {
@@ -273,7 +286,7 @@ __device__ __forceinline__ void scan_strided(const P4* __restrict__ tp, int s, i
                                              typename Scalar<P4>::type qy, typename Scalar<P4>::type qz, const CropDev& crop,
                                              NNBest<P4>& best, const Collect<typename Scalar<P4>::type>& col) {
   using R = typename Scalar<P4>::type;
-  constexpr int kInFlight = sizeof(R) == 8 ? (kCrop ? 1 : 2) : 4;
+  constexpr int kInFlight = sizeof(R) == 8 ? (kCrop ? 1 : 2) : (kCrop ? 2 : 4);  // (the crop predicate is f64 with a square root: its registers)
   for (int p = s + lane; p < e; p += kInFlight * stride) {
     int pk[kInFlight];
     bool vk[kInFlight];
@@ -697,10 +710,6 @@ __device__ __forceinline__ double to_sgpr(double v) {
 // special case), so M = Ct + R Cs R^T = 2I - k (a a^T + b b^T).  With A = [-[p]x | I] and W = M^-1/2 the three residual rows
 // W d and Jacobian rows W A contribute  J^T J = A^T M^-1 A  and  J^T r = A^T M^-1 d : only M^-1 is needed (3x3 cofactors).
 // Writes the 21 + 6 + 3 record values of ONE correspondence.
-// (gicp_record and write_record are compiled WITHOUT fused multiply-add contraction: a record is written from two places -- the
-// verified match and the searched one -- and both must round alike for the pass to be bit-identical whichever served a query; it is
-// also how the reference's own build rounds, -O3 without -march)
-#pragma clang fp contract(off)
 __device__ __forceinline__ void gicp_record(double px, double py, double pz, double dx, double dy, double dz, const double a[3],
                                             const double b[3], double k, double* rec) {
   const double m00 = 2.0 - k * (a[0] * a[0] + b[0] * b[0]), m01 = -k * (a[0] * a[1] + b[0] * b[1]), m02 = -k * (a[0] * a[2] + b[0] * b[2]);
@@ -739,7 +748,6 @@ __device__ __forceinline__ void gicp_record(double px, double py, double pz, dou
   rec[30] = 0.0;
   rec[31] = 0.0;
 }
-#pragma clang fp contract(fast)
 
 // Which query slot ql of batch b serves.  Passes that have a cached match per query take CONSECUTIVE queries (neighbours on a
 // scan ring share cells and cache lines).  Pass 0 of a registration has no bound, so queries whose neighbour is far are
@@ -835,7 +843,6 @@ struct SetMargin {
 };
 
 // The record of ONE correspondence (query at p, matched target point q with normal nq) into its 10 (or, generalized ICP, 32) LDS slots.
-#pragma clang fp contract(off)
 template <typename P4, bool kGicp>
 __device__ __forceinline__ void write_record(const IcpPassArgs& a, double* rec, bool p2p, double px, double py, double pz, const P4& q,
                                              const P4& nq, size_t i, double t00, double t01, double t02, double t10, double t11,
@@ -877,7 +884,6 @@ __device__ __forceinline__ void write_record(const IcpPassArgs& a, double* rec, 
     rec[9] = 0.0;
   }
 }
-#pragma clang fp contract(fast)
 
 template <typename P4, bool kCrop, int kPassBlock, int kGroup, bool kGicp, bool kKeys = false /* the keys_mode code (classic kernel only) */,
           bool kCollect = false /* the searches of this pass list candidate sets (see Collect) */,
@@ -1129,7 +1135,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
       if (kGicp)
         acc += rec[term];  // the record already holds the 32 terms of this correspondence
       else
-        acc += rec[ta] * rec[tb];
+        acc = fma(rec[ta], rec[tb], acc);
     }
     __syncthreads();  // s_rec is rewritten by the next batch
   }
@@ -1413,9 +1419,9 @@ __device__ __forceinline__ void solve6_wave(const double* rec, double* x_out, in
 #pragma unroll
     for (int j = s + 1; j < 6; ++j) {
       const double rs = O3DS_BCAST(a[j], s);
-      if (below) a[j] -= l * rs;
+      if (below) a[j] = fma(-l, rs, a[j]);
     }
-    if (below) b -= l * bs;
+    if (below) b = fma(-l, bs, b);
   }
   double xs[6];
   double mine = 0.0;
@@ -1423,7 +1429,7 @@ __device__ __forceinline__ void solve6_wave(const double* rec, double* x_out, in
   for (int i = 5; i >= 0; --i) {
     double num = b;
 #pragma unroll
-    for (int j = i + 1; j < 6; ++j) num -= a[j] * xs[j];
+    for (int j = i + 1; j < 6; ++j) num = fma(-a[j], xs[j], num);
     // a[i] of lane i is pivot i; after the elimination a[j] (j > i) of lane i is D_i L_ji (L_ji itself under an invalid pivot), so
     // with z_i = y_i / D_i (0 under an invalid pivot): w_i = z_i - sum_j L_ji w_j
     const double xi = rd[i] != 0.0 ? num * rd[i] : num - b;
@@ -1614,7 +1620,7 @@ __device__ __forceinline__ void icp_step_block(const double* s_rec, IcpStateDev*
     if (lane < 16) {  // U * T
       const int c = lane >> 2, r = lane & 3;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) tnew += s_U[k * 4 + r] * s_T[c * 4 + k];
+      for (int k = 0; k < 4; ++k) tnew = fma(s_U[k * 4 + r], s_T[c * 4 + k], tnew);
     }
   } else if (wv == 1) {
     const double fitness = count > 0.0 ? count / (double)n_src_total : 0.0;
@@ -1860,3 +1866,4 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
 }
 
 }  // namespace o3ds
+#pragma clang fp contract(fast)
