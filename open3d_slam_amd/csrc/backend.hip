@@ -161,7 +161,7 @@ struct o3ds_context {
   // candidate sets of the fused loop (icp_kernels.hpp, Collect): one allocation of nn_cache_cap x (kSetCap ints + {p_ref, L} at f64 width)
   int* d_set_pos = nullptr;
   void* d_set_ref = nullptr;
-  int seed_stride = 16;                                  // O3DS_ICP_SEED_STRIDE (0: pass 0 starts every query from the radius): icp_seed_kernel
+  int seed_stride = 0;                                   // O3DS_ICP_SEED_STRIDE (0: pass 0 starts every query from the radius): icp_seed_kernel
   bool sets = true;                                      // O3DS_ICP_SETS=0: every pass searches (same results bit for bit)
   float set_gain = 2.0f, set_min = 1e-3f, set_cap = 0.04f;  // O3DS_SET_GAIN / _MIN / _CAP (metres)
   char* d_fused = nullptr;  // [2 states | 3 x kFusedSlots slot records (hi and lo sums)]
@@ -1124,6 +1124,7 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
   }
   a.kmax = std::max(1, (int)std::ceil(r / tgt->grid.cell));  // a neighbour within r is at most this many cells away
   a.nn_cache = h->d_nn_cache;
+  a.p0_skip2 = getenv("O3DS_P0_SKIP2") ? atoi(getenv("O3DS_P0_SKIP2")) : 0;
   a.set_pos = h->fused && h->sets ? h->d_set_pos : nullptr;
   a.set_ref = h->d_set_ref;
   a.set_gain = h->set_gain;

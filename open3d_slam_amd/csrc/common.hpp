@@ -110,7 +110,7 @@ struct IcpStateDev {
   int done;
   int converged;
   int error;  // 1: a workgroup of the persistent loop kernel timed out at the grid rendezvous (never expected)
-  int pad;
+  int pad;  // the pivot order of the last 6x6 solve (icp_kernels.hpp solve6_wave_ordered): bit 31 valid, 3 bits per position
 };
 
 }  // namespace o3ds

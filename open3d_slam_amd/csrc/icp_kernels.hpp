@@ -431,7 +431,8 @@ __device__ __forceinline__ NNBest<P4> nn_search_group(const GridDev& g, const P4
                                                       typename Scalar<P4>::type qy, typename Scalar<P4>::type qz, int kmax,
                                                       const CropDev& crop, int gl, int2* seg /* this group's kSegMax entries */,
                                                       NNBest<P4> best, typename Scalar<P4>::type m,
-                                                      const Collect<typename Scalar<P4>::type>& col, bool* resolved, int* kdone) {
+                                                      const Collect<typename Scalar<P4>::type>& col, bool* resolved, int* kdone,
+                                                      bool skip2 = false /* leave the 5x5x5 shell to stage 3 as well */) {
   const QueryCell c = locate(g, (double)qx, (double)qy, (double)qz);
   const int* __restrict__ cs = g.cell_start;
   // ---- one batch, issued before the bound is even computed: the 4 cell_start values of each of this lane's rows of the 3x3
@@ -490,7 +491,7 @@ __device__ __forceinline__ NNBest<P4> nn_search_group(const GridDev& g, const P4
   bool proven = kmax <= 1 || widen2(best.d2, m) * ic2 <= (1.0f + c.mf) * (1.0f + c.mf);
   *kdone = 1;
   // ---- stage 2: the 5x5x5 shell, trimmed by the bound (group-uniform branch), rows in two batches
-  if (!proven) {
+  if (!proven && !skip2) {
     constexpr int kHalf = 13, kOwn2 = (kHalf + G - 1) / G;
 #pragma unroll 1
     for (int r0 = 0; r0 < 25; r0 += kHalf) {
@@ -555,8 +556,9 @@ template <typename P4, bool kCrop, bool kCollect, int kDone = 2 /* cells within 
 __device__ __forceinline__ void nn_search_wave_far(const GridDev& g, const P4* __restrict__ tp, typename Scalar<P4>::type qx,
                                                    typename Scalar<P4>::type qy, typename Scalar<P4>::type qz, int K,
                                                    const CropDev& crop, NNBest<P4>& best, int lane, int2* s_list /* kFarList entries */,
-                                                   typename Scalar<P4>::type m, const Collect<typename Scalar<P4>::type>& col) {
-  constexpr int kdone = kDone;
+                                                   typename Scalar<P4>::type m, const Collect<typename Scalar<P4>::type>& col,
+                                                   int kdone_rt = kDone /* run-time form of kDone (pass 0 may skip the group stage 2) */) {
+  const int kdone = kdone_rt;
   constexpr int kPer = 4;   // half-rows per lane and round: all their bounds are fetched in one batch
   const QueryCell c = locate(g, (double)qx, (double)qy, (double)qz);
   const float b2 = bound_cells2(best.d2, m, g);
@@ -659,6 +661,7 @@ struct IcpPassArgs {
   int* set_pos;
   void* set_ref;
   float set_gain, set_min, set_cap;  // margin m = gain * (|R - I|_F |p| + |t|) of the last update, at least set_min; above set_cap: no set
+  int p0_skip2;               // pass 0 without the group stage 2 (experiment)
   int seed_stride;            // > 0: pass 0 starts every query from the match of query (i / seed_stride) * seed_stride (icp_seed_kernel)
   unsigned long long* stats;  // null, or per-launch counters [launch][4]: verified matches, searches, sets left behind, stage-3 queries (O3DS_ICP_STATS)
 };
@@ -924,6 +927,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
 #endif
   // candidate sets: read (verified matches) whenever the previous pass left them, written whenever this pass has a margin
   const bool sets = !kKeys && a.set_pos != nullptr && s_set != nullptr;
+  const bool skip2 = !use_cache && a.p0_skip2;  // pass 0: whatever the 3x3x3 block does not settle goes to a whole wavefront (stage 3)
   const bool sets_in = sets && use_cache;
   const bool sets_out = kCollect && sets;
   const R rmax = (R)sqrt(a.r2max);
@@ -1014,7 +1018,8 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
           // (the lane's row offsets are recomputed per batch: hoisted out of the batch loop they cost a dozen registers, i.e. spills)
           int gl_b = gl;
           asm volatile("" : "+v"(gl_b));
-          nn = nn_search_group<P4, kCrop, kGroup, kCollect>(a.grid, tp, qx, qy, qz, a.kmax, a.crop, gl_b, s_seg + ql * kSegMax, best, m, col, &resolved, &kdone);
+          nn = nn_search_group<P4, kCrop, kGroup, kCollect>(a.grid, tp, qx, qy, qz, a.kmax, a.crop, gl_b, s_seg + ql * kSegMax, best, m, col, &resolved, &kdone,
+                                                            skip2);
           if (!resolved && gl == 0) {  // park the query for stage 3 (its record slot is still unused)
             FarItem<P4>* mine_item = (FarItem<P4>*)(s_rec_flat + ql * kStride);
             mine_item->x = qx;
@@ -1058,7 +1063,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
           col.tau2 = it->tau2;
           col.cnt = sets ? s_set + slot * (1 + kSetCap) : nullptr;
           col.list = col.cnt + 1;
-          if (a.debug != 32) nn_search_wave_far<P4, kCrop, kCollect>(a.grid, tp, it->x, it->y, it->z, a.kmax, a.crop, bq, lane, list, it->m, col);
+          if (a.debug != 32) nn_search_wave_far<P4, kCrop, kCollect>(a.grid, tp, it->x, it->y, it->z, a.kmax, a.crop, bq, lane, list, it->m, col, skip2 ? 1 : 2);
           // every lane holds the same winner and stores it (same address, same value): no lane-0 branch inside this loop --
           // with one, the structurised code re-ran the body for the other lanes forever (seen on ROCm 7.2)
           it->d2 = bq.d2;
@@ -1370,7 +1375,7 @@ __host__ __device__ inline void solve6_ldlt(const double* rec, double x[6]) {
 // costs an LDS round trip -- the solve has ~80 of them on the critical path of every ICP iteration
 #define O3DS_BCAST(v, SRC) __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), (SRC)), __builtin_amdgcn_readlane(__double2loint(v), (SRC)))
 
-__device__ __forceinline__ void solve6_wave(const double* rec, double* x_out, int lane) {
+__device__ __forceinline__ void solve6_wave(const double* rec, double* x_out, int lane, int* order_out = nullptr /* [6]: row at pivot position t */) {
   double a[6], b = 0.0;
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
@@ -1439,7 +1444,62 @@ __device__ __forceinline__ void solve6_wave(const double* rec, double* x_out, in
     xs[i] = O3DS_BCAST(xi, i);
     if (lane == i) mine = xi;
   }
-  if (lane < 6) x_out[perm] = mine;
+  if (lane < 6) {
+    x_out[perm] = mine;
+    if (order_out) order_out[lane] = perm;
+  }
+}
+
+// The same solve when the pivot order is KNOWN (the order the previous iteration's solve found: the normal equations of consecutive ICP
+// iterations are almost the same matrix).  Position t of the order is loaded into lane t with its columns in pivot order, so the
+// elimination is solve6_wave's with every "is the pivot already in place" answered yes: no search, no exchange of rows and columns --
+// those were two fifths of the instructions on this serial path -- and the same operations on the same values, hence the same bits.
+// Each step checks that the pivot it was handed is the STRICT maximum of the remaining diagonal (then Eigen's first-maximum rule picks
+// it too); if any step fails the result is discarded and the caller runs the searching solve.  Returns whether the order held.
+__device__ __forceinline__ bool solve6_wave_ordered(const double* rec, double* x_out, int lane, unsigned order) {
+  const int pt = (int)((order >> (3 * min(lane, 5))) & 7u);
+  double a[6], b = 0.0;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int pj = (int)((order >> (3 * j)) & 7u);
+    const int r = min(pt, pj), c = max(pt, pj);
+    a[j] = lane < 6 ? rec[r * 6 - (r * (r - 1)) / 2 + (c - r)] : (j == 0 ? 1.0 : 0.0);
+  }
+  if (lane < 6) b = -rec[21 + pt];
+  bool bad = false;
+  double rd[6];
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
+    double diag = a[0];
+#pragma unroll
+    for (int k = 1; k < 6; ++k) diag = lane == k ? a[k] : diag;
+    const double d = O3DS_BCAST(a[s], s);
+    const double bs = O3DS_BCAST(b, s);
+    bad |= lane > s && lane < 6 && fabs(diag) >= fabs(d);
+    rd[s] = fabs(d) > 2.2250738585072014e-308 ? 1.0 / d : 0.0;
+    const double l = d != 0.0 ? a[s] * (1.0 / d) : a[s];
+    const bool below = lane > s && lane < 6;
+#pragma unroll
+    for (int j = s + 1; j < 6; ++j) {
+      const double rs = O3DS_BCAST(a[j], s);
+      if (below) a[j] = fma(-l, rs, a[j]);
+    }
+    if (below) b = fma(-l, bs, b);
+  }
+  if (__ballot(bad) != 0ull) return false;
+  double xs[6];
+  double mine = 0.0;
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    double num = b;
+#pragma unroll
+    for (int j = i + 1; j < 6; ++j) num = fma(-a[j], xs[j], num);
+    const double xi = rd[i] != 0.0 ? num * rd[i] : num - b;
+    xs[i] = O3DS_BCAST(xi, i);
+    if (lane == i) mine = xi;
+  }
+  if (lane < 6) x_out[pt] = mine;
+  return true;
 }
 
 // One-sided Jacobi SVD of a 3x3 (row-major): A = U diag(d) V^T, d descending; columns of U for vanishing singular values are
@@ -1559,13 +1619,12 @@ __device__ inline void umeyama_from_record(const double* rec, double Ucm[16]) {
 // U*T speculatively; wavefront 1 computes fitness / rmse and the convergence test and decides whether the update is
 // applied.  (Measured inside icp_fused_kernel: 4.7 us for the one-thread-plus-barriers form this replaces.)
 __device__ __forceinline__ void icp_step_block(const double* s_rec, IcpStateDev* st, unsigned long long n_src_total, int max_iter,
-                                               double rel_fitness, double rel_rmse, double* s_x /* [8] */, double* s_sc /* unused */,
+                                               double rel_fitness, double rel_rmse, double* s_x /* [8] */, double* s_sc /* [8]: scratch of the solve (pivot order) */,
                                                double* s_U /* [16] */, double* s_T /* [16] */, int* s_go,
                                                unsigned long long* tr = nullptr /* 8 timestamps, development aid */,
                                                int method = O3DS_ICP_POINT_TO_PLANE,
                                                float* s_margin = nullptr /* [2]: |R - I|_F and |t| of the update (candidate-set margin) */) {
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  (void)s_sc;
 #define O3DS_TSTAMP(k)                                       \
   do {                                                       \
     if (tr && threadIdx.x == 0) tr[k] = wall_clock64();      \
@@ -1587,7 +1646,21 @@ __device__ __forceinline__ void icp_step_block(const double* s_rec, IcpStateDev*
       lds_wave_sync();
     } else {
     if (count > 0.0) {  // empty correspondence set => identity update (x = 0)
-      solve6_wave(s_rec, s_x, lane);
+      // the pivot order of the previous iteration's solve travels in the state (bit 31: valid; 3 bits per position)
+      const unsigned order = (unsigned)st->pad;
+      bool held = false;
+      if (order & 0x80000000u) held = solve6_wave_ordered(s_rec, s_x, lane, order);
+      if (!held) {
+        int* s_ord = (int*)s_sc;
+        solve6_wave(s_rec, s_x, lane, s_ord);
+        lds_wave_sync();
+        if (lane == 0) {
+          unsigned o = 0x80000000u;
+#pragma unroll
+          for (int t = 0; t < 6; ++t) o |= ((unsigned)s_ord[t] & 7u) << (3 * t);
+          st->pad = (int)o;
+        }
+      }
       lds_wave_sync();
     }
     O3DS_TSTAMP(2);

@@ -20,14 +20,9 @@ PY
   env "$@" O3DS_FUSED_TRACE=$OUT/$tag.trace0 O3DS_FUSED_TRACE_LAUNCH=0 $M1 --steps 2 --warmup 1 >/dev/null 2>&1
   for k in 0 5; do [ -f $OUT/$tag.trace$k ] && python scripts/fused_trace.py $OUT/$tag.trace$k > $OUT/$tag.trace$k.txt 2>&1; done
 }
-timeout 900 python -m pytest tests/test_icp_gpu.py tests/test_edge_parity_gpu.py tests/test_sharded_gpu.py -m gpu -q 2>&1 | grep -v "amdgpu.ids\|socket.cpp" | tail -60 > $OUT/pytest_icp.log
+timeout 900 python -m pytest tests/test_icp_gpu.py tests/test_sharded_gpu.py -m gpu -q 2>&1 | grep -v "amdgpu.ids\|socket.cpp" | tail -60 > $OUT/pytest_icp.log
 tail -3 $OUT/pytest_icp.log
-one r3 O3DS_BACKEND_LIB=$R/open3d_slam_amd/lib/libo3ds_backend_r3.so
-one new_noseed O3DS_ICP_SEED_STRIDE=0
 one new_sets_on O3DS_ICP_SETS=1
-one new_seed8 O3DS_ICP_SEED_STRIDE=8
-one new_seed4 O3DS_ICP_SEED_STRIDE=4
-one new_seed32 O3DS_ICP_SEED_STRIDE=32
 O3DS_ICP_STATS=1 $M1 --steps 1 --warmup 1 2>&1 >/dev/null | grep "icp stats" | tail -2 > $OUT/stats_default.txt
 cat $OUT/stats_*.txt
 for t in new_sets_on; do echo "== $t trace5"; tail -12 $OUT/$t.trace5.txt; done
