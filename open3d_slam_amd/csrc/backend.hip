@@ -161,14 +161,6 @@ struct o3ds_context {
   // candidate sets of the fused loop (icp_kernels.hpp, Collect): one allocation of nn_cache_cap x (kSetCap ints + {p_ref, L} at f64 width)
   int* d_set_pos = nullptr;
   void* d_set_ref = nullptr;
-  // pass 0 with the far kernel (icp_far_kernel): the list and the two alternating counters live behind the candidate sets' allocation;
-  // engaged per registration (O3DS_P0_FAR = 0 never / 1 always / default: when the handle's previous registration of that kind counted
-  // at least kFarEngage far queries in its pass 0 -- a stream that starts from a good prior never pays the extra launch)
-  void* d_far_list = nullptr;
-  unsigned* d_far_count = nullptr;  // [2], 64 unsigned apart
-  unsigned long long registrations = 0;
-  int far_mode = -1;
-  int last_p0_far[2] = {0, 0};
   int seed_stride = 0;                                   // O3DS_ICP_SEED_STRIDE (0: pass 0 starts every query from the radius): icp_seed_kernel
   bool sets = true;                                      // O3DS_ICP_SETS=0: every pass searches (same results bit for bit)
   float set_gain = 2.0f, set_min = 1e-3f, set_cap = 0.04f;  // O3DS_SET_GAIN / _MIN / _CAP (metres)
@@ -1010,32 +1002,6 @@ void launch_fused(o3ds_handle h, const IcpFusedArgs& fa, bool crop, int nblocks,
 constexpr size_t kFusedMaxQueries = (size_t)4096 * 64;
 int fused_blocks(size_t count) { return (int)std::max<size_t>((count + 63) / 64, 1); }
 
-// the far kernel of pass 0 (icp_kernels.hpp): 2048 workgroups = 8192 wavefronts take the listed queries round-robin
-void launch_far(o3ds_handle h, const IcpFusedArgs& fa) {
-  IcpFarArgs ka{};
-  ka.pass = fa.pass;
-  ka.init = fa.init;
-  ka.slots_out = fa.slots_out;
-  constexpr int kFarBlocks = 2048;
-  const bool gicp = h->session_method == O3DS_ICP_GENERALIZED, crop = h->session_crop;
-  if (h->session_precision == O3DS_PRECISION_F64) {  // (never with a crop: o3ds_icp_register_dev)
-    if (gicp)
-      icp_far_kernel<P4d, false, true><<<kFarBlocks, 256, 0, h->stream>>>(ka);
-    else
-      icp_far_kernel<P4d, false, false><<<kFarBlocks, 256, 0, h->stream>>>(ka);
-  } else if (crop) {
-    if (gicp)
-      icp_far_kernel<P4f, true, true><<<kFarBlocks, 256, 0, h->stream>>>(ka);
-    else
-      icp_far_kernel<P4f, true, false><<<kFarBlocks, 256, 0, h->stream>>>(ka);
-  } else {
-    if (gicp)
-      icp_far_kernel<P4f, false, true><<<kFarBlocks, 256, 0, h->stream>>>(ka);
-    else
-      icp_far_kernel<P4f, false, false><<<kFarBlocks, 256, 0, h->stream>>>(ka);
-  }
-}
-
 int pass_blocks(o3ds_handle h, size_t count) {
   const size_t qpb = 64;  // one batch of 256 / 4 queries per workgroup iteration
   size_t g = (count + qpb - 1) / qpb;
@@ -1086,18 +1052,12 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
     if (h->d_set_pos) (void)hipFree(h->d_set_pos);
     h->d_set_pos = nullptr;
     h->d_set_ref = nullptr;
-    h->d_far_list = nullptr;
-    h->d_far_count = nullptr;
-    constexpr size_t kFarCounters = 512;  // bytes: the two counters, 256 apart
-    if (hipMalloc((void**)&h->d_set_pos, cap * (kSetCap * sizeof(int) + 4 * sizeof(double) + sizeof(FarQuery<P4d>)) + kFarCounters) != hipSuccess) {
+    if (hipMalloc((void**)&h->d_set_pos, cap * (kSetCap * sizeof(int) + 4 * sizeof(double))) != hipSuccess) {
       (void)hipFree(h->d_nn_cache);
       h->d_nn_cache = nullptr;
       return fail(h, O3DS_ERR_OOM, "icp: candidate-set allocation failed");
     }
-    h->d_set_ref = (char*)h->d_set_pos + cap * kSetCap * sizeof(int);  // (cap is a multiple of 8: 32-byte aligned)
-    h->d_far_list = (char*)h->d_set_ref + cap * 4 * sizeof(double);
-    h->d_far_count = (unsigned*)((char*)h->d_far_list + cap * sizeof(FarQuery<P4d>));
-    if (hipMemsetAsync(h->d_far_count, 0, kFarCounters, h->stream) != hipSuccess) return fail(h, O3DS_ERR_HIP, "icp: counter initialisation failed");
+    h->d_set_ref = (char*)h->d_set_pos + cap * kSetCap * sizeof(int);  // (cap is a multiple of 4: 32-byte aligned)
     h->nn_cache_cap = cap;
   }
   IcpStateDev st{};
@@ -1254,7 +1214,6 @@ int o3ds_create(int device_id, o3ds_handle* out) {
     }
     if (const char* e = getenv("O3DS_ICP_SETS")) h->sets = atoi(e) != 0;
     if (const char* e = getenv("O3DS_ICP_SEED_STRIDE")) h->seed_stride = std::max(atoi(e), 0);
-    if (const char* e = getenv("O3DS_P0_FAR")) h->far_mode = atoi(e);
     if (const char* e = getenv("O3DS_SET_GAIN")) h->set_gain = (float)atof(e);
     if (const char* e = getenv("O3DS_SET_MIN")) h->set_min = (float)atof(e);
     if (const char* e = getenv("O3DS_SET_CAP")) h->set_cap = (float)atof(e);
@@ -1957,17 +1916,6 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
           icp_seed_kernel<P4f, false><<<sb, 256, 0, h->stream>>>(fa.pass, fa.init, h->seed_stride);
       }
     }
-    // pass 0 with the far kernel behind it?  (the f64-storage kernel with a crop does not carry the hand-over code)
-    const int slot = target_crop ? 1 : 0;
-    constexpr int kFarEngage = 2048;
-    unsigned* const far_counter = h->d_far_count ? h->d_far_count + 64 * (h->registrations & 1) : nullptr;
-    unsigned* const far_counter_next = h->d_far_count ? h->d_far_count + 64 * ((h->registrations + 1) & 1) : nullptr;
-    h->registrations++;
-    const bool far_ok = far_counter && !(h->session_precision == O3DS_PRECISION_F64 && h->session_crop) && a.count >= 4096;
-    const bool p0_far = far_ok && (h->far_mode == 1 || (h->far_mode < 0 && h->last_p0_far[slot] >= kFarEngage));
-    fa.pass.far_count = far_counter;
-    fa.pass.far_list = h->d_far_list;
-    fa.pass.p0_far = p0_far ? 1 : 0;
     int j = 0;
     const IcpStateDev* last = h->d_state;
     while (j < total) {
@@ -1988,14 +1936,11 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
         const bool tail_only = j == total - 1;
         fa.trace = j == trace_launch ? d_trace : nullptr;
         fa.pass.stats = d_stats ? d_stats + 4 * (size_t)j : nullptr;
-        fa.far_count_read = j == 1 ? far_counter : nullptr;
-        fa.far_count_clear = j == 1 ? far_counter_next : nullptr;
         fa.state_host = k == chunk - 1 ? h->h_state_dev : nullptr;  // the launch the host waits for also writes the pinned copy
         if (h->session_precision == O3DS_PRECISION_F64)
           launch_fused<P4d>(h, fa, h->session_crop, tail_only ? 1 : nb, !tail_only);
         else
           launch_fused<P4f>(h, fa, h->session_crop, tail_only ? 1 : nb, !tail_only);
-        if (j == 0 && p0_far) launch_far(h, fa);
         last = fa.state_out;
       }
       {
@@ -2014,7 +1959,6 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
       if (h->h_state->done) break;
     }
     h->fused_chunk_hint[target_crop ? 1 : 0] = std::min(std::max(h->h_state->iterations + 3, 4), 12);  // iterations + 2 launches were needed
-    h->last_p0_far[slot] = h->h_state->error;  // pass 0's count of far queries (launch 1 copied it into the state)
     if (d_stats) {
       std::vector<unsigned long long> t((size_t)4 * total);
       (void)hipMemcpy(t.data(), d_stats, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);

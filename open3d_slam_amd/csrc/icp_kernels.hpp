@@ -662,12 +662,6 @@ struct IcpPassArgs {
   void* set_ref;
   float set_gain, set_min, set_cap;  // margin m = gain * (|R - I|_F |p| + |t|) of the last update, at least set_min; above set_cap: no set
   int p0_skip2;               // pass 0 without the group stage 2 (experiment)
-  // Pass 0 with the far kernel (icp_far_kernel): the launch settles what the 3x3x3 block settles and lists every other query in far_list
-  // (far_count[0] = how many); their matches, cache entries and records are the far kernel's.  far_count is also filled without it
-  // (stage-3 queries of pass 0): the host engages the far kernel for a registration when the previous one on the handle counted many.
-  int p0_far;
-  unsigned* far_count;        // [1], zero on entry of pass 0
-  void* far_list;             // FarQuery[n_src]
   int seed_stride;            // > 0: pass 0 starts every query from the match of query (i / seed_stride) * seed_stride (icp_seed_kernel)
   unsigned long long* stats;  // null, or per-launch counters [launch][4]: verified matches, searches, sets left behind, stage-3 queries (O3DS_ICP_STATS)
 };
@@ -840,15 +834,6 @@ __device__ __forceinline__ int wave_pop(int* counter, int lane) {
   return __builtin_amdgcn_readfirstlane(k);
 }
 
-// a query of pass 0 handed to the far kernel: its index and the bound the 3x3x3 block left
-template <typename P4>
-struct alignas(8) FarQuery {
-  typename Scalar<P4>::type d2;
-  typename Scalar<P4>::index idx;
-  unsigned i;
-  int pos;
-};
-
 // an unresolved query parked for stage 3
 template <typename P4>
 struct FarItem {
@@ -932,15 +917,17 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
   const bool p2p = a.method == O3DS_ICP_POINT_TO_POINT || inf;  // uniform: records built from the points themselves, no normals
   // which two slots a record term multiplies: from the tables above, packed four bits per term into literals (a table in memory would
   // be a load whose latency the verified-match path has nothing to hide behind)
+#ifdef O3DS_DBG_OLD_TABLES
+  static __device__ const unsigned char dA[kRec] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9};
+  static __device__ const unsigned char dB[kRec] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5, 6, 6, 6, 6, 6, 6, 6, 7, 7, 9, 9};
+  const int ta = dA[term], tb = dB[term];
+#else
   const int ta = term_slot(inf ? kPackA_inf : (p2p ? kPackA_p2p : kPackA), term);
   const int tb = term_slot(inf ? kPackB_inf : (p2p ? kPackB_p2p : kPackB), term);
+#endif
   // candidate sets: read (verified matches) whenever the previous pass left them, written whenever this pass has a margin
   const bool sets = !kKeys && a.set_pos != nullptr && s_set != nullptr;
-  // pass 0 with the far kernel behind it (not compiled into the f64-storage kernel with a crop: the few registers it costs are ones that
-  // instantiation does not have; the host never engages it there)
-  constexpr bool kFarOk = !kKeys && !(sizeof(R) == 8 && kCrop);
-  const bool p0_far = kFarOk && !use_cache && a.p0_far && a.far_list != nullptr;
-  const bool skip2 = !use_cache && (a.p0_skip2 || p0_far);  // pass 0: whatever the 3x3x3 block does not settle goes to a whole wavefront
+  const bool skip2 = !use_cache && a.p0_skip2;  // pass 0: whatever the 3x3x3 block does not settle goes to a whole wavefront (stage 3)
   const bool sets_in = sets && use_cache;
   const bool sets_out = kCollect && sets;
   const R rmax = (R)sqrt(a.r2max);
@@ -1056,35 +1043,13 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
     {
       FarItem<P4>* mine_item = (FarItem<P4>*)(s_rec_flat + ql * kStride);
       if (a.debug == 16) unresolved = false;
-      int far_k = 0;
       if (unresolved && gl == 0) {
-        far_k = atomicAdd(&s_far[0], 1);
-        s_far[2 + far_k] = ql;
+        const int k = atomicAdd(&s_far[0], 1);
+        s_far[2 + k] = ql;
       }
       __syncthreads();
       const int n_far = __builtin_amdgcn_readfirstlane(s_far[0]);
-      if (!use_cache && a.far_count && n_far > 0) {  // pass 0 counts its far queries; with the far kernel they also get their places in its list
-        if (threadIdx.x == 0) {
-          const unsigned base = atomicAdd(a.far_count, (unsigned)n_far);
-          if (p0_far) s_far[1] = (int)base;
-        }
-        if (p0_far) __syncthreads();
-      }
-      if (p0_far) {  // workgroup-uniform: hand the unresolved queries over (their records stay zero here)
-        if (n_far > 0) {
-          if (unresolved && gl == 0) {
-            // (the order inside the list is whatever the atomics made it: the far kernel's sums are exact per query)
-            const int k = far_k;
-            FarQuery<P4> fq;
-            fq.d2 = nn.d2;
-            fq.idx = nn.idx;
-            fq.i = (unsigned)i;
-            fq.pos = nn.pos;
-            ((FarQuery<P4>*)a.far_list)[(size_t)s_far[1] + (size_t)k] = fq;
-          }
-          __syncthreads();  // s_far is reset below
-        }
-      } else if (n_far > 0) {  // workgroup-uniform
+      if (n_far > 0) {  // workgroup-uniform
         const int lane = threadIdx.x & 63;
         int2* list = s_seg + (threadIdx.x >> 6) * (64 / kGroup) * kSegMax;
         for (int k = wave_pop(&s_far[1], lane); k < n_far; k = wave_pop(&s_far[1], lane)) {  // k is scalar: a uniform loop
@@ -1128,8 +1093,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
       }
     }
     // ---- the candidate set this query's search leaves for the next pass (a verified match keeps the one it has)
-    const bool handed_over = p0_far && unresolved;  // the far kernel writes this query's cache entry, set and record
-    if (sets && i < a.count && !verified && a.debug != 2 && !handed_over) {
+    if (sets && i < a.count && !verified && a.debug != 2) {
       const int n_listed = my_set[0];
       const bool have = m > (R)0 && n_listed <= kSetCap;
       int pos_out = have ? (gl < n_listed ? my_set[1 + gl] : -1) : (gl == 0 ? nn.pos : -1);
@@ -1153,13 +1117,13 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
     // ---- records
     if (!verified && gl == 0) {
       {
-        if (i < a.count && !(kKeys && a.keys_mode == 2) && !handed_over) a.nn_cache[a.first + i] = nn.pos;
+        if (i < a.count && !(kKeys && a.keys_mode == 2)) a.nn_cache[a.first + i] = nn.pos;
         if (kKeys && a.keys_mode == 1 && i < a.count)
           a.keys[a.first + i] = nn.pos == -1 ? kNoKey
                                              : ((unsigned long long)__float_as_uint((float)nn.d2) << 32) |
                                                    ((unsigned long long)(a.keys_rank & 0xf) << 28) | (unsigned long long)(nn.pos & 0x0fffffff);
         double* rec = s_rec_flat + ql * kStride;
-        if (nn.pos != -1 && !(kKeys && a.keys_mode == 1) && !handed_over) {
+        if (nn.pos != -1 && !(kKeys && a.keys_mode == 1)) {
           if (a.debug == 3) nn.pos = (int)(i % 1000);
           const P4 q = tp[nn.pos];
           const P4 nq = (!kGicp && p2p) ? P4{} : tn[nn.pos];
@@ -1232,14 +1196,11 @@ constexpr int kUpdBlock = 1024;
 // 4.4e-4 m of pose accuracy at |p| = 2e5 m where plain f64 sums give 1.7e-5 (tests/test_icp_gpu.py::test_large_coordinates_*).
 // If a caller's data exceed a bound (e.g. normals far from unit length) the split degrades to hi = v, lo = 0 -- ordinary f64 sums,
 // still correct, merely no longer order-independent.
-// lo_scale = q_lo / q_hi: kLoScale (2^-41) when a pass adds one value per WORKGROUP (<= 4096 of them); kLoScaleQueries (2^-32) when it adds
-// values per QUERY as well (the far kernel of pass 0: sums of up to 2^21 such lo values are exact) -- one scale per pass, all its addends.
-constexpr double kLoScale = 4.547473508864641e-13, kLoScaleQueries = 2.3283064365386963e-10;
-__device__ __forceinline__ void split_exact(double v, double q_hi, double* hi, double* lo, double lo_scale = kLoScale) {
+__device__ __forceinline__ void split_exact(double v, double q_hi, double* hi, double* lo) {
   const double c_hi = 6755399441055744.0 * q_hi;  // 1.5 * 2^52 * q_hi: (v + c) - c rounds v to a multiple of q_hi (|v| < 2^51 q_hi)
   const double h = (v + c_hi) - c_hi;
   const double r = v - h;  // exact
-  const double c_lo = c_hi * lo_scale;
+  const double c_lo = c_hi * 4.547473508864641e-13;  // * 2^-41
   *hi = h;
   *lo = (r + c_lo) - c_lo;
 }
@@ -1871,8 +1832,6 @@ struct IcpFusedArgs {
   int max_iter;
   double rel_fitness, rel_rmse;
   int first;                      // 1: launch 0 -- there is no previous pass to fold
-  unsigned* far_count_read;       // launch 1: pass 0's count of far queries, copied into the state's `error` field for the host (null otherwise)
-  unsigned* far_count_clear;      // launch 1: the counter the NEXT registration's pass 0 will use (the two alternate), zeroed here
   unsigned long long* trace;      // null, or [gridDim.x][16] phase timestamps (100 MHz wall clock) of thread 0 (O3DS_FUSED_TRACE)
 };
 
@@ -1916,7 +1875,9 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   __shared__ int s_set[kQPB * (1 + kSetCap)];
   __shared__ float s_margin[2];
   __shared__ int s_go;
+#ifndef O3DS_DBG_NO_WARM
   kernarg_warm<(int)sizeof(IcpFusedArgs)>();
+#endif
 #define O3DS_STAMP(k)                                                                                  \
   do {                                                                                                 \
     if (fa.trace && threadIdx.x == 0) fa.trace[(size_t)blockIdx.x * 16 + (k)] = wall_clock64();         \
@@ -1975,8 +1936,6 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
     __syncthreads();
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (fa.far_count_read) s_st.error = (int)*fa.far_count_read;
-    if (fa.far_count_clear) *fa.far_count_clear = 0u;
     *fa.state_out = s_st;
     if (fa.state_host) *fa.state_host = s_st;
   }
@@ -1998,8 +1957,11 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   // ---------------- epilogue: add the record to this workgroup's slot, exactly ----------------
   if (threadIdx.x < kRec) {
     double hi, lo;
-    // (a pass 0 that hands queries to the far kernel shares its lo quantum: one scale for all addends of a pass)
-    split_exact(v, q_hi_mine, &hi, &lo, fa.first && fa.pass.p0_far && fa.pass.far_list ? kLoScaleQueries : kLoScale);
+#ifdef O3DS_DBG_QHI_LATE
+    split_exact(v, fa.pass.q_hi[threadIdx.x], &hi, &lo);
+#else
+    split_exact(v, q_hi_mine, &hi, &lo);
+#endif
     double* slot = fa.slots_out + (size_t)(blockIdx.x % kFusedSlots) * kSlotDoubles;
     if (hi != 0.0) (void)__hip_atomic_fetch_add(slot + threadIdx.x, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (lo != 0.0) (void)__hip_atomic_fetch_add(slot + kRec + threadIdx.x, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2009,97 +1971,6 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   O3DS_STAMP(6);
   if (fa.trace && threadIdx.x == 0) fa.trace[(size_t)blockIdx.x * 16 + 7] = 0ull;
 #undef O3DS_STAMP
-}
-
-// ----------------------------------------------------------------------------------------------
-// the far kernel of pass 0
-// ----------------------------------------------------------------------------------------------
-// Pass 0 of a misaligned registration is a third of its time in this file's own traces: two fifths of the queries are not settled by
-// the 3x3x3 block, they cluster, and a workgroup that holds many of them finishes at 53 us where the mean is 35.  With the far kernel
-// behind it the fused launch 0 only does the block (9 us mean / 16 max) and lists the rest; here every listed query gets a whole
-// wavefront (nn_search_wave_far over everything beyond the block), taken round-robin from ONE list by twice as many wavefronts as the
-// fused kernel's registers allow -- balanced over the device, not per workgroup.  Its correspondences are the same; its records are
-// added PER QUERY: each of the 30 terms is split into exact hi / lo parts before it is added (split_exact with the per-query lo quantum,
-// which launch 0 shares), so the slot sums do not depend on which wavefront served which query, nor on the order of the list.  The
-// record a workgroup would have formed from 64 queries is rounded differently, so a registration with the far kernel engaged agrees with
-// one without to rounding (1e-15 relative), not bit for bit; both are bitwise repeatable.
-struct IcpFarArgs {
-  IcpPassArgs pass;
-  IcpStateDev init;   // the pose pass 0 runs under
-  double* slots_out;  // the slot buffer launch 0 adds into
-};
-
-template <typename P4, bool kCrop, bool kGicp>
-__global__ __launch_bounds__(256) void icp_far_kernel(IcpFarArgs fa) {
-  using R = typename Scalar<P4>::type;
-  constexpr int kStride = kGicp ? kRec : kRecSlots;
-  __shared__ int2 s_list[4][kFarList];
-  __shared__ double s_rec[4][kStride];
-  kernarg_warm<(int)sizeof(IcpFarArgs)>();
-  const IcpPassArgs& a = fa.pass;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const unsigned n = min(*a.far_count, (unsigned)a.count);
-  const unsigned wave_gid = blockIdx.x * 4u + (unsigned)wv, n_waves = gridDim.x * 4u;
-  const P4* __restrict__ tp = (const P4*)a.tpts;
-  const P4* __restrict__ tn = (const P4*)a.tnrm;
-  const double* T = fa.init.T;
-  const int term = lane & 31;
-  const bool p2p = a.method == O3DS_ICP_POINT_TO_POINT;
-  const int ta = term_slot(p2p ? kPackA_p2p : kPackA, term), tb = term_slot(p2p ? kPackB_p2p : kPackB, term);
-  const double q_mine = a.q_hi[term];
-  double acc_hi = 0.0, acc_lo = 0.0;
-  double* rec = s_rec[wv];
-  for (unsigned k = wave_gid; k < n; k += n_waves) {  // wave-uniform
-    const FarQuery<P4> fq = ((const FarQuery<P4>*)a.far_list)[k];
-    const size_t i = (size_t)fq.i;
-    const P4 s = ((const P4*)a.src)[a.first + i];
-    const double px = T[0] * (double)s.x + T[4] * (double)s.y + T[8] * (double)s.z + T[12];
-    const double py = T[1] * (double)s.x + T[5] * (double)s.y + T[9] * (double)s.z + T[13];
-    const double pz = T[2] * (double)s.x + T[6] * (double)s.y + T[10] * (double)s.z + T[14];
-    const R qx = (R)px, qy = (R)py, qz = (R)pz;
-    NNBest<P4> best;
-    best.d2 = fq.d2;
-    best.pos = fq.pos;
-    best.idx = fq.idx;
-    Collect<R> col;
-    col.tau2 = (R)0;
-    col.cnt = nullptr;
-    col.list = nullptr;
-    nn_search_wave_far<P4, kCrop, false, 1>(a.grid, tp, qx, qy, qz, a.kmax, a.crop, best, lane, s_list[wv], (R)0, col);
-    if (lane == 0) {
-      a.nn_cache[a.first + i] = best.pos;
-      if (a.set_pos) {  // no candidate set from pass 0 (no margin yet): the match is the next search's bound
-#pragma unroll
-        for (int g = 0; g < kSetCap; ++g) a.set_pos[(a.first + i) * kSetCap + g] = g == 0 ? best.pos : -1;
-        SetRef<P4> r;
-        r.x = qx, r.y = qy, r.z = qz;
-        r.L = (R)0;
-        ((SetRef<P4>*)a.set_ref)[a.first + i] = r;
-      }
-      if (best.pos != -1) {
-        const P4 q = tp[best.pos];
-        const P4 nq = (!kGicp && p2p) ? P4{} : tn[best.pos];
-        write_record<P4, kGicp>(a, rec, p2p, px, py, pz, q, nq, i, T[0], T[4], T[8], T[1], T[5], T[9], T[2], T[6], T[10]);
-      } else {
-#pragma unroll
-        for (int t = 0; t < kStride; ++t) rec[t] = 0.0;
-      }
-    }
-    lds_wave_sync();
-    if (lane < kRec) {
-      const double v = kGicp ? rec[term] : rec[ta] * rec[tb];
-      double hi, lo;
-      split_exact(v, q_mine, &hi, &lo, kLoScaleQueries);
-      acc_hi += hi;  // exact
-      acc_lo += lo;  // exact
-    }
-    lds_wave_sync();  // the record is rewritten by the next query
-  }
-  if (lane < 30) {
-    double* slot = fa.slots_out + (size_t)(wave_gid % kFusedSlots) * kSlotDoubles;
-    if (acc_hi != 0.0) (void)__hip_atomic_fetch_add(slot + lane, acc_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (acc_lo != 0.0) (void)__hip_atomic_fetch_add(slot + kRec + lane, acc_lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
 }
 
 }  // namespace o3ds

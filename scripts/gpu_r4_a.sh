@@ -22,13 +22,11 @@ PY
 }
 timeout 900 python -m pytest tests/test_icp_gpu.py tests/test_sharded_gpu.py -m gpu -q 2>&1 | grep -v "amdgpu.ids\|socket.cpp" | tail -60 > $OUT/pytest_icp.log
 tail -3 $OUT/pytest_icp.log
-one new_far0 O3DS_P0_FAR=0
-one new_far1 O3DS_P0_FAR=1
-one new_auto O3DS_ICP_SETS=1
+one new_sets_on O3DS_ICP_SETS=1
 O3DS_ICP_STATS=1 $M1 --steps 1 --warmup 1 2>&1 >/dev/null | grep "icp stats" | tail -2 > $OUT/stats_default.txt
 cat $OUT/stats_*.txt
-for t in new_auto; do echo "== $t trace5"; tail -12 $OUT/$t.trace5.txt; done
-echo "== new_far1 trace0"; tail -6 $OUT/new_far1.trace0.txt
+for t in new_sets_on; do echo "== $t trace5"; tail -12 $OUT/$t.trace5.txt; done
+echo "== new_sets_on trace0"; tail -6 $OUT/new_sets_on.trace0.txt
 cd /tmp && export TMPDIR=/tmp && rm -rf $OUT/prof_m1 && timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_m1 -o m1 -- python $R/bench.py --no-cpu-baseline --no-f64 --concurrent 0 --m2-frames 0 --large-map 0 --no-host-seam --steps 50 > /dev/null 2>&1
 python $R/scripts/prof_summary.py $OUT/prof_m1/m1_results.db $OUT/rocprof_stats_m1.txt > /dev/null; rm -rf $OUT/prof_m1
 sed -n 1,6p $OUT/rocprof_stats_m1.txt | cut -c1-60,110-170; sed -n 14,27p $OUT/rocprof_stats_m1.txt | cut -c60-120

@@ -586,9 +586,8 @@ def test_rank_deficient_normal_equations_follow_eigen_ldlt(backend_f64, oracle):
 
 # ---- candidate sets: a steady pass verifies its matches instead of searching (icp_kernels.hpp, Collect) ----------------------
 def _set_variants(monkeypatch, env):
-    for k in ("O3DS_ICP_SETS", "O3DS_SET_GAIN", "O3DS_SET_MIN", "O3DS_SET_CAP", "O3DS_ICP_SEED_STRIDE", "O3DS_P0_FAR"):
+    for k in ("O3DS_ICP_SETS", "O3DS_SET_GAIN", "O3DS_SET_MIN", "O3DS_SET_CAP", "O3DS_ICP_SEED_STRIDE"):
         monkeypatch.delenv(k, raising=False)
-    monkeypatch.setenv("O3DS_P0_FAR", "0")  # (the far kernel of pass 0 rounds its records per query: its own test below)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
 
@@ -631,44 +630,3 @@ def test_candidate_sets_do_not_change_a_single_bit(small_c2, oracle, monkeypatch
             np.testing.assert_array_equal(a["transformation"], b["transformation"], err_msg=str(env))
             assert (a["iterations"], a["converged"], a["n_corr"], a["fitness"], a["inlier_rmse"]) == (
                 b["iterations"], b["converged"], b["n_corr"], b["fitness"], b["inlier_rmse"]), env
-
-
-@pytest.mark.parametrize("prec", [backend.PRECISION_F32, backend.PRECISION_F64])
-def test_far_kernel_of_pass_0_same_correspondences_exact_sums(small_c2, oracle, monkeypatch, prec):
-    """Pass 0 with the far kernel behind it (icp_far_kernel: launch 0 settles what the 3x3x3 block settles, every other query gets a
-    whole wavefront from ONE device-wide list) finds the same correspondences -- same fitness, same number of them, after every
-    number of iterations -- and adds the far queries' records per query with exact hi / lo parts: poses agree with the default form to
-    rounding (a workgroup's record of 64 queries rounds differently), are bitwise repeatable although the list's order is not, and are
-    the oracle's within the stated tolerance.  Engaged by itself once a registration has counted enough far queries in its pass 0."""
-    src, tgt, nrm, _ = small_c2
-    sn = oracle.estimate_normals(src, 3.0, 20)
-    crop = backend.make_crop(backend.CROP_MAX_RADIUS, center=(1.0, -2.0, 0.0), rmax=22.0)
-    runs = {}
-    for far in ("0", "1"):
-        _set_variants(monkeypatch, {})
-        monkeypatch.setenv("O3DS_P0_FAR", far)
-        be = backend.Backend(0, prec)
-        try:
-            s_id, t_id = be.upload(src, sn), be.upload(tgt, nrm)
-            out = []
-            for rep in range(2):
-                for it in (0, 1, 2, 5, 12):
-                    out.append(be.icp_point_to_plane_dev(s_id, t_id, 1.0, max_iter=it, rel_fitness=0.0, rel_rmse=0.0))
-                out.append(be.icp_point_to_plane_dev(s_id, t_id, 1.0, max_iter=30))
-                if not (prec == backend.PRECISION_F64):  # (the f64-storage kernel with a crop does not carry the hand-over)
-                    out.append(be.icp_point_to_plane_dev(s_id, t_id, 1.0, target_crop=crop, max_iter=12, rel_fitness=0.0, rel_rmse=0.0))
-                out.append(be.icp_generalized_dev(s_id, t_id, 1.0, max_iter=8, rel_fitness=0.0, rel_rmse=0.0))
-                out.append(be.icp_point_to_point_dev(s_id, t_id, 1.0, max_iter=8, rel_fitness=0.0, rel_rmse=0.0))
-            runs[far] = out
-        finally:
-            be.close()
-    n = len(runs["1"]) // 2
-    for a, b in zip(runs["1"][:n], runs["1"][n:]):  # repeatable bit for bit
-        np.testing.assert_array_equal(a["transformation"], b["transformation"])
-        assert (a["fitness"], a["inlier_rmse"], a["n_corr"]) == (b["fitness"], b["inlier_rmse"], b["n_corr"])
-    for a, b in zip(runs["0"], runs["1"]):
-        assert (a["iterations"], a["converged"], a["n_corr"], a["fitness"]) == (b["iterations"], b["converged"], b["n_corr"], b["fitness"])
-        np.testing.assert_allclose(a["transformation"], b["transformation"], rtol=0, atol=1e-11)
-        assert abs(a["inlier_rmse"] - b["inlier_rmse"]) <= 1e-12
-    ref = oracle.icp_point_to_plane(src, tgt, nrm, 1.0, max_iter=12, rel_fitness=0.0, rel_rmse=0.0)
-    _check(runs["1"][4], ref, len(src), TOL_T64 if prec == backend.PRECISION_F64 else TOL_T, TOL_R64 if prec == backend.PRECISION_F64 else TOL_R)
