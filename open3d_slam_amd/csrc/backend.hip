@@ -161,7 +161,6 @@ struct o3ds_context {
   // candidate sets of the fused loop (icp_kernels.hpp, Collect): one allocation of nn_cache_cap x (kSetCap ints + {p_ref, L} at f64 width)
   int* d_set_pos = nullptr;
   void* d_set_ref = nullptr;
-  int seed_stride = 0;                                   // O3DS_ICP_SEED_STRIDE (0: pass 0 starts every query from the radius): icp_seed_kernel
   bool sets = true;                                      // O3DS_ICP_SETS=0: every pass searches (same results bit for bit)
   float set_gain = 2.0f, set_min = 1e-3f, set_cap = 0.04f;  // O3DS_SET_GAIN / _MIN / _CAP (metres)
   char* d_fused = nullptr;  // [2 states | 3 x kFusedSlots slot records (hi and lo sums)]
@@ -1124,7 +1123,6 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
   }
   a.kmax = std::max(1, (int)std::ceil(r / tgt->grid.cell));  // a neighbour within r is at most this many cells away
   a.nn_cache = h->d_nn_cache;
-  a.p0_skip2 = getenv("O3DS_P0_SKIP2") ? atoi(getenv("O3DS_P0_SKIP2")) : 0;
   a.set_pos = h->fused && h->sets ? h->d_set_pos : nullptr;
   a.set_ref = h->d_set_ref;
   a.set_gain = h->set_gain;
@@ -1213,7 +1211,6 @@ int o3ds_create(int device_id, o3ds_handle* out) {
       return fail(nullptr, O3DS_ERR_OOM, "o3ds_create: scratch allocation failed");
     }
     if (const char* e = getenv("O3DS_ICP_SETS")) h->sets = atoi(e) != 0;
-    if (const char* e = getenv("O3DS_ICP_SEED_STRIDE")) h->seed_stride = std::max(atoi(e), 0);
     if (const char* e = getenv("O3DS_SET_GAIN")) h->set_gain = (float)atof(e);
     if (const char* e = getenv("O3DS_SET_MIN")) h->set_min = (float)atof(e);
     if (const char* e = getenv("O3DS_SET_CAP")) h->set_cap = (float)atof(e);
@@ -1897,24 +1894,6 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
     if (want_stats) {
       HIP_TRY(hipMalloc((void**)&d_stats, sizeof(unsigned long long) * 4 * (size_t)total));
       HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof(unsigned long long) * 4 * (size_t)total, h->stream));
-    }
-    // seeds for pass 0 (icp_seed_kernel): one query in every seed_stride searched by a whole wavefront; worth its launch from a few
-    // thousand queries on
-    if (h->seed_stride > 0 && a.count >= 4096) {
-      fa.pass.seed_stride = h->seed_stride;
-      const size_t n_seeds = (a.count + (size_t)h->seed_stride - 1) / (size_t)h->seed_stride;
-      const int sb = (int)((n_seeds + 3) / 4);
-      if (h->session_precision == O3DS_PRECISION_F64) {
-        if (h->session_crop)
-          icp_seed_kernel<P4d, true><<<sb, 256, 0, h->stream>>>(fa.pass, fa.init, h->seed_stride);
-        else
-          icp_seed_kernel<P4d, false><<<sb, 256, 0, h->stream>>>(fa.pass, fa.init, h->seed_stride);
-      } else {
-        if (h->session_crop)
-          icp_seed_kernel<P4f, true><<<sb, 256, 0, h->stream>>>(fa.pass, fa.init, h->seed_stride);
-        else
-          icp_seed_kernel<P4f, false><<<sb, 256, 0, h->stream>>>(fa.pass, fa.init, h->seed_stride);
-      }
     }
     int j = 0;
     const IcpStateDev* last = h->d_state;

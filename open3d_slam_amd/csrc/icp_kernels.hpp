@@ -431,8 +431,7 @@ __device__ __forceinline__ NNBest<P4> nn_search_group(const GridDev& g, const P4
                                                       typename Scalar<P4>::type qy, typename Scalar<P4>::type qz, int kmax,
                                                       const CropDev& crop, int gl, int2* seg /* this group's kSegMax entries */,
                                                       NNBest<P4> best, typename Scalar<P4>::type m,
-                                                      const Collect<typename Scalar<P4>::type>& col, bool* resolved, int* kdone,
-                                                      bool skip2 = false /* leave the 5x5x5 shell to stage 3 as well */) {
+                                                      const Collect<typename Scalar<P4>::type>& col, bool* resolved, int* kdone) {
   const QueryCell c = locate(g, (double)qx, (double)qy, (double)qz);
   const int* __restrict__ cs = g.cell_start;
   // ---- one batch, issued before the bound is even computed: the 4 cell_start values of each of this lane's rows of the 3x3
@@ -491,7 +490,7 @@ __device__ __forceinline__ NNBest<P4> nn_search_group(const GridDev& g, const P4
   bool proven = kmax <= 1 || widen2(best.d2, m) * ic2 <= (1.0f + c.mf) * (1.0f + c.mf);
   *kdone = 1;
   // ---- stage 2: the 5x5x5 shell, trimmed by the bound (group-uniform branch), rows in two batches
-  if (!proven && !skip2) {
+  if (!proven) {
     constexpr int kHalf = 13, kOwn2 = (kHalf + G - 1) / G;
 #pragma unroll 1
     for (int r0 = 0; r0 < 25; r0 += kHalf) {
@@ -552,13 +551,12 @@ __device__ __forceinline__ NNBest<P4> nn_search_group(const GridDev& g, const P4
 // of the current bound and were not scanned by stages 0-2 are dealt to the lanes (one cell_start pair each), compacted
 // through the wavefront's LDS list (mbcnt rank), and the lanes regroup so that every listed half-row gets
 // 64 / pow2(#rows) (>= 4) lanes striding over it.
-template <typename P4, bool kCrop, bool kCollect, int kDone = 2 /* cells within this offset were scanned by the group stages; -1: none */>
+template <typename P4, bool kCrop, bool kCollect>
 __device__ __forceinline__ void nn_search_wave_far(const GridDev& g, const P4* __restrict__ tp, typename Scalar<P4>::type qx,
                                                    typename Scalar<P4>::type qy, typename Scalar<P4>::type qz, int K,
                                                    const CropDev& crop, NNBest<P4>& best, int lane, int2* s_list /* kFarList entries */,
-                                                   typename Scalar<P4>::type m, const Collect<typename Scalar<P4>::type>& col,
-                                                   int kdone_rt = kDone /* run-time form of kDone (pass 0 may skip the group stage 2) */) {
-  const int kdone = kdone_rt;
+                                                   typename Scalar<P4>::type m, const Collect<typename Scalar<P4>::type>& col) {
+  constexpr int kdone = 2;  // cells within offset 2 were scanned by the group stages
   constexpr int kPer = 4;   // half-rows per lane and round: all their bounds are fetched in one batch
   const QueryCell c = locate(g, (double)qx, (double)qy, (double)qz);
   const float b2 = bound_cells2(best.d2, m, g);
@@ -661,8 +659,6 @@ struct IcpPassArgs {
   int* set_pos;
   void* set_ref;
   float set_gain, set_min, set_cap;  // margin m = gain * (|R - I|_F |p| + |t|) of the last update, at least set_min; above set_cap: no set
-  int p0_skip2;               // pass 0 without the group stage 2 (experiment)
-  int seed_stride;            // > 0: pass 0 starts every query from the match of query (i / seed_stride) * seed_stride (icp_seed_kernel)
   unsigned long long* stats;  // null, or per-launch counters [launch][4]: verified matches, searches, sets left behind, stage-3 queries (O3DS_ICP_STATS)
 };
 
@@ -816,8 +812,6 @@ __device__ __forceinline__ QueryPrefetch<P4> prefetch_query(const IcpPassArgs& a
       q.rx = r.x, q.ry = r.y, q.rz = r.z, q.rL = r.L;
     } else if (use_cache) {
       prev = a.nn_cache[a.first + i];
-    } else if (a.seed_stride > 0) {
-      prev = a.nn_cache[a.first + i - i % (size_t)a.seed_stride];
     }
     if (prev >= a.n_tgt) prev = -1;  // never trust the cache with an address
     q.prev = prev;
@@ -927,7 +921,6 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
 #endif
   // candidate sets: read (verified matches) whenever the previous pass left them, written whenever this pass has a margin
   const bool sets = !kKeys && a.set_pos != nullptr && s_set != nullptr;
-  const bool skip2 = !use_cache && a.p0_skip2;  // pass 0: whatever the 3x3x3 block does not settle goes to a whole wavefront (stage 3)
   const bool sets_in = sets && use_cache;
   const bool sets_out = kCollect && sets;
   const R rmax = (R)sqrt(a.r2max);
@@ -1018,8 +1011,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
           // (the lane's row offsets are recomputed per batch: hoisted out of the batch loop they cost a dozen registers, i.e. spills)
           int gl_b = gl;
           asm volatile("" : "+v"(gl_b));
-          nn = nn_search_group<P4, kCrop, kGroup, kCollect>(a.grid, tp, qx, qy, qz, a.kmax, a.crop, gl_b, s_seg + ql * kSegMax, best, m, col, &resolved, &kdone,
-                                                            skip2);
+          nn = nn_search_group<P4, kCrop, kGroup, kCollect>(a.grid, tp, qx, qy, qz, a.kmax, a.crop, gl_b, s_seg + ql * kSegMax, best, m, col, &resolved, &kdone);
           if (!resolved && gl == 0) {  // park the query for stage 3 (its record slot is still unused)
             FarItem<P4>* mine_item = (FarItem<P4>*)(s_rec_flat + ql * kStride);
             mine_item->x = qx;
@@ -1063,7 +1055,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
           col.tau2 = it->tau2;
           col.cnt = sets ? s_set + slot * (1 + kSetCap) : nullptr;
           col.list = col.cnt + 1;
-          if (a.debug != 32) nn_search_wave_far<P4, kCrop, kCollect>(a.grid, tp, it->x, it->y, it->z, a.kmax, a.crop, bq, lane, list, it->m, col, skip2 ? 1 : 2);
+          if (a.debug != 32) nn_search_wave_far<P4, kCrop, kCollect>(a.grid, tp, it->x, it->y, it->z, a.kmax, a.crop, bq, lane, list, it->m, col);
           // every lane holds the same winner and stores it (same address, same value): no lane-0 branch inside this loop --
           // with one, the structurised code re-ran the body for the other lanes forever (seen on ROCm 7.2)
           it->d2 = bq.d2;
@@ -1769,38 +1761,6 @@ __global__ __launch_bounds__(128) void icp_update_kernel(const double* __restric
   if (threadIdx.x < kRec) s_out[threadIdx.x] = record[threadIdx.x];
   __syncthreads();
   icp_step_block(s_out, state, n_src_total, max_iter, rel_fitness, rel_rmse, s_x, s_sc, s_U, s_T, &s_go, nullptr, method);
-}
-
-// ----------------------------------------------------------------------------------------------
-// seeds for pass 0
-// ----------------------------------------------------------------------------------------------
-// The first pass of a registration has no bound: with the bench's misalignment a fifth of the queries look through the whole ball of
-// radius r (stage 3) and the rest through all 27 cells around them, 62 of the 250 us of a ten-iteration registration.  Neighbours on a
-// scan line see neighbouring surface, so ONE query in every `stride` is searched first, by a whole wavefront (all half-rows of the
-// r-ball in one batch of cell_start loads, 64 lanes on the candidates: three memory rounds), and pass 0 starts every query from the
-// match of its seed -- any target point is a valid bound, so this changes what the search costs and nothing of what it finds.
-template <typename P4, bool kCrop>
-__global__ __launch_bounds__(256) void icp_seed_kernel(IcpPassArgs a, IcpStateDev init, int stride) {
-  using R = typename Scalar<P4>::type;
-  __shared__ int2 s_list[4][kFarList];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const size_t i = ((size_t)blockIdx.x * 4 + (size_t)wv) * (size_t)stride;
-  if (i >= a.count) return;  // wave-uniform
-  const P4 s = ((const P4*)a.src)[a.first + i];
-  const double* T = init.T;
-  const double px = T[0] * (double)s.x + T[4] * (double)s.y + T[8] * (double)s.z + T[12];
-  const double py = T[1] * (double)s.x + T[5] * (double)s.y + T[9] * (double)s.z + T[13];
-  const double pz = T[2] * (double)s.x + T[6] * (double)s.y + T[10] * (double)s.z + T[14];
-  NNBest<P4> best;
-  best.d2 = (R)a.r2max;
-  best.pos = -1;
-  best.idx = -1;
-  Collect<R> col;
-  col.tau2 = (R)0;
-  col.cnt = nullptr;
-  col.list = nullptr;
-  nn_search_wave_far<P4, kCrop, false, -1>(a.grid, (const P4*)a.tpts, (R)px, (R)py, (R)pz, a.kmax, a.crop, best, lane, s_list[wv], (R)0, col);
-  if (lane == 0) a.nn_cache[a.first + i] = best.pos;
 }
 
 // ----------------------------------------------------------------------------------------------

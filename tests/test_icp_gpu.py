@@ -586,7 +586,7 @@ def test_rank_deficient_normal_equations_follow_eigen_ldlt(backend_f64, oracle):
 
 # ---- candidate sets: a steady pass verifies its matches instead of searching (icp_kernels.hpp, Collect) ----------------------
 def _set_variants(monkeypatch, env):
-    for k in ("O3DS_ICP_SETS", "O3DS_SET_GAIN", "O3DS_SET_MIN", "O3DS_SET_CAP", "O3DS_ICP_SEED_STRIDE"):
+    for k in ("O3DS_ICP_SETS", "O3DS_SET_GAIN", "O3DS_SET_MIN", "O3DS_SET_CAP"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -596,15 +596,13 @@ def _set_variants(monkeypatch, env):
 def test_candidate_sets_do_not_change_a_single_bit(small_c2, oracle, monkeypatch, prec):
     """A pass that proves its matches inside the candidate sets the previous pass left (no search) yields the SAME correspondences as
     the search, hence bit-identical sums, poses, fitness and rmse -- for every margin policy: off, default, margins so small that
-    nearly every verification fails, margins so large that the lists overflow -- and whether or not pass 0 starts from the matches of
-    seed queries (icp_seed_kernel).  Point-to-plane with and without a map crop,
+    nearly every verification fails, margins so large that the lists overflow.  Point-to-plane with and without a map crop,
     generalized, point-to-point; fixed iterations and the default convergence criteria."""
     src, tgt, nrm, _ = small_c2
     sn = oracle.estimate_normals(src, 3.0, 20)
     crop = backend.make_crop(backend.CROP_MAX_RADIUS, center=(1.0, -2.0, 0.0), rmax=22.0)
-    policies = [{"O3DS_ICP_SETS": "0", "O3DS_ICP_SEED_STRIDE": "0"}, {}, {"O3DS_SET_MIN": "1e-6", "O3DS_SET_GAIN": "0.01"},
-                {"O3DS_SET_MIN": "0.04", "O3DS_SET_CAP": "10", "O3DS_SET_GAIN": "8"}, {"O3DS_SET_MIN": "0.3", "O3DS_SET_CAP": "10"},
-                {"O3DS_ICP_SETS": "0", "O3DS_ICP_SEED_STRIDE": "3"}, {"O3DS_ICP_SEED_STRIDE": "64"}]
+    policies = [{"O3DS_ICP_SETS": "0"}, {}, {"O3DS_SET_MIN": "1e-6", "O3DS_SET_GAIN": "0.01"},
+                {"O3DS_SET_MIN": "0.04", "O3DS_SET_CAP": "10", "O3DS_SET_GAIN": "8"}, {"O3DS_SET_MIN": "0.3", "O3DS_SET_CAP": "10"}]
     results = []
     for env in policies:
         _set_variants(monkeypatch, env)
