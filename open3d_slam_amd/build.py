@@ -32,7 +32,10 @@ def build_backend(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Rpass-analysis=kernel-resource-usage", "-o", LIB,
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Rpass-analysis=kernel-resource-usage",
+           # leading pointer / scalar kernel arguments arrive in SGPRs with the dispatch instead of through a first scalar load
+           # (icp_fused_kernel issues its state loads from them; code for firmware without the feature is emitted alongside)
+           "-mllvm", "-amdgpu-kernarg-preload-count=8", "-o", LIB,
            os.path.join(CSRC, "backend.hip")]
     if verbose:
         print(" ".join(cmd))

@@ -984,14 +984,14 @@ void launch_fused(o3ds_handle h, const IcpFusedArgs& fa, bool crop, int nblocks,
   }
   if (h->session_method == O3DS_ICP_GENERALIZED) {
     if (crop)
-      icp_fused_kernel<P4, true, 256, 4, true><<<nblocks, 256, 0, h->stream>>>(fa);
+      icp_fused_kernel<P4, true, 256, 4, true><<<nblocks, 256, 0, h->stream>>>(fa.state_in, fa.slots_in, fa.first, fa);
     else
-      icp_fused_kernel<P4, false, 256, 4, true><<<nblocks, 256, 0, h->stream>>>(fa);
+      icp_fused_kernel<P4, false, 256, 4, true><<<nblocks, 256, 0, h->stream>>>(fa.state_in, fa.slots_in, fa.first, fa);
   } else {
     if (crop)
-      icp_fused_kernel<P4, true, 256, 4, false><<<nblocks, 256, 0, h->stream>>>(fa);
+      icp_fused_kernel<P4, true, 256, 4, false><<<nblocks, 256, 0, h->stream>>>(fa.state_in, fa.slots_in, fa.first, fa);
     else
-      icp_fused_kernel<P4, false, 256, 4, false><<<nblocks, 256, 0, h->stream>>>(fa);
+      icp_fused_kernel<P4, false, 256, 4, false><<<nblocks, 256, 0, h->stream>>>(fa.state_in, fa.slots_in, fa.first, fa);
   }
   if (e1) (void)hipEventRecord(e1, h->stream);
 }

@@ -799,25 +799,34 @@ __device__ __forceinline__ QueryPrefetch<P4> prefetch_query(const IcpPassArgs& a
   q.prev = -1;
   q.s = P4{};
   q.nprev = P4{};
+  q.tprev = P4{};
   q.rx = q.ry = q.rz = q.rL = (R)0;
   const bool sets = use_cache && use_sets && a.set_pos != nullptr;  // (use_sets: the fused kernel only, see icp_pass_body)
   const size_t i = query_index<kQPB, 64 / kGroup>(a.count, batch, threadIdx.x / kGroup, !use_cache);
-  if (i < a.count) {
-    q.s = ((const P4*)a.src)[a.first + i];
-    int prev = -1;
-    if (sets) {
-      static_assert(kGroup == kSetCap, "one listed point per lane of the group");
-      prev = a.set_pos[(a.first + i) * kSetCap + (threadIdx.x & (kGroup - 1))];
-      const SetRef<P4> r = ((const SetRef<P4>*)a.set_ref)[a.first + i];
-      q.rx = r.x, q.ry = r.y, q.rz = r.z, q.rL = r.L;
-    } else if (use_cache) {
-      prev = a.nn_cache[a.first + i];
-    }
-    if (prev >= a.n_tgt) prev = -1;  // never trust the cache with an address
-    q.prev = prev;
-  }
-  q.tprev = ((const P4*)a.tpts)[max(q.prev, 0)];
-  if (sets && a.tnrm) q.nprev = ((const P4*)a.tnrm)[max(q.prev, 0)];
+  if (a.count == 0) return q;
+  // Straight-line loads, no branch per lane and none per mode (a lane past the end reads the last query and drops it; a mode that has no
+  // use for a load reads a harmless address): a load inside a conditional block is followed by the moves that merge it with the other
+  // arm's value, i.e. by a wait for it right where it was issued -- three memory round trips one after the other in front of the solve
+  // instead of two overlapped ones.
+  static_assert(sizeof(SetRef<P4>) == sizeof(P4), "a source point stands in for the reference a mode without sets does not read");
+  static_assert(kGroup == kSetCap, "one listed point per lane of the group");
+  const bool live = i < a.count;
+  const size_t ic = a.first + (live ? i : a.count - 1);
+  const P4* __restrict__ src = (const P4*)a.src;
+  const int* pprev = sets ? a.set_pos + ic * kSetCap + (threadIdx.x & (kGroup - 1)) : a.nn_cache + ic;
+  const SetRef<P4>* pref = sets ? (const SetRef<P4>*)a.set_ref + ic : (const SetRef<P4>*)(src + ic);
+  const P4 s = src[ic];
+  int prev = *pprev;
+  const SetRef<P4> r = *pref;
+  if (prev >= a.n_tgt || !live || !use_cache) prev = -1;  // never trust the cache with an address
+  const int pc = max(prev, 0);
+  const P4 t = ((const P4*)a.tpts)[pc];
+  const P4 nrm = ((const P4*)(sets && a.tnrm ? a.tnrm : a.tpts))[pc];
+  q.s = s;  // (a dropped lane's point is never looked at: every use is behind i < count)
+  q.prev = prev;
+  q.tprev = t;
+  q.nprev = nrm;
+  q.rx = r.x, q.ry = r.y, q.rz = r.z, q.rL = sets && live ? r.L : (R)0;
   return q;
 }
 
@@ -911,14 +920,8 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
   const bool p2p = a.method == O3DS_ICP_POINT_TO_POINT || inf;  // uniform: records built from the points themselves, no normals
   // which two slots a record term multiplies: from the tables above, packed four bits per term into literals (a table in memory would
   // be a load whose latency the verified-match path has nothing to hide behind)
-#ifdef O3DS_DBG_OLD_TABLES
-  static __device__ const unsigned char dA[kRec] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9};
-  static __device__ const unsigned char dB[kRec] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5, 6, 6, 6, 6, 6, 6, 6, 7, 7, 9, 9};
-  const int ta = dA[term], tb = dB[term];
-#else
   const int ta = term_slot(inf ? kPackA_inf : (p2p ? kPackA_p2p : kPackA), term);
   const int tb = term_slot(inf ? kPackB_inf : (p2p ? kPackB_p2p : kPackB), term);
-#endif
   // candidate sets: read (verified matches) whenever the previous pass left them, written whenever this pass has a margin
   const bool sets = !kKeys && a.set_pos != nullptr && s_set != nullptr;
   const bool sets_in = sets && use_cache;
@@ -987,7 +990,11 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
             a.nn_cache[a.first + i] = nn.pos;
             double* rec = s_rec_flat + ql * kStride;
             if (nn.pos != -1) {
-              write_record<P4, kGicp>(a, rec, p2p, px, py, pz, qp.tprev, qp.nprev, i, t00, t01, t02, t10, t11, t12, t20, t21, t22);
+              // (the normal is first looked at HERE: left to itself the compiler widens it to f64 right behind its load, i.e. waits
+              // for that load in the prologue, in front of the solve)
+              P4 nprev = qp.nprev;
+              asm volatile("" : "+v"(nprev.x), "+v"(nprev.y), "+v"(nprev.z));
+              write_record<P4, kGicp>(a, rec, p2p, px, py, pz, qp.tprev, nprev, i, t00, t01, t02, t10, t11, t12, t20, t21, t22);
             } else {
 #pragma unroll
               for (int k = 0; k < kStride; ++k) rec[k] = 0.0;
@@ -1823,7 +1830,11 @@ __device__ __forceinline__ void kernarg_warm() {
 }
 
 template <typename P4, bool kCrop, int kPassBlock, int kGroup, bool kGicp>
-__global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4))) void icp_fused_kernel(IcpFusedArgs fa) {
+__global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4))) void icp_fused_kernel(
+    const IcpStateDev* state_in, const double* slots_in, int first /* = fa.state_in, fa.slots_in, first: leading scalar arguments are
+    PRELOADED into SGPRs at dispatch (-mllvm -amdgpu-kernarg-preload-count), so the loads the serial tail waits for go out before the
+    first byte of the argument block has been fetched */,
+    IcpFusedArgs fa) {
   constexpr int kQPB = kPassBlock / kGroup;
   constexpr int kParts = kPassBlock / 32;
   __shared__ double s_rec[kQPB * (kGicp ? kRec : kRecSlots)];
@@ -1834,32 +1845,33 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   __shared__ IcpStateDev s_st;
   __shared__ int s_set[kQPB * (1 + kSetCap)];
   __shared__ float s_margin[2];
+  __shared__ double s_qhi[kRec];
   __shared__ int s_go;
-#ifndef O3DS_DBG_NO_WARM
-  kernarg_warm<(int)sizeof(IcpFusedArgs)>();
-#endif
-#define O3DS_STAMP(k)                                                                                  \
-  do {                                                                                                 \
-    if (fa.trace && threadIdx.x == 0) fa.trace[(size_t)blockIdx.x * 16 + (k)] = wall_clock64();         \
-  } while (0)
-  O3DS_STAMP(0);
-  const bool use_cache = !fa.first;  // launch j evaluates pass j of the registration
   // ---------------- prologue: this pass's state from the previous state and the previous pass's slot records ----------------
-  // The loads the serial tail waits for go out FIRST (the memory pipeline returns in order): the previous state (thread 0) and the
-  // kFusedSlots x 64 slot values, 16 per lane of the first half-wavefront (value index = slot * 64 + {hi: 0..31, lo: 32..63} + term).
-  // wavefront 0: lane l holds dword l of the state and slot values l, 64 + l, ..., 448 + l (the hi sums of term l, or the lo sums of
-  // term l - 32, of the eight slots)
+  // The loads the serial tail waits for go out FIRST (the memory pipeline returns in order), from preloaded pointers: wavefront 0, lane l
+  // holds dword l of the state and slot values l, 64 + l, ..., 448 + l (the hi sums of term l, or the lo sums of term l - 32, of the
+  // eight slots)
   constexpr int kStateWords = (int)(sizeof(IcpStateDev) / sizeof(unsigned));
   static_assert(sizeof(IcpStateDev) % sizeof(unsigned) == 0 && kStateWords <= 64, "one dword of the state per lane");
   typedef unsigned __attribute__((may_alias)) word_alias;  // the state's doubles and ints travel as dwords: tell the compiler these accesses alias them
   unsigned st_word = 0u;
   double sv[kFusedSlots];
-  if (!fa.first && threadIdx.x < 64) {
-    if (threadIdx.x < kStateWords) st_word = ((const word_alias*)fa.state_in)[threadIdx.x];
+  if (!first && threadIdx.x < 64) {
+    if (threadIdx.x < kStateWords) st_word = ((const word_alias*)state_in)[threadIdx.x];
 #pragma unroll
-    for (int k = 0; k < kFusedSlots; ++k) sv[k] = fa.slots_in[k * kSlotDoubles + threadIdx.x];
+    for (int k = 0; k < kFusedSlots; ++k) sv[k] = slots_in[k * kSlotDoubles + threadIdx.x];
   }
-  const double q_hi_mine = threadIdx.x < kRec ? fa.pass.q_hi[threadIdx.x] : 0.0;  // (a per-lane load of a kernel argument: not at the very end)
+  __builtin_amdgcn_sched_barrier(0);
+  kernarg_warm<(int)sizeof(IcpFusedArgs) + 24>();  // (+ the three leading arguments)
+#define O3DS_STAMP(k)                                                                                  \
+  do {                                                                                                 \
+    if (fa.trace && threadIdx.x == 0) fa.trace[(size_t)blockIdx.x * 16 + (k)] = wall_clock64();         \
+  } while (0)
+  O3DS_STAMP(0);
+  const bool use_cache = !first;  // launch j evaluates pass j of the registration
+  // (the quanta of the epilogue: a per-lane load of a kernel argument, fetched now and parked in LDS -- loaded at the very end it is a
+  // memory round trip on the tail of every pass, kept in a register it is live through the whole kernel)
+  const double q_hi_mine = threadIdx.x < kRec ? fa.pass.q_hi[threadIdx.x] : 0.0;
   __builtin_amdgcn_sched_barrier(0);
   // pose-independent loads of this workgroup's queries: source point, cached match or candidate set (points AND normals); they land
   // while the tail of the previous pass is computed
@@ -1869,7 +1881,7 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
     fa.slots_clear[threadIdx.x] = 0.0;
     fa.slots_clear[kPassBlock + threadIdx.x] = 0.0;
   }
-  if (fa.first) {
+  if (first) {
     if (threadIdx.x == 0) s_st = fa.init;
   } else if (threadIdx.x < 64) {
     if (threadIdx.x < kStateWords) ((word_alias*)&s_st)[threadIdx.x] = st_word;
@@ -1881,6 +1893,7 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
     if (threadIdx.x < kRec) s_out[threadIdx.x] = t + tl;  // the one rounding, as in reduce_partials
   }
   if (threadIdx.x < 2) s_margin[threadIdx.x] = threadIdx.x == 0 ? -1.0f : 0.0f;
+  if (threadIdx.x < kRec) s_qhi[threadIdx.x] = q_hi_mine;
   __syncthreads();
   if (s_st.done) {  // loop already terminated: hand the final state on
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1890,7 +1903,7 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
     return;
   }
   O3DS_STAMP(1);
-  if (!fa.first) {
+  if (!first) {
     icp_step_block(s_out, &s_st, fa.n_src_total, fa.max_iter, fa.rel_fitness, fa.rel_rmse, s_x, s_sc, s_U, s_T, &s_go,
                    fa.trace ? fa.trace + (size_t)blockIdx.x * 16 + 8 : nullptr, fa.pass.method, s_margin);
     __syncthreads();
@@ -1917,11 +1930,7 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   // ---------------- epilogue: add the record to this workgroup's slot, exactly ----------------
   if (threadIdx.x < kRec) {
     double hi, lo;
-#ifdef O3DS_DBG_QHI_LATE
-    split_exact(v, fa.pass.q_hi[threadIdx.x], &hi, &lo);
-#else
-    split_exact(v, q_hi_mine, &hi, &lo);
-#endif
+    split_exact(v, s_qhi[threadIdx.x], &hi, &lo);
     double* slot = fa.slots_out + (size_t)(blockIdx.x % kFusedSlots) * kSlotDoubles;
     if (hi != 0.0) (void)__hip_atomic_fetch_add(slot + threadIdx.x, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (lo != 0.0) (void)__hip_atomic_fetch_add(slot + kRec + threadIdx.x, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
