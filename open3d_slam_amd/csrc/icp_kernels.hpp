@@ -350,6 +350,13 @@ __device__ __forceinline__ void lanes_min(NNBest<P4>& b) {
 constexpr int kFarList = 256;  // stage 3 list, aliased onto the wavefront's groups' lists
 constexpr int kSegMax = 32;   // stage 1: <= 9 segments; stage 2: <= 19 per batch of 13 rows; 32 so that a wavefront (>= 8 groups) owns >= kFarList entries
 
+// Workgroup barrier that orders LDS only.  __syncthreads() is a release/acquire fence over GLOBAL memory as well: it waits for every
+// outstanding vector-memory operation of the wavefront (s_waitcnt vmcnt(0)), i.e. for the acknowledgement of the cache-entry and
+// candidate-set stores a pass has just issued and for any load still in flight -- a memory round trip per barrier on a path that has
+// six of them and, with verified matches, nothing else to wait for.  Nothing in the pass kernels hands global data from one wavefront
+// of a workgroup to another, so their barriers wait for the LDS queue alone.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ void lds_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -690,8 +697,8 @@ constexpr TermPack pack_terms(const unsigned char (&t)[kRec]) {
 }
 constexpr TermPack kPackA = pack_terms(kTermA), kPackB = pack_terms(kTermB), kPackA_p2p = pack_terms(kTermA_p2p),
                    kPackB_p2p = pack_terms(kTermB_p2p), kPackA_inf = pack_terms(kTermA_inf), kPackB_inf = pack_terms(kTermB_inf);
-__device__ __forceinline__ int term_slot(const TermPack& p, int term) {
-  return (int)(((term & 16) ? p.hi : p.lo) >> (4 * (term & 15))) & 15;
+__device__ __forceinline__ int term_slot(unsigned long long lo, unsigned long long hi, int term) {  // (by value: literals, not a table in memory)
+  return (int)(((term & 16) ? hi : lo) >> (4 * (term & 15))) & 15;
 }
 
 // Workgroup = BLOCK threads = BLOCK/G queries x G lanes for the search, then (32 record terms) x (BLOCK/32 query slices) for the
@@ -920,8 +927,8 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
   const bool p2p = a.method == O3DS_ICP_POINT_TO_POINT || inf;  // uniform: records built from the points themselves, no normals
   // which two slots a record term multiplies: from the tables above, packed four bits per term into literals (a table in memory would
   // be a load whose latency the verified-match path has nothing to hide behind)
-  const int ta = term_slot(inf ? kPackA_inf : (p2p ? kPackA_p2p : kPackA), term);
-  const int tb = term_slot(inf ? kPackB_inf : (p2p ? kPackB_p2p : kPackB), term);
+  const int ta = term_slot(inf ? kPackA_inf.lo : (p2p ? kPackA_p2p.lo : kPackA.lo), inf ? kPackA_inf.hi : (p2p ? kPackA_p2p.hi : kPackA.hi), term);
+  const int tb = term_slot(inf ? kPackB_inf.lo : (p2p ? kPackB_p2p.lo : kPackB.lo), inf ? kPackB_inf.hi : (p2p ? kPackB_p2p.hi : kPackB.hi), term);
   // candidate sets: read (verified matches) whenever the previous pass left them, written whenever this pass has a margin
   const bool sets = !kKeys && a.set_pos != nullptr && s_set != nullptr;
   const bool sets_in = sets && use_cache;
@@ -934,7 +941,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
   static_assert((2 + kQPB) * sizeof(int) <= (kPassBlock / 32) * kRec * sizeof(double), "the far list fits s_red");
   int* s_far = (int*)&s_red[0][0];  // [0] count, [1] next, [2..] query slots; s_red itself is only used after the loop
   if (threadIdx.x == 0) s_far[0] = s_far[1] = 0;
-  __syncthreads();
+  lds_barrier();
   for (size_t b = (size_t)wg; b < n_batches; b += kSingle ? n_batches : (size_t)nwg) {
     const size_t i = query_index<kQPB, 64 / kGroup>(a.count, b, ql, !use_cache);
     double px = 0, py = 0, pz = 0;
@@ -1046,7 +1053,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
         const int k = atomicAdd(&s_far[0], 1);
         s_far[2 + k] = ql;
       }
-      __syncthreads();
+      lds_barrier();
       const int n_far = __builtin_amdgcn_readfirstlane(s_far[0]);
       if (n_far > 0) {  // workgroup-uniform
         const int lane = threadIdx.x & 63;
@@ -1069,7 +1076,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
           it->pos = bq.pos;
           it->idx = bq.idx;
         }
-        __syncthreads();
+        lds_barrier();
         if (unresolved) {  // (all lanes of the group: the set below is written by all of them)
           nn.d2 = mine_item->d2;
           nn.pos = mine_item->pos;
@@ -1133,7 +1140,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     if (tr && threadIdx.x == 0) tr[2] = wall_clock64();
     if (threadIdx.x == 0) s_far[0] = s_far[1] = 0;  // everyone is past the far list (ordered before its next use by the barrier below)
 #pragma unroll
@@ -1144,18 +1151,18 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
       else
         acc = fma(rec[ta], rec[tb], acc);
     }
-    __syncthreads();  // s_rec is rewritten by the next batch
+    lds_barrier();  // s_rec is rewritten by the next batch
   }
   // query slices -> 1, fixed order => bitwise reproducible for a given launch geometry
   s_red[qs][term] = acc;
-  __syncthreads();
+  lds_barrier();
   double v = 0.0;
   if (threadIdx.x < kRec) {
 #pragma unroll
     for (int k = 0; k < kPassBlock / 32; ++k) v += s_red[k][threadIdx.x];
     if (threadIdx.x >= 30) v = 0.0;
   }
-  __syncthreads();  // s_red may be reused by the caller
+  lds_barrier();  // s_red may be reused by the caller
   return v;         // valid in threads 0..31
 }
 
@@ -1714,7 +1721,7 @@ __device__ __forceinline__ void icp_step_block(const double* s_rec, IcpStateDev*
       *s_go = go;
     }
   }
-  __syncthreads();
+  lds_barrier();
   if (wv == 0 && *s_go) {  // T <- U * T
     if (lane < 16) st->T[lane] = tnew;
     if (lane == 0) st->iterations += 1;
@@ -1894,7 +1901,7 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   }
   if (threadIdx.x < 2) s_margin[threadIdx.x] = threadIdx.x == 0 ? -1.0f : 0.0f;
   if (threadIdx.x < kRec) s_qhi[threadIdx.x] = q_hi_mine;
-  __syncthreads();
+  lds_barrier();
   if (s_st.done) {  // loop already terminated: hand the final state on
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       *fa.state_out = s_st;
@@ -1906,7 +1913,7 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   if (!first) {
     icp_step_block(s_out, &s_st, fa.n_src_total, fa.max_iter, fa.rel_fitness, fa.rel_rmse, s_x, s_sc, s_U, s_T, &s_go,
                    fa.trace ? fa.trace + (size_t)blockIdx.x * 16 + 8 : nullptr, fa.pass.method, s_margin);
-    __syncthreads();
+    lds_barrier();
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     *fa.state_out = s_st;
