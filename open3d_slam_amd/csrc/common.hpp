@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cmath>
 #include <string>
 
 #include "../../include/o3ds_backend.h"
@@ -32,12 +33,16 @@ struct Scalar<P4d> {
   using index = int64_t;
 };
 
-// Cropping volume in device form (croppers.cpp:121-165).  Radii are compared squared.
+// Cropping volume in device form (croppers.cpp:121-165).  The reference compares DISTANCES (the square root of a squared norm) with
+// its radii; here the squared norm is compared with thresholds that are the radii's exact pre-images under the correctly rounded
+// square root -- le2 = the largest x with sqrt(x) <= rmax, ge2 = the smallest x with sqrt(x) >= rmin (to_dev, a few steps of
+// nextafter around r * r on the host) -- so the predicate keeps exactly the points the reference keeps, points on the radius included,
+// without a double-precision square root per candidate (fifteen instructions and the registers of the search's inner loop).
 struct CropDev {
   int kind;    // o3ds_crop_kind
   int invert;
   double cx, cy, cz;
-  double rmin, rmax;  // NOT squared (predicate uses sqrt like the reference for boundary fidelity)
+  double le2, ge2;  // thresholds of the squared distance for rmax / rmin (see above)
   double zmin, zmax;
 };
 
@@ -47,18 +52,18 @@ __host__ __device__ inline bool crop_contains(const CropDev& c, double x, double
   const double dx = x - c.cx, dy = y - c.cy, dz = z - c.cz;
   switch (c.kind) {
     case O3DS_CROP_MAX_RADIUS:
-      in = sqrt(dx * dx + dy * dy + dz * dz) <= c.rmax;
+      in = dx * dx + dy * dy + dz * dz <= c.le2;
       break;
     case O3DS_CROP_MIN_RADIUS:
-      in = sqrt(dx * dx + dy * dy + dz * dz) >= c.rmin;
+      in = dx * dx + dy * dy + dz * dz >= c.ge2;
       break;
     case O3DS_CROP_MIN_MAX_RADIUS: {
-      const double d = sqrt(dx * dx + dy * dy + dz * dz);
-      in = d <= c.rmax && d >= c.rmin;
+      const double d2 = dx * dx + dy * dy + dz * dz;
+      in = d2 <= c.le2 && d2 >= c.ge2;
       break;
     }
     case O3DS_CROP_CYLINDER:
-      in = z >= c.zmin && z <= c.zmax && sqrt(dx * dx + dy * dy) <= c.rmax;
+      in = z >= c.zmin && z <= c.zmax && dx * dx + dy * dy <= c.le2;
       break;
     default:
       return !c.invert;  // O3DS_CROP_NONE = the base CroppingVolume (croppers.cpp:49-55): everything is inside, so inverted nothing is
@@ -66,6 +71,37 @@ __host__ __device__ inline bool crop_contains(const CropDev& c, double x, double
   return c.invert ? !in : in;
 }
 #pragma clang fp contract(fast)
+
+// the largest x with sqrt(x) <= r (r >= 0; -1 for a negative or NaN radius: nothing passes `<=`, as with the reference's comparison)
+inline double sqrt_preimage_le(double r) {
+  if (!(r >= 0.0)) return -1.0;
+  if (std::isinf(r)) return r;
+  double x = r * r;
+  if (std::isinf(x)) x = 1.7976931348623157e308;
+  while (std::sqrt(x) > r) x = std::nextafter(x, -1.0);
+  for (;;) {
+    const double up = std::nextafter(x, INFINITY);
+    if (std::isinf(up) || !(std::sqrt(up) <= r)) break;
+    x = up;
+  }
+  return x;
+}
+// the smallest x >= 0 with sqrt(x) >= r (0 for r <= 0: every squared distance passes `>=`; +inf for an infinite or NaN radius... a NaN
+// radius passes nothing in the reference either: the comparison is false)
+inline double sqrt_preimage_ge(double r) {
+  if (r != r) return r;  // NaN: `>=` is false for every distance, as in the reference
+  if (r <= 0.0) return 0.0;
+  if (std::isinf(r)) return r;
+  double x = r * r;
+  if (std::isinf(x)) return x;
+  while (std::sqrt(x) < r) x = std::nextafter(x, INFINITY);
+  for (;;) {
+    const double dn = std::nextafter(x, -1.0);
+    if (dn < 0.0 || !(std::sqrt(dn) >= r)) break;
+    x = dn;
+  }
+  return x;
+}
 
 inline CropDev to_dev(const o3ds_crop* c) {
   CropDev d{};
@@ -78,8 +114,8 @@ inline CropDev to_dev(const o3ds_crop* c) {
   d.cx = c->center[0];
   d.cy = c->center[1];
   d.cz = c->center[2];
-  d.rmin = c->rmin;
-  d.rmax = c->rmax;
+  d.le2 = sqrt_preimage_le(c->rmax);
+  d.ge2 = sqrt_preimage_ge(c->rmin);
   d.zmin = c->zmin;
   d.zmax = c->zmax;
   return d;
@@ -110,6 +146,8 @@ struct IcpStateDev {
   int done;
   int converged;
   int error;  // 1: a workgroup of the persistent loop kernel timed out at the grid rendezvous (never expected)
+  float first_w, first_t;  // |R - I|_F and |t| of the registration's FIRST update: the next registration on the handle sizes the candidate-set
+                           // margin of its pass 0 from them (a stream's priors are about as good from one frame to the next)
   int pad;  // the pivot order of the last 6x6 solve (icp_kernels.hpp solve6_wave_ordered): bit 31 valid, 3 bits per position
 };
 

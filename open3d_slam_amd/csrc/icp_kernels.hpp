@@ -286,7 +286,7 @@ __device__ __forceinline__ void scan_strided(const P4* __restrict__ tp, int s, i
                                              typename Scalar<P4>::type qy, typename Scalar<P4>::type qz, const CropDev& crop,
                                              NNBest<P4>& best, const Collect<typename Scalar<P4>::type>& col) {
   using R = typename Scalar<P4>::type;
-  constexpr int kInFlight = sizeof(R) == 8 ? (kCrop ? 1 : 2) : (kCrop ? 2 : 4);  // (the crop predicate is f64 with a square root: its registers)
+  constexpr int kInFlight = sizeof(R) == 8 ? 2 : 4;
   for (int p = s + lane; p < e; p += kInFlight * stride) {
     int pk[kInFlight];
     bool vk[kInFlight];
@@ -666,6 +666,7 @@ struct IcpPassArgs {
   int* set_pos;
   void* set_ref;
   float set_gain, set_min, set_cap;  // margin m = gain * (|R - I|_F |p| + |t|) of the last update, at least set_min; above set_cap: no set
+  float p0_w, p0_t;                  // the "last update" pass 0 assumes (the previous registration's first update); p0_w < 0: pass 0 leaves no sets
   unsigned long long* stats;  // null, or per-launch counters [launch][4]: verified matches, searches, sets left behind, stage-3 queries (O3DS_ICP_STATS)
 };
 
@@ -1899,7 +1900,7 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
     const double tl = __shfl_down(t, 32, 64);
     if (threadIdx.x < kRec) s_out[threadIdx.x] = t + tl;  // the one rounding, as in reduce_partials
   }
-  if (threadIdx.x < 2) s_margin[threadIdx.x] = threadIdx.x == 0 ? -1.0f : 0.0f;
+  if (threadIdx.x < 2) s_margin[threadIdx.x] = threadIdx.x == 0 ? (first ? fa.pass.p0_w : -1.0f) : (first ? fa.pass.p0_t : 0.0f);
   if (threadIdx.x < kRec) s_qhi[threadIdx.x] = q_hi_mine;
   lds_barrier();
   if (s_st.done) {  // loop already terminated: hand the final state on
@@ -1916,6 +1917,10 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
     lds_barrier();
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (!first && s_st.pass == 1) {  // this launch has just formed the registration's first update
+      s_st.first_w = s_margin[0];
+      s_st.first_t = s_margin[1];
+    }
     *fa.state_out = s_st;
     if (fa.state_host) *fa.state_host = s_st;
   }
