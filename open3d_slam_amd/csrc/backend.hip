@@ -1952,7 +1952,8 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
       std::vector<unsigned long long> t((size_t)4 * total);
       (void)hipMemcpy(t.data(), d_stats, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
       (void)hipFree(d_stats);
-      fprintf(stderr, "icp stats (n_src %zu):", (size_t)a.count);
+      fprintf(stderr, "icp stats (n_src %zu, crop %d, pass-0 margin from w %.2e t %.2e, first update w %.2e t %.2e):", (size_t)a.count, target_crop ? 1 : 0,
+              fa.pass.p0_w, fa.pass.p0_t, h->h_state->first_w, h->h_state->first_t);
       for (int k = 0; k < j; ++k) fprintf(stderr, " [%d v%llu s%llu k%llu f%llu]", k, t[4 * k], t[4 * k + 1], t[4 * k + 2], t[4 * k + 3]);
       fprintf(stderr, "\n");
     }

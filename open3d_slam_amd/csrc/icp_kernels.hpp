@@ -1020,13 +1020,26 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
             }
           }
           Collect<R> col;
-          col.tau2 = tau2;
           col.cnt = my_set;
           col.list = my_set + 1;
-          // (the lane's row offsets are recomputed per batch: hoisted out of the batch loop they cost a dozen registers, i.e. spills)
-          int gl_b = gl;
-          asm volatile("" : "+v"(gl_b));
-          nn = nn_search_group<P4, kCrop, kGroup, kCollect>(a.grid, tp, qx, qy, qz, a.kmax, a.crop, gl_b, s_seg + ql * kSegMax, best, m, col, &resolved, &kdone);
+          // Pass 0 has no bound to list against (tau = r + m lists everything): with a margin it looks twice -- the search proper, then
+          // the same search from the bound it found, which only touches the few cells of the ball (d1 + m) and lists what lies inside.
+          // One copy of the search in a two-trip loop; every later pass makes one trip.
+          const int trips = kCollect && !use_cache && m > (R)0 ? 2 : 1;
+          for (int trip = 0; trip < trips; ++trip) {  // (uniform per group)
+            if (trip == 1) {
+              if (!resolved || nn.pos == -1) break;  // stage 3 is still to come, or nothing within r: no set from this pass
+              best = nn;
+              const R tau = (R)sqrt(nn.d2) + m;
+              tau2 = tau * tau;
+            }
+            col.tau2 = trip == trips - 1 ? tau2 : (R)0;
+            // (the lane's row offsets are recomputed per batch: hoisted out of the batch loop they cost a dozen registers, i.e. spills)
+            int gl_b = gl;
+            asm volatile("" : "+v"(gl_b));
+            nn = nn_search_group<P4, kCrop, kGroup, kCollect>(a.grid, tp, qx, qy, qz, a.kmax, a.crop, gl_b, s_seg + ql * kSegMax, best, m, col, &resolved, &kdone);
+          }
+          if (trips == 2 && (!resolved || nn.pos == -1)) m = (R)0, tau2 = (R)0;  // (no set: see above)
           if (!resolved && gl == 0) {  // park the query for stage 3 (its record slot is still unused)
             FarItem<P4>* mine_item = (FarItem<P4>*)(s_rec_flat + ql * kStride);
             mine_item->x = qx;
