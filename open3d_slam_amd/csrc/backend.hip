@@ -1125,6 +1125,11 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
   a.kmax = std::max(1, (int)std::ceil(r / tgt->grid.cell));  // a neighbour within r is at most this many cells away
   a.nn_cache = h->d_nn_cache;
   a.p0_w = -1.0f;  // (o3ds_icp_register_dev fills in what the handle's previous registration suggests)
+  {  // the first look of a search without a bound: half a cell (O3DS_FIRST_LOOK: fraction of the cell, 0 = off)
+    static const double f = getenv("O3DS_FIRST_LOOK") ? atof(getenv("O3DS_FIRST_LOOK")) : 0.5;
+    const double r0 = f * tgt->grid.cell;
+    a.r2_first = r0 > 0.0 ? r0 * r0 : 0.0;
+  }
   a.set_pos = h->fused && h->sets ? h->d_set_pos : nullptr;
   a.set_ref = h->d_set_ref;
   a.set_gain = h->set_gain;
