@@ -174,7 +174,6 @@ struct o3ds_context {
   unsigned char* d_voxtab = nullptr;
   size_t voxtab_cap = 0;  // slots
   bool voxtab_clean = false;
-  float first_update[2][2] = {{-1.0f, 0.0f}, {-1.0f, 0.0f}};  // [scan-to-map?][|R - I|_F, |t|] of the previous registration's first update (-1: none yet)
   int fused_chunk_hint[2] = {12, 12};  // [registration against a cropped target?]: scan-to-map and scan-to-scan alternate on a handle  // launches queued before the host first looks at the state: what the previous registration needed, plus one
   int debug_update = 0;  // O3DS_DEBUG_UPDATE: timing experiments only
   int pass_rows = 1024;
@@ -1124,12 +1123,6 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
   }
   a.kmax = std::max(1, (int)std::ceil(r / tgt->grid.cell));  // a neighbour within r is at most this many cells away
   a.nn_cache = h->d_nn_cache;
-  a.p0_w = -1.0f;  // (o3ds_icp_register_dev fills in what the handle's previous registration suggests)
-  {  // the first look of a search without a bound: half a cell (O3DS_FIRST_LOOK: fraction of the cell, 0 = off)
-    static const double f = getenv("O3DS_FIRST_LOOK") ? atof(getenv("O3DS_FIRST_LOOK")) : 0.5;
-    const double r0 = f * tgt->grid.cell;
-    a.r2_first = r0 > 0.0 ? r0 * r0 : 0.0;
-  }
   a.set_pos = h->fused && h->sets ? h->d_set_pos : nullptr;
   a.set_ref = h->d_set_ref;
   a.set_gain = h->set_gain;
@@ -1902,10 +1895,6 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
       HIP_TRY(hipMalloc((void**)&d_stats, sizeof(unsigned long long) * 4 * (size_t)total));
       HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof(unsigned long long) * 4 * (size_t)total, h->stream));
     }
-    // candidate sets from pass 0 on: its margin assumes the first update will be about what the previous registration's was
-    static const bool p0_sets = !(getenv("O3DS_P0_SETS") && atoi(getenv("O3DS_P0_SETS")) == 0);
-    fa.pass.p0_w = p0_sets ? h->first_update[target_crop ? 1 : 0][0] : -1.0f;
-    fa.pass.p0_t = h->first_update[target_crop ? 1 : 0][1];
     int j = 0;
     const IcpStateDev* last = h->d_state;
     while (j < total) {
@@ -1949,16 +1938,11 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
       if (h->h_state->done) break;
     }
     h->fused_chunk_hint[target_crop ? 1 : 0] = std::min(std::max(h->h_state->iterations + 3, 4), 12);  // iterations + 2 launches were needed
-    if (h->h_state->iterations > 0) {
-      h->first_update[target_crop ? 1 : 0][0] = h->h_state->first_w;
-      h->first_update[target_crop ? 1 : 0][1] = h->h_state->first_t;
-    }
     if (d_stats) {
       std::vector<unsigned long long> t((size_t)4 * total);
       (void)hipMemcpy(t.data(), d_stats, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
       (void)hipFree(d_stats);
-      fprintf(stderr, "icp stats (n_src %zu, crop %d, pass-0 margin from w %.2e t %.2e, first update w %.2e t %.2e):", (size_t)a.count, target_crop ? 1 : 0,
-              fa.pass.p0_w, fa.pass.p0_t, h->h_state->first_w, h->h_state->first_t);
+      fprintf(stderr, "icp stats (n_src %zu):", (size_t)a.count);
       for (int k = 0; k < j; ++k) fprintf(stderr, " [%d v%llu s%llu k%llu f%llu]", k, t[4 * k], t[4 * k + 1], t[4 * k + 2], t[4 * k + 3]);
       fprintf(stderr, "\n");
     }

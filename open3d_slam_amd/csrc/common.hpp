@@ -146,8 +146,6 @@ struct IcpStateDev {
   int done;
   int converged;
   int error;  // 1: a workgroup of the persistent loop kernel timed out at the grid rendezvous (never expected)
-  float first_w, first_t;  // |R - I|_F and |t| of the registration's FIRST update: the next registration on the handle sizes the candidate-set
-                           // margin of its pass 0 from them (a stream's priors are about as good from one frame to the next)
   int pad;  // the pivot order of the last 6x6 solve (icp_kernels.hpp solve6_wave_ordered): bit 31 valid, 3 bits per position
 };
 

@@ -438,45 +438,32 @@ __device__ __forceinline__ NNBest<P4> nn_search_group(const GridDev& g, const P4
                                                       typename Scalar<P4>::type qy, typename Scalar<P4>::type qz, int kmax,
                                                       const CropDev& crop, int gl, int2* seg /* this group's kSegMax entries */,
                                                       NNBest<P4> best, typename Scalar<P4>::type m,
-                                                      const Collect<typename Scalar<P4>::type>& col_in, bool* resolved, int* kdone,
-                                                      typename Scalar<P4>::type r2_first = 0 /* see stage 1 */) {
-  using R = typename Scalar<P4>::type;
-  Collect<R> col = col_in;
+                                                      const Collect<typename Scalar<P4>::type>& col, bool* resolved, int* kdone) {
   const QueryCell c = locate(g, (double)qx, (double)qy, (double)qz);
   const int* __restrict__ cs = g.cell_start;
   // ---- one batch, issued before the bound is even computed: the 4 cell_start values of each of this lane's rows of the 3x3
   // cross-section (fetching only the rows in reach, after the bound, measured slower: the ALU chain delays the loads)
   const int xlo = max(c.ix - 1, 0), xhi = min(c.ix + 1, g.nx - 1);
   constexpr int kOwn = (9 + G - 1) / G;
-  // ---- stage 1: the 3x3x3 block, trimmed by the bound.
-  // A search WITHOUT a bound (pass 0: best = {r^2, none}) looks twice: first into the small ball of squared radius r2_first (a good
-  // prior puts nearly every neighbour there; a trimmed block is a quarter of the 27 cells), then -- unless a point inside that ball was
-  // found and nothing is to be listed -- from whatever the first look found.  With a candidate-set margin the second look is also where
-  // the list is made: against the bound the first look found, not against r (which would list everything).
-  bool first_look = best.pos == -1 && r2_first > (R)0 && r2_first < best.d2;
-  if (first_look) col.tau2 = (R)0;
-  for (;;) {  // (uniform per group)
-    // (the cell_start values are fetched per look -- the second look's hit the cache: kept across the first look's scan they are twelve
-    // registers the scan does not have; the lane id is made opaque so that the loads are not hoisted back out of the loop)
-    int gl_l = gl;
-    asm volatile("" : "+v"(gl_l));
-    int v[kOwn][4];
-    bool rv[kOwn];
+  int v[kOwn][4];
+  bool rv[kOwn];
 #pragma unroll
-    for (int k = 0; k < kOwn; ++k) {
-      const int r = gl_l + k * G;
-      const int y = c.iy + (r % 3) - 1, z = c.iz + (r / 3) - 1;
-      rv[k] = r < 9 && xlo <= xhi && (unsigned)y < (unsigned)g.ny && (unsigned)z < (unsigned)g.nz;
-      const int row = rv[k] ? (z * g.ny + y) * g.nx : 0;
+  for (int k = 0; k < kOwn; ++k) {
+    const int r = gl + k * G;
+    const int y = c.iy + (r % 3) - 1, z = c.iz + (r / 3) - 1;
+    rv[k] = r < 9 && xlo <= xhi && (unsigned)y < (unsigned)g.ny && (unsigned)z < (unsigned)g.nz;
+    const int row = rv[k] ? (z * g.ny + y) * g.nx : 0;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[k][j] = rv[k] ? cs[row + min(xlo + j, xhi + 1)] : 0;
-    }
-    const float b2 = first_look ? bound_cells2(r2_first, (R)0, g) : bound_cells2(best.d2, m, g);
+    for (int j = 0; j < 4; ++j) v[k][j] = rv[k] ? cs[row + min(xlo + j, xhi + 1)] : 0;
+  }
+  // ---- stage 1: the 3x3x3 block, trimmed by the bound
+  {
+    const float b2 = bound_cells2(best.d2, m, g);
     int ss[kOwn], ee[kOwn];
     int cnt = 0;
 #pragma unroll
     for (int k = 0; k < kOwn; ++k) {
-      const int r = gl_l + k * G;
+      const int r = gl + k * G;
       const float ddy = slab_dist((r % 3) - 1, c.uy), ddz = slab_dist((r / 3) - 1, c.uz);
       int xa, xb;
       ss[k] = ee[k] = 0;
@@ -501,16 +488,8 @@ __device__ __forceinline__ NNBest<P4> nn_search_group(const GridDev& g, const P4
       const int2 se = seg[t];
       scan_strided<P4, kCrop, kCollect>(tp, se.x, se.y, gl, G, qx, qy, qz, crop, best, col);
     }
-    lds_wave_sync();  // the list is rewritten by the second look and by stage 2
+    lds_wave_sync();  // the list is rewritten by stage 2
     lanes_min<P4, G>(best);
-    if (!first_look) break;
-    first_look = false;
-    const bool listing = kCollect && col_in.tau2 > (R)0 && best.pos != -1;
-    if (best.pos != -1 && best.d2 <= r2_first && !listing) break;  // inside the small ball: nothing outside it is nearer
-    if (listing) {
-      const R tau = (R)sqrt(best.d2) + m;
-      col.tau2 = tau * tau;
-    }
   }
   // proven exact if nothing outside the scanned block can be nearer: best <= (cell * (k + face distance))^2, tested with margin
   // (with a candidate-set margin: if the ball of best + m lies inside the block)
@@ -687,8 +666,6 @@ struct IcpPassArgs {
   int* set_pos;
   void* set_ref;
   float set_gain, set_min, set_cap;  // margin m = gain * (|R - I|_F |p| + |t|) of the last update, at least set_min; above set_cap: no set
-  double r2_first;                   // squared radius of the small ball a search without a bound looks into first (0: off)
-  float p0_w, p0_t;                  // the "last update" pass 0 assumes (the previous registration's first update); p0_w < 0: pass 0 leaves no sets
   unsigned long long* stats;  // null, or per-launch counters [launch][4]: verified matches, searches, sets left behind, stage-3 queries (O3DS_ICP_STATS)
 };
 
@@ -1042,15 +1019,13 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
             }
           }
           Collect<R> col;
+          col.tau2 = tau2;
           col.cnt = my_set;
           col.list = my_set + 1;
-          col.tau2 = tau2;  // (a search without a bound lists on its second look, against what the first one found: nn_search_group)
           // (the lane's row offsets are recomputed per batch: hoisted out of the batch loop they cost a dozen registers, i.e. spills)
           int gl_b = gl;
           asm volatile("" : "+v"(gl_b));
-          nn = nn_search_group<P4, kCrop, kGroup, kCollect>(a.grid, tp, qx, qy, qz, a.kmax, a.crop, gl_b, s_seg + ql * kSegMax, best, m, col, &resolved, &kdone,
-                                                            (R)a.r2_first);
-          if (!use_cache && (!resolved || nn.pos == -1)) m = (R)0, tau2 = (R)0;  // pass 0: no set for a query stage 3 still has to serve, or without a match
+          nn = nn_search_group<P4, kCrop, kGroup, kCollect>(a.grid, tp, qx, qy, qz, a.kmax, a.crop, gl_b, s_seg + ql * kSegMax, best, m, col, &resolved, &kdone);
           if (!resolved && gl == 0) {  // park the query for stage 3 (its record slot is still unused)
             FarItem<P4>* mine_item = (FarItem<P4>*)(s_rec_flat + ql * kStride);
             mine_item->x = qx;
@@ -1924,7 +1899,7 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
     const double tl = __shfl_down(t, 32, 64);
     if (threadIdx.x < kRec) s_out[threadIdx.x] = t + tl;  // the one rounding, as in reduce_partials
   }
-  if (threadIdx.x < 2) s_margin[threadIdx.x] = threadIdx.x == 0 ? (first ? fa.pass.p0_w : -1.0f) : (first ? fa.pass.p0_t : 0.0f);
+  if (threadIdx.x < 2) s_margin[threadIdx.x] = threadIdx.x == 0 ? -1.0f : 0.0f;
   if (threadIdx.x < kRec) s_qhi[threadIdx.x] = q_hi_mine;
   lds_barrier();
   if (s_st.done) {  // loop already terminated: hand the final state on
@@ -1941,10 +1916,6 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
     lds_barrier();
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (!first && s_st.pass == 1) {  // this launch has just formed the registration's first update
-      s_st.first_w = s_margin[0];
-      s_st.first_t = s_margin[1];
-    }
     *fa.state_out = s_st;
     if (fa.state_host) *fa.state_host = s_st;
   }
