@@ -8,7 +8,7 @@ import numpy as np
 from .cloud_registration import cloudRegistrationFactory
 from .croppers import CroppingVolume, croppingVolumeFactory
 from .parameters import OdometryParameters
-from .pointcloud import PointCloud, random_down_sample
+from .pointcloud import PointCloud, random_down_sample, shared_preprocess
 
 
 class LidarOdometry:
@@ -31,8 +31,7 @@ class LidarOdometry:
 
     def preprocess(self, cloud: PointCloud) -> PointCloud:  # Odometry.cpp:25-30
         # cropper_->crop(in) then voxelize(voxelSize_, cropped) (Odometry.cpp:26-27) as one call, same result bit for bit
-        vox = PointCloud(self.be, self.be.crop_voxel_down_sample(cloud.id, self.cropper_.to_abi(), self.params_.scanProcessing_.voxelSize_))
-        self.cloudRegistration_.estimateNormalsOrCovariancesIfNeeded(vox)
+        vox = shared_preprocess(cloud, self.cropper_.to_abi(), self.params_.scanProcessing_.voxelSize_, self.cloudRegistration_)
         # RandomDownSample(ratio) (Odometry.cpp:29); setDownSampleSeed pins the kept-index lists
         return random_down_sample(vox, self.params_.scanProcessing_.downSamplingRatio_, self._downsample_rng, self._shuffle_at_full_ratio)
 

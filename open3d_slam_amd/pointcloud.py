@@ -3,12 +3,22 @@ Holds an o3ds_cloud id; points_/normals_ download lazily.  Method names follow t
 reference touches on this path (HasNormals, IsEmpty, points_, normals_)."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 
 class PointCloud:
     def __init__(self, be, cid: int, owns: bool = True):
         self.be, self.id, self._owns = be, cid, owns
+        self._refs = 1          # holders of this device cloud (retain / release)
+        self._pre_memo = None   # pre-processed versions of this (raw) scan: shared_preprocess
+
+    def retain(self) -> "PointCloud":
+        """One more holder of the same device cloud: release() frees it when the last one lets go.  (open3d_slam hands its clouds
+        around as shared_ptr; the mirror's explicit release() needs the count spelt out.)"""
+        self._refs += 1
+        return self
 
     @classmethod
     def from_numpy(cls, be, points, normals=None, colors=None) -> "PointCloud":
@@ -64,6 +74,14 @@ class PointCloud:
         return self.be.download(self.id)[1]
 
     def release(self):
+        if self._refs > 1:
+            self._refs -= 1
+            return
+        self._refs = 0
+        if self._pre_memo:
+            memo, self._pre_memo = self._pre_memo, None
+            for c in memo.values():
+                c.release()
         if self._owns and self.id:
             try:
                 self.be.free(self.id)
@@ -94,3 +112,28 @@ def random_down_sample(cloud: "PointCloud", ratio: float, rng=None, shuffle_at_f
     out = PointCloud(cloud.be, cloud.be.select_by_index(cloud.id, keep))
     cloud.release()
     return out
+
+
+SHARE_PREPROCESS = os.environ.get("O3DS_SHARE_PREPROCESS", "1") != "0"
+
+
+def shared_preprocess(raw: "PointCloud", crop_abi, voxel_size: float, cloud_registration) -> "PointCloud":
+    """crop -> voxelize -> estimateNormalsOrCovariancesIfNeeded, the first three lines of BOTH LidarOdometry::preprocess
+    (Odometry.cpp:25-30) and ScanToMapIcp::preprocess (ScanToMapRegistration.cpp:35-40).  The shipped configuration gives the two the
+    same cropping volume, voxel size and normal-estimation parameters (parameter_structure_definitions.lua: both `scan_processing`
+    blocks and the map builder's `scan_cropping` are copies of one table), so on one raw scan they compute the same cloud twice.
+    Here the second caller gets the first caller's cloud: the result is remembered ON the raw scan, keyed by every parameter that
+    enters it, and dies with it.  Each caller holds its own reference (retain / release) and applies its own RandomDownSample
+    afterwards, as in the reference.  O3DS_SHARE_PREPROCESS=0 computes it twice, as the reference does."""
+    key = (bytes(crop_abi) if crop_abi is not None else b"", float(voxel_size), type(cloud_registration).__name__,
+           getattr(cloud_registration, "knnNormalEstimation_", None), getattr(cloud_registration, "maxRadiusNormalEstimation_", None))
+    if SHARE_PREPROCESS and raw._pre_memo and key in raw._pre_memo:
+        return raw._pre_memo[key].retain()
+    be = raw.be
+    vox = PointCloud(be, be.crop_voxel_down_sample(raw.id, crop_abi, voxel_size))
+    cloud_registration.estimateNormalsOrCovariancesIfNeeded(vox)
+    if SHARE_PREPROCESS:
+        if raw._pre_memo is None:
+            raw._pre_memo = {}
+        raw._pre_memo[key] = vox.retain()  # (the memo's own reference, released with the raw scan)
+    return vox

@@ -9,7 +9,7 @@ from .cloud_registration import RegistrationResult, cloudRegistrationFactory
 from .croppers import croppingVolumeFactory
 from .parameters import (CloudRegistrationParameters, CloudRegistrationType, MapperParameters, ScanToMapRegistrationParameters,
                          ScanToMapRegistrationType)
-from .pointcloud import PointCloud, random_down_sample
+from .pointcloud import PointCloud, random_down_sample, shared_preprocess
 
 
 @dataclasses.dataclass
@@ -70,9 +70,9 @@ class ScanToMapIcp(ScanToMapRegistration):  # ScanToMapRegistration.hpp:40-59
         return random_down_sample(cloud, ratio, self._downsample_rng, getattr(self, "_shuffle_at_full_ratio", False))
 
     def preprocess(self, cloud: PointCloud) -> PointCloud:  # ScanToMapRegistration.cpp:35-40
-        be = cloud.be  # mapBuilderCropper_->crop(in) then voxelize(voxelSize_, cropped) (.cpp:36-37) as one call, same result bit for bit
-        voxelized = PointCloud(be, be.crop_voxel_down_sample(cloud.id, self.mapBuilderCropper_.to_abi(), self.params_.scanProcessing_.voxelSize_))
-        self.cloudRegistration.estimateNormalsOrCovariancesIfNeeded(voxelized)
+        # mapBuilderCropper_->crop(in), voxelize(voxelSize_, cropped), estimateNormalsOrCovariancesIfNeeded (.cpp:36-38): the cloud the
+        # odometry has just computed from the same raw scan when the two are configured alike (pointcloud.shared_preprocess)
+        voxelized = shared_preprocess(cloud, self.mapBuilderCropper_.to_abi(), self.params_.scanProcessing_.voxelSize_, self.cloudRegistration)
         return self._random_down_sample(voxelized, self.params_.scanProcessing_.downSamplingRatio_)
 
     def processForScanMatchingAndMerging(self, cloud: PointCloud, mapToRangeSensor) -> ProcessedScans:  # .cpp:42-54
