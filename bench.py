@@ -716,6 +716,20 @@ def main():
                               "what": "the same loop without the stream drains that make the per-stage times exact (after the odometry and after "
                                       "the mapping of every frame): what a consumer that only needs the poses sees; frames 1.. / wall time"}
         be2.close()
+        # the same loop with the odometry's and the mapper's identical pre-processing of a raw scan computed twice, as the reference does
+        # (open3d_slam_amd/pointcloud.py shared_preprocess: by default the second caller gets the first caller's cloud)
+        from open3d_slam_amd import pointcloud as _pc
+        be2 = backend.Backend(local_rank)
+        _pc.SHARE_PREPROCESS = False
+        try:
+            twice = run_stream(be2, scans32)
+        finally:
+            _pc.SHARE_PREPROCESS = True
+        m2["shared_preprocess"] = {"what": "LidarOdometry::preprocess and ScanToMapIcp::preprocess run the same crop -> voxelize -> normals on the same raw "
+                                           "scan when configured alike (the shipped configuration); the host mirror computes it once per scan",
+                                   "scans_per_sec_when_computed_twice": twice["scans_per_sec"],
+                                   "pose_equals_bitwise": bool(np.array_equal(twice["pose"], m2["pose"]))}
+        be2.close()
         be2 = backend.Backend(local_rank)
         prof = run_stream(be2, scans32, profile=True)
         be2.close()
