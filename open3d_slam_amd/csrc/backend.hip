@@ -2256,7 +2256,10 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
           unsigned long long *ka = xk2, *kb = xk;  // the tile sort reads xk / xv and writes the second pair of buffers; passes ping-pong
           uint32_t *va = xv2, *vb = xv;
           sort_tile_kernel<<<(unsigned int)((nx + kSortTile - 1) / kSortTile), kBlock, 0, h->stream>>>(xk, xv, nx, ka, va);
-          static const int ways = getenv("O3DS_SORT_WAYS") ? atoi(getenv("O3DS_SORT_WAYS")) : kSortWays;  // tuning experiments: 2, 4, 8, 16
+          static const int ways = [] {  // tuning experiments: 2, 4, 8 or 16 runs merged per pass; anything else is ignored (a width that
+            const int w = getenv("O3DS_SORT_WAYS") ? atoi(getenv("O3DS_SORT_WAYS")) : kSortWays;  // grows by 3 under an 8-way kernel sorts wrongly)
+            return (w == 2 || w == 4 || w == 8 || w == 16) ? w : kSortWays;
+          }();
           for (size_t width = kSortTile; width < nx; width *= (size_t)ways) {  // nx < 2^31 on this path
             const unsigned int gsz = (unsigned int)grid_for(nx);
             if (ways == 2)

@@ -15,7 +15,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(HERE, "_ref", "libo3dslam_ref.so")
+LIB = os.environ.get("O3DS_REF_LIB") or os.path.join(HERE, "_ref", "libo3dslam_ref.so")  # (the override: the same units built with other flags, tests/test_oracle_vs_reference.py)
 # the same units with integration/open3d_slam_o3ds.patch applied, linked against the HIP backend: needs a GPU to run
 LIB_PATCHED = os.path.join(HERE, "_ref", "libo3dslam_ref_patched.so")
 REFERENCE = os.environ.get("O3DS_REFERENCE_DIR", "/root/reference")

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from oracle import ref  # noqa: E402
 
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_units.npz")
+OUT = os.environ.get("O3DS_REF_GOLDEN_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_units.npz")
 
 
 def f32(a):

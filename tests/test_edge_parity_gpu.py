@@ -141,7 +141,9 @@ def _neighbourhoods(stored, radius, knn):
     near_r = (np.abs(d2 - r2) <= eps * r2).any(axis=1)
     # boundary at the knn-th place: the (knn+1)-th candidate (if inside) is clearly farther than the knn-th
     last, nxt = d2[:, knn - 1], d2[:, knn]
-    tie = inside[:, knn] & (nxt - last <= eps * nxt)
+    both = np.isfinite(last) & np.isfinite(nxt)  # (inf - inf is not a comparison: a missing candidate is no tie)
+    gap = np.where(both, np.where(both, nxt, 1.0) - np.where(both, last, 0.0), np.inf)
+    tie = inside[:, knn] & both & (gap <= eps * np.where(both, nxt, 1.0))
     return j[:, :knn], inside[:, :knn], count, ~(near_r | tie)
 
 

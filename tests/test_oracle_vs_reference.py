@@ -379,3 +379,51 @@ def test_the_eigen_stand_in_checks_itself(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def _golden_with_flags(tmp_path, tag, flags):
+    """the reference's units rebuilt with other compiler flags into a scratch directory, the golden generator run against that library"""
+    import subprocess
+    import sys
+
+    out = tmp_path / tag
+    out.mkdir()
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    r = subprocess.run(["make", "-j", "8", "-C", os.path.join(root, "oracle", "ref_build"), f"REF={ref.REFERENCE}", f"OUT={out}", f"CXXFLAGS={flags}",
+                        f"{out}/libo3dslam_ref.so"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    npz = out / "units.npz"
+    env = dict(os.environ, O3DS_REF_LIB=str(out / "libo3dslam_ref.so"), O3DS_REF_GOLDEN_OUT=str(npz),
+               LD_LIBRARY_PATH=os.path.join(root, "oracle") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))  # (libo3d_oracle.so: the scratch library's rpath points elsewhere)
+    r = subprocess.run([sys.executable, os.path.join(here, "golden", "make_ref_golden.py")], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return np.load(npz)
+
+
+@pytest.mark.skipif(not ref.sources_present(), reason="needs the reference checkout")
+def test_reference_fixtures_do_not_depend_on_the_optimisation_level_and_what_fma_would_move(tmp_path):
+    """The committed fixtures (tests/golden/ref_units.npz) come from the reference's units built -O2 -ffp-contract=off.  The reference
+    itself builds -O3 without -march (open3d_slam/CMakeLists.txt:6): rebuilt that way, every array is IDENTICAL.  Rebuilt with fused
+    multiply-add allowed (-O3 -mfma -ffp-contract=fast, which the reference's build does not do), what moves is reported: only
+    floating-point values (voxel means, transformed points), by rounding; every index, count, key and kept / carved set stays put.  This
+    bounds the caveat of the stand-in Eigen (oracle/ref_build/README.md): the bit-for-bit claims concern comparisons, index formation,
+    ordering and NaN handling, and those do not move with the flags."""
+    base = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_units.npz"))
+    shim = "-std=c++17 -fPIC -w -Ishim -I" + os.path.join(ref.REFERENCE, "open3d_slam", "open3d_slam", "include")
+    o3 = _golden_with_flags(tmp_path, "o3", "-O3 " + shim)
+    assert sorted(o3.files) == sorted(base.files)
+    for k in base.files:
+        np.testing.assert_array_equal(o3[k], base[k], err_msg=k)
+    fma = _golden_with_flags(tmp_path, "fma", "-O3 -mfma -ffp-contract=fast " + shim)
+    moved = []
+    for k in base.files:
+        a, b = base[k], fma[k]
+        assert a.shape == b.shape, k  # no point changes side of a volume, no voxel gains or loses a member
+        if not np.array_equal(a, b, equal_nan=True):
+            assert np.issubdtype(a.dtype, np.floating), k  # integers (indices, keys, counts) never move
+            with np.errstate(invalid="ignore"):
+                err = np.nanmax(np.abs(a - b) / np.maximum(np.abs(a), 1e-300))
+            moved.append((k, float(err)))
+            assert err < 1e-13, (k, err)
+    print("arrays that move when fused multiply-add is allowed:", moved)
