@@ -781,12 +781,19 @@ def main():
         dt_gt, dr_gt = syn.se3_error(res["transformation"], T_gt)
 
         # counter-based traffic per launch: measured under rocprofv3 --pmc in separate passes (scripts/gpu_pmc_traffic.sh), calibrated against
-        # known byte counts in this kernel's access pattern (scripts/pmc_calib.hip), committed as profiles/r03_pmc_traffic.json -- a profiler
+        # known byte counts in this kernel's access pattern (scripts/pmc_calib.hip), committed as profiles/r04_pmc_traffic.json -- a profiler
         # cannot run inside this process, so the line quotes the committed measurement of the same command and names it
+        # (quoted only while the kernel source is the one it was measured on: the file carries the hash of icp_kernels.hpp)
+        TRAFFIC_FILE = "profiles/r04_pmc_traffic.json"
         try:
-            traffic_db = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))["kernels"]
+            import hashlib
+
+            tdoc = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
+            now = hashlib.sha256(open(os.path.join(ROOT, "open3d_slam_amd", "csrc", "icp_kernels.hpp"), "rb").read()).hexdigest()[:16]
+            traffic_db = tdoc["kernels"] if tdoc.get("kernel_source_sha16", {}).get("icp_kernels.hpp") == now else {}
+            stream_traffic = tdoc.get("stream_kernels", {})
         except (OSError, ValueError, KeyError):
-            traffic_db = {}
+            traffic_db, stream_traffic = {}, {}
 
         def roof(r, which="icp_fused_kernel<P4f> configs[1] (1 M-point map)"):
             t = traffic_db.get(which) if pass_kernel == "icp_fused_kernel" and world == 1 else None
@@ -796,7 +803,7 @@ def main():
                         "what": "bytes per launch between L2 and the fabric (Infinity Cache + HBM; the counters cannot separate them): TCC_EA0_RDREQ x 64 B + "
                                 "TCC_EA0_WRREQ x 64 B, means over the pass launches; the upper figure takes every read request as a full 128-B line",
                         "upper": t["traffic_bytes_per_launch_if_every_read_is_a_full_line"], "over_algorithmic": t["traffic_over_algorithmic"],
-                        "over_compulsory": t["traffic_over_compulsory"], "source": "profiles/r03_pmc_traffic.json (" + which + ")"},
+                        "over_compulsory": t["traffic_over_compulsory"], "source": TRAFFIC_FILE + " (" + which + ")"},
                     "kernel": pass_kernel, "launches": r["n_launch"], "avg_launch_us": r["avg_kernel_s"] * 1e6,
                     "algorithmic_bytes_per_launch": algo_bytes, "measured_copy_gbs": copy_gbs,
                     "frac_of_measured_copy": r["gbs"] / copy_gbs if copy_gbs else None}
@@ -852,6 +859,23 @@ def main():
             out["scans_per_sec"] = {"workload": f"configs[2]: OS-128-like stream, {len(scans32[0])} raw float32 points/scan, {args.m2_frames} frames, "
                                                 "LidarOdometry::addRangeScan + Mapper::addRangeMeasurement through the host classes (voxel 0.1, knn 20 / r 3, "
                                                 "default ICP criteria, map voxel 0.1); upload included", **m2}
+            if stream_traffic:
+                # counter-based bytes per launch of the stream's kernels (same file, same calibration as roofline.traffic), and on the rows
+                # of the per-call table that are one or two kernels
+                kt = {k: {"traffic": v["traffic_bytes_per_launch"], "upper": v["traffic_bytes_per_launch_if_every_read_is_a_full_line"], "launches": v["launches"]}
+                      for k, v in stream_traffic.items()}
+                out["scans_per_sec"]["kernel_traffic"] = {"source": TRAFFIC_FILE + " (stream_kernels)", "bytes_per_launch": kt}
+                calls_ = out["scans_per_sec"].get("calls") or {}
+
+                def tsum(*pats):
+                    vals = [v["traffic"] for k, v in kt.items() if any(p_ in k for p_ in pats)]
+                    return sum(vals) if vals else None
+                for row_name, pats in (("normals kernels alone", ("normals_kernel", "normals_finish_kernel")),
+                                       ("crop + VoxelDownSample", ("bbox_kernel", "bbox_final", "vox_insert", "vox_number", "vox_gather", "vox_mean", "VoxFirstFlag")),
+                                       ("index build kernels (every build of the stream)", ("cell_count_kernel", "scatter_kernel"))):
+                    if row_name in calls_ and calls_[row_name]:
+                        calls_[row_name]["traffic"] = tsum(*pats)
+                        calls_[row_name]["traffic_what"] = "sum over one launch each of: " + ", ".join(pats) + " (scans excluded)"
         cres, best_t = None, min(32, os.cpu_count() or 1)
         if world == 1 and not args.no_cpu_baseline:
             cb, cres, best_t = cpu_baseline_m1(src, tgt, nrm, args.cpu_budget)

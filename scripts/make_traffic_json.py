@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""profiles/r03_pmc_traffic.json from the per-dispatch counter rows of scripts/gpu_pmc_traffic.sh (gpurun_out/pmc_traffic/m1_{dram,wr}):
+"""profiles/r04_pmc_traffic.json (or the path given as argument) from the per-dispatch counter rows of scripts/gpu_pmc_traffic.sh (gpurun_out/pmc_traffic/m1_{dram,wr}):
 what bench.py quotes as roofline.traffic.  The calibration behind the byte-per-request figures is profiles/r03_pmc_calibration*.txt."""
-import collections, csv, glob, json, os, sys
+import collections, csv, glob, hashlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {"source": "rocprofv3 --kernel-trace --pmc, one counter set per run, `python bench.py --steps 20 --warmup 3 --m2-frames 0 --no-cpu-baseline --concurrent 0` "
                  "(scripts/gpu_pmc_traffic.sh); per-launch means over the pass launches (the one-workgroup tail launches of the fused loop dropped)",
@@ -14,8 +14,15 @@ out = {"source": "rocprofv3 --kernel-trace --pmc, one counter set per run, `pyth
                        "infinity_cache": "cold and warm dispatches give identical counts at 32 MiB, 128 MiB and 1 GiB working sets, and TCC_EA0_RDREQ_DRAM equals TCC_EA0_RDREQ "
                                          "everywhere: the counters sit at the L2 <-> fabric boundary, Infinity-Cache hits are included and cannot be separated from HBM reads"},
        "kernels": {}}
-def rows(setname, pat):
-    f = glob.glob(os.path.join(ROOT, f"gpurun_out/pmc_traffic/m1_{setname}/**/*counter_collection.csv"), recursive=True)[0]
+def src_hash(*names):
+    h = hashlib.sha256()
+    for n in names:
+        h.update(open(os.path.join(ROOT, "open3d_slam_amd", "csrc", n), "rb").read())
+    return h.hexdigest()[:16]
+# the figures belong to the kernel sources they were measured on: bench.py quotes them only while the hash still matches
+out["kernel_source_sha16"] = {"icp_kernels.hpp": src_hash("icp_kernels.hpp"), "stream (cloud_kernels.hpp + normals_kernel.hpp)": src_hash("cloud_kernels.hpp", "normals_kernel.hpp")}
+def rows(setname, pat, run="m1"):
+    f = glob.glob(os.path.join(ROOT, f"gpurun_out/pmc_traffic/{run}_{setname}/**/*counter_collection.csv"), recursive=True)[0]
     by = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if pat in r["Kernel_Name"]:
@@ -36,5 +43,28 @@ for name, pat, sl in (("icp_fused_kernel<P4f> configs[1] (1 M-point map)", "icp_
                             "traffic_bytes_per_launch": lo, "traffic_bytes_per_launch_if_every_read_is_a_full_line": hi,
                             "algorithmic_bytes_per_launch": ALGO, "traffic_over_algorithmic": [lo / ALGO, hi / ALGO],
                             "compulsory_bytes_per_launch": 65536 * 48, "traffic_over_compulsory": [lo / (65536 * 48), hi / (65536 * 48)]}
-json.dump(out, open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json"), "w"), indent=1)
+# ---- the kernels of a configs[2] frame (scripts/stream_few_frames.py under the same two counter sets): per-launch means by kernel
+out["stream_kernels"] = {}
+try:
+    def all_rows(setname):
+        f = glob.glob(os.path.join(ROOT, f"gpurun_out/pmc_traffic/stream_{setname}/**/*counter_collection.csv"), recursive=True)[0]
+        by = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].replace("void ", "").replace("o3ds::", "").split("(")[0][:60]
+            by[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        return by
+    rd_by, wr_by = all_rows("dram"), all_rows("wr")
+    for k in sorted(rd_by):
+        if "rocprim" in k or "rocclr" in k or k not in wr_by:
+            continue
+        rd, wr = rd_by[k].get("TCC_EA0_RDREQ_sum", []), wr_by[k].get("TCC_EA0_WRREQ_sum", [])
+        if not rd or not wr:
+            continue
+        mr, mw = sum(rd) / len(rd), sum(wr) / len(wr)
+        out["stream_kernels"][k] = {"launches": len(rd), "read_requests_per_launch": mr, "write_requests_per_launch": mw,
+                                    "traffic_bytes_per_launch": mr * 64 + mw * 64, "traffic_bytes_per_launch_if_every_read_is_a_full_line": mr * 128 + mw * 64}
+except Exception as e:  # the stream sets are optional
+    out["stream_kernels_error"] = repr(e)
+dst = sys.argv[1] if len(sys.argv) > 1 else os.path.join("profiles", "r04_pmc_traffic.json")
+json.dump(out, open(os.path.join(ROOT, dst), "w"), indent=1)
 print(json.dumps(out["kernels"], indent=1))
