@@ -67,11 +67,19 @@ class LidarOdometry:
         return True
 
     def getOdomToRangeSensor(self, t: float) -> np.ndarray:
-        """exact-stamp lookup (the reference interpolates in TransformInterpolationBuffer; the harness feeds exact stamps)"""
+        """exact-stamp lookup (the reference interpolates in TransformInterpolationBuffer; the harness feeds exact stamps).  The stamps
+        asked for are the newest ones: looked for from the back (a scan of the whole buffer per call grew with the stream)."""
         for ts, T in reversed(self.odomToRangeSensorBuffer_):
             if ts == t:
                 return T
+            if ts < t:
+                break  # stamps ascend
         raise RuntimeError("odomToRangeSensorBuffer_ does not have the desired transform")
 
     def hasTransform(self, t: float) -> bool:
-        return any(ts == t for ts, _ in self.odomToRangeSensorBuffer_)
+        for ts, _ in reversed(self.odomToRangeSensorBuffer_):
+            if ts == t:
+                return True
+            if ts < t:
+                break
+        return False
