@@ -304,6 +304,34 @@ inline std::shared_ptr<PointCloud> adopt(const std::shared_ptr<HandleBox>& box, 
 }
 // ScanToMapIcp::preprocess (ScanToMapRegistration.cpp:35-40) and LidarOdometry::preprocess (Odometry.cpp:25-30):
 //   cropper->crop(in); voxelize(voxelSize, cropped); estimateNormalsOrCovariancesIfNeeded(cropped); cropped->RandomDownSample(ratio)
+// LidarOdometry::preprocess (Odometry.cpp:25-30) and ScanToMapIcp::preprocess (ScanToMapRegistration.cpp:35-40) run the same chain on
+// the same raw scan, and the shipped configuration gives them the same parameters (parameter_structure_definitions.lua: both
+// `scan_processing` blocks and the map builder's `scan_cropping` are copies of one table).  Without random down-sampling (ratio >= 1) the
+// second caller therefore gets the first caller's cloud -- the same object, read-only for both as in the patched flow (the odometry copies
+// it into cloudPrev_, the mapper crops / registers / inserts it), with its device copy (a caller on another handle copies it device to
+// device, DeviceCloud).  The memo holds ONE entry weakly: it lives as long as a caller still holds the cloud (the odometry does until
+// the next scan).  The key is the raw scan's size and fingerprint (64 sampled points) and every parameter of the chain.
+// O3DS_SHARE_PREPROCESS=0 computes it twice, as the reference does.
+struct PreprocessMemo {
+  std::mutex m;
+  uint64_t stamp = 0;
+  size_t n = 0;
+  ScanChain chain{};
+  std::weak_ptr<PointCloud> result;
+};
+inline PreprocessMemo& preprocessMemo() {
+  static PreprocessMemo memo;
+  return memo;
+}
+inline bool sameChain(const ScanChain& a, const ScanChain& b) {
+  return std::memcmp(&a.crop, &b.crop, sizeof(o3ds_crop)) == 0 && a.voxelSize == b.voxelSize && a.estimateNormals == b.estimateNormals &&
+         a.normalRadius == b.normalRadius && a.normalKnn == b.normalKnn && a.downSamplingRatio == b.downSamplingRatio;
+}
+inline bool sharePreprocess() {
+  static const bool on = !(std::getenv("O3DS_SHARE_PREPROCESS") && std::atoi(std::getenv("O3DS_SHARE_PREPROCESS")) == 0);
+  return on;
+}
+
 // One upload of the raw scan, the chain on the device, one download; the result stays on the device behind the returned cloud.
 // With ratio >= 1 Open3D's RandomDownSample returns a permutation of the cloud; here the cloud keeps its order (same points, only
 // summation orders downstream differ), which saves a 60 k-element host shuffle per scan.
@@ -318,6 +346,15 @@ inline std::shared_ptr<PointCloud> preprocessScan(const PointCloud& raw, const S
   std::lock_guard<std::recursive_mutex> lck(box->m);
   const o3ds_handle h = box->h.get();
   if (raw.points_.empty()) return std::make_shared<PointCloud>();
+  const bool share = sharePreprocess() && p.downSamplingRatio >= 1.0;
+  uint64_t stamp = 0;
+  if (share) {
+    stamp = fingerprint(raw);
+    PreprocessMemo& memo = preprocessMemo();
+    std::lock_guard<std::mutex> ml(memo.m);
+    if (memo.stamp == stamp && memo.n == raw.points_.size() && sameChain(memo.chain, p))
+      if (std::shared_ptr<PointCloud> r = memo.result.lock()) return r;
+  }
   DeviceCloud in(h, box.get(), raw);
   o3ds_cloud cur = 0;
   check(h, o3ds_crop_voxel_down_sample(h, in.id(), &p.crop, p.voxelSize, &cur));
@@ -335,9 +372,19 @@ inline std::shared_ptr<PointCloud> preprocessScan(const PointCloud& raw, const S
       o3ds_cloud_free(h, cur);
       cur = kept;
     }
-    return adopt(box, cur);
+    std::shared_ptr<PointCloud> out = adopt(box, cur);
+    cur = 0;  // (adopted)
+    if (share) {
+      PreprocessMemo& memo = preprocessMemo();
+      std::lock_guard<std::mutex> ml(memo.m);
+      memo.stamp = stamp;
+      memo.n = raw.points_.size();
+      memo.chain = p;
+      memo.result = out;
+    }
+    return out;
   } catch (...) {
-    o3ds_cloud_free(h, cur);
+    if (cur) o3ds_cloud_free(h, cur);
     throw;
   }
 }

@@ -172,6 +172,26 @@ int main(int argc, char** argv) {
     CHECK(pre->points_.size() > 1000 && pre->points_.size() < raw.points_.size() && pre->HasNormals());
     CHECK(dynamic_cast<o3ds::ScanOnDevice*>(pre.get()) != nullptr);
     CHECK(o3ds::deviceCopyOf(*pre) != nullptr);
+    // the second caller of the same chain on (a copy of) the same raw scan -- the mapper after the odometry -- gets the first caller's
+    // cloud, also from another thread; another parameter, another scan or random down-sampling compute their own
+    {
+      const PointCloud rawCopy = raw;
+      CHECK(o3ds::preprocessScan(rawCopy, chain).get() == pre.get());
+      std::shared_ptr<PointCloud> fromThread;
+      std::thread([&] { fromThread = o3ds::preprocessScan(rawCopy, chain); }).join();
+      CHECK(fromThread.get() == pre.get());
+      o3ds::ScanChain other = chain;
+      other.voxelSize = 0.11;
+      std::shared_ptr<PointCloud> coarser = o3ds::preprocessScan(rawCopy, other);
+      CHECK(coarser.get() != pre.get() && coarser->points_.size() < pre->points_.size());
+      PointCloud moved = raw;
+      for (auto& q : moved.points_) q[0] += 0.5;
+      CHECK(o3ds::preprocessScan(moved, other).get() != coarser.get());
+      std::shared_ptr<PointCloud> recomputed = o3ds::preprocessScan(rawCopy, chain);  // the memo holds one entry: computed again, same values
+      CHECK(recomputed.get() != pre.get() && recomputed->points_.size() == pre->points_.size());
+      for (size_t i = 0; i < pre->points_.size(); ++i)
+        for (int a = 0; a < 3; ++a) CHECK(recomputed->points_[i][a] == pre->points_[i][a] && recomputed->normals_[i][a] == pre->normals_[i][a]);
+    }
     // the same chain seam by seam on host clouds (what round 2's patch left to the CPU, here through the stateless calls)
     const PointCloud plain = *pre;  // sliced: an ordinary host cloud, no device copy
     CHECK(o3ds::deviceCopyOf(plain) == nullptr);
