@@ -2425,12 +2425,12 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn, bool knn_ra
     const P4* p_pts = (const P4*)c.pts;
     const P4* p_sp = (const P4*)tmp.spts;
     P4* p_out = (P4*)c.nrm;
-    const unsigned int gsz = (unsigned int)((c.n + 15) / 16);
+    const unsigned int gsz = (unsigned int)((c.n + o3ds::kNrmPointsPerBlock - 1) / o3ds::kNrmPointsPerBlock);
 #ifdef O3DS_NRM_CHECK
     unsigned long long* d_ws = nullptr;
     if (getenv("O3DS_NRM_STATS_FILE")) {
-      HIP_TRY(hipMalloc((void**)&d_ws, sizeof(unsigned long long) * o3ds::kNrmStatWords * 4 * gsz));
-      HIP_TRY(hipMemset(d_ws, 0, sizeof(unsigned long long) * o3ds::kNrmStatWords * 4 * gsz));
+      HIP_TRY(hipMalloc((void**)&d_ws, sizeof(unsigned long long) * o3ds::kNrmStatWords * o3ds::kNrmWaves * gsz));
+      HIP_TRY(hipMemset(d_ws, 0, sizeof(unsigned long long) * o3ds::kNrmStatWords * o3ds::kNrmWaves * gsz));
     }
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(o3ds::g_nrm_wave_stats), &d_ws, sizeof(d_ws)));
 #endif
@@ -2440,9 +2440,9 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn, bool knn_ra
     TMP_ALLOC(d_cnts, sizeof(int) * c.n);
     span_mark(h, kSpanNormalsKernels);
     if (max_nn <= 32)  // the shipped configs' knn is 20
-      normals_kernel<P4, 32><<<gsz, 256, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, d_sums, d_cnts);
+      normals_kernel<P4, 32><<<gsz, 64 * o3ds::kNrmWaves, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, d_sums, d_cnts);
     else
-      normals_kernel<P4, 128><<<gsz, 256, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, d_sums, d_cnts);
+      normals_kernel<P4, 128><<<gsz, 64 * o3ds::kNrmWaves, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, d_sums, d_cnts);
     // the grid, the cell-ordered points and (written here) the cell-ordered normals are a complete nearest-neighbour index of the cloud:
     // kept, so that a registration against this cloud (scan-to-scan odometry: the previous scan) does not build another one
     if (dev_alloc(h, (void**)&tmp.snrm, sizeof(P4) * c.n) != hipSuccess) {
@@ -2457,11 +2457,11 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn, bool knn_ra
   dbg_sync(h, 16);
 #ifdef O3DS_NRM_CHECK
   if (const char* sf = getenv("O3DS_NRM_STATS_FILE")) {
-    const unsigned int gsz = (unsigned int)((c.n + 15) / 16);
+    const unsigned int gsz = (unsigned int)((c.n + o3ds::kNrmPointsPerBlock - 1) / o3ds::kNrmPointsPerBlock);
     unsigned long long* d_ws = nullptr;
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpyFromSymbol(&d_ws, HIP_SYMBOL(o3ds::g_nrm_wave_stats), sizeof(d_ws)));
-    std::vector<unsigned long long> ws((size_t)o3ds::kNrmStatWords * 4 * gsz);
+    std::vector<unsigned long long> ws((size_t)o3ds::kNrmStatWords * o3ds::kNrmWaves * gsz);
     HIP_TRY(hipMemcpy(ws.data(), d_ws, sizeof(unsigned long long) * ws.size(), hipMemcpyDeviceToHost));
     (void)hipFree(d_ws);
     if (FILE* f = fopen(sf, "wb")) {

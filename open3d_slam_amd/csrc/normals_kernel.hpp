@@ -103,17 +103,23 @@ __device__ __forceinline__ bool nrm_less(unsigned long long ak, int ai, unsigned
     return ak < bk;
 }
 
+#ifndef O3DS_NRM_WAVES
+#define O3DS_NRM_WAVES 1
+#endif
+constexpr int kNrmWaves = O3DS_NRM_WAVES;  // wavefronts per workgroup (they share nothing)
+constexpr int kNrmPointsPerBlock = 4 * kNrmWaves;
+
 template <typename P4, int KMAX>
-__global__ __launch_bounds__(256) void normals_kernel(const P4* __restrict__ pts /* original order */, size_t n, GridDev g,
+__global__ __launch_bounds__(64 * kNrmWaves) void normals_kernel(const P4* __restrict__ pts /* original order */, size_t n, GridDev g,
                                                       const P4* __restrict__ sp /* sorted by cell */, double radius, int max_nn, int rmax_cells,
                                                       double* __restrict__ out_sums /* [n][9], cell order */, int* __restrict__ out_cnt /* [n] */) {
   using R = typename Scalar<P4>::type;
   constexpr bool WIDE = sizeof(P4) > 16;
   constexpr int KPL = (KMAX + 15) / 16;  // kept keys per lane
   constexpr int PW = 4;                  // points per wavefront: one group of 16 lanes each
-  constexpr int PB = 4 * PW;             // points per workgroup (four wavefronts)
+  constexpr int PB = kNrmWaves * PW;     // points per workgroup
   constexpr unsigned long long kNever = ~0ull;  // a key no candidate is smaller than (masks table entries past the end)
-  __shared__ NrmGroupLds<WIDE, KMAX, R> s_grp[16];
+  __shared__ NrmGroupLds<WIDE, KMAX, R> s_grp[4 * kNrmWaves];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l = lane & 15, grp = lane >> 4;
   NrmGroupLds<WIDE, KMAX, R>& L = s_grp[wv * 4 + grp];
   const size_t base = (size_t)blockIdx.x * PB + (size_t)wv * PW;
@@ -151,8 +157,36 @@ __global__ __launch_bounds__(256) void normals_kernel(const P4* __restrict__ pts
     // ... and this lane's cursor: it owns the rows t = l, l + 16, ... of the ring
     int tnext = l;
 
+    // ROUND ONE is the same for every point: the 3 x 3 rows of the block around its cell, one per lane l < 9, each one segment of the sorted
+    // cloud.  Nothing is known yet that could rule a row out (the radius test is part of the key test every candidate takes anyway), so the
+    // f64 row geometry of the general round is not needed, and with one segment per lane the segment table stays in registers: the segment of a
+    // flat candidate number comes from eight DPP row broadcasts and compares, not from a search of the LDS table.
+    bool round1 = true;  // wavefront-uniform
+    int r1_off = 0, r1_base = 0;
+    const int r1_dz = (l * 11 >> 5) - 1, r1_dy = l - 3 * (l * 11 >> 5) - 1;  // l / 3 - 1, l % 3 - 1 for l < 9
+
     O3DS_PH(0);  // set-up
     for (;;) {
+      int T = 0;
+      if (round1) {
+        int s0 = 0, e0 = 0;
+        const int z = iz + r1_dz, y = iy + r1_dy;
+        if (active && l < 9 && (unsigned)z < (unsigned)g.nz && (unsigned)y < (unsigned)g.ny) {
+          const int row = (z * g.ny + y) * g.nx;
+          s0 = cs[row + max(ix - 1, 0)];
+          e0 = cs[row + min(ix + 1, g.nx - 1) + 1];
+        }
+        const int tot = e0 - s0, incl = row_incl_scan(tot);
+        T = row_last(incl);
+        r1_off = incl - tot;
+        r1_base = s0 - r1_off;
+        tnext = ntask;  // the nine rows are taken: the general round starts by moving on to ring 2
+#ifdef O3DS_NRM_CHECK
+        ++st_rounds;
+        st_ring = max(st_ring, 1u);
+#endif
+        O3DS_PH(2);
+      } else {
       // ---- find work: every lane moves to its next row that the current bound does not rule out (arithmetic only: at ring 5-6 of a
       // sparse neighbourhood nearly all of the 100-200 rows are ruled out); when no lane of the group has one left the ring is done.
       // A lane takes up to FOUR rows per round (their cell_start loads are in flight together): a walk to ring 6 of a neighbourhood
@@ -235,7 +269,7 @@ __global__ __launch_bounds__(256) void normals_kernel(const P4* __restrict__ pts
 #pragma unroll
       for (int k = 0; k < 8; ++k) tot += ee[k] - ss[k];
       const int incl = row_incl_scan(tot);
-      const int T = row_last(incl);
+      T = row_last(incl);
       {
         int run = incl - tot;
         int so[8], sb[8];
@@ -254,6 +288,7 @@ __global__ __launch_bounds__(256) void normals_kernel(const P4* __restrict__ pts
       }
       O3DS_WAVE_SYNC();
       O3DS_PH(2);  // row bounds (cell_start loads) + segment table
+      }
 
       for (int f0 = 0; __ballot(f0 < T) != 0ull; f0 += 64) {
         // ---- four candidates per lane (fewer when the round has few left: nslot is wavefront-uniform): flat number -> segment by a
@@ -262,21 +297,34 @@ __global__ __launch_bounds__(256) void normals_kernel(const P4* __restrict__ pts
         ++st_chunks;
 #endif
         const int nslot = __ballot(T - f0 > 48) != 0ull ? 4 : __ballot(T - f0 > 32) != 0ull ? 3 : __ballot(T - f0 > 16) != 0ull ? 2 : 1;
-        int pos[4] = {0, 0, 0, 0};  // last segment whose first candidate number is <= f (empty segments share their successor's)
-#pragma unroll
-        for (int step = 64; step >= 1; step >>= 1) {
-          int v[4] = {0, 0, 0, 0};
-#pragma unroll
-          for (int c = 0; c < 4; ++c)
-            if (c < nslot) v[c] = L.seg_off[pos[c] + step];
-#pragma unroll
-          for (int c = 0; c < 4; ++c)
-            if (c < nslot && v[c] <= f0 + l + 16 * c) pos[c] += step;
-        }
         int sb[4] = {0, 0, 0, 0};
+        if (round1) {  // the last lane m whose first candidate number is <= f (an empty segment shares its successor's number, which wins)
+          const int b0 = __builtin_amdgcn_update_dpp(0, r1_base, 0x150, 0xf, 0xf, false);  // row_newbcast:0
+          sb[0] = sb[1] = sb[2] = sb[3] = b0;
+#define O3DS_R1_STEP(m)                                                                        \
+  {                                                                                            \
+    const int o = __builtin_amdgcn_update_dpp(0, r1_off, 0x150 + (m), 0xf, 0xf, false);        \
+    const int b = __builtin_amdgcn_update_dpp(0, r1_base, 0x150 + (m), 0xf, 0xf, false);       \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) sb[c] = o <= f0 + l + 16 * c ? b : sb[c];   \
+  }
+          O3DS_R1_STEP(1) O3DS_R1_STEP(2) O3DS_R1_STEP(3) O3DS_R1_STEP(4) O3DS_R1_STEP(5) O3DS_R1_STEP(6) O3DS_R1_STEP(7) O3DS_R1_STEP(8)
+#undef O3DS_R1_STEP
+        } else {
+          int pos[4] = {0, 0, 0, 0};  // last segment whose first candidate number is <= f (empty segments share their successor's)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-          if (c < nslot) sb[c] = L.seg_base[pos[c]];
+          for (int step = 64; step >= 1; step >>= 1) {
+            int v[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (c < nslot) v[c] = L.seg_off[pos[c] + step];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (c < nslot && v[c] <= f0 + l + 16 * c) pos[c] += step;
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (c < nslot) sb[c] = L.seg_base[pos[c]];
+        }
         O3DS_PH(3);  // flat number -> segment
         P4 cand[4];
 #pragma unroll
@@ -498,6 +546,7 @@ __global__ __launch_bounds__(256) void normals_kernel(const P4* __restrict__ pts
         O3DS_PH(7);  // ranking + new bound
       }
       O3DS_WAVE_SYNC();  // the segment table is rewritten by the next round
+      round1 = false;
     }
 
     // ---- cumulants over the kept list in its order
@@ -551,7 +600,7 @@ __global__ __launch_bounds__(256) void normals_kernel(const P4* __restrict__ pts
   }
 #ifdef O3DS_NRM_CHECK
   if (g_nrm_wave_stats && lane == 0) {
-    unsigned long long* o = g_nrm_wave_stats + kNrmStatWords * ((size_t)blockIdx.x * 4 + wv);
+    unsigned long long* o = g_nrm_wave_stats + kNrmStatWords * ((size_t)blockIdx.x * kNrmWaves + wv);
     o[0] = wall_clock64() - st_t0, o[1] = st_t0, o[2] = st_rounds, o[3] = st_ring, o[4] = st_chunks, o[5] = 0;
 #ifdef O3DS_NRM_PHASES
     for (int k = 0; k < 10; ++k) o[6 + k] = (unsigned long long)st_ph[k];
