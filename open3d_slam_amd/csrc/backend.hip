@@ -2429,8 +2429,8 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn, bool knn_ra
 #ifdef O3DS_NRM_CHECK
     unsigned long long* d_ws = nullptr;
     if (getenv("O3DS_NRM_STATS_FILE")) {
-      HIP_TRY(hipMalloc((void**)&d_ws, sizeof(unsigned long long) * o3ds::kNrmStatWords * o3ds::kNrmWaves * gsz));
-      HIP_TRY(hipMemset(d_ws, 0, sizeof(unsigned long long) * o3ds::kNrmStatWords * o3ds::kNrmWaves * gsz));
+      HIP_TRY(hipMalloc((void**)&d_ws, sizeof(unsigned long long) * o3ds::kNrmStatWords * ((size_t)o3ds::kNrmWaves * gsz)));
+      HIP_TRY(hipMemset(d_ws, 0, sizeof(unsigned long long) * o3ds::kNrmStatWords * ((size_t)o3ds::kNrmWaves * gsz)));
     }
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(o3ds::g_nrm_wave_stats), &d_ws, sizeof(d_ws)));
 #endif
@@ -2439,9 +2439,12 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn, bool knn_ra
     TMP_ALLOC(d_sums, sizeof(double) * 9 * c.n);
     TMP_ALLOC(d_cnts, sizeof(int) * c.n);
     span_mark(h, kSpanNormalsKernels);
-    if (max_nn <= 32)  // the shipped configs' knn is 20
-      normals_kernel<P4, 32><<<gsz, 64 * o3ds::kNrmWaves, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, d_sums, d_cnts);
-    else
+    if (max_nn <= 32) {  // the shipped configs' knn is 20
+      if constexpr (sizeof(P4) == 16)
+        normals_kernel_occ5<P4, 32><<<gsz, 64 * o3ds::kNrmWaves, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, d_sums, d_cnts);
+      else
+        normals_kernel<P4, 32><<<gsz, 64 * o3ds::kNrmWaves, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, d_sums, d_cnts);
+    } else
       normals_kernel<P4, 128><<<gsz, 64 * o3ds::kNrmWaves, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, d_sums, d_cnts);
     // the grid, the cell-ordered points and (written here) the cell-ordered normals are a complete nearest-neighbour index of the cloud:
     // kept, so that a registration against this cloud (scan-to-scan odometry: the previous scan) does not build another one
@@ -2461,7 +2464,7 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn, bool knn_ra
     unsigned long long* d_ws = nullptr;
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpyFromSymbol(&d_ws, HIP_SYMBOL(o3ds::g_nrm_wave_stats), sizeof(d_ws)));
-    std::vector<unsigned long long> ws((size_t)o3ds::kNrmStatWords * o3ds::kNrmWaves * gsz);
+    std::vector<unsigned long long> ws((size_t)o3ds::kNrmStatWords * ((size_t)o3ds::kNrmWaves * gsz));
     HIP_TRY(hipMemcpy(ws.data(), d_ws, sizeof(unsigned long long) * ws.size(), hipMemcpyDeviceToHost));
     (void)hipFree(d_ws);
     if (FILE* f = fopen(sf, "wb")) {

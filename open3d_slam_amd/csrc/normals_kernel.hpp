@@ -109,10 +109,15 @@ __device__ __forceinline__ bool nrm_less(unsigned long long ak, int ai, unsigned
 constexpr int kNrmWaves = O3DS_NRM_WAVES;  // wavefronts per workgroup (they share nothing)
 constexpr int kNrmPointsPerBlock = 4 * kNrmWaves;
 
+#ifndef O3DS_NRM_REACH_GAIN
+#define O3DS_NRM_REACH_GAIN 1.1f
+#endif
+constexpr float nrm_reach_gain = O3DS_NRM_REACH_GAIN;  // how far beyond the estimate a sweep of a list that is not full yet reaches
+
 template <typename P4, int KMAX>
-__global__ __launch_bounds__(64 * kNrmWaves) void normals_kernel(const P4* __restrict__ pts /* original order */, size_t n, GridDev g,
-                                                      const P4* __restrict__ sp /* sorted by cell */, double radius, int max_nn, int rmax_cells,
-                                                      double* __restrict__ out_sums /* [n][9], cell order */, int* __restrict__ out_cnt /* [n] */) {
+__device__ __forceinline__ void normals_body(const P4* __restrict__ pts /* original order */, size_t n, const GridDev& g,
+                                             const P4* __restrict__ sp /* sorted by cell */, double radius, int max_nn, int rmax_cells,
+                                             double* __restrict__ out_sums /* [n][9], cell order */, int* __restrict__ out_cnt /* [n] */) {
   using R = typename Scalar<P4>::type;
   constexpr bool WIDE = sizeof(P4) > 16;
   constexpr int KPL = (KMAX + 15) / 16;  // kept keys per lane
@@ -123,7 +128,15 @@ __global__ __launch_bounds__(64 * kNrmWaves) void normals_kernel(const P4* __res
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l = lane & 15, grp = lane >> 4;
   NrmGroupLds<WIDE, KMAX, R>& L = s_grp[wv * 4 + grp];
   const size_t base = (size_t)blockIdx.x * PB + (size_t)wv * PW;
-  auto gap = [](int d, double f) { return d > 0 ? (double)d - f : d < 0 ? f - (double)(d + 1) : 0.0; };
+  // Which rows of a ring the current bound still allows is a FILTER: a row let through in vain costs candidates that the exact key test
+  // rejects, a row ruled out wrongly would cost a neighbour.  So the row geometry runs in f32 with every rounding pushed to the side of
+  // letting through (f64 sqrt alone is ~115 cycles a lane on gfx950, scripts/ubench/op_rates.hip): gaps are LOWER bounds of the distance in
+  // cells between the query and a row / cell, `left` and the x-reach UPPER bounds.  Coordinates enter as fractions of the query's own cell
+  // (< 1, so f32 holds them to 3e-8) and small integer offsets, never as absolute cell numbers.
+  auto gap_lo = [](int d, float f) {
+    const float v = d > 0 ? (float)d - f : d < 0 ? f - (float)(d + 1) : 0.0f;
+    return fmaxf(v * (1.0f - 1e-6f) - 1e-7f, 0.0f);
+  };
 
 #ifdef O3DS_NRM_CHECK
   const unsigned long long st_t0 = wall_clock64();
@@ -133,7 +146,8 @@ __global__ __launch_bounds__(64 * kNrmWaves) void normals_kernel(const P4* __res
   long long st_ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = clock64();
 #endif
   const int* __restrict__ cs = g.cell_start;
-  const double cell2 = g.cell * g.cell * (1.0 - 2e-6);
+  const float cell2_lo = (float)(g.cell * g.cell * (1.0 - 4e-6));
+  const float inv_cell_hi = (float)(g.inv_cell * (1.0 + 2e-6));
   // queries are taken in CELL order (sp), so the four points of a wavefront walk the same few cells
   for (int it = 0; it < PW / 4; ++it) {
     const size_t j = base + (size_t)(it * 4 + grp);
@@ -151,7 +165,15 @@ __global__ __launch_bounds__(64 * kNrmWaves) void normals_kernel(const P4* __res
     unsigned long long tau_k = nrm_key(r2, 0);  // accept iff (key, idx) < (tau_k, tau_i): d2 < r^2 until the list is full
     int tau_i = 0;
     double worst = (double)r2;
-    int ring = 1, ntask = 9;  // ring 1 = the whole 3x3x3 block (rings 0 and 1 of a ring-by-ring walk)
+    float worst_hi = (float)worst * (1.0f + 1e-6f);
+    const float frx_f = (float)frx, fry_f = (float)fry, frz_f = (float)frz;
+    // A SWEEP covers the cells of the block of half-width `ring` around the query's cell that are not in the block of half-width `rin`
+    // searched before (-1: nothing yet).  The first sweep is the 3x3x3 block.  How far the next one reaches is a guess that costs or saves
+    // work, never a neighbour: with a full list it is the reach that makes the max_nn-th distance certain, otherwise the reach at which a
+    // surface of the density seen so far holds max_nn points (a walk ring by ring spent a round per ring -- row tests, two dependent memory
+    // round trips, a ranking -- on neighbourhoods that need five of them: the sparse far end of a lidar scan, a sixth of its points and
+    // almost half of this kernel's time).
+    int ring = 1, rin = -1, ntask = 9;
     float inv_w = 1.0f / 3.0f;
     bool active = have;
     // ... and this lane's cursor: it owns the rows t = l, l + 16, ... of the ring
@@ -192,7 +214,7 @@ __global__ __launch_bounds__(64 * kNrmWaves) void normals_kernel(const P4* __res
       // A lane takes up to FOUR rows per round (their cell_start loads are in flight together): a walk to ring 6 of a neighbourhood
       // that never fills its list -- 31 rounds of 16 rows, each a chain of two memory round trips -- becomes 10 rounds.
       int ss[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ee[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      auto next_row = [&](int& row, int& dzf, int& dyf, double& left) -> bool {
+      auto next_row = [&](int& row, int& dzf, int& dyf, float& left) -> bool {
         while (tnext < ntask) {
           const int w = 2 * ring + 1;
           const int tz = (int)(((float)tnext + 0.5f) * inv_w);  // exact for these sizes
@@ -200,9 +222,9 @@ __global__ __launch_bounds__(64 * kNrmWaves) void normals_kernel(const P4* __res
           const int z = iz + dz, y = iy + dy;
           tnext += 16;
           if ((unsigned)z >= (unsigned)g.nz || (unsigned)y >= (unsigned)g.ny) continue;
-          const double gz = gap(dz, frz), gy = gap(dy, fry);
-          left = worst - (gz * gz + gy * gy) * cell2;  // what the x-offset may still use; the bound only ever shrinks
-          if (left <= 0.0) continue;
+          const float gz = gap_lo(dz, frz_f), gy = gap_lo(dy, fry_f);
+          left = fmaf(-(gz * gz + gy * gy) * (1.0f - 1e-6f), cell2_lo, worst_hi) + 2e-7f * worst_hi;  // what the x-offset may still use (upper bound)
+          if (left <= 0.0f) continue;
           row = (z * g.ny + y) * g.nx;
           dzf = dz, dyf = dy;
           return true;
@@ -210,44 +232,44 @@ __global__ __launch_bounds__(64 * kNrmWaves) void normals_kernel(const P4* __res
         return false;
       };
       // up to two segments of the sorted cloud for one row
-      auto load_row = [&](int row, int dzf, int dyf, double left, int& s0, int& e0, int& s1, int& e1) {
-        const bool full = ring == 1 || dzf == -ring || dzf == ring || dyf == -ring || dyf == ring;
-        if (full) {
-          const double wx = sqrt(left) * g.inv_cell * (1.0 + 1e-6);  // in cells
-          const int x0 = max(max(ix - ring, 0), (int)floor(fx - wx)), x1 = min(min(ix + ring, g.nx - 1), (int)floor(fx + wx));
+      auto load_row = [&](int row, int dzf, int dyf, float left, int& s0, int& e0, int& s1, int& e1) {
+        const float wx = __builtin_amdgcn_sqrtf(left) * inv_cell_hi * (1.0f + 1e-5f) + 1e-6f;  // in cells (upper bound; the instruction is good to 1 ulp)
+        const int xlo = max(-ring, (int)floorf(frx_f - wx)), xhi = min(ring, (int)floorf(frx_f + wx));  // cells of the row in reach, relative to ix
+        const bool inner = abs(dzf) <= rin && abs(dyf) <= rin;  // a row through the block searched before: its cells |dx| <= rin are done
+        if (!inner) {
+          const int x0 = max(ix + xlo, 0), x1 = min(ix + xhi, g.nx - 1);
           if (x0 <= x1) {
             s0 = cs[row + x0];
             e0 = cs[row + x1 + 1];
           }
-        } else {  // interior rows: only the two end cells are new
-          const int xl = ix - ring, xr = ix + ring;
-          const double w2 = left * g.inv_cell * g.inv_cell * (1.0 + 4e-6);
-          const double gl = gap(-ring, frx), gr = gap(ring, frx);
-          const bool okl = (unsigned)xl < (unsigned)g.nx && gl * gl < w2, okr = (unsigned)xr < (unsigned)g.nx && gr * gr < w2;
-          const int il = okl ? row + xl : 0, ir = okr ? row + xr : 0;
-          const int sl = cs[il], el = cs[il + 1], sr = cs[ir], er = cs[ir + 1];
+        } else {
+          const int a0 = max(ix + xlo, 0), a1 = min(ix - rin - 1, g.nx - 1), b0 = max(ix + rin + 1, 0), b1 = min(ix + xhi, g.nx - 1);
+          const bool okl = a0 <= a1, okr = b0 <= b1;
+          const int sl = cs[okl ? row + a0 : 0], el = cs[okl ? row + a1 + 1 : 0], sr = cs[okr ? row + b0 : 0], er = cs[okr ? row + b1 + 1 : 0];
           if (okl) s0 = sl, e0 = el;
           if (okr) s1 = sr, e1 = er;
         }
       };
       bool found = false;
       int row = 0, dzf = 0, dyf = 0;
-      double left = 0.0;
+      float left = 0.0f;
       for (;;) {
         if (active && !found) found = next_row(row, dzf, dyf, left);
         const unsigned int mine = (unsigned int)(__ballot(found) >> (grp * 16)) & 0xffffu;
         const bool next_ring = active && mine == 0u;
         if (__ballot(next_ring) == 0ull) break;
         if (next_ring) {
-          ring += 1;
-          ntask = (2 * ring + 1) * (2 * ring + 1);
-          inv_w = 1.0f / (float)(2 * ring + 1);
-          tnext = l;
-          if (ring > rmax_cells) {
+          rin = ring;
+          const double lb = g.cell * ((double)rin + mf) * (1.0 - 1e-6);
+          if (rin >= rmax_cells || worst <= lb * lb) {  // the max_nn-th best (or r^2) already lies inside the searched block
             active = false;
           } else {
-            const double lb = g.cell * ((double)(ring - 1) + mf) * (1.0 - 1e-6);
-            if (worst <= lb * lb) active = false;  // the max_nn-th best (or r^2) already lies inside the searched block
+            const float reach = cnt == max_nn ? __builtin_amdgcn_sqrtf(worst_hi) * inv_cell_hi - (float)mf
+                                              : ((float)rin + 0.5f) * __builtin_amdgcn_sqrtf((float)max_nn * __builtin_amdgcn_rcpf((float)max(cnt, 1))) * nrm_reach_gain;
+            ring = min(max((int)ceilf(reach), rin + 1), rmax_cells);
+            ntask = (2 * ring + 1) * (2 * ring + 1);
+            inv_w = 1.0f / (float)(2 * ring + 1);
+            tnext = l;
           }
         }
       }
@@ -299,12 +321,12 @@ __global__ __launch_bounds__(64 * kNrmWaves) void normals_kernel(const P4* __res
         const int nslot = __ballot(T - f0 > 48) != 0ull ? 4 : __ballot(T - f0 > 32) != 0ull ? 3 : __ballot(T - f0 > 16) != 0ull ? 2 : 1;
         int sb[4] = {0, 0, 0, 0};
         if (round1) {  // the last lane m whose first candidate number is <= f (an empty segment shares its successor's number, which wins)
-          const int b0 = __builtin_amdgcn_update_dpp(0, r1_base, 0x150, 0xf, 0xf, false);  // row_newbcast:0
+          const int b0 = __builtin_amdgcn_update_dpp(0, r1_base, 0x150, 0xf, 0xf, true);  // row_newbcast:0
           sb[0] = sb[1] = sb[2] = sb[3] = b0;
 #define O3DS_R1_STEP(m)                                                                        \
   {                                                                                            \
-    const int o = __builtin_amdgcn_update_dpp(0, r1_off, 0x150 + (m), 0xf, 0xf, false);        \
-    const int b = __builtin_amdgcn_update_dpp(0, r1_base, 0x150 + (m), 0xf, 0xf, false);       \
+    const int o = __builtin_amdgcn_update_dpp(0, r1_off, 0x150 + (m), 0xf, 0xf, true);        \
+    const int b = __builtin_amdgcn_update_dpp(0, r1_base, 0x150 + (m), 0xf, 0xf, true);       \
     _Pragma("unroll") for (int c = 0; c < 4; ++c) sb[c] = o <= f0 + l + 16 * c ? b : sb[c];   \
   }
           O3DS_R1_STEP(1) O3DS_R1_STEP(2) O3DS_R1_STEP(3) O3DS_R1_STEP(4) O3DS_R1_STEP(5) O3DS_R1_STEP(6) O3DS_R1_STEP(7) O3DS_R1_STEP(8)
@@ -538,9 +560,12 @@ __global__ __launch_bounds__(64 * kNrmWaves) void normals_kernel(const P4* __res
           if constexpr (WIDE) {
             tau_i = L.Ki[max_nn - 1];
             worst = __longlong_as_double((long long)tau_k);
+            worst_hi = (float)worst * (1.0f + 1e-6f);
           } else {
             tau_i = 0;
-            worst = (double)__uint_as_float((unsigned int)(tau_k >> 32));
+            worst_hi = __uint_as_float((unsigned int)(tau_k >> 32));
+            worst = (double)worst_hi;
+            worst_hi *= 1.0f + 1e-6f;
           }
         }
         O3DS_PH(7);  // ranking + new bound
@@ -607,6 +632,22 @@ __global__ __launch_bounds__(64 * kNrmWaves) void normals_kernel(const P4* __res
 #endif
   }
 #endif
+}
+
+template <typename P4, int KMAX>
+__global__ __launch_bounds__(64 * kNrmWaves) void normals_kernel(const P4* __restrict__ pts, size_t n, GridDev g, const P4* __restrict__ sp, double radius,
+                                                                 int max_nn, int rmax_cells, double* __restrict__ out_sums, int* __restrict__ out_cnt) {
+  normals_body<P4, KMAX>(pts, n, g, sp, radius, max_nn, rmax_cells, out_sums, out_cnt);
+}
+// The instantiation the lidar stream uses (f32 storage, max_nn <= 32) fits 96 registers without spilling when asked to: five wavefronts per
+// SIMD instead of four (their 5 x 4 x 7.3 KB of LDS just fit a CU's 160 KB).  The kernel is a chain of dependent memory round trips per
+// point (query -> cell table -> candidates -> kept points), so a fifth wavefront to switch to is worth 7 % (100.5 -> 92.7 us per 108 k points).
+template <typename P4, int KMAX>
+__global__ __launch_bounds__(64 * kNrmWaves) __attribute__((amdgpu_waves_per_eu(5))) void normals_kernel_occ5(const P4* __restrict__ pts, size_t n, GridDev g,
+                                                                                                              const P4* __restrict__ sp, double radius, int max_nn,
+                                                                                                              int rmax_cells, double* __restrict__ out_sums,
+                                                                                                              int* __restrict__ out_cnt) {
+  normals_body<P4, KMAX>(pts, n, g, sp, radius, max_nn, rmax_cells, out_sums, out_cnt);
 }
 
 // Covariance from the cumulants, eigenvector of the smallest eigenvalue, normalise, orient: ~1200 instructions of f64 per point that
