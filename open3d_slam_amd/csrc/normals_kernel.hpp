@@ -66,6 +66,25 @@ __device__ __forceinline__ int row_incl_scan(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
   return v;
 }
+// maximum over the 16 lanes of a DPP row, in every lane (rotations by 1, 2, 4, 8)
+template <int CTRL>
+__device__ __forceinline__ float row_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double row_dpp(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, true), hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <typename R>
+__device__ __forceinline__ R row_max(R v) {
+  v = fmax(v, row_dpp<0x121>(v));  // row_ror:1
+  v = fmax(v, row_dpp<0x122>(v));
+  v = fmax(v, row_dpp<0x124>(v));
+  v = fmax(v, row_dpp<0x128>(v));
+  return v;
+}
 __device__ __forceinline__ int row_last(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x15f, 0xf, 0xf, true); }  // row_newbcast:15
 
 template <bool WIDE, int KMAX, typename R>
@@ -79,7 +98,8 @@ struct alignas(16) NrmGroupLds {
       int seg_off[128];   // first flat candidate number of each segment of the round (8 per lane: up to 4 rows of 2 segments)
       int seg_base[128];  // position in the sorted cloud minus seg_off
     };
-    R X[KMAX][4];  // x y z 1 of the kept points, for the cumulants (after the search)
+    // x y z 1 of the kept points for the cumulants (after the search); widened once where that fits the space of the tables above
+    std::conditional_t<(KMAX <= 32), double, R> X[KMAX][4];
   };
 };
 
@@ -185,7 +205,9 @@ __device__ __forceinline__ void normals_body(const P4* __restrict__ pts /* origi
     // flat candidate number comes from eight DPP row broadcasts and compares, not from a search of the LDS table.
     bool round1 = true;  // wavefront-uniform
     int r1_off = 0, r1_base = 0;
-    const int r1_dz = (l * 11 >> 5) - 1, r1_dy = l - 3 * (l * 11 >> 5) - 1;  // l / 3 - 1, l % 3 - 1 for l < 9
+    // the nine rows from the middle outwards -- the query's own row, its four neighbours, the four diagonal ones -- so that a second chunk,
+    // when the block holds more than 64 points, is made of the rows least likely to hold anything below the bound the first chunk set
+    const int r1_dz = (int)((164373u >> (2 * l)) & 3u) - 1, r1_dy = (int)((139617u >> (2 * l)) & 3u) - 1;  // lanes 0 .. 8; the others take no row
 
     O3DS_PH(0);  // set-up
     for (;;) {
@@ -389,7 +411,13 @@ __device__ __forceinline__ void normals_body(const P4* __restrict__ pts /* origi
           const bool refine0 = cnt == 0 && stot > max_nn + 8;
           if (__ballot(refine0) != 0ull) {
             bool refine = refine0;
-            R t_lo = (R)0, t_hi = WIDE ? (R)__longlong_as_double((long long)tau_k) : (R)__uint_as_float((unsigned int)(tau_k >> 32));
+            // the bracket starts at the largest distance present (just above it: all stot candidates lie below), not at r^2 -- with r = 3 m
+            // and a block 1 m across the interpolation spent its first three steps walking down from 9 m^2
+            R dmax = (R)0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dmax = sv[c] ? fmax(dmax, cd[c]) : dmax;
+            dmax = row_max<R>(dmax);
+            R t_lo = (R)0, t_hi = dmax * (R)(1.0 + 1e-6) + (R)1e-30;
             int c_lo = 0, c_hi = stot;
             for (int stepn = 0; stepn < 6 && __ballot(refine) != 0ull; ++stepn) {
               const R t = t_lo + (t_hi - t_lo) * ((R)(max_nn + 4 - c_lo) * (R)__builtin_amdgcn_rcpf((float)(c_hi - c_lo)));  // any t in between will do
@@ -591,10 +619,11 @@ __device__ __forceinline__ void normals_body(const P4* __restrict__ pts /* origi
         }
 #endif
         const P4 tpt = pts[oi];
-        L.X[idx][0] = tpt.x;
-        L.X[idx][1] = tpt.y;
-        L.X[idx][2] = tpt.z;
-        L.X[idx][3] = (R)1;
+        using XT = std::remove_reference_t<decltype(L.X[0][0])>;
+        L.X[idx][0] = (XT)tpt.x;
+        L.X[idx][1] = (XT)tpt.y;
+        L.X[idx][2] = (XT)tpt.z;
+        L.X[idx][3] = (XT)1;
       }
     }
     O3DS_WAVE_SYNC();

@@ -34,6 +34,11 @@ for lo, hi in ((0, 25), (25, 50), (50, 75), (75, 100)):
     live = ((start < b) & (end > a)).sum()
     print(f"  wavefronts alive during {lo:3d}-{hi:3d} % of the span: {live}")
 print("corr(duration, rounds) %.2f  corr(duration, chunks) %.2f" % (np.corrcoef(clk, rounds)[0, 1], np.corrcoef(clk, chunks)[0, 1]))
+order = np.argsort(start)
+for d in range(10):
+    sel = order[len(order) * d // 10:len(order) * (d + 1) // 10]
+    print("  start decile %d: start %6.1f .. %6.1f us, duration mean %5.1f p90 %5.1f max %5.1f, chunks mean %.2f rounds mean %.2f" % (
+        d, start[sel].min(), start[sel].max(), clk[sel].mean(), np.percentile(clk[sel], 90), clk[sel].max(), chunks[sel].mean(), rounds[sel].mean()))
 slow = np.argsort(-clk)[:8]
 for i in slow:
     print("  slow wavefront %5d: %7.1f us rounds %3d ring %d chunks %3d start %7.1f" % (i, clk[i], rounds[i], ring[i], chunks[i], start[i]))
