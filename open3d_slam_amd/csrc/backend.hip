@@ -33,6 +33,8 @@ struct CloudRec {
   void* pts = nullptr;  // P4[n]
   void* nrm = nullptr;  // P4[n] or null
   void* col = nullptr;  // P4[n] or null: PointCloud::colors_ (carried by the cloud operations, never read by registration)
+  size_t cap = 0;       // points the pts / nrm arrays have room for when that is more than n (a map after its merge: the next scan is placed
+                        // behind the last point instead of copying the map into larger arrays); 0 = exactly n
   // nearest-neighbour index
   bool has_index = false;
   bool index_byproduct = false;  // the index was left by the normal estimation (its cell size suits THAT search): a registration
@@ -492,6 +494,7 @@ void free_cloud(o3ds_handle h, CloudRec& c) {
   if (c.col) dev_free(h, c.col);
   c.pts = c.nrm = c.col = nullptr;
   c.n = 0;
+  c.cap = 0;
 }
 
 // a cloud under construction in a function that may still fail: freed on every early return, handed over by release()
@@ -2317,8 +2320,12 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
   const int drop = filter ? 1 : 0;
   out.n = filter ? (size_t)n_seg - n_pass : (size_t)n_seg;
   if (out.n == 0) return O3DS_OK;
-  HIP_TRY(dev_alloc(h, (void**)&out.pts, sizeof(P4) * out.n));
-  if (in.nrm) HIP_TRY(dev_alloc(h, (void**)&out.nrm, sizeof(P4) * out.n));
+  // a map (mode 1) gets room for the scans to come: Submap::insertScan appends one before every merge, and with the room in place the
+  // append is one kernel that places the scan's points behind the map's instead of two allocations and a copy of the whole map
+  const size_t room = (mode == 1 && !filter) ? out.n + std::max<size_t>(out.n / 4, (size_t)1 << 18) : out.n;
+  HIP_TRY(dev_alloc(h, (void**)&out.pts, sizeof(P4) * room));
+  if (in.nrm) HIP_TRY(dev_alloc(h, (void**)&out.nrm, sizeof(P4) * room));
+  if (room > out.n && !in.col) out.cap = room;
   segment_mean_kernel<P4><<<grid_for((size_t)n_seg), kBlock, 0, h->stream>>>((const P4*)in.pts, (const P4*)in.nrm, k1, v1, seg_start, (size_t)n_seg, n,
                                                                             mode == 1 ? 1 : 0, n_pass, (P4*)out.pts, (P4*)out.nrm, drop);
   if (in.col) {
@@ -2604,6 +2611,7 @@ int carve_t(o3ds_handle h, CloudRec& map, const CloudRec& scan, const double T[1
   map.nrm = nn;
   map.col = nc;
   map.n = (size_t)total;
+  map.cap = 0;
   return O3DS_OK;
 }
 
@@ -2709,6 +2717,7 @@ int append_t(o3ds_handle h, CloudRec& map, const CloudRec& add) {
   map.nrm = nn;
   map.col = nc;
   map.n = n;
+  map.cap = 0;
   box_copy(map, joined);
   return O3DS_OK;
 }
@@ -3238,10 +3247,33 @@ int o3ds_map_insert_scan(o3ds_handle h, o3ds_cloud map, o3ds_cloud scan, const d
   const bool known = m->vox_first >= 0 && (size_t)m->vox_first + m->vox_count == m->n;
   const long long merge_np = known ? m->vox_first : -1;
   const size_t merge_nv = known ? m->vox_count : 0;
-  CloudRec t;
-  int rc = DISPATCH(s->precision, transform_t, h, *s, T, t);  // Submap.cpp:54
-  if (!rc) rc = DISPATCH(m->precision, append_t, h, *m, t);   // Submap.cpp:70
-  free_cloud(h, t);
+  int rc = O3DS_OK;
+  if (m->n > 0 && m->cap >= m->n + s->n && m->nrm && s->nrm && !m->col && !s->col) {
+    // transform (Submap.cpp:54) and operator+= (Submap.cpp:70) in one launch: the placed points go behind the map's last one, where the
+    // previous merge left room -- the same kernel with the same arithmetic as transform_t, indices as append_t assigns them
+    CloudRec placed, joined;
+    placed.n = s->n;
+    box_transform(placed, *s, T);
+    box_union(joined, *m, placed);
+    Mat34 M;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 4; ++c) M.m[r * 4 + c] = T[c * 4 + r];
+    if (m->precision == O3DS_PRECISION_F64)
+      transform_kernel<P4d><<<grid_for(s->n), kBlock, 0, h->stream>>>((const P4d*)s->pts, (const P4d*)s->nrm, s->n, M, T[3], T[7], T[11], T[15], (P4d*)m->pts,
+                                                                      (P4d*)m->nrm, m->n);
+    else
+      transform_kernel<P4f><<<grid_for(s->n), kBlock, 0, h->stream>>>((const P4f*)s->pts, (const P4f*)s->nrm, s->n, M, T[3], T[7], T[11], T[15], (P4f*)m->pts,
+                                                                      (P4f*)m->nrm, m->n);
+    HIP_TRY(hipGetLastError());
+    free_index(h, *m);
+    m->n += s->n;
+    box_copy(*m, joined);
+  } else {
+    CloudRec t;
+    rc = DISPATCH(s->precision, transform_t, h, *s, T, t);      // Submap.cpp:54
+    if (!rc) rc = DISPATCH(m->precision, append_t, h, *m, t);   // Submap.cpp:70
+    free_cloud(h, t);
+  }
   if (rc) return rc;
   rc = voxelize_within_volume_impl(h, map, map_voxel_size, map_builder_crop, merge_np, merge_nv);  // Submap.cpp:71-72
   if (rc) return rc;
