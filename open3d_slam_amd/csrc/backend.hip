@@ -2241,7 +2241,11 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
     const int unsorted = pub_value<int>(h, 2);
     if (!unsorted) {
       const size_t npass_ = (size_t)(tot & kCntMask), nvin = (size_t)(tot >> 32), nx = n - npass_ - nvin;
-      merge_split_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(k0, rank, n, np, nv, k1, v1, vk, vv, xk, xv);
+      int *xpos = nullptr, *cnt = nullptr, *before = nullptr;
+      TMP_ALLOC(xpos, sizeof(int) * (nx + 1));
+      TMP_ALLOC(cnt, sizeof(int) * (nvin + 2));
+      TMP_ALLOC(before, sizeof(int) * (nvin + 2));
+      merge_split_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(k0, rank, n, np, nv, k1, v1, vk, vv, xk, xv, cnt, nvin + 2);
       const unsigned long long* xks = xk;
       const uint32_t* xvs = xv;
       if (nx > 1) {  // the only sort: the points that are new to the volume -- tile sort in LDS, then merge passes (cloud_kernels.hpp)
@@ -2279,11 +2283,6 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
           xks = ka, xvs = va;
         }
       }
-      int *xpos = nullptr, *cnt = nullptr, *before = nullptr;
-      TMP_ALLOC(xpos, sizeof(int) * (nx + 1));
-      TMP_ALLOC(cnt, sizeof(int) * (nvin + 2));
-      TMP_ALLOC(before, sizeof(int) * (nvin + 2));
-      HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int) * (nvin + 2), h->stream));
       if (nx) merge_rank_kernel<<<grid_for(nx), kBlock, 0, h->stream>>>(xks, xvs, nx, vk, nvin, np, xpos, cnt);
       rcs = exclusive_scan_int(h, cnt, before, nvin + 2);
       if (rcs) return rcs;

@@ -295,9 +295,11 @@ __global__ __launch_bounds__(kBlock) void merge_class_kernel(const P4* __restric
 __global__ __launch_bounds__(kBlock) void merge_split_kernel(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ rank,
                                                              size_t n, size_t np, size_t nv, unsigned long long* __restrict__ k_sorted,
                                                              uint32_t* __restrict__ v_sorted, unsigned long long* __restrict__ vk, uint32_t* __restrict__ vv,
-                                                             unsigned long long* __restrict__ xk, uint32_t* __restrict__ xv) {
+                                                             unsigned long long* __restrict__ xk, uint32_t* __restrict__ xv,
+                                                             int* __restrict__ zero /* the gap counters merge_rank_kernel adds to */, size_t n_zero) {
   const unsigned long long tot = rank[n];
   const size_t n_in = n - (size_t)(tot & kCntMask);
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n_zero; i += (size_t)gridDim.x * kBlock) zero[i] = 0;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
     const unsigned long long k = keys[i], r = rank[i];
     if (k & kPassBit) {
