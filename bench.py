@@ -555,14 +555,21 @@ def main():
             import socket
             import subprocess
 
-            with socket.socket() as sk:
-                sk.bind(("127.0.0.1", 0))
-                port = sk.getsockname()[1]
             env = dict(os.environ)
             env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-                   "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-            raise SystemExit(subprocess.call(cmd, env=env))
+            rc = 1
+            for _attempt in range(3):  # a port found free by bind-and-close can be taken before the rendezvous binds it: then try another
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    port = sk.getsockname()[1]
+                cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+                       "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+                p = subprocess.run(cmd, env=env, stderr=subprocess.PIPE, text=True)
+                sys.stderr.write(p.stderr)
+                rc = p.returncode
+                if rc == 0 or "address already in use" not in p.stderr.lower():
+                    break
+            raise SystemExit(rc)
         args.gpus = world
     if args.config == "auto":
         args.config = "1" if world == 1 else "3"

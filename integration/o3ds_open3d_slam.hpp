@@ -148,14 +148,16 @@ class ScanOnDevice : public PointCloud {
  public:
   std::shared_ptr<const DeviceRef> device_;
 };
-// Guards against a caller that edits the host arrays after the device copy was made (the copy would be stale): size, presence of
-// normals and the bits of up to 64 evenly spaced points and normals.  Not a proof of equality; open3d_slam's own flow never edits a
-// pre-processed scan between the seams, and an edited cloud that still matches in all 64 samples is not a case worth a full pass.
+// Guards against a caller that edits the host arrays after the device copy was made (the copy would be stale): sizes, presence of
+// normals / colours and the bits of up to 64 evenly spaced points, normals and colours.  Not a proof of equality: open3d_slam's own flow
+// never edits a pre-processed scan between the seams; code that does calls invalidateDeviceCopy() after the edit, and O3DS_FINGERPRINT_FULL=1
+// hashes every element (a debugging aid: one pass over the host arrays per seam).
 inline uint64_t fingerprint(const PointCloud& c) {
-  uint64_t f = 0x9e3779b97f4a7c15ull ^ (uint64_t)c.points_.size() ^ ((uint64_t)c.normals_.size() << 32);
+  static const bool full = std::getenv("O3DS_FINGERPRINT_FULL") && std::atoi(std::getenv("O3DS_FINGERPRINT_FULL")) != 0;
+  uint64_t f = 0x9e3779b97f4a7c15ull ^ (uint64_t)c.points_.size() ^ ((uint64_t)c.normals_.size() << 32) ^ ((uint64_t)c.colors_.size() << 17);
   const size_t n = c.points_.size();
   if (n == 0) return f;
-  const size_t step = n > 64 ? n / 64 : 1;
+  const size_t step = (!full && n > 64) ? n / 64 : 1;
   for (size_t i = 0; i < n; i += step) {
     uint64_t w[3];
     std::memcpy(w, c.points_[i].data(), sizeof(w));
@@ -164,8 +166,21 @@ inline uint64_t fingerprint(const PointCloud& c) {
       std::memcpy(w, c.normals_[i].data(), sizeof(w));
       f = (f << 11 | f >> 53) ^ w[0] ^ (w[1] << 3) ^ (w[2] << 5);
     }
+    if (c.colors_.size() == n) {
+      std::memcpy(w, c.colors_[i].data(), sizeof(w));
+      f = (f << 13 | f >> 51) ^ w[0] ^ (w[1] << 7) ^ (w[2] << 9);
+    }
   }
   return f;
+}
+// for code that edits a cloud the seams handed out: the next seam uploads the host arrays again
+inline void invalidateDeviceCopy(PointCloud& c) {
+  if (ScanOnDevice* s = dynamic_cast<ScanOnDevice*>(&c)) s->device_.reset();
+}
+// PointCloud::colors_ (typedefs.hpp:24) cross the seam with the points: the reference's crop / VoxelDownSample / RandomDownSample keep
+// them on the pre-processed scan that reaches mapCloud_, and so do the device operations (o3ds_backend.h: o3ds_cloud_set_colors)
+inline void uploadColors(o3ds_handle h, o3ds_cloud id, const PointCloud& c) {
+  if (!c.points_.empty() && c.colors_.size() == c.points_.size()) check(h, o3ds_cloud_set_colors(h, id, reinterpret_cast<const double*>(c.colors_.data())));
 }
 inline std::shared_ptr<const DeviceRef> deviceCopyOf(const PointCloud& c) {
   const ScanOnDevice* s = dynamic_cast<const ScanOnDevice*>(&c);
@@ -180,6 +195,7 @@ class DeviceCloud {
   DeviceCloud(o3ds_handle h, const PointCloud& c) : h_(h) {
     const double* nrm = c.HasNormals() ? reinterpret_cast<const double*>(c.normals_.data()) : nullptr;
     check(h_, o3ds_cloud_upload(h_, reinterpret_cast<const double*>(c.points_.data()), nrm, c.points_.size(), &id_));
+    colorsOrFree(c);
   }
   // The cloud on handle h, whose lock the caller holds: borrowed if its device copy already lives on this handle (`mine` is the
   // box h belongs to, null for a handle no ScanOnDevice can belong to), copied device to device if it lives on another handle,
@@ -200,6 +216,7 @@ class DeviceCloud {
     }
     const double* nrm = c.HasNormals() ? reinterpret_cast<const double*>(c.normals_.data()) : nullptr;
     check(h_, o3ds_cloud_upload(h_, reinterpret_cast<const double*>(c.points_.data()), nrm, c.points_.size(), &id_));
+    colorsOrFree(c);
   }
   DeviceCloud(const DeviceCloud&) = delete;
   DeviceCloud& operator=(const DeviceCloud&) = delete;
@@ -210,6 +227,15 @@ class DeviceCloud {
   bool uploaded() const { return !borrowed_ && !fromDevice_; }
 
  private:
+  void colorsOrFree(const PointCloud& c) {  // in a constructor: what was uploaded does not outlive a failure
+    try {
+      uploadColors(h_, id_, c);
+    } catch (...) {
+      o3ds_cloud_free(h_, id_);
+      id_ = 0;
+      throw;
+    }
+  }
   o3ds_handle h_;
   o3ds_cloud id_ = 0;
   std::shared_ptr<const DeviceRef> borrowed_;
@@ -227,6 +253,12 @@ inline void downloadCloud(o3ds_handle h, o3ds_cloud id, PointCloud* out) {
   if (n == 0) return;
   check(h, o3ds_cloud_download(h, id, reinterpret_cast<double*>(out->points_.data()),
                                hasNormals ? reinterpret_cast<double*>(out->normals_.data()) : nullptr, n));
+  int hasColors = 0;
+  check(h, o3ds_cloud_has_colors(h, id, &hasColors));
+  if (hasColors) {
+    out->colors_.resize(n);
+    check(h, o3ds_cloud_get_colors(h, id, reinterpret_cast<double*>(out->colors_.data()), n));
+  }
 }
 
 inline RegistrationResult toResult(const o3ds_icp_result& r) {
@@ -462,23 +494,30 @@ class DeviceSubmap {
                const o3d_slam::SpaceCarvingParameters& p, PointCloud* toRemove = nullptr, PointCloud* scanRef = nullptr) {
     auto s = unique();
     std::lock_guard<std::mutex> lck(s->m);
-    if (rawScan.IsEmpty() || s->size() == 0) return 0;
+    if (s->size() == 0) return 0;  // Submap.cpp:111-113: an empty map returns before toRemove_ / scanRef_ are touched
+    if (rawScan.IsEmpty()) {       // no rays: nothing is carved, and the reference's members become the (empty) results of this call
+      if (toRemove) *toRemove = PointCloud();
+      if (scanRef) *scanRef = PointCloud();
+      return 0;
+    }
     const o3ds_handle h = s->h.get();
+    struct Owned {  // a device cloud this call made: freed on every way out
+      o3ds_handle h;
+      o3ds_cloud id = 0;
+      ~Owned() {
+        if (id) o3ds_cloud_free(h, id);
+      }
+    };
     DeviceCloud in(h, rawScan);
     const o3ds_carving_params cp{p.voxelSize_, p.maxRaytracingLength_, p.truncationDistance_, p.minDotProductWithNormal_};
     size_t removed = 0;
-    o3ds_cloud gone = 0;
-    check(h, o3ds_map_carve_removed(h, s->id(), in.id(), mapToRangeSensor.matrix().data(), &mapBuilderCrop, &cp, &removed, toRemove ? &gone : nullptr));
-    ++s->version;
-    if (toRemove) {
-      downloadCloud(h, gone, toRemove);
-      o3ds_cloud_free(h, gone);
-    }
+    Owned gone{h}, placed{h};
+    check(h, o3ds_map_carve_removed(h, s->id(), in.id(), mapToRangeSensor.matrix().data(), &mapBuilderCrop, &cp, &removed, toRemove ? &gone.id : nullptr));
+    if (removed > 0) ++s->version;  // an unchanged map keeps its host mirror
+    if (toRemove) downloadCloud(h, gone.id, toRemove);
     if (scanRef) {
-      o3ds_cloud placed = 0;
-      check(h, o3ds_transform_cloud(h, in.id(), mapToRangeSensor.matrix().data(), &placed));
-      downloadCloud(h, placed, scanRef);
-      o3ds_cloud_free(h, placed);
+      check(h, o3ds_transform_cloud(h, in.id(), mapToRangeSensor.matrix().data(), &placed.id));
+      downloadCloud(h, placed.id, scanRef);
     }
     return removed;
   }

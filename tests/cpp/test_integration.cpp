@@ -192,6 +192,24 @@ int main(int argc, char** argv) {
       for (size_t i = 0; i < pre->points_.size(); ++i)
         for (int a = 0; a < 3; ++a) CHECK(recomputed->points_[i][a] == pre->points_[i][a] && recomputed->normals_[i][a] == pre->normals_[i][a]);
     }
+    // colours cross the seams with the points (the reference's crop / VoxelDownSample keep them on the scan that reaches mapCloud_)
+    {
+      PointCloud tinted = raw;
+      tinted.colors_.assign(tinted.points_.size(), Eigen::Vector3d(0.25, 0.5, 0.75));
+      std::shared_ptr<PointCloud> pt = o3ds::preprocessScan(tinted, chain);
+      CHECK(pt.get() != pre.get() && pt->points_.size() == pre->points_.size() && pt->colors_.size() == pt->points_.size());
+      for (size_t i = 0; i < pt->colors_.size(); i += 97)
+        CHECK(std::fabs(pt->colors_[i][0] - 0.25) < 1e-6 && std::fabs(pt->colors_[i][1] - 0.5) < 1e-6 && std::fabs(pt->colors_[i][2] - 0.75) < 1e-6);
+      o3d_slam::ScanCroppingParameters np2 = cp;
+      np2.croppingMinRadius_ = 1.0;
+      np2.croppingMaxRadius_ = 6.0;
+      auto cropped = o3ds::cropScan(*pt, o3ds::makeCrop(np2, I));
+      CHECK(cropped->points_.size() > 100 && cropped->colors_.size() == cropped->points_.size());
+      // an edit of the host arrays that the 64 samples would miss: the caller says so
+      CHECK(o3ds::deviceCopyOf(*pt) != nullptr);
+      o3ds::invalidateDeviceCopy(*pt);
+      CHECK(o3ds::deviceCopyOf(*pt) == nullptr);
+    }
     // the same chain seam by seam on host clouds (what round 2's patch left to the CPU, here through the stateless calls)
     const PointCloud plain = *pre;  // sliced: an ordinary host cloud, no device copy
     CHECK(o3ds::deviceCopyOf(plain) == nullptr);
