@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -167,6 +169,7 @@ struct o3ds_context {
   float set_gain = 2.0f, set_min = 1e-3f, set_cap = 0.04f;  // O3DS_SET_GAIN / _MIN / _CAP (metres)
   char* d_fused = nullptr;  // [2 states | 3 x kFusedSlots slot records (hi and lo sums)]
   unsigned long long fused_launches = 0;
+  unsigned long long fused_seq = 0;  // stamp of the last launch that was asked to write the pinned state (wait_fused_state)
   // Scratch that its users leave the way they found it, so that no launch is spent on clearing it: the per-cell counters of an index
   // build (the scatter counts them back down to zero) and the voxel table of VoxelDownSample (vox_mean_kernel empties the slots it
   // used).  `*_clean` is false while an operation is in flight or after one failed: the next user clears the block first.
@@ -538,6 +541,28 @@ T pub_value(o3ds_handle h, int k) { return *(const volatile T*)(h->h_pin + kPubO
 int wait_stream(o3ds_handle h) {
   HIP_TRY(hipStreamSynchronize(h->stream));
   return O3DS_OK;
+}
+// The fused registration loop's wait.  The launch the host waits for writes the state into pinned memory and then, with a system-scope
+// release, the stamp `seq` into a pinned word (icp_fused_kernel); every earlier launch of the stream has completed by then, and once the
+// loop is done the rest of that launch is workgroups returning.  Watching the word hands the result over as it is written instead of
+// after the kernel's completion signal has made its way through the runtime (a few microseconds per registration of ~200).  A stamp
+// that does not show up within 50 ms (a faulted queue) falls back to the stream wait, which reports the error.
+constexpr int kSeqSlot = 8;
+hipError_t wait_fused_state(o3ds_handle h, unsigned long long seq) {
+  static const bool watch = !(getenv("O3DS_ICP_WATCH_STATE") && atoi(getenv("O3DS_ICP_WATCH_STATE")) == 0);
+  if (watch) {
+    const volatile unsigned long long* w = (const volatile unsigned long long*)(h->h_pin + kPubOff + 16 * (size_t)kSeqSlot);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned int spins = 1;; ++spins) {
+      if (*w == seq) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        return hipSuccess;
+      }
+      __builtin_ia32_pause();
+      if ((spins & 0x3ffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
+    }
+  }
+  return hipStreamSynchronize(h->stream);
 }
 
 template <typename P4>
@@ -1679,6 +1704,8 @@ int o3ds_icp_pass_finish(o3ds_handle h, size_t n_src_total, const double* d_sums
   fa.state_in = h->session_state;
   fa.state_out = (IcpStateDev*)(h->d_fused + (size_t)(j & 1) * kFusedStateStride);
   fa.state_host = h->h_state_dev;
+  fa.seq_host = pub_slot<unsigned long long>(h, kSeqSlot);
+  fa.seq = ++h->fused_seq;
   fa.slots_in = d_sums_in;
   fa.slots_out = d_sums_scratch;  // a launch that still has iterations left would add an (empty) pass here
   fa.slots_clear = d_sums_scratch;
@@ -1687,7 +1714,7 @@ int o3ds_icp_pass_finish(o3ds_handle h, size_t n_src_total, const double* d_sums
   else
     launch_fused<P4f>(h, fa, h->session_crop, 1, false);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(wait_fused_state(h, fa.seq));
   h->session = false;
   h->session_state = nullptr;
   copy_result(h, out);
@@ -1919,6 +1946,8 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
         fa.trace = j == trace_launch ? d_trace : nullptr;
         fa.pass.stats = d_stats ? d_stats + 4 * (size_t)j : nullptr;
         fa.state_host = k == chunk - 1 ? h->h_state_dev : nullptr;  // the launch the host waits for also writes the pinned copy
+        fa.seq_host = pub_slot<unsigned long long>(h, kSeqSlot);
+        if (fa.state_host) fa.seq = ++h->fused_seq;
         if (h->session_precision == O3DS_PRECISION_F64)
           launch_fused<P4d>(h, fa, h->session_crop, tail_only ? 1 : nb, !tail_only);
         else
@@ -1929,7 +1958,7 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
         // a failed launch or stream breaks the "slot buffer g % 3 was cleared by launch g - 1" rotation: clear all three and restart
         // the counter, so that the next registration does not add into records that were never cleared
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess) e = wait_fused_state(h, h->fused_seq);
         if (e != hipSuccess) {
           (void)hipMemset(h->d_fused + kFusedSlotsOff, 0, 3 * kFusedSlotBufBytes);
           h->fused_launches = 0;

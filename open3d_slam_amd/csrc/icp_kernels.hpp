@@ -1807,6 +1807,8 @@ struct IcpFusedArgs {
   double rel_fitness, rel_rmse;
   int first;                      // 1: launch 0 -- there is no previous pass to fold
   unsigned long long* trace;      // null, or [gridDim.x][16] phase timestamps (100 MHz wall clock) of thread 0 (O3DS_FUSED_TRACE)
+  unsigned long long* seq_host;   // with state_host: a pinned word that receives `seq` AFTER the state (system-scope release), so that the
+  unsigned long long seq;         // host can pick the state up the moment it is written instead of after the kernel's completion signal
 };
 
 // Kernel arguments live in a kernarg segment the scalar cache has never seen when a wavefront starts; the compiler fetches each
@@ -1905,7 +1907,10 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   if (s_st.done) {  // loop already terminated: hand the final state on
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       *fa.state_out = s_st;
-      if (fa.state_host) *fa.state_host = s_st;
+      if (fa.state_host) {
+        *fa.state_host = s_st;
+        __hip_atomic_store(fa.seq_host, fa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
     return;
   }
@@ -1917,7 +1922,10 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     *fa.state_out = s_st;
-    if (fa.state_host) *fa.state_host = s_st;
+    if (fa.state_host) {
+      *fa.state_host = s_st;
+      __hip_atomic_store(fa.seq_host, fa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
   if (s_st.done) return;
   O3DS_STAMP(2);
