@@ -1706,7 +1706,6 @@ int o3ds_icp_pass_finish(o3ds_handle h, size_t n_src_total, const double* d_sums
   fa.state_host = h->h_state_dev;
   fa.seq_host = pub_slot<unsigned long long>(h, kSeqSlot);
   fa.seq = ++h->fused_seq;
-  fa.host_always = 2;
   fa.slots_in = d_sums_in;
   fa.slots_out = d_sums_scratch;  // a launch that still has iterations left would add an (empty) pass here
   fa.slots_clear = d_sums_scratch;
@@ -1946,11 +1945,9 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
         const bool tail_only = j == total - 1;
         fa.trace = j == trace_launch ? d_trace : nullptr;
         fa.pass.stats = d_stats ? d_stats + 4 * (size_t)j : nullptr;
-        // every launch of the chunk may be the one that ends the loop and says so in pinned memory; the last one reports in any case
-        fa.state_host = h->h_state_dev;
+        fa.state_host = k == chunk - 1 ? h->h_state_dev : nullptr;  // the launch the host waits for also writes the pinned copy
         fa.seq_host = pub_slot<unsigned long long>(h, kSeqSlot);
-        if (k == 0) fa.seq = ++h->fused_seq;
-        fa.host_always = k == chunk - 1;
+        if (fa.state_host) fa.seq = ++h->fused_seq;
         if (h->session_precision == O3DS_PRECISION_F64)
           launch_fused<P4d>(h, fa, h->session_crop, tail_only ? 1 : nb, !tail_only);
         else

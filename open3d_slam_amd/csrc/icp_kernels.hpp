@@ -1809,11 +1809,6 @@ struct IcpFusedArgs {
   unsigned long long* trace;      // null, or [gridDim.x][16] phase timestamps (100 MHz wall clock) of thread 0 (O3DS_FUSED_TRACE)
   unsigned long long* seq_host;   // with state_host: a pinned word that receives `seq` AFTER the state (system-scope release), so that the
   unsigned long long seq;         // host can pick the state up the moment it is written instead of after the kernel's completion signal
-  int host_always;                // 0: this launch reports only when ITS step ends the loop (the launches queued behind it then find the loop
-                                  // ended and touch nothing the host reads: they drain while the host is already on its way -- it may be
-                                  // writing the next registration's initial state into the same pinned block); 1: the last launch the host
-                                  // queued also reports a loop that goes on; 2: the session API's tail launch, the only one that was given the
-                                  // pinned block, reports in every case
 };
 
 // Kernel arguments live in a kernarg segment the scalar cache has never seen when a wavefront starts; the compiler fetches each
@@ -1912,7 +1907,7 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   if (s_st.done) {  // loop already terminated: hand the final state on
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       *fa.state_out = s_st;
-      if (fa.state_host && fa.host_always == 2) {  // (otherwise the launch whose step ended the loop has told the host)
+      if (fa.state_host) {
         *fa.state_host = s_st;
         __hip_atomic_store(fa.seq_host, fa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
@@ -1927,7 +1922,7 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     *fa.state_out = s_st;
-    if (fa.state_host && (s_st.done || fa.host_always)) {
+    if (fa.state_host) {
       *fa.state_host = s_st;
       __hip_atomic_store(fa.seq_host, fa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
