@@ -798,7 +798,11 @@ def main():
             tdoc = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
             now = hashlib.sha256(open(os.path.join(ROOT, "open3d_slam_amd", "csrc", "icp_kernels.hpp"), "rb").read()).hexdigest()[:16]
             traffic_db = tdoc["kernels"] if tdoc.get("kernel_source_sha16", {}).get("icp_kernels.hpp") == now else {}
-            stream_traffic = tdoc.get("stream_kernels", {})
+            hs = hashlib.sha256()
+            for name in ("cloud_kernels.hpp", "normals_kernel.hpp"):
+                hs.update(open(os.path.join(ROOT, "open3d_slam_amd", "csrc", name), "rb").read())
+            stream_traffic = (tdoc.get("stream_kernels", {})
+                              if tdoc.get("kernel_source_sha16", {}).get("stream (cloud_kernels.hpp + normals_kernel.hpp)") == hs.hexdigest()[:16] else {})
         except (OSError, ValueError, KeyError):
             traffic_db, stream_traffic = {}, {}
 
