@@ -2570,18 +2570,54 @@ int carve_t(o3ds_handle h, CloudRec& map, const CloudRec& scan, const double T[1
   TMP_ALLOC(seg_id, sizeof(int) * (n + 1));
   // VoxelMap of the map points inside the wide cropping volume (cropper.getIndicesWithinVolume + insertCloud): same key as the merge
   voxel_key_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>((const P4*)map.pts, n, 1, 0.0, 0.0, 0.0, cp.voxel_size, crop, k0, v0);
-  size_t temp_bytes = 0;
-  HIP_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, k0, k1, v0, v1, n, 0, 64, h->stream));
-  void* temp = nullptr;
-  TMP_ALLOC(temp, temp_bytes ? temp_bytes : 16);
-  HIP_TRY(rocprim::radix_sort_pairs(temp, temp_bytes, k0, k1, v0, v1, n, 0, 64, h->stream));
-  HIP_TRY(hipMemsetAsync(head + n, 0, sizeof(int), h->stream));
-  segment_head_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(k1, n, head);
-  int rc = exclusive_scan_int(h, head, seg_id, n + 1);
-  if (rc) return rc;
+  // The sorted (key, index) list.  A map that the merge of an insertion left is [outside points | voxel block in ascending key order], and the
+  // carving volume is the volume of that insertion (Submap.cpp:56-71: the cropper still holds its pose): the inside entries are then already in
+  // key order, and a stable PARTITION by "inside" (one scan, one scatter) gives what the stable sort gives.  Whether they really were in order
+  // -- another voxel size, a map assembled otherwise, a mean that rounding put across a voxel boundary -- is checked on the device while the
+  // segment heads are formed; if not, the library sort runs as before (O3DS_CARVE_SORT=1 forces it, for A/B runs).
+  static const bool carve_sort = getenv("O3DS_CARVE_SORT") != nullptr;
+  const bool try_partition = !carve_sort && map.vox_first >= 0 && (size_t)map.vox_first + map.vox_count == n && n < ((size_t)1 << 31);
+  int rc = O3DS_OK;
   int n_seg = 0;
-  rc = read_back(h, {{&n_seg, seg_id + n, sizeof(int)}});
-  if (rc) return rc;
+  bool sorted_ok = false;
+  if (try_partition) {
+    int* rank = nullptr;
+    TMP_ALLOC(rank, sizeof(int) * (n + 1));
+    {
+      const size_t ms = n + 1;
+      const int nbs = (int)((ms + kScanPerBlock - 1) / kScanPerBlock);
+      int* sums = nullptr;
+      TMP_ALLOC(sums, sizeof(int) * (size_t)nbs);
+      scan_local_fn_kernel<int, KeyInsideFlag><<<nbs, kBlock, 0, h->stream>>>(KeyInsideFlag{k0, n}, rank, sums, ms, nullptr);
+      if (nbs > 1 && nbs <= kScanFusedBlocks) {
+        scan_add_fused_kernel<int><<<nbs, kBlock, 0, h->stream>>>(rank, sums, ms, nullptr);
+      } else if (nbs > 1) {
+        scan_sums_kernel<int><<<1, kBlock, 0, h->stream>>>(sums, nbs);
+        scan_add_kernel<int><<<nbs, kBlock, 0, h->stream>>>(rank, sums, ms, nullptr);
+      }
+    }
+    partition_keys_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(k0, rank, n, k1, v1);
+    int* d_unsorted = pub_slot<int>(h, 2);
+    *(volatile int*)(h->h_pin + kPubOff + 32) = 0;  // (nothing in flight writes the slot: every use ends in a synchronisation)
+    segment_head_check_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(k1, n, head, d_unsorted);
+    rc = exclusive_scan_int(h, head, seg_id, n + 1);
+    if (rc) return rc;
+    rc = read_back(h, {{&n_seg, seg_id + n, sizeof(int)}});
+    if (rc) return rc;
+    sorted_ok = pub_value<int>(h, 2) == 0;
+  }
+  if (!sorted_ok) {
+    size_t temp_bytes = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, k0, k1, v0, v1, n, 0, 64, h->stream));
+    void* temp = nullptr;
+    TMP_ALLOC(temp, temp_bytes ? temp_bytes : 16);
+    HIP_TRY(rocprim::radix_sort_pairs(temp, temp_bytes, k0, k1, v0, v1, n, 0, 64, h->stream));
+    segment_head_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(k1, n, head);  // also writes the sentinel head[n] = 0
+    rc = exclusive_scan_int(h, head, seg_id, n + 1);
+    if (rc) return rc;
+    rc = read_back(h, {{&n_seg, seg_id + n, sizeof(int)}});
+    if (rc) return rc;
+  }
   TMP_ALLOC(seg_start, sizeof(int) * ((size_t)n_seg + 1));
   segment_start_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(head, seg_id, n, seg_start);
   size_t tsize = 1024;
@@ -2603,8 +2639,12 @@ int carve_t(o3ds_handle h, CloudRec& map, const CloudRec& scan, const double T[1
                                                                    (size_t)n_seg, n, v1, (const P4*)map.nrm, keep);
   rc = exclusive_scan_int(h, keep, pos, n + 1);
   if (rc) return rc;
-  int total = 0;
-  rc = read_back(h, {{&total, pos + n, sizeof(int)}});
+  int total = 0, kept_outside = 0;
+  // with the merge's layout known, the number of kept points of its first block comes back with the total: both blocks shrink in place, in
+  // order, and the next insertion still finds [outside points | voxel block in key order] -- no sort of the whole map after a carve
+  const bool layout = map.vox_first >= 0 && (size_t)map.vox_first + map.vox_count == n;
+  rc = layout ? read_back(h, {{&total, pos + n, sizeof(int)}, {&kept_outside, pos + (size_t)map.vox_first, sizeof(int)}})
+              : read_back(h, {{&total, pos + n, sizeof(int)}});
   if (rc) return rc;
   *n_removed = n - (size_t)total;
   if (*n_removed == 0) return O3DS_OK;  // removeByIds: nothing to do (helpers.cpp:221-223)
@@ -2640,6 +2680,12 @@ int carve_t(o3ds_handle h, CloudRec& map, const CloudRec& scan, const double T[1
   map.col = nc;
   map.n = (size_t)total;
   map.cap = 0;
+  if (layout) {
+    map.vox_first = (long long)kept_outside;
+    map.vox_count = (size_t)total - (size_t)kept_outside;
+  } else {
+    map.vox_first = -1;
+  }
   return O3DS_OK;
 }
 
@@ -3252,7 +3298,6 @@ int o3ds_map_carve_removed(o3ds_handle h, o3ds_cloud map, o3ds_cloud raw_scan, c
   const int rc = m->precision == O3DS_PRECISION_F64 ? carve_t<P4d>(h, *m, *s, map_to_range_sensor, cd, *params, &removed, removed_out ? &gone : nullptr)
                                                     : carve_t<P4f>(h, *m, *s, map_to_range_sensor, cd, *params, &removed, removed_out ? &gone : nullptr);
   if (n_removed) *n_removed = removed;
-  if (removed) m->vox_first = -1;  // the blocks shrank by unknown amounts: the next insertion sorts once and re-establishes the layout
   if (rc) return rc;
   if (removed_out) {
     gone_guard.release();

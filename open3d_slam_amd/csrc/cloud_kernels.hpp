@@ -449,6 +449,35 @@ __global__ __launch_bounds__(kBlock) void segment_head_kernel(const unsigned lon
     head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
   if (blockIdx.x == 0 && threadIdx.x == 0) head[n] = 0;  // sentinel: the exclusive scan of n + 1 heads ends with the segment count
 }
+// the same, and a flag when the keys are NOT in ascending order (the caller took them for sorted: carve_t's partition path)
+__global__ __launch_bounds__(kBlock) void segment_head_check_kernel(const unsigned long long* __restrict__ keys, size_t n, int* __restrict__ head,
+                                                                    int* __restrict__ unsorted) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const unsigned long long k = keys[i], kp = i ? keys[i - 1] : 0ull;
+    head[i] = (i == 0 || k != kp) ? 1 : 0;
+    if (i && k < kp) atomicOr(unsorted, 1);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) head[n] = 0;
+}
+// "entry i lies inside the volume" (its key carries no pass-through bit) as the input of a scan; entry n is the zero sentinel
+struct KeyInsideFlag {
+  const unsigned long long* keys;
+  size_t n;
+  __device__ __forceinline__ int operator()(size_t i) const { return i < n && !(keys[i] & kPassBit); }
+};
+// stable partition of (key, index) by that flag: inside entries first, in their order, then the others in theirs -- for a map whose inside
+// entries already lie in ascending key order (the voxel block a merge left) this IS the sorted list, ties in ascending index as a stable sort has them
+__global__ __launch_bounds__(kBlock) void partition_keys_kernel(const unsigned long long* __restrict__ keys, const int* __restrict__ rank, size_t n,
+                                                                unsigned long long* __restrict__ k_out, uint32_t* __restrict__ v_out) {
+  const size_t n_in = (size_t)rank[n];
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const unsigned long long k = keys[i];
+    const size_t r = (size_t)rank[i];
+    const size_t o = (k & kPassBit) ? n_in + (i - r) : r;
+    k_out[o] = k;
+    v_out[o] = (uint32_t)i;
+  }
+}
 // seg_start[seg_id] = i for every head (seg ids from the exclusive scan of head)
 __global__ __launch_bounds__(kBlock) void segment_start_kernel(const int* __restrict__ head, const int* __restrict__ seg_id, size_t n,
                                                                int* __restrict__ seg_start) {
