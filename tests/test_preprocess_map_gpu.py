@@ -402,6 +402,50 @@ def test_pointcloud2_style_f32_upload_equals_the_double_route(backend_f32, backe
         backend_f32.upload_f32(np.zeros((4, 2), np.float32))  # x/y/z do not fit an 8-byte step
 
 
+@pytest.mark.parametrize("which", ["f64", "f32"])
+def test_carving_a_merged_map_needs_no_sort_and_keeps_the_layout(backend_f64, backend_f32, which):
+    """A map that an insertion's merge left is [outside points | voxel block in key order]: carving it takes its sorted (key, index) list
+    from a stable partition instead of a radix sort, and the layout survives the carve so that the NEXT insertion merges instead of
+    sorting the whole map.  Both must be invisible: the same sequence on a copy of the map whose layout is unknown to the backend (an
+    identity `select_by_index` hands back the same points in a fresh cloud) goes through the library sort in the carve and in the
+    insertion after it, and every cloud along the way must be the same bit for bit -- also when the carving voxel is not the map's, where
+    the partition's order check fails on the device and the sort takes over."""
+    be = backend_f64 if which == "f64" else backend_f32
+    scene = syn.make_scene()
+    poses = syn.figure_eight_poses(40, 0.1)
+    crop_at = lambda T: backend.make_crop(backend.CROP_MIN_MAX_RADIUS, center=T[:3, 3], rmin=1.0, rmax=25.0)
+
+    def pre(k):
+        c = be.upload(syn.vlp16_scan(scene, poses[k], n_az=1024))
+        v = be.crop_voxel_down_sample(c, backend.make_crop(backend.CROP_MIN_MAX_RADIUS, rmin=1.0, rmax=25.0), 0.1)
+        be.estimate_normals(v, 1.0, 10)
+        be.free(c)
+        return v
+
+    for carve_voxel in (0.1, 0.15):
+        m = be.upload(np.zeros((0, 3)))
+        for k in range(3):  # the third insertion already merges into the layout the second left
+            s = pre(k)
+            be.map_insert_scan(m, s, poses[k], 0.1, crop_at(poses[k]), 1.0)
+            be.free(s)
+        n = be.size(m)[0]
+        twin = be.select_by_index(m, np.arange(n, dtype=np.uint32))  # same points and normals, layout unknown
+        raw = be.upload(syn.vlp16_scan(scene, poses[3], n_az=1024))
+        kw = dict(voxel=carve_voxel, max_length=20.0, truncation=0.1, min_dot=0.5)
+        removed_m = be.map_carve(m, raw, poses[3], crop_at(poses[2]), **kw)
+        removed_t = be.map_carve(twin, raw, poses[3], crop_at(poses[2]), **kw)
+        assert removed_m == removed_t and removed_m > 0
+        for a, b in zip(be.download(m), be.download(twin)):
+            np.testing.assert_array_equal(a, b)
+        s = pre(3)
+        be.map_insert_scan(m, s, poses[3], 0.1, crop_at(poses[3]), 1.0)
+        be.map_insert_scan(twin, s, poses[3], 0.1, crop_at(poses[3]), 1.0)
+        for a, b in zip(be.download(m), be.download(twin)):
+            np.testing.assert_array_equal(a, b)
+        for c in (m, twin, raw, s):
+            be.free(c)
+
+
 def test_map_carve_matches_oracle(backend_f64, backend_f32, oracle):
     """Submap::carve on the device-resident sparse map (Submap.cpp:109-125, helpers.cpp:235-271) vs the oracle: same removed set,
     survivors in their original order, points outside the cropping volume untouched, with and without map normals."""
