@@ -672,23 +672,42 @@ template <typename P4>
 __global__ __launch_bounds__(kBlock) void vox_insert_kernel(const P4* __restrict__ pts, size_t n, const double* __restrict__ box, double v,
                                                             CropDev crop, int filter, VoxTable t, int* __restrict__ slot_of) {
   const double ox = box[0] - v * 0.5, oy = box[1] - v * 0.5, oz = box[2] - v * 0.5;
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
-    const P4 p = pts[i];
-    const double x = (double)p.x, y = (double)p.y, z = (double)p.z;
-    if (filter && !crop_contains(crop, x, y, z)) {
-      slot_of[i] = -1;
-      continue;
+  const int lane = threadIdx.x & 63;
+  // A lidar scan lists its points along the scan lines, so neighbours in the array are neighbours in space: on the stream's scans two points
+  // share a voxel on average and they mostly sit next to each other.  A RUN of equal keys in consecutive lanes enters the table once -- its
+  // first lane claims the slot, records its own index as the run's smallest and the run's length as the count (three atomics per run
+  // instead of per point; the table saw 8.5 bytes written per byte of scan, profiles/r03_pmc_stream_kernels_traffic.txt) -- and hands
+  // the slot to the other lanes of the run.  Whole wavefronts iterate together (the exchange is by lane).
+  for (size_t i0 = (size_t)blockIdx.x * kBlock; i0 < n; i0 += (size_t)gridDim.x * kBlock) {
+    const size_t i = i0 + threadIdx.x;
+    unsigned long long k = kEmptyKey;  // no entry: past the end, or outside the volume
+    if (i < n) {
+      const P4 p = pts[i];
+      const double x = (double)p.x, y = (double)p.y, z = (double)p.z;
+      if (!filter || crop_contains(crop, x, y, z))
+        k = pack_key((long long)floor((x - ox) / v), (long long)floor((y - oy) / v), (long long)floor((z - oz) / v));
     }
-    const unsigned long long k = pack_key((long long)floor((x - ox) / v), (long long)floor((y - oy) / v), (long long)floor((z - oz) / v));
-    unsigned int slot = (unsigned int)((k * 0x9E3779B97F4A7C15ull) >> 32) & t.mask;
-    while (true) {
-      const unsigned long long prev = atomicCAS(&t.key[slot], kEmptyKey, k);
-      if (prev == kEmptyKey || prev == k) break;
-      slot = (slot + 1) & t.mask;
+    const unsigned long long kp = __shfl_up(k, 1, 64);
+    const bool lead = k != kEmptyKey && (lane == 0 || kp != k);
+    const unsigned long long leaders = __ballot(lead), ends = __ballot(lane == 0 || kp != k);  // a run also ends where entries without a key begin
+    unsigned int slot = 0;
+    if (lead) {
+      const unsigned long long above = lane == 63 ? 0ull : (ends >> (lane + 1));
+      const unsigned int len = above ? (unsigned int)__builtin_ctzll(above) + 1u : (unsigned int)(64 - lane);
+      slot = (unsigned int)((k * 0x9E3779B97F4A7C15ull) >> 32) & t.mask;
+      while (true) {
+        const unsigned long long prev = atomicCAS(&t.key[slot], kEmptyKey, k);
+        if (prev == kEmptyKey || prev == k) break;
+        slot = (slot + 1) & t.mask;
+      }
+      atomicMin(&t.first[slot], (unsigned int)i);
+      atomicSub(&t.ncnt[slot], len);
     }
-    slot_of[i] = (int)slot;
-    atomicMin(&t.first[slot], (unsigned int)i);
-    atomicSub(&t.ncnt[slot], 1u);
+    // every lane of a run reads the slot from the run's first lane: the highest leader at or below it
+    const unsigned long long below = leaders & (lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull));
+    const int src = below ? 63 - __builtin_clzll(below) : lane;
+    const unsigned int run_slot = __shfl(slot, src, 64);
+    if (i < n) slot_of[i] = k != kEmptyKey ? (int)run_slot : -1;
   }
 }
 
