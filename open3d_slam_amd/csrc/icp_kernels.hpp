@@ -95,14 +95,34 @@ __device__ __forceinline__ int cell_of(const GridDev& g, const P4& p) {
   return (iz * g.ny + iy) * g.nx + ix;
 }
 
-// counts[cell]++ ; cell_id[i] = cell
+// A run of equal cells in consecutive lanes (clouds come in scan-line or voxel-key order: neighbours in the array are neighbours in space) is
+// served by ONE atomic of its first lane.  `c` < 0 marks a lane without a point.  Returns whether this lane leads a run, the run's length
+// and the lane that leads the run this lane belongs to.  All 64 lanes call it together.
+__device__ __forceinline__ bool cell_run(int c, int lane, int* len, int* lead_lane) {
+  const int cp = __shfl_up(c, 1, 64);
+  const bool start = lane == 0 || cp != c;
+  const unsigned long long starts = __ballot(start);
+  const unsigned long long above = lane == 63 ? 0ull : (starts >> (lane + 1));
+  *len = above ? (int)__builtin_ctzll(above) + 1 : 64 - lane;
+  const unsigned long long below = starts & (lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull));
+  *lead_lane = 63 - __builtin_clzll(below);  // lane 0 always starts a run
+  return start && c >= 0;
+}
+
+// counts[cell] += (points of the cell) ; cell_id[i] = cell
 template <typename P4>
 __global__ __launch_bounds__(kBlock) void cell_count_kernel(const P4* __restrict__ pts, size_t n, GridDev g, int* __restrict__ counts,
                                                             int* __restrict__ cell_id) {
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
-    const int c = cell_of(g, pts[i]);
-    cell_id[i] = c;
-    atomicAdd(&counts[c], 1);
+  const int lane = threadIdx.x & 63;
+  for (size_t i0 = (size_t)blockIdx.x * kBlock; i0 < n; i0 += (size_t)gridDim.x * kBlock) {  // whole wavefronts iterate together
+    const size_t i = i0 + threadIdx.x;
+    int c = -1;
+    if (i < n) {
+      c = cell_of(g, pts[i]);
+      cell_id[i] = c;
+    }
+    int len, lead_lane;
+    if (cell_run(c, lane, &len, &lead_lane)) atomicAdd(&counts[c], len);
   }
 }
 
@@ -202,13 +222,20 @@ template <typename P4>
 __global__ __launch_bounds__(kBlock) void scatter_kernel(const P4* __restrict__ pts, const P4* __restrict__ nrm, size_t n,
                                                          const int* __restrict__ cell_id, const int* __restrict__ cell_start,
                                                          int* __restrict__ counts, P4* __restrict__ spts, P4* __restrict__ snrm) {
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
-    const int c = cell_id[i];
-    const int pos = cell_start[c] + atomicSub(&counts[c], 1) - 1;
-    P4 p = pts[i];
-    p.i = (typename Scalar<P4>::index)i;
-    spts[pos] = p;
-    if (nrm) snrm[pos] = nrm[i];
+  const int lane = threadIdx.x & 63;
+  for (size_t i0 = (size_t)blockIdx.x * kBlock; i0 < n; i0 += (size_t)gridDim.x * kBlock) {  // whole wavefronts iterate together
+    const size_t i = i0 + threadIdx.x;
+    const int c = i < n ? cell_id[i] : -1;
+    int len, lead_lane, old = 0;
+    if (cell_run(c, lane, &len, &lead_lane)) old = atomicSub(&counts[c], len);  // the run takes the places old - len ... old - 1 of its cell
+    old = __shfl(old, lead_lane, 64);
+    if (i < n) {
+      const int pos = cell_start[c] + old - 1 - (lane - lead_lane);
+      P4 p = pts[i];
+      p.i = (typename Scalar<P4>::index)i;
+      spts[pos] = p;
+      if (nrm) snrm[pos] = nrm[i];
+    }
   }
 }
 
