@@ -2625,7 +2625,11 @@ int carve_t(o3ds_handle h, CloudRec& map, const CloudRec& scan, const double T[1
   TMP_ALLOC(tkey, sizeof(unsigned long long) * tsize);
   TMP_ALLOC(tseg, sizeof(int) * tsize);
   HIP_TRY(hipMemsetAsync(tkey, 0xFF, sizeof(unsigned long long) * tsize, h->stream));
-  carve_table_insert_kernel<<<grid_for((size_t)n_seg), kBlock, 0, h->stream>>>(k1, seg_start, (size_t)n_seg, tkey, tseg, (unsigned int)(tsize - 1));
+  unsigned int* block_bits = nullptr;  // one bit per hashed 4 x 4 x 4 block of voxels (cloud_kernels.hpp, carve_block_bit)
+  TMP_ALLOC(block_bits, sizeof(unsigned int) << (kCarveBitsLog2 - 5));
+  HIP_TRY(hipMemsetAsync(block_bits, 0, sizeof(unsigned int) << (kCarveBitsLog2 - 5), h->stream));
+  carve_table_insert_kernel<<<grid_for((size_t)n_seg), kBlock, 0, h->stream>>>(k1, seg_start, (size_t)n_seg, tkey, tseg, (unsigned int)(tsize - 1),
+                                                                               block_bits);
   TMP_ALLOC(keep, sizeof(int) * (n + 1));
   TMP_ALLOC(pos, sizeof(int) * (n + 1));
   fill_int_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(keep, n, 1);
@@ -2636,7 +2640,7 @@ int carve_t(o3ds_handle h, CloudRec& map, const CloudRec& scan, const double T[1
   carve_rays_kernel<P4><<<grid_for(scan.n), kBlock, 0, h->stream>>>((const P4*)scan.pts, scan.n, M, T[12], T[13], T[14], cp.voxel_size,
                                                                    cp.max_raytracing_length, cp.truncation_distance,
                                                                    cp.min_dot_product_with_normal, tkey, tseg, (unsigned int)(tsize - 1), seg_start,
-                                                                   (size_t)n_seg, n, v1, (const P4*)map.nrm, keep);
+                                                                   (size_t)n_seg, n, v1, (const P4*)map.nrm, keep, block_bits);
   rc = exclusive_scan_int(h, keep, pos, n + 1);
   if (rc) return rc;
   int total = 0, kept_outside = 0;

@@ -858,13 +858,27 @@ __global__ __launch_bounds__(kBlock) void vox_mean_kernel(const P4* __restrict__
   }
 }
 
+// A ray of the carving takes up to 200 samples, nearly all of them in free space, and each used to cost a random 8-byte probe of the
+// 16 MB voxel table: 26 M probes per scan, three quarters of them fetched as whole lines from beyond the L2 -- the kernel was bound by
+// that traffic (its time follows the number of samples, putting eight probes in flight together changed nothing).  Free space is now
+// answered by a 512 KB bit set that stays in the L2: one bit per hashed 4 x 4 x 4 block of voxels, set where the block holds a voxel of
+// the table.  A clear bit proves the voxel absent (no probe); a set bit -- an occupied block, or another block with the same hash --
+// sends the sample to the table as before.  The block of a key is the key with the two low bits of its three fields cleared.
+constexpr int kCarveBitsLog2 = 22;
+constexpr unsigned long long kCarveBlockMask = ~((3ull << 42) | (3ull << 21) | 3ull);
+__device__ __forceinline__ unsigned int carve_block_bit(unsigned long long key) {
+  return (unsigned int)(((key & kCarveBlockMask) * 0x9E3779B97F4A7C15ull) >> (64 - kCarveBitsLog2));
+}
+
 // keys of the map points inside the wide cropping volume, everything else gets the pass-through bit (never probed)
 __global__ __launch_bounds__(kBlock) void carve_table_insert_kernel(const unsigned long long* __restrict__ keys, const int* __restrict__ seg_start,
                                                                     size_t n_seg, unsigned long long* __restrict__ tkey, int* __restrict__ tseg,
-                                                                    unsigned int mask) {
+                                                                    unsigned int mask, unsigned int* __restrict__ block_bits) {
   for (size_t s = (size_t)blockIdx.x * kBlock + threadIdx.x; s < n_seg; s += (size_t)gridDim.x * kBlock) {
     const unsigned long long k = keys[seg_start[s]];
     if (k & kPassBit) continue;  // segments of points outside the volume
+    const unsigned int bit = carve_block_bit(k);
+    atomicOr(&block_bits[bit >> 5], 1u << (bit & 31u));
     unsigned int slot = (unsigned int)((k * 0x9E3779B97F4A7C15ull) >> 32) & mask;
     while (true) {
       const unsigned long long prev = atomicCAS(&tkey[slot], kEmptyKey, k);
@@ -883,7 +897,8 @@ __global__ __launch_bounds__(kBlock) void carve_rays_kernel(const P4* __restrict
                                                             double min_dot, const unsigned long long* __restrict__ tkey,
                                                             const int* __restrict__ tseg, unsigned int mask, const int* __restrict__ seg_start,
                                                             size_t n_seg, size_t n_sorted, const uint32_t* __restrict__ vals,
-                                                            const P4* __restrict__ map_nrm, int* __restrict__ flags) {
+                                                            const P4* __restrict__ map_nrm, int* __restrict__ flags,
+                                                            const unsigned int* __restrict__ block_bits) {
   const double inv = 1.0 / voxel;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n_scan; i += (size_t)gridDim.x * kBlock) {
     const P4 q = scan[i];
@@ -896,33 +911,57 @@ __global__ __launch_bounds__(kBlock) void carve_rays_kernel(const P4* __restrict
     if (!(length > 0.0)) continue;
     const double ux = dx / length, uy = dy / length, uz = dz / length;
     const double lim = fmax(voxel, fmin(length - trunc, max_len));
-    for (double dist = 0.0; dist < lim; dist += voxel) {
-      const double cx = dist * ux + sx, cy = dist * uy + sy, cz = dist * uz + sz;
-      const unsigned long long k = pack_key((long long)(int)floor(cx * inv), (long long)(int)floor(cy * inv), (long long)(int)floor(cz * inv));
-      unsigned int slot = (unsigned int)((k * 0x9E3779B97F4A7C15ull) >> 32) & mask;
-      int seg = -1;
-      while (true) {
-        const unsigned long long t = tkey[slot];
-        if (t == k) {
-          seg = tseg[slot];
-          break;
+    // The samples of a ray do not depend on each other -- only `dist` does, by the reference's repeated addition -- so kBatch of them look
+    // their blocks up together (the bit set answers from the L2, a few hundred cycles each when asked one by one); the few that find their
+    // bit set go to the table one after the other (clearing a keep flag is an idempotent store, the order does not matter).
+    constexpr int kBatch = 8;
+    double dist = 0.0;
+    while (dist < lim) {
+      unsigned long long ks[kBatch];
+      unsigned int bits[kBatch], words[kBatch];
+      int m = 0;
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u)
+        if (dist < lim) {
+          const double cx = dist * ux + sx, cy = dist * uy + sy, cz = dist * uz + sz;
+          ks[u] = pack_key((long long)(int)floor(cx * inv), (long long)(int)floor(cy * inv), (long long)(int)floor(cz * inv));
+          bits[u] = carve_block_bit(ks[u]);
+          dist += voxel;
+          m = u + 1;
         }
-        if (t == kEmptyKey) break;
-        slot = (slot + 1) & mask;
-      }
-      if (seg < 0) continue;
-      const size_t b = (size_t)seg_start[seg], e = (size_t)seg + 1 < n_seg ? (size_t)seg_start[seg + 1] : n_sorted;
-      for (size_t j = b; j < e; ++j) {
-        const uint32_t id = vals[j];
-        bool rem = true;
-        if (map_nrm) {
-          const P4 nn = map_nrm[id];
-          const double a = (double)nn.x, bb = (double)nn.y, c = (double)nn.z;
-          const double nl = sqrt(a * a + bb * bb + c * c);
-          const double dot = nl > 0.0 ? (ux * a + uy * bb + uz * c) / nl : 0.0;  // Eigen normalized(): the zero vector stays zero
-          rem = fabs(dot) > min_dot;
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u)
+        if (u < m) words[u] = block_bits[bits[u] >> 5];
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        if (u >= m) break;
+        if (!((words[u] >> (bits[u] & 31u)) & 1u)) continue;  // nothing of the table in this block of voxels
+        const unsigned long long k = ks[u];
+        unsigned int slot = (unsigned int)((k * 0x9E3779B97F4A7C15ull) >> 32) & mask;
+        int seg = -1;
+        while (true) {
+          const unsigned long long t = tkey[slot];
+          if (t == k) {
+            seg = tseg[slot];
+            break;
+          }
+          if (t == kEmptyKey) break;
+          slot = (slot + 1) & mask;
         }
-        if (rem) flags[id] = 0;  // flags are "keep" flags: 1 = stays in the map
+        if (seg < 0) continue;
+        const size_t b = (size_t)seg_start[seg], e = (size_t)seg + 1 < n_seg ? (size_t)seg_start[seg + 1] : n_sorted;
+        for (size_t j = b; j < e; ++j) {
+          const uint32_t id = vals[j];
+          bool rem = true;
+          if (map_nrm) {
+            const P4 nn = map_nrm[id];
+            const double a = (double)nn.x, bb = (double)nn.y, c = (double)nn.z;
+            const double nl = sqrt(a * a + bb * bb + c * c);
+            const double dot = nl > 0.0 ? (ux * a + uy * bb + uz * c) / nl : 0.0;  // Eigen normalized(): the zero vector stays zero
+            rem = fabs(dot) > min_dot;
+          }
+          if (rem) flags[id] = 0;  // flags are "keep" flags: 1 = stays in the map
+        }
       }
     }
   }
