@@ -434,18 +434,19 @@ def run_m1(be, world, s_id, t_id, steps, warmup, barrier, drv):
     else:
         def step():
             return be.icp_point_to_plane_dev(s_id, t_id, MAX_CORR, max_iter=ICP_ITERS, rel_fitness=0.0, rel_rmse=0.0)
-    res = None
-    for _ in range(warmup):
-        res = step()
-    barrier()
     import gc
 
     gc_log = []
     def on_gc(phase, info):
         gc_log.append((phase, info.get("generation"), time.perf_counter()))
-    gc.callbacks.append(on_gc)
-    gc.collect()  # cheap once main() has frozen the interpreter's long-lived objects
+    gc.collect()  # cheap once main() has frozen the interpreter's long-lived objects; BEFORE the warm-up, so that the device does not sit
+    # idle for milliseconds between the last warm-up step and the first timed one (the first timed step was 15-25 us slower than the rest)
     marks = [0.0] * (steps + 1)
+    res = None
+    for _ in range(warmup):
+        res = step()
+    barrier()
+    gc.callbacks.append(on_gc)
     t0 = marks[0] = time.perf_counter()
     for k in range(steps):
         res = step()

@@ -157,21 +157,28 @@ def make_crop(kind=CROP_NONE, center=(0.0, 0.0, 0.0), rmin=0.0, rmax=0.0, zmin=0
 
 
 def colmajor(T) -> np.ndarray:
-    return np.ascontiguousarray(np.asarray(T, dtype=np.float64).T).ravel()
+    return np.asarray(T, dtype=np.float64).ravel(order="F")  # (a fresh, contiguous array: the transpose flattened row by row)
 
 
 def from_colmajor(v) -> np.ndarray:
-    return np.array(v, dtype=np.float64).reshape(4, 4).T.copy()
+    return np.ndarray((4, 4), np.float64, v, 0, None, "F").copy()  # a view of the 16 doubles as a column-major matrix, copied row-major
 
 
 def _d(a):
+    """(array kept alive by the caller, what ctypes passes for a `const double*`).  `ndarray.ctypes.data_as` costs ~5 us per call -- more than
+    everything else a registration call does on the host -- so small writable arrays are handed over as a ctypes array over their buffer (~1 us)."""
     if a is None:
         return None, None
     a = np.ascontiguousarray(a, dtype=np.float64)
     if a.size == 0:  # numpy may hand out a NULL data pointer for empty arrays; the ABI reads NULL as "absent"
         a = np.zeros((0, 3), dtype=np.float64)
         return a, C.cast(_EMPTY, _dp)
+    if a.size <= 64 and a.flags.writeable:  # poses, velocities, 6x6 matrices: where the call's own cost is what counts
+        return a, (C.c_double * a.size).from_buffer(a)
     return a, a.ctypes.data_as(_dp)
+
+
+_IDENTITY16 = (C.c_double * 16)(*np.eye(4).ravel())  # init = None of the registration calls (read-only for the library)
 
 
 class Backend:
@@ -306,7 +313,7 @@ class Backend:
         src, sp = _d(np.asarray(src).reshape(-1, 3))
         tgt, tp = _d(np.asarray(tgt).reshape(-1, 3))
         nrm, npp = _d(None if tgt_normals is None else np.asarray(tgt_normals).reshape(-1, 3))
-        T0, ip = _d(colmajor(np.eye(4) if init is None else init))
+        T0, ip = (None, _IDENTITY16) if init is None else _d(colmajor(init))
         p = self._params(max_corr, max_iter, rel_fitness, rel_rmse)
         out = IcpResult()
         self._ck(self.lib.o3ds_icp_point_to_plane(self.h, sp, len(src), tp, npp, len(tgt), ip, C.byref(p), C.byref(out)))
@@ -314,7 +321,7 @@ class Backend:
 
     def icp_point_to_plane_dev(self, source: int, target: int, max_corr, init=None, max_iter=30, rel_fitness=1e-6,
                                rel_rmse=1e-6, target_crop: Crop | None = None):
-        T0, ip = _d(colmajor(np.eye(4) if init is None else init))
+        T0, ip = (None, _IDENTITY16) if init is None else _d(colmajor(init))
         p = self._params(max_corr, max_iter, rel_fitness, rel_rmse)
         out = IcpResult()
         self._ck(self.lib.o3ds_icp_point_to_plane_dev(self.h, source, target, C.byref(target_crop) if target_crop else None, ip,
@@ -340,7 +347,7 @@ class Backend:
     def icp_point_to_point(self, src, tgt, max_corr, init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6):
         src, sp = _d(np.asarray(src).reshape(-1, 3))
         tgt, tp = _d(np.asarray(tgt).reshape(-1, 3))
-        T0, ip = _d(colmajor(np.eye(4) if init is None else init))
+        T0, ip = (None, _IDENTITY16) if init is None else _d(colmajor(init))
         p = self._params(max_corr, max_iter, rel_fitness, rel_rmse, ICP_POINT_TO_POINT)
         out = IcpResult()
         self._ck(self.lib.o3ds_icp_point_to_point(self.h, sp, len(src), tp, len(tgt), ip, C.byref(p), C.byref(out)))
@@ -348,7 +355,7 @@ class Backend:
 
     def icp_point_to_point_dev(self, source: int, target: int, max_corr, init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6,
                                target_crop: Crop | None = None):
-        T0, ip = _d(colmajor(np.eye(4) if init is None else init))
+        T0, ip = (None, _IDENTITY16) if init is None else _d(colmajor(init))
         p = self._params(max_corr, max_iter, rel_fitness, rel_rmse, ICP_POINT_TO_POINT)
         out = IcpResult()
         self._ck(self.lib.o3ds_icp_point_to_point_dev(self.h, source, target, C.byref(target_crop) if target_crop else None, ip,
@@ -360,7 +367,7 @@ class Backend:
         sn, snp = _d(None if src_normals is None else np.asarray(src_normals).reshape(-1, 3))
         tgt, tp = _d(np.asarray(tgt).reshape(-1, 3))
         tn, tnp = _d(None if tgt_normals is None else np.asarray(tgt_normals).reshape(-1, 3))
-        T0, ip = _d(colmajor(np.eye(4) if init is None else init))
+        T0, ip = (None, _IDENTITY16) if init is None else _d(colmajor(init))
         p = self._params(max_corr, max_iter, rel_fitness, rel_rmse, ICP_GENERALIZED)
         out = IcpResult()
         self._ck(self.lib.o3ds_icp_generalized(self.h, sp, snp, len(src), tp, tnp, len(tgt), ip, C.byref(p), C.byref(out)))
@@ -368,7 +375,7 @@ class Backend:
 
     def icp_generalized_dev(self, source: int, target: int, max_corr, init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6,
                             target_crop: Crop | None = None):
-        T0, ip = _d(colmajor(np.eye(4) if init is None else init))
+        T0, ip = (None, _IDENTITY16) if init is None else _d(colmajor(init))
         p = self._params(max_corr, max_iter, rel_fitness, rel_rmse, ICP_GENERALIZED)
         out = IcpResult()
         self._ck(self.lib.o3ds_icp_generalized_dev(self.h, source, target, C.byref(target_crop) if target_crop else None, ip,
@@ -392,7 +399,7 @@ class Backend:
 
     def icp_begin(self, source: int, target: int, max_corr, init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6,
                   target_crop: Crop | None = None, method=ICP_POINT_TO_PLANE):
-        T0, ip = _d(colmajor(np.eye(4) if init is None else init))
+        T0, ip = (None, _IDENTITY16) if init is None else _d(colmajor(init))
         p = self._params(max_corr, max_iter, rel_fitness, rel_rmse, method)
         self._ck(self.lib.o3ds_icp_begin(self.h, source, target, C.byref(target_crop) if target_crop else None, ip, C.byref(p)))
 
