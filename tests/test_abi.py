@@ -90,3 +90,41 @@ def test_no_hand_written_kernel_spills_registers():
     assert not spilling, spilling
     fused = [v for k, v in ours.items() if "icp_fused_kernel" in k]
     assert len(fused) == 8 and all(v["vgpr"] <= 128 and v["occupancy"] >= 4 for v in fused), fused
+
+
+def test_poses_cross_the_ctypes_boundary_column_major_and_unchanged():
+    """The Python side hands 4x4 poses to the library as 16 doubles in column-major order (Eigen's layout, o3ds_backend.h) and reads
+    results back the same way.  The marshalling takes short cuts (one `ravel(order="F")`, a ctypes array over the buffer instead of
+    `ndarray.ctypes.data_as`, a constant identity, a view for the way back): every path must deliver the same doubles."""
+    import numpy as np
+
+    rng = np.random.default_rng(3)
+    T = rng.normal(size=(4, 4))
+    want = [T[r, c] for c in range(4) for r in range(4)]
+    for src in (T, np.asfortranarray(T), T.astype(np.float32).astype(np.float64), T[::1], [list(r) for r in T]):
+        flat = backend.colmajor(src)
+        assert flat.flags["C_CONTIGUOUS"] and flat.dtype == np.float64 and flat.shape == (16,)
+        ref = [np.asarray(src, dtype=np.float64)[r, c] for c in range(4) for r in range(4)]
+        assert list(flat) == ref
+        keep, ptr = backend._d(flat)
+        assert [ptr[i] for i in range(16)] == ref
+    assert list(backend.colmajor(T)) == want
+    ro = backend.colmajor(T)
+    ro.flags.writeable = False  # read-only arrays take the slower pointer path
+    keep, ptr = backend._d(ro)
+    assert [ptr[i] for i in range(16)] == want
+    big = rng.normal(size=(1000, 3))  # large arrays are passed in place, not copied
+    keep, ptr = backend._d(big)
+    assert keep is big and [ptr[i] for i in range(6)] == list(big.ravel()[:6])
+    keep, ptr = backend._d(np.zeros((0, 3)))
+    assert ptr is not None and keep.shape == (0, 3)  # the ABI reads NULL as "absent": empty clouds get a placeholder
+    assert backend._d(None) == (None, None)
+    assert [backend._IDENTITY16[i] for i in range(16)] == [1.0 if i % 5 == 0 else 0.0 for i in range(16)]
+    res = backend.IcpResult()
+    for i, v in enumerate(want):
+        res.transformation[i] = v
+    back = backend.from_colmajor(res.transformation)
+    assert back.flags["C_CONTIGUOUS"] and back.flags["OWNDATA"]
+    np.testing.assert_array_equal(back, T)
+    res.transformation[0] = 123.0  # the result is a copy, not a view of the struct
+    assert back[0, 0] == T[0, 0]
