@@ -784,7 +784,7 @@ def main():
 
     if rank == 0:
         res, elapsed = r32["res"], r32["elapsed"]
-        classic = (world > 1 and os.environ.get("O3DS_SHARDED_FORM") == "classic") or (world == 1 and os.environ.get("O3DS_ICP_MODE") == "launch")
+        classic = world > 1 and os.environ.get("O3DS_SHARDED_FORM") == "classic"  # (the shipped library has no O3DS_ICP_MODE switch: always the fused form)
         pass_kernel = "icp_accumulate_kernel" if classic else "icp_fused_kernel"
         dt_gt, dr_gt = syn.se3_error(res["transformation"], T_gt)
 

@@ -132,20 +132,31 @@ class BackendError(RuntimeError):
         self.code = code
 
 
-def load():
-    """dlopen the HIP backend; raises if it has not been built (no fallback)."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise ImportError(f"{LIB_PATH} not built -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+LIB_AB_PATH = os.path.join(_PKG, "lib", "libo3ds_backend_ab.so")  # built with -DO3DS_AB_SWITCHES: the O3DS_* A/B levers exist only there
+_lib_ab = None
+
+
+def load(ab: bool = False):
+    """dlopen the HIP backend; raises if it has not been built (no fallback).  ab=True: the twin library whose A/B switches are compiled
+    in (tests and experiment scripts; the shipped library does not read them)."""
+    global _lib, _lib_ab
+    cur = _lib_ab if ab else _lib
+    if cur is None:
+        path = LIB_AB_PATH if ab and not os.environ.get("O3DS_BACKEND_LIB") else LIB_PATH
+        if not os.path.exists(path):
+            raise ImportError(f"{path} not built -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950); there is no CPU fallback")
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        _lib = L
-    return _lib
+        cur = L
+        if ab:
+            _lib_ab = L
+        else:
+            _lib = L
+    return cur
 
 
 def make_crop(kind=CROP_NONE, center=(0.0, 0.0, 0.0), rmin=0.0, rmax=0.0, zmin=0.0, zmax=0.0, invert=False) -> Crop:
@@ -184,8 +195,8 @@ _IDENTITY16 = (C.c_double * 16)(*np.eye(4).ravel())  # init = None of the regist
 class Backend:
     """One handle = one HIP stream + scratch (not re-entrant; one per thread)."""
 
-    def __init__(self, device_id: int = 0, precision: int = PRECISION_F32):
-        self.lib = load()
+    def __init__(self, device_id: int = 0, precision: int = PRECISION_F32, ab: bool = False):
+        self.lib = load(ab)
         self.h = _H()
         rc = self.lib.o3ds_create(device_id, C.byref(self.h))
         if rc != OK:
@@ -383,6 +394,7 @@ class Backend:
         return self._result(out)
 
     ICP_SUMS_DOUBLES = 512
+    ICP_PASS_MAX_QUERIES = 262144  # O3DS_ICP_PASS_MAX_QUERIES
 
     def icp_pass(self, first: int, count: int, n_src_total: int, sums_in_ptr: int | None, sums_out_ptr: int, sums_next_ptr: int):
         """fused step-wise form: one kernel; the caller all-reduces sums_out afterwards (device pointers to 512 doubles each)"""

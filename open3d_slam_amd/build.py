@@ -20,29 +20,43 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
+LIB_AB = os.path.join(LIB_DIR, "libo3ds_backend_ab.so")  # the same source with -DO3DS_AB_SWITCHES: A/B levers and debugging aids read from
+                                                          # the environment (tests / scripts only; the shipped library has none)
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
     srcs = glob.glob(os.path.join(CSRC, "*")) + [os.path.join(_PKG, "..", "include", "o3ds_backend.h")]
-    return any(os.path.getmtime(s) > t for s in srcs)
+    for lib in (LIB, LIB_AB):
+        if not os.path.exists(lib):
+            return True
+        t = os.path.getmtime(lib)
+        if any(os.path.getmtime(s) > t for s in srcs):
+            return True
+    return False
+
+
+def _cmd(out: str, extra=()) -> list:
+    return [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Rpass-analysis=kernel-resource-usage",
+            # leading pointer / scalar kernel arguments arrive in SGPRs with the dispatch instead of through a first scalar load
+            # (icp_fused_kernel issues its state loads from them; code for firmware without the feature is emitted alongside)
+            "-mllvm", "-amdgpu-kernarg-preload-count=8", *extra, "-o", out, os.path.join(CSRC, "backend.hip")]
 
 
 def build_backend(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Rpass-analysis=kernel-resource-usage",
-           # leading pointer / scalar kernel arguments arrive in SGPRs with the dispatch instead of through a first scalar load
-           # (icp_fused_kernel issues its state loads from them; code for firmware without the feature is emitted alongside)
-           "-mllvm", "-amdgpu-kernarg-preload-count=8", "-o", LIB,
-           os.path.join(CSRC, "backend.hip")]
-    if verbose:
-        print(" ".join(cmd))
-    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    if p.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + p.stderr[-4000:])
-    _write_resources(p.stderr)
+    jobs = [(_cmd(LIB), LIB), (_cmd(LIB_AB, ["-DO3DS_AB_SWITCHES"]), LIB_AB)]
+    procs = []
+    for cmd, _ in jobs:  # the two compilations side by side
+        if verbose:
+            print(" ".join(cmd))
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate() for p in procs]
+    for (cmd, lib), p, (_, err) in zip(jobs, procs, outs):
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed ({os.path.basename(lib)}):\n" + err[-4000:])
+    _write_resources(outs[0][1])
     return LIB
 
 

@@ -1,6 +1,7 @@
 // backend.hip -- C-ABI (include/o3ds_backend.h) of the gfx950 scan-matching / map-fusion backend.
 // Host-side orchestration only; all arithmetic is in icp_kernels.hpp / cloud_kernels.hpp.
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <atomic>
@@ -28,6 +29,16 @@ using namespace o3ds;
 namespace {
 
 thread_local std::string g_thread_error;
+
+// A/B levers, tuning knobs and debugging aids (O3DS_ICP_MODE, O3DS_ICP_SETS, O3DS_SUM_NO_SPLIT, O3DS_VOXEL_SORT, O3DS_CARVE_SORT, ...) exist
+// only in the library built with -DO3DS_AB_SWITCHES (lib/libo3ds_backend_ab.so: what the A/B tests and the experiment scripts load).  The
+// shipped library reads two environment variables, both memory sizing: O3DS_POOL_CAP_MB and O3DS_ARENA_MB -- a drop-in library's results
+// and code paths must not depend on its host process's environment.
+#ifdef O3DS_AB_SWITCHES
+inline const char* ab_getenv(const char* name) { return getenv(name); }
+#else
+inline const char* ab_getenv(const char*) { return nullptr; }
+#endif
 
 struct CloudRec {
   size_t n = 0;
@@ -392,7 +403,7 @@ struct DevGuard {
 int arena_alloc(o3ds_handle h, void** out, size_t bytes) {
   bytes = (bytes + 255) & ~(size_t)255;
   if (bytes == 0) bytes = 256;
-  static const bool no_reuse = getenv("O3DS_NO_ARENA") != nullptr;  // debugging aid: every temporary is its own pool allocation
+  static const bool no_reuse = ab_getenv("O3DS_NO_ARENA") != nullptr;  // debugging aid: every temporary is its own pool allocation
   if (no_reuse) {
     char* p = nullptr;
     if (dev_alloc(h, (void**)&p, bytes) != hipSuccess) return fail(h, O3DS_ERR_OOM, "arena: out of memory");
@@ -419,7 +430,7 @@ int arena_alloc(o3ds_handle h, void** out, size_t bytes) {
     hipError_t e = dev_alloc(h, (void**)&p, want);
     if (e != hipSuccess) return fail(h, O3DS_ERR_OOM, std::string("arena: ") + hipGetErrorString(e));
     h->arena_blocks.emplace_back(p, want);
-    if (getenv("O3DS_ARENA_LOG"))
+    if (ab_getenv("O3DS_ARENA_LOG"))
       fprintf(stderr, "[arena] new block %zu MB (request %zu B, blocks now %zu, prev off %zu)\n", want >> 20, bytes, h->arena_blocks.size(), h->arena_off);
   }
 }
@@ -427,7 +438,7 @@ struct ArenaScope {
   o3ds_handle h;
   explicit ArenaScope(o3ds_handle hh) : h(hh) {
     if (h && h->arena_depth++ == 0) {
-      if (getenv("O3DS_NO_ARENA")) {
+      if (ab_getenv("O3DS_NO_ARENA")) {
         for (auto& b : h->arena_blocks) dev_free(h, b.first);
         h->arena_blocks.clear();
       }
@@ -445,7 +456,7 @@ struct ArenaScope {
 };
 // debugging aid: O3DS_SYNC_MASK re-inserts a stream synchronisation at the end of selected internal steps
 inline void dbg_sync(o3ds_handle h, int bit) {
-  static const int mask = getenv("O3DS_SYNC_MASK") ? atoi(getenv("O3DS_SYNC_MASK")) : 0;
+  static const int mask = ab_getenv("O3DS_SYNC_MASK") ? atoi(ab_getenv("O3DS_SYNC_MASK")) : 0;
   if (mask & bit) (void)hipStreamSynchronize(h->stream);
 }
 // tagged span marks on the handle's stream (only while profiling is enabled): begin and end alternate per tag
@@ -548,18 +559,35 @@ int wait_stream(o3ds_handle h) {
 // after the kernel's completion signal has made its way through the runtime (a few microseconds per registration of ~200).  A stamp
 // that does not show up within 50 ms (a faulted queue) falls back to the stream wait, which reports the error.
 constexpr int kSeqSlot = 8;
+constexpr int kWaitSpinUs = 20;
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  asm volatile("yield" ::: "memory");
+#else
+  std::atomic_signal_fence(std::memory_order_seq_cst);
+#endif
+}
 hipError_t wait_fused_state(o3ds_handle h, unsigned long long seq) {
-  static const bool watch = !(getenv("O3DS_ICP_WATCH_STATE") && atoi(getenv("O3DS_ICP_WATCH_STATE")) == 0);
+  static const bool watch = !(ab_getenv("O3DS_ICP_WATCH_STATE") && atoi(ab_getenv("O3DS_ICP_WATCH_STATE")) == 0);
   if (watch) {
     const volatile unsigned long long* w = (const volatile unsigned long long*)(h->h_pin + kPubOff + 16 * (size_t)kSeqSlot);
+    // spin for ~20 us (a steady pass launch is 10 us: the stamp of a registration that is about to finish shows up inside that), then
+    // give the core away between looks: SlamWrapper runs four to seven threads (SlamWrapper.cpp:227-236) and a GPU box grants its
+    // container a CPU quota -- a core that spins through a whole registration is a core the other worker does not get
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned int spins = 1;; ++spins) {
       if (*w == seq) {
         std::atomic_thread_fence(std::memory_order_acquire);
         return hipSuccess;
       }
-      __builtin_ia32_pause();
-      if ((spins & 0x3ffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
+      cpu_relax();
+      if ((spins & 0x3fu) == 0) {
+        const auto dt = std::chrono::steady_clock::now() - t0;
+        if (dt > std::chrono::milliseconds(50)) break;
+        if (dt > std::chrono::microseconds(kWaitSpinUs)) sched_yield();
+      }
     }
   }
   return hipStreamSynchronize(h->stream);
@@ -594,7 +622,7 @@ int build_grid_t(o3ds_handle h, const P4* pts, const P4* nrm, size_t n, double c
   if (n == 0) return fail(h, O3DS_ERR_EMPTY, "build_index: empty cloud");
   double mn[3], mx[3];
   int rc = O3DS_OK;
-  static const bool no_box_cache = getenv("O3DS_NO_BOX_CACHE") != nullptr;  // debugging aid: always reduce
+  static const bool no_box_cache = ab_getenv("O3DS_NO_BOX_CACHE") != nullptr;  // debugging aid: always reduce
   if (box && box->has_box && !no_box_cache) {
     for (int a = 0; a < 3; ++a) mn[a] = box->bmn[a], mx[a] = box->bmx[a];
   } else {
@@ -642,7 +670,7 @@ int build_grid_t(o3ds_handle h, const P4* pts, const P4* nrm, size_t n, double c
     h->cells_cap = cap;
     h->cells_clean = false;
   }
-  static const bool always_clear = getenv("O3DS_ALWAYS_CLEAR") != nullptr;  // debugging / A/B aid: do not rely on self-cleaning scratch
+  static const bool always_clear = ab_getenv("O3DS_ALWAYS_CLEAR") != nullptr;  // debugging / A/B aid: do not rely on self-cleaning scratch
   if (!h->cells_clean || always_clear) HIP_TRY(hipMemsetAsync(h->d_cells, 0, sizeof(int) * h->cells_cap, h->stream));
   h->cells_clean = false;
   counts = h->d_cells;
@@ -678,7 +706,7 @@ int build_index_t(o3ds_handle h, CloudRec& c, double cell) {
 
 // grid cell of a registration target = max_correspondence_distance / this (O3DS_INDEX_CELL_DIV: tuning experiments)
 double index_cell_div() {
-  static const double d = getenv("O3DS_INDEX_CELL_DIV") ? std::max(1.0, atof(getenv("O3DS_INDEX_CELL_DIV"))) : 4.0;
+  static const double d = ab_getenv("O3DS_INDEX_CELL_DIV") ? std::max(1.0, atof(ab_getenv("O3DS_INDEX_CELL_DIV"))) : 4.0;
   return d;
 }
 
@@ -725,7 +753,7 @@ int d2h_copy_widen(o3ds_handle h, double* h_dst, const float* d_src, size_t coun
   }
   return O3DS_OK;
 }
-static const bool kNarrowOnHost = getenv("O3DS_NO_HOST_NARROW") == nullptr;  // A/B switch
+static const bool kNarrowOnHost = ab_getenv("O3DS_NO_HOST_NARROW") == nullptr;  // A/B switch
 
 template <typename P4>
 int upload_array_t(o3ds_handle h, const double* host, size_t n, P4* d_out) {  // host double[3n] -> device P4[n]
@@ -1027,6 +1055,7 @@ void launch_fused(o3ds_handle h, const IcpFusedArgs& fa, bool crop, int nblocks,
 // the fused kernel serves ONE batch of 64 queries per workgroup (no batch loop: icp_pass_body, kSingle); its records go to slot
 // blockIdx % kFusedSlots, so the grid has no capacity to respect
 constexpr size_t kFusedMaxQueries = (size_t)4096 * 64;
+static_assert(kFusedMaxQueries == O3DS_ICP_PASS_MAX_QUERIES, "the limit the header documents");
 int fused_blocks(size_t count) { return (int)std::max<size_t>((count + 63) / 64, 1); }
 
 int pass_blocks(o3ds_handle h, size_t count) {
@@ -1062,7 +1091,7 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
   int rc = validate_icp(h, src, tgt, params);
   if (rc) return rc;
   const double r_hint = params->max_correspondence_distance;
-  static const double reuse_max = getenv("O3DS_INDEX_REUSE_MAX") ? atof(getenv("O3DS_INDEX_REUSE_MAX")) : 0.75;  // tuning experiments
+  static const double reuse_max = ab_getenv("O3DS_INDEX_REUSE_MAX") ? atof(ab_getenv("O3DS_INDEX_REUSE_MAX")) : 0.75;  // tuning experiments
   if (!tgt->has_index || (tgt->nrm && !tgt->snrm) || (tgt->index_byproduct && (tgt->grid.cell < r_hint / 8.0 || tgt->grid.cell > r_hint * reuse_max))) {
     rc = build_index(h, *tgt, params->max_correspondence_distance / index_cell_div());
     if (rc) return rc;
@@ -1142,7 +1171,7 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
       if (params->method == O3DS_ICP_POINT_TO_POINT)
         for (int k = 0; k < 9; ++k) bound[k] = P * P;  // information matrix: terms 0..8 are q_a q_b or q_a (<= P^2 either way)
     }
-    const bool no_split = getenv("O3DS_SUM_NO_SPLIT") != nullptr;  // diagnostic: plain f64 sums
+    const bool no_split = ab_getenv("O3DS_SUM_NO_SPLIT") != nullptr;  // diagnostic: plain f64 sums
     for (int k = 0; k < kRec; ++k) {
       int e = 0;
       (void)std::frexp(nn * bound[k], &e);                      // n * bound < 2^e
@@ -1161,7 +1190,7 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
   a.gicp_k = 1.0 - h->gicp_epsilon;
   a.state = h->d_state;
   a.partials = h->d_partials;
-  a.debug = getenv("O3DS_DEBUG_ACC") ? atoi(getenv("O3DS_DEBUG_ACC")) : 0;
+  a.debug = ab_getenv("O3DS_DEBUG_ACC") ? atoi(ab_getenv("O3DS_DEBUG_ACC")) : 0;
   h->pass = a;
   h->params = *params;
   h->session = true;
@@ -1209,7 +1238,13 @@ int gicp_knn_normals(o3ds_handle h, CloudRec& c);  // defined after normals_t
 
 extern "C" {
 
-const char* o3ds_version(void) { return "o3ds_backend 0.1 (gfx950, hip, f32/f64 storage, f64 accumulate)"; }
+const char* o3ds_version(void) {
+#ifdef O3DS_AB_SWITCHES
+  return "o3ds_backend 0.2 (gfx950, hip, f32/f64 storage, f64 accumulate; A/B switches compiled in)";
+#else
+  return "o3ds_backend 0.2 (gfx950, hip, f32/f64 storage, f64 accumulate)";
+#endif
+}
 
 const char* o3ds_last_error(o3ds_handle h) { return h ? h->err.c_str() : g_thread_error.c_str(); }
 
@@ -1238,16 +1273,16 @@ int o3ds_create(int device_id, o3ds_handle* out) {
       o3ds_destroy(h);
       return fail(nullptr, O3DS_ERR_OOM, "o3ds_create: scratch allocation failed");
     }
-    if (const char* e = getenv("O3DS_ICP_SETS")) h->sets = atoi(e) != 0;
-    if (const char* e = getenv("O3DS_SET_GAIN")) h->set_gain = (float)atof(e);
-    if (const char* e = getenv("O3DS_SET_MIN")) h->set_min = (float)atof(e);
-    if (const char* e = getenv("O3DS_SET_CAP")) h->set_cap = (float)atof(e);
-    if (const char* e = getenv("O3DS_ICP_MODE")) {
+    if (const char* e = ab_getenv("O3DS_ICP_SETS")) h->sets = atoi(e) != 0;
+    if (const char* e = ab_getenv("O3DS_SET_GAIN")) h->set_gain = (float)atof(e);
+    if (const char* e = ab_getenv("O3DS_SET_MIN")) h->set_min = (float)atof(e);
+    if (const char* e = ab_getenv("O3DS_SET_CAP")) h->set_cap = (float)atof(e);
+    if (const char* e = ab_getenv("O3DS_ICP_MODE")) {
       h->fused = std::string(e) != "launch";
     }
   }
-  if (const char* e = getenv("O3DS_DEBUG_UPDATE")) h->debug_update = atoi(e);
-  if (const char* e = getenv("O3DS_PASS_ROWS")) h->pass_rows = std::min(std::max(atoi(e), 1), kMaxPassBlocks);
+  if (const char* e = ab_getenv("O3DS_DEBUG_UPDATE")) h->debug_update = atoi(e);
+  if (const char* e = ab_getenv("O3DS_PASS_ROWS")) h->pass_rows = std::min(std::max(atoi(e), 1), kMaxPassBlocks);
   *out = h;
   return O3DS_OK;
 }
@@ -1411,7 +1446,7 @@ int o3ds_cloud_free(o3ds_handle h, o3ds_cloud id) {
   if (it == h->clouds.end()) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_free: unknown cloud id");
   // no host synchronisation: the buffers go back to the handle's allocator behind whatever still reads them on this stream
   // (o3ds_set_stream synchronises the stream it leaves).  O3DS_SYNC_ON_FREE=1 restores the wait (six of them per lidar frame).
-  static const bool sync_on_free = getenv("O3DS_SYNC_ON_FREE") != nullptr;
+  static const bool sync_on_free = ab_getenv("O3DS_SYNC_ON_FREE") != nullptr;
   if (sync_on_free) (void)hipStreamSynchronize(h->stream);
   free_cloud(h, it->second);
   h->clouds.erase(it);
@@ -1657,7 +1692,8 @@ int o3ds_icp_pass(o3ds_handle h, size_t first, size_t count, size_t n_src_total,
   if (!h->session) return fail(h, O3DS_ERR_INVALID_ARG, "icp_pass: no session (call o3ds_icp_begin)");
   if (!d_sums_out || !d_sums_next || (h->session_launches > 0 && !d_sums_in)) return fail(h, O3DS_ERR_INVALID_ARG, "icp_pass: null sums buffer");
   if (first + count > h->session_n_src) return fail(h, O3DS_ERR_INVALID_ARG, "icp_pass: range outside source");
-  if (count > kFusedMaxQueries) return fail(h, O3DS_ERR_CAPACITY, "icp_pass: at most 262144 source points per call (split the range, or use o3ds_icp_accumulate)");
+  if (count > kFusedMaxQueries)
+    return fail(h, O3DS_ERR_CAPACITY, "icp_pass: at most O3DS_ICP_PASS_MAX_QUERIES (262144) source points per call: use o3ds_icp_accumulate / o3ds_icp_update for larger shards");
   IcpFusedArgs fa{};
   fa.pass = h->pass;
   fa.pass.first = first;
@@ -1910,16 +1946,16 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
     fa.init = *h->h_state;
     const int total = params->max_iteration + 2;
     // O3DS_FUSED_TRACE=<file>: phase timestamps of every workgroup of launch 5 (development aid, see scripts/fused_trace.py)
-    const char* trace_path = getenv("O3DS_FUSED_TRACE");
+    const char* trace_path = ab_getenv("O3DS_FUSED_TRACE");
     unsigned long long* d_trace = nullptr;
-    const int trace_launch = getenv("O3DS_FUSED_TRACE_LAUNCH") ? atoi(getenv("O3DS_FUSED_TRACE_LAUNCH")) : 5;
+    const int trace_launch = ab_getenv("O3DS_FUSED_TRACE_LAUNCH") ? atoi(ab_getenv("O3DS_FUSED_TRACE_LAUNCH")) : 5;
     if (trace_path && total > trace_launch + 1) {
       HIP_TRY(hipMalloc((void**)&d_trace, sizeof(unsigned long long) * 16 * nb));
       HIP_TRY(hipMemset(d_trace, 0, sizeof(unsigned long long) * 16 * nb));
     }
     // O3DS_ICP_STATS=1: per-launch counters of how the queries were served (verified from their candidate set / searched / sets left /
     // stage-3 queries), printed to stderr after the registration (development aid)
-    static const bool want_stats = getenv("O3DS_ICP_STATS") != nullptr;
+    static const bool want_stats = ab_getenv("O3DS_ICP_STATS") != nullptr;
     unsigned long long* d_stats = nullptr;
     if (want_stats) {
       HIP_TRY(hipMalloc((void**)&d_stats, sizeof(unsigned long long) * 4 * (size_t)total));
@@ -1960,6 +1996,7 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = wait_fused_state(h, h->fused_seq);
         if (e != hipSuccess) {
+          (void)hipStreamSynchronize(h->stream);
           (void)hipMemset(h->d_fused + kFusedSlotsOff, 0, 3 * kFusedSlotBufBytes);
           h->fused_launches = 0;
           if (d_trace) (void)hipFree(d_trace);
@@ -1970,6 +2007,9 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
       if (h->h_state->done) break;
     }
     h->fused_chunk_hint[target_crop ? 1 : 0] = std::min(std::max(h->h_state->iterations + 3, 4), 12);  // iterations + 2 launches were needed
+    // (development aids below read device memory with null-stream copies: the handle's stream is non-blocking and the pinned stamp may have
+    // been seen while the last launch was still draining)
+    if (d_stats || d_trace) (void)hipStreamSynchronize(h->stream);
     if (d_stats) {
       std::vector<unsigned long long> t((size_t)4 * total);
       (void)hipMemcpy(t.data(), d_stats, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
@@ -2118,7 +2158,7 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
   if (n == 0) return O3DS_OK;
   double ox = 0, oy = 0, oz = 0;
   // VoxelDownSample proper: no sort (cloud_kernels.hpp, VoxTable); O3DS_VOXEL_SORT=1 keeps the sort-based path below for A/B runs
-  static const bool voxel_sort = getenv("O3DS_VOXEL_SORT") != nullptr;
+  static const bool voxel_sort = ab_getenv("O3DS_VOXEL_SORT") != nullptr;
   const bool table_path = mode == 0 && !voxel_sort && n < ((size_t)1 << 30);
   double* d_box = nullptr;  // table path: the box stays on the device until the call's one synchronisation (bbox_final_kernel)
   if (table_path) {
@@ -2172,7 +2212,7 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
     TMP_ALLOC(members, sizeof(uint32_t) * n);
     VoxTable t{(unsigned long long*)tab, (unsigned int*)(tab + 8 * cap), (unsigned int*)(tab + 12 * cap), (unsigned int*)(tab + 16 * cap),
                (unsigned int)(cap - 1)};
-    static const bool always_clear = getenv("O3DS_ALWAYS_CLEAR") != nullptr;
+    static const bool always_clear = ab_getenv("O3DS_ALWAYS_CLEAR") != nullptr;
     if (!h->voxtab_clean || always_clear) HIP_TRY(hipMemsetAsync(tab, 0xff, 16 * cap + 16, h->stream));
     h->voxtab_clean = false;
     vox_insert_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>((const P4*)in.pts, n, d_box, voxel, crop, filter ? 1 : 0, t, slot_of);
@@ -2243,7 +2283,7 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
   TMP_ALLOC(d_scalar, sizeof(unsigned long long));
   // The sorted (key, index) list: by merging when the input is a map the previous merge left in key order plus new points (only the
   // new keys are sorted), by one radix sort of everything otherwise.  Same arrays either way (cloud_kernels.hpp, merge_class_kernel).
-  static const bool no_incremental = getenv("O3DS_NO_INCREMENTAL_MERGE") != nullptr;  // A/B and debugging
+  static const bool no_incremental = ab_getenv("O3DS_NO_INCREMENTAL_MERGE") != nullptr;  // A/B and debugging
   bool merged = false;
   if (mode == 1 && !filter && merge_np >= 0 && !no_incremental && n < ((size_t)1 << 31) && (size_t)merge_np + merge_nv <= n) {
     const size_t np = (size_t)merge_np, nv = merge_nv;
@@ -2280,7 +2320,7 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
       if (nx > 1) {  // the only sort: the points that are new to the volume -- tile sort in LDS, then merge passes (cloud_kernels.hpp)
         TMP_ALLOC(xk2, sizeof(unsigned long long) * nx);
         TMP_ALLOC(xv2, sizeof(uint32_t) * nx);
-        static const bool lib_sort = getenv("O3DS_MERGE_LIBRARY_SORT") != nullptr;  // A/B: rocPRIM's radix sort of the same pairs
+        static const bool lib_sort = ab_getenv("O3DS_MERGE_LIBRARY_SORT") != nullptr;  // A/B: rocPRIM's radix sort of the same pairs
         if (lib_sort) {
           size_t tb = 0;
           HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, xk, xk2, xv, xv2, nx, 0, 63, h->stream));
@@ -2293,7 +2333,7 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
           uint32_t *va = xv2, *vb = xv;
           sort_tile_kernel<<<(unsigned int)((nx + kSortTile - 1) / kSortTile), kBlock, 0, h->stream>>>(xk, xv, nx, ka, va);
           static const int ways = [] {  // tuning experiments: 2, 4, 8 or 16 runs merged per pass; anything else is ignored (a width that
-            const int w = getenv("O3DS_SORT_WAYS") ? atoi(getenv("O3DS_SORT_WAYS")) : kSortWays;  // grows by 3 under an 8-way kernel sorts wrongly)
+            const int w = ab_getenv("O3DS_SORT_WAYS") ? atoi(ab_getenv("O3DS_SORT_WAYS")) : kSortWays;  // grows by 3 under an 8-way kernel sorts wrongly)
             return (w == 2 || w == 4 || w == 8 || w == 16) ? w : kSortWays;
           }();
           for (size_t width = kSortTile; width < nx; width *= (size_t)ways) {  // nx < 2^31 on this path
@@ -2420,7 +2460,7 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn, bool knn_ra
       return rc;
     }
     const double avg = occ ? (double)c.n / (double)occ : 1.0;
-    static const double cell_scale = getenv("O3DS_NRM_CELL_SCALE") ? atof(getenv("O3DS_NRM_CELL_SCALE")) : 1.0;  // tuning experiments
+    static const double cell_scale = ab_getenv("O3DS_NRM_CELL_SCALE") ? atof(ab_getenv("O3DS_NRM_CELL_SCALE")) : 1.0;  // tuning experiments
     double cell = cell_scale * tmp.grid.cell * std::sqrt(std::max(1.0, (double)max_nn) / (3.14159265358979 * avg));
     cell = std::min(std::max(cell, radius / 64.0), radius);
     rc = build_index_t<P4>(h, tmp, cell);
@@ -2435,9 +2475,11 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn, bool knn_ra
     h->nrm_n = c.n;
     h->nrm_age = 0;
   }
-  if (!c.nrm) HIP_TRY(dev_alloc(h, (void**)&c.nrm, sizeof(P4) * c.n));
+  // (a map keeps room behind its points, CloudRec::cap: normals that arrive later get the same room, the in-place append of
+  // o3ds_map_insert_scan writes both arrays behind the last point)
+  if (!c.nrm) HIP_TRY(dev_alloc(h, (void**)&c.nrm, sizeof(P4) * std::max(c.n, c.cap)));
   const int rmax = std::max(1, (int)std::ceil(radius / tmp.grid.cell));
-  static const bool nrm_debug = getenv("O3DS_NRM_DEBUG") != nullptr;  // debugging aid: where a fault happens
+  static const bool nrm_debug = ab_getenv("O3DS_NRM_DEBUG") != nullptr;  // debugging aid: where a fault happens
   if (nrm_debug) {
     const hipError_t e = hipStreamSynchronize(h->stream);
     fprintf(stderr, "[normals] n %zu radius %g max_nn %d reuse %d grid %d x %d x %d cell %g rmax %d (index built: %s)\n", c.n, radius, max_nn, (int)reuse,
@@ -2463,7 +2505,7 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn, bool knn_ra
     const unsigned int gsz = (unsigned int)((c.n + o3ds::kNrmPointsPerBlock - 1) / o3ds::kNrmPointsPerBlock);
 #ifdef O3DS_NRM_CHECK
     unsigned long long* d_ws = nullptr;
-    if (getenv("O3DS_NRM_STATS_FILE")) {
+    if (ab_getenv("O3DS_NRM_STATS_FILE")) {
       HIP_TRY(hipMalloc((void**)&d_ws, sizeof(unsigned long long) * o3ds::kNrmStatWords * ((size_t)o3ds::kNrmWaves * gsz)));
       HIP_TRY(hipMemset(d_ws, 0, sizeof(unsigned long long) * o3ds::kNrmStatWords * ((size_t)o3ds::kNrmWaves * gsz)));
     }
@@ -2494,7 +2536,7 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn, bool knn_ra
   HIP_TRY(hipGetLastError());
   dbg_sync(h, 16);
 #ifdef O3DS_NRM_CHECK
-  if (const char* sf = getenv("O3DS_NRM_STATS_FILE")) {
+  if (const char* sf = ab_getenv("O3DS_NRM_STATS_FILE")) {
     const unsigned int gsz = (unsigned int)((c.n + o3ds::kNrmPointsPerBlock - 1) / o3ds::kNrmPointsPerBlock);
     unsigned long long* d_ws = nullptr;
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -2575,7 +2617,7 @@ int carve_t(o3ds_handle h, CloudRec& map, const CloudRec& scan, const double T[1
   // key order, and a stable PARTITION by "inside" (one scan, one scatter) gives what the stable sort gives.  Whether they really were in order
   // -- another voxel size, a map assembled otherwise, a mean that rounding put across a voxel boundary -- is checked on the device while the
   // segment heads are formed; if not, the library sort runs as before (O3DS_CARVE_SORT=1 forces it, for A/B runs).
-  static const bool carve_sort = getenv("O3DS_CARVE_SORT") != nullptr;
+  static const bool carve_sort = ab_getenv("O3DS_CARVE_SORT") != nullptr;
   const bool try_partition = !carve_sort && map.vox_first >= 0 && (size_t)map.vox_first + map.vox_count == n && n < ((size_t)1 << 31);
   int rc = O3DS_OK;
   int n_seg = 0;

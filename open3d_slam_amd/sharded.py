@@ -127,8 +127,12 @@ class ShardedIcp:
             be.icp_pass(first, count, n_total, prev.data_ptr() if p > 0 else None, out.data_ptr(), nxt.data_ptr())
             return out
 
+        # the fused pass serves at most ICP_PASS_MAX_QUERIES points per call (o3ds_backend.h): larger shards take the classic triple,
+        # whose pass kernel loops -- on EVERY rank (count differs by at most one between ranks of a "source" split, but the decision must
+        # be the same everywhere: the two forms issue different collectives)
+        fused = self.fused and -(-n_src // (self.world if self.mode == "source" else 1)) <= be.ICP_PASS_MAX_QUERIES
         with self.torch.cuda.stream(self.tstream):
-            if not self.fused:
+            if not fused:
                 run_sharded_loop(accumulate, all_reduce, update, be.icp_done, max_iter, check_every)
                 return be.icp_finish()
             for t in self.sums:

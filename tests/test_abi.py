@@ -128,3 +128,20 @@ def test_poses_cross_the_ctypes_boundary_column_major_and_unchanged():
     np.testing.assert_array_equal(back, T)
     res.transformation[0] = 123.0  # the result is a copy, not a view of the struct
     assert back[0, 0] == T[0, 0]
+
+
+def test_the_shipped_library_reads_no_ab_switch_from_the_environment():
+    """A drop-in library's results and code paths must not depend on the environment of the process that loads it: the A/B levers,
+    tuning knobs and debugging aids (O3DS_ICP_MODE, O3DS_ICP_SETS, O3DS_SUM_NO_SPLIT, O3DS_VOXEL_SORT, ...) are compiled into
+    lib/libo3ds_backend_ab.so only (-DO3DS_AB_SWITCHES, loaded with Backend(..., ab=True)); the shipped library knows two names, both
+    memory sizing.  Checked on the binaries: the names a library can look up are the string constants it holds."""
+    from open3d_slam_amd import build
+
+    def names(path):
+        return set(m.decode() for m in re.findall(rb"O3DS_[A-Z][A-Z0-9_]+", open(path, "rb").read()))
+
+    shipped, ab = names(build.LIB), names(build.LIB_AB)
+    allowed = {"O3DS_POOL_CAP_MB", "O3DS_ARENA_MB", "O3DS_ICP_PASS_MAX_QUERIES"}  # (the last one: an error text quoting the header's constant)
+    assert shipped <= allowed, shipped - allowed
+    assert {"O3DS_ICP_MODE", "O3DS_ICP_SETS", "O3DS_SUM_NO_SPLIT", "O3DS_VOXEL_SORT", "O3DS_CARVE_SORT", "O3DS_MERGE_LIBRARY_SORT"} <= ab
+    assert b"A/B switches" in backend.load(ab=True).o3ds_version() and b"A/B switches" not in backend.load().o3ds_version()

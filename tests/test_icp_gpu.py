@@ -274,7 +274,7 @@ def test_two_launch_mode_is_bitwise_the_default(oracle, small_c2, backend_f32, m
     order as the default fused form (slot = row % 32, rows ascending, slots ascending), so the two agree bit for bit."""
     src, tgt, nrm, _ = small_c2
     monkeypatch.setenv("O3DS_ICP_MODE", "launch")
-    be = backend.Backend(0, backend.PRECISION_F32)
+    be = backend.Backend(0, backend.PRECISION_F32, ab=True)
     try:
         for kw in (dict(max_iter=10, rel_fitness=0.0, rel_rmse=0.0), dict(max_iter=30)):
             got = be.icp_point_to_plane(src, tgt, nrm, 1.0, **kw)
@@ -295,7 +295,7 @@ def test_fused_prologue_kernel_mode(oracle, small_c2, monkeypatch):
     monkeypatch.setenv("O3DS_ICP_MODE", "fused")
     src, tgt, nrm, _ = small_c2
     for prec, tt, tr in ((backend.PRECISION_F64, TOL_T64, TOL_R64), (backend.PRECISION_F32, TOL_T, TOL_R)):
-        be = backend.Backend(0, prec)
+        be = backend.Backend(0, prec, ab=True)
         try:
             for kw in (dict(max_iter=10, rel_fitness=0.0, rel_rmse=0.0), dict(max_iter=30), dict(max_iter=0), dict(max_iter=1)):
                 got = be.icp_point_to_plane(src, tgt, nrm, 1.0, **kw)
@@ -313,7 +313,7 @@ def test_fused_prologue_kernel_mode(oracle, small_c2, monkeypatch):
             _check(tiny, ref, 37, tt, tr)
         finally:
             be.close()
-    be = backend.Backend(0, backend.PRECISION_F64)
+    be = backend.Backend(0, backend.PRECISION_F64, ab=True)
     try:
         sn = oracle.estimate_normals(src, 3.0, 20)
         ref = oracle.icp_generalized(src, sn, tgt, nrm, 1.0, max_iter=8, rel_fitness=0.0, rel_rmse=0.0)
@@ -460,7 +460,7 @@ def test_point_to_point_device_forms(backend_f32, oracle, small_c2, monkeypatch)
     step = backend_f32.icp_finish()
     np.testing.assert_array_equal(step["transformation"], one["transformation"])
     monkeypatch.setenv("O3DS_ICP_MODE", "launch")
-    be2 = backend.Backend(0, backend.PRECISION_F32)
+    be2 = backend.Backend(0, backend.PRECISION_F32, ab=True)
     try:
         two = be2.icp_point_to_point(src, tgt, 1.0, max_iter=6, rel_fitness=0.0, rel_rmse=0.0)
         np.testing.assert_array_equal(two["transformation"], one["transformation"])
@@ -554,7 +554,7 @@ def test_large_coordinates_and_exact_sums(backend_f64, oracle, small_c2):
     np.testing.assert_array_equal(again["transformation"], got["transformation"])  # and it is reproducible, unlike the CPU reduction
     os.environ["O3DS_PASS_ROWS"] = "333"
     try:
-        be = backend.Backend(0, backend.PRECISION_F64)
+        be = backend.Backend(0, backend.PRECISION_F64, ab=True)
         other = be.icp_point_to_plane(src, tgt + off, nrm, 1.0, **kw)
         be.close()
     finally:
@@ -606,7 +606,7 @@ def test_candidate_sets_do_not_change_a_single_bit(small_c2, oracle, monkeypatch
     results = []
     for env in policies:
         _set_variants(monkeypatch, env)
-        be = backend.Backend(0, prec)
+        be = backend.Backend(0, prec, ab=True)
         try:
             out = []
             s_id, t_id = be.upload(src, sn), be.upload(tgt, nrm)

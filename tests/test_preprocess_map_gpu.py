@@ -1215,7 +1215,7 @@ def test_map_merge_by_merging_beyond_two_million_points():
     import sys
 
     code = ("import sys, pickle; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_preprocess_map_gpu as t; from open3d_slam_amd import backend; "
-            "be = backend.Backend(0); sys.stdout.buffer.write(pickle.dumps(t._big_map_inserts(be)))"
+            "be = backend.Backend(0, ab=True); sys.stdout.buffer.write(pickle.dumps(t._big_map_inserts(be)))"
             % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
     ref = pickle.loads(subprocess.run([sys.executable, "-c", code], capture_output=True, check=True,
                                       env=dict(os.environ, O3DS_NO_INCREMENTAL_MERGE="1")).stdout)
@@ -1238,7 +1238,7 @@ def test_map_merge_by_merging_is_bitwise_the_full_sort(prec, monkeypatch):
 
     # the switch is read once per process: the reference run goes to a child process
     code = ("import sys, pickle; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_preprocess_map_gpu as t; from open3d_slam_amd import backend; "
-            "be = backend.Backend(0, %d); sys.stdout.buffer.write(pickle.dumps(t._insert_sequence(be, 14, 12.0, 0.2, carve_at=(9,))))"
+            "be = backend.Backend(0, %d, ab=True); sys.stdout.buffer.write(pickle.dumps(t._insert_sequence(be, 14, 12.0, 0.2, carve_at=(9,))))"
             % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), p))
     import pickle
 
