@@ -121,8 +121,28 @@ int o3ds_cloud_upload(o3ds_handle h, const double* xyz, const double* normals, s
  * double route would store.  Other fields (intensity, ring, t, rgb) are ignored, as on the scan-matching path. */
 int o3ds_cloud_upload_f32(o3ds_handle h, const void* data, size_t n, size_t point_step, size_t off_x, size_t off_y, size_t off_z,
                           o3ds_cloud* out);
+/* The ingest is ASYNCHRONOUS: copy, unpack and (for the volume this handle last passed to o3ds_crop_voxel_down_sample) the bounding box
+ * of the points inside the cropping volume run on the handle's copy stream, so that scan k + 1 crosses PCIe while frame k is still being
+ * registered and merged; the first operation that uses the cloud queues a wait for it on the handle's stream (no host wait).  A buffer
+ * of ordinary (pageable) memory has been consumed when the call returns (it goes through the handle's pinned ring).  A buffer from
+ * o3ds_pinned_alloc (or any memory registered with the HIP runtime) is read by DMA after the call has returned: keep its contents until
+ * o3ds_cloud_wait_ingest(cloud) has returned or any call that returns data derived from the cloud (a registration result, a size, a
+ * download) has. */
+int o3ds_pinned_alloc(o3ds_handle h, size_t bytes, void** out);  /* page-locked host memory for sensor / message buffers (ROS 2 allocators, drivers) */
+int o3ds_pinned_free(o3ds_handle h, void* p);
+int o3ds_cloud_wait_ingest(o3ds_handle h, o3ds_cloud c);
 int o3ds_cloud_free(o3ds_handle h, o3ds_cloud c);
+/* The number of points of a cloud and whether it has normals.  The clouds of the per-scan chain -- o3ds_voxel_down_sample /
+ * o3ds_crop_voxel_down_sample and what o3ds_estimate_normals, the registrations and o3ds_map_insert_scan make of their results -- are
+ * sized ON THE DEVICE: the kernel that counts the voxels publishes the number where the kernels that consume the cloud read it, the
+ * frame's launches are queued from an upper bound, and nothing waits for a size to come back.  Asking for n is what waits (once; the
+ * number usually arrived with the next registration result and then costs nothing); n == NULL asks for has_normals only and never
+ * waits.  Every call that sizes a host buffer or another cloud by the number (download, crop, select, transform, append ...) asks. */
 int o3ds_cloud_size(o3ds_handle h, o3ds_cloud c, size_t* n, int* has_normals);
+/* What is known of the size without waiting: lower <= n <= upper (equal once the number has arrived).  The reference's emptiness checks
+ * (assert_gt(cloud.size(), 0), ScanToMapRegistration.cpp:51-52; preProcessedScan.IsEmpty(), Submap.cpp:41) are decided by the bounds:
+ * a VoxelDownSample result whose input had a point inside the volume has lower = 1. */
+int o3ds_cloud_size_bound(o3ds_handle h, o3ds_cloud c, size_t* lower, size_t* upper);
 /* Download into caller buffers of capacity >= n points (normals may be NULL). */
 int o3ds_cloud_download(o3ds_handle h, o3ds_cloud c, double* xyz, double* normals, size_t capacity);
 /* The way out, again without a double detour: write the cloud as n records of point_step bytes with float32 x / y / z at byte

@@ -67,6 +67,10 @@ SIGNATURES = {
     "o3ds_profile_span_read": (C.c_int, [_H, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     "o3ds_cloud_upload": (C.c_int, [_H, _dp, _dp, C.c_size_t, C.POINTER(_CL)]),
     "o3ds_cloud_upload_f32": (C.c_int, [_H, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(_CL)]),
+    "o3ds_pinned_alloc": (C.c_int, [_H, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "o3ds_pinned_free": (C.c_int, [_H, C.c_void_p]),
+    "o3ds_cloud_wait_ingest": (C.c_int, [_H, _CL]),
+    "o3ds_cloud_size_bound": (C.c_int, [_H, _CL, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "o3ds_cloud_free": (C.c_int, [_H, _CL]),
     "o3ds_cloud_size": (C.c_int, [_H, _CL, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "o3ds_cloud_download": (C.c_int, [_H, _CL, _dp, _dp, C.c_size_t]),
@@ -208,6 +212,7 @@ class Backend:
 
     def close(self):
         if getattr(self, "h", None):
+            self.free_pinned()
             self.lib.o3ds_destroy(self.h)
             self.h = None
 
@@ -238,6 +243,38 @@ class Backend:
         cid = _CL()
         self._ck(self.lib.o3ds_cloud_upload_f32(self.h, a.ctypes.data_as(C.c_void_p), n, step, off_x, off_y, off_z, C.byref(cid)))
         return cid.value
+
+    def pinned_records(self, n: int, point_step: int = 16) -> np.ndarray:
+        """(n, point_step) bytes of page-locked host memory (o3ds_pinned_alloc) as a numpy array: a sensor / message buffer that
+        upload_f32 DMAs from directly and asynchronously instead of copying it through the handle's pinned ring first.  Freed with the
+        handle (or free_pinned)."""
+        p = C.c_void_p()
+        self._ck(self.lib.o3ds_pinned_alloc(self.h, max(n * point_step, 1), C.byref(p)))
+        buf = (C.c_uint8 * (n * point_step)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=np.uint8).reshape(n, point_step)
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p.value)
+        return arr
+
+    def free_pinned(self):
+        for p in getattr(self, "_pinned", []):
+            self.lib.o3ds_pinned_free(self.h, C.c_void_p(p))
+        self._pinned = []
+
+    def wait_ingest(self, cid: int):
+        self._ck(self.lib.o3ds_cloud_wait_ingest(self.h, cid))
+
+    def size_bound(self, cid: int):
+        """(lower, upper) bounds of the size, never waits (o3ds_cloud_size_bound)"""
+        lo, up = C.c_size_t(), C.c_size_t()
+        self._ck(self.lib.o3ds_cloud_size_bound(self.h, cid, C.byref(lo), C.byref(up)))
+        return lo.value, up.value
+
+    def has_normals(self, cid: int) -> bool:
+        """without waiting for a size that is still in flight (o3ds_cloud_size with n = NULL)"""
+        hn = C.c_int()
+        self._ck(self.lib.o3ds_cloud_size(self.h, cid, None, C.byref(hn)))
+        return bool(hn.value)
 
     def free(self, cid: int):
         self._ck(self.lib.o3ds_cloud_free(self.h, cid))

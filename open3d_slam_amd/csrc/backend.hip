@@ -22,6 +22,7 @@
 #include "cloud_kernels.hpp"
 #include "common.hpp"
 #include "icp_kernels.hpp"
+#include "map_kernels.hpp"
 #include "normals_kernel.hpp"
 
 using namespace o3ds;
@@ -63,6 +64,23 @@ struct CloudRec {
   // operation that reorders or moves points resets it), see voxel_reduce_t
   long long vox_first = -1;
   size_t vox_count = 0;
+  struct PMapRec* pm = nullptr;  // non-null: the cloud is a submap in its PERSISTENT form (map_kernels.hpp): pts / nrm are slot arrays, n an
+                                 // upper bound of the slots in use, the index is row-paged and kept up to date by the insertions
+  size_t index_positions = 0;    // positions the cell-sorted arrays of the index span (0: n; the row-paged index has gaps)
+  // A count the host has not seen yet (common.hpp, CountPub): `n` is then an UPPER bound -- the arrays have room for it, launches are
+  // sized by it -- and the exact number is in the device word of record `lazy_slot` once the producing kernel has run (and in the pinned
+  // record, stamped `lazy_seq`, for the host: resolve_count).  -1: n is exact.
+  int lazy_slot = -1;
+  int lazy_seq = 0;
+  size_t n_lower = 0;  // ... and a lower bound of it (o3ds_cloud_size_bound: "is it empty" rarely needs the exact number)
+  // An ingest that is still in flight on the handle's copy stream (o3ds_cloud_upload_f32): the first use of the cloud on the handle's
+  // stream waits for this event (cloud_ready); `ingest_buf` is the ingest buffer the points live in (not a pool block), -1 = none.
+  hipEvent_t ingest_ev = nullptr;
+  int ingest_buf = -1;
+  // ... and the box of the points inside `pre_crop` that the ingest kernel reduced on the way (pinned record `pre_slot`, stamp `pre_seq`)
+  int pre_slot = -1;
+  int pre_seq = 0;
+  CropDev pre_crop{};
   bool has_box = false;
   bool box_padded = false;  // the box already has a margin against the rounding of derived values (never padded twice: a map is
                             // re-voxelised at every insertion and its box must not creep outwards over a long mission)
@@ -109,6 +127,20 @@ void box_transform(CloudRec& to, const CloudRec& from, const double T[16]) {  //
   if (to.has_box) box_inflate(to);
 }
 
+// host side of a submap in its persistent form (map_kernels.hpp)
+struct PMapRec {
+  PmDev dev{};
+  CropDev* d_hist = nullptr;
+  int t = 0;              // insertions since the map entered this form (their volumes: d_hist[1..t])
+  size_t n_upper = 0;     // slots in use: the host's upper bound (exact value: dev.counters[kPmN])
+  size_t live_lower = 0;  // live points: a lower bound
+  double pool_top = 0;    // first free position of the index pool: an upper bound (the last record the host saw + the worst case of
+                          // every insertion since)
+  int rec_slot = -1, rec_seq = 0;  // pinned record the insertions publish {slots, pool top, dead, error} into; stamp of the latest
+  size_t rows = 0;
+  std::vector<void*> blocks;  // every pool block of the form except the slot arrays and the index arrays (those hang on the CloudRec)
+};
+
 constexpr int kMaxPassBlocks = 4096;  // capacity of the partial-record buffer (rows per pass <= pass_rows <= this)
 constexpr size_t kMaxCells = (size_t)1 << 27;  // 512 MiB of cell_start at most
 
@@ -129,7 +161,7 @@ struct o3ds_context {
   int device = 0;
   hipStream_t stream = nullptr;
   int precision = O3DS_PRECISION_F32;
-  std::string err;
+  std::string err, deferred_err;
   std::unordered_map<uint64_t, CloudRec> clouds;
   std::unordered_map<uint64_t, DenseRec> dense_maps;
   uint64_t next_id = 1;
@@ -190,6 +222,41 @@ struct o3ds_context {
   unsigned char* d_voxtab = nullptr;
   size_t voxtab_cap = 0;  // slots
   bool voxtab_clean = false;
+  // ---- values kernels publish for the host without a copy or a wait on the stream: kPinRecs records {count, stamp, box} in pinned
+  // memory (h_rec; the device's view h_rec_dev), the counts also in device words (d_cnt) for the kernels that consume a cloud whose size
+  // the host has not seen yet.  A record belongs to one cloud at a time (rec_owner: cloud id, 0 = free).
+  struct PinRec {
+    int cnt, seq;
+    double box[6];
+    double pad;
+  };
+  PinRec* h_rec = nullptr;
+  PinRec* h_rec_dev = nullptr;
+  int* d_cnt = nullptr;  // [kPinRecs * 16]: one word per record, 64 bytes apart
+  uint64_t rec_owner[64] = {0};
+  int rec_next = 0, rec_seq = 0;
+  size_t voxel_count_hint = 0;  // the last VoxelDownSample size the host saw: the estimate heuristics use while the current one is in flight
+  // ---- ingest (o3ds_cloud_upload_f32): its own stream, so that scan k + 1 crosses PCIe and is unpacked while frame k runs; buffers of
+  // its own (not pool blocks: the pool's reuse is ordered by the handle's ONE stream), handed back behind an event on that stream
+  struct IngestBuf {
+    void* pts = nullptr;
+    size_t pts_bytes = 0;
+    unsigned long long* box = nullptr;  // device box record (order_bits images), armed
+    hipEvent_t freed = nullptr;         // recorded on the handle's stream when the cloud was freed: the next ingest into the buffer waits for it
+    bool in_use = false;
+  };
+  std::vector<IngestBuf> ingest_bufs;
+  hipStream_t copy_stream = nullptr;
+  unsigned char* d_raw = nullptr;  // the records as they crossed PCIe (copy-stream ordered: one buffer)
+  size_t raw_cap = 0;
+  std::vector<hipEvent_t> ev_pool;  // disable-timing events for ingest_ev
+  bool pre_crop_valid = false;      // the volume of the last crop + VoxelDownSample: what the next ingest reduces its box for
+  CropDev pre_crop{};
+  // chained scan of vox_order_kernel: tile records (never cleared: they carry the call's number) and the running ticket counter
+  unsigned long long* d_tiles = nullptr;
+  size_t tiles_cap = 0;
+  unsigned int* d_ticket = nullptr;
+  unsigned int ticket_base = 0, scan_gen = 0;
   int fused_chunk_hint[2] = {12, 12};  // [registration against a cropped target?]: scan-to-map and scan-to-scan alternate on a handle  // launches queued before the host first looks at the state: what the previous registration needed, plus one
   int debug_update = 0;  // O3DS_DEBUG_UPDATE: timing experiments only
   int pass_rows = 1024;
@@ -206,8 +273,13 @@ struct o3ds_context {
 namespace {
 
 int fail(o3ds_handle h, int code, const std::string& msg) {
-  g_thread_error = msg;
-  if (h) h->err = msg;
+  std::string text = msg;
+  if (h && !h->deferred_err.empty()) {  // what went wrong inside find_cloud (a size that never arrived, a map that could not be folded)
+    text += " [" + h->deferred_err + "]";
+    h->deferred_err.clear();
+  }
+  g_thread_error = text;
+  if (h) h->err = text;
   return code;
 }
 
@@ -268,9 +340,10 @@ int stage_init(o3ds_handle h) {
   }
   return O3DS_OK;
 }
-int h2d_copy(o3ds_handle h, void* d_dst, const void* h_src, size_t bytes) {
+int h2d_copy(o3ds_handle h, void* d_dst, const void* h_src, size_t bytes, hipStream_t stream = nullptr /* the handle's */) {
+  if (!stream) stream = h->stream;
   if (bytes < kStageMin) {
-    HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, stream));
     return O3DS_OK;
   }
   int rc = stage_init(h);
@@ -280,8 +353,8 @@ int h2d_copy(o3ds_handle h, void* d_dst, const void* h_src, size_t bytes) {
     const size_t n = std::min(kStageBytes, bytes - off);
     HIP_TRY(hipEventSynchronize(h->stage_ev[k]));  // the DMA that last read this buffer is done (a fresh event is complete)
     memcpy(h->h_stage[k], (const char*)h_src + off, n);
-    HIP_TRY(hipMemcpyAsync((char*)d_dst + off, h->h_stage[k], n, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipEventRecord(h->stage_ev[k], h->stream));
+    HIP_TRY(hipMemcpyAsync((char*)d_dst + off, h->h_stage[k], n, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(h->stage_ev[k], stream));
   }
   return O3DS_OK;
 }
@@ -487,9 +560,29 @@ inline int grid_for(size_t n, int cap = 4096) {
 
 size_t p4_size(int precision) { return precision == O3DS_PRECISION_F64 ? sizeof(P4d) : sizeof(P4f); }
 
+void cloud_ready(o3ds_handle h, CloudRec& c);
+int resolve_count(o3ds_handle h, CloudRec& c, bool block);
+// A cloud for an operation on the handle's stream.  find_cloud: with its exact size (waits for a size a kernel has yet to publish -- the
+// default, every operation that sizes anything on the host by the cloud); find_cloud_lazy: for the operations of the per-scan chain that
+// take the size as it is (an upper bound + the device word, count_ref): normal estimation, registration, map insertion.
+int pm_poll(o3ds_handle h, PMapRec* pm, bool block);
+int pm_exit(o3ds_handle h, CloudRec& c);  // a persistent submap back into the reference's array form (defined with the map functions)
+CloudRec* find_cloud_lazy(o3ds_handle h, o3ds_cloud id) {
+  auto it = h->clouds.find(id);
+  if (it == h->clouds.end()) return nullptr;
+  cloud_ready(h, it->second);
+  (void)resolve_count(h, it->second, false);
+  return &it->second;
+}
 CloudRec* find_cloud(o3ds_handle h, o3ds_cloud id) {
   auto it = h->clouds.find(id);
-  return it == h->clouds.end() ? nullptr : &it->second;
+  if (it == h->clouds.end()) return nullptr;
+  cloud_ready(h, it->second);
+  if (resolve_count(h, it->second, true) != O3DS_OK || (it->second.pm && pm_exit(h, it->second) != O3DS_OK)) {  // whoever wants the map as an
+    h->deferred_err = h->err;                                                                                     // array gets the reference's array
+    return nullptr;
+  }
+  return &it->second;
 }
 
 void free_index(o3ds_handle h, CloudRec& c) {
@@ -501,12 +594,102 @@ void free_index(o3ds_handle h, CloudRec& c) {
   c.has_index = false;
   c.index_byproduct = false;
 }
+// ---- records kernels publish into, events, ingest buffers ---------------------------------------------------------------------------
+constexpr int kPinRecs = 64;
+inline int* cnt_word(o3ds_handle h, int slot) { return h->d_cnt + 16 * slot; }
+int resolve_count(o3ds_handle h, CloudRec& c, bool block);
+
+// a free record; when all are held (64 clouds with a size or a box in flight) the oldest holder is settled first
+int take_rec(o3ds_handle h) {
+  for (int tries = 0; tries < kPinRecs; ++tries) {
+    const int slot = h->rec_next;
+    h->rec_next = (h->rec_next + 1) % kPinRecs;
+    if (h->rec_owner[slot] == 0) {
+      h->rec_owner[slot] = ~0ull;  // (taken; add_cloud writes the id)
+      return slot;
+    }
+  }
+  const int slot = h->rec_next;
+  h->rec_next = (h->rec_next + 1) % kPinRecs;
+  auto it = h->clouds.find(h->rec_owner[slot]);
+  if (it != h->clouds.end()) {
+    if (it->second.lazy_slot == slot) (void)resolve_count(h, it->second, true);
+    if (it->second.pre_slot == slot) it->second.pre_slot = -1;  // the box is reduced again when it is asked for
+  }
+  h->rec_owner[slot] = ~0ull;
+  return slot;
+}
+hipEvent_t take_event(o3ds_handle h) {
+  if (!h->ev_pool.empty()) {
+    hipEvent_t e = h->ev_pool.back();
+    h->ev_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+  return e;
+}
+// the first use of an ingested cloud on the handle's stream: queue the wait for its copy + unpack (no host wait)
+void cloud_ready(o3ds_handle h, CloudRec& c) {
+  if (!c.ingest_ev) return;
+  (void)hipStreamWaitEvent(h->stream, c.ingest_ev, 0);
+  h->ev_pool.push_back(c.ingest_ev);
+  c.ingest_ev = nullptr;
+}
+// the size of a cloud whose count a kernel published: taken from the pinned record if its stamp is there; `block`: wait for it
+int resolve_count(o3ds_handle h, CloudRec& c, bool block) {
+  if (c.lazy_slot < 0) return O3DS_OK;
+  volatile o3ds_context::PinRec* r = h->h_rec + c.lazy_slot;
+  if (r->seq != c.lazy_seq) {
+    if (!block) return O3DS_OK;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (r->seq != c.lazy_seq) return fail(h, O3DS_ERR_HIP, "the size of a cloud was never published by the kernel that decides it");
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  const int cnt = r->cnt;
+  if (cnt < 0 || (size_t)cnt > c.n) return fail(h, O3DS_ERR_HIP, "published cloud size outside its bound");
+  c.n = (size_t)cnt;
+  h->voxel_count_hint = c.n;
+  h->rec_owner[c.lazy_slot] = 0;
+  c.lazy_slot = -1;
+  return O3DS_OK;
+}
+// what a consumer kernel is handed for the cloud's size
+inline CountRef count_ref(o3ds_handle h, const CloudRec& c) { return CountRef{c.n, c.lazy_slot >= 0 ? cnt_word(h, c.lazy_slot) : nullptr}; }
+
+// the point array of a cloud goes back where it came from: the pool, or the ingest buffers (behind an event on the handle's stream, so
+// that the next ingest into the buffer -- on the copy stream -- comes after everything that still reads it here)
+void free_points(o3ds_handle h, CloudRec& c) {
+  if (c.ingest_ev) cloud_ready(h, c);
+  if (c.ingest_buf >= 0) {
+    o3ds_context::IngestBuf& b = h->ingest_bufs[(size_t)c.ingest_buf];
+    if (!b.freed) (void)hipEventCreateWithFlags(&b.freed, hipEventDisableTiming);
+    (void)hipEventRecord(b.freed, h->stream);
+    b.in_use = false;
+    c.ingest_buf = -1;
+  } else if (c.pts) {
+    dev_free(h, c.pts);
+  }
+  c.pts = nullptr;
+}
+void pm_release(o3ds_handle h, CloudRec& c) {  // the persistent form's own blocks (slot arrays and index arrays stay with the cloud)
+  if (!c.pm) return;
+  for (void* b : c.pm->blocks) dev_free(h, b);
+  if (c.pm->rec_slot >= 0) h->rec_owner[c.pm->rec_slot] = 0;
+  delete c.pm;
+  c.pm = nullptr;
+  c.index_positions = 0;
+}
 void free_cloud(o3ds_handle h, CloudRec& c) {
+  pm_release(h, c);
   free_index(h, c);
-  if (c.pts) dev_free(h, c.pts);
+  free_points(h, c);
   if (c.nrm) dev_free(h, c.nrm);
   if (c.col) dev_free(h, c.col);
-  c.pts = c.nrm = c.col = nullptr;
+  c.nrm = c.col = nullptr;
+  if (c.lazy_slot >= 0) h->rec_owner[c.lazy_slot] = 0;
+  if (c.pre_slot >= 0) h->rec_owner[c.pre_slot] = 0;
+  c.lazy_slot = c.pre_slot = -1;
   c.n = 0;
   c.cap = 0;
 }
@@ -618,7 +801,8 @@ int bbox_of(o3ds_handle h, const P4* pts, size_t n, double mn[3], double mx[3], 
 // given) re-stored in cell order.  Output buffers are allocated here; the caller owns them.
 template <typename P4>
 int build_grid_t(o3ds_handle h, const P4* pts, const P4* nrm, size_t n, double cell, GridDev* out_grid, int** out_cell_start, void** out_spts,
-                 void** out_snrm, CloudRec* box /* in: a known box, if has_box; out: the box used */) {
+                 void** out_snrm, CloudRec* box /* in: a known box, if has_box; out: the box used */,
+                 const int* n_dev = nullptr /* n is an upper bound, the exact count is here (a cloud whose size the host has not seen: it then brings its box) */) {
   if (n == 0) return fail(h, O3DS_ERR_EMPTY, "build_index: empty cloud");
   double mn[3], mx[3];
   int rc = O3DS_OK;
@@ -626,6 +810,7 @@ int build_grid_t(o3ds_handle h, const P4* pts, const P4* nrm, size_t n, double c
   if (box && box->has_box && !no_box_cache) {
     for (int a = 0; a < 3; ++a) mn[a] = box->bmn[a], mx[a] = box->bmx[a];
   } else {
+    if (n_dev) return fail(h, O3DS_ERR_INVALID_ARG, "build_index: a cloud whose size is still in flight must bring its box");
     rc = bbox_of<P4>(h, pts, n, mn, mx);
     if (rc) return rc;
     if (box) {
@@ -652,6 +837,7 @@ int build_grid_t(o3ds_handle h, const P4* pts, const P4* nrm, size_t n, double c
   g.cell = cell;
   g.inv_cell = 1.0 / cell;
   g.nx = (int)nx;
+  g.sx = (int)nx;
   g.ny = (int)ny;
   g.nz = (int)nz;
   int *counts = nullptr, *cell_id = nullptr, *cell_start = nullptr;
@@ -679,10 +865,10 @@ int build_grid_t(o3ds_handle h, const P4* pts, const P4* nrm, size_t n, double c
   HIP_TRY(dev_alloc(h, (void**)&spts, sizeof(P4) * n));
   if (nrm) HIP_TRY(dev_alloc(h, (void**)&snrm, sizeof(P4) * n));
   span_mark(h, kSpanIndexBuild);
-  cell_count_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(pts, n, g, counts, cell_id);
+  cell_count_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(pts, n, g, counts, cell_id, n_dev);
   rc = exclusive_scan_int(h, counts, cell_start, ncell + 1);
   if (rc) return rc;
-  scatter_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(pts, nrm, n, cell_id, cell_start, counts, (P4*)spts, (P4*)snrm);
+  scatter_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(pts, nrm, n, cell_id, cell_start, counts, (P4*)spts, (P4*)snrm, n_dev);
   span_mark(h, kSpanIndexBuild);
   HIP_TRY(hipGetLastError());
   h->cells_clean = true;  // (stream order: whoever counts next runs after the scatter)
@@ -698,7 +884,12 @@ int build_grid_t(o3ds_handle h, const P4* pts, const P4* nrm, size_t n, double c
 template <typename P4>
 int build_index_t(o3ds_handle h, CloudRec& c, double cell) {
   free_index(h, c);
-  int rc = build_grid_t<P4>(h, (const P4*)c.pts, (const P4*)c.nrm, c.n, cell, &c.grid, &c.cell_start, &c.spts, &c.snrm, &c);
+  if (c.lazy_slot >= 0 && !c.has_box) {
+    const int rr = resolve_count(h, c, true);
+    if (rr) return rr;
+  }
+  int rc = build_grid_t<P4>(h, (const P4*)c.pts, (const P4*)c.nrm, c.n, cell, &c.grid, &c.cell_start, &c.spts, &c.snrm, &c,
+                            c.lazy_slot >= 0 ? cnt_word(h, c.lazy_slot) : nullptr);
   if (rc) return rc;
   c.has_index = true;
   return O3DS_OK;
@@ -821,6 +1012,8 @@ int download_t(o3ds_handle h, const CloudRec& c, double* xyz, double* normals) {
 
 o3ds_cloud add_cloud(o3ds_handle h, CloudRec&& c) {
   const uint64_t id = h->next_id++;
+  if (c.lazy_slot >= 0) h->rec_owner[c.lazy_slot] = id;
+  if (c.pre_slot >= 0) h->rec_owner[c.pre_slot] = id;
   h->clouds.emplace(id, std::move(c));
   return id;
 }
@@ -1086,8 +1279,9 @@ int validate_icp(o3ds_handle h, const CloudRec* src, const CloudRec* tgt, const 
 
 int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3ds_crop* crop, const double init[16],
                   const o3ds_icp_params* params, bool upload_state = true) {
-  CloudRec* src = find_cloud(h, source);
-  CloudRec* tgt = find_cloud(h, target);
+  // (sizes as they are: a source or target whose size a kernel has yet to publish enters with its upper bound and the device word)
+  CloudRec* src = find_cloud_lazy(h, source);
+  CloudRec* tgt = find_cloud_lazy(h, target);
   int rc = validate_icp(h, src, tgt, params);
   if (rc) return rc;
   const double r_hint = params->max_correspondence_distance;
@@ -1185,8 +1379,9 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
   a.set_gain = h->set_gain;
   a.set_min = h->set_min;
   a.set_cap = h->set_cap;
-  a.n_tgt = (int)tgt->n;
+  a.n_tgt = (int)(tgt->index_positions ? tgt->index_positions : tgt->n);
   a.snrm = src->nrm;
+  a.count_dev = src->lazy_slot >= 0 ? cnt_word(h, src->lazy_slot) : nullptr;
   a.gicp_k = 1.0 - h->gicp_epsilon;
   a.state = h->d_state;
   a.partials = h->d_partials;
@@ -1281,6 +1476,18 @@ int o3ds_create(int device_id, o3ds_handle* out) {
       h->fused = std::string(e) != "launch";
     }
   }
+  {
+    static_assert(sizeof(o3ds_context::PinRec) == 64, "one pinned record per cache line");
+    if (hipHostMalloc((void**)&h->h_rec, sizeof(o3ds_context::PinRec) * kPinRecs, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&h->h_rec_dev, h->h_rec, 0) != hipSuccess ||
+        hipMalloc((void**)&h->d_cnt, sizeof(int) * 16 * kPinRecs) != hipSuccess || hipMemset(h->d_cnt, 0, sizeof(int) * 16 * kPinRecs) != hipSuccess ||
+        hipMalloc((void**)&h->d_ticket, 64) != hipSuccess || hipMemset(h->d_ticket, 0, 64) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+      o3ds_destroy(h);
+      return fail(nullptr, O3DS_ERR_OOM, "o3ds_create: record allocation failed");
+    }
+    memset(h->h_rec, 0, sizeof(o3ds_context::PinRec) * kPinRecs);
+  }
   if (const char* e = ab_getenv("O3DS_DEBUG_UPDATE")) h->debug_update = atoi(e);
   if (const char* e = ab_getenv("O3DS_PASS_ROWS")) h->pass_rows = std::min(std::max(atoi(e), 1), kMaxPassBlocks);
   *out = h;
@@ -1292,11 +1499,24 @@ int o3ds_destroy(o3ds_handle h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   (void)hipStreamSynchronize(h->own_stream);
+  if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
   for (auto& kv : h->clouds) free_cloud(h, kv.second);
   for (auto& kv : h->dense_maps) dense_release(h, kv.second);
   for (auto& b : h->arena_blocks) dev_free(h, b.first);
   (void)hipStreamSynchronize(h->stream);
   dev_release_all(h);
+  for (auto& b : h->ingest_bufs) {
+    if (b.pts) (void)hipFree(b.pts);
+    if (b.box) (void)hipFree(b.box);
+    if (b.freed) (void)hipEventDestroy(b.freed);
+  }
+  for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+  if (h->d_raw) (void)hipFree(h->d_raw);
+  if (h->d_tiles) (void)hipFree(h->d_tiles);
+  if (h->d_ticket) (void)hipFree(h->d_ticket);
+  if (h->d_cnt) (void)hipFree(h->d_cnt);
+  if (h->h_rec) (void)hipHostFree(h->h_rec);
+  if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   if (h->d_fused) (void)hipFree(h->d_fused);
   if (h->d_nn_cache) (void)hipFree(h->d_nn_cache);
   if (h->d_set_pos) (void)hipFree(h->d_set_pos);
@@ -1409,7 +1629,6 @@ int o3ds_cloud_upload(o3ds_handle h, const double* xyz, const double* normals, s
 int o3ds_cloud_upload_f32(o3ds_handle h, const void* data, size_t n, size_t point_step, size_t off_x, size_t off_y, size_t off_z,
                           o3ds_cloud* out) {
   CHECK_HANDLE(h);
-  ArenaScope arena_scope(h);
   if (!out || (n > 0 && !data)) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_upload_f32: null argument");
   if (n > 0x7fffffffull) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_upload_f32: more than 2^31-1 points");
   if (point_step < 12 || off_x + 4 > point_step || off_y + 4 > point_step || off_z + 4 > point_step)
@@ -1420,23 +1639,107 @@ int o3ds_cloud_upload_f32(o3ds_handle h, const void* data, size_t n, size_t poin
   c.n = n;
   c.precision = h->precision;
   if (n > 0) {
-    unsigned char* d_raw = nullptr;
-    TMP_ALLOC(d_raw, n * point_step);
-    {
-      const int rcc = h2d_copy(h, d_raw, data, n * point_step);
+    // The whole ingest runs on the handle's COPY stream -- DMA of the records, unpack, box -- and the call returns with it queued: the
+    // scan crosses PCIe while the frame before it is still being registered and merged on the handle's stream, whose first use of the
+    // cloud waits for an event (cloud_ready), not the host.  The points live in an ingest buffer (free_points).
+    const size_t psz = p4_size(h->precision), bytes = n * point_step;
+    int bi = -1;
+    for (size_t k = 0; k < h->ingest_bufs.size(); ++k)
+      if (!h->ingest_bufs[k].in_use && h->ingest_bufs[k].pts_bytes >= psz * n && (bi < 0 || h->ingest_bufs[k].pts_bytes < h->ingest_bufs[(size_t)bi].pts_bytes)) bi = (int)k;
+    if (bi < 0) {
+      for (size_t k = 0; k < h->ingest_bufs.size() && bi < 0; ++k)
+        if (!h->ingest_bufs[k].in_use) bi = (int)k;  // an idle buffer that is too small: grown below
+      if (bi < 0) {
+        h->ingest_bufs.emplace_back();
+        bi = (int)h->ingest_bufs.size() - 1;
+      }
+    }
+    o3ds_context::IngestBuf& b = h->ingest_bufs[(size_t)bi];
+    if (b.pts_bytes < psz * n) {
+      if (b.pts) {
+        if (b.freed) HIP_TRY(hipEventSynchronize(b.freed));
+        HIP_TRY(hipStreamSynchronize(h->copy_stream));
+        (void)hipFree(b.pts);
+        b.pts = nullptr;
+        b.pts_bytes = 0;
+      }
+      const size_t want = psz * (n + n / 8);
+      if (hipMalloc(&b.pts, want) != hipSuccess) return fail(h, O3DS_ERR_OOM, "cloud_upload_f32: ingest buffer allocation failed");
+      b.pts_bytes = want;
+    }
+    if (!b.box) {
+      if (hipMalloc((void**)&b.box, 64) != hipSuccess) return fail(h, O3DS_ERR_OOM, "cloud_upload_f32: box record allocation failed");
+      unsigned long long arm[8] = {0};
+      for (int a = 0; a < 6; ++a) arm[a] = order_bits(a < 3 ? 1e300 : -1e300);
+      HIP_TRY(hipMemcpy(b.box, arm, sizeof(arm), hipMemcpyHostToDevice));
+    }
+    if (h->raw_cap < bytes) {
+      HIP_TRY(hipStreamSynchronize(h->copy_stream));
+      if (h->d_raw) (void)hipFree(h->d_raw);
+      h->d_raw = nullptr;
+      h->raw_cap = 0;
+      if (hipMalloc((void**)&h->d_raw, bytes + bytes / 8) != hipSuccess) return fail(h, O3DS_ERR_OOM, "cloud_upload_f32: staging allocation failed");
+      h->raw_cap = bytes + bytes / 8;
+    }
+    if (b.freed) HIP_TRY(hipStreamWaitEvent(h->copy_stream, b.freed, 0));  // whatever still read the buffer's last cloud on the handle's stream
+    // the records: straight DMA from memory the runtime knows as pinned (o3ds_pinned_alloc, hipHostRegister: read asynchronously, see the
+    // header), through the handle's pinned ring otherwise (the caller's buffer is consumed when this returns)
+    hipPointerAttribute_t attr{};
+    const bool pinned = hipPointerGetAttributes(&attr, data) == hipSuccess && attr.type == hipMemoryTypeHost;
+    (void)hipGetLastError();  // (a pageable pointer makes the query fail: not an error of ours)
+    if (pinned) {
+      HIP_TRY(hipMemcpyAsync(h->d_raw, data, bytes, hipMemcpyHostToDevice, h->copy_stream));
+    } else {
+      const int rcc = h2d_copy(h, h->d_raw, data, bytes, h->copy_stream);
       if (rcc) return rcc;
     }
-    const size_t bytes = (h->precision == O3DS_PRECISION_F64 ? sizeof(P4d) : sizeof(P4f)) * n;
-    HIP_TRY(dev_alloc(h, (void**)&c.pts, bytes));
-    if (h->precision == O3DS_PRECISION_F64)
-      pack_strided_f32_kernel<P4d><<<grid_for(n), kBlock, 0, h->stream>>>(d_raw, n, point_step, off_x, off_y, off_z, (P4d*)c.pts);
-    else
-      pack_strided_f32_kernel<P4f><<<grid_for(n), kBlock, 0, h->stream>>>(d_raw, n, point_step, off_x, off_y, off_z, (P4f*)c.pts);
+    b.in_use = true;
+    c.pts = b.pts;
+    c.ingest_buf = bi;
+    // the box of the points inside the volume the handle last cropped with rides on the unpack (pack_strided_f32_box_kernel)
+    if (h->pre_crop_valid) {
+      c.pre_slot = take_rec(h);
+      c.pre_seq = ++h->rec_seq;
+      c.pre_crop = h->pre_crop;
+      o3ds_context::PinRec* rec = h->h_rec_dev + c.pre_slot;
+      if (h->precision == O3DS_PRECISION_F64)
+        pack_strided_f32_box_kernel<P4d><<<grid_for(n, 1024), kBlock, 0, h->copy_stream>>>(h->d_raw, n, point_step, off_x, off_y, off_z, (P4d*)c.pts, c.pre_crop, b.box);
+      else
+        pack_strided_f32_box_kernel<P4f><<<grid_for(n, 1024), kBlock, 0, h->copy_stream>>>(h->d_raw, n, point_step, off_x, off_y, off_z, (P4f*)c.pts, c.pre_crop, b.box);
+      box_publish_kernel<<<1, 64, 0, h->copy_stream>>>(b.box, rec->box, &rec->seq, c.pre_seq);
+    } else if (h->precision == O3DS_PRECISION_F64) {
+      pack_strided_f32_kernel<P4d><<<grid_for(n), kBlock, 0, h->copy_stream>>>(h->d_raw, n, point_step, off_x, off_y, off_z, (P4d*)c.pts);
+    } else {
+      pack_strided_f32_kernel<P4f><<<grid_for(n), kBlock, 0, h->copy_stream>>>(h->d_raw, n, point_step, off_x, off_y, off_z, (P4f*)c.pts);
+    }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(h->stream));  // `data` may be reused by the caller as soon as this returns
+    c.ingest_ev = take_event(h);
+    if (!c.ingest_ev) return fail(h, O3DS_ERR_HIP, "cloud_upload_f32: event creation failed");
+    HIP_TRY(hipEventRecord(c.ingest_ev, h->copy_stream));
   }
   c_guard.release();
   *out = add_cloud(h, std::move(c));
+  return O3DS_OK;
+}
+
+int o3ds_pinned_alloc(o3ds_handle h, size_t bytes, void** out) {
+  CHECK_HANDLE(h);
+  if (!out) return fail(h, O3DS_ERR_INVALID_ARG, "pinned_alloc: null out");
+  *out = nullptr;
+  HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+  return O3DS_OK;
+}
+int o3ds_pinned_free(o3ds_handle h, void* p) {
+  CHECK_HANDLE(h);
+  if (h->copy_stream) HIP_TRY(hipStreamSynchronize(h->copy_stream));  // an ingest may still be reading it
+  if (p) HIP_TRY(hipHostFree(p));
+  return O3DS_OK;
+}
+int o3ds_cloud_wait_ingest(o3ds_handle h, o3ds_cloud id) {
+  CHECK_HANDLE(h);
+  auto it = h->clouds.find(id);
+  if (it == h->clouds.end()) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_wait_ingest: unknown cloud id");
+  if (it->second.ingest_ev) HIP_TRY(hipEventSynchronize(it->second.ingest_ev));
   return O3DS_OK;
 }
 
@@ -1455,10 +1758,38 @@ int o3ds_cloud_free(o3ds_handle h, o3ds_cloud id) {
 
 int o3ds_cloud_size(o3ds_handle h, o3ds_cloud id, size_t* n, int* has_normals) {
   CHECK_HANDLE(h);
-  CloudRec* c = find_cloud(h, id);
+  CloudRec* c = find_cloud_lazy(h, id);  // (whether a cloud has normals is known without waiting for its size)
   if (!c) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_size: unknown cloud id");
+  if (n && c->pm) {  // a submap in its persistent form stays in it: its live points = slots in use - dead slots, from the device's counters
+    int counters[kPmCounters];
+    ArenaScope arena_scope(h);
+    const int rb = read_back(h, {{counters, c->pm->dev.counters, sizeof(counters)}});
+    if (rb) return rb;
+    *n = (size_t)(counters[kPmN] - counters[kPmDeadCnt]);
+    if (has_normals) *has_normals = c->nrm != nullptr;
+    return O3DS_OK;
+  }
+  if (n) {
+    const int rr = resolve_count(h, *c, true);
+    if (rr) return rr;
+  }
   if (n) *n = c->n;
   if (has_normals) *has_normals = c->nrm != nullptr;
+  return O3DS_OK;
+}
+
+int o3ds_cloud_size_bound(o3ds_handle h, o3ds_cloud id, size_t* lower, size_t* upper) {
+  CHECK_HANDLE(h);
+  CloudRec* c = find_cloud_lazy(h, id);
+  if (!c) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_size_bound: unknown cloud id");
+  if (c->pm) {
+    (void)pm_poll(h, c->pm, false);
+    if (lower) *lower = c->pm->live_lower;
+    if (upper) *upper = c->pm->n_upper;
+    return O3DS_OK;
+  }
+  if (lower) *lower = c->lazy_slot >= 0 ? std::min(c->n_lower, c->n) : c->n;
+  if (upper) *upper = c->n;
   return O3DS_OK;
 }
 
@@ -1604,6 +1935,7 @@ int o3ds_icp_begin(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3
   CHECK_HANDLE(h);
   ArenaScope arena_scope(h);
   if (!init) return fail(h, O3DS_ERR_INVALID_ARG, "icp_begin: null init");
+  (void)find_cloud(h, source);  // the step-wise forms address source RANGES: they take the exact size
   return begin_session(h, source, target, target_crop, init, params);
 }
 
@@ -1799,6 +2131,7 @@ int o3ds_information_matrix_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud tar
   p.max_correspondence_distance = max_correspondence_distance;
   p.max_iteration = 0;
   p.method = O3DS_ICP_POINT_TO_POINT;  // validation as for point-to-point: no normals needed
+  (void)find_cloud(h, source);
   int rc = begin_session(h, source, target, target_crop, T, &p);
   if (rc) return rc;
   h->session = false;
@@ -1885,7 +2218,7 @@ int o3ds_icp_generalized_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target
   int rc = O3DS_OK;
   static const double kIdentity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   for (int k = 0; k < 2 && !rc; ++k) {
-    const CloudRec* c = find_cloud(h, use[k]);
+    const CloudRec* c = find_cloud_lazy(h, use[k]);
     if (!c || c->n == 0 || c->nrm) continue;
     rc = o3ds_transform_cloud(h, use[k], kIdentity, &own[k]);  // x * 1 + 0: a bit-exact copy
     if (rc) break;
@@ -1928,8 +2261,12 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
   if (!init || !out) return fail(h, O3DS_ERR_INVALID_ARG, "icp: null init/out");
   // the fused loop runs one workgroup per 64 queries; its exact record sums are order-independent for up to 4096 workgroup records
   // (split_exact), so sources beyond kFusedMaxQueries points take the two-launch form (same results, looped pass kernel)
-  const CloudRec* src_rec = find_cloud(h, source);
+  CloudRec* src_rec = find_cloud_lazy(h, source);
   const bool use_fused = h->fused && src_rec && src_rec->n <= kFusedMaxQueries;
+  if (src_rec && !use_fused) {  // the two-launch form hands the source size to its update kernel by value
+    const int rr = resolve_count(h, *src_rec, true);
+    if (rr) return rr;
+  }
   int rc = begin_session(h, source, target, target_crop, init, params, !use_fused);
   if (rc) return rc;
   h->session = false;  // the loop below owns the state
@@ -2160,20 +2497,30 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
   // VoxelDownSample proper: no sort (cloud_kernels.hpp, VoxTable); O3DS_VOXEL_SORT=1 keeps the sort-based path below for A/B runs
   static const bool voxel_sort = ab_getenv("O3DS_VOXEL_SORT") != nullptr;
   const bool table_path = mode == 0 && !voxel_sort && n < ((size_t)1 << 30);
-  double* d_box = nullptr;  // table path: the box stays on the device until the call's one synchronisation (bbox_final_kernel)
-  if (table_path) {
-    const int g = grid_for(n, 1024);
-    double* d_blocks = nullptr;
-    TMP_ALLOC(d_blocks, sizeof(double) * 6 * (size_t)g);
-    TMP_ALLOC(d_box, sizeof(double) * 6);
-    CropDev all{};
-    bbox_kernel<P4><<<g, kBlock, 0, h->stream>>>((const P4*)in.pts, n, filter ? crop : all, d_blocks);
-    bbox_final_kernel<<<1, 64, 0, h->stream>>>(d_blocks, g, d_box, (double*)h->h_pin_dev);
-    HIP_TRY(hipGetLastError());
-  } else if (mode == 0) {  // [O3D] voxel_min_bound = GetMinBound() - voxel_size * 0.5
+  if (mode == 0) {  // [O3D] voxel_min_bound = GetMinBound() - voxel_size * 0.5
     double mn[3], mx[3];
-    int rc = bbox_of<P4>(h, (const P4*)in.pts, n, mn, mx, filter ? &crop : nullptr);
-    if (rc) return rc;
+    // the box of the points inside the volume: reduced by the ingest of this very cloud if it assumed the volume asked for now (a lidar
+    // stream: always) -- the pinned record is normally there long before anyone asks; reduced now otherwise (one launch + a wait)
+    CropDev want{};
+    if (filter) want = crop;
+    bool have_box = false;
+    if (in.pre_slot >= 0 && memcmp(&in.pre_crop, &want, sizeof(CropDev)) == 0) {
+      volatile o3ds_context::PinRec* r = h->h_rec + in.pre_slot;
+      if (r->seq != in.pre_seq) HIP_TRY(hipStreamSynchronize(h->copy_stream));
+      if (r->seq == in.pre_seq) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        for (int a = 0; a < 3; ++a) mn[a] = r->box[a], mx[a] = r->box[3 + a];
+        have_box = true;
+      }
+    }
+    if (!have_box) {
+      int rc = bbox_of<P4>(h, (const P4*)in.pts, n, mn, mx, filter ? &crop : nullptr);
+      if (rc) return rc;
+    }
+    if (filter) {  // the next ingest of this handle reduces its box for this volume
+      h->pre_crop = crop;
+      h->pre_crop_valid = true;
+    }
     if (filter && mn[0] > mx[0]) return O3DS_OK;  // nothing inside the volume: an empty cloud
     if (voxel * 2147483647.0 < std::max({mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]}) + voxel)
       return fail(h, O3DS_ERR_INVALID_ARG, "[VoxelDownSample] voxel_size is too small.");
@@ -2199,73 +2546,60 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
         h->d_voxtab = nullptr;
         h->voxtab_cap = 0;
       }
-      if (hipMalloc((void**)&h->d_voxtab, 16 * cap + 16) != hipSuccess) return fail(h, O3DS_ERR_OOM, "VoxelDownSample: voxel table allocation failed");
+      if (hipMalloc((void**)&h->d_voxtab, kVoxSlotBytes * cap + 16) != hipSuccess) return fail(h, O3DS_ERR_OOM, "VoxelDownSample: voxel table allocation failed");
       h->voxtab_cap = cap;
       h->voxtab_clean = false;
     }
     cap = h->voxtab_cap;
     unsigned char* tab = h->d_voxtab;
-    int *slot_of = nullptr, *rank = nullptr, *seg_cnt = nullptr, *seg_start = nullptr, *vox_slot = nullptr;
-    uint32_t* members = nullptr;
-    TMP_ALLOC(slot_of, sizeof(int) * n);
-    TMP_ALLOC(rank, sizeof(int) * (n + 1));
-    TMP_ALLOC(members, sizeof(uint32_t) * n);
-    VoxTable t{(unsigned long long*)tab, (unsigned int*)(tab + 8 * cap), (unsigned int*)(tab + 12 * cap), (unsigned int*)(tab + 16 * cap),
-               (unsigned int)(cap - 1)};
+    int *lead_slot = nullptr, *run_next = nullptr, *run_len = nullptr, *order = nullptr;
+    uint32_t* starts = nullptr;
+    int2* piece = nullptr;
+    TMP_ALLOC(lead_slot, sizeof(int) * n);
+    TMP_ALLOC(run_next, sizeof(int) * n);
+    TMP_ALLOC(run_len, sizeof(int) * n);
+    TMP_ALLOC(order, sizeof(int) * n);
+    TMP_ALLOC(starts, sizeof(uint32_t) * n);
+    if (in.col) TMP_ALLOC(piece, sizeof(int2) * n);
+    VoxTable t{(unsigned long long*)tab, (unsigned int*)(tab + 8 * cap), (int*)(tab + 12 * cap), (unsigned int*)(tab + 16 * cap),
+               (unsigned int*)(tab + kVoxSlotBytes * cap), (unsigned int)(cap - 1)};
     static const bool always_clear = ab_getenv("O3DS_ALWAYS_CLEAR") != nullptr;
-    if (!h->voxtab_clean || always_clear) HIP_TRY(hipMemsetAsync(tab, 0xff, 16 * cap + 16, h->stream));
+    if (!h->voxtab_clean || always_clear) HIP_TRY(hipMemsetAsync(tab, 0xff, kVoxSlotBytes * cap + 16, h->stream));
     h->voxtab_clean = false;
-    vox_insert_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>((const P4*)in.pts, n, d_box, voxel, crop, filter ? 1 : 0, t, slot_of);
-    // voxels numbered in order of first appearance: scan over "point i opens its voxel", the flag computed as the scan loads it; the
-    // number of voxels goes straight to the pinned block
-    int rc = O3DS_OK;
-    {
-      const size_t ms = n + 1;
-      const int nbs = (int)((ms + kScanPerBlock - 1) / kScanPerBlock);
-      int* sums = nullptr;
-      TMP_ALLOC(sums, sizeof(int) * (size_t)nbs);
-      int* pub = pub_slot<int>(h, 0);
-      scan_local_fn_kernel<int, VoxFirstFlag><<<nbs, kBlock, 0, h->stream>>>(VoxFirstFlag{slot_of, n, t}, rank, sums, ms, nbs == 1 ? pub : nullptr);
-      if (nbs > 1 && nbs <= kScanFusedBlocks) {
-        scan_add_fused_kernel<int><<<nbs, kBlock, 0, h->stream>>>(rank, sums, ms, pub);
-      } else if (nbs > 1) {
-        scan_sums_kernel<int><<<1, kBlock, 0, h->stream>>>(sums, nbs);
-        scan_add_kernel<int><<<nbs, kBlock, 0, h->stream>>>(rank, sums, ms, pub);
+    // the chained scan's tile records (kept across calls, see vox_order_kernel)
+    const size_t n_tiles = (n + kVoxTile - 1) / kVoxTile;
+    if (h->tiles_cap < n_tiles) {
+      if (h->d_tiles) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        (void)hipFree(h->d_tiles);
+        h->d_tiles = nullptr;
+        h->tiles_cap = 0;
       }
-      HIP_TRY(hipGetLastError());
+      const size_t want = std::max<size_t>(n_tiles + n_tiles / 4, 1024);
+      if (hipMalloc((void**)&h->d_tiles, sizeof(unsigned long long) * want) != hipSuccess) return fail(h, O3DS_ERR_OOM, "VoxelDownSample: scan state allocation failed");
+      HIP_TRY(hipMemsetAsync(h->d_tiles, 0, sizeof(unsigned long long) * want, h->stream));
+      h->tiles_cap = want;
     }
-    rc = wait_stream(h);
-    if (rc) return rc;
-    const int m = pub_value<int>(h, 0);
-    out.n = (size_t)m;
-    if (m == 0) {  // every point outside the volume: nothing was entered
-      h->voxtab_clean = true;
-      return O3DS_OK;
-    }
-    {  // the box the grid was anchored at, now that the host may look: the checks and the bookkeeping the sort path does up front
-      const double* hb = (const double*)h->h_pin;
-      const double mn[3] = {hb[0], hb[1], hb[2]}, mx[3] = {hb[3], hb[4], hb[5]};
-      if (voxel * 2147483647.0 < std::max({mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]}) + voxel)
-        return fail(h, O3DS_ERR_INVALID_ARG, "[VoxelDownSample] voxel_size is too small.");  // (the table is cleared before its next use)
-      out.has_box = std::isfinite(mn[0] + mn[1] + mn[2] + mx[0] + mx[1] + mx[2]);  // voxel means lie in the box of the points they average
-      out.box_padded = false;
-      for (int a = 0; a < 3; ++a) out.bmn[a] = mn[a], out.bmx[a] = mx[a];
-      if (out.has_box) box_inflate(out);
-    }
-    TMP_ALLOC(seg_cnt, sizeof(int) * (size_t)m);
-    TMP_ALLOC(seg_start, sizeof(int) * (size_t)m);
-    TMP_ALLOC(vox_slot, sizeof(int) * (size_t)m);
-    vox_number_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(slot_of, rank, n, t, seg_start, seg_cnt, vox_slot);
-    vox_gather_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(slot_of, n, t, seg_start, seg_cnt, members);
-    HIP_TRY(dev_alloc(h, (void**)&out.pts, sizeof(P4) * out.n));
-    if (in.nrm) HIP_TRY(dev_alloc(h, (void**)&out.nrm, sizeof(P4) * out.n));
-    vox_mean_kernel<P4><<<grid_for(out.n), kBlock, 0, h->stream>>>((const P4*)in.pts, (const P4*)in.nrm, seg_start, seg_cnt, out.n, members, 0,
-                                                                  (P4*)out.pts, (P4*)out.nrm, t, vox_slot);
+    // the size of the result: an upper bound here, the number of voxels in a device word and a pinned record when vox_order_kernel has run
+    out.n = n;
+    out.n_lower = 1;  // (the box is not empty: at least one point lies inside the volume, hence at least one voxel)
+    out.lazy_slot = take_rec(h);
+    out.lazy_seq = ++h->rec_seq;
+    CountPub pub{cnt_word(h, out.lazy_slot), &(h->h_rec_dev + out.lazy_slot)->cnt, out.lazy_seq};
+    const CountRef m_ref{n, pub.dev};
+    HIP_TRY(dev_alloc(h, (void**)&out.pts, sizeof(P4) * n));
+    if (in.nrm) HIP_TRY(dev_alloc(h, (void**)&out.nrm, sizeof(P4) * n));
+    if (in.col) HIP_TRY(dev_alloc(h, (void**)&out.col, sizeof(P4) * n));
+    if (++h->scan_gen == 0) h->scan_gen = 1;
+    vox_insert_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>((const P4*)in.pts, n, ox, oy, oz, voxel, crop, filter ? 1 : 0, t, lead_slot, run_next, run_len);
+    vox_order_kernel<<<(unsigned int)n_tiles, kBlock, 0, h->stream>>>(lead_slot, CountRef{n, nullptr}, t, h->d_tiles, h->d_ticket, h->ticket_base, h->scan_gen, order, pub);
+    h->ticket_base += (unsigned int)n_tiles;
+    vox_mean_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>((const P4*)in.pts, (const P4*)in.nrm, m_ref, order, run_next, run_len, starts, piece, 0,
+                                                             (P4*)out.pts, (P4*)out.nrm, t);
     h->voxtab_clean = true;
-    if (in.col) {  // [O3D] VoxelDownSample: AccumulatedPoint averages the colours
-      HIP_TRY(dev_alloc(h, (void**)&out.col, sizeof(P4) * out.n));
-      vox_mean_kernel<P4><<<grid_for(out.n), kBlock, 0, h->stream>>>((const P4*)in.col, nullptr, seg_start, seg_cnt, out.n, members, 1, (P4*)out.col, nullptr);
-    }
+    if (in.col)  // [O3D] VoxelDownSample: AccumulatedPoint averages the colours
+      vox_mean_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>((const P4*)in.col, nullptr, m_ref, order, run_next, run_len, starts, piece, 1, (P4*)out.col,
+                                                               nullptr, t);
     HIP_TRY(hipGetLastError());
     dbg_sync(h, 8);
     return O3DS_OK;
@@ -2412,6 +2746,11 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
 template <typename P4>
 int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn, bool knn_raw = false) {
   if (c.n == 0) return O3DS_OK;
+  if (knn_raw || !c.has_box) {  // (paths that reduce a box on the host need the exact size first)
+    const int rr = resolve_count(h, c, true);
+    if (rr) return rr;
+    if (c.n == 0) return O3DS_OK;
+  }
   if (knn_raw) {  // [O3D] EstimateNormals(KDTreeSearchParamKNN(max_nn)) and nothing after it: a radius no pair of points exceeds
     double mn[3], mx[3];
     const int rb = bbox_of<P4>(h, (const P4*)c.pts, c.n, mn, mx);
@@ -2424,14 +2763,27 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn, bool knn_ra
   // max_nn-th neighbour typically lies inside the first 3x3x3 ring.  The density comes from a pilot grid at radius/8 -- one
   // extra index build, one counting kernel and a host round trip -- so it is remembered per (radius, max_nn) and reused
   // while the cloud size stays within 25 % (a lidar stream: every scan), refreshed every 32 calls.
+  // (a cloud whose size is still in flight: the heuristics below go by the size of the handle's previous VoxelDownSample result -- a lidar
+  // stream's scans are alike --, the kernels by the device word; the density pilot needs the real size and waits for it)
+  size_t n_est = c.lazy_slot >= 0 ? std::min(c.n, h->voxel_count_hint) : c.n;
+  bool reuse = h->nrm_cell > 0.0 && h->nrm_radius == radius && h->nrm_knn == max_nn && h->nrm_age < 32 && n_est > 0 &&
+               (double)n_est <= 1.25 * (double)h->nrm_n && (double)n_est >= 0.75 * (double)h->nrm_n;
+  if (!reuse && c.lazy_slot >= 0) {
+    const int rr = resolve_count(h, c, true);
+    if (rr) return rr;
+    if (c.n == 0) return O3DS_OK;
+    n_est = c.n;
+    reuse = h->nrm_cell > 0.0 && h->nrm_radius == radius && h->nrm_knn == max_nn && h->nrm_age < 32 &&
+            (double)n_est <= 1.25 * (double)h->nrm_n && (double)n_est >= 0.75 * (double)h->nrm_n;
+  }
+  const int* n_dev = c.lazy_slot >= 0 ? cnt_word(h, c.lazy_slot) : nullptr;
   CloudRec tmp;
   tmp.n = c.n;
   tmp.precision = c.precision;
   tmp.pts = c.pts;  // borrowed
+  tmp.lazy_slot = c.lazy_slot;  // (borrowed as well: build_index_t hands the device word to its kernels)
   box_copy(tmp, c);
   int rc = O3DS_OK;
-  const bool reuse = h->nrm_cell > 0.0 && h->nrm_radius == radius && h->nrm_knn == max_nn && h->nrm_age < 32 &&
-                     (double)c.n <= 1.25 * (double)h->nrm_n && (double)c.n >= 0.75 * (double)h->nrm_n;
   if (reuse) {
     ++h->nrm_age;
     rc = build_index_t<P4>(h, tmp, h->nrm_cell);
@@ -2518,11 +2870,11 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn, bool knn_ra
     span_mark(h, kSpanNormalsKernels);
     if (max_nn <= 32) {  // the shipped configs' knn is 20
       if constexpr (sizeof(P4) == 16)
-        normals_kernel_occ5<P4, 32><<<gsz, 64 * o3ds::kNrmWaves, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, d_sums, d_cnts);
+        normals_kernel_occ5<P4, 32><<<gsz, 64 * o3ds::kNrmWaves, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, d_sums, d_cnts, n_dev);
       else
-        normals_kernel<P4, 32><<<gsz, 64 * o3ds::kNrmWaves, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, d_sums, d_cnts);
+        normals_kernel<P4, 32><<<gsz, 64 * o3ds::kNrmWaves, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, d_sums, d_cnts, n_dev);
     } else
-      normals_kernel<P4, 128><<<gsz, 64 * o3ds::kNrmWaves, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, d_sums, d_cnts);
+      normals_kernel<P4, 128><<<gsz, 64 * o3ds::kNrmWaves, 0, h->stream>>>(p_pts, c.n, tmp.grid, p_sp, radius, max_nn, rmax, d_sums, d_cnts, n_dev);
     // the grid, the cell-ordered points and (written here) the cell-ordered normals are a complete nearest-neighbour index of the cloud:
     // kept, so that a registration against this cloud (scan-to-scan odometry: the previous scan) does not build another one
     if (dev_alloc(h, (void**)&tmp.snrm, sizeof(P4) * c.n) != hipSuccess) {
@@ -2530,7 +2882,7 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn, bool knn_ra
       free_index(h, tmp);
       return fail(h, O3DS_ERR_OOM, "estimate_normals: out of device memory");
     }
-    normals_finish_kernel<P4><<<(unsigned int)((c.n + 255) / 256), 256, 0, h->stream>>>(p_sp, c.n, d_sums, d_cnts, p_out, knn_raw ? 1 : 0, (P4*)tmp.snrm);
+    normals_finish_kernel<P4><<<(unsigned int)((c.n + 255) / 256), 256, 0, h->stream>>>(p_sp, c.n, d_sums, d_cnts, p_out, knn_raw ? 1 : 0, (P4*)tmp.snrm, n_dev);
     span_mark(h, kSpanNormalsKernels);
   }
   HIP_TRY(hipGetLastError());
@@ -2718,7 +3070,7 @@ int carve_t(o3ds_handle h, CloudRec& map, const CloudRec& scan, const double T[1
     HIP_TRY(hipGetLastError());
   }
   free_index(h, map);
-  dev_free(h, map.pts);
+  free_points(h, map);
   if (map.nrm) dev_free(h, map.nrm);
   if (map.col) dev_free(h, map.col);
   map.pts = np;
@@ -2830,7 +3182,7 @@ int append_t(o3ds_handle h, CloudRec& map, const CloudRec& add) {
   dbg_sync(h, 32);
   guard.release();
   free_index(h, map);
-  if (map.pts) dev_free(h, map.pts);
+  free_points(h, map);
   if (map.nrm) dev_free(h, map.nrm);
   if (map.col) dev_free(h, map.col);
   map.pts = np;
@@ -2906,7 +3258,7 @@ int o3ds_crop_voxel_down_sample(o3ds_handle h, o3ds_cloud in, const o3ds_crop* c
 int o3ds_estimate_normals(o3ds_handle h, o3ds_cloud id, double radius, int max_nn) {
   CHECK_HANDLE(h);
   ArenaScope arena_scope(h);
-  CloudRec* c = find_cloud(h, id);
+  CloudRec* c = find_cloud_lazy(h, id);
   if (!c) return fail(h, O3DS_ERR_INVALID_ARG, "estimate_normals: unknown cloud id");
   if (!(radius > 0.0)) return fail(h, O3DS_ERR_INVALID_ARG, "maxRadiusNormalEstimation_ must be > 0");  // CloudRegistration.cpp:50
   if (max_nn <= 0) return fail(h, O3DS_ERR_INVALID_ARG, "knnNormalEstimation_ must be > 0");              // CloudRegistration.cpp:51
@@ -3040,6 +3392,360 @@ int voxelize_within_volume_impl(o3ds_handle h, o3ds_cloud map, double voxel_size
   return O3DS_OK;
 }
 }  // namespace
+
+// ---- the persistent form of a submap (map_kernels.hpp): enter, insert, leave ------------------------------------------------------------
+namespace {
+
+#define PM_ALLOC(ptr, bytes)                                                                               \
+  do {                                                                                                     \
+    void* _p = nullptr;                                                                                    \
+    if (dev_alloc(h, &_p, (size_t)(bytes)) != hipSuccess) return fail(h, O3DS_ERR_OOM, "persistent map: out of device memory"); \
+    pm->blocks.push_back(_p);                                                                              \
+    (ptr) = (decltype(ptr))_p;                                                                             \
+  } while (0)
+
+// cell edge of the row-paged index in voxels: the classic index uses max_corr / 4; here a whole number of voxels
+int pm_cell_voxels(double max_corr_hint, double voxel) {
+  const double want = max_corr_hint > 0.0 ? max_corr_hint / index_cell_div() : 2.5 * voxel;
+  return std::max(1, (int)std::floor(want / voxel + 0.5));
+}
+
+// The map `c` -- an array [pass-through block | voxel block in key order] (vox_first / vox_count) with normals or without -- enters the
+// persistent form.  O(N): history and voxel hash of every point, the row-paged search index.
+template <typename P4>
+int pm_enter_t(o3ds_handle h, CloudRec& c, double voxel, double max_corr_hint, size_t scan_upper) {
+  const size_t n = c.n;
+  PMapRec* pm = new PMapRec();
+  c.pm = pm;  // (from here on free_cloud / pm_release own it)
+  // room: half the map again and a few scans' worth
+  const size_t want_cap = n + std::max<size_t>({n / 2, 16 * scan_upper, (size_t)1 << 18});
+  if (c.cap < n + 4 * scan_upper || (c.nrm && false)) {
+    void *np = nullptr, *nn = nullptr;
+    HIP_TRY(dev_alloc(h, &np, sizeof(P4) * want_cap));
+    HIP_TRY(hipMemcpyAsync(np, c.pts, sizeof(P4) * n, hipMemcpyDeviceToDevice, h->stream));
+    if (c.nrm) {
+      if (dev_alloc(h, &nn, sizeof(P4) * want_cap) != hipSuccess) {
+        dev_free(h, np);
+        return fail(h, O3DS_ERR_OOM, "persistent map: out of device memory");
+      }
+      HIP_TRY(hipMemcpyAsync(nn, c.nrm, sizeof(P4) * n, hipMemcpyDeviceToDevice, h->stream));
+    }
+    free_points(h, c);
+    if (c.nrm) dev_free(h, c.nrm);
+    c.pts = np;
+    c.nrm = nn;
+    c.cap = want_cap;
+  }
+  const size_t cap = c.cap;
+  PmDev& d = pm->dev;
+  d.pts = c.pts;
+  d.nrm = c.nrm;
+  d.cap = cap;
+  PM_ALLOC(d.stamp, sizeof(int) * cap);
+  PM_ALLOC(d.okey, sizeof(unsigned long long) * cap);
+  PM_ALLOC(d.hnext, sizeof(int) * cap);
+  PM_ALLOC(d.pos, sizeof(int) * cap);
+  PM_ALLOC(d.rnext, sizeof(int) * cap);
+  PM_ALLOC(d.flags, cap);
+  size_t hcap = 1024;
+  while (hcap < 2 * cap) hcap <<= 1;
+  PM_ALLOC(d.hkey, sizeof(unsigned long long) * hcap);
+  PM_ALLOC(d.hhead, sizeof(int) * hcap);
+  PM_ALLOC(d.hflag, sizeof(unsigned int) * hcap);
+  d.hmask = (unsigned int)(hcap - 1);
+  HIP_TRY(hipMemsetAsync(d.hkey, 0xff, sizeof(unsigned long long) * hcap, h->stream));
+  HIP_TRY(hipMemsetAsync(d.hhead, 0xff, sizeof(int) * hcap, h->stream));
+  HIP_TRY(hipMemsetAsync(d.hflag, 0, sizeof(unsigned int) * hcap, h->stream));
+  d.list_cap = (int)std::min<size_t>(cap, 0x7fffffff);
+  PM_ALLOC(d.counters, sizeof(int) * kPmCounters);
+  for (int k = 0; k < 2; ++k) {
+    PM_ALLOC(d.unsettled[k], sizeof(int) * cap);
+    PM_ALLOC(d.multi[k], sizeof(unsigned long long) * cap);
+  }
+  PM_ALLOC(d.complex_groups, sizeof(int) * cap);
+  PM_ALLOC(d.outside_pts, sizeof(int) * cap);
+  PM_ALLOC(d.relink, sizeof(int) * cap);
+  PM_ALLOC(d.touched_rows, sizeof(int) * cap);
+  PM_ALLOC(pm->d_hist, sizeof(CropDev) * (kPmHistory + 1));
+  d.hist = pm->d_hist;
+  d.n_base = (int)n;
+  d.np_base = (int)c.vox_first;
+  d.voxel = voxel;
+  d.inv_voxel = 1.0 / voxel;
+  // the grid of the index: aligned with the voxel grid, over the map's box with a margin (points beyond it are clamped into the border cells,
+  // as build_grid_t's cell_of does: slower to search, never wrong)
+  if (!c.has_box) {
+    double mn[3], mx[3];
+    const int rb = bbox_of<P4>(h, (const P4*)c.pts, n, mn, mx);
+    if (rb) return rb;
+    c.has_box = true;
+    c.box_padded = false;
+    for (int a = 0; a < 3; ++a) c.bmn[a] = mn[a], c.bmx[a] = mx[a];
+  }
+  for (int a = 0; a < 3; ++a)
+    if (!std::isfinite(c.bmn[a]) || !std::isfinite(c.bmx[a])) return fail(h, O3DS_ERR_INVALID_ARG, "persistent map: non-finite coordinates");
+  d.kc = pm_cell_voxels(max_corr_hint, voxel);
+  double cell = d.kc * voxel;
+  long long g0[3], gn[3];
+  for (;;) {
+    for (int a = 0; a < 3; ++a) {
+      const double ext = c.bmx[a] - c.bmn[a];
+      const double pad = a < 2 ? std::max(5.0, 0.1 * ext) : std::max(2.0, 0.1 * ext);
+      const long long lo = (long long)std::floor((c.bmn[a] - pad) / cell), hi = (long long)std::floor((c.bmx[a] + pad) / cell);
+      g0[a] = lo * d.kc;
+      gn[a] = hi - lo + 1;
+    }
+    if ((double)gn[0] * (double)gn[1] * (double)gn[2] <= (double)kMaxCells / 2 && gn[0] < 5000) break;  // (pm_rows_kernel keeps three ints per cell of a row in LDS)
+    d.kc *= 2;
+    cell = d.kc * voxel;
+  }
+  for (int a = 0; a < 3; ++a)
+    if (std::llabs(g0[a]) + gn[a] * d.kc >= (1ll << 20)) return fail(h, O3DS_ERR_INVALID_ARG, "persistent map: voxel coordinates beyond 2^20");
+  d.gx0 = g0[0], d.gy0 = g0[1], d.gz0 = g0[2];
+  GridDev g{};
+  g.ox = (double)g0[0] * voxel;
+  g.oy = (double)g0[1] * voxel;
+  g.oz = (double)g0[2] * voxel;
+  g.cell = cell;
+  g.inv_cell = 1.0 / cell;
+  g.nx = (int)gn[0], g.ny = (int)gn[1], g.nz = (int)gn[2];
+  g.sx = g.nx + 1;
+  pm->rows = (size_t)g.ny * g.nz;
+  const size_t table = pm->rows * (size_t)g.sx;
+  // the arrays of the index hang on the cloud (free_index): the registration uses them like any index
+  free_index(h, c);
+  int* cs = nullptr;
+  HIP_TRY(dev_alloc(h, (void**)&cs, sizeof(int) * (table + 1 + 4)));
+  c.cell_start = cs;
+  const size_t pool = 6 * n + 16 * scan_upper + ((size_t)1 << 22);
+  if (pool >= ((size_t)1 << 31)) return fail(h, O3DS_ERR_OOM, "persistent map: index pool beyond 2^31 positions");
+  HIP_TRY(dev_alloc(h, &c.spts, sizeof(P4) * pool));
+  if (c.nrm) HIP_TRY(dev_alloc(h, &c.snrm, sizeof(P4) * pool));
+  PM_ALLOC(d.row_cap, sizeof(int) * pm->rows);
+  PM_ALLOC(d.row_head, sizeof(int) * pm->rows);
+  g.cell_start = cs;
+  d.grid = g;
+  d.cs = cs;
+  d.spts = c.spts;
+  d.snrm = c.snrm;
+  d.pool_cap = (int)pool;
+  // counters: the handle's block of zeros (build_grid_t's: counted up, scanned, counted back down to zero by the scatter)
+  if (h->cells_cap < table + 1) {
+    if (h->d_cells) {
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      (void)hipFree(h->d_cells);
+      h->d_cells = nullptr;
+      h->cells_cap = 0;
+    }
+    const size_t want = table + 1 + table / 4;
+    if (hipMalloc((void**)&h->d_cells, sizeof(int) * want) != hipSuccess) return fail(h, O3DS_ERR_OOM, "persistent map: cell counters allocation failed");
+    h->cells_cap = want;
+    h->cells_clean = false;
+  }
+  if (!h->cells_clean) HIP_TRY(hipMemsetAsync(h->d_cells, 0, sizeof(int) * h->cells_cap, h->stream));
+  h->cells_clean = false;
+  HIP_TRY(hipMemsetAsync(d.counters, 0, sizeof(int) * kPmCounters, h->stream));
+  HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(d.counters + kPmN), (int)n, 1, h->stream));
+  int* cell_id = nullptr;
+  TMP_ALLOC(cell_id, sizeof(int) * n);
+  const int ni = (int)n;
+  span_mark(h, kSpanIndexBuild);
+  pm_enter_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(d, ni);
+  pm_cell_count_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(d, ni, h->d_cells, cell_id);
+  pm_row_slack_kernel<<<grid_for(pm->rows * 64), kBlock, 0, h->stream>>>(h->d_cells, (int)pm->rows, g.nx, d.row_cap, d.row_head);
+  int rc = exclusive_scan_int(h, h->d_cells, cs, table + 1);
+  if (rc) return rc;
+  pm_row_finish_kernel<<<grid_for(pm->rows), kBlock, 0, h->stream>>>(h->d_cells, cs, (int)pm->rows, g.nx, d.counters + kPmPoolTop);
+  pm_scatter_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(d, ni, cell_id, h->d_cells);
+  span_mark(h, kSpanIndexBuild);
+  HIP_TRY(hipGetLastError());
+  h->cells_clean = true;
+  c.grid = g;
+  c.has_index = true;
+  c.index_byproduct = false;
+  c.index_positions = pool;
+  pm->t = 0;
+  pm->n_upper = n;
+  pm->live_lower = n;
+  pm->pool_top = (double)(n + n / 2 + 8 * pm->rows);  // (an upper bound until the first record arrives: count + slack of every row)
+  pm->rec_slot = take_rec(h);
+  h->rec_owner[pm->rec_slot] = ~0ull;
+  pm->rec_seq = 0;
+  return O3DS_OK;
+}
+
+// what the latest record the insertions published says, if it has arrived (never waits unless `block`)
+int pm_poll(o3ds_handle h, PMapRec* pm, bool block) {
+  if (pm->rec_seq == 0) return O3DS_OK;
+  volatile o3ds_context::PinRec* r = h->h_rec + pm->rec_slot;
+  if (r->seq != pm->rec_seq) {
+    if (!block) return O3DS_OK;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (r->seq != pm->rec_seq) return fail(h, O3DS_ERR_HIP, "persistent map: an insertion never published its record");
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  const size_t slots = (size_t)r->cnt, dead = (size_t)r->box[1];
+  if ((int)r->box[2] != 0) return fail(h, O3DS_ERR_CAPACITY, "persistent map: an internal capacity was exceeded (error " + std::to_string((int)r->box[2]) + ")");
+  pm->n_upper = slots;
+  pm->live_lower = slots - dead;
+  pm->pool_top = r->box[0];
+  pm->rec_seq = 0;  // consumed
+  return O3DS_OK;
+}
+
+// Submap::insertScan's map += T * scan; voxelizeWithinCroppingVolume on the persistent form: six launches over the scan, nothing returns
+template <typename P4>
+int pm_insert_t(o3ds_handle h, CloudRec& c, const CloudRec& scan, const double T[16], const CropDev& crop) {
+  PMapRec* pm = c.pm;
+  PmDev d = pm->dev;
+  const size_t ms = scan.n;  // (an upper bound when the scan's size is still in flight)
+  const bool has_nrm = c.nrm != nullptr;
+  const int t_now = pm->t + 1;
+  // scratch: the voxel table of VoxelDownSample, the chained scan's tiles
+  size_t tcap = 1024;
+  while (tcap < 2 * ms) tcap <<= 1;
+  if (h->voxtab_cap < tcap) {
+    if (h->d_voxtab) {
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      (void)hipFree(h->d_voxtab);
+      h->d_voxtab = nullptr;
+      h->voxtab_cap = 0;
+    }
+    if (hipMalloc((void**)&h->d_voxtab, kVoxSlotBytes * tcap + 16) != hipSuccess) return fail(h, O3DS_ERR_OOM, "map_insert_scan: voxel table allocation failed");
+    h->voxtab_cap = tcap;
+    h->voxtab_clean = false;
+  }
+  tcap = h->voxtab_cap;
+  unsigned char* tab = h->d_voxtab;
+  VoxTable t{(unsigned long long*)tab, (unsigned int*)(tab + 8 * tcap), (int*)(tab + 12 * tcap), (unsigned int*)(tab + 16 * tcap),
+             (unsigned int*)(tab + kVoxSlotBytes * tcap), (unsigned int)(tcap - 1)};
+  if (!h->voxtab_clean) HIP_TRY(hipMemsetAsync(tab, 0xff, kVoxSlotBytes * tcap + 16, h->stream));
+  h->voxtab_clean = false;
+  const size_t n_tiles = (ms + kVoxTile - 1) / kVoxTile;
+  if (h->tiles_cap < n_tiles) {
+    if (h->d_tiles) {
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      (void)hipFree(h->d_tiles);
+      h->d_tiles = nullptr;
+      h->tiles_cap = 0;
+    }
+    const size_t want = std::max<size_t>(n_tiles + n_tiles / 4, 1024);
+    if (hipMalloc((void**)&h->d_tiles, sizeof(unsigned long long) * want) != hipSuccess) return fail(h, O3DS_ERR_OOM, "map_insert_scan: scan state allocation failed");
+    HIP_TRY(hipMemsetAsync(h->d_tiles, 0, sizeof(unsigned long long) * want, h->stream));
+    h->tiles_cap = want;
+  }
+  P4 *placed = nullptr, *placed_nrm = nullptr;
+  int *lead_slot = nullptr, *run_next = nullptr, *run_len = nullptr, *order = nullptr, *d_groups = nullptr;
+  uint32_t* starts = nullptr;
+  int2* piece = nullptr;
+  unsigned long long* group_key = nullptr;
+  TMP_ALLOC(placed, sizeof(P4) * ms);
+  if (has_nrm) TMP_ALLOC(placed_nrm, sizeof(P4) * ms);
+  TMP_ALLOC(lead_slot, sizeof(int) * ms);
+  TMP_ALLOC(run_next, sizeof(int) * ms);
+  TMP_ALLOC(run_len, sizeof(int) * ms);
+  TMP_ALLOC(order, sizeof(int) * ms);
+  TMP_ALLOC(starts, sizeof(uint32_t) * ms);
+  TMP_ALLOC(piece, sizeof(int2) * ms);
+  TMP_ALLOC(group_key, sizeof(unsigned long long) * ms);
+  TMP_ALLOC(d_groups, sizeof(int) * 16);
+  Mat34 M;
+  for (int r = 0; r < 3; ++r)
+    for (int cc = 0; cc < 4; ++cc) M.m[r * 4 + cc] = T[cc * 4 + r];
+  if (++h->scan_gen == 0) h->scan_gen = 1;
+  const CountRef n_scan = count_ref(h, scan);
+  const CountPub groups_pub{d_groups, nullptr, 0};
+  const CountRef groups{ms, d_groups};
+  pm_place_kernel<P4><<<grid_for(ms), kBlock, 0, h->stream>>>((const P4*)scan.pts, has_nrm ? (const P4*)scan.nrm : nullptr, n_scan, M, T[3], T[7], T[11], T[15], crop, d, t,
+                                                            placed, placed_nrm, lead_slot, run_next, run_len);
+  vox_order_kernel<<<(unsigned int)n_tiles, kBlock, 0, h->stream>>>(lead_slot, n_scan, t, h->d_tiles, h->d_ticket, h->ticket_base, h->scan_gen, order, groups_pub);
+  h->ticket_base += (unsigned int)n_tiles;
+  pm_group_kernel<P4><<<grid_for(ms), kBlock, 0, h->stream>>>(d, groups, order, run_next, run_len, starts, piece, placed, placed_nrm, t, crop, t_now, group_key);
+  h->voxtab_clean = true;
+  pm_merge_kernel<P4><<<16, 64, 0, h->stream>>>(d, piece, starts, run_len, placed, placed_nrm, group_key, crop, t_now);
+  pm_misc_kernel<P4><<<256, kBlock, 0, h->stream>>>(d, placed, placed_nrm, crop, t_now);
+  const unsigned int row_blocks = (unsigned int)std::min<size_t>(std::max<size_t>(ms / 8, 64), 2048);
+  pm_rows_kernel<P4><<<row_blocks, 64, sizeof(int) * 3 * (size_t)(d.grid.nx + 1), h->stream>>>(d);
+  pm->rec_seq = ++h->rec_seq;
+  o3ds_context::PinRec* rec = h->h_rec_dev + pm->rec_slot;
+  const CountPub pub{cnt_word(h, pm->rec_slot), &rec->cnt, pm->rec_seq};
+  pm_turn_kernel<<<1, 64, 0, h->stream>>>(d, pub, pm->d_hist, crop, t_now, rec->box);
+  HIP_TRY(hipGetLastError());
+  // the lists trade places for the next insertion
+  std::swap(pm->dev.unsettled[0], pm->dev.unsettled[1]);
+  std::swap(pm->dev.multi[0], pm->dev.multi[1]);
+  pm->t = t_now;
+  pm->n_upper += ms;
+  c.n = pm->n_upper;
+  return O3DS_OK;
+}
+
+// the reference's array back: [pass-through block in original order | voxel block in key order], then the ordinary cloud it was
+template <typename P4>
+int pm_exit_t(o3ds_handle h, CloudRec& c) {
+  PMapRec* pm = c.pm;
+  int rc = pm_poll(h, pm, true);
+  if (rc) return rc;
+  int counters[kPmCounters];
+  rc = read_back(h, {{counters, pm->dev.counters, sizeof(counters)}});
+  if (rc) return rc;
+  if (counters[kPmError]) return fail(h, O3DS_ERR_CAPACITY, "persistent map: an internal capacity was exceeded (error " + std::to_string(counters[kPmError]) + ")");
+  const size_t n = (size_t)counters[kPmN], live = n - (size_t)counters[kPmDeadCnt];
+  unsigned long long *hi = nullptr, *lo = nullptr, *k1 = nullptr, *d_np = nullptr;
+  uint32_t *v0 = nullptr, *v1 = nullptr;
+  TMP_ALLOC(hi, sizeof(unsigned long long) * n);
+  TMP_ALLOC(lo, sizeof(unsigned long long) * n);
+  TMP_ALLOC(k1, sizeof(unsigned long long) * n);
+  TMP_ALLOC(v0, sizeof(uint32_t) * n);
+  TMP_ALLOC(v1, sizeof(uint32_t) * n);
+  TMP_ALLOC(d_np, sizeof(unsigned long long));
+  HIP_TRY(hipMemsetAsync(d_np, 0, sizeof(unsigned long long), h->stream));
+  pm_view_key_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(pm->dev, (int)n, pm->t, hi, lo, v0, d_np);
+  // order by (hi, lo): two stable sorts, least significant key first
+  size_t tb = 0;
+  HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, lo, k1, v0, v1, n, 0, 64, h->stream));
+  void* tmp = nullptr;
+  TMP_ALLOC(tmp, tb ? tb : 16);
+  HIP_TRY(rocprim::radix_sort_pairs(tmp, tb, lo, k1, v0, v1, n, 0, 64, h->stream));
+  pm_gather_u64_kernel<<<grid_for(n), kBlock, 0, h->stream>>>(hi, v1, n, lo);  // lo := hi in the order of the first sort
+  HIP_TRY(rocprim::radix_sort_pairs(tmp, tb, lo, k1, v1, v0, n, 0, 64, h->stream));
+  unsigned long long n_pass = 0;
+  rc = read_back(h, {{&n_pass, d_np, sizeof(n_pass)}});
+  if (rc) return rc;
+  const size_t room = live + std::max<size_t>(live / 4, (size_t)1 << 18);
+  void *np = nullptr, *nn = nullptr;
+  if (live > 0) {
+    HIP_TRY(dev_alloc(h, &np, sizeof(P4) * room));
+    if (c.nrm && dev_alloc(h, &nn, sizeof(P4) * room) != hipSuccess) {
+      dev_free(h, np);
+      return fail(h, O3DS_ERR_OOM, "persistent map: out of device memory");
+    }
+    pm_permute_kernel<P4><<<grid_for(live), kBlock, 0, h->stream>>>((const P4*)c.pts, (const P4*)c.nrm, v0, live, (P4*)np, (P4*)nn);
+    HIP_TRY(hipGetLastError());
+  }
+  pm_release(h, c);
+  free_index(h, c);
+  free_points(h, c);
+  if (c.nrm) dev_free(h, c.nrm);
+  c.pts = np;
+  c.nrm = nn;
+  c.n = live;
+  c.cap = live > 0 ? room : 0;
+  c.vox_first = (long long)n_pass;
+  c.vox_count = live - (size_t)n_pass;
+  return O3DS_OK;
+}
+
+}  // namespace
+
+namespace {
+int pm_exit(o3ds_handle h, CloudRec& c) {
+  if (!c.pm) return O3DS_OK;
+  ArenaScope arena_scope(h);
+  return c.precision == O3DS_PRECISION_F64 ? pm_exit_t<P4d>(h, c) : pm_exit_t<P4f>(h, c);
+}
+}  // namespace
+
 extern "C" {
 
 int o3ds_voxelize_within_volume(o3ds_handle h, o3ds_cloud map, double voxel_size, const o3ds_crop* crop) {
@@ -3356,23 +4062,76 @@ int o3ds_map_insert_scan(o3ds_handle h, o3ds_cloud map, o3ds_cloud scan, const d
                          const o3ds_crop* map_builder_crop, double max_corr_hint) {
   CHECK_HANDLE(h);
   ArenaScope arena_scope(h);
-  CloudRec* m = find_cloud(h, map);
-  CloudRec* s = find_cloud(h, scan);
+  CloudRec* m = find_cloud_lazy(h, map);  // (a map in its persistent form stays in it)
+  CloudRec* s = find_cloud_lazy(h, scan);
   if (!m || !s || !T || m == s) return fail(h, O3DS_ERR_INVALID_ARG, "map_insert_scan: bad argument");
+  if (s->pm) return fail(h, O3DS_ERR_INVALID_ARG, "map_insert_scan: the scan is a map");
   if (s->n == 0) return O3DS_OK;  // Submap.cpp:41-43: empty pre-processed scan is a no-op
   if (m->n == 0) m->precision = s->precision;
   if (m->precision != s->precision) return fail(h, O3DS_ERR_INVALID_ARG, "map_insert_scan: precision mismatch");
+  int rc = O3DS_OK;
+  // ---- the persistent form (map_kernels.hpp): work proportional to the scan.  It takes a map with a known layout [pass-through block | voxel
+  // block in key order] -- what the first insertion into a map (below) or a fold leaves --, a search index being wanted, no colours, and map
+  // and scan agreeing on normals ([O3D] operator+= drops the map's normals otherwise).
+  static const bool no_pm = ab_getenv("O3DS_NO_PERSISTENT_MAP") != nullptr;  // A/B and the bitwise tests: the array form at every insertion
+  const bool pm_ok = !no_pm && map_voxel_size > 0.0 && max_corr_hint > 0.0 && !m->col && !s->col && m->n > 0 && (m->nrm != nullptr) == (s->nrm != nullptr) &&
+                     m->n + s->n < ((size_t)1 << 30);
+  const CropDev cd = to_dev(map_builder_crop);
+  CloudRec placed;
+  placed.n = s->n;
+  box_transform(placed, *s, T);
+  if (m->pm) {
+    PMapRec* pm = m->pm;
+    rc = pm_poll(h, pm, false);
+    if (rc) return rc;
+    bool refold = !pm_ok || pm->dev.voxel != map_voxel_size || pm->dev.kc != pm_cell_voxels(max_corr_hint, map_voxel_size) || pm->t + 1 > kPmHistory;
+    const double growth = 2.0 * (double)(pm->n_upper + s->n) + 8.0 * (double)s->n;  // every touched row moving to the pool's end
+    if (!refold && (pm->n_upper + s->n > pm->dev.cap || pm->pool_top + growth > (double)pm->dev.pool_cap)) {
+      rc = pm_poll(h, pm, true);  // the bounds were pessimistic? the exact numbers
+      if (rc) return rc;
+      refold = pm->n_upper + s->n > pm->dev.cap || pm->pool_top + growth > (double)pm->dev.pool_cap;
+    }
+    if (!refold && placed.has_box) {  // a scan far outside the index grid: new extents at the fold
+      const GridDev& g = pm->dev.grid;
+      const double lo[3] = {g.ox, g.oy, g.oz}, hi[3] = {g.ox + g.nx * g.cell, g.oy + g.ny * g.cell, g.oz + g.nz * g.cell};
+      for (int a = 0; a < 3; ++a)
+        if (placed.bmn[a] < lo[a] - 8.0 * g.cell || placed.bmx[a] > hi[a] + 8.0 * g.cell) refold = true;
+    }
+    if (refold) {
+      rc = pm_exit(h, *m);
+      if (rc) return rc;
+    }
+  }
+  if (!m->pm && pm_ok && m->vox_first >= 0 && (size_t)m->vox_first + m->vox_count == m->n) {
+    rc = DISPATCH(m->precision, pm_enter_t, h, *m, map_voxel_size, max_corr_hint, s->n);
+    if (rc) {
+      pm_release(h, *m);
+      m->vox_first = -1;
+      return rc;
+    }
+  }
+  if (m->pm) {
+    CloudRec joined;
+    box_union(joined, *m, placed);
+    rc = DISPATCH(m->precision, pm_insert_t, h, *m, *s, T, cd);
+    if (rc) return rc;
+    box_copy(*m, joined);
+    m->pm->pool_top += 2.0 * (double)(m->pm->n_upper) + 8.0 * (double)s->n;
+    return O3DS_OK;
+  }
+  // ---- the array form (the reference's own way: everything is re-binned): the first insertions of a map, colours, a call without index ...
+  rc = resolve_count(h, *s, true);
+  if (rc) return rc;
+  if (s->n == 0) return O3DS_OK;
   // the layout the previous insertion left (pass-through block, then the voxel block in key order): the merge below re-bins by merging
   const bool known = m->vox_first >= 0 && (size_t)m->vox_first + m->vox_count == m->n;
   const long long merge_np = known ? m->vox_first : -1;
   const size_t merge_nv = known ? m->vox_count : 0;
-  int rc = O3DS_OK;
   if (m->n > 0 && m->cap >= m->n + s->n && m->nrm && s->nrm && !m->col && !s->col) {
     // transform (Submap.cpp:54) and operator+= (Submap.cpp:70) in one launch: the placed points go behind the map's last one, where the
     // previous merge left room -- the same kernel with the same arithmetic as transform_t, indices as append_t assigns them
-    CloudRec placed, joined;
+    CloudRec joined;
     placed.n = s->n;
-    box_transform(placed, *s, T);
     box_union(joined, *m, placed);
     Mat34 M;
     for (int r = 0; r < 3; ++r)

@@ -585,32 +585,31 @@ __global__ __launch_bounds__(kBlock) void segment_last_kernel(const P4* __restri
 // (key -> segment) and one thread per ray marches and probes; marking a point is an idempotent store, no atomics.
 constexpr unsigned long long kEmptyKey = ~0ull;
 
-// ---- VoxelDownSample without a sort -------------------------------------------------------------------------------------------------------
+// ---- VoxelDownSample without a sort, in three launches ------------------------------------------------------------------------------------
 // [O3D] VoxelDownSample walks the points once and keeps an unordered_map voxel -> AccumulatedPoint, so a voxel's sum runs over its points
-// in cloud order.  Same thing here: an open-addressing table finds the voxels (which thread claims a slot is a race, what is READ from the
-// table is not: the set of keys, a voxel's smallest point index and its count), the voxels are numbered in order of first appearance
-// by a scan over "I am the first point of my voxel" flags, the members of a voxel are gathered and put in ascending index order, then
-// summed.  Four small kernels and two scans instead of a 64-bit radix sort of every point; output order = first appearance, which is
-// also the order the oracle emits.  One 0xff memset initialises the table: empty keys, first = UINT_MAX, and the counter holds ~count.
+// in cloud order and (here, as in the oracle) the voxels come out in order of first appearance.  Three kernels, no sort, no size read-back:
+//   vox_insert_kernel   every RUN of equal keys in consecutive lanes (a lidar scan lists its points along the scan lines: neighbours in the
+//                       array are neighbours in space, two points share a voxel on average and mostly sit next to each other) enters an
+//                       open-addressing table once: its first lane claims the slot, lowers the voxel's smallest point index, and pushes
+//                       the run {first index, length} onto the voxel's run list (an exchange of the list head).  Which thread claims a slot
+//                       or pushes first is a race; what is READ later is not: the set of keys, a voxel's smallest index, its set of runs.
+//   vox_order_kernel    one pass over "this point opens its voxel" flags (a chained scan: every tile publishes its sum and looks back):
+//                       the voxels numbered in order of first appearance, order[r] = table slot, the number of voxels to the device
+//                       word and the pinned record the consumers of the cloud and the host read it from (CountPub).
+//   vox_mean_kernel     one thread per voxel: its runs put in ascending order (they are few), the sums taken run by run -- i.e. in cloud
+//                       order --, the slot handed back empty (the table is all 0xff between calls, no memset per call).
+// Rounds 1-4 ran bbox, bbox-final, insert, two scan kernels, a wait for the size, number, gather, mean: 46 MB of counter traffic for a
+// 4.4 MB job; the box now comes with the ingest (pack_strided_f32_box_kernel), the scan is one kernel, the member lists
+// are run lists built by the insert itself.
 struct VoxTable {
   unsigned long long* key;  // [cap]
-  unsigned int* first;      // [cap] smallest point index of the voxel; after vox_number_kernel: the voxel's output position
-  unsigned int* ncnt;       // [cap] ~(number of points)
-  unsigned int* cursor;     // one word behind the table: (next free entry of the member list) - 1, i.e. 0xffffffff like everything else
+  unsigned int* first;      // [cap] smallest point index of the voxel
+  int* head;                // [cap] last run pushed (index of its first point); -1 = none
+  unsigned int* nrun;       // [cap] (number of runs) - 1
+  unsigned int* cursor;     // one word behind the table: next free entry of vox_mean_kernel's run-start scratch
   unsigned int mask;
 };
-
-// "point i opens its voxel" as the input of a scan (no flag array, no kernel to fill it): entry n is the zero sentinel
-struct VoxFirstFlag {
-  const int* slot_of;
-  size_t n;
-  VoxTable t;
-  __device__ __forceinline__ int operator()(size_t i) const {
-    if (i >= n) return 0;
-    const int s = slot_of[i];
-    return s >= 0 && t.first[s] == (unsigned int)i;
-  }
-};
+constexpr size_t kVoxSlotBytes = 20;  // 8 + 4 + 4 + 4 per slot
 
 // scan_local_kernel (icp_kernels.hpp) with its input computed on the fly
 template <typename T, typename Load>
@@ -667,18 +666,101 @@ __global__ __launch_bounds__(64) void bbox_final_kernel(const double* __restrict
     }
 }
 
-// box: {min x y z, ...} of the points the grid is anchored at; [O3D] voxel_min_bound = GetMinBound() - voxel_size * 0.5
+// one workgroup's bounding box into the cloud's box record: 6 atomics on order-preserving integer images of the doubles (min x y z, max x y z);
+// all threads call it.
+__device__ __forceinline__ void block_box_atomic(double mn[3], double mx[3], unsigned long long* __restrict__ box) {
+  __shared__ double s_box[kBlock / 64][6];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      mn[a] = fmin(mn[a], __shfl_xor(mn[a], m, 64));
+      mx[a] = fmax(mx[a], __shfl_xor(mx[a], m, 64));
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      s_box[w][a] = mn[a];
+      s_box[w][3 + a] = mx[a];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    double v = s_box[0][threadIdx.x];
+    for (int k = 1; k < kBlock / 64; ++k) v = threadIdx.x < 3 ? fmin(v, s_box[k][threadIdx.x]) : fmax(v, s_box[k][threadIdx.x]);
+    // (a workgroup without a point inside the volume adds the record's own initial values: 1e300 / -1e300)
+    if (threadIdx.x < 3)
+      atomicMin(box + threadIdx.x, order_bits(v));
+    else
+      atomicMax(box + threadIdx.x, order_bits(v));
+  }
+}
+// the ingest of a PointCloud2-style buffer (pack_strided_f32_kernel) that also reduces the bounding box of the points inside `crop` -- the
+// volume the handle's last crop + VoxelDownSample used: a lidar stream crops every scan with the same one -- so that the pre-processing
+// of the scan starts with its grid anchor known instead of with two launches that read every point again
 template <typename P4>
-__global__ __launch_bounds__(kBlock) void vox_insert_kernel(const P4* __restrict__ pts, size_t n, const double* __restrict__ box, double v,
-                                                            CropDev crop, int filter, VoxTable t, int* __restrict__ slot_of) {
-  const double ox = box[0] - v * 0.5, oy = box[1] - v * 0.5, oz = box[2] - v * 0.5;
+__global__ __launch_bounds__(kBlock) void pack_strided_f32_box_kernel(const unsigned char* __restrict__ raw, size_t n, size_t step, size_t ox,
+                                                                      size_t oy, size_t oz, P4* __restrict__ out, CropDev crop,
+                                                                      unsigned long long* __restrict__ box) {
+  using R = typename Scalar<P4>::type;
+  double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const unsigned char* rec = raw + i * step;
+    float x, y, z;
+    __builtin_memcpy(&x, rec + ox, 4);
+    __builtin_memcpy(&y, rec + oy, 4);
+    __builtin_memcpy(&z, rec + oz, 4);
+    P4 p;
+    p.x = (R)x;
+    p.y = (R)y;
+    p.z = (R)z;
+    p.i = (typename Scalar<P4>::index)i;
+    out[i] = p;
+    const double dx = (double)p.x, dy = (double)p.y, dz = (double)p.z;
+    if (crop_contains(crop, dx, dy, dz)) {  // fmin / fmax pass over NaN like bbox_kernel's
+      mn[0] = fmin(mn[0], dx), mn[1] = fmin(mn[1], dy), mn[2] = fmin(mn[2], dz);
+      mx[0] = fmax(mx[0], dx), mx[1] = fmax(mx[1], dy), mx[2] = fmax(mx[2], dz);
+    }
+  }
+  block_box_atomic(mn, mx, box);
+}
+// the same reduction for a cloud that is already on the device (no ingest to ride on, or another volume than the ingest assumed)
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void bbox_atomic_kernel(const P4* __restrict__ pts, size_t n, CropDev crop, unsigned long long* __restrict__ box) {
+  double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const P4 p = pts[i];
+    const double dx = (double)p.x, dy = (double)p.y, dz = (double)p.z;
+    if (crop_contains(crop, dx, dy, dz)) {
+      mn[0] = fmin(mn[0], dx), mn[1] = fmin(mn[1], dy), mn[2] = fmin(mn[2], dz);
+      mx[0] = fmax(mx[0], dx), mx[1] = fmax(mx[1], dy), mx[2] = fmax(mx[2], dz);
+    }
+  }
+  block_box_atomic(mn, mx, box);
+}
+// box record -> the pinned record the host reads it from: {stamp, pad, min x y z, max x y z} (the stamp last, system-scope release);
+// re-arms the device record for its next use
+__global__ __launch_bounds__(64) void box_publish_kernel(unsigned long long* __restrict__ box, double* __restrict__ host_box, int* __restrict__ host_seq,
+                                                         int seq) {
+  if (threadIdx.x < 6) {
+    host_box[threadIdx.x] = order_value(box[threadIdx.x]);
+    box[threadIdx.x] = order_bits(threadIdx.x < 3 ? 1e300 : -1e300);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __builtin_amdgcn_wave_barrier();
+  if (threadIdx.x == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// [O3D] voxel_min_bound = GetMinBound() - voxel_size * 0.5 arrives as (ox, oy, oz): the host knows the box before it launches
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void vox_insert_kernel(const P4* __restrict__ pts, size_t n, double ox, double oy, double oz, double v,
+                                                            CropDev crop, int filter, VoxTable t, int* __restrict__ lead_slot,
+                                                            int* __restrict__ run_next, int* __restrict__ run_len) {
   const int lane = threadIdx.x & 63;
-  // A lidar scan lists its points along the scan lines, so neighbours in the array are neighbours in space: on the stream's scans two points
-  // share a voxel on average and they mostly sit next to each other.  A RUN of equal keys in consecutive lanes enters the table once -- its
-  // first lane claims the slot, records its own index as the run's smallest and the run's length as the count (three atomics per run
-  // instead of per point; the table saw 8.5 bytes written per byte of scan, profiles/r03_pmc_stream_kernels_traffic.txt) -- and hands
-  // the slot to the other lanes of the run.  Whole wavefronts iterate together (the exchange is by lane).
-  for (size_t i0 = (size_t)blockIdx.x * kBlock; i0 < n; i0 += (size_t)gridDim.x * kBlock) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *t.cursor = 0u;  // (vox_mean_kernel, two launches on, hands out the scratch from zero)
+  for (size_t i0 = (size_t)blockIdx.x * kBlock; i0 < n; i0 += (size_t)gridDim.x * kBlock) {  // whole wavefronts iterate together (the runs are found by lane)
     const size_t i = i0 + threadIdx.x;
     unsigned long long k = kEmptyKey;  // no entry: past the end, or outside the volume
     if (i < n) {
@@ -689,86 +771,97 @@ __global__ __launch_bounds__(kBlock) void vox_insert_kernel(const P4* __restrict
     }
     const unsigned long long kp = __shfl_up(k, 1, 64);
     const bool lead = k != kEmptyKey && (lane == 0 || kp != k);
-    const unsigned long long leaders = __ballot(lead), ends = __ballot(lane == 0 || kp != k);  // a run also ends where entries without a key begin
-    unsigned int slot = 0;
+    const unsigned long long ends = __ballot(lane == 0 || kp != k);  // a run also ends where entries without a key begin
+    int slot = -1;
     if (lead) {
       const unsigned long long above = lane == 63 ? 0ull : (ends >> (lane + 1));
-      const unsigned int len = above ? (unsigned int)__builtin_ctzll(above) + 1u : (unsigned int)(64 - lane);
-      slot = (unsigned int)((k * 0x9E3779B97F4A7C15ull) >> 32) & t.mask;
+      const int len = above ? (int)__builtin_ctzll(above) + 1 : 64 - lane;
+      unsigned int sl = (unsigned int)((k * 0x9E3779B97F4A7C15ull) >> 32) & t.mask;
       while (true) {
-        const unsigned long long prev = atomicCAS(&t.key[slot], kEmptyKey, k);
+        const unsigned long long prev = atomicCAS(&t.key[sl], kEmptyKey, k);
         if (prev == kEmptyKey || prev == k) break;
-        slot = (slot + 1) & t.mask;
+        sl = (sl + 1) & t.mask;
       }
-      atomicMin(&t.first[slot], (unsigned int)i);
-      atomicSub(&t.ncnt[slot], len);
+      atomicMin(&t.first[sl], (unsigned int)i);
+      atomicAdd(&t.nrun[sl], 1u);
+      run_next[i] = atomicExch(&t.head[sl], (int)i);
+      run_len[i] = len;
+      slot = (int)sl;
     }
-    // every lane of a run reads the slot from the run's first lane: the highest leader at or below it
-    const unsigned long long below = leaders & (lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull));
-    const int src = below ? 63 - __builtin_clzll(below) : lane;
-    const unsigned int run_slot = __shfl(slot, src, 64);
-    if (i < n) slot_of[i] = k != kEmptyKey ? (int)run_slot : -1;
+    if (i < n) lead_slot[i] = slot;
   }
 }
 
-// The first point of voxel number r (r = its rank among the first points, from the scan) gives the voxel its piece of the member list --
-// one atomic per wavefront: the sizes of a wavefront's voxels are scanned across its lanes -- and leaves r in the table for the other
-// members.  Where a voxel's piece lies in the list does not matter, only that the pieces do not overlap.
-__global__ __launch_bounds__(kBlock) void vox_number_kernel(const int* __restrict__ slot_of, const int* __restrict__ rank, size_t n, VoxTable t,
-                                                            int* __restrict__ seg_start, int* __restrict__ seg_cnt, int* __restrict__ vox_slot) {
-  const int lane = threadIdx.x & 63;
-  for (size_t i0 = (size_t)blockIdx.x * kBlock; i0 < n; i0 += (size_t)gridDim.x * kBlock) {  // whole wavefronts iterate together
-    const size_t i = i0 + threadIdx.x;
-    int s = -1;
-    bool f = false;
-    if (i < n) {
-      s = slot_of[i];
-      f = s >= 0 && t.first[s] == (unsigned int)i;
-    }
-    const int cnt = f ? (int)~t.ncnt[s] : 0;
-    int incl = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int y = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += y;
-    }
-    // one atomic per WORKGROUP (2 k same-address atomics, one per wavefront of a 131 k-point scan, took 25 us)
-    __shared__ int s_tot[kBlock / 64];
-    __shared__ unsigned int s_base;
-    const int w = threadIdx.x >> 6;
-    if (lane == 63) s_tot[w] = incl;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int all = 0;
-#pragma unroll
-      for (int k = 0; k < kBlock / 64; ++k) all += s_tot[k];
-      s_base = all > 0 ? atomicAdd(t.cursor, (unsigned int)all) + 1u : 0u;
-    }
-    __syncthreads();
-    unsigned int base = s_base;
-    for (int k = 0; k < w; ++k) base += (unsigned int)s_tot[k];
-    __syncthreads();  // s_tot / s_base are rewritten by the next iteration
-    if (f) {
-      const int r = rank[i];
-      seg_start[r] = (int)base + incl - cnt;
-      seg_cnt[r] = cnt;
-      vox_slot[r] = s;  // for vox_mean_kernel, which hands the slot back empty
-      t.first[s] = (unsigned int)r;
-    }
-  }
+// Chained scan (one pass, decoupled look-back) over the flags "point i is the smallest index of its voxel": tile b publishes its own sum,
+// then the sum of everything up to and including itself; a tile adds up its predecessors' records from b - 1 downwards until it meets an
+// inclusive one.  The records carry the number of this call (`gen`), so the buffer is never cleared: a record of an earlier call reads as
+// "not there yet".  Tiles take their number from a ticket counter that runs on across calls (`ticket_base` = its value before this launch):
+// a tile only ever waits for tiles whose ticket was drawn earlier, i.e. for workgroups that are already running.
+constexpr int kVoxTile = 1024;
+__device__ __forceinline__ unsigned long long tile_record(unsigned int gen, unsigned int kind /* 1 own sum, 2 inclusive */, unsigned int value) {
+  return ((unsigned long long)(gen & 0x3fffffffu) << 34) | ((unsigned long long)kind << 32) | value;
 }
-
-// members[seg_start[r] ..] = the point indices of voxel r, in whatever order the atomics hand out (put in order by vox_mean_kernel).
-// The counter still holds ~count: the j-th increment returns ~count + j.
-__global__ __launch_bounds__(kBlock) void vox_gather_kernel(const int* __restrict__ slot_of, size_t n, VoxTable t, const int* __restrict__ seg_start,
-                                                            const int* __restrict__ seg_cnt, uint32_t* __restrict__ members) {
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
-    const int s = slot_of[i];
-    if (s < 0) continue;
-    const unsigned int r = t.first[s];
-    const int b = seg_start[r], cnt = seg_cnt[r];
-    const unsigned int j = atomicAdd(&t.ncnt[s], 1u) + (unsigned int)cnt + 1u;  // old - ~cnt
-    members[(size_t)b + j] = (uint32_t)i;
+__global__ __launch_bounds__(kBlock) void vox_order_kernel(const int* __restrict__ lead_slot, CountRef n_in, VoxTable t, unsigned long long* __restrict__ tiles,
+                                                           unsigned int* __restrict__ ticket, unsigned int ticket_base, unsigned int gen,
+                                                           int* __restrict__ order, CountPub pub) {
+  __shared__ unsigned int s_tile;
+  __shared__ int s_wave[kBlock / 64];
+  __shared__ int s_prefix;
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
+  __syncthreads();
+  const unsigned int tile = s_tile, n_tiles = gridDim.x;
+  const size_t n = count_of(n_in);
+  const size_t base = (size_t)tile * kVoxTile + (size_t)threadIdx.x * 4;
+  int sl[4], f[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    sl[k] = base + k < n ? lead_slot[base + k] : -1;
+    f[k] = 0;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (sl[k] >= 0) f[k] = t.first[sl[k]] == (unsigned int)(base + k) ? 1 : 0;
+  const int tsum = f[0] + f[1] + f[2] + f[3];
+  int x = tsum;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  if (lane == 63) s_wave[w] = x;
+  __syncthreads();
+  int woff = 0, total = 0;
+#pragma unroll
+  for (int k = 0; k < kBlock / 64; ++k) {
+    if (k < w) woff += s_wave[k];
+    total += s_wave[k];
+  }
+  if (threadIdx.x == 0) {
+    int prefix = 0;
+    if (tile > 0) {
+      __hip_atomic_store(&tiles[tile], tile_record(gen, 1u, (unsigned int)total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      for (int b = (int)tile - 1; b >= 0;) {
+        const unsigned long long r = __hip_atomic_load(&tiles[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned int)(r >> 34) != (gen & 0x3fffffffu)) {
+          __builtin_amdgcn_s_sleep(1);
+          continue;  // not published yet
+        }
+        prefix += (int)(unsigned int)r;
+        if (((r >> 32) & 3u) == 2u) break;
+        --b;
+      }
+    }
+    __hip_atomic_store(&tiles[tile], tile_record(gen, 2u, (unsigned int)(prefix + total)), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    s_prefix = prefix;
+    if (tile == n_tiles - 1) publish_count(pub, prefix + total);  // the number of voxels = the size of the cloud being made
+  }
+  __syncthreads();
+  int r = s_prefix + woff + x - tsum;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (f[k]) order[r] = sl[k];
+    r += f[k];
   }
 }
 
@@ -809,49 +902,85 @@ __device__ inline void sort_indices(uint32_t* a, int k) {
 }
 
 // AccumulatedPoint::GetAveragePoint / GetAverageNormal / GetAverageColor ([O3D] PointCloud.cpp VoxelDownSample): sums in cloud order,
-// divided by the count; normals are averaged, not re-normalised.  attr_only: `members` is already in order (the colour pass).
+// divided by the count; normals are averaged, not re-normalised.  One thread per voxel r (the number of voxels comes from the device word
+// vox_order_kernel left): the voxel's runs are copied from its list into a piece of `starts` (one cursor atomic per wavefront), put in
+// ascending order, and summed run by run.  attr_only: the pieces are already there and in order (the colour pass); piece[r] = where.
 template <typename P4>
-__global__ __launch_bounds__(kBlock) void vox_mean_kernel(const P4* __restrict__ pts, const P4* __restrict__ nrm, const int* __restrict__ seg_start,
-                                                          const int* __restrict__ seg_cnt, size_t m, uint32_t* __restrict__ members, int attr_only,
-                                                          P4* __restrict__ out_pts, P4* __restrict__ out_nrm, VoxTable t = VoxTable{},
-                                                          const int* __restrict__ vox_slot = nullptr) {
+__global__ __launch_bounds__(kBlock) void vox_mean_kernel(const P4* __restrict__ pts, const P4* __restrict__ nrm, CountRef m_in, const int* __restrict__ order,
+                                                          const int* __restrict__ run_next, const int* __restrict__ run_len, uint32_t* __restrict__ starts,
+                                                          int2* __restrict__ piece, int attr_only, P4* __restrict__ out_pts, P4* __restrict__ out_nrm,
+                                                          VoxTable t) {
   using R = typename Scalar<P4>::type;
-  for (size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x; r < m; r += (size_t)gridDim.x * kBlock) {
-    const int b = seg_start[r], e = b + seg_cnt[r];
-    if (!attr_only) sort_indices(members + b, e - b);
-    if (vox_slot) {  // the table is done with (vox_gather_kernel has run): leave the slot as the 0xff fill left it, for the next call
-      const int s = vox_slot[r];
-      t.key[s] = kEmptyKey;
-      t.first[s] = ~0u;
-      t.ncnt[s] = ~0u;
-      if (r == 0) *t.cursor = ~0u;
-    }
-    double sx = 0, sy = 0, sz = 0, nx = 0, ny = 0, nz = 0;
-    for (int j = b; j < e; ++j) {
-      const uint32_t id = members[j];
-      const P4 p = pts[id];
-      sx += (double)p.x;
-      sy += (double)p.y;
-      sz += (double)p.z;
-      if (nrm) {
-        const P4 q = nrm[id];
-        nx += (double)q.x;
-        ny += (double)q.y;
-        nz += (double)q.z;
+  const size_t m = count_of(m_in);
+  const int lane = threadIdx.x & 63;
+  for (size_t r0 = (size_t)blockIdx.x * kBlock; r0 < m; r0 += (size_t)gridDim.x * kBlock) {  // whole wavefronts iterate together
+    const size_t r = r0 + threadIdx.x;
+    const bool have = r < m;
+    int b = 0, k = 0;
+    if (attr_only) {
+      if (have) b = piece[r].x, k = piece[r].y;
+    } else {
+      int s = 0, node = -1;
+      if (have) {
+        s = order[r];
+        k = (int)t.nrun[s] + 1;
+        node = t.head[s];
+        // the table is done with this voxel: leave the slot as the 0xff fill left it, for the next call
+        t.key[s] = kEmptyKey;
+        t.first[s] = ~0u;
+        t.head[s] = -1;
+        t.nrun[s] = ~0u;
       }
+      int incl = k;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += y;
+      }
+      const int wave_total = __shfl(incl, 63, 64);
+      unsigned int wbase = 0;
+      if (lane == 0 && wave_total > 0) wbase = atomicAdd(t.cursor, (unsigned int)wave_total);
+      wbase = __shfl(wbase, 0, 64);
+      b = (int)wbase + incl - k;
+      for (int j = 0; j < k; ++j) {
+        starts[b + j] = (uint32_t)node;
+        node = run_next[node];
+      }
+      if (k > 1) sort_indices(starts + b, k);
+      if (have && piece) piece[r] = make_int2(b, k);
     }
-    const double cnt = (double)(e - b);
+    if (!have) continue;
+    double sx = 0, sy = 0, sz = 0, nx = 0, ny = 0, nz = 0;
+    int cnt = 0;
+    for (int j = 0; j < k; ++j) {
+      const uint32_t st = starts[b + j];
+      const int len = run_len[st];
+      for (int q = 0; q < len; ++q) {
+        const P4 p = pts[st + q];
+        sx += (double)p.x;
+        sy += (double)p.y;
+        sz += (double)p.z;
+        if (nrm) {
+          const P4 v = nrm[st + q];
+          nx += (double)v.x;
+          ny += (double)v.y;
+          nz += (double)v.z;
+        }
+      }
+      cnt += len;
+    }
+    const double c = (double)cnt;
     P4 op;
-    op.x = (R)(sx / cnt);
-    op.y = (R)(sy / cnt);
-    op.z = (R)(sz / cnt);
+    op.x = (R)(sx / c);
+    op.y = (R)(sy / c);
+    op.z = (R)(sz / c);
     op.i = (typename Scalar<P4>::index)r;
     out_pts[r] = op;
     if (nrm) {
       P4 on;
-      on.x = (R)(nx / cnt);
-      on.y = (R)(ny / cnt);
-      on.z = (R)(nz / cnt);
+      on.x = (R)(nx / c);
+      on.y = (R)(ny / c);
+      on.z = (R)(nz / c);
       on.i = 0;
       out_nrm[r] = on;
     }

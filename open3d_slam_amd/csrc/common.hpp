@@ -130,7 +130,45 @@ struct GridDev {
   double inv_cell;
   int nx, ny, nz;
   const int* cell_start;  // nx*ny*nz + 1 entries (exclusive scan of per-cell counts)
+  int sx;                 // entries per row of cell_start: nx (the classic table), or nx + 1 for the row-paged table of a persistent map
+                          // (map_kernels.hpp: every row owns a region with room to spare, the extra entry is the end of its last cell)
 };
+
+// ---- counts the host has not seen yet ---------------------------------------------------------------------------------------------
+// A kernel that decides how many points a cloud has (VoxelDownSample: the number of voxels) leaves the number in a device word, where
+// the kernels that consume the cloud read it, and in a pinned record {count, stamp} the host looks at when it next needs the number:
+// the frame's launches are queued from the cloud's UPPER bound (the size of the input) and nothing waits for a size to come back.
+struct CountPub {
+  int* dev;   // device word
+  int* host;  // pinned {count, stamp}; the stamp is stored last, with a system-scope release
+  int seq;
+};
+__device__ __forceinline__ void publish_count(const CountPub& p, int cnt) {
+  *p.dev = cnt;
+  if (p.host) {
+    p.host[0] = cnt;
+    __hip_atomic_store(p.host + 1, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+// what a consumer is handed: the exact count, or the upper bound together with the device word that holds the exact one
+struct CountRef {
+  size_t n;
+  const int* dev;
+};
+__device__ __forceinline__ size_t count_of(const CountRef& c) { return c.dev ? (size_t)*c.dev : c.n; }
+
+// doubles as unsigned integers of the same order (atomicMin / atomicMax on bounding boxes)
+__host__ __device__ __forceinline__ unsigned long long order_bits(double x) {
+  unsigned long long u;
+  __builtin_memcpy(&u, &x, 8);
+  return (u >> 63) ? ~u : (u | (1ull << 63));
+}
+__host__ __device__ __forceinline__ double order_value(unsigned long long e) {
+  const unsigned long long u = (e >> 63) ? (e & ~(1ull << 63)) : ~e;
+  double x;
+  __builtin_memcpy(&x, &u, 8);
+  return x;
+}
 
 // The 32-double normal-equation record (see include/o3ds_backend.h, o3ds_icp_accumulate).
 constexpr int kRec = 32;

@@ -112,7 +112,8 @@ __device__ __forceinline__ bool cell_run(int c, int lane, int* len, int* lead_la
 // counts[cell] += (points of the cell) ; cell_id[i] = cell
 template <typename P4>
 __global__ __launch_bounds__(kBlock) void cell_count_kernel(const P4* __restrict__ pts, size_t n, GridDev g, int* __restrict__ counts,
-                                                            int* __restrict__ cell_id) {
+                                                            int* __restrict__ cell_id, const int* __restrict__ n_dev = nullptr /* the exact count when n is an upper bound */) {
+  if (n_dev) n = (size_t)*n_dev;
   const int lane = threadIdx.x & 63;
   for (size_t i0 = (size_t)blockIdx.x * kBlock; i0 < n; i0 += (size_t)gridDim.x * kBlock) {  // whole wavefronts iterate together
     const size_t i = i0 + threadIdx.x;
@@ -221,7 +222,9 @@ __global__ __launch_bounds__(kBlock) void scan_add_kernel(T* __restrict__ out, c
 template <typename P4>
 __global__ __launch_bounds__(kBlock) void scatter_kernel(const P4* __restrict__ pts, const P4* __restrict__ nrm, size_t n,
                                                          const int* __restrict__ cell_id, const int* __restrict__ cell_start,
-                                                         int* __restrict__ counts, P4* __restrict__ spts, P4* __restrict__ snrm) {
+                                                         int* __restrict__ counts, P4* __restrict__ spts, P4* __restrict__ snrm,
+                                                         const int* __restrict__ n_dev = nullptr) {
+  if (n_dev) n = (size_t)*n_dev;
   const int lane = threadIdx.x & 63;
   for (size_t i0 = (size_t)blockIdx.x * kBlock; i0 < n; i0 += (size_t)gridDim.x * kBlock) {  // whole wavefronts iterate together
     const size_t i = i0 + threadIdx.x;
@@ -479,7 +482,7 @@ __device__ __forceinline__ NNBest<P4> nn_search_group(const GridDev& g, const P4
     const int r = gl + k * G;
     const int y = c.iy + (r % 3) - 1, z = c.iz + (r / 3) - 1;
     rv[k] = r < 9 && xlo <= xhi && (unsigned)y < (unsigned)g.ny && (unsigned)z < (unsigned)g.nz;
-    const int row = rv[k] ? (z * g.ny + y) * g.nx : 0;
+    const int row = rv[k] ? (z * g.ny + y) * g.sx : 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[k][j] = rv[k] ? cs[row + min(xlo + j, xhi + 1)] : 0;
   }
@@ -543,7 +546,7 @@ __device__ __forceinline__ NNBest<P4> nn_search_group(const GridDev& g, const P4
             xa = max(max(c.ix + xa, c.ix - 2), 0);
             xb = min(min(c.ix + xb, c.ix + 2), g.nx - 1);
             const bool inner = abs(dy) <= 1 && abs(dz) <= 1;  // cells ix-1..ix+1 of these rows were stage 1
-            const int row = (z * g.ny + y) * g.nx;
+            const int row = (z * g.ny + y) * g.sx;
             const int xb1 = inner ? min(xb, c.ix - 2) : xb;
             if (xa <= xb1) {
               s2[2 * k] = cs[row + xa];
@@ -621,7 +624,7 @@ __device__ __forceinline__ void nn_search_wave_far(const GridDev& g, const P4* _
             xa = max(xa, 0);
             xb = min(xb, g.nx - 1);
             if (xa <= xb) {
-              const int row = (z * g.ny + y) * g.nx;
+              const int row = (z * g.ny + y) * g.sx;
               s_own[u] = cs[row + xa];
               e_own[u] = cs[row + xb + 1];
             }
@@ -694,6 +697,10 @@ struct IcpPassArgs {
   void* set_ref;
   float set_gain, set_min, set_cap;  // margin m = gain * (|R - I|_F |p| + |t|) of the last update, at least set_min; above set_cap: no set
   unsigned long long* stats;  // null, or per-launch counters [launch][4]: verified matches, searches, sets left behind, stage-3 queries (O3DS_ICP_STATS)
+  // null, or the exact number of source points when `count` is only an upper bound (a source cloud whose size the host has not seen:
+  // common.hpp, CountPub).  Queries are dealt out over `count` as always; the ones at or beyond the exact number are dropped where a query
+  // past the end is dropped, and the fitness is taken over the exact number.
+  const int* count_dev;
 };
 
 // Per-query record staged in LDS: {J0..J5, r, one, d2, 0}.  Every entry of the 32-double normal-equation record is a
@@ -937,8 +944,10 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
                                                 double (*s_red)[kRec], int2* s_seg /* [kPassBlock / kGroup][kSegMax] */,
                                                 bool use_cache, const QueryPrefetch<P4>& first_batch,
                                                 unsigned long long* tr = nullptr /* 3 timestamps, development aid */,
-                                                SetMargin sm = SetMargin{-1.0f, 0.0f}, int* s_set = nullptr /* [kQPB][1 + kSetCap] */) {
+                                                SetMargin sm = SetMargin{-1.0f, 0.0f}, int* s_set = nullptr /* [kQPB][1 + kSetCap] */,
+                                                size_t n_live = ~(size_t)0 /* queries at or beyond it are dropped (IcpPassArgs::count_dev) */) {
   constexpr int kQPB = kPassBlock / kGroup;
+  n_live = min(n_live, a.count);
   constexpr int kStride = kGicp ? kRec : kRecSlots;  // doubles per query record
   static_assert((64 / kGroup) * kSegMax >= kFarList, "a wavefront's share of s_seg holds the stage-3 list");
   using R = typename Scalar<P4>::type;
@@ -982,7 +991,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
     R m = (R)0;  // candidate-set margin of this query's search (0: the search leaves no set)
     const QueryPrefetch<P4> qp = (kSingle || b == (size_t)wg) ? first_batch : prefetch_query<P4, kPassBlock, kGroup>(a, b, use_cache, sets);
     if (sets && gl == 0) my_set[0] = 0;  // (same wavefront as its readers and writers below; the far stage is behind a barrier)
-    if (i < a.count) {  // uniform across the lanes of a group
+    if (i < n_live) {  // uniform across the lanes of a group
       const P4 s = qp.s;
       // [O3D] PointCloud::Transform: rigid 4x4 (bottom row 0 0 0 1 for every pose the reference passes)
       px = t00 * (double)s.x + t01 * (double)s.y + t02 * (double)s.z + t03;
@@ -1114,7 +1123,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
     }
     if (tr && threadIdx.x == 0) tr[1] = wall_clock64();
     if (a.stats) {  // development aid: how the queries of this launch were served
-      const bool q0 = gl == 0 && i < a.count;
+      const bool q0 = gl == 0 && i < n_live;
       const unsigned long long nv = __popcll(__ballot(q0 && verified)), ns = __popcll(__ballot(q0 && !verified)),
                                nk = __popcll(__ballot(q0 && !verified && m > (R)0 && sets && s_set[ql * (1 + kSetCap)] <= kSetCap)),
                                nf = __popcll(__ballot(q0 && unresolved));
@@ -1126,7 +1135,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
       }
     }
     // ---- the candidate set this query's search leaves for the next pass (a verified match keeps the one it has)
-    if (sets && i < a.count && !verified && a.debug != 2) {
+    if (sets && i < n_live && !verified && a.debug != 2) {
       const int n_listed = my_set[0];
       const bool have = m > (R)0 && n_listed <= kSetCap;
       int pos_out = have ? (gl < n_listed ? my_set[1 + gl] : -1) : (gl == 0 ? nn.pos : -1);
@@ -1150,8 +1159,8 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
     // ---- records
     if (!verified && gl == 0) {
       {
-        if (i < a.count && !(kKeys && a.keys_mode == 2)) a.nn_cache[a.first + i] = nn.pos;
-        if (kKeys && a.keys_mode == 1 && i < a.count)
+        if (i < n_live && !(kKeys && a.keys_mode == 2)) a.nn_cache[a.first + i] = nn.pos;
+        if (kKeys && a.keys_mode == 1 && i < n_live)
           a.keys[a.first + i] = nn.pos == -1 ? kNoKey
                                              : ((unsigned long long)__float_as_uint((float)nn.d2) << 32) |
                                                    ((unsigned long long)(a.keys_rank & 0xf) << 28) | (unsigned long long)(nn.pos & 0x0fffffff);
@@ -1209,7 +1218,9 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   }
   const bool use_cache = a.state->pass > 0;
   const QueryPrefetch<P4> qp = prefetch_query<P4, kPassBlock, kGroup>(a, blockIdx.x, use_cache);
-  const double v = icp_pass_body<P4, kCrop, kPassBlock, kGroup, kGicp, kKeys>(a, a.state->T, blockIdx.x, gridDim.x, s_rec, s_red, s_seg, use_cache, qp);
+  const size_t n_live = a.count_dev ? (size_t)*a.count_dev : a.count;
+  const double v = icp_pass_body<P4, kCrop, kPassBlock, kGroup, kGicp, kKeys>(a, a.state->T, blockIdx.x, gridDim.x, s_rec, s_red, s_seg, use_cache, qp, nullptr,
+                                                                                SetMargin{-1.0f, 0.0f}, nullptr, n_live);
   if (threadIdx.x < kRec) a.partials[(size_t)blockIdx.x * kRec + threadIdx.x] = v;
 }
 
@@ -1905,6 +1916,13 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   } while (0)
   O3DS_STAMP(0);
   const bool use_cache = !first;  // launch j evaluates pass j of the registration
+  // (a source whose size the host has not seen: the exact number from the device word, fetched here, used after the serial tail)
+  size_t n_live = fa.pass.count;
+  unsigned long long n_src_total = fa.n_src_total;
+  if (fa.pass.count_dev) {
+    n_live = (size_t)*fa.pass.count_dev;
+    n_src_total = (unsigned long long)n_live;
+  }
   // (the quanta of the epilogue: a per-lane load of a kernel argument, fetched now and parked in LDS -- loaded at the very end it is a
   // memory round trip on the tail of every pass, kept in a register it is live through the whole kernel)
   const double q_hi_mine = threadIdx.x < kRec ? fa.pass.q_hi[threadIdx.x] : 0.0;
@@ -1943,7 +1961,7 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   }
   O3DS_STAMP(1);
   if (!first) {
-    icp_step_block(s_out, &s_st, fa.n_src_total, fa.max_iter, fa.rel_fitness, fa.rel_rmse, s_x, s_sc, s_U, s_T, &s_go,
+    icp_step_block(s_out, &s_st, n_src_total, fa.max_iter, fa.rel_fitness, fa.rel_rmse, s_x, s_sc, s_U, s_T, &s_go,
                    fa.trace ? fa.trace + (size_t)blockIdx.x * 16 + 8 : nullptr, fa.pass.method, s_margin);
     lds_barrier();
   }
@@ -1965,9 +1983,9 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   const bool collect = fa.pass.set_pos != nullptr && sm.w >= 0.0f && fa.pass.set_gain * sm.t <= fa.pass.set_cap;
   unsigned long long* const trb = fa.trace ? fa.trace + (size_t)blockIdx.x * 16 + 13 : nullptr;
   const double v = collect ? icp_pass_body<P4, kCrop, kPassBlock, kGroup, kGicp, false, true, true>(fa.pass, s_st.T, blockIdx.x, gridDim.x, s_rec, s_red, s_seg,
-                                                                                              use_cache, qp, trb, sm, s_set)
+                                                                                              use_cache, qp, trb, sm, s_set, n_live)
                            : icp_pass_body<P4, kCrop, kPassBlock, kGroup, kGicp, false, false, true>(fa.pass, s_st.T, blockIdx.x, gridDim.x, s_rec, s_red, s_seg,
-                                                                                               use_cache, qp, trb, sm, s_set);
+                                                                                               use_cache, qp, trb, sm, s_set, n_live);
   O3DS_STAMP(3);
   // ---------------- epilogue: add the record to this workgroup's slot, exactly ----------------
   if (threadIdx.x < kRec) {

@@ -1,0 +1,1008 @@
+// map_kernels.hpp -- Submap::insertScan (Submap.cpp:39-75) in time independent of the map's size: the PERSISTENT form of a submap.
+//
+// The reference re-bins the whole map at every inserted scan: mapCloud_ += T * scan, then voxelizeWithinCroppingVolume (helpers.cpp:115-183)
+// walks all N + m points -- inside the cropping volume each voxel's points are replaced by their mean (normal averaged and re-normalised),
+// outside they pass through -- and rounds 1-4 of this backend did the same with sorted key lists (backend.hip voxel_reduce_t) plus a
+// rebuild of the search index: ~230 us per scan at 1 M points, linear in N.  But an insertion CHANGES only what the scan touches.  A voxel
+// that holds one point and receives none keeps it: mean of one point p is p / 1 = p exactly (only its normal is re-normalised, see below).
+// So the map is kept as
+//   * slot arrays      pts / nrm [cap]: a point lives in one slot from its creation to its death; new points are appended;
+//   * a voxel hash     key floor(p * (1 / v)) (VoxelHashMap.hpp:47-50) -> chain of the slots whose point has that key.  Nearly every
+//                      chain has one member; two points share a voxel only if they were never inside a volume together (points outside
+//                      pass through unmerged) or a mean was rounded across a voxel face;
+//   * the search index a uniform grid like build_grid_t's, but aligned with the voxel grid (cell = k voxels: a mean never leaves its voxel,
+//                      hence never its cell, so it is updated in place) and PAGED BY ROW: every (y, z) row of cells owns a region of the
+//                      cell-sorted arrays with room to spare, `cell_start` holds nx + 1 absolute positions per row, and new points are
+//                      merged into their rows by a kernel that rewrites only those rows (a row that outgrows its region moves to the
+//                      end of the pool).  The registration kernels search it unchanged: a row's cells are still one contiguous range;
+//   * per-slot history the insertion that last wrote the slot and the voxel key it was written under, and the list of the volumes since
+//                      the map entered this form: enough to reproduce the reference's output ORDER (pass-through points first, "in
+//                      original order", then the voxel means, here in key order) when somebody looks (pm_view_key_kernel).
+// and an insertion is five launches over the m scan points: group the placed scan by voxel (the VoxelDownSample machinery), one thread
+// per touched voxel sums [old members inside the volume, in map order] + [scan points, in scan order] exactly as the reference's loop
+// does, writes the mean into the old member's slot (or a new one), then the few special cases (voxels with several old members, means
+// that crossed a face, scan points outside the volume, normals that are not yet a fixed point of the re-normalisation), then the rows.
+// Nothing returns to the host: the number of slots lives in a device word, the host keeps an upper bound.
+//
+// Exactness notes.  (1) normalized(n) is not idempotent in floating point: re-normalising a unit vector may move its last bit, and the
+// reference re-normalises EVERY point inside the volume at EVERY insertion.  A slot whose normal is not yet a fixed point is kept on a list
+// and re-normalised at each insertion that has it inside the volume until it is; all others need no work.  (2) A voxel with several old
+// members sums them in map order, which for the persistent form means the order of pm_view_key (the same function the view uses).
+#pragma once
+#include "cloud_kernels.hpp"
+#include "common.hpp"
+
+namespace o3ds {
+
+#pragma clang fp contract(off)
+
+constexpr int kPmHistory = 256;                 // insertions between two folds at most (the list of their volumes)
+constexpr unsigned long long kPmRaw = 1ull << 63;  // okey flag: a scan point that was inserted OUTSIDE the volume (low bits: its scan index)
+constexpr unsigned char kPmDead = 1, kPmUnsettled = 2;
+constexpr int kPmMaxOld = 8;  // old members of one voxel the special-case path sorts in LDS (more: pm_merge_many)
+
+// everything a kernel needs of a persistent map (device pointers; a copy travels by value in the kernel arguments)
+struct PmDev {
+  void* pts;  // P4[cap]
+  void* nrm;  // P4[cap] or null
+  int* stamp;                // [cap] insertion (1, 2, ...; 0 = the base the map entered with) that last wrote the slot
+  unsigned long long* okey;  // [cap] voxel key the slot was written under (kPmRaw | scan index for a point inserted outside the volume)
+  int* hnext;                // [cap] next slot of the same voxel chain, -1 = end
+  int* pos;                  // [cap] position in the paged index
+  int* rnext;                // [cap] next NEW slot of the same index row (lists built by an insertion, consumed by pm_rows_kernel)
+  unsigned char* flags;      // [cap]
+  size_t cap;
+  // voxel hash (open addressing, never deleted from: a chain may be empty)
+  unsigned long long* hkey;
+  int* hhead;
+  unsigned int* hflag;  // bit 0: on the multi list
+  unsigned int hmask;
+  // lists and counters (device)
+  int* counters;        // see PmCounter
+  int* unsettled[2];    // double-buffered list of slots whose normal is not a fixed point of the re-normalisation
+  unsigned long long* multi[2];  // ... of voxel keys whose chain holds more than one live slot
+  int* complex_groups;  // groups of this insertion with more than one old member inside the volume (by number in `order`)
+  int* outside_pts;     // scan points of this insertion that lie outside the volume
+  int* relink;          // slots whose mean left its voxel (rounding): re-hashed and re-indexed one by one
+  int list_cap;
+  // base layout and history
+  int n_base, np_base;  // slots [0, np_base): pass-through block of the base, [np_base, n_base): its voxel block in key order
+  const CropDev* hist;  // [kPmHistory + 1] volume of insertion t (entry 0 unused)
+  double voxel, inv_voxel;
+  // paged index
+  GridDev grid;         // cell_start = row-paged table: (nx + 1) entries per row, absolute positions
+  int* cs;              // the same table, writable
+  void* spts;           // P4[pool]
+  void* snrm;           // P4[pool] or null
+  int* row_cap;         // [rows] capacity of the row's region
+  int* row_head;        // [rows] head of the list of new slots of the row (-1), built per insertion
+  int* touched_rows;    // rows with new slots this insertion
+  int pool_cap;         // positions the cell-sorted arrays have
+  int kc;               // cell edge in voxels
+  long long gx0, gy0, gz0;  // voxel coordinates of the grid's min corner
+};
+enum PmCounter {
+  kPmN = 0,        // slots in use (dead ones included)
+  kPmDeadCnt,      // ... of which dead
+  kPmUnsettledIn,  // entries of unsettled[cur]
+  kPmUnsettledOut,
+  kPmMultiIn,
+  kPmMultiOut,
+  kPmComplex,
+  kPmOutside,
+  kPmRelink,
+  kPmTouched,
+  kPmPoolTop,      // first free position of the index pool
+  kPmError,        // sticky: 1 a list overflowed, 2 the slot arrays, 4 the index pool (the host sizes all three so that none can happen)
+  kPmCounters = 16
+};
+
+template <typename P4>
+__device__ __forceinline__ unsigned long long pm_key(const P4& p, double inv) {
+  return pack_key((long long)floor((double)p.x * inv), (long long)floor((double)p.y * inv), (long long)floor((double)p.z * inv));
+}
+__device__ __forceinline__ unsigned int pm_hash(unsigned long long k) { return (unsigned int)((k * 0x9E3779B97F4A7C15ull) >> 32); }
+
+// hash entry of key k (inserted if absent)
+__device__ __forceinline__ unsigned int pm_entry(const PmDev& m, unsigned long long k) {
+  unsigned int e = pm_hash(k) & m.hmask;
+  while (true) {
+    const unsigned long long prev = atomicCAS(&m.hkey[e], kEmptyKey, k);
+    if (prev == kEmptyKey || prev == k) return e;
+    e = (e + 1) & m.hmask;
+  }
+}
+// ... or ~0u when the key is not in the table (read-only probe)
+__device__ __forceinline__ unsigned int pm_find(const PmDev& m, unsigned long long k) {
+  unsigned int e = pm_hash(k) & m.hmask;
+  while (true) {
+    const unsigned long long cur = m.hkey[e];
+    if (cur == k) return e;
+    if (cur == kEmptyKey) return ~0u;
+    e = (e + 1) & m.hmask;
+  }
+}
+
+// index cell of a voxel key: (row, x) with the clamping build_grid_t's cell_of has
+__device__ __forceinline__ void pm_cell(const PmDev& m, unsigned long long key, int* row, int* x) {
+  const long long vx = (long long)(key & 0x1FFFFFull) - (1ll << 20), vy = (long long)((key >> 21) & 0x1FFFFFull) - (1ll << 20),
+                  vz = (long long)((key >> 42) & 0x1FFFFFull) - (1ll << 20);
+  auto cell = [](long long v, long long g0, int kc, int n) {
+    long long d = v - g0;
+    long long c = d >= 0 ? d / kc : -((-d + kc - 1) / kc);
+    return (int)(c < 0 ? 0 : (c >= n ? n - 1 : c));
+  };
+  const int ix = cell(vx, m.gx0, m.kc, m.grid.nx), iy = cell(vy, m.gy0, m.kc, m.grid.ny), iz = cell(vz, m.gz0, m.kc, m.grid.nz);
+  *row = iz * m.grid.ny + iy;
+  *x = ix;
+}
+
+// Eigen normalized() as segment_mean_kernel spells it; returns whether anything was divided
+__device__ __forceinline__ void pm_normalize(double& nx, double& ny, double& nz) {
+  const double z2 = (nx * nx + ny * ny) + nz * nz;
+  if (z2 > 0.0) {
+    const double nn = sqrt(z2);
+    nx /= nn;
+    ny /= nn;
+    nz /= nn;
+  }
+}
+// what the NEXT insertion makes of a slot that stays alone in its voxel: mean of one normal (NaN skipped: the sum stays 0), re-normalised,
+// rounded to storage.  A slot is settled when that is the normal it has.
+template <typename P4>
+__device__ __forceinline__ P4 pm_renormalized(const P4& n) {
+  using R = typename Scalar<P4>::type;
+  double a = (double)n.x, b = (double)n.y, c = (double)n.z;
+  if (isnan(a) || isnan(b) || isnan(c)) a = b = c = 0.0;
+  a /= 1.0;  // (the mean of one: spelled out, exact)
+  b /= 1.0;
+  c /= 1.0;
+  pm_normalize(a, b, c);
+  P4 o;
+  o.x = (R)a;
+  o.y = (R)b;
+  o.z = (R)c;
+  o.i = 0;
+  return o;
+}
+template <typename P4>
+__device__ __forceinline__ bool pm_same_bits(const P4& a, const P4& b) {
+  using R = typename Scalar<P4>::type;
+  if (sizeof(R) == 4) return __float_as_uint((float)a.x) == __float_as_uint((float)b.x) && __float_as_uint((float)a.y) == __float_as_uint((float)b.y) && __float_as_uint((float)a.z) == __float_as_uint((float)b.z);
+  return __double_as_longlong((double)a.x) == __double_as_longlong((double)b.x) && __double_as_longlong((double)a.y) == __double_as_longlong((double)b.y) &&
+         __double_as_longlong((double)a.z) == __double_as_longlong((double)b.z);
+}
+
+__device__ __forceinline__ void pm_push(int* list, int* counter, int cap, int v, int* err) {
+  const int k = atomicAdd(counter, 1);
+  if (k < cap)
+    list[k] = v;
+  else
+    atomicOr(err, 1);
+}
+__device__ __forceinline__ void pm_push64(unsigned long long* list, int* counter, int cap, unsigned long long v, int* err) {
+  const int k = atomicAdd(counter, 1);
+  if (k < cap)
+    list[k] = v;
+  else
+    atomicOr(err, 1);
+}
+
+// "the slot was inside the volume of insertion t, or written by it" -- i.e. it belonged to the voxel block the reference's array had after
+// insertion t.  Only asked for t >= the slot's stamp (before that the slot held another point, or none).
+template <typename P4>
+__device__ __forceinline__ bool pm_in_block(const PmDev& m, int s, const P4& p, int st, unsigned long long ok, int t) {
+  if (t == 0) return s >= m.np_base && s < m.n_base;
+  if (st == t) return !(ok & kPmRaw);
+  const CropDev c = m.hist[t];
+  return crop_contains(c, (double)p.x, (double)p.y, (double)p.z);
+}
+// Position of a live slot in the reference's array after insertion t_ref, as a 128-bit sort key (hi, lo): pass-through block first ("in
+// original order": by the insertion after which the point was last outside for good, base pass-through points before everything; points
+// that left the voxel block of insertion t' follow in that block's order; scan points inserted outside come after them, in scan order),
+// then the voxel block in key order.
+template <typename P4>
+__device__ __forceinline__ void pm_view_key(const PmDev& m, int s, int t_ref, unsigned long long* hi, unsigned long long* lo) {
+  const P4 p = ((const P4*)m.pts)[s];
+  const int st = m.stamp[s];
+  const unsigned long long ok = m.okey[s];
+  const unsigned long long kp = pm_key(p, m.inv_voxel);
+  if (pm_in_block(m, s, p, st, ok, t_ref)) {
+    *hi = 1ull << 63;
+    *lo = t_ref == 0 ? (unsigned long long)s : (st == t_ref ? ok : kp);
+    return;
+  }
+  for (int t = t_ref - 1; t >= st; --t) {
+    if (t < 0) break;
+    if (pm_in_block(m, s, p, st, ok, t)) {
+      *hi = (unsigned long long)(t + 1) << 1;
+      *lo = t == 0 ? (unsigned long long)s : (st == t ? ok : kp);
+      return;
+    }
+  }
+  if ((ok & kPmRaw) && st > 0) {  // inserted outside the volume at insertion st and never inside since
+    *hi = ((unsigned long long)st << 1) | 1ull;
+    *lo = ok & ~kPmRaw;
+    return;
+  }
+  *hi = 0;  // a pass-through point of the base that has not been inside since
+  *lo = (unsigned long long)s;
+}
+
+// ---- entering the persistent form -------------------------------------------------------------------------------------------------
+// per slot of the base [pass block | voxel block in key order]: history, hash chain, settled or not
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void pm_enter_kernel(PmDev m, int n) {
+  int* err = m.counters + kPmError;
+  for (int s = blockIdx.x * kBlock + threadIdx.x; s < n; s += gridDim.x * kBlock) {
+    const P4 p = ((const P4*)m.pts)[s];
+    const unsigned long long k = pm_key(p, m.inv_voxel);
+    m.stamp[s] = 0;
+    m.okey[s] = k;
+    m.rnext[s] = -2;  // (in the index; >= -1: on the list of new slots of its row)
+    unsigned char fl = 0;
+    if (m.nrm) {
+      const P4 nv = ((const P4*)m.nrm)[s];
+      if (!pm_same_bits(pm_renormalized(nv), nv)) {
+        fl |= kPmUnsettled;
+        pm_push(m.unsettled[0], m.counters + kPmUnsettledIn, m.list_cap, s, err);
+      }
+    }
+    m.flags[s] = fl;
+    const unsigned int e = pm_entry(m, k);
+    const int old = atomicExch(&m.hhead[e], s);
+    m.hnext[s] = old;
+    if (old != -1 && !(atomicOr(&m.hflag[e], 1u) & 1u)) pm_push64(m.multi[0], m.counters + kPmMultiIn, m.list_cap, k, err);
+  }
+}
+
+// ---- the paged index: build -----------------------------------------------------------------------------------------------------------
+// counts per cell of the (nx + 1)-strided table; the extra entry of every row receives the row's spare room afterwards (pm_row_slack_kernel),
+// so that ONE exclusive scan of the table yields absolute cell starts with the rows' regions laid out one after the other
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void pm_cell_count_kernel(PmDev m, int n, int* __restrict__ counts, int* __restrict__ cell_id) {
+  for (int s = blockIdx.x * kBlock + threadIdx.x; s < n; s += gridDim.x * kBlock) {
+    if (m.flags[s] & kPmDead) {
+      cell_id[s] = -1;
+      continue;
+    }
+    const P4 p = ((const P4*)m.pts)[s];
+    int row, x;
+    pm_cell(m, pm_key(p, m.inv_voxel), &row, &x);
+    const int c = row * (m.grid.nx + 1) + x;
+    cell_id[s] = c;
+    atomicAdd(&counts[c], 1);
+  }
+}
+__global__ __launch_bounds__(kBlock) void pm_row_slack_kernel(int* __restrict__ counts, int rows, int nx, int* __restrict__ row_cap, int* __restrict__ row_head) {
+  const int lane = threadIdx.x & 63;
+  for (int r = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); r < rows; r += gridDim.x * (kBlock / 64)) {  // one wavefront per row
+    int c = 0;
+    for (int x = lane; x < nx; x += 64) c += counts[(size_t)r * (nx + 1) + x];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if (lane == 0) {
+      const int slack = c > 0 ? max(8, c / 2) : 0;  // a row that has points gets room for half as many again; an empty one moves to the pool's end with its first point
+      counts[(size_t)r * (nx + 1) + nx] = slack;
+      row_cap[r] = c + slack;
+      row_head[r] = -1;
+    }
+  }
+}
+// the slack entries must not stay in the counters the scatter counts down: cleared after the scan; the pool's first free position = the total
+__global__ __launch_bounds__(kBlock) void pm_row_finish_kernel(int* __restrict__ counts, const int* __restrict__ cs, int rows, int nx, int* __restrict__ pool_top) {
+  for (int r = blockIdx.x * kBlock + threadIdx.x; r < rows; r += gridDim.x * kBlock) counts[(size_t)r * (nx + 1) + nx] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *pool_top = cs[(size_t)rows * (nx + 1)];
+}
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void pm_scatter_kernel(PmDev m, int n, const int* __restrict__ cell_id, int* __restrict__ counts) {
+  for (int s = blockIdx.x * kBlock + threadIdx.x; s < n; s += gridDim.x * kBlock) {
+    const int c = cell_id[s];
+    if (c < 0) continue;
+    const int old = atomicSub(&counts[c], 1);
+    const int pos = m.cs[c] + old - 1;
+    P4 p = ((const P4*)m.pts)[s];
+    p.i = (typename Scalar<P4>::index)s;
+    ((P4*)m.spts)[pos] = p;
+    if (m.nrm) ((P4*)m.snrm)[pos] = ((const P4*)m.nrm)[s];
+    m.pos[s] = pos;
+  }
+}
+
+// ---- an insertion -----------------------------------------------------------------------------------------------------------------------
+// (1) place the scan (o3d_slam::transform: the arithmetic of transform_kernel), round to storage, and group the placed points that lie inside
+// the volume by voxel: vox_insert_kernel's run lists on the WORLD-anchored key.  Points outside the volume go on a list.
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void pm_place_kernel(const P4* __restrict__ spts, const P4* __restrict__ snrm, CountRef n_in, Mat34 M, double w0,
+                                                          double w1, double w2, double w3, CropDev crop, PmDev m, VoxTable t, P4* __restrict__ placed,
+                                                          P4* __restrict__ placed_nrm, int* __restrict__ lead_slot, int* __restrict__ run_next,
+                                                          int* __restrict__ run_len) {
+  using R = typename Scalar<P4>::type;
+  const size_t n = count_of(n_in);
+  const int lane = threadIdx.x & 63;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *t.cursor = 0u;
+  for (size_t i0 = (size_t)blockIdx.x * kBlock; i0 < n; i0 += (size_t)gridDim.x * kBlock) {  // whole wavefronts iterate together
+    const size_t i = i0 + threadIdx.x;
+    unsigned long long k = kEmptyKey;
+    if (i < n) {
+      const P4 p = spts[i];
+      const double x = (double)p.x, y = (double)p.y, z = (double)p.z;
+      const double w = w0 * x + w1 * y + w2 * z + w3;
+      P4 o;
+      o.x = (R)((M.m[0] * x + M.m[1] * y + M.m[2] * z + M.m[3]) / w);
+      o.y = (R)((M.m[4] * x + M.m[5] * y + M.m[6] * z + M.m[7]) / w);
+      o.z = (R)((M.m[8] * x + M.m[9] * y + M.m[10] * z + M.m[11]) / w);
+      o.i = (typename Scalar<P4>::index)i;
+      placed[i] = o;
+      if (snrm) {
+        const P4 q = snrm[i];
+        const double a = (double)q.x, b = (double)q.y, c = (double)q.z;
+        P4 on;
+        on.x = (R)(M.m[0] * a + M.m[1] * b + M.m[2] * c);
+        on.y = (R)(M.m[4] * a + M.m[5] * b + M.m[6] * c);
+        on.z = (R)(M.m[8] * a + M.m[9] * b + M.m[10] * c);
+        on.i = 0;
+        placed_nrm[i] = on;
+      }
+      if (crop_contains(crop, (double)o.x, (double)o.y, (double)o.z))
+        k = pm_key(o, m.inv_voxel);
+      else
+        pm_push(m.outside_pts, m.counters + kPmOutside, m.list_cap, (int)i, m.counters + kPmError);
+    }
+    const unsigned long long kp = __shfl_up(k, 1, 64);
+    const bool lead = k != kEmptyKey && (lane == 0 || kp != k);
+    const unsigned long long ends = __ballot(lane == 0 || kp != k);
+    int slot = -1;
+    if (lead) {
+      const unsigned long long above = lane == 63 ? 0ull : (ends >> (lane + 1));
+      const int len = above ? (int)__builtin_ctzll(above) + 1 : 64 - lane;
+      unsigned int sl = pm_hash(k) & t.mask;
+      while (true) {
+        const unsigned long long prev = atomicCAS(&t.key[sl], kEmptyKey, k);
+        if (prev == kEmptyKey || prev == k) break;
+        sl = (sl + 1) & t.mask;
+      }
+      atomicMin(&t.first[sl], (unsigned int)i);
+      atomicAdd(&t.nrun[sl], 1u);
+      run_next[i] = atomicExch(&t.head[sl], (int)i);
+      run_len[i] = len;
+      slot = (int)sl;
+    }
+    if (i < n) lead_slot[i] = slot;
+  }
+}
+
+// a new slot for a point; -1 (and the error flag) when the arrays are full
+__device__ __forceinline__ int pm_new_slot(const PmDev& m) {
+  const int s = atomicAdd(m.counters + kPmN, 1);
+  if ((size_t)s >= m.cap) {
+    atomicOr(m.counters + kPmError, 2);
+    return -1;
+  }
+  return s;
+}
+// a new slot enters the list of its index row (pm_rows_kernel merges the lists into the rows)
+__device__ __forceinline__ void pm_row_push(const PmDev& m, int s, unsigned long long key) {
+  int row, x;
+  pm_cell(m, key, &row, &x);
+  const int old = atomicExch(&m.row_head[row], s);
+  m.rnext[s] = old;
+  if (old == -1) pm_push(m.touched_rows, m.counters + kPmTouched, m.list_cap, row, m.counters + kPmError);
+}
+// the mean of a voxel's members written where it belongs: point, normal, history, search index (in place: the mean of points of one voxel
+// lies in that voxel, hence in the same index cell), settled or not; `fresh`: the slot is new (its index entry comes with its row)
+template <typename P4>
+__device__ __forceinline__ void pm_store(const PmDev& m, int s, const P4& op, const P4& on, bool has_nrm, int t, unsigned long long key, bool fresh) {
+  P4 o = op;
+  o.i = (typename Scalar<P4>::index)s;
+  ((P4*)m.pts)[s] = o;
+  if (has_nrm) ((P4*)m.nrm)[s] = on;
+  m.stamp[s] = t;
+  m.okey[s] = key;
+  unsigned char fl = 0;
+  if (has_nrm && !pm_same_bits(pm_renormalized(on), on)) {
+    fl |= kPmUnsettled;
+    pm_push(m.unsettled[1], m.counters + kPmUnsettledOut, m.list_cap, s, m.counters + kPmError);
+  }
+  m.flags[s] = fl;
+  if (!fresh) {
+    const int pos = m.pos[s];
+    ((P4*)m.spts)[pos] = o;
+    if (has_nrm) ((P4*)m.snrm)[pos] = on;
+  }
+}
+template <typename P4>
+__device__ __forceinline__ void pm_kill(const PmDev& m, int s) {
+  using R = typename Scalar<P4>::type;
+  m.flags[s] = kPmDead;
+  atomicAdd(m.counters + kPmDeadCnt, 1);
+  P4 far;  // never the nearest neighbour of anything: its squared distance is +inf
+  far.x = far.y = far.z = sizeof(R) == 4 ? (R)3.0e38f : (R)1.0e300;
+  far.i = (typename Scalar<P4>::index)0x7fffffff;
+  ((P4*)m.spts)[m.pos[s]] = far;
+}
+
+// AccumulatedPoint (helpers.cpp:30-73) over the members of one voxel in the reference's order
+struct PmAcc {
+  double sx = 0, sy = 0, sz = 0, nx = 0, ny = 0, nz = 0;
+  int cnt = 0;
+  template <typename P4>
+  __device__ __forceinline__ void add(const P4& p, bool has_n, const P4& nq) {
+    sx += (double)p.x;
+    sy += (double)p.y;
+    sz += (double)p.z;
+    if (has_n) {
+      const double a = (double)nq.x, b = (double)nq.y, c = (double)nq.z;
+      if (!(isnan(a) || isnan(b) || isnan(c))) {  // helpers.cpp:35-38
+        nx += a;
+        ny += b;
+        nz += c;
+      }
+    }
+    ++cnt;
+  }
+  template <typename P4>
+  __device__ __forceinline__ void mean(P4* op, P4* on) {
+    using R = typename Scalar<P4>::type;
+    const double c = (double)cnt;
+    op->x = (R)(sx / c);
+    op->y = (R)(sy / c);
+    op->z = (R)(sz / c);
+    op->i = 0;
+    double a = nx / c, b = ny / c, d = nz / c;
+    pm_normalize(a, b, d);  // helpers.cpp:172
+    on->x = (R)a;
+    on->y = (R)b;
+    on->z = (R)d;
+    on->i = 0;
+  }
+};
+
+// after a mean was stored under key k: does it still lie in voxel k?  (rounding to storage can put it on the far side of a face.)  If not it
+// is re-hashed and re-indexed by the serial step.
+template <typename P4>
+__device__ __forceinline__ void pm_check_face(const PmDev& m, int s, const P4& op, unsigned long long k) {
+  if (pm_key(op, m.inv_voxel) != k) pm_push(m.relink, m.counters + kPmRelink, m.list_cap, s, m.counters + kPmError);
+}
+
+// (3) one thread per voxel the scan touched (numbered by vox_order_kernel, their number in a device word): the voxel's runs in ascending
+// order (as vox_mean_kernel), its chain in the voxel hash, the sum old member first -- the common cases, at most one old member inside the
+// volume, are finished here; a voxel with more goes on the list of pm_special_kernel.
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void pm_group_kernel(PmDev m, CountRef g_in, const int* __restrict__ order, const int* __restrict__ run_next,
+                                                          const int* __restrict__ run_len, uint32_t* __restrict__ starts, int2* __restrict__ piece,
+                                                          const P4* __restrict__ placed, const P4* __restrict__ placed_nrm, VoxTable t, CropDev crop,
+                                                          int t_now, unsigned long long* __restrict__ group_key) {
+  const size_t g = count_of(g_in);
+  const int lane = threadIdx.x & 63;
+  const bool has_nrm = m.nrm != nullptr;
+  for (size_t r0 = (size_t)blockIdx.x * kBlock; r0 < g; r0 += (size_t)gridDim.x * kBlock) {  // whole wavefronts iterate together
+    const size_t r = r0 + threadIdx.x;
+    const bool have = r < g;
+    int k = 0, node = -1;
+    unsigned long long key = 0;
+    if (have) {
+      const int s = order[r];
+      k = (int)t.nrun[s] + 1;
+      node = t.head[s];
+      key = t.key[s];
+      t.key[s] = kEmptyKey;  // the scratch table is handed back empty (all 0xff), as vox_mean_kernel does
+      t.first[s] = ~0u;
+      t.head[s] = -1;
+      t.nrun[s] = ~0u;
+    }
+    int incl = k;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int y = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += y;
+    }
+    const int wave_total = __shfl(incl, 63, 64);
+    unsigned int wbase = 0;
+    if (lane == 0 && wave_total > 0) wbase = atomicAdd(t.cursor, (unsigned int)wave_total);
+    wbase = __shfl(wbase, 0, 64);
+    const int b = (int)wbase + incl - k;
+    for (int j = 0; j < k; ++j) {
+      starts[b + j] = (uint32_t)node;
+      node = run_next[node];
+    }
+    if (k > 1) sort_indices(starts + b, k);
+    if (!have) continue;
+    piece[r] = make_int2(b, k);
+    group_key[r] = key;
+    // old members of the voxel that lie inside the volume (they are in the voxel hash under the same key)
+    int old_slot = -1, n_old_in = 0, n_live = 0;
+    const unsigned int e = pm_entry(m, key);
+    for (int s = m.hhead[e]; s != -1; s = m.hnext[s]) {
+      ++n_live;
+      const P4 p = ((const P4*)m.pts)[s];
+      if (crop_contains(crop, (double)p.x, (double)p.y, (double)p.z)) {
+        ++n_old_in;
+        old_slot = s;
+      }
+    }
+    if (n_old_in > 1) {
+      pm_push(m.complex_groups, m.counters + kPmComplex, m.list_cap, (int)r, m.counters + kPmError);
+      continue;
+    }
+    PmAcc acc;
+    if (n_old_in == 1) {
+      const P4 p = ((const P4*)m.pts)[old_slot];
+      P4 q{};
+      if (has_nrm) q = ((const P4*)m.nrm)[old_slot];
+      acc.add(p, has_nrm, q);
+    }
+    for (int j = 0; j < k; ++j) {
+      const uint32_t st = starts[b + j];
+      const int len = run_len[st];
+      for (int q = 0; q < len; ++q) {
+        const P4 p = placed[st + q];
+        P4 nq{};
+        if (has_nrm) nq = placed_nrm[st + q];
+        acc.add(p, has_nrm, nq);
+      }
+    }
+    P4 op, on;
+    acc.mean(&op, &on);
+    int s = old_slot;
+    const bool fresh = s < 0;
+    if (fresh) {
+      s = pm_new_slot(m);
+      if (s < 0) continue;
+      m.hnext[s] = m.hhead[e];  // (this thread is the only one that touches this voxel's chain in this launch)
+      m.hhead[e] = s;
+      if (n_live > 0 && !(atomicOr(&m.hflag[e], 1u) & 1u)) pm_push64(m.multi[1], m.counters + kPmMultiOut, m.list_cap, key, m.counters + kPmError);
+    }
+    pm_store(m, s, op, on, has_nrm, t_now, key, fresh);
+    if (fresh) pm_row_push(m, s, pm_key(op, m.inv_voxel));  // (the cell of where the mean really is: pm_check_face re-hashes it if that is another voxel)
+    pm_check_face(m, s, op, key);
+  }
+}
+
+// unlink slot s from the chain of hash entry e (serial contexts only)
+__device__ __forceinline__ void pm_unlink(const PmDev& m, unsigned int e, int s) {
+  int prev = -1;
+  for (int c = m.hhead[e]; c != -1; prev = c, c = m.hnext[c]) {
+    if (c != s) continue;
+    if (prev == -1)
+      m.hhead[e] = m.hnext[c];
+    else
+      m.hnext[prev] = m.hnext[c];
+    return;
+  }
+}
+
+// (4a) the voxels with several old members: those of the scan (listed by pm_group_kernel) and those on the multi list that the scan did
+// not touch but whose members now lie inside the volume together.  One thread per voxel (a voxel's chain belongs to its thread; the lists
+// are pushed to with atomics).  The members inside the volume are summed in the order of the reference's array before this insertion
+// (pm_view_key at t - 1), then the scan's points of the voxel, into the first member's slot; the others die.
+struct PmOld {
+  unsigned long long hi[kPmMaxOld], lo[kPmMaxOld];
+  int slot[kPmMaxOld];
+};
+template <typename P4>
+__device__ __forceinline__ int pm_gather_old(const PmDev& m, unsigned int e, const CropDev& crop, int t_now, PmOld& o /* LDS */) {
+  int n = 0;
+  for (int s = m.hhead[e]; s != -1; s = m.hnext[s]) {
+    const P4 p = ((const P4*)m.pts)[s];
+    if (!crop_contains(crop, (double)p.x, (double)p.y, (double)p.z)) continue;
+    if (n == kPmMaxOld) return kPmMaxOld + 1;  // more than the sorted list holds: pm_merge_many
+    unsigned long long h, l;
+    pm_view_key<P4>(m, s, t_now - 1, &h, &l);
+    int j = n++;
+    while (j > 0 && (o.hi[j - 1] > h || (o.hi[j - 1] == h && o.lo[j - 1] > l))) {
+      o.hi[j] = o.hi[j - 1], o.lo[j] = o.lo[j - 1], o.slot[j] = o.slot[j - 1];
+      --j;
+    }
+    o.hi[j] = h, o.lo[j] = l, o.slot[j] = s;
+  }
+  return n;
+}
+template <typename P4>
+__device__ __forceinline__ void pm_merge_old(const PmDev& m, unsigned int e, unsigned long long key, const PmOld& o, int n_old, int group /* -1: no scan points */,
+                                             const int2* __restrict__ piece, const uint32_t* __restrict__ starts, const int* __restrict__ run_len,
+                                             const P4* __restrict__ placed, const P4* __restrict__ placed_nrm, int t_now) {
+  const bool has_nrm = m.nrm != nullptr;
+  PmAcc acc;
+  for (int j = 0; j < n_old; ++j) {
+    const P4 p = ((const P4*)m.pts)[o.slot[j]];
+    P4 q{};
+    if (has_nrm) q = ((const P4*)m.nrm)[o.slot[j]];
+    acc.add(p, has_nrm, q);
+  }
+  if (group >= 0) {
+    const int2 pc = piece[group];
+    for (int j = 0; j < pc.y; ++j) {
+      const uint32_t st = starts[pc.x + j];
+      const int len = run_len[st];
+      for (int q = 0; q < len; ++q) {
+        P4 nq{};
+        if (has_nrm) nq = placed_nrm[st + q];
+        acc.add(placed[st + q], has_nrm, nq);
+      }
+    }
+  }
+  P4 op, on;
+  acc.mean(&op, &on);
+  for (int j = 1; j < n_old; ++j) {
+    pm_unlink(m, e, o.slot[j]);
+    pm_kill<P4>(m, o.slot[j]);
+  }
+  pm_store(m, o.slot[0], op, on, has_nrm, t_now, key, false);
+  pm_check_face(m, o.slot[0], op, key);
+}
+// the same for a voxel with more old members inside the volume than the sorted list holds (a map that entered with many raw points per
+// voxel): no list -- the member next in order is looked for again for every addend (quadratic in the members; such voxels are few)
+template <typename P4>
+__device__ __forceinline__ void pm_merge_many(const PmDev& m, unsigned int e, unsigned long long key, const CropDev& crop, int group,
+                                              const int2* __restrict__ piece, const uint32_t* __restrict__ starts, const int* __restrict__ run_len,
+                                              const P4* __restrict__ placed, const P4* __restrict__ placed_nrm, int t_now) {
+  const bool has_nrm = m.nrm != nullptr;
+  PmAcc acc;
+  unsigned long long last_hi = 0, last_lo = 0;
+  int first = -1;
+  for (bool any = false;; any = true) {
+    int best = -1;
+    unsigned long long bh = ~0ull, bl = ~0ull;
+    for (int s = m.hhead[e]; s != -1; s = m.hnext[s]) {
+      const P4 p = ((const P4*)m.pts)[s];
+      if (!crop_contains(crop, (double)p.x, (double)p.y, (double)p.z)) continue;
+      unsigned long long h, l;
+      pm_view_key<P4>(m, s, t_now - 1, &h, &l);
+      if (any && !(h > last_hi || (h == last_hi && l > last_lo))) continue;  // summed already
+      if (best == -1 || h < bh || (h == bh && l < bl)) best = s, bh = h, bl = l;
+    }
+    if (best == -1) break;
+    const P4 p = ((const P4*)m.pts)[best];
+    P4 q{};
+    if (has_nrm) q = ((const P4*)m.nrm)[best];
+    acc.add(p, has_nrm, q);
+    if (first == -1) first = best;
+    last_hi = bh, last_lo = bl;
+  }
+  if (first == -1) return;
+  if (group >= 0) {
+    const int2 pc = piece[group];
+    for (int j = 0; j < pc.y; ++j) {
+      const uint32_t st = starts[pc.x + j];
+      const int len = run_len[st];
+      for (int q = 0; q < len; ++q) {
+        P4 nq{};
+        if (has_nrm) nq = placed_nrm[st + q];
+        acc.add(placed[st + q], has_nrm, nq);
+      }
+    }
+  }
+  P4 op, on;
+  acc.mean(&op, &on);
+  for (int s = m.hhead[e]; s != -1;) {  // the other members inside the volume die
+    const int nxt = m.hnext[s];
+    const P4 p = ((const P4*)m.pts)[s];
+    if (s != first && crop_contains(crop, (double)p.x, (double)p.y, (double)p.z)) {
+      pm_unlink(m, e, s);
+      pm_kill<P4>(m, s);
+    }
+    s = nxt;
+  }
+  pm_store(m, first, op, on, has_nrm, t_now, key, false);
+  pm_check_face(m, first, op, key);
+}
+
+template <typename P4>
+__global__ __launch_bounds__(64) void pm_merge_kernel(PmDev m, const int2* __restrict__ piece, const uint32_t* __restrict__ starts, const int* __restrict__ run_len,
+                                                      const P4* __restrict__ placed, const P4* __restrict__ placed_nrm,
+                                                      const unsigned long long* __restrict__ group_key /* [groups] key of group r */, CropDev crop, int t_now) {
+  __shared__ PmOld s_old[64];
+  PmOld& o = s_old[threadIdx.x];
+  int* err = m.counters + kPmError;
+  const int cap = m.list_cap;
+  const int n_complex = min(m.counters[kPmComplex], cap), n_multi = min(m.counters[kPmMultiIn], cap);
+  for (int i = blockIdx.x * 64 + threadIdx.x; i < n_complex + n_multi; i += gridDim.x * 64) {
+    if (i < n_complex) {  // a voxel of the scan with several old members inside the volume
+      const int r = m.complex_groups[i];
+      const unsigned long long key = group_key[r];
+      const unsigned int e = pm_entry(m, key);
+      const int n_old = pm_gather_old<P4>(m, e, crop, t_now, o);
+      if (n_old > kPmMaxOld)
+        pm_merge_many<P4>(m, e, key, crop, r, piece, starts, run_len, placed, placed_nrm, t_now);
+      else
+        pm_merge_old<P4>(m, e, key, o, n_old, r, piece, starts, run_len, placed, placed_nrm, t_now);
+      continue;
+    }
+    // a voxel on the multi list.  One the scan touched has been dealt with: its group saw the whole chain (a complex group of this very
+    // launch belongs to another thread, which may be rewriting the chain right now: told apart by the list of this launch, not by the chain).
+    const unsigned long long key = m.multi[0][i - n_complex];
+    const unsigned int e = pm_entry(m, key);
+    bool touched = false;
+    for (int j = 0; j < n_complex && !touched; ++j) touched = group_key[m.complex_groups[j]] == key;
+    if (!touched) {
+      for (int s = m.hhead[e]; s != -1; s = m.hnext[s]) touched |= m.stamp[s] == t_now && !(m.okey[s] & kPmRaw);
+      if (!touched) {
+        const int n_old = pm_gather_old<P4>(m, e, crop, t_now, o);
+        if (n_old > kPmMaxOld)
+          pm_merge_many<P4>(m, e, key, crop, -1, piece, starts, run_len, placed, placed_nrm, t_now);
+        else if (n_old > 1)
+          pm_merge_old<P4>(m, e, key, o, n_old, -1, piece, starts, run_len, placed, placed_nrm, t_now);
+      }
+      int live = 0;
+      for (int s = m.hhead[e]; s != -1; s = m.hnext[s]) ++live;
+      if (live > 1)
+        pm_push64(m.multi[1], m.counters + kPmMultiOut, cap, key, err);
+      else
+        m.hflag[e] &= ~1u;
+    } else {
+      pm_push64(m.multi[1], m.counters + kPmMultiOut, cap, key, err);  // (stays listed; settled at the next insertion)
+    }
+  }
+}
+
+// (4b) the rest.  In parallel, the normals that are not a fixed point yet: a slot that nothing wrote this time and that lies inside the
+// volume is alone in its voxel there -- the reference replaces its normal by the re-normalised one (its point by itself).  And, on ONE
+// thread (a handful of items, and what they do to the chains needs no locks that way): the scan points outside the volume (they pass
+// through, i.e. join the map as they were placed) and the means that were rounded across a voxel face (chain of the old key -> chain of
+// the key they have now; the index entry of an old slot is killed and comes back with the rows, a new slot is on its row's list already).
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void pm_misc_kernel(PmDev m, const P4* __restrict__ placed, const P4* __restrict__ placed_nrm, CropDev crop, int t_now) {
+  int* err = m.counters + kPmError;
+  const bool has_nrm = m.nrm != nullptr;
+  const int cap = m.list_cap;
+  const int n_uns = min(m.counters[kPmUnsettledIn], cap);
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_uns; i += gridDim.x * kBlock) {
+    const int s = m.unsettled[0][i];
+    const unsigned char fl = m.flags[s];
+    if ((fl & kPmDead) || !(fl & kPmUnsettled) || m.stamp[s] == t_now) continue;  // (a slot written now was listed again by pm_store if need be)
+    const P4 p = ((const P4*)m.pts)[s];
+    if (crop_contains(crop, (double)p.x, (double)p.y, (double)p.z)) {
+      const P4 nv = ((const P4*)m.nrm)[s];
+      const P4 nn = pm_renormalized(nv);
+      ((P4*)m.nrm)[s] = nn;
+      ((P4*)m.snrm)[m.pos[s]] = nn;
+      if (pm_same_bits(pm_renormalized(nn), nn)) {
+        m.flags[s] = fl & ~kPmUnsettled;
+        continue;
+      }
+    }
+    pm_push(m.unsettled[1], m.counters + kPmUnsettledOut, cap, s, err);
+  }
+  if (blockIdx.x != gridDim.x - 1 || threadIdx.x != 0) return;
+  const int n_out = min(m.counters[kPmOutside], cap);
+  for (int i = 0; i < n_out; ++i) {
+    const int si = m.outside_pts[i];
+    const int s = pm_new_slot(m);
+    if (s < 0) break;
+    P4 o = placed[si];
+    const unsigned long long key = pm_key(o, m.inv_voxel);
+    o.i = (typename Scalar<P4>::index)s;
+    ((P4*)m.pts)[s] = o;
+    P4 on{};
+    if (has_nrm) {
+      on = placed_nrm[si];
+      ((P4*)m.nrm)[s] = on;
+    }
+    m.stamp[s] = t_now;
+    m.okey[s] = kPmRaw | (unsigned long long)si;
+    unsigned char fl = 0;
+    if (has_nrm && !pm_same_bits(pm_renormalized(on), on)) {
+      fl |= kPmUnsettled;
+      pm_push(m.unsettled[1], m.counters + kPmUnsettledOut, cap, s, err);
+    }
+    m.flags[s] = fl;
+    const unsigned int e = pm_entry(m, key);
+    m.hnext[s] = m.hhead[e];
+    const bool had = m.hhead[e] != -1;
+    m.hhead[e] = s;
+    if (had && !(m.hflag[e] & 1u)) {
+      m.hflag[e] |= 1u;
+      pm_push64(m.multi[1], m.counters + kPmMultiOut, cap, key, err);
+    }
+    pm_row_push(m, s, key);
+  }
+  const int n_rel = min(m.counters[kPmRelink], cap);
+  for (int i = 0; i < n_rel; ++i) {
+    const int s = m.relink[i];
+    if (m.flags[s] & kPmDead) continue;
+    const P4 p = ((const P4*)m.pts)[s];
+    const unsigned long long k_old = m.okey[s], k_new = pm_key(p, m.inv_voxel);
+    pm_unlink(m, pm_entry(m, k_old), s);
+    const unsigned int e = pm_entry(m, k_new);
+    const bool had = m.hhead[e] != -1;
+    m.hnext[s] = m.hhead[e];
+    m.hhead[e] = s;
+    if (had && !(m.hflag[e] & 1u)) {
+      m.hflag[e] |= 1u;
+      pm_push64(m.multi[1], m.counters + kPmMultiOut, cap, k_new, err);
+    }
+    if (m.rnext[s] == -2) {  // in the index, in the cell of its old voxel (a new slot is on the list of the row it really is in)
+      using R = typename Scalar<P4>::type;
+      P4 far;
+      far.x = far.y = far.z = sizeof(R) == 4 ? (R)3.0e38f : (R)1.0e300;
+      far.i = (typename Scalar<P4>::index)0x7fffffff;
+      ((P4*)m.spts)[m.pos[s]] = far;
+      pm_row_push(m, s, k_new);
+    }
+  }
+}
+
+// (5) the rows of the index that received new slots: ONE wavefront per row.  The row's cells keep their order; every cell grows by the new
+// slots that fall into it, so its old points move up by the number of new points in the cells before it -- inside the row's region if that
+// has the room, into a fresh region at the end of the pool (twice the need) otherwise.  The old points are moved from the back in chunks of
+// a wavefront (read, then written: a point only ever moves up), the new ones go behind their cell's old ones.
+template <typename P4>
+__global__ __launch_bounds__(64) void pm_rows_kernel(PmDev m) {
+  extern __shared__ int s_cells[];  // [3][nx + 1]: old starts, added counts -> new starts, cursors
+  const int nx = m.grid.nx, lane = threadIdx.x;
+  int* s_old = s_cells;
+  int* s_add = s_cells + (nx + 1);
+  int* s_new = s_cells + 2 * (nx + 1);
+  const int n_rows = min(m.counters[kPmTouched], m.list_cap);
+  for (int ri = blockIdx.x; ri < n_rows; ri += gridDim.x) {
+    const int row = m.touched_rows[ri];
+    int* cs = m.cs + (size_t)row * (nx + 1);
+    for (int x = lane; x <= nx; x += 64) {
+      s_old[x] = cs[x];
+      s_add[x] = 0;
+    }
+    __syncthreads();
+    // the row's list: counted per cell (lane 0 walks it: a few entries)
+    int n_new = 0;
+    if (lane == 0) {
+      for (int s = m.row_head[row]; s >= 0; s = m.rnext[s]) {
+        const P4 p = ((const P4*)m.pts)[s];
+        int r2, x;
+        pm_cell(m, pm_key(p, m.inv_voxel), &r2, &x);
+        ++s_add[x];
+        ++n_new;
+      }
+    }
+    n_new = __shfl(n_new, 0, 64);
+    __syncthreads();
+    const int old_start = s_old[0], old_end = s_old[nx], old_cnt = old_end - old_start;
+    const int need = old_cnt + n_new;
+    int base = old_start;
+    if (need > m.row_cap[row]) {  // the row moves to the end of the pool
+      int nb = 0;
+      const int cap_new = 2 * need + 8;
+      if (lane == 0) {
+        nb = atomicAdd(m.counters + kPmPoolTop, cap_new);
+        if (nb + cap_new > m.pool_cap) {
+          atomicOr(m.counters + kPmError, 4);
+          nb = -1;
+        }
+      }
+      nb = __shfl(nb, 0, 64);
+      if (nb < 0) {
+        if (lane == 0) m.row_head[row] = -1;
+        __syncthreads();
+        continue;
+      }
+      base = nb;
+      if (lane == 0) m.row_cap[row] = cap_new;
+    }
+    // new starts: exclusive scan over (old count + added) per cell, chunks of 64 cells
+    int run = base;
+    for (int x0 = 0; x0 <= nx; x0 += 64) {
+      const int x = x0 + lane;
+      const int c = x < nx ? (s_old[x + 1] - s_old[x]) + s_add[x] : 0;
+      int incl = c;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += y;
+      }
+      if (x <= nx) s_new[x] = run + incl - c;
+      run += __shfl(incl, 63, 64);
+    }
+    __syncthreads();
+    // old points, from the back
+    const bool has_nrm = m.snrm != nullptr;
+    for (int hi = old_end; hi > old_start; hi -= 64) {
+      const int j = hi - 64 + lane;
+      const int jc = max(j, old_start);  // (clamped, not predicated: the loads stay out of the branch)
+      const P4 p = ((const P4*)m.spts)[jc];
+      const P4 q = ((const P4*)(has_nrm ? m.snrm : m.spts))[jc];
+      int dst = -1;
+      if (j >= old_start) {
+        // its cell: the last x with s_old[x] <= j
+        int lo = 0, hh = nx - 1;
+        while (lo < hh) {
+          const int mid = (lo + hh + 1) >> 1;
+          if (s_old[mid] <= j)
+            lo = mid;
+          else
+            hh = mid - 1;
+        }
+        dst = s_new[lo] + (j - s_old[lo]);
+      }
+      // (every lane's store depends on the wavefront's load instruction having returned: all of the chunk is read before any of it is written)
+      if (dst >= 0 && dst != j) {
+        P4 pp, qq;  // (field by field: an aggregate copy through a conditional branch went through scratch memory)
+        pp.x = p.x, pp.y = p.y, pp.z = p.z, pp.i = p.i;
+        qq.x = q.x, qq.y = q.y, qq.z = q.z, qq.i = q.i;
+        ((P4*)m.spts)[dst] = pp;
+        if (has_nrm) ((P4*)m.snrm)[dst] = qq;
+        if ((int)p.i != 0x7fffffff) m.pos[(int)p.i] = dst;
+      }
+    }
+    __syncthreads();
+    // new points behind their cell's old ones; cursors in s_add (reused: position of the next new point of the cell)
+    for (int x = lane; x < nx; x += 64) s_add[x] = s_new[x] + (s_old[x + 1] - s_old[x]);
+    __syncthreads();
+    if (lane == 0) {
+      for (int s = m.row_head[row]; s >= 0;) {
+        const int nxt = m.rnext[s];
+        P4 p = ((const P4*)m.pts)[s];
+        int r2, x;
+        pm_cell(m, pm_key(p, m.inv_voxel), &r2, &x);
+        const int dst = s_add[x]++;
+        p.i = (typename Scalar<P4>::index)s;
+        ((P4*)m.spts)[dst] = p;
+        if (has_nrm) ((P4*)m.snrm)[dst] = ((const P4*)m.nrm)[s];
+        m.pos[s] = dst;
+        m.rnext[s] = -2;
+        s = nxt;
+      }
+      m.row_head[row] = -1;
+    }
+    __syncthreads();
+    for (int x = lane; x <= nx; x += 64) cs[x] = s_new[x];
+    __syncthreads();
+  }
+}
+
+// bookkeeping between two insertions: the "out" lists become the "in" lists, the per-insertion lists are emptied; the number of slots goes
+// to the pinned record
+__global__ __launch_bounds__(64) void pm_turn_kernel(PmDev m, CountPub pub, CropDev* __restrict__ hist, CropDev crop, int t_now, double* __restrict__ host_vals) {
+  if (threadIdx.x != 0) return;
+  int* c = m.counters;
+  hist[t_now] = crop;  // the volume of this insertion joins the history (pm_view_key)
+  if (host_vals) {     // what the host sizes the next insertion by: first free index position, dead slots, sticky error
+    host_vals[0] = (double)c[kPmPoolTop];
+    host_vals[1] = (double)c[kPmDeadCnt];
+    host_vals[2] = (double)c[kPmError];
+  }
+  c[kPmUnsettledIn] = min(c[kPmUnsettledOut], m.list_cap);
+  c[kPmUnsettledOut] = 0;
+  c[kPmMultiIn] = min(c[kPmMultiOut], m.list_cap);
+  c[kPmMultiOut] = 0;
+  c[kPmComplex] = c[kPmOutside] = c[kPmRelink] = c[kPmTouched] = 0;
+  publish_count(pub, c[kPmN]);
+}
+
+// ---- leaving the persistent form: the reference's array --------------------------------------------------------------------------------
+// 128-bit position key of every live slot (dead ones sort behind everything and are counted)
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void pm_view_key_kernel(PmDev m, int n, int t_last, unsigned long long* __restrict__ hi, unsigned long long* __restrict__ lo,
+                                                             uint32_t* __restrict__ val, unsigned long long* __restrict__ n_pass) {
+  unsigned long long cnt = 0;
+  for (int s = blockIdx.x * kBlock + threadIdx.x; s < n; s += gridDim.x * kBlock) {
+    unsigned long long h = ~0ull, l = ~0ull;
+    if (!(m.flags[s] & kPmDead)) {
+      pm_view_key<P4>(m, s, t_last, &h, &l);
+      if (!(h >> 63)) ++cnt;
+    }
+    hi[s] = h;
+    lo[s] = l;
+    val[s] = (uint32_t)s;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(n_pass, cnt);
+}
+__global__ __launch_bounds__(kBlock) void pm_gather_u64_kernel(const unsigned long long* __restrict__ in, const uint32_t* __restrict__ idx, size_t n,
+                                                               unsigned long long* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) out[i] = in[idx[i]];
+}
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void pm_permute_kernel(const P4* __restrict__ pts, const P4* __restrict__ nrm, const uint32_t* __restrict__ idx, size_t n,
+                                                            P4* __restrict__ out_pts, P4* __restrict__ out_nrm) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    P4 p = pts[idx[i]];
+    p.i = (typename Scalar<P4>::index)i;
+    out_pts[i] = p;
+    if (nrm) out_nrm[i] = nrm[idx[i]];
+  }
+}
+
+#pragma clang fp contract(fast)
+
+}  // namespace o3ds

@@ -665,7 +665,11 @@ __device__ __forceinline__ void normals_body(const P4* __restrict__ pts /* origi
 
 template <typename P4, int KMAX>
 __global__ __launch_bounds__(64 * kNrmWaves) void normals_kernel(const P4* __restrict__ pts, size_t n, GridDev g, const P4* __restrict__ sp, double radius,
-                                                                 int max_nn, int rmax_cells, double* __restrict__ out_sums, int* __restrict__ out_cnt) {
+                                                                 int max_nn, int rmax_cells, double* __restrict__ out_sums, int* __restrict__ out_cnt,
+                                                                 const int* __restrict__ n_dev = nullptr /* the exact count when n is an upper bound */) {
+  if (n_dev) n = (size_t)*n_dev;
+  // (no early return for the workgroups past the end: it cost the occ5 instantiation its last registers -- 12 bytes of scratch;
+  // their groups find `have` false and fall through)
   normals_body<P4, KMAX>(pts, n, g, sp, radius, max_nn, rmax_cells, out_sums, out_cnt);
 }
 // The instantiation the lidar stream uses (f32 storage, max_nn <= 32) fits 96 registers without spilling when asked to: five wavefronts per
@@ -675,7 +679,8 @@ template <typename P4, int KMAX>
 __global__ __launch_bounds__(64 * kNrmWaves) __attribute__((amdgpu_waves_per_eu(5))) void normals_kernel_occ5(const P4* __restrict__ pts, size_t n, GridDev g,
                                                                                                               const P4* __restrict__ sp, double radius, int max_nn,
                                                                                                               int rmax_cells, double* __restrict__ out_sums,
-                                                                                                              int* __restrict__ out_cnt) {
+                                                                                                              int* __restrict__ out_cnt, const int* __restrict__ n_dev = nullptr) {
+  if (n_dev) n = (size_t)*n_dev;
   normals_body<P4, KMAX>(pts, n, g, sp, radius, max_nn, rmax_cells, out_sums, out_cnt);
 }
 
@@ -684,8 +689,10 @@ __global__ __launch_bounds__(64 * kNrmWaves) __attribute__((amdgpu_waves_per_eu(
 template <typename P4>
 __global__ __launch_bounds__(256) void normals_finish_kernel(const P4* __restrict__ sp /* sorted by cell */, size_t n, const double* __restrict__ sums,
                                                              const int* __restrict__ cnts, P4* __restrict__ out_nrm, int raw = 0,
-                                                             P4* __restrict__ out_sorted = nullptr /* the same normals in cell order */) {
+                                                             P4* __restrict__ out_sorted = nullptr /* the same normals in cell order */,
+                                                             const int* __restrict__ n_dev = nullptr) {
   using R = typename Scalar<P4>::type;
+  if (n_dev) n = (size_t)*n_dev;
   const size_t pj = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (pj < n) {
     const P4 q = sp[pj];

@@ -52,11 +52,18 @@ class PointCloud:
         return self.be.size(self.id)[0]
 
     def IsEmpty(self) -> bool:
+        """decided by what is known of the size without waiting for it where that suffices (o3ds_cloud_size_bound)"""
+        lo, up = self.be.size_bound(self.id)
+        if up == 0:
+            return True
+        if lo > 0:
+            return False
         return len(self) == 0
 
     def HasNormals(self) -> bool:
-        n, hn = self.be.size(self.id)
-        return n > 0 and hn
+        """[O3D] points_.size() > 0 && normals_.size() == points_.size().  Whether the device cloud carries normals is known at once; its
+        size may still be in flight (o3ds_cloud_size), so it is only asked for when there are normals to speak of."""
+        return self.be.has_normals(self.id) and not self.IsEmpty()
 
     def HasColors(self) -> bool:
         return len(self) > 0 and self.be.has_colors(self.id)
@@ -103,8 +110,10 @@ def random_down_sample(cloud: "PointCloud", ratio: float, rng=None, shuffle_at_f
     std::random_device per call, so the reference is not reproducible here; `rng` (a numpy Generator) pins the list.
     With ratio >= 1 Open3D still returns a PERMUTATION of the cloud; that only changes summation orders downstream, so the default
     leaves the cloud alone and `shuffle_at_full_ratio` reproduces the permutation when a test wants it.  Consumes `cloud`."""
+    if ratio >= 1.0 and not shuffle_at_full_ratio:
+        return cloud  # (before the size is asked for: it may still be in flight on the device, o3ds_cloud_size)
     n = len(cloud)
-    if n == 0 or (ratio >= 1.0 and not shuffle_at_full_ratio):
+    if n == 0:
         return cloud
     if rng is None:
         rng = np.random.default_rng()

@@ -81,9 +81,9 @@ class ScanToMapIcp(ScanToMapRegistration):  # ScanToMapRegistration.hpp:40-59
         # the scan-matcher volume of the shipped configurations is the map-builder volume (or contains it): cropping what the latter kept
         # returns it unchanged, so the second cloud is the first (no kernels, no size read-back)
         narrow = wide if self.scanMatcherCropper_.contains(self.mapBuilderCropper_) else self.scanMatcherCropper_.crop(wide)
-        if not len(narrow) > 0:
-            raise RuntimeError("ScanToMapIcp::narrow cropped size is zero")  # assert_gt
-        if not len(wide) > 0:
+        if narrow.IsEmpty():  # (assert_gt(size, 0): decided without waiting for a size that is still in flight on the device)
+            raise RuntimeError("ScanToMapIcp::narrow cropped size is zero")
+        if wide.IsEmpty():
             raise RuntimeError("ScanToMapIcp::wideCropped cropped size is zero")
         return ProcessedScans(merge_=wide, match_=narrow)
 
@@ -93,7 +93,7 @@ class ScanToMapIcp(ScanToMapRegistration):  # ScanToMapRegistration.hpp:40-59
         the submap's resident index -- same correspondences, no O(N) copy or rebuild per scan."""
         mapCloud = activeSubmap.getMapPointCloud()
         self.scanMatcherCropper_.setPose(mapToRangeSensor)
-        if len(mapCloud) == 0:
+        if mapCloud.IsEmpty():
             raise RuntimeError("map patch size is zero")
         r = self.cloudRegistration.registerClouds(scan, mapCloud, initialGuess, target_crop=self.scanMatcherCropper_.to_abi())
         return r

@@ -1159,9 +1159,10 @@ def test_crop_voxel_down_sample_is_crop_then_voxel_bit_for_bit(backend_f64, back
         be.free(c)
 
 
-def _insert_sequence(be, n_frames, rmax, voxel, carve_at=()):
+def _insert_sequence(be, n_frames, rmax, voxel, carve_at=(), look_at=None, scan_rmax=None):
     """a short mapping run: scans along an out-and-back path (points leave the map builder's volume and come back), returns the map
-    after every insertion as raw bytes"""
+    after every insertion (look_at: after these insertions only -- a map in its persistent form folds back into an array when somebody
+    looks, so looking rarely is what exercises its history) as raw bytes; scan_rmax: the scans are cropped to this range first"""
     scene = syn.make_scene()
     m = be.upload(np.zeros((0, 3)))
     out = []
@@ -1170,14 +1171,18 @@ def _insert_sequence(be, n_frames, rmax, voxel, carve_at=()):
         T = syn.make_pose([1.5 * t, 0.4 * t, 0.0], [0.0, 0.0, 4.0 * t])
         raw = syn.vlp16_scan(scene, T, frame=k, n_az=256)
         s = be.upload(raw)
-        v = be.voxel_down_sample(s, 0.1)
+        if scan_rmax is None:
+            v = be.voxel_down_sample(s, 0.1)
+        else:
+            v = be.crop_voxel_down_sample(s, backend.make_crop(backend.CROP_MAX_RADIUS, rmax=scan_rmax), 0.1)
         be.estimate_normals(v, 2.0, 10)
         crop = backend.make_crop(backend.CROP_MIN_MAX_RADIUS, center=T[:3, 3], rmin=0.0, rmax=rmax)
         if k in carve_at:
             be.map_carve(m, s, T, crop)
         be.map_insert_scan(m, v, T, voxel, crop, max_corr_hint=1.0)
-        p, n = be.download(m)
-        out.append((p.tobytes(), n.tobytes(), len(p)))
+        if look_at is None or k in look_at:
+            p, n = be.download(m)
+            out.append((p.tobytes(), n.tobytes(), len(p)))
         be.free(s)
         be.free(v)
     be.free(m)
@@ -1243,9 +1248,41 @@ def test_map_merge_by_merging_is_bitwise_the_full_sort(prec, monkeypatch):
     import pickle
 
     ref = pickle.loads(subprocess.run([sys.executable, "-c", code], capture_output=True, check=True,
-                                      env=dict(os.environ, O3DS_NO_INCREMENTAL_MERGE="1")).stdout)
+                                      env=dict(os.environ, O3DS_NO_INCREMENTAL_MERGE="1", O3DS_NO_PERSISTENT_MAP="1")).stdout)
     be = backend.Backend(0, p)
     got = _insert_sequence(be, 14, 12.0, 0.2, carve_at=(9,))
+    be.close()
+    assert [g[2] for g in got] == [r[2] for r in ref]
+    for k, (g, r) in enumerate(zip(got, ref)):
+        assert g[0] == r[0] and g[1] == r[1], k
+    assert got[-1][2] > 5000
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+@pytest.mark.parametrize("case", ["look_rarely", "scan_inside_volume", "never_until_the_end"])
+def test_persistent_map_is_bitwise_the_array_form(prec, case):
+    """Submap::insertScan in time independent of the map's size (map_kernels.hpp): from its second insertion on a map lives in slot
+    arrays + a voxel hash + a row-paged search index, an insertion touches only the voxels the scan falls into, and the reference's array
+    [pass-through points in original order | voxel means in key order] is only formed when somebody looks.  It must be the SAME array,
+    byte for byte, as re-binning the whole map at every insertion gives (O3DS_NO_PERSISTENT_MAP=1 in a child process, the path the golden
+    and oracle tests hold to the reference): 24 insertions along an out-and-back path with a small builder volume -- points leave the
+    volume, pass through for a while and re-enter, scan points beyond the volume join the map unmerged, means round across voxel faces,
+    several old points of one voxel merge when the volume comes back over them -- looked at rarely (long histories) or only at the end,
+    with a carve in between (which folds the map), and a registration against the persistent map's index after every insertion."""
+    import pickle
+    import subprocess
+    import sys
+
+    p = backend.PRECISION_F64 if prec == "f64" else backend.PRECISION_F32
+    kw = {"look_rarely": dict(look_at=(3, 4, 11, 17, 23), carve_at=(14,)), "scan_inside_volume": dict(look_at=(7, 15, 23), scan_rmax=11.5),
+          "never_until_the_end": dict(look_at=(23,))}[case]
+    code = ("import sys, pickle; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_preprocess_map_gpu as t; from open3d_slam_amd import backend; "
+            "be = backend.Backend(0, %d, ab=True); sys.stdout.buffer.write(pickle.dumps(t._insert_sequence(be, 24, 12.0, 0.2, **%r)))"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), p, kw))
+    ref = pickle.loads(subprocess.run([sys.executable, "-c", code], capture_output=True, check=True,
+                                      env=dict(os.environ, O3DS_NO_PERSISTENT_MAP="1")).stdout)
+    be = backend.Backend(0, p)
+    got = _insert_sequence(be, 24, 12.0, 0.2, **kw)
     be.close()
     assert [g[2] for g in got] == [r[2] for r in ref]
     for k, (g, r) in enumerate(zip(got, ref)):
