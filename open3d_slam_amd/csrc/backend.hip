@@ -1643,15 +1643,25 @@ int o3ds_cloud_upload_f32(o3ds_handle h, const void* data, size_t n, size_t poin
     // scan crosses PCIe while the frame before it is still being registered and merged on the handle's stream, whose first use of the
     // cloud waits for an event (cloud_ready), not the host.  The points live in an ingest buffer (free_points).
     const size_t psz = p4_size(h->precision), bytes = n * point_step;
-    int bi = -1;
-    for (size_t k = 0; k < h->ingest_bufs.size(); ++k)
-      if (!h->ingest_bufs[k].in_use && h->ingest_bufs[k].pts_bytes >= psz * n && (bi < 0 || h->ingest_bufs[k].pts_bytes < h->ingest_bufs[(size_t)bi].pts_bytes)) bi = (int)k;
+    // a buffer nothing on the handle's stream still reads (its "freed" event has passed): the ingest must not queue behind the frame
+    // that used the buffer last -- that frame is exactly what it is meant to overlap with.  Up to four buffers before one is waited for.
+    int bi = -1, idle = -1;
+    for (size_t k = 0; k < h->ingest_bufs.size(); ++k) {
+      o3ds_context::IngestBuf& cand = h->ingest_bufs[k];
+      if (cand.in_use) continue;
+      if (idle < 0) idle = (int)k;
+      if (cand.pts_bytes >= psz * n && (!cand.freed || hipEventQuery(cand.freed) == hipSuccess)) {
+        bi = (int)k;
+        break;
+      }
+    }
+    (void)hipGetLastError();  // (hipErrorNotReady of a pending event is not an error)
     if (bi < 0) {
-      for (size_t k = 0; k < h->ingest_bufs.size() && bi < 0; ++k)
-        if (!h->ingest_bufs[k].in_use) bi = (int)k;  // an idle buffer that is too small: grown below
-      if (bi < 0) {
+      if (h->ingest_bufs.size() < 4 || idle < 0) {
         h->ingest_bufs.emplace_back();
         bi = (int)h->ingest_bufs.size() - 1;
+      } else {
+        bi = idle;  // too small (grown below) or still being read (waited for on the copy stream)
       }
     }
     o3ds_context::IngestBuf& b = h->ingest_bufs[(size_t)bi];
@@ -2561,8 +2571,7 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
     TMP_ALLOC(order, sizeof(int) * n);
     TMP_ALLOC(starts, sizeof(uint32_t) * n);
     if (in.col) TMP_ALLOC(piece, sizeof(int2) * n);
-    VoxTable t{(unsigned long long*)tab, (unsigned int*)(tab + 8 * cap), (int*)(tab + 12 * cap), (unsigned int*)(tab + 16 * cap),
-               (unsigned int*)(tab + kVoxSlotBytes * cap), (unsigned int)(cap - 1)};
+    VoxTable t{(VoxSlot*)tab, (unsigned int*)(tab + kVoxSlotBytes * cap), (unsigned int)(cap - 1)};
     static const bool always_clear = ab_getenv("O3DS_ALWAYS_CLEAR") != nullptr;
     if (!h->voxtab_clean || always_clear) HIP_TRY(hipMemsetAsync(tab, 0xff, kVoxSlotBytes * cap + 16, h->stream));
     h->voxtab_clean = false;
@@ -3445,13 +3454,14 @@ int pm_enter_t(o3ds_handle h, CloudRec& c, double voxel, double max_corr_hint, s
   PM_ALLOC(d.okey, sizeof(unsigned long long) * cap);
   PM_ALLOC(d.hnext, sizeof(int) * cap);
   PM_ALLOC(d.pos, sizeof(int) * cap);
-  PM_ALLOC(d.rnext, sizeof(int) * cap);
   PM_ALLOC(d.flags, cap);
   size_t hcap = 1024;
   while (hcap < 2 * cap) hcap <<= 1;
   PM_ALLOC(d.hkey, sizeof(unsigned long long) * hcap);
   PM_ALLOC(d.hhead, sizeof(int) * hcap);
   PM_ALLOC(d.hflag, sizeof(unsigned int) * hcap);
+  PM_ALLOC(d.hmark, sizeof(int) * hcap);
+  HIP_TRY(hipMemsetAsync(d.hmark, 0, sizeof(int) * hcap, h->stream));
   d.hmask = (unsigned int)(hcap - 1);
   HIP_TRY(hipMemsetAsync(d.hkey, 0xff, sizeof(unsigned long long) * hcap, h->stream));
   HIP_TRY(hipMemsetAsync(d.hhead, 0xff, sizeof(int) * hcap, h->stream));
@@ -3466,6 +3476,7 @@ int pm_enter_t(o3ds_handle h, CloudRec& c, double voxel, double max_corr_hint, s
   PM_ALLOC(d.outside_pts, sizeof(int) * cap);
   PM_ALLOC(d.relink, sizeof(int) * cap);
   PM_ALLOC(d.touched_rows, sizeof(int) * cap);
+  PM_ALLOC(d.new_slots, sizeof(int) * cap);
   PM_ALLOC(pm->d_hist, sizeof(CropDev) * (kPmHistory + 1));
   d.hist = pm->d_hist;
   d.n_base = (int)n;
@@ -3522,7 +3533,9 @@ int pm_enter_t(o3ds_handle h, CloudRec& c, double voxel, double max_corr_hint, s
   HIP_TRY(dev_alloc(h, &c.spts, sizeof(P4) * pool));
   if (c.nrm) HIP_TRY(dev_alloc(h, &c.snrm, sizeof(P4) * pool));
   PM_ALLOC(d.row_cap, sizeof(int) * pm->rows);
-  PM_ALLOC(d.row_head, sizeof(int) * pm->rows);
+  PM_ALLOC(d.row_flag, sizeof(int) * pm->rows);
+  PM_ALLOC(d.cell_add, sizeof(int) * (table + 1));
+  HIP_TRY(hipMemsetAsync(d.cell_add, 0, sizeof(int) * (table + 1), h->stream));
   g.cell_start = cs;
   d.grid = g;
   d.cs = cs;
@@ -3552,7 +3565,7 @@ int pm_enter_t(o3ds_handle h, CloudRec& c, double voxel, double max_corr_hint, s
   span_mark(h, kSpanIndexBuild);
   pm_enter_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(d, ni);
   pm_cell_count_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(d, ni, h->d_cells, cell_id);
-  pm_row_slack_kernel<<<grid_for(pm->rows * 64), kBlock, 0, h->stream>>>(h->d_cells, (int)pm->rows, g.nx, d.row_cap, d.row_head);
+  pm_row_slack_kernel<<<grid_for(pm->rows * 64), kBlock, 0, h->stream>>>(h->d_cells, (int)pm->rows, g.nx, d.row_cap, d.row_flag);
   int rc = exclusive_scan_int(h, h->d_cells, cs, table + 1);
   if (rc) return rc;
   pm_row_finish_kernel<<<grid_for(pm->rows), kBlock, 0, h->stream>>>(h->d_cells, cs, (int)pm->rows, g.nx, d.counters + kPmPoolTop);
@@ -3586,6 +3599,10 @@ int pm_poll(o3ds_handle h, PMapRec* pm, bool block) {
   std::atomic_thread_fence(std::memory_order_acquire);
   const size_t slots = (size_t)r->cnt, dead = (size_t)r->box[1];
   if ((int)r->box[2] != 0) return fail(h, O3DS_ERR_CAPACITY, "persistent map: an internal capacity was exceeded (error " + std::to_string((int)r->box[2]) + ")");
+  static const bool stats = ab_getenv("O3DS_PM_STATS") != nullptr;  // development aid: what the insertions left behind
+  if (stats)
+    fprintf(stderr, "[pm] t %d slots %zu dead %zu pool top %.0f of %d; multi %.0f unsettled %.0f entered the index %.0f\n", pm->t, slots, dead, r->box[0],
+            pm->dev.pool_cap, r->box[3], r->box[4], r->box[5]);
   pm->n_upper = slots;
   pm->live_lower = slots - dead;
   pm->pool_top = r->box[0];
@@ -3617,8 +3634,7 @@ int pm_insert_t(o3ds_handle h, CloudRec& c, const CloudRec& scan, const double T
   }
   tcap = h->voxtab_cap;
   unsigned char* tab = h->d_voxtab;
-  VoxTable t{(unsigned long long*)tab, (unsigned int*)(tab + 8 * tcap), (int*)(tab + 12 * tcap), (unsigned int*)(tab + 16 * tcap),
-             (unsigned int*)(tab + kVoxSlotBytes * tcap), (unsigned int)(tcap - 1)};
+  VoxTable t{(VoxSlot*)tab, (unsigned int*)(tab + kVoxSlotBytes * tcap), (unsigned int)(tcap - 1)};
   if (!h->voxtab_clean) HIP_TRY(hipMemsetAsync(tab, 0xff, kVoxSlotBytes * tcap + 16, h->stream));
   h->voxtab_clean = false;
   const size_t n_tiles = (ms + kVoxTile - 1) / kVoxTile;
@@ -3662,10 +3678,11 @@ int pm_insert_t(o3ds_handle h, CloudRec& c, const CloudRec& scan, const double T
   h->ticket_base += (unsigned int)n_tiles;
   pm_group_kernel<P4><<<grid_for(ms), kBlock, 0, h->stream>>>(d, groups, order, run_next, run_len, starts, piece, placed, placed_nrm, t, crop, t_now, group_key);
   h->voxtab_clean = true;
-  pm_merge_kernel<P4><<<16, 64, 0, h->stream>>>(d, piece, starts, run_len, placed, placed_nrm, group_key, crop, t_now);
+  pm_merge_kernel<P4><<<128, 64, 0, h->stream>>>(d, piece, starts, run_len, placed, placed_nrm, group_key, crop, t_now);
   pm_misc_kernel<P4><<<256, kBlock, 0, h->stream>>>(d, placed, placed_nrm, crop, t_now);
   const unsigned int row_blocks = (unsigned int)std::min<size_t>(std::max<size_t>(ms / 8, 64), 2048);
-  pm_rows_kernel<P4><<<row_blocks, 64, sizeof(int) * 3 * (size_t)(d.grid.nx + 1), h->stream>>>(d);
+  pm_rows_kernel<P4><<<row_blocks, kBlock, sizeof(int) * 3 * (size_t)(d.grid.nx + 1), h->stream>>>(d);
+  pm_place_new_kernel<P4><<<grid_for(ms), kBlock, 0, h->stream>>>(d);
   pm->rec_seq = ++h->rec_seq;
   o3ds_context::PinRec* rec = h->h_rec_dev + pm->rec_slot;
   const CountPub pub{cnt_word(h, pm->rec_slot), &rec->cnt, pm->rec_seq};

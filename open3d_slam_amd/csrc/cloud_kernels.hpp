@@ -601,15 +601,19 @@ constexpr unsigned long long kEmptyKey = ~0ull;
 // Rounds 1-4 ran bbox, bbox-final, insert, two scan kernels, a wait for the size, number, gather, mean: 46 MB of counter traffic for a
 // 4.4 MB job; the box now comes with the ingest (pack_strided_f32_box_kernel), the scan is one kernel, the member lists
 // are run lists built by the insert itself.
+struct alignas(32) VoxSlot {  // one record per slot: the four words an insertion touches share a cache line (as four arrays they were four
+  unsigned long long key;     // lines per run: most of the 46 MB this step moved for a 4.4 MB job in round 4)
+  unsigned int first;         // smallest point index of the voxel
+  int head;                   // last run pushed (index of its first point); -1 = none
+  unsigned int nrun;          // (number of runs) - 1
+  unsigned int pad[3];
+};
 struct VoxTable {
-  unsigned long long* key;  // [cap]
-  unsigned int* first;      // [cap] smallest point index of the voxel
-  int* head;                // [cap] last run pushed (index of its first point); -1 = none
-  unsigned int* nrun;       // [cap] (number of runs) - 1
-  unsigned int* cursor;     // one word behind the table: next free entry of vox_mean_kernel's run-start scratch
+  VoxSlot* s;            // [cap], all 0xff when not in use
+  unsigned int* cursor;  // one word behind the table: next free entry of vox_mean_kernel's run-start scratch
   unsigned int mask;
 };
-constexpr size_t kVoxSlotBytes = 20;  // 8 + 4 + 4 + 4 per slot
+constexpr size_t kVoxSlotBytes = sizeof(VoxSlot);
 
 // scan_local_kernel (icp_kernels.hpp) with its input computed on the fly
 template <typename T, typename Load>
@@ -778,13 +782,13 @@ __global__ __launch_bounds__(kBlock) void vox_insert_kernel(const P4* __restrict
       const int len = above ? (int)__builtin_ctzll(above) + 1 : 64 - lane;
       unsigned int sl = (unsigned int)((k * 0x9E3779B97F4A7C15ull) >> 32) & t.mask;
       while (true) {
-        const unsigned long long prev = atomicCAS(&t.key[sl], kEmptyKey, k);
+        const unsigned long long prev = atomicCAS(&t.s[sl].key, kEmptyKey, k);
         if (prev == kEmptyKey || prev == k) break;
         sl = (sl + 1) & t.mask;
       }
-      atomicMin(&t.first[sl], (unsigned int)i);
-      atomicAdd(&t.nrun[sl], 1u);
-      run_next[i] = atomicExch(&t.head[sl], (int)i);
+      atomicMin(&t.s[sl].first, (unsigned int)i);
+      atomicAdd(&t.s[sl].nrun, 1u);
+      run_next[i] = atomicExch(&t.s[sl].head, (int)i);
       run_len[i] = len;
       slot = (int)sl;
     }
@@ -820,7 +824,7 @@ __global__ __launch_bounds__(kBlock) void vox_order_kernel(const int* __restrict
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k)
-    if (sl[k] >= 0) f[k] = t.first[sl[k]] == (unsigned int)(base + k) ? 1 : 0;
+    if (sl[k] >= 0) f[k] = t.s[sl[k]].first == (unsigned int)(base + k) ? 1 : 0;
   const int tsum = f[0] + f[1] + f[2] + f[3];
   int x = tsum;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -837,24 +841,36 @@ __global__ __launch_bounds__(kBlock) void vox_order_kernel(const int* __restrict
     if (k < w) woff += s_wave[k];
     total += s_wave[k];
   }
-  if (threadIdx.x == 0) {
+  if (w == 0) {  // the look-back: wavefront 0, 64 predecessors per round (a walk by one thread is as many dependent loads as there are tiles)
+    if (lane == 0 && tile > 0) __hip_atomic_store(&tiles[tile], tile_record(gen, 1u, (unsigned int)total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     int prefix = 0;
-    if (tile > 0) {
-      __hip_atomic_store(&tiles[tile], tile_record(gen, 1u, (unsigned int)total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      for (int b = (int)tile - 1; b >= 0;) {
-        const unsigned long long r = __hip_atomic_load(&tiles[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-        if ((unsigned int)(r >> 34) != (gen & 0x3fffffffu)) {
-          __builtin_amdgcn_s_sleep(1);
-          continue;  // not published yet
-        }
-        prefix += (int)(unsigned int)r;
-        if (((r >> 32) & 3u) == 2u) break;
-        --b;
+    for (int hi = (int)tile - 1; hi >= 0;) {
+      const int b = hi - lane;
+      unsigned long long r = 0;
+      bool there = true;
+      if (b >= 0) {
+        r = __hip_atomic_load(&tiles[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        there = (unsigned int)(r >> 34) == (gen & 0x3fffffffu);
       }
+      if (__ballot(!there) != 0ull) {  // a predecessor in the window has not published yet
+        __builtin_amdgcn_s_sleep(1);
+        continue;
+      }
+      // the nearest inclusive record in the window ends the walk: only the lanes in front of it (smaller lane = nearer tile) and itself count
+      const unsigned long long incl = __ballot(b >= 0 && ((r >> 32) & 3u) == 2u);
+      const int stop = incl ? (int)__builtin_ctzll(incl) : 64;
+      int v = (b >= 0 && lane <= stop) ? (int)(unsigned int)r : 0;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+      prefix += v;
+      if (incl) break;
+      hi -= 64;
     }
-    __hip_atomic_store(&tiles[tile], tile_record(gen, 2u, (unsigned int)(prefix + total)), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    s_prefix = prefix;
-    if (tile == n_tiles - 1) publish_count(pub, prefix + total);  // the number of voxels = the size of the cloud being made
+    if (lane == 0) {
+      __hip_atomic_store(&tiles[tile], tile_record(gen, 2u, (unsigned int)(prefix + total)), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      s_prefix = prefix;
+      if (tile == n_tiles - 1) publish_count(pub, prefix + total);  // the number of voxels = the size of the cloud being made
+    }
   }
   __syncthreads();
   int r = s_prefix + woff + x - tsum;
@@ -923,13 +939,13 @@ __global__ __launch_bounds__(kBlock) void vox_mean_kernel(const P4* __restrict__
       int s = 0, node = -1;
       if (have) {
         s = order[r];
-        k = (int)t.nrun[s] + 1;
-        node = t.head[s];
+        k = (int)t.s[s].nrun + 1;
+        node = t.s[s].head;
         // the table is done with this voxel: leave the slot as the 0xff fill left it, for the next call
-        t.key[s] = kEmptyKey;
-        t.first[s] = ~0u;
-        t.head[s] = -1;
-        t.nrun[s] = ~0u;
+        t.s[s].key = kEmptyKey;
+        t.s[s].first = ~0u;
+        t.s[s].head = -1;
+        t.s[s].nrun = ~0u;
       }
       int incl = k;
 #pragma unroll

@@ -38,7 +38,7 @@ namespace o3ds {
 
 constexpr int kPmHistory = 256;                 // insertions between two folds at most (the list of their volumes)
 constexpr unsigned long long kPmRaw = 1ull << 63;  // okey flag: a scan point that was inserted OUTSIDE the volume (low bits: its scan index)
-constexpr unsigned char kPmDead = 1, kPmUnsettled = 2;
+constexpr unsigned char kPmDead = 1, kPmUnsettled = 2, kPmFresh = 4;  // (fresh: created by the running insertion, not in the index yet)
 constexpr int kPmMaxOld = 8;  // old members of one voxel the special-case path sorts in LDS (more: pm_merge_many)
 
 // everything a kernel needs of a persistent map (device pointers; a copy travels by value in the kernel arguments)
@@ -49,13 +49,13 @@ struct PmDev {
   unsigned long long* okey;  // [cap] voxel key the slot was written under (kPmRaw | scan index for a point inserted outside the volume)
   int* hnext;                // [cap] next slot of the same voxel chain, -1 = end
   int* pos;                  // [cap] position in the paged index
-  int* rnext;                // [cap] next NEW slot of the same index row (lists built by an insertion, consumed by pm_rows_kernel)
   unsigned char* flags;      // [cap]
   size_t cap;
   // voxel hash (open addressing, never deleted from: a chain may be empty)
   unsigned long long* hkey;
   int* hhead;
   unsigned int* hflag;  // bit 0: on the multi list
+  int* hmark;           // the insertion whose pm_group_kernel found several old members of the voxel inside the volume (pm_merge_kernel: "dealt with")
   unsigned int hmask;
   // lists and counters (device)
   int* counters;        // see PmCounter
@@ -75,8 +75,11 @@ struct PmDev {
   void* spts;           // P4[pool]
   void* snrm;           // P4[pool] or null
   int* row_cap;         // [rows] capacity of the row's region
-  int* row_head;        // [rows] head of the list of new slots of the row (-1), built per insertion
+  int* row_flag;        // [rows] 1: on the list of touched rows (cleared by pm_rows_kernel)
+  int* cell_add;        // [like cs] slots that enter the cell this insertion: counted up by pm_row_push, read by pm_rows_kernel, counted back
+                        // down to zero by pm_place_new_kernel (the cursors of the placement)
   int* touched_rows;    // rows with new slots this insertion
+  int* new_slots;       // the slots that enter the index this insertion
   int pool_cap;         // positions the cell-sorted arrays have
   int kc;               // cell edge in voxels
   long long gx0, gy0, gz0;  // voxel coordinates of the grid's min corner
@@ -92,6 +95,7 @@ enum PmCounter {
   kPmOutside,
   kPmRelink,
   kPmTouched,
+  kPmNew,          // entries of new_slots
   kPmPoolTop,      // first free position of the index pool
   kPmError,        // sticky: 1 a list overflowed, 2 the slot arrays, 4 the index pool (the host sizes all three so that none can happen)
   kPmCounters = 16
@@ -173,15 +177,28 @@ __device__ __forceinline__ bool pm_same_bits(const P4& a, const P4& b) {
          __double_as_longlong((double)a.z) == __double_as_longlong((double)b.z);
 }
 
+// One ticket per ACTIVE lane from a shared counter with ONE atomic per wavefront: a device-scope atomic that returns its value costs ~25 ns
+// when many wavefronts aim at the same address, and an insertion draws ~15 k tickets from three counters (new slots,
+// slots entering the index, unsettled normals).  The lanes that reach the call together -- whatever branch they are in: __ballot(1) is the
+// execution mask -- are served by their lowest lane.
+__device__ __forceinline__ int pm_ticket(int* counter) {
+  const unsigned long long act = __ballot(1);
+  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int leader = (int)__builtin_ctzll(act);
+  int base = 0;
+  if (lane == leader) base = atomicAdd(counter, (int)__popcll(act));
+  base = __shfl(base, leader, 64);
+  return base + (int)__popcll(act & ((1ull << lane) - 1ull));
+}
 __device__ __forceinline__ void pm_push(int* list, int* counter, int cap, int v, int* err) {
-  const int k = atomicAdd(counter, 1);
+  const int k = pm_ticket(counter);
   if (k < cap)
     list[k] = v;
   else
     atomicOr(err, 1);
 }
 __device__ __forceinline__ void pm_push64(unsigned long long* list, int* counter, int cap, unsigned long long v, int* err) {
-  const int k = atomicAdd(counter, 1);
+  const int k = pm_ticket(counter);
   if (k < cap)
     list[k] = v;
   else
@@ -239,7 +256,6 @@ __global__ __launch_bounds__(kBlock) void pm_enter_kernel(PmDev m, int n) {
     const unsigned long long k = pm_key(p, m.inv_voxel);
     m.stamp[s] = 0;
     m.okey[s] = k;
-    m.rnext[s] = -2;  // (in the index; >= -1: on the list of new slots of its row)
     unsigned char fl = 0;
     if (m.nrm) {
       const P4 nv = ((const P4*)m.nrm)[s];
@@ -274,7 +290,7 @@ __global__ __launch_bounds__(kBlock) void pm_cell_count_kernel(PmDev m, int n, i
     atomicAdd(&counts[c], 1);
   }
 }
-__global__ __launch_bounds__(kBlock) void pm_row_slack_kernel(int* __restrict__ counts, int rows, int nx, int* __restrict__ row_cap, int* __restrict__ row_head) {
+__global__ __launch_bounds__(kBlock) void pm_row_slack_kernel(int* __restrict__ counts, int rows, int nx, int* __restrict__ row_cap, int* __restrict__ row_flag) {
   const int lane = threadIdx.x & 63;
   for (int r = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); r < rows; r += gridDim.x * (kBlock / 64)) {  // one wavefront per row
     int c = 0;
@@ -285,7 +301,7 @@ __global__ __launch_bounds__(kBlock) void pm_row_slack_kernel(int* __restrict__ 
       const int slack = c > 0 ? max(8, c / 2) : 0;  // a row that has points gets room for half as many again; an empty one moves to the pool's end with its first point
       counts[(size_t)r * (nx + 1) + nx] = slack;
       row_cap[r] = c + slack;
-      row_head[r] = -1;
+      row_flag[r] = 0;
     }
   }
 }
@@ -358,13 +374,13 @@ __global__ __launch_bounds__(kBlock) void pm_place_kernel(const P4* __restrict__
       const int len = above ? (int)__builtin_ctzll(above) + 1 : 64 - lane;
       unsigned int sl = pm_hash(k) & t.mask;
       while (true) {
-        const unsigned long long prev = atomicCAS(&t.key[sl], kEmptyKey, k);
+        const unsigned long long prev = atomicCAS(&t.s[sl].key, kEmptyKey, k);
         if (prev == kEmptyKey || prev == k) break;
         sl = (sl + 1) & t.mask;
       }
-      atomicMin(&t.first[sl], (unsigned int)i);
-      atomicAdd(&t.nrun[sl], 1u);
-      run_next[i] = atomicExch(&t.head[sl], (int)i);
+      atomicMin(&t.s[sl].first, (unsigned int)i);
+      atomicAdd(&t.s[sl].nrun, 1u);
+      run_next[i] = atomicExch(&t.s[sl].head, (int)i);
       run_len[i] = len;
       slot = (int)sl;
     }
@@ -374,20 +390,20 @@ __global__ __launch_bounds__(kBlock) void pm_place_kernel(const P4* __restrict__
 
 // a new slot for a point; -1 (and the error flag) when the arrays are full
 __device__ __forceinline__ int pm_new_slot(const PmDev& m) {
-  const int s = atomicAdd(m.counters + kPmN, 1);
+  const int s = pm_ticket(m.counters + kPmN);
   if ((size_t)s >= m.cap) {
     atomicOr(m.counters + kPmError, 2);
     return -1;
   }
   return s;
 }
-// a new slot enters the list of its index row (pm_rows_kernel merges the lists into the rows)
+// a slot enters the index: counted into its cell, its row marked, the slot listed (pm_rows_kernel makes the room, pm_place_new_kernel fills it)
 __device__ __forceinline__ void pm_row_push(const PmDev& m, int s, unsigned long long key) {
   int row, x;
   pm_cell(m, key, &row, &x);
-  const int old = atomicExch(&m.row_head[row], s);
-  m.rnext[s] = old;
-  if (old == -1) pm_push(m.touched_rows, m.counters + kPmTouched, m.list_cap, row, m.counters + kPmError);
+  atomicAdd(&m.cell_add[(size_t)row * (m.grid.nx + 1) + x], 1);
+  if (atomicExch(&m.row_flag[row], 1) == 0) pm_push(m.touched_rows, m.counters + kPmTouched, m.list_cap, row, m.counters + kPmError);
+  pm_push(m.new_slots, m.counters + kPmNew, m.list_cap, s, m.counters + kPmError);
 }
 // the mean of a voxel's members written where it belongs: point, normal, history, search index (in place: the mean of points of one voxel
 // lies in that voxel, hence in the same index cell), settled or not; `fresh`: the slot is new (its index entry comes with its row)
@@ -399,7 +415,7 @@ __device__ __forceinline__ void pm_store(const PmDev& m, int s, const P4& op, co
   if (has_nrm) ((P4*)m.nrm)[s] = on;
   m.stamp[s] = t;
   m.okey[s] = key;
-  unsigned char fl = 0;
+  unsigned char fl = fresh ? kPmFresh : 0;
   if (has_nrm && !pm_same_bits(pm_renormalized(on), on)) {
     fl |= kPmUnsettled;
     pm_push(m.unsettled[1], m.counters + kPmUnsettledOut, m.list_cap, s, m.counters + kPmError);
@@ -483,13 +499,13 @@ __global__ __launch_bounds__(kBlock) void pm_group_kernel(PmDev m, CountRef g_in
     unsigned long long key = 0;
     if (have) {
       const int s = order[r];
-      k = (int)t.nrun[s] + 1;
-      node = t.head[s];
-      key = t.key[s];
-      t.key[s] = kEmptyKey;  // the scratch table is handed back empty (all 0xff), as vox_mean_kernel does
-      t.first[s] = ~0u;
-      t.head[s] = -1;
-      t.nrun[s] = ~0u;
+      k = (int)t.s[s].nrun + 1;
+      node = t.s[s].head;
+      key = t.s[s].key;
+      t.s[s].key = kEmptyKey;  // the scratch table is handed back empty (all 0xff), as vox_mean_kernel does
+      t.s[s].first = ~0u;
+      t.s[s].head = -1;
+      t.s[s].nrun = ~0u;
     }
     int incl = k;
 #pragma unroll
@@ -502,6 +518,10 @@ __global__ __launch_bounds__(kBlock) void pm_group_kernel(PmDev m, CountRef g_in
     if (lane == 0 && wave_total > 0) wbase = atomicAdd(t.cursor, (unsigned int)wave_total);
     wbase = __shfl(wbase, 0, 64);
     const int b = (int)wbase + incl - k;
+    // (the first probe of the voxel hash goes out now, beside the walk over the runs: two chains of dependent loads, side by side)
+    const unsigned int e0 = pm_hash(key) & m.hmask;
+    const unsigned long long hk0 = have ? m.hkey[e0] : kEmptyKey;
+    const int hh0 = have ? m.hhead[e0] : -1;
     for (int j = 0; j < k; ++j) {
       starts[b + j] = (uint32_t)node;
       node = run_next[node];
@@ -510,28 +530,37 @@ __global__ __launch_bounds__(kBlock) void pm_group_kernel(PmDev m, CountRef g_in
     if (!have) continue;
     piece[r] = make_int2(b, k);
     group_key[r] = key;
-    // old members of the voxel that lie inside the volume (they are in the voxel hash under the same key)
+    // old members of the voxel that lie inside the volume (they are in the voxel hash under the same key).  The first member's point and
+    // normal are what nearly every voxel needs: fetched in the walk, kept.
     int old_slot = -1, n_old_in = 0, n_live = 0;
-    const unsigned int e = pm_entry(m, key);
-    for (int s = m.hhead[e]; s != -1; s = m.hnext[s]) {
+    unsigned int e = e0;
+    int head = hh0;
+    if (hk0 != key) {  // not at its home entry: probe on (plain loads; the compare-and-swap only for a voxel the map has never seen)
+      e = pm_find(m, key);
+      if (e == ~0u) e = pm_entry(m, key);
+      head = m.hhead[e];
+    }
+    P4 old_p{}, old_n{};
+    for (int s = head; s != -1;) {
       ++n_live;
       const P4 p = ((const P4*)m.pts)[s];
+      const P4 q = has_nrm ? ((const P4*)m.nrm)[s] : p;
+      const int nxt = m.hnext[s];
       if (crop_contains(crop, (double)p.x, (double)p.y, (double)p.z)) {
         ++n_old_in;
         old_slot = s;
+        old_p = p;
+        old_n = q;
       }
+      s = nxt;
     }
     if (n_old_in > 1) {
+      m.hmark[e] = t_now;
       pm_push(m.complex_groups, m.counters + kPmComplex, m.list_cap, (int)r, m.counters + kPmError);
       continue;
     }
     PmAcc acc;
-    if (n_old_in == 1) {
-      const P4 p = ((const P4*)m.pts)[old_slot];
-      P4 q{};
-      if (has_nrm) q = ((const P4*)m.nrm)[old_slot];
-      acc.add(p, has_nrm, q);
-    }
+    if (n_old_in == 1) acc.add(old_p, has_nrm, old_n);
     for (int j = 0; j < k; ++j) {
       const uint32_t st = starts[b + j];
       const int len = run_len[st];
@@ -712,27 +741,32 @@ __global__ __launch_bounds__(64) void pm_merge_kernel(PmDev m, const int2* __res
     // a voxel on the multi list.  One the scan touched has been dealt with: its group saw the whole chain (a complex group of this very
     // launch belongs to another thread, which may be rewriting the chain right now: told apart by the list of this launch, not by the chain).
     const unsigned long long key = m.multi[0][i - n_complex];
-    const unsigned int e = pm_entry(m, key);
-    bool touched = false;
-    for (int j = 0; j < n_complex && !touched; ++j) touched = group_key[m.complex_groups[j]] == key;
-    if (!touched) {
-      for (int s = m.hhead[e]; s != -1; s = m.hnext[s]) touched |= m.stamp[s] == t_now && !(m.okey[s] & kPmRaw);
-      if (!touched) {
-        const int n_old = pm_gather_old<P4>(m, e, crop, t_now, o);
-        if (n_old > kPmMaxOld)
-          pm_merge_many<P4>(m, e, key, crop, -1, piece, starts, run_len, placed, placed_nrm, t_now);
-        else if (n_old > 1)
-          pm_merge_old<P4>(m, e, key, o, n_old, -1, piece, starts, run_len, placed, placed_nrm, t_now);
-      }
-      int live = 0;
-      for (int s = m.hhead[e]; s != -1; s = m.hnext[s]) ++live;
-      if (live > 1)
-        pm_push64(m.multi[1], m.counters + kPmMultiOut, cap, key, err);
-      else
-        m.hflag[e] &= ~1u;
-    } else {
+    const unsigned int e = pm_find(m, key);
+    if (e == ~0u) continue;
+    bool touched = m.hmark[e] == t_now;  // a voxel pm_group_kernel handed to the other branch of this launch
+    if (touched) {
       pm_push64(m.multi[1], m.counters + kPmMultiOut, cap, key, err);  // (stays listed; settled at the next insertion)
+      continue;
     }
+    int live = 0, inside = 0;  // one walk: members, members inside the volume, written by this insertion?
+    for (int s = m.hhead[e]; s != -1; s = m.hnext[s]) {
+      ++live;
+      touched |= m.stamp[s] == t_now && !(m.okey[s] & kPmRaw);
+      const P4 p = ((const P4*)m.pts)[s];
+      inside += crop_contains(crop, (double)p.x, (double)p.y, (double)p.z) ? 1 : 0;
+    }
+    if (!touched && inside > 1) {
+      const int n_old = pm_gather_old<P4>(m, e, crop, t_now, o);
+      if (n_old > kPmMaxOld)
+        pm_merge_many<P4>(m, e, key, crop, -1, piece, starts, run_len, placed, placed_nrm, t_now);
+      else if (n_old > 1)
+        pm_merge_old<P4>(m, e, key, o, n_old, -1, piece, starts, run_len, placed, placed_nrm, t_now);
+      live -= inside - 1;
+    }
+    if (live > 1)
+      pm_push64(m.multi[1], m.counters + kPmMultiOut, cap, key, err);
+    else
+      m.hflag[e] &= ~1u;
   }
 }
 
@@ -781,7 +815,7 @@ __global__ __launch_bounds__(kBlock) void pm_misc_kernel(PmDev m, const P4* __re
     }
     m.stamp[s] = t_now;
     m.okey[s] = kPmRaw | (unsigned long long)si;
-    unsigned char fl = 0;
+    unsigned char fl = kPmFresh;
     if (has_nrm && !pm_same_bits(pm_renormalized(on), on)) {
       fl |= kPmUnsettled;
       pm_push(m.unsettled[1], m.counters + kPmUnsettledOut, cap, s, err);
@@ -812,7 +846,7 @@ __global__ __launch_bounds__(kBlock) void pm_misc_kernel(PmDev m, const P4* __re
       m.hflag[e] |= 1u;
       pm_push64(m.multi[1], m.counters + kPmMultiOut, cap, k_new, err);
     }
-    if (m.rnext[s] == -2) {  // in the index, in the cell of its old voxel (a new slot is on the list of the row it really is in)
+    if (!(m.flags[s] & kPmFresh)) {  // in the index, in the cell of its old voxel (a new slot is listed under the cell it really is in)
       using R = typename Scalar<P4>::type;
       P4 far;
       far.x = far.y = far.z = sizeof(R) == 4 ? (R)3.0e38f : (R)1.0e300;
@@ -823,87 +857,97 @@ __global__ __launch_bounds__(kBlock) void pm_misc_kernel(PmDev m, const P4* __re
   }
 }
 
-// (5) the rows of the index that received new slots: ONE wavefront per row.  The row's cells keep their order; every cell grows by the new
-// slots that fall into it, so its old points move up by the number of new points in the cells before it -- inside the row's region if that
-// has the room, into a fresh region at the end of the pool (twice the need) otherwise.  The old points are moved from the back in chunks of
-// a wavefront (read, then written: a point only ever moves up), the new ones go behind their cell's old ones.
+// (5) the rows of the index that receive slots: one workgroup per row makes the room.  The row's cells keep their order; every cell grows by
+// the slots counted into it (cell_add), so its old points move up by the number of new ones in the cells before it -- inside the row's
+// region if that has the room, into a fresh region at the end of the pool (twice the need) otherwise.  The old points are moved from the
+// back in chunks of a wavefront (all of a chunk is read before any of it is written, and a point only ever moves up).  The new slots
+// themselves are written by pm_place_new_kernel, one thread each, into the gaps this leaves at the end of every cell.
 template <typename P4>
-__global__ __launch_bounds__(64) void pm_rows_kernel(PmDev m) {
-  extern __shared__ int s_cells[];  // [3][nx + 1]: old starts, added counts -> new starts, cursors
-  const int nx = m.grid.nx, lane = threadIdx.x;
+__global__ __launch_bounds__(kBlock) void pm_rows_kernel(PmDev m) {
+  extern __shared__ int s_cells[];  // [3][nx + 1]: old starts, slots added per cell, new starts
+  __shared__ int s_wave[kBlock / 64];
+  __shared__ int s_base, s_first;
+  const int nx = m.grid.nx, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   int* s_old = s_cells;
   int* s_add = s_cells + (nx + 1);
   int* s_new = s_cells + 2 * (nx + 1);
   const int n_rows = min(m.counters[kPmTouched], m.list_cap);
-  for (int ri = blockIdx.x; ri < n_rows; ri += gridDim.x) {
+  const bool has_nrm = m.snrm != nullptr;
+  for (int ri = blockIdx.x; ri < n_rows; ri += gridDim.x) {  // one workgroup per row (a floor row of a lidar map holds thousands of points)
     const int row = m.touched_rows[ri];
     int* cs = m.cs + (size_t)row * (nx + 1);
-    for (int x = lane; x <= nx; x += 64) {
+    int* add = m.cell_add + (size_t)row * (nx + 1);
+    int n_new = 0, first = nx;
+    for (int x = tid; x <= nx; x += kBlock) {
       s_old[x] = cs[x];
-      s_add[x] = 0;
+      const int a = x < nx ? add[x] : 0;
+      s_add[x] = a;
+      n_new += a;
+      if (a > 0) first = min(first, x);
     }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      n_new += __shfl_xor(n_new, d, 64);
+      first = min(first, __shfl_xor(first, d, 64));
+    }
+    if (lane == 0) s_wave[w] = n_new;
+    if (tid == 0) s_first = nx;
     __syncthreads();
-    // the row's list: counted per cell (lane 0 walks it: a few entries)
-    int n_new = 0;
-    if (lane == 0) {
-      for (int s = m.row_head[row]; s >= 0; s = m.rnext[s]) {
-        const P4 p = ((const P4*)m.pts)[s];
-        int r2, x;
-        pm_cell(m, pm_key(p, m.inv_voxel), &r2, &x);
-        ++s_add[x];
-        ++n_new;
-      }
-    }
-    n_new = __shfl(n_new, 0, 64);
+    if (lane == 0) atomicMin(&s_first, first);
+    n_new = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    static_assert(kBlock / 64 == 4, "four wavefronts per workgroup");
     __syncthreads();
     const int old_start = s_old[0], old_end = s_old[nx], old_cnt = old_end - old_start;
     const int need = old_cnt + n_new;
-    int base = old_start;
-    if (need > m.row_cap[row]) {  // the row moves to the end of the pool
-      int nb = 0;
-      const int cap_new = 2 * need + 8;
-      if (lane == 0) {
-        nb = atomicAdd(m.counters + kPmPoolTop, cap_new);
-        if (nb + cap_new > m.pool_cap) {
+    if (tid == 0) {
+      int base = old_start;
+      if (need > m.row_cap[row]) {  // the row moves to the end of the pool
+        const int cap_new = 2 * need + 8;
+        base = atomicAdd(m.counters + kPmPoolTop, cap_new);
+        if (base + cap_new > m.pool_cap) {
           atomicOr(m.counters + kPmError, 4);
-          nb = -1;
+          base = -1;
+        } else {
+          m.row_cap[row] = cap_new;
         }
       }
-      nb = __shfl(nb, 0, 64);
-      if (nb < 0) {
-        if (lane == 0) m.row_head[row] = -1;
-        __syncthreads();
-        continue;
-      }
-      base = nb;
-      if (lane == 0) m.row_cap[row] = cap_new;
-    }
-    // new starts: exclusive scan over (old count + added) per cell, chunks of 64 cells
-    int run = base;
-    for (int x0 = 0; x0 <= nx; x0 += 64) {
-      const int x = x0 + lane;
-      const int c = x < nx ? (s_old[x + 1] - s_old[x]) + s_add[x] : 0;
-      int incl = c;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const int y = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += y;
-      }
-      if (x <= nx) s_new[x] = run + incl - c;
-      run += __shfl(incl, 63, 64);
+      s_base = base;
     }
     __syncthreads();
-    // old points, from the back
-    const bool has_nrm = m.snrm != nullptr;
-    for (int hi = old_end; hi > old_start; hi -= 64) {
-      const int j = hi - 64 + lane;
+    const int base = s_base;
+    if (base < 0) {  // (never: the host sizes the pool for the worst case) -- the row's slots stay out of the index
+      for (int x = tid; x < nx; x += kBlock) add[x] = 0;
+      if (tid == 0) m.row_flag[row] = 0;
+      __syncthreads();
+      continue;
+    }
+    if (w == 0) {  // new starts: exclusive scan over (old count + added) per cell, 64 cells at a time
+      int run = base;
+      for (int x0 = 0; x0 <= nx; x0 += 64) {
+        const int x = x0 + lane;
+        const int c = x < nx ? (s_old[x + 1] - s_old[x]) + s_add[x] : 0;
+        int incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int y = __shfl_up(incl, d, 64);
+          if (lane >= d) incl += y;
+        }
+        if (x <= nx) s_new[x] = run + incl - c;
+        run += __shfl(incl, 63, 64);
+      }
+    }
+    __syncthreads();
+    // the old points from the back, a workgroup's worth per round; the cells in front of the first one that grows stay where they are
+    // (unless the whole row moved)
+    const int stop = base == old_start ? s_old[min(s_first, nx - 1)] : old_start;
+    for (int hi = old_end; hi > stop; hi -= kBlock) {
+      const int j = hi - kBlock + tid;
       const int jc = max(j, old_start);  // (clamped, not predicated: the loads stay out of the branch)
       const P4 p = ((const P4*)m.spts)[jc];
       const P4 q = ((const P4*)(has_nrm ? m.snrm : m.spts))[jc];
       int dst = -1;
-      if (j >= old_start) {
-        // its cell: the last x with s_old[x] <= j
-        int lo = 0, hh = nx - 1;
+      if (j >= stop) {
+        int lo = 0, hh = nx - 1;  // its cell: the last x with s_old[x] <= j
         while (lo < hh) {
           const int mid = (lo + hh + 1) >> 1;
           if (s_old[mid] <= j)
@@ -913,7 +957,7 @@ __global__ __launch_bounds__(64) void pm_rows_kernel(PmDev m) {
         }
         dst = s_new[lo] + (j - s_old[lo]);
       }
-      // (every lane's store depends on the wavefront's load instruction having returned: all of the chunk is read before any of it is written)
+      __syncthreads();  // all of the round is read before any of it is written (a point only ever moves up: into this round's range or beyond)
       if (dst >= 0 && dst != j) {
         P4 pp, qq;  // (field by field: an aggregate copy through a conditional branch went through scratch memory)
         pp.x = p.x, pp.y = p.y, pp.z = p.z, pp.i = p.i;
@@ -922,30 +966,36 @@ __global__ __launch_bounds__(64) void pm_rows_kernel(PmDev m) {
         if (has_nrm) ((P4*)m.snrm)[dst] = qq;
         if ((int)p.i != 0x7fffffff) m.pos[(int)p.i] = dst;
       }
+      __syncthreads();
     }
+    for (int x = tid; x <= nx; x += kBlock) cs[x] = s_new[x];
+    if (tid == 0) m.row_flag[row] = 0;
     __syncthreads();
-    // new points behind their cell's old ones; cursors in s_add (reused: position of the next new point of the cell)
-    for (int x = lane; x < nx; x += 64) s_add[x] = s_new[x] + (s_old[x + 1] - s_old[x]);
-    __syncthreads();
-    if (lane == 0) {
-      for (int s = m.row_head[row]; s >= 0;) {
-        const int nxt = m.rnext[s];
-        P4 p = ((const P4*)m.pts)[s];
-        int r2, x;
-        pm_cell(m, pm_key(p, m.inv_voxel), &r2, &x);
-        const int dst = s_add[x]++;
-        p.i = (typename Scalar<P4>::index)s;
-        ((P4*)m.spts)[dst] = p;
-        if (has_nrm) ((P4*)m.snrm)[dst] = ((const P4*)m.nrm)[s];
-        m.pos[s] = dst;
-        m.rnext[s] = -2;
-        s = nxt;
-      }
-      m.row_head[row] = -1;
+  }
+}
+// ... and the slots that enter: the k-th arrival of a cell takes the k-th place from the cell's end (the counters run back down to zero: the
+// block of counters needs no clearing).  The order inside a cell is the order the atomics are served in; nothing depends on it.
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void pm_place_new_kernel(PmDev m) {
+  const int n_new = min(m.counters[kPmNew], m.list_cap);
+  const bool has_nrm = m.snrm != nullptr;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_new; i += gridDim.x * kBlock) {
+    const int s = m.new_slots[i];
+    P4 p = ((const P4*)m.pts)[s];
+    int row, x;
+    pm_cell(m, pm_key(p, m.inv_voxel), &row, &x);
+    const size_t c = (size_t)row * (m.grid.nx + 1) + x;
+    const int k = atomicSub(&m.cell_add[c], 1);
+    if (k <= 0) {  // (the row found no room: see pm_rows_kernel)
+      atomicAdd(&m.cell_add[c], 1);
+      continue;
     }
-    __syncthreads();
-    for (int x = lane; x <= nx; x += 64) cs[x] = s_new[x];
-    __syncthreads();
+    const int dst = m.cs[c + 1] - k;
+    p.i = (typename Scalar<P4>::index)s;
+    ((P4*)m.spts)[dst] = p;
+    if (has_nrm) ((P4*)m.snrm)[dst] = ((const P4*)m.nrm)[s];
+    m.pos[s] = dst;
+    m.flags[s] &= (unsigned char)~kPmFresh;
   }
 }
 
@@ -959,12 +1009,15 @@ __global__ __launch_bounds__(64) void pm_turn_kernel(PmDev m, CountPub pub, Crop
     host_vals[0] = (double)c[kPmPoolTop];
     host_vals[1] = (double)c[kPmDeadCnt];
     host_vals[2] = (double)c[kPmError];
+    host_vals[3] = (double)c[kPmMultiOut];      // (diagnostics: sizes of the lists the next insertion walks, slots that entered the index)
+    host_vals[4] = (double)c[kPmUnsettledOut];
+    host_vals[5] = (double)c[kPmNew];
   }
   c[kPmUnsettledIn] = min(c[kPmUnsettledOut], m.list_cap);
   c[kPmUnsettledOut] = 0;
   c[kPmMultiIn] = min(c[kPmMultiOut], m.list_cap);
   c[kPmMultiOut] = 0;
-  c[kPmComplex] = c[kPmOutside] = c[kPmRelink] = c[kPmTouched] = 0;
+  c[kPmComplex] = c[kPmOutside] = c[kPmRelink] = c[kPmTouched] = c[kPmNew] = 0;
   publish_count(pub, c[kPmN]);
 }
 

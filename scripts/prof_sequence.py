@@ -16,19 +16,22 @@ def short(n):
 def main(db_path, out_path, frame=60):
     db = sqlite3.connect(db_path)
     rows = list(db.execute("select name,start,end from kernels order by start"))
-    marks = [k for k, r in enumerate(rows) if "pack_strided_f32_kernel" in r[0]]
+    # a frame = from the first kernel of a scan's pre-processing (vox_insert_kernel: one per scan, the odometry and the mapper share the
+    # pre-processed cloud) to the next one; the ingest of the NEXT scan (copy stream: pack_strided_f32_box_kernel, box_publish_kernel)
+    # runs inside it, beside the frame's own kernels
+    marks = [k for k, r in enumerate(rows) if "vox_insert_kernel" in r[0]]
     a, b = marks[frame], marks[frame + 1]
     t0 = rows[a][1]
-    lines = ["# dispatches of stream frame %d (between two ingests): start_us dur_us gap_us kernel" % frame]
+    lines = ["# dispatches of stream frame %d (from its first pre-processing kernel to the next frame's): start_us dur_us gap_us kernel" % frame]
     prev_end = None
     busy = 0.0
     for name, s, e in rows[a:b]:
-        gap = 0.0 if prev_end is None else (s - prev_end) / 1e3
+        gap = 0.0 if prev_end is None else max(0.0, (s - prev_end) / 1e3)
         lines.append("%9.1f %8.1f %7.1f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, gap, short(name)))
-        prev_end = e
-        busy += (e - s) / 1e3
+        busy += (e - max(s, prev_end or s)) / 1e3 if (prev_end is None or e > prev_end) else 0.0  # (union of the intervals: two streams)
+        prev_end = e if prev_end is None else max(prev_end, e)
     span = (rows[b][1] - t0) / 1e3
-    lines.append("# %d dispatches, %.1f us busy of %.1f us between the two ingests" % (b - a, busy, span))
+    lines.append("# %d dispatches, %.1f us busy of %.1f us between the two frame starts (%.0f %%)" % (b - a, busy, span, 100.0 * busy / span))
     open(out_path, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
