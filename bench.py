@@ -69,7 +69,9 @@ def make_stream(frames):
         return pool.map(_scan_job, range(frames), chunksize=max(1, frames // (4 * procs)))
 
 
-def stream_parameters(max_iter=50):
+def stream_parameters(max_iter=50, shipped=False):
+    """shipped: the registration type and the random down-sampling as the shipped Lua has them
+    (ros/open3d_slam_ros/param/default/parameter_structure_definitions.lua:62,76,109: GeneralizedIcp, downsampling_ratio 0.3)"""
     from open3d_slam_amd import parameters as P
 
     mp = P.lua_default_mapper_parameters()
@@ -78,6 +80,11 @@ def stream_parameters(max_iter=50):
     op.scanMatcher_.icp_ = P.IcpParameters(maxNumIter_=max_iter, maxCorrespondenceDistance_=1.0, knn_=20, maxDistanceKnn_=3.0)
     op.scanProcessing_.voxelSize_ = 0.1
     op.scanProcessing_.cropper_ = P.ScanCroppingParameters(croppingMinRadius_=2.0, croppingMaxRadius_=30.0, cropperName_="MinMaxRadius")
+    if shipped:
+        mp.scanMatcher_.scanToMapRegType_ = P.ScanToMapRegistrationType.GeneralizedIcp
+        op.scanMatcher_.regType_ = P.CloudRegistrationType.GeneralizedIcp
+        mp.scanProcessing_.downSamplingRatio_ = 0.3
+        op.scanProcessing_.downSamplingRatio_ = 0.3
     return mp, op
 
 
@@ -232,12 +239,14 @@ def _wrap_spans(backend):
     B = backend.Backend
     saved, sizes = {}, {"normals": [], "insert": [], "voxel": [], "icp": [], "upload": []}
 
-    def wrap(name, tag, note):
+    def wrap(name, tag, note, spacer=None):
         fn = getattr(B, name)
         saved[name] = fn
 
         def w(self, *a, **k):
             pre = note(self, a, None)
+            if spacer is not None:
+                spacer(self, a)
             with self.span(tag):
                 r = fn(self, *a, **k)
             note(self, a, (pre, r))
@@ -271,7 +280,9 @@ def _wrap_spans(backend):
             sizes["upload"].append(n_of(be, done[1]))
 
     wrap("estimate_normals", TAG_NORMALS, note_normals)
-    wrap("map_insert_scan", TAG_INSERT, note_insert)
+    # (asking for the sizes above drains the stream: without something for the device to do while the call queues its eight launches the span
+    # would be the host's time, not the kernels' -- a normal estimation of the scan being inserted: same scan, same normals, ~100 us of work)
+    wrap("map_insert_scan", TAG_INSERT, note_insert, spacer=lambda be, a: saved["estimate_normals"](be, a[1], 3.0, 20))
     wrap("crop_voxel_down_sample", TAG_VOXEL, note_voxel)
     wrap("icp_point_to_plane_dev", TAG_ICP, note_icp)
     wrap("upload_f32", TAG_UPLOAD, note_upload)
@@ -291,7 +302,7 @@ def stage_scans(be, scans32, pinned=True):
     return out
 
 
-def run_stream(be, scans32, profile=False, stage_sync=True, pinned=True, prefetch=True):
+def run_stream(be, scans32, profile=False, stage_sync=True, pinned=True, prefetch=True, shipped=False):
     """frames through the reference-named host classes; returns rates, per-stage wall times and (profile) the per-call table.
     pinned / prefetch: the scans wait in page-locked buffers and scan k + 1 is handed to the backend (o3ds_cloud_upload_f32: asynchronous, on
     the handle's copy stream) while frame k is being processed -- what the ROS callback thread does in open3d_slam; without
@@ -303,11 +314,14 @@ def run_stream(be, scans32, profile=False, stage_sync=True, pinned=True, prefetc
     from open3d_slam_amd.odometry import LidarOdometry
     from open3d_slam_amd.pointcloud import PointCloud
 
-    mp, op = stream_parameters()
+    mp, op = stream_parameters(shipped=shipped)
     odo = LidarOdometry(be)
     odo.setParameters(op)
     mapper = Mapper(be, odo)
     mapper.setParameters(mp)
+    if shipped:  # [O3D] RandomDownSample draws from std::random_device: the kept-index lists are pinned by seeds here
+        odo.setDownSampleSeed(1001)
+        mapper.scan2MapReg_.setDownSampleSeed(1002)
     saved, sizes = ({}, None)
     if profile:
         saved, sizes = _wrap_spans(backend)
@@ -456,6 +470,93 @@ def run_stream_pipelined(device, scans32, depth=4):
     return out
 
 
+def run_m1_gicp(device, src, tgt, nrm, steps, warmup, with_oracle=True):
+    """configs[1] under the registration the shipped Lua selects: RegistrationIcpGeneralized (CloudRegistration.cpp:16-39), fixed 10
+    iterations, device clouds, index prebuilt; the source's normals estimated on the device as estimateNormalsOrCovariancesIfNeeded does.
+    Algorithmic bytes per source point and pass: the point-to-plane figure + the source normal (12 B)."""
+    from open3d_slam_amd import backend, synthetic as syn
+
+    be = backend.Backend(device)
+    s_id = be.upload(src)
+    be.estimate_normals(s_id, 3.0, 20)
+    src_n = be.download(s_id)[1]
+    t_id = be.upload(tgt, nrm)
+    be.build_index(t_id, MAX_CORR, 0.0)
+    kw = dict(max_iter=ICP_ITERS, rel_fitness=0.0, rel_rmse=0.0)
+    for _ in range(warmup):
+        res = be.icp_generalized_dev(s_id, t_id, MAX_CORR, **kw)
+    be.synchronize()
+    be.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = be.icp_generalized_dev(s_id, t_id, MAX_CORR, **kw)
+    be.synchronize()
+    elapsed = time.perf_counter() - t0
+    n_launch, kern_ms = be.profile_read()
+    be.profile_enable(False)
+    be.close()
+    bytes_per_launch = N_SRC * (ALGO_BYTES_PER_POINT + 12)
+    avg = kern_ms * 1e-3 / max(n_launch, 1)
+    out = {"value": ICP_ITERS * steps / elapsed, "unit": "icp_iterations/s", "steps": steps, "ms_per_step": elapsed / steps * 1e3, "dtype": "f32 points, f64 accumulate",
+           "workload": "configs[1] under GeneralizedIcp (the shipped scan_to_map_refinement_type): 65536-pt scan with device-estimated normals vs 1,000,000-pt submap",
+           "roofline": {"bound": "hbm", "achieved": bytes_per_launch / avg / 1e9 if avg else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": bytes_per_launch / avg / 1e9 / HBM_PEAK_GBS if avg else None, "traffic": None,
+                        "kernel": "icp_fused_kernel<P4f, ..., kGicp>", "launches": n_launch, "avg_launch_us_event_brackets": avg * 1e6,
+                        "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_bytes_per_point": ALGO_BYTES_PER_POINT + 12},
+           "result": {"fitness": res["fitness"], "inlier_rmse": res["inlier_rmse"], "iterations": res["iterations"]}}
+    if with_oracle:  # the checker beside it, same inputs, same fixed iterations
+        from oracle import pyoracle as po
+
+        ref = po.icp_generalized(src, src_n, tgt, nrm, MAX_CORR, **kw)
+        dt, dr = syn.se3_error(res["transformation"], ref["transformation"])
+        out["parity_vs_oracle"] = {"dt_m": dt, "dr_rad": dr, "fitness_gpu": res["fitness"], "fitness_oracle": ref["fitness"],
+                                   "what": "oracle/o3d_oracle.c orc_icp_generalized on the same clouds and normals (restated from Open3D v0.15.1, unpinned)"}
+    return out
+
+
+def run_insert_sweep(device, scans32, marks=(100_000, 300_000, 1_000_000)):
+    """Submap::insertScan (o3ds_map_insert_scan) as the map grows: the stream's pre-processed scans inserted at their true poses, one after
+    the other, into one map -- the way the mapper fills a submap, without the registrations --, every insertion under a hipEvent span; the
+    rows are the insertions whose map size lies within 20 % of a mark.  (A map seeded with random surface samples is not a submap: its
+    points outside the volume were never merged, tens of thousands of voxels hold several of them, and the insertion walks that list.)"""
+    from open3d_slam_amd import backend, synthetic as syn
+
+    poses = syn.figure_eight_poses(200, 0.1)
+    be = backend.Backend(device)
+    m = be.upload(np.zeros((0, 3)))
+    crop_scan = backend.make_crop(backend.CROP_MIN_MAX_RADIUS, rmin=2.0, rmax=30.0)
+    be.profile_enable(True)
+    rec = []
+    for k in range(len(scans32)):
+        raw = be.upload_f32(np.ascontiguousarray(np.hstack([scans32[k], np.zeros((len(scans32[k]), 1), np.float32)])))
+        v = be.crop_voxel_down_sample(raw, crop_scan, 0.1)
+        be.estimate_normals(v, 3.0, 20)
+        be.free(raw)
+        n_scan = be.size(v)[0]  # (its size has arrived, as it has in the stream by the time a scan is inserted: two registrations lie in between)
+        T = np.linalg.inv(poses[0]) @ poses[k]
+        crop = backend.make_crop(backend.CROP_MIN_MAX_RADIUS, center=T[:3, 3], rmin=2.0, rmax=30.0)
+        n_before = be.size(m)[0]
+        # the device is busy while the call queues its launches -- a normal estimation of the same scan, same result -- so that the span is
+        # the kernels' time and not the host's (in the stream the host runs ahead of the device)
+        be.estimate_normals(v, 3.0, 20)
+        with be.span(0):
+            be.map_insert_scan(m, v, T, 0.1, crop, max_corr_hint=1.0)
+        cnt, ms = be.span_read(0)
+        rec.append((n_before, 1e3 * ms, n_scan))
+        be.free(v)
+    be.profile_enable(False)
+    be.close()
+    rows = []
+    for mark in marks:
+        sel = [r for r in rec[2:] if 0.8 * mark <= r[0] <= 1.2 * mark]  # (the first two insertions found the map and bring it into its persistent form)
+        if sel:
+            rows.append({"map_points_mark": int(mark), "map_points": [int(sel[0][0]), int(sel[-1][0])], "insertions": len(sel),
+                         "avg_us": float(np.mean([r[1] for r in sel])), "median_us": float(np.median([r[1] for r in sel])),
+                         "max_us": float(np.max([r[1] for r in sel])),
+                         "scan_points": int(np.mean([r[2] for r in sel]))})
+    return rows
+
+
 # ------------------------------------------------------------------------------------------------ M1
 def run_m1(be, world, s_id, t_id, steps, warmup, barrier, drv):
     if drv is not None:
@@ -566,6 +667,7 @@ def main():
     ap.add_argument("--m2-cpu-frames", type=int, default=200, help="frames of the stream the CPU oracle loop plays (all of them by default: like for like)")
     ap.add_argument("--no-host-seam", action="store_true", help="skip the configs[2] run through the integration header with host clouds at the seams")
     ap.add_argument("--no-f64", action="store_true")
+    ap.add_argument("--no-gicp", action="store_true", help="skip the m1_gicp line (configs[1] under GeneralizedIcp)")
     ap.add_argument("--large-map", type=int, default=8_000_000, help="points of the larger-than-Infinity-Cache map of the m1_large_map line (0: skip)")
     ap.add_argument("--concurrent", type=int, default=4, help="registrations in flight at once for the `concurrent` line (0 / 1: skip)")
     ap.add_argument("--config", default="auto", choices=["auto", "1", "3", "3u", "4"],
@@ -664,16 +766,28 @@ def main():
             mode = "union" if args.config == "3u" else "submap"
         drv = sharded.ShardedIcp(be, mode=mode) if (world > 1 or args.config == "3u") else None
         res, elapsed, n_launch, kern_ms, su, collections = run_m1(be, world, s_id, t_id, steps, warmup, barrier, drv)
+        # what a hipEvent bracket costs by itself on this stream (two records back to back): the brackets around the pass launches include it
+        be.profile_enable(True)
+        for _ in range(200):
+            with be.span(0):
+                pass
+        n_br, br_ms = be.span_read(0)
+        be.profile_enable(False)
+        bracket_s = br_ms * 1e-3 / max(n_br, 1)
         if world > 1:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
         be.close()
-        avg_kernel_s = kern_ms * 1e-3 / max(n_launch, 1)
+        avg_bracket_s = kern_ms * 1e-3 / max(n_launch, 1)
+        avg_kernel_s = max(avg_bracket_s - bracket_s, 1e-9)  # the kernel's share of a bracket
         gbs = algo_bytes / avg_kernel_s / 1e9
         spread = {"median": float(np.median(su)), "p10": float(np.percentile(su, 10)), "p90": float(np.percentile(su, 90)), "max": float(su.max()),
                   "host_cpu": host_cpu(), "argmax": int(np.argmax(su)), "gc": collections}
-        return dict(res=res, elapsed=elapsed, index_build_ms=index_build_ms, n_launch=n_launch, avg_kernel_s=avg_kernel_s, gbs=gbs, step_us=spread)
+        # (the pass launches of a step must fit inside the step they are part of: a roofline figure that does not invites distrust of the rest)
+        assert n_launch == 0 or world > 1 or n_launch / max(steps, 1) * avg_kernel_s <= elapsed / steps * 1.02, (n_launch, avg_kernel_s, elapsed / steps)
+        return dict(res=res, elapsed=elapsed, index_build_ms=index_build_ms, n_launch=n_launch, avg_kernel_s=avg_kernel_s, gbs=gbs, step_us=spread,
+                    avg_bracket_s=avg_bracket_s, bracket_overhead_s=bracket_s)
 
     r32 = m1(backend.PRECISION_F32, args.steps, args.warmup)
     r64 = None if args.no_f64 else m1(backend.PRECISION_F64, max(args.steps // 2, 1), args.warmup)
@@ -789,6 +903,48 @@ def main():
                                "what": "odometry and mapping on two host threads and two backend handles (SlamWrapper.cpp:228-229), raw scan ingested by both"}
         except Exception as e:  # noqa: BLE001
             m2["pipelined"] = {"error": repr(e)}
+        try:  # the stream as the shipped Lua configures it: GeneralizedIcp in both workers, downsampling_ratio 0.3 (seeded index lists)
+            be2 = backend.Backend(local_rank)
+            run_stream(be2, scans32[: min(12, len(scans32))], shipped=True)
+            be2.close()
+            be2 = backend.Backend(local_rank)
+            sh = run_stream(be2, scans32, shipped=True)
+            be2.close()
+            m2["shipped_configuration"] = {
+                "scans_per_sec": sh["scans_per_sec"], "mapping_only_scans_per_sec": sh["mapping_only_scans_per_sec"], "ms_per_scan": sh["ms_per_scan"],
+                "map_points": sh["map_points"], "final_pose_error_vs_truth": sh["final_pose_error_vs_truth"],
+                "what": "the same 200 frames with cloud_registration_type / scan_to_map_refinement_type = GeneralizedIcp and downsampling_ratio = 0.3 "
+                        "(parameter_structure_definitions.lua:62,76,109) in the odometry and the mapper; the crop -> voxelize -> normals chain is "
+                        "shared up to the RandomDownSample, each worker draws its own (seeded) index list"}
+        except Exception as e:  # noqa: BLE001
+            m2["shipped_configuration"] = {"error": repr(e)[:400]}
+        try:
+            m2["map_insert_scan_by_map_size"] = {
+                "rows": run_insert_sweep(local_rank, scans32),
+                "what": "o3ds_map_insert_scan (Submap::insertScan: transform, +=, voxelizeWithinCroppingVolume, search index) of the stream's "
+                        "pre-processed scans at their true poses into one growing map; hipEvent span per call; rows = the insertions whose map "
+                        "size lies within 20 % of 100 k / 300 k / 1 M points"}
+        except Exception as e:  # noqa: BLE001
+            m2["map_insert_scan_by_map_size"] = {"error": repr(e)[:400]}
+        try:  # open3d_slam's own LidarOdometry / Mapper sources with integration/open3d_slam_o3ds.patch applied, on this library
+            from oracle import ref as _ref
+
+            if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libo3dslam_ref_patched.so")):
+                mp_, op_ = stream_parameters()
+                res_p = {}
+                for name, threads in (("serial", False), ("two_threads", True)):
+                    R = _ref.ReferenceSlam(mp_, op_, patched=True)
+                    R.run_stream(scans32[:8], threads=threads)
+                    R.close()
+                    R = _ref.ReferenceSlam(mp_, op_, patched=True)
+                    ok, M_, O_, ms_, n_map_ = R.run_stream(scans32, threads=threads)
+                    R.close()
+                    res_p[name] = {"scans_per_sec": len(scans32) * 1e3 / ms_, "frames_ok": int(ok), "map_points": int(n_map_)}
+                res_p["what"] = ("the reference's own addRangeScan + addRangeMeasurement (sources compiled with the patch, stand-in Eigen / PointCloud "
+                                 "container: oracle/ref_build) calling libo3ds_backend.so; raw scans are host PointClouds of doubles")
+                m2["patched_reference"] = res_p
+        except Exception as e:  # noqa: BLE001
+            m2["patched_reference"] = {"error": repr(e)[:400]}
         del m2["pose"]
         m2_poses = m2.pop("poses_per_frame")
         prof.pop("poses_per_frame", None)
@@ -855,6 +1011,9 @@ def main():
                         "upper": t["traffic_bytes_per_launch_if_every_read_is_a_full_line"], "over_algorithmic": t["traffic_over_algorithmic"],
                         "over_compulsory": t["traffic_over_compulsory"], "source": TRAFFIC_FILE + " (" + which + ")"},
                     "kernel": pass_kernel, "launches": r["n_launch"], "avg_launch_us": r["avg_kernel_s"] * 1e6,
+                    "avg_launch_us_what": "hipEvent bracket around every pass launch minus what an empty bracket costs on the same stream "
+                                          f"({r['bracket_overhead_s'] * 1e6:.2f} us; bracket itself {r['avg_bracket_s'] * 1e6:.2f} us); launches x this fits the "
+                                          "step (asserted); the rocprofv3 kernel-trace average of the same command is under profiles/",
                     "algorithmic_bytes_per_launch": algo_bytes, "measured_copy_gbs": copy_gbs,
                     "frac_of_measured_copy": r["gbs"] / copy_gbs if copy_gbs else None}
 
@@ -903,6 +1062,11 @@ def main():
                                    "n_map": r_big["n_map"], "index_build_ms": r_big["index_build_ms"], "roofline": roof(r_big, "icp_fused_kernel<P4f> 8 M-point map"),
                                    "pose_error_vs_truth": dict(zip(("dt_m", "dr_rad"), syn.se3_error(r_big["res"]["transformation"], T_gt))),
                                    "what": "the configs[1] scan against a map whose index (256 MB cell-sorted + 36 MB grid) exceeds the Infinity Cache"}
+        if world == 1 and args.config == "1" and not args.no_gicp:
+            try:
+                out["m1_gicp"] = run_m1_gicp(local_rank, src, tgt, nrm, max(args.steps // 2, 1), args.warmup, with_oracle=not args.no_cpu_baseline)
+            except Exception as e:  # noqa: BLE001
+                out["m1_gicp"] = {"error": repr(e)[:400]}
         if conc is not None:
             out["concurrent"] = conc
         if m2 is not None:

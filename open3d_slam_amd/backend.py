@@ -633,13 +633,15 @@ class Backend:
                                                C.byref(c_s), i_t.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(c_t)))
         return i_s[: c_s.value].copy(), i_t[: c_t.value].copy()
 
-    def map_carve(self, map_id: int, raw_scan_id: int, T, crop: Crop | None, voxel=0.1, max_length=20.0, truncation=0.1, min_dot=0.5) -> int:
-        """Submap::carve on the device-resident sparse map; returns the number of removed points."""
+    def map_carve(self, map_id: int, raw_scan_id: int, T, crop: Crop | None, voxel=0.1, max_length=20.0, truncation=0.1, min_dot=0.5,
+                  want_count: bool = True):
+        """Submap::carve on the device-resident sparse map; returns the number of removed points (want_count=False: nothing -- the count is
+        what a carve of a submap in its persistent form would have to wait for; Submap::carve itself returns void)."""
         Tc, tp = _d(colmajor(T))
         p = CarvingParams(voxel, max_length, truncation, min_dot)
         n = C.c_size_t(0)
-        self._ck(self.lib.o3ds_map_carve(self.h, map_id, raw_scan_id, tp, C.byref(crop) if crop else None, C.byref(p), C.byref(n)))
-        return int(n.value)
+        self._ck(self.lib.o3ds_map_carve(self.h, map_id, raw_scan_id, tp, C.byref(crop) if crop else None, C.byref(p), C.byref(n) if want_count else None))
+        return int(n.value) if want_count else None
 
     def map_carve_removed(self, map_id: int, raw_scan_id: int, T, crop: Crop | None, voxel=0.1, max_length=20.0, truncation=0.1, min_dot=0.5):
         """Submap::carve with its toRemove_ cloud: (number of removed points, device cloud of the removed points in map order)."""

@@ -134,6 +134,7 @@ struct PMapRec {
   int t = 0;              // insertions since the map entered this form (their volumes: d_hist[1..t])
   size_t n_upper = 0;     // slots in use: the host's upper bound (exact value: dev.counters[kPmN])
   size_t live_lower = 0;  // live points: a lower bound
+  double clamped = 0;     // slots that entered the index outside its grid, as of the last record
   double pool_top = 0;    // first free position of the index pool: an upper bound (the last record the host saw + the worst case of
                           // every insertion since)
   int rec_slot = -1, rec_seq = 0;  // pinned record the insertions publish {slots, pool top, dead, error} into; stamp of the latest
@@ -3428,7 +3429,7 @@ int pm_enter_t(o3ds_handle h, CloudRec& c, double voxel, double max_corr_hint, s
   c.pm = pm;  // (from here on free_cloud / pm_release own it)
   // room: half the map again and a few scans' worth
   const size_t want_cap = n + std::max<size_t>({n / 2, 16 * scan_upper, (size_t)1 << 18});
-  if (c.cap < n + 4 * scan_upper || (c.nrm && false)) {
+  if (c.cap < want_cap) {  // (entering costs a pass over the map anyway; room for half the map again makes the next capacity fold a rare event)
     void *np = nullptr, *nn = nullptr;
     HIP_TRY(dev_alloc(h, &np, sizeof(P4) * want_cap));
     HIP_TRY(hipMemcpyAsync(np, c.pts, sizeof(P4) * n, hipMemcpyDeviceToDevice, h->stream));
@@ -3450,22 +3451,12 @@ int pm_enter_t(o3ds_handle h, CloudRec& c, double voxel, double max_corr_hint, s
   d.pts = c.pts;
   d.nrm = c.nrm;
   d.cap = cap;
-  PM_ALLOC(d.stamp, sizeof(int) * cap);
-  PM_ALLOC(d.okey, sizeof(unsigned long long) * cap);
-  PM_ALLOC(d.hnext, sizeof(int) * cap);
-  PM_ALLOC(d.pos, sizeof(int) * cap);
-  PM_ALLOC(d.flags, cap);
+  PM_ALLOC(d.slot, sizeof(PmSlot) * cap);
   size_t hcap = 1024;
   while (hcap < 2 * cap) hcap <<= 1;
-  PM_ALLOC(d.hkey, sizeof(unsigned long long) * hcap);
-  PM_ALLOC(d.hhead, sizeof(int) * hcap);
-  PM_ALLOC(d.hflag, sizeof(unsigned int) * hcap);
-  PM_ALLOC(d.hmark, sizeof(int) * hcap);
-  HIP_TRY(hipMemsetAsync(d.hmark, 0, sizeof(int) * hcap, h->stream));
+  PM_ALLOC(d.h, sizeof(PmHash) * hcap);
   d.hmask = (unsigned int)(hcap - 1);
-  HIP_TRY(hipMemsetAsync(d.hkey, 0xff, sizeof(unsigned long long) * hcap, h->stream));
-  HIP_TRY(hipMemsetAsync(d.hhead, 0xff, sizeof(int) * hcap, h->stream));
-  HIP_TRY(hipMemsetAsync(d.hflag, 0, sizeof(unsigned int) * hcap, h->stream));
+  pm_hash_init_kernel<<<grid_for(hcap), kBlock, 0, h->stream>>>(d.h, hcap);
   d.list_cap = (int)std::min<size_t>(cap, 0x7fffffff);
   PM_ALLOC(d.counters, sizeof(int) * kPmCounters);
   for (int k = 0; k < 2; ++k) {
@@ -3601,11 +3592,12 @@ int pm_poll(o3ds_handle h, PMapRec* pm, bool block) {
   if ((int)r->box[2] != 0) return fail(h, O3DS_ERR_CAPACITY, "persistent map: an internal capacity was exceeded (error " + std::to_string((int)r->box[2]) + ")");
   static const bool stats = ab_getenv("O3DS_PM_STATS") != nullptr;  // development aid: what the insertions left behind
   if (stats)
-    fprintf(stderr, "[pm] t %d slots %zu dead %zu pool top %.0f of %d; multi %.0f unsettled %.0f entered the index %.0f\n", pm->t, slots, dead, r->box[0],
+    fprintf(stderr, "[pm] t %d slots %zu dead %zu pool top %.0f of %d; multi %.0f complex %.0f outside the grid %.0f\n", pm->t, slots, dead, r->box[0],
             pm->dev.pool_cap, r->box[3], r->box[4], r->box[5]);
   pm->n_upper = slots;
   pm->live_lower = slots - dead;
   pm->pool_top = r->box[0];
+  pm->clamped = r->box[5];
   pm->rec_seq = 0;  // consumed
   return O3DS_OK;
 }
@@ -3678,7 +3670,7 @@ int pm_insert_t(o3ds_handle h, CloudRec& c, const CloudRec& scan, const double T
   h->ticket_base += (unsigned int)n_tiles;
   pm_group_kernel<P4><<<grid_for(ms), kBlock, 0, h->stream>>>(d, groups, order, run_next, run_len, starts, piece, placed, placed_nrm, t, crop, t_now, group_key);
   h->voxtab_clean = true;
-  pm_merge_kernel<P4><<<128, 64, 0, h->stream>>>(d, piece, starts, run_len, placed, placed_nrm, group_key, crop, t_now);
+  pm_merge_kernel<P4><<<128, 64, 0, h->stream>>>(d, piece, run_next, run_len, placed, placed_nrm, group_key, crop, t_now);
   pm_misc_kernel<P4><<<256, kBlock, 0, h->stream>>>(d, placed, placed_nrm, crop, t_now);
   const unsigned int row_blocks = (unsigned int)std::min<size_t>(std::max<size_t>(ms / 8, 64), 2048);
   pm_rows_kernel<P4><<<row_blocks, kBlock, sizeof(int) * 3 * (size_t)(d.grid.nx + 1), h->stream>>>(d);
@@ -4054,6 +4046,47 @@ int o3ds_map_carve_removed(o3ds_handle h, o3ds_cloud map, o3ds_cloud raw_scan, c
                            const o3ds_carving_params* params, size_t* n_removed, o3ds_cloud* removed_out) {
   CHECK_HANDLE(h);
   ArenaScope arena_scope(h);
+  {  // a submap in its persistent form is carved where it is when the carving voxel is the map's (the voxel hash is the reference's table)
+    CloudRec* pmc = find_cloud_lazy(h, map);
+    CloudRec* sc = find_cloud(h, raw_scan);
+    if (pmc && sc && pmc != sc && pmc->pm && params && map_to_range_sensor && !removed_out && params->voxel_size == pmc->pm->dev.voxel &&
+        (pmc->n == 0 || sc->n == 0 || pmc->precision == sc->precision)) {
+      if (n_removed) *n_removed = 0;
+      if (sc->n == 0) return O3DS_OK;
+      PMapRec* pm = pmc->pm;
+      const PmDev d = pm->dev;
+      const double* T = map_to_range_sensor;
+      Mat34 M;
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c) M.m[r * 4 + c] = T[c * 4 + r];
+      const CropDev cd = to_dev(map_builder_crop);
+      unsigned int* block_bits = nullptr;
+      TMP_ALLOC(block_bits, sizeof(unsigned int) << (kCarveBitsLog2 - 5));
+      HIP_TRY(hipMemsetAsync(block_bits, 0, sizeof(unsigned int) << (kCarveBitsLog2 - 5), h->stream));
+      pm_carve_bits_kernel<<<grid_for((size_t)d.hmask + 1), kBlock, 0, h->stream>>>(d.h, (size_t)d.hmask + 1, block_bits);
+      pm->rec_seq = ++h->rec_seq;
+      o3ds_context::PinRec* rec = h->h_rec_dev + pm->rec_slot;
+      const CountPub pub{cnt_word(h, pm->rec_slot), &rec->cnt, pm->rec_seq};
+      if (pmc->precision == O3DS_PRECISION_F64) {
+        pm_carve_rays_kernel<P4d><<<grid_for(sc->n), kBlock, 0, h->stream>>>(d, (const P4d*)sc->pts, sc->n, M, T[12], T[13], T[14], params->max_raytracing_length,
+                                                                            params->truncation_distance, params->min_dot_product_with_normal, cd, block_bits);
+        pm_carve_apply_kernel<P4d><<<256, kBlock, 0, h->stream>>>(d, pub, rec->box);
+      } else {
+        pm_carve_rays_kernel<P4f><<<grid_for(sc->n), kBlock, 0, h->stream>>>(d, (const P4f*)sc->pts, sc->n, M, T[12], T[13], T[14], params->max_raytracing_length,
+                                                                            params->truncation_distance, params->min_dot_product_with_normal, cd, block_bits);
+        pm_carve_apply_kernel<P4f><<<256, kBlock, 0, h->stream>>>(d, pub, rec->box);
+      }
+      pm_carve_finish_kernel<<<1, 64, 0, h->stream>>>(d, pub, rec->box);
+      HIP_TRY(hipGetLastError());
+      if (n_removed) {  // (asking for the count is what waits)
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        *n_removed = (size_t)(h->h_rec + pm->rec_slot)->box[3];
+        const int rp = pm_poll(h, pm, true);
+        if (rp) return rp;
+      }
+      return O3DS_OK;
+    }
+  }
   CloudRec* m = find_cloud(h, map);
   CloudRec* s = find_cloud(h, raw_scan);
   if (!m || !s || !map_to_range_sensor || !params || m == s) return fail(h, O3DS_ERR_INVALID_ARG, "map_carve: bad argument");
@@ -4108,12 +4141,7 @@ int o3ds_map_insert_scan(o3ds_handle h, o3ds_cloud map, o3ds_cloud scan, const d
       if (rc) return rc;
       refold = pm->n_upper + s->n > pm->dev.cap || pm->pool_top + growth > (double)pm->dev.pool_cap;
     }
-    if (!refold && placed.has_box) {  // a scan far outside the index grid: new extents at the fold
-      const GridDev& g = pm->dev.grid;
-      const double lo[3] = {g.ox, g.oy, g.oz}, hi[3] = {g.ox + g.nx * g.cell, g.oy + g.ny * g.cell, g.oz + g.nz * g.cell};
-      for (int a = 0; a < 3; ++a)
-        if (placed.bmn[a] < lo[a] - 8.0 * g.cell || placed.bmx[a] > hi[a] + 8.0 * g.cell) refold = true;
-    }
+    if (!refold && pm->clamped > 20000.0) refold = true;  // the map has grown well beyond the index grid: new extents (the fold re-grids)
     if (refold) {
       rc = pm_exit(h, *m);
       if (rc) return rc;

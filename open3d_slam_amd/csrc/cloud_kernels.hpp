@@ -917,10 +917,21 @@ __device__ inline void sort_indices(uint32_t* a, int k) {
   }
 }
 
+// The runs of a voxel in ascending order of their first point WITHOUT a list in memory: the next one is looked for again each time (a voxel
+// of a lidar scan has one or two runs; a list per voxel needs a place in a scratch array, i.e. a ticket from ONE counter -- a thousand
+// wavefronts drawing tickets from one address took longer than everything else the kernel does).  INT_MAX when there is none.
+constexpr int kInlineRuns = 6;  // voxels with more runs than this do get a sorted list in the scratch array (they are a fraction of a per cent)
+__device__ __forceinline__ int next_run(const int* __restrict__ run_next, int head, int prev) {
+  int best = 0x7fffffff;
+  for (int node = head; node != -1; node = run_next[node])
+    if (node > prev && node < best) best = node;
+  return best;
+}
+
 // AccumulatedPoint::GetAveragePoint / GetAverageNormal / GetAverageColor ([O3D] PointCloud.cpp VoxelDownSample): sums in cloud order,
 // divided by the count; normals are averaged, not re-normalised.  One thread per voxel r (the number of voxels comes from the device word
-// vox_order_kernel left): the voxel's runs are copied from its list into a piece of `starts` (one cursor atomic per wavefront), put in
-// ascending order, and summed run by run.  attr_only: the pieces are already there and in order (the colour pass); piece[r] = where.
+// vox_order_kernel left): the voxel's runs in ascending order (next_run; a voxel with many runs: copied into a piece of `starts` and sorted),
+// summed run by run.  piece[r] = {head of the run list, number of runs} is left for a second pass over another attribute (colours).
 template <typename P4>
 __global__ __launch_bounds__(kBlock) void vox_mean_kernel(const P4* __restrict__ pts, const P4* __restrict__ nrm, CountRef m_in, const int* __restrict__ order,
                                                           const int* __restrict__ run_next, const int* __restrict__ run_len, uint32_t* __restrict__ starts,
@@ -932,22 +943,27 @@ __global__ __launch_bounds__(kBlock) void vox_mean_kernel(const P4* __restrict__
   for (size_t r0 = (size_t)blockIdx.x * kBlock; r0 < m; r0 += (size_t)gridDim.x * kBlock) {  // whole wavefronts iterate together
     const size_t r = r0 + threadIdx.x;
     const bool have = r < m;
-    int b = 0, k = 0;
-    if (attr_only) {
-      if (have) b = piece[r].x, k = piece[r].y;
-    } else {
-      int s = 0, node = -1;
-      if (have) {
-        s = order[r];
-        k = (int)t.s[s].nrun + 1;
-        node = t.s[s].head;
+    int head = -1, k = 0;
+    if (have) {
+      if (attr_only) {
+        head = piece[r].x, k = piece[r].y;
+      } else {
+        const int s = order[r];
+        const VoxSlot v = t.s[s];
+        k = (int)v.nrun + 1;
+        head = v.head;
         // the table is done with this voxel: leave the slot as the 0xff fill left it, for the next call
-        t.s[s].key = kEmptyKey;
-        t.s[s].first = ~0u;
-        t.s[s].head = -1;
-        t.s[s].nrun = ~0u;
+        VoxSlot e;
+        e.key = kEmptyKey, e.first = ~0u, e.head = -1, e.nrun = ~0u, e.pad[0] = e.pad[1] = e.pad[2] = ~0u;
+        t.s[s] = e;
+        if (piece) piece[r] = make_int2(head, k);
       }
-      int incl = k;
+    }
+    // the few voxels with many runs: a sorted list in the scratch array, its place from one cursor atomic per wavefront that has any
+    const int kk = k > kInlineRuns ? k : 0;
+    int b = 0;
+    if (__ballot(kk > 0) != 0ull) {
+      int incl = kk;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
         const int y = __shfl_up(incl, d, 64);
@@ -955,33 +971,43 @@ __global__ __launch_bounds__(kBlock) void vox_mean_kernel(const P4* __restrict__
       }
       const int wave_total = __shfl(incl, 63, 64);
       unsigned int wbase = 0;
-      if (lane == 0 && wave_total > 0) wbase = atomicAdd(t.cursor, (unsigned int)wave_total);
+      if (lane == 0) wbase = atomicAdd(t.cursor, (unsigned int)wave_total);
       wbase = __shfl(wbase, 0, 64);
-      b = (int)wbase + incl - k;
-      for (int j = 0; j < k; ++j) {
+      b = (int)wbase + incl - kk;
+      int node = head;
+      for (int j = 0; j < kk; ++j) {
         starts[b + j] = (uint32_t)node;
         node = run_next[node];
       }
-      if (k > 1) sort_indices(starts + b, k);
-      if (have && piece) piece[r] = make_int2(b, k);
+      if (kk > 1) sort_indices(starts + b, kk);
     }
     if (!have) continue;
     double sx = 0, sy = 0, sz = 0, nx = 0, ny = 0, nz = 0;
-    int cnt = 0;
+    int cnt = 0, prev = -1;
     for (int j = 0; j < k; ++j) {
-      const uint32_t st = starts[b + j];
+      const int st = kk ? (int)starts[b + j] : next_run(run_next, head, prev);
+      prev = st;
       const int len = run_len[st];
-      for (int q = 0; q < len; ++q) {
-        const P4 p = pts[st + q];
-        sx += (double)p.x;
-        sy += (double)p.y;
-        sz += (double)p.z;
-        if (nrm) {
-          const P4 v = nrm[st + q];
-          nx += (double)v.x;
-          ny += (double)v.y;
-          nz += (double)v.z;
+      for (int q = 0; q < len; q += 4) {  // four points' loads in flight together (clamped), added in order
+        P4 pp[4], nn[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = st + min(q + u, len - 1);
+          pp[u] = pts[idx];
+          nn[u] = nrm ? nrm[idx] : pp[u];
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (q + u < len) {
+            sx += (double)pp[u].x;
+            sy += (double)pp[u].y;
+            sz += (double)pp[u].z;
+            if (nrm) {
+              nx += (double)nn[u].x;
+              ny += (double)nn[u].y;
+              nz += (double)nn[u].z;
+            }
+          }
       }
       cnt += len;
     }

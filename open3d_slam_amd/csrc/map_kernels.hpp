@@ -38,24 +38,31 @@ namespace o3ds {
 
 constexpr int kPmHistory = 256;                 // insertions between two folds at most (the list of their volumes)
 constexpr unsigned long long kPmRaw = 1ull << 63;  // okey flag: a scan point that was inserted OUTSIDE the volume (low bits: its scan index)
-constexpr unsigned char kPmDead = 1, kPmUnsettled = 2, kPmFresh = 4;  // (fresh: created by the running insertion, not in the index yet)
+constexpr unsigned int kPmDead = 1, kPmUnsettled = 2, kPmFresh = 4, kPmCarved = 8;  // (fresh: created by the running insertion, not in the index yet)
 constexpr int kPmMaxOld = 8;  // old members of one voxel the special-case path sorts in LDS (more: pm_merge_many)
 
+struct alignas(32) PmSlot {
+  unsigned long long okey;  // voxel key the slot was written under (kPmRaw | scan index for a point inserted outside the volume)
+  int stamp;                // insertion (1, 2, ...; 0 = the base the map entered with) that last wrote the slot
+  int pos;                  // position in the paged index
+  int hnext;                // next slot of the same voxel chain, -1 = end
+  unsigned int flags;       // kPmDead | kPmUnsettled | kPmFresh
+  int pad[2];
+};
+struct alignas(16) PmHash {
+  unsigned long long key;
+  int head;           // first slot of the chain, -1 = none
+  unsigned int info;  // bit 0: on the multi list; bits 8..31: the insertion whose pm_group_kernel found several old members of the voxel
+                      // inside the volume (pm_merge_kernel: "dealt with")
+};
 // everything a kernel needs of a persistent map (device pointers; a copy travels by value in the kernel arguments)
 struct PmDev {
   void* pts;  // P4[cap]
   void* nrm;  // P4[cap] or null
-  int* stamp;                // [cap] insertion (1, 2, ...; 0 = the base the map entered with) that last wrote the slot
-  unsigned long long* okey;  // [cap] voxel key the slot was written under (kPmRaw | scan index for a point inserted outside the volume)
-  int* hnext;                // [cap] next slot of the same voxel chain, -1 = end
-  int* pos;                  // [cap] position in the paged index
-  unsigned char* flags;      // [cap]
+  struct PmSlot* slot;       // [cap] per-slot record (one cache line per slot: as separate arrays an insertion touched five lines per voxel)
   size_t cap;
   // voxel hash (open addressing, never deleted from: a chain may be empty)
-  unsigned long long* hkey;
-  int* hhead;
-  unsigned int* hflag;  // bit 0: on the multi list
-  int* hmark;           // the insertion whose pm_group_kernel found several old members of the voxel inside the volume (pm_merge_kernel: "dealt with")
+  struct PmHash* h;
   unsigned int hmask;
   // lists and counters (device)
   int* counters;        // see PmCounter
@@ -96,6 +103,8 @@ enum PmCounter {
   kPmRelink,
   kPmTouched,
   kPmNew,          // entries of new_slots
+  kPmClamped,      // slots that entered the index outside its grid since the map took this form (the host re-grids when they are many)
+  kPmCarvedCnt,    // slots the running carve removes (listed in new_slots: no insertion is in flight then)
   kPmPoolTop,      // first free position of the index pool
   kPmError,        // sticky: 1 a list overflowed, 2 the slot arrays, 4 the index pool (the host sizes all three so that none can happen)
   kPmCounters = 16
@@ -111,7 +120,7 @@ __device__ __forceinline__ unsigned int pm_hash(unsigned long long k) { return (
 __device__ __forceinline__ unsigned int pm_entry(const PmDev& m, unsigned long long k) {
   unsigned int e = pm_hash(k) & m.hmask;
   while (true) {
-    const unsigned long long prev = atomicCAS(&m.hkey[e], kEmptyKey, k);
+    const unsigned long long prev = atomicCAS(&m.h[e].key, kEmptyKey, k);
     if (prev == kEmptyKey || prev == k) return e;
     e = (e + 1) & m.hmask;
   }
@@ -120,7 +129,7 @@ __device__ __forceinline__ unsigned int pm_entry(const PmDev& m, unsigned long l
 __device__ __forceinline__ unsigned int pm_find(const PmDev& m, unsigned long long k) {
   unsigned int e = pm_hash(k) & m.hmask;
   while (true) {
-    const unsigned long long cur = m.hkey[e];
+    const unsigned long long cur = m.h[e].key;
     if (cur == k) return e;
     if (cur == kEmptyKey) return ~0u;
     e = (e + 1) & m.hmask;
@@ -139,6 +148,13 @@ __device__ __forceinline__ void pm_cell(const PmDev& m, unsigned long long key, 
   const int ix = cell(vx, m.gx0, m.kc, m.grid.nx), iy = cell(vy, m.gy0, m.kc, m.grid.ny), iz = cell(vz, m.gz0, m.kc, m.grid.nz);
   *row = iz * m.grid.ny + iy;
   *x = ix;
+}
+// whether the voxel lies outside the grid (its points are kept in the border cells: exact, but the search wades through them)
+__device__ __forceinline__ bool pm_outside_grid(const PmDev& m, unsigned long long key) {
+  const long long vx = (long long)(key & 0x1FFFFFull) - (1ll << 20), vy = (long long)((key >> 21) & 0x1FFFFFull) - (1ll << 20),
+                  vz = (long long)((key >> 42) & 0x1FFFFFull) - (1ll << 20);
+  return vx < m.gx0 || vx >= m.gx0 + (long long)m.grid.nx * m.kc || vy < m.gy0 || vy >= m.gy0 + (long long)m.grid.ny * m.kc || vz < m.gz0 ||
+         vz >= m.gz0 + (long long)m.grid.nz * m.kc;
 }
 
 // Eigen normalized() as segment_mean_kernel spells it; returns whether anything was divided
@@ -221,8 +237,8 @@ __device__ __forceinline__ bool pm_in_block(const PmDev& m, int s, const P4& p, 
 template <typename P4>
 __device__ __forceinline__ void pm_view_key(const PmDev& m, int s, int t_ref, unsigned long long* hi, unsigned long long* lo) {
   const P4 p = ((const P4*)m.pts)[s];
-  const int st = m.stamp[s];
-  const unsigned long long ok = m.okey[s];
+  const int st = m.slot[s].stamp;
+  const unsigned long long ok = m.slot[s].okey;
   const unsigned long long kp = pm_key(p, m.inv_voxel);
   if (pm_in_block(m, s, p, st, ok, t_ref)) {
     *hi = 1ull << 63;
@@ -247,6 +263,15 @@ __device__ __forceinline__ void pm_view_key(const PmDev& m, int s, int t_ref, un
 }
 
 // ---- entering the persistent form -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void pm_hash_init_kernel(PmHash* __restrict__ hh, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    PmHash e;
+    e.key = kEmptyKey;
+    e.head = -1;
+    e.info = 0u;
+    hh[i] = e;
+  }
+}
 // per slot of the base [pass block | voxel block in key order]: history, hash chain, settled or not
 template <typename P4>
 __global__ __launch_bounds__(kBlock) void pm_enter_kernel(PmDev m, int n) {
@@ -254,9 +279,9 @@ __global__ __launch_bounds__(kBlock) void pm_enter_kernel(PmDev m, int n) {
   for (int s = blockIdx.x * kBlock + threadIdx.x; s < n; s += gridDim.x * kBlock) {
     const P4 p = ((const P4*)m.pts)[s];
     const unsigned long long k = pm_key(p, m.inv_voxel);
-    m.stamp[s] = 0;
-    m.okey[s] = k;
-    unsigned char fl = 0;
+    m.slot[s].stamp = 0;
+    m.slot[s].okey = k;
+    unsigned int fl = 0;
     if (m.nrm) {
       const P4 nv = ((const P4*)m.nrm)[s];
       if (!pm_same_bits(pm_renormalized(nv), nv)) {
@@ -264,11 +289,11 @@ __global__ __launch_bounds__(kBlock) void pm_enter_kernel(PmDev m, int n) {
         pm_push(m.unsettled[0], m.counters + kPmUnsettledIn, m.list_cap, s, err);
       }
     }
-    m.flags[s] = fl;
+    m.slot[s].flags = fl;
     const unsigned int e = pm_entry(m, k);
-    const int old = atomicExch(&m.hhead[e], s);
-    m.hnext[s] = old;
-    if (old != -1 && !(atomicOr(&m.hflag[e], 1u) & 1u)) pm_push64(m.multi[0], m.counters + kPmMultiIn, m.list_cap, k, err);
+    const int old = atomicExch(&m.h[e].head, s);
+    m.slot[s].hnext = old;
+    if (old != -1 && !(atomicOr(&m.h[e].info, 1u) & 1u)) pm_push64(m.multi[0], m.counters + kPmMultiIn, m.list_cap, k, err);
   }
 }
 
@@ -278,7 +303,7 @@ __global__ __launch_bounds__(kBlock) void pm_enter_kernel(PmDev m, int n) {
 template <typename P4>
 __global__ __launch_bounds__(kBlock) void pm_cell_count_kernel(PmDev m, int n, int* __restrict__ counts, int* __restrict__ cell_id) {
   for (int s = blockIdx.x * kBlock + threadIdx.x; s < n; s += gridDim.x * kBlock) {
-    if (m.flags[s] & kPmDead) {
+    if (m.slot[s].flags & kPmDead) {
       cell_id[s] = -1;
       continue;
     }
@@ -321,7 +346,7 @@ __global__ __launch_bounds__(kBlock) void pm_scatter_kernel(PmDev m, int n, cons
     p.i = (typename Scalar<P4>::index)s;
     ((P4*)m.spts)[pos] = p;
     if (m.nrm) ((P4*)m.snrm)[pos] = ((const P4*)m.nrm)[s];
-    m.pos[s] = pos;
+    m.slot[s].pos = pos;
   }
 }
 
@@ -402,6 +427,7 @@ __device__ __forceinline__ void pm_row_push(const PmDev& m, int s, unsigned long
   int row, x;
   pm_cell(m, key, &row, &x);
   atomicAdd(&m.cell_add[(size_t)row * (m.grid.nx + 1) + x], 1);
+  if (pm_outside_grid(m, key)) atomicAdd(m.counters + kPmClamped, 1);
   if (atomicExch(&m.row_flag[row], 1) == 0) pm_push(m.touched_rows, m.counters + kPmTouched, m.list_cap, row, m.counters + kPmError);
   pm_push(m.new_slots, m.counters + kPmNew, m.list_cap, s, m.counters + kPmError);
 }
@@ -413,16 +439,16 @@ __device__ __forceinline__ void pm_store(const PmDev& m, int s, const P4& op, co
   o.i = (typename Scalar<P4>::index)s;
   ((P4*)m.pts)[s] = o;
   if (has_nrm) ((P4*)m.nrm)[s] = on;
-  m.stamp[s] = t;
-  m.okey[s] = key;
-  unsigned char fl = fresh ? kPmFresh : 0;
+  m.slot[s].stamp = t;
+  m.slot[s].okey = key;
+  unsigned int fl = fresh ? kPmFresh : 0u;
   if (has_nrm && !pm_same_bits(pm_renormalized(on), on)) {
     fl |= kPmUnsettled;
     pm_push(m.unsettled[1], m.counters + kPmUnsettledOut, m.list_cap, s, m.counters + kPmError);
   }
-  m.flags[s] = fl;
+  m.slot[s].flags = fl;
   if (!fresh) {
-    const int pos = m.pos[s];
+    const int pos = m.slot[s].pos;
     ((P4*)m.spts)[pos] = o;
     if (has_nrm) ((P4*)m.snrm)[pos] = on;
   }
@@ -430,12 +456,12 @@ __device__ __forceinline__ void pm_store(const PmDev& m, int s, const P4& op, co
 template <typename P4>
 __device__ __forceinline__ void pm_kill(const PmDev& m, int s) {
   using R = typename Scalar<P4>::type;
-  m.flags[s] = kPmDead;
+  m.slot[s].flags = kPmDead;
   atomicAdd(m.counters + kPmDeadCnt, 1);
   P4 far;  // never the nearest neighbour of anything: its squared distance is +inf
   far.x = far.y = far.z = sizeof(R) == 4 ? (R)3.0e38f : (R)1.0e300;
   far.i = (typename Scalar<P4>::index)0x7fffffff;
-  ((P4*)m.spts)[m.pos[s]] = far;
+  ((P4*)m.spts)[m.slot[s].pos] = far;
 }
 
 // AccumulatedPoint (helpers.cpp:30-73) over the members of one voxel in the reference's order
@@ -495,57 +521,69 @@ __global__ __launch_bounds__(kBlock) void pm_group_kernel(PmDev m, CountRef g_in
   for (size_t r0 = (size_t)blockIdx.x * kBlock; r0 < g; r0 += (size_t)gridDim.x * kBlock) {  // whole wavefronts iterate together
     const size_t r = r0 + threadIdx.x;
     const bool have = r < g;
-    int k = 0, node = -1;
+    int k = 0, head = -1;
     unsigned long long key = 0;
     if (have) {
       const int s = order[r];
-      k = (int)t.s[s].nrun + 1;
-      node = t.s[s].head;
-      key = t.s[s].key;
-      t.s[s].key = kEmptyKey;  // the scratch table is handed back empty (all 0xff), as vox_mean_kernel does
-      t.s[s].first = ~0u;
-      t.s[s].head = -1;
-      t.s[s].nrun = ~0u;
+      const VoxSlot v = t.s[s];
+      k = (int)v.nrun + 1;
+      head = v.head;
+      key = v.key;
+      VoxSlot e0;  // the scratch table is handed back empty (all 0xff), as vox_mean_kernel does
+      e0.key = kEmptyKey, e0.first = ~0u, e0.head = -1, e0.nrun = ~0u, e0.pad[0] = e0.pad[1] = e0.pad[2] = ~0u;
+      t.s[s] = e0;
     }
-    int incl = k;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int y = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += y;
-    }
-    const int wave_total = __shfl(incl, 63, 64);
-    unsigned int wbase = 0;
-    if (lane == 0 && wave_total > 0) wbase = atomicAdd(t.cursor, (unsigned int)wave_total);
-    wbase = __shfl(wbase, 0, 64);
-    const int b = (int)wbase + incl - k;
-    // (the first probe of the voxel hash goes out now, beside the walk over the runs: two chains of dependent loads, side by side)
+    // (the first probe of the voxel hash goes out now, beside the walks over the runs: two chains of dependent loads, side by side)
     const unsigned int e0 = pm_hash(key) & m.hmask;
-    const unsigned long long hk0 = have ? m.hkey[e0] : kEmptyKey;
-    const int hh0 = have ? m.hhead[e0] : -1;
-    for (int j = 0; j < k; ++j) {
-      starts[b + j] = (uint32_t)node;
-      node = run_next[node];
+    const PmHash h0 = have ? m.h[e0] : PmHash{kEmptyKey, -1, 0u};
+    const unsigned long long hk0 = h0.key;
+    const int hh0 = h0.head;
+    // the runs in ascending order: looked for one by one (next_run), or -- the few voxels with many -- from a sorted list in the scratch array
+    const int kk = k > kInlineRuns ? k : 0;
+    int b = 0;
+    if (__ballot(kk > 0) != 0ull) {
+      int incl = kk;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += y;
+      }
+      const int wave_total = __shfl(incl, 63, 64);
+      unsigned int wbase = 0;
+      if (lane == 0) wbase = atomicAdd(t.cursor, (unsigned int)wave_total);
+      wbase = __shfl(wbase, 0, 64);
+      b = (int)wbase + incl - kk;
+      int node = head;
+      for (int j = 0; j < kk; ++j) {
+        starts[b + j] = (uint32_t)node;
+        node = run_next[node];
+      }
+      if (kk > 1) sort_indices(starts + b, kk);
     }
-    if (k > 1) sort_indices(starts + b, k);
     if (!have) continue;
-    piece[r] = make_int2(b, k);
+    piece[r] = make_int2(head, k);  // (for pm_merge_kernel, should the voxel turn out to have several old members)
     group_key[r] = key;
     // old members of the voxel that lie inside the volume (they are in the voxel hash under the same key).  The first member's point and
     // normal are what nearly every voxel needs: fetched in the walk, kept.
     int old_slot = -1, n_old_in = 0, n_live = 0;
     unsigned int e = e0;
-    int head = hh0;
+    int chain = hh0;
     if (hk0 != key) {  // not at its home entry: probe on (plain loads; the compare-and-swap only for a voxel the map has never seen)
       e = pm_find(m, key);
       if (e == ~0u) e = pm_entry(m, key);
-      head = m.hhead[e];
+      chain = m.h[e].head;
     }
     P4 old_p{}, old_n{};
-    for (int s = head; s != -1;) {
-      ++n_live;
+    for (int s = chain; s != -1;) {
       const P4 p = ((const P4*)m.pts)[s];
       const P4 q = has_nrm ? ((const P4*)m.nrm)[s] : p;
-      const int nxt = m.hnext[s];
+      const PmSlot ms = m.slot[s];
+      const int nxt = ms.hnext;
+      if (ms.flags & kPmDead) {  // (carved: a carve leaves its dead in the chains, the next fold drops them)
+        s = nxt;
+        continue;
+      }
+      ++n_live;
       if (crop_contains(crop, (double)p.x, (double)p.y, (double)p.z)) {
         ++n_old_in;
         old_slot = s;
@@ -555,20 +593,28 @@ __global__ __launch_bounds__(kBlock) void pm_group_kernel(PmDev m, CountRef g_in
       s = nxt;
     }
     if (n_old_in > 1) {
-      m.hmark[e] = t_now;
+      m.h[e].info = (m.h[e].info & 0xffu) | ((unsigned int)t_now << 8);
       pm_push(m.complex_groups, m.counters + kPmComplex, m.list_cap, (int)r, m.counters + kPmError);
       continue;
     }
     PmAcc acc;
     if (n_old_in == 1) acc.add(old_p, has_nrm, old_n);
+    int prev = -1;
     for (int j = 0; j < k; ++j) {
-      const uint32_t st = starts[b + j];
+      const int st = kk ? (int)starts[b + j] : next_run(run_next, head, prev);
+      prev = st;
       const int len = run_len[st];
-      for (int q = 0; q < len; ++q) {
-        const P4 p = placed[st + q];
-        P4 nq{};
-        if (has_nrm) nq = placed_nrm[st + q];
-        acc.add(p, has_nrm, nq);
+      for (int q = 0; q < len; q += 4) {  // four points' loads in flight together (clamped), added in order
+        P4 pp[4], nn[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = st + min(q + u, len - 1);
+          pp[u] = placed[idx];
+          nn[u] = has_nrm ? placed_nrm[idx] : pp[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (q + u < len) acc.add(pp[u], has_nrm, nn[u]);
       }
     }
     P4 op, on;
@@ -578,9 +624,9 @@ __global__ __launch_bounds__(kBlock) void pm_group_kernel(PmDev m, CountRef g_in
     if (fresh) {
       s = pm_new_slot(m);
       if (s < 0) continue;
-      m.hnext[s] = m.hhead[e];  // (this thread is the only one that touches this voxel's chain in this launch)
-      m.hhead[e] = s;
-      if (n_live > 0 && !(atomicOr(&m.hflag[e], 1u) & 1u)) pm_push64(m.multi[1], m.counters + kPmMultiOut, m.list_cap, key, m.counters + kPmError);
+      m.slot[s].hnext = m.h[e].head;  // (this thread is the only one that touches this voxel's chain in this launch)
+      m.h[e].head = s;
+      if (n_live > 0 && !(atomicOr(&m.h[e].info, 1u) & 1u)) pm_push64(m.multi[1], m.counters + kPmMultiOut, m.list_cap, key, m.counters + kPmError);
     }
     pm_store(m, s, op, on, has_nrm, t_now, key, fresh);
     if (fresh) pm_row_push(m, s, pm_key(op, m.inv_voxel));  // (the cell of where the mean really is: pm_check_face re-hashes it if that is another voxel)
@@ -591,12 +637,12 @@ __global__ __launch_bounds__(kBlock) void pm_group_kernel(PmDev m, CountRef g_in
 // unlink slot s from the chain of hash entry e (serial contexts only)
 __device__ __forceinline__ void pm_unlink(const PmDev& m, unsigned int e, int s) {
   int prev = -1;
-  for (int c = m.hhead[e]; c != -1; prev = c, c = m.hnext[c]) {
+  for (int c = m.h[e].head; c != -1; prev = c, c = m.slot[c].hnext) {
     if (c != s) continue;
     if (prev == -1)
-      m.hhead[e] = m.hnext[c];
+      m.h[e].head = m.slot[c].hnext;
     else
-      m.hnext[prev] = m.hnext[c];
+      m.slot[prev].hnext = m.slot[c].hnext;
     return;
   }
 }
@@ -612,7 +658,8 @@ struct PmOld {
 template <typename P4>
 __device__ __forceinline__ int pm_gather_old(const PmDev& m, unsigned int e, const CropDev& crop, int t_now, PmOld& o /* LDS */) {
   int n = 0;
-  for (int s = m.hhead[e]; s != -1; s = m.hnext[s]) {
+  for (int s = m.h[e].head; s != -1; s = m.slot[s].hnext) {
+    if (m.slot[s].flags & kPmDead) continue;
     const P4 p = ((const P4*)m.pts)[s];
     if (!crop_contains(crop, (double)p.x, (double)p.y, (double)p.z)) continue;
     if (n == kPmMaxOld) return kPmMaxOld + 1;  // more than the sorted list holds: pm_merge_many
@@ -629,7 +676,7 @@ __device__ __forceinline__ int pm_gather_old(const PmDev& m, unsigned int e, con
 }
 template <typename P4>
 __device__ __forceinline__ void pm_merge_old(const PmDev& m, unsigned int e, unsigned long long key, const PmOld& o, int n_old, int group /* -1: no scan points */,
-                                             const int2* __restrict__ piece, const uint32_t* __restrict__ starts, const int* __restrict__ run_len,
+                                             const int2* __restrict__ piece, const int* __restrict__ run_next, const int* __restrict__ run_len,
                                              const P4* __restrict__ placed, const P4* __restrict__ placed_nrm, int t_now) {
   const bool has_nrm = m.nrm != nullptr;
   PmAcc acc;
@@ -640,9 +687,11 @@ __device__ __forceinline__ void pm_merge_old(const PmDev& m, unsigned int e, uns
     acc.add(p, has_nrm, q);
   }
   if (group >= 0) {
-    const int2 pc = piece[group];
+    const int2 pc = piece[group];  // {head of the run list, number of runs}
+    int prev = -1;
     for (int j = 0; j < pc.y; ++j) {
-      const uint32_t st = starts[pc.x + j];
+      const int st = next_run(run_next, pc.x, prev);
+      prev = st;
       const int len = run_len[st];
       for (int q = 0; q < len; ++q) {
         P4 nq{};
@@ -664,7 +713,7 @@ __device__ __forceinline__ void pm_merge_old(const PmDev& m, unsigned int e, uns
 // voxel): no list -- the member next in order is looked for again for every addend (quadratic in the members; such voxels are few)
 template <typename P4>
 __device__ __forceinline__ void pm_merge_many(const PmDev& m, unsigned int e, unsigned long long key, const CropDev& crop, int group,
-                                              const int2* __restrict__ piece, const uint32_t* __restrict__ starts, const int* __restrict__ run_len,
+                                              const int2* __restrict__ piece, const int* __restrict__ run_next, const int* __restrict__ run_len,
                                               const P4* __restrict__ placed, const P4* __restrict__ placed_nrm, int t_now) {
   const bool has_nrm = m.nrm != nullptr;
   PmAcc acc;
@@ -673,7 +722,8 @@ __device__ __forceinline__ void pm_merge_many(const PmDev& m, unsigned int e, un
   for (bool any = false;; any = true) {
     int best = -1;
     unsigned long long bh = ~0ull, bl = ~0ull;
-    for (int s = m.hhead[e]; s != -1; s = m.hnext[s]) {
+    for (int s = m.h[e].head; s != -1; s = m.slot[s].hnext) {
+      if (m.slot[s].flags & kPmDead) continue;
       const P4 p = ((const P4*)m.pts)[s];
       if (!crop_contains(crop, (double)p.x, (double)p.y, (double)p.z)) continue;
       unsigned long long h, l;
@@ -691,9 +741,11 @@ __device__ __forceinline__ void pm_merge_many(const PmDev& m, unsigned int e, un
   }
   if (first == -1) return;
   if (group >= 0) {
-    const int2 pc = piece[group];
+    const int2 pc = piece[group];  // {head of the run list, number of runs}
+    int prev = -1;
     for (int j = 0; j < pc.y; ++j) {
-      const uint32_t st = starts[pc.x + j];
+      const int st = next_run(run_next, pc.x, prev);
+      prev = st;
       const int len = run_len[st];
       for (int q = 0; q < len; ++q) {
         P4 nq{};
@@ -704,10 +756,10 @@ __device__ __forceinline__ void pm_merge_many(const PmDev& m, unsigned int e, un
   }
   P4 op, on;
   acc.mean(&op, &on);
-  for (int s = m.hhead[e]; s != -1;) {  // the other members inside the volume die
-    const int nxt = m.hnext[s];
+  for (int s = m.h[e].head; s != -1;) {  // the other members inside the volume die
+    const int nxt = m.slot[s].hnext;
     const P4 p = ((const P4*)m.pts)[s];
-    if (s != first && crop_contains(crop, (double)p.x, (double)p.y, (double)p.z)) {
+    if (s != first && !(m.slot[s].flags & kPmDead) && crop_contains(crop, (double)p.x, (double)p.y, (double)p.z)) {
       pm_unlink(m, e, s);
       pm_kill<P4>(m, s);
     }
@@ -718,7 +770,7 @@ __device__ __forceinline__ void pm_merge_many(const PmDev& m, unsigned int e, un
 }
 
 template <typename P4>
-__global__ __launch_bounds__(64) void pm_merge_kernel(PmDev m, const int2* __restrict__ piece, const uint32_t* __restrict__ starts, const int* __restrict__ run_len,
+__global__ __launch_bounds__(64) void pm_merge_kernel(PmDev m, const int2* __restrict__ piece, const int* __restrict__ run_next, const int* __restrict__ run_len,
                                                       const P4* __restrict__ placed, const P4* __restrict__ placed_nrm,
                                                       const unsigned long long* __restrict__ group_key /* [groups] key of group r */, CropDev crop, int t_now) {
   __shared__ PmOld s_old[64];
@@ -733,9 +785,9 @@ __global__ __launch_bounds__(64) void pm_merge_kernel(PmDev m, const int2* __res
       const unsigned int e = pm_entry(m, key);
       const int n_old = pm_gather_old<P4>(m, e, crop, t_now, o);
       if (n_old > kPmMaxOld)
-        pm_merge_many<P4>(m, e, key, crop, r, piece, starts, run_len, placed, placed_nrm, t_now);
+        pm_merge_many<P4>(m, e, key, crop, r, piece, run_next, run_len, placed, placed_nrm, t_now);
       else
-        pm_merge_old<P4>(m, e, key, o, n_old, r, piece, starts, run_len, placed, placed_nrm, t_now);
+        pm_merge_old<P4>(m, e, key, o, n_old, r, piece, run_next, run_len, placed, placed_nrm, t_now);
       continue;
     }
     // a voxel on the multi list.  One the scan touched has been dealt with: its group saw the whole chain (a complex group of this very
@@ -743,30 +795,31 @@ __global__ __launch_bounds__(64) void pm_merge_kernel(PmDev m, const int2* __res
     const unsigned long long key = m.multi[0][i - n_complex];
     const unsigned int e = pm_find(m, key);
     if (e == ~0u) continue;
-    bool touched = m.hmark[e] == t_now;  // a voxel pm_group_kernel handed to the other branch of this launch
+    bool touched = (int)(m.h[e].info >> 8) == t_now;  // a voxel pm_group_kernel handed to the other branch of this launch
     if (touched) {
       pm_push64(m.multi[1], m.counters + kPmMultiOut, cap, key, err);  // (stays listed; settled at the next insertion)
       continue;
     }
     int live = 0, inside = 0;  // one walk: members, members inside the volume, written by this insertion?
-    for (int s = m.hhead[e]; s != -1; s = m.hnext[s]) {
+    for (int s = m.h[e].head; s != -1; s = m.slot[s].hnext) {
+      if (m.slot[s].flags & kPmDead) continue;
       ++live;
-      touched |= m.stamp[s] == t_now && !(m.okey[s] & kPmRaw);
+      touched |= m.slot[s].stamp == t_now && !(m.slot[s].okey & kPmRaw);
       const P4 p = ((const P4*)m.pts)[s];
       inside += crop_contains(crop, (double)p.x, (double)p.y, (double)p.z) ? 1 : 0;
     }
     if (!touched && inside > 1) {
       const int n_old = pm_gather_old<P4>(m, e, crop, t_now, o);
       if (n_old > kPmMaxOld)
-        pm_merge_many<P4>(m, e, key, crop, -1, piece, starts, run_len, placed, placed_nrm, t_now);
+        pm_merge_many<P4>(m, e, key, crop, -1, piece, run_next, run_len, placed, placed_nrm, t_now);
       else if (n_old > 1)
-        pm_merge_old<P4>(m, e, key, o, n_old, -1, piece, starts, run_len, placed, placed_nrm, t_now);
+        pm_merge_old<P4>(m, e, key, o, n_old, -1, piece, run_next, run_len, placed, placed_nrm, t_now);
       live -= inside - 1;
     }
     if (live > 1)
       pm_push64(m.multi[1], m.counters + kPmMultiOut, cap, key, err);
     else
-      m.hflag[e] &= ~1u;
+      m.h[e].info &= ~1u;
   }
 }
 
@@ -783,16 +836,16 @@ __global__ __launch_bounds__(kBlock) void pm_misc_kernel(PmDev m, const P4* __re
   const int n_uns = min(m.counters[kPmUnsettledIn], cap);
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_uns; i += gridDim.x * kBlock) {
     const int s = m.unsettled[0][i];
-    const unsigned char fl = m.flags[s];
-    if ((fl & kPmDead) || !(fl & kPmUnsettled) || m.stamp[s] == t_now) continue;  // (a slot written now was listed again by pm_store if need be)
+    const unsigned int fl = m.slot[s].flags;
+    if ((fl & kPmDead) || !(fl & kPmUnsettled) || m.slot[s].stamp == t_now) continue;  // (a slot written now was listed again by pm_store if need be)
     const P4 p = ((const P4*)m.pts)[s];
     if (crop_contains(crop, (double)p.x, (double)p.y, (double)p.z)) {
       const P4 nv = ((const P4*)m.nrm)[s];
       const P4 nn = pm_renormalized(nv);
       ((P4*)m.nrm)[s] = nn;
-      ((P4*)m.snrm)[m.pos[s]] = nn;
+      ((P4*)m.snrm)[m.slot[s].pos] = nn;
       if (pm_same_bits(pm_renormalized(nn), nn)) {
-        m.flags[s] = fl & ~kPmUnsettled;
+        m.slot[s].flags = fl & ~kPmUnsettled;
         continue;
       }
     }
@@ -813,20 +866,20 @@ __global__ __launch_bounds__(kBlock) void pm_misc_kernel(PmDev m, const P4* __re
       on = placed_nrm[si];
       ((P4*)m.nrm)[s] = on;
     }
-    m.stamp[s] = t_now;
-    m.okey[s] = kPmRaw | (unsigned long long)si;
-    unsigned char fl = kPmFresh;
+    m.slot[s].stamp = t_now;
+    m.slot[s].okey = kPmRaw | (unsigned long long)si;
+    unsigned int fl = kPmFresh;
     if (has_nrm && !pm_same_bits(pm_renormalized(on), on)) {
       fl |= kPmUnsettled;
       pm_push(m.unsettled[1], m.counters + kPmUnsettledOut, cap, s, err);
     }
-    m.flags[s] = fl;
+    m.slot[s].flags = fl;
     const unsigned int e = pm_entry(m, key);
-    m.hnext[s] = m.hhead[e];
-    const bool had = m.hhead[e] != -1;
-    m.hhead[e] = s;
-    if (had && !(m.hflag[e] & 1u)) {
-      m.hflag[e] |= 1u;
+    m.slot[s].hnext = m.h[e].head;
+    const bool had = m.h[e].head != -1;
+    m.h[e].head = s;
+    if (had && !(m.h[e].info & 1u)) {
+      m.h[e].info |= 1u;
       pm_push64(m.multi[1], m.counters + kPmMultiOut, cap, key, err);
     }
     pm_row_push(m, s, key);
@@ -834,24 +887,24 @@ __global__ __launch_bounds__(kBlock) void pm_misc_kernel(PmDev m, const P4* __re
   const int n_rel = min(m.counters[kPmRelink], cap);
   for (int i = 0; i < n_rel; ++i) {
     const int s = m.relink[i];
-    if (m.flags[s] & kPmDead) continue;
+    if (m.slot[s].flags & kPmDead) continue;
     const P4 p = ((const P4*)m.pts)[s];
-    const unsigned long long k_old = m.okey[s], k_new = pm_key(p, m.inv_voxel);
+    const unsigned long long k_old = m.slot[s].okey, k_new = pm_key(p, m.inv_voxel);
     pm_unlink(m, pm_entry(m, k_old), s);
     const unsigned int e = pm_entry(m, k_new);
-    const bool had = m.hhead[e] != -1;
-    m.hnext[s] = m.hhead[e];
-    m.hhead[e] = s;
-    if (had && !(m.hflag[e] & 1u)) {
-      m.hflag[e] |= 1u;
+    const bool had = m.h[e].head != -1;
+    m.slot[s].hnext = m.h[e].head;
+    m.h[e].head = s;
+    if (had && !(m.h[e].info & 1u)) {
+      m.h[e].info |= 1u;
       pm_push64(m.multi[1], m.counters + kPmMultiOut, cap, k_new, err);
     }
-    if (!(m.flags[s] & kPmFresh)) {  // in the index, in the cell of its old voxel (a new slot is listed under the cell it really is in)
+    if (!(m.slot[s].flags & kPmFresh)) {  // in the index, in the cell of its old voxel (a new slot is listed under the cell it really is in)
       using R = typename Scalar<P4>::type;
       P4 far;
       far.x = far.y = far.z = sizeof(R) == 4 ? (R)3.0e38f : (R)1.0e300;
       far.i = (typename Scalar<P4>::index)0x7fffffff;
-      ((P4*)m.spts)[m.pos[s]] = far;
+      ((P4*)m.spts)[m.slot[s].pos] = far;
       pm_row_push(m, s, k_new);
     }
   }
@@ -964,7 +1017,7 @@ __global__ __launch_bounds__(kBlock) void pm_rows_kernel(PmDev m) {
         qq.x = q.x, qq.y = q.y, qq.z = q.z, qq.i = q.i;
         ((P4*)m.spts)[dst] = pp;
         if (has_nrm) ((P4*)m.snrm)[dst] = qq;
-        if ((int)p.i != 0x7fffffff) m.pos[(int)p.i] = dst;
+        if ((int)p.i != 0x7fffffff) m.slot[(int)p.i].pos = dst;
       }
       __syncthreads();
     }
@@ -994,8 +1047,8 @@ __global__ __launch_bounds__(kBlock) void pm_place_new_kernel(PmDev m) {
     p.i = (typename Scalar<P4>::index)s;
     ((P4*)m.spts)[dst] = p;
     if (has_nrm) ((P4*)m.snrm)[dst] = ((const P4*)m.nrm)[s];
-    m.pos[s] = dst;
-    m.flags[s] &= (unsigned char)~kPmFresh;
+    m.slot[s].pos = dst;
+    m.slot[s].flags &= ~kPmFresh;
   }
 }
 
@@ -1009,15 +1062,121 @@ __global__ __launch_bounds__(64) void pm_turn_kernel(PmDev m, CountPub pub, Crop
     host_vals[0] = (double)c[kPmPoolTop];
     host_vals[1] = (double)c[kPmDeadCnt];
     host_vals[2] = (double)c[kPmError];
-    host_vals[3] = (double)c[kPmMultiOut];      // (diagnostics: sizes of the lists the next insertion walks, slots that entered the index)
-    host_vals[4] = (double)c[kPmUnsettledOut];
-    host_vals[5] = (double)c[kPmNew];
+    host_vals[3] = (double)c[kPmMultiOut];  // (diagnostics: voxels with several members, voxels of this scan with several old members inside)
+    host_vals[4] = (double)c[kPmComplex];
+    host_vals[5] = (double)c[kPmClamped];   // slots outside the index grid so far
   }
   c[kPmUnsettledIn] = min(c[kPmUnsettledOut], m.list_cap);
   c[kPmUnsettledOut] = 0;
   c[kPmMultiIn] = min(c[kPmMultiOut], m.list_cap);
   c[kPmMultiOut] = 0;
   c[kPmComplex] = c[kPmOutside] = c[kPmRelink] = c[kPmTouched] = c[kPmNew] = 0;
+  publish_count(pub, c[kPmN]);
+}
+
+// ---- Submap::carve (Submap.cpp:109-125 -> getIdxsOfCarvedPoints, helpers.cpp:235-271) on the persistent form -----------------------------
+// The reference bins the map points inside the cropping volume by voxel and lets every scan ray probe that table; here the table exists
+// already -- the voxel hash, when the carving voxel is the map's voxel (the shipped configuration: 0.1 m both).  Same rays, same samples
+// (carve_rays_kernel's arithmetic), same test per point (inside the volume; |ray . unit normal| > min_dot or no normals); a point that
+// goes is marked, listed once, and killed by pm_carve_apply_kernel: dead flag, its index entry replaced by the far sentinel.  It stays
+// in its chain (many rays reach one voxel at the same time: no unlinking here), chain walks skip the dead, the next fold drops them.
+// The survivors keep their order by construction: the order is a function of the slots' histories (pm_view_key), not of an array.
+__global__ __launch_bounds__(kBlock) void pm_carve_bits_kernel(const PmHash* __restrict__ hh, size_t n, unsigned int* __restrict__ block_bits) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const PmHash e = hh[i];
+    if (e.key == kEmptyKey || e.head == -1) continue;
+    const unsigned int bit = carve_block_bit(e.key);
+    atomicOr(&block_bits[bit >> 5], 1u << (bit & 31u));
+  }
+}
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void pm_carve_rays_kernel(PmDev m, const P4* __restrict__ scan, size_t n_scan, Mat34 M /* map <- sensor */, double sx,
+                                                               double sy, double sz, double max_len, double trunc, double min_dot, CropDev crop,
+                                                               const unsigned int* __restrict__ block_bits) {
+  const double voxel = m.voxel, inv = 1.0 / voxel;
+  const bool has_nrm = m.nrm != nullptr;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n_scan; i += (size_t)gridDim.x * kBlock) {
+    const P4 q = scan[i];
+    const double x = (double)q.x, y = (double)q.y, z = (double)q.z;
+    const double px = M.m[0] * x + M.m[1] * y + M.m[2] * z + M.m[3], py = M.m[4] * x + M.m[5] * y + M.m[6] * z + M.m[7],
+                 pz = M.m[8] * x + M.m[9] * y + M.m[10] * z + M.m[11];
+    const double dx = px - sx, dy = py - sy, dz = pz - sz;
+    const double length = sqrt(dx * dx + dy * dy + dz * dz);
+    if (!(length > 0.0)) continue;
+    const double ux = dx / length, uy = dy / length, uz = dz / length;
+    const double lim = fmax(voxel, fmin(length - trunc, max_len));
+    constexpr int kBatch = 8;
+    double dist = 0.0;
+    while (dist < lim) {
+      unsigned long long ks[kBatch];
+      unsigned int bits[kBatch], words[kBatch];
+      int nb = 0;
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u)
+        if (dist < lim) {
+          const double cx = dist * ux + sx, cy = dist * uy + sy, cz = dist * uz + sz;
+          ks[u] = pack_key((long long)(int)floor(cx * inv), (long long)(int)floor(cy * inv), (long long)(int)floor(cz * inv));
+          bits[u] = carve_block_bit(ks[u]);
+          dist += voxel;
+          nb = u + 1;
+        }
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u)
+        if (u < nb) words[u] = block_bits[bits[u] >> 5];
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        if (u >= nb) break;
+        if (!((words[u] >> (bits[u] & 31u)) & 1u)) continue;  // nothing of the map in this block of voxels
+        const unsigned int e = pm_find(m, ks[u]);
+        if (e == ~0u) continue;
+        for (int s = m.h[e].head; s != -1; s = m.slot[s].hnext) {
+          const unsigned int fl = m.slot[s].flags;
+          if (fl & (kPmDead | kPmCarved)) continue;
+          const P4 p = ((const P4*)m.pts)[s];
+          if (!crop_contains(crop, (double)p.x, (double)p.y, (double)p.z)) continue;  // (the reference's table holds the points inside the volume)
+          bool rem = true;
+          if (has_nrm) {
+            const P4 nn = ((const P4*)m.nrm)[s];
+            const double a = (double)nn.x, bb = (double)nn.y, c = (double)nn.z;
+            const double nl = sqrt(a * a + bb * bb + c * c);
+            const double dot = nl > 0.0 ? (ux * a + uy * bb + uz * c) / nl : 0.0;  // Eigen normalized(): the zero vector stays zero
+            rem = fabs(dot) > min_dot;
+          }
+          if (rem && !(atomicOr(&m.slot[s].flags, kPmCarved) & kPmCarved))
+            pm_push(m.new_slots, m.counters + kPmCarvedCnt, m.list_cap, s, m.counters + kPmError);
+        }
+      }
+    }
+  }
+}
+template <typename P4>
+__global__ __launch_bounds__(kBlock) void pm_carve_apply_kernel(PmDev m, CountPub pub, double* __restrict__ host_vals) {
+  using R = typename Scalar<P4>::type;
+  const int n = min(m.counters[kPmCarvedCnt], m.list_cap);
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const int s = m.new_slots[i];
+    m.slot[s].flags = kPmDead;
+    P4 far;
+    far.x = far.y = far.z = sizeof(R) == 4 ? (R)3.0e38f : (R)1.0e300;
+    far.i = (typename Scalar<P4>::index)0x7fffffff;
+    ((P4*)m.spts)[m.slot[s].pos] = far;
+  }
+  // (the last workgroup to get here would be the place to fold the count into the dead counter; done by pm_carve_finish_kernel, one launch on)
+  (void)pub;
+  (void)host_vals;
+}
+__global__ __launch_bounds__(64) void pm_carve_finish_kernel(PmDev m, CountPub pub, double* __restrict__ host_vals) {
+  if (threadIdx.x != 0) return;
+  int* c = m.counters;
+  const int n = min(c[kPmCarvedCnt], m.list_cap);
+  c[kPmDeadCnt] += n;
+  c[kPmCarvedCnt] = 0;
+  host_vals[0] = (double)c[kPmPoolTop];
+  host_vals[1] = (double)c[kPmDeadCnt];
+  host_vals[2] = (double)c[kPmError];
+  host_vals[3] = (double)n;  // removed by this carve
+  host_vals[4] = 0.0;
+  host_vals[5] = (double)c[kPmClamped];
   publish_count(pub, c[kPmN]);
 }
 
@@ -1029,7 +1188,7 @@ __global__ __launch_bounds__(kBlock) void pm_view_key_kernel(PmDev m, int n, int
   unsigned long long cnt = 0;
   for (int s = blockIdx.x * kBlock + threadIdx.x; s < n; s += gridDim.x * kBlock) {
     unsigned long long h = ~0ull, l = ~0ull;
-    if (!(m.flags[s] & kPmDead)) {
+    if (!(m.slot[s].flags & kPmDead)) {
       pm_view_key<P4>(m, s, t_last, &h, &l);
       if (!(h >> 63)) ++cnt;
     }

@@ -107,17 +107,19 @@ class Submap:
             self.be.build_index(self.mapCloud_.id, icp.maxCorrespondenceDistance_)
             return True
         if isPerformCarving:  # Submap.cpp:56-60 (the cropper still holds the pose of the previous insertion, as in the reference)
-            self.carve(rawScan, self.mapToRangeSensor_)
+            self.carve(rawScan, self.mapToRangeSensor_, want_count=False)
         self.mapBuilderCropper_.setPose(self.mapToRangeSensor_)
         self.be.map_insert_scan(self.mapCloud_.id, preProcessedScan.id, self.mapToRangeSensor_, self.params_.mapBuilder_.mapVoxelSize_,
                                 self.mapBuilderCropper_.to_abi(), max_corr_hint=icp.maxCorrespondenceDistance_)
         self.nScansInsertedMap_ += 1
         return True
 
-    def carve(self, rawScan: PointCloud, mapToRangeSensor) -> int:
-        """Submap::carve (Submap.cpp:109-125): only every carveSpaceEveryNscans_-th insertion, never on an empty map."""
+    def carve(self, rawScan: PointCloud, mapToRangeSensor, want_count: bool = True):
+        """Submap::carve (Submap.cpp:109-125): only every carveSpaceEveryNscans_-th insertion, never on an empty map.  Returns the number of
+        removed points (the reference returns nothing; want_count=False does not wait for it)."""
         c = self.params_.mapBuilder_.carving_
         if self.mapCloud_.IsEmpty() or not (self.nScansInsertedMap_ % c.carveSpaceEveryNscans_ == 1):
             return 0
         return self.be.map_carve(self.mapCloud_.id, rawScan.id, mapToRangeSensor, self.mapBuilderCropper_.to_abi(), voxel=c.voxelSize_,
-                                 max_length=c.maxRaytracingLength_, truncation=c.truncationDistance_, min_dot=c.minDotProductWithNormal_)
+                                 max_length=c.maxRaytracingLength_, truncation=c.truncationDistance_, min_dot=c.minDotProductWithNormal_,
+                                 want_count=want_count)

@@ -1159,7 +1159,7 @@ def test_crop_voxel_down_sample_is_crop_then_voxel_bit_for_bit(backend_f64, back
         be.free(c)
 
 
-def _insert_sequence(be, n_frames, rmax, voxel, carve_at=(), look_at=None, scan_rmax=None):
+def _insert_sequence(be, n_frames, rmax, voxel, carve_at=(), look_at=None, scan_rmax=None, carve_voxel=0.1):
     """a short mapping run: scans along an out-and-back path (points leave the map builder's volume and come back), returns the map
     after every insertion (look_at: after these insertions only -- a map in its persistent form folds back into an array when somebody
     looks, so looking rarely is what exercises its history) as raw bytes; scan_rmax: the scans are cropped to this range first"""
@@ -1178,7 +1178,7 @@ def _insert_sequence(be, n_frames, rmax, voxel, carve_at=(), look_at=None, scan_
         be.estimate_normals(v, 2.0, 10)
         crop = backend.make_crop(backend.CROP_MIN_MAX_RADIUS, center=T[:3, 3], rmin=0.0, rmax=rmax)
         if k in carve_at:
-            be.map_carve(m, s, T, crop)
+            be.map_carve(m, s, T, crop, voxel=carve_voxel)
         be.map_insert_scan(m, v, T, voxel, crop, max_corr_hint=1.0)
         if look_at is None or k in look_at:
             p, n = be.download(m)
@@ -1259,7 +1259,7 @@ def test_map_merge_by_merging_is_bitwise_the_full_sort(prec, monkeypatch):
 
 
 @pytest.mark.parametrize("prec", ["f64", "f32"])
-@pytest.mark.parametrize("case", ["look_rarely", "scan_inside_volume", "never_until_the_end"])
+@pytest.mark.parametrize("case", ["look_rarely", "scan_inside_volume", "never_until_the_end", "carved_in_place"])
 def test_persistent_map_is_bitwise_the_array_form(prec, case):
     """Submap::insertScan in time independent of the map's size (map_kernels.hpp): from its second insertion on a map lives in slot
     arrays + a voxel hash + a row-paged search index, an insertion touches only the voxels the scan falls into, and the reference's array
@@ -1275,7 +1275,9 @@ def test_persistent_map_is_bitwise_the_array_form(prec, case):
 
     p = backend.PRECISION_F64 if prec == "f64" else backend.PRECISION_F32
     kw = {"look_rarely": dict(look_at=(3, 4, 11, 17, 23), carve_at=(14,)), "scan_inside_volume": dict(look_at=(7, 15, 23), scan_rmax=11.5),
-          "never_until_the_end": dict(look_at=(23,))}[case]
+          "never_until_the_end": dict(look_at=(23,)),
+          # the carving voxel is the map's voxel: the persistent map is carved where it is (its voxel hash is the reference's table), twice
+          "carved_in_place": dict(look_at=(5, 12, 23), carve_at=(8, 16), carve_voxel=0.2)}[case]
     code = ("import sys, pickle; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_preprocess_map_gpu as t; from open3d_slam_amd import backend; "
             "be = backend.Backend(0, %d, ab=True); sys.stdout.buffer.write(pickle.dumps(t._insert_sequence(be, 24, 12.0, 0.2, **%r)))"
             % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), p, kw))
