@@ -147,6 +147,7 @@ struct DeviceRef {
 class ScanOnDevice : public PointCloud {
  public:
   std::shared_ptr<const DeviceRef> device_;
+  std::shared_ptr<const DeviceRef> before_draw_;  // the cloud before its RandomDownSample, kept for the other worker (preprocessScan's memo)
 };
 // Guards against a caller that edits the host arrays after the device copy was made (the copy would be stale): sizes, presence of
 // normals / colours and the bits of up to 64 evenly spaced points, normals and colours.  Not a proof of equality: open3d_slam's own flow
@@ -336,32 +337,55 @@ inline std::shared_ptr<PointCloud> adopt(const std::shared_ptr<HandleBox>& box, 
 }
 // ScanToMapIcp::preprocess (ScanToMapRegistration.cpp:35-40) and LidarOdometry::preprocess (Odometry.cpp:25-30):
 //   cropper->crop(in); voxelize(voxelSize, cropped); estimateNormalsOrCovariancesIfNeeded(cropped); cropped->RandomDownSample(ratio)
-// LidarOdometry::preprocess (Odometry.cpp:25-30) and ScanToMapIcp::preprocess (ScanToMapRegistration.cpp:35-40) run the same chain on
-// the same raw scan, and the shipped configuration gives them the same parameters (parameter_structure_definitions.lua: both
-// `scan_processing` blocks and the map builder's `scan_cropping` are copies of one table).  Without random down-sampling (ratio >= 1) the
-// second caller therefore gets the first caller's cloud -- the same object, read-only for both as in the patched flow (the odometry copies
-// it into cloudPrev_, the mapper crops / registers / inserts it), with its device copy (a caller on another handle copies it device to
-// device, DeviceCloud).  The memo holds ONE entry weakly: it lives as long as a caller still holds the cloud (the odometry does until
-// the next scan).  The key is the raw scan's size and fingerprint (64 sampled points) and every parameter of the chain.
-// O3DS_SHARE_PREPROCESS=0 computes it twice, as the reference does.
+// Both run this chain on the same raw scan, and the shipped configuration gives them the same parameters
+// (parameter_structure_definitions.lua: both `scan_processing` blocks and the map builder's `scan_cropping` are copies of one table), so the
+// second caller gets what the first computed UP TO the RandomDownSample -- the crop, the voxel grid and the normal estimation are the
+// expensive steps; each caller draws its own index list afterwards, as in the reference (at the shipped ratio of 0.3 as well as at 1).
+// WHICH scan a call is about is said by the reference itself: both seams receive the scan's Time stamp (Odometry.hpp:27 addRangeScan(cloud,
+// timestamp), Mapper.hpp:47 addRangeMeasurement(cloud, timestamp)); the patched call sites pass it on (setScanStamp) and the memo is keyed
+// on it, the raw scan's size and every parameter of the chain.  Without a stamp (a caller that does not say) nothing is shared.
+// The memo holds ONE entry weakly: it lives as long as a caller still holds the cloud (the odometry does until the next scan).
+// O3DS_SHARE_PREPROCESS=0 computes everything twice, as the reference does.
+inline int64_t& scanStamp() {  // of the calling thread: set by the patched addRangeScan / addRangeMeasurement, 0 = unknown
+  static thread_local int64_t stamp = 0;
+  return stamp;
+}
+inline void setScanStamp(int64_t ticks) { scanStamp() = ticks; }
+struct ScanStampScope {  // for the duration of a seam call
+  int64_t saved;
+  explicit ScanStampScope(int64_t ticks) : saved(scanStamp()) { scanStamp() = ticks; }
+  ~ScanStampScope() { scanStamp() = saved; }
+};
 struct PreprocessMemo {
   std::mutex m;
-  uint64_t stamp = 0;
+  int64_t stamp = 0;
   size_t n = 0;
   ScanChain chain{};
-  std::weak_ptr<PointCloud> result;
+  std::weak_ptr<PointCloud> result;            // ratio >= 1: the finished cloud (host arrays + device copy), the same object for both callers
+  std::weak_ptr<const DeviceRef> before_draw;  // ratio < 1: the cloud before RandomDownSample, on the device only
 };
 inline PreprocessMemo& preprocessMemo() {
   static PreprocessMemo memo;
   return memo;
 }
-inline bool sameChain(const ScanChain& a, const ScanChain& b) {
+inline bool sameChain(const ScanChain& a, const ScanChain& b) {  // everything in front of the RandomDownSample
   return std::memcmp(&a.crop, &b.crop, sizeof(o3ds_crop)) == 0 && a.voxelSize == b.voxelSize && a.estimateNormals == b.estimateNormals &&
-         a.normalRadius == b.normalRadius && a.normalKnn == b.normalKnn && a.downSamplingRatio == b.downSamplingRatio;
+         a.normalRadius == b.normalRadius && a.normalKnn == b.normalKnn;
 }
 inline bool sharePreprocess() {
   static const bool on = !(std::getenv("O3DS_SHARE_PREPROCESS") && std::atoi(std::getenv("O3DS_SHARE_PREPROCESS")) == 0);
   return on;
+}
+
+// [O3D] RandomDownSample(ratio) of a device cloud of n points: shuffled indices, the first int(ratio * n) kept (SelectByIndex)
+inline o3ds_cloud drawOnDevice(o3ds_handle h, o3ds_cloud cloud, size_t n, double ratio) {
+  std::vector<uint32_t> idx(n);
+  std::iota(idx.begin(), idx.end(), 0u);
+  std::shuffle(idx.begin(), idx.end(), downSampleGenerator());
+  idx.resize((size_t)(int)(ratio * (double)n));
+  o3ds_cloud kept = 0;
+  check(h, o3ds_select_by_index(h, cloud, idx.data(), idx.size(), &kept));
+  return kept;
 }
 
 // One upload of the raw scan, the chain on the device, one download; the result stays on the device behind the returned cloud.
@@ -378,34 +402,75 @@ inline std::shared_ptr<PointCloud> preprocessScan(const PointCloud& raw, const S
   std::lock_guard<std::recursive_mutex> lck(box->m);
   const o3ds_handle h = box->h.get();
   if (raw.points_.empty()) return std::make_shared<PointCloud>();
-  const bool share = sharePreprocess() && p.downSamplingRatio >= 1.0;
-  uint64_t stamp = 0;
-  if (share) {
-    stamp = fingerprint(raw);
+  const int64_t stamp = scanStamp();
+  const bool share = sharePreprocess() && stamp != 0;
+  const bool draw = p.downSamplingRatio < 1.0;
+  if (share) {  // what the other worker made of this very scan
     PreprocessMemo& memo = preprocessMemo();
-    std::lock_guard<std::mutex> ml(memo.m);
-    if (memo.stamp == stamp && memo.n == raw.points_.size() && sameChain(memo.chain, p))
-      if (std::shared_ptr<PointCloud> r = memo.result.lock()) return r;
+    std::shared_ptr<PointCloud> whole;
+    std::shared_ptr<const DeviceRef> before;
+    {
+      std::lock_guard<std::mutex> ml(memo.m);
+      if (memo.stamp == stamp && memo.n == raw.points_.size() && sameChain(memo.chain, p)) {
+        whole = memo.result.lock();
+        before = memo.before_draw.lock();
+      }
+    }
+    if (!draw && whole && memo.chain.downSamplingRatio >= 1.0) return whole;
+    if (draw && before && before->n > 0) {  // its cloud before the draw: here (or copied here device to device), then this caller's own draw
+      o3ds_cloud mine = 0, use = before->id;
+      bool ok = true;
+      if (before->box.get() != box.get()) {
+        std::unique_lock<std::recursive_mutex> other(before->box->m, std::try_to_lock);  // never wait for a second handle while holding one
+        ok = other.owns_lock() && o3ds_cloud_copy_across(h, before->box->h.get(), before->id, &mine) == O3DS_OK;
+        use = mine;
+      }
+      if (ok) {
+        o3ds_cloud kept = 0;
+        try {
+          kept = drawOnDevice(h, use, before->n, p.downSamplingRatio);
+          if (mine) o3ds_cloud_free(h, mine);
+          mine = 0;
+          return adopt(box, kept);
+        } catch (...) {
+          if (mine) o3ds_cloud_free(h, mine);
+          if (kept) o3ds_cloud_free(h, kept);
+          throw;
+        }
+      }
+    }
   }
   DeviceCloud in(h, box.get(), raw);
   o3ds_cloud cur = 0;
   check(h, o3ds_crop_voxel_down_sample(h, in.id(), &p.crop, p.voxelSize, &cur));
+  std::shared_ptr<DeviceRef> before;  // ratio < 1: keeps the cloud before the draw alive for the other worker
   try {
     size_t n = 0;
     check(h, o3ds_cloud_size(h, cur, &n, nullptr));
     if (p.estimateNormals && n > 0) check(h, o3ds_estimate_normals(h, cur, p.normalRadius, p.normalKnn));
-    if (p.downSamplingRatio < 1.0 && n > 0) {
-      std::vector<uint32_t> idx(n);
-      std::iota(idx.begin(), idx.end(), 0u);
-      std::shuffle(idx.begin(), idx.end(), downSampleGenerator());
-      idx.resize((size_t)(int)(p.downSamplingRatio * (double)n));
-      o3ds_cloud kept = 0;
-      check(h, o3ds_select_by_index(h, cur, idx.data(), idx.size(), &kept));
-      o3ds_cloud_free(h, cur);
-      cur = kept;
+    std::shared_ptr<PointCloud> out;
+    if (draw && n > 0) {
+      const o3ds_cloud kept = drawOnDevice(h, cur, n, p.downSamplingRatio);
+      if (share) {
+        before = std::make_shared<DeviceRef>();
+        before->box = box;
+        before->id = cur;
+        before->n = n;
+        cur = 0;  // (owned by `before` now)
+      } else {
+        o3ds_cloud_free(h, cur);
+        cur = 0;
+      }
+      try {
+        out = adopt(box, kept);
+      } catch (...) {
+        o3ds_cloud_free(h, kept);
+        throw;
+      }
+    } else {
+      out = adopt(box, cur);
+      cur = 0;  // (adopted)
     }
-    std::shared_ptr<PointCloud> out = adopt(box, cur);
-    cur = 0;  // (adopted)
     if (share) {
       PreprocessMemo& memo = preprocessMemo();
       std::lock_guard<std::mutex> ml(memo.m);
@@ -413,6 +478,10 @@ inline std::shared_ptr<PointCloud> preprocessScan(const PointCloud& raw, const S
       memo.n = raw.points_.size();
       memo.chain = p;
       memo.result = out;
+      memo.before_draw = before;
+      if (before) {  // the memo's entry lives as long as the caller's cloud does: the cloud carries the reference
+        if (ScanOnDevice* sd = dynamic_cast<ScanOnDevice*>(out.get())) sd->before_draw_ = before;
+      }
     }
     return out;
   } catch (...) {

@@ -99,6 +99,7 @@ class PointCloud:
     def __del__(self):
         try:
             if getattr(self.be, "h", None):
+                self._refs = 1  # (the object is going away: whatever holders forgot to release() cannot use it any more)
                 self.release()
         except Exception:
             pass

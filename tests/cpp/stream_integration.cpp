@@ -184,6 +184,7 @@ int main(int argc, char** argv) {
   const auto t0 = Clock::now();
   if (!threads) {
     for (int k = 0; k < frames && ok; ++k) {
+      const o3ds::ScanStampScope stamp(1000 + k);  // the scan's Time stamp, as the patched addRangeScan / addRangeMeasurement pass it on
       ok = odo.add(scans[k]);
       odomAt[k] = odo.cumulative;
       ok = ok && mapping.add(scans[k], odomAt[k]);
@@ -196,6 +197,7 @@ int main(int argc, char** argv) {
     bool odoOk = true;
     std::thread odometryWorker([&] {
       for (int k = 0; k < frames; ++k) {
+        const o3ds::ScanStampScope stamp(1000 + k);
         const bool good = odo.add(scans[k]);
         std::lock_guard<std::mutex> l(m);
         odomAt[k] = odo.cumulative;
@@ -212,6 +214,7 @@ int main(int argc, char** argv) {
           cv.wait(l, [&] { return odomDone > k; });
           odom = odomAt[k];
         }
+        const o3ds::ScanStampScope stamp(1000 + k);
         ok = mapping.add(scans[k], odom);
         mapAt[k] = mapping.T;
       }

@@ -4,6 +4,7 @@
 //   test_integration          : Seam 1 (registerClouds, estimateNormals), Seam 2 (registerScan), Seam 3 (insertScan, copy on write,
 //                               transform, carve) on the GPU, self-checked against each other and against analytic truth; the scan
 //                               chain (preprocessScan, cropScan) and scans that stay on the device between the seams (ScanOnDevice)
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -168,6 +169,7 @@ int main(int argc, char** argv) {
     chain.estimateNormals = true;
     chain.normalRadius = 1.0;
     chain.normalKnn = 20;
+    o3ds::setScanStamp(41);  // the scan's Time stamp, as the patched seams pass it on: what the pre-processing memo tells scans apart by
     std::shared_ptr<PointCloud> pre = o3ds::preprocessScan(raw, chain);
     CHECK(pre->points_.size() > 1000 && pre->points_.size() < raw.points_.size() && pre->HasNormals());
     CHECK(dynamic_cast<o3ds::ScanOnDevice*>(pre.get()) != nullptr);
@@ -178,15 +180,49 @@ int main(int argc, char** argv) {
       const PointCloud rawCopy = raw;
       CHECK(o3ds::preprocessScan(rawCopy, chain).get() == pre.get());
       std::shared_ptr<PointCloud> fromThread;
-      std::thread([&] { fromThread = o3ds::preprocessScan(rawCopy, chain); }).join();
+      std::thread([&] {
+        const o3ds::ScanStampScope sameScan(41);  // (the stamp is the calling thread's)
+        fromThread = o3ds::preprocessScan(rawCopy, chain);
+      }).join();
       CHECK(fromThread.get() == pre.get());
+      {  // a caller that does not say which scan it has shares nothing
+        const o3ds::ScanStampScope unknown(0);
+        CHECK(o3ds::preprocessScan(rawCopy, chain).get() != pre.get());
+      }
+      {  // RandomDownSample: the chain is shared up to the draw (a memo entry of its own scan), every caller draws for itself
+        const o3ds::ScanStampScope drawn(77);
+        o3ds::ScanChain third = chain;
+        third.downSamplingRatio = 0.3;
+        std::shared_ptr<PointCloud> a = o3ds::preprocessScan(rawCopy, third), b = o3ds::preprocessScan(rawCopy, third), c;
+        std::thread([&] {
+          const o3ds::ScanStampScope sameScan(77);
+          c = o3ds::preprocessScan(rawCopy, third);
+        }).join();
+        const size_t want = (size_t)(int)(0.3 * (double)pre->points_.size());
+        CHECK(a->points_.size() == want && b->points_.size() == want && c->points_.size() == want && a.get() != b.get());
+        size_t differ = 0;
+        for (size_t i = 0; i < want; ++i) differ += (a->points_[i][0] != b->points_[i][0] || a->points_[i][1] != b->points_[i][1] || a->points_[i][2] != b->points_[i][2]) ? 1 : 0;
+        CHECK(differ > want / 2);  // two draws
+        // every drawn point (and its normal) is a point of the undrawn cloud
+        std::vector<std::array<double, 6>> all(pre->points_.size());
+        for (size_t i = 0; i < all.size(); ++i)
+          all[i] = {pre->points_[i][0], pre->points_[i][1], pre->points_[i][2], pre->normals_[i][0], pre->normals_[i][1], pre->normals_[i][2]};
+        std::sort(all.begin(), all.end());
+        for (const std::shared_ptr<PointCloud>& d : {a, b, c})
+          for (size_t i = 0; i < want; i += 7) {
+            const std::array<double, 6> q = {d->points_[i][0], d->points_[i][1], d->points_[i][2], d->normals_[i][0], d->normals_[i][1], d->normals_[i][2]};
+            CHECK(std::binary_search(all.begin(), all.end(), q));
+          }
+      }
       o3ds::ScanChain other = chain;
       other.voxelSize = 0.11;
       std::shared_ptr<PointCloud> coarser = o3ds::preprocessScan(rawCopy, other);
       CHECK(coarser.get() != pre.get() && coarser->points_.size() < pre->points_.size());
       PointCloud moved = raw;
       for (auto& q : moved.points_) q[0] += 0.5;
+      o3ds::setScanStamp(42);  // another scan
       CHECK(o3ds::preprocessScan(moved, other).get() != coarser.get());
+      o3ds::setScanStamp(41);
       std::shared_ptr<PointCloud> recomputed = o3ds::preprocessScan(rawCopy, chain);  // the memo holds one entry: computed again, same values
       CHECK(recomputed.get() != pre.get() && recomputed->points_.size() == pre->points_.size());
       for (size_t i = 0; i < pre->points_.size(); ++i)
@@ -196,6 +232,7 @@ int main(int argc, char** argv) {
     {
       PointCloud tinted = raw;
       tinted.colors_.assign(tinted.points_.size(), Eigen::Vector3d(0.25, 0.5, 0.75));
+      o3ds::setScanStamp(43);  // (another scan: same points, with colours)
       std::shared_ptr<PointCloud> pt = o3ds::preprocessScan(tinted, chain);
       CHECK(pt.get() != pre.get() && pt->points_.size() == pre->points_.size() && pt->colors_.size() == pt->points_.size());
       for (size_t i = 0; i < pt->colors_.size(); i += 97)

@@ -41,7 +41,8 @@ def test_patch_applies_and_the_patched_sources_type_check(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     touched = {ln.split("b/", 1)[1].strip() for ln in open(PATCH) if ln.startswith("+++ b/")}
     assert touched == {"CMakeLists.txt", "include/open3d_slam/Submap.hpp", "include/open3d_slam/Odometry.hpp", "src/CloudRegistration.cpp",
-                       "src/ScanToMapRegistration.cpp", "src/Odometry.cpp", "src/Submap.cpp"}
+                       "src/ScanToMapRegistration.cpp", "src/Odometry.cpp", "src/Submap.cpp",
+                       "src/Mapper.cpp"}  # (Mapper.cpp: two lines -- the scan's Time stamp is passed on to the pre-processing memo)
     for unit in UNITS:
         r = _syntax_check(str(tree), unit)
         assert r.returncode == 0, (unit, r.stderr[-3000:])

@@ -1326,3 +1326,46 @@ def test_allocator_cache_is_bounded_and_survives_a_trim():
     outs = [subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True, env=dict(os.environ, O3DS_POOL_CAP_MB=cap)).stdout.strip()
             for cap in ("32768", "1")]
     assert outs[0] == outs[1] and len(outs[0]) == 40
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_normals_estimated_after_the_merge_get_the_map_s_spare_room(prec):
+    """A map that was merged WITHOUT normals keeps room behind its points (the next scan is placed there); normals estimated afterwards
+    must get the same room, or the in-place append of o3ds_map_insert_scan writes past their end (the initial-map flow --
+    voxelize, prepareInitialMap's estimateNormals, then a scan with normals).  Checked against the same steps on host copies."""
+    p = backend.PRECISION_F64 if prec == "f64" else backend.PRECISION_F32
+    be = backend.Backend(0, p)
+    scene = syn.make_scene()
+    pts, _ = syn.sample_map(scene, 60_000)
+    m = be.upload(pts)
+    crop = backend.make_crop(backend.CROP_MAX_RADIUS, rmax=25.0)
+    be.voxelize_within_volume(m, 0.2, crop)
+    be.estimate_normals(m, 2.0, 10)
+    n0 = be.size(m)[0]
+    p0, nn0 = be.download(m)
+    for k in range(3):  # (also past the point where the map takes its persistent form)
+        T = syn.make_pose([0.3 * k, 0.0, 0.0], [0.0, 0.0, 2.0 * k])
+        s = be.upload(syn.vlp16_scan(scene, T, frame=k, n_az=256))
+        v = be.voxel_down_sample(s, 0.1)
+        be.estimate_normals(v, 2.0, 10)
+        be.map_insert_scan(m, v, T, 0.2, backend.make_crop(backend.CROP_MAX_RADIUS, center=T[:3, 3], rmax=25.0), max_corr_hint=1.0)
+        be.free(s)
+        be.free(v)
+    got_p, got_n = be.download(m)
+    assert len(got_p) >= n0 and np.isfinite(got_p).all() and got_n is not None and len(got_n) == len(got_p)
+    ln = np.linalg.norm(got_n, axis=1)
+    assert np.all((np.abs(ln - 1.0) < 1e-5) | (ln == 0.0))  # every normal is a unit vector (or the zero vector of a degenerate voxel): no garbage
+    # a second handle that repeats the steps gives the same bytes (nothing was written out of bounds into something else's memory)
+    be2 = backend.Backend(0, p)
+    m2 = be2.upload(p0, nn0)
+    for k in range(3):
+        T = syn.make_pose([0.3 * k, 0.0, 0.0], [0.0, 0.0, 2.0 * k])
+        s = be2.upload(syn.vlp16_scan(scene, T, frame=k, n_az=256))
+        v = be2.voxel_down_sample(s, 0.1)
+        be2.estimate_normals(v, 2.0, 10)
+        be2.map_insert_scan(m2, v, T, 0.2, backend.make_crop(backend.CROP_MAX_RADIUS, center=T[:3, 3], rmax=25.0), max_corr_hint=1.0)
+    q_p, q_n = be2.download(m2)
+    np.testing.assert_array_equal(q_p, got_p)
+    np.testing.assert_array_equal(q_n, got_n)
+    be.close()
+    be2.close()

@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, mode, out_path):
+def _worker(rank, world, port, mode, out_path, dist_backend="gloo"):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -29,36 +29,51 @@ def _worker(rank, world, port, mode, out_path):
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = rank if dist_backend == "nccl" else 0  # RCCL: one GPU per rank; gloo: the ranks share the box's one GPU
+    torch.cuda.set_device(dev)
+    dist.init_process_group(dist_backend, rank=rank, world_size=world)
     scene = syn.make_scene()
     src = syn.vlp16_scan(scene, syn.ground_truth_pose(), n_az=512)
     tgt, nrm = syn.sample_map(scene, 100_000, seed=syn.SEED_MAP + (rank if mode == "submap" else 0))
     if mode == "union":  # ONE map in two spatial shards
         mine = (tgt[:, 0] < 0.0) == (rank == 0)
         tgt, nrm = tgt[mine], nrm[mine]
-    be = backend.Backend(0, backend.PRECISION_F64)
+    be = backend.Backend(dev, backend.PRECISION_F64)
     s, t = be.upload(src), be.upload(tgt, nrm)
     be.build_index(t, 1.0)
     drv = sharded.ShardedIcp(be, mode=mode)
     res = drv.register(s, t, len(src), 1.0, max_iter=30, check_every=2)
-    Ts = [torch.zeros(16, dtype=torch.float64) for _ in range(world)]
-    dist.all_gather(Ts, torch.from_numpy(res["transformation"].ravel().copy()))
+    where = f"cuda:{dev}" if dist_backend == "nccl" else "cpu"
+    Ts = [torch.zeros(16, dtype=torch.float64, device=where) for _ in range(world)]
+    dist.all_gather(Ts, torch.from_numpy(res["transformation"].ravel().copy()).to(where))
     if rank == 0:
         np.savez(out_path, T=res["transformation"], fitness=res["fitness"], rmse=res["inlier_rmse"], iterations=res["iterations"],
-                 converged=res["converged"], all_T=np.stack([x.numpy() for x in Ts]))
+                 converged=res["converged"], all_T=np.stack([x.cpu().numpy() for x in Ts]))
     be.close()
     dist.destroy_process_group()
 
 
+def _two_gpus():
+    import torch
+
+    return torch.cuda.is_available() and torch.cuda.device_count() >= 2
+
+
 @pytest.mark.parametrize("mode", ["source", "submap", "union"])
-def test_two_ranks_one_gpu(tmp_path, backend_f64, oracle, mode):
+@pytest.mark.parametrize("dist_backend", ["gloo", "nccl"])
+def test_two_ranks_one_gpu(tmp_path, backend_f64, oracle, mode, dist_backend):
+    """dist_backend "nccl": the same three partitionings over RCCL with one GPU per rank -- the int64 MIN all-reduce of the union form, the
+    4-KB sum all-reduce of the fused form, o3ds_set_stream ordering against a real second device -- on the first box that has two GPUs
+    (skipped on the one-GPU test boxes: RCCL needs a device per rank)."""
     import torch.multiprocessing as mp
 
     from open3d_slam_amd import synthetic as syn
 
+    if dist_backend == "nccl" and not _two_gpus():
+        pytest.skip("RCCL needs one GPU per rank: this box has fewer than two")
     out = str(tmp_path / f"{mode}.npz")
-    mp.spawn(_worker, args=(2, _free_port(), mode, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), mode, out, dist_backend), nprocs=2, join=True)
     r = np.load(out)
     np.testing.assert_array_equal(r["all_T"][0], r["all_T"][1])  # identical pose on every rank, no broadcast
     scene = syn.make_scene()
@@ -77,7 +92,7 @@ def test_two_ranks_one_gpu(tmp_path, backend_f64, oracle, mode):
 
 
 # ---- ONE dense voxel map over two ranks, rows exchanged between device buffers (sharded.ShardedDenseMap; BASELINE configs[4]) ----------
-def _dense_worker(rank, world, port, out_dir):
+def _dense_worker(rank, world, port, out_dir, dist_backend="gloo"):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -86,10 +101,12 @@ def _dense_worker(rank, world, port, out_dir):
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = rank if dist_backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    dist.init_process_group(dist_backend, rank=rank, world_size=world)
     scene = syn.make_scene()
-    be = backend.Backend(0, backend.PRECISION_F64)
+    be = backend.Backend(dev, backend.PRECISION_F64)
     dm = sharded.ShardedDenseMap(be, 0.1, has_normals=True)
     fused = 0
     for ins in range(3):  # ragged shares, one of them empty, one with a NaN return, each placed by its own pose
@@ -115,13 +132,16 @@ def _dense_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_ranks_dense_map_fusion_on_device(tmp_path, backend_f64):
+@pytest.mark.parametrize("dist_backend", ["gloo", "nccl"])
+def test_two_ranks_dense_map_fusion_on_device(tmp_path, backend_f64, dist_backend):
     import torch.multiprocessing as mp
     from scipy.spatial import cKDTree
 
     from open3d_slam_amd import synthetic as syn
 
-    mp.spawn(_dense_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    if dist_backend == "nccl" and not _two_gpus():
+        pytest.skip("RCCL needs one GPU per rank: this box has fewer than two")
+    mp.spawn(_dense_worker, args=(2, _free_port(), str(tmp_path), dist_backend), nprocs=2, join=True)
     parts = [np.load(str(tmp_path / f"dense{r}.npz")) for r in range(2)]
     # the same insertions into ONE map on one rank
     scene = syn.make_scene()
@@ -234,3 +254,51 @@ def test_rccl_one_rank_collectives_and_stream_ordering(tmp_path):
         else:
             np.testing.assert_allclose(r[f"T_{m}"], r["one"], atol=tol)
     assert int(r["fused"]) == 100_000 and int(r["n_vox"]) == int(r["n_single"]) > 0
+
+
+def _big_source_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from open3d_slam_amd import backend, sharded, synthetic as syn
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scene = syn.make_scene()
+    one_scan = syn.vlp16_scan(scene, syn.ground_truth_pose(), n_az=4096)  # 65 536 points
+    src = np.concatenate([one_scan + 1e-4 * k for k in range(5)])  # 327 680 source points: beyond O3DS_ICP_PASS_MAX_QUERIES
+    tgt, nrm = syn.sample_map(scene, 200_000)
+    be = backend.Backend(0, backend.PRECISION_F64)
+    s, t = be.upload(src), be.upload(tgt, nrm)
+    be.build_index(t, 1.0)
+    assert len(src) > be.ICP_PASS_MAX_QUERIES
+    one = be.icp_point_to_plane_dev(s, t, 1.0, max_iter=8, rel_fitness=0.0, rel_rmse=0.0)  # (switches to the looping form by itself)
+    drv = sharded.ShardedIcp(be, mode="submap", always_collective=True)
+    res = drv.register(s, t, len(src), 1.0, max_iter=8, rel_fitness=0.0, rel_rmse=0.0, check_every=4)  # whole source per rank: falls back
+    limit_error = ""
+    try:
+        be.icp_begin(s, t, 1.0, max_iter=2)
+        z = torch.zeros(be.ICP_SUMS_DOUBLES, dtype=torch.float64, device="cuda:0")
+        be.icp_pass(0, len(src), len(src), None, z.data_ptr(), z.clone().data_ptr())
+    except backend.BackendError as e:
+        limit_error = str(e)
+    np.savez(out_path, one=one["transformation"], got=res["transformation"], it=res["iterations"], limit_error=limit_error)
+    be.close()
+    dist.destroy_process_group()
+
+
+def test_sources_beyond_the_fused_pass_limit_fall_back_to_the_looping_form(tmp_path):
+    """o3ds_icp_pass serves at most O3DS_ICP_PASS_MAX_QUERIES source points per call and says so (O3DS_ERR_CAPACITY, o3ds_backend.h);
+    ShardedIcp takes the classic accumulate / update triple for larger shards instead of raising, and agrees with the
+    one-shot registration of the same clouds."""
+    import torch.multiprocessing as mp
+
+    out = str(tmp_path / "big.npz")
+    mp.spawn(_big_source_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    r = np.load(out)
+    assert "O3DS_ICP_PASS_MAX_QUERIES" in str(r["limit_error"])
+    assert int(r["it"]) == 8
+    np.testing.assert_allclose(r["got"], r["one"], atol=1e-9)
