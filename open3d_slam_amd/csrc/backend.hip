@@ -4068,11 +4068,11 @@ int o3ds_map_carve_removed(o3ds_handle h, o3ds_cloud map, o3ds_cloud raw_scan, c
       o3ds_context::PinRec* rec = h->h_rec_dev + pm->rec_slot;
       const CountPub pub{cnt_word(h, pm->rec_slot), &rec->cnt, pm->rec_seq};
       if (pmc->precision == O3DS_PRECISION_F64) {
-        pm_carve_rays_kernel<P4d><<<grid_for(sc->n), kBlock, 0, h->stream>>>(d, (const P4d*)sc->pts, sc->n, M, T[12], T[13], T[14], params->max_raytracing_length,
+        pm_carve_rays_kernel<P4d><<<(unsigned int)((sc->n + kBlock - 1) / kBlock), kBlock, 0, h->stream>>>(d, (const P4d*)sc->pts, sc->n, M, T[12], T[13], T[14], params->max_raytracing_length,
                                                                             params->truncation_distance, params->min_dot_product_with_normal, cd, block_bits);
         pm_carve_apply_kernel<P4d><<<256, kBlock, 0, h->stream>>>(d, pub, rec->box);
       } else {
-        pm_carve_rays_kernel<P4f><<<grid_for(sc->n), kBlock, 0, h->stream>>>(d, (const P4f*)sc->pts, sc->n, M, T[12], T[13], T[14], params->max_raytracing_length,
+        pm_carve_rays_kernel<P4f><<<(unsigned int)((sc->n + kBlock - 1) / kBlock), kBlock, 0, h->stream>>>(d, (const P4f*)sc->pts, sc->n, M, T[12], T[13], T[14], params->max_raytracing_length,
                                                                             params->truncation_distance, params->min_dot_product_with_normal, cd, block_bits);
         pm_carve_apply_kernel<P4f><<<256, kBlock, 0, h->stream>>>(d, pub, rec->box);
       }

@@ -157,6 +157,13 @@ struct CountRef {
 };
 __device__ __forceinline__ size_t count_of(const CountRef& c) { return c.dev ? (size_t)*c.dev : c.n; }
 
+// A word ONE thread reads and then overwrites (the counters a bookkeeping kernel consumes and resets).  The compiler turns a uniform plain
+// load into a scalar-cache load and waits for it only where the value is first USED; the hardware does not order the scalar and the vector
+// memory pipelines against each other, so a vector store to the same word issued in between can overtake the load -- the thread reads its
+// own reset (pm_carve_finish_kernel did, once in ten cold starts).  An agent-scope atomic load is a vector load: ordered with the wave's
+// later stores to the address.  scripts/check_scalar_war.py looks for the pattern in the assembly of every kernel (tests/test_abi.py).
+__device__ __forceinline__ int load_then_store(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // doubles as unsigned integers of the same order (atomicMin / atomicMax on bounding boxes)
 __host__ __device__ __forceinline__ unsigned long long order_bits(double x) {
   unsigned long long u;

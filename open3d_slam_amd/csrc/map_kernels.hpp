@@ -47,7 +47,9 @@ struct alignas(32) PmSlot {
   int pos;                  // position in the paged index
   int hnext;                // next slot of the same voxel chain, -1 = end
   unsigned int flags;       // kPmDead | kPmUnsettled | kPmFresh
-  int pad[2];
+  int out_tau;              // memo of pm_view_key's walk back through the volumes: the slot left the voxel block with insertion out_tau
+  int out_checked;          // (0: it never was in one since its stamp) and has been outside ever since up to insertion out_checked;
+                            // valid while out_checked >= stamp (a write of the slot makes it stale by itself); -1 = no memo
 };
 struct alignas(16) PmHash {
   unsigned long long key;
@@ -157,6 +159,27 @@ __device__ __forceinline__ bool pm_outside_grid(const PmDev& m, unsigned long lo
          vz >= m.gz0 + (long long)m.grid.nz * m.kc;
 }
 
+// whether every point a voxel can hold lies outside the cropping volume (false when in doubt)
+__device__ __forceinline__ bool pm_voxel_outside(const PmDev& m, unsigned long long key, const CropDev& c) {
+  if (c.invert || c.kind == O3DS_CROP_NONE) return false;
+  const double vx = (double)((long long)(key & 0x1FFFFFull) - (1ll << 20)), vy = (double)((long long)((key >> 21) & 0x1FFFFFull) - (1ll << 20)),
+               vz = (double)((long long)((key >> 42) & 0x1FFFFFull) - (1ll << 20));
+  const double v = m.voxel, half = 0.5 * v;
+  const double dx = (vx + 0.5) * v - c.cx, dy = (vy + 0.5) * v - c.cy, dz = (vz + 0.5) * v - c.cz;
+  const double slack = 0.8661 * v + 1e-6 * (fabs(dx) + fabs(dy) + fabs(dz) + 1.0);  // half the voxel's diagonal, rounded up, and a margin
+  if (c.kind == O3DS_CROP_CYLINDER) {
+    const double lo = (vz + 0.0) * v, hi = (vz + 1.0) * v;
+    if (lo > c.zmax + 1e-9 * fabs(c.zmax) + 1e-12 || hi < c.zmin - 1e-9 * fabs(c.zmin) - 1e-12) return true;
+    const double d = sqrt(dx * dx + dy * dy);
+    return c.le2 >= 0.0 ? d - slack > sqrt(c.le2) : true;
+  }
+  (void)half;
+  const double d = sqrt(dx * dx + dy * dy + dz * dz);
+  const bool beyond = (c.kind == O3DS_CROP_MAX_RADIUS || c.kind == O3DS_CROP_MIN_MAX_RADIUS) && (c.le2 < 0.0 || d - slack > sqrt(c.le2));
+  const bool within = (c.kind == O3DS_CROP_MIN_RADIUS || c.kind == O3DS_CROP_MIN_MAX_RADIUS) && c.ge2 > 0.0 && d + slack < sqrt(c.ge2);
+  return beyond || within;
+}
+
 // Eigen normalized() as segment_mean_kernel spells it; returns whether anything was divided
 __device__ __forceinline__ void pm_normalize(double& nx, double& ny, double& nz) {
   const double z2 = (nx * nx + ny * ny) + nz * nz;
@@ -203,7 +226,7 @@ __device__ __forceinline__ int pm_ticket(int* counter) {
   const int leader = (int)__builtin_ctzll(act);
   int base = 0;
   if (lane == leader) base = atomicAdd(counter, (int)__popcll(act));
-  base = __shfl(base, leader, 64);
+  base = __builtin_amdgcn_readfirstlane(base);  // the first active lane is the leader
   return base + (int)__popcll(act & ((1ull << lane) - 1ull));
 }
 __device__ __forceinline__ void pm_push(int* list, int* counter, int cap, int v, int* err) {
@@ -245,13 +268,32 @@ __device__ __forceinline__ void pm_view_key(const PmDev& m, int s, int t_ref, un
     *lo = t_ref == 0 ? (unsigned long long)s : (st == t_ref ? ok : kp);
     return;
   }
-  for (int t = t_ref - 1; t >= st; --t) {
-    if (t < 0) break;
-    if (pm_in_block(m, s, p, st, ok, t)) {
-      *hi = (unsigned long long)(t + 1) << 1;
-      *lo = t == 0 ? (unsigned long long)s : (st == t ? ok : kp);
-      return;
+  // the walk back through the volumes, as far as the slot's memo does not already answer it (a listed voxel far from the volume is looked at
+  // at every insertion: without the memo each look walks the whole history again, hundreds of steps late in a long run)
+  const PmSlot ms = m.slot[s];
+  const bool memo = ms.out_checked >= st && ms.out_checked < t_ref;
+  int tau = memo ? ms.out_tau : 0;
+  const int t_low = max(memo ? ms.out_checked + 1 : st, 0);
+  for (int t_hi = t_ref - 1; t_hi >= t_low; t_hi -= 8) {  // eight volumes per round: their loads go out together
+    bool in[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) in[u] = t_hi - u >= t_low && pm_in_block(m, s, p, st, ok, t_hi - u);
+    int hit = -1;
+#pragma unroll
+    for (int u = 7; u >= 0; --u)
+      if (in[u]) hit = u;
+    if (hit >= 0) {
+      tau = t_hi - hit + 1;
+      break;
     }
+  }
+  m.slot[s].out_tau = tau;
+  m.slot[s].out_checked = t_ref - 1;
+  if (tau > 0) {  // it belonged to the voxel block of insertion tau - 1 and left with insertion tau
+    const int t = tau - 1;
+    *hi = (unsigned long long)tau << 1;
+    *lo = t == 0 ? (unsigned long long)s : (st == t ? ok : kp);
+    return;
   }
   if ((ok & kPmRaw) && st > 0) {  // inserted outside the volume at insertion st and never inside since
     *hi = ((unsigned long long)st << 1) | 1ull;
@@ -281,6 +323,8 @@ __global__ __launch_bounds__(kBlock) void pm_enter_kernel(PmDev m, int n) {
     const unsigned long long k = pm_key(p, m.inv_voxel);
     m.slot[s].stamp = 0;
     m.slot[s].okey = k;
+    m.slot[s].out_checked = -1;
+    m.slot[s].out_tau = 0;
     unsigned int fl = 0;
     if (m.nrm) {
       const P4 nv = ((const P4*)m.nrm)[s];
@@ -428,7 +472,9 @@ __device__ __forceinline__ void pm_row_push(const PmDev& m, int s, unsigned long
   pm_cell(m, key, &row, &x);
   atomicAdd(&m.cell_add[(size_t)row * (m.grid.nx + 1) + x], 1);
   if (pm_outside_grid(m, key)) atomicAdd(m.counters + kPmClamped, 1);
-  if (atomicExch(&m.row_flag[row], 1) == 0) pm_push(m.touched_rows, m.counters + kPmTouched, m.list_cap, row, m.counters + kPmError);
+  // (a look before the exchange: a floor row receives hundreds of slots per scan, and all but the first find the row marked already)
+  if (__hip_atomic_load(&m.row_flag[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && atomicExch(&m.row_flag[row], 1) == 0)
+    pm_push(m.touched_rows, m.counters + kPmTouched, m.list_cap, row, m.counters + kPmError);
   pm_push(m.new_slots, m.counters + kPmNew, m.list_cap, s, m.counters + kPmError);
 }
 // the mean of a voxel's members written where it belongs: point, normal, history, search index (in place: the mean of points of one voxel
@@ -441,6 +487,7 @@ __device__ __forceinline__ void pm_store(const PmDev& m, int s, const P4& op, co
   if (has_nrm) ((P4*)m.nrm)[s] = on;
   m.slot[s].stamp = t;
   m.slot[s].okey = key;
+  m.slot[s].out_checked = -1;  // (whatever pm_view_key remembered of the slot's history belonged to the point it held before)
   unsigned int fl = fresh ? kPmFresh : 0u;
   if (has_nrm && !pm_same_bits(pm_renormalized(on), on)) {
     fl |= kPmUnsettled;
@@ -663,14 +710,41 @@ __device__ __forceinline__ int pm_gather_old(const PmDev& m, unsigned int e, con
     const P4 p = ((const P4*)m.pts)[s];
     if (!crop_contains(crop, (double)p.x, (double)p.y, (double)p.z)) continue;
     if (n == kPmMaxOld) return kPmMaxOld + 1;  // more than the sorted list holds: pm_merge_many
+    // Its place in the array before this insertion.  The usual pair is one point that passed through last time (it lay outside the
+    // volume) and one voxel mean: the pass-through block comes first whatever its history, so the walk back through the volumes
+    // (pm_view_key: as many steps as the point has been outside) is only taken when a SECOND pass-through member turns up (below).
     unsigned long long h, l;
-    pm_view_key<P4>(m, s, t_now - 1, &h, &l);
+    {
+      const PmSlot ms = m.slot[s];
+      if (pm_in_block(m, s, p, ms.stamp, ms.okey, t_now - 1)) {
+        h = 1ull << 63;
+        l = t_now - 1 == 0 ? (unsigned long long)s : (ms.stamp == t_now - 1 ? ms.okey : pm_key(p, m.inv_voxel));
+      } else {
+        h = 0;  // "somewhere in the pass-through block": exact only if it stays the only one
+        l = ~0ull;
+      }
+    }
     int j = n++;
     while (j > 0 && (o.hi[j - 1] > h || (o.hi[j - 1] == h && o.lo[j - 1] > l))) {
       o.hi[j] = o.hi[j - 1], o.lo[j] = o.lo[j - 1], o.slot[j] = o.slot[j - 1];
       --j;
     }
     o.hi[j] = h, o.lo[j] = l, o.slot[j] = s;
+  }
+  if (n > 1 && o.hi[1] == 0) {  // several pass-through members: their order is their history
+    int np = 0;
+    while (np < n && o.hi[np] == 0) ++np;
+    for (int a = 0; a < np; ++a) pm_view_key<P4>(m, o.slot[a], t_now - 1, &o.hi[a], &o.lo[a]);
+    for (int a = 1; a < np; ++a) {  // insertion sort of the first np entries
+      const unsigned long long h = o.hi[a], l = o.lo[a];
+      const int sl = o.slot[a];
+      int j = a;
+      while (j > 0 && (o.hi[j - 1] > h || (o.hi[j - 1] == h && o.lo[j - 1] > l))) {
+        o.hi[j] = o.hi[j - 1], o.lo[j] = o.lo[j - 1], o.slot[j] = o.slot[j - 1];
+        --j;
+      }
+      o.hi[j] = h, o.lo[j] = l, o.slot[j] = sl;
+    }
   }
   return n;
 }
@@ -793,6 +867,15 @@ __global__ __launch_bounds__(64) void pm_merge_kernel(PmDev m, const int2* __res
     // a voxel on the multi list.  One the scan touched has been dealt with: its group saw the whole chain (a complex group of this very
     // launch belongs to another thread, which may be rewriting the chain right now: told apart by the list of this launch, not by the chain).
     const unsigned long long key = m.multi[0][i - n_complex];
+    // Most listed voxels lie far from where anything happens: a voxel that straddled the volume's outer boundary when the sensor passed
+    // stays listed (two members that were never inside together) for as long as the volume stays away.  A voxel that lies ENTIRELY
+    // outside the volume has no member inside it, so nothing merges and the scan cannot have touched it: told from the key alone --
+    // no load --, it goes straight back on the list.  (Conservative by the voxel's half diagonal plus a margin; only for the plain
+    // radius / cylinder volumes.)
+    if (pm_voxel_outside(m, key, crop)) {
+      pm_push64(m.multi[1], m.counters + kPmMultiOut, cap, key, err);
+      continue;
+    }
     const unsigned int e = pm_find(m, key);
     if (e == ~0u) continue;
     bool touched = (int)(m.h[e].info >> 8) == t_now;  // a voxel pm_group_kernel handed to the other branch of this launch
@@ -868,6 +951,7 @@ __global__ __launch_bounds__(kBlock) void pm_misc_kernel(PmDev m, const P4* __re
     }
     m.slot[s].stamp = t_now;
     m.slot[s].okey = kPmRaw | (unsigned long long)si;
+    m.slot[s].out_checked = -1;
     unsigned int fl = kPmFresh;
     if (has_nrm && !pm_same_bits(pm_renormalized(on), on)) {
       fl |= kPmUnsettled;
@@ -993,32 +1077,43 @@ __global__ __launch_bounds__(kBlock) void pm_rows_kernel(PmDev m) {
     // the old points from the back, a workgroup's worth per round; the cells in front of the first one that grows stay where they are
     // (unless the whole row moved)
     const int stop = base == old_start ? s_old[min(s_first, nx - 1)] : old_start;
-    for (int hi = old_end; hi > stop; hi -= kBlock) {
-      const int j = hi - kBlock + tid;
-      const int jc = max(j, old_start);  // (clamped, not predicated: the loads stay out of the branch)
-      const P4 p = ((const P4*)m.spts)[jc];
-      const P4 q = ((const P4*)(has_nrm ? m.snrm : m.spts))[jc];
-      int dst = -1;
-      if (j >= stop) {
-        int lo = 0, hh = nx - 1;  // its cell: the last x with s_old[x] <= j
-        while (lo < hh) {
-          const int mid = (lo + hh + 1) >> 1;
-          if (s_old[mid] <= j)
-            lo = mid;
-          else
-            hh = mid - 1;
+    constexpr int kPer = 4;  // points per thread and round: a floor row of a dense map holds thousands of points, and a round is two barriers
+    for (int hi = old_end; hi > stop; hi -= kBlock * kPer) {
+      P4 p[kPer], q[kPer];
+      int j[kPer], dst[kPer];
+#pragma unroll
+      for (int u = 0; u < kPer; ++u) {
+        j[u] = hi - kBlock * (u + 1) + tid;
+        const int jc = max(j[u], old_start);  // (clamped, not predicated: the loads stay out of the branch)
+        p[u] = ((const P4*)m.spts)[jc];
+        q[u] = ((const P4*)(has_nrm ? m.snrm : m.spts))[jc];
+      }
+#pragma unroll
+      for (int u = 0; u < kPer; ++u) {
+        dst[u] = -1;
+        if (j[u] >= stop) {
+          int lo = 0, hh = nx - 1;  // its cell: the last x with s_old[x] <= j
+          while (lo < hh) {
+            const int mid = (lo + hh + 1) >> 1;
+            if (s_old[mid] <= j[u])
+              lo = mid;
+            else
+              hh = mid - 1;
+          }
+          dst[u] = s_new[lo] + (j[u] - s_old[lo]);
         }
-        dst = s_new[lo] + (j - s_old[lo]);
       }
       __syncthreads();  // all of the round is read before any of it is written (a point only ever moves up: into this round's range or beyond)
-      if (dst >= 0 && dst != j) {
-        P4 pp, qq;  // (field by field: an aggregate copy through a conditional branch went through scratch memory)
-        pp.x = p.x, pp.y = p.y, pp.z = p.z, pp.i = p.i;
-        qq.x = q.x, qq.y = q.y, qq.z = q.z, qq.i = q.i;
-        ((P4*)m.spts)[dst] = pp;
-        if (has_nrm) ((P4*)m.snrm)[dst] = qq;
-        if ((int)p.i != 0x7fffffff) m.slot[(int)p.i].pos = dst;
-      }
+#pragma unroll
+      for (int u = 0; u < kPer; ++u)
+        if (dst[u] >= 0 && dst[u] != j[u]) {
+          P4 pp, qq;  // (field by field: an aggregate copy through a conditional branch went through scratch memory)
+          pp.x = p[u].x, pp.y = p[u].y, pp.z = p[u].z, pp.i = p[u].i;
+          qq.x = q[u].x, qq.y = q[u].y, qq.z = q[u].z, qq.i = q[u].i;
+          ((P4*)m.spts)[dst[u]] = pp;
+          if (has_nrm) ((P4*)m.snrm)[dst[u]] = qq;
+          if ((int)p[u].i != 0x7fffffff) m.slot[(int)p[u].i].pos = dst[u];
+        }
       __syncthreads();
     }
     for (int x = tid; x <= nx; x += kBlock) cs[x] = s_new[x];
@@ -1062,13 +1157,13 @@ __global__ __launch_bounds__(64) void pm_turn_kernel(PmDev m, CountPub pub, Crop
     host_vals[0] = (double)c[kPmPoolTop];
     host_vals[1] = (double)c[kPmDeadCnt];
     host_vals[2] = (double)c[kPmError];
-    host_vals[3] = (double)c[kPmMultiOut];  // (diagnostics: voxels with several members, voxels of this scan with several old members inside)
-    host_vals[4] = (double)c[kPmComplex];
-    host_vals[5] = (double)c[kPmClamped];   // slots outside the index grid so far
+    host_vals[3] = (double)load_then_store(c + kPmMultiOut);  // (diagnostics: voxels with several members, voxels of this scan with several old
+    host_vals[4] = (double)load_then_store(c + kPmComplex);   // members inside)
+    host_vals[5] = (double)c[kPmClamped];                     // slots outside the index grid so far
   }
-  c[kPmUnsettledIn] = min(c[kPmUnsettledOut], m.list_cap);
+  c[kPmUnsettledIn] = min(load_then_store(c + kPmUnsettledOut), m.list_cap);  // (read and reset by this thread: see common.hpp)
   c[kPmUnsettledOut] = 0;
-  c[kPmMultiIn] = min(c[kPmMultiOut], m.list_cap);
+  c[kPmMultiIn] = min(load_then_store(c + kPmMultiOut), m.list_cap);
   c[kPmMultiOut] = 0;
   c[kPmComplex] = c[kPmOutside] = c[kPmRelink] = c[kPmTouched] = c[kPmNew] = 0;
   publish_count(pub, c[kPmN]);
@@ -1095,14 +1190,17 @@ __global__ __launch_bounds__(kBlock) void pm_carve_rays_kernel(PmDev m, const P4
                                                                const unsigned int* __restrict__ block_bits) {
   const double voxel = m.voxel, inv = 1.0 / voxel;
   const bool has_nrm = m.nrm != nullptr;
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n_scan; i += (size_t)gridDim.x * kBlock) {
+  {  // one ray per thread (no loop over rays: the pose and the scan's address are dead after these lines, which is what keeps the kernel's
+     // scalar registers within the file)
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_scan) return;
     const P4 q = scan[i];
     const double x = (double)q.x, y = (double)q.y, z = (double)q.z;
     const double px = M.m[0] * x + M.m[1] * y + M.m[2] * z + M.m[3], py = M.m[4] * x + M.m[5] * y + M.m[6] * z + M.m[7],
                  pz = M.m[8] * x + M.m[9] * y + M.m[10] * z + M.m[11];
     const double dx = px - sx, dy = py - sy, dz = pz - sz;
     const double length = sqrt(dx * dx + dy * dy + dz * dz);
-    if (!(length > 0.0)) continue;
+    if (!(length > 0.0)) return;
     const double ux = dx / length, uy = dy / length, uz = dz / length;
     const double lim = fmax(voxel, fmin(length - trunc, max_len));
     constexpr int kBatch = 8;
@@ -1142,8 +1240,13 @@ __global__ __launch_bounds__(kBlock) void pm_carve_rays_kernel(PmDev m, const P4
             const double dot = nl > 0.0 ? (ux * a + uy * bb + uz * c) / nl : 0.0;  // Eigen normalized(): the zero vector stays zero
             rem = fabs(dot) > min_dot;
           }
-          if (rem && !(atomicOr(&m.slot[s].flags, kPmCarved) & kPmCarved))
-            pm_push(m.new_slots, m.counters + kPmCarvedCnt, m.list_cap, s, m.counters + kPmError);
+          if (rem && !(atomicOr(&m.slot[s].flags, kPmCarved) & kPmCarved)) {
+            const int k = atomicAdd(m.counters + kPmCarvedCnt, 1);  // (one ticket per removal: a carve removes a few hundred points)
+            if (k < m.list_cap)
+              m.new_slots[k] = s;
+            else
+              atomicOr(m.counters + kPmError, 1);
+          }
         }
       }
     }
@@ -1168,11 +1271,12 @@ __global__ __launch_bounds__(kBlock) void pm_carve_apply_kernel(PmDev m, CountPu
 __global__ __launch_bounds__(64) void pm_carve_finish_kernel(PmDev m, CountPub pub, double* __restrict__ host_vals) {
   if (threadIdx.x != 0) return;
   int* c = m.counters;
-  const int n = min(c[kPmCarvedCnt], m.list_cap);
-  c[kPmDeadCnt] += n;
+  const int n = min(load_then_store(c + kPmCarvedCnt), m.list_cap);  // (see common.hpp: read and reset by the same thread)
+  const int dead = load_then_store(c + kPmDeadCnt) + n;
+  c[kPmDeadCnt] = dead;
   c[kPmCarvedCnt] = 0;
   host_vals[0] = (double)c[kPmPoolTop];
-  host_vals[1] = (double)c[kPmDeadCnt];
+  host_vals[1] = (double)dead;
   host_vals[2] = (double)c[kPmError];
   host_vals[3] = (double)n;  // removed by this carve
   host_vals[4] = 0.0;

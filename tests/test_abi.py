@@ -92,6 +92,27 @@ def test_no_hand_written_kernel_spills_registers():
     assert len(fused) == 8 and all(v["vgpr"] <= 128 and v["occupancy"] >= 4 for v in fused), fused
 
 
+def test_no_kernel_reads_a_word_through_the_scalar_cache_that_it_overwrites_while_the_load_is_in_flight():
+    """A uniform plain load compiles to a scalar-cache load that is only waited for where its value is first used, and the hardware does
+    not order it against the wavefront's later vector STORE to the same address: pm_carve_finish_kernel read the counter it was about to
+    reset as the zero of its own reset, once in ten cold starts (round 5; the carve then reported nothing removed).  Such words are read
+    with load_then_store (common.hpp); scripts/check_scalar_war.py looks for the pattern in the gfx950 assembly of every kernel."""
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("check_scalar_war", os.path.join(root, "scripts", "check_scalar_war.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    # the checker finds the pattern where it is (the code the round-5 kernel compiled to) ...
+    seen = mod.check("_Z3foov:\n\ts_load_dwordx4 s[12:15], s[10:11], 0x2c\n\tglobal_store_dword v0, v0, s[10:11] offset:48\n\ts_waitcnt lgkmcnt(0)\n\ts_endpgm\n")
+    assert len(seen) == 1
+    assert not mod.check("_Z3foov:\n\ts_load_dwordx4 s[12:15], s[10:11], 0x2c\n\ts_waitcnt lgkmcnt(0)\n\tglobal_store_dword v0, v0, s[10:11] offset:48\n\ts_endpgm\n")
+    # ... and nowhere in the backend
+    text = mod.assembly()
+    assert text.count("s_endpgm") > 300
+    assert mod.check(text) == []
+
+
 def test_poses_cross_the_ctypes_boundary_column_major_and_unchanged():
     """The Python side hands 4x4 poses to the library as 16 doubles in column-major order (Eigen's layout, o3ds_backend.h) and reads
     results back the same way.  The marshalling takes short cuts (one `ravel(order="F")`, a ctypes array over the buffer instead of
