@@ -135,6 +135,7 @@ struct PMapRec {
   size_t n_upper = 0;     // slots in use: the host's upper bound (exact value: dev.counters[kPmN])
   size_t live_lower = 0;  // live points: a lower bound
   double clamped = 0;     // slots that entered the index outside its grid, as of the last record
+  double multi_total = 0; // entries of the multi list so far (appended to, never compacted), as of the last record
   double pool_top = 0;    // first free position of the index pool: an upper bound (the last record the host saw + the worst case of
                           // every insertion since)
   int rec_slot = -1, rec_seq = 0;  // pinned record the insertions publish {slots, pool top, dead, error} into; stamp of the latest
@@ -3459,10 +3460,9 @@ int pm_enter_t(o3ds_handle h, CloudRec& c, double voxel, double max_corr_hint, s
   pm_hash_init_kernel<<<grid_for(hcap), kBlock, 0, h->stream>>>(d.h, hcap);
   d.list_cap = (int)std::min<size_t>(cap, 0x7fffffff);
   PM_ALLOC(d.counters, sizeof(int) * kPmCounters);
-  for (int k = 0; k < 2; ++k) {
-    PM_ALLOC(d.unsettled[k], sizeof(int) * cap);
-    PM_ALLOC(d.multi[k], sizeof(unsigned long long) * cap);
-  }
+  for (int k = 0; k < 2; ++k) PM_ALLOC(d.unsettled[k], sizeof(int) * cap);
+  PM_ALLOC(d.multi[0], sizeof(unsigned long long) * cap);
+  d.multi[1] = nullptr;
   PM_ALLOC(d.complex_groups, sizeof(int) * cap);
   PM_ALLOC(d.outside_pts, sizeof(int) * cap);
   PM_ALLOC(d.relink, sizeof(int) * cap);
@@ -3561,6 +3561,8 @@ int pm_enter_t(o3ds_handle h, CloudRec& c, double voxel, double max_corr_hint, s
   if (rc) return rc;
   pm_row_finish_kernel<<<grid_for(pm->rows), kBlock, 0, h->stream>>>(h->d_cells, cs, (int)pm->rows, g.nx, d.counters + kPmPoolTop);
   pm_scatter_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(d, ni, cell_id, h->d_cells);
+  // (the voxels with several members that pm_enter_kernel listed are what the first insertion looks at)
+  HIP_TRY(hipMemcpyAsync(d.counters + kPmMultiIn, d.counters + kPmMultiOut, sizeof(int), hipMemcpyDeviceToDevice, h->stream));
   span_mark(h, kSpanIndexBuild);
   HIP_TRY(hipGetLastError());
   h->cells_clean = true;
@@ -3598,6 +3600,7 @@ int pm_poll(o3ds_handle h, PMapRec* pm, bool block) {
   pm->live_lower = slots - dead;
   pm->pool_top = r->box[0];
   pm->clamped = r->box[5];
+  pm->multi_total = std::max(pm->multi_total, (double)r->box[3]);  // (a carve's record carries 0 here)
   pm->rec_seq = 0;  // consumed
   return O3DS_OK;
 }
@@ -3670,7 +3673,7 @@ int pm_insert_t(o3ds_handle h, CloudRec& c, const CloudRec& scan, const double T
   h->ticket_base += (unsigned int)n_tiles;
   pm_group_kernel<P4><<<grid_for(ms), kBlock, 0, h->stream>>>(d, groups, order, run_next, run_len, starts, piece, placed, placed_nrm, t, crop, t_now, group_key);
   h->voxtab_clean = true;
-  pm_merge_kernel<P4><<<128, 64, 0, h->stream>>>(d, piece, run_next, run_len, placed, placed_nrm, group_key, crop, t_now);
+  pm_merge_kernel<P4><<<512, 64, 0, h->stream>>>(d, piece, run_next, run_len, placed, placed_nrm, group_key, crop, t_now);
   pm_misc_kernel<P4><<<256, kBlock, 0, h->stream>>>(d, placed, placed_nrm, crop, t_now);
   const unsigned int row_blocks = (unsigned int)std::min<size_t>(std::max<size_t>(ms / 8, 64), 2048);
   pm_rows_kernel<P4><<<row_blocks, kBlock, sizeof(int) * 3 * (size_t)(d.grid.nx + 1), h->stream>>>(d);
@@ -3682,7 +3685,6 @@ int pm_insert_t(o3ds_handle h, CloudRec& c, const CloudRec& scan, const double T
   HIP_TRY(hipGetLastError());
   // the lists trade places for the next insertion
   std::swap(pm->dev.unsettled[0], pm->dev.unsettled[1]);
-  std::swap(pm->dev.multi[0], pm->dev.multi[1]);
   pm->t = t_now;
   pm->n_upper += ms;
   c.n = pm->n_upper;
@@ -4142,6 +4144,7 @@ int o3ds_map_insert_scan(o3ds_handle h, o3ds_cloud map, o3ds_cloud scan, const d
       refold = pm->n_upper + s->n > pm->dev.cap || pm->pool_top + growth > (double)pm->dev.pool_cap;
     }
     if (!refold && pm->clamped > 20000.0) refold = true;  // the map has grown well beyond the index grid: new extents (the fold re-grids)
+    if (!refold && pm->multi_total + 4.0 * (double)s->n > 0.5 * (double)pm->dev.list_cap) refold = true;  // the multi list only grows (a fold starts it afresh)
     if (refold) {
       rc = pm_exit(h, *m);
       if (rc) return rc;

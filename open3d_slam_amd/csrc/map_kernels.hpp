@@ -69,7 +69,9 @@ struct PmDev {
   // lists and counters (device)
   int* counters;        // see PmCounter
   int* unsettled[2];    // double-buffered list of slots whose normal is not a fixed point of the re-normalisation
-  unsigned long long* multi[2];  // ... of voxel keys whose chain holds more than one live slot
+  unsigned long long* multi[2];  // [0]: list of the voxel keys whose chain holds more than one live slot -- appended to (kPmMultiOut entries so far), never
+                                 // compacted: an entry that is settled becomes kEmptyKey where it stands; an insertion looks at the first kPmMultiIn
+                                 // ([1] is unused)
   int* complex_groups;  // groups of this insertion with more than one old member inside the volume (by number in `order`)
   int* outside_pts;     // scan points of this insertion that lie outside the volume
   int* relink;          // slots whose mean left its voxel (rounding): re-hashed and re-indexed one by one
@@ -304,6 +306,59 @@ __device__ __forceinline__ void pm_view_key(const PmDev& m, int s, int t_ref, un
   *lo = (unsigned long long)s;
 }
 
+// The same for the lanes of a wavefront that ask (`want`), one after the other, with all 64 lanes walking: 64 volumes per round instead of
+// eight.  A point that comes back into the volume after two hundred insertions outside is a walk of two hundred steps -- 25 rounds of
+// dependent loads on one lane, and pm_merge_kernel is as long as its longest lane; four rounds this way.  Whole wavefronts only.
+template <typename P4>
+__device__ __forceinline__ void pm_view_key_wave(const PmDev& m, bool want, int s_mine, int t_ref, unsigned long long* hi, unsigned long long* lo) {
+  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  unsigned long long pending = __ballot(want);
+  while (pending) {
+    const int leader = (int)__builtin_ctzll(pending);
+    pending &= pending - 1ull;
+    const int s = __shfl(s_mine, leader, 64);
+    const P4 p = ((const P4*)m.pts)[s];
+    const PmSlot ms = m.slot[s];
+    const int st = ms.stamp;
+    const unsigned long long ok = ms.okey;
+    const unsigned long long kp = pm_key(p, m.inv_voxel);
+    unsigned long long h, l;
+    if (pm_in_block(m, s, p, st, ok, t_ref)) {
+      h = 1ull << 63;
+      l = t_ref == 0 ? (unsigned long long)s : (st == t_ref ? ok : kp);
+    } else {
+      const bool memo = ms.out_checked >= st && ms.out_checked < t_ref;
+      int tau = memo ? ms.out_tau : 0;
+      const int t_low = max(memo ? ms.out_checked + 1 : st, 0);
+      for (int base = t_ref - 1; base >= t_low; base -= 64) {
+        const int t = base - lane;
+        const bool in = t >= t_low && pm_in_block(m, s, p, st, ok, t);
+        const unsigned long long hit = __ballot(in);
+        if (hit) {  // the lowest lane is the latest volume
+          tau = base - (int)__builtin_ctzll(hit) + 1;
+          break;
+        }
+      }
+      if (lane == leader) {
+        m.slot[s].out_tau = tau;
+        m.slot[s].out_checked = t_ref - 1;
+      }
+      if (tau > 0) {
+        const int t = tau - 1;
+        h = (unsigned long long)tau << 1;
+        l = t == 0 ? (unsigned long long)s : (st == t ? ok : kp);
+      } else if ((ok & kPmRaw) && st > 0) {
+        h = ((unsigned long long)st << 1) | 1ull;
+        l = ok & ~kPmRaw;
+      } else {
+        h = 0;
+        l = (unsigned long long)s;
+      }
+    }
+    if (lane == leader) *hi = h, *lo = l;
+  }
+}
+
 // ---- entering the persistent form -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void pm_hash_init_kernel(PmHash* __restrict__ hh, size_t n) {
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
@@ -337,7 +392,7 @@ __global__ __launch_bounds__(kBlock) void pm_enter_kernel(PmDev m, int n) {
     const unsigned int e = pm_entry(m, k);
     const int old = atomicExch(&m.h[e].head, s);
     m.slot[s].hnext = old;
-    if (old != -1 && !(atomicOr(&m.h[e].info, 1u) & 1u)) pm_push64(m.multi[0], m.counters + kPmMultiIn, m.list_cap, k, err);
+    if (old != -1 && !(atomicOr(&m.h[e].info, 1u) & 1u)) pm_push64(m.multi[0], m.counters + kPmMultiOut, m.list_cap, k, err);
   }
 }
 
@@ -480,7 +535,8 @@ __device__ __forceinline__ void pm_row_push(const PmDev& m, int s, unsigned long
 // the mean of a voxel's members written where it belongs: point, normal, history, search index (in place: the mean of points of one voxel
 // lies in that voxel, hence in the same index cell), settled or not; `fresh`: the slot is new (its index entry comes with its row)
 template <typename P4>
-__device__ __forceinline__ void pm_store(const PmDev& m, int s, const P4& op, const P4& on, bool has_nrm, int t, unsigned long long key, bool fresh) {
+__device__ __forceinline__ void pm_store(const PmDev& m, int s, const P4& op, const P4& on, bool has_nrm, int t, unsigned long long key, bool fresh,
+                                         int known_pos = -1) {
   P4 o = op;
   o.i = (typename Scalar<P4>::index)s;
   ((P4*)m.pts)[s] = o;
@@ -495,7 +551,7 @@ __device__ __forceinline__ void pm_store(const PmDev& m, int s, const P4& op, co
   }
   m.slot[s].flags = fl;
   if (!fresh) {
-    const int pos = m.slot[s].pos;
+    const int pos = known_pos >= 0 ? known_pos : m.slot[s].pos;
     ((P4*)m.spts)[pos] = o;
     if (has_nrm) ((P4*)m.snrm)[pos] = on;
   }
@@ -673,7 +729,7 @@ __global__ __launch_bounds__(kBlock) void pm_group_kernel(PmDev m, CountRef g_in
       if (s < 0) continue;
       m.slot[s].hnext = m.h[e].head;  // (this thread is the only one that touches this voxel's chain in this launch)
       m.h[e].head = s;
-      if (n_live > 0 && !(atomicOr(&m.h[e].info, 1u) & 1u)) pm_push64(m.multi[1], m.counters + kPmMultiOut, m.list_cap, key, m.counters + kPmError);
+      if (n_live > 0 && !(atomicOr(&m.h[e].info, 1u) & 1u)) pm_push64(m.multi[0], m.counters + kPmMultiOut, m.list_cap, key, m.counters + kPmError);
     }
     pm_store(m, s, op, on, has_nrm, t_now, key, fresh);
     if (fresh) pm_row_push(m, s, pm_key(op, m.inv_voxel));  // (the cell of where the mean really is: pm_check_face re-hashes it if that is another voxel)
@@ -843,66 +899,257 @@ __device__ __forceinline__ void pm_merge_many(const PmDev& m, unsigned int e, un
   pm_check_face(m, first, op, key);
 }
 
+// The same in ONE walk over the chain.  A thread that merges a voxel is a chain of dependent loads -- hash entry, member after member, their
+// points, their histories, their index positions -- and the kernel is as long as its longest chain: written as above (walk to count, walk to
+// gather, walk to unlink each member that goes, slot records loaded again for their positions) that was fifty round trips to memory late
+// in a long run, 70 us for a few hundred voxels.  Here every member's slot record and point are fetched together, once, into a small table
+// in LDS; the order, the sum (all addends' loads in flight together), the deaths and the new links of the chain come from the table.
+// Chains of more than kPmMaxOld members take the functions above.
+constexpr int kPmNodeIn = 1 << 8, kPmNodeInBlock = 1 << 9, kPmNodeGone = 1 << 10;
+struct PmNode {
+  unsigned long long okey, kp;  // history key; voxel key of where the point is
+  int s, pos, stamp, flags;     // slot, index position, stamp, slot flags | kPmNode*
+};
+struct PmNodes {
+  PmNode n[kPmMaxOld];
+};
+// returns the number of chain members (all of them: the dead too), -1 if the chain is longer than the table
+template <typename P4>
+__device__ __forceinline__ int pm_walk_chain(const PmDev& m, unsigned int e, const CropDev& crop, const CropDev& prev_crop, int t_now, PmNodes& nd /* LDS */,
+                                             int* live, int* inside, bool* touched) {
+  const int t_prev = t_now - 1;
+  int cnt = 0, lv = 0, in = 0;
+  bool tch = false;
+  for (int s = m.h[e].head; s != -1;) {
+    if (cnt == kPmMaxOld) return -1;
+    const PmSlot ms = m.slot[s];
+    const P4 p = ((const P4*)m.pts)[s];
+    int fl = (int)(ms.flags & 0xffu);
+    if (!(ms.flags & kPmDead)) {
+      ++lv;
+      tch |= ms.stamp == t_now && !(ms.okey & kPmRaw);
+      if (crop_contains(crop, (double)p.x, (double)p.y, (double)p.z)) {
+        ++in;
+        fl |= kPmNodeIn;
+        const bool in_block = t_prev == 0 ? (s >= m.np_base && s < m.n_base)
+                                          : (ms.stamp == t_prev ? !(ms.okey & kPmRaw) : crop_contains(prev_crop, (double)p.x, (double)p.y, (double)p.z));
+        if (in_block) fl |= kPmNodeInBlock;
+      }
+    }
+    PmNode& n = nd.n[cnt++];
+    n.okey = ms.okey;
+    n.kp = pm_key(p, m.inv_voxel);
+    n.s = s;
+    n.pos = ms.pos;
+    n.stamp = ms.stamp;
+    n.flags = fl;
+    s = ms.hnext;
+  }
+  *live = lv, *inside = in, *touched = tch;
+  return cnt;
+}
+// the members inside the volume (there are several) become one: summed in the order of the reference's array before this insertion, then the
+// scan's points of the voxel (group >= 0), into the first member's slot; the others die and leave the chain.  In three steps, because the
+// middle one is taken by the whole wavefront together: (1) the members inside the volume in the order of pm_gather_old's keys -- returns
+// how many there are, and in *np how many of them need their history looked at (several pass-through members); (2) pm_view_key_wave for
+// o.slot[0 .. np); (3) the rest.
+template <typename P4>
+__device__ __forceinline__ int pm_nodes_order(const PmDev& m, const PmNodes& nd, int cnt, PmOld& o /* LDS */, int t_now, int* np_out) {
+  const int t_prev = t_now - 1;
+  int n = 0;
+  for (int i = 0; i < cnt; ++i) {
+    const PmNode nn = nd.n[i];
+    if (!(nn.flags & kPmNodeIn)) continue;
+    unsigned long long h, l;
+    if (nn.flags & kPmNodeInBlock) {
+      h = 1ull << 63;
+      l = t_prev == 0 ? (unsigned long long)nn.s : (nn.stamp == t_prev ? nn.okey : nn.kp);
+    } else {
+      h = 0;
+      l = ~0ull;
+    }
+    int j = n++;
+    while (j > 0 && (o.hi[j - 1] > h || (o.hi[j - 1] == h && o.lo[j - 1] > l))) {
+      o.hi[j] = o.hi[j - 1], o.lo[j] = o.lo[j - 1], o.slot[j] = o.slot[j - 1];
+      --j;
+    }
+    o.hi[j] = h, o.lo[j] = l, o.slot[j] = i;
+  }
+  int np = 0;
+  if (n > 1 && o.hi[1] == 0)  // several pass-through members: their order is their history
+    while (np < n && o.hi[np] == 0) ++np;
+  *np_out = np;
+  return n;
+}
+template <typename P4>
+__device__ __forceinline__ void pm_nodes_finish(const PmDev& m, unsigned int e, unsigned long long key, PmNodes& nd, int cnt, PmOld& o /* LDS */, int n, int np,
+                                                int group, const int2* __restrict__ piece, const int* __restrict__ run_next,
+                                                const int* __restrict__ run_len, const P4* __restrict__ placed, const P4* __restrict__ placed_nrm, int t_now) {
+  using R = typename Scalar<P4>::type;
+  const bool has_nrm = m.nrm != nullptr;
+  for (int a = 1; a < np; ++a) {  // the pass-through members by their histories (insertion sort of the first np entries)
+    const unsigned long long h = o.hi[a], l = o.lo[a];
+    const int sl = o.slot[a];
+    int j = a;
+    while (j > 0 && (o.hi[j - 1] > h || (o.hi[j - 1] == h && o.lo[j - 1] > l))) {
+      o.hi[j] = o.hi[j - 1], o.lo[j] = o.lo[j - 1], o.slot[j] = o.slot[j - 1];
+      --j;
+    }
+    o.hi[j] = h, o.lo[j] = l, o.slot[j] = sl;
+  }
+  PmAcc acc;
+  for (int j0 = 0; j0 < n; j0 += 4) {  // four members' loads in flight together (clamped), added in order
+    P4 pp[4], qq[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int sl = nd.n[o.slot[min(j0 + u, n - 1)]].s;
+      pp[u] = ((const P4*)m.pts)[sl];
+      qq[u] = has_nrm ? ((const P4*)m.nrm)[sl] : pp[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (j0 + u < n) acc.add(pp[u], has_nrm, qq[u]);
+  }
+  if (group >= 0) {
+    const int2 pc = piece[group];  // {head of the run list, number of runs}
+    int prev = -1;
+    for (int j = 0; j < pc.y; ++j) {
+      const int st = next_run(run_next, pc.x, prev);
+      prev = st;
+      const int len = run_len[st];
+      for (int q = 0; q < len; ++q) {
+        P4 nq{};
+        if (has_nrm) nq = placed_nrm[st + q];
+        acc.add(placed[st + q], has_nrm, nq);
+      }
+    }
+  }
+  P4 op, on;
+  acc.mean(&op, &on);
+  P4 far;  // (pm_kill's sentinel)
+  far.x = far.y = far.z = sizeof(R) == 4 ? (R)3.0e38f : (R)1.0e300;
+  far.i = (typename Scalar<P4>::index)0x7fffffff;
+  for (int j = 1; j < n; ++j) {
+    PmNode& g = nd.n[o.slot[j]];
+    g.flags |= kPmNodeGone;
+    m.slot[g.s].flags = kPmDead;
+    ((P4*)m.spts)[g.pos] = far;
+  }
+  atomicAdd(m.counters + kPmDeadCnt, n - 1);
+  int prev_s = -1;  // the chain without the members that went, in the order it had
+  bool gap = false;
+  for (int i = 0; i < cnt; ++i) {
+    const int fl = nd.n[i].flags, si = nd.n[i].s;
+    if (fl & kPmNodeGone) {
+      gap = true;
+      continue;
+    }
+    if (gap) {
+      if (prev_s == -1)
+        m.h[e].head = si;
+      else
+        m.slot[prev_s].hnext = si;
+      gap = false;
+    }
+    prev_s = si;
+  }
+  if (gap) m.slot[prev_s].hnext = -1;  // (the member that stays is never the one that went: prev_s is a slot)
+  const PmNode keep = nd.n[o.slot[0]];
+  pm_store(m, keep.s, op, on, has_nrm, t_now, key, false, keep.pos);
+  pm_check_face(m, keep.s, op, key);
+}
+
 template <typename P4>
 __global__ __launch_bounds__(64) void pm_merge_kernel(PmDev m, const int2* __restrict__ piece, const int* __restrict__ run_next, const int* __restrict__ run_len,
                                                       const P4* __restrict__ placed, const P4* __restrict__ placed_nrm,
                                                       const unsigned long long* __restrict__ group_key /* [groups] key of group r */, CropDev crop, int t_now) {
   __shared__ PmOld s_old[64];
+  __shared__ PmNodes s_nodes[64];
   PmOld& o = s_old[threadIdx.x];
-  int* err = m.counters + kPmError;
+  PmNodes& nd = s_nodes[threadIdx.x];
   const int cap = m.list_cap;
   const int n_complex = min(m.counters[kPmComplex], cap), n_multi = min(m.counters[kPmMultiIn], cap);
-  for (int i = blockIdx.x * 64 + threadIdx.x; i < n_complex + n_multi; i += gridDim.x * 64) {
+  const CropDev prev_crop = m.hist[max(t_now - 1, 0)];  // (entry 0 is unused: insertion 0 is the base, told by the slot's number)
+  for (int i0 = blockIdx.x * 64; i0 < n_complex + n_multi; i0 += gridDim.x * 64) {  // the wavefront iterates together (pm_view_key_wave)
+    const int i = i0 + threadIdx.x;
+    // (a) per lane: the voxel, its chain, whether its members inside the volume merge
+    unsigned long long key = kEmptyKey;
+    unsigned int e = ~0u;
+    int group = -1, cnt = 0, live = 0, inside = 0;
+    bool merge = false, listed = false;  // listed: an entry of the multi list whose voxel was looked at (its place on the list is decided below)
     if (i < n_complex) {  // a voxel of the scan with several old members inside the volume
-      const int r = m.complex_groups[i];
-      const unsigned long long key = group_key[r];
-      const unsigned int e = pm_entry(m, key);
-      const int n_old = pm_gather_old<P4>(m, e, crop, t_now, o);
-      if (n_old > kPmMaxOld)
-        pm_merge_many<P4>(m, e, key, crop, r, piece, run_next, run_len, placed, placed_nrm, t_now);
-      else
-        pm_merge_old<P4>(m, e, key, o, n_old, r, piece, run_next, run_len, placed, placed_nrm, t_now);
-      continue;
+      group = m.complex_groups[i];
+      key = group_key[group];
+      e = pm_entry(m, key);
+      bool touched;
+      cnt = pm_walk_chain<P4>(m, e, crop, prev_crop, t_now, nd, &live, &inside, &touched);
+      if (cnt >= 0) {
+        merge = true;
+      } else {  // a chain longer than the table
+        const int n_old = pm_gather_old<P4>(m, e, crop, t_now, o);
+        if (n_old > kPmMaxOld)
+          pm_merge_many<P4>(m, e, key, crop, group, piece, run_next, run_len, placed, placed_nrm, t_now);
+        else
+          pm_merge_old<P4>(m, e, key, o, n_old, group, piece, run_next, run_len, placed, placed_nrm, t_now);
+      }
+    } else if (i < n_complex + n_multi) {
+      // a voxel on the multi list.  One the scan touched has been dealt with: its group saw the whole chain (a complex group of this very
+      // launch belongs to another thread, which may be rewriting the chain right now: told apart by the list of this launch, not by the
+      // chain).  The list is not rewritten from insertion to insertion (that was an atomic ticket and a store per entry and insertion,
+      // 20 000 entries in a map of a million points): an entry stays where it is until its voxel is down to one member, then it is blanked.
+      key = m.multi[0][i - n_complex];
+      // Most listed voxels lie far from where anything happens: a voxel that straddled the volume's outer boundary when the sensor passed
+      // stays listed (two members that were never inside together) for as long as the volume stays away.  A voxel that lies ENTIRELY
+      // outside the volume has no member inside it, so nothing merges and the scan cannot have touched it: told from the key alone --
+      // no load.  (Conservative by the voxel's half diagonal plus a margin; only for the plain radius / cylinder volumes.)
+      if (key != kEmptyKey && !pm_voxel_outside(m, key, crop)) {
+        e = pm_find(m, key);
+        if (e == ~0u) {
+          m.multi[0][i - n_complex] = kEmptyKey;
+        } else if ((int)(m.h[e].info >> 8) != t_now) {  // (== t_now: pm_group_kernel handed it to the other branch of this launch; stays listed)
+          listed = true;
+          bool touched = false;
+          cnt = pm_walk_chain<P4>(m, e, crop, prev_crop, t_now, nd, &live, &inside, &touched);
+          if (cnt >= 0) {
+            merge = !touched && inside > 1;
+          } else {  // a chain longer than the table: walk by walk
+            live = inside = 0;
+            for (int s = m.h[e].head; s != -1; s = m.slot[s].hnext) {
+              if (m.slot[s].flags & kPmDead) continue;
+              ++live;
+              touched |= m.slot[s].stamp == t_now && !(m.slot[s].okey & kPmRaw);
+              const P4 p = ((const P4*)m.pts)[s];
+              inside += crop_contains(crop, (double)p.x, (double)p.y, (double)p.z) ? 1 : 0;
+            }
+            if (!touched && inside > 1) {
+              const int n_old = pm_gather_old<P4>(m, e, crop, t_now, o);
+              if (n_old > kPmMaxOld)
+                pm_merge_many<P4>(m, e, key, crop, -1, piece, run_next, run_len, placed, placed_nrm, t_now);
+              else if (n_old > 1)
+                pm_merge_old<P4>(m, e, key, o, n_old, -1, piece, run_next, run_len, placed, placed_nrm, t_now);
+              live -= inside - 1;
+            }
+          }
+        }
+      }
     }
-    // a voxel on the multi list.  One the scan touched has been dealt with: its group saw the whole chain (a complex group of this very
-    // launch belongs to another thread, which may be rewriting the chain right now: told apart by the list of this launch, not by the chain).
-    const unsigned long long key = m.multi[0][i - n_complex];
-    // Most listed voxels lie far from where anything happens: a voxel that straddled the volume's outer boundary when the sensor passed
-    // stays listed (two members that were never inside together) for as long as the volume stays away.  A voxel that lies ENTIRELY
-    // outside the volume has no member inside it, so nothing merges and the scan cannot have touched it: told from the key alone --
-    // no load --, it goes straight back on the list.  (Conservative by the voxel's half diagonal plus a margin; only for the plain
-    // radius / cylinder volumes.)
-    if (pm_voxel_outside(m, key, crop)) {
-      pm_push64(m.multi[1], m.counters + kPmMultiOut, cap, key, err);
-      continue;
+    // (b) the members in order; the histories of several pass-through members by the whole wavefront, lane after lane
+    int n = 0, np = 0;
+    if (merge) n = pm_nodes_order<P4>(m, nd, cnt, o, t_now, &np);
+    for (int a = 0; a < kPmMaxOld; ++a) {
+      const bool want = a < np;
+      if (__ballot(want) == 0ull) break;
+      pm_view_key_wave<P4>(m, want, want ? nd.n[o.slot[a]].s : 0, t_now - 1, &o.hi[a], &o.lo[a]);
     }
-    const unsigned int e = pm_find(m, key);
-    if (e == ~0u) continue;
-    bool touched = (int)(m.h[e].info >> 8) == t_now;  // a voxel pm_group_kernel handed to the other branch of this launch
-    if (touched) {
-      pm_push64(m.multi[1], m.counters + kPmMultiOut, cap, key, err);  // (stays listed; settled at the next insertion)
-      continue;
-    }
-    int live = 0, inside = 0;  // one walk: members, members inside the volume, written by this insertion?
-    for (int s = m.h[e].head; s != -1; s = m.slot[s].hnext) {
-      if (m.slot[s].flags & kPmDead) continue;
-      ++live;
-      touched |= m.slot[s].stamp == t_now && !(m.slot[s].okey & kPmRaw);
-      const P4 p = ((const P4*)m.pts)[s];
-      inside += crop_contains(crop, (double)p.x, (double)p.y, (double)p.z) ? 1 : 0;
-    }
-    if (!touched && inside > 1) {
-      const int n_old = pm_gather_old<P4>(m, e, crop, t_now, o);
-      if (n_old > kPmMaxOld)
-        pm_merge_many<P4>(m, e, key, crop, -1, piece, run_next, run_len, placed, placed_nrm, t_now);
-      else if (n_old > 1)
-        pm_merge_old<P4>(m, e, key, o, n_old, -1, piece, run_next, run_len, placed, placed_nrm, t_now);
+    // (c) per lane again
+    if (merge) {
+      pm_nodes_finish<P4>(m, e, key, nd, cnt, o, n, np, group, piece, run_next, run_len, placed, placed_nrm, t_now);
       live -= inside - 1;
     }
-    if (live > 1)
-      pm_push64(m.multi[1], m.counters + kPmMultiOut, cap, key, err);
-    else
+    if (listed && live <= 1) {  // settled: off the list
+      m.multi[0][i - n_complex] = kEmptyKey;
       m.h[e].info &= ~1u;
+    }
   }
 }
 
@@ -964,7 +1211,7 @@ __global__ __launch_bounds__(kBlock) void pm_misc_kernel(PmDev m, const P4* __re
     m.h[e].head = s;
     if (had && !(m.h[e].info & 1u)) {
       m.h[e].info |= 1u;
-      pm_push64(m.multi[1], m.counters + kPmMultiOut, cap, key, err);
+      pm_push64(m.multi[0], m.counters + kPmMultiOut, cap, key, err);
     }
     pm_row_push(m, s, key);
   }
@@ -981,7 +1228,7 @@ __global__ __launch_bounds__(kBlock) void pm_misc_kernel(PmDev m, const P4* __re
     m.h[e].head = s;
     if (had && !(m.h[e].info & 1u)) {
       m.h[e].info |= 1u;
-      pm_push64(m.multi[1], m.counters + kPmMultiOut, cap, k_new, err);
+      pm_push64(m.multi[0], m.counters + kPmMultiOut, cap, k_new, err);
     }
     if (!(m.slot[s].flags & kPmFresh)) {  // in the index, in the cell of its old voxel (a new slot is listed under the cell it really is in)
       using R = typename Scalar<P4>::type;
@@ -1157,14 +1404,13 @@ __global__ __launch_bounds__(64) void pm_turn_kernel(PmDev m, CountPub pub, Crop
     host_vals[0] = (double)c[kPmPoolTop];
     host_vals[1] = (double)c[kPmDeadCnt];
     host_vals[2] = (double)c[kPmError];
-    host_vals[3] = (double)load_then_store(c + kPmMultiOut);  // (diagnostics: voxels with several members, voxels of this scan with several old
+    host_vals[3] = (double)c[kPmMultiOut];                    // entries of the multi list so far; voxels of this scan with several old
     host_vals[4] = (double)load_then_store(c + kPmComplex);   // members inside)
     host_vals[5] = (double)c[kPmClamped];                     // slots outside the index grid so far
   }
   c[kPmUnsettledIn] = min(load_then_store(c + kPmUnsettledOut), m.list_cap);  // (read and reset by this thread: see common.hpp)
   c[kPmUnsettledOut] = 0;
-  c[kPmMultiIn] = min(load_then_store(c + kPmMultiOut), m.list_cap);
-  c[kPmMultiOut] = 0;
+  c[kPmMultiIn] = min(c[kPmMultiOut], m.list_cap);  // (the multi list is appended to, never rewritten: what it holds now is what the next insertion looks at)
   c[kPmComplex] = c[kPmOutside] = c[kPmRelink] = c[kPmTouched] = c[kPmNew] = 0;
   publish_count(pub, c[kPmN]);
 }

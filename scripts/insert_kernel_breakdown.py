@@ -1,9 +1,12 @@
-"""Per-kernel time of o3ds_map_insert_scan early and late in the growth of a map, from a rocprofv3 --kernel-trace database of
-`python scripts/insert_sweep_run.py`: insertions are told apart by their pm_place_kernel; prints the mean duration of every kernel of an
-insertion for insertions [a0, a1) and [b0, b1)."""
-import collections, re, sqlite3, sys
-db = sqlite3.connect(sys.argv[1])
-rows = list(db.execute("select name,start,end from kernels order by start"))
+"""Per-kernel time of o3ds_map_insert_scan early and late in the growth of a map, from a rocprofv3 --kernel-trace --output-format csv
+directory of `python scripts/insert_sweep_run.py`: insertions are told apart by their pm_place_kernel; prints the mean duration of every
+kernel of an insertion for an early and a late window."""
+import collections, csv, glob, re, sys
+rows = []
+for f in glob.glob(sys.argv[1] + "/**/*_kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        rows.append((r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+rows.sort(key=lambda r: r[1])
 marks = [k for k, r in enumerate(rows) if "pm_place_kernel" in r[0]]
 def short(n):
     n = re.sub(r"^void ", "", n); n = re.sub(r"o3ds::", "", n); return n.split("<")[0].split("(")[0]
