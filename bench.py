@@ -302,8 +302,13 @@ def stage_scans(be, scans32, pinned=True):
     return out
 
 
-def run_stream(be, scans32, profile=False, stage_sync=True, pinned=True, prefetch=True, shipped=False):
+def run_stream(be, scans32, profile=False, stage_sync=True, pinned=True, prefetch=True, shipped=False, ahead=True):
     """frames through the reference-named host classes; returns rates, per-stage wall times and (profile) the per-call table.
+    ahead (with prefetch, not while profiling): the odometry's pre-processing of scan k + 1 is queued behind the launches of frame k's
+    scan-to-scan registration, before the host waits for its result (o3ds_icp_overlap_next) -- the device works through it while the host
+    waits, composes poses and sets the scan-to-map registration up; open3d_slam's odometry worker runs ahead of the mapper the same way, on
+    its own thread (SlamWrapper.cpp:228-229).  The drains of a staged run (stage_sync) wait for it too: it shows in the free-running rate.
+    Same kernels on the same inputs, only earlier: the poses are those of the loop without it, bit for bit (checked in main).
     pinned / prefetch: the scans wait in page-locked buffers and scan k + 1 is handed to the backend (o3ds_cloud_upload_f32: asynchronous, on
     the handle's copy stream) while frame k is being processed -- what the ROS callback thread does in open3d_slam; without
     them the scan is copied from pageable memory and ingested at the start of its own frame, as rounds 1-4 measured it.
@@ -348,7 +353,11 @@ def run_stream(be, scans32, profile=False, stage_sync=True, pinned=True, prefetc
                 be.wait_ingest((nxt or cloud).id)
                 ingest_s.append(time.perf_counter() - tw + (tw - t0))
             t1 = time.perf_counter()
+            if ahead and prefetch and not profile and nxt is not None:
+                be.overlap_next = (lambda c=nxt: odo.preprocessAhead(c))
             ok1 = odo.addRangeScan(cloud, 0.1 * k)
+            if be.overlap_next is not None:  # no registration took it (the first scan): nothing to overlap with
+                be.overlap_next = None
             if stage_sync:
                 be.synchronize()
             t2 = time.perf_counter()
@@ -876,6 +885,19 @@ def main():
                     "through the handle's pinned ring and the wait for it are on the frame's critical path); the headline keeps the scans in "
                     "page-locked message buffers and hands scan k + 1 over while frame k runs (o3ds_pinned_alloc, o3ds_cloud_upload_f32)"}
         be2.close()
+        be2 = backend.Backend(local_rank)
+        free_na = run_stream(be2, scans32, stage_sync=False, ahead=False)
+        m2["free_running"]["scans_per_sec_without_preprocessing_ahead"] = free_na["scans_per_sec"]
+        m2["free_running"]["pose_equals_bitwise_without_it"] = bool(np.array_equal(free_na["pose"], m2["pose"]))
+        be2.close()
+        be2 = backend.Backend(local_rank)
+        na = run_stream(be2, scans32, ahead=False)
+        m2["next_scan_preprocessed_behind_the_odometry_registration"] = {
+            "scans_per_sec_without": na["scans_per_sec"], "pose_equals_bitwise": bool(np.array_equal(na["pose"], m2["pose"])),
+            "what": "the odometry's pre-processing of scan k + 1 is queued behind frame k's scan-to-scan registration, before the host waits for the result "
+                    "(o3ds_icp_overlap_next; open3d_slam's odometry worker runs ahead on its own thread); without: at the start of frame k + 1.  A staged "
+                    "run drains the stream after every stage and so gains nothing from it; free-running loops do (free_running_without below)"}
+        be2.close()
         # the same loop with the odometry's and the mapper's identical pre-processing of a raw scan computed twice, as the reference does
         # (open3d_slam_amd/pointcloud.py shared_preprocess: by default the second caller gets the first caller's cloud)
         from open3d_slam_amd import pointcloud as _pc
@@ -929,7 +951,9 @@ def main():
         try:  # open3d_slam's own LidarOdometry / Mapper sources with integration/open3d_slam_o3ds.patch applied, on this library
             from oracle import ref as _ref
 
-            if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libo3dslam_ref_patched.so")):
+            if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libo3dslam_ref_patched.so")) and not args.no_host_seam:
+                # (--no-host-seam, the profiler runs: under rocprofv3 the reference's worker threads abort the process -- round 5's evidence
+                # visit lost 35 GPU-minutes to that)
                 mp_, op_ = stream_parameters()
                 res_p = {}
                 for name, threads in (("serial", False), ("two_threads", True)):
@@ -983,10 +1007,10 @@ def main():
         dt_gt, dr_gt = syn.se3_error(res["transformation"], T_gt)
 
         # counter-based traffic per launch: measured under rocprofv3 --pmc in separate passes (scripts/gpu_pmc_traffic.sh), calibrated against
-        # known byte counts in this kernel's access pattern (scripts/pmc_calib.hip), committed as profiles/r04_pmc_traffic.json -- a profiler
+        # known byte counts in this kernel's access pattern (scripts/pmc_calib.hip), committed as profiles/r05_pmc_traffic.json -- a profiler
         # cannot run inside this process, so the line quotes the committed measurement of the same command and names it
         # (quoted only while the kernel source is the one it was measured on: the file carries the hash of icp_kernels.hpp)
-        TRAFFIC_FILE = "profiles/r04_pmc_traffic.json"
+        TRAFFIC_FILE = "profiles/r05_pmc_traffic.json"
         try:
             import hashlib
 
@@ -994,10 +1018,10 @@ def main():
             now = hashlib.sha256(open(os.path.join(ROOT, "open3d_slam_amd", "csrc", "icp_kernels.hpp"), "rb").read()).hexdigest()[:16]
             traffic_db = tdoc["kernels"] if tdoc.get("kernel_source_sha16", {}).get("icp_kernels.hpp") == now else {}
             hs = hashlib.sha256()
-            for name in ("cloud_kernels.hpp", "normals_kernel.hpp"):
+            for name in ("cloud_kernels.hpp", "normals_kernel.hpp", "map_kernels.hpp"):
                 hs.update(open(os.path.join(ROOT, "open3d_slam_amd", "csrc", name), "rb").read())
             stream_traffic = (tdoc.get("stream_kernels", {})
-                              if tdoc.get("kernel_source_sha16", {}).get("stream (cloud_kernels.hpp + normals_kernel.hpp)") == hs.hexdigest()[:16] else {})
+                              if tdoc.get("kernel_source_sha16", {}).get("stream (cloud_kernels.hpp + normals_kernel.hpp + map_kernels.hpp)") == hs.hexdigest()[:16] else {})
         except (OSError, ValueError, KeyError):
             traffic_db, stream_traffic = {}, {}
 
@@ -1085,7 +1109,10 @@ def main():
                     vals = [v["traffic"] for k, v in kt.items() if any(p_ in k for p_ in pats)]
                     return sum(vals) if vals else None
                 for row_name, pats in (("normals kernels alone", ("normals_kernel", "normals_finish_kernel")),
-                                       ("crop + VoxelDownSample", ("bbox_kernel", "bbox_final", "vox_insert", "vox_number", "vox_gather", "vox_mean", "VoxFirstFlag")),
+                                       ("crop + VoxelDownSample", ("vox_insert_kernel", "vox_order_kernel", "vox_mean_kernel")),
+                                       ("map_insert_scan (transform + append + voxelizeWithinCroppingVolume + index rebuild)",
+                                        ("pm_place_kernel", "vox_order_kernel", "pm_group_kernel", "pm_merge_kernel", "pm_misc_kernel", "pm_rows_kernel", "pm_place_new_kernel",
+                                         "pm_turn_kernel")),
                                        ("index build kernels (every build of the stream)", ("cell_count_kernel", "scatter_kernel"))):
                     if row_name in calls_ and calls_[row_name]:
                         calls_[row_name]["traffic"] = tsum(*pats)

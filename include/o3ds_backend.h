@@ -194,6 +194,17 @@ int o3ds_icp_point_to_plane_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud tar
 /* Same loop with params->method selecting the estimator (point-to-plane, generalized or point-to-point). */
 int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3ds_crop* target_crop, const double init[16],
                           const o3ds_icp_params* params, o3ds_icp_result* out);
+/* Work for the time the host would wait for a registration.  The callback is handed to the NEXT device-resident registration on the
+ * handle (o3ds_icp_register_dev and the per-estimator entry points above) and is called at most once, on the calling thread, after the
+ * registration's launches have been queued and before the host waits for their result: whatever it queues on the handle runs behind them,
+ * in the time the host spends waiting and -- afterwards -- deciding what to do with the pose.  In open3d_slam that is the odometry
+ * worker's pre-processing of the NEXT raw scan (SlamWrapper.cpp:228-229 runs it on its own thread; a single-threaded caller gets the
+ * same overlap this way).  The callback may call any o3ds_* function on this handle except a registration, a session call or anything
+ * that frees or changes the two clouds being registered; calls that read a size back (o3ds_cloud_size, downloads) wait for the
+ * registration first and so defeat the purpose.  Not called when the registration fails before it queues anything or takes the
+ * two-launch form (sources beyond 262 144 points): *the caller checks* (the callback can count).  fn == NULL withdraws it. */
+typedef void (*o3ds_overlap_fn)(void* arg);
+int o3ds_icp_overlap_next(o3ds_handle h, o3ds_overlap_fn fn, void* arg);
 /* RegistrationIcpGeneralized::registerClouds (CloudRegistration.cpp:16-21) = [O3D] RegistrationGeneralizedICP with a
  * default TransformationEstimationForGeneralizedICP (epsilon 1e-3): per-point covariances C = Rx diag(eps,1,1) Rx^T built from
  * the clouds' (unit) normals, residual (Ct + R Cs R^T)^-1/2 (p - q), same loop / solve / convergence test as point-to-plane.

@@ -48,6 +48,8 @@ class CarvingParams(C.Structure):  # o3ds_carving_params (SpaceCarvingParameters
                 ("min_dot_product_with_normal", C.c_double)]
 
 
+OVERLAP_FN = C.CFUNCTYPE(None, C.c_void_p)  # o3ds_overlap_fn
+
 SIGNATURES = {
     "o3ds_create": (C.c_int, [C.c_int, C.POINTER(_H)]),
     "o3ds_destroy": (C.c_int, [_H]),
@@ -85,6 +87,7 @@ SIGNATURES = {
                                           C.POINTER(IcpResult)]),
     "o3ds_icp_point_to_plane_dev": (C.c_int, [_H, _CL, _CL, C.POINTER(Crop), _dp, C.POINTER(IcpParams), C.POINTER(IcpResult)]),
     "o3ds_icp_register_dev": (C.c_int, [_H, _CL, _CL, C.POINTER(Crop), _dp, C.POINTER(IcpParams), C.POINTER(IcpResult)]),
+    "o3ds_icp_overlap_next": (C.c_int, [_H, OVERLAP_FN, C.c_void_p]),
     "o3ds_icp_pass": (C.c_int, [_H, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "o3ds_icp_pass_finish": (C.c_int, [_H, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(IcpResult)]),
     "o3ds_cloud_undistort": (C.c_int, [_H, _CL, _dp, _dp, C.c_double, C.c_int]),
@@ -367,13 +370,47 @@ class Backend:
         self._ck(self.lib.o3ds_icp_point_to_plane(self.h, sp, len(src), tp, npp, len(tgt), ip, C.byref(p), C.byref(out)))
         return self._result(out)
 
+    # o3ds_icp_overlap_next: `overlap_next` (a callable, set by the caller) is handed to the next device-resident registration and runs
+    # once its launches are queued, before the host waits for the result -- the stream driver queues the pre-processing of the next scan
+    # there (bench.run_stream).  An exception raised inside it is re-raised when the registration has returned.
+    overlap_next = None
+
+    def _hand_over_overlap(self):
+        fn, self.overlap_next = self.overlap_next, None
+        if fn is None:
+            return None
+        state = {"called": False, "error": None, "fn": fn}
+
+        def cb(_arg):
+            state["called"] = True
+            try:
+                fn()
+            except BaseException as e:  # noqa: BLE001 -- crosses a C frame: kept and re-raised by _after_overlap
+                state["error"] = e
+
+        state["cb"] = OVERLAP_FN(cb)  # (kept alive until the registration has returned)
+        self._ck(self.lib.o3ds_icp_overlap_next(self.h, state["cb"], None))
+        return state
+
+    def _after_overlap(self, state):
+        if state is None:
+            return
+        if not state["called"]:  # the registration did not get that far (an error path, the two-launch form): the work is still due
+            state["fn"]()
+        if state["error"] is not None:
+            raise state["error"]
+
     def icp_point_to_plane_dev(self, source: int, target: int, max_corr, init=None, max_iter=30, rel_fitness=1e-6,
                                rel_rmse=1e-6, target_crop: Crop | None = None):
         T0, ip = (None, _IDENTITY16) if init is None else _d(colmajor(init))
         p = self._params(max_corr, max_iter, rel_fitness, rel_rmse)
         out = IcpResult()
-        self._ck(self.lib.o3ds_icp_point_to_plane_dev(self.h, source, target, C.byref(target_crop) if target_crop else None, ip,
-                                                      C.byref(p), C.byref(out)))
+        held = self._hand_over_overlap()
+        try:
+            self._ck(self.lib.o3ds_icp_point_to_plane_dev(self.h, source, target, C.byref(target_crop) if target_crop else None, ip, C.byref(p),
+                                                         C.byref(out)))
+        finally:
+            self._after_overlap(held)
         return self._result(out)
 
     def information_matrix(self, src, tgt, max_corr, T=None) -> np.ndarray:
@@ -406,8 +443,12 @@ class Backend:
         T0, ip = (None, _IDENTITY16) if init is None else _d(colmajor(init))
         p = self._params(max_corr, max_iter, rel_fitness, rel_rmse, ICP_POINT_TO_POINT)
         out = IcpResult()
-        self._ck(self.lib.o3ds_icp_point_to_point_dev(self.h, source, target, C.byref(target_crop) if target_crop else None, ip,
-                                                      C.byref(p), C.byref(out)))
+        held = self._hand_over_overlap()
+        try:
+            self._ck(self.lib.o3ds_icp_point_to_point_dev(self.h, source, target, C.byref(target_crop) if target_crop else None, ip, C.byref(p),
+                                                         C.byref(out)))
+        finally:
+            self._after_overlap(held)
         return self._result(out)
 
     def icp_generalized(self, src, src_normals, tgt, tgt_normals, max_corr, init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6):
@@ -426,8 +467,12 @@ class Backend:
         T0, ip = (None, _IDENTITY16) if init is None else _d(colmajor(init))
         p = self._params(max_corr, max_iter, rel_fitness, rel_rmse, ICP_GENERALIZED)
         out = IcpResult()
-        self._ck(self.lib.o3ds_icp_generalized_dev(self.h, source, target, C.byref(target_crop) if target_crop else None, ip,
-                                                   C.byref(p), C.byref(out)))
+        held = self._hand_over_overlap()
+        try:
+            self._ck(self.lib.o3ds_icp_generalized_dev(self.h, source, target, C.byref(target_crop) if target_crop else None, ip, C.byref(p),
+                                                         C.byref(out)))
+        finally:
+            self._after_overlap(held)
         return self._result(out)
 
     ICP_SUMS_DOUBLES = 512

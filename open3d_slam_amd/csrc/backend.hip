@@ -215,6 +215,8 @@ struct o3ds_context {
   char* d_fused = nullptr;  // [2 states | 3 x kFusedSlots slot records (hi and lo sums)]
   unsigned long long fused_launches = 0;
   unsigned long long fused_seq = 0;  // stamp of the last launch that was asked to write the pinned state (wait_fused_state)
+  o3ds_overlap_fn overlap_fn = nullptr;  // o3ds_icp_overlap_next: called once behind the next registration's launches
+  void* overlap_arg = nullptr;
   // Scratch that its users leave the way they found it, so that no launch is spent on clearing it: the per-cell counters of an index
   // build (the scatter counts them back down to zero) and the voxel table of VoxelDownSample (vox_mean_kernel empties the slots it
   // used).  `*_clean` is false while an operation is in flight or after one failed: the next user clears the block first.
@@ -2266,10 +2268,21 @@ int o3ds_icp_generalized(o3ds_handle h, const double* src_xyz, const double* src
   return rc;
 }
 
+int o3ds_icp_overlap_next(o3ds_handle h, o3ds_overlap_fn fn, void* arg) {
+  CHECK_HANDLE(h);
+  h->overlap_fn = fn;
+  h->overlap_arg = fn ? arg : nullptr;
+  return O3DS_OK;
+}
+
 int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3ds_crop* target_crop, const double init[16],
                           const o3ds_icp_params* params, o3ds_icp_result* out) {
   CHECK_HANDLE(h);
   ArenaScope arena_scope(h);
+  struct OverlapOnce {  // the callback belongs to THIS registration: whatever happens, the next one does not inherit it
+    o3ds_handle h;
+    ~OverlapOnce() { h->overlap_fn = nullptr, h->overlap_arg = nullptr; }
+  } overlap_once{h};
   if (!init || !out) return fail(h, O3DS_ERR_INVALID_ARG, "icp: null init/out");
   // the fused loop runs one workgroup per 64 queries; its exact record sums are order-independent for up to 4096 workgroup records
   // (split_exact), so sources beyond kFusedMaxQueries points take the two-launch form (same results, looped pass kernel)
@@ -2343,6 +2356,14 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
         // a failed launch or stream breaks the "slot buffer g % 3 was cleared by launch g - 1" rotation: clear all three and restart
         // the counter, so that the next registration does not add into records that were never cleared
         hipError_t e = hipGetLastError();
+        if (e == hipSuccess && h->overlap_fn) {  // o3ds_icp_overlap_next: the caller's work for the time this thread would wait (nested
+          const o3ds_overlap_fn fn = h->overlap_fn;  // ABI calls bump-allocate behind this call's temporaries: the arena is reset by the
+          void* const arg = h->overlap_arg;          // outermost call only)
+          h->overlap_fn = nullptr;
+          fn(arg);
+          (void)hipSetDevice(h->device);
+          e = hipGetLastError();
+        }
         if (e == hipSuccess) e = wait_fused_state(h, h->fused_seq);
         if (e != hipSuccess) {
           (void)hipStreamSynchronize(h->stream);

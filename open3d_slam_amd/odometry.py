@@ -35,6 +35,13 @@ class LidarOdometry:
         # RandomDownSample(ratio) (Odometry.cpp:29); setDownSampleSeed pins the kept-index lists
         return random_down_sample(vox, self.params_.scanProcessing_.downSamplingRatio_, self._downsample_rng, self._shuffle_at_full_ratio)
 
+    def preprocessAhead(self, cloud: PointCloud) -> None:
+        """crop -> voxelize -> normals of a raw scan that addRangeScan will be given next, queued now: the result waits on the raw scan
+        (pointcloud.shared_preprocess) for preprocess() -- which still draws its own RandomDownSample -- and for the mapper.  What
+        open3d_slam's odometry worker does on its own thread while the mapper is busy with the previous scan (SlamWrapper.cpp:228-229);
+        a single-threaded driver calls it from o3ds_icp_overlap_next (Backend.overlap_next), behind a registration's launches."""
+        shared_preprocess(cloud, self.cropper_.to_abi(), self.params_.scanProcessing_.voxelSize_, self.cloudRegistration_).release()
+
     def setDownSampleSeed(self, seed: int | None, shuffle_at_full_ratio: bool = False):
         self._downsample_rng = None if seed is None else np.random.default_rng(seed)
         self._shuffle_at_full_ratio = bool(shuffle_at_full_ratio)

@@ -1,4 +1,5 @@
-"""one persistent run of the carved_in_place sequence in a fresh process; prints sizes and what the carve said it removed"""
+"""One persistent-map run of the carved-in-place sequence in a fresh process; prints the map sizes and what the carve said it removed (58 / 56
+points at f64 / f32, every time).  The reproducer of the scalar-load / vector-store hazard of DESIGN.md 4.7: before the fix one run in ten removed 0."""
 import os
 import sys
 

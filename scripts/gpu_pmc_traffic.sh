@@ -15,9 +15,9 @@ SET[dram]="TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_BUBBLE_sum TCC_EA0_RD_UN
 SET[wr]="TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_DRAM_sum TCC_EA0_WRREQ_64B_sum"
 for name in ${SETS-dram wr}; do
   [ -n "$SKIP_CALIB" ] || { ( cd $R && timeout 120 rocprofv3 --kernel-trace --pmc ${SET[$name]} --output-format csv -d $OUT/calib_$name -o pmc -- scripts/build/pmc_calib > $OUT/calib_$name.log 2>&1 ); echo "calib $name rc=$?"; }
-  ( cd $R && timeout 300 rocprofv3 --kernel-trace --pmc ${SET[$name]} --output-format csv -d $OUT/m1_$name -o pmc -- python bench.py --steps 20 --warmup 3 --m2-frames 0 --no-cpu-baseline --concurrent 0 --no-host-seam > $OUT/m1_$name.log 2>&1 ); echo "m1 $name rc=$?"
+  ( cd $R && timeout 300 rocprofv3 --kernel-trace --pmc ${SET[$name]} --output-format csv -d $OUT/m1_$name -o pmc -- python bench.py --steps 20 --warmup 3 --m2-frames 0 --no-cpu-baseline --concurrent 0 --no-host-seam --no-gicp > $OUT/m1_$name.log 2>&1 ); echo "m1 $name rc=$?"
 done
-for name in ${STREAM_SETS-dram}; do
+for name in ${STREAM_SETS-dram wr}; do
   ( cd $R && timeout 240 rocprofv3 --kernel-trace --pmc ${SET[$name]} --output-format csv -d $OUT/stream_$name -o pmc -- python scripts/stream_few_frames.py 3 > $OUT/stream_$name.log 2>&1 ); echo "stream $name rc=$?"
 done
 ( cd $R && python scripts/pmc_traffic_summary.py $OUT --json > $R/gpurun_out/pmc_traffic.txt 2>&1 ); echo "summary rc=$?"

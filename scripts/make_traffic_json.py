@@ -1,9 +1,9 @@
 #!/usr/bin/env python
-"""profiles/r04_pmc_traffic.json (or the path given as argument) from the per-dispatch counter rows of scripts/gpu_pmc_traffic.sh (gpurun_out/pmc_traffic/m1_{dram,wr}):
+"""profiles/r05_pmc_traffic.json (or the path given as argument) from the per-dispatch counter rows of scripts/gpu_pmc_traffic.sh (gpurun_out/pmc_traffic/m1_{dram,wr}):
 what bench.py quotes as roofline.traffic.  The calibration behind the byte-per-request figures is profiles/r03_pmc_calibration*.txt."""
 import collections, csv, glob, hashlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out = {"source": "rocprofv3 --kernel-trace --pmc, one counter set per run, `python bench.py --steps 20 --warmup 3 --m2-frames 0 --no-cpu-baseline --concurrent 0` "
+out = {"source": "rocprofv3 --kernel-trace --pmc, one counter set per run, `python bench.py --steps 20 --warmup 3 --m2-frames 0 --no-cpu-baseline --concurrent 0 --no-gicp --no-host-seam` "
                  "(scripts/gpu_pmc_traffic.sh); per-launch means over the pass launches (the one-workgroup tail launches of the fused loop dropped)",
        "calibration": {"file": "profiles/r03_pmc_calibration_and_m1_traffic.txt",
                        "read_request_bytes": "TCC_EA0_RDREQ counts ONE request per 128-B line for coalesced / fully used lines (stream, aligned 128-B runs: requested bytes / "
@@ -20,7 +20,7 @@ def src_hash(*names):
         h.update(open(os.path.join(ROOT, "open3d_slam_amd", "csrc", n), "rb").read())
     return h.hexdigest()[:16]
 # the figures belong to the kernel sources they were measured on: bench.py quotes them only while the hash still matches
-out["kernel_source_sha16"] = {"icp_kernels.hpp": src_hash("icp_kernels.hpp"), "stream (cloud_kernels.hpp + normals_kernel.hpp)": src_hash("cloud_kernels.hpp", "normals_kernel.hpp")}
+out["kernel_source_sha16"] = {"icp_kernels.hpp": src_hash("icp_kernels.hpp"), "stream (cloud_kernels.hpp + normals_kernel.hpp + map_kernels.hpp)": src_hash("cloud_kernels.hpp", "normals_kernel.hpp", "map_kernels.hpp")}
 def rows(setname, pat, run="m1"):
     f = glob.glob(os.path.join(ROOT, f"gpurun_out/pmc_traffic/{run}_{setname}/**/*counter_collection.csv"), recursive=True)[0]
     by = collections.defaultdict(list)
@@ -65,6 +65,6 @@ try:
                                     "traffic_bytes_per_launch": mr * 64 + mw * 64, "traffic_bytes_per_launch_if_every_read_is_a_full_line": mr * 128 + mw * 64}
 except Exception as e:  # the stream sets are optional
     out["stream_kernels_error"] = repr(e)
-dst = sys.argv[1] if len(sys.argv) > 1 else os.path.join("profiles", "r04_pmc_traffic.json")
+dst = sys.argv[1] if len(sys.argv) > 1 else os.path.join("profiles", "r05_pmc_traffic.json")
 json.dump(out, open(os.path.join(ROOT, dst), "w"), indent=1)
 print(json.dumps(out["kernels"], indent=1))

@@ -628,3 +628,64 @@ def test_candidate_sets_do_not_change_a_single_bit(small_c2, oracle, monkeypatch
             np.testing.assert_array_equal(a["transformation"], b["transformation"], err_msg=str(env))
             assert (a["iterations"], a["converged"], a["n_corr"], a["fitness"], a["inlier_rmse"]) == (
                 b["iterations"], b["converged"], b["n_corr"], b["fitness"], b["inlier_rmse"]), env
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_work_queued_behind_a_registration_changes_neither_result(prec, small_c2):
+    """o3ds_icp_overlap_next: a callback that runs once the registration's launches are queued, before the host waits (the stream driver
+    queues the pre-processing of the next scan there).  The registration's result and the nested calls' clouds must be, bit for bit,
+    what they are without it; the callback runs exactly once, belongs to ONE registration, and what it raises reaches the caller."""
+    be = backend.Backend(0, backend.PRECISION_F64 if prec == "f64" else backend.PRECISION_F32)
+    src, tgt, nrm, _ = small_c2
+    s = be.upload(src)
+    t = be.upload(tgt, nrm)
+    be.build_index(t, 1.0)
+    scene = syn.make_scene()
+    raw = syn.vlp16_scan(scene, syn.make_pose([1.0, 0.5, 0.0], [0.0, 0.0, 10.0]), frame=3, n_az=512)
+    crop = backend.make_crop(backend.CROP_MAX_RADIUS, rmax=25.0)
+
+    def chain():
+        r = be.upload(raw)
+        v = be.crop_voxel_down_sample(r, crop, 0.1)
+        be.estimate_normals(v, 2.0, 10)
+        be.free(r)
+        return v
+
+    plain = be.icp_point_to_plane_dev(s, t, 1.0, max_iter=12)
+    v0 = chain()
+    ref_p, ref_n = be.download(v0)
+    be.free(v0)
+
+    made, calls = [], []
+
+    def behind():
+        calls.append(1)
+        made.append(chain())
+
+    be.overlap_next = behind
+    got = be.icp_point_to_plane_dev(s, t, 1.0, max_iter=12)
+    assert calls == [1] and be.overlap_next is None
+    assert np.array_equal(got["transformation"], plain["transformation"]) and got["iterations"] == plain["iterations"]
+    assert got["fitness"] == plain["fitness"] and got["inlier_rmse"] == plain["inlier_rmse"]
+    p, n = be.download(made[0])
+    assert p.tobytes() == ref_p.tobytes() and n.tobytes() == ref_n.tobytes()
+    be.free(made.pop())
+
+    again = be.icp_point_to_plane_dev(s, t, 1.0, max_iter=12)  # the next registration inherits nothing
+    assert calls == [1] and np.array_equal(again["transformation"], plain["transformation"])
+
+    def raises():
+        raise ValueError("from inside the callback")
+
+    be.overlap_next = raises
+    with pytest.raises(ValueError, match="from inside the callback"):
+        be.icp_point_to_plane_dev(s, t, 1.0, max_iter=12)
+    # a registration that fails before it queues anything: the work is still done, by the wrapper, and the error is the registration's
+    be.overlap_next = behind
+    with pytest.raises(backend.BackendError):
+        be.icp_point_to_plane_dev(s, 987654, 1.0, max_iter=12)
+    assert calls == [1, 1] and len(made) == 1
+    be.free(made.pop())
+    be.free(s)
+    be.free(t)
+    be.close()
