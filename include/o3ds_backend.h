@@ -322,8 +322,7 @@ int o3ds_cloud_copy_across(o3ds_handle dst, o3ds_handle src, o3ds_cloud src_clou
  * the WORLD-anchored grid key = floor(p * (1/voxel)) (VoxelHashMap.hpp:47-50), normals averaged (NaN skipped) and
  * re-normalised (helpers.cpp:172).  Voxel means are emitted in ascending key order.  In place. */
 int o3ds_voxelize_within_volume(o3ds_handle h, o3ds_cloud map, double voxel_size, const o3ds_crop* crop);
-/* Submap::insertScan core (Submap.cpp:54,70-72) in one call: map += T*scan; re-voxelize inside crop; rebuild the
- * NN index (max_corr_hint as in o3ds_cloud_build_index; <= 0 skips the rebuild). */
+/* (Submap::insertScan's core in one call: o3ds_map_insert_scan, declared with its description at the end of this header.) */
 /* ConstantVelocityMotionCompensation::undistortInputPointCloud (src/MotionCompensation.cpp:64-139), in place on a device cloud in
  * the sensor frame: every point is moved by the motion accumulated over phase * scan_duration at the given constant velocity
  * (phase = azimuth / 2 pi, or 1 - that for spinning_clockwise; angular velocity as roll / pitch / yaw rates, R = Rz Ry Rx).  The
@@ -394,6 +393,18 @@ int o3ds_map_carve(o3ds_handle h, o3ds_cloud map, o3ds_cloud raw_scan, const dou
  * its toRemove_ member for the visualisation (Submap.cpp:119, `toRemove_ = *map->SelectByIndex(idxsToRemove)`).  removed_out may be NULL. */
 int o3ds_map_carve_removed(o3ds_handle h, o3ds_cloud map, o3ds_cloud raw_scan, const double map_to_range_sensor[16],
                            const o3ds_crop* map_builder_crop, const o3ds_carving_params* params, size_t* n_removed, o3ds_cloud* removed_out);
+/* Submap::insertScan's tail (Submap.cpp:66-75): map += T * scan, voxelizeWithinCroppingVolume(map_voxel_size, map_builder_crop)
+ * (helpers.cpp:115-183), and -- max_corr_hint > 0 -- the map's search index for the next registration.  The RESULT is the reference's: the
+ * array [points outside the volume in their previous order | one mean per voxel inside it, in voxel-key order], bit for bit in f64
+ * storage.  HOW it is kept is the backend's: from its second insertion on a map with an index and without colours stays in a PERSISTENT
+ * form (slot arrays + voxel hash + row-paged index) that an insertion updates only where the scan falls -- the call queues
+ * eight kernels over the scan and returns, nothing is proportional to the map's size and nothing comes back to the host -- and turns into
+ * the array above when somebody asks for it: o3ds_cloud_download*, o3ds_cloud_size, o3ds_map_carve with another voxel size,
+ * o3ds_overlap_indices, any call that reads or rewrites the map as an array (that fold sorts the live points once, O(N log N)).
+ * Registrations against the map (target = map), o3ds_estimate_normals' readers and o3ds_map_carve with params->voxel_size ==
+ * map_voxel_size and n_removed == NULL or not -- the shipped configuration: 0.1 m both -- work on the persistent form directly.  The map's
+ * o3ds_cloud_size_bound is an upper bound while it is in that form.  An error inside the queued kernels (an internal capacity) is
+ * reported by the next call on the map. */
 int o3ds_map_insert_scan(o3ds_handle h, o3ds_cloud map, o3ds_cloud scan, const double T[16], double map_voxel_size,
                          const o3ds_crop* map_builder_crop, double max_corr_hint);
 
