@@ -9,6 +9,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=40)
 ap.add_argument("--cpu-frames", type=int, default=0)
 ap.add_argument("--profile", action="store_true", help="per-call table from hipEvent spans (perturbs the rates slightly)")
+ap.add_argument("--free", action="store_true", help="no stream drains between the stages (bench.py's free_running leg): what work queued ahead looks like")
 args = ap.parse_args()
 scans = bench.make_stream(args.frames)
 from open3d_slam_amd import backend
@@ -16,7 +17,7 @@ be = backend.Backend(0)
 bench.run_stream(be, scans[: min(8, len(scans))])
 be.close()
 be = backend.Backend(0)
-out = bench.run_stream(be, scans, profile=args.profile)
+out = bench.run_stream(be, scans, profile=args.profile, stage_sync=not args.free)
 be.close()
 out.pop("pose")
 out.pop("poses_per_frame", None)

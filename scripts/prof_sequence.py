@@ -32,6 +32,20 @@ def main(db_path, out_path, frame=60):
         prev_end = e if prev_end is None else max(prev_end, e)
     span = (rows[b][1] - t0) / 1e3
     lines.append("# %d dispatches, %.1f us busy of %.1f us between the two frame starts (%.0f %%)" % (b - a, busy, span, 100.0 * busy / span))
+    # ... and the same two figures over many frames (a single frame may be a carving frame or not)
+    tot_busy = tot_span = 0.0
+    lo_f, hi_f = 20, min(len(marks) - 2, 90)
+    for f in range(lo_f, hi_f):
+        prev_end, fb = None, 0.0
+        for name, s, e in rows[marks[f]:marks[f + 1]]:
+            if prev_end is None or e > prev_end:
+                fb += (e - max(s, prev_end or s)) / 1e3
+            prev_end = e if prev_end is None else max(prev_end, e)
+        tot_busy += fb
+        tot_span += (rows[marks[f + 1]][1] - rows[marks[f]][1]) / 1e3
+    if hi_f > lo_f:
+        lines.append("# frames %d..%d: %.1f us busy of %.1f us per frame on average (%.0f %%)" % (lo_f, hi_f - 1, tot_busy / (hi_f - lo_f), tot_span / (hi_f - lo_f),
+                                                                                                  100.0 * tot_busy / tot_span))
     open(out_path, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
