@@ -20,6 +20,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <numeric>
@@ -282,6 +283,28 @@ inline o3ds_icp_params icpParams(int method, double maxCorrespondenceDistance, c
 // device (ScanOnDevice) is used where it is -- LidarOdometry::addRangeScan then registers two resident clouds, the target with the
 // search grid its normal estimation left behind; a host cloud is uploaded and its index built per call, as the reference builds its
 // KD-tree per call.
+// Work for the time the calling thread would wait for its NEXT stateless registration (o3ds_icp_overlap_next, include/o3ds_backend.h): `fn`
+// runs once, on this thread, after that registration's launches are queued -- a driver that feeds LidarOdometry::addRangeScan from one thread
+// queues the pre-processing of the following scan there.  It may call the seams of this header (the handle's lock is
+// recursive); it must not touch the two clouds being registered.
+inline std::function<void()>& overlapHeld() {
+  static thread_local std::function<void()> held;
+  return held;
+}
+inline void overlapNext(std::function<void()> fn) {
+  const std::shared_ptr<HandleBox> box = threadBox();
+  std::lock_guard<std::recursive_mutex> lck(box->m);
+  overlapHeld() = std::move(fn);
+  o3ds_overlap_fn cb = nullptr;
+  if (overlapHeld())
+    cb = [](void*) {
+      std::function<void()> f = std::move(overlapHeld());
+      overlapHeld() = nullptr;
+      if (f) f();
+    };
+  check(box->h.get(), o3ds_icp_overlap_next(box->h.get(), cb, nullptr));
+}
+
 inline RegistrationResult registerClouds(int method /* o3ds_icp_method */, const PointCloud& source, const PointCloud& target,
                                          const Eigen::Matrix4d& init, double maxCorrespondenceDistance, const ICPConvergenceCriteria& criteria) {
   const std::shared_ptr<HandleBox> box = threadBox();

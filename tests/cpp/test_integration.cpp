@@ -270,6 +270,26 @@ int main(int argc, char** argv) {
     CHECK(ra.fitness_ > 0.9);
     CHECK(translationError(ra.transformation_, rb.transformation_) < 1e-9);
     CHECK(std::fabs(ra.transformation_(0, 3) + 0.05) < 0.02 && std::fabs(ra.transformation_(1, 3) - 0.05) < 0.02);  // p_target = p_source + (o1 - o2)
+    // work queued behind a registration's launches (o3ds::overlapNext): the pre-processing of a third scan, made while the host waits --
+    // the registration and the scan are what they are without it; the callback runs once and is not inherited
+    {
+      PointCloud raw3 = cornerScan(60000, 9, 3.1, 2.9, 1.5);
+      const std::shared_ptr<PointCloud> want3 = o3ds::preprocessScan(raw3, chain);
+      std::shared_ptr<PointCloud> got3;
+      int calls = 0;
+      o3ds::overlapNext([&] {
+        ++calls;
+        got3 = o3ds::preprocessScan(raw3, chain);
+      });
+      const auto rh = o3ds::registerClouds(O3DS_ICP_POINT_TO_PLANE, *pre, *pre2, I.matrix(), maxCorr, crit);
+      CHECK(calls == 1 && got3 && got3->points_.size() == want3->points_.size());
+      for (size_t i = 0; i < want3->points_.size(); i += 53)
+        for (int a = 0; a < 3; ++a) CHECK(got3->points_[i][a] == want3->points_[i][a] && got3->normals_[i][a] == want3->normals_[i][a]);
+      const auto rn = o3ds::registerClouds(O3DS_ICP_POINT_TO_PLANE, *pre, *pre2, I.matrix(), maxCorr, crit);
+      CHECK(calls == 1 && rh.fitness_ == ra.fitness_);
+      for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) CHECK(rh.transformation_(r, c) == ra.transformation_(r, c) && rn.transformation_(r, c) == ra.transformation_(r, c));
+    }
     // a caller that edits the host arrays invalidates the device copy: the edited values are what gets used
     o3ds::ScanOnDevice edited = *dynamic_cast<o3ds::ScanOnDevice*>(pre.get());
     CHECK(o3ds::deviceCopyOf(edited) != nullptr);  // a copy of the object shares the device copy
