@@ -603,7 +603,10 @@ constexpr int kPinRecs = 64;
 inline int* cnt_word(o3ds_handle h, int slot) { return h->d_cnt + 16 * slot; }
 int resolve_count(o3ds_handle h, CloudRec& c, bool block);
 
-// a free record; when all are held (64 clouds with a size or a box in flight) the oldest holder is settled first
+// a free record; when all are held (64 clouds with a size or a box in flight) the oldest holder among the CLOUDS is settled first.  A
+// record of a persistent map (kRecOwnerMap) or of a cloud still being made (~0) is never taken from its owner; -1 if every record is one
+// of those (sixty-odd persistent maps on one handle: the callers fail or do without)
+constexpr uint64_t kRecOwnerMap = ~0ull - 1;
 int take_rec(o3ds_handle h) {
   for (int tries = 0; tries < kPinRecs; ++tries) {
     const int slot = h->rec_next;
@@ -613,15 +616,17 @@ int take_rec(o3ds_handle h) {
       return slot;
     }
   }
-  const int slot = h->rec_next;
-  h->rec_next = (h->rec_next + 1) % kPinRecs;
-  auto it = h->clouds.find(h->rec_owner[slot]);
-  if (it != h->clouds.end()) {
-    if (it->second.lazy_slot == slot) (void)resolve_count(h, it->second, true);
+  for (int tries = 0; tries < kPinRecs; ++tries) {
+    const int slot = h->rec_next;
+    h->rec_next = (h->rec_next + 1) % kPinRecs;
+    auto it = h->clouds.find(h->rec_owner[slot]);
+    if (it == h->clouds.end()) continue;  // a map's record, or a cloud in the making
+    if (it->second.lazy_slot == slot && resolve_count(h, it->second, true) != O3DS_OK) continue;
     if (it->second.pre_slot == slot) it->second.pre_slot = -1;  // the box is reduced again when it is asked for
+    h->rec_owner[slot] = ~0ull;
+    return slot;
   }
-  h->rec_owner[slot] = ~0ull;
-  return slot;
+  return -1;
 }
 hipEvent_t take_event(o3ds_handle h) {
   if (!h->ev_pool.empty()) {
@@ -1711,8 +1716,9 @@ int o3ds_cloud_upload_f32(o3ds_handle h, const void* data, size_t n, size_t poin
     c.pts = b.pts;
     c.ingest_buf = bi;
     // the box of the points inside the volume the handle last cropped with rides on the unpack (pack_strided_f32_box_kernel)
-    if (h->pre_crop_valid) {
-      c.pre_slot = take_rec(h);
+    const int box_slot = h->pre_crop_valid ? take_rec(h) : -1;  // (-1: every record is held by a map -- the box is reduced when it is asked for)
+    if (box_slot >= 0) {
+      c.pre_slot = box_slot;
       c.pre_seq = ++h->rec_seq;
       c.pre_crop = h->pre_crop;
       o3ds_context::PinRec* rec = h->h_rec_dev + c.pre_slot;
@@ -2616,6 +2622,7 @@ int voxel_reduce_t(o3ds_handle h, const CloudRec& in, int mode, double voxel, co
     out.n = n;
     out.n_lower = 1;  // (the box is not empty: at least one point lies inside the volume, hence at least one voxel)
     out.lazy_slot = take_rec(h);
+    if (out.lazy_slot < 0) return fail(h, O3DS_ERR_CAPACITY, "VoxelDownSample: no record free for the size of the result (every one is held by a persistent map)");
     out.lazy_seq = ++h->rec_seq;
     CountPub pub{cnt_word(h, out.lazy_slot), &(h->h_rec_dev + out.lazy_slot)->cnt, out.lazy_seq};
     const CountRef m_ref{n, pub.dev};
@@ -3596,7 +3603,8 @@ int pm_enter_t(o3ds_handle h, CloudRec& c, double voxel, double max_corr_hint, s
   pm->live_lower = n;
   pm->pool_top = (double)(n + n / 2 + 8 * pm->rows);  // (an upper bound until the first record arrives: count + slack of every row)
   pm->rec_slot = take_rec(h);
-  h->rec_owner[pm->rec_slot] = ~0ull;
+  if (pm->rec_slot < 0) return fail(h, O3DS_ERR_CAPACITY, "persistent map: no record free for its counters");
+  h->rec_owner[pm->rec_slot] = kRecOwnerMap;
   pm->rec_seq = 0;
   return O3DS_OK;
 }

@@ -1369,3 +1369,41 @@ def test_normals_estimated_after_the_merge_get_the_map_s_spare_room(prec):
     np.testing.assert_array_equal(q_n, got_n)
     be.close()
     be2.close()
+
+
+def test_a_persistent_map_keeps_its_record_when_every_record_is_wanted():
+    """A handle has 64 pinned records for counts the host has not seen (lazily sized clouds, ingest boxes) and a persistent map holds one
+    for its counters; when more than 64 sizes are in flight the oldest holder among the CLOUDS is settled -- never the map (its record
+    used to be taken: the map's next look at its counters then read a scan's bounding box).  Seventy unasked VoxelDownSample results
+    beside a map in its persistent form: the map must end as it does without them."""
+    scene = syn.make_scene()
+
+    def run(pressure):
+        be = backend.Backend(0)
+        m = be.upload(np.zeros((0, 3)))
+        held = []
+        for k in range(6):
+            T = syn.make_pose([1.2 * k, 0.3 * k, 0.0], [0.0, 0.0, 3.0 * k])
+            s = be.upload(syn.vlp16_scan(scene, T, frame=k, n_az=256))
+            v = be.voxel_down_sample(s, 0.1)
+            be.estimate_normals(v, 2.0, 10)
+            crop = backend.make_crop(backend.CROP_MIN_MAX_RADIUS, center=T[:3, 3], rmin=0.0, rmax=12.0)
+            be.map_insert_scan(m, v, T, 0.2, crop, max_corr_hint=1.0)
+            if pressure and k == 3:  # the map is in its persistent form by now
+                small = be.upload(syn.vlp16_scan(scene, T, frame=100, n_az=64))
+                held = [be.voxel_down_sample(small, 0.1 + 0.01 * j) for j in range(70)]  # sizes nobody asks for
+                be.free(small)
+            be.free(s)
+            be.free(v)
+        p, n = be.download(m)
+        sizes = [be.size(c)[0] for c in held]
+        for c in held:
+            be.free(c)
+        be.free(m)
+        be.close()
+        return p.tobytes(), n.tobytes(), sizes
+
+    p0, n0, _ = run(False)
+    p1, n1, sizes = run(True)
+    assert p0 == p1 and n0 == n1
+    assert len(sizes) == 70 and all(0 < x < 5000 for x in sizes) and sizes[0] >= sizes[-1]
