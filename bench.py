@@ -946,6 +946,11 @@ def main():
                 "what": "o3ds_map_insert_scan (Submap::insertScan: transform, +=, voxelizeWithinCroppingVolume, search index) of the stream's "
                         "pre-processed scans at their true poses into one growing map; hipEvent span per call; rows = the insertions whose map "
                         "size lies within 20 % of 100 k / 300 k / 1 M points"}
+            for row_ in m2["map_insert_scan_by_map_size"]["rows"]:  # ... and as rows of the per-call table, beside the stream's average
+                m2["calls"]["map_insert_scan at ~%d k map points (growing map, sweep)" % (row_["map_points_mark"] // 1000)] = {
+                    "calls": row_["insertions"], "avg_us": row_["avg_us"], "median_us": row_["median_us"], "max_us": row_["max_us"],
+                    "map_points": row_["map_points"], "scan_points": row_["scan_points"],
+                    "bytes": "independent of the map's size by construction (DESIGN.md 4.7): ~100 B per scan point and voxel touched"}
         except Exception as e:  # noqa: BLE001
             m2["map_insert_scan_by_map_size"] = {"error": repr(e)[:400]}
         try:  # open3d_slam's own LidarOdometry / Mapper sources with integration/open3d_slam_o3ds.patch applied, on this library
