@@ -43,8 +43,15 @@ class CroppingVolume:
         return dict(rmin=0.0, rmax=0.0, zmin=0.0, zmax=0.0)
 
     def to_abi(self) -> _b.Crop:
-        """o3ds_crop for this volume; only pose_.translation() enters the predicate (croppers.cpp:121-165)."""
-        return _b.make_crop(self._kind, center=self.pose_[:3, 3], invert=self.isInvertVolume_, **self._radii())
+        """o3ds_crop for this volume; only pose_.translation() enters the predicate (croppers.cpp:121-165).  The struct is kept until
+        something that enters it changes (a frame of the stream asks for the same four volumes again and again; callers only read it)."""
+        pose = self.pose_
+        key = (float(pose[0, 3]), float(pose[1, 3]), float(pose[2, 3]), self.isInvertVolume_, tuple(self._radii().values()))
+        cached = getattr(self, "_abi_cache", None)
+        if cached is None or cached[0] != key:
+            cached = (key, _b.make_crop(self._kind, center=pose[:3, 3], invert=self.isInvertVolume_, **self._radii()))
+            self._abi_cache = cached
+        return cached[1]
 
     def isWithinVolume(self, p) -> bool:
         """Scalar predicate (host); the bulk path is `crop`."""
@@ -74,7 +81,8 @@ class CroppingVolume:
             return not self.isInvertVolume_  # the base volume keeps everything (croppers.cpp:49-55), inverted nothing
         if type(self) is not type(other) or self.isInvertVolume_ or other.isInvertVolume_:
             return False
-        if not np.array_equal(self.pose_[:3, 3], other.pose_[:3, 3]):
+        a_, b_ = self.pose_, other.pose_
+        if not (a_[0, 3] == b_[0, 3] and a_[1, 3] == b_[1, 3] and a_[2, 3] == b_[2, 3]):
             return False
         a, b = self._radii(), other._radii()
         if self._kind == _b.CROP_MAX_RADIUS:

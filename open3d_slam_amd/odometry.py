@@ -10,6 +10,9 @@ from .croppers import CroppingVolume, croppingVolumeFactory
 from .parameters import OdometryParameters
 from .pointcloud import PointCloud, random_down_sample, shared_preprocess
 
+_IDENTITY = np.eye(4)
+_IDENTITY.setflags(write=False)  # (the initial guess of every scan-to-scan registration: read, never written)
+
 
 class LidarOdometry:
     def __init__(self, be):
@@ -57,7 +60,7 @@ class LidarOdometry:
         pre = self.preprocess(cloud)
         # B3: registers PREVIOUS -> CURRENT and integrates the inverse; the target normals are the current scan's
         # (the grid the normal estimation just built for `pre` is kept with the cloud and serves as the registration's target index)
-        result = self.cloudRegistration_.registerClouds(self.cloudPrev_, pre, np.eye(4))
+        result = self.cloudRegistration_.registerClouds(self.cloudPrev_, pre, _IDENTITY)
         ok = result.fitness_ > 0.1  # Odometry.cpp:51 ("todo magic")
         if not ok:
             if not pre.IsEmpty():

@@ -13,6 +13,7 @@ class PointCloud:
         self.be, self.id, self._owns = be, cid, owns
         self._refs = 1          # holders of this device cloud (retain / release)
         self._pre_memo = None   # pre-processed versions of this (raw) scan: shared_preprocess
+        self._known_nonempty = False  # IsEmpty() has seen points in it (see there)
 
     def retain(self) -> "PointCloud":
         """One more holder of the same device cloud: release() frees it when the last one lets go.  (open3d_slam hands its clouds
@@ -52,13 +53,22 @@ class PointCloud:
         return self.be.size(self.id)[0]
 
     def IsEmpty(self) -> bool:
-        """decided by what is known of the size without waiting for it where that suffices (o3ds_cloud_size_bound)"""
+        """decided by what is known of the size without waiting for it where that suffices (o3ds_cloud_size_bound).  A cloud seen to
+        hold points keeps holding them (the mirror's clouds are made once; the map only grows): remembered, not asked again -- except
+        where points are taken away in place (Submap.carve forgets it: forget_size)."""
+        if self._known_nonempty:
+            return False
         lo, up = self.be.size_bound(self.id)
         if up == 0:
             return True
-        if lo > 0:
+        if lo > 0 or len(self) > 0:
+            self._known_nonempty = True
             return False
-        return len(self) == 0
+        return True
+
+    def forget_size(self):
+        """after an operation that removes points from this cloud in place"""
+        self._known_nonempty = False
 
     def HasNormals(self) -> bool:
         """[O3D] points_.size() > 0 && normals_.size() == points_.size().  Whether the device cloud carries normals is known at once; its

@@ -11,6 +11,9 @@ from .parameters import (CloudRegistrationParameters, CloudRegistrationType, Map
                          ScanToMapRegistrationType)
 from .pointcloud import PointCloud, random_down_sample, shared_preprocess
 
+_IDENTITY = np.eye(4)
+_IDENTITY.setflags(write=False)
+
 
 @dataclasses.dataclass
 class ProcessedScans:  # ScanToMapRegistration.hpp:24-27
@@ -77,7 +80,7 @@ class ScanToMapIcp(ScanToMapRegistration):  # ScanToMapRegistration.hpp:40-59
 
     def processForScanMatchingAndMerging(self, cloud: PointCloud, mapToRangeSensor) -> ProcessedScans:  # .cpp:42-54
         wide = self.preprocess(cloud)
-        self.scanMatcherCropper_.setPose(np.eye(4))
+        self.scanMatcherCropper_.setPose(_IDENTITY)
         # the scan-matcher volume of the shipped configurations is the map-builder volume (or contains it): cropping what the latter kept
         # returns it unchanged, so the second cloud is the first (no kernels, no size read-back)
         narrow = wide if self.scanMatcherCropper_.contains(self.mapBuilderCropper_) else self.scanMatcherCropper_.crop(wide)

@@ -120,6 +120,7 @@ class Submap:
         c = self.params_.mapBuilder_.carving_
         if self.mapCloud_.IsEmpty() or not (self.nScansInsertedMap_ % c.carveSpaceEveryNscans_ == 1):
             return 0
+        self.mapCloud_.forget_size()  # (the one place where points leave a cloud of the mirror in place)
         return self.be.map_carve(self.mapCloud_.id, rawScan.id, mapToRangeSensor, self.mapBuilderCropper_.to_abi(), voxel=c.voxelSize_,
                                  max_length=c.maxRaytracingLength_, truncation=c.truncationDistance_, min_dot=c.minDotProductWithNormal_,
                                  want_count=want_count)
