@@ -137,9 +137,15 @@ class PersistentMapModel:
     def array(self):  # pm_exit_t: the live slots by their view keys (ties by slot number: the sort is stable)
         t_last = len(self.hist) - 1
         keyed = sorted(((self.view_key(s, t_last), s) for s, sl in enumerate(self.slots) if not sl.dead))
+        self.order = [s for _, s in keyed]  # slot of every array position (carve)
         pts = np.array([self.slots[s].p for _, s in keyed]).reshape(-1, 3)
         nrm = np.array([self.slots[s].n for _, s in keyed]).reshape(-1, 3)
         return pts, nrm, sum(1 for k, _ in keyed if k[0] < (1 << 63))
+
+
+    def carve(self, removed):  # pm_carve_*: the points that go are marked dead where they are; the survivors' order is their histories'
+        for pos in np.flatnonzero(removed):
+            self.slots[self.order[pos]].dead = True
 
 
 def reference_step(oracle, pts, nrm, scan_p, scan_n, crop_abi, crop, voxel):
@@ -162,7 +168,8 @@ def reference_step(oracle, pts, nrm, scan_p, scan_n, crop_abi, crop, voxel):
     return out_p, out_n, n_pass
 
 
-def _scans(oracle, n_frames, n_az):
+def _scans(oracle, n_frames, n_az, ghosts=()):
+    """ghosts: frames whose scan also sees a small obstacle 3 m ahead that later scans look straight through (what space carving removes)"""
     scene = syn.make_scene()
     out = []
     for k in range(n_frames):
@@ -171,6 +178,10 @@ def _scans(oracle, n_frames, n_az):
         raw = syn.vlp16_scan(scene, T, frame=k, n_az=n_az)
         v = oracle.voxel_down_sample(raw, 0.25)
         n = oracle.estimate_normals(v, 2.0, 10)
+        if k in ghosts:
+            g = np.array([[3.0 + 0.05 * a, -0.3 + 0.15 * b, 0.2 + 0.15 * c] for a in range(2) for b in range(5) for c in range(4)])
+            v = np.vstack([v, g])
+            n = np.vstack([n, np.tile([-1.0, 0.0, 0.0], (len(g), 1))])
         out.append((oracle.transform_points(v, T), oracle.transform_normals(n, T), T))
     return out
 
@@ -216,3 +227,39 @@ def test_the_persistent_form_is_the_reference_s_array(oracle, rebase_at):
     print(stats)
     assert stats["outside"] > 100 and stats["dead"] > 20 and stats["merges_of_several"] > 20, stats
     assert len(ref_p) > 1500
+
+
+def test_carving_the_persistent_form_in_place_keeps_the_survivors_in_order(oracle):
+    """Submap::carve (Submap.cpp:109-125) removes points from the array and keeps the rest in order.  On the persistent form the points
+    that go are marked dead in their slots (pm_carve_apply_kernel) and nothing else happens: the survivors' places are functions of their
+    histories, not of an array.  Carved before insertions 6, 9 and 13 of the out-and-back run (the rays of the scan being inserted,
+    inside the volume of the previous insertion, as Submap::insertScan does it), the model must stay the oracle's array."""
+    from oracle import pyoracle
+
+    voxel, rmax = 0.4, 7.0
+    scans = _scans(oracle, 16, 48, ghosts=(4, 5, 7, 8, 11, 12))
+    ref_p, ref_n = np.zeros((0, 3)), np.zeros((0, 3))
+    model, prev_crop, carved = None, None, 0
+    for k, (sp, sn, T) in enumerate(scans):
+        centre = [float(x) for x in T[:3, 3]]
+        crop = (centre, 0.0, rmax)
+        crop_abi = pyoracle.make_crop(pyoracle.CROP_MIN_MAX_RADIUS, center=centre, rmin=0.0, rmax=rmax)
+        if k in (6, 9, 13):
+            subset = np.array([i for i, p in enumerate(ref_p) if contains(prev_crop, p)], dtype=np.int64)
+            gone = oracle.carve_flags(sp, centre, ref_p, ref_n, subset, voxel=voxel, max_length=20.0, truncation=0.1, min_dot=0.5)
+            assert gone.any() and not gone.all()
+            carved += int(gone.sum())
+            model.array()
+            model.carve(gone)
+            ref_p, ref_n = ref_p[~gone], ref_n[~gone]
+            got_p, got_n, _ = model.array()
+            assert got_p.tobytes() == ref_p.tobytes() and got_n.tobytes() == ref_n.tobytes(), ("after the carve", k)
+        ref_p, ref_n, ref_np = reference_step(oracle, ref_p, ref_n, sp, sn, crop_abi, crop, voxel)
+        prev_crop = crop
+        if model is None:
+            model = PersistentMapModel(ref_p, ref_n, ref_np, voxel)
+            continue
+        model.insert([list(map(float, p)) for p in sp], [list(map(float, n)) for n in sn], crop)
+        got_p, got_n, got_np = model.array()
+        assert got_np == ref_np and got_p.tobytes() == ref_p.tobytes() and got_n.tobytes() == ref_n.tobytes(), k
+    assert carved > 10, carved
