@@ -228,3 +228,68 @@ def test_cropper_containment_is_what_makes_the_narrow_crop_a_no_op(oracle):
     assert said_yes >= 12  # every volume contains itself (but the inverted one), the nested pairs, everything inside the base volume
     assert vols[4].contains(vols[4]) and vols[4].contains(vols[5]) and not vols[5].contains(vols[4])
     assert vols[8].contains(vols[0]) and not vols[0].contains(vols[8]) and not shifted.contains(vols[0]) and not inverted.contains(inverted)
+
+
+def test_a_cropping_volume_s_abi_struct_follows_every_change_of_what_enters_it():
+    """to_abi() keeps its struct between calls (a frame asks for the same volumes again and again); a new pose, a new radius or the
+    inversion flag must give a new one, and the same state the same one."""
+    import numpy as np
+
+    from open3d_slam_amd import croppers as C
+
+    v = C.MinMaxRadiusCroppingVolume(2.0, 30.0)
+    a = v.to_abi()
+    assert v.to_abi() is a and tuple(a.center) == (0.0, 0.0, 0.0) and (a.rmin, a.rmax, a.invert) == (2.0, 30.0, 0)
+    T = np.eye(4)
+    T[:3, 3] = [1.5, -2.0, 0.25]
+    v.setPose(T)
+    b = v.to_abi()
+    assert b is not a and tuple(b.center) == (1.5, -2.0, 0.25) and v.to_abi() is b
+    v.setPose(T.copy())  # the same translation again: nothing that enters the struct changed
+    assert v.to_abi() is b
+    v.setParameters(2.0, 25.0)
+    c = v.to_abi()
+    assert c is not b and c.rmax == 25.0 and tuple(c.center) == (1.5, -2.0, 0.25)
+    v.setIsInvertVolume(True)
+    d = v.to_abi()
+    assert d is not c and d.invert == 1
+    v.pose_[0, 3] = 9.0  # (even a write into the pose array is seen: the key is read from it)
+    assert tuple(v.to_abi().center) == (9.0, -2.0, 0.25)
+    cyl = C.CylinderCroppingVolume(10.0, -1.0, 2.0)
+    assert (cyl.to_abi().rmax, cyl.to_abi().zmin, cyl.to_abi().zmax) == (10.0, -1.0, 2.0)
+    cyl.setParameters(10.0, -1.5, 2.0)
+    assert cyl.to_abi().zmin == -1.5
+
+
+def test_a_cloud_seen_to_hold_points_is_not_asked_again_until_points_are_taken_from_it():
+    """PointCloud.IsEmpty() remembers a non-empty answer (the mirror's clouds are made once and the map only grows); Submap.carve, the one
+    place where points leave a cloud in place, forgets it.  An empty answer is never remembered (a size still in flight may resolve)."""
+    from open3d_slam_amd.pointcloud import PointCloud
+
+    class Be:
+        h = None
+
+        def __init__(self):
+            self.bounds, self.n, self.asked = (0, 100), 0, 0
+
+        def size_bound(self, cid):
+            self.asked += 1
+            return self.bounds
+
+        def size(self, cid):
+            self.asked += 1
+            return self.n, False
+
+    be = Be()
+    c = PointCloud(be, 7, owns=False)
+    assert c.IsEmpty() and be.asked == 2  # bounds say "perhaps": the exact size is asked for, and it is 0
+    assert c.IsEmpty() and be.asked == 4  # ... and asked again the next time
+    be.n = 5
+    assert not c.IsEmpty() and be.asked == 6
+    assert not c.IsEmpty() and not c.IsEmpty() and be.asked == 6  # remembered
+    be.bounds, be.n = (0, 0), 0
+    assert not c.IsEmpty()  # (nobody told the mirror that points were taken away)
+    c.forget_size()
+    assert c.IsEmpty() and be.asked == 7  # upper bound 0: empty without asking for the exact size
+    be.bounds = (3, 50)
+    assert not c.IsEmpty() and be.asked == 8 and not c.IsEmpty() and be.asked == 8
