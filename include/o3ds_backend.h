@@ -99,7 +99,9 @@ void* o3ds_stream(o3ds_handle h);
 int o3ds_set_stream(o3ds_handle h, void* hip_stream);
 /* Kernel timing for bench.py's roofline line: when enabled, every ICP correspondence/reduction pass
  * (icp_accumulate_kernel launch) is bracketed by hipEvents on the launch stream.  profile_read synchronises,
- * returns the number of bracketed launches and their summed duration (ms), and resets the counters. */
+ * returns the number of bracketed launches and their summed duration (ms), and resets the counters.
+ * on = 2 enables the tagged spans below WITHOUT the per-launch brackets: a span around a whole registration then
+ * measures its kernels back to back (bench.py's roofline.avg_launch_us = that span / passes). */
 int o3ds_profile_enable(o3ds_handle h, int on);
 int o3ds_profile_read(o3ds_handle h, uint64_t* n_launches, double* total_ms);
 /* Tagged spans for bench.py's per-call table: while profiling is enabled, o3ds_profile_span(h, tag, 0) / (h, tag, 1) record a pair
@@ -399,9 +401,11 @@ int o3ds_map_carve_removed(o3ds_handle h, o3ds_cloud map, o3ds_cloud raw_scan, c
  * storage.  HOW it is kept is the backend's: from its second insertion on a map with an index and without colours stays in a PERSISTENT
  * form (slot arrays + voxel hash + row-paged index) that an insertion updates only where the scan falls -- the call queues
  * eight kernels over the scan and returns, nothing is proportional to the map's size and nothing comes back to the host -- and turns into
- * the array above when somebody asks for it: o3ds_cloud_download*, o3ds_cloud_size, o3ds_map_carve with another voxel size,
- * o3ds_overlap_indices, any call that reads or rewrites the map as an array (that fold sorts the live points once, O(N log N)).
- * Registrations against the map (target = map), o3ds_estimate_normals' readers and o3ds_map_carve with params->voxel_size ==
+ * the array above when somebody asks for it: o3ds_cloud_download*, o3ds_map_carve with another voxel size, o3ds_overlap_indices,
+ * o3ds_estimate_normals ON the map, a registration with the map as its SOURCE, any call that reads or rewrites the map as an array
+ * (that fold sorts the live points once, O(N log N)).  o3ds_cloud_size answers from the device's counters (live = slots - dead) and
+ * leaves the map persistent.
+ * Registrations against the map (target = map) and o3ds_map_carve with params->voxel_size ==
  * map_voxel_size and n_removed == NULL or not -- the shipped configuration: 0.1 m both -- work on the persistent form directly.  The map's
  * o3ds_cloud_size_bound is an upper bound while it is in that form.  An error inside the queued kernels (an internal capacity) is
  * reported by the next call on the map. */

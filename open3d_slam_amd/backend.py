@@ -525,7 +525,8 @@ class Backend:
     def set_stream(self, hip_stream: int | None):
         self._ck(self.lib.o3ds_set_stream(self.h, C.c_void_p(hip_stream or 0)))
 
-    def profile_enable(self, on: bool):
+    def profile_enable(self, on):
+        """True / 1: hipEvent brackets around every ICP pass launch + tagged spans; 2: tagged spans only; False: off"""
         self._ck(self.lib.o3ds_profile_enable(self.h, int(on)))
 
     def profile_read(self):

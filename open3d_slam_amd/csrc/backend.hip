@@ -232,7 +232,7 @@ struct o3ds_context {
   struct PinRec {
     int cnt, seq;
     double box[6];
-    double pad;
+    double pad;  // box[6] to the kernels that publish seven values (pm_carve_finish_kernel: the number of carved points)
   };
   PinRec* h_rec = nullptr;
   PinRec* h_rec_dev = nullptr;
@@ -264,8 +264,9 @@ struct o3ds_context {
   int fused_chunk_hint[2] = {12, 12};  // [registration against a cropped target?]: scan-to-map and scan-to-scan alternate on a handle  // launches queued before the host first looks at the state: what the previous registration needed, plus one
   int debug_update = 0;  // O3DS_DEBUG_UPDATE: timing experiments only
   int pass_rows = 1024;
-  // profiling (bench.py roofline): event pairs around every accumulate launch
-  bool profiling = false;
+  // profiling (bench.py roofline): 1 = event pairs around every accumulate launch + tagged spans, 2 = tagged spans only (a span around
+  // a whole registration then holds its kernels and nothing else)
+  int profiling = 0;
   std::vector<hipEvent_t> ev;
   size_t ev_used = 0;
   // ... and tagged spans (o3ds_profile_span): pairs of events around whatever the caller -- or, for the internal tags, a kernel
@@ -622,11 +623,22 @@ int take_rec(o3ds_handle h) {
     auto it = h->clouds.find(h->rec_owner[slot]);
     if (it == h->clouds.end()) continue;  // a map's record, or a cloud in the making
     if (it->second.lazy_slot == slot && resolve_count(h, it->second, true) != O3DS_OK) continue;
+    if (it->second.pre_slot == slot && it->second.ingest_ev) continue;  // its box_publish_kernel may still be queued on the copy stream: it would write over the new owner
     if (it->second.pre_slot == slot) it->second.pre_slot = -1;  // the box is reduced again when it is asked for
     h->rec_owner[slot] = ~0ull;
     return slot;
   }
   return -1;
+}
+// the points of a cloud changed in place, or its point array was replaced: the box the asynchronous ingest reduced (pre_slot / pre_crop) is
+// the box of points that no longer exist -- VoxelDownSample's grid origin, the 'nothing inside the volume' return and the index's clamping
+// must not be fed from it (advisor, round 5).  The callers have used the cloud on the handle's stream, i.e. its ingest is ordered before
+// whatever the record is used for next.
+void drop_ingest_box(o3ds_handle h, CloudRec& c) {
+  if (c.pre_slot >= 0) {
+    h->rec_owner[c.pre_slot] = 0;
+    c.pre_slot = -1;
+  }
 }
 hipEvent_t take_event(o3ds_handle h) {
   if (!h->ev_pool.empty()) {
@@ -1172,7 +1184,7 @@ inline QuantumTable quantum_table(const IcpPassArgs& a) {
 template <typename P4>
 void launch_accumulate(o3ds_handle h, const IcpPassArgs& a, bool crop, int nblocks) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (h->profiling) {
+  if (h->profiling == 1) {
     if (h->ev_used + 2 > h->ev.size()) {
       hipEvent_t a0, a1;
       if (hipEventCreate(&a0) == hipSuccess && hipEventCreate(&a1) == hipSuccess) {
@@ -1225,7 +1237,7 @@ static_assert(sizeof(IcpStateDev) <= kFusedStateStride, "state slot too small");
 template <typename P4>
 void launch_fused(o3ds_handle h, const IcpFusedArgs& fa, bool crop, int nblocks, bool bracket) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (h->profiling && bracket) {
+  if (h->profiling == 1 && bracket) {
     if (h->ev_used + 2 > h->ev.size()) {
       hipEvent_t a0, a1;
       if (hipEventCreate(&a0) == hipSuccess && hipEventCreate(&a1) == hipSuccess) {
@@ -1291,6 +1303,13 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
   // (sizes as they are: a source or target whose size a kernel has yet to publish enters with its upper bound and the device word)
   CloudRec* src = find_cloud_lazy(h, source);
   CloudRec* tgt = find_cloud_lazy(h, target);
+  // a persistent submap stays persistent as the TARGET (its row-paged index is what the pass kernel reads); as the SOURCE its slot array
+  // -- dead and never-written slots among the live ones -- would become queries and the fitness denominator: it is folded first
+  if (src && src->pm) {
+    const int re = pm_exit(h, *src);
+    if (re) return re;
+    tgt = find_cloud_lazy(h, target);  // (source == target: the fold dropped the index)
+  }
   int rc = validate_icp(h, src, tgt, params);
   if (rc) return rc;
   const double r_hint = params->max_correspondence_distance;
@@ -1572,7 +1591,7 @@ int o3ds_set_stream(o3ds_handle h, void* hip_stream) {
 int o3ds_profile_enable(o3ds_handle h, int on) {
   CHECK_HANDLE(h);
   HIP_TRY(hipStreamSynchronize(h->stream));
-  h->profiling = on != 0;
+  h->profiling = on == 2 ? 2 : (on != 0);
   h->ev_used = 0;
   for (auto& u : h->span_used) u = 0;
   return O3DS_OK;
@@ -3110,6 +3129,7 @@ int carve_t(o3ds_handle h, CloudRec& map, const CloudRec& scan, const double T[1
   }
   free_index(h, map);
   free_points(h, map);
+  drop_ingest_box(h, map);
   if (map.nrm) dev_free(h, map.nrm);
   if (map.col) dev_free(h, map.col);
   map.pts = np;
@@ -3222,6 +3242,7 @@ int append_t(o3ds_handle h, CloudRec& map, const CloudRec& add) {
   guard.release();
   free_index(h, map);
   free_points(h, map);
+  drop_ingest_box(h, map);
   if (map.nrm) dev_free(h, map.nrm);
   if (map.col) dev_free(h, map.col);
   map.pts = np;
@@ -3302,6 +3323,10 @@ int o3ds_estimate_normals(o3ds_handle h, o3ds_cloud id, double radius, int max_n
   if (!(radius > 0.0)) return fail(h, O3DS_ERR_INVALID_ARG, "maxRadiusNormalEstimation_ must be > 0");  // CloudRegistration.cpp:50
   if (max_nn <= 0) return fail(h, O3DS_ERR_INVALID_ARG, "knnNormalEstimation_ must be > 0");              // CloudRegistration.cpp:51
   if (max_nn > 128) return fail(h, O3DS_ERR_INVALID_ARG, "estimate_normals: max_nn > 128 unsupported");
+  if (c->pm) {  // normals_t reads pts[0..n) as an array: a persistent submap is folded into the reference's array first (o3ds_backend.h)
+    const int re = pm_exit(h, *c);
+    if (re) return re;
+  }
   return DISPATCH(c->precision, normals_t, h, *c, radius, max_nn);
 }
 
@@ -3629,7 +3654,7 @@ int pm_poll(o3ds_handle h, PMapRec* pm, bool block) {
   pm->live_lower = slots - dead;
   pm->pool_top = r->box[0];
   pm->clamped = r->box[5];
-  pm->multi_total = std::max(pm->multi_total, (double)r->box[3]);  // (a carve's record carries 0 here)
+  pm->multi_total = std::max(pm->multi_total, (double)r->box[3]);  // (a carve's record repeats the list's count; its removed points travel in PinRec::pad)
   pm->rec_seq = 0;  // consumed
   return O3DS_OK;
 }
@@ -3817,6 +3842,7 @@ int o3ds_cloud_undistort(o3ds_handle h, o3ds_cloud cloud, const double linear_ve
   }
   free_index(h, *c);
   c->has_box = false;  // the points moved
+  drop_ingest_box(h, *c);  // ... and so did the box the ingest reduced
   return O3DS_OK;
 }
 
@@ -4111,7 +4137,7 @@ int o3ds_map_carve_removed(o3ds_handle h, o3ds_cloud map, o3ds_cloud raw_scan, c
       HIP_TRY(hipGetLastError());
       if (n_removed) {  // (asking for the count is what waits)
         HIP_TRY(hipStreamSynchronize(h->stream));
-        *n_removed = (size_t)(h->h_rec + pm->rec_slot)->box[3];
+        *n_removed = (size_t)(h->h_rec + pm->rec_slot)->pad;  // (the seventh double of the record)
         const int rp = pm_poll(h, pm, true);
         if (rp) return rp;
       }

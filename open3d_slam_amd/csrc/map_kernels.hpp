@@ -1524,9 +1524,10 @@ __global__ __launch_bounds__(64) void pm_carve_finish_kernel(PmDev m, CountPub p
   host_vals[0] = (double)c[kPmPoolTop];
   host_vals[1] = (double)dead;
   host_vals[2] = (double)c[kPmError];
-  host_vals[3] = (double)n;  // removed by this carve
+  host_vals[3] = (double)c[kPmMultiOut];  // (what pm_poll folds into its multi-list total: unchanged by a carve)
   host_vals[4] = 0.0;
   host_vals[5] = (double)c[kPmClamped];
+  host_vals[6] = (double)n;  // removed by this carve (PinRec::pad: read by o3ds_map_carve only)
   publish_count(pub, c[kPmN]);
 }
 

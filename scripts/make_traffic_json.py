@@ -33,6 +33,15 @@ def stat(a):
     keep = [x for x in a if x >= 0.25 * m] if m > 0 else a
     return {"launches": len(keep), "mean": sum(keep) / max(len(keep), 1), "median": m, "max": max(a)}
 ALGO = 65536 * 228
+
+
+def kernel_key(name):
+    """`void o3ds::(anonymous namespace)::foo_kernel<o3ds::P4f>(args)` -> `foo_kernel<P4f>`: cut at the ARGUMENT list's parenthesis, not at
+    the one of `(anonymous namespace)` (round 5 filed every such kernel under the key "")"""
+    name = name.replace("void ", "").replace("(anonymous namespace)::", "").replace("o3ds::", "")
+    return name.split("(")[0][:60]
+
+
 for name, pat, sl in (("icp_fused_kernel<P4f> configs[1] (1 M-point map)", "icp_fused_kernel<o3ds::P4f", slice(0, 516)),
                       ("icp_fused_kernel<P4f> 8 M-point map", "icp_fused_kernel<o3ds::P4f", slice(516, None)),
                       ("icp_fused_kernel<P4d> configs[1] (f64 storage)", "icp_fused_kernel<o3ds::P4d", slice(None))):
@@ -50,7 +59,7 @@ try:
         f = glob.glob(os.path.join(ROOT, f"gpurun_out/pmc_traffic/stream_{setname}/**/*counter_collection.csv"), recursive=True)[0]
         by = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].replace("void ", "").replace("o3ds::", "").split("(")[0][:60]
+            k = kernel_key(r["Kernel_Name"])
             by[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         return by
     rd_by, wr_by = all_rows("dram"), all_rows("wr")
@@ -65,6 +74,6 @@ try:
                                     "traffic_bytes_per_launch": mr * 64 + mw * 64, "traffic_bytes_per_launch_if_every_read_is_a_full_line": mr * 128 + mw * 64}
 except Exception as e:  # the stream sets are optional
     out["stream_kernels_error"] = repr(e)
-dst = sys.argv[1] if len(sys.argv) > 1 else os.path.join("profiles", "r05_pmc_traffic.json")
+dst = sys.argv[1] if len(sys.argv) > 1 else os.path.join("profiles", "r06_pmc_traffic.json")
 json.dump(out, open(os.path.join(ROOT, dst), "w"), indent=1)
 print(json.dumps(out["kernels"], indent=1))
