@@ -21,9 +21,46 @@
 // 6x6 solve) say fma() explicitly.
 #pragma clang fp contract(off)
 
+// Compile-time levers of the search (variant builds: scripts/build_variant.sh <suffix> -DO3DS_ICP_...=0|1)
+#ifndef O3DS_ICP_SEEDS
+#define O3DS_ICP_SEEDS 1  // a query without a usable bound starts from its cell's seed (GridDev::seed)
+#endif
+#ifndef O3DS_ICP_FAR16
+#define O3DS_ICP_FAR16 1  // stage 3 by 16 lanes per query, four queries of the workgroup's list at a time (0: one query per wavefront)
+#endif
+
 namespace o3ds {
 
 constexpr int kBlock = 256;  // 4 wavefronts of 64
+
+// Development aid (-DO3DS_PHASE_PROFILE, with O3DS_ICP_STATS in an A/B build): shader-clock cycles every wavefront spends in the phases of
+// a pass, summed per launch into stats[4 + phase].  A wavefront shares its SIMD with three others, so a phase's cycles include their
+// instructions: read the numbers as shares of the pass, not as instruction counts.
+#ifdef O3DS_PHASE_PROFILE
+constexpr int kPhases = 12;
+__shared__ unsigned long long g_ph_acc[4][kPhases];
+__shared__ unsigned long long g_ph_last[4];
+__device__ __forceinline__ void ph_start() {
+  if ((threadIdx.x & 63) == 0) {
+    for (int k = 0; k < kPhases; ++k) g_ph_acc[threadIdx.x >> 6][k] = 0;
+    g_ph_last[threadIdx.x >> 6] = clock64();
+  }
+}
+__device__ __forceinline__ void ph_mark(int k) {  // (by the first ACTIVE lane: some marks sit inside divergent branches)
+  if ((int)(threadIdx.x & 63) == __ffsll((unsigned long long)__ballot(1)) - 1) {
+    const unsigned long long now = clock64();
+    g_ph_acc[threadIdx.x >> 6][k] += now - g_ph_last[threadIdx.x >> 6];
+    g_ph_last[threadIdx.x >> 6] = now;
+  }
+}
+__device__ __forceinline__ void ph_flush(unsigned long long* stats) {
+  if (stats && (threadIdx.x & 63) == 0)  // (plain stores into this wavefront's own row: atomics on shared counters would be what the phases wait for)
+    for (int k = 0; k < kPhases; ++k) stats[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * kPhases + k] = g_ph_acc[threadIdx.x >> 6][k];
+}
+#define O3DS_PH(k) ph_mark(k)
+#else
+#define O3DS_PH(k) do {} while (0)
+#endif
 
 // ----------------------------------------------------------------------------------------------
 // wave / block reductions (64-wide wavefronts)
@@ -239,6 +276,114 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(const P4* __restrict__ 
       spts[pos] = p;
       if (nrm) snrm[pos] = nrm[i];
     }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// occupancy bits: which cells of a row hold anything, in one load
+// ----------------------------------------------------------------------------------------------
+// A search walks (y, z) rows of cells and needs, per row, the range of the cell-sorted target that the cells xa..xb hold: two cell_start
+// values, anywhere in a table of tens of megabytes -- and most rows a far query looks at are empty (free space), so most of those loads
+// fetch two equal numbers.  What bounds a pass whose queries share no cache lines is the NUMBER of line requests a CU issues (one per
+// clock; scripts/ubench/gather_rates.hip: 270-290 G lane-loads/s chip-wide when the lines are L2-resident, 64 G/s when they come from
+// the Infinity Cache), so the rows are first looked up in a bit set that stays in the L2 (one bit per cell: 300 KB for the configs[1]
+// map): one 64-bit window per row answers "anything in xa..xb?" and trims the range to the occupied cells; only then are the two
+// cell_start values fetched.
+constexpr int kOccMaxK = 15;  // a window covers the x-range of any search with kmax <= this (31 + 2 * 15 < 64)
+__host__ __device__ inline int occ_words_per_row(int nx) { return (nx + 31) / 32 + 1; }
+__global__ __launch_bounds__(kBlock) void occ_build_kernel(GridDev g, unsigned* __restrict__ occ) {
+  const size_t rows = (size_t)g.ny * g.nz, words = rows * (size_t)g.occ_wpr;
+  for (size_t w = (size_t)blockIdx.x * kBlock + threadIdx.x; w < words; w += (size_t)gridDim.x * kBlock) {
+    const size_t row = w / (size_t)g.occ_wpr;
+    const int x0 = (int)(w % (size_t)g.occ_wpr) * 32;
+    const int* cs = g.cell_start + row * (size_t)g.sx;
+    unsigned bits = 0u;
+    if (x0 < g.nx) {
+      int prev = cs[x0];
+      for (int b = 0; b < 32 && x0 + b < g.nx; ++b) {
+        const int next = cs[x0 + b + 1];
+        bits |= next > prev ? 1u << b : 0u;
+        prev = next;
+      }
+    }
+    occ[w] = bits;
+  }
+}
+// the 64 cells of row `rowid` (= z * ny + y) from cell 32 * w on: bit j = cell 32 w + j holds something
+__device__ __forceinline__ unsigned long long occ_window(const GridDev& g, int rowid, int w) {
+  const unsigned* __restrict__ p = g.occ + (size_t)rowid * (size_t)g.occ_wpr + w;
+  return (unsigned long long)p[0] | ((unsigned long long)p[1] << 32);
+}
+// [xa, xb] (cells of the row, 32 w <= xa <= xb < 32 w + 64) trimmed to the occupied cells inside it; false: none
+__device__ __forceinline__ bool occ_trim(unsigned long long win, int w, int* xa, int* xb) {
+  const int a = *xa - 32 * w, b = *xb - 32 * w;
+  const unsigned long long m = win & (~0ull >> (63 - b)) & (~0ull << a);
+  if (!m) return false;
+  *xa = 32 * w + __builtin_ctzll(m);
+  *xb = 32 * w + 63 - __builtin_clzll(m);
+  return true;
+}
+
+// ----------------------------------------------------------------------------------------------
+// seeds: one nearby target point per cell, known before any search starts
+// ----------------------------------------------------------------------------------------------
+// A search that starts without a bound (pass 0 of a registration, a query whose previous pass found nothing, a cached match that a large
+// update has carried away) expands block by block until something turns up, and a query that has NO neighbour within r pays for the
+// whole (2K+1)^3 block to prove it.  seed[cell] = position (in the cell-sorted target) of the first point of the occupied cell whose
+// centre is nearest to this cell's centre, over the block of +-K cells per axis; -1 = that block is empty.  Any target point is a valid
+// starting bound, so the seed changes what a search costs and never what it returns; -1 with K >= kmax PROVES "nothing within r" (every
+// cell a neighbour could lie in is inside the block).  Built once per index by an exact separable Euclidean distance transform of the
+// cell centres: along x, then y, then z, each pass one thread per cell and 2K + 1 reads.
+constexpr int kSeedNone = 127;    // offset value: no occupied cell in the window
+constexpr int kSeedMaxK = 15;
+__global__ __launch_bounds__(kBlock) void seed_x_kernel(GridDev g, int K, signed char* __restrict__ ox) {
+  const size_t ncell = (size_t)g.nx * g.ny * g.nz;
+  for (size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x; c < ncell; c += (size_t)gridDim.x * kBlock) {
+    const int x = (int)(c % (size_t)g.nx);
+    const size_t row = c / (size_t)g.nx * (size_t)g.sx;
+    int best = kSeedNone;
+    for (int d = 0; d <= K && best == kSeedNone; ++d) {  // nearest first: |offset| d, the negative side on ties
+      if (x - d >= 0 && g.cell_start[row + x - d + 1] > g.cell_start[row + x - d]) best = -d;
+      else if (x + d < g.nx && g.cell_start[row + x + d + 1] > g.cell_start[row + x + d]) best = d;
+    }
+    ox[c] = (signed char)best;
+  }
+}
+// oxy[c] = {dx, dy} of the nearest occupied cell of the (x, y) slab window
+__global__ __launch_bounds__(kBlock) void seed_y_kernel(GridDev g, int K, const signed char* __restrict__ ox, short* __restrict__ oxy) {
+  const size_t ncell = (size_t)g.nx * g.ny * g.nz;
+  for (size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x; c < ncell; c += (size_t)gridDim.x * kBlock) {
+    const int y = (int)(c / (size_t)g.nx % (size_t)g.ny);
+    int bd = 1 << 30, bx = kSeedNone, by = 0;
+    for (int d = -K; d <= K; ++d) {
+      if ((unsigned)(y + d) >= (unsigned)g.ny) continue;
+      const int dx = ox[(long long)c + (long long)d * g.nx];
+      if (dx == kSeedNone) continue;
+      const int dd = dx * dx + d * d;
+      if (dd < bd) bd = dd, bx = dx, by = d;
+    }
+    oxy[c] = (short)((bx & 0xff) | ((by & 0xff) << 8));
+  }
+}
+__global__ __launch_bounds__(kBlock) void seed_z_kernel(GridDev g, int K, const short* __restrict__ oxy, int* __restrict__ seed) {
+  const size_t ncell = (size_t)g.nx * g.ny * g.nz, plane = (size_t)g.nx * g.ny;
+  for (size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x; c < ncell; c += (size_t)gridDim.x * kBlock) {
+    const int z = (int)(c / plane);
+    int bd = 1 << 30, bx = 0, by = 0, bz = 0;
+    for (int d = -K; d <= K; ++d) {
+      if ((unsigned)(z + d) >= (unsigned)g.nz) continue;
+      const int v = oxy[(long long)c + (long long)d * (long long)plane];
+      const int dx = (signed char)(v & 0xff), dy = (signed char)((v >> 8) & 0xff);
+      if (dx == kSeedNone) continue;
+      const int dd = dx * dx + dy * dy + d * d;
+      if (dd < bd) bd = dd, bx = dx, by = dy, bz = d;
+    }
+    int out = -1;
+    if (bd != 1 << 30) {
+      const size_t cc = (size_t)((long long)c + bx + (long long)by * g.nx + (long long)bz * (long long)plane);
+      out = g.cell_start[cc / (size_t)g.nx * (size_t)g.sx + cc % (size_t)g.nx];  // the first point of that (occupied) cell
+    }
+    seed[c] = out;
   }
 }
 
@@ -471,22 +616,21 @@ __device__ __forceinline__ NNBest<P4> nn_search_group(const GridDev& g, const P4
                                                       const Collect<typename Scalar<P4>::type>& col, bool* resolved, int* kdone) {
   const QueryCell c = locate(g, (double)qx, (double)qy, (double)qz);
   const int* __restrict__ cs = g.cell_start;
-  // ---- one batch, issued before the bound is even computed: the 4 cell_start values of each of this lane's rows of the 3x3
-  // cross-section (fetching only the rows in reach, after the bound, measured slower: the ALU chain delays the loads)
+  // ---- one batch, issued before the bound is even computed: the occupancy window of each of this lane's rows of the 3x3 cross-section
   const int xlo = max(c.ix - 1, 0), xhi = min(c.ix + 1, g.nx - 1);
+  const int w1 = xlo >> 5;
   constexpr int kOwn = (9 + G - 1) / G;
-  int v[kOwn][4];
-  bool rv[kOwn];
+  unsigned long long ow[kOwn];
+  int rid[kOwn];
 #pragma unroll
   for (int k = 0; k < kOwn; ++k) {
     const int r = gl + k * G;
     const int y = c.iy + (r % 3) - 1, z = c.iz + (r / 3) - 1;
-    rv[k] = r < 9 && xlo <= xhi && (unsigned)y < (unsigned)g.ny && (unsigned)z < (unsigned)g.nz;
-    const int row = rv[k] ? (z * g.ny + y) * g.sx : 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[k][j] = rv[k] ? cs[row + min(xlo + j, xhi + 1)] : 0;
+    const bool rv = r < 9 && xlo <= xhi && (unsigned)y < (unsigned)g.ny && (unsigned)z < (unsigned)g.nz;
+    rid[k] = rv ? z * g.ny + y : -1;
+    ow[k] = occ_window(g, max(rid[k], 0), rv ? w1 : 0);
   }
-  // ---- stage 1: the 3x3x3 block, trimmed by the bound
+  // ---- stage 1: the 3x3x3 block, trimmed by the bound and by what the rows hold
   {
     const float b2 = bound_cells2(best.d2, m, g);
     int ss[kOwn], ee[kOwn];
@@ -497,13 +641,13 @@ __device__ __forceinline__ NNBest<P4> nn_search_group(const GridDev& g, const P4
       const float ddy = slab_dist((r % 3) - 1, c.uy), ddz = slab_dist((r / 3) - 1, c.uz);
       int xa, xb;
       ss[k] = ee[k] = 0;
-      if (rv[k] && row_extent(b2, ddy * ddy + ddz * ddz, c.ux, &xa, &xb)) {
+      if (rid[k] >= 0 && row_extent(b2, ddy * ddy + ddz * ddz, c.ux, &xa, &xb)) {
         xa = max(c.ix + xa, xlo);
         xb = min(c.ix + xb, xhi);
-        if (xa <= xb) {
-          const int ja = xa - xlo, jb = xb - xlo + 1;
-          ss[k] = ja == 0 ? v[k][0] : (ja == 1 ? v[k][1] : v[k][2]);
-          ee[k] = jb == 1 ? v[k][1] : (jb == 2 ? v[k][2] : v[k][3]);
+        if (xa <= xb && occ_trim(ow[k], w1, &xa, &xb)) {
+          const int row = rid[k] * g.sx;
+          ss[k] = cs[row + xa];
+          ee[k] = cs[row + xb + 1];
         }
       }
       cnt += ee[k] > ss[k] ? 1 : 0;
@@ -514,12 +658,14 @@ __device__ __forceinline__ NNBest<P4> nn_search_group(const GridDev& g, const P4
     for (int k = 0; k < kOwn; ++k)
       if (ee[k] > ss[k]) seg[off++] = make_int2(ss[k], ee[k]);
     lds_wave_sync();
+    O3DS_PH(1);
     for (int t = 0; t < total; ++t) {
       const int2 se = seg[t];
       scan_strided<P4, kCrop, kCollect>(tp, se.x, se.y, gl, G, qx, qy, qz, crop, best, col);
     }
     lds_wave_sync();  // the list is rewritten by stage 2
     lanes_min<P4, G>(best);
+    O3DS_PH(2);
   }
   // proven exact if nothing outside the scanned block can be nearer: best <= (cell * (k + face distance))^2, tested with margin
   // (with a candidate-set margin: if the ball of best + m lies inside the block)
@@ -533,30 +679,44 @@ __device__ __forceinline__ NNBest<P4> nn_search_group(const GridDev& g, const P4
     for (int r0 = 0; r0 < 25; r0 += kHalf) {
       const float b2 = bound_cells2(best.d2, m, g);
       int s2[2 * kOwn2], e2[2 * kOwn2];
+      // the occupancy windows of this lane's rows in reach, all in flight together ...
+      int rr[kOwn2], xr[kOwn2];  // row id (-1: nothing to do) and xa | (xb - xa) << 26
+      unsigned long long win[kOwn2];
 #pragma unroll
       for (int k = 0; k < kOwn2; ++k) {
         const int rl = gl + k * G, r = r0 + rl;
         const int dy = (r % 5) - 2, dz = (r / 5) - 2;
         const int y = c.iy + dy, z = c.iz + dz;
-        s2[2 * k] = e2[2 * k] = s2[2 * k + 1] = e2[2 * k + 1] = 0;
+        rr[k] = -1;
+        xr[k] = 0;
         if (rl < kHalf && r < 25 && (unsigned)y < (unsigned)g.ny && (unsigned)z < (unsigned)g.nz) {
           const float ddy = slab_dist(dy, c.uy), ddz = slab_dist(dz, c.uz);
           int xa, xb;
           if (row_extent(b2, ddy * ddy + ddz * ddz, c.ux, &xa, &xb)) {
             xa = max(max(c.ix + xa, c.ix - 2), 0);
             xb = min(min(c.ix + xb, c.ix + 2), g.nx - 1);
-            const bool inner = abs(dy) <= 1 && abs(dz) <= 1;  // cells ix-1..ix+1 of these rows were stage 1
-            const int row = (z * g.ny + y) * g.sx;
-            const int xb1 = inner ? min(xb, c.ix - 2) : xb;
-            if (xa <= xb1) {
-              s2[2 * k] = cs[row + xa];
-              e2[2 * k] = cs[row + xb1 + 1];
-            }
-            const int xa2 = max(xa, c.ix + 2);
-            if (inner && xa2 <= xb) {
-              s2[2 * k + 1] = cs[row + xa2];
-              e2[2 * k + 1] = cs[row + xb + 1];
-            }
+            if (xa <= xb) rr[k] = z * g.ny + y, xr[k] = xa | ((xb - xa) << 26);
+          }
+        }
+        win[k] = occ_window(g, max(rr[k], 0), rr[k] >= 0 ? (xr[k] & 0x3ffffff) >> 5 : 0);
+      }
+      // ... then the cell_start pairs of the runs that hold anything
+#pragma unroll
+      for (int k = 0; k < kOwn2; ++k) {
+        s2[2 * k] = e2[2 * k] = s2[2 * k + 1] = e2[2 * k + 1] = 0;
+        if (rr[k] >= 0) {
+          const int r = r0 + gl + k * G;
+          const bool inner = abs((r % 5) - 2) <= 1 && abs((r / 5) - 2) <= 1;  // cells ix-1..ix+1 of these rows were stage 1
+          const int xa = xr[k] & 0x3ffffff, xb = xa + (xr[k] >> 26), row = rr[k] * g.sx, w2 = xa >> 5;
+          int xa1 = xa, xb1 = inner ? min(xb, c.ix - 2) : xb;
+          if (xa1 <= xb1 && occ_trim(win[k], w2, &xa1, &xb1)) {
+            s2[2 * k] = cs[row + xa1];
+            e2[2 * k] = cs[row + xb1 + 1];
+          }
+          int xa2 = max(xa, c.ix + 2), xb2 = xb;
+          if (inner && xa2 <= xb2 && occ_trim(win[k], w2, &xa2, &xb2)) {
+            s2[2 * k + 1] = cs[row + xa2];
+            e2[2 * k + 1] = cs[row + xb2 + 1];
           }
         }
       }
@@ -569,12 +729,14 @@ __device__ __forceinline__ NNBest<P4> nn_search_group(const GridDev& g, const P4
       for (int k = 0; k < 2 * kOwn2; ++k)
         if (e2[k] > s2[k]) seg[off++] = make_int2(s2[k], e2[k]);
       lds_wave_sync();
+      O3DS_PH(3);
       for (int t = 0; t < total; ++t) {
         const int2 se = seg[t];
         scan_strided<P4, kCrop, kCollect>(tp, se.x, se.y, gl, G, qx, qy, qz, crop, best, col);
       }
       lds_wave_sync();
       lanes_min<P4, G>(best);
+      O3DS_PH(4);
     }
     proven = kmax <= 2 || widen2(best.d2, m) * ic2 <= (2.0f + c.mf) * (2.0f + c.mf);
     *kdone = 2;
@@ -654,6 +816,116 @@ __device__ __forceinline__ void nn_search_wave_far(const GridDev& g, const P4* _
     lds_wave_sync();  // s_list is rewritten by the next round
   }
   lanes_min<P4, 64>(mine);
+  best = mine;
+}
+
+// Stage 3, sub-wavefront form: W lanes serve ONE parked query, 64 / W queries at a time.  A far search is a chain of three or four
+// dependent memory rounds whoever runs it (profiles/r04_pass0_experiments.txt: ~4.7 us for a whole wavefront per query), so what a
+// wavefront gains is queries in flight, not lanes per query.  The rows are those of the RECTANGLE of (dy, dz) offsets the balls of the
+// wavefront's queries can reach (per axis: the slab distance of the offset <= the bound; the union over the 64 / W queries, so that the
+// row loop is the wavefront's and its bookkeeping lives in scalar registers), kPer per lane and round with all their cell_start values in
+// flight together; a row out of a query's own reach costs it a few instructions and no load.  Rows through the block the group stages
+// scanned (offsets <= 2 on every axis) give their two outer runs.  Non-empty runs are compacted into the sub-group's share of the
+// wavefront's LDS list and the W lanes regroup over them as in the wavefront form.  A sub-group without a query runs along on a copy of
+// sub-group 0's and lists nothing (the caller sees to that).
+template <typename P4, bool kCrop, bool kCollect, int W>
+__device__ __forceinline__ void nn_search_sub_far(const GridDev& g, const P4* __restrict__ tp, typename Scalar<P4>::type qx,
+                                                  typename Scalar<P4>::type qy, typename Scalar<P4>::type qz, int K,
+                                                  const CropDev& crop, NNBest<P4>& best, int lane, int2* s_list /* the wavefront's 2 * kFarList entries */,
+                                                  typename Scalar<P4>::type m, const Collect<typename Scalar<P4>::type>& col) {
+  constexpr int kdone = 2;  // cells within offset 2 were scanned by the group stages
+#ifndef O3DS_FAR16_KPER
+#define O3DS_FAR16_KPER 2
+#endif
+  constexpr int kPer = O3DS_FAR16_KPER;    // rows per lane and round (each up to two runs)
+  constexpr int kSubList = 2 * kPer * W;   // runs one round can list per sub-group
+  constexpr int kSubs = 64 / W;
+  static_assert(kSubs * kSubList <= 2 * kFarList, "the sub-lists fit the wavefront's share of s_seg");
+  const QueryCell c = locate(g, (double)qx, (double)qy, (double)qz);
+  const float b2 = bound_cells2(best.d2, m, g);
+  const int* __restrict__ cs = g.cell_start;
+  int y0, y1, z0, z1;  // the wavefront's rectangle of row offsets, scalar
+  {
+    // offsets d with slab_dist(d, u) <= b: d >= -(floor(b - u) + 1) and d <= floor(b - (1 - u)) + 1 (never empty: d = 0 has distance 0)
+    const float b = sqrtf(b2) + 1e-4f;
+    const int ly0 = -((int)floorf(b - c.uy) + 1), ly1 = (int)floorf(b - (1.0f - c.uy)) + 1;
+    const int lz0 = -((int)floorf(b - c.uz) + 1), lz1 = (int)floorf(b - (1.0f - c.uz)) + 1;
+    y0 = __builtin_amdgcn_readlane(ly0, 0), y1 = __builtin_amdgcn_readlane(ly1, 0);
+    z0 = __builtin_amdgcn_readlane(lz0, 0), z1 = __builtin_amdgcn_readlane(lz1, 0);
+#pragma unroll
+    for (int j = 1; j < kSubs; ++j) {
+      y0 = min(y0, __builtin_amdgcn_readlane(ly0, j * W)), y1 = max(y1, __builtin_amdgcn_readlane(ly1, j * W));
+      z0 = min(z0, __builtin_amdgcn_readlane(lz0, j * W)), z1 = max(z1, __builtin_amdgcn_readlane(lz1, j * W));
+    }
+    y0 = max(y0, -K), y1 = min(y1, K), z0 = max(z0, -K), z1 = min(z1, K);
+  }
+  const int ny = y1 - y0 + 1, rows = ny * (z1 - z0 + 1);
+  NNBest<P4> mine = best;
+  for (int base = 0; base < rows; base += kPer * W) {  // scalar
+    int s_own[2 * kPer], e_own[2 * kPer];
+    int rr[kPer], xr[kPer];  // row id (-1: nothing to do) and xa | (xb - xa) << 26
+    unsigned long long win[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {  // the occupancy windows of this lane's rows in reach, all in flight together ...
+      const int r = base + u * W + (lane & (W - 1));
+      rr[u] = -1;
+      xr[u] = 0;
+      if (r < rows) {
+        const int dy = y0 + r % ny, dz = z0 + r / ny;
+        const int y = c.iy + dy, z = c.iz + dz;
+        if ((unsigned)y < (unsigned)g.ny && (unsigned)z < (unsigned)g.nz) {
+          const float ddy = slab_dist(dy, c.uy), ddz = slab_dist(dz, c.uz);
+          int xa, xb;
+          if (row_extent(b2, ddy * ddy + ddz * ddz, c.ux, &xa, &xb)) {
+            xa = max(max(c.ix + xa, c.ix - K), 0);
+            xb = min(min(c.ix + xb, c.ix + K), g.nx - 1);
+            if (xa <= xb) rr[u] = z * g.ny + y, xr[u] = xa | ((xb - xa) << 26);
+          }
+        }
+      }
+      win[u] = occ_window(g, max(rr[u], 0), rr[u] >= 0 ? (xr[u] & 0x3ffffff) >> 5 : 0);
+    }
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {  // ... then the cell_start pairs of the runs that hold anything
+      s_own[2 * u] = e_own[2 * u] = s_own[2 * u + 1] = e_own[2 * u + 1] = 0;
+      if (rr[u] >= 0) {
+        const int r = base + u * W + (lane & (W - 1));
+        const bool inner = abs(y0 + r % ny) <= kdone && abs(z0 + r / ny) <= kdone;
+        const int xa = xr[u] & 0x3ffffff, xb = xa + (xr[u] >> 26), row = rr[u] * g.sx, w3 = xa >> 5;
+        int xa1 = xa, xb1 = inner ? min(xb, c.ix - kdone - 1) : xb;
+        if (xa1 <= xb1 && occ_trim(win[u], w3, &xa1, &xb1)) {
+          s_own[2 * u] = cs[row + xa1];
+          e_own[2 * u] = cs[row + xb1 + 1];
+        }
+        int xa2 = max(xa, c.ix + kdone + 1), xb2 = xb;
+        if (inner && xa2 <= xb2 && occ_trim(win[u], w3, &xa2, &xb2)) {
+          s_own[2 * u + 1] = cs[row + xa2];
+          e_own[2 * u + 1] = cs[row + xb2 + 1];
+        }
+      }
+    }
+    int2* my_list = s_list + (lane / W) * kSubList;
+    int total = 0;
+#pragma unroll
+    for (int u = 0; u < 2 * kPer; ++u) {
+      const bool have = e_own[u] > s_own[u];
+      const unsigned bits = (unsigned)(__ballot(have) >> (lane & ~(W - 1))) & ((1u << W) - 1u);
+      if (have) my_list[total + __popc(bits & ((1u << (lane & (W - 1))) - 1u))] = make_int2(s_own[u], e_own[u]);
+      total += __popc(bits);
+    }
+    lds_wave_sync();
+    O3DS_PH(6);
+    int groups = 1;  // lanes per listed run: W / pow2ceil(min(total, W))
+    while (groups < total && groups < W) groups <<= 1;
+    const int Wl = W / groups, grp = (lane & (W - 1)) / Wl, gl = (lane & (W - 1)) % Wl;
+    for (int t = grp; t < total; t += groups) {
+      const int2 se = my_list[t];
+      scan_strided<P4, kCrop, kCollect>(tp, se.x, se.y, gl, Wl, qx, qy, qz, crop, mine, col);
+    }
+    lds_wave_sync();  // the list is rewritten by the next round
+    O3DS_PH(7);
+  }
+  lanes_min<P4, W>(mine);
   best = mine;
 }
 
@@ -872,9 +1144,9 @@ __device__ __forceinline__ QueryPrefetch<P4> prefetch_query(const IcpPassArgs& a
 }
 
 // lane 0 takes the next ticket of an LDS counter; the result is a scalar (SGPR) value in every lane
-__device__ __forceinline__ int wave_pop(int* counter, int lane) {
+__device__ __forceinline__ int wave_pop(int* counter, int lane, int take = 1) {
   int k = 0;
-  if (lane == 0) k = atomicAdd(counter, 1);
+  if (lane == 0) k = atomicAdd(counter, take);
   return __builtin_amdgcn_readfirstlane(k);
 }
 
@@ -978,6 +1250,9 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
   int* s_far = (int*)&s_red[0][0];  // [0] count, [1] next, [2..] query slots; s_red itself is only used after the loop
   if (threadIdx.x == 0) s_far[0] = s_far[1] = 0;
   lds_barrier();
+#ifdef O3DS_PHASE_PROFILE
+  ph_start();
+#endif
   for (size_t b = (size_t)wg; b < n_batches; b += kSingle ? n_batches : (size_t)nwg) {
     const size_t i = query_index<kQPB, 64 / kGroup>(a.count, b, ql, !use_cache);
     double px = 0, py = 0, pz = 0;
@@ -1044,6 +1319,22 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
             }
           }
         } else {
+          // a query without a usable bound -- pass 0, nothing found last pass, a cached match more than a cell away after a large update --
+          // asks its cell's seed (see "seeds"): a target point nearby, or the proof that nothing lies within r
+          bool nothing = false;
+#if O3DS_ICP_SEEDS
+          if (!kKeys && a.grid.seed != nullptr && a.kmax <= a.grid.seed_k) {  // uniform
+            const QueryCell c = locate(a.grid, (double)qx, (double)qy, (double)qz);
+            const float ic2s = (float)(a.grid.inv_cell * a.grid.inv_cell);
+            const bool loose = best.pos == -1 || (float)best.d2 * ic2s > (1.0f + c.mf) * (1.0f + c.mf);
+            if (loose && (unsigned)c.ix < (unsigned)a.grid.nx && (unsigned)c.iy < (unsigned)a.grid.ny && (unsigned)c.iz < (unsigned)a.grid.nz) {
+              const int sp = a.grid.seed[((size_t)c.iz * a.grid.ny + c.iy) * a.grid.nx + c.ix];
+              nothing = sp < 0;
+              const int spc = min(max(sp, 0), a.n_tgt - 1);
+              consider<P4, kCrop>(tp[spc], spc, sp >= 0, qx, qy, qz, a.crop, best);
+            }
+          }
+#endif
           R tau2 = (R)0;
           if (sets_out) {  // margin of this query's search from the update just applied: the next update is smaller
             const float pn = sqrtf((float)(px * px + py * py + pz * pz));
@@ -1061,7 +1352,13 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
           // (the lane's row offsets are recomputed per batch: hoisted out of the batch loop they cost a dozen registers, i.e. spills)
           int gl_b = gl;
           asm volatile("" : "+v"(gl_b));
-          nn = nn_search_group<P4, kCrop, kGroup, kCollect>(a.grid, tp, qx, qy, qz, a.kmax, a.crop, gl_b, s_seg + ql * kSegMax, best, m, col, &resolved, &kdone);
+          O3DS_PH(0);
+          if (nothing) {  // the block of +-kmax cells around the query's cell is empty: no match, proven as far as that block reaches
+            nn = best;
+            kdone = a.kmax;
+          } else {
+            nn = nn_search_group<P4, kCrop, kGroup, kCollect>(a.grid, tp, qx, qy, qz, a.kmax, a.crop, gl_b, s_seg + ql * kSegMax, best, m, col, &resolved, &kdone);
+          }
           if (!resolved && gl == 0) {  // park the query for stage 3 (its record slot is still unused)
             FarItem<P4>* mine_item = (FarItem<P4>*)(s_rec_flat + ql * kStride);
             mine_item->x = qx;
@@ -1077,6 +1374,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
       }
       unresolved = !resolved;
     }
+    O3DS_PH(5);
     if (tr && threadIdx.x == 0) tr[0] = wall_clock64();
     // Stage 3.  A far query takes a whole wavefront for a few memory rounds, and far queries cluster, so they are pooled per
     // WORKGROUP: every unresolved query parks its state in its (still unused) record slot and enters a list; the four
@@ -1090,10 +1388,28 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
         s_far[2 + k] = ql;
       }
       lds_barrier();
+      O3DS_PH(8);
       const int n_far = __builtin_amdgcn_readfirstlane(s_far[0]);
       if (n_far > 0) {  // workgroup-uniform
         const int lane = threadIdx.x & 63;
         int2* list = s_seg + (threadIdx.x >> 6) * (64 / kGroup) * kSegMax;
+#if O3DS_ICP_FAR16
+        constexpr int kFarW = 16, kFarQ = 64 / kFarW;  // lanes per parked query, queries per wavefront and step
+        for (int k = wave_pop(&s_far[1], lane, kFarQ); k < n_far; k = wave_pop(&s_far[1], lane, kFarQ)) {  // k is scalar: a uniform loop
+          // (a sub-group beyond the end of the list runs along on sub-group 0's query, lists nothing and stores the same winner)
+          const bool active = k + lane / kFarW < n_far;
+          const int slot = s_far[2 + (active ? k + lane / kFarW : k)];
+          FarItem<P4>* it = (FarItem<P4>*)(s_rec_flat + slot * kStride);
+          NNBest<P4> bq;
+          bq.d2 = it->d2;
+          bq.pos = it->pos;
+          bq.idx = it->idx;
+          Collect<R> col;
+          col.tau2 = active ? it->tau2 : (R)0;
+          col.cnt = sets ? s_set + slot * (1 + kSetCap) : nullptr;
+          col.list = col.cnt + 1;
+          if (a.debug != 32) nn_search_sub_far<P4, kCrop, kCollect, kFarW>(a.grid, tp, it->x, it->y, it->z, a.kmax, a.crop, bq, lane, list, it->m, col);
+#else
         for (int k = wave_pop(&s_far[1], lane); k < n_far; k = wave_pop(&s_far[1], lane)) {  // k is scalar: a uniform loop
           const int slot = s_far[2 + k];
           FarItem<P4>* it = (FarItem<P4>*)(s_rec_flat + slot * kStride);
@@ -1106,13 +1422,16 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
           col.cnt = sets ? s_set + slot * (1 + kSetCap) : nullptr;
           col.list = col.cnt + 1;
           if (a.debug != 32) nn_search_wave_far<P4, kCrop, kCollect>(a.grid, tp, it->x, it->y, it->z, a.kmax, a.crop, bq, lane, list, it->m, col);
+#endif
           // every lane holds the same winner and stores it (same address, same value): no lane-0 branch inside this loop --
           // with one, the structurised code re-ran the body for the other lanes forever (seen on ROCm 7.2)
           it->d2 = bq.d2;
           it->pos = bq.pos;
           it->idx = bq.idx;
         }
+        O3DS_PH(9);
         lds_barrier();
+        O3DS_PH(10);
         if (unresolved) {  // (all lanes of the group: the set below is written by all of them)
           nn.d2 = mine_item->d2;
           nn.pos = mine_item->pos;
@@ -1122,6 +1441,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
       }
     }
     if (tr && threadIdx.x == 0) tr[1] = wall_clock64();
+#ifndef O3DS_PHASE_PROFILE
     if (a.stats) {  // development aid: how the queries of this launch were served
       const bool q0 = gl == 0 && i < n_live;
       const unsigned long long nv = __popcll(__ballot(q0 && verified)), ns = __popcll(__ballot(q0 && !verified)),
@@ -1134,6 +1454,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
         atomicAdd(a.stats + 3, nf);
       }
     }
+#endif
     // ---- the candidate set this query's search leaves for the next pass (a verified match keeps the one it has)
     if (sets && i < n_live && !verified && a.debug != 2) {
       const int n_listed = my_set[0];
@@ -1177,6 +1498,10 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
       }
     }
     lds_barrier();
+    O3DS_PH(11);
+#ifdef O3DS_PHASE_PROFILE
+    ph_flush(a.stats);
+#endif
     if (tr && threadIdx.x == 0) tr[2] = wall_clock64();
     if (threadIdx.x == 0) s_far[0] = s_far[1] = 0;  // everyone is past the far list (ordered before its next use by the barrier below)
 #pragma unroll
