@@ -618,7 +618,7 @@ def compact_line(out, detail_path=None):
         line["speedup_vs_cpu_baseline"] = _num(out["speedup_vs_cpu_baseline"])
     line.update(_pick(out, "index_build_ms", "joint_registration_iterations_per_sec", "point_queries_per_sec"))
     line["pose_error_vs_truth"] = _pick(out.get("pose_error_vs_truth", {}), "dt_m", "dr_rad", "fitness", "inlier_rmse")
-    for leg in ("m1_f64", "m1_large_map", "m1_gicp"):
+    for leg in ("m1_f64", "m1_large_map", "m1_gicp", "m1_in_library_sharded_one_rank"):
         if isinstance(out.get(leg), dict):
             line[leg] = _pick(out[leg], "value", "ms_per_step", "roofline.frac", "roofline.avg_launch_us", "roofline.traffic", "n_map", "error")
             if "error" in out[leg]:
@@ -885,7 +885,7 @@ def main():
     assert len(src) == N_SRC
     algo_bytes = N_SRC * ALGO_BYTES_PER_POINT
 
-    def m1(prec, steps, warmup, target=None, mode=None):
+    def m1(prec, steps, warmup, target=None, mode=None, library=False):
         be = backend.Backend(local_rank, prec)
         s_id = be.upload(src)
         t_id = be.upload(*(target or (tgt, nrm)))
@@ -895,7 +895,9 @@ def main():
         index_build_ms = (time.perf_counter() - t0) * 1e3
         if mode is None:
             mode = "union" if args.config == "3u" else "submap"
-        drv = sharded.ShardedIcp(be, mode=mode) if (world > 1 or args.config == "3u") else None
+        # library: o3ds_icp_register_sharded -- the loop, the kernels and the ncclAllReduce calls inside libo3ds_backend.so (its own RCCL
+        # communicator); else open3d_slam_amd/sharded.py: the same kernels driven from Python with torch.distributed collectives in between
+        drv = (sharded.LibraryShardedIcp(be, mode=mode) if library else sharded.ShardedIcp(be, mode=mode)) if (world > 1 or args.config == "3u" or library) else None
         res, elapsed, n_launch, kern_ms, su, collections, (n_span, span_ms) = run_m1(be, world, s_id, t_id, steps, warmup, barrier, drv)
         # what a hipEvent bracket costs by itself on this stream (two records back to back): the brackets around the pass launches include it
         be.profile_enable(True)
@@ -934,6 +936,12 @@ def main():
         r_big["n_map"] = args.large_map
         del big
 
+    r_lib = None
+    if world == 1 and args.config == "1" and not args.no_f64:
+        try:
+            r_lib = m1(backend.PRECISION_F32, max(args.steps // 4, 5), 3, mode="source", library=True)
+        except Exception as e:  # noqa: BLE001 -- an extra leg: it must not take the line down
+            r_lib = {"error": repr(e)[:300]}
     # ---- the same registration from several host threads at once, one handle (= one HIP stream) each: how open3d_slam calls it
     # (odometry, mapping and loop-closure workers register concurrently, SlamWrapper.cpp:258-347).  One 64k-query grid is a single wave of
     # workgroups and a registration is a chain of dependent launches, so one stream leaves most of the chip idle most of the time.
@@ -1225,6 +1233,13 @@ def main():
                 out["m1_gicp"] = run_m1_gicp(local_rank, src, tgt, nrm, max(args.steps // 2, 1), args.warmup, with_oracle=not args.no_cpu_baseline)
             except Exception as e:  # noqa: BLE001
                 out["m1_gicp"] = {"error": repr(e)[:400]}
+        if r_lib is not None:
+            sl_ = max(args.steps // 4, 5)
+            out["m1_in_library_sharded_one_rank"] = r_lib if "error" in r_lib else {
+                "value": ICP_ITERS * sl_ / r_lib["elapsed"], "unit": "icp_iterations/s", "steps": sl_, "ms_per_step": r_lib["elapsed"] / sl_ * 1e3,
+                "pose_equals_value_leg_bitwise": bool(np.array_equal(r_lib["res"]["transformation"], res["transformation"])),
+                "what": "o3ds_icp_register_sharded(O3DS_SHARD_SOURCE) with an RCCL communicator of ONE rank: per pass one icp_fused_kernel + one "
+                        "ncclAllReduce(512 doubles) on the handle's stream, queued by the library -- what the collective costs when it moves nothing"}
         if conc is not None:
             out["concurrent"] = conc
         if m2 is not None:
@@ -1283,6 +1298,17 @@ def main():
         dog.daemon = True
         dog.start()
         also = {}
+        try:  # configs[3] once more with the registration sharded INSIDE the library (RCCL called by libo3ds_backend.so, no Python in the loop)
+            sl = max(args.steps // 2, 5)
+            rl = m1(backend.PRECISION_F32, sl, 3, library=True)
+            if rank == 0:
+                also["config_3_in_library"] = {"metric": "icp_iterations_per_sec", "value": world * ICP_ITERS * sl / rl["elapsed"], "unit": "icp_iterations/s", "steps": sl,
+                                               "ms_per_step": rl["elapsed"] / sl * 1e3, "joint_registration_iterations_per_sec": ICP_ITERS * sl / rl["elapsed"],
+                                               "what": "o3ds_icp_register_sharded(O3DS_SHARD_SUBMAP): per pass one icp_fused_kernel + one ncclAllReduce of 512 doubles, "
+                                                       "queued by the library on its own stream for all passes; same work as the line above",
+                                               "pose_equals_the_line_above_bitwise": bool(np.array_equal(rl["res"]["transformation"], r32["res"]["transformation"]))}
+        except Exception as e:  # noqa: BLE001
+            also["config_3_in_library"] = {"error": repr(e)[:400]}
         try:
             s3u = max(args.steps // 4, 5)
             r3u = m1(backend.PRECISION_F32, s3u, 3, mode="union")

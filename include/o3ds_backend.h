@@ -285,6 +285,37 @@ int o3ds_icp_pass(o3ds_handle h, size_t first, size_t count, size_t n_src_total,
 int o3ds_icp_pass_finish(o3ds_handle h, size_t n_src_total, const double* d_sums_in, double* d_sums_scratch, o3ds_icp_result* out);
 int o3ds_icp_done(o3ds_handle h, int* done);
 
+/* ---- the same registrations, sharded over the GPUs of a node, entirely inside the library: kernels and RCCL collectives queued on
+ *      o3ds_stream(h) for ALL max_iteration + 1 passes, no host code between them (the reference registers against one cloud,
+ *      Mapper.cpp:141 -> ScanToMapRegistration.cpp:55-62 -> CloudRegistration.cpp:44-48; the partitionings are SURVEY.md 8e's).
+ * One process per GPU, one handle per process.  RCCL (librccl.so) is loaded with dlopen at the first call of this group -- a
+ * single-GPU user of the library does not need it installed -- and the communicator is created by THAT copy of the library:
+ *   o3ds_comm_unique_id   on ONE rank: a 128-byte ncclUniqueId, to be handed to every rank by whatever the processes share
+ *                         (torch.distributed's broadcast, MPI, a file);
+ *   o3ds_comm_init        on EVERY rank (collective: ncclCommInitRank): the handle keeps the communicator;
+ *   o3ds_comm_attach      instead of init: an ncclComm_t the caller made with the same librccl.so the process has loaded;
+ *   o3ds_comm_destroy     (also done by o3ds_destroy).
+ * o3ds_icp_register_sharded: `partitioning`
+ *   O3DS_SHARD_SOURCE  every rank holds the same target; rank r contributes the source points [r n / W, (r + 1) n / W): per pass ONE
+ *                      icp_fused_kernel + ONE ncclAllReduce(sum) of the 512-double exact hi / lo record (4 KB) -- equal to the one-GPU
+ *                      registration bit for bit, whatever W (the sums are exact);
+ *   O3DS_SHARD_SUBMAP  every rank holds ITS OWN submap and the whole source: the same kernel and collective, the summed record is the
+ *                      joint problem over the W submaps (BASELINE.json configs[3]; fitness = mean over the submaps);
+ *   O3DS_SHARD_UNION   ONE map split over the ranks, every rank holds the whole source: per pass search kernel -> ncclAllReduce(min) of
+ *                      n 64-bit keys -> accumulate kernel -> ncclAllReduce(sum) of 32 doubles -> update kernel; equal to the
+ *                      registration against the whole map (W <= 16).
+ * Point-to-plane, generalized and point-to-point estimators (params->method) as o3ds_icp_register_dev.  With a communicator of one
+ * rank every collective is the identity and SOURCE / SUBMAP reproduce o3ds_icp_register_dev bit for bit. */
+#define O3DS_SHARD_SOURCE 0
+#define O3DS_SHARD_SUBMAP 1
+#define O3DS_SHARD_UNION 2
+int o3ds_comm_unique_id(o3ds_handle h, unsigned char id[128]);
+int o3ds_comm_init(o3ds_handle h, const unsigned char id[128], int rank, int world);
+int o3ds_comm_attach(o3ds_handle h, void* nccl_comm, int rank, int world);
+int o3ds_comm_destroy(o3ds_handle h);
+int o3ds_icp_register_sharded(o3ds_handle h, int partitioning, o3ds_cloud source, o3ds_cloud target, const o3ds_crop* target_crop,
+                              const double init[16], const o3ds_icp_params* params, o3ds_icp_result* out);
+
 /* ---- scan pre-processing: ScanToMapIcp::preprocess (ScanToMapRegistration.cpp:35-40),
  *      LidarOdometry::preprocess (Odometry.cpp:25-30) ------------------------------------------ */
 /* CroppingVolume::crop (croppers.cpp:76-106): stable compaction of points (+normals) inside the volume. */

@@ -115,6 +115,11 @@ SIGNATURES = {
     "o3ds_icp_update": (C.c_int, [_H, C.c_void_p, C.c_uint64]),
     "o3ds_icp_finish": (C.c_int, [_H, C.POINTER(IcpResult)]),
     "o3ds_icp_done": (C.c_int, [_H, C.POINTER(C.c_int)]),
+    "o3ds_comm_unique_id": (C.c_int, [_H, C.c_char_p]),
+    "o3ds_comm_init": (C.c_int, [_H, C.c_char_p, C.c_int, C.c_int]),
+    "o3ds_comm_attach": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int]),
+    "o3ds_comm_destroy": (C.c_int, [_H]),
+    "o3ds_icp_register_sharded": (C.c_int, [_H, C.c_int, _CL, _CL, C.POINTER(Crop), _dp, C.POINTER(IcpParams), C.POINTER(IcpResult)]),
     "o3ds_crop_cloud": (C.c_int, [_H, _CL, C.POINTER(Crop), C.POINTER(_CL)]),
     "o3ds_voxel_down_sample": (C.c_int, [_H, _CL, C.c_double, C.POINTER(_CL)]),
     "o3ds_crop_voxel_down_sample": (C.c_int, [_H, _CL, C.POINTER(Crop), C.c_double, C.POINTER(_CL)]),
@@ -486,6 +491,39 @@ class Backend:
     def icp_pass_finish(self, n_src_total: int, sums_in_ptr: int, sums_scratch_ptr: int):
         out = IcpResult()
         self._ck(self.lib.o3ds_icp_pass_finish(self.h, n_src_total, C.c_void_p(sums_in_ptr), C.c_void_p(sums_scratch_ptr), C.byref(out)))
+        return self._result(out)
+
+    def icp_register_dev(self, source: int, target: int, max_corr, init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6,
+                         target_crop: Crop | None = None, method=ICP_POINT_TO_PLANE):
+        """o3ds_icp_register_dev: the estimator chosen by `method` (what the three per-estimator wrappers above call)"""
+        T0, ip = (None, _IDENTITY16) if init is None else _d(colmajor(init))
+        p = self._params(max_corr, max_iter, rel_fitness, rel_rmse, method)
+        out = IcpResult()
+        self._ck(self.lib.o3ds_icp_register_dev(self.h, source, target, C.byref(target_crop) if target_crop else None, ip, C.byref(p), C.byref(out)))
+        return self._result(out)
+
+    # -- sharded registrations inside the library (RCCL through dlopen; o3ds_backend.h)
+    SHARD_SOURCE, SHARD_SUBMAP, SHARD_UNION = 0, 1, 2
+
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        self._ck(self.lib.o3ds_comm_unique_id(self.h, buf))
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        assert len(unique_id) == 128
+        self._ck(self.lib.o3ds_comm_init(self.h, C.create_string_buffer(unique_id, 128), int(rank), int(world)))
+
+    def comm_destroy(self):
+        self._ck(self.lib.o3ds_comm_destroy(self.h))
+
+    def icp_register_sharded(self, partitioning: int, source: int, target: int, max_corr, init=None, max_iter=30, rel_fitness=1e-6,
+                             rel_rmse=1e-6, target_crop: Crop | None = None, method=ICP_POINT_TO_PLANE):
+        T0, ip = (None, _IDENTITY16) if init is None else _d(colmajor(init))
+        p = self._params(max_corr, max_iter, rel_fitness, rel_rmse, method)
+        out = IcpResult()
+        self._ck(self.lib.o3ds_icp_register_sharded(self.h, int(partitioning), source, target, C.byref(target_crop) if target_crop else None, ip,
+                                                    C.byref(p), C.byref(out)))
         return self._result(out)
 
     def set_gicp_epsilon(self, eps: float):

@@ -33,7 +33,7 @@ thread_local std::string g_thread_error;
 
 // A/B levers, tuning knobs and debugging aids (O3DS_ICP_MODE, O3DS_ICP_SETS, O3DS_SUM_NO_SPLIT, O3DS_VOXEL_SORT, O3DS_CARVE_SORT, ...) exist
 // only in the library built with -DO3DS_AB_SWITCHES (lib/libo3ds_backend_ab.so: what the A/B tests and the experiment scripts load).  The
-// shipped library reads two environment variables, both memory sizing: O3DS_POOL_CAP_MB and O3DS_ARENA_MB -- a drop-in library's results
+// shipped library reads three environment variables, two of memory sizing and the file name of RCCL: O3DS_POOL_CAP_MB, O3DS_ARENA_MB, O3DS_RCCL_LIB -- a drop-in library's results
 // and code paths must not depend on its host process's environment.
 #ifdef O3DS_AB_SWITCHES
 inline const char* ab_getenv(const char* name) { return getenv(name); }
@@ -57,8 +57,6 @@ struct CloudRec {
   int* cell_start = nullptr;
   void* spts = nullptr;
   void* snrm = nullptr;
-  unsigned* occ = nullptr;  // one bit per cell (GridDev::occ): every index has it
-  int* seed = nullptr;  // per cell one nearby target point (GridDev::seed): explicit index builds for a registration radius only
   // A box that is known to contain every point (not necessarily tight): set where a bounding box has been computed anyway
   // (VoxelDownSample, an index build) and carried to clouds derived from it (subsets, voxel means, rigid placements, unions), so
   // that the next index build of the per-scan pipeline does not pay a reduction kernel + read-back + host sync for it again.
@@ -266,6 +264,14 @@ struct o3ds_context {
   int fused_chunk_hint[2] = {12, 12};  // [registration against a cropped target?]: scan-to-map and scan-to-scan alternate on a handle  // launches queued before the host first looks at the state: what the previous registration needed, plus one
   int debug_update = 0;  // O3DS_DEBUG_UPDATE: timing experiments only
   int pass_rows = 1024;
+  // sharded registrations inside the library (sharded.hpp): the RCCL communicator (created by o3ds_comm_init: owned; attached: the
+  // caller's), this handle's place in it, and the buffers the collectives run on
+  void* nccl_comm = nullptr;
+  bool nccl_owned = false;
+  int comm_rank = 0, comm_world = 1;
+  double* d_shard_sums = nullptr;  // 3 x O3DS_ICP_SUMS_DOUBLES
+  unsigned long long* d_shard_keys = nullptr;
+  size_t shard_keys_cap = 0;
   // profiling (bench.py roofline): 1 = event pairs around every accumulate launch + tagged spans, 2 = tagged spans only (a span around
   // a whole registration then holds its kernels and nothing else)
   int profiling = 0;
@@ -596,14 +602,8 @@ void free_index(o3ds_handle h, CloudRec& c) {
   if (c.cell_start) dev_free(h, c.cell_start);
   if (c.spts) dev_free(h, c.spts);
   if (c.snrm) dev_free(h, c.snrm);
-  if (c.seed) dev_free(h, c.seed);
-  if (c.occ) dev_free(h, c.occ);
   c.cell_start = nullptr;
   c.spts = c.snrm = nullptr;
-  c.seed = nullptr;
-  c.occ = nullptr;
-  c.grid.seed = nullptr;
-  c.grid.occ = nullptr;
   c.has_index = false;
   c.index_byproduct = false;
 }
@@ -910,49 +910,6 @@ int build_grid_t(o3ds_handle h, const P4* pts, const P4* nrm, size_t n, double c
   return O3DS_OK;
 }
 
-// the occupancy bits of an index (icp_kernels.hpp): one pass over its cell_start table
-int build_occ(o3ds_handle h, CloudRec& c) {
-  GridDev& g = c.grid;
-  g.occ_wpr = occ_words_per_row(g.nx);
-  const size_t words = (size_t)g.ny * g.nz * (size_t)g.occ_wpr;
-  HIP_TRY(dev_alloc(h, (void**)&c.occ, sizeof(unsigned) * (words + 2)));  // (+2: a window is two words)
-  span_mark(h, kSpanIndexBuild);
-  occ_build_kernel<<<grid_for(words), kBlock, 0, h->stream>>>(g, c.occ);
-  HIP_TRY(hipMemsetAsync(c.occ + words, 0, 2 * sizeof(unsigned), h->stream));
-  span_mark(h, kSpanIndexBuild);
-  HIP_TRY(hipGetLastError());
-  g.occ = c.occ;
-  return O3DS_OK;
-}
-
-// the seeds of an index (icp_kernels.hpp): three passes over the cells; K = the reach in cells of the radius the index is built for
-int build_seeds(o3ds_handle h, CloudRec& c, double seed_r) {
-  static const bool off = ab_getenv("O3DS_NO_SEEDS") != nullptr;  // A/B
-  if (off || !(seed_r > 0.0)) return O3DS_OK;
-  const GridDev& g = c.grid;
-  const int K = std::max(1, (int)std::ceil(seed_r / g.cell));
-  const size_t ncell = (size_t)g.nx * g.ny * g.nz;
-  if (K > kSeedMaxK || g.sx != g.nx) return O3DS_OK;  // (a cell far smaller than the radius; a row-paged table: no seeds, the searches expand as before)
-  signed char* ox = nullptr;
-  short* oxy = nullptr;
-  TMP_ALLOC(ox, ncell);
-  TMP_ALLOC(oxy, sizeof(short) * ncell);
-  if (dev_alloc(h, (void**)&c.seed, sizeof(int) * ncell) != hipSuccess) {
-    c.seed = nullptr;
-    (void)hipGetLastError();
-    return O3DS_OK;  // no room for them: not an error, the index works without
-  }
-  span_mark(h, kSpanIndexBuild);
-  seed_x_kernel<<<grid_for(ncell), kBlock, 0, h->stream>>>(g, K, ox);
-  seed_y_kernel<<<grid_for(ncell), kBlock, 0, h->stream>>>(g, K, ox, oxy);
-  seed_z_kernel<<<grid_for(ncell), kBlock, 0, h->stream>>>(g, K, oxy, c.seed);
-  span_mark(h, kSpanIndexBuild);
-  HIP_TRY(hipGetLastError());
-  c.grid.seed = c.seed;
-  c.grid.seed_k = K;
-  return O3DS_OK;
-}
-
 template <typename P4>
 int build_index_t(o3ds_handle h, CloudRec& c, double cell) {
   free_index(h, c);
@@ -962,8 +919,6 @@ int build_index_t(o3ds_handle h, CloudRec& c, double cell) {
   }
   int rc = build_grid_t<P4>(h, (const P4*)c.pts, (const P4*)c.nrm, c.n, cell, &c.grid, &c.cell_start, &c.spts, &c.snrm, &c,
                             c.lazy_slot >= 0 ? cnt_word(h, c.lazy_slot) : nullptr);
-  if (rc) return rc;
-  rc = build_occ(h, c);
   if (rc) return rc;
   c.has_index = true;
   return O3DS_OK;
@@ -975,10 +930,8 @@ double index_cell_div() {
   return d;
 }
 
-// seed_r > 0: the radius of the registrations the index is built for (its seeds reach that far); 0: no seeds
-int build_index(o3ds_handle h, CloudRec& c, double cell, double seed_r = 0.0) {
-  const int rc = c.precision == O3DS_PRECISION_F64 ? build_index_t<P4d>(h, c, cell) : build_index_t<P4f>(h, c, cell);
-  return rc ? rc : build_seeds(h, c, seed_r);
+int build_index(o3ds_handle h, CloudRec& c, double cell) {
+  return c.precision == O3DS_PRECISION_F64 ? build_index_t<P4d>(h, c, cell) : build_index_t<P4f>(h, c, cell);
 }
 
 // f32 storage: the caller's doubles are narrowed on their way into the pinned ring (the narrowing the device would do: round to nearest
@@ -1353,11 +1306,6 @@ int validate_icp(o3ds_handle h, const CloudRec* src, const CloudRec* tgt, const 
   return O3DS_OK;
 }
 
-#ifdef O3DS_PHASE_PROFILE
-constexpr int kStatWords = 4096 * 4 * 12;  // per launch: 12 phase sums per wavefront (up to 4096 workgroups)
-#else
-constexpr int kStatWords = 4;  // per launch: 4 query counters (O3DS_ICP_STATS)
-#endif
 int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3ds_crop* crop, const double init[16],
                   const o3ds_icp_params* params, bool upload_state = true) {
   // (sizes as they are: a source or target whose size a kernel has yet to publish enters with its upper bound and the device word)
@@ -1374,15 +1322,8 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
   if (rc) return rc;
   const double r_hint = params->max_correspondence_distance;
   static const double reuse_max = ab_getenv("O3DS_INDEX_REUSE_MAX") ? atof(ab_getenv("O3DS_INDEX_REUSE_MAX")) : 0.75;  // tuning experiments
-  // (a cell more than kOccMaxK times smaller than the radius -- an explicit cell_size far below the radius it is then searched with: the
-  // row windows of the occupancy bits do not reach that far, and such a search would walk thousands of cells per query -- is rebuilt too)
-  const bool cell_too_small = tgt->has_index && std::ceil(r_hint / tgt->grid.cell) > (double)kOccMaxK;
-  if (cell_too_small && tgt->pm) {
-    const int re = pm_exit(h, *tgt);
-    if (re) return re;
-  }
-  if (!tgt->has_index || cell_too_small || (tgt->nrm && !tgt->snrm) || (tgt->index_byproduct && (tgt->grid.cell < r_hint / 8.0 || tgt->grid.cell > r_hint * reuse_max))) {
-    rc = build_index(h, *tgt, params->max_correspondence_distance / index_cell_div(), params->max_correspondence_distance);
+  if (!tgt->has_index || (tgt->nrm && !tgt->snrm) || (tgt->index_byproduct && (tgt->grid.cell < r_hint / 8.0 || tgt->grid.cell > r_hint * reuse_max))) {
+    rc = build_index(h, *tgt, params->max_correspondence_distance / index_cell_div());
     if (rc) return rc;
   }
   if (src->n > h->nn_cache_cap) {
@@ -1612,6 +1553,9 @@ int o3ds_destroy(o3ds_handle h) {
   if (h->d_cnt) (void)hipFree(h->d_cnt);
   if (h->h_rec) (void)hipHostFree(h->h_rec);
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+  (void)o3ds_comm_destroy(h);
+  if (h->d_shard_sums) (void)hipFree(h->d_shard_sums);
+  if (h->d_shard_keys) (void)hipFree(h->d_shard_keys);
   if (h->d_fused) (void)hipFree(h->d_fused);
   if (h->d_nn_cache) (void)hipFree(h->d_nn_cache);
   if (h->d_set_pos) (void)hipFree(h->d_set_pos);
@@ -2031,7 +1975,7 @@ int o3ds_cloud_build_index(o3ds_handle h, o3ds_cloud id, double max_corr_hint, d
   if (!c) return fail(h, O3DS_ERR_INVALID_ARG, "build_index: unknown cloud id");
   double cell = cell_size > 0.0 ? cell_size : max_corr_hint / index_cell_div();
   if (!(cell > 0.0)) return fail(h, O3DS_ERR_INVALID_ARG, "build_index: need cell_size > 0 or max_corr_hint > 0");
-  int rc = build_index(h, *c, cell, max_corr_hint);
+  int rc = build_index(h, *c, cell);
   return rc;
 }
 
@@ -2412,8 +2356,8 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
     static const bool want_stats = ab_getenv("O3DS_ICP_STATS") != nullptr;
     unsigned long long* d_stats = nullptr;
     if (want_stats) {
-      HIP_TRY(hipMalloc((void**)&d_stats, sizeof(unsigned long long) * kStatWords * (size_t)total));
-      HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof(unsigned long long) * kStatWords * (size_t)total, h->stream));
+      HIP_TRY(hipMalloc((void**)&d_stats, sizeof(unsigned long long) * 4 * (size_t)total));
+      HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof(unsigned long long) * 4 * (size_t)total, h->stream));
     }
     int j = 0;
     const IcpStateDev* last = h->d_state;
@@ -2434,7 +2378,7 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
         fa.slots_clear = (double*)(h->d_fused + kFusedSlotsOff + ((g + 1) % 3) * kFusedSlotBufBytes);
         const bool tail_only = j == total - 1;
         fa.trace = j == trace_launch ? d_trace : nullptr;
-        fa.pass.stats = d_stats ? d_stats + kStatWords * (size_t)j : nullptr;
+        fa.pass.stats = d_stats ? d_stats + 4 * (size_t)j : nullptr;
         fa.state_host = k == chunk - 1 ? h->h_state_dev : nullptr;  // the launch the host waits for also writes the pinned copy
         fa.seq_host = pub_slot<unsigned long long>(h, kSeqSlot);
         if (fa.state_host) fa.seq = ++h->fused_seq;
@@ -2473,26 +2417,12 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
     // been seen while the last launch was still draining)
     if (d_stats || d_trace) (void)hipStreamSynchronize(h->stream);
     if (d_stats) {
-      std::vector<unsigned long long> t((size_t)kStatWords * total);
+      std::vector<unsigned long long> t((size_t)4 * total);
       (void)hipMemcpy(t.data(), d_stats, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
       (void)hipFree(d_stats);
       fprintf(stderr, "icp stats (n_src %zu):", (size_t)a.count);
-      for (int k = 0; k < j; ++k) fprintf(stderr, " [%d v%llu s%llu k%llu f%llu]", k, t[kStatWords * k], t[kStatWords * k + 1], t[kStatWords * k + 2], t[kStatWords * k + 3]);
+      for (int k = 0; k < j; ++k) fprintf(stderr, " [%d v%llu s%llu k%llu f%llu]", k, t[4 * k], t[4 * k + 1], t[4 * k + 2], t[4 * k + 3]);
       fprintf(stderr, "\n");
-#ifdef O3DS_PHASE_PROFILE
-      for (int k = 0; k < j && k < 6; ++k) {
-        fprintf(stderr, "icp phases launch %d (cycles per wavefront: mean | max):", k);
-        for (int p = 0; p < 12; ++p) {
-          double sum = 0.0, mx = 0.0;
-          for (int w = 0; w < 4096; ++w) {
-            const double v = (double)t[(size_t)kStatWords * k + (size_t)w * 12 + p];
-            sum += v, mx = std::max(mx, v);
-          }
-          fprintf(stderr, " %d: %.0f|%.0f", p, sum / 4096.0, mx);
-        }
-        fprintf(stderr, "\n");
-      }
-#endif
     }
     if (d_trace) {
       std::vector<unsigned long long> t((size_t)16 * nb);
@@ -3054,7 +2984,7 @@ int normals_t(o3ds_handle h, CloudRec& c, double radius, int max_nn, bool knn_ra
   tmp.pts = nullptr;
   box_copy(c, tmp);  // the box an index build reduced is kept for the cloud
   free_index(h, c);  // the cloud's own index (if any) no longer matches its normals
-  c.grid = tmp.grid, c.cell_start = tmp.cell_start, c.spts = tmp.spts, c.snrm = tmp.snrm, c.occ = tmp.occ;
+  c.grid = tmp.grid, c.cell_start = tmp.cell_start, c.spts = tmp.spts, c.snrm = tmp.snrm;
   c.has_index = true;
   c.index_byproduct = true;
   return O3DS_OK;
@@ -3662,12 +3592,6 @@ int pm_enter_t(o3ds_handle h, CloudRec& c, double voxel, double max_corr_hint, s
   PM_ALLOC(d.cell_add, sizeof(int) * (table + 1));
   HIP_TRY(hipMemsetAsync(d.cell_add, 0, sizeof(int) * (table + 1), h->stream));
   g.cell_start = cs;
-  // the occupancy bits of the rows (GridDev::occ): built with the table below, set by every slot that enters a cell (pm_row_push), never cleared
-  g.occ_wpr = occ_words_per_row(g.nx);
-  const size_t occ_words = pm->rows * (size_t)g.occ_wpr;
-  HIP_TRY(dev_alloc(h, (void**)&c.occ, sizeof(unsigned) * (occ_words + 2)));
-  HIP_TRY(hipMemsetAsync(c.occ + occ_words, 0, 2 * sizeof(unsigned), h->stream));
-  g.occ = c.occ;
   d.grid = g;
   d.cs = cs;
   d.spts = c.spts;
@@ -3701,7 +3625,6 @@ int pm_enter_t(o3ds_handle h, CloudRec& c, double voxel, double max_corr_hint, s
   if (rc) return rc;
   pm_row_finish_kernel<<<grid_for(pm->rows), kBlock, 0, h->stream>>>(h->d_cells, cs, (int)pm->rows, g.nx, d.counters + kPmPoolTop);
   pm_scatter_kernel<P4><<<grid_for(n), kBlock, 0, h->stream>>>(d, ni, cell_id, h->d_cells);
-  occ_build_kernel<<<grid_for(occ_words), kBlock, 0, h->stream>>>(g, c.occ);
   // (the voxels with several members that pm_enter_kernel listed are what the first insertion looks at)
   HIP_TRY(hipMemcpyAsync(d.counters + kPmMultiIn, d.counters + kPmMultiOut, sizeof(int), hipMemcpyDeviceToDevice, h->stream));
   span_mark(h, kSpanIndexBuild);
@@ -4354,3 +4277,5 @@ int o3ds_map_insert_scan(o3ds_handle h, o3ds_cloud map, o3ds_cloud scan, const d
 }
 
 }  // extern "C"
+
+#include "sharded.hpp"

@@ -132,10 +132,6 @@ struct GridDev {
   const int* cell_start;  // nx*ny*nz + 1 entries (exclusive scan of per-cell counts)
   int sx;                 // entries per row of cell_start: nx (the classic table), or nx + 1 for the row-paged table of a persistent map
                           // (map_kernels.hpp: every row owns a region with room to spare, the extra entry is the end of its last cell)
-  const unsigned* occ;    // one bit per cell, occ_wpr 32-bit words per (y, z) row (bit x & 31 of word x >> 5; one zero pad word per row): set iff the
-  int occ_wpr;            // cell holds a point (a persistent map's bits are never cleared: a set bit may name an emptied cell).  Every index has it.
-  const int* seed;        // null, or per cell (nx * ny * nz, x fastest) the position of one target point of the nearest occupied cell within
-  int seed_k;             // +-seed_k cells per axis, -1 = that block is empty (icp_kernels.hpp "seeds"); built with explicit index builds only
 };
 
 // ---- counts the host has not seen yet ---------------------------------------------------------------------------------------------

@@ -21,49 +21,9 @@
 // 6x6 solve) say fma() explicitly.
 #pragma clang fp contract(off)
 
-// Compile-time levers of the search (variant builds: scripts/build_variant.sh <suffix> -DO3DS_ICP_...=0|1)
-#ifndef O3DS_ICP_SEEDS
-#define O3DS_ICP_SEEDS 1  // a query without a usable bound starts from its cell's seed (GridDev::seed)
-#endif
-#ifndef O3DS_ICP_FAR16
-#define O3DS_ICP_FAR16 1
-#endif
-#ifndef O3DS_SUB4_KPER
-#define O3DS_SUB4_KPER 2  // rows per lane and round of the 4-lane block searches
-#endif
-
 namespace o3ds {
 
 constexpr int kBlock = 256;  // 4 wavefronts of 64
-
-// Development aid (-DO3DS_PHASE_PROFILE, with O3DS_ICP_STATS in an A/B build): shader-clock cycles every wavefront spends in the phases of
-// a pass, summed per launch into stats[4 + phase].  A wavefront shares its SIMD with three others, so a phase's cycles include their
-// instructions: read the numbers as shares of the pass, not as instruction counts.
-#ifdef O3DS_PHASE_PROFILE
-constexpr int kPhases = 12;
-__shared__ unsigned long long g_ph_acc[4][kPhases];
-__shared__ unsigned long long g_ph_last[4];
-__device__ __forceinline__ void ph_start() {
-  if ((threadIdx.x & 63) == 0) {
-    for (int k = 0; k < kPhases; ++k) g_ph_acc[threadIdx.x >> 6][k] = 0;
-    g_ph_last[threadIdx.x >> 6] = clock64();
-  }
-}
-__device__ __forceinline__ void ph_mark(int k) {  // (by the first ACTIVE lane: some marks sit inside divergent branches)
-  if ((int)(threadIdx.x & 63) == __ffsll((unsigned long long)__ballot(1)) - 1) {
-    const unsigned long long now = clock64();
-    g_ph_acc[threadIdx.x >> 6][k] += now - g_ph_last[threadIdx.x >> 6];
-    g_ph_last[threadIdx.x >> 6] = now;
-  }
-}
-__device__ __forceinline__ void ph_flush(unsigned long long* stats) {
-  if (stats && (threadIdx.x & 63) == 0)  // (plain stores into this wavefront's own row: atomics on shared counters would be what the phases wait for)
-    for (int k = 0; k < kPhases; ++k) stats[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * kPhases + k] = g_ph_acc[threadIdx.x >> 6][k];
-}
-#define O3DS_PH(k) ph_mark(k)
-#else
-#define O3DS_PH(k) do {} while (0)
-#endif
 
 // ----------------------------------------------------------------------------------------------
 // wave / block reductions (64-wide wavefronts)
@@ -283,114 +243,6 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(const P4* __restrict__ 
 }
 
 // ----------------------------------------------------------------------------------------------
-// occupancy bits: which cells of a row hold anything, in one load
-// ----------------------------------------------------------------------------------------------
-// A search walks (y, z) rows of cells and needs, per row, the range of the cell-sorted target that the cells xa..xb hold: two cell_start
-// values, anywhere in a table of tens of megabytes -- and most rows a far query looks at are empty (free space), so most of those loads
-// fetch two equal numbers.  What bounds a pass whose queries share no cache lines is the NUMBER of line requests a CU issues (one per
-// clock; scripts/ubench/gather_rates.hip: 270-290 G lane-loads/s chip-wide when the lines are L2-resident, 64 G/s when they come from
-// the Infinity Cache), so the rows are first looked up in a bit set that stays in the L2 (one bit per cell: 300 KB for the configs[1]
-// map): one 64-bit window per row answers "anything in xa..xb?" and trims the range to the occupied cells; only then are the two
-// cell_start values fetched.
-constexpr int kOccMaxK = 15;  // a window covers the x-range of any search with kmax <= this (31 + 2 * 15 < 64)
-__host__ __device__ inline int occ_words_per_row(int nx) { return (nx + 31) / 32 + 1; }
-__global__ __launch_bounds__(kBlock) void occ_build_kernel(GridDev g, unsigned* __restrict__ occ) {
-  const size_t rows = (size_t)g.ny * g.nz, words = rows * (size_t)g.occ_wpr;
-  for (size_t w = (size_t)blockIdx.x * kBlock + threadIdx.x; w < words; w += (size_t)gridDim.x * kBlock) {
-    const size_t row = w / (size_t)g.occ_wpr;
-    const int x0 = (int)(w % (size_t)g.occ_wpr) * 32;
-    const int* cs = g.cell_start + row * (size_t)g.sx;
-    unsigned bits = 0u;
-    if (x0 < g.nx) {
-      int prev = cs[x0];
-      for (int b = 0; b < 32 && x0 + b < g.nx; ++b) {
-        const int next = cs[x0 + b + 1];
-        bits |= next > prev ? 1u << b : 0u;
-        prev = next;
-      }
-    }
-    occ[w] = bits;
-  }
-}
-// the 64 cells of row `rowid` (= z * ny + y) from cell 32 * w on: bit j = cell 32 w + j holds something
-__device__ __forceinline__ unsigned long long occ_window(const GridDev& g, int rowid, int w) {
-  const unsigned* __restrict__ p = g.occ + (size_t)rowid * (size_t)g.occ_wpr + w;
-  return (unsigned long long)p[0] | ((unsigned long long)p[1] << 32);
-}
-// [xa, xb] (cells of the row, 32 w <= xa <= xb < 32 w + 64) trimmed to the occupied cells inside it; false: none
-__device__ __forceinline__ bool occ_trim(unsigned long long win, int w, int* xa, int* xb) {
-  const int a = *xa - 32 * w, b = *xb - 32 * w;
-  const unsigned long long m = win & (~0ull >> (63 - b)) & (~0ull << a);
-  if (!m) return false;
-  *xa = 32 * w + __builtin_ctzll(m);
-  *xb = 32 * w + 63 - __builtin_clzll(m);
-  return true;
-}
-
-// ----------------------------------------------------------------------------------------------
-// seeds: one nearby target point per cell, known before any search starts
-// ----------------------------------------------------------------------------------------------
-// A search that starts without a bound (pass 0 of a registration, a query whose previous pass found nothing, a cached match that a large
-// update has carried away) expands block by block until something turns up, and a query that has NO neighbour within r pays for the
-// whole (2K+1)^3 block to prove it.  seed[cell] = position (in the cell-sorted target) of the first point of the occupied cell whose
-// centre is nearest to this cell's centre, over the block of +-K cells per axis; -1 = that block is empty.  Any target point is a valid
-// starting bound, so the seed changes what a search costs and never what it returns; -1 with K >= kmax PROVES "nothing within r" (every
-// cell a neighbour could lie in is inside the block).  Built once per index by an exact separable Euclidean distance transform of the
-// cell centres: along x, then y, then z, each pass one thread per cell and 2K + 1 reads.
-constexpr int kSeedNone = 127;    // offset value: no occupied cell in the window
-constexpr int kSeedMaxK = 15;
-__global__ __launch_bounds__(kBlock) void seed_x_kernel(GridDev g, int K, signed char* __restrict__ ox) {
-  const size_t ncell = (size_t)g.nx * g.ny * g.nz;
-  for (size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x; c < ncell; c += (size_t)gridDim.x * kBlock) {
-    const int x = (int)(c % (size_t)g.nx);
-    const size_t row = c / (size_t)g.nx * (size_t)g.sx;
-    int best = kSeedNone;
-    for (int d = 0; d <= K && best == kSeedNone; ++d) {  // nearest first: |offset| d, the negative side on ties
-      if (x - d >= 0 && g.cell_start[row + x - d + 1] > g.cell_start[row + x - d]) best = -d;
-      else if (x + d < g.nx && g.cell_start[row + x + d + 1] > g.cell_start[row + x + d]) best = d;
-    }
-    ox[c] = (signed char)best;
-  }
-}
-// oxy[c] = {dx, dy} of the nearest occupied cell of the (x, y) slab window
-__global__ __launch_bounds__(kBlock) void seed_y_kernel(GridDev g, int K, const signed char* __restrict__ ox, short* __restrict__ oxy) {
-  const size_t ncell = (size_t)g.nx * g.ny * g.nz;
-  for (size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x; c < ncell; c += (size_t)gridDim.x * kBlock) {
-    const int y = (int)(c / (size_t)g.nx % (size_t)g.ny);
-    int bd = 1 << 30, bx = kSeedNone, by = 0;
-    for (int d = -K; d <= K; ++d) {
-      if ((unsigned)(y + d) >= (unsigned)g.ny) continue;
-      const int dx = ox[(long long)c + (long long)d * g.nx];
-      if (dx == kSeedNone) continue;
-      const int dd = dx * dx + d * d;
-      if (dd < bd) bd = dd, bx = dx, by = d;
-    }
-    oxy[c] = (short)((bx & 0xff) | ((by & 0xff) << 8));
-  }
-}
-__global__ __launch_bounds__(kBlock) void seed_z_kernel(GridDev g, int K, const short* __restrict__ oxy, int* __restrict__ seed) {
-  const size_t ncell = (size_t)g.nx * g.ny * g.nz, plane = (size_t)g.nx * g.ny;
-  for (size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x; c < ncell; c += (size_t)gridDim.x * kBlock) {
-    const int z = (int)(c / plane);
-    int bd = 1 << 30, bx = 0, by = 0, bz = 0;
-    for (int d = -K; d <= K; ++d) {
-      if ((unsigned)(z + d) >= (unsigned)g.nz) continue;
-      const int v = oxy[(long long)c + (long long)d * (long long)plane];
-      const int dx = (signed char)(v & 0xff), dy = (signed char)((v >> 8) & 0xff);
-      if (dx == kSeedNone) continue;
-      const int dd = dx * dx + dy * dy + d * d;
-      if (dd < bd) bd = dd, bx = dx, by = dy, bz = d;
-    }
-    int out = -1;
-    if (bd != 1 << 30) {
-      const size_t cc = (size_t)((long long)c + bx + (long long)by * g.nx + (long long)bz * (long long)plane);
-      out = g.cell_start[cc / (size_t)g.nx * (size_t)g.sx + cc % (size_t)g.nx];  // the first point of that (occupied) cell
-    }
-    seed[c] = out;
-  }
-}
-
-// ----------------------------------------------------------------------------------------------
 // exact 1-NN within radius on the grid ([O3D] KDTreeFlann::SearchHybrid(q, r, 1)), G lanes per query
 // ----------------------------------------------------------------------------------------------
 // Two costs trade against each other (measured with PMC counters on MI355X): with many lanes per query the per-query
@@ -525,8 +377,8 @@ __device__ __forceinline__ void lanes_min(NNBest<P4>& b) {
 // iterates max-over-groups(#segments) times and not over the union of the groups' rows.  Pruned cells only hold points
 // strictly farther than the current best, so the result (nearest within r, ties to the smaller original index) is the
 // one the full scan gives.
-constexpr int kSegMax = 32;     // s_seg holds kSegMax entries per query of the workgroup, i.e. ...
-constexpr int kWaveList = 512;  // ... this many per wavefront (16 queries x 32): the run lists of the queries a wavefront searches at a time
+constexpr int kFarList = 256;  // stage 3 list, aliased onto the wavefront's groups' lists
+constexpr int kSegMax = 32;   // stage 1: <= 9 segments; stage 2: <= 19 per batch of 13 rows; 32 so that a wavefront (>= 8 groups) owns >= kFarList entries
 
 // Workgroup barrier that orders LDS only.  __syncthreads() is a release/acquire fence over GLOBAL memory as well: it waits for every
 // outstanding vector-memory operation of the wavefront (s_waitcnt vmcnt(0)), i.e. for the acknowledgement of the cache-entry and
@@ -608,111 +460,200 @@ __device__ __forceinline__ float bound_cells2(R d2, R m, const GridDev& g) {
   return widen2(d2, m) * ic * ic * (1.0f + 1e-4f) + 1e-6f;
 }
 
-// The search of ONE parked query by a sub-group of W lanes (4 or 16), 64 / W queries of a list per call.  It scans what the block of
-// +-K cells around the query's cell holds inside the ball of the bound -- minus the block of +-kdone cells an earlier stage of the same
-// query has scanned (kdone = 0: none) -- and returns the nearest point found or the bound it came with, ties to the smaller original
-// index.  The rows are the (dy, dz) offsets of a rectangle: for W = 4 the square +-K (K is 1 or 2 there, scalar), for W = 16 the union
-// over the wavefront's queries of the offsets their balls can reach (per axis: slab distance <= bound; scalar after four readlanes, so
-// that the row loop is the wavefront's and its bookkeeping lives in scalar registers).  kPer rows per lane and round: first their
-// occupancy windows, all in flight together, then the cell_start pairs of the runs that hold anything; a row out of the query's own
-// reach costs a few instructions and no load.  Non-empty runs are compacted into the sub-group's share of the wavefront's LDS list and
-// the W lanes regroup over them: W / pow2ceil(min(runs, W)) lanes stride over each run.
-// A sub-group without a query of its own runs along on a copy of sub-group 0's and lists nothing (the caller sees to that: col.tau2 = 0).
-template <typename P4, bool kCrop, bool kCollect, int W, int kPer>
-__device__ __forceinline__ void nn_search_sub(const GridDev& g, const P4* __restrict__ tp, typename Scalar<P4>::type qx,
-                                              typename Scalar<P4>::type qy, typename Scalar<P4>::type qz, int K /* scalar */, int kdone,
-                                              const CropDev& crop, NNBest<P4>& best, int lane, int2* s_list /* the wavefront's kWaveList entries */,
-                                              typename Scalar<P4>::type m, const Collect<typename Scalar<P4>::type>& col) {
-  constexpr int kSubList = 2 * kPer * W;   // runs one round can list per sub-group
-  constexpr int kSubs = 64 / W;
-  static_assert(kSubs * kSubList <= kWaveList, "the sub-lists fit the wavefront's share of s_seg");
+// All G lanes of a group call this with the same query and the same starting bound `best` (any eligible target point, or {r^2, -1,
+// -1}); every lane returns the same winner.  m / col: the candidate-set margin and list (m = 0, col.tau2 = 0: off); *kdone = the
+// block radius (cells) the search covered.
+template <typename P4, bool kCrop, int G, bool kCollect>
+__device__ __forceinline__ NNBest<P4> nn_search_group(const GridDev& g, const P4* __restrict__ tp, typename Scalar<P4>::type qx,
+                                                      typename Scalar<P4>::type qy, typename Scalar<P4>::type qz, int kmax,
+                                                      const CropDev& crop, int gl, int2* seg /* this group's kSegMax entries */,
+                                                      NNBest<P4> best, typename Scalar<P4>::type m,
+                                                      const Collect<typename Scalar<P4>::type>& col, bool* resolved, int* kdone) {
+  const QueryCell c = locate(g, (double)qx, (double)qy, (double)qz);
+  const int* __restrict__ cs = g.cell_start;
+  // ---- one batch, issued before the bound is even computed: the 4 cell_start values of each of this lane's rows of the 3x3
+  // cross-section (fetching only the rows in reach, after the bound, measured slower: the ALU chain delays the loads)
+  const int xlo = max(c.ix - 1, 0), xhi = min(c.ix + 1, g.nx - 1);
+  constexpr int kOwn = (9 + G - 1) / G;
+  int v[kOwn][4];
+  bool rv[kOwn];
+#pragma unroll
+  for (int k = 0; k < kOwn; ++k) {
+    const int r = gl + k * G;
+    const int y = c.iy + (r % 3) - 1, z = c.iz + (r / 3) - 1;
+    rv[k] = r < 9 && xlo <= xhi && (unsigned)y < (unsigned)g.ny && (unsigned)z < (unsigned)g.nz;
+    const int row = rv[k] ? (z * g.ny + y) * g.sx : 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[k][j] = rv[k] ? cs[row + min(xlo + j, xhi + 1)] : 0;
+  }
+  // ---- stage 1: the 3x3x3 block, trimmed by the bound
+  {
+    const float b2 = bound_cells2(best.d2, m, g);
+    int ss[kOwn], ee[kOwn];
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < kOwn; ++k) {
+      const int r = gl + k * G;
+      const float ddy = slab_dist((r % 3) - 1, c.uy), ddz = slab_dist((r / 3) - 1, c.uz);
+      int xa, xb;
+      ss[k] = ee[k] = 0;
+      if (rv[k] && row_extent(b2, ddy * ddy + ddz * ddz, c.ux, &xa, &xb)) {
+        xa = max(c.ix + xa, xlo);
+        xb = min(c.ix + xb, xhi);
+        if (xa <= xb) {
+          const int ja = xa - xlo, jb = xb - xlo + 1;
+          ss[k] = ja == 0 ? v[k][0] : (ja == 1 ? v[k][1] : v[k][2]);
+          ee[k] = jb == 1 ? v[k][1] : (jb == 2 ? v[k][2] : v[k][3]);
+        }
+      }
+      cnt += ee[k] > ss[k] ? 1 : 0;
+    }
+    int total;
+    int off = group_exclusive_sum<G>(cnt, gl, &total);
+#pragma unroll
+    for (int k = 0; k < kOwn; ++k)
+      if (ee[k] > ss[k]) seg[off++] = make_int2(ss[k], ee[k]);
+    lds_wave_sync();
+    for (int t = 0; t < total; ++t) {
+      const int2 se = seg[t];
+      scan_strided<P4, kCrop, kCollect>(tp, se.x, se.y, gl, G, qx, qy, qz, crop, best, col);
+    }
+    lds_wave_sync();  // the list is rewritten by stage 2
+    lanes_min<P4, G>(best);
+  }
+  // proven exact if nothing outside the scanned block can be nearer: best <= (cell * (k + face distance))^2, tested with margin
+  // (with a candidate-set margin: if the ball of best + m lies inside the block)
+  const float ic2 = (float)(g.inv_cell * g.inv_cell) * (1.0f + 1e-4f);
+  bool proven = kmax <= 1 || widen2(best.d2, m) * ic2 <= (1.0f + c.mf) * (1.0f + c.mf);
+  *kdone = 1;
+  // ---- stage 2: the 5x5x5 shell, trimmed by the bound (group-uniform branch), rows in two batches
+  if (!proven) {
+    constexpr int kHalf = 13, kOwn2 = (kHalf + G - 1) / G;
+#pragma unroll 1
+    for (int r0 = 0; r0 < 25; r0 += kHalf) {
+      const float b2 = bound_cells2(best.d2, m, g);
+      int s2[2 * kOwn2], e2[2 * kOwn2];
+#pragma unroll
+      for (int k = 0; k < kOwn2; ++k) {
+        const int rl = gl + k * G, r = r0 + rl;
+        const int dy = (r % 5) - 2, dz = (r / 5) - 2;
+        const int y = c.iy + dy, z = c.iz + dz;
+        s2[2 * k] = e2[2 * k] = s2[2 * k + 1] = e2[2 * k + 1] = 0;
+        if (rl < kHalf && r < 25 && (unsigned)y < (unsigned)g.ny && (unsigned)z < (unsigned)g.nz) {
+          const float ddy = slab_dist(dy, c.uy), ddz = slab_dist(dz, c.uz);
+          int xa, xb;
+          if (row_extent(b2, ddy * ddy + ddz * ddz, c.ux, &xa, &xb)) {
+            xa = max(max(c.ix + xa, c.ix - 2), 0);
+            xb = min(min(c.ix + xb, c.ix + 2), g.nx - 1);
+            const bool inner = abs(dy) <= 1 && abs(dz) <= 1;  // cells ix-1..ix+1 of these rows were stage 1
+            const int row = (z * g.ny + y) * g.sx;
+            const int xb1 = inner ? min(xb, c.ix - 2) : xb;
+            if (xa <= xb1) {
+              s2[2 * k] = cs[row + xa];
+              e2[2 * k] = cs[row + xb1 + 1];
+            }
+            const int xa2 = max(xa, c.ix + 2);
+            if (inner && xa2 <= xb) {
+              s2[2 * k + 1] = cs[row + xa2];
+              e2[2 * k + 1] = cs[row + xb + 1];
+            }
+          }
+        }
+      }
+      int cnt = 0;
+#pragma unroll
+      for (int k = 0; k < 2 * kOwn2; ++k) cnt += e2[k] > s2[k] ? 1 : 0;
+      int total;
+      int off = group_exclusive_sum<G>(cnt, gl, &total);
+#pragma unroll
+      for (int k = 0; k < 2 * kOwn2; ++k)
+        if (e2[k] > s2[k]) seg[off++] = make_int2(s2[k], e2[k]);
+      lds_wave_sync();
+      for (int t = 0; t < total; ++t) {
+        const int2 se = seg[t];
+        scan_strided<P4, kCrop, kCollect>(tp, se.x, se.y, gl, G, qx, qy, qz, crop, best, col);
+      }
+      lds_wave_sync();
+      lanes_min<P4, G>(best);
+    }
+    proven = kmax <= 2 || widen2(best.d2, m) * ic2 <= (2.0f + c.mf) * (2.0f + c.mf);
+    *kdone = 2;
+  }
+  *resolved = proven;
+  return best;
+}
+
+// Stage 3 -- queries whose nearest neighbour (if any) is farther than two cells: all 64 lanes of the wavefront serve ONE
+// query, still on the fine grid.  The half-rows of the (2K+1)^2 cross-section (K = ceil(r / cell)) that intersect the ball
+// of the current bound and were not scanned by stages 0-2 are dealt to the lanes (one cell_start pair each), compacted
+// through the wavefront's LDS list (mbcnt rank), and the lanes regroup so that every listed half-row gets
+// 64 / pow2(#rows) (>= 4) lanes striding over it.
+template <typename P4, bool kCrop, bool kCollect>
+__device__ __forceinline__ void nn_search_wave_far(const GridDev& g, const P4* __restrict__ tp, typename Scalar<P4>::type qx,
+                                                   typename Scalar<P4>::type qy, typename Scalar<P4>::type qz, int K,
+                                                   const CropDev& crop, NNBest<P4>& best, int lane, int2* s_list /* kFarList entries */,
+                                                   typename Scalar<P4>::type m, const Collect<typename Scalar<P4>::type>& col) {
+  constexpr int kdone = 2;  // cells within offset 2 were scanned by the group stages
+  constexpr int kPer = 4;   // half-rows per lane and round: all their bounds are fetched in one batch
   const QueryCell c = locate(g, (double)qx, (double)qy, (double)qz);
   const float b2 = bound_cells2(best.d2, m, g);
   const int* __restrict__ cs = g.cell_start;
-  int y0, y1, z0, z1;  // the wavefront's rectangle of row offsets, scalar
-  if (W >= 16) {
-    // offsets d with slab_dist(d, u) <= b: d >= -(floor(b - u) + 1) and d <= floor(b - (1 - u)) + 1 (never empty: d = 0 has distance 0)
-    const float bb = sqrtf(b2) + 1e-4f;
-    const int ly0 = -((int)floorf(bb - c.uy) + 1), ly1 = (int)floorf(bb - (1.0f - c.uy)) + 1;
-    const int lz0 = -((int)floorf(bb - c.uz) + 1), lz1 = (int)floorf(bb - (1.0f - c.uz)) + 1;
-    y0 = __builtin_amdgcn_readlane(ly0, 0), y1 = __builtin_amdgcn_readlane(ly1, 0);
-    z0 = __builtin_amdgcn_readlane(lz0, 0), z1 = __builtin_amdgcn_readlane(lz1, 0);
-#pragma unroll
-    for (int j = 1; j < kSubs; ++j) {
-      y0 = min(y0, __builtin_amdgcn_readlane(ly0, j * W)), y1 = max(y1, __builtin_amdgcn_readlane(ly1, j * W));
-      z0 = min(z0, __builtin_amdgcn_readlane(lz0, j * W)), z1 = max(z1, __builtin_amdgcn_readlane(lz1, j * W));
-    }
-    y0 = max(y0, -K), y1 = min(y1, K), z0 = max(z0, -K), z1 = min(z1, K);
-  } else {
-    y0 = z0 = -K, y1 = z1 = K;
-  }
-  const int ny = y1 - y0 + 1, rows = ny * (z1 - z0 + 1);
-  int2* my_list = s_list + (lane / W) * kSubList;
+  const int side = 2 * K + 1, entries = 2 * side * side;
   NNBest<P4> mine = best;
-  for (int base = 0; base < rows; base += kPer * W) {  // scalar
-    int s_own[2 * kPer], e_own[2 * kPer];
-    int rr[kPer], xr[kPer];  // row id (-1: nothing to do) and xa | (xb - xa) << 26
-    unsigned long long win[kPer];
+  for (int base = 0; base < entries; base += 64 * kPer) {  // wave-uniform; one round for K <= 5
+    int s_own[kPer], e_own[kPer];
 #pragma unroll
-    for (int u = 0; u < kPer; ++u) {  // the occupancy windows of this lane's rows in reach, all in flight together ...
-      const int r = base + u * W + (lane & (W - 1));
-      rr[u] = -1;
-      xr[u] = 0;
-      if (r < rows) {
-        const int dy = y0 + r % ny, dz = z0 + r / ny;
+    for (int u = 0; u < kPer; ++u) {
+      const int e = base + u * 64 + lane;
+      s_own[u] = e_own[u] = 0;
+      if (e < entries) {
+        const int half = e & 1, rr = e >> 1;
+        const int dy = rr % side - K, dz = rr / side - K;
         const int y = c.iy + dy, z = c.iz + dz;
         if ((unsigned)y < (unsigned)g.ny && (unsigned)z < (unsigned)g.nz) {
           const float ddy = slab_dist(dy, c.uy), ddz = slab_dist(dz, c.uz);
           int xa, xb;
           if (row_extent(b2, ddy * ddy + ddz * ddz, c.ux, &xa, &xb)) {
-            xa = max(max(c.ix + xa, c.ix - K), 0);
-            xb = min(min(c.ix + xb, c.ix + K), g.nx - 1);
-            if (xa <= xb) rr[u] = z * g.ny + y, xr[u] = xa | ((xb - xa) << 26);
+            xa = max(c.ix + xa, c.ix - K);
+            xb = min(c.ix + xb, c.ix + K);
+            const bool inner = abs(dy) <= kdone && abs(dz) <= kdone;
+            if (half == 0)
+              xb = min(xb, inner ? c.ix - kdone - 1 : c.ix);
+            else
+              xa = max(xa, inner ? c.ix + kdone + 1 : c.ix + 1);
+            xa = max(xa, 0);
+            xb = min(xb, g.nx - 1);
+            if (xa <= xb) {
+              const int row = (z * g.ny + y) * g.sx;
+              s_own[u] = cs[row + xa];
+              e_own[u] = cs[row + xb + 1];
+            }
           }
         }
       }
-      win[u] = occ_window(g, max(rr[u], 0), rr[u] >= 0 ? (xr[u] & 0x3ffffff) >> 5 : 0);
     }
-#pragma unroll
-    for (int u = 0; u < kPer; ++u) {  // ... then the cell_start pairs of the runs that hold anything
-      s_own[2 * u] = e_own[2 * u] = s_own[2 * u + 1] = e_own[2 * u + 1] = 0;
-      if (rr[u] >= 0) {
-        const int r = base + u * W + (lane & (W - 1));
-        const bool inner = kdone > 0 && abs(y0 + r % ny) <= kdone && abs(z0 + r / ny) <= kdone;  // cells ix-kdone..ix+kdone of these rows were scanned before
-        const int xa = xr[u] & 0x3ffffff, xb = xa + (xr[u] >> 26), row = rr[u] * g.sx, w3 = xa >> 5;
-        int xa1 = xa, xb1 = inner ? min(xb, c.ix - kdone - 1) : xb;
-        if (xa1 <= xb1 && occ_trim(win[u], w3, &xa1, &xb1)) {
-          s_own[2 * u] = cs[row + xa1];
-          e_own[2 * u] = cs[row + xb1 + 1];
-        }
-        int xa2 = max(xa, c.ix + kdone + 1), xb2 = xb;
-        if (inner && xa2 <= xb2 && occ_trim(win[u], w3, &xa2, &xb2)) {
-          s_own[2 * u + 1] = cs[row + xa2];
-          e_own[2 * u + 1] = cs[row + xb2 + 1];
-        }
-      }
-    }
-    O3DS_PH(1);
+    // compact the non-empty half-rows of all kPer slices into the wavefront's list
     int total = 0;
 #pragma unroll
-    for (int u = 0; u < 2 * kPer; ++u) {
-      const bool have = e_own[u] > s_own[u];
-      const unsigned bits = (unsigned)(__ballot(have) >> (lane & ~(W - 1))) & ((1u << W) - 1u);
-      if (have) my_list[total + __popc(bits & ((1u << (lane & (W - 1))) - 1u))] = make_int2(s_own[u], e_own[u]);
-      total += __popc(bits);
+    for (int u = 0; u < kPer; ++u) {
+      const unsigned long long have = __ballot(e_own[u] > s_own[u]);
+      const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(have >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)have, 0u));
+      if (e_own[u] > s_own[u]) s_list[total + rank] = make_int2(s_own[u], e_own[u]);
+      total += __popcll(have);
     }
+    if (!total) continue;
     lds_wave_sync();
-    int groups = 1;  // lanes per listed run: W / pow2ceil(min(total, W))
-    while (groups < total && groups < W) groups <<= 1;
-    const int Wl = W / groups, grp = (lane & (W - 1)) / Wl, gl = (lane & (W - 1)) % Wl;
+    int groups = 1;  // lanes per listed half-row: 64 / pow2ceil(min(total,16)), i.e. 64,32,16,8,4
+    while (groups < total && groups < 16) groups <<= 1;
+    const int W = 64 / groups;
+    const int grp = lane / W, gl = lane % W;
     for (int t = grp; t < total; t += groups) {
-      const int2 se = my_list[t];
-      scan_strided<P4, kCrop, kCollect>(tp, se.x, se.y, gl, Wl, qx, qy, qz, crop, mine, col);
+      const int2 se = s_list[t];
+      scan_strided<P4, kCrop, kCollect>(tp, se.x, se.y, gl, W, qx, qy, qz, crop, mine, col);
     }
-    lds_wave_sync();  // the list is rewritten by the next round
-    O3DS_PH(2);
+    lds_wave_sync();  // s_list is rewritten by the next round
   }
-  lanes_min<P4, W>(mine);
+  lanes_min<P4, 64>(mine);
   best = mine;
 }
 
@@ -931,39 +872,19 @@ __device__ __forceinline__ QueryPrefetch<P4> prefetch_query(const IcpPassArgs& a
 }
 
 // lane 0 takes the next ticket of an LDS counter; the result is a scalar (SGPR) value in every lane
-__device__ __forceinline__ int wave_pop(int* counter, int lane, int take = 1) {
+__device__ __forceinline__ int wave_pop(int* counter, int lane) {
   int k = 0;
-  if (lane == 0) k = atomicAdd(counter, take);
+  if (lane == 0) k = atomicAdd(counter, 1);
   return __builtin_amdgcn_readfirstlane(k);
 }
 
-// A query that is not settled by its candidate set parks its state in its own, still unused, record slot: what the pooled search of its
-// workgroup needs, and what its own lanes need afterwards (they keep nothing in registers across the pool)
+// an unresolved query parked for stage 3
 template <typename P4>
-struct PoolItem;
-template <>
-struct PoolItem<P4f> {
-  float x, y, z, d2, m, tau2;  // the query in storage precision, the bound / result, the candidate-set margin and list radius
-  int32_t idx;
+struct FarItem {
+  typename Scalar<P4>::type x, y, z, d2, m, tau2;
+  typename Scalar<P4>::index idx;
   int pos;
-  int kin;   // in: block radius (cells) earlier levels have scanned around the query, 0 = none; out: the radius its search covered
-  float mf;  // distance of the query to the nearest face of its cell, cell units
-  double px, py, pz;  // the placed query as the records need it
 };
-template <>
-struct PoolItem<P4d> {
-  double x, y, z, d2, m, tau2;  // (x, y, z ARE the placed query)
-  int64_t idx;
-  int pos;
-  int kin;
-  float mf;
-};
-__device__ __forceinline__ void item_set_p(PoolItem<P4f>* it, double px, double py, double pz) { it->px = px, it->py = py, it->pz = pz; }
-__device__ __forceinline__ void item_set_p(PoolItem<P4d>*, double, double, double) {}
-__device__ __forceinline__ void item_get_p(const PoolItem<P4f>* it, double* px, double* py, double* pz) { *px = it->px, *py = it->py, *pz = it->pz; }
-__device__ __forceinline__ void item_get_p(const PoolItem<P4d>* it, double* px, double* py, double* pz) { *px = it->x, *py = it->y, *pz = it->z; }
-// the lists of the pooled search in LDS: [l] entries of level l, [3 + l] its pop cursor, [8 + 64 l + k] the k-th query slot of level l
-constexpr int kPoolInts = 8 + 3 * 64;
 
 // What the prologue of a fused launch knows about the update it has just applied (the candidate-set margin is derived from it per
 // query); unit = off.
@@ -1028,7 +949,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
   constexpr int kQPB = kPassBlock / kGroup;
   n_live = min(n_live, a.count);
   constexpr int kStride = kGicp ? kRec : kRecSlots;  // doubles per query record
-  static_assert((64 / kGroup) * kSegMax >= kWaveList, "a wavefront's share of s_seg holds the run lists of the queries it searches at a time");
+  static_assert((64 / kGroup) * kSegMax >= kFarList, "a wavefront's share of s_seg holds the stage-3 list");
   using R = typename Scalar<P4>::type;
   const P4* __restrict__ tp = (const P4*)a.tpts;  // (the source points arrive through the prefetch)
   const P4* __restrict__ tn = (const P4*)a.tnrm;
@@ -1037,8 +958,13 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
                t21 = to_sgpr(Tm[6]), t02 = to_sgpr(Tm[8]), t12 = to_sgpr(Tm[9]), t22 = to_sgpr(Tm[10]), t03 = to_sgpr(Tm[12]),
                t13 = to_sgpr(Tm[13]), t23 = to_sgpr(Tm[14]);
   const int gl = threadIdx.x & (kGroup - 1), ql = threadIdx.x / kGroup;
+  const int term = threadIdx.x & 31, qs = threadIdx.x >> 5;
   const bool inf = a.method == kMethodInformation;
   const bool p2p = a.method == O3DS_ICP_POINT_TO_POINT || inf;  // uniform: records built from the points themselves, no normals
+  // which two slots a record term multiplies: from the tables above, packed four bits per term into literals (a table in memory would
+  // be a load whose latency the verified-match path has nothing to hide behind)
+  const int ta = term_slot(inf ? kPackA_inf.lo : (p2p ? kPackA_p2p.lo : kPackA.lo), inf ? kPackA_inf.hi : (p2p ? kPackA_p2p.hi : kPackA.hi), term);
+  const int tb = term_slot(inf ? kPackB_inf.lo : (p2p ? kPackB_p2p.lo : kPackB.lo), inf ? kPackB_inf.hi : (p2p ? kPackB_p2p.hi : kPackB.hi), term);
   // candidate sets: read (verified matches) whenever the previous pass left them, written whenever this pass has a margin
   const bool sets = !kKeys && a.set_pos != nullptr && s_set != nullptr;
   const bool sets_in = sets && use_cache;
@@ -1047,40 +973,41 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
   int* my_set = sets ? s_set + ql * (1 + kSetCap) : nullptr;
   double acc = 0.0;
   const size_t n_batches = (a.count + kQPB - 1) / kQPB;
-  static_assert(sizeof(PoolItem<P4>) <= kStride * sizeof(double), "a parked query fits its record slot");
-  static_assert(kPoolInts * sizeof(int) <= (kPassBlock / 32) * kRec * sizeof(double) && kQPB == 64, "the pool's lists fit s_red");
-  int* s_pool = (int*)&s_red[0][0];  // the lists of the pooled search (kPoolInts); s_red itself is only used after the loop
-  if (threadIdx.x < 8) s_pool[threadIdx.x] = 0;
+  static_assert(sizeof(FarItem<P4>) <= kStride * sizeof(double), "a parked far query fits its record slot");
+  static_assert((2 + kQPB) * sizeof(int) <= (kPassBlock / 32) * kRec * sizeof(double), "the far list fits s_red");
+  int* s_far = (int*)&s_red[0][0];  // [0] count, [1] next, [2..] query slots; s_red itself is only used after the loop
+  if (threadIdx.x == 0) s_far[0] = s_far[1] = 0;
   lds_barrier();
-#ifdef O3DS_PHASE_PROFILE
-  ph_start();
-#endif
   for (size_t b = (size_t)wg; b < n_batches; b += kSingle ? n_batches : (size_t)nwg) {
     const size_t i = query_index<kQPB, 64 / kGroup>(a.count, b, ql, !use_cache);
-    bool searched = false;   // the query left its state in its record slot (PoolItem): everything that is not a verified match
-    int n_far_stat = 0;
+    double px = 0, py = 0, pz = 0;
+    NNBest<P4> nn;
+    nn.pos = -1;
+    nn.idx = -1;
+    nn.d2 = (R)0;
+    bool unresolved = false;
     bool verified = false;   // the match was proven inside the prefetched candidate set: the winner's lane holds point and normal
+    int kdone = 0;           // block radius (cells) the search of this query covered; 0 = no search ran
+    R m = (R)0;  // candidate-set margin of this query's search (0: the search leaves no set)
     const QueryPrefetch<P4> qp = (kSingle || b == (size_t)wg) ? first_batch : prefetch_query<P4, kPassBlock, kGroup>(a, b, use_cache, sets);
-    if (sets && gl == 0) my_set[0] = 0;  // (same wavefront as its readers and writers below; the pool is behind a barrier)
+    if (sets && gl == 0) my_set[0] = 0;  // (same wavefront as its readers and writers below; the far stage is behind a barrier)
     if (i < n_live) {  // uniform across the lanes of a group
       const P4 s = qp.s;
       // [O3D] PointCloud::Transform: rigid 4x4 (bottom row 0 0 0 1 for every pose the reference passes)
-      const double px = t00 * (double)s.x + t01 * (double)s.y + t02 * (double)s.z + t03;
-      const double py = t10 * (double)s.x + t11 * (double)s.y + t12 * (double)s.z + t13;
-      const double pz = t20 * (double)s.x + t21 * (double)s.y + t22 * (double)s.z + t23;
+      px = t00 * (double)s.x + t01 * (double)s.y + t02 * (double)s.z + t03;
+      py = t10 * (double)s.x + t11 * (double)s.y + t12 * (double)s.z + t13;
+      pz = t20 * (double)s.x + t21 * (double)s.y + t22 * (double)s.z + t23;
       const R qx = (R)px, qy = (R)py, qz = (R)pz;
-      PoolItem<P4>* const item = (PoolItem<P4>*)(s_rec_flat + ql * kStride);
-      if (kKeys && a.keys_mode == 2) {  // the match was decided by the all-reduce: mine iff the key names this rank
+      bool resolved = true;
+      if (a.debug == 2) {
+        nn.pos = (int)(i % 1000);
+        nn.idx = nn.pos;
+      } else if (kKeys && a.keys_mode == 2) {  // the match was decided by the all-reduce: mine iff the key names this rank
         const unsigned long long key = a.keys[a.first + i];
-        const bool mine = key != kNoKey && (int)((key >> 28) & 0xfu) == a.keys_rank;
-        searched = true;
-        if (gl == 0) {
-          item->x = qx, item->y = qy, item->z = qz;
-          item_set_p(item, px, py, pz);
-          item->pos = mine ? (int)(key & 0x0fffffffu) : -1;
-          item->idx = item->pos;
-          item->d2 = mine ? (R)__uint_as_float((unsigned int)(key >> 32)) : (R)0;
-          item->m = (R)0, item->tau2 = (R)0, item->kin = 0, item->mf = 0.0f;
+        if (key != kNoKey && (int)((key >> 28) & 0xfu) == a.keys_rank) {
+          nn.pos = (int)(key & 0x0fffffffu);
+          nn.idx = nn.pos;
+          nn.d2 = (R)__uint_as_float((unsigned int)(key >> 32));
         }
       } else {
         // the starting bound: the cached match (every lane the same point) or, with candidate sets, the best of the listed points
@@ -1101,10 +1028,11 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
         }
         if (verified) {
           // the lane that holds the winner writes the record now (point and normal are in its registers); no match: lane 0, zeros
-          if (best.pos != -1 ? qp.prev == best.pos : gl == 0) {
-            a.nn_cache[a.first + i] = best.pos;
+          nn = best;
+          if (nn.pos != -1 ? qp.prev == nn.pos : gl == 0) {
+            a.nn_cache[a.first + i] = nn.pos;
             double* rec = s_rec_flat + ql * kStride;
-            if (best.pos != -1) {
+            if (nn.pos != -1) {
               // (the normal is first looked at HERE: left to itself the compiler widens it to f64 right behind its load, i.e. waits
               // for that load in the prologue, in front of the solve)
               P4 nprev = qp.nprev;
@@ -1116,24 +1044,8 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
             }
           }
         } else {
-          // a query without a usable bound -- pass 0, nothing found last pass, a cached match more than a cell away after a large update --
-          // asks its cell's seed (see "seeds"): a target point nearby, or the proof that nothing lies within r
-          bool nothing = false;
-#if O3DS_ICP_SEEDS
-          if (!kKeys && a.grid.seed != nullptr && a.kmax <= a.grid.seed_k) {  // uniform
-            const QueryCell c = locate(a.grid, (double)qx, (double)qy, (double)qz);
-            const float ic2s = (float)(a.grid.inv_cell * a.grid.inv_cell);
-            const bool loose = best.pos == -1 || (float)best.d2 * ic2s > (1.0f + c.mf) * (1.0f + c.mf);
-            if (loose && (unsigned)c.ix < (unsigned)a.grid.nx && (unsigned)c.iy < (unsigned)a.grid.ny && (unsigned)c.iz < (unsigned)a.grid.nz) {
-              const int sp = a.grid.seed[((size_t)c.iz * a.grid.ny + c.iy) * a.grid.nx + c.ix];
-              nothing = sp < 0 && best.pos == -1;  // (a bound and an empty block cannot both be: then search)
-              const int spc = min(max(sp, 0), a.n_tgt - 1);
-              consider<P4, kCrop>(tp[spc], spc, sp >= 0, qx, qy, qz, a.crop, best);
-            }
-          }
-#endif
-          R tau2 = (R)0, m = (R)0;  // the candidate-set margin of this query's search (0: the search leaves no set) and its list radius
-          if (sets_out) {  // margin from the update just applied: the next update is smaller
+          R tau2 = (R)0;
+          if (sets_out) {  // margin of this query's search from the update just applied: the next update is smaller
             const float pn = sqrtf((float)(px * px + py * py + pz * pz));
             const float mm = a.set_gain * (sm.w * pn + sm.t);
             if (mm <= a.set_cap) {
@@ -1142,143 +1054,79 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
               tau2 = tau * tau;
             }
           }
-          O3DS_PH(0);
-          // The query parks for the pooled search (its record slot is still unused).  The level it enters: with a bound -- any target
-          // point: the cached match, the best of a candidate set, the seed -- the smallest block that holds the ball of the bound (plus
-          // the candidate-set margin), so that ONE search settles it; without one, the 3x3x3 block, and on from there.  `nothing`: the
-          // block of +-kmax cells around the query's cell is empty -- no match, proven as far as that block reaches, no search.
-          const QueryCell c = locate(a.grid, (double)qx, (double)qy, (double)qz);
-          const float w2 = widen2(best.d2, m) * (float)(a.grid.inv_cell * a.grid.inv_cell) * (1.0f + 1e-4f);
-          const int level = (best.pos == -1 || a.kmax <= 1 || w2 <= (1.0f + c.mf) * (1.0f + c.mf)) ? 0
-                            : ((a.kmax <= 2 || w2 <= (2.0f + c.mf) * (2.0f + c.mf)) ? 1 : 2);
-          searched = true;
-          if (gl == 0) {
-            item->x = qx, item->y = qy, item->z = qz;
-            item_set_p(item, px, py, pz);
-            item->d2 = best.d2, item->idx = best.idx, item->pos = best.pos;
-            item->m = m, item->tau2 = tau2;
-            item->kin = nothing ? a.kmax : 0;
-            item->mf = c.mf;
-            if (!nothing) s_pool[8 + 64 * level + atomicAdd(&s_pool[level], 1)] = ql;
+          Collect<R> col;
+          col.tau2 = tau2;
+          col.cnt = my_set;
+          col.list = my_set + 1;
+          // (the lane's row offsets are recomputed per batch: hoisted out of the batch loop they cost a dozen registers, i.e. spills)
+          int gl_b = gl;
+          asm volatile("" : "+v"(gl_b));
+          nn = nn_search_group<P4, kCrop, kGroup, kCollect>(a.grid, tp, qx, qy, qz, a.kmax, a.crop, gl_b, s_seg + ql * kSegMax, best, m, col, &resolved, &kdone);
+          if (!resolved && gl == 0) {  // park the query for stage 3 (its record slot is still unused)
+            FarItem<P4>* mine_item = (FarItem<P4>*)(s_rec_flat + ql * kStride);
+            mine_item->x = qx;
+            mine_item->y = qy;
+            mine_item->z = qz;
+            mine_item->d2 = nn.d2;
+            mine_item->m = m;
+            mine_item->tau2 = tau2;
+            mine_item->idx = nn.idx;
+            mine_item->pos = nn.pos;
           }
         }
       }
+      unresolved = !resolved;
     }
-    O3DS_PH(5);
     if (tr && threadIdx.x == 0) tr[0] = wall_clock64();
-    // The pooled search.  What a search costs is instructions (the passes that search are VALU-issue bound: profiles/r06_*), and the 16
-    // queries of a wavefront need different things -- most are settled by the 3x3x3 block, some need the 5x5x5 shell, a few the whole
-    // ball of the radius -- so a wavefront that serves its own 16 queries executes every level for the benefit of a few of its lanes.
-    // Instead every query that must search parks its state and enters the list of its level; the four wavefronts then pop queries level
-    // by level -- 16 at a time with 4 lanes each for the two block levels, 4 at a time with 16 lanes each for the far level -- so that
-    // every wavefront instruction serves queries that need it, and a region of far queries is shared by the workgroup.  A query whose
-    // search does not prove its result (no bound to start from, nothing close enough found) moves on to the level that will.  The
-    // result of a search does not depend on who computes it, and the records stay in their slots, so the sums are unchanged.
+    // Stage 3.  A far query takes a whole wavefront for a few memory rounds, and far queries cluster, so they are pooled per
+    // WORKGROUP: every unresolved query parks its state in its (still unused) record slot and enters a list; the four
+    // wavefronts then pop queries from the list until it is empty and write the winner back for the owner.  The search
+    // result does not depend on who computes it, and the records stay in their slots, so the sums are unchanged.
     {
+      FarItem<P4>* mine_item = (FarItem<P4>*)(s_rec_flat + ql * kStride);
+      if (a.debug == 16) unresolved = false;
+      if (unresolved && gl == 0) {
+        const int k = atomicAdd(&s_far[0], 1);
+        s_far[2 + k] = ql;
+      }
       lds_barrier();
-      O3DS_PH(8);
-      const int n_pool = __builtin_amdgcn_readfirstlane(s_pool[0] + s_pool[1] + s_pool[2]);
-      if (n_pool > 0) {  // workgroup-uniform
+      const int n_far = __builtin_amdgcn_readfirstlane(s_far[0]);
+      if (n_far > 0) {  // workgroup-uniform
         const int lane = threadIdx.x & 63;
         int2* list = s_seg + (threadIdx.x >> 6) * (64 / kGroup) * kSegMax;
-        const float ic2 = (float)(a.grid.inv_cell * a.grid.inv_cell) * (1.0f + 1e-4f);
-        // levels 0 and 1: the 3x3x3 block, the 5x5x5 block -- 4 lanes per query, 16 queries per wavefront at a time
-#pragma unroll 1
-        for (int level = 0; level < 2; ++level) {
-          const int n_lvl = __builtin_amdgcn_readfirstlane(s_pool[level]);
-          const int K = level == 0 ? 1 : min(2, a.kmax);
-          constexpr int W = 4, Q = 64 / W;
-          for (int k = wave_pop(&s_pool[3 + level], lane, Q); k < n_lvl; k = wave_pop(&s_pool[3 + level], lane, Q)) {  // k is scalar: a uniform loop
-            // (a sub-group beyond the end of the list runs along on sub-group 0's query, lists nothing and stores the same winner)
-            const bool active = k + lane / W < n_lvl;
-            const int slot = s_pool[8 + 64 * level + (active ? k + lane / W : k)];
-            PoolItem<P4>* it = (PoolItem<P4>*)(s_rec_flat + slot * kStride);
-            NNBest<P4> bq;
-            bq.d2 = it->d2;
-            bq.pos = it->pos;
-            bq.idx = it->idx;
-            Collect<R> col;
-            col.tau2 = active ? it->tau2 : (R)0;
-            col.cnt = sets ? s_set + slot * (1 + kSetCap) : nullptr;
-            col.list = col.cnt + 1;
-            if (a.debug != 32) nn_search_sub<P4, kCrop, kCollect, W, O3DS_SUB4_KPER>(a.grid, tp, it->x, it->y, it->z, K, it->kin, a.crop, bq, lane, list, it->m, col);
-            // every lane of the sub-group holds the same winner and stores it (same address, same value)
-            it->d2 = bq.d2;
-            it->pos = bq.pos;
-            it->idx = bq.idx;
-            it->kin = K;
-            // proven exact if nothing outside the scanned block can be nearer: best + margin <= cell * (K + face distance), tested with
-            // margin; a query that came with a bound is proven by construction (its level was chosen so).  Not proven: on to the next
-            // block (nothing found yet, or something the 5x5x5 block can settle) or to the whole ball at once (something farther)
-            const float w2 = widen2(bq.d2, it->m) * ic2, imf = it->mf;
-            const bool proven = K >= a.kmax || (bq.pos != -1 && w2 <= ((float)K + imf) * ((float)K + imf));
-            const bool move = !proven && active && (lane & (W - 1)) == 0;
-            const bool to1 = move && level == 0 && (a.kmax <= 2 || bq.pos == -1 || w2 <= (2.0f + imf) * (2.0f + imf));
-            const bool to2 = move && !to1;
-            const unsigned long long m1 = __ballot(to1), m2 = __ballot(to2);
-            if (m1) {  // uniform
-              const int base = wave_pop(&s_pool[1], lane, __popcll(m1));
-              if (to1) s_pool[8 + 64 + base + __popcll(m1 & ((1ull << lane) - 1ull))] = slot;
-            }
-            if (m2) {
-              const int base = wave_pop(&s_pool[2], lane, __popcll(m2));
-              if (to2) s_pool[8 + 128 + base + __popcll(m2 & ((1ull << lane) - 1ull))] = slot;
-            }
-          }
-          O3DS_PH(9);
-          lds_barrier();  // the next level's list is complete
-          O3DS_PH(10);
+        for (int k = wave_pop(&s_far[1], lane); k < n_far; k = wave_pop(&s_far[1], lane)) {  // k is scalar: a uniform loop
+          const int slot = s_far[2 + k];
+          FarItem<P4>* it = (FarItem<P4>*)(s_rec_flat + slot * kStride);
+          NNBest<P4> bq;
+          bq.d2 = it->d2;
+          bq.pos = it->pos;
+          bq.idx = it->idx;
+          Collect<R> col;
+          col.tau2 = it->tau2;
+          col.cnt = sets ? s_set + slot * (1 + kSetCap) : nullptr;
+          col.list = col.cnt + 1;
+          if (a.debug != 32) nn_search_wave_far<P4, kCrop, kCollect>(a.grid, tp, it->x, it->y, it->z, a.kmax, a.crop, bq, lane, list, it->m, col);
+          // every lane holds the same winner and stores it (same address, same value): no lane-0 branch inside this loop --
+          // with one, the structurised code re-ran the body for the other lanes forever (seen on ROCm 7.2)
+          it->d2 = bq.d2;
+          it->pos = bq.pos;
+          it->idx = bq.idx;
         }
-        // level 2: the whole ball of the bound -- 16 lanes per query, 4 queries per wavefront at a time
-        {
-          const int n_lvl = __builtin_amdgcn_readfirstlane(s_pool[2]);
-          constexpr int W = 16, Q = 64 / W;
-          n_far_stat = n_lvl;
-          if (a.debug != 16)
-          for (int k = wave_pop(&s_pool[5], lane, Q); k < n_lvl; k = wave_pop(&s_pool[5], lane, Q)) {
-            const bool active = k + lane / W < n_lvl;
-            const int slot = s_pool[8 + 128 + (active ? k + lane / W : k)];
-            PoolItem<P4>* it = (PoolItem<P4>*)(s_rec_flat + slot * kStride);
-            NNBest<P4> bq;
-            bq.d2 = it->d2;
-            bq.pos = it->pos;
-            bq.idx = it->idx;
-            Collect<R> col;
-            col.tau2 = active ? it->tau2 : (R)0;
-            col.cnt = sets ? s_set + slot * (1 + kSetCap) : nullptr;
-            col.list = col.cnt + 1;
-            if (a.debug != 32) nn_search_sub<P4, kCrop, kCollect, W, 2>(a.grid, tp, it->x, it->y, it->z, a.kmax, it->kin, a.crop, bq, lane, list, it->m, col);
-            it->d2 = bq.d2;
-            it->pos = bq.pos;
-            it->idx = bq.idx;
-            it->kin = a.kmax;
-          }
-          O3DS_PH(9);
-          lds_barrier();  // the owners read their results
-          O3DS_PH(10);
+        lds_barrier();
+        if (unresolved) {  // (all lanes of the group: the set below is written by all of them)
+          nn.d2 = mine_item->d2;
+          nn.pos = mine_item->pos;
+          nn.idx = mine_item->idx;
+          kdone = a.kmax;
         }
       }
     }
-    // what the query's own lanes go on with (all lanes of the group: the set below is written by all of them)
-    double px = 0, py = 0, pz = 0;
-    NNBest<P4> nn;
-    nn.pos = -1, nn.idx = -1, nn.d2 = (R)0;
-    int kdone = 0;  // block radius (cells) the search of this query covered
-    R m = (R)0;
-    if (searched) {
-      const PoolItem<P4>* it = (const PoolItem<P4>*)(s_rec_flat + ql * kStride);
-      item_get_p(it, &px, &py, &pz);
-      nn.d2 = it->d2, nn.pos = it->pos, nn.idx = it->idx;
-      kdone = it->kin;
-      m = it->m;
-    }
     if (tr && threadIdx.x == 0) tr[1] = wall_clock64();
-#ifndef O3DS_PHASE_PROFILE
     if (a.stats) {  // development aid: how the queries of this launch were served
       const bool q0 = gl == 0 && i < n_live;
       const unsigned long long nv = __popcll(__ballot(q0 && verified)), ns = __popcll(__ballot(q0 && !verified)),
                                nk = __popcll(__ballot(q0 && !verified && m > (R)0 && sets && s_set[ql * (1 + kSetCap)] <= kSetCap)),
-                               nf = (threadIdx.x >> 6) == 0 ? (unsigned long long)n_far_stat : 0ull;
+                               nf = __popcll(__ballot(q0 && unresolved));
       if ((threadIdx.x & 63) == 0) {
         atomicAdd(a.stats + 0, nv);
         atomicAdd(a.stats + 1, ns);
@@ -1286,9 +1134,8 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
         atomicAdd(a.stats + 3, nf);
       }
     }
-#endif
     // ---- the candidate set this query's search leaves for the next pass (a verified match keeps the one it has)
-    if (sets && searched) {
+    if (sets && i < n_live && !verified && a.debug != 2) {
       const int n_listed = my_set[0];
       const bool have = m > (R)0 && n_listed <= kSetCap;
       int pos_out = have ? (gl < n_listed ? my_set[1 + gl] : -1) : (gl == 0 ? nn.pos : -1);
@@ -1312,13 +1159,14 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
     // ---- records
     if (!verified && gl == 0) {
       {
-        if (searched && !(kKeys && a.keys_mode == 2)) a.nn_cache[a.first + i] = nn.pos;
-        if (kKeys && a.keys_mode == 1 && searched)
+        if (i < n_live && !(kKeys && a.keys_mode == 2)) a.nn_cache[a.first + i] = nn.pos;
+        if (kKeys && a.keys_mode == 1 && i < n_live)
           a.keys[a.first + i] = nn.pos == -1 ? kNoKey
                                              : ((unsigned long long)__float_as_uint((float)nn.d2) << 32) |
                                                    ((unsigned long long)(a.keys_rank & 0xf) << 28) | (unsigned long long)(nn.pos & 0x0fffffff);
         double* rec = s_rec_flat + ql * kStride;
         if (nn.pos != -1 && !(kKeys && a.keys_mode == 1)) {
+          if (a.debug == 3) nn.pos = (int)(i % 1000);
           const P4 q = tp[nn.pos];
           const P4 nq = (!kGicp && p2p) ? P4{} : tn[nn.pos];
           write_record<P4, kGicp>(a, rec, p2p, px, py, pz, q, nq, i, t00, t01, t02, t10, t11, t12, t20, t21, t22);
@@ -1329,18 +1177,8 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
       }
     }
     lds_barrier();
-    O3DS_PH(11);
-#ifdef O3DS_PHASE_PROFILE
-    ph_flush(a.stats);
-#endif
     if (tr && threadIdx.x == 0) tr[2] = wall_clock64();
-    if (threadIdx.x < 8) s_pool[threadIdx.x] = 0;  // everyone is past the pool's lists (ordered before their next use by the barrier below)
-    // which two slots a record term multiplies: from the tables above, packed four bits per term into literals (a table in memory would
-    // be a load whose latency the verified-match path has nothing to hide behind); computed HERE, not in front of the searches: four
-    // registers less across them
-    const int term = threadIdx.x & 31, qs = threadIdx.x >> 5;
-    const int ta = term_slot(inf ? kPackA_inf.lo : (p2p ? kPackA_p2p.lo : kPackA.lo), inf ? kPackA_inf.hi : (p2p ? kPackA_p2p.hi : kPackA.hi), term);
-    const int tb = term_slot(inf ? kPackB_inf.lo : (p2p ? kPackB_p2p.lo : kPackB.lo), inf ? kPackB_inf.hi : (p2p ? kPackB_p2p.hi : kPackB.hi), term);
+    if (threadIdx.x == 0) s_far[0] = s_far[1] = 0;  // everyone is past the far list (ordered before its next use by the barrier below)
 #pragma unroll
     for (int qq = 0; qq < kQPB / (kPassBlock / 32); ++qq) {
       const double* rec = s_rec_flat + (qs * (kQPB / (kPassBlock / 32)) + qq) * kStride;
@@ -1352,7 +1190,6 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
     lds_barrier();  // s_rec is rewritten by the next batch
   }
   // query slices -> 1, fixed order => bitwise reproducible for a given launch geometry
-  const int term = threadIdx.x & 31, qs = threadIdx.x >> 5;
   s_red[qs][term] = acc;
   lds_barrier();
   double v = 0.0;

@@ -526,11 +526,6 @@ __device__ __forceinline__ void pm_row_push(const PmDev& m, int s, unsigned long
   int row, x;
   pm_cell(m, key, &row, &x);
   atomicAdd(&m.cell_add[(size_t)row * (m.grid.nx + 1) + x], 1);
-  {  // the cell holds something from now on (GridDev::occ: the searches look here before they fetch a cell_start pair)
-    unsigned* w = const_cast<unsigned*>(m.grid.occ) + (size_t)row * (size_t)m.grid.occ_wpr + (x >> 5);
-    const unsigned bit = 1u << (x & 31);
-    if (!(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(w, bit);
-  }
   if (pm_outside_grid(m, key)) atomicAdd(m.counters + kPmClamped, 1);
   // (a look before the exchange: a floor row receives hundreds of slots per scan, and all but the first find the row marked already)
   if (__hip_atomic_load(&m.row_flag[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && atomicExch(&m.row_flag[row], 1) == 0)

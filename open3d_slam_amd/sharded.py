@@ -66,6 +66,43 @@ def run_sharded_fused_loop(issue_pass: Callable[[int], object], all_reduce: Call
     return passes
 
 
+def init_library_comm(be, group=None) -> None:
+    """The backend handle's OWN RCCL communicator (o3ds_comm_init) for the ranks of a torch.distributed group: rank 0 draws the
+    ncclUniqueId inside the library, torch.distributed only carries its 128 bytes to the other ranks.  After this,
+    Backend.icp_register_sharded queues kernels and ncclAllReduce calls itself -- no Python, no torch between the passes."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_initialized():
+        be.comm_init(be.comm_unique_id(), 0, 1)
+        return
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    on_gpu = dist.get_backend(group) == "nccl"
+    dev = torch.device(f"cuda:{be.device_id}") if on_gpu else torch.device("cpu")
+    t = torch.zeros(128, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        t = torch.frombuffer(bytearray(be.comm_unique_id()), dtype=torch.uint8).to(dev)
+    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    be.comm_init(bytes(t.cpu().numpy().tobytes()), rank, world)
+
+
+class LibraryShardedIcp:
+    """ShardedIcp's interface over o3ds_icp_register_sharded: the loop, the kernels and the collectives live in libo3ds_backend.so."""
+
+    MODES = {"source": 0, "submap": 1, "union": 2}
+
+    def __init__(self, be, mode: str = "source", group=None):
+        assert mode in self.MODES
+        self.be, self.mode = be, mode
+        init_library_comm(be, group)
+
+    def register(self, source: int, target: int, n_src: int, max_corr: float, init=None, max_iter: int = 30, rel_fitness: float = 1e-6,
+                 rel_rmse: float = 1e-6, target_crop=None, check_every: int = 4, method=None) -> dict:
+        kw = {} if method is None else {"method": method}
+        return self.be.icp_register_sharded(self.MODES[self.mode], source, target, max_corr, init=init, max_iter=max_iter,
+                                            rel_fitness=rel_fitness, rel_rmse=rel_rmse, target_crop=target_crop, **kw)
+
+
 class ShardedIcp:
     """GPU driver of run_sharded_loop over a Backend handle and a torch.distributed process group."""
 

@@ -4,7 +4,7 @@
 # parity tests on the default library.  LIBS="default v_base ..." (default = open3d_slam_amd/lib/libo3ds_backend.so)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-M1="--no-cpu-baseline --no-f64 --concurrent 0 --m2-frames 0 --large-map ${LARGE:-0} --no-gicp --no-host-seam"
+M1="${CELL:+--cell $CELL} --no-cpu-baseline --no-f64 --concurrent 0 --m2-frames 0 --large-map ${LARGE:-0} --no-gicp --no-host-seam"
 : > $OUT/r6_icp.txt
 for v in ${LIBS:-default}; do
   lib=$R/open3d_slam_amd/lib/libo3ds_backend_$v.so; [ "$v" = default ] && lib=$R/open3d_slam_amd/lib/libo3ds_backend.so

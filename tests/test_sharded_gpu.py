@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, mode, out_path, dist_backend="gloo"):
+def _worker(rank, world, port, mode, out_path, dist_backend="gloo", library=False):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -42,7 +42,8 @@ def _worker(rank, world, port, mode, out_path, dist_backend="gloo"):
     be = backend.Backend(dev, backend.PRECISION_F64)
     s, t = be.upload(src), be.upload(tgt, nrm)
     be.build_index(t, 1.0)
-    drv = sharded.ShardedIcp(be, mode=mode)
+    # library: the loop, the kernels and the ncclAllReduce calls inside libo3ds_backend.so (o3ds_icp_register_sharded); else Python + torch
+    drv = sharded.LibraryShardedIcp(be, mode=mode) if library else sharded.ShardedIcp(be, mode=mode)
     res = drv.register(s, t, len(src), 1.0, max_iter=30, check_every=2)
     where = f"cuda:{dev}" if dist_backend == "nccl" else "cpu"
     Ts = [torch.zeros(16, dtype=torch.float64, device=where) for _ in range(world)]
@@ -61,7 +62,7 @@ def _two_gpus():
 
 
 @pytest.mark.parametrize("mode", ["source", "submap", "union"])
-@pytest.mark.parametrize("dist_backend", ["gloo", "nccl"])
+@pytest.mark.parametrize("dist_backend", ["gloo", "nccl", "nccl-library"])
 def test_two_ranks_one_gpu(tmp_path, backend_f64, oracle, mode, dist_backend):
     """dist_backend "nccl": the same three partitionings over RCCL with one GPU per rank -- the int64 MIN all-reduce of the union form, the
     4-KB sum all-reduce of the fused form, o3ds_set_stream ordering against a real second device -- on the first box that has two GPUs
@@ -70,10 +71,12 @@ def test_two_ranks_one_gpu(tmp_path, backend_f64, oracle, mode, dist_backend):
 
     from open3d_slam_amd import synthetic as syn
 
+    library = dist_backend == "nccl-library"  # o3ds_icp_register_sharded: RCCL called by the library itself
+    dist_backend = "nccl" if library else dist_backend
     if dist_backend == "nccl" and not _two_gpus():
         pytest.skip("RCCL needs one GPU per rank: this box has fewer than two")
     out = str(tmp_path / f"{mode}.npz")
-    mp.spawn(_worker, args=(2, _free_port(), mode, out, dist_backend), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), mode, out, dist_backend, library), nprocs=2, join=True)
     r = np.load(out)
     np.testing.assert_array_equal(r["all_T"][0], r["all_T"][1])  # identical pose on every rank, no broadcast
     scene = syn.make_scene()
@@ -302,3 +305,70 @@ def test_sources_beyond_the_fused_pass_limit_fall_back_to_the_looping_form(tmp_p
     assert "O3DS_ICP_PASS_MAX_QUERIES" in str(r["limit_error"])
     assert int(r["it"]) == 8
     np.testing.assert_allclose(r["got"], r["one"], atol=1e-9)
+
+
+# ---- the sharded registration INSIDE the library (o3ds_icp_register_sharded: kernels + ncclAllReduce queued by libo3ds_backend.so) ----------
+def _library_worker(rank, world, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from open3d_slam_amd import backend, synthetic as syn
+
+    scene = syn.make_scene()
+    src = syn.vlp16_scan(scene, syn.ground_truth_pose(), n_az=512)
+    tgt, nrm = syn.sample_map(scene, 100_000)
+    res = {}
+    for prec, tag in ((backend.PRECISION_F64, "f64"), (backend.PRECISION_F32, "f32")):
+        be = backend.Backend(0, prec)
+        s, t = be.upload(src), be.upload(tgt, nrm)
+        be.build_index(t, 1.0)
+        be.estimate_normals(s, 3.0, 20)
+        for meth, mtag in ((backend.ICP_POINT_TO_PLANE, "p2l"), (backend.ICP_GENERALIZED, "gicp")):
+            one = be.icp_register_dev(s, t, 1.0, max_iter=30, method=meth)
+            res[f"one_{tag}_{mtag}"], res[f"one_it_{tag}_{mtag}"] = one["transformation"], one["iterations"]
+            for comm in (False, True):  # without a communicator (a group of one, no collective) and with a real RCCL communicator of one rank
+                if comm:
+                    be.comm_init(be.comm_unique_id(), 0, 1)
+                for mode, mname in ((be.SHARD_SOURCE, "source"), (be.SHARD_SUBMAP, "submap"), (be.SHARD_UNION, "union")):
+                    if mode == be.SHARD_UNION and meth != backend.ICP_POINT_TO_PLANE:
+                        continue
+                    r = be.icp_register_sharded(mode, s, t, 1.0, max_iter=30, method=meth)
+                    k = f"{tag}_{mtag}_{mname}_{int(comm)}"
+                    res["T_" + k], res["it_" + k], res["fit_" + k] = r["transformation"], r["iterations"], r["fitness"]
+                if comm:
+                    be.comm_destroy()
+        # fixed iteration count, no convergence: every pass of the loop issues its collective
+        be.comm_init(be.comm_unique_id(), 0, 1)
+        a = be.icp_register_dev(s, t, 1.0, max_iter=10, rel_fitness=0.0, rel_rmse=0.0, method=backend.ICP_POINT_TO_PLANE)
+        b = be.icp_register_sharded(be.SHARD_SOURCE, s, t, 1.0, max_iter=10, rel_fitness=0.0, rel_rmse=0.0)
+        res[f"fixed_one_{tag}"], res[f"fixed_lib_{tag}"], res[f"fixed_it_{tag}"] = a["transformation"], b["transformation"], b["iterations"]
+        be.close()
+    np.savez(out_path, **res)
+
+
+def test_library_sharded_registration_of_one_rank_is_the_one_shot_registration(tmp_path):
+    """o3ds_icp_register_sharded with a communicator of ONE rank (what a one-GPU box can run of RCCL): ncclGetUniqueId / ncclCommInitRank /
+    ncclAllReduce(sum, 512 doubles) / ncclAllReduce(min, n x u64) / ncclCommDestroy are called by the library itself, between its own
+    kernels on its own stream; every collective is the identity, so SOURCE and SUBMAP must reproduce o3ds_icp_register_dev bit for bit
+    (f64 and f32 storage, point-to-plane and generalized ICP) and UNION to 1e-9 (its keys carry the distance as a float)."""
+    import torch.multiprocessing as mp
+
+    out = str(tmp_path / "lib.npz")
+    mp.spawn(_library_worker, args=(1, out), nprocs=1, join=True)
+    r = np.load(out)
+    n_checked = 0
+    for tag in ("f64", "f32"):
+        for mtag in ("p2l", "gicp"):
+            for comm in (0, 1):
+                for mname in ("source", "submap", "union"):
+                    k = f"{tag}_{mtag}_{mname}_{comm}"
+                    if "T_" + k not in r:
+                        continue
+                    assert int(r["it_" + k]) == int(r[f"one_it_{tag}_{mtag}"]), k
+                    if mname == "union":
+                        np.testing.assert_allclose(r["T_" + k], r[f"one_{tag}_{mtag}"], atol=1e-9 if tag == "f64" else 1e-6, err_msg=k)
+                    else:
+                        np.testing.assert_array_equal(r["T_" + k], r[f"one_{tag}_{mtag}"], err_msg=k)
+                    n_checked += 1
+        np.testing.assert_array_equal(r[f"fixed_lib_{tag}"], r[f"fixed_one_{tag}"])
+        assert int(r[f"fixed_it_{tag}"]) == 10
+    assert n_checked == 2 * (2 * 3 + 2 * 2)
