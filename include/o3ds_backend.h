@@ -350,6 +350,30 @@ int o3ds_cloud_append(o3ds_handle h, o3ds_cloud map, o3ds_cloud add);
  * trip through host memory -- the reference passes the same host PointCloud to both.  `dst`'s stream waits for what `src` queued;
  * neither handle may be in use by another thread during the call; returns when the copy is complete. */
 int o3ds_cloud_copy_across(o3ds_handle dst, o3ds_handle src, o3ds_cloud src_cloud, o3ds_cloud* out);
+/* The same hand-over WITHOUT the source handle: open3d_slam's odometry and mapping workers run on two threads (SlamWrapper.cpp:227-236),
+ * each with its own handle, and the mapper wants the scan the odometry worker pre-processed while that worker is busy registering -- a
+ * call that needs both handles idle (o3ds_cloud_copy_across) either waits for the other worker or falls back to the host arrays.
+ * o3ds_cloud_export_view, called by the OWNER right after it made the cloud, freezes what a copy needs -- the device arrays, the size,
+ * the box, and an event behind everything the owner has queued for the cloud -- in a plain struct the caller keeps with the cloud;
+ * o3ds_cloud_import_view makes a copy on `dst` from the struct alone (dst's stream waits for the event; device-to-device copies;
+ * complete on return) and may run while the owner's handle is in use by its own thread.  The owner keeps the cloud alive and does not
+ * change it while views of it are in use (a pre-processed scan is never changed), and releases the view (its event) before or after
+ * freeing the cloud.  Same device, same storage precision. */
+typedef struct o3ds_cloud_view {
+  void* pts;
+  void* nrm;
+  void* col;
+  size_t n;
+  int precision;
+  int device;
+  int has_box;
+  int reserved;
+  double box_min[3], box_max[3];
+  void* event;
+} o3ds_cloud_view;
+int o3ds_cloud_export_view(o3ds_handle h, o3ds_cloud c, o3ds_cloud_view* out);
+int o3ds_cloud_import_view(o3ds_handle dst, const o3ds_cloud_view* view, o3ds_cloud* out);
+int o3ds_cloud_view_release(o3ds_cloud_view* view);
 /* voxelizeWithinCroppingVolume (helpers.cpp:115-183) via Submap::voxelizeInsideCroppingVolume (Submap.cpp:138-144):
  * points outside the volume pass through (original order, first); points inside are replaced by per-voxel means on
  * the WORLD-anchored grid key = floor(p * (1/voxel)) (VoxelHashMap.hpp:47-50), normals averaged (NaN skipped) and

@@ -127,6 +127,45 @@ inline o3ds_crop noCrop() {  // the base CroppingVolume (croppers.cpp:49-51): ev
   return c;
 }
 
+// A device cloud whose last reference drops on a thread that does not own its handle is not freed there and then if the owner is inside a
+// call (its lock is taken): waiting for a second handle while holding one is how two workers deadlock.  It goes to a short list that
+// whoever next holds that handle's lock empties (drainDeferredFrees, called where the seams take the lock).
+struct DeferredFrees {
+  std::mutex m;
+  std::vector<std::pair<std::shared_ptr<HandleBox>, o3ds_cloud>> dead;
+};
+inline DeferredFrees& deferredFrees() {
+  static DeferredFrees d;
+  return d;
+}
+inline void freeOrDefer(const std::shared_ptr<HandleBox>& box, o3ds_cloud id) {
+  std::unique_lock<std::recursive_mutex> lck(box->m, std::try_to_lock);
+  if (lck.owns_lock()) {
+    o3ds_cloud_free(box->h.get(), id);
+    return;
+  }
+  DeferredFrees& d = deferredFrees();
+  std::lock_guard<std::mutex> dl(d.m);
+  d.dead.emplace_back(box, id);
+}
+inline void drainDeferredFrees(const std::shared_ptr<HandleBox>& box) {  // box->m held by the caller
+  DeferredFrees& d = deferredFrees();
+  std::vector<o3ds_cloud> mine;
+  {
+    std::lock_guard<std::mutex> dl(d.m);
+    if (d.dead.empty()) return;
+    for (size_t i = 0; i < d.dead.size();)
+      if (d.dead[i].first.get() == box.get()) {
+        mine.push_back(d.dead[i].second);
+        d.dead[i] = d.dead.back();
+        d.dead.pop_back();
+      } else {
+        ++i;
+      }
+  }
+  for (o3ds_cloud id : mine) o3ds_cloud_free(box->h.get(), id);
+}
+
 // ---- a pre-processed scan that is still on the device ------------------------------------------------------------------------------
 // The device copy belongs to the handle (box) of the thread that made it and is freed with the last PointCloud that refers to it.
 struct DeviceRef {
@@ -134,16 +173,30 @@ struct DeviceRef {
   o3ds_cloud id = 0;
   size_t n = 0;
   uint64_t stamp = 0;  // fingerprint of the host arrays when the copy was made (see fingerprint)
+  // What ANOTHER worker's handle needs to copy the cloud without this one's lock (o3ds_cloud_export_view): open3d_slam's odometry and
+  // mapping workers run on two threads (SlamWrapper.cpp:227-236), and the mapper asks for the scan while the odometry worker is inside
+  // its registration -- holding its handle for hundreds of microseconds.  Exported by the owner right after it made the cloud.
+  o3ds_cloud_view view{};
   DeviceRef() = default;
   DeviceRef(const DeviceRef&) = delete;
   DeviceRef& operator=(const DeviceRef&) = delete;
+  void exportView() {  // box->m held by the caller
+    if (id && box && !view.event) (void)o3ds_cloud_export_view(box->h.get(), id, &view);  // (a failure leaves the view empty: readers fall back)
+  }
   ~DeviceRef() {
-    if (id && box) {
-      std::lock_guard<std::recursive_mutex> lck(box->m);
-      o3ds_cloud_free(box->h.get(), id);
-    }
+    o3ds_cloud_view_release(&view);
+    if (id && box) freeOrDefer(box, id);
   }
 };
+// the cloud behind `ref`, which lives on another worker's handle, as a cloud of handle h: from the exported view if there is one (no
+// lock of the other handle needed), else device to device if the other handle happens to be free; 0 if neither (the caller uploads)
+inline o3ds_cloud copyFromOtherHandle(o3ds_handle h, const DeviceRef& ref) {
+  o3ds_cloud mine = 0;
+  if (ref.view.event && ref.view.n == ref.n && o3ds_cloud_import_view(h, &ref.view, &mine) == O3DS_OK) return mine;
+  std::unique_lock<std::recursive_mutex> other(ref.box->m, std::try_to_lock);  // never wait for a second handle while holding one
+  if (other.owns_lock() && o3ds_cloud_copy_across(h, ref.box->h.get(), ref.id, &mine) == O3DS_OK) return mine;
+  return 0;
+}
 // what the seams hand out instead of a plain PointCloud: the same object for every reader, plus the device copy
 class ScanOnDevice : public PointCloud {
  public:
@@ -209,9 +262,8 @@ class DeviceCloud {
         borrowed_ = ref;  // keeps the copy alive; nothing to free here
         return;
       }
-      std::unique_lock<std::recursive_mutex> other(ref->box->m, std::try_to_lock);  // never wait for a second handle while holding one
-      if (other.owns_lock()) {
-        check(h_, o3ds_cloud_copy_across(h_, ref->box->h.get(), ref->id, &id_));
+      id_ = copyFromOtherHandle(h_, *ref);
+      if (id_) {
         fromDevice_ = true;
         return;
       }
@@ -355,6 +407,7 @@ inline std::shared_ptr<PointCloud> adopt(const std::shared_ptr<HandleBox>& box, 
   ref->id = id;
   ref->n = out->points_.size();
   ref->stamp = fingerprint(*out);
+  ref->exportView();
   out->device_ = ref;
   return out;
 }
@@ -379,13 +432,23 @@ struct ScanStampScope {  // for the duration of a seam call
   explicit ScanStampScope(int64_t ticks) : saved(scanStamp()) { scanStamp() = ticks; }
   ~ScanStampScope() { scanStamp() = saved; }
 };
-struct PreprocessMemo {
-  std::mutex m;
+struct PreprocessMemoEntry {
   int64_t stamp = 0;
   size_t n = 0;
+  uint64_t raw_print = 0;  // fingerprint of the raw scan (64 sampled points): two workers' motion compensations give clouds of one stamp and size
   ScanChain chain{};
-  std::weak_ptr<PointCloud> result;            // ratio >= 1: the finished cloud (host arrays + device copy), the same object for both callers
-  std::weak_ptr<const DeviceRef> before_draw;  // ratio < 1: the cloud before RandomDownSample, on the device only
+  std::shared_ptr<PointCloud> result;            // ratio >= 1: the finished cloud (host arrays + device copy), the same object for both callers
+  std::shared_ptr<const DeviceRef> before_draw;  // ratio < 1: the cloud before RandomDownSample, on the device only
+};
+// The last few scans, HELD (a few megabytes each, host and device).  More than one, and not weakly: open3d_slam's two workers are some
+// scans apart (SlamWrapper.cpp:258-347: the mapper takes scan k from its buffer while the odometry worker is on k + 1, k + 2 ...) -- with
+// a single weak entry the mapper found the NEXT scan's entry in place of its own, or its own already released by the odometry, and
+// computed everything again (0.5 ms per scan of the two-thread runs of round 5).
+struct PreprocessMemo {
+  std::mutex m;
+  static constexpr int kEntries = 8;
+  PreprocessMemoEntry e[kEntries];
+  int next = 0;
 };
 inline PreprocessMemo& preprocessMemo() {
   static PreprocessMemo memo;
@@ -423,6 +486,7 @@ inline std::shared_ptr<PointCloud> preprocessScan(const PointCloud& raw, const S
     throw std::runtime_error("[RandomDownSample] Illegal sampling_ratio, sampling_ratio must be between 0 and 1.");  // [O3D]
   const std::shared_ptr<HandleBox> box = threadBox();
   std::lock_guard<std::recursive_mutex> lck(box->m);
+  drainDeferredFrees(box);
   const o3ds_handle h = box->h.get();
   if (raw.points_.empty()) return std::make_shared<PointCloud>();
   const int64_t stamp = scanStamp();
@@ -432,20 +496,27 @@ inline std::shared_ptr<PointCloud> preprocessScan(const PointCloud& raw, const S
     PreprocessMemo& memo = preprocessMemo();
     std::shared_ptr<PointCloud> whole;
     std::shared_ptr<const DeviceRef> before;
+    double memo_ratio = 0.0;
     {
+      // (the reference runs separate motionCompensationOdom_ / motionCompensationMap_ objects, SlamWrapper.cpp:39-40,266,301: with a
+      // non-trivial compensation the two workers hold DIFFERENT clouds of the same stamp and size -- the content is part of the key)
       std::lock_guard<std::mutex> ml(memo.m);
-      if (memo.stamp == stamp && memo.n == raw.points_.size() && sameChain(memo.chain, p)) {
-        whole = memo.result.lock();
-        before = memo.before_draw.lock();
-      }
+      const uint64_t print = fingerprint(raw);
+      for (const PreprocessMemoEntry& e : memo.e)
+        if (e.stamp == stamp && e.n == raw.points_.size() && sameChain(e.chain, p) && e.raw_print == print) {
+          whole = e.result;
+          before = e.before_draw;
+          memo_ratio = e.chain.downSamplingRatio;
+          if (whole || before) break;
+        }
     }
-    if (!draw && whole && memo.chain.downSamplingRatio >= 1.0) return whole;
+    if (!draw && whole && memo_ratio >= 1.0) return whole;
     if (draw && before && before->n > 0) {  // its cloud before the draw: here (or copied here device to device), then this caller's own draw
       o3ds_cloud mine = 0, use = before->id;
       bool ok = true;
       if (before->box.get() != box.get()) {
-        std::unique_lock<std::recursive_mutex> other(before->box->m, std::try_to_lock);  // never wait for a second handle while holding one
-        ok = other.owns_lock() && o3ds_cloud_copy_across(h, before->box->h.get(), before->id, &mine) == O3DS_OK;
+        mine = copyFromOtherHandle(h, *before);
+        ok = mine != 0;
         use = mine;
       }
       if (ok) {
@@ -479,6 +550,7 @@ inline std::shared_ptr<PointCloud> preprocessScan(const PointCloud& raw, const S
         before->box = box;
         before->id = cur;
         before->n = n;
+        before->exportView();
         cur = 0;  // (owned by `before` now)
       } else {
         o3ds_cloud_free(h, cur);
@@ -497,11 +569,14 @@ inline std::shared_ptr<PointCloud> preprocessScan(const PointCloud& raw, const S
     if (share) {
       PreprocessMemo& memo = preprocessMemo();
       std::lock_guard<std::mutex> ml(memo.m);
-      memo.stamp = stamp;
-      memo.n = raw.points_.size();
-      memo.chain = p;
-      memo.result = out;
-      memo.before_draw = before;
+      PreprocessMemoEntry& e = memo.e[memo.next];
+      memo.next = (memo.next + 1) % PreprocessMemo::kEntries;
+      e.stamp = stamp;
+      e.n = raw.points_.size();
+      e.raw_print = fingerprint(raw);
+      e.chain = p;
+      e.result = out;
+      e.before_draw = before;
       if (before) {  // the memo's entry lives as long as the caller's cloud does: the cloud carries the reference
         if (ScanOnDevice* sd = dynamic_cast<ScanOnDevice*>(out.get())) sd->before_draw_ = before;
       }

@@ -33,6 +33,11 @@ class IcpResult(C.Structure):
                 ("iterations", C.c_int32), ("converged", C.c_int32), ("n_corr", C.c_uint64)]
 
 
+class CloudView(C.Structure):  # o3ds_cloud_view
+    _fields_ = [("pts", C.c_void_p), ("nrm", C.c_void_p), ("col", C.c_void_p), ("n", C.c_size_t), ("precision", C.c_int), ("device", C.c_int),
+                ("has_box", C.c_int), ("reserved", C.c_int), ("box_min", C.c_double * 3), ("box_max", C.c_double * 3), ("event", C.c_void_p)]
+
+
 class IcpParams(C.Structure):
     _fields_ = [("max_correspondence_distance", C.c_double), ("max_iteration", C.c_int32), ("method", C.c_int32),
                 ("relative_fitness", C.c_double), ("relative_rmse", C.c_double)]
@@ -115,6 +120,9 @@ SIGNATURES = {
     "o3ds_icp_update": (C.c_int, [_H, C.c_void_p, C.c_uint64]),
     "o3ds_icp_finish": (C.c_int, [_H, C.POINTER(IcpResult)]),
     "o3ds_icp_done": (C.c_int, [_H, C.POINTER(C.c_int)]),
+    "o3ds_cloud_export_view": (C.c_int, [_H, _CL, C.POINTER(CloudView)]),
+    "o3ds_cloud_import_view": (C.c_int, [_H, C.POINTER(CloudView), C.POINTER(_CL)]),
+    "o3ds_cloud_view_release": (C.c_int, [C.POINTER(CloudView)]),
     "o3ds_comm_unique_id": (C.c_int, [_H, C.c_char_p]),
     "o3ds_comm_init": (C.c_int, [_H, C.c_char_p, C.c_int, C.c_int]),
     "o3ds_comm_attach": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int]),
@@ -492,6 +500,20 @@ class Backend:
         out = IcpResult()
         self._ck(self.lib.o3ds_icp_pass_finish(self.h, n_src_total, C.c_void_p(sums_in_ptr), C.c_void_p(sums_scratch_ptr), C.byref(out)))
         return self._result(out)
+
+    def export_view(self, cid: int) -> "CloudView":
+        """o3ds_cloud_export_view: what another handle needs to copy this cloud without touching this handle"""
+        v = CloudView()
+        self._ck(self.lib.o3ds_cloud_export_view(self.h, cid, C.byref(v)))
+        return v
+
+    def import_view(self, view: "CloudView") -> int:
+        out = _CL()
+        self._ck(self.lib.o3ds_cloud_import_view(self.h, C.byref(view), C.byref(out)))
+        return out.value
+
+    def release_view(self, view: "CloudView"):
+        self.lib.o3ds_cloud_view_release(C.byref(view))
 
     def icp_register_dev(self, source: int, target: int, max_corr, init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6,
                          target_crop: Crop | None = None, method=ICP_POINT_TO_PLANE):

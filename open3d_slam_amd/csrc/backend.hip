@@ -3447,6 +3447,73 @@ int o3ds_cloud_copy_across(o3ds_handle dst, o3ds_handle src, o3ds_cloud src_clou
   return O3DS_OK;
 }
 
+int o3ds_cloud_export_view(o3ds_handle h, o3ds_cloud id, o3ds_cloud_view* out) {
+  CHECK_HANDLE(h);
+  if (!out) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_export_view: null view");
+  memset(out, 0, sizeof(*out));
+  CloudRec* c = find_cloud(h, id);  // (the exact size; a persistent map is folded: a view is of arrays)
+  if (!c) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_export_view: unknown cloud id");
+  HIP_TRY(hipSetDevice(h->device));
+  out->pts = c->pts, out->nrm = c->nrm, out->col = c->col;
+  out->n = c->n;
+  out->precision = c->n ? c->precision : h->precision;
+  out->device = h->device;
+  out->has_box = c->has_box ? (c->box_padded ? 2 : 1) : 0;
+  for (int a = 0; a < 3; ++a) out->box_min[a] = c->bmn[a], out->box_max[a] = c->bmx[a];
+  if (c->n) {  // behind everything this handle has queued for the cloud so far
+    hipEvent_t ev = nullptr;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    const hipError_t e = hipEventRecord(ev, h->stream);
+    if (e != hipSuccess) {
+      (void)hipEventDestroy(ev);
+      HIP_TRY(e);
+    }
+    out->event = ev;
+  }
+  return O3DS_OK;
+}
+
+int o3ds_cloud_view_release(o3ds_cloud_view* view) {
+  if (view && view->event) (void)hipEventDestroy((hipEvent_t)view->event);
+  if (view) memset(view, 0, sizeof(*view));
+  return O3DS_OK;
+}
+
+int o3ds_cloud_import_view(o3ds_handle h, const o3ds_cloud_view* v, o3ds_cloud* out) {
+  CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
+  if (!v || !out) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_import_view: null argument");
+  if (v->device != h->device) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_import_view: the view's cloud lives on another device");
+  if (v->n && v->precision != h->precision) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_import_view: the view's cloud is stored in another precision");
+  if (v->n && (!v->pts || !v->event)) return fail(h, O3DS_ERR_INVALID_ARG, "cloud_import_view: a released or incomplete view");
+  HIP_TRY(hipSetDevice(h->device));
+  CloudRec o;
+  CloudGuard o_guard(h, o);
+  o.precision = h->precision;
+  o.n = v->n;
+  o.has_box = v->has_box != 0;
+  o.box_padded = v->has_box == 2;
+  for (int a = 0; a < 3; ++a) o.bmn[a] = v->box_min[a], o.bmx[a] = v->box_max[a];
+  if (v->n) {
+    HIP_TRY(hipStreamWaitEvent(h->stream, (hipEvent_t)v->event, 0));  // what the owner queued for the cloud before it exported the view
+    const size_t bytes = p4_size(h->precision) * v->n;
+    HIP_TRY(dev_alloc(h, (void**)&o.pts, bytes));
+    HIP_TRY(hipMemcpyAsync(o.pts, v->pts, bytes, hipMemcpyDeviceToDevice, h->stream));
+    if (v->nrm) {
+      HIP_TRY(dev_alloc(h, (void**)&o.nrm, bytes));
+      HIP_TRY(hipMemcpyAsync(o.nrm, v->nrm, bytes, hipMemcpyDeviceToDevice, h->stream));
+    }
+    if (v->col) {
+      HIP_TRY(dev_alloc(h, (void**)&o.col, bytes));
+      HIP_TRY(hipMemcpyAsync(o.col, v->col, bytes, hipMemcpyDeviceToDevice, h->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));  // the owner may free its cloud as soon as this returns
+  }
+  o_guard.release();
+  *out = add_cloud(h, std::move(o));
+  return O3DS_OK;
+}
+
 }  // extern "C" (a helper with default arguments follows)
 namespace {
 // voxelizeWithinCroppingVolume of a device cloud in place; merge_np >= 0: the cloud is [pass block | voxel block in key order | new points]

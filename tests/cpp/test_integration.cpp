@@ -223,7 +223,18 @@ int main(int argc, char** argv) {
       o3ds::setScanStamp(42);  // another scan
       CHECK(o3ds::preprocessScan(moved, other).get() != coarser.get());
       o3ds::setScanStamp(41);
-      std::shared_ptr<PointCloud> recomputed = o3ds::preprocessScan(rawCopy, chain);  // the memo holds one entry: computed again, same values
+      // the memo holds the last few scans: scan 41 is still there after scan 42 (the mapper is a scan or two behind the odometry) ...
+      std::shared_ptr<PointCloud> again = o3ds::preprocessScan(rawCopy, chain);
+      CHECK(again.get() == pre.get());
+      // ... and gone after a handful of others: computed again, same values
+      for (int k = 0; k < 9; ++k) {
+        o3ds::setScanStamp(100 + k);
+        PointCloud shifted = raw;
+        for (auto& q : shifted.points_) q[1] += 0.01 * (k + 1);
+        CHECK(o3ds::preprocessScan(shifted, chain) != nullptr);
+      }
+      o3ds::setScanStamp(41);
+      std::shared_ptr<PointCloud> recomputed = o3ds::preprocessScan(rawCopy, chain);
       CHECK(recomputed.get() != pre.get() && recomputed->points_.size() == pre->points_.size());
       for (size_t i = 0; i < pre->points_.size(); ++i)
         for (int a = 0; a < 3; ++a) CHECK(recomputed->points_[i][a] == pre->points_[i][a] && recomputed->normals_[i][a] == pre->normals_[i][a]);

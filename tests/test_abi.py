@@ -162,9 +162,9 @@ def test_the_shipped_library_reads_no_ab_switch_from_the_environment():
         return set(m.decode() for m in re.findall(rb"O3DS_[A-Z][A-Z0-9_]+", open(path, "rb").read()))
 
     shipped, ab = names(build.LIB), names(build.LIB_AB)
-    # (O3DS_ICP_PASS_MAX_QUERIES: an error text quoting the header's constant; O3DS_RCCL_LIB: WHICH librccl.so file a multi-GPU process
+    # (O3DS_ICP_PASS_MAX_QUERIES, O3DS_ICP_SUMS_DOUBLES: error texts quoting the header's constants; O3DS_RCCL_LIB: WHICH librccl.so file a multi-GPU process
     # loads -- a deployment choice like the two memory sizes, no effect on results or code paths)
-    allowed = {"O3DS_POOL_CAP_MB", "O3DS_ARENA_MB", "O3DS_ICP_PASS_MAX_QUERIES", "O3DS_RCCL_LIB"}
+    allowed = {"O3DS_POOL_CAP_MB", "O3DS_ARENA_MB", "O3DS_ICP_PASS_MAX_QUERIES", "O3DS_ICP_SUMS_DOUBLES", "O3DS_RCCL_LIB"}
     assert shipped <= allowed, shipped - allowed
     assert {"O3DS_ICP_MODE", "O3DS_ICP_SETS", "O3DS_SUM_NO_SPLIT", "O3DS_VOXEL_SORT", "O3DS_CARVE_SORT", "O3DS_MERGE_LIBRARY_SORT"} <= ab
     assert b"A/B switches" in backend.load(ab=True).o3ds_version() and b"A/B switches" not in backend.load().o3ds_version()

@@ -1407,3 +1407,53 @@ def test_a_persistent_map_keeps_its_record_when_every_record_is_wanted():
     p1, n1, sizes = run(True)
     assert p0 == p1 and n0 == n1
     assert len(sizes) == 70 and all(0 < x < 5000 for x in sizes) and sizes[0] >= sizes[-1]
+
+
+def test_a_view_carries_a_cloud_to_another_handle_while_its_owner_is_busy(scan):
+    """o3ds_cloud_export_view / o3ds_cloud_import_view: the copy a second worker's handle makes of a pre-processed scan needs nothing of the
+    owner's handle -- it is made here from another THREAD while the owner's thread is inside a registration on the owner's handle (what
+    open3d_slam's mapping worker does while the odometry worker registers, SlamWrapper.cpp:227-236).  Points, normals and the box arrive
+    bit for bit; the copy is an ordinary cloud of its handle; an empty cloud; a released view is a view of nothing."""
+    import threading
+
+    from open3d_slam_amd import backend
+
+    owner, other = backend.Backend(0), backend.Backend(0)
+    try:
+        raw = owner.upload(scan)
+        pre = owner.crop_voxel_down_sample(raw, backend.make_crop(backend.CROP_MIN_MAX_RADIUS, rmin=2.0, rmax=30.0), 0.1)
+        owner.estimate_normals(pre, 3.0, 20)
+        view = owner.export_view(pre)
+        want_p, want_n = owner.download(pre)
+        assert view.n == len(want_p) and view.event
+        got = {}
+
+        def importer():  # the other worker: its own handle, its own thread
+            for k in range(8):
+                cid = other.import_view(view)
+                got[k] = other.download(cid)
+                other.free(cid)
+
+        t = threading.Thread(target=importer)
+        t.start()
+        for _ in range(6):  # the owner is busy on its handle meanwhile
+            owner.icp_point_to_plane_dev(pre, pre, 1.0, max_iter=5, rel_fitness=0.0, rel_rmse=0.0)
+        t.join()
+        assert len(got) == 8
+        for p, n in got.values():
+            np.testing.assert_array_equal(p, want_p)
+            np.testing.assert_array_equal(n, want_n)
+        # the copy is a cloud like any other on its handle: it registers against itself at identity
+        cid = other.import_view(view)
+        r = other.icp_point_to_plane_dev(cid, cid, 1.0, max_iter=2)
+        assert r["fitness"] == 1.0 and np.allclose(r["transformation"], np.eye(4), atol=1e-12)
+        other.release_view(view)  # (a released view is a view of nothing)
+        assert view.n == 0 and not view.event and other.size(other.import_view(view))[0] == 0
+        empty = owner.upload(np.zeros((0, 3)))
+        v0 = owner.export_view(empty)
+        e2 = other.import_view(v0)
+        assert other.size(e2)[0] == 0
+        owner.release_view(v0)
+    finally:
+        owner.close()
+        other.close()
