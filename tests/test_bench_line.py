@@ -55,3 +55,22 @@ def test_line_survives_nan_numpy_scalars_and_oversize():
     # a config string of absurd length is cut, never printed whole
     out["config"]["workload"] = "w" * 20000
     assert len(bench.compact_line(out)) < bench.LINE_LIMIT
+
+
+def test_nothing_but_the_line_reaches_stdout():
+    """Libraries write to stdout on their own (RCCL's version banner comes out of C stdio at process exit, behind the line): bench.py sets
+    file descriptor 1 aside, points it at stderr for the run and writes the one line to the real stdout."""
+    code = (
+        "import sys, json, ctypes; sys.path.insert(0, %r); import bench\n"
+        "bench.claim_stdout()\n"
+        "print('a library banner through Python')\n"
+        "libc = ctypes.CDLL(None); libc.puts(b'a library banner through C stdio (buffered until exit)')\n"
+        "bench.emit(json.load(open(%r)))\n"
+        "libc.puts(b'and one more at exit')\n" % (ROOT, DETAIL))
+    env = dict(os.environ, O3DS_BENCH_DETAIL=os.devnull)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode == 0, p.stderr
+    lines = p.stdout.splitlines()
+    assert len(lines) == 1, p.stdout
+    assert _strict(lines[0])["metric"] == "icp_iterations_per_sec"
+    assert "banner" in p.stderr
