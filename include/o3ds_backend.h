@@ -175,6 +175,12 @@ int o3ds_cloud_set_colors_from_records(o3ds_handle h, o3ds_cloud c, const void* 
  * colour of its LAST point in cloud order (AccumulatedPoint::AddPoint assigns, helpers.cpp:40-42,61-63; isValidColor,
  * helpers.cpp:83-85, holds for every value).  rgb == NULL clears.  get_colors returns O3DS_ERR_EMPTY for an uncoloured cloud. */
 int o3ds_cloud_set_colors(o3ds_handle h, o3ds_cloud c, const double* rgb);
+/* PointCloud::covariances_ is NOT carried: a device cloud has points, normals and colours.  The reference's own flow never holds any --
+ * the one call that would fill them, EstimateCovariances, is commented out (CloudRegistration.cpp:29), generalized ICP builds its
+ * covariances from the normals inside the registration (Open3D does the same when a cloud has none), and nothing else writes the field --
+ * so the copies croppers.cpp:86-101 and helpers.cpp:48-50,64-67,297-302 make of it move empty vectors.  A caller that fills
+ * covariances_ itself keeps them on its host PointCloud; they do not cross the seams (integration/o3ds_open3d_slam.hpp clears the field
+ * of every cloud it hands back, as an Open3D call that recomputes a cloud would). */
 int o3ds_cloud_has_colors(o3ds_handle h, o3ds_cloud c, int* has_colors);
 int o3ds_cloud_get_colors(o3ds_handle h, o3ds_cloud c, double* rgb, size_t capacity);
 /* Build the nearest-neighbour index of a cloud (replaces [O3D] KDTreeFlann::SetGeometry(target), which

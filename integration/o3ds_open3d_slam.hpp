@@ -463,20 +463,26 @@ inline bool sharePreprocess() {
   return on;
 }
 
-// [O3D] RandomDownSample(ratio) of a device cloud of n points: shuffled indices, the first int(ratio * n) kept (SelectByIndex)
+// [O3D] RandomDownSample(ratio) of a device cloud of n points: shuffled indices, the first int(ratio * n) kept (SelectByIndex).
+// [O3D] SelectByIndex marks the listed indices in a mask and walks the cloud once, so the kept points come out in CLOUD order (v0.15.1
+// PointCloud.cpp; restated, unpinned); O3DS_SELECT_SHUFFLED=1 keeps them in the order of the shuffled list instead (SURVEY A.7's reading).
+inline bool selectByIndexKeepsCloudOrder() {
+  static const bool on = !(std::getenv("O3DS_SELECT_SHUFFLED") && std::atoi(std::getenv("O3DS_SELECT_SHUFFLED")) != 0);
+  return on;
+}
 inline o3ds_cloud drawOnDevice(o3ds_handle h, o3ds_cloud cloud, size_t n, double ratio) {
   std::vector<uint32_t> idx(n);
   std::iota(idx.begin(), idx.end(), 0u);
   std::shuffle(idx.begin(), idx.end(), downSampleGenerator());
   idx.resize((size_t)(int)(ratio * (double)n));
+  if (selectByIndexKeepsCloudOrder()) std::sort(idx.begin(), idx.end());
   o3ds_cloud kept = 0;
   check(h, o3ds_select_by_index(h, cloud, idx.data(), idx.size(), &kept));
   return kept;
 }
 
 // One upload of the raw scan, the chain on the device, one download; the result stays on the device behind the returned cloud.
-// With ratio >= 1 Open3D's RandomDownSample returns a permutation of the cloud; here the cloud keeps its order (same points, only
-// summation orders downstream differ), which saves a 60 k-element host shuffle per scan.
+// With ratio >= 1 every index is kept and [O3D] SelectByIndex walks the cloud in its own order: the cloud itself (no shuffle needed).
 inline std::shared_ptr<PointCloud> preprocessScan(const PointCloud& raw, const ScanChain& p) {
   if (p.estimateNormals) {
     if (!(p.normalRadius > 0.0)) throw std::runtime_error("maxRadiusNormalEstimation_");  // assert_gt, CloudRegistration.cpp:50-51

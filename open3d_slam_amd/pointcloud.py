@@ -115,13 +115,20 @@ class PointCloud:
             pass
 
 
+# [O3D] PointCloud::SelectByIndex(indices) marks the listed indices in a mask and walks the cloud once: the selection comes out in CLOUD
+# order whatever the order of the list (PointCloud.cpp of v0.15.1, restated from the upstream source -- unpinned like every Open3D row).
+# SURVEY A.7 reads it as "output in shuffled order"; the two readings differ only in the order of the kept points (summation orders
+# downstream), and both are kept selectable: False = the selection in the order of the shuffled list.
+SELECT_BY_INDEX_KEEPS_CLOUD_ORDER = os.environ.get("O3DS_SELECT_SHUFFLED", "0") == "0"
+
+
 def random_down_sample(cloud: "PointCloud", ratio: float, rng=None, shuffle_at_full_ratio: bool = False) -> "PointCloud":
     """[O3D] PointCloud::RandomDownSample as open3d_slam calls it (Odometry.cpp:29, ScanToMapRegistration.cpp:39): shuffle the
-    indices 0..n-1, keep the first int(ratio * n), SelectByIndex (output in shuffled order).  Open3D seeds a fresh mt19937 from
-    std::random_device per call, so the reference is not reproducible here; `rng` (a numpy Generator) pins the list.
-    With ratio >= 1 Open3D still returns a PERMUTATION of the cloud; that only changes summation orders downstream, so the default
-    leaves the cloud alone and `shuffle_at_full_ratio` reproduces the permutation when a test wants it.  Consumes `cloud`."""
-    if ratio >= 1.0 and not shuffle_at_full_ratio:
+    indices 0..n-1, keep the first int(ratio * n), SelectByIndex (SELECT_BY_INDEX_KEEPS_CLOUD_ORDER: the kept points in cloud order, or in
+    the order of the shuffled list).  Open3D seeds a fresh mt19937 from std::random_device per call, so the reference is not reproducible
+    here; `rng` (a numpy Generator) pins the list.  With ratio >= 1 every point is kept -- in cloud order the cloud itself; under the
+    other reading a PERMUTATION of it, which `shuffle_at_full_ratio` reproduces when a test wants it.  Consumes `cloud`."""
+    if ratio >= 1.0 and (SELECT_BY_INDEX_KEEPS_CLOUD_ORDER or not shuffle_at_full_ratio):
         return cloud  # (before the size is asked for: it may still be in flight on the device, o3ds_cloud_size)
     n = len(cloud)
     if n == 0:
@@ -129,6 +136,8 @@ def random_down_sample(cloud: "PointCloud", ratio: float, rng=None, shuffle_at_f
     if rng is None:
         rng = np.random.default_rng()
     keep = rng.permutation(n)[: int(min(ratio, 1.0) * n)]
+    if SELECT_BY_INDEX_KEEPS_CLOUD_ORDER:
+        keep = np.sort(keep)
     out = PointCloud(cloud.be, cloud.be.select_by_index(cloud.id, keep))
     cloud.release()
     return out

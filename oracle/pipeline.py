@@ -29,15 +29,22 @@ class OracleLoop:
     def set_down_sample_seeds(self, odo_seed, map_seed, shuffle_at_full_ratio=False):
         """[O3D] RandomDownSample (Odometry.cpp:29, ScanToMapRegistration.cpp:39) shuffles with a generator seeded from
         std::random_device; the test hands both sides the same numpy generators, advanced once per scan, so both keep the same
-        index list: permutation(n)[: int(ratio * n)], output in shuffled order."""
+        index list: permutation(n)[: int(ratio * n)] (see select_by_index_keeps_cloud_order for the order of the kept points)."""
         self.rng_odo = np.random.default_rng(odo_seed)
         self.rng_map = np.random.default_rng(map_seed)
         self.shuffle_at_full_ratio = shuffle_at_full_ratio
 
+    # [O3D] SelectByIndex walks the cloud through a mask of the listed indices: the kept points come out in CLOUD order (v0.15.1
+    # PointCloud.cpp, restated; unpinned).  False: in the order of the shuffled list (SURVEY A.7's reading).  The device loop has the same switch.
+    select_by_index_keeps_cloud_order = True
+
     def _down(self, v, n, ratio, rng):
-        if len(v) == 0 or (ratio >= 1.0 and not self.shuffle_at_full_ratio):
+        cloud_order = self.select_by_index_keeps_cloud_order
+        if len(v) == 0 or (ratio >= 1.0 and (cloud_order or not self.shuffle_at_full_ratio)):
             return v, n
         keep = (rng or np.random.default_rng()).permutation(len(v))[: int(min(ratio, 1.0) * len(v))]
+        if cloud_order:
+            keep = np.sort(keep)
         return v[keep], n[keep]
 
     def _pre(self, raw, crop_p, voxel, icp):

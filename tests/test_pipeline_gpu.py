@@ -117,12 +117,18 @@ def test_full_length_stream_200_frames_matches_oracle(backend_f64, backend_f32, 
     assert worst[0][0] <= 1e-6
 
 
-@pytest.mark.parametrize("ratio,shuffle", [(0.5, False), (1.0, True)])
-def test_stream_with_random_down_sample_matches_oracle(backend_f64, oracle, ratio, shuffle):
+@pytest.mark.parametrize("ratio,shuffle,cloud_order", [(0.5, False, True), (0.5, False, False), (1.0, True, False)])
+def test_stream_with_random_down_sample_matches_oracle(backend_f64, oracle, ratio, shuffle, cloud_order, monkeypatch):
     """downSamplingRatio_ < 1 (Odometry.cpp:29, ScanToMapRegistration.cpp:39 -> [O3D] RandomDownSample) inside the loop: both sides keep
-    the same explicit index lists (a shuffled prefix, output in shuffled order), so o3ds_select_by_index, the narrow crop of a
-    down-sampled cloud and the insertion of a shuffled merge_ cloud are on the path.  ratio 1.0 with the shuffle is what the
-    reference does at its default ratio: a permutation of every scan.  f64 storage, 12 frames of 65 536 points, 1e-6."""
+    the same explicit index lists, so o3ds_select_by_index, the narrow crop of a down-sampled cloud and the insertion of the merge_
+    cloud are on the path.  BOTH readings of [O3D] SelectByIndex: the kept points in cloud order (the mask walk of v0.15.1, the default)
+    and in the order of the shuffled list; under the latter ratio 1.0 is a permutation of every scan.  f64 storage, 12
+    frames of 65 536 points, 1e-6."""
+    from oracle.pipeline import OracleLoop
+    from open3d_slam_amd import pointcloud
+
+    monkeypatch.setattr(pointcloud, "SELECT_BY_INDEX_KEEPS_CLOUD_ORDER", cloud_order)
+    monkeypatch.setattr(OracleLoop, "select_by_index_keeps_cloud_order", cloud_order)
     _run_loops([(backend_f64, 1e-6, 1e-6, 1e-6, 0.0)], oracle, 12, 512, ratio=ratio, seeds=(71, 72), shuffle_at_full_ratio=shuffle)
 
 
