@@ -2087,6 +2087,7 @@ int o3ds_icp_pass(o3ds_handle h, size_t first, size_t count, size_t n_src_total,
   fa.init = *h->h_state;  // written by begin_session
   const int j = h->session_launches++;
   fa.first = j == 0;
+  fa.pass_index = j;
   fa.state_in = h->session_state ? h->session_state : h->d_state;
   fa.state_out = (IcpStateDev*)(h->d_fused + (size_t)(j & 1) * kFusedStateStride);
   fa.state_host = nullptr;
@@ -2369,6 +2370,7 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
       for (int k = 0; k < chunk; ++k, ++j) {
         const int par = j & 1;
         fa.first = j == 0;
+        fa.pass_index = j;
         fa.state_in = last;
         fa.state_out = (IcpStateDev*)(h->d_fused + par * kFusedStateStride);
         // slot buffers rotate with a launch counter that runs across registrations: launch g reads (g-1)%3, adds into g%3, clears (g+1)%3

@@ -190,8 +190,7 @@ struct IcpStateDev {
   int iterations;  // updates applied
   int done;
   int converged;
-  int far_prev;  // queries of the last evaluated pass that went to stage 3 (record term 30): a pass that follows one with many of them
-                 // deals its queries out spread over the scan, as pass 0 does (icp_kernels.hpp query_index, spread_rule)
+  int error;  // 1: a workgroup of the persistent loop kernel timed out at the grid rendezvous (never expected)
   int pad;  // the pivot order of the last 6x6 solve (icp_kernels.hpp solve6_wave_ordered): bit 31 valid, 3 bits per position
 };
 

@@ -794,8 +794,8 @@ __device__ __forceinline__ void gicp_record(double px, double py, double pz, dou
 // scan ring share cells and cache lines).  Pass 0 of a registration has no bound, so queries whose neighbour is far are
 // expensive and they cluster (the misalignment grows with range: measured mean 21 us per workgroup, slowest 85 us); it
 // takes queries count/16 apart, which spreads every region of the scan over all wavefronts.
-// order: 0 = consecutive, 1 = single queries spread over the scan (pass 0), 2 = every wavefront ONE run of kQPW consecutive queries, the runs
-// scattered over the scan (a later pass that follows a far-heavy one, spread_rule)
+// order: 0 = scan order, 1 = single queries spread over the scan, 2 = every wavefront ONE run of kQPW consecutive queries, the runs scattered
+// over the scan (pass_order below)
 template <int kQPB, int kQPW /* queries per wavefront */>
 __device__ __forceinline__ size_t query_index(size_t count, size_t b, int ql, int order) {
   if (order == 0) return b * kQPB + (size_t)ql;
@@ -803,10 +803,6 @@ __device__ __forceinline__ size_t query_index(size_t count, size_t b, int ql, in
   const size_t off = b * (kQPB / kQPW) + (size_t)(ql / kQPW);  // this wavefront's number among all wavefronts of the pass
   const int qw = ql % kQPW;
   if (order == 2) {
-    // Later passes have a cached match per query and profit from neighbours sharing cells and cache lines; what hurts them is a REGION of
-    // the scan whose queries all go to stage 3 (a wavefront serves its far queries one after the other, a workgroup of 64 of them is
-    // sixteen rounds of stage 3 while the chip idles).  Runs of one wavefront keep the sharing inside the wavefront and hand the four
-    // wavefronts of a workgroup four different places of the scan: the workgroup's far pool then holds a quarter of such a region.
     const size_t n_run = (count + kQPW - 1) / kQPW;
     const size_t run = n_run % kMul ? (size_t)(((unsigned long long)off * kMul) % n_run) : off;
     const size_t i = run * kQPW + (size_t)qw;
@@ -827,14 +823,21 @@ __device__ __forceinline__ size_t query_index(size_t count, size_t b, int ql, in
   return off < n_off && run < n_run && i < count ? i : count;
 }
 
-// Which passes spread.  Pass 0 has no bound: its far queries are expensive and cluster.  So does any pass that follows an update which
-// left many queries more than two cells from their neighbour -- pass 1 of a generalized-ICP registration of configs[1] has 3 550 of them
-// (the plane-to-plane update after the misaligned pass 0), in scan order they fill a few dozen workgroups whose wavefronts then run
-// sixteen far searches one after the other, and the launch lasts 97 us with a mean workgroup at a third of that.  The far count of the
-// previous pass is what predicts it, and every workgroup knows it: it travels as term 30 of the record (an exact integer sum).
-__host__ __device__ __forceinline__ int spread_rule(bool first_pass, double far_prev, unsigned long long n_src_total) {
-  return first_pass ? 1 : (far_prev * 256.0 > (double)n_src_total ? 2 : 0);
-}
+// How pass number `pass` of a registration deals its queries out.  Any order gives the same matches; what it changes is time.
+//   pass 0   has no bound: its far queries are expensive and cluster (the misalignment grows with range), so single queries are spread over
+//            all wavefronts;
+//   pass 1   follows the first, largest update.  It has a cached match per query and profits from neighbours sharing cells and cache lines
+//            -- and after an update that did not land (generalized ICP on configs[1]: 3 550 queries are still more than two cells from their
+//            neighbour) those queries are ONE region of the scan: in scan order they fill a few dozen workgroups of 64, each sixteen rounds
+//            of stage 3, while the chip idles (97 us for a pass of 2 395 VALU instructions per wavefront, against 64 us for pass 0's 4 366:
+//            profiles/r06_pmc_gicp_per_pass.txt).  Runs of one wavefront keep the sharing inside the wavefront and give the four
+//            wavefronts of a workgroup four places of the scan: the workgroup's far pool holds a quarter of such a region (68 us), and a
+//            pass 1 without far queries -- point-to-plane's -- costs what it did (22.6 us);
+//   later    scan order.
+// A function of the pass number alone, so every form of the loop and every rank deals alike, and a workgroup knows its queries before it
+// has read anything: the fetch of their points goes out first (a rule on the previous pass's far count, carried as a record term, gave
+// the same 68 us and cost every pass the wait for that term: -1 % on configs[1]).
+__host__ __device__ __forceinline__ int pass_order(int pass) { return pass == 0 ? 1 : (pass == 1 ? 2 : 0); }
 
 // What a query's search needs that does NOT depend on the pose: its source point, the position of its match in the previous
 // pass and that matched target point.  The fused kernel issues these loads for the workgroup's first batch BEFORE it waits
@@ -854,7 +857,7 @@ struct alignas(4 * sizeof(typename Scalar<P4>::type)) SetRef {
 };
 
 template <typename P4, int kPassBlock, int kGroup>
-__device__ __forceinline__ QueryPrefetch<P4> prefetch_query(const IcpPassArgs& a, size_t batch, bool use_cache, bool use_sets, int spread) {
+__device__ __forceinline__ QueryPrefetch<P4> prefetch_query(const IcpPassArgs& a, size_t batch, bool use_cache, bool use_sets, int order) {
   constexpr int kQPB = kPassBlock / kGroup;
   using R = typename Scalar<P4>::type;
   QueryPrefetch<P4> q;
@@ -864,7 +867,7 @@ __device__ __forceinline__ QueryPrefetch<P4> prefetch_query(const IcpPassArgs& a
   q.tprev = P4{};
   q.rx = q.ry = q.rz = q.rL = (R)0;
   const bool sets = use_cache && use_sets && a.set_pos != nullptr;  // (use_sets: the fused kernel only, see icp_pass_body)
-  const size_t i = query_index<kQPB, 64 / kGroup>(a.count, batch, threadIdx.x / kGroup, spread);
+  const size_t i = query_index<kQPB, 64 / kGroup>(a.count, batch, threadIdx.x / kGroup, order);
   if (a.count == 0) return q;
   // Straight-line loads, no branch per lane and none per mode (a lane past the end reads the last query and drops it; a mode that has no
   // use for a load reads a harmless address): a load inside a conditional block is followed by the moves that merge it with the other
@@ -967,7 +970,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
                                                 unsigned long long* tr = nullptr /* 3 timestamps, development aid */,
                                                 SetMargin sm = SetMargin{-1.0f, 0.0f}, int* s_set = nullptr /* [kQPB][1 + kSetCap] */,
                                                 size_t n_live = ~(size_t)0 /* queries at or beyond it are dropped (IcpPassArgs::count_dev) */,
-                                                int spread = 0 /* how the queries are dealt out (query_index, spread_rule) */) {
+                                                int order = 0 /* how the queries are dealt out (pass_order) */) {
   constexpr int kQPB = kPassBlock / kGroup;
   n_live = min(n_live, a.count);
   constexpr int kStride = kGicp ? kRec : kRecSlots;  // doubles per query record
@@ -994,7 +997,6 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
   const R rmax = (R)sqrt(a.r2max);
   int* my_set = sets ? s_set + ql * (1 + kSetCap) : nullptr;
   double acc = 0.0;
-  int far_total = 0;  // queries of this workgroup that went to stage 3: term 30 of the record
   const size_t n_batches = (a.count + kQPB - 1) / kQPB;
   static_assert(sizeof(FarItem<P4>) <= kStride * sizeof(double), "a parked far query fits its record slot");
   static_assert((2 + kQPB) * sizeof(int) <= (kPassBlock / 32) * kRec * sizeof(double), "the far list fits s_red");
@@ -1002,7 +1004,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
   if (threadIdx.x == 0) s_far[0] = s_far[1] = 0;
   lds_barrier();
   for (size_t b = (size_t)wg; b < n_batches; b += kSingle ? n_batches : (size_t)nwg) {
-    const size_t i = query_index<kQPB, 64 / kGroup>(a.count, b, ql, spread);
+    const size_t i = query_index<kQPB, 64 / kGroup>(a.count, b, ql, order);
     double px = 0, py = 0, pz = 0;
     NNBest<P4> nn;
     nn.pos = -1;
@@ -1012,7 +1014,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
     bool verified = false;   // the match was proven inside the prefetched candidate set: the winner's lane holds point and normal
     int kdone = 0;           // block radius (cells) the search of this query covered; 0 = no search ran
     R m = (R)0;  // candidate-set margin of this query's search (0: the search leaves no set)
-    const QueryPrefetch<P4> qp = (kSingle || b == (size_t)wg) ? first_batch : prefetch_query<P4, kPassBlock, kGroup>(a, b, use_cache, sets, spread);
+    const QueryPrefetch<P4> qp = (kSingle || b == (size_t)wg) ? first_batch : prefetch_query<P4, kPassBlock, kGroup>(a, b, use_cache, sets, order);
     if (sets && gl == 0) my_set[0] = 0;  // (same wavefront as its readers and writers below; the far stage is behind a barrier)
     if (i < n_live) {  // uniform across the lanes of a group
       const P4 s = qp.s;
@@ -1114,7 +1116,6 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
       }
       lds_barrier();
       const int n_far = __builtin_amdgcn_readfirstlane(s_far[0]);
-      far_total += n_far;
       if (n_far > 0) {  // workgroup-uniform
         const int lane = threadIdx.x & 63;
         int2* list = s_seg + (threadIdx.x >> 6) * (64 / kGroup) * kSegMax;
@@ -1220,7 +1221,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
   if (threadIdx.x < kRec) {
 #pragma unroll
     for (int k = 0; k < kPassBlock / 32; ++k) v += s_red[k][threadIdx.x];
-    if (threadIdx.x >= 30) v = threadIdx.x == 30 ? (double)far_total : 0.0;
+    if (threadIdx.x >= 30) v = 0.0;
   }
   lds_barrier();  // s_red may be reused by the caller
   return v;         // valid in threads 0..31
@@ -1241,11 +1242,11 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
     return;
   }
   const bool use_cache = a.state->pass > 0;
-  const int spread = !use_cache ? 1 : a.state->far_prev;  // (spread_rule, decided by the update that preceded this pass)
-  const QueryPrefetch<P4> qp = prefetch_query<P4, kPassBlock, kGroup>(a, blockIdx.x, use_cache, false, spread);
+  const int order = pass_order(a.state->pass);
+  const QueryPrefetch<P4> qp = prefetch_query<P4, kPassBlock, kGroup>(a, blockIdx.x, use_cache, false, order);
   const size_t n_live = a.count_dev ? (size_t)*a.count_dev : a.count;
   const double v = icp_pass_body<P4, kCrop, kPassBlock, kGroup, kGicp, kKeys>(a, a.state->T, blockIdx.x, gridDim.x, s_rec, s_red, s_seg, use_cache, qp, nullptr,
-                                                                                SetMargin{-1.0f, 0.0f}, nullptr, n_live, spread);
+                                                                                SetMargin{-1.0f, 0.0f}, nullptr, n_live, order);
   if (threadIdx.x < kRec) a.partials[(size_t)blockIdx.x * kRec + threadIdx.x] = v;
 }
 
@@ -1779,7 +1780,6 @@ __device__ __forceinline__ void icp_step_block(const double* s_rec, IcpStateDev*
       st->rmse = rmse;
       st->n_corr = (unsigned long long)(count + 0.5);
       st->pass = pass + 1;
-      st->far_prev = spread_rule(false, s_rec[30], n_src_total);  // how the NEXT pass deals its queries out (the two-launch forms read it here)
       if (conv) st->converged = 1;
       if (!go) st->done = 1;
       *s_go = go;
@@ -1870,6 +1870,7 @@ struct IcpFusedArgs {
   int max_iter;
   double rel_fitness, rel_rmse;
   int first;                      // 1: launch 0 -- there is no previous pass to fold
+  int pass_index;                 // which pass of the registration this launch evaluates (= its number in the launch sequence): pass_order
   unsigned long long* trace;      // null, or [gridDim.x][16] phase timestamps (100 MHz wall clock) of thread 0 (O3DS_FUSED_TRACE)
   unsigned long long* seq_host;   // with state_host: a pinned word that receives `seq` AFTER the state (system-scope release), so that the
   unsigned long long seq;         // host can pick the state up the moment it is written instead of after the kernel's completion signal
@@ -1954,13 +1955,9 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   const double q_hi_mine = threadIdx.x < kRec ? fa.pass.q_hi[threadIdx.x] : 0.0;
   __builtin_amdgcn_sched_barrier(0);
   // pose-independent loads of this workgroup's queries: source point, cached match or candidate set (points AND normals); they land
-  // while the tail of the previous pass is computed.  WHICH queries are this workgroup's depends on how the pass deals them out
-  // (spread_rule): pass 0 spreads by definition and fetches here; a later pass first needs the far count the previous pass left in
-  // the record (below, behind the fold: the record's loads went out first, and the fetch still has the whole solve to land in.
-  // Fetching here for scan order and again below when the rule says otherwise measured 2 % slower on every registration)
-  int spread = 1;
-  QueryPrefetch<P4> qp;
-  if (first) qp = prefetch_query<P4, kPassBlock, kGroup>(fa.pass, blockIdx.x, false, true, 1);
+  // while the tail of the previous pass is computed
+  const int order = pass_order(first ? 0 : max(fa.pass_index, 1));
+  const QueryPrefetch<P4> qp = prefetch_query<P4, kPassBlock, kGroup>(fa.pass, blockIdx.x, use_cache, true, order);
   if (blockIdx.x == 0) {  // the buffer of the NEXT pass was last read two launches ago
     static_assert(kFusedSlots * kSlotDoubles == 2 * kPassBlock, "two slot values per thread");
     fa.slots_clear[threadIdx.x] = 0.0;
@@ -1992,9 +1989,6 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   }
   O3DS_STAMP(1);
   if (!first) {
-    spread = spread_rule(false, s_out[30], n_src_total);
-    qp = prefetch_query<P4, kPassBlock, kGroup>(fa.pass, blockIdx.x, true, true, spread);
-    __builtin_amdgcn_sched_barrier(0);
     icp_step_block(s_out, &s_st, n_src_total, fa.max_iter, fa.rel_fitness, fa.rel_rmse, s_x, s_sc, s_U, s_T, &s_go,
                    fa.trace ? fa.trace + (size_t)blockIdx.x * 16 + 8 : nullptr, fa.pass.method, s_margin);
     lds_barrier();
@@ -2017,9 +2011,9 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   const bool collect = fa.pass.set_pos != nullptr && sm.w >= 0.0f && fa.pass.set_gain * sm.t <= fa.pass.set_cap;
   unsigned long long* const trb = fa.trace ? fa.trace + (size_t)blockIdx.x * 16 + 13 : nullptr;
   const double v = collect ? icp_pass_body<P4, kCrop, kPassBlock, kGroup, kGicp, false, true, true>(fa.pass, s_st.T, blockIdx.x, gridDim.x, s_rec, s_red, s_seg,
-                                                                                              use_cache, qp, trb, sm, s_set, n_live, spread)
+                                                                                              use_cache, qp, trb, sm, s_set, n_live, order)
                            : icp_pass_body<P4, kCrop, kPassBlock, kGroup, kGicp, false, false, true>(fa.pass, s_st.T, blockIdx.x, gridDim.x, s_rec, s_red, s_seg,
-                                                                                               use_cache, qp, trb, sm, s_set, n_live, spread);
+                                                                                               use_cache, qp, trb, sm, s_set, n_live, order);
   O3DS_STAMP(3);
   // ---------------- epilogue: add the record to this workgroup's slot, exactly ----------------
   if (threadIdx.x < kRec) {
