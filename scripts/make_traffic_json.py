@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""profiles/r05_pmc_traffic.json (or the path given as argument) from the per-dispatch counter rows of scripts/gpu_pmc_traffic.sh (gpurun_out/pmc_traffic/m1_{dram,wr}):
+"""profiles/r06_pmc_traffic.json (or the path given as argument) from the per-dispatch counter rows of scripts/gpu_pmc_traffic.sh (gpurun_out/pmc_traffic/m1_{dram,wr}):
 what bench.py quotes as roofline.traffic.  The calibration behind the byte-per-request figures is profiles/r03_pmc_calibration*.txt."""
 import collections, csv, glob, hashlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -42,8 +42,14 @@ def kernel_key(name):
     return name.split("(")[0][:60]
 
 
-for name, pat, sl in (("icp_fused_kernel<P4f> configs[1] (1 M-point map)", "icp_fused_kernel<o3ds::P4f", slice(0, 516)),
-                      ("icp_fused_kernel<P4f> 8 M-point map", "icp_fused_kernel<o3ds::P4f", slice(516, None)),
+# launches of the legs of `bench.py --steps 20 --warmup 3` in the order they run (12 per registration: 11 passes + the fold launch): a leg is
+# warm-up + timed steps + the bracketed re-run + the span re-run (round 6) registrations
+STEPS, WARMUP = 20, 3
+N32 = (WARMUP + STEPS + 2 * min(STEPS, 100)) * 12
+SB = max(STEPS // 4, 5)
+NBIG = (3 + SB + 2 * min(SB, 100)) * 12  # (the in-library one-rank leg that follows uses the same instantiation: cut off)
+for name, pat, sl in (("icp_fused_kernel<P4f> configs[1] (1 M-point map)", "icp_fused_kernel<o3ds::P4f", slice(0, N32)),
+                      ("icp_fused_kernel<P4f> 8 M-point map", "icp_fused_kernel<o3ds::P4f", slice(N32, N32 + NBIG)),
                       ("icp_fused_kernel<P4d> configs[1] (f64 storage)", "icp_fused_kernel<o3ds::P4d", slice(None))):
     rd, wr = stat(rows("dram", pat)["TCC_EA0_RDREQ_sum"][sl]), stat(rows("wr", pat)["TCC_EA0_WRREQ_sum"][sl])
     lo = rd["mean"] * 64 + wr["mean"] * 64
