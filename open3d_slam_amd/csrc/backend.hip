@@ -1367,8 +1367,16 @@ int begin_session(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, const o3d
                  ez = std::max(std::fabs(g.oz), std::fabs(g.oz + g.nz * g.cell));
     const double P = std::max(1.0, std::sqrt(ex * ex + ey * ey + ez * ez) + r);  // a matched source point lies within r of the target's box
     const double rr = std::max(r, 1e-3);
-    // headroom: 64 ranks of a sharded run may add up ("submap" mode: every rank contributes up to n correspondences)
-    const double nn = 64.0 * (double)std::max<size_t>(src->n, 1);
+    // headroom: 64 ranks of a sharded run may add up ("submap" mode: every rank contributes up to n correspondences).  The number of
+    // queries enters as a CONSTANT (2^24, or the next power of two above a larger scan), not as src->n: for the head of a lazy chain
+    // that is the exact count or the chain's upper bound, whichever the host happens to know when the registration starts, and a
+    // quantum that follows it makes the dropped bits -- below 2^-85 of a term's bound, but the whole last place of J^T r once that sum
+    // has converged to nothing -- a matter of timing: two-handle runs of the stream differed from one-handle runs by an ulp of a pose entry
+    // in every third run (round 6, scripts/debug_wobble.py), the two-kernel form, which waits for the count, never did.  (The other half
+    // of the same story is in the kernels: the queries are dealt out over the exact number the DEVICE holds, icp_kernels.hpp deal_count.)
+    size_t n_for_quantum = (size_t)1 << 24;
+    while (n_for_quantum < src->n) n_for_quantum <<= 1;
+    const double nn = 64.0 * (double)n_for_quantum;
     double bound[kRec];
     if (params->method == O3DS_ICP_GENERALIZED) {
       const double gw = 4.0 * std::max(1.0, 0.5 / h->gicp_epsilon);  // |M^-1| <= 1 / (2 eps)

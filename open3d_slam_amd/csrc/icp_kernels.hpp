@@ -856,8 +856,16 @@ struct alignas(4 * sizeof(typename Scalar<P4>::type)) SetRef {
   typename Scalar<P4>::type x, y, z, L;
 };
 
+// The number a pass deals its queries out over: the exact size of the source -- from the device word where the host has only an upper bound
+// (IcpPassArgs::count_dev), NOT that bound.  Which workgroup sums which queries decides the last place of the sums (one rounded f64
+// reduction per workgroup), and `count` is the bound or the exact number depending on whether the size had reached the host when the
+// registration was queued: dealt out over `count`, a stream's poses wobbled by an ulp with the timing of its host threads (round 6,
+// scripts/debug_wobble.py; tests/test_icp_gpu.py::test_a_registration_does_not_depend_on_when_the_host_learnt_the_size_of_its_scan).
+// The launch is still sized by `count`: the workgroups beyond the exact number find no query.
+__device__ __forceinline__ size_t deal_count(const IcpPassArgs& a) { return a.count_dev ? min((size_t)*a.count_dev, a.count) : a.count; }
+
 template <typename P4, int kPassBlock, int kGroup>
-__device__ __forceinline__ QueryPrefetch<P4> prefetch_query(const IcpPassArgs& a, size_t batch, bool use_cache, bool use_sets, int order) {
+__device__ __forceinline__ QueryPrefetch<P4> prefetch_query(const IcpPassArgs& a, size_t batch, bool use_cache, bool use_sets, int order, size_t n_deal) {
   constexpr int kQPB = kPassBlock / kGroup;
   using R = typename Scalar<P4>::type;
   QueryPrefetch<P4> q;
@@ -867,7 +875,7 @@ __device__ __forceinline__ QueryPrefetch<P4> prefetch_query(const IcpPassArgs& a
   q.tprev = P4{};
   q.rx = q.ry = q.rz = q.rL = (R)0;
   const bool sets = use_cache && use_sets && a.set_pos != nullptr;  // (use_sets: the fused kernel only, see icp_pass_body)
-  const size_t i = query_index<kQPB, 64 / kGroup>(a.count, batch, threadIdx.x / kGroup, order);
+  const size_t i = query_index<kQPB, 64 / kGroup>(n_deal, batch, threadIdx.x / kGroup, order);
   if (a.count == 0) return q;
   // Straight-line loads, no branch per lane and none per mode (a lane past the end reads the last query and drops it; a mode that has no
   // use for a load reads a harmless address): a load inside a conditional block is followed by the moves that merge it with the other
@@ -997,14 +1005,14 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
   const R rmax = (R)sqrt(a.r2max);
   int* my_set = sets ? s_set + ql * (1 + kSetCap) : nullptr;
   double acc = 0.0;
-  const size_t n_batches = (a.count + kQPB - 1) / kQPB;
+  const size_t n_batches = (n_live + kQPB - 1) / kQPB;  // (n_live is deal_count: see there)
   static_assert(sizeof(FarItem<P4>) <= kStride * sizeof(double), "a parked far query fits its record slot");
   static_assert((2 + kQPB) * sizeof(int) <= (kPassBlock / 32) * kRec * sizeof(double), "the far list fits s_red");
   int* s_far = (int*)&s_red[0][0];  // [0] count, [1] next, [2..] query slots; s_red itself is only used after the loop
   if (threadIdx.x == 0) s_far[0] = s_far[1] = 0;
   lds_barrier();
   for (size_t b = (size_t)wg; b < n_batches; b += kSingle ? n_batches : (size_t)nwg) {
-    const size_t i = query_index<kQPB, 64 / kGroup>(a.count, b, ql, order);
+    const size_t i = query_index<kQPB, 64 / kGroup>(n_live, b, ql, order);
     double px = 0, py = 0, pz = 0;
     NNBest<P4> nn;
     nn.pos = -1;
@@ -1014,7 +1022,7 @@ __device__ __forceinline__ double icp_pass_body(const IcpPassArgs& a, const doub
     bool verified = false;   // the match was proven inside the prefetched candidate set: the winner's lane holds point and normal
     int kdone = 0;           // block radius (cells) the search of this query covered; 0 = no search ran
     R m = (R)0;  // candidate-set margin of this query's search (0: the search leaves no set)
-    const QueryPrefetch<P4> qp = (kSingle || b == (size_t)wg) ? first_batch : prefetch_query<P4, kPassBlock, kGroup>(a, b, use_cache, sets, order);
+    const QueryPrefetch<P4> qp = (kSingle || b == (size_t)wg) ? first_batch : prefetch_query<P4, kPassBlock, kGroup>(a, b, use_cache, sets, order, n_live);
     if (sets && gl == 0) my_set[0] = 0;  // (same wavefront as its readers and writers below; the far stage is behind a barrier)
     if (i < n_live) {  // uniform across the lanes of a group
       const P4 s = qp.s;
@@ -1243,8 +1251,8 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   }
   const bool use_cache = a.state->pass > 0;
   const int order = pass_order(a.state->pass);
-  const QueryPrefetch<P4> qp = prefetch_query<P4, kPassBlock, kGroup>(a, blockIdx.x, use_cache, false, order);
-  const size_t n_live = a.count_dev ? (size_t)*a.count_dev : a.count;
+  const size_t n_live = deal_count(a);
+  const QueryPrefetch<P4> qp = prefetch_query<P4, kPassBlock, kGroup>(a, blockIdx.x, use_cache, false, order, n_live);
   const double v = icp_pass_body<P4, kCrop, kPassBlock, kGroup, kGicp, kKeys>(a, a.state->T, blockIdx.x, gridDim.x, s_rec, s_red, s_seg, use_cache, qp, nullptr,
                                                                                 SetMargin{-1.0f, 0.0f}, nullptr, n_live, order);
   if (threadIdx.x < kRec) a.partials[(size_t)blockIdx.x * kRec + threadIdx.x] = v;
@@ -1947,7 +1955,7 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   size_t n_live = fa.pass.count;
   unsigned long long n_src_total = fa.n_src_total;
   if (fa.pass.count_dev) {
-    n_live = (size_t)*fa.pass.count_dev;
+    n_live = min((size_t)*fa.pass.count_dev, fa.pass.count);
     n_src_total = (unsigned long long)n_live;
   }
   // (the quanta of the epilogue: a per-lane load of a kernel argument, fetched now and parked in LDS -- loaded at the very end it is a
@@ -1957,7 +1965,7 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   // pose-independent loads of this workgroup's queries: source point, cached match or candidate set (points AND normals); they land
   // while the tail of the previous pass is computed
   const int order = pass_order(first ? 0 : max(fa.pass_index, 1));
-  const QueryPrefetch<P4> qp = prefetch_query<P4, kPassBlock, kGroup>(fa.pass, blockIdx.x, use_cache, true, order);
+  const QueryPrefetch<P4> qp = prefetch_query<P4, kPassBlock, kGroup>(fa.pass, blockIdx.x, use_cache, true, order, n_live);
   if (blockIdx.x == 0) {  // the buffer of the NEXT pass was last read two launches ago
     static_assert(kFusedSlots * kSlotDoubles == 2 * kPassBlock, "two slot values per thread");
     fa.slots_clear[threadIdx.x] = 0.0;

@@ -312,7 +312,7 @@ class ReferenceSlam:
         self.L.ref_slam_preprocessed_scan(self.h, p.ctypes.data_as(_dp), nn.ctypes.data_as(_dp))
         return p[:n].copy(), nn[:n].copy()
 
-    def run_stream(self, scans32, dt=0.1, threads=False):
+    def run_stream(self, scans32, dt=0.1, threads=False, lead=None):
         """all frames through the reference's two workers, timed inside the library: (accepted frames, per-frame mapToRangeSensor,
         per-frame odomToRangeSensor, total ms, points in the active submap)"""
         a = np.ascontiguousarray(np.stack([np.asarray(s, dtype=np.float32).reshape(-1, 3) for s in scans32]))
@@ -320,7 +320,7 @@ class ReferenceSlam:
         poses = np.empty((f, 32))
         ms, n_map = C.c_double(), C.c_size_t()
         workers = np.zeros(2)
-        ok = self.L.ref_slam_run_stream(self.h, a.ctypes.data_as(C.POINTER(C.c_float)), n, f, float(dt), int(bool(threads)), poses.ctypes.data_as(_dp),
+        ok = self.L.ref_slam_run_stream(self.h, a.ctypes.data_as(C.POINTER(C.c_float)), n, f, float(dt), (int(lead) + 1 if lead else 1) if threads else 0, poses.ctypes.data_as(_dp),
                                         C.byref(ms), C.byref(n_map), workers.ctypes.data_as(_dp))
         self.ms_workers = {"odometry": float(workers[0]), "mapping": float(workers[1])}  # serial mode, frames 1..
         M = poses[:, :16].reshape(f, 4, 4).transpose(0, 2, 1).copy()

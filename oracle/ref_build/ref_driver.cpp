@@ -27,9 +27,105 @@
 #include "open3d_slam/math.hpp"
 #include "open3d_slam/time.hpp"
 
+#include <cxxabi.h>
+#include <dlfcn.h>
+#include <execinfo.h>
+#include <signal.h>
+#include <sys/syscall.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+
 using open3d::geometry::PointCloud;
 
 namespace {
+// Where a worker's WALL time goes (REF_SAMPLE_OUT=<file> in the environment, scripts/sample_patched_reference.py): a 2 kHz timer signal to
+// the calling thread records its call stack; the report counts, per function, the samples whose stack holds it.  No perf on the GPU box.
+struct StackSampler {
+  static constexpr int kDepth = 40, kMax = 1 << 15;
+  void* pc[kMax][kDepth];
+  int depth[kMax];
+  std::atomic<int> n{0};
+  timer_t timer{};
+  bool on = false;
+  static StackSampler*& self() {
+    static StackSampler* p = nullptr;
+    return p;
+  }
+  static void tick(int) {
+    StackSampler* s = self();
+    if (!s) return;
+    const int i = s->n.fetch_add(1);
+    if (i < kMax) s->depth[i] = backtrace(s->pc[i], kDepth);
+  }
+  void start() {
+    void* warm[4];
+    backtrace(warm, 4);  // (loads the unwinder outside the handler)
+    self() = this;
+    struct sigaction sa {};
+    sa.sa_handler = &StackSampler::tick;
+    sa.sa_flags = SA_RESTART;
+    sigaction(SIGRTMIN + 3, &sa, nullptr);
+    struct sigevent ev {};
+    ev.sigev_notify = SIGEV_THREAD_ID;
+    ev.sigev_signo = SIGRTMIN + 3;
+    ev._sigev_un._tid = (pid_t)syscall(SYS_gettid);
+    if (timer_create(CLOCK_MONOTONIC, &ev, &timer) != 0) return;
+    struct itimerspec its {};
+    its.it_interval.tv_nsec = its.it_value.tv_nsec = 500000;
+    timer_settime(timer, 0, &its, nullptr);
+    on = true;
+  }
+  void stop(const char* path, const char* title) {
+    if (!on) return;
+    timer_delete(timer);
+    on = false;
+    self() = nullptr;
+    const int total = std::min(n.load(), (int)kMax);
+    std::map<std::string, int> inclusive, innermost;
+    for (int i = 0; i < total; ++i) {
+      std::vector<std::string> seen;
+      bool first = true;
+      for (int d = 0; d < depth[i]; ++d) {
+        Dl_info info{};
+        std::string name = "?";
+        if (dladdr((char*)pc[i][d] - 1, &info)) {
+          if (info.dli_sname) {
+            int st = 0;
+            char* dm = abi::__cxa_demangle(info.dli_sname, nullptr, nullptr, &st);
+            name = st == 0 && dm ? dm : info.dli_sname;
+            std::free(dm);
+          } else if (info.dli_fname) {
+            const char* b = std::strrchr(info.dli_fname, '/');
+            name = std::string("[") + (b ? b + 1 : info.dli_fname) + "]";
+          }
+        }
+        if (name.find("StackSampler") != std::string::npos || name.find("__restore_rt") != std::string::npos || name == "[libc.so.6]" && d < 3) continue;
+        if (name.size() > 150) name.resize(150);
+        if (first) ++innermost[name], first = false;
+        if (std::find(seen.begin(), seen.end(), name) == seen.end()) seen.push_back(name), ++inclusive[name];
+      }
+    }
+    std::FILE* f = std::fopen(path, "a");
+    if (!f) return;
+    std::fprintf(f, "== %s: %d samples at 2 kHz of wall time on the calling thread\n-- samples whose stack holds the function (inclusive)\n", title, total);
+    auto dump = [&](const std::map<std::string, int>& m, int top) {
+      std::vector<std::pair<int, std::string>> v;
+      for (const auto& kv : m) v.emplace_back(kv.second, kv.first);
+      std::sort(v.rbegin(), v.rend());
+      for (int i = 0; i < (int)v.size() && i < top; ++i) std::fprintf(f, "%6.1f %%  %s\n", 100.0 * v[i].first / std::max(total, 1), v[i].second.c_str());
+    };
+    dump(inclusive, 70);
+    std::fprintf(f, "-- innermost resolved frame\n");
+    dump(innermost, 30);
+    std::fclose(f);
+  }
+};
 PointCloud make_cloud(const double* pts, const double* nrm, const double* col, size_t n) {
   PointCloud c;
   c.points_.resize(n);
@@ -371,7 +467,7 @@ size_t ref_slam_preprocessed_scan(void* h, double* out_pts, double* out_nrm) {
 // SlamWrapper runs them (SlamWrapper.cpp:228-229), the mapper waiting for the odometry of its scan.  poses_out: per frame 16 doubles
 // mapToRangeSensor + 16 doubles odomToRangeSensor (column-major).  Returns the number of frames both workers accepted.
 int ref_slam_run_stream(void* h, const float* scans, size_t n_pts, int n_frames, double dt, int threads, double* poses_out, double* ms_total,
-                        size_t* map_points, double* ms_workers /* may be null; serial mode: {odometry, mapping} summed over frames 1.. */) {
+                        size_t* map_points, double* ms_workers /* may be null: {odometry, mapping} busy time summed over frames 1.. (two threads: each worker's own clock) */) {
   auto* s = static_cast<RefSlam*>(h);
   std::vector<PointCloud> clouds((size_t)n_frames);
   for (int k = 0; k < n_frames; ++k) {
@@ -386,6 +482,12 @@ int ref_slam_run_stream(void* h, const float* scans, size_t n_pts, int n_frames,
       for (int r = 0; r < 4; ++r) poses_out[(size_t)k * 32 + c * 4 + r] = M(r, c), poses_out[(size_t)k * 32 + 16 + c * 4 + r] = O(r, c);
   };
   int ok = 0;
+  const char* samplePath = std::getenv("REF_SAMPLE_OUT");
+  std::unique_ptr<StackSampler> sampler;
+  if (samplePath && !threads) {
+    sampler.reset(new StackSampler());
+    sampler->start();
+  }
   const auto t0 = std::chrono::steady_clock::now();
   double msOdo = 0.0, msMap = 0.0;
   if (!threads) {
@@ -405,11 +507,21 @@ int ref_slam_run_stream(void* h, const float* scans, size_t n_pts, int n_frames,
   } else {
     std::mutex m;
     std::condition_variable cv;
-    int odomDone = 0;
+    int odomDone = 0, mapDone = 0;
+    // the odometry worker is at most kLead scans ahead of the mapper: SlamWrapper hands scans over through buffers of
+    // odometryBufferSize_ / mappingBufferSize_ entries (Parameters.hpp:82,175: 1 each; SlamWrapper.cpp:204-205) and, reading a bag, waits while
+    // they are full -- an unbounded lead is not a state the reference can be in (and it lets the faster worker run dozens of scans ahead)
+    const int kLead = threads > 1 ? threads - 1 : 2;  // (threads > 1: a lead of threads - 1, for the sweep in tests/test_patched_reference_gpu.py)
     std::vector<char> odomOk((size_t)n_frames, 0);
     std::thread odometryWorker([&] {
       for (int k = 0; k < n_frames; ++k) {
+        {
+          std::unique_lock<std::mutex> l(m);
+          cv.wait(l, [&] { return mapDone >= k - kLead; });
+        }
+        const auto a0 = std::chrono::steady_clock::now();
         const bool a = s->odometry->addRangeScan(clouds[k], stamp(k));
+        if (k > 0) msOdo += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a0).count();  // (busy time of this worker)
         std::lock_guard<std::mutex> l(m);
         odomOk[k] = a ? 1 : 0;
         odomDone = k + 1;
@@ -424,15 +536,23 @@ int ref_slam_run_stream(void* h, const float* scans, size_t n_pts, int n_frames,
           cv.wait(l, [&] { return odomDone > k; });
           a = odomOk[k] != 0;
         }
+        const auto a1 = std::chrono::steady_clock::now();
         const bool b = a && s->mapper->addRangeMeasurement(clouds[k], stamp(k));
+        if (k > 0) msMap += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a1).count();
         record(k);
         ok += (a && b) ? 1 : 0;
+        {
+          std::lock_guard<std::mutex> l(m);
+          mapDone = k + 1;
+        }
+        cv.notify_all();
       }
     });
     odometryWorker.join();
     mappingWorker.join();
   }
   *ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (sampler) sampler->stop(samplePath, "ref_slam_run_stream, one thread");
   if (ms_workers) ms_workers[0] = msOdo, ms_workers[1] = msMap;
   *map_points = s->mapper->getActiveSubmap().getMapPointCloud().points_.size();
   return ok;

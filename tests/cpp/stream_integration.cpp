@@ -193,10 +193,17 @@ int main(int argc, char** argv) {
   } else {
     std::mutex m;
     std::condition_variable cv;
-    int odomDone = 0;
+    int odomDone = 0, mapDone = 0;
     bool odoOk = true;
+    // neither worker is more than kLead scans ahead of the other: the reference's workers hand scans over through buffers of
+    // odometryBufferSize_ / mappingBufferSize_ entries (Parameters.hpp:82,175: 1 each; SlamWrapper.cpp:204-205)
+    constexpr int kLead = 2;
     std::thread odometryWorker([&] {
       for (int k = 0; k < frames; ++k) {
+        {
+          std::unique_lock<std::mutex> l(m);
+          cv.wait(l, [&] { return mapDone >= k - kLead || !ok; });
+        }
         const o3ds::ScanStampScope stamp(1000 + k);
         const bool good = odo.add(scans[k]);
         std::lock_guard<std::mutex> l(m);
@@ -215,8 +222,14 @@ int main(int argc, char** argv) {
           odom = odomAt[k];
         }
         const o3ds::ScanStampScope stamp(1000 + k);
-        ok = mapping.add(scans[k], odom);
+        const bool good = mapping.add(scans[k], odom);
         mapAt[k] = mapping.T;
+        {
+          std::lock_guard<std::mutex> l(m);
+          ok = good;
+          mapDone = k + 1;
+        }
+        cv.notify_all();
       }
     });
     odometryWorker.join();
