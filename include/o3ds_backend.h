@@ -342,6 +342,14 @@ int o3ds_estimate_normals(o3ds_handle h, o3ds_cloud c, double radius, int max_nn
 /* [O3D] RandomDownSample is seeded from std::random_device (non-reproducible); the ABI takes the
  * kept indices explicitly: SelectByIndex(keep_idx[0..m)). */
 int o3ds_select_by_index(o3ds_handle h, o3ds_cloud in, const uint32_t* keep_idx, size_t m, o3ds_cloud* out);
+/* [O3D] PointCloud::RandomDownSample(sampling_ratio) as open3d_slam calls it (Odometry.cpp:29, ScanToMapRegistration.cpp:39), drawn on the
+ * device: keeps k = (int)(ratio * n) points, a uniformly drawn k-subset, in cloud order (the order [O3D] SelectByIndex's mask walk emits).
+ * The reference draws from an mt19937 seeded by std::random_device -- there is no sequence to reproduce --; here index i gets the 64-bit key
+ * mix(seed + (i + 1) * 0x9E3779B97F4A7C15) (splitmix64's finaliser: distinct keys) and the k smallest keys are kept, so the subset is a
+ * function of (seed, n, ratio) alone, restated in numpy for the checker (oracle/pipeline.py draw_keep).  Neither n nor k passes through the
+ * host: a cloud whose size is still in flight (o3ds_crop_voxel_down_sample's result) is drawn from as it is, and the result's size is in
+ * flight in turn.  ratio outside [0, 1]: O3DS_ERR_INVALID_ARG with Open3D's message; the input is left as it is. */
+int o3ds_random_down_sample(o3ds_handle h, o3ds_cloud in, double ratio, uint64_t seed, o3ds_cloud* out);
 
 /* ---- map fusion: Submap::insertScan (Submap.cpp:39-75) ------------------------------------- */
 /* o3d_slam::transform (helpers.cpp:273-305): p' = (T p).xyz/w, n' = R n.  Returns a new cloud.

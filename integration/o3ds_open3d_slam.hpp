@@ -471,6 +471,16 @@ inline bool selectByIndexKeepsCloudOrder() {
   return on;
 }
 inline o3ds_cloud drawOnDevice(o3ds_handle h, o3ds_cloud cloud, size_t n, double ratio) {
+  if (selectByIndexKeepsCloudOrder()) {
+    // the draw itself on the device (o3ds_random_down_sample): one 64-bit seed from the generator names the subset; no shuffle of n
+    // indices on the host, no index list to upload.  [O3D] seeds an mt19937 from std::random_device per call -- any uniformly drawn
+    // k-subset is its outcome, none is reproducible; setRandomDownSampleSeed makes this one so
+    std::mt19937& gen = downSampleGenerator();
+    const uint64_t hi = gen(), lo = gen();
+    o3ds_cloud kept = 0;
+    check(h, o3ds_random_down_sample(h, cloud, ratio, (hi << 32) | lo, &kept));
+    return kept;
+  }
   std::vector<uint32_t> idx(n);
   std::iota(idx.begin(), idx.end(), 0u);
   std::shuffle(idx.begin(), idx.end(), downSampleGenerator());

@@ -133,6 +133,7 @@ SIGNATURES = {
     "o3ds_crop_voxel_down_sample": (C.c_int, [_H, _CL, C.POINTER(Crop), C.c_double, C.POINTER(_CL)]),
     "o3ds_estimate_normals": (C.c_int, [_H, _CL, C.c_double, C.c_int]),
     "o3ds_select_by_index": (C.c_int, [_H, _CL, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(_CL)]),
+    "o3ds_random_down_sample": (C.c_int, [_H, _CL, C.c_double, C.c_uint64, C.POINTER(_CL)]),
     "o3ds_transform_cloud": (C.c_int, [_H, _CL, _dp, C.POINTER(_CL)]),
     "o3ds_cloud_append": (C.c_int, [_H, _CL, _CL]),
     "o3ds_cloud_copy_across": (C.c_int, [_H, _H, _CL, C.POINTER(_CL)]),
@@ -643,6 +644,13 @@ class Backend:
         idx = np.ascontiguousarray(idx, dtype=np.uint32)
         out = _CL()
         self._ck(self.lib.o3ds_select_by_index(self.h, cid, idx.ctypes.data_as(C.POINTER(C.c_uint32)), len(idx), C.byref(out)))
+        return out.value
+
+    def random_down_sample(self, cid: int, ratio: float, seed: int) -> int:
+        """[O3D] RandomDownSample drawn on the device (o3ds_random_down_sample): the k = int(ratio * n) points with the smallest keys of the
+        counter-based generator seeded with `seed`, in cloud order; the input's size may still be in flight, the result's then is too"""
+        out = _CL()
+        self._ck(self.lib.o3ds_random_down_sample(self.h, cid, float(ratio), int(seed) & 0xFFFFFFFFFFFFFFFF, C.byref(out)))
         return out.value
 
     # -- map fusion

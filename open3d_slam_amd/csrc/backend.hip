@@ -224,6 +224,7 @@ struct o3ds_context {
   size_t cells_cap = 0;
   bool cells_clean = false;
   unsigned char* d_voxtab = nullptr;
+  o3ds::DrawState* d_draw = nullptr;  // RandomDownSample on the device (cloud_kernels.hpp): histograms zero between calls
   size_t voxtab_cap = 0;  // slots
   bool voxtab_clean = false;
   // ---- values kernels publish for the host without a copy or a wait on the stream: kPinRecs records {count, stamp, box} in pinned
@@ -1569,6 +1570,7 @@ int o3ds_destroy(o3ds_handle h) {
   if (h->d_set_pos) (void)hipFree(h->d_set_pos);
   if (h->d_cells) (void)hipFree(h->d_cells);
   if (h->d_voxtab) (void)hipFree(h->d_voxtab);
+  if (h->d_draw) (void)hipFree(h->d_draw);
   if (h->d_partials) (void)hipFree(h->d_partials);
   if (h->d_state) (void)hipFree(h->d_state);
   if (h->h_state) (void)hipHostFree(h->h_state);
@@ -3275,6 +3277,53 @@ int append_t(o3ds_handle h, CloudRec& map, const CloudRec& add) {
   return O3DS_OK;
 }
 
+// [O3D] PointCloud::RandomDownSample(ratio) (Odometry.cpp:29, ScanToMapRegistration.cpp:39) as a draw on the device (cloud_kernels.hpp,
+// DrawState): nothing of it -- not the size of the input, not the number kept -- passes through the host
+template <typename P4>
+int random_down_sample_t(o3ds_handle h, const CloudRec& in, double ratio, unsigned long long seed, CloudRec& out) {
+  out.precision = in.precision;
+  out.n = 0;
+  box_copy(out, in);  // a subset
+  const size_t bound = in.n;  // (an upper bound when the input's size is still in flight)
+  const size_t k_bound = (size_t)std::max(0, (int)(ratio * (double)bound));  // monotone in the size: at least the exact number
+  if (bound == 0 || k_bound == 0) return O3DS_OK;
+  if (bound >= ((size_t)1 << 31)) return fail(h, O3DS_ERR_INVALID_ARG, "random_down_sample: more than 2^31 points");
+  if (!h->d_draw) {
+    if (hipMalloc((void**)&h->d_draw, sizeof(o3ds::DrawState)) != hipSuccess) return fail(h, O3DS_ERR_OOM, "random_down_sample: state allocation failed");
+    HIP_TRY(hipMemsetAsync(h->d_draw, 0, sizeof(o3ds::DrawState), h->stream));
+  }
+  o3ds::DrawState* st = h->d_draw;
+  const CountRef n_ref = count_ref(h, in);
+  CountPub pub{&st->cnt_dummy, nullptr, 0};
+  if (in.lazy_slot >= 0) {  // the number kept follows the input's: published like a VoxelDownSample's
+    out.lazy_slot = take_rec(h);
+    if (out.lazy_slot < 0) return fail(h, O3DS_ERR_CAPACITY, "random_down_sample: no record free for the size of the result");
+    out.lazy_seq = ++h->rec_seq;
+    out.n_lower = (size_t)std::max(0, (int)(ratio * (double)in.n_lower));
+    pub = CountPub{cnt_word(h, out.lazy_slot), &(h->h_rec_dev + out.lazy_slot)->cnt, out.lazy_seq};
+  }
+  out.n = k_bound;
+  int *flags = nullptr, *pos = nullptr;
+  TMP_ALLOC(flags, sizeof(int) * (bound + 1));
+  TMP_ALLOC(pos, sizeof(int) * (bound + 1));
+  HIP_TRY(dev_alloc(h, (void**)&out.pts, sizeof(P4) * k_bound));
+  if (in.nrm) HIP_TRY(dev_alloc(h, (void**)&out.nrm, sizeof(P4) * k_bound));
+  if (in.col) HIP_TRY(dev_alloc(h, (void**)&out.col, sizeof(P4) * k_bound));
+  const unsigned int g = grid_for(bound);
+  draw_hist1_kernel<<<g, kBlock, 0, h->stream>>>(n_ref, seed, st);
+  draw_hist2_kernel<<<g, kBlock, 0, h->stream>>>(n_ref, seed, ratio, st);
+  draw_collect_kernel<<<g, kBlock, 0, h->stream>>>(n_ref, seed, st);
+  draw_pick_kernel<<<1, kBlock, 0, h->stream>>>(st, pub);
+  draw_flag_kernel<<<grid_for(bound + 1), kBlock, 0, h->stream>>>(n_ref, seed, st, flags);
+  int rc = exclusive_scan_int(h, flags, pos, bound + 1);
+  if (rc) return rc;
+  compact_kernel<P4><<<g, kBlock, 0, h->stream>>>((const P4*)in.pts, (const P4*)in.nrm, bound, flags, pos, 1, (P4*)out.pts, (P4*)out.nrm);
+  if (in.col) compact_kernel<P4><<<g, kBlock, 0, h->stream>>>((const P4*)in.col, nullptr, bound, flags, pos, 1, (P4*)out.col, nullptr);
+  HIP_TRY(hipGetLastError());
+  dbg_sync(h, 4);
+  return O3DS_OK;
+}
+
 #define DISPATCH(prec, fn, ...) ((prec) == O3DS_PRECISION_F64 ? fn<P4d>(__VA_ARGS__) : fn<P4f>(__VA_ARGS__))
 
 }  // namespace
@@ -3384,6 +3433,24 @@ int o3ds_select_by_index(o3ds_handle h, o3ds_cloud in, const uint32_t* keep_idx,
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));  // keep_idx may be released by the caller
   }
+  o_guard.release();
+  *out = add_cloud(h, std::move(o));
+  return O3DS_OK;
+}
+
+int o3ds_random_down_sample(o3ds_handle h, o3ds_cloud in, double ratio, uint64_t seed, o3ds_cloud* out) {
+  CHECK_HANDLE(h);
+  ArenaScope arena_scope(h);
+  CloudRec* c = find_cloud_lazy(h, in);
+  if (!c || !out) return fail(h, O3DS_ERR_INVALID_ARG, "random_down_sample: bad argument");
+  if (c->pm) return fail(h, O3DS_ERR_INVALID_ARG, "random_down_sample: the cloud is a map");
+  if (!(ratio >= 0.0 && ratio <= 1.0))
+    return fail(h, O3DS_ERR_INVALID_ARG, "[RandomDownSample] Illegal sampling_ratio, sampling_ratio must be between 0 and 1.");  // [O3D]
+  HIP_TRY(hipSetDevice(h->device));
+  CloudRec o;
+  CloudGuard o_guard(h, o);
+  int rc = DISPATCH(c->precision, random_down_sample_t, h, *c, ratio, (unsigned long long)seed, o);
+  if (rc) return rc;
   o_guard.release();
   *out = add_cloud(h, std::move(o));
   return O3DS_OK;

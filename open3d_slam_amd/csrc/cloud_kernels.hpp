@@ -143,6 +143,146 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(const P4* __restrict__ 
     if (nrm) out_nrm[o] = nrm[i];
   }
 }
+// ---------------------------------------------------------------------------------------------- [O3D] RandomDownSample on the device
+// PointCloud::RandomDownSample(ratio) (call sites Odometry.cpp:29, ScanToMapRegistration.cpp:39) shuffles the indices 0..n-1 with an mt19937
+// seeded from std::random_device and keeps the first k = (int)(ratio * n): a uniformly drawn k-subset that no two runs of the reference
+// share.  On the host that is a 55 000-element shuffle per call and a wait for n in front of it (0.45 ms, twice per frame of the shipped
+// configuration, the GPU idle meanwhile).  Here every index gets a 64-bit key from a counter-based generator -- key(i) = mix(seed + (i + 1) *
+// golden), the splitmix64 finaliser: a bijection of distinct arguments, so the keys are DISTINCT -- and the k points with the smallest keys are
+// kept, in cloud order ([O3D] SelectByIndex walks the cloud through a mask): the same distribution, reproducible from the seed, restated
+// in numpy for the checker (oracle/pipeline.py draw_keys).  The k-th smallest key is found exactly without a sort: an 11-bit histogram of
+// the keys' top bits names the bin that holds it, a second one inside that bin the next 11 bits, the handful of keys of that sub-bin are
+// listed and ranked by one workgroup; n and k never leave the device (CountRef in, CountPub out).
+constexpr int kDrawBits = 11, kDrawBins = 1 << kDrawBits, kDrawListCap = 2048;
+struct DrawState {  // one per handle; hist1 / hist2 / list_n are zero between calls (draw_pick_kernel leaves them so)
+  unsigned int hist1[kDrawBins], hist2[kDrawBins];
+  unsigned long long list[kDrawListCap];
+  unsigned int list_n;
+  int k;                                   // points to keep
+  unsigned int bin1, below1, bin2, below2; // the bin of the k-th smallest key at each level, and the keys below it
+  unsigned long long thr;                  // k > 0: keys <= thr are kept
+  int error;                               // sticky: the listed sub-bin overflowed (it holds n / 4 M keys on average)
+  int cnt_dummy;                           // where the count goes when the host knows it already
+};
+__host__ __device__ __forceinline__ unsigned long long draw_key(unsigned long long seed, unsigned long long i) {
+  unsigned long long z = seed + (i + 1ull) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+// the bin that holds the key of rank `target` (1-based) and the number of keys in the bins before it; kBlock threads, result in every thread
+__device__ __forceinline__ void draw_find_bin(const unsigned int* __restrict__ hist, unsigned int target, unsigned int* s_scan /* [kBlock + 2] */,
+                                              unsigned int* bin, unsigned int* below) {
+  constexpr int kPer = kDrawBins / kBlock;
+  static_assert(kDrawBins % kBlock == 0, "bins split evenly over the threads");
+  unsigned int mine[kPer], sum = 0;
+#pragma unroll
+  for (int j = 0; j < kPer; ++j) {
+    mine[j] = hist[threadIdx.x * kPer + j];
+    sum += mine[j];
+  }
+  s_scan[threadIdx.x] = sum;
+  __syncthreads();
+  for (int d = 1; d < kBlock; d <<= 1) {  // inclusive scan of the threads' sums
+    const unsigned int add = threadIdx.x >= (unsigned)d ? s_scan[threadIdx.x - d] : 0u;
+    __syncthreads();
+    s_scan[threadIdx.x] += add;
+    __syncthreads();
+  }
+  const unsigned int incl = s_scan[threadIdx.x], excl = incl - sum;
+  if (excl < target && target <= incl) {  // exactly one thread
+    unsigned int run = excl;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      if (run < target && target <= run + mine[j]) {
+        s_scan[kBlock] = threadIdx.x * kPer + j;
+        s_scan[kBlock + 1] = run;
+      }
+      run += mine[j];
+    }
+  }
+  __syncthreads();
+  *bin = s_scan[kBlock];
+  *below = s_scan[kBlock + 1];
+  __syncthreads();
+}
+__global__ __launch_bounds__(kBlock) void draw_hist1_kernel(CountRef n_ref, unsigned long long seed, DrawState* __restrict__ st) {
+  __shared__ unsigned int s_hist[kDrawBins];
+  for (int b = threadIdx.x; b < kDrawBins; b += kBlock) s_hist[b] = 0u;
+  __syncthreads();
+  const size_t n = count_of(n_ref);
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) atomicAdd(&s_hist[draw_key(seed, i) >> (64 - kDrawBits)], 1u);
+  __syncthreads();
+  for (int b = threadIdx.x; b < kDrawBins; b += kBlock)
+    if (s_hist[b]) atomicAdd(&st->hist1[b], s_hist[b]);
+}
+__global__ __launch_bounds__(kBlock) void draw_hist2_kernel(CountRef n_ref, unsigned long long seed, double ratio, DrawState* __restrict__ st) {
+  __shared__ unsigned int s_scan[kBlock + 2];
+  const size_t n = count_of(n_ref);
+  const int k = (int)(ratio * (double)n);  // [O3D] indices.resize((int)(sampling_ratio * points_.size()))
+  if (k <= 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->k = 0;
+    return;
+  }
+  unsigned int bin1, below1;
+  draw_find_bin(st->hist1, (unsigned int)k, s_scan, &bin1, &below1);
+  if (blockIdx.x == 0 && threadIdx.x == 0) st->k = k, st->bin1 = bin1, st->below1 = below1;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const unsigned long long key = draw_key(seed, i);
+    if ((unsigned int)(key >> (64 - kDrawBits)) == bin1) atomicAdd(&st->hist2[(key >> (64 - 2 * kDrawBits)) & (kDrawBins - 1)], 1u);
+  }
+}
+__global__ __launch_bounds__(kBlock) void draw_collect_kernel(CountRef n_ref, unsigned long long seed, DrawState* __restrict__ st) {
+  __shared__ unsigned int s_scan[kBlock + 2];
+  const int k = st->k;
+  if (k <= 0) return;
+  const unsigned int bin1 = st->bin1, below1 = st->below1;
+  unsigned int bin2, below2;
+  draw_find_bin(st->hist2, (unsigned int)k - below1, s_scan, &bin2, &below2);
+  if (blockIdx.x == 0 && threadIdx.x == 0) st->bin2 = bin2, st->below2 = below2;
+  const unsigned long long want = ((unsigned long long)bin1 << kDrawBits) | bin2;
+  const size_t n = count_of(n_ref);
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const unsigned long long key = draw_key(seed, i);
+    if ((key >> (64 - 2 * kDrawBits)) == want) {
+      const unsigned int at = atomicAdd(&st->list_n, 1u);
+      if (at < (unsigned)kDrawListCap) st->list[at] = key;
+    }
+  }
+}
+// one workgroup: the key of rank k among the listed ones is the threshold; the count goes where the consumers and the host look for it;
+// the histograms are handed back empty
+__global__ __launch_bounds__(kBlock) void draw_pick_kernel(DrawState* __restrict__ st, CountPub pub) {
+  const int k = st->k;
+  if (k > 0) {
+    const unsigned int m = st->list_n, r = (unsigned int)k - st->below1 - st->below2;  // rank inside the list, 1-based
+    if (m > (unsigned)kDrawListCap || r == 0 || r > m) {
+      if (threadIdx.x == 0) st->error = 1, st->thr = 0ull, st->k = 0;
+    } else {
+      for (unsigned int j = threadIdx.x; j < m; j += kBlock) {
+        const unsigned long long mine = st->list[j];
+        unsigned int smaller = 0;
+        for (unsigned int x = 0; x < m; ++x) smaller += st->list[x] < mine ? 1u : 0u;
+        if (smaller + 1 == r) st->thr = mine;  // (keys are distinct: exactly one)
+      }
+    }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < kDrawBins; b += kBlock) st->hist1[b] = 0u, st->hist2[b] = 0u;
+  if (threadIdx.x == 0) {
+    st->list_n = 0u;
+    publish_count(pub, st->error ? 0 : st->k);
+  }
+}
+// flags[i] = the point is kept; flags[n_bound] = 0 (sentinel of the scan).  n_bound >= the exact size.
+__global__ __launch_bounds__(kBlock) void draw_flag_kernel(CountRef n_ref, unsigned long long seed, const DrawState* __restrict__ st, int* __restrict__ flags) {
+  const size_t n = count_of(n_ref);
+  const int k = st->k;
+  const unsigned long long thr = st->thr;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i <= n_ref.n; i += (size_t)gridDim.x * kBlock)
+    flags[i] = (i < n && k > 0 && draw_key(seed, i) <= thr) ? 1 : 0;
+}
+
 template <typename P4>
 __global__ __launch_bounds__(kBlock) void gather_kernel(const P4* __restrict__ pts, const P4* __restrict__ nrm, const uint32_t* __restrict__ idx,
                                                         size_t m, P4* __restrict__ out_pts, P4* __restrict__ out_nrm) {

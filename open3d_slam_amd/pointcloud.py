@@ -126,10 +126,21 @@ def random_down_sample(cloud: "PointCloud", ratio: float, rng=None, shuffle_at_f
     """[O3D] PointCloud::RandomDownSample as open3d_slam calls it (Odometry.cpp:29, ScanToMapRegistration.cpp:39): shuffle the
     indices 0..n-1, keep the first int(ratio * n), SelectByIndex (SELECT_BY_INDEX_KEEPS_CLOUD_ORDER: the kept points in cloud order, or in
     the order of the shuffled list).  Open3D seeds a fresh mt19937 from std::random_device per call, so the reference is not reproducible
-    here; `rng` (a numpy Generator) pins the list.  With ratio >= 1 every point is kept -- in cloud order the cloud itself; under the
+    here; `rng` (a numpy Generator) pins the list: under the default reading of SelectByIndex (cloud order) one 64-bit seed per call and the
+    draw happens on the device (o3ds_random_down_sample); under the other reading the shuffled list itself.  With ratio >= 1 every point is kept -- in cloud order the cloud itself; under the
     other reading a PERMUTATION of it, which `shuffle_at_full_ratio` reproduces when a test wants it.  Consumes `cloud`."""
     if ratio >= 1.0 and (SELECT_BY_INDEX_KEEPS_CLOUD_ORDER or not shuffle_at_full_ratio):
         return cloud  # (before the size is asked for: it may still be in flight on the device, o3ds_cloud_size)
+    if SELECT_BY_INDEX_KEEPS_CLOUD_ORDER:
+        # drawn on the device (o3ds_random_down_sample): the size of the cloud is not asked for, nothing is shuffled or uploaded -- the host
+        # draw below is a 55 000-element permutation and a wait per call, 0.9 ms of a 1.6 ms frame of the shipped configuration.  One
+        # 64-bit seed per call from the caller's generator names the subset (oracle/pipeline.py draw_keep restates it)
+        if rng is None:
+            rng = np.random.default_rng()
+        seed = int(rng.integers(0, 2**64, dtype=np.uint64))
+        out = PointCloud(cloud.be, cloud.be.random_down_sample(cloud.id, ratio, seed))
+        cloud.release()
+        return out
     n = len(cloud)
     if n == 0:
         return cloud

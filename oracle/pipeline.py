@@ -4,6 +4,27 @@ Used by tests/test_pipeline_gpu.py as the reference loop and by bench.py as the 
 import numpy as np
 
 
+def draw_keys(seed: int, n: int) -> np.ndarray:
+    """The 64-bit key of every index under o3ds_random_down_sample's counter-based generator (include/o3ds_backend.h): splitmix64's finaliser of
+    seed + (i + 1) * 0x9E3779B97F4A7C15, all arithmetic modulo 2^64.  Distinct arguments, a bijective mix: distinct keys."""
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + (np.arange(n, dtype=np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def draw_keep(seed: int, n: int, ratio: float) -> np.ndarray:
+    """[O3D] RandomDownSample as this repository draws it: the k = int(ratio * n) indices with the smallest keys, ascending (the cloud order
+    [O3D] SelectByIndex's mask walk emits).  Open3D itself shuffles with an mt19937 seeded from std::random_device: any uniformly drawn
+    k-subset is a faithful outcome, none is reproducible; this one is a function of the seed."""
+    k = int(ratio * n)
+    if k <= 0:
+        return np.zeros(0, dtype=np.int64)
+    keys = draw_keys(seed, n)
+    return np.sort(np.argpartition(keys, k - 1)[:k]) if k < n else np.arange(n)
+
+
 class OracleLoop:
     """The same orchestration (Odometry.cpp:25-79, Mapper.cpp:101-181, ScanToMapRegistration.cpp:35-62, Submap.cpp:39-75) on
     the CPU oracle."""
@@ -40,11 +61,15 @@ class OracleLoop:
 
     def _down(self, v, n, ratio, rng):
         cloud_order = self.select_by_index_keeps_cloud_order
-        if len(v) == 0 or (ratio >= 1.0 and (cloud_order or not self.shuffle_at_full_ratio)):
+        if ratio >= 1.0 and (cloud_order or not self.shuffle_at_full_ratio):
+            return v, n
+        if cloud_order:  # the draw the device makes (o3ds_random_down_sample): one seed per call, whatever the size of the cloud
+            seed = int((rng or np.random.default_rng()).integers(0, 2**64, dtype=np.uint64))
+            keep = draw_keep(seed, len(v), min(ratio, 1.0))
+            return v[keep], n[keep]
+        if len(v) == 0:
             return v, n
         keep = (rng or np.random.default_rng()).permutation(len(v))[: int(min(ratio, 1.0) * len(v))]
-        if cloud_order:
-            keep = np.sort(keep)
         return v[keep], n[keep]
 
     def _pre(self, raw, crop_p, voxel, icp):

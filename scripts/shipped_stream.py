@@ -1,0 +1,13 @@
+#!/usr/bin/env python
+"""The shipped configuration's stream alone (GeneralizedIcp, downsampling_ratio 0.3), as bench.py times it: for rocprofv3 / host traces."""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from open3d_slam_amd import backend
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+scans = bench.make_stream(frames)
+be = backend.Backend(0); bench.run_stream(be, scans[:8], shipped=True); be.close()
+be = backend.Backend(0)
+out = bench.run_stream(be, scans, shipped=True, stage_sync="free" not in sys.argv)
+be.close()
+print(json.dumps({k: out[k] for k in ("scans_per_sec", "ms_per_scan")}))

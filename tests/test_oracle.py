@@ -661,3 +661,23 @@ def test_solve_update_with_null_pivots_follows_eigen_ldlt(oracle):
     # all-zero system (no correspondence): the zero update
     U0, x0 = oracle.solve_update(np.zeros((6, 6)), np.zeros(6))
     assert np.array_equal(x0, np.zeros(6)) and np.array_equal(U0, np.eye(4))
+
+
+def test_draw_keys_are_splitmix64_and_draw_keep_is_a_k_subset_in_cloud_order():
+    """oracle/pipeline.py draw_keys / draw_keep (the checker of o3ds_random_down_sample): known answers from plain Python integers
+    (key(seed 0, index 0) is the first output of splitmix64 seeded with 0), distinct keys, exactly int(ratio * n) indices, ascending,
+    nested in the ratio for one seed (the k smallest keys), and spread evenly over the cloud."""
+    from oracle.pipeline import draw_keep, draw_keys
+
+    k0 = draw_keys(0, 3)
+    assert [int(x) for x in k0] == [0xE220A8397B1DCDAF, 0x6E789E6AA1B965F4, 0x06C45D188009454F]
+    k1 = draw_keys(0xDEADBEEFCAFEF00D, 65536)
+    assert int(k1[0]) == 0x901D4F652FB472CB and int(k1[1]) == 0xA7CE246440F74527 and int(k1[65535]) == 0x078F43DA993EA80E
+    assert len(np.unique(k1)) == len(k1)
+    n = 50_000
+    a, b = draw_keep(5, n, 0.3), draw_keep(5, n, 0.6)
+    assert len(a) == int(0.3 * n) and len(b) == int(0.6 * n) and np.all(np.diff(a) > 0) and np.all(np.diff(b) > 0)
+    assert np.isin(a, b).all() and not np.array_equal(a, draw_keep(6, n, 0.3))
+    assert len(draw_keep(5, n, 0.0)) == 0 and np.array_equal(draw_keep(5, n, 1.0), np.arange(n)) and len(draw_keep(5, 0, 0.5)) == 0
+    counts = np.bincount(a * 10 // n, minlength=10)  # a tenth of the cloud holds a tenth of the kept points, within 5 sigma
+    assert np.all(np.abs(counts - len(a) / 10) < 5 * np.sqrt(len(a) / 10))

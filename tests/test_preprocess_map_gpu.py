@@ -210,6 +210,99 @@ def test_select_by_index(backend_f64, scan):
     backend_f64.free(out)
 
 
+@pytest.mark.parametrize("which", ["f64", "f32"])
+def test_random_down_sample_on_the_device_is_the_checkers_subset(backend_f64, backend_f32, scan, which):
+    """o3ds_random_down_sample ([O3D] RandomDownSample, Odometry.cpp:29 / ScanToMapRegistration.cpp:39): the k = int(ratio * n) indices with
+    the smallest keys of the counter-based generator, in cloud order -- the very index list oracle/pipeline.py draw_keep names, for every
+    ratio and seed, with normals and colours riding along; ratio 0 keeps nothing, ratio 1 everything, a ratio outside [0, 1] is Open3D's
+    error; the input is left as it is."""
+    from oracle.pipeline import draw_keep
+
+    be = backend_f64 if which == "f64" else backend_f32
+    pts = scan if which == "f64" else scan.astype(np.float32).astype(np.float64)
+    nrm = -pts / np.linalg.norm(pts, axis=1, keepdims=True)
+    col = np.random.default_rng(3).uniform(0, 1, pts.shape)
+    c = be.upload(pts, nrm)
+    be.set_colors(c, col)
+    n = len(pts)
+    for ratio, seed in [(0.3, 1), (0.3, 2), (0.5, 0xDEADBEEFCAFEF00D), (0.999, 7), (1e-4, 7), (1.0, 9), (0.0, 9), (0.5 / n, 9), (1.5 / n, 11), ((n - 0.5) / n, 12)]:
+        keep = draw_keep(seed, n, ratio)
+        assert len(keep) == int(ratio * n)
+        out = be.random_down_sample(c, ratio, seed)
+        assert be.size(out)[0] == len(keep)
+        if len(keep):
+            xyz, nn = be.download(out)
+            np.testing.assert_array_equal(xyz, pts[keep])
+            if which == "f64":
+                np.testing.assert_array_equal(nn, nrm[keep])
+                np.testing.assert_array_equal(be.get_colors(out), col[keep])
+            else:
+                np.testing.assert_array_equal(nn, nrm.astype(np.float32).astype(np.float64)[keep])
+        be.free(out)
+    for bad in (-0.1, 1.0001, float("nan")):
+        with pytest.raises(backend.BackendError, match="Illegal sampling_ratio"):
+            be.random_down_sample(c, bad, 1)
+    xyz, _ = be.download(c)
+    np.testing.assert_array_equal(xyz, pts)
+    empty = be.upload(np.zeros((0, 3)))
+    out = be.random_down_sample(empty, 0.5, 1)
+    assert be.size(out)[0] == 0
+    for x in (c, empty, out):
+        be.free(x)
+
+
+def test_random_down_sample_of_a_cloud_whose_size_is_in_flight(backend_f32):
+    """The head of a crop + VoxelDownSample chain is drawn from without its size reaching the host, and the draw's own size stays on the
+    device in turn: the points are those drawn from the same cloud once its size is known, and the registration, the normal estimation
+    and the insertion that follow take the result as it is.  Full size (131 072 raw points), twenty seeds."""
+    from oracle.pipeline import draw_keep
+
+    be = backend_f32
+    scene = syn.make_scene()
+    raw = np.ascontiguousarray(syn.os128_scan(scene, np.eye(4)), dtype=np.float32)
+    crop = backend.make_crop(backend.CROP_MIN_MAX_RADIUS, rmin=2.0, rmax=30.0)
+    r = be.upload_f32(raw)
+    v = be.crop_voxel_down_sample(r, crop, 0.1)
+    be.estimate_normals(v, 3.0, 20)
+    ref_p, ref_n = be.download(v)  # (the size is known from here on)
+    n = len(ref_p)
+    for seed in range(20):
+        r2 = be.upload_f32(raw)
+        v2 = be.crop_voxel_down_sample(r2, crop, 0.1)
+        be.estimate_normals(v2, 3.0, 20)
+        d = be.random_down_sample(v2, 0.3, seed)  # queued behind the chain, whatever the host knows of its size
+        lo, up = be.size_bound(d)
+        assert up <= int(0.3 * len(raw)) and lo <= int(0.3 * n) <= up
+        keep = draw_keep(seed, n, 0.3)
+        p, nn = be.download(d)
+        assert len(p) == len(keep) == int(0.3 * n)
+        np.testing.assert_array_equal(p, ref_p[keep])
+        np.testing.assert_array_equal(nn, ref_n[keep])
+        for x in (r2, v2, d):
+            be.free(x)
+    be.free(r)
+    be.free(v)
+
+
+def test_random_down_sample_at_a_million_points_keeps_exactly_k_in_cloud_order(backend_f32):
+    """size-independent properties at 2^20 + 3 points: exactly int(ratio * n) points are kept, they are the checker's, and their order
+    is the cloud's (the x coordinate carries the original index)"""
+    from oracle.pipeline import draw_keep
+
+    n = (1 << 20) + 3
+    pts = np.zeros((n, 3))
+    pts[:, 0] = np.arange(n)
+    c = backend_f32.upload(pts)
+    for ratio, seed in [(0.3, 5), (0.71, 6)]:
+        out = backend_f32.random_down_sample(c, ratio, seed)
+        xyz, _ = backend_f32.download(out)
+        got = xyz[:, 0].astype(np.int64)
+        assert len(got) == int(ratio * n) and np.all(np.diff(got) > 0)
+        np.testing.assert_array_equal(got, draw_keep(seed, n, ratio))
+        backend_f32.free(out)
+    backend_f32.free(c)
+
+
 def test_transform_and_append(backend_f64, oracle, scan):
     nrm = scan / np.linalg.norm(scan, axis=1, keepdims=True)
     T = syn.make_pose([1.0, -2.0, 0.5], [3.0, -4.0, 25.0])
