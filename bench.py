@@ -1115,7 +1115,7 @@ def main():
                     "map_points": sh["map_points"], "final_pose_error_vs_truth": sh["final_pose_error_vs_truth"],
                     "what": "the same 200 frames with cloud_registration_type / scan_to_map_refinement_type = GeneralizedIcp and downsampling_ratio = 0.3 "
                             "(parameter_structure_definitions.lua:62,76,109) in the odometry and the mapper; the crop -> voxelize -> normals chain is "
-                            "shared up to the RandomDownSample, each worker draws its own (seeded) index list"}
+                            "shared up to the RandomDownSample, each worker draws its own (seeded) subset ON THE DEVICE (o3ds_random_down_sample: no shuffle on the host, no wait for the size)"}
             except Exception as e:  # noqa: BLE001
                 m2["shipped_configuration"] = {"error": repr(e)[:400]}
             try:
