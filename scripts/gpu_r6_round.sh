@@ -42,3 +42,10 @@ s=d["scans_per_sec"]; print({k:s[k] for k in ("scans_per_sec","mapping_only_scan
 print(d.get("m1_large_map")); print(d.get("m1_gicp"))
 print(s.get("map_insert_scan_by_map_size"))
 PY
+# the shipped configuration's stream alone: kernel stats and the dispatch sequence of a frame
+cd /tmp; rm -rf $OUT/prof_shipped
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_shipped -o s -- python $R/scripts/shipped_stream.py 100 > $OUT/shipped_stream.json 2>/dev/null
+python $R/scripts/prof_summary.py $OUT/prof_shipped/s_results.db $OUT/shipped_stats.txt > /dev/null
+python $R/scripts/prof_sequence.py $OUT/prof_shipped/s_results.db $OUT/shipped_sequence.txt 65 > /dev/null
+rm -rf $OUT/prof_shipped/*.db; tail -2 $OUT/shipped_sequence.txt
+cd $R
