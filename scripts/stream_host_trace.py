@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=60)
 ap.add_argument("--pinned", action="store_true")
 ap.add_argument("--stage-sync", action="store_true")
+ap.add_argument("--shipped", action="store_true", help="GeneralizedIcp + downsampling_ratio 0.3, as the shipped Lua")
 args = ap.parse_args()
 scans = bench.make_stream(args.frames)
 acc = collections.defaultdict(lambda: [0, 0.0])
@@ -38,8 +39,10 @@ if args.pinned:
         rec = np.zeros((len(s), 4), dtype=np.float32); rec[:, :3] = s
         p = be.pinned_records(len(s), 16); p[:] = rec.view(np.uint8).reshape(len(s), 16); pin.append(p.view(np.float32).reshape(len(s), 4))
     scans = pin
-mp, op = bench.stream_parameters()
+mp, op = bench.stream_parameters(shipped=args.shipped)
 odo = LidarOdometry(be); odo.setParameters(op); mapper = Mapper(be, odo); mapper.setParameters(mp)
+if args.shipped:
+    odo.setDownSampleSeed(71); mapper.scan2MapReg_.setDownSampleSeed(72)
 frame_t = []
 for k, raw in enumerate(scans):
     if k == 5: acc.clear()
