@@ -242,7 +242,7 @@ class SlamParams(C.Structure):
                 ("map_max_iter", C.c_int32),
                 ("builder_voxel", C.c_double), ("builder_rmin", C.c_double), ("builder_rmax", C.c_double),
                 ("carve_voxel", C.c_double), ("carve_max_length", C.c_double), ("carve_truncation", C.c_double), ("carve_min_dot", C.c_double),
-                ("carve_every_n_scans", C.c_int32), ("submap_radius", C.c_double)]
+                ("carve_every_n_scans", C.c_int32), ("submap_radius", C.c_double), ("generalized", C.c_int32)]
 
 
 class ReferenceSlam:
@@ -280,7 +280,8 @@ class ReferenceSlam:
                        mp.scanProcessing_.cropper_.croppingMaxRadius_, mi.maxCorrespondenceDistance_, mi.maxDistanceKnn_,
                        mp.scanMatcher_.minRefinementFitness_, min_movement, mi.knn_, mi.maxNumIter_,
                        mp.mapBuilder_.mapVoxelSize_, mp.mapBuilder_.cropper_.croppingMinRadius_, mp.mapBuilder_.cropper_.croppingMaxRadius_,
-                       carving[0], carving[1], carving[2], carving[3], int(carve_every_n_scans), float(submap_radius))
+                       carving[0], carving[1], carving[2], carving[3], int(carve_every_n_scans), float(submap_radius),
+                       int(getattr(mp.scanMatcher_.scanToMapRegType_, "name", "") == "GeneralizedIcp"))
         self.L = L
         self.h = L.ref_slam_create(C.byref(q))
 

@@ -363,6 +363,7 @@ struct ref_slam_params {
   double carve_voxel, carve_max_length, carve_truncation, carve_min_dot;
   int32_t carve_every_n_scans;
   double submap_radius;
+  int32_t generalized;  // 1: cloud_registration_type / scan_to_map_refinement_type = GeneralizedIcp (the shipped Lua), 0: PointToPlaneIcp
 };
 struct RefSlam {
   std::shared_ptr<o3d_slam::LidarOdometry> odometry;
@@ -386,7 +387,7 @@ void* ref_slam_create(const ref_slam_params* q) {
   op.scanProcessing_.cropper_.cropperName_ = "MinMaxRadius";
   op.scanProcessing_.cropper_.croppingMinRadius_ = q->odo_rmin;
   op.scanProcessing_.cropper_.croppingMaxRadius_ = q->odo_rmax;
-  op.scanMatcher_.regType_ = o3d_slam::CloudRegistrationType::PointToPlaneIcp;
+  op.scanMatcher_.regType_ = q->generalized ? o3d_slam::CloudRegistrationType::GeneralizedIcp : o3d_slam::CloudRegistrationType::PointToPlaneIcp;
   op.scanMatcher_.icp_.maxCorrespondenceDistance_ = q->odo_max_corr;
   op.scanMatcher_.icp_.maxDistanceKnn_ = q->odo_knn_radius;
   op.scanMatcher_.icp_.knn_ = q->odo_knn;
@@ -397,7 +398,8 @@ void* ref_slam_create(const ref_slam_params* q) {
   mp.scanProcessing_.cropper_.cropperName_ = "MinMaxRadius";
   mp.scanProcessing_.cropper_.croppingMinRadius_ = q->map_rmin;
   mp.scanProcessing_.cropper_.croppingMaxRadius_ = q->map_rmax;
-  mp.scanMatcher_.scanToMapRegType_ = o3d_slam::ScanToMapRegistrationType::PointToPlaneIcp;
+  mp.scanMatcher_.scanToMapRegType_ =
+      q->generalized ? o3d_slam::ScanToMapRegistrationType::GeneralizedIcp : o3d_slam::ScanToMapRegistrationType::PointToPlaneIcp;
   mp.scanMatcher_.minRefinementFitness_ = q->min_refinement_fitness;
   mp.scanMatcher_.icp_.maxCorrespondenceDistance_ = q->map_max_corr;
   mp.scanMatcher_.icp_.maxDistanceKnn_ = q->map_knn_radius;

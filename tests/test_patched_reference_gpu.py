@@ -118,6 +118,21 @@ def test_scans_per_second_of_the_patched_reference(record_property):
         out[name] = {"scans_per_sec": 200e3 / ms, "ms_total": ms, "map_points": n_map, "final_translation_error_m": err,
                      "ms_per_scan_busy": {k: v / 199.0 for k, v in R.ms_workers.items()}}  # each worker's own clock inside its calls
         record_property(f"patched_reference_{name}_scans_per_sec", 200e3 / ms)
+    # the same under the shipped Lua's registration type and down-sampling ratio (GeneralizedIcp, 0.3: parameter_structure_definitions.lua:62,76,109):
+    # what the patch does with [O3D] RandomDownSample (o3ds::preprocessScan draws on the device) is on this path only
+    mp_s, op_s = bench.stream_parameters(shipped=True)
+    for name, threads in (("shipped_serial", False), ("shipped_two_threads", True)):
+        warm = ref.ReferenceSlam(mp_s, op_s, patched=True)
+        warm.run_stream(scans[:8], threads=threads, lead=2)
+        warm.close()
+        R = ref.ReferenceSlam(mp_s, op_s, patched=True)
+        ok, M, O, ms, n_map = R.run_stream(scans, threads=threads, lead=2)
+        R.close()
+        rel = np.linalg.inv(truth[0]) @ truth[-1]
+        err = float(np.linalg.norm(M[-1][:3, 3] - rel[:3, 3]))
+        assert ok == 200 and err < 0.05, (ok, err)
+        out[name] = {"scans_per_sec": 200e3 / ms, "ms_total": ms, "map_points": n_map, "final_translation_error_m": err,
+                     "ms_per_scan_busy": {k: v / 199.0 for k, v in R.ms_workers.items()}}
     out["what"] = ("open3d_slam's own LidarOdometry::addRangeScan + Mapper::addRangeMeasurement (reference sources with "
                    "integration/open3d_slam_o3ds.patch applied, stand-in Eigen / PointCloud container) on libo3ds_backend.so, 200 frames x "
                    "131072 points, carving every 10th insertion as the reference does")
