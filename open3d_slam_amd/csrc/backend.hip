@@ -3288,10 +3288,14 @@ int random_down_sample_t(o3ds_handle h, const CloudRec& in, double ratio, unsign
   const size_t k_bound = (size_t)std::max(0, (int)(ratio * (double)bound));  // monotone in the size: at least the exact number
   if (bound == 0 || k_bound == 0) return O3DS_OK;
   if (bound >= ((size_t)1 << 31)) return fail(h, O3DS_ERR_INVALID_ARG, "random_down_sample: more than 2^31 points");
+  constexpr int kDrawErrSlot = 9;  // pinned word draw_pick_kernel raises when its candidate list overflowed (sticky, like DrawState::error)
   if (!h->d_draw) {
     if (hipMalloc((void**)&h->d_draw, sizeof(o3ds::DrawState)) != hipSuccess) return fail(h, O3DS_ERR_OOM, "random_down_sample: state allocation failed");
     HIP_TRY(hipMemsetAsync(h->d_draw, 0, sizeof(o3ds::DrawState), h->stream));
+    *(volatile int*)(h->h_pin + kPubOff + 16 * (size_t)kDrawErrSlot) = 0;
   }
+  if (pub_value<int>(h, kDrawErrSlot) != 0)
+    return fail(h, O3DS_ERR_CAPACITY, "random_down_sample: an earlier draw on this handle found more than 2048 keys sharing 22 leading bits and kept nothing");
   o3ds::DrawState* st = h->d_draw;
   const CountRef n_ref = count_ref(h, in);
   CountPub pub{&st->cnt_dummy, nullptr, 0};
@@ -3312,8 +3316,10 @@ int random_down_sample_t(o3ds_handle h, const CloudRec& in, double ratio, unsign
   const unsigned int g = grid_for(bound);
   draw_hist1_kernel<<<g, kBlock, 0, h->stream>>>(n_ref, seed, st);
   draw_hist2_kernel<<<g, kBlock, 0, h->stream>>>(n_ref, seed, ratio, st);
-  draw_collect_kernel<<<g, kBlock, 0, h->stream>>>(n_ref, seed, st);
-  draw_pick_kernel<<<1, kBlock, 0, h->stream>>>(st, pub);
+  // (O3DS_DRAW_LIST_CAP in the A/B library: a smaller list, so that the overflow path can be walked by a test)
+  static const unsigned int list_cap = ab_getenv("O3DS_DRAW_LIST_CAP") ? (unsigned int)std::min(atoi(ab_getenv("O3DS_DRAW_LIST_CAP")), o3ds::kDrawListCap) : (unsigned int)o3ds::kDrawListCap;
+  draw_collect_kernel<<<g, kBlock, 0, h->stream>>>(n_ref, seed, st, list_cap);
+  draw_pick_kernel<<<1, kBlock, 0, h->stream>>>(st, pub, pub_slot<int>(h, kDrawErrSlot), list_cap);
   draw_flag_kernel<<<grid_for(bound + 1), kBlock, 0, h->stream>>>(n_ref, seed, st, flags);
   int rc = exclusive_scan_int(h, flags, pos, bound + 1);
   if (rc) return rc;

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(kBlock) void draw_hist2_kernel(CountRef n_ref, unsi
     if ((unsigned int)(key >> (64 - kDrawBits)) == bin1) atomicAdd(&st->hist2[(key >> (64 - 2 * kDrawBits)) & (kDrawBins - 1)], 1u);
   }
 }
-__global__ __launch_bounds__(kBlock) void draw_collect_kernel(CountRef n_ref, unsigned long long seed, DrawState* __restrict__ st) {
+__global__ __launch_bounds__(kBlock) void draw_collect_kernel(CountRef n_ref, unsigned long long seed, DrawState* __restrict__ st, unsigned int list_cap) {
   __shared__ unsigned int s_scan[kBlock + 2];
   const int k = st->k;
   if (k <= 0) return;
@@ -246,18 +246,21 @@ __global__ __launch_bounds__(kBlock) void draw_collect_kernel(CountRef n_ref, un
     const unsigned long long key = draw_key(seed, i);
     if ((key >> (64 - 2 * kDrawBits)) == want) {
       const unsigned int at = atomicAdd(&st->list_n, 1u);
-      if (at < (unsigned)kDrawListCap) st->list[at] = key;
+      if (at < list_cap) st->list[at] = key;
     }
   }
 }
 // one workgroup: the key of rank k among the listed ones is the threshold; the count goes where the consumers and the host look for it;
 // the histograms are handed back empty
-__global__ __launch_bounds__(kBlock) void draw_pick_kernel(DrawState* __restrict__ st, CountPub pub) {
+__global__ __launch_bounds__(kBlock) void draw_pick_kernel(DrawState* __restrict__ st, CountPub pub, int* __restrict__ host_error, unsigned int list_cap) {
   const int k = st->k;
   if (k > 0) {
     const unsigned int m = st->list_n, r = (unsigned int)k - st->below1 - st->below2;  // rank inside the list, 1-based
-    if (m > (unsigned)kDrawListCap || r == 0 || r > m) {
-      if (threadIdx.x == 0) st->error = 1, st->thr = 0ull, st->k = 0;
+    if (m > list_cap || r == 0 || r > m) {  // more than 2 048 keys share 22 leading bits (their number averages n / 4 M): nothing
+      if (threadIdx.x == 0) {                              // is kept, and the handle's next draw -- or whoever asks for this size -- is told
+        st->error = 1, st->thr = 0ull, st->k = 0;
+        __hip_atomic_store(host_error, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     } else {
       for (unsigned int j = threadIdx.x; j < m; j += kBlock) {
         const unsigned long long mine = st->list[j];
@@ -271,7 +274,15 @@ __global__ __launch_bounds__(kBlock) void draw_pick_kernel(DrawState* __restrict
   for (int b = threadIdx.x; b < kDrawBins; b += kBlock) st->hist1[b] = 0u, st->hist2[b] = 0u;
   if (threadIdx.x == 0) {
     st->list_n = 0u;
-    publish_count(pub, st->error ? 0 : st->k);
+    if (st->error) {  // the consumers' word says "no points"; the host's record carries a size no cloud has (resolve_count fails on it)
+      *pub.dev = 0;
+      if (pub.host) {
+        pub.host[0] = -1;
+        __hip_atomic_store(pub.host + 1, pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    } else {
+      publish_count(pub, st->k);
+    }
   }
 }
 // flags[i] = the point is kept; flags[n_bound] = 0 (sentinel of the scan).  n_bound >= the exact size.

@@ -284,6 +284,24 @@ def test_random_down_sample_of_a_cloud_whose_size_is_in_flight(backend_f32):
     be.free(v)
 
 
+def test_random_down_sample_overflow_of_the_candidate_list_is_an_error_not_an_empty_cloud(monkeypatch):
+    """The draw lists the keys that share 22 leading bits with the k-th smallest (n / 4 M of them on average, room for 2 048).  Should
+    the list ever overflow, nothing is kept -- and that must not pass for a result: the size of a cloud whose size was in flight fails
+    to resolve, and the handle's next draw is refused.  Walked with the A/B library's O3DS_DRAW_LIST_CAP=0 (every draw overflows)."""
+    monkeypatch.setenv("O3DS_DRAW_LIST_CAP", "0")
+    be = backend.Backend(0, ab=True)
+    scene = syn.make_scene()
+    raw = np.ascontiguousarray(syn.os128_scan(scene, np.eye(4), n_az=256), dtype=np.float32)
+    r = be.upload_f32(raw)
+    v = be.crop_voxel_down_sample(r, backend.make_crop(backend.CROP_MAX_RADIUS, rmax=30.0), 0.1)
+    d = be.random_down_sample(v, 0.3, 1)  # queued: nothing has failed on the host yet
+    with pytest.raises(backend.BackendError):
+        be.size(d)
+    with pytest.raises(backend.BackendError, match="earlier draw"):
+        be.random_down_sample(v, 0.3, 2)
+    be.close()
+
+
 def test_random_down_sample_at_a_million_points_keeps_exactly_k_in_cloud_order(backend_f32):
     """size-independent properties at 2^20 + 3 points: exactly int(ratio * n) points are kept, they are the checker's, and their order
     is the cloud's (the x coordinate carries the original index)"""
