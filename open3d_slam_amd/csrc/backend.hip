@@ -3284,10 +3284,8 @@ int random_down_sample_t(o3ds_handle h, const CloudRec& in, double ratio, unsign
   out.precision = in.precision;
   out.n = 0;
   box_copy(out, in);  // a subset
-  const size_t bound = in.n;  // (an upper bound when the input's size is still in flight)
-  const size_t k_bound = (size_t)std::max(0, (int)(ratio * (double)bound));  // monotone in the size: at least the exact number
-  if (bound == 0 || k_bound == 0) return O3DS_OK;
-  if (bound >= ((size_t)1 << 31)) return fail(h, O3DS_ERR_INVALID_ARG, "random_down_sample: more than 2^31 points");
+  if (in.n == 0 || (int)(ratio * (double)in.n) <= 0) return O3DS_OK;  // (k is monotone in the size: nothing is kept of the bound, nothing of the exact size)
+  if (in.n >= ((size_t)1 << 31)) return fail(h, O3DS_ERR_INVALID_ARG, "random_down_sample: more than 2^31 points");
   constexpr int kDrawErrSlot = 9;  // pinned word draw_pick_kernel raises when its candidate list overflowed (sticky, like DrawState::error)
   if (!h->d_draw) {
     if (hipMalloc((void**)&h->d_draw, sizeof(o3ds::DrawState)) != hipSuccess) return fail(h, O3DS_ERR_OOM, "random_down_sample: state allocation failed");
@@ -3297,16 +3295,24 @@ int random_down_sample_t(o3ds_handle h, const CloudRec& in, double ratio, unsign
   if (pub_value<int>(h, kDrawErrSlot) != 0)
     return fail(h, O3DS_ERR_CAPACITY, "random_down_sample: an earlier draw on this handle found more than 2048 keys sharing 22 leading bits and kept nothing");
   o3ds::DrawState* st = h->d_draw;
-  const CountRef n_ref = count_ref(h, in);
   CountPub pub{&st->cnt_dummy, nullptr, 0};
   if (in.lazy_slot >= 0) {  // the number kept follows the input's: published like a VoxelDownSample's
+    // (the record FIRST: with all of them held, take_rec settles the oldest holder -- possibly `in`, whose size is exact from then on and
+    // whose device word may be the very record handed out here; everything below reads `in` as it is afterwards)
     out.lazy_slot = take_rec(h);
     if (out.lazy_slot < 0) return fail(h, O3DS_ERR_CAPACITY, "random_down_sample: no record free for the size of the result");
     out.lazy_seq = ++h->rec_seq;
-    out.n_lower = (size_t)std::max(0, (int)(ratio * (double)in.n_lower));
     pub = CountPub{cnt_word(h, out.lazy_slot), &(h->h_rec_dev + out.lazy_slot)->cnt, out.lazy_seq};
   }
+  const size_t bound = in.n;  // (an upper bound while the input's size is in flight)
+  const size_t k_bound = (size_t)std::max(0, (int)(ratio * (double)bound));  // monotone in the size: at least the exact number
+  const CountRef n_ref = count_ref(h, in);
   out.n = k_bound;
+  out.n_lower = in.lazy_slot >= 0 ? (size_t)std::max(0, (int)(ratio * (double)in.n_lower)) : k_bound;
+  if (k_bound == 0) {  // (the settled size keeps nothing)
+    if (out.lazy_slot >= 0) h->rec_owner[out.lazy_slot] = 0, out.lazy_slot = -1;
+    return O3DS_OK;
+  }
   int *flags = nullptr, *pos = nullptr;
   TMP_ALLOC(flags, sizeof(int) * (bound + 1));
   TMP_ALLOC(pos, sizeof(int) * (bound + 1));
@@ -3314,10 +3320,11 @@ int random_down_sample_t(o3ds_handle h, const CloudRec& in, double ratio, unsign
   if (in.nrm) HIP_TRY(dev_alloc(h, (void**)&out.nrm, sizeof(P4) * k_bound));
   if (in.col) HIP_TRY(dev_alloc(h, (void**)&out.col, sizeof(P4) * k_bound));
   const unsigned int g = grid_for(bound);
+  // (O3DS_DRAW_LIST_CAP in the A/B library: a smaller list, so that the overflow path can be walked by a test)
+  static const unsigned int list_cap =
+      ab_getenv("O3DS_DRAW_LIST_CAP") ? (unsigned int)std::min(atoi(ab_getenv("O3DS_DRAW_LIST_CAP")), o3ds::kDrawListCap) : (unsigned int)o3ds::kDrawListCap;
   draw_hist1_kernel<<<g, kBlock, 0, h->stream>>>(n_ref, seed, st);
   draw_hist2_kernel<<<g, kBlock, 0, h->stream>>>(n_ref, seed, ratio, st);
-  // (O3DS_DRAW_LIST_CAP in the A/B library: a smaller list, so that the overflow path can be walked by a test)
-  static const unsigned int list_cap = ab_getenv("O3DS_DRAW_LIST_CAP") ? (unsigned int)std::min(atoi(ab_getenv("O3DS_DRAW_LIST_CAP")), o3ds::kDrawListCap) : (unsigned int)o3ds::kDrawListCap;
   draw_collect_kernel<<<g, kBlock, 0, h->stream>>>(n_ref, seed, st, list_cap);
   draw_pick_kernel<<<1, kBlock, 0, h->stream>>>(st, pub, pub_slot<int>(h, kDrawErrSlot), list_cap);
   draw_flag_kernel<<<grid_for(bound + 1), kBlock, 0, h->stream>>>(n_ref, seed, st, flags);
