@@ -15,9 +15,9 @@ import bench  # noqa: E402
 from oracle import ref  # noqa: E402
 import test_patched_reference_gpu as T  # noqa: E402
 
-frames = min(int(sys.argv[1]) if len(sys.argv) > 1 else 200, 200)  # (the trajectory has 200 poses)
-repeats = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-mp, op = bench.stream_parameters()
+frames = min(int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 200, 200)  # (the trajectory has 200 poses)
+repeats = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 3
+mp, op = bench.stream_parameters(shipped=("shipped" in sys.argv))
 scans, truth = T._scans(frames)
 warm = ref.ReferenceSlam(mp, op, patched=True)
 warm.run_stream(scans[:8])
