@@ -422,11 +422,15 @@ def run_stream(be, scans32, profile=False, stage_sync=True, pinned=True, prefetc
     return out
 
 
-def run_stream_pipelined(device, scans32, depth=4):
+def run_stream_pipelined(device, scans32, depth=4, share=False, drain=True):
     """the same frames with odometry and mapping on two host threads, as the reference runs them (SlamWrapper.cpp:228-229 odometryWorker /
     mappingWorker, a bounded buffer between them): LidarOdometry on one backend handle (its own stream), Mapper on another, each ingesting
     the raw scan into its own handle (handles do not share clouds).  The mapper only reads the odometry pose of a frame that is already
-    through, so the poses are those of the serial loop, bit for bit (checked by the caller)."""
+    through, so the poses are those of the serial loop, bit for bit (checked by the caller).
+    share: the mapper's handle takes the raw scan and its pre-processed version from VIEWS the odometry worker exports (o3ds_cloud_export_view /
+    _import_view: device-to-device copies behind an event, nothing of the other handle is touched) instead of ingesting and pre-processing the
+    scan a second time -- what integration/o3ds_open3d_slam.hpp does between the reference's two workers.
+    drain=False: no stream drain at the end of a worker's frame (the registrations hand their results back, nothing else waits)."""
     import queue
     import threading
 
@@ -444,15 +448,49 @@ def run_stream_pipelined(device, scans32, depth=4):
     q = queue.Queue(maxsize=depth)
     err = []
 
+    done = queue.Queue()  # share: (cloud on the odometry handle, its views) the mapper has finished copying from
+
+    def drain_done(block=False):
+        while True:
+            try:
+                cloud, views = done.get(block) if block else done.get_nowait()
+            except queue.Empty:
+                return
+            for v in views:
+                be_o.release_view(v)
+            cloud.release()
+            block = False
+
+    # (share: the odometry worker takes its scans as run_stream does -- page-locked records, the next scan ingested and pre-processed
+    # behind the registration of this one, o3ds_icp_overlap_next)
+    records = stage_scans(be_o, scans32, True) if share else scans32
+
     def odometry_worker():
         try:
-            for k, raw in enumerate(scans32):
-                cloud = PointCloud.from_pointcloud2(be_o, raw)
+            nxt = None
+            for k, raw in enumerate(records):
+                if share:
+                    cloud = nxt if nxt is not None else PointCloud.from_pointcloud2(be_o, raw)
+                    nxt = PointCloud.from_pointcloud2(be_o, records[k + 1]) if k + 1 < len(records) else None
+                    if nxt is not None:
+                        be_o.overlap_next = (lambda c=nxt: odo.preprocessAhead(c))
+                else:
+                    cloud = PointCloud.from_pointcloud2(be_o, raw)
                 ok = odo.addRangeScan(cloud, 0.1 * k)
-                be_o.synchronize()
-                cloud.release()
+                if be_o.overlap_next is not None:  # no registration took it (the first scan)
+                    be_o.overlap_next = None
+                if drain:
+                    be_o.synchronize()
                 assert ok, k
-                q.put(k)
+                if share:  # views of the raw scan and of what the pre-processing made of it; the clouds live until the mapper has copied
+                    memo = dict(cloud._pre_memo or {})
+                    views = {key: be_o.export_view(v.id) for key, v in memo.items()}
+                    raw_view = be_o.export_view(cloud.id)
+                    q.put((k, raw_view, views, cloud))
+                    drain_done()
+                else:
+                    cloud.release()
+                    q.put(k)
         except BaseException as e:  # noqa: BLE001 -- handed to the main thread
             err.append(e)
             q.put(-1)
@@ -463,19 +501,30 @@ def run_stream_pipelined(device, scans32, depth=4):
     th.start()
     frames = len(scans32)
     for _ in range(frames):
-        k = q.get()
-        if k < 0:
+        item = q.get()
+        if item == -1:
             raise err[0]
-        cloud = PointCloud.from_pointcloud2(be_m, scans32[k])
+        if share:
+            k, raw_view, views, theirs = item
+            cloud = PointCloud(be_m, be_m.import_view(raw_view))
+            cloud._pre_memo = {key: PointCloud(be_m, be_m.import_view(v)) for key, v in views.items()}
+        else:
+            k = item
+            cloud = PointCloud.from_pointcloud2(be_m, scans32[k])
         ok = mapper.addRangeMeasurement(cloud, 0.1 * k)
-        be_m.synchronize()
+        if drain:
+            be_m.synchronize()
         cloud.release()
+        if share:  # (the copies are done -- they were queued in front of a registration whose result is here: the odometry worker may free what they were made from)
+            done.put((theirs, [raw_view] + list(views.values())))
         assert ok, k
         per_frame.append(mapper.getMapToRangeSensor().copy())
         if k == 0:  # frame 0 only initialises (as in run_stream)
             t_start = time.perf_counter()
+    be_m.synchronize()
     elapsed = time.perf_counter() - t_start
     th.join()
+    drain_done()
     out = {"scans_per_sec": (frames - 1) / elapsed, "pose": mapper.getMapToRangeSensor().copy(), "poses_per_frame": per_frame,
            "odometry_poses_per_frame": [T.copy() for _, T in odo.odomToRangeSensorBuffer_],
            "map_points": len(mapper.getActiveSubmap().getMapPointCloud())}
@@ -641,6 +690,7 @@ def compact_line(out, detail_path=None):
             "patched_reference_two_threads": _num(((m2.get("patched_reference") or {}).get("two_threads") or {}).get("scans_per_sec")),
             "shipped_configuration": _num((m2.get("shipped_configuration") or {}).get("scans_per_sec")),
             "pipelined": _num((m2.get("pipelined") or {}).get("scans_per_sec")),
+            "two_workers": _num((m2.get("two_workers") or {}).get("scans_per_sec")),
             "pageable_ingest": _num((m2.get("pageable_ingest_at_frame_start") or {}).get("scans_per_sec")),
             "cpu_baseline": _pick(m2.get("cpu_baseline") or {}, "value", "unit", "cores", "kind"),
             "parity_vs_cpu": _pick(m2.get("parity_vs_cpu") or {}, "frames_compared", "worst_dt_m", "worst_dr_rad", "within_stated_tolerance"),
@@ -1101,6 +1151,18 @@ def main():
                 m2["pipelined"] = {"scans_per_sec": pl["scans_per_sec"], "map_points": pl["map_points"],
                                    "pose_equals_serial_bitwise": bool(np.array_equal(m2["pose"], pl["pose"])),
                                    "what": "odometry and mapping on two host threads and two backend handles (SlamWrapper.cpp:228-229), raw scan ingested by both"}
+                # ... and with the hand-over the integration header has between the reference's two workers: the mapper's handle copies
+                # the raw scan and its pre-processed version from views the odometry worker exported, the odometry worker takes its
+                # scans as the one-handle loop does (page-locked records, the next scan pre-processed behind this one's registration)
+                run_stream_pipelined(local_rank, scans32[: min(12, len(scans32))], share=True, drain=False)
+                ps = run_stream_pipelined(local_rank, scans32, share=True, drain=False)
+                same = len(ps["poses_per_frame"]) == len(m2["poses_per_frame"]) and all(
+                    np.array_equal(a, b) for a, b in zip(ps["poses_per_frame"], m2["poses_per_frame"]))
+                m2["two_workers"] = {"scans_per_sec": ps["scans_per_sec"], "map_points": ps["map_points"], "every_pose_equals_the_one_handle_run_bitwise": bool(same),
+                                     "what": "odometry and mapping on two host threads and two backend handles; the mapper's handle takes the raw scan and "
+                                             "its pre-processed version through o3ds_cloud_export_view / _import_view (device-to-device copies behind an "
+                                             "event), nothing is ingested or pre-processed twice; no stream drains (each worker waits only for its own "
+                                             "registrations' results)"}
             except Exception as e:  # noqa: BLE001
                 m2["pipelined"] = {"error": repr(e)}
             try:  # the stream as the shipped Lua configures it: GeneralizedIcp in both workers, downsampling_ratio 0.3 (seeded index lists)

@@ -292,3 +292,24 @@ def test_the_gates_of_the_loop_follow_the_oracle_loop(backend_f64, oracle):
         assert len(mapper.getActiveSubmap().getMapPointCloud()) == len(O.map_p), k
         assert max(*syn.se3_error(mapper.getMapToRangeSensor(), O.T)) < 1e-6, k
     assert (True, False) in seen and (False, None) in seen and O.n_not_inserted >= 2
+
+
+@pytest.mark.gpu
+def test_two_workers_sharing_through_views_reproduce_the_one_handle_stream_bit_for_bit():
+    """bench.run_stream_pipelined(share=True): odometry and mapping on two host threads and two handles, the mapper's handle taking the raw
+    scan and its pre-processed version from views the odometry worker exported (o3ds_cloud_export_view / _import_view) -- as the
+    integration header does between the reference's two workers (SlamWrapper.cpp:228-229).  Whatever the threads' timing, every pose of
+    every frame is the one-handle loop's, bit for bit; with and without the stream drains, carving frames included (30 frames)."""
+    import bench
+    from open3d_slam_amd import backend
+
+    scans = bench.make_stream(30)
+    be = backend.Backend(0)
+    ref = bench.run_stream(be, scans)
+    be.close()
+    for drain in (True, False):
+        got = bench.run_stream_pipelined(0, scans, share=True, drain=drain)
+        assert got["map_points"] == ref["map_points"]
+        assert len(got["poses_per_frame"]) == len(ref["poses_per_frame"]) == 30
+        for k, (a, b) in enumerate(zip(got["poses_per_frame"], ref["poses_per_frame"])):
+            assert np.array_equal(a, b), (drain, k, float(np.abs(a - b).max()))
