@@ -422,7 +422,7 @@ def run_stream(be, scans32, profile=False, stage_sync=True, pinned=True, prefetc
     return out
 
 
-def run_stream_pipelined(device, scans32, depth=4, share=False, drain=True):
+def run_stream_pipelined(device, scans32, depth=4, share=False, drain=True, shipped=False):
     """the same frames with odometry and mapping on two host threads, as the reference runs them (SlamWrapper.cpp:228-229 odometryWorker /
     mappingWorker, a bounded buffer between them): LidarOdometry on one backend handle (its own stream), Mapper on another, each ingesting
     the raw scan into its own handle (handles do not share clouds).  The mapper only reads the odometry pose of a frame that is already
@@ -439,12 +439,15 @@ def run_stream_pipelined(device, scans32, depth=4, share=False, drain=True):
     from open3d_slam_amd.odometry import LidarOdometry
     from open3d_slam_amd.pointcloud import PointCloud
 
-    mp, op = stream_parameters()
+    mp, op = stream_parameters(shipped=shipped)
     be_o, be_m = backend.Backend(device), backend.Backend(device)
     odo = LidarOdometry(be_o)
     odo.setParameters(op)
     mapper = Mapper(be_m, odo)
     mapper.setParameters(mp)
+    if shipped:  # (the seeds of run_stream's shipped leg: the same draws, the same poses)
+        odo.setDownSampleSeed(1001)
+        mapper.scan2MapReg_.setDownSampleSeed(1002)
     q = queue.Queue(maxsize=depth)
     err = []
 
@@ -691,6 +694,7 @@ def compact_line(out, detail_path=None):
             "shipped_configuration": _num((m2.get("shipped_configuration") or {}).get("scans_per_sec")),
             "pipelined": _num((m2.get("pipelined") or {}).get("scans_per_sec")),
             "two_workers": _num((m2.get("two_workers") or {}).get("scans_per_sec")),
+            "shipped_configuration_two_workers": _num((m2.get("shipped_configuration") or {}).get("two_workers_scans_per_sec")),
             "pageable_ingest": _num((m2.get("pageable_ingest_at_frame_start") or {}).get("scans_per_sec")),
             "cpu_baseline": _pick(m2.get("cpu_baseline") or {}, "value", "unit", "cores", "kind"),
             "parity_vs_cpu": _pick(m2.get("parity_vs_cpu") or {}, "frames_compared", "worst_dt_m", "worst_dr_rad", "within_stated_tolerance"),
@@ -1172,7 +1176,11 @@ def main():
                 be2 = backend.Backend(local_rank)
                 sh = run_stream(be2, scans32, shipped=True)
                 be2.close()
+                run_stream_pipelined(local_rank, scans32[: min(12, len(scans32))], share=True, drain=False, shipped=True)
+                sh2 = run_stream_pipelined(local_rank, scans32, share=True, drain=False, shipped=True)
+                same2 = len(sh2["poses_per_frame"]) == len(sh["poses_per_frame"]) and all(np.array_equal(a, b) for a, b in zip(sh2["poses_per_frame"], sh["poses_per_frame"]))
                 m2["shipped_configuration"] = {
+                    "two_workers_scans_per_sec": sh2["scans_per_sec"], "two_workers_every_pose_equals_the_one_handle_run_bitwise": bool(same2),
                     "scans_per_sec": sh["scans_per_sec"], "mapping_only_scans_per_sec": sh["mapping_only_scans_per_sec"], "ms_per_scan": sh["ms_per_scan"],
                     "map_points": sh["map_points"], "final_pose_error_vs_truth": sh["final_pose_error_vs_truth"],
                     "what": "the same 200 frames with cloud_registration_type / scan_to_map_refinement_type = GeneralizedIcp and downsampling_ratio = 0.3 "
