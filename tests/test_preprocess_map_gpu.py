@@ -284,31 +284,40 @@ def test_random_down_sample_of_a_cloud_whose_size_is_in_flight(backend_f32):
     be.free(v)
 
 
-def test_random_down_sample_when_every_size_record_is_held(backend_f32):
+def test_random_down_sample_when_every_size_record_is_held():
     """Sixty-four clouds whose sizes are in flight hold all of the handle's records; the draw's own record is then made by settling the
     oldest holder -- here the very cloud that is drawn from, whose device word is the record the result inherits.  The draw must read the
     input as it is AFTER that (its size exact, no device word), not through the word its own last kernel overwrites."""
     from oracle.pipeline import draw_keep
 
-    be = backend_f32
+    be = backend.Backend(0)  # (a handle of its own: which record is the oldest depends on everything the handle has done before)
     scene = syn.make_scene()
     raw = np.ascontiguousarray(syn.os128_scan(scene, np.eye(4), n_az=128), dtype=np.float32)  # 16 384 points
     crop = backend.make_crop(backend.CROP_MAX_RADIUS, rmax=30.0)
-    ref = be.crop_voxel_down_sample(be.upload_f32(raw), crop, 0.1)
+    r0 = be.upload_f32(raw)
+    ref = be.crop_voxel_down_sample(r0, crop, 0.1)
     ref_p, _ = be.download(ref)
+    be.free(r0)
     big = be.upload(np.random.default_rng(5).uniform(-15.0, 15.0, (4_000_000, 3)))
-    raws = [be.upload_f32(raw) for _ in range(64)]
-    be.synchronize()
-    for _ in range(60):  # a backlog: none of the sizes below can have reached the host when the draw is made
-        be.free(be.transform_cloud(big, np.eye(4)))
-    lazy = [be.crop_voxel_down_sample(r, crop, 0.1) for r in raws]
-    assert be.size_bound(lazy[0])[1] == len(raw)  # the premise: still the bound
-    d = be.random_down_sample(lazy[0], 0.5, 3)
     keep = draw_keep(3, len(ref_p), 0.5)
-    p, _ = be.download(d)
-    np.testing.assert_array_equal(p, ref_p[keep])
-    for x in [ref, big, d] + raws + lazy:
+    in_flight = []
+    for attempt in range(3):  # (the first pass also fills the handle's block pool: an allocation from the driver waits for the device)
+        raws = [be.upload_f32(raw) for _ in range(64)]
+        be.synchronize()
+        for _ in range(60):  # a backlog: none of the sizes below can have reached the host when the draw is made
+            be.free(be.transform_cloud(big, np.eye(4)))
+        lazy = [be.crop_voxel_down_sample(r, crop, 0.1) for r in raws]
+        in_flight.append(be.size_bound(lazy[0])[1] == len(raw))  # still the bound?
+        d = be.random_down_sample(lazy[0], 0.5, 3)
+        p, _ = be.download(d)
+        np.testing.assert_array_equal(p, ref_p[keep])
+        for x in [d] + raws + lazy:
+            be.free(x)
+    for x in (ref, big):
         be.free(x)
+    be.close()
+    if not any(in_flight):
+        pytest.skip("the sizes reached the host before the draw in every attempt: the case was not reached on this machine (the draws were right)")
 
 
 def test_random_down_sample_overflow_of_the_candidate_list_is_an_error_not_an_empty_cloud(monkeypatch):
