@@ -3321,8 +3321,9 @@ int random_down_sample_t(o3ds_handle h, const CloudRec& in, double ratio, unsign
   if (in.col) HIP_TRY(dev_alloc(h, (void**)&out.col, sizeof(P4) * k_bound));
   const unsigned int g = grid_for(bound);
   // (O3DS_DRAW_LIST_CAP in the A/B library: a smaller list, so that the overflow path can be walked by a test)
-  static const unsigned int list_cap =
-      ab_getenv("O3DS_DRAW_LIST_CAP") ? (unsigned int)std::min(atoi(ab_getenv("O3DS_DRAW_LIST_CAP")), o3ds::kDrawListCap) : (unsigned int)o3ds::kDrawListCap;
+  // (read at every call, not once per process: the test that sets it shares its process with tests that draw before it)
+  const char* cap_env = ab_getenv("O3DS_DRAW_LIST_CAP");
+  const unsigned int list_cap = cap_env ? (unsigned int)std::max(0, std::min(atoi(cap_env), o3ds::kDrawListCap)) : (unsigned int)o3ds::kDrawListCap;
   draw_hist1_kernel<<<g, kBlock, 0, h->stream>>>(n_ref, seed, st);
   draw_hist2_kernel<<<g, kBlock, 0, h->stream>>>(n_ref, seed, ratio, st);
   draw_collect_kernel<<<g, kBlock, 0, h->stream>>>(n_ref, seed, st, list_cap);
