@@ -3295,22 +3295,21 @@ int random_down_sample_t(o3ds_handle h, const CloudRec& in, double ratio, unsign
   if (pub_value<int>(h, kDrawErrSlot) != 0)
     return fail(h, O3DS_ERR_CAPACITY, "random_down_sample: an earlier draw on this handle found more than 2048 keys sharing 22 leading bits and kept nothing");
   o3ds::DrawState* st = h->d_draw;
-  CountPub pub{&st->cnt_dummy, nullptr, 0};
-  if (in.lazy_slot >= 0) {  // the number kept follows the input's: published like a VoxelDownSample's
-    // (the record FIRST: with all of them held, take_rec settles the oldest holder -- possibly `in`, whose size is exact from then on and
-    // whose device word may be the very record handed out here; everything below reads `in` as it is afterwards)
-    out.lazy_slot = take_rec(h);
-    if (out.lazy_slot < 0) return fail(h, O3DS_ERR_CAPACITY, "random_down_sample: no record free for the size of the result");
-    out.lazy_seq = ++h->rec_seq;
-    pub = CountPub{cnt_word(h, out.lazy_slot), &(h->h_rec_dev + out.lazy_slot)->cnt, out.lazy_seq};
-  }
+  // The number kept is published like a VoxelDownSample's -- also when the input's size is known and the host could compute it: the record
+  // is how a draw that failed on the device (draw_pick_kernel) reaches whoever asks for the result's size.
+  // (the record FIRST: with all of them held, take_rec settles the oldest holder -- possibly `in`, whose size is exact from then on and
+  // whose device word may be the very record handed out here; everything below reads `in` as it is afterwards)
+  out.lazy_slot = take_rec(h);
+  if (out.lazy_slot < 0) return fail(h, O3DS_ERR_CAPACITY, "random_down_sample: no record free for the size of the result");
+  out.lazy_seq = ++h->rec_seq;
+  const CountPub pub{cnt_word(h, out.lazy_slot), &(h->h_rec_dev + out.lazy_slot)->cnt, out.lazy_seq};
   const size_t bound = in.n;  // (an upper bound while the input's size is in flight)
   const size_t k_bound = (size_t)std::max(0, (int)(ratio * (double)bound));  // monotone in the size: at least the exact number
   const CountRef n_ref = count_ref(h, in);
   out.n = k_bound;
   out.n_lower = in.lazy_slot >= 0 ? (size_t)std::max(0, (int)(ratio * (double)in.n_lower)) : k_bound;
   if (k_bound == 0) {  // (the settled size keeps nothing)
-    if (out.lazy_slot >= 0) h->rec_owner[out.lazy_slot] = 0, out.lazy_slot = -1;
+    h->rec_owner[out.lazy_slot] = 0, out.lazy_slot = -1;
     return O3DS_OK;
   }
   int *flags = nullptr, *pos = nullptr;

@@ -162,7 +162,6 @@ struct DrawState {  // one per handle; hist1 / hist2 / list_n are zero between c
   unsigned int bin1, below1, bin2, below2; // the bin of the k-th smallest key at each level, and the keys below it
   unsigned long long thr;                  // k > 0: keys <= thr are kept
   int error;                               // sticky: the listed sub-bin overflowed (it holds n / 4 M keys on average)
-  int cnt_dummy;                           // where the count goes when the host knows it already
 };
 __host__ __device__ __forceinline__ unsigned long long draw_key(unsigned long long seed, unsigned long long i) {
   unsigned long long z = seed + (i + 1ull) * 0x9E3779B97F4A7C15ull;
