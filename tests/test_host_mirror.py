@@ -293,3 +293,67 @@ def test_a_cloud_seen_to_hold_points_is_not_asked_again_until_points_are_taken_f
     assert c.IsEmpty() and be.asked == 7  # upper bound 0: empty without asking for the exact size
     be.bounds = (3, 50)
     assert not c.IsEmpty() and be.asked == 8 and not c.IsEmpty() and be.asked == 8
+
+
+def test_random_down_sample_in_the_mirror_asks_the_device_to_draw_and_never_for_the_size(monkeypatch):
+    """pointcloud.random_down_sample ([O3D] RandomDownSample at Odometry.cpp:29 / ScanToMapRegistration.cpp:39): under the default reading
+    of SelectByIndex one 64-bit seed per call goes to o3ds_random_down_sample -- the cloud's size is not asked for (it may be in flight), no
+    index list is made; the seeds are the caller's generator's, so two mirrors with the same seed name the same subsets, and the oracle
+    loop's _down draws the same seed from the same generator.  ratio >= 1 keeps the cloud itself; the shuffled-order reading still goes
+    through the host's permutation and o3ds_select_by_index."""
+    from open3d_slam_amd import pointcloud
+    from open3d_slam_amd.pointcloud import PointCloud, random_down_sample
+    from oracle.pipeline import OracleLoop
+
+    class Be:
+        h = None
+
+        def __init__(self):
+            self.calls = []
+
+        def random_down_sample(self, cid, ratio, seed):
+            self.calls.append(("draw", cid, ratio, seed))
+            return 100 + len(self.calls)
+
+        def select_by_index(self, cid, idx):
+            self.calls.append(("select", cid, len(idx)))
+            return 200 + len(self.calls)
+
+        def size(self, cid):
+            self.calls.append(("size", cid))
+            return 1000, False
+
+        def size_bound(self, cid):
+            self.calls.append(("size_bound", cid))
+            return 0, 1000
+
+        def free(self, cid):
+            self.calls.append(("free", cid))
+
+    monkeypatch.setattr(pointcloud, "SELECT_BY_INDEX_KEEPS_CLOUD_ORDER", True)
+    be = Be()
+    rng = np.random.default_rng(71)
+    c = PointCloud(be, 7)
+    assert random_down_sample(c, 1.0, rng) is c and be.calls == []
+    out = random_down_sample(c, 0.3, rng)
+    assert [x[0] for x in be.calls] == ["draw", "free"] and be.calls[0][1:3] == (7, 0.3) and out.id == 101
+    seeds = [be.calls[0][3]]
+    c2 = PointCloud(be, 8)
+    random_down_sample(c2, 0.3, rng)
+    seeds.append(be.calls[2][3])
+    want = np.random.default_rng(71)
+    assert seeds == [int(want.integers(0, 2**64, dtype=np.uint64)) for _ in range(2)] and seeds[0] != seeds[1]
+    # the oracle loop draws the same seeds from the same generator (and applies them to whatever cloud it is handed)
+    loop = OracleLoop.__new__(OracleLoop)
+    loop.select_by_index_keeps_cloud_order, loop.shuffle_at_full_ratio = True, False
+    from oracle.pipeline import draw_keep
+
+    v = np.arange(3000.0).reshape(1000, 3)
+    g = np.random.default_rng(71)
+    got_v, _ = loop._down(v, -v, 0.3, g)
+    np.testing.assert_array_equal(got_v, v[draw_keep(seeds[0], 1000, 0.3)])
+    # the other reading of SelectByIndex: the shuffled list itself, made on the host from the exact size
+    monkeypatch.setattr(pointcloud, "SELECT_BY_INDEX_KEEPS_CLOUD_ORDER", False)
+    be.calls.clear()
+    random_down_sample(PointCloud(be, 9), 0.3, np.random.default_rng(5))
+    assert [x[0] for x in be.calls] == ["size", "select", "free"] and be.calls[1][2] == 300
