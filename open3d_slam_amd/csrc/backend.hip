@@ -1190,6 +1190,13 @@ inline QuantumTable quantum_table(const IcpPassArgs& a) {
 }
 
 // ---- ICP launch helpers -------------------------------------------------------------------------
+// threads per workgroup of the pass kernels (4 lanes per query): every form of the pass uses the same number, so that the queries are
+// partitioned into the same batches -- a batch's record is one rounded f64 reduction -- and the forms agree bit for bit
+#ifndef O3DS_ICP_BLOCK
+#define O3DS_ICP_BLOCK 512
+#endif
+constexpr int kIcpBlock = O3DS_ICP_BLOCK, kIcpQ = kIcpBlock / 4;
+
 template <typename P4>
 void launch_accumulate(o3ds_handle h, const IcpPassArgs& a, bool crop, int nblocks) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1208,29 +1215,30 @@ void launch_accumulate(o3ds_handle h, const IcpPassArgs& a, bool crop, int nbloc
       (void)hipEventRecord(e0, h->stream);
     }
   }
-  // one geometry: 256 threads = 64 queries x 4 lanes (G = 2 / 8 and 512-thread variants were swept and dropped)
+  // one geometry: kIcpBlock threads = kIcpBlock / 4 queries x 4 lanes (G = 2 / 8 were swept and dropped; 512 threads against 256: a launch costs 2.7 ns per
+  // workgroup beyond the first 256 -- scripts/ubench/launch_shape.hip -- and a steady pass is 9.7 us instead of 10.2)
   if (a.keys_mode != 0) {  // target-sharded registration (o3ds_icp_nn_keys / o3ds_icp_accumulate_keys): the instantiation with the key code
     if (h->session_method == O3DS_ICP_GENERALIZED) {
       if (crop)
-        icp_accumulate_kernel<P4, true, 256, 4, true, true><<<nblocks, 256, 0, h->stream>>>(a);
+        icp_accumulate_kernel<P4, true, kIcpBlock, 4, true, true><<<nblocks, kIcpBlock, 0, h->stream>>>(a);
       else
-        icp_accumulate_kernel<P4, false, 256, 4, true, true><<<nblocks, 256, 0, h->stream>>>(a);
+        icp_accumulate_kernel<P4, false, kIcpBlock, 4, true, true><<<nblocks, kIcpBlock, 0, h->stream>>>(a);
     } else {
       if (crop)
-        icp_accumulate_kernel<P4, true, 256, 4, false, true><<<nblocks, 256, 0, h->stream>>>(a);
+        icp_accumulate_kernel<P4, true, kIcpBlock, 4, false, true><<<nblocks, kIcpBlock, 0, h->stream>>>(a);
       else
-        icp_accumulate_kernel<P4, false, 256, 4, false, true><<<nblocks, 256, 0, h->stream>>>(a);
+        icp_accumulate_kernel<P4, false, kIcpBlock, 4, false, true><<<nblocks, kIcpBlock, 0, h->stream>>>(a);
     }
   } else if (h->session_method == O3DS_ICP_GENERALIZED) {
     if (crop)
-      icp_accumulate_kernel<P4, true, 256, 4, true><<<nblocks, 256, 0, h->stream>>>(a);
+      icp_accumulate_kernel<P4, true, kIcpBlock, 4, true><<<nblocks, kIcpBlock, 0, h->stream>>>(a);
     else
-      icp_accumulate_kernel<P4, false, 256, 4, true><<<nblocks, 256, 0, h->stream>>>(a);
+      icp_accumulate_kernel<P4, false, kIcpBlock, 4, true><<<nblocks, kIcpBlock, 0, h->stream>>>(a);
   } else {
     if (crop)
-      icp_accumulate_kernel<P4, true, 256, 4, false><<<nblocks, 256, 0, h->stream>>>(a);
+      icp_accumulate_kernel<P4, true, kIcpBlock, 4, false><<<nblocks, kIcpBlock, 0, h->stream>>>(a);
     else
-      icp_accumulate_kernel<P4, false, 256, 4, false><<<nblocks, 256, 0, h->stream>>>(a);
+      icp_accumulate_kernel<P4, false, kIcpBlock, 4, false><<<nblocks, kIcpBlock, 0, h->stream>>>(a);
   }
   if (e1) (void)hipEventRecord(e1, h->stream);
 }
@@ -1263,26 +1271,26 @@ void launch_fused(o3ds_handle h, const IcpFusedArgs& fa, bool crop, int nblocks,
   }
   if (h->session_method == O3DS_ICP_GENERALIZED) {
     if (crop)
-      icp_fused_kernel<P4, true, 256, 4, true><<<nblocks, 256, 0, h->stream>>>(fa.state_in, fa.slots_in, fa.first, fa);
+      icp_fused_kernel<P4, true, kIcpBlock, 4, true><<<nblocks, kIcpBlock, 0, h->stream>>>(fa.state_in, fa.slots_in, fa.first, fa);
     else
-      icp_fused_kernel<P4, false, 256, 4, true><<<nblocks, 256, 0, h->stream>>>(fa.state_in, fa.slots_in, fa.first, fa);
+      icp_fused_kernel<P4, false, kIcpBlock, 4, true><<<nblocks, kIcpBlock, 0, h->stream>>>(fa.state_in, fa.slots_in, fa.first, fa);
   } else {
     if (crop)
-      icp_fused_kernel<P4, true, 256, 4, false><<<nblocks, 256, 0, h->stream>>>(fa.state_in, fa.slots_in, fa.first, fa);
+      icp_fused_kernel<P4, true, kIcpBlock, 4, false><<<nblocks, kIcpBlock, 0, h->stream>>>(fa.state_in, fa.slots_in, fa.first, fa);
     else
-      icp_fused_kernel<P4, false, 256, 4, false><<<nblocks, 256, 0, h->stream>>>(fa.state_in, fa.slots_in, fa.first, fa);
+      icp_fused_kernel<P4, false, kIcpBlock, 4, false><<<nblocks, kIcpBlock, 0, h->stream>>>(fa.state_in, fa.slots_in, fa.first, fa);
   }
   if (e1) (void)hipEventRecord(e1, h->stream);
 }
 
-// the fused kernel serves ONE batch of 64 queries per workgroup (no batch loop: icp_pass_body, kSingle); its records go to slot
-// blockIdx % kFusedSlots, so the grid has no capacity to respect
+// the fused kernel serves ONE batch of kIcpQ queries per workgroup (no batch loop: icp_pass_body, kSingle); its records go to slot
+// blockIdx % kFusedSlots, so the grid has no capacity to respect (the exact sums hold for 4 096 workgroup records: 2 048 at most here)
 constexpr size_t kFusedMaxQueries = (size_t)4096 * 64;
 static_assert(kFusedMaxQueries == O3DS_ICP_PASS_MAX_QUERIES, "the limit the header documents");
-int fused_blocks(size_t count) { return (int)std::max<size_t>((count + 63) / 64, 1); }
+int fused_blocks(size_t count) { return (int)std::max<size_t>((count + kIcpQ - 1) / kIcpQ, 1); }
 
 int pass_blocks(o3ds_handle h, size_t count) {
-  const size_t qpb = 64;  // one batch of 256 / 4 queries per workgroup iteration
+  const size_t qpb = kIcpQ;  // one batch of kIcpBlock / 4 queries per workgroup iteration
   size_t g = (count + qpb - 1) / qpb;
   if (g < 1) g = 1;
   if (g > (size_t)h->pass_rows) g = h->pass_rows;

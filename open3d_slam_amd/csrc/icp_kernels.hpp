@@ -1967,9 +1967,7 @@ __global__ __launch_bounds__(kPassBlock) __attribute__((amdgpu_waves_per_eu(4)))
   const int order = pass_order(first ? 0 : max(fa.pass_index, 1));
   const QueryPrefetch<P4> qp = prefetch_query<P4, kPassBlock, kGroup>(fa.pass, blockIdx.x, use_cache, true, order, n_live);
   if (blockIdx.x == 0) {  // the buffer of the NEXT pass was last read two launches ago
-    static_assert(kFusedSlots * kSlotDoubles == 2 * kPassBlock, "two slot values per thread");
-    fa.slots_clear[threadIdx.x] = 0.0;
-    fa.slots_clear[kPassBlock + threadIdx.x] = 0.0;
+    for (int j = threadIdx.x; j < kFusedSlots * kSlotDoubles; j += kPassBlock) fa.slots_clear[j] = 0.0;
   }
   if (first) {
     if (threadIdx.x == 0) s_st = fa.init;
