@@ -282,7 +282,7 @@ int o3ds_icp_accumulate_keys(o3ds_handle h, size_t first, size_t count, int rank
  * o3ds_icp_pass_finish folds the last pass (one-workgroup launch) and returns the result; max_iteration + 1 passes make a full
  * registration, passes issued after the loop has terminated on the device are no-ops. */
 #define O3DS_ICP_SUMS_DOUBLES 512
-/* o3ds_icp_pass serves at most this many source points per call (one workgroup per 64 queries, 4096 exact workgroup records per pass);
+/* o3ds_icp_pass serves at most this many source points per call (one workgroup per 128 queries -- 64 until the end of round 6 --; the exact sums hold for 4096 workgroup records per pass);
  * a larger range returns O3DS_ERR_CAPACITY -- shards beyond it use the o3ds_icp_accumulate / o3ds_icp_update triple, which loops
  * (open3d_slam_amd/sharded.py falls back by itself).  o3ds_icp_register_dev has no such limit (it switches form internally). */
 #define O3DS_ICP_PASS_MAX_QUERIES 262144

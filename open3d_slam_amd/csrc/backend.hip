@@ -2339,7 +2339,7 @@ int o3ds_icp_register_dev(o3ds_handle h, o3ds_cloud source, o3ds_cloud target, c
     ~OverlapOnce() { h->overlap_fn = nullptr, h->overlap_arg = nullptr; }
   } overlap_once{h};
   if (!init || !out) return fail(h, O3DS_ERR_INVALID_ARG, "icp: null init/out");
-  // the fused loop runs one workgroup per 64 queries; its exact record sums are order-independent for up to 4096 workgroup records
+  // the fused loop runs one workgroup per kIcpQ queries; its exact record sums are order-independent for up to 4096 workgroup records
   // (split_exact), so sources beyond kFusedMaxQueries points take the two-launch form (same results, looped pass kernel)
   CloudRec* src_rec = find_cloud_lazy(h, source);
   const bool use_fused = h->fused && src_rec && src_rec->n <= kFusedMaxQueries;
